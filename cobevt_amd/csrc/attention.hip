@@ -1,0 +1,344 @@
+// Gathered window / dilated-grid attention on MFMA (gfx950): QK^T -> online softmax -> PV in one kernel,
+// with the einops window<->grid partition / reverse done as index arithmetic on token rows (no permute
+// round trips through HBM).
+//
+// Replaces, for already-projected q/k/v token matrices:
+//   * CrossWinAttention core          reference: opv2v/opencood/models/sub_modules/fax_modules.py:211-237,243
+//     (window partition :399-404, grid partition :417-424, window reverse :409,433, camera mean :243)
+//   * swap-fusion Attention core      reference: opv2v/opencood/models/fusion_modules/swap_fusion_modules.py:93-123
+//     (3-D relative position bias :55-85,106-107; key mask :110-115; window/grid partition :172-190)
+//   * FAX global self-attention core  reference: fax_modules.py:137-171 (2-D relative position bias :121-130,157-158)
+//
+// Work decomposition: one workgroup = (batch b, window l, head m, query tile).  All waves of the
+// workgroup share the K / V^T tiles of that window+head staged in LDS (64 keys per step).  A wave owns 32
+// query tokens.  In "mean" mode (level-0 cross attention, per-camera queries) wave w handles camera w of
+// the same 32 BEV positions and the workgroup averages the waves' outputs in LDS (z.mean(1), :243;
+// the out-projection is linear so the mean commutes with it).
+//
+// MFMA mapping (32x32 tiles, dh = 32):  S^T = K.Q^T  (A = K rows from LDS, B = Q rows held in registers)
+// so lane (q = lane&31, half h) holds 16 of the 32 key scores of its query -> softmax reductions are
+// lane-local plus one xor-32 exchange.  O^T += V^T.P^T uses the score registers directly as the B
+// operand; the key <-> k-slot permutation this implies is applied identically when reading V^T from LDS.
+#include "common.hpp"
+
+namespace cobevt {
+
+struct TokMap {
+    int mode;  // 0 window partition, 1 grid partition, 2 rows already stored window-partitioned
+    int ncam;  // cameras / agents concatenated inside a window
+    int HH, WW;
+    int w1, w2;
+    int X, Y;  // windows along H and W (HH == X*w1, WW == Y*w2)
+};
+
+struct TokCoord { int cam, i, j; };
+
+__device__ __forceinline__ TokCoord tok_coord(const TokMap& m, int t) {
+    const int ws = m.w1 * m.w2;
+    TokCoord c;
+    c.cam = t / ws;
+    const int rem = t - c.cam * ws;
+    c.i = rem / m.w2;
+    c.j = rem - c.i * m.w2;
+    return c;
+}
+
+// (ph, pw) pixel of the token in the un-partitioned map; reference fax_modules.py:399-404 (window),
+// :420-424 (grid: 'b n (w1 x) (w2 y) d -> b n x y w1 w2 d')
+__device__ __forceinline__ void tok_pixel(const TokMap& m, int l, const TokCoord& c, int& ph, int& pw) {
+    const int x = l / m.Y, y = l - x * m.Y;
+    if (m.mode == 1) { ph = c.i * m.X + x; pw = c.j * m.Y + y; }
+    else { ph = x * m.w1 + c.i; pw = y * m.w2 + c.j; }
+}
+
+__device__ __forceinline__ size_t tok_row(const TokMap& m, int b, int l, const TokCoord& c) {
+    if (m.mode == 2) {
+        return (((size_t)(b * m.ncam + c.cam) * (m.X * m.Y) + l) * m.w1 + c.i) * m.w2 + c.j;
+    }
+    int ph, pw;
+    tok_pixel(m, l, c, ph, pw);
+    return ((size_t)(b * m.ncam + c.cam) * m.HH + ph) * m.WW + pw;
+}
+
+struct AttnParams {
+    const void* q; const void* k; const void* v; void* out;
+    int ldq, ldk, ldv, ldo;
+    int qoff, koff, voff, ooff;
+    TokMap qmap, kmap, omap;
+    int B, L, heads, Nq, Nk;
+    float scale;
+    int bias_mode;            // 0 none, 1 relative-position table lookup
+    const float* bias_table;  // [rows][heads]
+    int bias_rows;
+    int bias_L;               // agent extent of the 3-D table (1 => 2-D table)
+    const float* mask;        // key mask (B, HH, WW, ncam) fp32, 0 => key masked out ; may be null
+    int mean_q;
+};
+
+constexpr int kKeysPerTile = 64;
+
+template <typename T> struct AttnLds {
+    static constexpr int kKRow = 32 * Elem<T>::kBytes + 16;              // K tile row: 32 dh + pad
+    static constexpr int kVRow = kKeysPerTile * Elem<T>::kBytes + (Elem<T>::kIsBf16 ? 8 : 16);  // V^T row: 64 keys + pad
+    static constexpr int kKBytes = kKeysPerTile * kKRow;
+    static constexpr int kVBytes = 32 * kVRow;
+    static constexpr int kInfoBytes = kKeysPerTile * 4;
+    static constexpr int kFixed = kKBytes + kVBytes + kInfoBytes;
+};
+
+template <typename T>
+__global__ void attn_gather_kernel(AttnParams p) {
+    using L = AttnLds<T>;
+    constexpr int CH = Elem<T>::kChunk;
+    constexpr int NG = 32 * Elem<T>::kBytes / 32;  // 32-byte k-groups along dh (2 bf16, 4 fp32)
+    constexpr int CPR = 32 / CH;                   // 16-byte chunks per K/V token row (head slice)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ks = smem;
+    unsigned char* Vts = smem + L::kKBytes;
+    int* kinfo = (int*)(smem + L::kKBytes + L::kVBytes);
+    float* bias_col = (float*)(smem + L::kFixed);
+    float* red = (float*)smem;  // aliases the K/V tiles after the key loop (mean mode)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+    const int h = lane >> 5, ql = lane & 31;
+    const int b = blockIdx.z;
+    const int l = blockIdx.y / p.heads, head = blockIdx.y - l * p.heads;
+    const int qtile = blockIdx.x;
+
+    // ---- this lane's query token
+    const int P = p.qmap.w1 * p.qmap.w2;
+    int tq;
+    bool q_ok;
+    if (p.mean_q) { const int pos = qtile * 32 + ql; q_ok = pos < P; tq = wave * P + pos; }
+    else { tq = qtile * 32 * (nthr >> 6) + wave * 32 + ql; q_ok = tq < p.Nq; }
+    const TokCoord qc = tok_coord(p.qmap, q_ok ? tq : 0);
+
+    uint4 qf[NG];
+    {
+        const T* qrow = (const T*)p.q + tok_row(p.qmap, b, l, qc) * p.ldq + p.qoff + head * 32;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            qf[g] = q_ok ? *(const uint4*)(qrow + g * (2 * CH) + h * CH) : make_uint4(0, 0, 0, 0);
+    }
+    if (p.bias_mode) {
+        for (int i = tid; i < p.bias_rows; i += nthr) bias_col[i] = p.bias_table[(size_t)i * p.heads + head];
+    }
+
+    f32x16 ot;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sl2 = p.scale * 1.4426950408889634f;  // softmax in base 2
+
+    const int nkt = (p.Nk + kKeysPerTile - 1) / kKeysPerTile;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();  // previous tile fully consumed
+        for (int item = tid; item < kKeysPerTile * CPR; item += nthr) {
+            const int kk = item / CPR, cj = item - kk * CPR;
+            const int tk = kt * kKeysPerTile + kk;
+            const bool ok = tk < p.Nk;
+            const TokCoord kc = tok_coord(p.kmap, ok ? tk : 0);
+            const size_t row = tok_row(p.kmap, b, l, kc);
+            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                kv = *(const uint4*)((const T*)p.k + row * p.ldk + p.koff + head * 32 + cj * CH);
+                vv = *(const uint4*)((const T*)p.v + row * p.ldv + p.voff + head * 32 + cj * CH);
+            }
+            *(uint4*)(Ks + kk * L::kKRow + cj * 16) = kv;
+            if constexpr (Elem<T>::kIsBf16) {
+                const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    *(uint16_t*)(Vts + (cj * 8 + e) * L::kVRow + kk * 2) = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+            } else {
+                const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) *(uint32_t*)(Vts + (cj * 4 + e) * L::kVRow + kk * 4) = w[e];
+            }
+            if (cj == 0) {
+                int info = (kc.cam << 16) | (kc.i << 8) | kc.j;
+                bool valid = ok;
+                if (ok && p.mask) {
+                    int ph, pw;
+                    tok_pixel(p.kmap, l, kc, ph, pw);
+                    valid = p.mask[(((size_t)b * p.kmap.HH + ph) * p.kmap.WW + pw) * p.kmap.ncam + kc.cam] != 0.f;
+                }
+                kinfo[kk] = valid ? info : -1;
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T = K . Q^T for the two 32-key sub-tiles
+        f32x16 st[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[s][r] = 0.f;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const uint4 a = *(const uint4*)(Ks + (s * 32 + ql) * L::kKRow + g * 32 + h * 16);
+                mfma_kgroup<T>(a, qf[g], st[s]);
+            }
+        }
+        // ---- scale (base-2 domain), bias, mask
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = s * 32 + acc_row(r, lane);
+                const int info = kinfo[kk];
+                float v = st[s][r] * sl2;
+                if (p.bias_mode) {
+                    const int lk = (info >> 16) & 0x7fff, ak = (info >> 8) & 0xff, bk = info & 0xff;
+                    int idx = ((qc.cam - lk + p.bias_L - 1) * (2 * p.kmap.w1 - 1) + (qc.i - ak + p.kmap.w1 - 1)) *
+                                  (2 * p.kmap.w2 - 1) + (qc.j - bk + p.kmap.w2 - 1);
+                    idx = info < 0 ? 0 : idx;
+                    v += bias_col[idx] * 1.4426950408889634f;
+                }
+                v = info < 0 ? -INFINITY : v;
+                st[s][r] = v;
+                mloc = fmaxf(mloc, v);
+            }
+        }
+        const float mtile = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mtile);
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = exp2f(m_run - m_safe);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = exp2f(st[s][r] - m_safe);
+                st[s][r] = e;
+                psum += e;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[r] *= alpha;
+
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if constexpr (Elem<T>::kIsBf16) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    uint4 pb;
+                    pb.x = pack_bf2(st[s][8 * u + 0], st[s][8 * u + 1]);
+                    pb.y = pack_bf2(st[s][8 * u + 2], st[s][8 * u + 3]);
+                    pb.z = pack_bf2(st[s][8 * u + 4], st[s][8 * u + 5]);
+                    pb.w = pack_bf2(st[s][8 * u + 6], st[s][8 * u + 7]);
+                    const unsigned char* vr = Vts + ql * L::kVRow + (s * 32 + 16 * u + 4 * h) * 2;
+                    const uint2 lo = *(const uint2*)vr, hi = *(const uint2*)(vr + 16);
+                    mfma_kgroup<T>(make_uint4(lo.x, lo.y, hi.x, hi.y), pb, ot);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    uint4 pb;
+                    pb.x = __float_as_uint(st[s][4 * u + 0]); pb.y = __float_as_uint(st[s][4 * u + 1]);
+                    pb.z = __float_as_uint(st[s][4 * u + 2]); pb.w = __float_as_uint(st[s][4 * u + 3]);
+                    const uint4 a = *(const uint4*)(Vts + ql * L::kVRow + (s * 32 + 8 * u + 4 * h) * 4);
+                    mfma_kgroup<T>(a, pb, ot);
+                }
+            }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;  // an all-masked row yields NaN like the reference softmax
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[r] *= inv;
+
+    if (p.mean_q) {
+        const int nw = nthr >> 6;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = ot[r];
+        __syncthreads();
+        if (wave != 0) return;
+        const float invn = 1.0f / (float)nw;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float sacc = 0.f;
+            for (int w = 0; w < nw; ++w) sacc += red[(w * 16 + r) * 64 + lane];
+            ot[r] = sacc * invn;
+        }
+    }
+    if (!q_ok) return;
+    TokCoord oc = qc;
+    if (p.mean_q) oc.cam = 0;
+    T* orow = (T*)p.out + tok_row(p.omap, b, l, oc) * p.ldo + p.ooff + head * 32;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        const int d0 = 8 * g4 + 4 * h;
+        if constexpr (Elem<T>::kIsBf16) {
+            uint2 w;
+            w.x = pack_bf2(ot[4 * g4 + 0], ot[4 * g4 + 1]);
+            w.y = pack_bf2(ot[4 * g4 + 2], ot[4 * g4 + 3]);
+            *(uint2*)(orow + d0) = w;
+        } else {
+            *(float4*)(orow + d0) = make_float4(ot[4 * g4 + 0], ot[4 * g4 + 1], ot[4 * g4 + 2], ot[4 * g4 + 3]);
+        }
+    }
+}
+
+static bool map_ok(const TokMap& m) {
+    if (m.mode < 0 || m.mode > 2 || m.ncam < 1 || m.w1 < 1 || m.w2 < 1 || m.X < 1 || m.Y < 1) return false;
+    if (m.mode != 2 && (m.HH != m.X * m.w1 || m.WW != m.Y * m.w2)) return false;
+    return m.w1 < 256 && m.w2 < 256 && m.ncam < 32768;
+}
+
+static TokMap read_map(const int* d) {
+    TokMap m;
+    m.mode = d[0]; m.ncam = d[1]; m.HH = d[2]; m.WW = d[3]; m.w1 = d[4]; m.w2 = d[5]; m.X = d[6]; m.Y = d[7];
+    return m;
+}
+
+}  // namespace cobevt
+
+using namespace cobevt;
+
+// C-ABI entry point, see include/cobevt_hip.h
+extern "C" int cobevt_window_attention(const void* q, const void* k, const void* v, void* out,
+                                       const float* bias_table, const float* mask, const int* dims, float scale,
+                                       hipStream_t stream) {
+    // dims: [dtype, B, L, heads, ldq, ldk, ldv, ldo, qoff, koff, voff, ooff, bias_mode, bias_rows, bias_L,
+    //        mean_q, qmap[8], kmap[8], omap[8]]
+    if (!q || !k || !v || !out || !dims) return COBEVT_ERR_ARG;
+    AttnParams p;
+    const int dtype = dims[0];
+    p.q = q; p.k = k; p.v = v; p.out = out;
+    p.B = dims[1]; p.L = dims[2]; p.heads = dims[3];
+    p.ldq = dims[4]; p.ldk = dims[5]; p.ldv = dims[6]; p.ldo = dims[7];
+    p.qoff = dims[8]; p.koff = dims[9]; p.voff = dims[10]; p.ooff = dims[11];
+    p.bias_mode = dims[12]; p.bias_rows = dims[13]; p.bias_L = dims[14];
+    p.mean_q = dims[15];
+    p.qmap = read_map(dims + 16); p.kmap = read_map(dims + 24); p.omap = read_map(dims + 32);
+    p.bias_table = bias_table; p.mask = mask; p.scale = scale;
+    if (dtype != 0 && dtype != 1) return COBEVT_ERR_ARG;
+    if (!map_ok(p.qmap) || !map_ok(p.kmap) || !map_ok(p.omap)) return COBEVT_ERR_SHAPE;
+    if (p.B < 1 || p.heads < 1 || p.L != p.qmap.X * p.qmap.Y || p.L != p.kmap.X * p.kmap.Y) return COBEVT_ERR_SHAPE;
+    if (p.bias_mode && (!bias_table || p.bias_rows < 1 || p.bias_L < 1)) return COBEVT_ERR_ARG;
+    const int ch = dtype == 0 ? 8 : 4;
+    if ((p.ldq | p.ldk | p.ldv | p.ldo | p.qoff | p.koff | p.voff | p.ooff) % ch) return COBEVT_ERR_SHAPE;
+    p.Nq = p.qmap.ncam * p.qmap.w1 * p.qmap.w2;
+    p.Nk = p.kmap.ncam * p.kmap.w1 * p.kmap.w2;
+    if (p.mean_q && p.qmap.ncam == 1) p.mean_q = 0;
+    if (p.mean_q && (p.qmap.ncam > 16 || p.omap.ncam != 1)) return COBEVT_ERR_UNSUPPORTED;
+    if (p.mask && p.kmap.mode == 2) return COBEVT_ERR_UNSUPPORTED;
+    const int P = p.qmap.w1 * p.qmap.w2;
+    dim3 grid, block;
+    if (p.mean_q) { block = dim3(64 * p.qmap.ncam); grid = dim3((P + 31) / 32, p.L * p.heads, p.B); }
+    else { block = dim3(256); grid = dim3((p.Nq + 127) / 128, p.L * p.heads, p.B); }
+    if (grid.y > 65535 || grid.z > 65535) return COBEVT_ERR_SHAPE;
+    size_t lds = dtype == 0 ? AttnLds<bf16_t>::kFixed : AttnLds<float>::kFixed;
+    if (p.bias_mode) lds += (size_t)p.bias_rows * 4;
+    if (p.mean_q) { const size_t need = (size_t)p.qmap.ncam * 16 * 64 * 4; if (need > lds) lds = need; }
+    if (lds > 160 * 1024) return COBEVT_ERR_UNSUPPORTED;
+    if (dtype == 0) hipLaunchKernelGGL(attn_gather_kernel<bf16_t>, grid, block, lds, stream, p);
+    else hipLaunchKernelGGL(attn_gather_kernel<float>, grid, block, lds, stream, p);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}

@@ -1,0 +1,112 @@
+// Shared device helpers for the cobevt_amd HIP kernels (gfx950 / CDNA4 only).
+//
+// Two arithmetic modes share every kernel through one template parameter:
+//   T = bf16_t : activations/weights stored bf16, v_mfma_f32_32x32x16_bf16, fp32 accumulate (perf mode)
+//   T = float  : activations/weights stored fp32, v_mfma_f32_32x32x2_f32, exact fp32    (parity mode)
+// Both modes address LDS tiles at byte level the same way: a "k-group" is 32 bytes per row
+// (16 bf16 or 8 fp32); lane-half h = lane>>5 owns bytes [16h, 16h+16) of every k-group.  For fp32 the
+// four floats of that 16-byte piece feed four 32x32x2 MFMAs, i.e. the contraction index is permuted
+// identically on the A and B side, which leaves the sum unchanged.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cobevt {
+
+struct bf16_t { uint16_t bits; };
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+__device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+
+// round-to-nearest-even, NaN preserved (same rounding as torch.float32 -> torch.bfloat16)
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<bf16_t> {
+    static constexpr int kBytes = 2;
+    static constexpr int kChunk = 8;   // elements per 16-byte chunk
+    static constexpr bool kIsBf16 = true;
+};
+template <> struct Elem<float> {
+    static constexpr int kBytes = 4;
+    static constexpr int kChunk = 4;
+    static constexpr bool kIsBf16 = false;
+};
+
+// A 16-byte chunk unpacked to fp32 lanes (8 values for bf16, 4 for fp32; unused tail left untouched).
+template <typename T> __device__ __forceinline__ void chunk_to_f32(const uint4& c, float* v) {
+    if constexpr (Elem<T>::kIsBf16) {
+        v[0] = bf2f(c.x & 0xffff); v[1] = bf2f(c.x >> 16);
+        v[2] = bf2f(c.y & 0xffff); v[3] = bf2f(c.y >> 16);
+        v[4] = bf2f(c.z & 0xffff); v[5] = bf2f(c.z >> 16);
+        v[6] = bf2f(c.w & 0xffff); v[7] = bf2f(c.w >> 16);
+    } else {
+        v[0] = __uint_as_float(c.x); v[1] = __uint_as_float(c.y);
+        v[2] = __uint_as_float(c.z); v[3] = __uint_as_float(c.w);
+    }
+}
+template <typename T> __device__ __forceinline__ uint4 f32_to_chunk(const float* v) {
+    uint4 c;
+    if constexpr (Elem<T>::kIsBf16) {
+        c.x = pack_bf2(v[0], v[1]); c.y = pack_bf2(v[2], v[3]);
+        c.z = pack_bf2(v[4], v[5]); c.w = pack_bf2(v[6], v[7]);
+    } else {
+        c.x = __float_as_uint(v[0]); c.y = __float_as_uint(v[1]);
+        c.z = __float_as_uint(v[2]); c.w = __float_as_uint(v[3]);
+    }
+    return c;
+}
+
+template <typename T> __device__ __forceinline__ float load_elem(const T* p, size_t i);
+template <> __device__ __forceinline__ float load_elem<bf16_t>(const bf16_t* p, size_t i) { return bf2f(p[i].bits); }
+template <> __device__ __forceinline__ float load_elem<float>(const float* p, size_t i) { return p[i]; }
+template <typename T> __device__ __forceinline__ void store_elem(T* p, size_t i, float v);
+template <> __device__ __forceinline__ void store_elem<bf16_t>(bf16_t* p, size_t i, float v) { p[i].bits = f2bf(v); }
+template <> __device__ __forceinline__ void store_elem<float>(float* p, size_t i, float v) { p[i] = v; }
+
+// One 32-byte k-group of a 32x32 MFMA tile.  `a` and `b` are the 16-byte pieces this lane read from
+// row (lane&31) of the A tile and the B tile at byte offset 16*(lane>>5) of the k-group.
+// C/D layout (both dtypes): col = lane&31 (B row), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (A row).
+template <typename T>
+__device__ __forceinline__ void mfma_kgroup(const uint4& a, const uint4& b, f32x16& acc) {
+    if constexpr (Elem<T>::kIsBf16) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                      __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+}
+
+// accumulator register r of the 32x32 C/D fragment -> row within the tile
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum_xor(float v, int width) {
+    for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace cobevt
+
+// error codes shared with include/cobevt_hip.h
+#define COBEVT_OK 0
+#define COBEVT_ERR_ARG 1
+#define COBEVT_ERR_SHAPE 2
+#define COBEVT_ERR_LAUNCH 3
+#define COBEVT_ERR_UNSUPPORTED 4

@@ -1,0 +1,439 @@
+// HBM-bound glue kernels of the CoBEVT hot path (gfx950).  Every kernel moves 16-byte chunks per lane over
+// channels-last rows; a row of C channels is owned by a group of C/8 adjacent lanes so loads/stores stay
+// coalesced and the per-row reductions are xor-shuffles inside the group.
+#include "common.hpp"
+
+namespace cobevt {
+
+// 8 consecutive channels of one row, as fp32
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* v) {
+    if constexpr (Elem<T>::kIsBf16) {
+        chunk_to_f32<T>(*(const uint4*)p, v);
+    } else {
+        chunk_to_f32<T>(*(const uint4*)p, v);
+        chunk_to_f32<T>(*(const uint4*)(p + 4), v + 4);
+    }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* v) {
+    if constexpr (Elem<T>::kIsBf16) {
+        *(uint4*)p = f32_to_chunk<T>(v);
+    } else {
+        *(uint4*)p = f32_to_chunk<T>(v);
+        *(uint4*)(p + 4) = f32_to_chunk<T>(v + 4);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the channel axis (eps inside sqrt, biased variance), optionally preceded by a mean over
+// `navg` slices `avg_stride` elements apart (SwapFusionEncoder.mlp_head: mean over agents then LayerNorm).
+// reference: fax_modules.py:189-191,309-313,435-437 ; swap_fusion_modules.py:275-279 ; base_transformer.py:102-109
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* in, const float* gamma, const float* beta, T* out,
+                                                        int rows, int C, float eps, int navg, long avg_stride,
+                                                        long in_batch_stride, int rows_per_batch) {
+    const int G = C >> 3;  // lanes per row
+    const int gid = (blockIdx.x * 256 + threadIdx.x) / G;
+    const int gl = threadIdx.x & (G - 1);
+    if (gid >= rows) return;
+    // with averaging the input row r of batch bb lives at bb*in_batch_stride + r*C (+ s*avg_stride)
+    const int bb = gid / rows_per_batch, rr = gid - bb * rows_per_batch;
+    const T* src = in + (size_t)bb * in_batch_stride + (size_t)rr * C + gl * 8;
+    float v[8];
+    load8<T>(src, v);
+    if (navg > 1) {
+        for (int s = 1; s < navg; ++s) {
+            float w[8];
+            load8<T>(src + (size_t)s * avg_stride, w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += w[e];
+        }
+        const float inv = 1.0f / (float)navg;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= inv;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[e];
+    s = wave_sum_xor(s, G);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; q += d * d; }
+    q = wave_sum_xor(q, G);
+    const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * gamma[gl * 8 + e] + beta[gl * 8 + e];
+    store8<T>(out + (size_t)gid * C + gl * 8, v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Camera-ray positional embedding:  img_embed = L2norm_c( img_embed_conv(E_inv @ pad1(I_inv @ pixel)) - cam_embed(E_inv[:, 3]) )
+// reference: fax_modules.py:346-358.  Output (BN, h, w, D) channels-last.
+template <typename T>
+__global__ __launch_bounds__(256) void ray_embed_kernel(const float* I_inv, const float* E_inv, const float* plane,
+                                                        const float* w_img, const float* w_cam, T* out, int BN,
+                                                        int hw, int D) {
+    const int G = D >> 3;
+    const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / G;
+    const int gl = threadIdx.x & (G - 1);
+    if (gid >= (long)BN * hw) return;
+    const int bn = (int)(gid / hw), pix = (int)(gid - (long)bn * hw);
+    const float* I = I_inv + bn * 9;
+    const float* E = E_inv + bn * 16;
+    const float px = plane[pix], py = plane[hw + pix], pz = plane[2 * hw + pix];
+    float cam[4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) cam[r] = I[r * 3 + 0] * px + I[r * 3 + 1] * py + I[r * 3 + 2] * pz;
+    cam[3] = 1.f;
+    float d4[4], c4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        d4[r] = E[r * 4 + 0] * cam[0] + E[r * 4 + 1] * cam[1] + E[r * 4 + 2] * cam[2] + E[r * 4 + 3] * cam[3];
+        c4[r] = E[r * 4 + 3];
+    }
+    float v[8], ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = gl * 8 + e;
+        const float* wi = w_img + ch * 4;
+        const float* wc = w_cam + ch * 4;
+        const float de = wi[0] * d4[0] + wi[1] * d4[1] + wi[2] * d4[2] + wi[3] * d4[3];
+        const float ce = wc[0] * c4[0] + wc[1] * c4[1] + wc[2] * c4[2] + wc[3] * c4[3];
+        v[e] = de - ce;
+        ss += v[e] * v[e];
+    }
+    ss = wave_sum_xor(ss, G);
+    const float inv = 1.0f / (sqrtf(ss) + 1e-7f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= inv;
+    store8<T>(out + gid * D + gl * 8, v);
+}
+
+// BEV query positional embedding + prior: query[b,n] = L2norm_c( bev_embed(world) - cam_embed(c) ) + x[b]
+// reference: fax_modules.py:370-375,387-388.  world: (2, HW) fp32 ; x: (B, HW, D) ; out: (B, n, HW, D)
+template <typename T>
+__global__ __launch_bounds__(256) void bev_embed_kernel(const float* E_inv, const float* world, const float* w_bev,
+                                                        const float* b_bev, const float* w_cam, const T* x, T* out,
+                                                        int B, int n, int hw, int D) {
+    const int G = D >> 3;
+    const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / G;
+    const int gl = threadIdx.x & (G - 1);
+    if (gid >= (long)B * n * hw) return;
+    const int bn = (int)(gid / hw), pix = (int)(gid - (long)bn * hw);
+    const int b = bn / n;
+    const float* E = E_inv + bn * 16;
+    const float wx = world[pix], wy = world[hw + pix];
+    float c4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c4[r] = E[r * 4 + 3];
+    float v[8], ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = gl * 8 + e;
+        const float we = w_bev[ch * 2 + 0] * wx + w_bev[ch * 2 + 1] * wy + b_bev[ch];
+        const float* wc = w_cam + ch * 4;
+        const float ce = wc[0] * c4[0] + wc[1] * c4[1] + wc[2] * c4[2] + wc[3] * c4[3];
+        v[e] = we - ce;
+        ss += v[e] * v[e];
+    }
+    ss = wave_sum_xor(ss, G);
+    const float inv = 1.0f / (sqrtf(ss) + 1e-7f);
+    float xv[8];
+    load8<T>(x + ((size_t)b * hw + pix) * D + gl * 8, xv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * inv + xv[e];
+    store8<T>(out + gid * D + gl * 8, v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool2d(kernel 3, stride 2, padding 1) channels-last.  reference: resnet_ms.py:71 (torchvision resnet maxpool)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* in, T* out, int N, int H, int W, int C, int Ho,
+                                                           int Wo) {
+    const int G = C >> 3;
+    const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / G;
+    const int gl = threadIdx.x & (G - 1);
+    if (gid >= (long)N * Ho * Wo) return;
+    const int n = (int)(gid / (Ho * Wo)), rem = (int)(gid - (long)n * Ho * Wo);
+    const int oh = rem / Wo, ow = rem - oh * Wo;
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh * 2 - 1 + kh;
+        if (ih < 0 || ih >= H) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            const int iw = ow * 2 - 1 + kw;
+            if (iw < 0 || iw >= W) continue;
+            float v[8];
+            load8<T>(in + (((size_t)n * H + ih) * W + iw) * C + gl * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+        }
+    }
+    store8<T>(out + gid * C + gl * 8, m);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Strided (n,c,h,w) <-> channels-last conversion with dtype cast (module-boundary plumbing only).
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void to_nhwc_kernel(const TI* in, TO* out, int N, int C, int H, int W, long sN, long sC,
+                                                      long sH, long sW) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)N * C * H * W;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    store_elem<TO>(out, i, load_elem<TI>(in, n * sN + c * sC + h * sH + w * sW));
+}
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void from_nhwc_kernel(const TI* in, TO* out, int N, int C, int H, int W, long sN,
+                                                        long sC, long sH, long sW) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)N * C * H * W;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    store_elem<TO>(out, n * sN + c * sC + h * sH + w * sW, load_elem<TI>(in, i));
+}
+
+// ---------------------------------------------------------------------------------------------
+// regroup: split the agent batch by record_len, zero-pad every sample to max_cav agents, emit the agent mask.
+// reference: fuse_utils.py:8-61 (which syncs the host at :26; this kernel reads record_len on the device).
+template <typename T>
+__global__ __launch_bounds__(256) void regroup_kernel(const T* in, const int* record_len, T* out, float* mask, int B,
+                                                      int max_cav, long chunks_per_agent) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // 16-byte chunk index of the output
+    const long total = (long)B * max_cav * chunks_per_agent;
+    if (i >= total) return;
+    const long agent_slot = i / chunks_per_agent, within = i - agent_slot * chunks_per_agent;
+    const int b = (int)(agent_slot / max_cav), l = (int)(agent_slot - (long)b * max_cav);
+    int off = 0;
+    for (int bb = 0; bb < b; ++bb) off += record_len[bb];
+    const bool present = l < record_len[b];
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (present) v = ((const uint4*)in)[(long)(off + l) * chunks_per_agent + within];
+    ((uint4*)out)[i] = v;
+    if (within == 0) mask[agent_slot] = present ? 1.f : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// STTF: warp every agent's BEV map into the ego frame + ROI/agent mask.
+// reference: corpbevt.py:28-64 (transpose + flip, affine warp, flip + transpose back, channels last),
+//            torch_transformation_utils.py:108-134 (discretise), :254-297 (rotation about (W/2,H/2) + translation),
+//            :160-191 (normalise with (W-1),(H-1)), :317-355 (inverse, affine_grid + grid_sample align_corners=True),
+//            :11-105 (ROI mask: nearest warp of ones, NOT transposed/flipped, times agent mask).
+struct Affine { float t[6]; };
+
+// theta = rows 0..1 of inverse( Nrm(Hd,Wd) @ [T;0 0 1] @ Nrm(Hd,Wd)^-1 ),  T = rot about (Wd/2,Hd/2) + translation
+__device__ inline Affine sttf_theta(const float* m44, float discrete_ratio, float downsample_rate, int Hd, int Wd) {
+    const float r00 = m44[0], r01 = m44[1], r10 = m44[4], r11 = m44[5];
+    const float div = discrete_ratio * downsample_rate;
+    const float tx = m44[3] / div, ty = m44[7] / div;
+    const float cx = (float)Wd / 2.f, cy = (float)Hd / 2.f;
+    // shift(c) @ rot @ shift(-c), then + translation
+    const float T02 = (r00 * -cx + r01 * -cy + cx) + tx;
+    const float T12 = (r10 * -cx + r11 * -cy + cy) + ty;
+    // M @ Ninv, Ninv = [[(W-1)/2,0,(W-1)/2],[0,(H-1)/2,(H-1)/2],[0,0,1]]
+    const float sx = ((float)Wd - 1.f) / 2.f, sy = ((float)Hd - 1.f) / 2.f;
+    const float a00 = r00 * sx, a01 = r01 * sy, a02 = r00 * sx + r01 * sy + T02;
+    const float a10 = r10 * sx, a11 = r11 * sy, a12 = r10 * sx + r11 * sy + T12;
+    // N @ (.), N = [[2/(W-1),0,-1],[0,2/(H-1),-1],[0,0,1]]
+    const float nx = 2.f / ((float)Wd - 1.f), ny = 2.f / ((float)Hd - 1.f);
+    const float d00 = nx * a00, d01 = nx * a01, d02 = nx * a02 - 1.f;
+    const float d10 = ny * a10, d11 = ny * a11, d12 = ny * a12 - 1.f;
+    const float det = d00 * d11 - d01 * d10;
+    Affine A;
+    A.t[0] = d11 / det;  A.t[1] = -d01 / det; A.t[2] = (d01 * d12 - d02 * d11) / det;
+    A.t[3] = -d10 / det; A.t[4] = d00 / det;  A.t[5] = (d02 * d10 - d00 * d12) / det;
+    return A;
+}
+
+__device__ __forceinline__ void affine_sample_xy(const Affine& A, int i, int j, int Hd, int Wd, float& ix, float& iy) {
+    // affine_grid(align_corners=True) base coordinates, then grid_sample un-normalisation
+    const float xn = Wd > 1 ? (2.f * (float)j / (float)(Wd - 1) - 1.f) : 0.f;
+    const float yn = Hd > 1 ? (2.f * (float)i / (float)(Hd - 1) - 1.f) : 0.f;
+    const float xs = xn * A.t[0] + yn * A.t[1] + A.t[2];
+    const float ys = xn * A.t[3] + yn * A.t[4] + A.t[5];
+    ix = (xs + 1.f) * 0.5f * (float)(Wd - 1);
+    iy = (ys + 1.f) * 0.5f * (float)(Hd - 1);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sttf_warp_kernel(const T* x, const float* tmat, const float* cav_mask, T* out,
+                                                        float* com_mask, int B, int Lc, int H, int W, int C,
+                                                        float discrete_ratio, float downsample_rate) {
+    // x: (B*L, H, W, C) ; out: (B, L, H, W, C) ; com_mask: (B, H, W, 1, L)
+    const int G = C >> 3;
+    const int bl = blockIdx.y;
+    const int b = bl / Lc, l = bl - b * Lc;
+    __shared__ Affine th_feat, th_mask;
+    if (threadIdx.x == 0) {
+        th_feat = sttf_theta(tmat + (size_t)bl * 16, discrete_ratio, downsample_rate, /*Hd=*/W, /*Wd=*/H);
+        th_mask = sttf_theta(tmat + (size_t)bl * 16, discrete_ratio, downsample_rate, /*Hd=*/H, /*Wd=*/W);
+    }
+    __syncthreads();
+    const int gid = (blockIdx.x * 256 + threadIdx.x) / G;
+    const int gl = threadIdx.x & (G - 1);
+    if (gid >= H * W) return;
+    const int h = gid / W, w = gid - h * W;
+    // feature: warped map y has dims (Hd=W, Wd=H); out[h][w] = y[i=w][j=H-1-h]; y samples x2[iy][ix] = x0[H-1-ix][iy]
+    float ix, iy;
+    affine_sample_xy(th_feat, w, H - 1 - h, W, H, ix, iy);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const T* src = x + (size_t)bl * H * W * C + gl * 8;
+    auto tap = [&](int xx, int yy, float wgt) {
+        // (xx, yy) indexes x2 with dims (rows W, cols H)
+        if (xx < 0 || xx >= H || yy < 0 || yy >= W) return;
+        float v[8];
+        load8<T>(src + ((size_t)(H - 1 - xx) * W + yy) * C, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e] * wgt;
+    };
+    tap(x0, y0, wx0 * wy0);
+    tap(x1, y0, wx1 * wy0);
+    tap(x0, y1, wx0 * wy1);
+    tap(x1, y1, wx1 * wy1);
+    store8<T>(out + ((size_t)bl * H * W + gid) * C + gl * 8, acc);
+    if (gl == 0 && com_mask) {
+        float mx, my;
+        affine_sample_xy(th_mask, h, w, H, W, mx, my);
+        const float rx = nearbyintf(mx), ry = nearbyintf(my);
+        const bool inb = rx >= 0.f && rx <= (float)(W - 1) && ry >= 0.f && ry <= (float)(H - 1);
+        com_mask[((size_t)b * H * W + gid) * Lc + l] = inb ? cav_mask[bl] : 0.f;
+    }
+}
+
+template <typename K, typename... Args>
+static int launch1d(K kern, long work_items, hipStream_t stream, Args... args) {
+    const long blocks = (work_items + 255) / 256;
+    if (blocks <= 0 || blocks > 0x7fffffffL) return COBEVT_ERR_SHAPE;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, args...);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+static bool group_ok(int C) { const int G = C >> 3; return C % 8 == 0 && G >= 1 && G <= 64 && (G & (G - 1)) == 0; }
+
+}  // namespace cobevt
+
+using namespace cobevt;
+
+extern "C" int cobevt_layernorm(const void* in, const float* gamma, const float* beta, void* out, int dtype, int rows,
+                                int C, float eps, int navg, long avg_stride, long in_batch_stride, int rows_per_batch,
+                                hipStream_t stream) {
+    if (!in || !gamma || !beta || !out) return COBEVT_ERR_ARG;
+    if (!group_ok(C) || rows < 1 || navg < 1) return COBEVT_ERR_SHAPE;
+    if (rows_per_batch <= 0) { rows_per_batch = rows; in_batch_stride = 0; }
+    const long items = (long)rows * (C >> 3);
+    if (dtype == 0) return launch1d(layernorm_kernel<bf16_t>, items, stream, (const bf16_t*)in, gamma, beta, (bf16_t*)out, rows, C, eps, navg, avg_stride, in_batch_stride, rows_per_batch);
+    if (dtype == 1) return launch1d(layernorm_kernel<float>, items, stream, (const float*)in, gamma, beta, (float*)out, rows, C, eps, navg, avg_stride, in_batch_stride, rows_per_batch);
+    return COBEVT_ERR_ARG;
+}
+
+extern "C" int cobevt_fax_ray_embed(const float* I_inv, const float* E_inv, const float* image_plane, const float* w_img,
+                                    const float* w_cam, void* out, int dtype, int BN, int hw, int D, hipStream_t stream) {
+    if (!I_inv || !E_inv || !image_plane || !w_img || !w_cam || !out) return COBEVT_ERR_ARG;
+    if (!group_ok(D) || BN < 1 || hw < 1) return COBEVT_ERR_SHAPE;
+    const long items = (long)BN * hw * (D >> 3);
+    if (dtype == 0) return launch1d(ray_embed_kernel<bf16_t>, items, stream, I_inv, E_inv, image_plane, w_img, w_cam, (bf16_t*)out, BN, hw, D);
+    if (dtype == 1) return launch1d(ray_embed_kernel<float>, items, stream, I_inv, E_inv, image_plane, w_img, w_cam, (float*)out, BN, hw, D);
+    return COBEVT_ERR_ARG;
+}
+
+extern "C" int cobevt_fax_bev_embed(const float* E_inv, const float* world, const float* w_bev, const float* b_bev,
+                                    const float* w_cam, const void* x, void* out, int dtype, int B, int n, int hw, int D,
+                                    hipStream_t stream) {
+    if (!E_inv || !world || !w_bev || !b_bev || !w_cam || !x || !out) return COBEVT_ERR_ARG;
+    if (!group_ok(D) || B < 1 || n < 1 || hw < 1) return COBEVT_ERR_SHAPE;
+    const long items = (long)B * n * hw * (D >> 3);
+    if (dtype == 0) return launch1d(bev_embed_kernel<bf16_t>, items, stream, E_inv, world, w_bev, b_bev, w_cam, (const bf16_t*)x, (bf16_t*)out, B, n, hw, D);
+    if (dtype == 1) return launch1d(bev_embed_kernel<float>, items, stream, E_inv, world, w_bev, b_bev, w_cam, (const float*)x, (float*)out, B, n, hw, D);
+    return COBEVT_ERR_ARG;
+}
+
+extern "C" int cobevt_maxpool3x3s2(const void* in, void* out, int dtype, int N, int H, int W, int C, hipStream_t stream) {
+    if (!in || !out) return COBEVT_ERR_ARG;
+    if (!group_ok(C) || N < 1 || H < 1 || W < 1) return COBEVT_ERR_SHAPE;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long items = (long)N * Ho * Wo * (C >> 3);
+    if (dtype == 0) return launch1d(maxpool3x3s2_kernel<bf16_t>, items, stream, (const bf16_t*)in, (bf16_t*)out, N, H, W, C, Ho, Wo);
+    if (dtype == 1) return launch1d(maxpool3x3s2_kernel<float>, items, stream, (const float*)in, (float*)out, N, H, W, C, Ho, Wo);
+    return COBEVT_ERR_ARG;
+}
+
+// dtype codes: 0 bf16, 1 fp32
+extern "C" int cobevt_to_nhwc(const void* in, int in_dtype, void* out, int out_dtype, int N, int C, int H, int W,
+                              const long* strides, hipStream_t stream) {
+    if (!in || !out || !strides) return COBEVT_ERR_ARG;
+    const long total = (long)N * C * H * W;
+    if (total < 1) return COBEVT_ERR_SHAPE;
+    const long sN = strides[0], sC = strides[1], sH = strides[2], sW = strides[3];
+    if (in_dtype == 1 && out_dtype == 1) return launch1d(to_nhwc_kernel<float, float>, total, stream, (const float*)in, (float*)out, N, C, H, W, sN, sC, sH, sW);
+    if (in_dtype == 1 && out_dtype == 0) return launch1d(to_nhwc_kernel<float, bf16_t>, total, stream, (const float*)in, (bf16_t*)out, N, C, H, W, sN, sC, sH, sW);
+    if (in_dtype == 0 && out_dtype == 1) return launch1d(to_nhwc_kernel<bf16_t, float>, total, stream, (const bf16_t*)in, (float*)out, N, C, H, W, sN, sC, sH, sW);
+    if (in_dtype == 0 && out_dtype == 0) return launch1d(to_nhwc_kernel<bf16_t, bf16_t>, total, stream, (const bf16_t*)in, (bf16_t*)out, N, C, H, W, sN, sC, sH, sW);
+    return COBEVT_ERR_ARG;
+}
+
+extern "C" int cobevt_from_nhwc(const void* in, int in_dtype, void* out, int out_dtype, int N, int C, int H, int W,
+                                const long* strides, hipStream_t stream) {
+    if (!in || !out || !strides) return COBEVT_ERR_ARG;
+    const long total = (long)N * C * H * W;
+    if (total < 1) return COBEVT_ERR_SHAPE;
+    const long sN = strides[0], sC = strides[1], sH = strides[2], sW = strides[3];
+    if (in_dtype == 1 && out_dtype == 1) return launch1d(from_nhwc_kernel<float, float>, total, stream, (const float*)in, (float*)out, N, C, H, W, sN, sC, sH, sW);
+    if (in_dtype == 1 && out_dtype == 0) return launch1d(from_nhwc_kernel<float, bf16_t>, total, stream, (const float*)in, (bf16_t*)out, N, C, H, W, sN, sC, sH, sW);
+    if (in_dtype == 0 && out_dtype == 1) return launch1d(from_nhwc_kernel<bf16_t, float>, total, stream, (const bf16_t*)in, (float*)out, N, C, H, W, sN, sC, sH, sW);
+    if (in_dtype == 0 && out_dtype == 0) return launch1d(from_nhwc_kernel<bf16_t, bf16_t>, total, stream, (const bf16_t*)in, (bf16_t*)out, N, C, H, W, sN, sC, sH, sW);
+    return COBEVT_ERR_ARG;
+}
+
+extern "C" int cobevt_regroup(const void* in, const int* record_len, void* out, float* mask, int dtype, int B, int max_cav,
+                              long elems_per_agent, hipStream_t stream) {
+    if (!in || !record_len || !out || !mask) return COBEVT_ERR_ARG;
+    const int ch = dtype == 0 ? 8 : 4;
+    if (B < 1 || max_cav < 1 || elems_per_agent < 1 || elems_per_agent % ch) return COBEVT_ERR_SHAPE;
+    const long cpa = elems_per_agent / ch;
+    const long items = (long)B * max_cav * cpa;
+    if (dtype == 0) return launch1d(regroup_kernel<bf16_t>, items, stream, (const bf16_t*)in, record_len, (bf16_t*)out, mask, B, max_cav, cpa);
+    if (dtype == 1) return launch1d(regroup_kernel<float>, items, stream, (const float*)in, record_len, (float*)out, mask, B, max_cav, cpa);
+    return COBEVT_ERR_ARG;
+}
+
+extern "C" int cobevt_sttf_warp(const void* x, const float* tmat, const float* cav_mask, void* out, float* com_mask,
+                                int dtype, int B, int L, int H, int W, int C, float discrete_ratio, float downsample_rate,
+                                hipStream_t stream) {
+    if (!x || !tmat || !out) return COBEVT_ERR_ARG;
+    if (com_mask && !cav_mask) return COBEVT_ERR_ARG;
+    if (!group_ok(C) || B < 1 || L < 1 || H < 1 || W < 1 || B * L > 65535) return COBEVT_ERR_SHAPE;
+    const long items = (long)H * W * (C >> 3);
+    dim3 grid((unsigned)((items + 255) / 256), (unsigned)(B * L));
+    if (dtype == 0) hipLaunchKernelGGL(sttf_warp_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, tmat, cav_mask, (bf16_t*)out, com_mask, B, L, H, W, C, discrete_ratio, downsample_rate);
+    else if (dtype == 1) hipLaunchKernelGGL(sttf_warp_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, tmat, cav_mask, (float*)out, com_mask, B, L, H, W, C, discrete_ratio, downsample_rate);
+    else return COBEVT_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+extern "C" const char* cobevt_strerror(int code) {
+    switch (code) {
+        case COBEVT_OK: return "ok";
+        case COBEVT_ERR_ARG: return "invalid argument (null pointer or bad enum)";
+        case COBEVT_ERR_SHAPE: return "unsupported shape / alignment";
+        case COBEVT_ERR_LAUNCH: return "HIP kernel launch failed";
+        case COBEVT_ERR_UNSUPPORTED: return "combination not supported by this kernel";
+        default: return "unknown cobevt error";
+    }
+}
+
+extern "C" int cobevt_abi_version(void) { return 1; }

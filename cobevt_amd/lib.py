@@ -1,0 +1,71 @@
+"""ctypes binding of libcobevt_hip.so (the C ABI declared in include/cobevt_hip.h).
+
+There is deliberately no fallback: if the shared library is missing or a symbol is absent this raises.
+Import torch before loading so the HIP runtime already mapped by torch (same SONAME) is reused.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (maps libamdhip64 first; the kernels must share torch's HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcobevt_hip.so")
+
+_c_int_p = ctypes.POINTER(ctypes.c_int)
+_c_long_p = ctypes.POINTER(ctypes.c_long)
+_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol of include/cobevt_hip.h
+SIGNATURES = {
+    "cobevt_abi_version": (ctypes.c_int, []),
+    "cobevt_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "cobevt_conv2d_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int_p, _vp]),
+    "cobevt_window_attention": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int_p, ctypes.c_float, _vp]),
+    "cobevt_layernorm": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                        ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_int, _vp]),
+    "cobevt_fax_ray_embed": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, _vp]),
+    "cobevt_fax_bev_embed": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int, _vp]),
+    "cobevt_maxpool3x3s2": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           _vp]),
+    "cobevt_to_nhwc": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, _c_long_p, _vp]),
+    "cobevt_from_nhwc": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, _c_long_p, _vp]),
+    "cobevt_regroup": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long, _vp]),
+    "cobevt_sttf_warp": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp]),
+}
+
+_lib = None
+
+
+class CobevtHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CobevtHipError(
+            "libcobevt_hip.so not found at %s — build it with `python -m cobevt_amd.build` "
+            "(there is no CPU / eager fallback for the hot path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI drifted
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cobevt_abi_version() != 1:
+        raise CobevtHipError("libcobevt_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().cobevt_strerror(rc).decode()
+        raise CobevtHipError("%s failed: %s (code %d)" % (what, msg, rc))

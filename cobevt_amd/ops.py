@@ -1,0 +1,292 @@
+"""Thin tensor-level wrappers over the C ABI (include/cobevt_hip.h) + host-side weight preparation.
+
+torch is used for device memory, streams and one-time weight folding only; every arithmetic op of the
+forward path is a HIP kernel launched through ctypes.  All functions require CUDA (ROCm) tensors and raise
+otherwise — there is no CPU path here (the CPU restatement lives in oracle/ and is test infrastructure).
+"""
+import ctypes
+import math
+
+import torch
+
+from . import lib as _L
+from .lib import CobevtHipError
+
+BF16, FP32 = 0, 1
+
+
+def dcode(dtype):
+    if dtype == torch.bfloat16:
+        return BF16
+    if dtype == torch.float32:
+        return FP32
+    raise CobevtHipError("compute dtype must be torch.bfloat16 or torch.float32, got %s" % dtype)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise CobevtHipError("cobevt_amd kernels need tensors on a ROCm device (got a CPU tensor); "
+                                 "there is no CPU fallback")
+
+
+def _ints(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+# ----------------------------------------------------------------------------------------------
+# weight preparation (host, once per module/dtype)
+# ----------------------------------------------------------------------------------------------
+def bn_affine(bn):
+    """Eval-mode BatchNorm as per-channel (scale, shift) in float64."""
+    g = bn.weight.detach().double() if bn.weight is not None else torch.ones_like(bn.running_var).double()
+    b = bn.bias.detach().double() if bn.bias is not None else torch.zeros_like(bn.running_var).double()
+    s = g / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+    return s, b - bn.running_mean.detach().double() * s
+
+
+class ConvPlan(object):
+    """A conv / linear layer lowered to the implicit-GEMM kernel: folded, re-laid-out weights + static params."""
+
+    def __init__(self, weight, bias=None, bn=None, pre_bn=None, pre_relu=False, stride=1, pad=0, act=0,
+                 upsample=False, store_mode=0, dtype=torch.bfloat16, device="cuda", smallc=False):
+        w = weight.detach().double().cpu()
+        if w.dim() == 2:
+            w = w[:, :, None, None]
+        cout, cin, kh, kw = w.shape
+        b = bias.detach().double().cpu() if bias is not None else torch.zeros(cout, dtype=torch.float64)
+        has_bias = bias is not None or bn is not None
+        if bn is not None:
+            s, sh = bn_affine(bn)
+            s, sh = s.cpu(), sh.cpu()
+            w = w * s[:, None, None, None]
+            b = b * s + sh
+        self.dtype = dtype
+        self.code = dcode(dtype)
+        bke = 32 if self.code == BF16 else 16
+        ch = 8 if self.code == BF16 else 4
+        K = kh * kw * cin
+        kpad = (K + bke - 1) // bke * bke
+        wk = torch.zeros(cout, kpad, dtype=torch.float64)
+        wk[:, :K] = w.permute(0, 2, 3, 1).reshape(cout, K)
+        self.wgt = wk.to(torch.float32).to(dtype).to(device).contiguous()
+        self.bias = b.to(torch.float32).to(device).contiguous() if has_bias else None
+        self.pre_scale = self.pre_shift = None
+        if pre_bn is not None:
+            s, sh = bn_affine(pre_bn)
+            self.pre_scale = s.to(torch.float32).to(device).contiguous()
+            self.pre_shift = sh.to(torch.float32).to(device).contiguous()
+        self.pre_relu = int(bool(pre_relu))
+        self.klut = None
+        self.smallc = int(bool(smallc))
+        if not smallc and cin % ch != 0:
+            raise CobevtHipError("Cin=%d must be a multiple of %d for the %s kernel (use smallc=True for image "
+                                 "inputs)" % (cin, ch, dtype))
+        if smallc:
+            k = torch.arange(kpad)
+            tap, c = k // cin, k % cin
+            code = ((tap // kw) << 20) | ((tap % kw) << 10) | c
+            code[k >= K] = -1
+            self.klut = code.to(torch.int32).to(device).contiguous()
+        self.cin, self.cout, self.kh, self.kw = cin, cout, kh, kw
+        self.K, self.kpad = K, kpad
+        self.stride, self.pad, self.act = int(stride), int(pad), int(act)
+        self.upsample = int(bool(upsample))
+        self.store_mode = int(store_mode)
+
+    def out_hw(self, h, w):
+        hv, wv = (2 * h, 2 * w) if self.upsample else (h, w)
+        return (hv + 2 * self.pad - self.kh) // self.stride + 1, (wv + 2 * self.pad - self.kw) // self.stride + 1
+
+
+def conv2d(x, plan, residual=None, out=None):
+    """x: (N,H,W,Cin) channels-last contiguous in plan.dtype (fp32 image for smallc plans).  Returns the output
+    in the layout selected by plan.store_mode.  `out` may be a pre-zeroed, spatially larger (N,Hp,Wp,Cout) map."""
+    _need_cuda(x, residual, out)
+    n, h, w, cin = x.shape
+    if cin != plan.cin or not x.is_contiguous():
+        raise CobevtHipError("conv2d: bad input %s (contiguous=%s) for Cin=%d" % (tuple(x.shape), x.is_contiguous(), plan.cin))
+    if x.dtype != (torch.float32 if plan.smallc else plan.dtype):
+        raise CobevtHipError("conv2d: input dtype %s does not match plan (%s, smallc=%d)" % (x.dtype, plan.dtype, plan.smallc))
+    ho, wo = plan.out_hw(h, w)
+    sm = plan.store_mode
+    out_h, out_w = ho, wo
+    if out is None:
+        if sm == 0:
+            out = torch.empty((n, ho, wo, plan.cout), device=x.device, dtype=plan.dtype)
+        elif sm == 1:
+            out = torch.empty((n, ho // 2, wo // 2, plan.cout * 4), device=x.device, dtype=plan.dtype)
+        elif sm == 2:
+            out = torch.empty((n, plan.cout, ho, wo), device=x.device, dtype=torch.float32)
+        else:
+            out = torch.empty((n, ho, wo, plan.cout), device=x.device, dtype=torch.float32)
+    else:
+        if sm not in (0, 3) or out.dim() != 4 or out.shape[0] != n or out.shape[3] != plan.cout or not out.is_contiguous():
+            raise CobevtHipError("conv2d: incompatible `out`")
+        out_h, out_w = out.shape[1], out.shape[2]
+        if out_h < ho or out_w < wo:
+            raise CobevtHipError("conv2d: `out` smaller than the convolution result")
+    if residual is not None:
+        if tuple(residual.shape) != (n, ho, wo, plan.cout) or residual.dtype != plan.dtype or not residual.is_contiguous():
+            raise CobevtHipError("conv2d: residual must be (N,Ho,Wo,Cout) contiguous in the compute dtype")
+    dims = _ints([plan.code, n, h, w, cin, ho, wo, plan.cout, plan.kh, plan.kw, plan.stride, plan.pad, plan.K,
+                  plan.kpad, plan.upsample, plan.pre_relu, plan.act, sm, out_h, out_w, plan.smallc])
+    rc = _L.load().cobevt_conv2d_nhwc(_p(x), _p(plan.wgt), _p(plan.bias), _p(residual), _p(plan.pre_scale),
+                                      _p(plan.pre_shift), _p(plan.klut), _p(out), dims, _stream())
+    _L.check(rc, "cobevt_conv2d_nhwc")
+    return out
+
+
+def linear(x, plan, residual=None):
+    """x: (..., K) contiguous tokens -> (..., Cout).  A Linear is the 1x1 case of the implicit GEMM."""
+    lead = x.shape[:-1]
+    rows = int(math.prod(lead)) if len(lead) else 1
+    x4 = x.reshape(1, 1, rows, x.shape[-1])
+    r4 = residual.reshape(1, 1, rows, plan.cout) if residual is not None else None
+    y = conv2d(x4, plan, residual=r4)
+    return y.reshape(*lead, plan.cout)
+
+
+# ----------------------------------------------------------------------------------------------
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    """LayerNorm over the last axis of a contiguous tensor."""
+    _need_cuda(x, gamma, beta)
+    if not x.is_contiguous():
+        raise CobevtHipError("layernorm: input must be contiguous")
+    c = x.shape[-1]
+    rows = x.numel() // c
+    if out is None:
+        out = torch.empty_like(x)
+    rc = _L.load().cobevt_layernorm(_p(x), _p(gamma), _p(beta), _p(out), dcode(x.dtype), rows, c, float(eps), 1, 0, 0, 0,
+                                    _stream())
+    _L.check(rc, "cobevt_layernorm")
+    return out
+
+
+def mean_layernorm(x, gamma, beta, eps=1e-5):
+    """x: (B, L, R, C) contiguous -> LayerNorm(mean over L): (B, R, C)   (SwapFusionEncoder.mlp_head)."""
+    _need_cuda(x, gamma, beta)
+    b, l, r, c = x.shape
+    if not x.is_contiguous():
+        raise CobevtHipError("mean_layernorm: input must be contiguous")
+    out = torch.empty((b, r, c), device=x.device, dtype=x.dtype)
+    rc = _L.load().cobevt_layernorm(_p(x), _p(gamma), _p(beta), _p(out), dcode(x.dtype), b * r, c, float(eps), l,
+                                    r * c, l * r * c, r, _stream())
+    _L.check(rc, "cobevt_layernorm")
+    return out
+
+
+def tokmap(mode, ncam, hh, ww, w1, w2):
+    """Token map tuple for cobevt_window_attention: mode 0 window / 1 grid / 2 stored-partitioned."""
+    if hh % w1 or ww % w2:
+        raise CobevtHipError("map %dx%d not divisible by window %dx%d" % (hh, ww, w1, w2))
+    return (int(mode), int(ncam), int(hh), int(ww), int(w1), int(w2), hh // w1, ww // w2)
+
+
+def window_attention(q, k, v, out, qmap, kmap, omap, batch, heads, scale, ldq, ldk, ldv, ldo, qoff=0, koff=0, voff=0,
+                     ooff=0, bias_table=None, bias_L=1, mask=None, mean_q=False):
+    _need_cuda(q, k, v, out, bias_table, mask)
+    code = dcode(q.dtype)
+    if k.dtype != q.dtype or v.dtype != q.dtype or out.dtype != q.dtype:
+        raise CobevtHipError("window_attention: q/k/v/out dtypes differ")
+    L = qmap[6] * qmap[7]
+    dims = _ints([code, batch, L, heads, ldq, ldk, ldv, ldo, qoff, koff, voff, ooff,
+                  0 if bias_table is None else 1, 0 if bias_table is None else bias_table.shape[0], bias_L,
+                  int(bool(mean_q))] + list(qmap) + list(kmap) + list(omap))
+    rc = _L.load().cobevt_window_attention(_p(q), _p(k), _p(v), _p(out), _p(bias_table), _p(mask), dims,
+                                           ctypes.c_float(scale), _stream())
+    _L.check(rc, "cobevt_window_attention")
+    return out
+
+
+def ray_embed(i_inv, e_inv, image_plane, w_img, w_cam, hw, dim, dtype):
+    _need_cuda(i_inv, e_inv, image_plane, w_img, w_cam)
+    bn = i_inv.shape[0]
+    out = torch.empty((bn, hw, dim), device=i_inv.device, dtype=dtype)
+    rc = _L.load().cobevt_fax_ray_embed(_p(i_inv), _p(e_inv), _p(image_plane), _p(w_img), _p(w_cam), _p(out),
+                                        dcode(dtype), bn, hw, dim, _stream())
+    _L.check(rc, "cobevt_fax_ray_embed")
+    return out
+
+
+def bev_embed(e_inv, world, w_bev, b_bev, w_cam, x, n):
+    """x: (B, HW, D) -> query (B, n, HW, D)"""
+    _need_cuda(e_inv, world, w_bev, b_bev, w_cam, x)
+    b, hw, d = x.shape
+    out = torch.empty((b, n, hw, d), device=x.device, dtype=x.dtype)
+    rc = _L.load().cobevt_fax_bev_embed(_p(e_inv), _p(world), _p(w_bev), _p(b_bev), _p(w_cam), _p(x), _p(out),
+                                        dcode(x.dtype), b, n, hw, d, _stream())
+    _L.check(rc, "cobevt_fax_bev_embed")
+    return out
+
+
+def maxpool3x3s2(x):
+    _need_cuda(x)
+    n, h, w, c = x.shape
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    out = torch.empty((n, ho, wo, c), device=x.device, dtype=x.dtype)
+    rc = _L.load().cobevt_maxpool3x3s2(_p(x), _p(out), dcode(x.dtype), n, h, w, c, _stream())
+    _L.check(rc, "cobevt_maxpool3x3s2")
+    return out
+
+
+def to_nhwc(x, dtype):
+    """Any (N,C,H,W)-shaped CUDA tensor (arbitrary strides, bf16/fp32) -> contiguous (N,H,W,C) in `dtype`.
+    Zero-copy when x already is a channels-last view of the right dtype."""
+    _need_cuda(x)
+    n, c, h, w = x.shape
+    v = x.permute(0, 2, 3, 1)
+    if x.dtype == dtype and v.is_contiguous():
+        return v
+    out = torch.empty((n, h, w, c), device=x.device, dtype=dtype)
+    strides = (ctypes.c_long * 4)(*x.stride())
+    rc = _L.load().cobevt_to_nhwc(_p(x), dcode(x.dtype), _p(out), dcode(dtype), n, c, h, w, strides, _stream())
+    _L.check(rc, "cobevt_to_nhwc")
+    return out
+
+
+def from_nhwc(x, dtype):
+    """Contiguous (N,H,W,C) -> contiguous (N,C,H,W) in `dtype`."""
+    _need_cuda(x)
+    n, h, w, c = x.shape
+    out = torch.empty((n, c, h, w), device=x.device, dtype=dtype)
+    strides = (ctypes.c_long * 4)(*out.stride())
+    rc = _L.load().cobevt_from_nhwc(_p(x), dcode(x.dtype), _p(out), dcode(dtype), n, c, h, w, strides, _stream())
+    _L.check(rc, "cobevt_from_nhwc")
+    return out
+
+
+def regroup(x, record_len, max_cav):
+    """x: (N, ...) contiguous, record_len int32 device (B,) -> (B, max_cav, ...), mask (B, max_cav) fp32."""
+    _need_cuda(x, record_len)
+    if record_len.dtype != torch.int32 or not x.is_contiguous():
+        raise CobevtHipError("regroup: record_len must be int32 on the device and x contiguous")
+    b = record_len.shape[0]
+    per = x[0].numel()
+    out = torch.empty((b, max_cav) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
+    mask = torch.empty((b, max_cav), device=x.device, dtype=torch.float32)
+    rc = _L.load().cobevt_regroup(_p(x), _p(record_len), _p(out), _p(mask), dcode(x.dtype), b, max_cav, per, _stream())
+    _L.check(rc, "cobevt_regroup")
+    return out, mask
+
+
+def sttf_warp(x, tmat, cav_mask, discrete_ratio, downsample_rate, want_mask=True):
+    """x: (B, L, H, W, C) contiguous ; tmat (B, L, 4, 4) fp32 -> warped (B,L,H,W,C), com_mask (B,H,W,1,L)|None."""
+    _need_cuda(x, tmat, cav_mask)
+    b, l, h, w, c = x.shape
+    if tmat.dtype != torch.float32 or not tmat.is_contiguous() or not x.is_contiguous():
+        raise CobevtHipError("sttf_warp: tmat must be contiguous fp32, x contiguous")
+    out = torch.empty_like(x)
+    com = torch.empty((b, h, w, 1, l), device=x.device, dtype=torch.float32) if want_mask else None
+    rc = _L.load().cobevt_sttf_warp(_p(x), _p(tmat), _p(cav_mask), _p(out), _p(com), dcode(x.dtype), b, l, h, w, c,
+                                    ctypes.c_float(discrete_ratio), ctypes.c_float(downsample_rate), _stream())
+    _L.check(rc, "cobevt_sttf_warp")
+    return out, com

@@ -1,0 +1,205 @@
+"""Bit-reproducible synthetic weights and OPV2V-shaped synthetic inputs.
+
+There are no checkpoints or datasets in the build/bench environment, so weights are a procedural function of
+(state_dict key, shape): a 64-bit integer hash (pure integer arithmetic, identical on every machine) mapped
+to a distribution chosen from the key's role.  The same function fills the reference modules when the
+golden vectors are generated (tests/golden/make_golden.py), the oracle and the HIP modules, so a fixture is
+just (config, input recipe, expected outputs).
+"""
+import math
+
+import numpy as np
+import torch
+
+_MASK = (1 << 64) - 1
+
+
+def _fnv1a(s):
+    h = 0xCBF29CE484222325
+    for ch in s.encode("utf-8"):
+        h ^= ch
+        h = (h * 0x100000001B3) & _MASK
+    return h
+
+
+def _uniform01(key, n, seed):
+    """n doubles in [0,1): splitmix64 of (hash(key) + seed*C + index), top 24 bits."""
+    base = (_fnv1a(key) + ((seed * 0x9E3779B97F4A7C15) & _MASK)) & _MASK
+    z = (np.arange(n, dtype=np.uint64) + np.uint64(base)) * np.uint64(0x9E3779B97F4A7C15)
+    z ^= z >> np.uint64(30)
+    z *= np.uint64(0xBF58476D1CE4E5B9)
+    z ^= z >> np.uint64(27)
+    z *= np.uint64(0x94D049BB133111EB)
+    z ^= z >> np.uint64(31)
+    return (z >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+
+
+def procedural_tensor(key, shape, seed=0):
+    """fp32 tensor for a state_dict entry; None for entries that must keep their constructed value."""
+    shape = tuple(shape)
+    n = int(np.prod(shape)) if len(shape) else 1
+    leaf = key.rsplit(".", 1)[-1]
+    if leaf in ("num_batches_tracked", "relative_position_index"):
+        return None
+    with np.errstate(over="ignore"):
+        u = _uniform01(key, n, seed)
+    if leaf == "running_var":
+        v = 0.6 + 0.8 * u
+    elif leaf == "running_mean":
+        v = (u - 0.5) * 0.4
+    elif leaf == "learned_features":
+        v = (u - 0.5) * 2.0 * math.sqrt(3.0)
+    elif "relative_position_bias_table" in key or "rel_pos_bias" in key:
+        v = (u - 0.5) * 2.0
+    elif len(shape) <= 1:
+        if leaf == "weight":      # BatchNorm / LayerNorm scale
+            v = 0.8 + 0.4 * u
+        else:                     # biases
+            v = (u - 0.5) * 0.2
+    else:
+        fan_in = int(np.prod(shape[1:]))
+        # unit gain: variance preserving for the linear layers; the 16-34 residual conv blocks of the
+        # encoder then grow activations only mildly (He gain would double the variance per block)
+        a = math.sqrt(3.0 / fan_in)
+        v = (u - 0.5) * 2.0 * a
+    return torch.from_numpy(v.astype(np.float32).reshape(shape))
+
+
+@torch.no_grad()
+def fill_module_(module, seed=0):
+    """In-place procedural fill of every floating-point parameter/buffer that appears in state_dict()."""
+    sd = module.state_dict()
+    for key, t in sd.items():
+        if not torch.is_floating_point(t):
+            continue
+        v = procedural_tensor(key, t.shape, seed)
+        if v is not None:
+            t.copy_(v.to(t.dtype))
+    return module
+
+
+def fill_state_dict(shapes, seed=0):
+    """shapes: {key: shape} -> {key: tensor} (float entries only)."""
+    out = {}
+    for key, shape in shapes.items():
+        v = procedural_tensor(key, shape, seed)
+        if v is not None:
+            out[key] = v
+    return out
+
+
+def procedural_input(key, shape, seed=0, lo=-1.0, hi=1.0):
+    """Deterministic input tensor in [lo, hi)."""
+    n = int(np.prod(shape))
+    with np.errstate(over="ignore"):
+        u = _uniform01("input:" + key, n, seed)
+    return torch.from_numpy((lo + (hi - lo) * u).astype(np.float32).reshape(tuple(shape)))
+
+
+# ----------------------------------------------------------------------------------------------
+# OPV2V-camera shaped synthetic batch
+# ----------------------------------------------------------------------------------------------
+def _rz(deg):
+    a = math.radians(deg)
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float64)
+
+
+def _trans(x, y, z):
+    m = np.eye(4, dtype=np.float64)
+    m[:3, 3] = (x, y, z)
+    return m
+
+
+# camera frame (x right, y down, z forward) -> ego frame (x forward, y left, z up)
+_CAM2EGO_AXES = np.array([[0, 0, 1, 0], [-1, 0, 0, 0], [0, -1, 0, 0], [0, 0, 0, 1]], dtype=np.float64)
+
+
+def opv2v_batch(agents, cams=4, image=512, max_cav=5, seed=0, batch=1):
+    """`batch` samples with `agents` agents each.  Returns the batch dict CorpBEVT.forward consumes
+    (intermediate_fusion_dataset.py:289-321): inputs (N,1,M,H,W,3) fp32 channels-last, intrinsic (N,1,M,3,3),
+    extrinsic (N,1,M,4,4) camera->ego, transformation_matrix (B,max_cav,4,4), record_len (B,)."""
+    n = agents * batch
+    inputs = procedural_input("opv2v.inputs", (n, 1, cams, image, image, 3), seed, -1.7, 1.7)
+    f = image / 2.0
+    intr = np.array([[f, 0, image / 2.0], [0, f, image / 2.0], [0, 0, 1]], dtype=np.float64)
+    intrinsic = torch.from_numpy(np.broadcast_to(intr, (n, 1, cams, 3, 3)).astype(np.float32).copy())
+    yaws = [0.0, 100.0, -100.0, 180.0, 50.0, -50.0][:cams]
+    ext = np.zeros((n, 1, cams, 4, 4), dtype=np.float64)
+    for k, yaw in enumerate(yaws):
+        a = math.radians(yaw)
+        ext[:, 0, k] = _rz(yaw) @ _trans(1.5, 0.0, 1.8) @ _CAM2EGO_AXES
+        ext[:, 0, k, 0, 3] = 1.5 * math.cos(a)
+        ext[:, 0, k, 1, 3] = 1.5 * math.sin(a)
+        ext[:, 0, k, 2, 3] = 1.8
+    extrinsic = torch.from_numpy(ext.astype(np.float32))
+    tm = np.tile(np.eye(4, dtype=np.float64), (batch, max_cav, 1, 1))
+    for b in range(batch):
+        for a in range(min(agents, max_cav)):
+            tm[b, a] = _rz(10.0 * a) @ _trans(6.0 * a, -4.0 * a, 0.0)
+    return {
+        "inputs": inputs,
+        "intrinsic": intrinsic,
+        "extrinsic": extrinsic,
+        "transformation_matrix": torch.from_numpy(tm.astype(np.float32)),
+        "record_len": torch.full((batch,), agents, dtype=torch.int64),
+    }
+
+
+def corpbevt_config(max_cav=5, image=512, cams_resnet=34):
+    """model.args of opv2v/opencood/hypes_yaml/opcamera/corpbevt.yaml:47-110 as a plain dict."""
+    return {
+        "target": "dynamic",
+        "max_cav": max_cav,
+        "encoder": {"num_layers": cams_resnet, "pretrained": False, "image_width": image, "image_height": image,
+                    "id_pick": [1, 2, 3]},
+        "compression": 0,
+        "decoder": {"input_dim": 128, "num_layer": 3, "num_ch_dec": [32, 64, 128]},
+        "fax": {
+            "dim": [128, 128, 128],
+            "middle": [2, 2, 2],
+            "bev_embedding": {"sigma": 1.0, "bev_height": 256, "bev_width": 256, "h_meters": 100, "w_meters": 100,
+                              "offset": 0.0, "upsample_scales": [2, 4, 8]},
+            "cross_view": {"image_height": image, "image_width": image, "no_image_features": False, "skip": True,
+                           "heads": [4, 4, 4], "dim_head": [32, 32, 32], "qkv_bias": True},
+            "cross_view_swap": {"rel_pos_emb": False, "q_win_size": [[16, 16], [16, 16], [32, 32]],
+                                "feat_win_size": [[8, 8], [8, 8], [16, 16]],
+                                "bev_embedding_flag": [True, False, False]},
+            "self_attn": {"dim_head": 32, "dropout": 0.1, "window_size": 32},
+        },
+        "sttf": {"resolution": 0.390625, "downsample_rate": 8, "use_roi_mask": True},
+        "fax_fusion": {"input_dim": 128, "mlp_dim": 256, "agent_size": max_cav, "window_size": 8, "dim_head": 32,
+                       "drop_out": 0.1, "depth": 3, "mask": True},
+        "seg_head_dim": 32,
+        "output_class": 2,
+    }
+
+
+def corpbevt_small_config():
+    """Reduced CorpBEVT verified to run on the reference: resnet18, 128^2 images, 2 cams,
+    max_cav 3, dim 32, BEV 64 -> grids 32/16/8."""
+    return {
+        "target": "dynamic",
+        "max_cav": 3,
+        "encoder": {"num_layers": 18, "pretrained": False, "image_width": 128, "image_height": 128,
+                    "id_pick": [1, 2, 3]},
+        "compression": 0,
+        "decoder": {"input_dim": 32, "num_layer": 3, "num_ch_dec": [8, 16, 32]},
+        "fax": {
+            "dim": [32, 32, 32],
+            "middle": [1, 1, 1],
+            "bev_embedding": {"sigma": 1.0, "bev_height": 64, "bev_width": 64, "h_meters": 100, "w_meters": 100,
+                              "offset": 0.0, "upsample_scales": [2, 4, 8]},
+            "cross_view": {"image_height": 128, "image_width": 128, "no_image_features": False, "skip": True,
+                           "heads": [1, 1, 1], "dim_head": [32, 32, 32], "qkv_bias": True},
+            "cross_view_swap": {"rel_pos_emb": False, "q_win_size": [[8, 8], [8, 8], [8, 8]],
+                                "feat_win_size": [[4, 4], [4, 4], [4, 4]],
+                                "bev_embedding_flag": [True, False, False]},
+            "self_attn": {"dim_head": 32, "dropout": 0.1, "window_size": 8},
+        },
+        "sttf": {"resolution": 1.5625, "downsample_rate": 8, "use_roi_mask": True},
+        "fax_fusion": {"input_dim": 32, "mlp_dim": 64, "agent_size": 3, "window_size": 4, "dim_head": 32,
+                       "drop_out": 0.1, "depth": 2, "mask": True},
+        "seg_head_dim": 8,
+        "output_class": 2,
+    }

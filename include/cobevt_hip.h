@@ -1,0 +1,110 @@
+/*
+ * cobevt_hip.h — C ABI of libcobevt_hip.so: the MI355X (gfx950) kernels behind the CoBEVT FAX hot path.
+ *
+ * The reference (DerrickXuNu/CoBEVT) has no FFI: its hot path is Python nn.Modules calling ATen.  The
+ * drop-in boundary is therefore the nn.Module API (cobevt_amd/host/*, same class names / constructor
+ * arguments / state_dict keys / forward contracts); those modules bind the entry points below through
+ * ctypes (cobevt_amd/lib.py).  Every entry point cites the reference code whose arithmetic it replaces
+ * (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - plain C types only: device pointers (hipMalloc'ed / torch data_ptr()), ints, floats, a hipStream_t.
+ *   - all work is enqueued asynchronously on `stream`; nothing is allocated, nothing synchronises.
+ *   - return value: 0 = COBEVT_OK, otherwise an error code (see cobevt_strerror); on error nothing was launched.
+ *   - dtype code: 0 = bf16 storage + bf16 MFMA + fp32 accumulate ; 1 = fp32 storage + fp32 MFMA (parity mode).
+ *   - activations are channels-last ("NHWC", token-major); weights are [Cout][Kpad] with
+ *     k = (kh*Kw + kw)*Cin + c, zero padded to a multiple of 32 (bf16) / 16 (fp32) elements.
+ */
+#ifndef COBEVT_HIP_H
+#define COBEVT_HIP_H
+
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COBEVT_OK 0
+#define COBEVT_ERR_ARG 1
+#define COBEVT_ERR_SHAPE 2
+#define COBEVT_ERR_LAUNCH 3
+#define COBEVT_ERR_UNSUPPORTED 4
+
+int cobevt_abi_version(void);
+const char* cobevt_strerror(int code);
+
+/*
+ * Implicit-GEMM convolution / linear layer with fused prologue + epilogue.
+ * Replaces: torchvision ResNet convs + folded BatchNorm + ReLU + residual add called from
+ *   opv2v/opencood/models/backbones/resnet_ms.py:67-74; nn.Linear / 1x1 convs of
+ *   opv2v/opencood/models/sub_modules/fax_modules.py:107,114-117,189-193,281-292,311-312,472-489;
+ *   opv2v/opencood/models/fusion_modules/swap_fusion_modules.py:45-53; base_transformer.py:112-124;
+ *   naive_decoder.py:78-87 (nearest x2 up-sampling folded into the gather); bev_seg_head.py:35-61;
+ *   nuscenes/cross_view_transformer/model/{encoder_pyramid_axial.py:515-526, decoder.py:12-34, cvt.py:29-33}.
+ * dims (int32[21]): dtype, N, H, W, Cin, Ho, Wo, Cout, Kh, Kw, stride, pad, K, Kpad, upsample(0/1),
+ *   pre_relu(0/1), act(0 none,1 ReLU,2 exact GELU), store_mode(0 NHWC dtype,1 PixelUnshuffle(2) NHWC dtype,
+ *   2 NCHW fp32, 3 NHWC fp32), out_H, out_W (dims of a possibly zero-padded output map, modes 0/3),
+ *   smallc (1: `in` is fp32 NHWC with tiny Cin, taps decoded through klut[Kpad] = kh<<20|kw<<10|c, -1 = pad).
+ * pre_scale/pre_shift (fp32[Cin], nullable): a <- a*scale+shift (+ReLU if pre_relu) applied to the gathered
+ *   input (pre-activation BatchNorm->ReLU->1x1 conv).  bias fp32[Cout] nullable.  residual: same dtype,
+ *   (N,Ho,Wo,Cout), nullable, added before the activation.
+ */
+int cobevt_conv2d_nhwc(const void* in, const void* wgt, const float* bias, const void* residual,
+                       const float* pre_scale, const float* pre_shift, const int* klut, void* out,
+                       const int* dims, hipStream_t stream);
+
+/*
+ * Fused gathered attention: window / dilated-grid partition -> QK^T -> (+relative position bias, key mask)
+ * -> softmax -> PV -> (mean over query cameras) -> partition reverse, for projected token matrices.
+ * Replaces: CrossWinAttention core, fax_modules.py:211-237,243 with the partitions of :399-404,:417-424 and
+ *   reverses of :409,:433; swap Attention core, swap_fusion_modules.py:93-123 with :172-190;
+ *   FAX global Attention core, fax_modules.py:137-171.
+ * dims (int32[40]): dtype, B, L(windows), heads, ldq, ldk, ldv, ldo, qoff, koff, voff, ooff,
+ *   bias_mode(0/1), bias_rows, bias_L, mean_q, then three token maps {mode(0 window,1 grid,2 stored
+ *   partitioned), ncam, HH, WW, w1, w2, X, Y} for q, k/v and out.  Head dim is 32.
+ * bias_table fp32[bias_rows][heads] indexed ((dl+bias_L-1)(2w1-1)+(di+w1-1))(2w2-1)+(dj+w2-1);
+ * mask fp32 (B,HH,WW,ncam) over the key map, 0 = masked (nullable).  `scale` multiplies QK^T.
+ */
+int cobevt_window_attention(const void* q, const void* k, const void* v, void* out, const float* bias_table,
+                            const float* mask, const int* dims, float scale, hipStream_t stream);
+
+/* LayerNorm over channels, optionally after a mean over `navg` slices (mlp_head).
+ * Replaces: nn.LayerNorm of fax_modules.py:189-191,309-313,435-437; swap_fusion_modules.py:275-279;
+ *   base_transformer.py:102-109. */
+int cobevt_layernorm(const void* in, const float* gamma, const float* beta, void* out, int dtype, int rows, int C,
+                     float eps, int navg, long avg_stride, long in_batch_stride, int rows_per_batch,
+                     hipStream_t stream);
+
+/* Camera-ray positional embedding, fax_modules.py:346-358.  out (BN, hw, D) channels-last. */
+int cobevt_fax_ray_embed(const float* I_inv, const float* E_inv, const float* image_plane, const float* w_img,
+                         const float* w_cam, void* out, int dtype, int BN, int hw, int D, hipStream_t stream);
+
+/* BEV query embedding + prior, fax_modules.py:370-375,387-388.  out (B, n, hw, D). */
+int cobevt_fax_bev_embed(const float* E_inv, const float* world, const float* w_bev, const float* b_bev,
+                         const float* w_cam, const void* x, void* out, int dtype, int B, int n, int hw, int D,
+                         hipStream_t stream);
+
+/* MaxPool2d(3, 2, 1) channels-last; torchvision ResNet stem reached from resnet_ms.py:71. */
+int cobevt_maxpool3x3s2(const void* in, void* out, int dtype, int N, int H, int W, int C, hipStream_t stream);
+
+/* Strided (n,c,h,w) view <-> contiguous channels-last with dtype cast (module boundary; resnet_ms.py:62-65). */
+int cobevt_to_nhwc(const void* in, int in_dtype, void* out, int out_dtype, int N, int C, int H, int W,
+                   const long* strides, hipStream_t stream);
+int cobevt_from_nhwc(const void* in, int in_dtype, void* out, int out_dtype, int N, int C, int H, int W,
+                     const long* strides, hipStream_t stream);
+
+/* regroup: split by record_len (device int32[B]), zero pad to max_cav, agent mask (B,max_cav) fp32.
+ * Replaces fuse_utils.py:8-61 without its host synchronisation (:26). */
+int cobevt_regroup(const void* in, const int* record_len, void* out, float* mask, int dtype, int B, int max_cav,
+                   long elems_per_agent, hipStream_t stream);
+
+/* STTF warp into the ego frame + ROI/agent mask.  x (B*L,H,W,C) -> out (B,L,H,W,C), com_mask (B,H,W,1,L).
+ * Replaces corpbevt.py:28-64 and torch_transformation_utils.py:11-134,160-355. tmat: (B,L,4,4) fp32. */
+int cobevt_sttf_warp(const void* x, const float* tmat, const float* cav_mask, void* out, float* com_mask, int dtype,
+                     int B, int L, int H, int W, int C, float discrete_ratio, float downsample_rate,
+                     hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COBEVT_HIP_H */

@@ -1,0 +1,152 @@
+"""Hyper-parameters + input recipes of the golden-vector cases.
+
+Shared by make_golden.py (runs the REFERENCE, only possible in the build container) and by the tests (run the
+oracle / the HIP modules anywhere).  Inputs are procedural (cobevt_amd.synth.procedural_input), weights are
+procedural (cobevt_amd.synth.fill_module_), so a fixture file only needs the expected outputs.
+"""
+import math
+
+import numpy as np
+import torch
+
+from cobevt_amd.synth import procedural_input
+
+SEED = 0
+
+# GV1 — (H, W, w1, w2) pairs that occur in the configs (OPV2V, nuScenes incl. padded maps) + odd shapes
+INDEX_MAP_SHAPES = [
+    (128, 128, 16, 16), (64, 64, 16, 16), (32, 32, 32, 32), (64, 64, 8, 8), (32, 32, 8, 8), (16, 16, 16, 16),
+    (100, 100, 10, 10), (50, 50, 10, 10), (25, 25, 25, 25), (60, 120, 6, 12), (30, 60, 6, 12), (14, 30, 14, 30),
+    (24, 16, 8, 8), (18, 24, 6, 12), (8, 8, 4, 4),
+]
+REL_POS_3D = [(3, 4), (5, 8)]          # (agent_size, window_size)
+REL_POS_2D = [8, 32]
+
+# GV2 — CrossWinAttention
+CROSS_WIN = {
+    "a": dict(dim=32, heads=1, dim_head=32, qkv_bias=True, q=(1, 1, 2, 3, 4, 4, 32), kv=(1, 1, 2, 3, 2, 3, 32), skip=True),
+    "b": dict(dim=128, heads=4, dim_head=32, qkv_bias=True, q=(2, 3, 2, 2, 4, 4, 128), kv=(2, 3, 2, 2, 3, 6, 128), skip=False),
+    "c": dict(dim=128, heads=4, dim_head=32, qkv_bias=False, q=(1, 1, 1, 1, 8, 8, 128), kv=(1, 1, 1, 1, 4, 4, 128), skip=True),
+}
+
+
+def cross_win_inputs(name):
+    c = CROSS_WIN[name]
+    q = procedural_input("gv2.%s.q" % name, c["q"], SEED)
+    k = procedural_input("gv2.%s.k" % name, c["kv"], SEED)
+    v = procedural_input("gv2.%s.v" % name, c["kv"], SEED)
+    skip = procedural_input("gv2.%s.skip" % name, (c["q"][0],) + tuple(c["q"][2:]), SEED) if c["skip"] else None
+    return q, k, v, skip
+
+
+def camera_geometry(bn, n, image_h, image_w):
+    """Pin-hole intrinsics + yawed camera->ego extrinsics, (bn//n, n, ...) shaped fp32."""
+    f = image_w / 2.0
+    intr = np.array([[f, 0, image_w / 2.0], [0, f, image_h / 2.0], [0, 0, 1]], dtype=np.float64)
+    axes = np.array([[0, 0, 1, 0], [-1, 0, 0, 0], [0, -1, 0, 0], [0, 0, 0, 1]], dtype=np.float64)
+    ext = np.zeros((bn // n, n, 4, 4))
+    for b in range(bn // n):
+        for k in range(n):
+            a = math.radians(35.0 + 97.0 * k + 11.0 * b)
+            rz = np.array([[math.cos(a), -math.sin(a), 0, 0], [math.sin(a), math.cos(a), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+            t = np.eye(4)
+            t[:3, 3] = (1.2 + 0.1 * k, 0.3 * b, 1.6)
+            ext[b, k] = rz @ t @ axes
+    I = np.broadcast_to(intr, (bn // n, n, 3, 3)).copy()
+    return torch.from_numpy(I.astype(np.float32)), torch.from_numpy(ext.astype(np.float32))
+
+
+# GV3 — CrossViewSwapAttention
+CVSA = {
+    "plumbing": dict(
+        b=1, n=1, feat=(56, 28, 28), dim=128, index=0, bev=(64, 64), image=(224, 224),
+        bev_embedding=dict(sigma=1.0, bev_height=64, bev_width=64, h_meters=100, w_meters=100, offset=0.0,
+                           upsample_scales=[1]),
+        kwargs=dict(qkv_bias=True, q_win_size=[[16, 16]], feat_win_size=[[7, 7]], heads=[4], dim_head=[32],
+                    bev_embedding_flag=[True], rel_pos_emb=False, no_image_features=False, skip=True)),
+    "padded": dict(
+        b=2, n=2, feat=(32, 14, 15), dim=64, index=1, bev=(24, 16), image=(112, 120),
+        bev_embedding=dict(sigma=1.0, bev_height=24, bev_width=16, h_meters=50, w_meters=40, offset=0.0,
+                           upsample_scales=[1, 1]),
+        kwargs=dict(qkv_bias=True, q_win_size=[[8, 8], [8, 8]], feat_win_size=[[6, 12], [6, 12]], heads=[2, 2],
+                    dim_head=[32, 32], bev_embedding_flag=[True, False], rel_pos_emb=False, no_image_features=False,
+                    skip=True)),
+}
+
+
+def cvsa_inputs(name):
+    c = CVSA[name]
+    x = procedural_input("gv3.%s.x" % name, (c["b"], c["dim"]) + tuple(c["bev"]), SEED)
+    feat = procedural_input("gv3.%s.feature" % name, (c["b"], c["n"]) + tuple(c["feat"]), SEED)
+    I, E = camera_geometry(c["b"] * c["n"], c["n"], *c["image"])
+    return x, feat, I.inverse(), E
+
+
+# GV4 — FAXModule (reduced; verified to run on the reference)
+FAX_SMALL = dict(
+    b=1, l=2, n=2, image=64,
+    config=dict(
+        dim=[32, 32, 32], middle=[2, 2, 2],
+        backbone_output_shape=[(1, 1, 1, 16, 8, 8), (1, 1, 1, 32, 4, 4), (1, 1, 1, 64, 2, 2)],
+        bev_embedding=dict(sigma=1.0, bev_height=32, bev_width=32, h_meters=100, w_meters=100, offset=0.0,
+                           upsample_scales=[2, 4, 8]),
+        cross_view=dict(image_height=64, image_width=64, no_image_features=False, skip=True, heads=[1, 1, 1],
+                        dim_head=[32, 32, 32], qkv_bias=True),
+        cross_view_swap=dict(rel_pos_emb=False, q_win_size=[[4, 4], [4, 4], [4, 4]],
+                             feat_win_size=[[2, 2], [2, 2], [2, 2]], bev_embedding_flag=[True, False, False]),
+        self_attn=dict(dim_head=32, dropout=0.1, window_size=4)))
+
+
+def fax_small_inputs():
+    c = FAX_SMALL
+    feats = [procedural_input("gv4.feature%d" % i, (c["b"], c["l"], c["n"]) + tuple(s[3:]), SEED)
+             for i, s in enumerate(c["config"]["backbone_output_shape"])]
+    I, E = camera_geometry(c["b"] * c["l"] * c["n"], c["n"], c["image"], c["image"])
+    shape5 = (c["b"], c["l"], c["n"])
+    return {"inputs": torch.zeros(shape5 + (c["image"], c["image"], 3)), "features": feats,
+            "intrinsic": I.reshape(shape5 + (3, 3)), "extrinsic": E.reshape(shape5 + (4, 4))}
+
+
+# GV5 — swap fusion
+SWAP = dict(dim=64, dim_head=32, agent_size=3, window_size=4, mlp_dim=128, depth=2, b=2, hw=8)
+
+
+def swap_inputs():
+    c = SWAP
+    x = procedural_input("gv5.x", (c["b"], c["agent_size"], c["dim"], c["hw"], c["hw"]), SEED)
+    mask = torch.ones(c["b"], c["hw"], c["hw"], 1, c["agent_size"])
+    mask[1, :, :, :, 2] = 0                       # a padded agent in sample 1
+    mask[0, :3, :, :, 1] = 0                      # a partially visible ROI for agent 1 of sample 0
+    mask[0, :, 6:, :, 2] = 0
+    return x, mask
+
+
+# GV6 — regroup / STTF / ROI mask
+STTF = dict(resolution=1.5625, downsample_rate=8, C=8)
+
+
+def sttf_inputs(h, w):
+    L = 4
+    x = procedural_input("gv6.x.%dx%d" % (h, w), (1, L, STTF["C"], h, w), SEED)
+    cell = STTF["resolution"] * STTF["downsample_rate"]
+    tm = np.tile(np.eye(4), (1, L, 1, 1))
+    tm[0, 1, 0, 3] = cell                          # +1 cell along x
+    a = math.radians(10.0)
+    tm[0, 2, :2, :2] = [[math.cos(a), -math.sin(a)], [math.sin(a), math.cos(a)]]
+    tm[0, 2, :2, 3] = (2.3 * cell, -1.4 * cell)
+    a = math.radians(-33.0)
+    tm[0, 3, :2, :2] = [[math.cos(a), -math.sin(a)], [math.sin(a), math.cos(a)]]
+    tm[0, 3, :2, 3] = (-0.6 * cell, 3.2 * cell)
+    cav = torch.tensor([[1, 1, 1, 0]], dtype=torch.int64)
+    return x, torch.from_numpy(tm.astype(np.float32)), cav
+
+
+# GV7 — decoder + head
+DECODER = dict(input_dim=32, num_layer=3, num_ch_dec=[8, 16, 32])
+
+# GV9 — FAX global attention
+GLOBAL_ATTN = dict(dim=64, dim_head=32, window_size=8, b=2)
+
+# GV10 — ResnetEncoder
+RESNET = {18: dict(num_layers=18, pretrained=False, image_width=64, image_height=64, id_pick=[1, 2, 3]),
+          34: dict(num_layers=34, pretrained=False, image_width=64, image_height=64, id_pick=[1, 2, 3])}

@@ -1,0 +1,268 @@
+"""Generate the golden vectors by running the REFERENCE (read-only, /root/reference) in the build container.
+
+    python tests/golden/make_golden.py            # writes tests/golden/gv*.npz
+
+The reference is imported as Python with two stand-ins for absent third-party packages (tests/golden/_standins.py).
+Only OUTPUT tensors (and tiny integer maps) are stored: inputs and weights are procedural
+(cobevt_amd.synth), see tests/golden/cases.py.  Every case is also checked against the oracle on the spot so a
+mismatch between reference and restatement is caught at generation time.  The fixtures travel to the GPU box;
+the reference never does.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import _standins  # noqa: E402
+
+_standins.install()
+sys.path.insert(0, "/root/reference/opv2v")
+
+import cases  # noqa: E402
+from cobevt_amd import synth  # noqa: E402
+from cobevt_amd.synth import fill_module_  # noqa: E402
+import oracle.corpbevt as o_model  # noqa: E402
+import oracle.fax as o_fax  # noqa: E402
+import oracle.resnet as o_resnet  # noqa: E402
+import oracle.sttf as o_sttf  # noqa: E402
+import oracle.swap_fusion as o_swap  # noqa: E402
+
+from einops import rearrange  # noqa: E402
+from opencood.models.sub_modules import fax_modules as R_fax  # noqa: E402
+from opencood.models.fusion_modules import swap_fusion_modules as R_swap  # noqa: E402
+from opencood.models.sub_modules import torch_transformation_utils as R_ttu  # noqa: E402
+from opencood.models.sub_modules.fuse_utils import regroup as R_regroup  # noqa: E402
+from opencood.models.sub_modules.naive_decoder import NaiveDecoder as R_NaiveDecoder  # noqa: E402
+from opencood.models.sub_modules.bev_seg_head import BevSegHead as R_BevSegHead  # noqa: E402
+from opencood.models.backbones.resnet_ms import ResnetEncoder as R_ResnetEncoder  # noqa: E402
+from opencood.models import corpbevt as R_corpbevt  # noqa: E402
+from opencood.models.fax_fused_transformer import FaxFusedTransformer as R_FaxFused  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _close(name, got, ref, tol=2e-5):
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-12
+    print("  oracle vs reference %-34s max|err| %.3e  (max|ref| %.3e)" % (name, err, scale))
+    assert err <= tol * max(1.0, scale), "%s: oracle disagrees with the reference" % name
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024.0))
+
+
+def gv1():
+    out = {}
+    for (H, W, w1, w2) in cases.INDEX_MAP_SHAPES:
+        a = torch.arange(H * W).reshape(H, W)
+        win = rearrange(a, "(x w1) (y w2) -> (x y) (w1 w2)", w1=w1, w2=w2)
+        grd = rearrange(a, "(w1 x) (w2 y) -> (x y) (w1 w2)", w1=w1, w2=w2)
+        assert np.array_equal(_np(win), o_fax.window_partition_index(H, W, w1, w2))
+        assert np.array_equal(_np(grd), o_fax.grid_partition_index(H, W, w1, w2))
+        out["win_%d_%d_%d_%d" % (H, W, w1, w2)] = _np(win).astype(np.int32)
+        out["grid_%d_%d_%d_%d" % (H, W, w1, w2)] = _np(grd).astype(np.int32)
+    for (L, w) in cases.REL_POS_3D:
+        idx = _np(R_swap.Attention(32, 32, 0.0, L, w).relative_position_index)
+        assert np.array_equal(idx, o_swap.relative_position_index_3d(L, w))
+        out["rel3d_%d_%d" % (L, w)] = idx.astype(np.int32)
+    for w in cases.REL_POS_2D:
+        idx = _np(R_fax.Attention(32, 32, 0.0, w).rel_pos_indices)
+        assert np.array_equal(idx, o_fax.rel_pos_index_2d(w))
+        if w <= 8:
+            out["rel2d_%d" % w] = idx.astype(np.int32)
+        else:  # 1024 x 1024: keep a strided sample and a checksum
+            out["rel2d_%d_sample" % w] = idx[::37, ::41].astype(np.int32)
+            out["rel2d_%d_sum" % w] = np.array([idx.sum()], dtype=np.int64)
+    save("gv1_index_maps", **out)
+
+
+def gv2():
+    out = {}
+    for name, c in cases.CROSS_WIN.items():
+        m = fill_module_(R_fax.CrossWinAttention(c["dim"], c["heads"], c["dim_head"], c["qkv_bias"]).eval(), cases.SEED)
+        q, k, v, skip = cases.cross_win_inputs(name)
+        ref = m(q, k, v, skip)
+        got = o_fax.cross_win_attention(m.state_dict(), "", q, k, v, skip, c["heads"], c["dim_head"])
+        _close("CrossWinAttention." + name, got, ref)
+        out[name] = _np(ref)
+    save("gv2_cross_win_attention", **out)
+
+
+def gv3():
+    out = {}
+    for name, c in cases.CVSA.items():
+        fd, fh, fw = c["feat"]
+        m = R_fax.CrossViewSwapAttention(fh, fw, fd, c["dim"], c["index"], c["image"][0], c["image"][1], **c["kwargs"]).eval()
+        fill_module_(m, cases.SEED)
+        bev = R_fax.BEVEmbedding(c["dim"], **c["bev_embedding"])
+        x, feat, I_inv, E = cases.cvsa_inputs(name)
+        ref = m(c["index"], x, bev, feat, I_inv, E)
+        cfg = dict(c["kwargs"], image_height=c["image"][0], image_width=c["image"][1])
+        grid = o_fax.bev_grids(**c["bev_embedding"])[c["index"]]
+        assert torch.equal(grid, getattr(bev, "grid%d" % c["index"]))
+        assert torch.equal(o_fax.image_plane(fh, fw, *c["image"]), m.image_plane[0, 0])
+        got = o_fax.cross_view_swap_attention(m.state_dict(), "", cfg, c["index"], x, grid, feat, I_inv, E)
+        _close("CrossViewSwapAttention." + name, got, ref)
+        out[name] = _np(ref)
+    save("gv3_cross_view_swap_attention", **out)
+
+
+def gv4():
+    c = cases.FAX_SMALL
+    cfg = {k: (dict(v) if isinstance(v, dict) else list(v)) for k, v in c["config"].items()}
+    m = fill_module_(R_fax.FAXModule(cfg).eval(), cases.SEED)
+    batch = cases.fax_small_inputs()
+    ref = m(batch)
+    got = o_fax.fax_module(m.state_dict(), "", c["config"], batch["features"], batch["intrinsic"], batch["extrinsic"])
+    _close("FAXModule.small", got, ref)
+    save("gv4_fax_module", out=_np(ref))
+
+
+def gv5():
+    c = cases.SWAP
+    x, mask = cases.swap_inputs()
+    out = {}
+    w = c["window_size"]
+    att = fill_module_(R_swap.Attention(c["dim"], c["dim_head"], 0.1, c["agent_size"], w).eval(), cases.SEED)
+    xw = rearrange(x, "b m d (x w1) (y w2) -> b m x y w1 w2 d", w1=w, w2=w)
+    mw = rearrange(mask, "b (x w1) (y w2) e l -> b x y w1 w2 e l", w1=w, w2=w)
+    ref = att(xw, mask=mw)
+    got = o_swap.swap_attention(att.state_dict(), "", xw, mw, c["dim_head"], c["agent_size"], w)
+    _close("swap Attention (window, mask)", got, ref)
+    out["attention_window_mask"] = _np(ref)
+    ref = att(xw, mask=None)
+    _close("swap Attention (window, no mask)", o_swap.swap_attention(att.state_dict(), "", xw, None, c["dim_head"], c["agent_size"], w), ref)
+    out["attention_window_nomask"] = _np(ref)
+
+    blk = fill_module_(R_swap.SwapFusionBlockMask(c["dim"], c["mlp_dim"], c["dim_head"], w, c["agent_size"], 0.1).eval(), cases.SEED)
+    ref = blk(x, mask)
+    names = ["window_attention.", "window_ffd.", "grid_attention.", "grid_ffd."]
+    _close("SwapFusionBlockMask", o_swap.swap_fusion_block(blk.state_dict(), names, x, mask, c["dim_head"], c["agent_size"], w), ref)
+    out["block_mask"] = _np(ref)
+
+    for use_mask in (True, False):
+        args = dict(input_dim=c["dim"], mlp_dim=c["mlp_dim"], agent_size=c["agent_size"], window_size=w,
+                    dim_head=c["dim_head"], drop_out=0.1, depth=c["depth"], mask=use_mask)
+        enc = fill_module_(R_swap.SwapFusionEncoder(args).eval(), cases.SEED)
+        ref = enc(x, mask if use_mask else None)
+        got = o_swap.swap_fusion_encoder(enc.state_dict(), "", args, x, mask if use_mask else None)
+        _close("SwapFusionEncoder mask=%s" % use_mask, got, ref)
+        out["encoder_mask" if use_mask else "encoder_nomask"] = _np(ref)
+    save("gv5_swap_fusion", **out)
+
+
+def gv6():
+    out = {}
+    s = cases.STTF
+    for (h, w) in ((16, 16), (12, 16)):
+        x, tm, cav = cases.sttf_inputs(h, w)
+        m = R_corpbevt.STTF({"resolution": s["resolution"], "downsample_rate": s["downsample_rate"]})
+        ref = m(x, tm.clone())
+        got = o_sttf.sttf(x, tm, s["resolution"], s["downsample_rate"])
+        _close("STTF %dx%d" % (h, w), got, ref)
+        out["sttf_%dx%d" % (h, w)] = _np(ref)
+        refm = R_ttu.get_roi_and_cav_mask(tuple(ref.shape), cav, tm.clone(), s["resolution"], s["downsample_rate"])
+        gotm = o_sttf.roi_and_cav_mask(tuple(ref.shape), cav, tm, s["resolution"], s["downsample_rate"])
+        assert torch.equal(refm.float(), gotm.float()), "ROI mask mismatch"
+        out["mask_%dx%d" % (h, w)] = _np(refm.float())
+    dense = synth.procedural_input("gv6.regroup", (5, 4, 6, 6), cases.SEED)
+    rl = torch.tensor([2, 3])
+    rg, rmask = R_regroup(dense, rl, 3)
+    og, omask = o_sttf.regroup(dense, rl, 3)
+    assert torch.equal(rg, og) and torch.equal(rmask, omask)
+    out["regroup"] = _np(rg)
+    out["regroup_mask"] = _np(rmask).astype(np.int32)
+    save("gv6_sttf_regroup", **out)
+
+
+def gv7():
+    out = {}
+    d = cases.DECODER
+    dec = fill_module_(R_NaiveDecoder(dict(d)).eval(), cases.SEED)
+    x = synth.procedural_input("gv7.x", (1, 2, d["input_dim"], 8, 8), cases.SEED)
+    ref = dec(x)
+    _close("NaiveDecoder", o_model.naive_decoder(dec.state_dict(), "", d, x), ref)
+    out["decoder"] = _np(ref)
+    y = ref.reshape(-1, *ref.shape[2:])
+    for target, classes in (("dynamic", 2), ("static", 3), ("both", 2)):
+        head = fill_module_(R_BevSegHead(target, d["num_ch_dec"][0], classes).eval(), cases.SEED)
+        r = head(y, 1, 2)
+        g = o_model.bev_seg_head(head.state_dict(), "", target, y, 1, 2)
+        for key in ("static_seg", "dynamic_seg"):
+            _close("BevSegHead.%s.%s" % (target, key), g[key], r[key])
+            out["head_%s_%s" % (target, key)] = _np(r[key])
+    save("gv7_decoder_head", **out)
+
+
+def gv8():
+    cfg = synth.corpbevt_small_config()
+    import copy
+    m = R_corpbevt.CorpBEVT(copy.deepcopy(cfg)).eval()
+    fill_module_(m, cases.SEED)
+    batch = synth.opv2v_batch(agents=2, cams=2, image=128, max_cav=3, seed=cases.SEED)
+    inter = {}
+    m.fax.register_forward_hook(lambda mod, i, o: inter.__setitem__("fax", o))
+    m.fusion_net.register_forward_hook(lambda mod, i, o: inter.__setitem__("fused", o))
+    ref = m({k: v.clone() for k, v in batch.items()})
+    got = o_model.corpbevt_forward(m.state_dict(), cfg, batch, return_intermediates=True)
+    _close("CorpBEVT.small fax", got["fax"], inter["fax"].squeeze(1))
+    _close("CorpBEVT.small fused", got["fused"], inter["fused"])
+    _close("CorpBEVT.small dynamic_seg", got["dynamic_seg"], ref["dynamic_seg"])
+    assert torch.equal(got["static_seg"], ref["static_seg"])
+    nkeys = len(m.state_dict())
+    save("gv8_corpbevt_small", dynamic_seg=_np(ref["dynamic_seg"]), static_seg=_np(ref["static_seg"]),
+         fax=_np(inter["fax"]), fused=_np(inter["fused"]),
+         argmax=_np(ref["dynamic_seg"].argmax(2)).astype(np.int8), n_state_dict_keys=np.array([nkeys]))
+
+    # FaxFusedTransformer (SinBEVT on OPV2V, no fusion) on the same reduced config
+    cfg2 = {k: copy.deepcopy(v) for k, v in cfg.items() if k in ("target", "encoder", "decoder", "fax", "seg_head_dim", "output_class")}
+    m2 = fill_module_(R_FaxFused(copy.deepcopy(cfg2)).eval(), cases.SEED)
+    b2 = {k: batch[k].reshape(1, 2, *batch[k].shape[2:]) for k in ("inputs", "intrinsic", "extrinsic")}
+    ref2 = m2({k: v.clone() for k, v in b2.items()})
+    got2 = o_model.fax_fused_transformer_forward(m2.state_dict(), cfg2, b2)
+    _close("FaxFusedTransformer.small dynamic_seg", got2["dynamic_seg"], ref2["dynamic_seg"])
+    save("gv8_fax_fused_small", dynamic_seg=_np(ref2["dynamic_seg"]))
+
+
+def gv9():
+    c = cases.GLOBAL_ATTN
+    m = fill_module_(R_fax.Attention(c["dim"], c["dim_head"], 0.1, c["window_size"]).eval(), cases.SEED)
+    x = synth.procedural_input("gv9.x", (c["b"], c["dim"], c["window_size"], c["window_size"]), cases.SEED)
+    ref = m(x)
+    _close("FAX global Attention", o_fax.global_attention(m.state_dict(), "", x, c["dim_head"], c["window_size"]), ref)
+    save("gv9_global_attention", out=_np(ref))
+
+
+def gv10():
+    out = {}
+    for depth, cfg in cases.RESNET.items():
+        m = fill_module_(R_ResnetEncoder(dict(cfg)).eval(), cases.SEED)
+        x = synth.procedural_input("gv10.x", (1, 1, 2, 64, 64, 3), cases.SEED)
+        ref = m(x)
+        got = o_resnet.resnet_encoder(m.state_dict(), "encoder.", cfg, x)
+        for i, (r, g) in enumerate(zip(ref, got)):
+            _close("ResnetEncoder%d[%d]" % (depth, i), g, r)
+            out["resnet%d_f%d" % (depth, i)] = _np(r)
+        out["resnet%d_shapes" % depth] = np.array([list(s) for s in m.output_shapes], dtype=np.int32)
+    save("gv10_resnet_encoder", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gv1", "gv2", "gv3", "gv4", "gv5", "gv6", "gv7", "gv8", "gv9", "gv10"]
+    for name in which:
+        print("== " + name)
+        globals()[name]()
