@@ -71,7 +71,7 @@ struct AttnParams {
     const float* bias_table;  // [rows][heads]
     int bias_rows;
     int bias_L;               // agent extent of the 3-D table (1 => 2-D table)
-    const float* mask;        // key mask (B, HH, WW, ncam) fp32, 0 => key masked out ; may be null
+    const float* mask;        // key mask fp32, 0 => key masked out; (B,HH,WW,ncam), or (B,L,w1,w2,ncam) for mode 2; may be null
     int mean_q;
 };
 
@@ -159,9 +159,13 @@ __global__ void attn_gather_kernel(AttnParams p) {
                 int info = (kc.cam << 16) | (kc.i << 8) | kc.j;
                 bool valid = ok;
                 if (ok && p.mask) {
-                    int ph, pw;
-                    tok_pixel(p.kmap, l, kc, ph, pw);
-                    valid = p.mask[(((size_t)b * p.kmap.HH + ph) * p.kmap.WW + pw) * p.kmap.ncam + kc.cam] != 0.f;
+                    if (p.kmap.mode == 2) {  // mask stored partitioned like the keys: (B, X*Y, w1, w2, ncam)
+                        valid = p.mask[((((size_t)b * p.L + l) * p.kmap.w1 + kc.i) * p.kmap.w2 + kc.j) * p.kmap.ncam + kc.cam] != 0.f;
+                    } else {
+                        int ph, pw;
+                        tok_pixel(p.kmap, l, kc, ph, pw);
+                        valid = p.mask[(((size_t)b * p.kmap.HH + ph) * p.kmap.WW + pw) * p.kmap.ncam + kc.cam] != 0.f;
+                    }
                 }
                 kinfo[kk] = valid ? info : -1;
             }
@@ -328,7 +332,6 @@ extern "C" int cobevt_window_attention(const void* q, const void* k, const void*
     p.Nk = p.kmap.ncam * p.kmap.w1 * p.kmap.w2;
     if (p.mean_q && p.qmap.ncam == 1) p.mean_q = 0;
     if (p.mean_q && (p.qmap.ncam > 16 || p.omap.ncam != 1)) return COBEVT_ERR_UNSUPPORTED;
-    if (p.mask && p.kmap.mode == 2) return COBEVT_ERR_UNSUPPORTED;
     const int P = p.qmap.w1 * p.qmap.w2;
     dim3 grid, block;
     if (p.mean_q) { block = dim3(64 * p.qmap.ncam); grid = dim3((P + 31) / 32, p.L * p.heads, p.B); }

@@ -309,7 +309,6 @@ extern "C" int cobevt_conv2d_nhwc(const void* in, const void* wgt, const float* 
     if (p.store_mode < 0 || p.store_mode > 3) return COBEVT_ERR_ARG;
     if (p.store_mode == 1 && ((p.Ho | p.Wo) & 1)) return COBEVT_ERR_SHAPE;
     if ((p.store_mode == 1 || p.store_mode == 2) && p.residual) return COBEVT_ERR_UNSUPPORTED;
-    if (p.residual && (p.out_H != p.Ho || p.out_W != p.Wo)) return COBEVT_ERR_UNSUPPORTED;
     if (smallc) {
         if (!klut || p.pre_scale || p.upsample) return COBEVT_ERR_ARG;
         if (p.Cin > 1023 || p.Kh > 1023 || p.Kw > 1023) return COBEVT_ERR_SHAPE;

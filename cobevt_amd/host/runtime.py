@@ -1,0 +1,126 @@
+"""Shared plumbing of the host modules: compute-dtype selection, lowered-plan caching, layout helpers."""
+import contextlib
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..lib import CobevtHipError
+
+_COMPUTE_DTYPE = torch.bfloat16
+
+
+def set_compute_dtype(dtype):
+    """torch.bfloat16 (perf mode: bf16 storage + bf16 MFMA, fp32 accumulate) or torch.float32 (parity mode:
+    fp32 storage + exact fp32 MFMA)."""
+    global _COMPUTE_DTYPE
+    ops.dcode(dtype)
+    _COMPUTE_DTYPE = dtype
+
+
+def get_compute_dtype():
+    return _COMPUTE_DTYPE
+
+
+@contextlib.contextmanager
+def compute_dtype(dtype):
+    prev = get_compute_dtype()
+    set_compute_dtype(dtype)
+    try:
+        yield
+    finally:
+        set_compute_dtype(prev)
+
+
+class HipModule(nn.Module):
+    """nn.Module whose parameters are plain torch containers (reference-compatible state_dict keys) and whose
+    forward is HIP kernels.  Lowered weights ("plans": folded BatchNorm, [Cout][K] layout, compute dtype) are
+    cached per (name, dtype, device) and rebuilt when a source parameter changes."""
+
+    def __init__(self):
+        super().__init__()
+        self._plan_cache = {}
+
+    def _plan(self, name, tensors, builder):
+        tensors = [t for t in tensors if t is not None]
+        dt, dev = get_compute_dtype(), tensors[0].device
+        key = (name, dt, dev)
+        ver = tuple((t._version, t.data_ptr()) for t in tensors)
+        ent = self._plan_cache.get(key)
+        if ent is None or ent[0] != ver:
+            ent = (ver, builder(dt, dev))
+            self._plan_cache[key] = ent
+        return ent[1]
+
+    def _require_inference(self, *tensors):
+        if self.training:
+            raise CobevtHipError("%s implements the inference hot path only: call .eval() first (training is out "
+                                 "of scope, SURVEY.md §8f)" % type(self).__name__)
+        for t in tensors:
+            if t is not None and not t.is_cuda:
+                raise CobevtHipError("%s.forward needs ROCm device tensors; the HIP path has no CPU fallback"
+                                     % type(self).__name__)
+
+
+def module_tensors(*mods):
+    out = []
+    for m in mods:
+        if m is None:
+            continue
+        out.extend(p for p in m.parameters(recurse=True))
+        out.extend(b for b in m.buffers(recurse=True) if torch.is_floating_point(b))
+    return out
+
+
+def conv_plan(owner, name, conv, bn=None, pre_bn=None, act=0, upsample=False, store_mode=0, smallc=False):
+    """Plan for an nn.Conv2d container (+ following eval BatchNorm, + preceding pre-activation BN->ReLU)."""
+    def build(dt, dev):
+        return ops.ConvPlan(conv.weight, conv.bias, bn=bn, pre_bn=pre_bn, pre_relu=pre_bn is not None,
+                            stride=conv.stride[0], pad=conv.padding[0], act=act, upsample=upsample,
+                            store_mode=store_mode, dtype=dt, device=dev, smallc=smallc)
+    return owner._plan(name, module_tensors(conv, bn, pre_bn), build)
+
+
+def linear_plan(owner, name, lin, act=0):
+    def build(dt, dev):
+        return ops.ConvPlan(lin.weight, lin.bias, act=act, dtype=dt, device=dev)
+    return owner._plan(name, module_tensors(lin), build)
+
+
+def f32_param(owner, name, tensor, shape=None):
+    """fp32 contiguous device copy of a small parameter/buffer (LayerNorm affine, embedding tables, 1x1 geometry convs)."""
+    def build(dt, dev):
+        t = tensor.detach().to(device=dev, dtype=torch.float32)
+        if shape is not None:
+            t = t.reshape(shape)
+        return t.contiguous()
+    return owner._plan("f32:" + name, [tensor], build)
+
+
+def layernorm(owner, name, ln, x):
+    g = f32_param(owner, name + ".w", ln.weight)
+    b = f32_param(owner, name + ".b", ln.bias)
+    return ops.layernorm(x, g, b, ln.eps)
+
+
+def to_nhwc(x):
+    """(N,C,H,W)-shaped tensor -> contiguous (N,H,W,C) in the compute dtype (zero-copy for channels-last views)."""
+    return ops.to_nhwc(x, get_compute_dtype())
+
+
+def nchw_view(x):
+    """contiguous (N,H,W,C) -> (N,C,H,W)-shaped view (no copy)."""
+    return x.permute(0, 3, 1, 2)
+
+
+def as_compute(x):
+    """Contiguous tensor in the compute dtype (API-boundary cast; internal tensors already are)."""
+    dt = get_compute_dtype()
+    if x.dtype != dt:
+        x = x.to(dt)
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def like_input(y, ref):
+    """Public sub-module forwards return the caller's dtype (the reference is fp32 in / fp32 out)."""
+    return y if y.dtype == ref.dtype else y.to(ref.dtype)

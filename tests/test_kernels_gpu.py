@@ -1,0 +1,397 @@
+"""Kernel-level parity: every C-ABI entry point against a plain PyTorch fp32 CPU computation of the same op.
+
+Tolerances: fp32 mode 2e-4 of the output scale (exact-fp32 MFMA, different summation order);
+bf16 mode 2e-2 of the output scale, measured against the fp32 result on bf16-rounded operands.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cobevt_amd import ops
+from cobevt_amd.synth import procedural_input
+import oracle.fax as o_fax
+import oracle.sttf as o_sttf
+import oracle.swap_fusion as o_swap
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype):
+    return 2e-4 if dtype == torch.float32 else 2e-2
+
+
+def rnd(t, dtype):
+    """value the kernel actually sees (bf16 rounding of operands in bf16 mode)"""
+    return t.to(dtype).to(torch.float32)
+
+
+def check(got, ref, dtype, what, scale=None):
+    got = got.detach().float().cpu()
+    assert got.shape == ref.shape, "%s: shape %s vs %s" % (what, tuple(got.shape), tuple(ref.shape))
+    assert torch.isfinite(got).all(), "%s: non-finite output" % what
+    s = ref.abs().max().item() if scale is None else scale
+    err = (got - ref).abs().max().item()
+    assert err <= tol(dtype) * max(s, 1e-6), "%s [%s]: max|err| %.3e vs scale %.3e" % (what, dtype, err, s)
+
+
+def nhwc(x):  # (N,C,H,W) cpu -> (N,H,W,C) contiguous
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+class FakeBN(object):
+    def __init__(self, c, key):
+        self.weight = 0.8 + 0.4 * procedural_input(key + ".w", (c,), 0, 0, 1)
+        self.bias = procedural_input(key + ".b", (c,), 0, -0.2, 0.2)
+        self.running_mean = procedural_input(key + ".m", (c,), 0, -0.3, 0.3)
+        self.running_var = 0.6 + 0.8 * procedural_input(key + ".v", (c,), 0, 0, 1)
+        self.eps = 1e-5
+
+    def apply(self, x):
+        return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, False, 0.0, self.eps)
+
+
+def _conv_case(cuda, dtype, name, n, cin, h, w, cout, k, stride, pad, bias=True, bn=False, act=0, residual=False,
+               pre_bn=False, upsample=False, store_mode=0, smallc=False, out_pad=None):
+    x = procedural_input(name + ".x", (n, cin, h, w), 0)
+    wt = procedural_input(name + ".w", (cout, cin, k, k), 0) * math.sqrt(3.0 / (cin * k * k))
+    b = procedural_input(name + ".b", (cout,), 0, -0.3, 0.3) if bias else None
+    bnm = FakeBN(cout, name + ".bn") if bn else None
+    pbn = FakeBN(cin, name + ".pbn") if pre_bn else None
+    plan = ops.ConvPlan(wt, b, bn=bnm, pre_bn=pbn, pre_relu=pre_bn, stride=stride, pad=pad, act=act, upsample=upsample,
+                        store_mode=store_mode, dtype=dtype, device=cuda, smallc=smallc)
+    # reference on the operands the kernel sees
+    xin = x if smallc else rnd(x, dtype)
+    if smallc and dtype == torch.bfloat16:
+        xin = rnd(x, dtype)  # the kernel rounds the fp32 image to bf16 when packing the A tile
+    wref = plan.wgt.float().cpu()[:, :plan.K].reshape(cout, k, k, cin).permute(0, 3, 1, 2)
+    bref = plan.bias.cpu() if plan.bias is not None else None
+    xr = xin
+    if pre_bn:
+        xr = rnd(F.relu(pbn.apply(xr)), dtype)
+    if upsample:
+        xr = F.interpolate(xr, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xr, wref, bref, stride=stride, padding=pad)
+    res = None
+    if residual:
+        res = procedural_input(name + ".res", tuple(ref.shape), 0)
+        ref = ref + rnd(res, dtype)
+    if act == 1:
+        ref = F.relu(ref)
+    elif act == 2:
+        ref = F.gelu(ref)
+    xd = nhwc(x).to(cuda) if smallc else nhwc(x).to(cuda).to(dtype)
+    rd = nhwc(res).to(cuda).to(dtype) if residual else None
+    out = None
+    if out_pad is not None:
+        out = torch.zeros((n, out_pad[0], out_pad[1], cout), device=cuda, dtype=dtype)
+    y = ops.conv2d(xd, plan, residual=rd, out=out)
+    torch.cuda.synchronize()
+    if store_mode == 0 and out_pad is None:
+        check(y.permute(0, 3, 1, 2), ref, dtype, name)
+    elif store_mode == 0:
+        refp = F.pad(ref, (0, out_pad[1] - ref.shape[3], 0, out_pad[0] - ref.shape[2]))
+        check(y.permute(0, 3, 1, 2), refp, dtype, name)
+    elif store_mode == 1:
+        check(y.permute(0, 3, 1, 2), F.pixel_unshuffle(ref, 2), dtype, name)
+    elif store_mode == 2:
+        assert y.dtype == torch.float32
+        check(y, ref, dtype, name)
+    else:
+        assert y.dtype == torch.float32
+        check(y.permute(0, 3, 1, 2), ref, dtype, name)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_3x3_bias_relu(cuda, dtype):
+    _conv_case(cuda, dtype, "c1", 2, 64, 24, 24, 64, 3, 1, 1, act=1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_3x3_s2_bn_residual_relu(cuda, dtype):
+    _conv_case(cuda, dtype, "c2", 2, 64, 32, 32, 128, 3, 2, 1, bias=False, bn=True, act=1, residual=True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_1x1_big_tile_gelu(cuda, dtype):
+    # M = 32768, Cout = 256 -> 512 tiles of 128x128
+    _conv_case(cuda, dtype, "c3", 8, 32, 64, 64, 256, 1, 1, 0, act=2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_7x7_s2_image_stem(cuda, dtype):
+    _conv_case(cuda, dtype, "c4", 2, 3, 64, 64, 64, 7, 2, 3, bias=False, bn=True, act=1, smallc=True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_1x1_preact_bn_relu_padded_out(cuda, dtype):
+    _conv_case(cuda, dtype, "c5", 2, 56, 14, 15, 128, 1, 1, 0, bias=False, pre_bn=True, out_pad=(18, 24))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_3x3_nearest_upsample(cuda, dtype):
+    _conv_case(cuda, dtype, "c6", 2, 32, 8, 8, 16, 3, 1, 1, bn=True, act=1, upsample=True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_3x3_pixel_unshuffle(cuda, dtype):
+    _conv_case(cuda, dtype, "c7", 1, 32, 16, 16, 8, 3, 1, 1, bias=False, store_mode=1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_3x3_head_nchw_fp32(cuda, dtype):
+    _conv_case(cuda, dtype, "c8", 2, 8, 16, 16, 2, 3, 1, 1, store_mode=2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_1x1_s2_downsample(cuda, dtype):
+    _conv_case(cuda, dtype, "c9", 2, 64, 16, 16, 128, 1, 2, 0, bias=False, bn=True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_ragged_rows(cuda, dtype):
+    x = procedural_input("l1.x", (3, 100, 128), 0)
+    w = procedural_input("l1.w", (384, 128), 0) * math.sqrt(3.0 / 128)
+    b = procedural_input("l1.b", (384,), 0, -0.2, 0.2)
+    plan = ops.ConvPlan(w, b, dtype=dtype, device=cuda)
+    y = ops.linear(x.to(cuda).to(dtype), plan)
+    ref = F.linear(rnd(x, dtype), plan.wgt.float().cpu()[:, :128], b)
+    check(y, ref, dtype, "linear")
+    # residual + gelu-free second GEMM 384 -> 128
+    w2 = procedural_input("l1.w2", (128, 384), 0) * math.sqrt(3.0 / 384)
+    plan2 = ops.ConvPlan(w2, None, dtype=dtype, device=cuda)
+    z = ops.linear(y, plan2, residual=x.to(cuda).to(dtype))
+    ref2 = F.linear(y.float().cpu(), plan2.wgt.float().cpu()[:, :384]) + rnd(x, dtype)
+    check(z, ref2, dtype, "linear+residual")
+
+
+# ---------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, scale, bias=None, key_mask=None):
+    """q (G, Nq, dh), k/v (G, Nk, dh) fp32 -> (G, Nq, dh)"""
+    s = torch.matmul(q, k.transpose(-1, -2)) * scale
+    if bias is not None:
+        s = s + bias
+    if key_mask is not None:
+        s = s.masked_fill(key_mask[:, None, :] == 0, -float("inf"))
+    return torch.matmul(s.softmax(-1), v)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kmode", [0, 1])
+@pytest.mark.parametrize("mean_q", [True, False])
+def test_cross_window_attention(cuda, dtype, kmode, mean_q):
+    B, n, heads, dh = 2, 3, 4, 32
+    d = heads * dh
+    H = W = 8
+    W1 = W2 = 4          # 2x2 query windows
+    h, w, w1, w2 = 12, 24, 6, 12   # 2x2 key windows of 6x12
+    nq = n if mean_q else 1
+    q = procedural_input("att.q", (B, nq, H, W, d), 0)
+    k = procedural_input("att.k", (B, n, h, w, d), 0)
+    v = procedural_input("att.v", (B, n, h, w, d), 0)
+    scale = dh ** -0.5
+    qd, kd, vd = [t.to(cuda).to(dtype) for t in (q, k, v)]
+    out = torch.empty((B, H, W, d), device=cuda, dtype=dtype)
+    qmap = ops.tokmap(0, nq, H, W, W1, W2)
+    kmap = ops.tokmap(kmode, n, h, w, w1, w2)
+    omap = ops.tokmap(0, 1, H, W, W1, W2)
+    ops.window_attention(qd, kd, vd, out, qmap, kmap, omap, B, heads, scale, d, d, d, d, mean_q=mean_q)
+    torch.cuda.synchronize()
+    # reference through the oracle's partitions
+    qp = o_fax._window_partition(rnd(q, dtype), W1, W2)                     # b nq X Y W1 W2 d
+    part = o_fax._window_partition if kmode == 0 else o_fax._grid_partition
+    kp, vp = part(rnd(k, dtype), w1, w2), part(rnd(v, dtype), w1, w2)
+    X, Y = H // W1, W // W2
+    qf = qp.permute(0, 2, 3, 1, 4, 5, 6).reshape(B, X * Y, nq * W1 * W2, heads, dh).permute(0, 3, 1, 2, 4)
+    kf = kp.permute(0, 2, 3, 1, 4, 5, 6).reshape(B, X * Y, n * w1 * w2, heads, dh).permute(0, 3, 1, 2, 4)
+    vf = vp.permute(0, 2, 3, 1, 4, 5, 6).reshape(B, X * Y, n * w1 * w2, heads, dh).permute(0, 3, 1, 2, 4)
+    a = torch.matmul((torch.matmul(qf, kf.transpose(-1, -2)) * scale).softmax(-1), vf)   # b m l Q dh
+    a = a.permute(0, 2, 3, 1, 4).reshape(B, X, Y, nq, W1, W2, d).mean(3)                    # b X Y W1 W2 d
+    ref = o_fax._window_reverse(a)
+    check(out, ref, dtype, "cross attention kmode=%d mean=%s" % (kmode, mean_q))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_prepartitioned_long_keys(cuda, dtype):
+    """mode-2 (stored partitioned) maps, Nq = 1024 rows in one window, Nk = 1024 keys (16 key tiles)."""
+    B, heads, dh = 1, 2, 32
+    d = heads * dh
+    q = procedural_input("att2.q", (B, 1, 1, 1, 32, 32, d), 0)
+    k = procedural_input("att2.k", (B, 4, 1, 1, 16, 16, d), 0)
+    v = procedural_input("att2.v", (B, 4, 1, 1, 16, 16, d), 0)
+    out = torch.empty((B, 1, 1, 32, 32, d), device=cuda, dtype=dtype)
+    qmap = (2, 1, 32, 32, 32, 32, 1, 1)
+    kmap = (2, 4, 16, 16, 16, 16, 1, 1)
+    ops.window_attention(q.to(cuda).to(dtype), k.to(cuda).to(dtype), v.to(cuda).to(dtype), out, qmap, kmap, qmap, B,
+                         heads, dh ** -0.5, d, d, d, d)
+    torch.cuda.synchronize()
+    qf = rnd(q, dtype).reshape(1024, heads, dh).permute(1, 0, 2)
+    kf = rnd(k, dtype).reshape(1024, heads, dh).permute(1, 0, 2)
+    vf = rnd(v, dtype).reshape(1024, heads, dh).permute(1, 0, 2)
+    ref = _attn_ref(qf, kf, vf, dh ** -0.5).permute(1, 0, 2).reshape(B, 1, 1, 32, 32, d)
+    check(out, ref, dtype, "prepartitioned attention")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode", [0, 1])
+def test_swap_attention_bias_mask(cuda, dtype, mode):
+    """fused qkv (ld = 3d), 3-D relative position bias, key mask, window / grid partition over (agent, h, w)."""
+    B, L, w, heads, dh = 2, 3, 4, 2, 32
+    d = heads * dh
+    H = W = 8
+    qkv = procedural_input("sw.qkv", (B, L, H, W, 3 * d), 0)
+    table = procedural_input("sw.table", ((2 * L - 1) * (2 * w - 1) ** 2, heads), 0)
+    mask = torch.ones(B, H, W, 1, L)
+    mask[1, :, :, :, 2] = 0
+    mask[0, :3, :, :, 1] = 0
+    mask[0, :, 6:, :, 2] = 0
+    out = torch.empty((B, L, H, W, d), device=cuda, dtype=dtype)
+    m = ops.tokmap(mode, L, H, W, w, w)
+    qd = qkv.to(cuda).to(dtype)
+    ops.window_attention(qd, qd, qd, out, m, m, m, B, heads, dh ** -0.5, 3 * d, 3 * d, 3 * d, d, qoff=0, koff=d,
+                         voff=2 * d, bias_table=table.to(cuda), bias_L=L, mask=mask.to(cuda).contiguous())
+    torch.cuda.synchronize()
+    x = rnd(qkv, dtype)
+    part = (lambda t: t.reshape(B, L, H // w, w, W // w, w, -1).permute(0, 1, 2, 4, 3, 5, 6)) if mode == 0 else \
+           (lambda t: t.reshape(B, L, w, H // w, w, W // w, -1).permute(0, 1, 3, 5, 2, 4, 6))
+    xp = part(x)                                                       # b l X Y w1 w2 3d
+    X = Y = H // w
+    t = xp.permute(0, 2, 3, 1, 4, 5, 6).reshape(B * X * Y, L * w * w, 3 * d)
+    qf, kf, vf = [z.reshape(B * X * Y, L * w * w, heads, dh).permute(0, 2, 1, 3) for z in t.chunk(3, -1)]
+    idx = torch.from_numpy(o_swap.relative_position_index_3d(L, w))
+    bias = table[idx].permute(2, 0, 1)
+    mp = mask.reshape(B, H // w, w, W // w, w, 1, L).permute(0, 1, 3, 2, 4, 5, 6) if mode == 0 else \
+        mask.reshape(B, w, H // w, w, W // w, 1, L).permute(0, 2, 4, 1, 3, 5, 6)
+    mk = mp.permute(0, 1, 2, 5, 6, 3, 4).reshape(B * X * Y, 1, L * w * w)
+    s = torch.matmul(qf, kf.transpose(-1, -2)) * dh ** -0.5 + bias
+    s = s.masked_fill(mk.unsqueeze(1) == 0, -float("inf"))
+    o = torch.matmul(s.softmax(-1), vf).permute(0, 2, 1, 3).reshape(B, X, Y, L, w, w, d).permute(0, 3, 1, 2, 4, 5, 6)
+    if mode == 0:
+        ref = o.permute(0, 1, 2, 4, 3, 5, 6).reshape(B, L, H, W, d)
+    else:
+        ref = o.permute(0, 1, 4, 2, 5, 3, 6).reshape(B, L, H, W, d)
+    check(out, ref, dtype, "swap attention mode=%d" % mode)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_global_attention_2d_bias(cuda, dtype):
+    B, ws, heads, dh = 2, 8, 2, 32
+    d = heads * dh
+    qkv = procedural_input("ga.qkv", (B, ws, ws, 3 * d), 0)
+    table = procedural_input("ga.table", ((2 * ws - 1) ** 2, heads), 0)
+    out = torch.empty((B, ws, ws, d), device=cuda, dtype=dtype)
+    m = ops.tokmap(0, 1, ws, ws, ws, ws)
+    qd = qkv.to(cuda).to(dtype)
+    ops.window_attention(qd, qd, qd, out, m, m, m, B, heads, dh ** -0.5, 3 * d, 3 * d, 3 * d, d, koff=d, voff=2 * d,
+                         bias_table=table.to(cuda), bias_L=1)
+    torch.cuda.synchronize()
+    t = rnd(qkv, dtype).reshape(B, ws * ws, 3 * d)
+    qf, kf, vf = [z.reshape(B, ws * ws, heads, dh).permute(0, 2, 1, 3) for z in t.chunk(3, -1)]
+    bias = table[torch.from_numpy(o_fax.rel_pos_index_2d(ws))].permute(2, 0, 1)
+    s = torch.matmul(qf, kf.transpose(-1, -2)) * dh ** -0.5 + bias
+    ref = torch.matmul(s.softmax(-1), vf).permute(0, 2, 1, 3).reshape(B, ws, ws, d)
+    check(out, ref, dtype, "global attention")
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c", [32, 128, 256])
+def test_layernorm(cuda, dtype, c):
+    x = procedural_input("ln.x%d" % c, (5, 37, c), 0, -2, 3)
+    g = 0.8 + 0.4 * procedural_input("ln.g%d" % c, (c,), 0, 0, 1)
+    b = procedural_input("ln.b%d" % c, (c,), 0, -0.2, 0.2)
+    y = ops.layernorm(x.to(cuda).to(dtype), g.to(cuda), b.to(cuda))
+    check(y, F.layer_norm(rnd(x, dtype), (c,), g, b, 1e-5), dtype, "layernorm C=%d" % c)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_mean_layernorm(cuda, dtype):
+    x = procedural_input("mln.x", (2, 3, 20, 64), 0, -2, 3)
+    g = 0.8 + 0.4 * procedural_input("mln.g", (64,), 0, 0, 1)
+    b = procedural_input("mln.b", (64,), 0, -0.2, 0.2)
+    y = ops.mean_layernorm(x.to(cuda).to(dtype), g.to(cuda), b.to(cuda))
+    check(y, F.layer_norm(rnd(x, dtype).mean(1), (64,), g, b, 1e-5), dtype, "mean+layernorm")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_maxpool(cuda, dtype):
+    x = procedural_input("mp.x", (2, 64, 18, 22), 0)
+    y = ops.maxpool3x3s2(nhwc(x).to(cuda).to(dtype))
+    check(y.permute(0, 3, 1, 2), F.max_pool2d(rnd(x, dtype), 3, 2, 1), dtype, "maxpool")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layout_roundtrip(cuda, dtype):
+    x = procedural_input("lay.x", (2, 24, 5, 7), 0)
+    y = ops.to_nhwc(x.to(cuda), dtype)
+    check(y, rnd(nhwc(x), dtype), dtype, "to_nhwc")
+    assert ops.to_nhwc(y.permute(0, 3, 1, 2), dtype).data_ptr() == y.data_ptr()      # zero-copy for channels-last views
+    z = ops.from_nhwc(y, torch.float32)
+    check(z, rnd(x, dtype), dtype, "from_nhwc")
+    sl = x.to(cuda)[:, 4:20]                                                          # a strided (non-contiguous) view
+    check(ops.to_nhwc(sl, dtype), rnd(nhwc(x[:, 4:20]), dtype), dtype, "to_nhwc strided")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_regroup(cuda, dtype):
+    x = procedural_input("rg.x", (5, 6, 6, 8), 0)
+    rl = torch.tensor([2, 3], dtype=torch.int32)
+    y, mask = ops.regroup(x.to(cuda).to(dtype), rl.to(cuda), 4)
+    ref, rmask = o_sttf.regroup(rnd(x, dtype), rl, 4)
+    check(y, ref, dtype, "regroup")
+    assert torch.equal(mask.cpu(), rmask.float())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hw", [(16, 16), (12, 16)])
+def test_sttf_warp_and_mask(cuda, dtype, hw):
+    import cases
+    h, w = hw
+    x, tm, cav = cases.sttf_inputs(h, w)                                     # x: (1, L, C, h, w)
+    s = cases.STTF
+    xd = x.permute(0, 1, 3, 4, 2).contiguous().to(cuda).to(dtype)           # (1, L, h, w, C)
+    y, com = ops.sttf_warp(xd, tm.to(cuda), cav.float().to(cuda), s["resolution"], s["downsample_rate"])
+    ref = o_sttf.sttf(rnd(x, dtype), tm, s["resolution"], s["downsample_rate"])
+    check(y, ref, dtype, "sttf warp %dx%d" % (h, w), scale=1.0)
+    refm = o_sttf.roi_and_cav_mask(tuple(ref.shape), cav, tm, s["resolution"], s["downsample_rate"])
+    assert torch.equal(com.cpu(), refm.float()), "ROI mask differs in %d cells" % (com.cpu() != refm.float()).sum()
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(cases.__file__), "gv6_sttf_regroup.npz"))
+    if dtype == torch.float32:
+        check(y, torch.from_numpy(g["sttf_%dx%d" % (h, w)]), dtype, "sttf vs golden", scale=1.0)
+        assert np.array_equal(com.cpu().numpy(), g["mask_%dx%d" % (h, w)])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ray_and_bev_embed(cuda, dtype):
+    import cases
+    b, n, d, h, w, H, W = 2, 2, 64, 14, 15, 24, 16
+    I, E = cases.camera_geometry(b * n, n, 112, 120)
+    I_inv = I.inverse().reshape(b * n, 3, 3).contiguous()
+    E = E.reshape(b * n, 4, 4).contiguous()
+    w_img = procedural_input("re.wimg", (d, 4), 0)
+    w_cam = procedural_input("re.wcam", (d, 4), 0)
+    plane = o_fax.image_plane(h, w, 112, 120)
+    y = ops.ray_embed(I_inv.to(cuda), E.to(cuda), plane.reshape(3, -1).contiguous().to(cuda), w_img.to(cuda),
+                      w_cam.to(cuda), h * w, d, dtype)
+    c_embed = F.conv2d(E[:, :, 3].reshape(b * n, 4, 1, 1), w_cam.reshape(d, 4, 1, 1))
+    cam = F.pad(I_inv[:, None] @ plane.reshape(1, 1, 3, h * w), (0, 0, 0, 1), value=1)[:, 0]
+    dd = (E @ cam).reshape(b * n, 4, h, w)
+    emb = F.conv2d(dd, w_img.reshape(d, 4, 1, 1)) - c_embed
+    emb = emb / (emb.norm(dim=1, keepdim=True) + 1e-7)
+    check(y.reshape(b * n, h, w, d), nhwc(emb), dtype, "ray embed", scale=1.0)
+
+    grid = o_fax.bev_grids(1.0, H, W, 50, 40, 0.0, [1])[0] if False else \
+        o_fax.bev_grids(bev_height=H, bev_width=W, h_meters=50, w_meters=40, offset=0.0, upsample_scales=[1])[0]
+    w_bev = procedural_input("re.wbev", (d, 2), 0)
+    b_bev = procedural_input("re.bbev", (d,), 0, -0.2, 0.2)
+    x = procedural_input("re.x", (b, H, W, d), 0)
+    q = ops.bev_embed(E.to(cuda), grid[:2].reshape(2, -1).contiguous().to(cuda), w_bev.to(cuda), b_bev.to(cuda),
+                      w_cam.to(cuda), x.reshape(b, H * W, d).to(cuda).to(dtype), n)
+    we = F.conv2d(grid[:2][None], w_bev.reshape(d, 2, 1, 1), b_bev) - c_embed
+    we = we / (we.norm(dim=1, keepdim=True) + 1e-7)
+    ref = nhwc(we).reshape(b, n, H, W, d) + rnd(x, dtype)[:, None]
+    check(q.reshape(b, n, H, W, d), ref, dtype, "bev embed")
