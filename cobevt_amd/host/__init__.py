@@ -1,0 +1,13 @@
+"""Host-side mirror of the reference's nn.Module interface for the FAX hot path."""
+from .runtime import compute_dtype, get_compute_dtype, set_compute_dtype  # noqa: F401
+from .fax_modules import (Attention as FaxAttention, BEVEmbedding, Bottleneck, CrossViewSwapAttention,  # noqa: F401
+                          CrossWinAttention, FAXModule, generate_grid, get_view_matrix)
+from .swap_fusion_modules import (Attention as SwapAttention, SwapFusionBlock, SwapFusionBlockMask,  # noqa: F401
+                                  SwapFusionEncoder)
+from .base_transformer import FeedForward, PreNormResidual  # noqa: F401
+from .resnet_ms import ResnetEncoder  # noqa: F401
+from .naive_decoder import NaiveDecoder  # noqa: F401
+from .bev_seg_head import BevSegHead  # noqa: F401
+from .fuse_utils import regroup  # noqa: F401
+from .corpbevt import STTF, CorpBEVT  # noqa: F401
+from .fax_fused_transformer import FaxFusedTransformer  # noqa: F401

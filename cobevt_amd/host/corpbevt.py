@@ -1,0 +1,84 @@
+"""CorpBEVT (CoBEVT = SinBEVT per agent + FuseBEVT across agents) — mirror of
+opv2v/opencood/models/corpbevt.py: STTF :22-64, CorpBEVT :67-145 (constructor config keys, state_dict keys,
+forward(batch_dict) -> {'static_seg', 'dynamic_seg'}, the `batch_dict['features']` side effect :113)."""
+import torch
+
+from .. import ops
+from ..lib import CobevtHipError
+from . import runtime as rt
+from .bev_seg_head import BevSegHead
+from .fax_modules import FAXModule
+from .naive_decoder import NaiveDecoder
+from .resnet_ms import ResnetEncoder
+from .runtime import HipModule
+from .swap_fusion_modules import SwapFusionEncoder
+
+
+class STTF(HipModule):
+    """Warp every agent's BEV feature map into the ego frame (corpbevt.py:22-64); the affine matrices
+    (torch_transformation_utils.py:108-134,160-297), affine_grid + bilinear grid_sample (:317-355) and the
+    transpose / flip sandwich are one kernel."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.discrete_ratio = args["resolution"]
+        self.downsample_rate = args["downsample_rate"]
+
+    def warp_blhwc(self, x, spatial_correction_matrix, cav_mask=None, want_mask=False):
+        tm = spatial_correction_matrix.to(device=x.device, dtype=torch.float32).contiguous()
+        return ops.sttf_warp(x, tm, cav_mask, self.discrete_ratio, self.downsample_rate, want_mask=want_mask)
+
+    def forward(self, x, spatial_correction_matrix):
+        """x: (B, L, C, H, W) -> (B, L, H, W, C)"""
+        self._require_inference(x)
+        b, l, c, h, w = x.shape
+        xl = rt.to_nhwc(x.reshape(b * l, c, h, w)).reshape(b, l, h, w, c)
+        y, _ = self.warp_blhwc(xl, spatial_correction_matrix)
+        return rt.like_input(y, x)
+
+
+class CorpBEVT(HipModule):
+    def __init__(self, config):
+        super().__init__()
+        self.max_cav = config["max_cav"]
+        self.encoder = ResnetEncoder(config["encoder"])
+        fax_params = config["fax"]
+        fax_params["backbone_output_shape"] = self.encoder.output_shapes
+        self.fax = FAXModule(fax_params)
+        if config["compression"] > 0:
+            raise CobevtHipError("NaiveCompressor (compression > 0) is outside the FAX hot path; every shipped "
+                                 "config uses compression: 0 (corpbevt.yaml:58)")
+        self.compression = False
+        self.downsample_rate = config["sttf"]["downsample_rate"]
+        self.discrete_ratio = config["sttf"]["resolution"]
+        self.use_roi_mask = config["sttf"]["use_roi_mask"]
+        self.sttf = STTF(config["sttf"])
+        self.fusion_net = SwapFusionEncoder(config["fax_fusion"])
+        self.decoder = NaiveDecoder(config["decoder"])
+        self.target = config["target"]
+        self.seg_head = BevSegHead(self.target, config["seg_head_dim"], config["output_class"])
+
+    def fuse_and_decode(self, feats, transformation_matrix, record_len):
+        """feats: (N, H, W, C) channels-last per-agent BEV features (what V2V sharing transmits) ->
+        output dict.  Split out so the multi-GPU path can all-gather `feats` first (cobevt_amd/dist.py)."""
+        dev = feats.device
+        rl = torch.as_tensor(record_len).to(device=dev, dtype=torch.int32)
+        x, cav_mask = ops.regroup(feats, rl, self.max_cav)                      # (B, L, H, W, C), (B, L)
+        x, com_mask = self.sttf.warp_blhwc(x, transformation_matrix, cav_mask, want_mask=self.use_roi_mask)
+        if not self.use_roi_mask:
+            b, l, h, w, _ = x.shape
+            com_mask = cav_mask[:, None, None, None, :].expand(b, h, w, 1, l).contiguous()
+        fused = self.fusion_net.forward_blhwc(x, com_mask)                      # (B, H, W, C)
+        y = self.decoder.forward_nhwc(fused)                                    # (B, 8H, 8W, C')
+        b = y.shape[0]
+        return self.seg_head(rt.nchw_view(y), b, 1)
+
+    def forward(self, batch_dict):
+        x = batch_dict["inputs"]
+        transformation_matrix = batch_dict["transformation_matrix"]
+        record_len = batch_dict["record_len"]
+        x = self.encoder(x)
+        batch_dict.update({"features": x})
+        x = self.fax(batch_dict)                    # (N, 1, C, H, W) channels-last view
+        x = x.squeeze(1)
+        return self.fuse_and_decode(rt.to_nhwc(x), transformation_matrix, record_len)

@@ -1,0 +1,364 @@
+"""MI355X-native FAX cross-view pyramid behind the reference's module API.
+
+Mirror of opv2v/opencood/models/sub_modules/fax_modules.py: same class names, constructor signatures,
+state_dict keys and forward contracts.  The nn.Linear / nn.Conv2d / nn.LayerNorm /
+nn.BatchNorm2d children are parameter containers only; the arithmetic is HIP kernels (cobevt_amd/ops.py).
+Internally activations are channels-last (b, H, W, d) in the compute dtype and the window / grid partitions
+are index arithmetic inside the attention kernel; the public forwards accept/return the reference's shapes as
+(zero-copy where possible) views.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..lib import CobevtHipError
+from . import runtime as rt
+from .runtime import HipModule
+
+
+def generate_grid(height, width):
+    """fax_modules.py:13-21 -> (1, 3, h, w)"""
+    xs = torch.linspace(0, 1, width)
+    ys = torch.linspace(0, 1, height)
+    gx = xs[None, :].expand(height, width)
+    gy = ys[:, None].expand(height, width)
+    return torch.stack([gx, gy, torch.ones(height, width)], 0)[None].contiguous()
+
+
+def get_view_matrix(h=200, w=200, h_meters=100.0, w_meters=100.0, offset=0.0):
+    """fax_modules.py:24-35"""
+    sh = h / h_meters
+    sw = w / w_meters
+    return [[0., -sw, w / 2.], [-sh, 0., h * offset + h / 2.], [0., 0., 1.]]
+
+
+class Bottleneck(HipModule):
+    """torchvision.models.resnet.Bottleneck(inplanes, planes) container + HIP forward (used as
+    ResNetBottleNeck(c) = Bottleneck(c, c // 4), fax_modules.py:10,472)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes):
+        super().__init__()
+        width = planes
+        self.conv1 = nn.Conv2d(inplanes, width, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, planes * self.expansion, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+
+    def forward_nhwc(self, x):
+        y = ops.conv2d(x, rt.conv_plan(self, "c1", self.conv1, self.bn1, act=1))
+        y = ops.conv2d(y, rt.conv_plan(self, "c2", self.conv2, self.bn2, act=1))
+        return ops.conv2d(y, rt.conv_plan(self, "c3", self.conv3, self.bn3, act=1), residual=x)
+
+    def forward(self, x):
+        self._require_inference(x)
+        return rt.like_input(rt.nchw_view(self.forward_nhwc(rt.to_nhwc(x))), x)
+
+
+ResNetBottleNeck = lambda c: Bottleneck(c, c // 4)  # noqa: E731
+
+
+class BEVEmbedding(nn.Module):
+    """fax_modules.py:38-90 — init-time grids (non-persistent buffers) + learned prior."""
+
+    def __init__(self, dim, sigma, bev_height, bev_width, h_meters, w_meters, offset, upsample_scales):
+        super().__init__()
+        V_inv = torch.FloatTensor(get_view_matrix(bev_height, bev_width, h_meters, w_meters, offset)).inverse()
+        for i, scale in enumerate(upsample_scales):
+            h, w = bev_height // scale, bev_width // scale
+            grid = generate_grid(h, w).squeeze(0)
+            grid[0] = bev_width * grid[0]
+            grid[1] = bev_height * grid[1]
+            grid = (V_inv @ grid.reshape(3, h * w)).reshape(3, h, w)
+            self.register_buffer("grid%d" % i, grid, persistent=False)
+        self.learned_features = nn.Parameter(
+            sigma * torch.randn(dim, bev_height // upsample_scales[0], bev_width // upsample_scales[0]))
+
+    def get_prior(self):
+        return self.learned_features
+
+
+class Attention(HipModule):
+    """FAX global self-attention with 2-D relative position bias, fax_modules.py:93-176."""
+
+    def __init__(self, dim, dim_head=32, dropout=0., window_size=25):
+        super().__init__()
+        assert (dim % dim_head) == 0, "dimension should be divisible by dimension per head"
+        if dim_head != 32:
+            raise CobevtHipError("the HIP attention kernel is built for dim_head = 32")
+        self.heads = dim // dim_head
+        self.scale = dim_head ** -0.5
+        self.window_size = window_size
+        self.to_qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.attend = nn.Sequential(nn.Softmax(dim=-1), nn.Dropout(dropout))
+        self.to_out = nn.Sequential(nn.Linear(dim, dim, bias=False), nn.Dropout(dropout))
+        self.rel_pos_bias = nn.Embedding((2 * window_size - 1) ** 2, self.heads)
+        pos = torch.arange(window_size)
+        gi, gj = torch.meshgrid(pos, pos, indexing="ij")
+        grid = torch.stack([gi.reshape(-1), gj.reshape(-1)], -1)              # (i j) c
+        rel_pos = grid[:, None, :] - grid[None, :, :] + window_size - 1
+        rel_pos_indices = (rel_pos * torch.tensor([2 * window_size - 1, 1])).sum(dim=-1)
+        self.register_buffer("rel_pos_indices", rel_pos_indices, persistent=False)
+
+    def forward_nhwc(self, x):
+        b, h, w, d = x.shape
+        if h != self.window_size or w != self.window_size:
+            raise CobevtHipError("FAX global attention expects a %dx%d map" % (self.window_size, self.window_size))
+        qkv = ops.linear(x, rt.linear_plan(self, "qkv", self.to_qkv))
+        out = torch.empty((b, h, w, d), device=x.device, dtype=x.dtype)
+        m = ops.tokmap(0, 1, h, w, h, w)
+        table = rt.f32_param(self, "bias", self.rel_pos_bias.weight)
+        ops.window_attention(qkv, qkv, qkv, out, m, m, m, b, self.heads, self.scale, 3 * d, 3 * d, 3 * d, d, koff=d,
+                             voff=2 * d, bias_table=table, bias_L=1)
+        return ops.linear(out, rt.linear_plan(self, "out", self.to_out[0]))
+
+    def forward(self, x):
+        self._require_inference(x)
+        return rt.like_input(rt.nchw_view(self.forward_nhwc(rt.to_nhwc(x))), x)
+
+
+class CrossWinAttention(HipModule):
+    """fax_modules.py:179-248."""
+
+    def __init__(self, dim, heads, dim_head, qkv_bias, rel_pos_emb=False, norm=nn.LayerNorm):
+        super().__init__()
+        if dim_head != 32:
+            raise CobevtHipError("the HIP attention kernel is built for dim_head = 32")
+        self.scale = dim_head ** -0.5
+        self.heads = heads
+        self.dim_head = dim_head
+        self.rel_pos_emb = rel_pos_emb
+        self.to_q = nn.Sequential(norm(dim), nn.Linear(dim, heads * dim_head, bias=qkv_bias))
+        self.to_k = nn.Sequential(norm(dim), nn.Linear(dim, heads * dim_head, bias=qkv_bias))
+        self.to_v = nn.Sequential(norm(dim), nn.Linear(dim, heads * dim_head, bias=qkv_bias))
+        self.proj = nn.Linear(heads * dim_head, dim)
+
+    def add_rel_pos_emb(self, x):
+        return x
+
+    def _project(self, name, seq, x):
+        return ops.linear(rt.layernorm(self, name + ".ln", seq[0], x), rt.linear_plan(self, name, seq[1]))
+
+    def attend(self, q_src, k_src, v_src, qmap, kmap, omap, batch, skip, out_shape):
+        """q_src/k_src/v_src: token-major tensors whose rows the maps address; returns proj(attn) (+skip)."""
+        inner = self.heads * self.dim_head
+        qt = self._project("q", self.to_q, q_src)
+        kt = self._project("k", self.to_k, k_src)
+        vt = self._project("v", self.to_v, v_src)
+        a = torch.empty(tuple(out_shape) + (inner,), device=qt.device, dtype=qt.dtype)
+        ops.window_attention(qt, kt, vt, a, qmap, kmap, omap, batch, self.heads, self.scale, inner, inner, inner, inner,
+                             mean_q=qmap[1] > 1)
+        return ops.linear(a, rt.linear_plan(self, "proj", self.proj), residual=skip)
+
+    def forward(self, q, k, v, skip=None):
+        """q: (b n X Y W1 W2 d); k, v: (b n x y w1 w2 d); skip (b X Y W1 W2 d) -> (b X Y W1 W2 d)"""
+        self._require_inference(q, k, v, skip)
+        assert k.shape == v.shape
+        b, n, X, Y, W1, W2, _ = q.shape
+        _, nk, kx, ky, w1, w2, _ = k.shape
+        assert X * Y == kx * ky
+        qmap = (2, n, X * W1, Y * W2, W1, W2, X, Y)
+        kmap = (2, nk, kx * w1, ky * w2, w1, w2, kx, ky)
+        omap = (2, 1, X * W1, Y * W2, W1, W2, X, Y)
+        sk = rt.as_compute(skip) if skip is not None else None
+        z = self.attend(rt.as_compute(q), rt.as_compute(k), rt.as_compute(v), qmap, kmap, omap, b, sk,
+                        (b, X, Y, W1, W2))
+        return rt.like_input(z, q)
+
+
+class CrossViewSwapAttention(HipModule):
+    """fax_modules.py:251-441."""
+
+    def __init__(self, feat_height, feat_width, feat_dim, dim, index, image_height, image_width, qkv_bias, q_win_size,
+                 feat_win_size, heads, dim_head, bev_embedding_flag, rel_pos_emb=False, no_image_features=False,
+                 skip=True, norm=nn.LayerNorm):
+        super().__init__()
+        image_plane = generate_grid(feat_height, feat_width)[None]
+        image_plane[:, :, 0] *= image_width
+        image_plane[:, :, 1] *= image_height
+        self.register_buffer("image_plane", image_plane, persistent=False)
+        self.feature_linear = nn.Sequential(nn.BatchNorm2d(feat_dim), nn.ReLU(), nn.Conv2d(feat_dim, dim, 1, bias=False))
+        if no_image_features:
+            self.feature_proj = None
+        else:
+            self.feature_proj = nn.Sequential(nn.BatchNorm2d(feat_dim), nn.ReLU(), nn.Conv2d(feat_dim, dim, 1, bias=False))
+        self.bev_embed_flag = bev_embedding_flag[index]
+        if self.bev_embed_flag:
+            self.bev_embed = nn.Conv2d(2, dim, 1)
+        self.img_embed = nn.Conv2d(4, dim, 1, bias=False)
+        self.cam_embed = nn.Conv2d(4, dim, 1, bias=False)
+        self.q_win_size = q_win_size[index]
+        self.feat_win_size = feat_win_size[index]
+        self.rel_pos_emb = rel_pos_emb
+        self.cross_win_attend_1 = CrossWinAttention(dim, heads[index], dim_head[index], qkv_bias)
+        self.cross_win_attend_2 = CrossWinAttention(dim, heads[index], dim_head[index], qkv_bias)
+        self.skip = skip
+        self.prenorm_1 = norm(dim)
+        self.prenorm_2 = norm(dim)
+        self.mlp_1 = nn.Sequential(nn.Linear(dim, 2 * dim), nn.GELU(), nn.Linear(2 * dim, dim))
+        self.mlp_2 = nn.Sequential(nn.Linear(dim, 2 * dim), nn.GELU(), nn.Linear(2 * dim, dim))
+        self.postnorm = norm(dim)
+        self.dim = dim
+
+    def _padded_hw(self, h, w):
+        """pad_divisble, fax_modules.py:315-321"""
+        wh, ww = self.feat_win_size
+        hp = ((h + wh) // wh) * wh if h % wh != 0 else h
+        wp = ((w + ww) // ww) * ww if w % ww != 0 else w
+        return hp, wp
+
+    def _mlp(self, name, prenorm, mlp, x):
+        t = rt.layernorm(self, name + ".ln", prenorm, x)
+        t = ops.linear(t, rt.linear_plan(self, name + ".0", mlp[0], act=2))
+        return ops.linear(t, rt.linear_plan(self, name + ".2", mlp[2]), residual=x)
+
+    def forward_nhwc(self, index, x, bev, feature, I_inv, E_inv):
+        """x (b,H,W,d); feature (b*n,h,w,C) compute dtype; I_inv (b*n,3,3), E_inv (b*n,4,4) fp32 -> (b,H,W,d)"""
+        b, H, W, d = x.shape
+        bn, h, w, _ = feature.shape
+        n = bn // b
+        dt = x.dtype
+        W1, W2 = self.q_win_size
+        w1, w2 = self.feat_win_size
+        hp, wp = self._padded_hw(h, w)
+        padded = (hp, wp) != (h, w)
+
+        plane = rt.f32_param(self, "plane", self.image_plane, (3, h * w))
+        w_img = rt.f32_param(self, "w_img", self.img_embed.weight, (d, 4))
+        w_cam = rt.f32_param(self, "w_cam", self.cam_embed.weight, (d, 4))
+        img = ops.ray_embed(I_inv, E_inv, plane, w_img, w_cam, h * w, d, dt).reshape(bn, h, w, d)
+
+        def kv_buffer():
+            return torch.zeros((bn, hp, wp, d), device=x.device, dtype=dt) if padded else None
+
+        if self.feature_proj is not None:
+            key = ops.conv2d(feature, rt.conv_plan(self, "fproj", self.feature_proj[2], pre_bn=self.feature_proj[0]),
+                             residual=img, out=kv_buffer())
+        elif padded:
+            key = kv_buffer()
+            key[:, :h, :w] = img
+        else:
+            key = img
+        val = ops.conv2d(feature, rt.conv_plan(self, "flin", self.feature_linear[2], pre_bn=self.feature_linear[0]),
+                         out=kv_buffer())
+
+        if self.bev_embed_flag:
+            grid = getattr(bev, "grid%d" % index)
+            world = rt.f32_param(self, "world%d" % index, grid[:2], (2, H * W))
+            w_bev = rt.f32_param(self, "w_bev", self.bev_embed.weight, (d, 2))
+            b_bev = rt.f32_param(self, "b_bev", self.bev_embed.bias)
+            query = ops.bev_embed(E_inv, world, w_bev, b_bev, w_cam, x.reshape(b, H * W, d), n)   # (b, n, HW, d)
+            nq = n
+        else:
+            query, nq = x, 1
+
+        qmap_n = ops.tokmap(0, nq, H, W, W1, W2)
+        qmap_1 = ops.tokmap(0, 1, H, W, W1, W2)
+        kwin = ops.tokmap(0, n, hp, wp, w1, w2)
+        kgrid = ops.tokmap(1, n, hp, wp, w1, w2)
+        if qmap_1[6] * qmap_1[7] != kwin[6] * kwin[7]:
+            raise CobevtHipError("query windows %dx%d != key windows %dx%d" % (qmap_1[6], qmap_1[7], kwin[6], kwin[7]))
+
+        # local-to-local: window queries x window keys; per-camera queries are averaged in-kernel
+        y = self.cross_win_attend_1.attend(query, key, val, qmap_n, kwin, qmap_1, b, x if self.skip else None, (b, H, W))
+        y = self._mlp("mlp1", self.prenorm_1, self.mlp_1, y)
+        # local-to-global: the n query replicas of the reference are identical -> one copy
+        z = self.cross_win_attend_2.attend(y, key, val, qmap_1, kgrid, qmap_1, b, y if self.skip else None, (b, H, W))
+        z = self._mlp("mlp2", self.prenorm_2, self.mlp_2, z)
+        return rt.layernorm(self, "postnorm", self.postnorm, z)
+
+    def forward(self, index, x, bev, feature, I_inv, E_inv):
+        """x (b,d,H,W); feature (b,n,C,h,w); I_inv (b,n,3,3); E_inv (b,n,4,4) -> (b,d,H,W)"""
+        self._require_inference(x, feature, I_inv, E_inv)
+        b, n = feature.shape[:2]
+        f = rt.to_nhwc(feature.reshape(b * n, *feature.shape[2:]))
+        Ii = I_inv.reshape(b * n, 3, 3).to(torch.float32).contiguous()
+        Ei = E_inv.reshape(b * n, 4, 4).to(torch.float32).contiguous()
+        y = self.forward_nhwc(index, rt.to_nhwc(x), bev, f, Ii, Ei)
+        return rt.like_input(rt.nchw_view(y), x)
+
+
+class _Downsample(HipModule):
+    """The inner nn.Sequential of FAXModule.downsample_layers[i] (fax_modules.py:477-489):
+    conv3x3 -> PixelUnshuffle(2) -> conv3x3 -> BN -> ReLU -> conv1x1 -> BN, indices 0,1,2,3,4,5,6."""
+
+    def __init__(self, dim_in, dim_mid, dim_out):
+        super().__init__()
+        mods = [nn.Conv2d(dim_in, dim_mid, kernel_size=3, stride=1, padding=1, bias=False), nn.PixelUnshuffle(2),
+                nn.Conv2d(dim_out, dim_out, 3, padding=1, bias=False), nn.BatchNorm2d(dim_out), nn.ReLU(inplace=True),
+                nn.Conv2d(dim_out, dim_out, 1, padding=0, bias=False), nn.BatchNorm2d(dim_out)]
+        for i, m in enumerate(mods):
+            self.add_module(str(i), m)
+
+    def __getitem__(self, i):
+        return getattr(self, str(i))
+
+    def forward_nhwc(self, x):
+        y = ops.conv2d(x, rt.conv_plan(self, "c0", self[0], store_mode=1))          # conv + PixelUnshuffle(2)
+        y = ops.conv2d(y, rt.conv_plan(self, "c2", self[2], self[3], act=1))
+        return ops.conv2d(y, rt.conv_plan(self, "c5", self[5], self[6]))
+
+
+class FAXModule(HipModule):
+    """fax_modules.py:444-521."""
+
+    # OPV2V flavour; the nuScenes encoder overrides these (encoder_pyramid_axial.py:515,532,539)
+    _downsample_div = 4
+
+    def __init__(self, config):
+        super().__init__()
+        middle = config["middle"]
+        dim = config["dim"]
+        self.backbone_output_shape = config["backbone_output_shape"]
+        assert len(middle) == len(self.backbone_output_shape)
+        cross_view = config["cross_view"]
+        cross_view_swap = config["cross_view_swap"]
+        cross_views, layers, downsample_layers = [], [], []
+        for i, (feat_shape, num_layers) in enumerate(zip(self.backbone_output_shape, middle)):
+            _, _, _, feat_dim, feat_height, feat_width = tuple(feat_shape)
+            cross_views.append(CrossViewSwapAttention(feat_height, feat_width, feat_dim, dim[i], i, **cross_view,
+                                                      **cross_view_swap))
+            layers.append(nn.Sequential(*[ResNetBottleNeck(dim[i]) for _ in range(num_layers)]))
+            if i < len(middle) - 1:
+                downsample_layers.append(nn.Sequential(_Downsample(dim[i], dim[i] // self._downsample_div, dim[i + 1])))
+        self.bev_embedding = BEVEmbedding(dim[0], **config["bev_embedding"])
+        self.cross_views = nn.ModuleList(cross_views)
+        self.layers = nn.ModuleList(layers)
+        self.downsample_layers = nn.ModuleList(downsample_layers)
+        self.self_attn = Attention(dim[-1], **config["self_attn"])
+
+    def forward_features(self, features, I_inv, E_inv, batch):
+        """features: list of (batch*n, h, w, C) channels-last; returns (batch, H, W, d) channels-last."""
+        dt = rt.get_compute_dtype()
+        prior = self._plan("prior", [self.bev_embedding.learned_features],
+                           lambda d_, dev: self.bev_embedding.learned_features.detach().permute(1, 2, 0).to(dt).contiguous())
+        x = prior[None].expand(batch, *prior.shape).contiguous()
+        for i, (cross_view, feature, layer) in enumerate(zip(self.cross_views, features, self.layers)):
+            x = cross_view.forward_nhwc(i, x, self.bev_embedding, feature, I_inv, E_inv)
+            for blk in layer:
+                x = blk.forward_nhwc(x)
+            if i < len(features) - 1:
+                x = self.downsample_layers[i][0].forward_nhwc(x)
+        if self.self_attn is not None:
+            x = self.self_attn.forward_nhwc(x)
+        return x
+
+    def forward(self, batch):
+        b, l, n = batch["inputs"].shape[:3]
+        intrinsic, extrinsic = batch["intrinsic"], batch["extrinsic"]
+        self._require_inference(intrinsic, extrinsic, *batch["features"])
+        # tiny (b*l*n) 3x3 inversions stay in torch (host-side geometry, fax_modules.py:500-503)
+        I_inv = intrinsic.reshape(b * l * n, 3, 3).to(torch.float32).inverse().contiguous()
+        E_inv = self._extrinsic(extrinsic.reshape(b * l * n, 4, 4).to(torch.float32)).contiguous()
+        feats = [rt.to_nhwc(f.reshape(b * l * n, *f.shape[3:])) for f in batch["features"]]
+        x = self.forward_features(feats, I_inv, E_inv, b * l)
+        x = rt.nchw_view(x)
+        return x.reshape(b, l, *x.shape[1:])
+
+    @staticmethod
+    def _extrinsic(e):
+        return e  # OPV2V passes camera->ego un-inverted (fax_modules.py:502-503)

@@ -1,0 +1,115 @@
+"""ResnetEncoder — mirror of opv2v/opencood/models/backbones/resnet_ms.py.
+
+torchvision is not a dependency: the ResNet-18/34 parameter container below is written from torchvision's
+public definition with torchvision's attribute names (conv1, bn1, layer1..4.{j}.{conv1,bn1,conv2,bn2,
+downsample.{0,1}}, fc) so reference checkpoints load key-for-key.  `pretrained` is
+accepted and ignored (no network; the reference would download ImageNet weights, resnet_ms.py:38).
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..lib import CobevtHipError
+from . import runtime as rt
+from .runtime import HipModule
+
+_BLOCKS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}
+
+
+class BasicBlock(HipModule):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward_nhwc(self, x):
+        identity = x
+        if self.downsample is not None:
+            identity = ops.conv2d(x, rt.conv_plan(self, "ds", self.downsample[0], self.downsample[1]))
+        y = ops.conv2d(x, rt.conv_plan(self, "c1", self.conv1, self.bn1, act=1))
+        return ops.conv2d(y, rt.conv_plan(self, "c2", self.conv2, self.bn2, act=1), residual=identity)
+
+
+class ResNet(HipModule):
+    """Parameter container with torchvision.models.ResNet's layout (BasicBlock variants)."""
+
+    def __init__(self, layers, num_classes=1000):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._make_layer(64, layers[0])
+        self.layer2 = self._make_layer(128, layers[1], 2)
+        self.layer3 = self._make_layer(256, layers[2], 2)
+        self.layer4 = self._make_layer(512, layers[3], 2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512, num_classes)   # unused by the encoder, kept for checkpoint compatibility
+
+    def _make_layer(self, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+        layers = [BasicBlock(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes
+        layers += [BasicBlock(planes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def stem_nhwc(self, images):
+        """images: (N, H, W, 3) fp32 channels-last -> (N, H/4, W/4, 64)"""
+        x = ops.conv2d(images, rt.conv_plan(self, "stem", self.conv1, self.bn1, act=1, smallc=True))
+        return ops.maxpool3x3s2(x)
+
+
+class ResnetEncoder(HipModule):
+    """resnet_ms.py:9-89."""
+
+    def __init__(self, params):
+        super().__init__()
+        self.num_layers = params["num_layers"]
+        self.pretrained = params["pretrained"]
+        image_height = params["image_height"]
+        image_width = params["image_width"]
+        self.idx_pick = params["id_pick"]
+        if self.num_layers not in (18, 34, 50, 101, 152):
+            raise ValueError("{} is not a valid number of resnet layers".format(self.num_layers))
+        if self.num_layers not in _BLOCKS:
+            raise CobevtHipError("resnet%d (Bottleneck variants) is not lowered to HIP; the FAX configs use 18/34"
+                                 % self.num_layers)
+        self.encoder = ResNet(_BLOCKS[self.num_layers])
+        # shapes the reference obtains from a dummy forward (resnet_ms.py:41-44), computed analytically here
+        def half(v, k, p):
+            return (v + 2 * p - k) // 2 + 1
+        h, w = half(half(image_height, 7, 3), 3, 1), half(half(image_width, 7, 3), 3, 1)
+        shapes = []
+        for i, c in enumerate((64, 128, 256, 512)):
+            if i > 0:
+                h, w = half(h, 3, 1), half(w, 3, 1)
+            shapes.append(torch.Size((1, 1, 1, c, h, w)))
+        self.output_shapes = [shapes[i] for i in self.idx_pick] if isinstance(self.idx_pick, list) else [shapes[self.idx_pick]]
+
+    def forward(self, input_images):
+        """(B, L, M, H, W, 3) channels-last fp32 -> list of (B, L, M, C, h, w) (channels-last views)."""
+        self._require_inference(input_images)
+        b, l, m, h, w, c = input_images.shape
+        x = input_images.reshape(b * l * m, h, w, c)
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.to(torch.float32).contiguous()
+        x = self.encoder.stem_nhwc(x)
+        results = []
+        for layer in (self.encoder.layer1, self.encoder.layer2, self.encoder.layer3, self.encoder.layer4):
+            for blk in layer:
+                x = blk.forward_nhwc(x)
+            v = rt.nchw_view(x)
+            results.append(v.reshape(b, l, m, *v.shape[1:]))
+        if isinstance(self.idx_pick, list):
+            return [results[i] for i in self.idx_pick]
+        return results[self.idx_pick]

@@ -1,0 +1,163 @@
+"""MI355X-native FuseBEVT (swap fusion) behind the reference's module API.
+
+Mirror of opv2v/opencood/models/fusion_modules/swap_fusion_modules.py (class names, constructor arguments,
+state_dict keys incl. the persistent `relative_position_index` buffer, forward contracts).  Agents x window
+tokens are gathered straight from the (b, l, h, w, d) channels-last tensor by the attention kernel for both the
+window and the dilated-grid pass; the 3-D relative position bias is computed from token coordinates in-kernel
+(the index buffer is kept only for state_dict compatibility).
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..lib import CobevtHipError
+from . import runtime as rt
+from .base_transformer import FeedForward, PreNormResidual
+from .runtime import HipModule
+
+
+class Attention(HipModule):
+    """swap_fusion_modules.py:13-128."""
+
+    def __init__(self, dim, dim_head=32, dropout=0., agent_size=6, window_size=7):
+        super().__init__()
+        assert (dim % dim_head) == 0, "dimension should be divisible by dimension per head"
+        if dim_head != 32:
+            raise CobevtHipError("the HIP attention kernel is built for dim_head = 32")
+        self.heads = dim // dim_head
+        self.scale = dim_head ** -0.5
+        self.window_size = [agent_size, window_size, window_size]
+        self.to_qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.attend = nn.Sequential(nn.Softmax(dim=-1))
+        self.to_out = nn.Sequential(nn.Linear(dim, dim, bias=False), nn.Dropout(dropout))
+        L, w = agent_size, window_size
+        self.relative_position_bias_table = nn.Embedding((2 * L - 1) * (2 * w - 1) * (2 * w - 1), self.heads)
+        # persistent buffer of the reference (:63-85): token t = (l*w + a)*w + b
+        cl, ca, cb = torch.meshgrid(torch.arange(L), torch.arange(w), torch.arange(w), indexing="ij")
+        cl, ca, cb = cl.reshape(-1), ca.reshape(-1), cb.reshape(-1)
+        index = ((cl[:, None] - cl[None, :] + L - 1) * (2 * w - 1) * (2 * w - 1)
+                 + (ca[:, None] - ca[None, :] + w - 1) * (2 * w - 1) + (cb[:, None] - cb[None, :] + w - 1))
+        self.register_buffer("relative_position_index", index)
+
+    def forward_fused(self, xn, residual=None, mask=None, mode=2):
+        """xn (already LayerNorm'ed, compute dtype): mode 2 -> (b l X Y w1 w2 d) partitioned, mask (b X Y w1 w2 1 l);
+        mode 0 (window) / 1 (grid) -> (b l H W d), mask (b H W 1 l).  Returns to_out(attn) (+ residual)."""
+        L, w = self.window_size[0], self.window_size[1]
+        if mode == 2:
+            b, l, X, Y, w1, w2, d = xn.shape
+            m = (2, l, X * w1, Y * w2, w1, w2, X, Y)
+        else:
+            b, l, H, W, d = xn.shape
+            w1 = w2 = w
+            m = ops.tokmap(mode, l, H, W, w, w)
+        if l != L or w1 != w or w2 != w:
+            raise CobevtHipError("swap attention built for %d agents x %dx%d windows, got %d x %dx%d" % (L, w, w, l, w1, w2))
+        qkv = ops.linear(xn, rt.linear_plan(self, "qkv", self.to_qkv))
+        out = torch.empty(xn.shape, device=xn.device, dtype=xn.dtype)
+        table = rt.f32_param(self, "table", self.relative_position_bias_table.weight)
+        mk = None
+        if mask is not None:
+            mk = mask.to(torch.float32)
+            mk = mk if mk.is_contiguous() else mk.contiguous()
+        ops.window_attention(qkv, qkv, qkv, out, m, m, m, b, self.heads, self.scale, 3 * d, 3 * d, 3 * d, d, koff=d,
+                             voff=2 * d, bias_table=table, bias_L=L, mask=mk)
+        return ops.linear(out, rt.linear_plan(self, "out", self.to_out[0]), residual=residual)
+
+    def forward(self, x, mask=None):
+        """x: (b, l, X, Y, w1, w2, c); mask: (b, X, Y, w1, w2, 1, l) or None"""
+        self._require_inference(x, mask)
+        return rt.like_input(self.forward_fused(rt.as_compute(x), mask=mask, mode=2), x)
+
+
+def _to_blhwc(x):
+    """(b, l, c, h, w)-shaped -> contiguous (b, l, h, w, c) compute dtype"""
+    b, l, c, h, w = x.shape
+    return rt.to_nhwc(x.reshape(b * l, c, h, w)).reshape(b, l, h, w, c)
+
+
+def _from_blhwc(x):
+    return x.permute(0, 1, 4, 2, 3)
+
+
+class SwapFusionBlockMask(HipModule):
+    """swap_fusion_modules.py:131-192."""
+
+    def __init__(self, input_dim, mlp_dim, dim_head, window_size, agent_size, drop_out):
+        super().__init__()
+        self.window_size = window_size
+        self.window_attention = PreNormResidual(input_dim, Attention(input_dim, dim_head, drop_out, agent_size, window_size))
+        self.window_ffd = PreNormResidual(input_dim, FeedForward(input_dim, mlp_dim, drop_out))
+        self.grid_attention = PreNormResidual(input_dim, Attention(input_dim, dim_head, drop_out, agent_size, window_size))
+        self.grid_ffd = PreNormResidual(input_dim, FeedForward(input_dim, mlp_dim, drop_out))
+
+    def forward_blhwc(self, x, mask):
+        x = self.window_attention.forward_fused(x, mask=mask, mode=0)
+        x = self.window_ffd.forward_fused(x)
+        x = self.grid_attention.forward_fused(x, mask=mask, mode=1)
+        return self.grid_ffd.forward_fused(x)
+
+    def forward(self, x, mask):
+        """x: (b, l, c, h, w); mask: (b, h, w, 1, l)"""
+        self._require_inference(x, mask)
+        return rt.like_input(_from_blhwc(self.forward_blhwc(_to_blhwc(x), mask)), x)
+
+
+class SwapFusionBlock(HipModule):
+    """swap_fusion_modules.py:195-230 — nn.Sequential `block` with parametrised entries at 1, 2, 5, 6."""
+
+    def __init__(self, input_dim, mlp_dim, dim_head, window_size, agent_size, drop_out):
+        super().__init__()
+        self.block = nn.Sequential(
+            nn.Identity(),
+            PreNormResidual(input_dim, Attention(input_dim, dim_head, drop_out, agent_size, window_size)),
+            PreNormResidual(input_dim, FeedForward(input_dim, mlp_dim, drop_out)),
+            nn.Identity(),
+            nn.Identity(),
+            PreNormResidual(input_dim, Attention(input_dim, dim_head, drop_out, agent_size, window_size)),
+            PreNormResidual(input_dim, FeedForward(input_dim, mlp_dim, drop_out)),
+            nn.Identity())
+
+    def forward_blhwc(self, x, mask=None):
+        x = self.block[1].forward_fused(x, mode=0)
+        x = self.block[2].forward_fused(x)
+        x = self.block[5].forward_fused(x, mode=1)
+        return self.block[6].forward_fused(x)
+
+    def forward(self, x, mask=None):
+        self._require_inference(x)
+        return rt.like_input(_from_blhwc(self.forward_blhwc(_to_blhwc(x))), x)
+
+
+class SwapFusionEncoder(HipModule):
+    """swap_fusion_modules.py:233-286."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.layers = nn.ModuleList([])
+        self.depth = args["depth"]
+        input_dim, mlp_dim = args["input_dim"], args["mlp_dim"]
+        agent_size, window_size = args["agent_size"], args["window_size"]
+        drop_out, dim_head = args["drop_out"], args["dim_head"]
+        self.mask = bool(args["mask"]) if "mask" in args else False
+        for _ in range(self.depth):
+            cls = SwapFusionBlockMask if self.mask else SwapFusionBlock
+            self.layers.append(cls(input_dim, mlp_dim, dim_head, window_size, agent_size, drop_out))
+        # Reduce('b m d h w -> b d h w', 'mean'), Rearrange, LayerNorm, Linear, Rearrange
+        self.mlp_head = nn.Sequential(nn.Identity(), nn.Identity(), nn.LayerNorm(input_dim),
+                                      nn.Linear(input_dim, input_dim), nn.Identity())
+
+    def forward_blhwc(self, x, mask=None):
+        """x (b, l, h, w, d) channels-last compute dtype -> (b, h, w, d)"""
+        for stage in self.layers:
+            x = stage.forward_blhwc(x, mask)
+        b, l, h, w, d = x.shape
+        ln = self.mlp_head[2]
+        y = ops.mean_layernorm(x.reshape(b, l, h * w, d), rt.f32_param(self, "head.ln.w", ln.weight),
+                               rt.f32_param(self, "head.ln.b", ln.bias), ln.eps)
+        y = ops.linear(y, rt.linear_plan(self, "head.fc", self.mlp_head[3]))
+        return y.reshape(b, h, w, d)
+
+    def forward(self, x, mask=None):
+        """x: (b, m, d, h, w); mask: (b, h, w, 1, m) -> (b, d, h, w)"""
+        self._require_inference(x, mask)
+        return rt.like_input(rt.nchw_view(self.forward_blhwc(_to_blhwc(x), mask)), x)

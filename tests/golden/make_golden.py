@@ -65,6 +65,19 @@ def save(name, **arrays):
     print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024.0))
 
 
+def gv0():
+    """state_dict key/shape schema of the reference models (drop-in contract)."""
+    import copy
+    out = {}
+    for name, cfg, cls in (("corpbevt_full", synth.corpbevt_config(), R_corpbevt.CorpBEVT),
+                           ("corpbevt_small", synth.corpbevt_small_config(), R_corpbevt.CorpBEVT)):
+        m = cls(copy.deepcopy(cfg))
+        sd = m.state_dict()
+        out[name + "_keys"] = np.array(list(sd.keys()))
+        out[name + "_shapes"] = np.array([",".join(str(int(d)) for d in v.shape) for v in sd.values()])
+    save("gv0_state_dict_schema", **out)
+
+
 def gv1():
     out = {}
     for (H, W, w1, w2) in cases.INDEX_MAP_SHAPES:
@@ -262,7 +275,7 @@ def gv10():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gv1", "gv2", "gv3", "gv4", "gv5", "gv6", "gv7", "gv8", "gv9", "gv10"]
+    which = sys.argv[1:] or ["gv0", "gv1", "gv2", "gv3", "gv4", "gv5", "gv6", "gv7", "gv8", "gv9", "gv10"]
     for name in which:
         print("== " + name)
         globals()[name]()
