@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""bench.py — BEV frames/s of the MI355X-native CoBEVT hot path on synthetic OPV2V-shaped inputs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--agents 5] [--no-graph]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full CorpBEVT forward per GPU: `agents` x 4 cameras x 512x512 fp32 images (resident in HBM) ->
+ResNet-34 -> FAX pyramid -> [all-gather of agent features] -> STTF -> swap fusion -> decoder -> 256x256 logits.
+N = 1 is the configuration BASELINE.json's metric is quoted on (OPV2V-camera CoBEVT, 5 agents).  For N > 1, N
+frames are in flight per step with the N*agents agent tasks dealt round-robin over the ranks and exchanged by ONE
+RCCL all-gather before fusion (cobevt_amd/dist.py) — per-GPU work is fixed ("weak" scaling) and
+value = N frames / step time.  Rank 0 prints ONE JSON line.
+
+Extra legs at N = 1 (rank 0): `roofline` — algorithmic FLOPs / HIP-event time of the dominant kernel family
+(implicit-GEMM) measured live over one frame, plus the FAX attention kernel; `cpu_baseline` — the oracle
+(oracle/, a CPU restatement of the reference, kind "port") timed on the host cores on ONE frame of the same
+workload, which also yields the parity numbers (rel. error of the logits, arg-max agreement, mIoU vs oracle).
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from cobevt_amd import dist as cdist  # noqa: E402
+from cobevt_amd import host, ops, synth  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+# algorithmic FLOPs per frame (SURVEY.md §8a ledger, de-duplicated query replicas): per agent ResNet-34 x4 cams
+# 153.1 GF + FAX 34.65 GF; per frame fusion 13.12 GF + decoder/head 5.21 GF
+GF_PER_AGENT, GF_PER_FRAME = 153.1 + 34.65, 13.12 + 5.21
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--agents", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+class Runner(object):
+    """Holds static inputs and (optionally) the captured HIP graphs of one step."""
+
+    def __init__(self, model, task_batch, pose, record_len, rank, world, agents, use_graph):
+        self.model, self.rank, self.world, self.agents = model, rank, world, agents
+        self.task_batch, self.pose, self.record_len = task_batch, pose, record_len
+        self.use_graph = use_graph
+        self.graphs = None
+        self.out = None
+
+    def _encode(self):
+        return self.model.encode_agents(dict(self.task_batch))
+
+    def _fuse(self, feats):
+        return self.model.fuse_and_decode(feats, self.pose, self.record_len)
+
+    def eager_step(self):
+        feats = self._encode()
+        mine = cdist.exchange_features(feats, self.rank, self.world, self.agents)
+        self.out = self._fuse(mine)
+        return self.out
+
+    def capture(self):
+        """Capture encode and fuse as HIP graphs (the collective stays eager between them)."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self.eager_step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            feats = self._encode()
+        self.feats = feats
+        if self.world == 1:
+            self.fuse_in = feats
+        else:
+            self.fuse_in = torch.empty_like(feats)
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            self.out = self._fuse(self.fuse_in)
+        self.graphs = (g1, g2)
+
+    def step(self):
+        if self.graphs is None:
+            return self.eager_step()
+        self.graphs[0].replay()
+        if self.world > 1:
+            self.fuse_in.copy_(cdist.exchange_features(self.feats, self.rank, self.world, self.agents))
+        self.graphs[1].replay()
+        return self.out
+
+
+def roofline_leg(runner, dtype_name):
+    best = None
+    for _ in range(3):
+        with ops.LaunchProfile() as prof:
+            runner.eager_step()
+        summ = prof.summary()
+        if best is None or summ["igemm"]["ms"] < best["igemm"]["ms"]:
+            best = summ
+    peak = PEAK_TFLOPS[dtype_name]
+
+    def entry(fam):
+        d = best[fam]
+        tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        return {"kernel": fam, "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(tf / peak, 4), "traffic": None, "launches_per_frame": d["calls"],
+                "avg_launch_us": round(d["ms"] * 1e3 / d["calls"], 2), "total_ms_per_frame": round(d["ms"], 3),
+                "algorithmic_gflop_per_frame": round(d["flops"] / 1e9, 1),
+                "algorithmic_gbyte_s": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1)}
+    return entry("igemm"), entry("attention")
+
+
+def cpu_baseline_leg(model, cfg, batch_cpu, gpu_out):
+    """Time the oracle (CPU restatement, parity-pinned to the reference's golden vectors) on one frame and use its
+    output as the parity reference for the GPU logits."""
+    import numpy as np
+    import oracle.corpbevt as o_model
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    t0 = time.time()
+    with torch.no_grad():
+        ref = o_model.corpbevt_forward(sd, cfg, batch_cpu)["dynamic_seg"]
+    dt = time.time() - t0
+    got = gpu_out["dynamic_seg"].detach().float().cpu()
+    rel = ((got - ref).abs().max() / ref.abs().max()).item()
+    pa, pr = got.argmax(2).numpy(), ref.argmax(2).numpy()
+    ious = o_model.mean_iu(pa[0, 0], pr[0, 0])
+    base = {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "1 frame (%d agents x 4 cams x 512x512 -> 256x256 BEV) of the bench workload, fp32, oracle/ "
+                      "(plain PyTorch CPU restatement of the reference forward), %.1f s" % (batch_cpu["inputs"].shape[0], dt)}
+    parity = {"logits_rel_err_vs_oracle": float("%.3e" % rel), "argmax_agreement": round(float((pa == pr).mean()), 5),
+              "miou_vs_oracle_argmax": round(float(np.mean(ious)), 5)}
+    return base, parity
+
+
+def main():
+    args = parse()
+    rank, world, local_rank = cdist.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    torch.set_grad_enabled(False)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    host.set_compute_dtype(dtype)
+
+    A = args.agents
+    cfg = synth.corpbevt_config(max_cav=max(5, A))
+    model = synth.fill_module_(host.CorpBEVT(copy.deepcopy(cfg)), 0).eval().to(dev)
+
+    # this rank's A agent tasks (images differ per rank), the pose / record_len of frame `rank`
+    full = synth.opv2v_batch(agents=A, max_cav=cfg["max_cav"], seed=rank)
+    task_batch = {k: full[k].to(dev) for k in ("inputs", "intrinsic", "extrinsic")}
+    pose = full["transformation_matrix"].to(dev)
+    record_len = full["record_len"].to(device=dev, dtype=torch.int32)
+
+    runner = Runner(model, task_batch, pose, record_len, rank, world, A, not args.no_graph)
+    graph_ok = False
+    runner.eager_step()                       # builds every weight plan
+    torch.cuda.synchronize()
+    if not args.no_graph:
+        try:
+            runner.capture()
+            graph_ok = True
+        except Exception as e:  # noqa: BLE001 — fall back to eager launches, say so in the JSON
+            runner.graphs = None
+            if rank == 0:
+                print("HIP graph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
+            torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        runner.step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+    ms_per_step = elapsed / args.steps * 1e3
+    fps = world / (ms_per_step * 1e-3)
+
+    result = {
+        "metric": "bev_frames_per_sec", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "frames_per_sec_per_gpu": round(fps / world, 3),
+        "config": {"workload": "OPV2V-camera CoBEVT (corpbevt.yaml): %d agents x 4 cams x 512x512 -> 256x256 BEV, "
+                               "ResNet-34 + FAX + swap fusion, batch 1 frame per GPU" % A,
+                   "agents": A, "frames_in_flight": world, "parallelism": "agent-shard x%d + 1 all-gather" % world if world > 1 else "single GPU",
+                   "hip_graph": graph_ok, "weights": "procedural (cobevt_amd.synth)"},
+        "achieved_tflops_end_to_end": round((GF_PER_AGENT * A + GF_PER_FRAME) * world / (ms_per_step * 1e-3) / 1e3, 2),
+    }
+    if rank == 0 and world == 1:
+        if not args.no_roofline:
+            ig, at = roofline_leg(runner, args.dtype)
+            result["roofline"] = ig
+            result["roofline_fax_attention"] = at
+        if not args.no_cpu_baseline:
+            out = runner.eager_step()
+            torch.cuda.synchronize()
+            batch_cpu = {k: v for k, v in full.items()}
+            base, parity = cpu_baseline_leg(model, cfg, batch_cpu, out)
+            result["cpu_baseline"] = base
+            result["parity"] = parity
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

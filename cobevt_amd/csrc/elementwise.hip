@@ -315,6 +315,46 @@ __global__ __launch_bounds__(256) void sttf_warp_kernel(const T* x, const float*
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Batched inverse of tiny (3x3 / 4x4) camera matrices: Gauss-Jordan with partial pivoting in fp64, one matrix
+// per thread.  reference: fax_modules.py:500-501 (intrinsic.inverse()), encoder_pyramid_axial.py:538-539.
+template <int D>
+__global__ __launch_bounds__(64) void invert_small_kernel(const float* in, float* out, int n) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    double a[D][2 * D];
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int c = 0; c < D; ++c) { a[r][c] = (double)in[(size_t)i * D * D + r * D + c]; a[r][D + c] = r == c ? 1.0 : 0.0; }
+#pragma unroll
+    for (int col = 0; col < D; ++col) {
+        int piv = col;
+        double best = fabs(a[col][col]);
+#pragma unroll
+        for (int r = 0; r < D; ++r) if (r > col && fabs(a[r][col]) > best) { best = fabs(a[r][col]); piv = r; }
+#pragma unroll
+        for (int r = 0; r < D; ++r) if (r == piv && piv != col) {
+#pragma unroll
+            for (int c = 0; c < 2 * D; ++c) { const double t = a[col][c]; a[col][c] = a[r][c]; a[r][c] = t; }
+        }
+        const double inv = 1.0 / a[col][col];
+#pragma unroll
+        for (int c = 0; c < 2 * D; ++c) a[col][c] *= inv;
+#pragma unroll
+        for (int r = 0; r < D; ++r) if (r != col) {
+            const double f = a[r][col];
+#pragma unroll
+            for (int c = 0; c < 2 * D; ++c) a[r][c] -= f * a[col][c];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int c = 0; c < D; ++c) out[(size_t)i * D * D + r * D + c] = (float)a[r][D + c];
+}
+
 template <typename K, typename... Args>
 static int launch1d(K kern, long work_items, hipStream_t stream, Args... args) {
     const long blocks = (work_items + 255) / 256;
@@ -422,6 +462,15 @@ extern "C" int cobevt_sttf_warp(const void* x, const float* tmat, const float* c
     if (dtype == 0) hipLaunchKernelGGL(sttf_warp_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, tmat, cav_mask, (bf16_t*)out, com_mask, B, L, H, W, C, discrete_ratio, downsample_rate);
     else if (dtype == 1) hipLaunchKernelGGL(sttf_warp_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, tmat, cav_mask, (float*)out, com_mask, B, L, H, W, C, discrete_ratio, downsample_rate);
     else return COBEVT_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+extern "C" int cobevt_invert_small(const float* in, float* out, int n, int dim, hipStream_t stream) {
+    if (!in || !out) return COBEVT_ERR_ARG;
+    if (n < 1 || (dim != 3 && dim != 4)) return COBEVT_ERR_SHAPE;
+    const dim3 grid((n + 63) / 64), block(64);
+    if (dim == 3) hipLaunchKernelGGL(invert_small_kernel<3>, grid, block, 0, stream, in, out, n);
+    else hipLaunchKernelGGL(invert_small_kernel<4>, grid, block, 0, stream, in, out, n);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 

@@ -73,12 +73,14 @@ class CorpBEVT(HipModule):
         b = y.shape[0]
         return self.seg_head(rt.nchw_view(y), b, 1)
 
-    def forward(self, batch_dict):
-        x = batch_dict["inputs"]
-        transformation_matrix = batch_dict["transformation_matrix"]
-        record_len = batch_dict["record_len"]
-        x = self.encoder(x)
+    def encode_agents(self, batch_dict):
+        """Per-agent SinBEVT: images -> (N, H, W, C) channels-last BEV features (the tensor V2V sharing transmits).
+        Agents are a pure batch dimension here (corpbevt.py:112-117), which is what the multi-GPU path shards."""
+        x = self.encoder(batch_dict["inputs"])
         batch_dict.update({"features": x})
         x = self.fax(batch_dict)                    # (N, 1, C, H, W) channels-last view
-        x = x.squeeze(1)
-        return self.fuse_and_decode(rt.to_nhwc(x), transformation_matrix, record_len)
+        return rt.to_nhwc(x.squeeze(1))
+
+    def forward(self, batch_dict):
+        feats = self.encode_agents(batch_dict)
+        return self.fuse_and_decode(feats, batch_dict["transformation_matrix"], batch_dict["record_len"])

@@ -351,8 +351,7 @@ class FAXModule(HipModule):
         b, l, n = batch["inputs"].shape[:3]
         intrinsic, extrinsic = batch["intrinsic"], batch["extrinsic"]
         self._require_inference(intrinsic, extrinsic, *batch["features"])
-        # tiny (b*l*n) 3x3 inversions stay in torch (host-side geometry, fax_modules.py:500-503)
-        I_inv = intrinsic.reshape(b * l * n, 3, 3).to(torch.float32).inverse().contiguous()
+        I_inv = ops.invert_small(intrinsic.reshape(b * l * n, 3, 3))            # fax_modules.py:500-501
         E_inv = self._extrinsic(extrinsic.reshape(b * l * n, 4, 4).to(torch.float32)).contiguous()
         feats = [rt.to_nhwc(f.reshape(b * l * n, *f.shape[3:])) for f in batch["features"]]
         x = self.forward_features(feats, I_inv, E_inv, b * l)

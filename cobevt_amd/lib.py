@@ -34,6 +34,7 @@ SIGNATURES = {
     "cobevt_from_nhwc": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, _c_long_p, _vp]),
     "cobevt_regroup": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long, _vp]),
+    "cobevt_invert_small": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "cobevt_sttf_warp": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp]),
 }

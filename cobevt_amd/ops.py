@@ -43,6 +43,74 @@ def _ints(vals):
 
 
 # ----------------------------------------------------------------------------------------------
+# optional per-launch timing (bench.py roofline leg): HIP events on the launch stream around each C-ABI call
+# ----------------------------------------------------------------------------------------------
+_PROFILE = None
+
+
+class LaunchProfile(object):
+    """with LaunchProfile() as prof: model(batch) -> prof.summary(): {family: {calls, ms, flops, bytes}}"""
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        global _PROFILE
+        _PROFILE = self
+        return self
+
+    def __exit__(self, *exc):
+        global _PROFILE
+        _PROFILE = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for fam, flops, nbytes, e0, e1 in self.records:
+            d = out.setdefault(fam, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+class _Timed(object):
+    __slots__ = ("fam", "flops", "nbytes", "e0")
+
+    def __init__(self, fam, flops, nbytes):
+        self.fam, self.flops, self.nbytes = fam, flops, nbytes
+
+    def __enter__(self):
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+
+    def __exit__(self, *exc):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        _PROFILE.records.append((self.fam, self.flops, self.nbytes, self.e0, e1))
+
+
+class _NoTime(object):
+    def __enter__(self):
+        pass
+
+    def __exit__(self, *exc):
+        pass
+
+
+_NOTIME = _NoTime()
+
+
+def _timed(fam, flops_fn):
+    """flops_fn() -> (algorithmic flops, algorithmic bytes); only evaluated while profiling."""
+    if _PROFILE is None:
+        return _NOTIME
+    f, b = flops_fn()
+    return _Timed(fam, f, b)
+
+
+# ----------------------------------------------------------------------------------------------
 # weight preparation (host, once per module/dtype)
 # ----------------------------------------------------------------------------------------------
 def bn_affine(bn):
@@ -139,8 +207,17 @@ def conv2d(x, plan, residual=None, out=None):
             raise CobevtHipError("conv2d: residual must be (N,Ho,Wo,Cout) contiguous in the compute dtype")
     dims = _ints([plan.code, n, h, w, cin, ho, wo, plan.cout, plan.kh, plan.kw, plan.stride, plan.pad, plan.K,
                   plan.kpad, plan.upsample, plan.pre_relu, plan.act, sm, out_h, out_w, plan.smallc])
-    rc = _L.load().cobevt_conv2d_nhwc(_p(x), _p(plan.wgt), _p(plan.bias), _p(residual), _p(plan.pre_scale),
-                                      _p(plan.pre_shift), _p(plan.klut), _p(out), dims, _stream())
+    def cost():
+        m = n * ho * wo
+        esz = 2 if plan.code == BF16 else 4
+        nbytes = x.numel() * x.element_size() + plan.cout * plan.K * esz + out.numel() * out.element_size()
+        if residual is not None:
+            nbytes += residual.numel() * esz
+        return 2.0 * m * plan.cout * plan.K, float(nbytes)
+
+    with _timed("igemm", cost):
+        rc = _L.load().cobevt_conv2d_nhwc(_p(x), _p(plan.wgt), _p(plan.bias), _p(residual), _p(plan.pre_scale),
+                                          _p(plan.pre_shift), _p(plan.klut), _p(out), dims, _stream())
     _L.check(rc, "cobevt_conv2d_nhwc")
     return out
 
@@ -201,8 +278,17 @@ def window_attention(q, k, v, out, qmap, kmap, omap, batch, heads, scale, ldq, l
     dims = _ints([code, batch, L, heads, ldq, ldk, ldv, ldo, qoff, koff, voff, ooff,
                   0 if bias_table is None else 1, 0 if bias_table is None else bias_table.shape[0], bias_L,
                   int(bool(mean_q))] + list(qmap) + list(kmap) + list(omap))
-    rc = _L.load().cobevt_window_attention(_p(q), _p(k), _p(v), _p(out), _p(bias_table), _p(mask), dims,
-                                           ctypes.c_float(scale), _stream())
+    def cost():
+        nq = qmap[1] * qmap[4] * qmap[5]
+        nk = kmap[1] * kmap[4] * kmap[5]
+        esz = q.element_size()
+        d = heads * 32
+        nbytes = batch * L * (nq + 2 * nk + nq // (qmap[1] if mean_q else 1)) * d * esz
+        return 4.0 * batch * L * heads * nq * nk * 32, float(nbytes)
+
+    with _timed("attention", cost):
+        rc = _L.load().cobevt_window_attention(_p(q), _p(k), _p(v), _p(out), _p(bias_table), _p(mask), dims,
+                                               ctypes.c_float(scale), _stream())
     _L.check(rc, "cobevt_window_attention")
     return out
 
@@ -290,3 +376,14 @@ def sttf_warp(x, tmat, cav_mask, discrete_ratio, downsample_rate, want_mask=True
                                     ctypes.c_float(discrete_ratio), ctypes.c_float(downsample_rate), _stream())
     _L.check(rc, "cobevt_sttf_warp")
     return out, com
+
+
+def invert_small(m):
+    """Batched inverse of (..., 3, 3) or (..., 4, 4) fp32 matrices on the device."""
+    _need_cuda(m)
+    d = m.shape[-1]
+    x = m.to(torch.float32).contiguous()
+    out = torch.empty_like(x)
+    rc = _L.load().cobevt_invert_small(_p(x), _p(out), x.numel() // (d * d), d, _stream())
+    _L.check(rc, "cobevt_invert_small")
+    return out

@@ -104,6 +104,10 @@ int cobevt_sttf_warp(const void* x, const float* tmat, const float* cav_mask, vo
                      int B, int L, int H, int W, int C, float discrete_ratio, float downsample_rate,
                      hipStream_t stream);
 
+/* Batched inverse of n (dim x dim) fp32 matrices, dim in {3, 4}; fax_modules.py:500-501 (intrinsic.inverse()),
+ * nuscenes encoder_pyramid_axial.py:538-539. */
+int cobevt_invert_small(const float* in, float* out, int n, int dim, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
