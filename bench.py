@@ -132,7 +132,9 @@ def cpu_baseline_leg(model, cfg, batch_cpu, gpu_out):
     import numpy as np
     import oracle.corpbevt as o_model
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    cores = os.cpu_count() or 1
+    # intra-op threads: all cores up to 32 (PyTorch's CPU kernels slow down badly when oversubscribed across
+    # the 256 hardware threads / NUMA domains of the GPU box: 118 s/frame at 256 threads)
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     t0 = time.time()
     with torch.no_grad():

@@ -43,14 +43,15 @@ def bev_seg_head(sd, pfx, target, x, b, l):
     return {"static_seg": head("static_head"), "dynamic_seg": head("dynamic_head")}
 
 
-def corpbevt_forward(sd, config, batch, return_intermediates=False):
-    """CorpBEVT.forward, corpbevt.py:104-145."""
-    x = batch["inputs"]
-    tm = batch["transformation_matrix"]
-    record_len = batch["record_len"]
-    feats = resnet_encoder(sd, "encoder.encoder.", config["encoder"], x)
+def encode_agents(sd, config, batch):
+    """Per-agent part of CorpBEVT.forward (corpbevt.py:112-117): encoder + FAX -> (N, C, H, W)."""
+    feats = resnet_encoder(sd, "encoder.encoder.", config["encoder"], batch["inputs"])
     f = fax_module(sd, "fax.", config["fax"], feats, batch["intrinsic"], batch["extrinsic"])
-    f = f.squeeze(1)
+    return f.squeeze(1)
+
+
+def fuse_and_decode(sd, config, f, tm, record_len, return_intermediates=False):
+    """Cross-agent part of CorpBEVT.forward (corpbevt.py:119-145): regroup, STTF, mask, swap fusion, decoder, head."""
     assert config["compression"] == 0, "NaiveCompressor is out of scope (SURVEY.md §2 O11)"
     g, mask = regroup(f, record_len, config["max_cav"])
     st = config["sttf"]
@@ -67,6 +68,12 @@ def corpbevt_forward(sd, config, batch, return_intermediates=False):
         out = dict(out)
         out.update({"fax": f, "regroup": g, "cav_mask": mask, "sttf": w, "com_mask": com_mask, "fused": fused})
     return out
+
+
+def corpbevt_forward(sd, config, batch, return_intermediates=False):
+    """CorpBEVT.forward, corpbevt.py:104-145."""
+    f = encode_agents(sd, config, batch)
+    return fuse_and_decode(sd, config, f, batch["transformation_matrix"], batch["record_len"], return_intermediates)
 
 
 def fax_fused_transformer_forward(sd, config, batch):
