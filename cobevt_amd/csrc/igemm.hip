@@ -45,22 +45,25 @@ struct IgemmParams {
 constexpr int kRowBytes = 80;  // 64 data + 16 pad
 constexpr int kTileBytes = 64;
 
-// Slow-path stores: padded output maps, fp32 outputs, PixelUnshuffle(2), NCHW logits.
+// Slow-path stores: padded output maps, fp32 outputs, PixelUnshuffle(2), NCHW logits.  Takes scalars, not the
+// params struct: passing IgemmParams by reference forced the whole struct into scratch memory and turned every
+// p.field access of the main loop into a memory round trip (236 VMEM reads per wave instead of 12, rocprofv3 PMC).
 template <typename T>
-__device__ __noinline__ void store_generic(const IgemmParams& p, int m, int col, float v) {
-    const int hw = p.Ho * p.Wo;
+__device__ __noinline__ void store_generic(void* out, int store_mode, int Ho, int Wo, int out_H, int out_W, int Cout,
+                                           int m, int col, float v) {
+    const int hw = Ho * Wo;
     const int n = m / hw, rem = m - n * hw;
-    const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-    if (p.store_mode == 0) {
-        store_elem<T>((T*)p.out, (((size_t)n * p.out_H + oh) * p.out_W + ow) * p.Cout + col, v);
-    } else if (p.store_mode == 3) {
-        ((float*)p.out)[(((size_t)n * p.out_H + oh) * p.out_W + ow) * p.Cout + col] = v;
-    } else if (p.store_mode == 1) {  // PixelUnshuffle(2): channel = c*4 + (oh&1)*2 + (ow&1)
-        const size_t o = (((size_t)n * (p.Ho >> 1) + (oh >> 1)) * (p.Wo >> 1) + (ow >> 1)) * (size_t)(p.Cout * 4) +
+    const int oh = rem / Wo, ow = rem - oh * Wo;
+    if (store_mode == 0) {
+        store_elem<T>((T*)out, (((size_t)n * out_H + oh) * out_W + ow) * Cout + col, v);
+    } else if (store_mode == 3) {
+        ((float*)out)[(((size_t)n * out_H + oh) * out_W + ow) * Cout + col] = v;
+    } else if (store_mode == 1) {  // PixelUnshuffle(2): channel = c*4 + (oh&1)*2 + (ow&1)
+        const size_t o = (((size_t)n * (Ho >> 1) + (oh >> 1)) * (Wo >> 1) + (ow >> 1)) * (size_t)(Cout * 4) +
                          col * 4 + (oh & 1) * 2 + (ow & 1);
-        store_elem<T>((T*)p.out, o, v);
+        store_elem<T>((T*)out, o, v);
     } else {  // 2: NCHW fp32
-        ((float*)p.out)[(((size_t)n * p.Cout + col) * p.Ho + oh) * p.Wo + ow] = v;
+        ((float*)out)[(((size_t)n * Cout + col) * Ho + oh) * Wo + ow] = v;
     }
 }
 
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
                     if (p.act == 1) v = fmaxf(v, 0.f);
                     else if (p.act == 2) v = gelu_erf(v);
                     if (plain) store_elem<T>((T*)p.out, (size_t)m * p.Cout + col, v);
-                    else store_generic<T>(p, m, col, v);
+                    else store_generic<T>(p.out, p.store_mode, p.Ho, p.Wo, p.out_H, p.out_W, p.Cout, m, col, v);
                 }
             }
         }

@@ -13,6 +13,7 @@ from . import lib as _L
 from .lib import CobevtHipError
 
 BF16, FP32 = 0, 1
+USE_CONV3X3 = True   # route eligible 3x3 convs to the LDS-patch kernel (tests flip this to cover both paths)
 
 
 def dcode(dtype):
@@ -63,10 +64,12 @@ class LaunchProfile(object):
         global _PROFILE
         _PROFILE = None
 
-    def summary(self):
+    def summary(self, by_shape=False):
         torch.cuda.synchronize()
         out = {}
         for fam, flops, nbytes, e0, e1 in self.records:
+            if not by_shape:
+                fam = fam.split("|")[0]
             d = out.setdefault(fam, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["calls"] += 1
             d["ms"] += e0.elapsed_time(e1)
@@ -164,6 +167,17 @@ class ConvPlan(object):
             code = ((tap // kw) << 20) | ((tap % kw) << 10) | c
             code[k >= K] = -1
             self.klut = code.to(torch.int32).to(device).contiguous()
+        # 3x3 / stride 1 / pad 1 fast path (conv3x3.hip): weights [Cout][Cin/cc][9][cc]
+        self.wgt3, self.cc3 = None, 0
+        if kh == 3 and kw == 3 and int(stride) == 1 and int(pad) == 1 and not smallc and pre_bn is None \
+                and int(store_mode) in (0, 1):
+            cands = (64, 32) if self.code == BF16 else (32, 16)
+            for cc in cands:
+                if cin % cc == 0:
+                    w3 = w.permute(0, 2, 3, 1).reshape(cout, 9, cin // cc, cc).permute(0, 2, 1, 3)
+                    self.wgt3 = w3.to(torch.float32).to(dtype).to(device).contiguous()
+                    self.cc3 = cc
+                    break
         self.cin, self.cout, self.kh, self.kw = cin, cout, kh, kw
         self.K, self.kpad = K, kpad
         self.stride, self.pad, self.act = int(stride), int(pad), int(act)
@@ -205,8 +219,6 @@ def conv2d(x, plan, residual=None, out=None):
     if residual is not None:
         if tuple(residual.shape) != (n, ho, wo, plan.cout) or residual.dtype != plan.dtype or not residual.is_contiguous():
             raise CobevtHipError("conv2d: residual must be (N,Ho,Wo,Cout) contiguous in the compute dtype")
-    dims = _ints([plan.code, n, h, w, cin, ho, wo, plan.cout, plan.kh, plan.kw, plan.stride, plan.pad, plan.K,
-                  plan.kpad, plan.upsample, plan.pre_relu, plan.act, sm, out_h, out_w, plan.smallc])
     def cost():
         m = n * ho * wo
         esz = 2 if plan.code == BF16 else 4
@@ -215,7 +227,15 @@ def conv2d(x, plan, residual=None, out=None):
             nbytes += residual.numel() * esz
         return 2.0 * m * plan.cout * plan.K, float(nbytes)
 
-    with _timed("igemm", cost):
+    if plan.wgt3 is not None and (out_h, out_w) == (ho, wo) and USE_CONV3X3:
+        dims = _ints([plan.code, n, h, w, cin, plan.cout, plan.upsample, plan.act, sm, plan.cc3])
+        with _timed("conv3x3|%d->%d %dx%dx%d" % (cin, plan.cout, n, ho, wo), cost):
+            rc = _L.load().cobevt_conv3x3_nhwc(_p(x), _p(plan.wgt3), _p(plan.bias), _p(residual), _p(out), dims, _stream())
+        _L.check(rc, "cobevt_conv3x3_nhwc")
+        return out
+    dims = _ints([plan.code, n, h, w, cin, ho, wo, plan.cout, plan.kh, plan.kw, plan.stride, plan.pad, plan.K,
+                  plan.kpad, plan.upsample, plan.pre_relu, plan.act, sm, out_h, out_w, plan.smallc])
+    with _timed("igemm|k%ds%d %d->%d M=%d%s" % (plan.kh, plan.stride, cin, plan.cout, n * ho * wo, " stem" if plan.smallc else ""), cost):
         rc = _L.load().cobevt_conv2d_nhwc(_p(x), _p(plan.wgt), _p(plan.bias), _p(residual), _p(plan.pre_scale),
                                           _p(plan.pre_shift), _p(plan.klut), _p(out), dims, _stream())
     _L.check(rc, "cobevt_conv2d_nhwc")
@@ -286,7 +306,7 @@ def window_attention(q, k, v, out, qmap, kmap, omap, batch, heads, scale, ldq, l
         nbytes = batch * L * (nq + 2 * nk + nq // (qmap[1] if mean_q else 1)) * d * esz
         return 4.0 * batch * L * heads * nq * nk * 32, float(nbytes)
 
-    with _timed("attention", cost):
+    with _timed("attention|B%d L%d h%d Nq%d Nk%d" % (batch, L, heads, qmap[1] * qmap[4] * qmap[5], kmap[1] * kmap[4] * kmap[5]), cost):
         rc = _L.load().cobevt_window_attention(_p(q), _p(k), _p(v), _p(out), _p(bias_table), _p(mask), dims,
                                                ctypes.c_float(scale), _stream())
     _L.check(rc, "cobevt_window_attention")

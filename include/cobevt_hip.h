@@ -54,6 +54,16 @@ int cobevt_conv2d_nhwc(const void* in, const void* wgt, const float* bias, const
                        const int* dims, hipStream_t stream);
 
 /*
+ * 3x3 / stride 1 / pad 1 convolution with an LDS-resident input patch (the fast path of cobevt_conv2d_nhwc for the
+ * ResNet BasicBlocks resnet_ms.py:67-74, FAX Bottleneck / downsample convs fax_modules.py:472-489 and NaiveDecoder
+ * naive_decoder.py:78-87).  Weights [Cout][Cin/cc][9][cc].  dims (int32[10]): dtype, N, H, W, Cin, Cout,
+ * upsample(0/1: input is read through a nearest x2 up-sampling), act, store_mode (0 NHWC, 1 PixelUnshuffle(2)),
+ * cc = channels per chunk (bf16: 64|32, fp32: 32|16; Cin % cc == 0).
+ */
+int cobevt_conv3x3_nhwc(const void* in, const void* wgt, const float* bias, const void* residual, void* out,
+                        const int* dims, hipStream_t stream);
+
+/*
  * Fused gathered attention: window / dilated-grid partition -> QK^T -> (+relative position bias, key mask)
  * -> softmax -> PV -> (mean over query cameras) -> partition reverse, for projected token matrices.
  * Replaces: CrossWinAttention core, fax_modules.py:211-237,243 with the partitions of :399-404,:417-424 and

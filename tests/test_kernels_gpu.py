@@ -152,6 +152,32 @@ def test_conv_1x1_s2_downsample(cuda, dtype):
     _conv_case(cuda, dtype, "c9", 2, 64, 16, 16, 128, 1, 2, 0, bias=False, bn=True)
 
 
+# ---- the LDS-patch 3x3 kernel (conv3x3.hip): both tile configs, chunk widths, ragged tiles, every epilogue
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,h,w", [(128, 128, 16, 32), (256, 192, 9, 21), (64, 64, 20, 20), (32, 32, 33, 17),
+                                          (96, 48, 8, 8)])
+def test_conv3x3_patch_kernel_shapes(cuda, dtype, cin, cout, h, w):
+    assert ops.USE_CONV3X3
+    _conv_case(cuda, dtype, "p%d_%d" % (cin, cout), 2, cin, h, w, cout, 3, 1, 1, bias=False, bn=True, act=1, residual=True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_matches_generic_igemm(cuda, dtype):
+    """same plan through both kernels (the generic implicit GEMM is the fallback for padded outputs / stride 2)"""
+    x = procedural_input("pg.x", (3, 128, 24, 40), 0)
+    wt = procedural_input("pg.w", (64, 128, 3, 3), 0) * math.sqrt(3.0 / (128 * 9))
+    plan = ops.ConvPlan(wt, None, bn=FakeBN(64, "pg.bn"), stride=1, pad=1, act=1, upsample=True, dtype=dtype, device=cuda)
+    assert plan.wgt3 is not None
+    xd = nhwc(x).to(cuda).to(dtype)
+    a = ops.conv2d(xd, plan)
+    ops.USE_CONV3X3 = False
+    try:
+        b = ops.conv2d(xd, plan)
+    finally:
+        ops.USE_CONV3X3 = True
+    check(a, b.float().cpu(), dtype, "conv3x3 vs igemm")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_linear_ragged_rows(cuda, dtype):
     x = procedural_input("l1.x", (3, 100, 128), 0)
