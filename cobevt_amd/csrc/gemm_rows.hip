@@ -1,0 +1,258 @@
+// Dense-row GEMM for every nn.Linear / 1x1 stride-1 convolution of the FAX hot path (gfx950), with the
+// LayerNorm that precedes most of them fused into the A-operand staging.
+//
+//   out[m][n] = act( f(A[m][:]) . W[n][:] + bias[n] + residual[m][n] ),   f = LayerNorm | BN-ReLU pre-activation | id
+//
+// Replaces (together with the epilogue fusions) the LayerNorm -> Linear pairs of
+// opv2v/opencood/models/sub_modules/fax_modules.py:189-193 (to_q/to_k/to_v), :309-313,411,435 (prenorm + mlp),
+// opv2v/opencood/models/fusion_modules/swap_fusion_modules.py:45-53 + base_transformer.py:102-124 (PreNormResidual +
+// to_qkv / FeedForward), the pre-activation 1x1 convs fax_modules.py:281-292, Bottleneck 1x1 convs :472.
+//
+// Tile 128 x 128, K-tile = 256 bytes per row (128 bf16 / 64 fp32), 512 threads = 8 waves (4 x 2, 32 x 64 each,
+// 16 MFMAs per wave per K-tile).  Thread t stages 64 contiguous bytes of row t>>2 of the A tile and of the W tile,
+// so a 256-byte row is owned by 4 adjacent lanes: LayerNorm statistics are two xor-shuffles in registers before
+// the tile is written to LDS (fused only when the whole row fits one K-tile: K <= 128 bf16 / 64 fp32; otherwise the
+// caller runs cobevt_layernorm first).  One LDS buffer + register prefetch of the next K-tile; fp32-staged,
+// 16-byte coalesced epilogue (bias, residual, ReLU / exact GELU) as in conv3x3.hip.
+#include "common.hpp"
+
+namespace cobevt {
+
+struct GemmRowsParams {
+    const void* in;
+    const void* wgt;        // [N][Kp], Kp = K rounded up to a whole K-tile, zero padded
+    const float* bias;
+    const void* residual;   // [M][N] or null
+    const float* ln_gamma;  // LayerNorm over the K axis of A (null = off)
+    const float* ln_beta;
+    const float* pre_scale; // per-channel affine (+ReLU) on A (null = off)
+    const float* pre_shift;
+    void* out;
+    long lda;               // elements between consecutive A rows
+    int M, N, K, Kp;
+    float ln_eps;
+    int pre_relu;
+    int act;
+    // optional spatial remap of output rows into a zero-padded (src_n, out_H, out_W) map
+    int src_H, src_W, out_H, out_W;
+};
+
+constexpr int kGrThreads = 512;
+constexpr int kGrRow = 256 + 16;          // LDS row stride (bytes)
+constexpr int kGrTile = 128;              // rows of A and of W per tile
+constexpr int kGrStageRow = 128 * 4 + 16; // fp32 staging row stride
+
+template <typename T>
+__global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams p) {
+    constexpr int CH = Elem<T>::kChunk;
+    constexpr int TK = 256 / Elem<T>::kBytes;        // elements per K-tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;
+    unsigned char* Ws = smem + kGrTile * kGrRow;
+
+    const int ntn = (p.N + 127) / 128;
+    int logical;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+        const int q = nblk >> 3, r = nblk & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int m0 = (logical / ntn) * 128, n0 = (logical % ntn) * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, ql = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int srow = tid >> 2, sub = tid & 3;        // staging: row of the tile, 64-byte quarter of the 256-byte row
+    const T* in = (const T*)p.in;
+    const T* wg = (const T*)p.wgt;
+    const bool a_ok = m0 + srow < p.M;
+    const bool w_ok = n0 + srow < p.N;
+    const T* arow = in + (size_t)(a_ok ? m0 + srow : 0) * p.lda;
+    const T* wrow = wg + (size_t)(w_ok ? n0 + srow : 0) * p.Kp;
+    const int nkt = p.Kp / TK;
+
+    uint4 areg[4], wreg[4];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = kt * TK + (sub * 4 + j) * CH;
+            areg[j] = (a_ok && k < p.K) ? *(const uint4*)(arow + k) : make_uint4(0, 0, 0, 0);
+            wreg[j] = w_ok ? *(const uint4*)(wrow + k) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    // LayerNorm / pre-activation on this thread's 64 bytes (and its 3 neighbours' for the row statistics)
+    auto transform_a = [&](int kt) {
+        if (p.ln_gamma) {
+            float v[4][8];
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                chunk_to_f32<T>(areg[j], v[j]);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) s += v[j][e];      // columns >= K are zero
+            }
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            const float mean = s / (float)p.K;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    const int k = (sub * 4 + j) * CH + e;
+                    const float d = k < p.K ? v[j][e] - mean : 0.f;
+                    q += d * d;
+                }
+            q += __shfl_xor(q, 1, 64);
+            q += __shfl_xor(q, 2, 64);
+            const float rstd = rsqrtf(q / (float)p.K + p.ln_eps);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    const int k = (sub * 4 + j) * CH + e;
+                    v[j][e] = k < p.K ? (v[j][e] - mean) * rstd * p.ln_gamma[k] + p.ln_beta[k] : 0.f;
+                }
+                areg[j] = f32_to_chunk<T>(v[j]);
+            }
+        } else if (p.pre_scale) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[8];
+                chunk_to_f32<T>(areg[j], v);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    const int k = kt * TK + (sub * 4 + j) * CH + e;
+                    float x = k < p.K ? v[e] * p.pre_scale[k] + p.pre_shift[k] : 0.f;
+                    v[e] = p.pre_relu ? fmaxf(x, 0.f) : x;
+                }
+                areg[j] = f32_to_chunk<T>(v);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *(uint4*)(As + srow * kGrRow + (sub * 4 + j) * 16) = areg[j];
+            *(uint4*)(Ws + srow * kGrRow + (sub * 4 + j) * 16) = wreg[j];
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    const int abase = (wm * 32 + ql) * kGrRow + h * 16;
+    const int bbase = (wn * 64 + ql) * kGrRow + h * 16;
+
+    load_tile(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        transform_a(kt);
+        if (kt > 0) __syncthreads();          // previous tile fully consumed
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const int kleft = p.K - kt * TK;
+        const int ng = kleft >= TK ? 8 : (kleft * Elem<T>::kBytes + 31) / 32;
+        for (int g = 0; g < ng; ++g) {
+            const uint4 af = *(const uint4*)(As + abase + g * 32);
+            const uint4 b0 = *(const uint4*)(Ws + bbase + g * 32);
+            const uint4 b1 = *(const uint4*)(Ws + bbase + 32 * kGrRow + g * 32);
+            mfma_kgroup<T>(af, b0, acc[0]);
+            mfma_kgroup<T>(af, b1, acc[1]);
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: fp32 staging [128][128] then coalesced 16-byte passes
+    float* stage = (float*)smem;
+    constexpr int SROW = kGrStageRow / 4;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int cl = wn * 64 + b * 32 + ql;
+        const float bias = (p.bias && n0 + cl < p.N) ? p.bias[n0 + cl] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[(wm * 32 + acc_row(r, lane)) * SROW + cl] = acc[b][r] + bias;
+    }
+    __syncthreads();
+    T* out = (T*)p.out;
+    constexpr int CPR = 128 / CH;                 // 16-byte output chunks per tile row
+    const bool remap = p.out_H != p.src_H || p.out_W != p.src_W;
+    const bool vec_ok = (p.N % CH) == 0;
+    for (int item = tid; item < 128 * CPR; item += kGrThreads) {
+        const int row = item / CPR, cj = item - row * CPR;
+        const int m = m0 + row, col = n0 + cj * CH;
+        if (m >= p.M || col >= p.N) continue;
+        size_t orow = (size_t)m;
+        if (remap) {
+            const int hw = p.src_H * p.src_W;
+            const int n = m / hw, rem = m - n * hw;
+            const int oh = rem / p.src_W, ow = rem - oh * p.src_W;
+            orow = ((size_t)n * p.out_H + oh) * p.out_W + ow;
+        }
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) v[e] = stage[row * SROW + cj * CH + e];
+        if (vec_ok && col + CH <= p.N) {
+            if (p.residual) {
+                float rv[8];
+                chunk_to_f32<T>(*(const uint4*)((const T*)p.residual + (size_t)m * p.N + col), rv);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) v[e] += rv[e];
+            }
+#pragma unroll
+            for (int e = 0; e < CH; ++e) v[e] = p.act == 1 ? fmaxf(v[e], 0.f) : (p.act == 2 ? gelu_erf(v[e]) : v[e]);
+            *(uint4*)(out + orow * p.N + col) = f32_to_chunk<T>(v);
+        } else {
+            for (int e = 0; e < CH && col + e < p.N; ++e) {
+                float x = v[e];
+                if (p.residual) x += load_elem<T>((const T*)p.residual, (size_t)m * p.N + col + e);
+                x = p.act == 1 ? fmaxf(x, 0.f) : (p.act == 2 ? gelu_erf(x) : x);
+                store_elem<T>(out, orow * p.N + col + e, x);
+            }
+        }
+    }
+}
+
+}  // namespace cobevt
+
+using namespace cobevt;
+
+// C-ABI entry point, see include/cobevt_hip.h
+extern "C" int cobevt_linear_rows(const void* in, const void* wgt, const float* bias, const void* residual,
+                                  const float* ln_gamma, const float* ln_beta, const float* pre_scale,
+                                  const float* pre_shift, void* out, const long* dims, float ln_eps, hipStream_t stream) {
+    // dims: [dtype, M, N, K, Kp, lda, pre_relu, act, src_H, src_W, out_H, out_W]
+    if (!in || !wgt || !out || !dims) return COBEVT_ERR_ARG;
+    GemmRowsParams p;
+    const int dtype = (int)dims[0];
+    p.in = in; p.wgt = wgt; p.bias = bias; p.residual = residual;
+    p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.out = out;
+    p.M = (int)dims[1]; p.N = (int)dims[2]; p.K = (int)dims[3]; p.Kp = (int)dims[4]; p.lda = dims[5];
+    p.pre_relu = (int)dims[6]; p.act = (int)dims[7];
+    p.src_H = (int)dims[8]; p.src_W = (int)dims[9]; p.out_H = (int)dims[10]; p.out_W = (int)dims[11];
+    p.ln_eps = ln_eps;
+    if (dtype != 0 && dtype != 1) return COBEVT_ERR_ARG;
+    const int tk = dtype == 0 ? 128 : 64, ch = dtype == 0 ? 8 : 4;
+    if (p.M < 1 || p.N < 1 || p.K < 1 || p.Kp % tk != 0 || p.Kp < p.K) return COBEVT_ERR_SHAPE;
+    if (p.K % ch != 0 || p.lda % ch != 0 || p.lda < p.K) return COBEVT_ERR_SHAPE;
+    if ((ln_gamma == nullptr) != (ln_beta == nullptr)) return COBEVT_ERR_ARG;
+    if (ln_gamma && p.K > tk) return COBEVT_ERR_UNSUPPORTED;       // LayerNorm fusion needs the row in one K-tile
+    if (ln_gamma && pre_scale) return COBEVT_ERR_UNSUPPORTED;
+    if ((pre_scale == nullptr) != (pre_shift == nullptr)) return COBEVT_ERR_ARG;
+    if (p.residual && (p.out_H != p.src_H || p.out_W != p.src_W)) return COBEVT_ERR_UNSUPPORTED;
+    const long blocks = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (blocks > 0x7fffffffL) return COBEVT_ERR_SHAPE;
+    constexpr size_t lds = 2 * kGrTile * kGrRow;   // 69,632 B: A + W tiles; the fp32 staging (128 x 528) fits inside
+    static_assert(128 * kGrStageRow <= 2 * kGrTile * kGrRow, "staging must fit");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    if (dtype == 0) hipLaunchKernelGGL(gemm_rows_kernel<bf16_t>, dim3((unsigned)blocks), dim3(kGrThreads), lds, stream, p);
+    else hipLaunchKernelGGL(gemm_rows_kernel<float>, dim3((unsigned)blocks), dim3(kGrThreads), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}

@@ -97,6 +97,11 @@ def f32_param(owner, name, tensor, shape=None):
     return owner._plan("f32:" + name, [tensor], build)
 
 
+def ln_params(owner, name, ln):
+    """(gamma, beta, eps) of an nn.LayerNorm container as fp32 device tensors, for ops.linear(..., ln=...)."""
+    return (f32_param(owner, name + ".w", ln.weight), f32_param(owner, name + ".b", ln.bias), ln.eps)
+
+
 def layernorm(owner, name, ln, x):
     g = f32_param(owner, name + ".w", ln.weight)
     b = f32_param(owner, name + ".b", ln.bias)

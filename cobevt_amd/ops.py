@@ -14,6 +14,7 @@ from .lib import CobevtHipError
 
 BF16, FP32 = 0, 1
 USE_CONV3X3 = True   # route eligible 3x3 convs to the LDS-patch kernel (tests flip this to cover both paths)
+USE_GEMM_ROWS = True  # route 1x1 stride-1 convs / linears to the dense-row GEMM with fused LayerNorm
 
 
 def dcode(dtype):
@@ -178,6 +179,16 @@ class ConvPlan(object):
                     self.wgt3 = w3.to(torch.float32).to(dtype).to(device).contiguous()
                     self.cc3 = cc
                     break
+        # dense-row GEMM fast path (gemm_rows.hip) for 1x1 / stride 1: weights [Cout][K rounded to a 256-byte tile]
+        self.wgt_rows, self.kp_rows = None, 0
+        if kh == 1 and kw == 1 and int(stride) == 1 and int(pad) == 0 and not smallc and int(store_mode) == 0 \
+                and not upsample:
+            tk = 128 if self.code == BF16 else 64
+            kp = (K + tk - 1) // tk * tk
+            wr = torch.zeros(cout, kp, dtype=torch.float64)
+            wr[:, :K] = w.reshape(cout, K)
+            self.wgt_rows = wr.to(torch.float32).to(dtype).to(device).contiguous()
+            self.kp_rows = kp
         self.cin, self.cout, self.kh, self.kw = cin, cout, kh, kw
         self.K, self.kpad = K, kpad
         self.stride, self.pad, self.act = int(stride), int(pad), int(act)
@@ -189,10 +200,19 @@ class ConvPlan(object):
         return (hv + 2 * self.pad - self.kh) // self.stride + 1, (wv + 2 * self.pad - self.kw) // self.stride + 1
 
 
-def conv2d(x, plan, residual=None, out=None):
+def ln_fusable(plan):
+    """LayerNorm over K can be folded into the dense-row GEMM when the row fits one 256-byte K-tile."""
+    return USE_GEMM_ROWS and plan.wgt_rows is not None and plan.K <= (128 if plan.code == BF16 else 64)
+
+
+def conv2d(x, plan, residual=None, out=None, ln=None):
     """x: (N,H,W,Cin) channels-last contiguous in plan.dtype (fp32 image for smallc plans).  Returns the output
-    in the layout selected by plan.store_mode.  `out` may be a pre-zeroed, spatially larger (N,Hp,Wp,Cout) map."""
+    in the layout selected by plan.store_mode.  `out` may be a pre-zeroed, spatially larger (N,Hp,Wp,Cout) map.
+    ln = (gamma, beta, eps): LayerNorm over the channel axis of x applied first (1x1 layers only)."""
     _need_cuda(x, residual, out)
+    if ln is not None and not ln_fusable(plan):
+        x = layernorm(x, ln[0], ln[1], ln[2])
+        ln = None
     n, h, w, cin = x.shape
     if cin != plan.cin or not x.is_contiguous():
         raise CobevtHipError("conv2d: bad input %s (contiguous=%s) for Cin=%d" % (tuple(x.shape), x.is_contiguous(), plan.cin))
@@ -227,6 +247,16 @@ def conv2d(x, plan, residual=None, out=None):
             nbytes += residual.numel() * esz
         return 2.0 * m * plan.cout * plan.K, float(nbytes)
 
+    if plan.wgt_rows is not None and USE_GEMM_ROWS and not (residual is not None and (out_h, out_w) != (ho, wo)):
+        ldims = (ctypes.c_long * 12)(plan.code, n * h * w, plan.cout, plan.K, plan.kp_rows, cin, plan.pre_relu, plan.act,
+                                     ho, wo, out_h, out_w)
+        g, b, eps = ln if ln is not None else (None, None, 0.0)
+        with _timed("gemm_rows|%d->%d M=%d%s" % (cin, plan.cout, n * h * w, " ln" if ln is not None else ""), cost):
+            rc = _L.load().cobevt_linear_rows(_p(x), _p(plan.wgt_rows), _p(plan.bias), _p(residual), _p(g), _p(b),
+                                              _p(plan.pre_scale), _p(plan.pre_shift), _p(out), ldims,
+                                              ctypes.c_float(eps), _stream())
+        _L.check(rc, "cobevt_linear_rows")
+        return out
     if plan.wgt3 is not None and (out_h, out_w) == (ho, wo) and USE_CONV3X3:
         dims = _ints([plan.code, n, h, w, cin, plan.cout, plan.upsample, plan.act, sm, plan.cc3])
         with _timed("conv3x3|%d->%d %dx%dx%d" % (cin, plan.cout, n, ho, wo), cost):
@@ -242,13 +272,14 @@ def conv2d(x, plan, residual=None, out=None):
     return out
 
 
-def linear(x, plan, residual=None):
-    """x: (..., K) contiguous tokens -> (..., Cout).  A Linear is the 1x1 case of the implicit GEMM."""
+def linear(x, plan, residual=None, ln=None):
+    """x: (..., K) contiguous tokens -> (..., Cout).  A Linear is the 1x1 case of the implicit GEMM.
+    ln = (gamma, beta, eps) applies LayerNorm(x) first (fused into the GEMM when the row fits one K-tile)."""
     lead = x.shape[:-1]
     rows = int(math.prod(lead)) if len(lead) else 1
     x4 = x.reshape(1, 1, rows, x.shape[-1])
     r4 = residual.reshape(1, 1, rows, plan.cout) if residual is not None else None
-    y = conv2d(x4, plan, residual=r4)
+    y = conv2d(x4, plan, residual=r4, ln=ln)
     return y.reshape(*lead, plan.cout)
 
 

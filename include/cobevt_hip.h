@@ -64,6 +64,18 @@ int cobevt_conv3x3_nhwc(const void* in, const void* wgt, const float* bias, cons
                         const int* dims, hipStream_t stream);
 
 /*
+ * Dense-row GEMM with fused LayerNorm / pre-activation on the A operand and fused bias / residual / activation:
+ * the fast path of every nn.Linear and 1x1 stride-1 convolution (fax_modules.py:189-193,281-292,309-313,411,435,472;
+ * swap_fusion_modules.py:45-53; base_transformer.py:102-124).  wgt [N][Kp] (Kp = K rounded up to 128 bf16 / 64 fp32
+ * elements).  dims (int64[12]): dtype, M, N, K, Kp, lda, pre_relu, act, src_H, src_W, out_H, out_W (the last four remap
+ * output rows into a zero-padded map; equal values = plain rows).  ln_gamma/ln_beta fp32[K] (nullable; needs K <= one
+ * K-tile), pre_scale/pre_shift fp32[K] (nullable).
+ */
+int cobevt_linear_rows(const void* in, const void* wgt, const float* bias, const void* residual, const float* ln_gamma,
+                       const float* ln_beta, const float* pre_scale, const float* pre_shift, void* out, const long* dims,
+                       float ln_eps, hipStream_t stream);
+
+/*
  * Fused gathered attention: window / dilated-grid partition -> QK^T -> (+relative position bias, key mask)
  * -> softmax -> PV -> (mean over query cameras) -> partition reverse, for projected token matrices.
  * Replaces: CrossWinAttention core, fax_modules.py:211-237,243 with the partitions of :399-404,:417-424 and

@@ -195,6 +195,31 @@ def test_linear_ragged_rows(cuda, dtype):
     check(z, ref2, dtype, "linear+residual")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k,n,rows", [(128, 128, 1000), (128, 384, 130), (32, 128, 257), (256, 128, 300), (64, 96, 64)])
+def test_gemm_rows_fused_layernorm(cuda, dtype, k, n, rows):
+    """LayerNorm -> Linear (+bias, GELU, residual) in one launch vs separate torch ops; and vs the generic igemm."""
+    x = procedural_input("gr.x", (rows, k), 0, -2, 3)
+    w = procedural_input("gr.w", (n, k), 0) * math.sqrt(3.0 / k)
+    b = procedural_input("gr.b", (n,), 0, -0.2, 0.2)
+    g = 0.8 + 0.4 * procedural_input("gr.g", (k,), 0, 0, 1)
+    be = procedural_input("gr.be", (k,), 0, -0.2, 0.2)
+    res = procedural_input("gr.res", (rows, n), 0)
+    plan = ops.ConvPlan(w, b, act=2, dtype=dtype, device=cuda)
+    assert plan.wgt_rows is not None
+    xd, rd = x.to(cuda).to(dtype), res.to(cuda).to(dtype)
+    y = ops.linear(xd, plan, residual=rd, ln=(g.to(cuda), be.to(cuda), 1e-5))
+    xn = rnd(F.layer_norm(rnd(x, dtype), (k,), g, be, 1e-5), dtype)      # the unfused path rounds LN output to the compute dtype
+    ref = F.gelu(F.linear(xn, plan.wgt.float().cpu()[:, :k], b) + rnd(res, dtype))
+    check(y, ref, dtype, "gemm_rows LN k=%d n=%d" % (k, n))
+    ops.USE_GEMM_ROWS = False
+    try:
+        y2 = ops.linear(xd, plan, residual=rd, ln=(g.to(cuda), be.to(cuda), 1e-5))
+    finally:
+        ops.USE_GEMM_ROWS = True
+    check(y, y2.float().cpu(), dtype, "gemm_rows vs igemm")
+
+
 # ---------------------------------------------------------------------------------------------
 def _attn_ref(q, k, v, scale, bias=None, key_mask=None):
     """q (G, Nq, dh), k/v (G, Nk, dh) fp32 -> (G, Nq, dh)"""
