@@ -355,6 +355,54 @@ __global__ __launch_bounds__(64) void invert_small_kernel(const float* in, float
         for (int c = 0; c < D; ++c) out[(size_t)i * D * D + r * D + c] = (float)a[r][D + c];
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Channels-last spatial resize: mode 0 = nearest (F.interpolate default: src = floor(dst * in/out)),
+// mode 1 = bilinear with align_corners=True (nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)).
+// reference: nuscenes/cross_view_transformer/model/decoder.py:12,31.
+template <typename T>
+__global__ __launch_bounds__(256) void resize_kernel(const T* in, T* out, int N, int H, int W, int C, int Ho, int Wo,
+                                                     int mode) {
+    const int G = C >> 3;
+    const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / G;
+    const int gl = threadIdx.x & (G - 1);
+    if (gid >= (long)N * Ho * Wo) return;
+    const int n = (int)(gid / (Ho * Wo)), rem = (int)(gid - (long)n * Ho * Wo);
+    const int oh = rem / Wo, ow = rem - oh * Wo;
+    const T* src = in + (size_t)n * H * W * C + gl * 8;
+    float v[8];
+    if (mode == 0) {
+        const float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
+        const int ih = min((int)floorf(oh * sh), H - 1), iw = min((int)floorf(ow * sw), W - 1);
+        load8<T>(src + ((size_t)ih * W + iw) * C, v);
+    } else {
+        const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+        const float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+        const float fy = oh * sh, fx = ow * sw;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        float a[8], b[8], c[8], d[8];
+        load8<T>(src + ((size_t)y0 * W + x0) * C, a);
+        load8<T>(src + ((size_t)y0 * W + x1) * C, b);
+        load8<T>(src + ((size_t)y1 * W + x0) * C, c);
+        load8<T>(src + ((size_t)y1 * W + x1) * C, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = hy * (hx * a[e] + lx * b[e]) + ly * (hx * c[e] + lx * d[e]);
+    }
+    store8<T>(out + gid * C + gl * 8, v);
+}
+
+// Per-channel affine on a contiguous (N, C, HW) fp32 tensor: y = x * scale[c] + shift[c]
+// (Normalize, nuscenes/cross_view_transformer/model/encoder_pyramid_axial.py:41-49).
+__global__ __launch_bounds__(256) void channel_affine_kernel(const float* in, const float* scale, const float* shift,
+                                                             float* out, long total, int C, long HW) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)((i / HW) % C);
+    out[i] = in[i] * scale[c] + shift[c];
+}
+
 template <typename K, typename... Args>
 static int launch1d(K kern, long work_items, hipStream_t stream, Args... args) {
     const long blocks = (work_items + 255) / 256;
@@ -472,6 +520,23 @@ extern "C" int cobevt_invert_small(const float* in, float* out, int n, int dim, 
     if (dim == 3) hipLaunchKernelGGL(invert_small_kernel<3>, grid, block, 0, stream, in, out, n);
     else hipLaunchKernelGGL(invert_small_kernel<4>, grid, block, 0, stream, in, out, n);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+extern "C" int cobevt_resize_nhwc(const void* in, void* out, int dtype, int N, int H, int W, int C, int Ho, int Wo, int mode,
+                                  hipStream_t stream) {
+    if (!in || !out) return COBEVT_ERR_ARG;
+    if (!group_ok(C) || N < 1 || H < 1 || W < 1 || Ho < 1 || Wo < 1 || (mode != 0 && mode != 1)) return COBEVT_ERR_SHAPE;
+    const long items = (long)N * Ho * Wo * (C >> 3);
+    if (dtype == 0) return launch1d(resize_kernel<bf16_t>, items, stream, (const bf16_t*)in, (bf16_t*)out, N, H, W, C, Ho, Wo, mode);
+    if (dtype == 1) return launch1d(resize_kernel<float>, items, stream, (const float*)in, (float*)out, N, H, W, C, Ho, Wo, mode);
+    return COBEVT_ERR_ARG;
+}
+
+extern "C" int cobevt_channel_affine(const float* in, const float* scale, const float* shift, float* out, long N, int C,
+                                     long HW, hipStream_t stream) {
+    if (!in || !scale || !shift || !out) return COBEVT_ERR_ARG;
+    if (N < 1 || C < 1 || HW < 1) return COBEVT_ERR_SHAPE;
+    return launch1d(channel_affine_kernel, N * C * HW, stream, in, scale, shift, out, N * C * HW, C, HW);
 }
 
 extern "C" const char* cobevt_strerror(int code) {

@@ -438,3 +438,26 @@ def invert_small(m):
     rc = _L.load().cobevt_invert_small(_p(x), _p(out), x.numel() // (d * d), d, _stream())
     _L.check(rc, "cobevt_invert_small")
     return out
+
+
+def resize_nhwc(x, ho, wo, mode):
+    """(N,H,W,C) -> (N,ho,wo,C); mode 'nearest' (F.interpolate default) or 'bilinear' (align_corners=True)."""
+    _need_cuda(x)
+    n, h, w, c = x.shape
+    out = torch.empty((n, ho, wo, c), device=x.device, dtype=x.dtype)
+    rc = _L.load().cobevt_resize_nhwc(_p(x), _p(out), dcode(x.dtype), n, h, w, c, ho, wo, 0 if mode == "nearest" else 1,
+                                      _stream())
+    _L.check(rc, "cobevt_resize_nhwc")
+    return out
+
+
+def channel_affine(x, scale, shift):
+    """x (N, C, ...) contiguous fp32 -> x * scale[c] + shift[c]"""
+    _need_cuda(x, scale, shift)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        x = x.to(torch.float32).contiguous()
+    out = torch.empty_like(x)
+    n, c = x.shape[0], x.shape[1]
+    rc = _L.load().cobevt_channel_affine(_p(x), _p(scale), _p(shift), _p(out), n, c, x.numel() // (n * c), _stream())
+    _L.check(rc, "cobevt_channel_affine")
+    return out

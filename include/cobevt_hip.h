@@ -130,6 +130,15 @@ int cobevt_sttf_warp(const void* x, const float* tmat, const float* cav_mask, vo
  * nuscenes encoder_pyramid_axial.py:538-539. */
 int cobevt_invert_small(const float* in, float* out, int n, int dim, hipStream_t stream);
 
+/* Channels-last resize: mode 0 nearest (F.interpolate default), mode 1 bilinear align_corners=True;
+ * nuscenes/cross_view_transformer/model/decoder.py:12,31. */
+int cobevt_resize_nhwc(const void* in, void* out, int dtype, int N, int H, int W, int C, int Ho, int Wo, int mode,
+                       hipStream_t stream);
+
+/* y = x*scale[c] + shift[c] on contiguous (N,C,HW) fp32; Normalize, nuscenes encoder_pyramid_axial.py:41-49. */
+int cobevt_channel_affine(const float* in, const float* scale, const float* shift, float* out, long N, int C, long HW,
+                          hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -274,8 +274,39 @@ def gv10():
     save("gv10_resnet_encoder", **out)
 
 
+def gv11():
+    """nuScenes SinBEVT: reference PyramidAxialEncoder + Decoder + CrossViewTransformer on the real config shapes."""
+    sys.path.insert(0, "/root/reference/nuscenes")
+    from cross_view_transformer.model.encoder_pyramid_axial import PyramidAxialEncoder as R_Enc
+    from cross_view_transformer.model.decoder import Decoder as R_Dec
+    from cross_view_transformer.model.cvt import CrossViewTransformer as R_CVT
+    from cobevt_amd.host.nuscenes.backbones import FeatureMapBackbone
+    import copy
+    import oracle.nuscenes as o_nu
+    c = cases.NUSCENES
+    feats, image, intr, ext = cases.nuscenes_inputs()
+    enc = R_Enc(FeatureMapBackbone(feats), **copy.deepcopy(c["encoder"]))
+    model = R_CVT(enc, R_Dec(**c["decoder"]), c["dim_last"], c["outputs"]).eval()
+    fill_module_(model, cases.SEED)
+    inter = {}
+    model.encoder.register_forward_hook(lambda mod, i, o: inter.__setitem__("enc", o))
+    model.decoder.register_forward_hook(lambda mod, i, o: inter.__setitem__("dec", o))
+    ref = model({"image": image, "intrinsics": intr, "extrinsics": ext})
+    sd = model.state_dict()
+    got_enc = o_nu.pyramid_axial_encoder(sd, "encoder.", c["encoder"], feats, intr, ext)
+    _close("nuScenes PyramidAxialEncoder", got_enc, inter["enc"])
+    got = o_nu.cross_view_transformer(sd, c["encoder"], len(c["decoder"]["blocks"]), c["outputs"], feats, intr, ext)
+    for k in ref:
+        _close("nuScenes CrossViewTransformer[%s]" % k, got[k], ref[k])
+    nrm = model.encoder.norm(image.flatten(0, 1))
+    assert torch.allclose(nrm, o_nu.normalize(image.flatten(0, 1)))
+    save("gv11_nuscenes_sinbevt", encoder=_np(inter["enc"]), bev=_np(ref["bev"]), center=_np(ref["center"]),
+         normalized_image_sample=_np(nrm[:, :, ::37, ::41]),
+         keys=np.array(list(sd.keys())), shapes=np.array([",".join(str(int(d)) for d in v.shape) for v in sd.values()]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gv0", "gv1", "gv2", "gv3", "gv4", "gv5", "gv6", "gv7", "gv8", "gv9", "gv10"]
+    which = sys.argv[1:] or ["gv0", "gv1", "gv2", "gv3", "gv4", "gv5", "gv6", "gv7", "gv8", "gv9", "gv10", "gv11"]
     for name in which:
         print("== " + name)
         globals()[name]()

@@ -205,3 +205,43 @@ def test_corpbevt_full_config_two_agents_vs_oracle(cuda):
     print("full CorpBEVT 2 agents: fp32 rel %.2e argmax %.5f | bf16 rel %.2e argmax %.5f" % (e32, a32, e16, a16))
     assert e32 <= 1e-3 and a32 >= 0.999
     assert e16 <= 5e-2 and a16 >= 0.98
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+def test_nuscenes_sinbevt(cuda, dtype, tol):
+    """BASELINE config[1]: nuScenes SinBEVT, 1 ego x 6 cams (EfficientNet-B4-shaped features of 224x480 images),
+    200x200 BEV, non-square 6x12 / 14x30 key windows on zero-padded maps, heads 1/2/4 — vs the reference's outputs."""
+    from cobevt_amd.host import nuscenes as nu
+    g = golden("gv11_nuscenes_sinbevt")
+    c = cases.NUSCENES
+    feats, image, intr, ext = cases.nuscenes_inputs()
+    enc = nu.PyramidAxialEncoder(nu.FeatureMapBackbone(feats), **copy.deepcopy(c["encoder"]))
+    model = dev(nu.CrossViewTransformer(enc, nu.Decoder(**c["decoder"]), c["dim_last"], c["outputs"]), cuda)
+    batch = {"image": image.to(cuda), "intrinsics": intr.to(cuda), "extrinsics": ext.to(cuda)}
+    with host.compute_dtype(dtype):
+        e = model.encoder(batch)
+        out = model(batch)
+        nrm = model.encoder.norm(batch["image"].flatten(0, 1))
+    assert_close(e, g["encoder"], tol, "PyramidAxialEncoder")
+    assert out["bev"].dtype == torch.float32 and tuple(out["bev"].shape) == (1, 1, 200, 200)
+    assert_close(out["bev"], g["bev"], tol, "bev logits")
+    assert_close(out["center"], g["center"], tol, "center logits")
+    assert np.allclose(nrm[:, :, ::37, ::41].cpu().numpy(), g["normalized_image_sample"], atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 3e-2)])
+def test_lidar_shaped_fusebevt(cuda, dtype, tol):
+    """BASELINE config[4] operator config (SwapFusionEncoder input_dim 64, 8 agents, window 8, depth 3, mask: 512 tokens
+    per window, 2 heads, 3375-row 3-D bias table) on a reduced 32x32 map, against the oracle."""
+    import oracle.swap_fusion as o_swap
+    args = dict(input_dim=64, mlp_dim=128, agent_size=8, window_size=8, dim_head=32, drop_out=0.1, depth=3, mask=True)
+    enc = fill_module_(host.SwapFusionEncoder(args), cases.SEED).eval()
+    x = synth.procedural_input("lidar.x", (1, 8, 64, 32, 32), cases.SEED)
+    mask = torch.ones(1, 32, 32, 1, 8)
+    mask[0, :, :, :, 6:] = 0                  # two padded agents
+    mask[0, :12, 20:, :, 3] = 0               # an ROI wedge for agent 3
+    ref = o_swap.swap_fusion_encoder(enc.state_dict(), "", args, x, mask)
+    enc = enc.to(cuda)
+    with host.compute_dtype(dtype):
+        y = enc(x.to(cuda), mask.to(cuda))
+    assert_close(y, ref, tol, "LiDAR-shaped SwapFusionEncoder")

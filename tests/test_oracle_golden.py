@@ -173,3 +173,31 @@ def test_gv10_resnet_encoder(depth):
     for i, f in enumerate(got):
         assert_close(f, g["resnet%d_f%d" % (depth, i)], TOL, "resnet%d[%d]" % (depth, i))
     assert [list(s) for s in m.output_shapes] == g["resnet%d_shapes" % depth].tolist()   # analytic == dummy forward
+
+
+def _nuscenes_model():
+    from cobevt_amd.host import nuscenes as nu
+    c = cases.NUSCENES
+    feats, image, intr, ext = cases.nuscenes_inputs()
+    enc = nu.PyramidAxialEncoder(nu.FeatureMapBackbone(feats), **copy.deepcopy(c["encoder"]))
+    model = nu.CrossViewTransformer(enc, nu.Decoder(**c["decoder"]), c["dim_last"], c["outputs"])
+    return fill_module_(model, cases.SEED), feats, image, intr, ext
+
+
+def test_gv11_nuscenes_sinbevt():
+    """BASELINE config[1] shapes (6 cams, 200x200 BEV, cvt_pyramid_axial.yaml) — oracle vs the reference's outputs;
+    also pins the nuScenes host modules' state_dict schema to the reference's."""
+    import oracle.nuscenes as o_nu
+    g = golden("gv11_nuscenes_sinbevt")
+    c = cases.NUSCENES
+    model, feats, image, intr, ext = _nuscenes_model()
+    sd = model.state_dict()
+    ref_schema = dict(zip(g["keys"].tolist(), g["shapes"].tolist()))
+    mine = {k: ",".join(str(int(d)) for d in v.shape) for k, v in sd.items()}
+    assert mine == ref_schema
+    enc = o_nu.pyramid_axial_encoder(sd, "encoder.", c["encoder"], feats, intr, ext)
+    assert_close(enc, g["encoder"], TOL, "PyramidAxialEncoder")
+    out = o_nu.cross_view_transformer(sd, c["encoder"], len(c["decoder"]["blocks"]), c["outputs"], feats, intr, ext)
+    assert_close(out["bev"], g["bev"], TOL, "bev")
+    assert_close(out["center"], g["center"], TOL, "center")
+    assert np.allclose(o_nu.normalize(image.flatten(0, 1))[:, :, ::37, ::41].numpy(), g["normalized_image_sample"], atol=1e-6)
