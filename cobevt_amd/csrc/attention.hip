@@ -83,19 +83,25 @@ template <typename T> struct AttnLds {
     static constexpr int kKBytes = kKeysPerTile * kKRow;
     static constexpr int kVBytes = 32 * kVRow;
     static constexpr int kInfoBytes = kKeysPerTile * 4;
-    static constexpr int kFixed = kKBytes + kVBytes + kInfoBytes;
+    static constexpr int kBuf = kKBytes + kVBytes + kInfoBytes;          // one K/V^T/info tile
+    static constexpr int kFixed = 2 * kBuf;                              // double buffered
 };
 
-template <typename T>
-__global__ void attn_gather_kernel(AttnParams p) {
+// BIAS / MASK are compile-time so the plain cross-attention path carries no per-element metadata work.
+template <typename T, bool BIAS, bool MASK>
+__global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
     using L = AttnLds<T>;
     constexpr int CH = Elem<T>::kChunk;
     constexpr int NG = 32 * Elem<T>::kBytes / 32;  // 32-byte k-groups along dh (2 bf16, 4 fp32)
-    constexpr int CPR = 32 / CH;                   // 16-byte chunks per K/V token row (head slice)
+    constexpr int CPR = 32 / CH;                   // 16-byte chunks per K token row (head slice)
+    constexpr int K_ITEMS = kKeysPerTile * CPR;    // 256 bf16 / 512 fp32
+    constexpr int K_IT = K_ITEMS / 256;
+    // V^T staging: bf16 pairs two consecutive keys so every LDS write is a full dword (key pair x 4 dh per item);
+    // fp32 writes one dword per element (key x 4 dh per item)
+    constexpr int V_ITEMS = Elem<T>::kIsBf16 ? (kKeysPerTile / 2) * 8 : kKeysPerTile * 8;
+    constexpr int V_IT = V_ITEMS / 256;
+    constexpr bool INFO = BIAS || MASK;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Ks = smem;
-    unsigned char* Vts = smem + L::kKBytes;
-    int* kinfo = (int*)(smem + L::kKBytes + L::kVBytes);
     float* bias_col = (float*)(smem + L::kFixed);
     float* red = (float*)smem;  // aliases the K/V tiles after the key loop (mean mode)
 
@@ -105,11 +111,11 @@ __global__ void attn_gather_kernel(AttnParams p) {
     const int l = blockIdx.y / p.heads, head = blockIdx.y - l * p.heads;
     const int qtile = blockIdx.x;
 
-    // ---- this lane's query token
+    // ---- this lane's query token (mean mode: wave = camera; waves beyond ncam only help staging)
     const int P = p.qmap.w1 * p.qmap.w2;
     int tq;
     bool q_ok;
-    if (p.mean_q) { const int pos = qtile * 32 + ql; q_ok = pos < P; tq = wave * P + pos; }
+    if (p.mean_q) { const int pos = qtile * 32 + ql; q_ok = pos < P && wave < p.qmap.ncam; tq = wave * P + pos; }
     else { tq = qtile * 32 * (nthr >> 6) + wave * 32 + ql; q_ok = tq < p.Nq; }
     const TokCoord qc = tok_coord(p.qmap, q_ok ? tq : 0);
 
@@ -120,9 +126,105 @@ __global__ void attn_gather_kernel(AttnParams p) {
         for (int g = 0; g < NG; ++g)
             qf[g] = q_ok ? *(const uint4*)(qrow + g * (2 * CH) + h * CH) : make_uint4(0, 0, 0, 0);
     }
-    if (p.bias_mode) {
+    if (BIAS) {
         for (int i = tid; i < p.bias_rows; i += nthr) bias_col[i] = p.bias_table[(size_t)i * p.heads + head];
     }
+
+    // ---- staging registers (threads 0..255 stage; K_IT / V_IT items each)
+    uint4 kreg[K_IT];
+    uint4 vreg[V_IT];          // bf16: {row0 lo, row0 hi, row1 lo, row1 hi} (8 bytes of 2 key rows); fp32: 16 bytes of 1 row
+    int ireg[K_IT];
+    const bool stager = tid < 256;
+    const int nkt = (p.Nk + kKeysPerTile - 1) / kKeysPerTile;
+
+    auto load_tile = [&](int kt) {
+        if (!stager) return;
+#pragma unroll
+        for (int it = 0; it < K_IT; ++it) {
+            const int item = tid + it * 256;
+            const int kk = item / CPR, cj = item - kk * CPR;
+            const int tk = kt * kKeysPerTile + kk;
+            const bool ok = tk < p.Nk;
+            const TokCoord kc = tok_coord(p.kmap, ok ? tk : 0);
+            const size_t row = tok_row(p.kmap, b, l, kc);
+            kreg[it] = ok ? *(const uint4*)((const T*)p.k + row * p.ldk + p.koff + head * 32 + cj * CH) : make_uint4(0, 0, 0, 0);
+            if (INFO) {
+                int info = -1;
+                if (ok && cj == 0) {
+                    bool valid = true;
+                    if (MASK) {
+                        if (p.kmap.mode == 2) {  // mask stored partitioned like the keys: (B, X*Y, w1, w2, ncam)
+                            valid = p.mask[((((size_t)b * p.L + l) * p.kmap.w1 + kc.i) * p.kmap.w2 + kc.j) * p.kmap.ncam + kc.cam] != 0.f;
+                        } else {
+                            int ph, pw;
+                            tok_pixel(p.kmap, l, kc, ph, pw);
+                            valid = p.mask[(((size_t)b * p.kmap.HH + ph) * p.kmap.WW + pw) * p.kmap.ncam + kc.cam] != 0.f;
+                        }
+                    }
+                    if (valid) info = (kc.cam << 16) | (kc.i << 8) | kc.j;
+                }
+                ireg[it] = info;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < V_IT; ++it) {
+            const int item = tid + it * 256;
+            if constexpr (Elem<T>::kIsBf16) {
+                const int kp = item >> 3, dq = item & 7;               // key pair, dh quad
+                uint2 r0 = make_uint2(0, 0), r1 = make_uint2(0, 0);
+                const int tk = kt * kKeysPerTile + 2 * kp;
+                if (tk < p.Nk) {
+                    const size_t row = tok_row(p.kmap, b, l, tok_coord(p.kmap, tk));
+                    r0 = *(const uint2*)((const T*)p.v + row * p.ldv + p.voff + head * 32 + dq * 4);
+                }
+                if (tk + 1 < p.Nk) {
+                    const size_t row = tok_row(p.kmap, b, l, tok_coord(p.kmap, tk + 1));
+                    r1 = *(const uint2*)((const T*)p.v + row * p.ldv + p.voff + head * 32 + dq * 4);
+                }
+                vreg[it] = make_uint4(r0.x, r0.y, r1.x, r1.y);
+            } else {
+                const int kk = item >> 3, dq = item & 7;
+                const int tk = kt * kKeysPerTile + kk;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (tk < p.Nk) {
+                    const size_t row = tok_row(p.kmap, b, l, tok_coord(p.kmap, tk));
+                    v = *(const uint4*)((const T*)p.v + row * p.ldv + p.voff + head * 32 + dq * 4);
+                }
+                vreg[it] = v;
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        if (!stager) return;
+        unsigned char* Ks = smem + buf * L::kBuf;
+        unsigned char* Vts = Ks + L::kKBytes;
+        int* kinfo = (int*)(Vts + L::kVBytes);
+#pragma unroll
+        for (int it = 0; it < K_IT; ++it) {
+            const int item = tid + it * 256;
+            const int kk = item / CPR, cj = item - kk * CPR;
+            *(uint4*)(Ks + kk * L::kKRow + cj * 16) = kreg[it];
+            if (INFO && cj == 0) kinfo[kk] = ireg[it];
+        }
+#pragma unroll
+        for (int it = 0; it < V_IT; ++it) {
+            const int item = tid + it * 256;
+            if constexpr (Elem<T>::kIsBf16) {
+                const int kp = item >> 3, dq = item & 7;
+                const uint32_t a[2] = {vreg[it].x, vreg[it].y}, c[2] = {vreg[it].z, vreg[it].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {   // dh = dq*4 + e : {key 2kp, key 2kp+1} as one dword
+                    const uint32_t lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xffffu, hi = (c[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+                    *(uint32_t*)(Vts + (dq * 4 + e) * L::kVRow + kp * 4) = lo | (hi << 16);
+                }
+            } else {
+                const int kk = item >> 3, dq = item & 7;
+                const uint32_t w[4] = {vreg[it].x, vreg[it].y, vreg[it].z, vreg[it].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) *(uint32_t*)(Vts + (dq * 4 + e) * L::kVRow + kk * 4) = w[e];
+            }
+        }
+    };
 
     f32x16 ot;
 #pragma unroll
@@ -130,47 +232,15 @@ __global__ void attn_gather_kernel(AttnParams p) {
     float m_run = -INFINITY, l_run = 0.f;
     const float sl2 = p.scale * 1.4426950408889634f;  // softmax in base 2
 
-    const int nkt = (p.Nk + kKeysPerTile - 1) / kKeysPerTile;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();  // previous tile fully consumed
-        for (int item = tid; item < kKeysPerTile * CPR; item += nthr) {
-            const int kk = item / CPR, cj = item - kk * CPR;
-            const int tk = kt * kKeysPerTile + kk;
-            const bool ok = tk < p.Nk;
-            const TokCoord kc = tok_coord(p.kmap, ok ? tk : 0);
-            const size_t row = tok_row(p.kmap, b, l, kc);
-            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                kv = *(const uint4*)((const T*)p.k + row * p.ldk + p.koff + head * 32 + cj * CH);
-                vv = *(const uint4*)((const T*)p.v + row * p.ldv + p.voff + head * 32 + cj * CH);
-            }
-            *(uint4*)(Ks + kk * L::kKRow + cj * 16) = kv;
-            if constexpr (Elem<T>::kIsBf16) {
-                const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    *(uint16_t*)(Vts + (cj * 8 + e) * L::kVRow + kk * 2) = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
-            } else {
-                const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) *(uint32_t*)(Vts + (cj * 4 + e) * L::kVRow + kk * 4) = w[e];
-            }
-            if (cj == 0) {
-                int info = (kc.cam << 16) | (kc.i << 8) | kc.j;
-                bool valid = ok;
-                if (ok && p.mask) {
-                    if (p.kmap.mode == 2) {  // mask stored partitioned like the keys: (B, X*Y, w1, w2, ncam)
-                        valid = p.mask[((((size_t)b * p.L + l) * p.kmap.w1 + kc.i) * p.kmap.w2 + kc.j) * p.kmap.ncam + kc.cam] != 0.f;
-                    } else {
-                        int ph, pw;
-                        tok_pixel(p.kmap, l, kc, ph, pw);
-                        valid = p.mask[(((size_t)b * p.kmap.HH + ph) * p.kmap.WW + pw) * p.kmap.ncam + kc.cam] != 0.f;
-                    }
-                }
-                kinfo[kk] = valid ? info : -1;
-            }
-        }
-        __syncthreads();
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const unsigned char* Ks = smem + buf * L::kBuf;
+        const unsigned char* Vts = Ks + L::kKBytes;
+        const int* kinfo = (const int*)(Vts + L::kVBytes);
 
         // ---- S^T = K . Q^T for the two 32-key sub-tiles
         f32x16 st[2];
@@ -184,38 +254,54 @@ __global__ void attn_gather_kernel(AttnParams p) {
                 mfma_kgroup<T>(a, qf[g], st[s]);
             }
         }
-        // ---- scale (base-2 domain), bias, mask
+        // ---- softmax numerators in the base-2 domain: p = 2^(s*scale*log2e [+ bias*log2e] - m)
         float mloc = -INFINITY;
+        const int nvalid = p.Nk - kt * kKeysPerTile;     // >= 64 except in the last tile
+        if (INFO) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < 2; ++s) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kk = s * 32 + acc_row(r, lane);
-                const int info = kinfo[kk];
-                float v = st[s][r] * sl2;
-                if (p.bias_mode) {
-                    const int lk = (info >> 16) & 0x7fff, ak = (info >> 8) & 0xff, bk = info & 0xff;
-                    int idx = ((qc.cam - lk + p.bias_L - 1) * (2 * p.kmap.w1 - 1) + (qc.i - ak + p.kmap.w1 - 1)) *
-                                  (2 * p.kmap.w2 - 1) + (qc.j - bk + p.kmap.w2 - 1);
-                    idx = info < 0 ? 0 : idx;
-                    v += bias_col[idx] * 1.4426950408889634f;
+                for (int r = 0; r < 16; ++r) {
+                    const int info = kinfo[s * 32 + acc_row(r, lane)];
+                    float v = st[s][r] * sl2;
+                    if (BIAS) {
+                        const int lk = (info >> 16) & 0x7fff, ak = (info >> 8) & 0xff, bk = info & 0xff;
+                        int idx = ((qc.cam - lk + p.bias_L - 1) * (2 * p.kmap.w1 - 1) + (qc.i - ak + p.kmap.w1 - 1)) *
+                                      (2 * p.kmap.w2 - 1) + (qc.j - bk + p.kmap.w2 - 1);
+                        idx = info < 0 ? 0 : idx;
+                        v = fmaf(bias_col[idx], 1.4426950408889634f, v);
+                    }
+                    v = info < 0 ? -INFINITY : v;
+                    st[s][r] = v;
+                    mloc = fmaxf(mloc, v);
                 }
-                v = info < 0 ? -INFINITY : v;
-                st[s][r] = v;
-                mloc = fmaxf(mloc, v);
             }
+        } else {
+            if (nvalid < kKeysPerTile) {                 // ragged last tile (wave-uniform branch)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (s * 32 + acc_row(r, lane) >= nvalid) st[s][r] = -INFINITY;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[s][r]);
+            mloc *= sl2;                                 // scale > 0: max commutes with the scaling
         }
         const float mtile = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mtile);
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = exp2f(m_run - m_safe);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = exp2f(st[s][r] - m_safe);
+                const float e = INFO ? __builtin_amdgcn_exp2f(st[s][r] - m_safe)
+                                     : __builtin_amdgcn_exp2f(fmaf(st[s][r], sl2, -m_safe));
                 st[s][r] = e;
                 psum += e;
             }
@@ -249,6 +335,8 @@ __global__ void attn_gather_kernel(AttnParams p) {
                 }
             }
         }
+        if (kt + 1 < nkt) store_tile(buf ^ 1);
+        __syncthreads();
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -257,10 +345,11 @@ __global__ void attn_gather_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) ot[r] *= inv;
 
     if (p.mean_q) {
-        const int nw = nthr >> 6;
-        __syncthreads();
+        const int nw = p.qmap.ncam;
+        if (wave < nw) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = ot[r];
+            for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = ot[r];
+        }
         __syncthreads();
         if (wave != 0) return;
         const float invn = 1.0f / (float)nw;
@@ -331,17 +420,26 @@ extern "C" int cobevt_window_attention(const void* q, const void* k, const void*
     p.Nq = p.qmap.ncam * p.qmap.w1 * p.qmap.w2;
     p.Nk = p.kmap.ncam * p.kmap.w1 * p.kmap.w2;
     if (p.mean_q && p.qmap.ncam == 1) p.mean_q = 0;
-    if (p.mean_q && (p.qmap.ncam > 16 || p.omap.ncam != 1)) return COBEVT_ERR_UNSUPPORTED;
+    if (p.mean_q && (p.qmap.ncam > 8 || p.omap.ncam != 1)) return COBEVT_ERR_UNSUPPORTED;
     const int P = p.qmap.w1 * p.qmap.w2;
     dim3 grid, block;
-    if (p.mean_q) { block = dim3(64 * p.qmap.ncam); grid = dim3((P + 31) / 32, p.L * p.heads, p.B); }
+    if (p.mean_q) { block = dim3(64 * (p.qmap.ncam < 4 ? 4 : p.qmap.ncam)); grid = dim3((P + 31) / 32, p.L * p.heads, p.B); }
     else { block = dim3(256); grid = dim3((p.Nq + 127) / 128, p.L * p.heads, p.B); }
     if (grid.y > 65535 || grid.z > 65535) return COBEVT_ERR_SHAPE;
     size_t lds = dtype == 0 ? AttnLds<bf16_t>::kFixed : AttnLds<float>::kFixed;
     if (p.bias_mode) lds += (size_t)p.bias_rows * 4;
     if (p.mean_q) { const size_t need = (size_t)p.qmap.ncam * 16 * 64 * 4; if (need > lds) lds = need; }
-    if (lds > 160 * 1024) return COBEVT_ERR_UNSUPPORTED;
-    if (dtype == 0) hipLaunchKernelGGL(attn_gather_kernel<bf16_t>, grid, block, lds, stream, p);
-    else hipLaunchKernelGGL(attn_gather_kernel<float>, grid, block, lds, stream, p);
+    if (lds > 64 * 1024) return COBEVT_ERR_UNSUPPORTED;
+    const bool hb = p.bias_mode != 0, hm = p.mask != nullptr;
+#define COBEVT_ATTN_LAUNCH(TT)                                                                                   \
+    do {                                                                                                          \
+        if (hb && hm) hipLaunchKernelGGL((attn_gather_kernel<TT, true, true>), grid, block, lds, stream, p);      \
+        else if (hb) hipLaunchKernelGGL((attn_gather_kernel<TT, true, false>), grid, block, lds, stream, p);      \
+        else if (hm) hipLaunchKernelGGL((attn_gather_kernel<TT, false, true>), grid, block, lds, stream, p);      \
+        else hipLaunchKernelGGL((attn_gather_kernel<TT, false, false>), grid, block, lds, stream, p);             \
+    } while (0)
+    if (dtype == 0) COBEVT_ATTN_LAUNCH(bf16_t);
+    else COBEVT_ATTN_LAUNCH(float);
+#undef COBEVT_ATTN_LAUNCH
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

@@ -21,17 +21,17 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 __device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 
-// round-to-nearest-even, NaN preserved (same rounding as torch.float32 -> torch.bfloat16)
-__device__ __forceinline__ uint16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+// fp32 pair -> packed bf16 pair with the hardware converter (v_cvt_pk_bf16_f32: round-to-nearest-even, the same
+// rounding as torch.float32 -> torch.bfloat16); `lo` lands in bits 15:0.
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
-}
+__device__ __forceinline__ uint16_t f2bf(float f) { return (uint16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Elem;
 template <> struct Elem<bf16_t> {
