@@ -62,7 +62,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* in, const float
     q = wave_sum_xor(q, G);
     const float rstd = rsqrtf(q / (float)C + eps);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * gamma[gl * 8 + e] + beta[gl * 8 + e];
+    for (int e = 0; e < 8; ++e) {
+        v[e] = (v[e] - mean) * rstd;
+        if (gamma) v[e] = v[e] * gamma[gl * 8 + e] + beta[gl * 8 + e];     // null affine: plain normalisation
+    }
     store8<T>(out + (size_t)gid * C + gl * 8, v);
 }
 
@@ -420,7 +423,7 @@ using namespace cobevt;
 extern "C" int cobevt_layernorm(const void* in, const float* gamma, const float* beta, void* out, int dtype, int rows,
                                 int C, float eps, int navg, long avg_stride, long in_batch_stride, int rows_per_batch,
                                 hipStream_t stream) {
-    if (!in || !gamma || !beta || !out) return COBEVT_ERR_ARG;
+    if (!in || !out || ((gamma == nullptr) != (beta == nullptr))) return COBEVT_ERR_ARG;
     if (!group_ok(C) || rows < 1 || navg < 1) return COBEVT_ERR_SHAPE;
     if (rows_per_batch <= 0) { rows_per_batch = rows; in_batch_stride = 0; }
     const long items = (long)rows * (C >> 3);

@@ -23,8 +23,9 @@ struct GemmRowsParams {
     const void* wgt;        // [N][Kp], Kp = K rounded up to a whole K-tile, zero padded
     const float* bias;
     const void* residual;   // [M][N] or null
-    const float* ln_gamma;  // LayerNorm over the K axis of A (null = off)
+    const float* ln_gamma;  // optional LayerNorm affine (normally folded into wgt / bias on the host -> null)
     const float* ln_beta;
+    int ln;                 // 1: normalise every A row over K (mean / biased variance, eps inside the sqrt)
     const float* pre_scale; // per-channel affine (+ReLU) on A (null = off)
     const float* pre_shift;
     void* out;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams
     };
     // LayerNorm / pre-activation on this thread's 64 bytes (and its 3 neighbours' for the row statistics)
     auto transform_a = [&](int kt) {
-        if (p.ln_gamma) {
+        if (p.ln) {
             float v[4][8];
             float s = 0.f;
 #pragma unroll
@@ -111,19 +112,28 @@ __global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams
 #pragma unroll
                 for (int e = 0; e < CH; ++e) {
                     const int k = (sub * 4 + j) * CH + e;
-                    v[j][e] = k < p.K ? (v[j][e] - mean) * rstd * p.ln_gamma[k] + p.ln_beta[k] : 0.f;
+                    float y = (v[j][e] - mean) * rstd;
+                    if (p.ln_gamma) y = y * p.ln_gamma[k] + p.ln_beta[k];
+                    v[j][e] = k < p.K ? y : 0.f;
                 }
                 areg[j] = f32_to_chunk<T>(v[j]);
             }
         } else if (p.pre_scale) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v[8];
+                const int k0 = kt * TK + (sub * 4 + j) * CH;     // K % CH == 0: a chunk is entirely inside or outside K
+                if (k0 >= p.K) { areg[j] = make_uint4(0, 0, 0, 0); continue; }
+                float v[8], sc[8], sh[8];
                 chunk_to_f32<T>(areg[j], v);
 #pragma unroll
+                for (int q = 0; q < CH / 4; ++q) {               // 16-byte loads of the per-channel affine
+                    const float4 a = *(const float4*)(p.pre_scale + k0 + 4 * q), c = *(const float4*)(p.pre_shift + k0 + 4 * q);
+                    sc[4 * q] = a.x; sc[4 * q + 1] = a.y; sc[4 * q + 2] = a.z; sc[4 * q + 3] = a.w;
+                    sh[4 * q] = c.x; sh[4 * q + 1] = c.y; sh[4 * q + 2] = c.z; sh[4 * q + 3] = c.w;
+                }
+#pragma unroll
                 for (int e = 0; e < CH; ++e) {
-                    const int k = kt * TK + (sub * 4 + j) * CH + e;
-                    float x = k < p.K ? v[e] * p.pre_scale[k] + p.pre_shift[k] : 0.f;
+                    const float x = v[e] * sc[e] + sh[e];
                     v[e] = p.pre_relu ? fmaxf(x, 0.f) : x;
                 }
                 areg[j] = f32_to_chunk<T>(v);
@@ -223,7 +233,7 @@ using namespace cobevt;
 extern "C" int cobevt_linear_rows(const void* in, const void* wgt, const float* bias, const void* residual,
                                   const float* ln_gamma, const float* ln_beta, const float* pre_scale,
                                   const float* pre_shift, void* out, const long* dims, float ln_eps, hipStream_t stream) {
-    // dims: [dtype, M, N, K, Kp, lda, pre_relu, act, src_H, src_W, out_H, out_W]
+    // dims: [dtype, M, N, K, Kp, lda, pre_relu, act, src_H, src_W, out_H, out_W, ln]
     if (!in || !wgt || !out || !dims) return COBEVT_ERR_ARG;
     GemmRowsParams p;
     const int dtype = (int)dims[0];
@@ -233,13 +243,14 @@ extern "C" int cobevt_linear_rows(const void* in, const void* wgt, const float* 
     p.pre_relu = (int)dims[6]; p.act = (int)dims[7];
     p.src_H = (int)dims[8]; p.src_W = (int)dims[9]; p.out_H = (int)dims[10]; p.out_W = (int)dims[11];
     p.ln_eps = ln_eps;
+    p.ln = (int)dims[12] || ln_gamma != nullptr;
     if (dtype != 0 && dtype != 1) return COBEVT_ERR_ARG;
     const int tk = dtype == 0 ? 128 : 64, ch = dtype == 0 ? 8 : 4;
     if (p.M < 1 || p.N < 1 || p.K < 1 || p.Kp % tk != 0 || p.Kp < p.K) return COBEVT_ERR_SHAPE;
     if (p.K % ch != 0 || p.lda % ch != 0 || p.lda < p.K) return COBEVT_ERR_SHAPE;
     if ((ln_gamma == nullptr) != (ln_beta == nullptr)) return COBEVT_ERR_ARG;
-    if (ln_gamma && p.K > tk) return COBEVT_ERR_UNSUPPORTED;       // LayerNorm fusion needs the row in one K-tile
-    if (ln_gamma && pre_scale) return COBEVT_ERR_UNSUPPORTED;
+    if (p.ln && p.K > tk) return COBEVT_ERR_UNSUPPORTED;           // LayerNorm fusion needs the row in one K-tile
+    if (p.ln && pre_scale) return COBEVT_ERR_UNSUPPORTED;
     if ((pre_scale == nullptr) != (pre_shift == nullptr)) return COBEVT_ERR_ARG;
     if (p.residual && (p.out_H != p.src_H || p.out_W != p.src_W)) return COBEVT_ERR_UNSUPPORTED;
     const long blocks = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);

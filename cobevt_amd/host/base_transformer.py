@@ -17,7 +17,7 @@ class PreNormResidual(HipModule):
 
     def forward_fused(self, x, **kwargs):
         """x: contiguous channels-last tensor in the compute dtype."""
-        return self.fn.forward_fused(x, residual=x, ln=rt.ln_params(self, "norm", self.norm), **kwargs)
+        return self.fn.forward_fused(x, residual=x, ln=self.norm, **kwargs)
 
     def forward(self, x, **kwargs):
         self._require_inference(x)
@@ -33,7 +33,7 @@ class FeedForward(HipModule):
                                  nn.Linear(hidden_dim, dim), nn.Dropout(dropout))
 
     def forward_fused(self, x, residual=None, ln=None):
-        t = ops.linear(x, rt.linear_plan(self, "fc1", self.net[0], act=2), ln=ln)
+        t = ops.linear(x, rt.linear_plan(self, "fc1", self.net[0], act=2, ln=ln))
         return ops.linear(t, rt.linear_plan(self, "fc2", self.net[3]), residual=residual)
 
     def forward(self, x):

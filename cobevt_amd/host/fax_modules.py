@@ -141,7 +141,7 @@ class CrossWinAttention(HipModule):
         return x
 
     def _project(self, name, seq, x):
-        return ops.linear(x, rt.linear_plan(self, name, seq[1]), ln=rt.ln_params(self, name + ".ln", seq[0]))
+        return ops.linear(x, rt.linear_plan(self, name, seq[1], ln=seq[0]))
 
     def attend(self, q_src, k_src, v_src, qmap, kmap, omap, batch, skip, out_shape):
         """q_src/k_src/v_src: token-major tensors whose rows the maps address; returns proj(attn) (+skip)."""
@@ -212,7 +212,7 @@ class CrossViewSwapAttention(HipModule):
         return hp, wp
 
     def _mlp(self, name, prenorm, mlp, x):
-        t = ops.linear(x, rt.linear_plan(self, name + ".0", mlp[0], act=2), ln=rt.ln_params(self, name + ".ln", prenorm))
+        t = ops.linear(x, rt.linear_plan(self, name + ".0", mlp[0], act=2, ln=prenorm))
         return ops.linear(t, rt.linear_plan(self, name + ".2", mlp[2]), residual=x)
 
     def forward_nhwc(self, index, x, bev, feature, I_inv, E_inv):

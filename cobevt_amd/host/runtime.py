@@ -81,10 +81,11 @@ def conv_plan(owner, name, conv, bn=None, pre_bn=None, act=0, upsample=False, st
     return owner._plan(name, module_tensors(conv, bn, pre_bn), build)
 
 
-def linear_plan(owner, name, lin, act=0):
+def linear_plan(owner, name, lin, act=0, ln=None):
+    """Plan for an nn.Linear container; ln = the nn.LayerNorm container applied to its input (folded into the plan)."""
     def build(dt, dev):
-        return ops.ConvPlan(lin.weight, lin.bias, act=act, dtype=dt, device=dev)
-    return owner._plan(name, module_tensors(lin), build)
+        return ops.ConvPlan(lin.weight, lin.bias, act=act, dtype=dt, device=dev, ln=ln)
+    return owner._plan(name, module_tensors(lin, ln), build)
 
 
 def f32_param(owner, name, tensor, shape=None):
@@ -95,11 +96,6 @@ def f32_param(owner, name, tensor, shape=None):
             t = t.reshape(shape)
         return t.contiguous()
     return owner._plan("f32:" + name, [tensor], build)
-
-
-def ln_params(owner, name, ln):
-    """(gamma, beta, eps) of an nn.LayerNorm container as fp32 device tensors, for ops.linear(..., ln=...)."""
-    return (f32_param(owner, name + ".w", ln.weight), f32_param(owner, name + ".b", ln.bias), ln.eps)
 
 
 def layernorm(owner, name, ln, x):

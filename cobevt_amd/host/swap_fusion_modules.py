@@ -40,7 +40,7 @@ class Attention(HipModule):
         self.register_buffer("relative_position_index", index)
 
     def forward_fused(self, xn, residual=None, mask=None, mode=2, ln=None):
-        """xn (compute dtype; LayerNorm'ed already, or raw with ln=(gamma, beta, eps) to fuse it): mode 2 -> (b l X Y w1 w2 d) partitioned, mask (b X Y w1 w2 1 l);
+        """xn (compute dtype; LayerNorm'ed already, or raw with ln=<nn.LayerNorm container> to fuse it): mode 2 -> (b l X Y w1 w2 d) partitioned, mask (b X Y w1 w2 1 l);
         mode 0 (window) / 1 (grid) -> (b l H W d), mask (b H W 1 l).  Returns to_out(attn) (+ residual)."""
         L, w = self.window_size[0], self.window_size[1]
         if mode == 2:
@@ -52,7 +52,7 @@ class Attention(HipModule):
             m = ops.tokmap(mode, l, H, W, w, w)
         if l != L or w1 != w or w2 != w:
             raise CobevtHipError("swap attention built for %d agents x %dx%d windows, got %d x %dx%d" % (L, w, w, l, w1, w2))
-        qkv = ops.linear(xn, rt.linear_plan(self, "qkv", self.to_qkv), ln=ln)
+        qkv = ops.linear(xn, rt.linear_plan(self, "qkv", self.to_qkv, ln=ln))
         out = torch.empty(xn.shape, device=xn.device, dtype=xn.dtype)
         table = rt.f32_param(self, "table", self.relative_position_bias_table.weight)
         mk = None

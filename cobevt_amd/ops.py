@@ -129,13 +129,24 @@ class ConvPlan(object):
     """A conv / linear layer lowered to the implicit-GEMM kernel: folded, re-laid-out weights + static params."""
 
     def __init__(self, weight, bias=None, bn=None, pre_bn=None, pre_relu=False, stride=1, pad=0, act=0,
-                 upsample=False, store_mode=0, dtype=torch.bfloat16, device="cuda", smallc=False):
+                 upsample=False, store_mode=0, dtype=torch.bfloat16, device="cuda", smallc=False, ln=None):
+        """ln = nn.LayerNorm-like (weight, bias, eps) applied to the input rows of a Linear / 1x1 layer: its affine
+        is folded here (W' = W diag(gamma), b' = b + W beta) so the kernels only have to normalise."""
         w = weight.detach().double().cpu()
         if w.dim() == 2:
             w = w[:, :, None, None]
         cout, cin, kh, kw = w.shape
         b = bias.detach().double().cpu() if bias is not None else torch.zeros(cout, dtype=torch.float64)
         has_bias = bias is not None or bn is not None
+        self.has_ln, self.ln_eps = False, 0.0
+        if ln is not None:
+            if kh != 1 or kw != 1 or bn is not None or pre_bn is not None:
+                raise CobevtHipError("LayerNorm folding applies to plain Linear / 1x1 layers")
+            g, be = ln.weight.detach().double().cpu(), ln.bias.detach().double().cpu()
+            b = b + (w[:, :, 0, 0] @ be)
+            w = w * g[None, :, None, None]
+            has_bias = True
+            self.has_ln, self.ln_eps = True, float(ln.eps)
         if bn is not None:
             s, sh = bn_affine(bn)
             s, sh = s.cpu(), sh.cpu()
@@ -201,18 +212,19 @@ class ConvPlan(object):
 
 
 def ln_fusable(plan):
-    """LayerNorm over K can be folded into the dense-row GEMM when the row fits one 256-byte K-tile."""
+    """The row normalisation can run inside the dense-row GEMM when the row fits one 256-byte K-tile."""
     return USE_GEMM_ROWS and plan.wgt_rows is not None and plan.K <= (128 if plan.code == BF16 else 64)
 
 
-def conv2d(x, plan, residual=None, out=None, ln=None):
+def conv2d(x, plan, residual=None, out=None):
     """x: (N,H,W,Cin) channels-last contiguous in plan.dtype (fp32 image for smallc plans).  Returns the output
     in the layout selected by plan.store_mode.  `out` may be a pre-zeroed, spatially larger (N,Hp,Wp,Cout) map.
-    ln = (gamma, beta, eps): LayerNorm over the channel axis of x applied first (1x1 layers only)."""
+    Plans built with ln=... normalise the rows of x first (LayerNorm affine already folded into the weights)."""
     _need_cuda(x, residual, out)
-    if ln is not None and not ln_fusable(plan):
-        x = layernorm(x, ln[0], ln[1], ln[2])
-        ln = None
+    ln = plan.has_ln
+    if ln and not ln_fusable(plan):
+        x = layernorm(x, None, None, plan.ln_eps)
+        ln = False
     n, h, w, cin = x.shape
     if cin != plan.cin or not x.is_contiguous():
         raise CobevtHipError("conv2d: bad input %s (contiguous=%s) for Cin=%d" % (tuple(x.shape), x.is_contiguous(), plan.cin))
@@ -248,13 +260,12 @@ def conv2d(x, plan, residual=None, out=None, ln=None):
         return 2.0 * m * plan.cout * plan.K, float(nbytes)
 
     if plan.wgt_rows is not None and USE_GEMM_ROWS and not (residual is not None and (out_h, out_w) != (ho, wo)):
-        ldims = (ctypes.c_long * 12)(plan.code, n * h * w, plan.cout, plan.K, plan.kp_rows, cin, plan.pre_relu, plan.act,
-                                     ho, wo, out_h, out_w)
-        g, b, eps = ln if ln is not None else (None, None, 0.0)
-        with _timed("gemm_rows|%d->%d M=%d%s" % (cin, plan.cout, n * h * w, " ln" if ln is not None else ""), cost):
-            rc = _L.load().cobevt_linear_rows(_p(x), _p(plan.wgt_rows), _p(plan.bias), _p(residual), _p(g), _p(b),
+        ldims = (ctypes.c_long * 13)(plan.code, n * h * w, plan.cout, plan.K, plan.kp_rows, cin, plan.pre_relu, plan.act,
+                                     ho, wo, out_h, out_w, int(ln))
+        with _timed("gemm_rows|%d->%d M=%d%s" % (cin, plan.cout, n * h * w, " ln" if ln else ""), cost):
+            rc = _L.load().cobevt_linear_rows(_p(x), _p(plan.wgt_rows), _p(plan.bias), _p(residual), None, None,
                                               _p(plan.pre_scale), _p(plan.pre_shift), _p(out), ldims,
-                                              ctypes.c_float(eps), _stream())
+                                              ctypes.c_float(plan.ln_eps), _stream())
         _L.check(rc, "cobevt_linear_rows")
         return out
     if plan.wgt3 is not None and (out_h, out_w) == (ho, wo) and USE_CONV3X3:
@@ -272,14 +283,14 @@ def conv2d(x, plan, residual=None, out=None, ln=None):
     return out
 
 
-def linear(x, plan, residual=None, ln=None):
-    """x: (..., K) contiguous tokens -> (..., Cout).  A Linear is the 1x1 case of the implicit GEMM.
-    ln = (gamma, beta, eps) applies LayerNorm(x) first (fused into the GEMM when the row fits one K-tile)."""
+def linear(x, plan, residual=None):
+    """x: (..., K) contiguous tokens -> (..., Cout).  A Linear is the 1x1 case of the implicit GEMM; plans built
+    with ln=... apply LayerNorm(x) first (fused into the GEMM when the row fits one K-tile)."""
     lead = x.shape[:-1]
     rows = int(math.prod(lead)) if len(lead) else 1
     x4 = x.reshape(1, 1, rows, x.shape[-1])
     r4 = residual.reshape(1, 1, rows, plan.cout) if residual is not None else None
-    y = conv2d(x4, plan, residual=r4, ln=ln)
+    y = conv2d(x4, plan, residual=r4)
     return y.reshape(*lead, plan.cout)
 
 

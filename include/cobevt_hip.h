@@ -67,9 +67,10 @@ int cobevt_conv3x3_nhwc(const void* in, const void* wgt, const float* bias, cons
  * Dense-row GEMM with fused LayerNorm / pre-activation on the A operand and fused bias / residual / activation:
  * the fast path of every nn.Linear and 1x1 stride-1 convolution (fax_modules.py:189-193,281-292,309-313,411,435,472;
  * swap_fusion_modules.py:45-53; base_transformer.py:102-124).  wgt [N][Kp] (Kp = K rounded up to 128 bf16 / 64 fp32
- * elements).  dims (int64[12]): dtype, M, N, K, Kp, lda, pre_relu, act, src_H, src_W, out_H, out_W (the last four remap
- * output rows into a zero-padded map; equal values = plain rows).  ln_gamma/ln_beta fp32[K] (nullable; needs K <= one
- * K-tile), pre_scale/pre_shift fp32[K] (nullable).
+ * elements).  dims (int64[13]): dtype, M, N, K, Kp, lda, pre_relu, act, src_H, src_W, out_H, out_W (these four remap
+ * output rows into a zero-padded map; equal values = plain rows), ln (1 = normalise each A row over K first; the
+ * LayerNorm affine is folded into wgt / bias by the host, or passed as ln_gamma/ln_beta fp32[K]; needs K <= one K-tile).
+ * pre_scale/pre_shift fp32[K] (nullable).
  */
 int cobevt_linear_rows(const void* in, const void* wgt, const float* bias, const void* residual, const float* ln_gamma,
                        const float* ln_beta, const float* pre_scale, const float* pre_shift, void* out, const long* dims,
@@ -90,7 +91,7 @@ int cobevt_linear_rows(const void* in, const void* wgt, const float* bias, const
 int cobevt_window_attention(const void* q, const void* k, const void* v, void* out, const float* bias_table,
                             const float* mask, const int* dims, float scale, hipStream_t stream);
 
-/* LayerNorm over channels, optionally after a mean over `navg` slices (mlp_head).
+/* LayerNorm over channels (gamma/beta both null = normalisation only), optionally after a mean over `navg` slices (mlp_head).
  * Replaces: nn.LayerNorm of fax_modules.py:189-191,309-313,435-437; swap_fusion_modules.py:275-279;
  *   base_transformer.py:102-109. */
 int cobevt_layernorm(const void* in, const float* gamma, const float* beta, void* out, int dtype, int rows, int C,

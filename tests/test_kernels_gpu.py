@@ -205,16 +205,22 @@ def test_gemm_rows_fused_layernorm(cuda, dtype, k, n, rows):
     g = 0.8 + 0.4 * procedural_input("gr.g", (k,), 0, 0, 1)
     be = procedural_input("gr.be", (k,), 0, -0.2, 0.2)
     res = procedural_input("gr.res", (rows, n), 0)
-    plan = ops.ConvPlan(w, b, act=2, dtype=dtype, device=cuda)
-    assert plan.wgt_rows is not None
+    class LN(object):
+        weight, bias, eps = g, be, 1e-5
+    plan = ops.ConvPlan(w, b, act=2, dtype=dtype, device=cuda, ln=LN)
+    assert plan.wgt_rows is not None and plan.has_ln
     xd, rd = x.to(cuda).to(dtype), res.to(cuda).to(dtype)
-    y = ops.linear(xd, plan, residual=rd, ln=(g.to(cuda), be.to(cuda), 1e-5))
-    xn = rnd(F.layer_norm(rnd(x, dtype), (k,), g, be, 1e-5), dtype)      # the unfused path rounds LN output to the compute dtype
-    ref = F.gelu(F.linear(xn, plan.wgt.float().cpu()[:, :k], b) + rnd(res, dtype))
+    y = ops.linear(xd, plan, residual=rd)
+    # the kernel normalises (no affine), rounds to the compute dtype, and multiplies by the folded weights
+    xhat = rnd(F.layer_norm(rnd(x, dtype), (k,), None, None, 1e-5), dtype)
+    ref = F.gelu(F.linear(xhat, plan.wgt_rows.float().cpu()[:, :k], plan.bias.cpu()) + rnd(res, dtype))
     check(y, ref, dtype, "gemm_rows LN k=%d n=%d" % (k, n))
+    # and agrees with the un-folded definition LayerNorm(x) @ W^T + b to the mode's tolerance
+    ref2 = F.gelu(F.linear(F.layer_norm(rnd(x, dtype), (k,), g, be, 1e-5), rnd(w, dtype), b) + rnd(res, dtype))
+    check(y, ref2, dtype, "gemm_rows LN (unfolded definition)", scale=ref2.abs().max().item() * (1.0 if dtype == torch.float32 else 2.0))
     ops.USE_GEMM_ROWS = False
     try:
-        y2 = ops.linear(xd, plan, residual=rd, ln=(g.to(cuda), be.to(cuda), 1e-5))
+        y2 = ops.linear(xd, plan, residual=rd)       # separate normalisation kernel + generic implicit GEMM
     finally:
         ops.USE_GEMM_ROWS = True
     check(y, y2.float().cpu(), dtype, "gemm_rows vs igemm")
@@ -357,6 +363,13 @@ def test_layernorm(cuda, dtype, c):
     b = procedural_input("ln.b%d" % c, (c,), 0, -0.2, 0.2)
     y = ops.layernorm(x.to(cuda).to(dtype), g.to(cuda), b.to(cuda))
     check(y, F.layer_norm(rnd(x, dtype), (c,), g, b, 1e-5), dtype, "layernorm C=%d" % c)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_without_affine(cuda, dtype):
+    x = procedural_input("ln0.x", (3, 50, 128), 0, -2, 3)
+    y = ops.layernorm(x.to(cuda).to(dtype), None, None)
+    check(y, F.layer_norm(rnd(x, dtype), (128,), None, None, 1e-5), dtype, "layernorm (no affine)")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -35,6 +35,14 @@ int main() {
         us = time_launches(20, [&] { cobevt_conv3x3_nhwc(a, w, bias, r, o, d5, 0); });
         printf("conv3x3 256->256 20x32x32 : %.2f us\n", us);
     }
+    {
+        float* gam; hipMalloc(&gam, 4096); hipMemset(gam, 0, 4096);
+        for (int M : {5120, 81920}) for (int ln = 0; ln < 2; ++ln) for (int N : {128, 384}) {
+            long d[12] = {0, M, N, 128, 128, 128, 0, 0, 1, M, 1, M};
+            float us = time_launches(30, [&] { cobevt_linear_rows(a, w, bias, nullptr, ln ? gam : nullptr, ln ? gam : nullptr, nullptr, nullptr, o, d, 1e-5f, 0); });
+            printf("gemm_rows 128->%d M=%6d ln=%d : %.2f us\n", N, M, ln, us);
+        }
+    }
     // alternate two different kernels (code of each evicted?) 
     {
         int dims[21] = {0, 1, 1, 5120, 128, 1, 5120, 128, 1, 1, 1, 0, 128, 128, 0, 0, 0, 0, 1, 5120, 0};
