@@ -107,9 +107,12 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
     const int h = lane >> 5, ql = lane & 31;
+    // grid = (windows*heads, query tiles, batch): the query-tile blocks of one (window, head) are gridDim.x apart in
+    // dispatch order, i.e. (for the usual multiple-of-8 window*head counts) on the SAME XCD, so its L2 serves their
+    // shared K/V instead of 8 XCDs each fetching it from HBM (rocprofv3 FETCH_SIZE was 3x the algorithmic bytes).
     const int b = blockIdx.z;
-    const int l = blockIdx.y / p.heads, head = blockIdx.y - l * p.heads;
-    const int qtile = blockIdx.x;
+    const int l = blockIdx.x / p.heads, head = blockIdx.x - l * p.heads;
+    const int qtile = blockIdx.y;
 
     // ---- this lane's query token (mean mode: wave = camera; waves beyond ncam only help staging)
     const int P = p.qmap.w1 * p.qmap.w2;
@@ -423,8 +426,8 @@ extern "C" int cobevt_window_attention(const void* q, const void* k, const void*
     if (p.mean_q && (p.qmap.ncam > 8 || p.omap.ncam != 1)) return COBEVT_ERR_UNSUPPORTED;
     const int P = p.qmap.w1 * p.qmap.w2;
     dim3 grid, block;
-    if (p.mean_q) { block = dim3(64 * (p.qmap.ncam < 4 ? 4 : p.qmap.ncam)); grid = dim3((P + 31) / 32, p.L * p.heads, p.B); }
-    else { block = dim3(256); grid = dim3((p.Nq + 127) / 128, p.L * p.heads, p.B); }
+    if (p.mean_q) { block = dim3(64 * (p.qmap.ncam < 4 ? 4 : p.qmap.ncam)); grid = dim3(p.L * p.heads, (P + 31) / 32, p.B); }
+    else { block = dim3(256); grid = dim3(p.L * p.heads, (p.Nq + 127) / 128, p.B); }
     if (grid.y > 65535 || grid.z > 65535) return COBEVT_ERR_SHAPE;
     size_t lds = dtype == 0 ? AttnLds<bf16_t>::kFixed : AttnLds<float>::kFixed;
     if (p.bias_mode) lds += (size_t)p.bias_rows * 4;

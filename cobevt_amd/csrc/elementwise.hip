@@ -72,44 +72,51 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* in, const float
 // ---------------------------------------------------------------------------------------------
 // Camera-ray positional embedding:  img_embed = L2norm_c( img_embed_conv(E_inv @ pad1(I_inv @ pixel)) - cam_embed(E_inv[:, 3]) )
 // reference: fax_modules.py:346-358.  Output (BN, h, w, D) channels-last.
+// One workgroup = one camera (blockIdx.y) x a strip of pixels; a lane keeps the weights of its 8 channels and the
+// camera embedding c_embed in registers and walks the strip (the weights used to be re-read per pixel).
+constexpr int kEmbedPixPerBlock = 256;
+
 template <typename T>
 __global__ __launch_bounds__(256) void ray_embed_kernel(const float* I_inv, const float* E_inv, const float* plane,
                                                         const float* w_img, const float* w_cam, T* out, int BN,
                                                         int hw, int D) {
-    const int G = D >> 3;
-    const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / G;
-    const int gl = threadIdx.x & (G - 1);
-    if (gid >= (long)BN * hw) return;
-    const int bn = (int)(gid / hw), pix = (int)(gid - (long)bn * hw);
+    const int G = D >> 3;                       // lanes per pixel
+    const int gl = threadIdx.x & (G - 1), gp = threadIdx.x / G, ngroups = 256 / G;
+    const int bn = blockIdx.y;
     const float* I = I_inv + bn * 9;
     const float* E = E_inv + bn * 16;
-    const float px = plane[pix], py = plane[hw + pix], pz = plane[2 * hw + pix];
-    float cam[4];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) cam[r] = I[r * 3 + 0] * px + I[r * 3 + 1] * py + I[r * 3 + 2] * pz;
-    cam[3] = 1.f;
-    float d4[4], c4[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        d4[r] = E[r * 4 + 0] * cam[0] + E[r * 4 + 1] * cam[1] + E[r * 4 + 2] * cam[2] + E[r * 4 + 3] * cam[3];
-        c4[r] = E[r * 4 + 3];
-    }
-    float v[8], ss = 0.f;
+    float wi[8][4], ce[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int ch = gl * 8 + e;
-        const float* wi = w_img + ch * 4;
-        const float* wc = w_cam + ch * 4;
-        const float de = wi[0] * d4[0] + wi[1] * d4[1] + wi[2] * d4[2] + wi[3] * d4[3];
-        const float ce = wc[0] * c4[0] + wc[1] * c4[1] + wc[2] * c4[2] + wc[3] * c4[3];
-        v[e] = de - ce;
-        ss += v[e] * v[e];
+        const float4 a = *(const float4*)(w_img + ch * 4), c = *(const float4*)(w_cam + ch * 4);
+        wi[e][0] = a.x; wi[e][1] = a.y; wi[e][2] = a.z; wi[e][3] = a.w;
+        ce[e] = c.x * E[3] + c.y * E[7] + c.z * E[11] + c.w * E[15];
     }
-    ss = wave_sum_xor(ss, G);
-    const float inv = 1.0f / (sqrtf(ss) + 1e-7f);
+    const int p0 = blockIdx.x * kEmbedPixPerBlock;
+    for (int pix = p0 + gp; pix < min(p0 + kEmbedPixPerBlock, hw); pix += ngroups) {
+        const float px = plane[pix], py = plane[hw + pix], pz = plane[2 * hw + pix];
+        float cam[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= inv;
-    store8<T>(out + gid * D + gl * 8, v);
+        for (int r = 0; r < 3; ++r) cam[r] = I[r * 3 + 0] * px + I[r * 3 + 1] * py + I[r * 3 + 2] * pz;
+        cam[3] = 1.f;
+        float d4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            d4[r] = E[r * 4 + 0] * cam[0] + E[r * 4 + 1] * cam[1] + E[r * 4 + 2] * cam[2] + E[r * 4 + 3] * cam[3];
+        float v[8], ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float de = wi[e][0] * d4[0] + wi[e][1] * d4[1] + wi[e][2] * d4[2] + wi[e][3] * d4[3];
+            v[e] = de - ce[e];
+            ss += v[e] * v[e];
+        }
+        ss = wave_sum_xor(ss, G);
+        const float inv = 1.0f / (sqrtf(ss) + 1e-7f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= inv;
+        store8<T>(out + ((size_t)bn * hw + pix) * D + gl * 8, v);
+    }
 }
 
 // BEV query positional embedding + prior: query[b,n] = L2norm_c( bev_embed(world) - cam_embed(c) ) + x[b]
@@ -119,33 +126,38 @@ __global__ __launch_bounds__(256) void bev_embed_kernel(const float* E_inv, cons
                                                         const float* b_bev, const float* w_cam, const T* x, T* out,
                                                         int B, int n, int hw, int D) {
     const int G = D >> 3;
-    const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / G;
-    const int gl = threadIdx.x & (G - 1);
-    if (gid >= (long)B * n * hw) return;
-    const int bn = (int)(gid / hw), pix = (int)(gid - (long)bn * hw);
-    const int b = bn / n;
+    const int gl = threadIdx.x & (G - 1), gp = threadIdx.x / G, ngroups = 256 / G;
+    const int bn = blockIdx.y, b = bn / n;
     const float* E = E_inv + bn * 16;
-    const float wx = world[pix], wy = world[hw + pix];
-    float c4[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) c4[r] = E[r * 4 + 3];
-    float v[8], ss = 0.f;
+    float wb[8][2], off[8];                     // off = bias - c_embed
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int ch = gl * 8 + e;
-        const float we = w_bev[ch * 2 + 0] * wx + w_bev[ch * 2 + 1] * wy + b_bev[ch];
-        const float* wc = w_cam + ch * 4;
-        const float ce = wc[0] * c4[0] + wc[1] * c4[1] + wc[2] * c4[2] + wc[3] * c4[3];
-        v[e] = we - ce;
-        ss += v[e] * v[e];
+        const float4 c = *(const float4*)(w_cam + ch * 4);
+        wb[e][0] = w_bev[ch * 2 + 0]; wb[e][1] = w_bev[ch * 2 + 1];
+        off[e] = c.x * E[3] + c.y * E[7] + c.z * E[11] + c.w * E[15];
     }
-    ss = wave_sum_xor(ss, G);
-    const float inv = 1.0f / (sqrtf(ss) + 1e-7f);
-    float xv[8];
-    load8<T>(x + ((size_t)b * hw + pix) * D + gl * 8, xv);
+    float bb[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = v[e] * inv + xv[e];
-    store8<T>(out + gid * D + gl * 8, v);
+    for (int e = 0; e < 8; ++e) bb[e] = b_bev[gl * 8 + e];
+    const int p0 = blockIdx.x * kEmbedPixPerBlock;
+    for (int pix = p0 + gp; pix < min(p0 + kEmbedPixPerBlock, hw); pix += ngroups) {
+        const float wx = world[pix], wy = world[hw + pix];
+        float v[8], ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float we = wb[e][0] * wx + wb[e][1] * wy + bb[e];
+            v[e] = we - off[e];
+            ss += v[e] * v[e];
+        }
+        ss = wave_sum_xor(ss, G);
+        const float inv = 1.0f / (sqrtf(ss) + 1e-7f);
+        float xv[8];
+        load8<T>(x + ((size_t)b * hw + pix) * D + gl * 8, xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * inv + xv[e];
+        store8<T>(out + ((size_t)bn * hw + pix) * D + gl * 8, v);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -436,10 +448,12 @@ extern "C" int cobevt_fax_ray_embed(const float* I_inv, const float* E_inv, cons
                                     const float* w_cam, void* out, int dtype, int BN, int hw, int D, hipStream_t stream) {
     if (!I_inv || !E_inv || !image_plane || !w_img || !w_cam || !out) return COBEVT_ERR_ARG;
     if (!group_ok(D) || BN < 1 || hw < 1) return COBEVT_ERR_SHAPE;
-    const long items = (long)BN * hw * (D >> 3);
-    if (dtype == 0) return launch1d(ray_embed_kernel<bf16_t>, items, stream, I_inv, E_inv, image_plane, w_img, w_cam, (bf16_t*)out, BN, hw, D);
-    if (dtype == 1) return launch1d(ray_embed_kernel<float>, items, stream, I_inv, E_inv, image_plane, w_img, w_cam, (float*)out, BN, hw, D);
-    return COBEVT_ERR_ARG;
+    if (BN > 65535) return COBEVT_ERR_SHAPE;
+    const dim3 grid((hw + kEmbedPixPerBlock - 1) / kEmbedPixPerBlock, BN), block(256);
+    if (dtype == 0) hipLaunchKernelGGL(ray_embed_kernel<bf16_t>, grid, block, 0, stream, I_inv, E_inv, image_plane, w_img, w_cam, (bf16_t*)out, BN, hw, D);
+    else if (dtype == 1) hipLaunchKernelGGL(ray_embed_kernel<float>, grid, block, 0, stream, I_inv, E_inv, image_plane, w_img, w_cam, (float*)out, BN, hw, D);
+    else return COBEVT_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
 extern "C" int cobevt_fax_bev_embed(const float* E_inv, const float* world, const float* w_bev, const float* b_bev,
@@ -447,10 +461,12 @@ extern "C" int cobevt_fax_bev_embed(const float* E_inv, const float* world, cons
                                     hipStream_t stream) {
     if (!E_inv || !world || !w_bev || !b_bev || !w_cam || !x || !out) return COBEVT_ERR_ARG;
     if (!group_ok(D) || B < 1 || n < 1 || hw < 1) return COBEVT_ERR_SHAPE;
-    const long items = (long)B * n * hw * (D >> 3);
-    if (dtype == 0) return launch1d(bev_embed_kernel<bf16_t>, items, stream, E_inv, world, w_bev, b_bev, w_cam, (const bf16_t*)x, (bf16_t*)out, B, n, hw, D);
-    if (dtype == 1) return launch1d(bev_embed_kernel<float>, items, stream, E_inv, world, w_bev, b_bev, w_cam, (const float*)x, (float*)out, B, n, hw, D);
-    return COBEVT_ERR_ARG;
+    if ((long)B * n > 65535) return COBEVT_ERR_SHAPE;
+    const dim3 grid((hw + kEmbedPixPerBlock - 1) / kEmbedPixPerBlock, B * n), block(256);
+    if (dtype == 0) hipLaunchKernelGGL(bev_embed_kernel<bf16_t>, grid, block, 0, stream, E_inv, world, w_bev, b_bev, w_cam, (const bf16_t*)x, (bf16_t*)out, B, n, hw, D);
+    else if (dtype == 1) hipLaunchKernelGGL(bev_embed_kernel<float>, grid, block, 0, stream, E_inv, world, w_bev, b_bev, w_cam, (const float*)x, (float*)out, B, n, hw, D);
+    else return COBEVT_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
 extern "C" int cobevt_maxpool3x3s2(const void* in, void* out, int dtype, int N, int H, int W, int C, hipStream_t stream) {
