@@ -143,8 +143,8 @@ class CrossWinAttention(HipModule):
     def _project(self, name, seq, x):
         return ops.linear(x, rt.linear_plan(self, name, seq[1], ln=seq[0]))
 
-    def attend(self, q_src, k_src, v_src, qmap, kmap, omap, batch, skip, out_shape):
-        """q_src/k_src/v_src: token-major tensors whose rows the maps address; returns proj(attn) (+skip)."""
+    def attend_core(self, q_src, k_src, v_src, qmap, kmap, omap, batch, out_shape):
+        """Projections + fused window attention; returns the head-merged attention output BEFORE self.proj."""
         inner = self.heads * self.dim_head
         qt = self._project("q", self.to_q, q_src)
         kt = self._project("k", self.to_k, k_src)
@@ -152,6 +152,11 @@ class CrossWinAttention(HipModule):
         a = torch.empty(tuple(out_shape) + (inner,), device=qt.device, dtype=qt.dtype)
         ops.window_attention(qt, kt, vt, a, qmap, kmap, omap, batch, self.heads, self.scale, inner, inner, inner, inner,
                              mean_q=qmap[1] > 1)
+        return a
+
+    def attend(self, q_src, k_src, v_src, qmap, kmap, omap, batch, skip, out_shape):
+        """q_src/k_src/v_src: token-major tensors whose rows the maps address; returns proj(attn) (+skip)."""
+        a = self.attend_core(q_src, k_src, v_src, qmap, kmap, omap, batch, out_shape)
         return ops.linear(a, rt.linear_plan(self, "proj", self.proj), residual=skip)
 
     def forward(self, q, k, v, skip=None):
@@ -211,9 +216,15 @@ class CrossViewSwapAttention(HipModule):
         wp = ((w + ww) // ww) * ww if w % ww != 0 else w
         return hp, wp
 
-    def _mlp(self, name, prenorm, mlp, x):
-        t = ops.linear(x, rt.linear_plan(self, name + ".0", mlp[0], act=2, ln=prenorm))
-        return ops.linear(t, rt.linear_plan(self, name + ".2", mlp[2]), residual=x)
+    def _proj_mlp(self, name, attn, a, skip, prenorm, mlp, postnorm=None):
+        """proj(a) + skip -> x + mlp(prenorm(x)) -> postnorm : one fused launch in bf16 mode (ops.attn_mlp_chain)."""
+        post = None
+        if postnorm is not None:
+            post = (rt.f32_param(self, name + ".post.w", postnorm.weight), rt.f32_param(self, name + ".post.b", postnorm.bias),
+                    postnorm.eps)
+        return ops.attn_mlp_chain(a, skip, rt.linear_plan(attn, "proj", attn.proj),
+                                  rt.linear_plan(self, name + ".0", mlp[0], act=2, ln=prenorm),
+                                  rt.linear_plan(self, name + ".2", mlp[2]), post)
 
     def forward_nhwc(self, index, x, bev, feature, I_inv, E_inv):
         """x (b,H,W,d); feature (b*n,h,w,C) compute dtype; I_inv (b*n,3,3), E_inv (b*n,4,4) fp32 -> (b,H,W,d)"""
@@ -263,12 +274,12 @@ class CrossViewSwapAttention(HipModule):
             raise CobevtHipError("query windows %dx%d != key windows %dx%d" % (qmap_1[6], qmap_1[7], kwin[6], kwin[7]))
 
         # local-to-local: window queries x window keys; per-camera queries are averaged in-kernel
-        y = self.cross_win_attend_1.attend(query, key, val, qmap_n, kwin, qmap_1, b, x if self.skip else None, (b, H, W))
-        y = self._mlp("mlp1", self.prenorm_1, self.mlp_1, y)
+        a = self.cross_win_attend_1.attend_core(query, key, val, qmap_n, kwin, qmap_1, b, (b, H, W))
+        y = self._proj_mlp("mlp1", self.cross_win_attend_1, a, x if self.skip else None, self.prenorm_1, self.mlp_1)
         # local-to-global: the n query replicas of the reference are identical -> one copy
-        z = self.cross_win_attend_2.attend(y, key, val, qmap_1, kgrid, qmap_1, b, y if self.skip else None, (b, H, W))
-        z = self._mlp("mlp2", self.prenorm_2, self.mlp_2, z)
-        return rt.layernorm(self, "postnorm", self.postnorm, z)
+        a = self.cross_win_attend_2.attend_core(y, key, val, qmap_1, kgrid, qmap_1, b, (b, H, W))
+        return self._proj_mlp("mlp2", self.cross_win_attend_2, a, y if self.skip else None, self.prenorm_2, self.mlp_2,
+                              self.postnorm)
 
     def forward(self, index, x, bev, feature, I_inv, E_inv):
         """x (b,d,H,W); feature (b,n,C,h,w); I_inv (b,n,3,3); E_inv (b,n,4,4) -> (b,d,H,W)"""

@@ -39,7 +39,7 @@ class Attention(HipModule):
                  + (ca[:, None] - ca[None, :] + w - 1) * (2 * w - 1) + (cb[:, None] - cb[None, :] + w - 1))
         self.register_buffer("relative_position_index", index)
 
-    def forward_fused(self, xn, residual=None, mask=None, mode=2, ln=None):
+    def forward_fused(self, xn, residual=None, mask=None, mode=2, ln=None, core_only=False):
         """xn (compute dtype; LayerNorm'ed already, or raw with ln=<nn.LayerNorm container> to fuse it): mode 2 -> (b l X Y w1 w2 d) partitioned, mask (b X Y w1 w2 1 l);
         mode 0 (window) / 1 (grid) -> (b l H W d), mask (b H W 1 l).  Returns to_out(attn) (+ residual)."""
         L, w = self.window_size[0], self.window_size[1]
@@ -61,6 +61,8 @@ class Attention(HipModule):
             mk = mk if mk.is_contiguous() else mk.contiguous()
         ops.window_attention(qkv, qkv, qkv, out, m, m, m, b, self.heads, self.scale, 3 * d, 3 * d, 3 * d, d, koff=d,
                              voff=2 * d, bias_table=table, bias_L=L, mask=mk)
+        if core_only:
+            return out
         return ops.linear(out, rt.linear_plan(self, "out", self.to_out[0]), residual=residual)
 
     def forward(self, x, mask=None):
@@ -79,6 +81,16 @@ def _from_blhwc(x):
     return x.permute(0, 1, 4, 2, 3)
 
 
+def _attn_ffd(attn_res, ffd_res, x, mask, mode):
+    """PreNormResidual(Attention) followed by PreNormResidual(FeedForward) on (b, l, h, w, d):
+    attention core, then to_out + residual + LayerNorm + FeedForward + residual as one fused row chain."""
+    attn, ffd = attn_res.fn, ffd_res.fn
+    a = attn.forward_fused(x, mask=mask, mode=mode, ln=attn_res.norm, core_only=True)
+    return ops.attn_mlp_chain(a, x, rt.linear_plan(attn, "out", attn.to_out[0]),
+                              rt.linear_plan(ffd, "fc1", ffd.net[0], act=2, ln=ffd_res.norm),
+                              rt.linear_plan(ffd, "fc2", ffd.net[3]))
+
+
 class SwapFusionBlockMask(HipModule):
     """swap_fusion_modules.py:131-192."""
 
@@ -91,10 +103,8 @@ class SwapFusionBlockMask(HipModule):
         self.grid_ffd = PreNormResidual(input_dim, FeedForward(input_dim, mlp_dim, drop_out))
 
     def forward_blhwc(self, x, mask):
-        x = self.window_attention.forward_fused(x, mask=mask, mode=0)
-        x = self.window_ffd.forward_fused(x)
-        x = self.grid_attention.forward_fused(x, mask=mask, mode=1)
-        return self.grid_ffd.forward_fused(x)
+        x = _attn_ffd(self.window_attention, self.window_ffd, x, mask, 0)
+        return _attn_ffd(self.grid_attention, self.grid_ffd, x, mask, 1)
 
     def forward(self, x, mask):
         """x: (b, l, c, h, w); mask: (b, h, w, 1, l)"""
@@ -118,10 +128,8 @@ class SwapFusionBlock(HipModule):
             nn.Identity())
 
     def forward_blhwc(self, x, mask=None):
-        x = self.block[1].forward_fused(x, mode=0)
-        x = self.block[2].forward_fused(x)
-        x = self.block[5].forward_fused(x, mode=1)
-        return self.block[6].forward_fused(x)
+        x = _attn_ffd(self.block[1], self.block[2], x, None, 0)
+        return _attn_ffd(self.block[5], self.block[6], x, None, 1)
 
     def forward(self, x, mask=None):
         self._require_inference(x)

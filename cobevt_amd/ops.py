@@ -15,6 +15,7 @@ from .lib import CobevtHipError
 BF16, FP32 = 0, 1
 USE_CONV3X3 = True   # route eligible 3x3 convs to the LDS-patch kernel (tests flip this to cover both paths)
 USE_GEMM_ROWS = True  # route 1x1 stride-1 convs / linears to the dense-row GEMM with fused LayerNorm
+USE_ROW_CHAIN = True  # fuse out-proj + skip + pre-norm MLP (+ post-norm) after attention into one launch (bf16)
 
 
 def dcode(dtype):
@@ -471,4 +472,38 @@ def channel_affine(x, scale, shift):
     n, c = x.shape[0], x.shape[1]
     rc = _L.load().cobevt_channel_affine(_p(x), _p(scale), _p(shift), _p(out), n, c, x.numel() // (n * c), _stream())
     _L.check(rc, "cobevt_channel_affine")
+    return out
+
+
+def attn_mlp_chain(a, skip, plan_p, plan_1, plan_2, post_ln=None):
+    """out = postLN( y + fc2(GELU(fc1(LN(y)))) ),  y = proj(a) + skip.   a, skip: (..., C) contiguous.
+    plan_1 must be built with ln=<prenorm> (affine folded) and act=GELU; post_ln = (gamma, beta, eps) fp32 or None.
+    One fused launch in bf16 mode when the shapes fit (C <= 128, hidden <= 256); otherwise three GEMM launches."""
+    _need_cuda(a, skip)
+    c, hd = plan_p.cout, plan_1.cout
+    fusable = (USE_ROW_CHAIN and a.dtype == torch.bfloat16 and plan_p.wgt_rows is not None and plan_1.wgt_rows is not None
+               and plan_2.wgt_rows is not None and plan_1.has_ln and plan_1.act == 2 and plan_p.act == 0
+               and plan_2.act == 0 and not plan_p.has_ln and not plan_2.has_ln and plan_p.K == c and plan_1.K == c
+               and plan_2.K == hd and plan_2.cout == c and c <= 128 and c % 8 == 0 and hd <= 256 and hd % 8 == 0
+               and plan_p.kp_rows == 128 and plan_1.kp_rows == 128 and a.shape[-1] == c and a.is_contiguous()
+               and (skip is None or (skip.is_contiguous() and skip.shape == a.shape)))
+    if not fusable:
+        y = linear(a, plan_p, residual=skip)
+        z = linear(linear(y, plan_1), plan_2, residual=y)
+        return layernorm(z, post_ln[0], post_ln[1], post_ln[2]) if post_ln is not None else z
+    m = a.numel() // c
+    out = torch.empty_like(a)
+    dims = _ints([0, m, c, hd, plan_2.kp_rows])
+    pg, pb, pe = post_ln if post_ln is not None else (None, None, 0.0)
+
+    def cost():
+        flops = 2.0 * m * (c * c + 2 * c * hd)
+        return flops, float((3 if skip is not None else 2) * m * c * 2 + (c * c + 2 * c * hd) * 2)
+
+    with _timed("row_chain|C%d H%d M=%d%s" % (c, hd, m, " post" if post_ln is not None else ""), cost):
+        rc = _L.load().cobevt_attn_mlp_chain(_p(a), _p(skip), _p(out), _p(plan_p.wgt_rows), _p(plan_p.bias),
+                                             _p(plan_1.wgt_rows), _p(plan_1.bias), _p(plan_2.wgt_rows), _p(plan_2.bias),
+                                             _p(pg), _p(pb), dims, ctypes.c_float(plan_1.ln_eps), ctypes.c_float(pe),
+                                             _stream())
+    _L.check(rc, "cobevt_attn_mlp_chain")
     return out

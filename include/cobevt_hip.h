@@ -77,6 +77,16 @@ int cobevt_linear_rows(const void* in, const void* wgt, const float* bias, const
                        float ln_eps, hipStream_t stream);
 
 /*
+ * Fused row-local chain after an attention (bf16 mode):  y = a.Wp^T (+bp) + skip ;  z = y + fc2(GELU(fc1'(norm(y)))) ;
+ * out = post-LayerNorm(z) (optional).  Replaces fax_modules.py:240,246-247 + :411 / :435-437 and
+ * swap_fusion_modules.py:126,177 + base_transformer.py:102-124 in one launch (hidden activations stay in LDS).
+ * wp [C][128], w1 [Hd][128] (LayerNorm affine folded in), w2 [C][Hdp]; dims (int32[5]): dtype(0), M, C(<=128), Hd(<=256), Hdp.
+ */
+int cobevt_attn_mlp_chain(const void* a, const void* skip, void* out, const void* wp, const float* bp, const void* w1,
+                          const float* b1, const void* w2, const float* b2, const float* post_gamma,
+                          const float* post_beta, const int* dims, float eps1, float eps_post, hipStream_t stream);
+
+/*
  * Fused gathered attention: window / dilated-grid partition -> QK^T -> (+relative position bias, key mask)
  * -> softmax -> PV -> (mean over query cameras) -> partition reverse, for projected token matrices.
  * Replaces: CrossWinAttention core, fax_modules.py:211-237,243 with the partitions of :399-404,:417-424 and

@@ -226,6 +226,46 @@ def test_gemm_rows_fused_layernorm(cuda, dtype, k, n, rows):
     check(y, y2.float().cpu(), dtype, "gemm_rows vs igemm")
 
 
+@pytest.mark.parametrize("c,hd,rows,post,proj_bias,skip", [(128, 256, 1000, True, True, True), (128, 256, 130, False, False, True),
+                                                           (64, 128, 70, False, False, True), (32, 64, 333, True, True, False)])
+def test_attn_mlp_chain_fused(cuda, c, hd, rows, post, proj_bias, skip):
+    """proj + skip -> pre-norm MLP + residual -> post-norm in ONE launch (bf16) vs the three-GEMM path vs torch fp32."""
+    dtype = torch.bfloat16
+    a = procedural_input("ch.a", (rows, c), 0, -2, 2)
+    sk = procedural_input("ch.s", (rows, c), 0, -1, 1) if skip else None
+    mk = lambda key, shape, fan: procedural_input(key, shape, 0) * math.sqrt(3.0 / fan)
+    wp, w1, w2 = mk("ch.wp", (c, c), c), mk("ch.w1", (hd, c), c), mk("ch.w2", (c, hd), hd)
+    bp = procedural_input("ch.bp", (c,), 0, -0.2, 0.2) if proj_bias else None
+    b1, b2 = procedural_input("ch.b1", (hd,), 0, -0.2, 0.2), procedural_input("ch.b2", (c,), 0, -0.2, 0.2)
+    g1, be1 = 0.8 + 0.4 * procedural_input("ch.g1", (c,), 0, 0, 1), procedural_input("ch.be1", (c,), 0, -0.2, 0.2)
+    g2, be2 = 0.8 + 0.4 * procedural_input("ch.g2", (c,), 0, 0, 1), procedural_input("ch.be2", (c,), 0, -0.2, 0.2)
+
+    class LN1(object):
+        weight, bias, eps = g1, be1, 1e-5
+    pp = ops.ConvPlan(wp, bp, dtype=dtype, device=cuda)
+    p1 = ops.ConvPlan(w1, b1, act=2, dtype=dtype, device=cuda, ln=LN1)
+    p2 = ops.ConvPlan(w2, b2, dtype=dtype, device=cuda)
+    post_ln = (g2.to(cuda), be2.to(cuda), 1e-5) if post else None
+    ad = a.to(cuda).to(dtype)
+    sd = sk.to(cuda).to(dtype) if skip else None
+    assert ops.USE_ROW_CHAIN
+    y = ops.attn_mlp_chain(ad, sd, pp, p1, p2, post_ln)
+    ops.USE_ROW_CHAIN = False
+    try:
+        y3 = ops.attn_mlp_chain(ad, sd, pp, p1, p2, post_ln)
+    finally:
+        ops.USE_ROW_CHAIN = True
+    # torch fp32 definition on the bf16-rounded operands
+    yy = F.linear(rnd(a, dtype), rnd(wp, dtype), bp) + (rnd(sk, dtype) if skip else 0)
+    zz = yy + F.linear(F.gelu(F.linear(F.layer_norm(yy, (c,), g1, be1, 1e-5), rnd(w1, dtype), b1)), rnd(w2, dtype), b2)
+    ref = F.layer_norm(zz, (c,), g2, be2, 1e-5) if post else zz
+    s = ref.abs().max().item()
+    e_f, e_3 = (y.float().cpu() - ref).abs().max().item(), (y3.float().cpu() - ref).abs().max().item()
+    assert e_f <= 3e-2 * s, "fused chain: %.3e vs scale %.3e" % (e_f, s)
+    assert e_3 <= 3e-2 * s
+    assert (y.float() - y3.float()).abs().max().item() <= 3e-2 * s
+
+
 # ---------------------------------------------------------------------------------------------
 def _attn_ref(q, k, v, scale, bias=None, key_mask=None):
     """q (G, Nq, dh), k/v (G, Nk, dh) fp32 -> (G, Nq, dh)"""
