@@ -105,7 +105,7 @@ class Runner(object):
         return self.out
 
 
-MFMA_FAMILIES = ("conv3x3", "gemm_rows", "igemm", "attention")
+MFMA_FAMILIES = ("conv3x3", "gemm_rows", "row_chain", "igemm", "attention", "stem7x7")
 
 
 def roofline_leg(runner, dtype_name):

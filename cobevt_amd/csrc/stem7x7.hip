@@ -1,0 +1,219 @@
+// ResNet stem: 7x7 / stride 2 / pad 3 convolution on the 3-channel fp32 channels-last image (+ folded BN + ReLU),
+// torchvision resnet conv1/bn1/relu reached from opv2v/opencood/models/backbones/resnet_ms.py:67-69 (gfx950).
+//
+// Reformulated as a 4x4 stride-1 convolution over the 2x2 space-to-depth image:
+//     S[Y][X][dy][dx][c] = in[2Y+dy][2X+dx][c]                      (12 channels, padded to 16)
+//     out[oy][ox][n] = sum_{a,b in 0..3} sum_{dy,dx,c} S[oy+a-2][ox+b-2][dy][dx][c] * W'[n][a][b][dy][dx][c]
+//     W'[n][a][b][dy][dx][c] = w[n][c][2a+dy-1][2b+dx-1]   (0 where an index is -1)
+// so every tap is exactly one 32-byte k-group (bf16) whose A fragment is read straight out of an LDS patch at the
+// tap's pixel offset, as in conv3x3.hip — no im2col, no per-element tap decoding (the generic igemm "small Cin" path
+// spent 269 us here).  A workgroup (4 waves, 8x16 output pixels x 64 channels) is persistent: the [64][16][16]
+// weight tile stays in LDS, the next tile's patch is prefetched into registers (fp32 image read once, converted on
+// the fly), and the epilogue is staged through LDS for 16-byte coalesced stores.
+#include "common.hpp"
+
+namespace cobevt {
+
+struct StemParams {
+    const float* in;     // (N, H, W, 3) fp32
+    const void* wgt;     // [Cout][16 taps][16 ch]
+    const float* bias;   // folded BN shift
+    void* out;           // (N, Ho, Wo, Cout)
+    int N, H, W, Ho, Wo, Cout;
+    int act;
+    int tiles_y, tiles_x, tiles_n, ntiles;
+};
+
+template <typename T> struct StemCfg {
+    static constexpr int KG = 16 * Elem<T>::kBytes / 32;      // k-groups per tap (1 bf16, 2 fp32)
+    static constexpr int PIX = 16 * Elem<T>::kBytes + 16;     // patch pixel stride (odd multiple of 16 bytes)
+    static constexpr int PH = 11, PW = 19;                    // (8 + 3) x (16 + 3) space-to-depth pixels
+    static constexpr int PROW = (PW * PIX + 255) / 256 * 256;
+    static constexpr int PATCH = PH * PROW;
+    static constexpr int WROW = 16 * 16 * Elem<T>::kBytes + 16;
+    static constexpr int WBYTES = 64 * WROW;
+    static constexpr int SROW = 64 * 4 + 16;                  // fp32 staging row (64 channels)
+    static constexpr int STAGE = 128 * SROW;
+    static constexpr int LDS = PATCH + WBYTES + STAGE;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem7x7_kernel(StemParams p) {
+    using C = StemCfg<T>;
+    constexpr int KG = C::KG;
+    constexpr int NPIECE = C::PH * C::PW * 2 * 3;             // (pixel, dy, 2-float piece): 8-byte global loads
+    constexpr int P_IT = (NPIECE + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* patch = smem;
+    unsigned char* wl = smem + C::PATCH;
+    float* stage = (float*)(smem + C::PATCH + C::WBYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, ql = lane & 31;
+
+    // zero the patch once: channels 12..15 of every pixel (and the pad bytes) stay zero for the whole kernel
+    for (int i = tid; i < C::PATCH / 16; i += 256) ((uint4*)patch)[i] = make_uint4(0, 0, 0, 0);
+
+    float2 preg[P_IT];
+    auto decode = [&](int tile, int& img, int& oy0, int& ox0, int& n0) {
+        const int tn = tile % p.tiles_n;
+        int rest = tile / p.tiles_n;
+        const int tx = rest % p.tiles_x; rest /= p.tiles_x;
+        const int ty = rest % p.tiles_y;
+        img = rest / p.tiles_y;
+        oy0 = ty * 8; ox0 = tx * 16; n0 = tn * 64;
+    };
+    auto load_patch = [&](int tile) {
+        int img, oy0, ox0, n0;
+        decode(tile, img, oy0, ox0, n0);
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const int item = tid + it * 256;
+            float2 v = make_float2(0.f, 0.f);
+            if (item < NPIECE) {
+                const int pc = item % 3, rest = item / 3;     // piece = 2 consecutive floats of the 6 (dx, c) values
+                const int dy = rest & 1, pix = rest >> 1;
+                const int py = pix / C::PW, px = pix - py * C::PW;
+                const int iy = 2 * (oy0 - 2 + py) + dy, ix = 2 * (ox0 - 2 + px);     // image row / first image column
+                // the 6 floats in[iy][ix..ix+1][0..2] are contiguous; columns are valid in pairs (W is even)
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix + 1 < p.W)
+                    v = *(const float2*)(p.in + (((size_t)img * p.H + iy) * p.W + ix) * 3 + pc * 2);
+            }
+            preg[it] = v;
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const int item = tid + it * 256;
+            if (item < NPIECE) {
+                const int pc = item % 3, rest = item / 3;
+                const int dy = rest & 1, pix = rest >> 1;
+                const int py = pix / C::PW, px = pix - py * C::PW;
+                unsigned char* dst = patch + py * C::PROW + px * C::PIX + (dy * 6 + pc * 2) * Elem<T>::kBytes;
+                if constexpr (Elem<T>::kIsBf16) *(uint32_t*)dst = pack_bf2(preg[it].x, preg[it].y);
+                else *(float2*)dst = preg[it];
+            }
+        }
+    };
+
+    // ---- weights resident in LDS: [64][16 taps][16 ch]
+    int img, oy0, ox0, n0;
+    int tile = blockIdx.x;
+    if (tile >= p.ntiles) return;
+    decode(tile, img, oy0, ox0, n0);
+    int n0_loaded = -1;
+    auto load_weights = [&](int nb) {
+        constexpr int PIECES = 16 * 16 * Elem<T>::kBytes / 16;        // 16-byte pieces per weight row
+        for (int i = tid; i < 64 * PIECES; i += 256) {
+            const int row = i / PIECES, j = i - row * PIECES;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (nb + row < p.Cout) v = *(const uint4*)((const unsigned char*)p.wgt + ((size_t)(nb + row) * PIECES + j) * 16);
+            *(uint4*)(wl + row * C::WROW + j * 16) = v;
+        }
+        n0_loaded = nb;
+    };
+    __syncthreads();          // patch zeroed
+    load_patch(tile);
+    load_weights(n0);
+
+    const int abase = ((2 * wave + (ql >> 4)) * C::PROW) + (ql & 15) * C::PIX + h * 16;   // wave owns output rows 2w, 2w+1
+    const int bbase = ql * C::WROW + h * 16;
+
+    for (; tile < p.ntiles; tile += gridDim.x) {
+        decode(tile, img, oy0, ox0, n0);
+        store_patch();
+        if (n0 != n0_loaded) { __syncthreads(); load_weights(n0); }
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < p.ntiles) load_patch(next);
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const unsigned char* pa = patch + abase + a * C::PROW + bb * C::PIX;
+                const unsigned char* pw = wl + bbase + (a * 4 + bb) * 16 * Elem<T>::kBytes;
+#pragma unroll
+                for (int g = 0; g < KG; ++g) {
+                    const uint4 af = *(const uint4*)(pa + g * 32);
+                    const uint4 b0 = *(const uint4*)(pw + g * 32);
+                    const uint4 b1 = *(const uint4*)(pw + 32 * C::WROW + g * 32);
+                    mfma_kgroup<T>(af, b0, acc[0]);
+                    mfma_kgroup<T>(af, b1, acc[1]);
+                }
+            }
+        }
+        // ---- epilogue: bias + activation staged as fp32, then coalesced 16-byte stores
+        constexpr int SR = C::SROW / 4;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int cl = b * 32 + ql;
+            const float bias = (p.bias && n0 + cl < p.Cout) ? p.bias[n0 + cl] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = acc_row(r, lane);
+                float v = acc[b][r] + bias;
+                v = p.act == 1 ? fmaxf(v, 0.f) : v;
+                stage[((2 * wave + (row >> 4)) * 16 + (row & 15)) * SR + cl] = v;
+            }
+        }
+        __syncthreads();      // staging complete; every wave is done with the patch -> next store_patch may overwrite it
+        constexpr int CH = Elem<T>::kChunk;
+        constexpr int CPP = 64 / CH;
+        T* out = (T*)p.out;
+        for (int item = tid; item < 128 * CPP; item += 256) {
+            const int px = item / CPP, cj = item - px * CPP;
+            const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15), col = n0 + cj * CH;
+            if (oy >= p.Ho || ox >= p.Wo || col >= p.Cout) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < CH; ++e) v[e] = stage[px * SR + cj * CH + e];
+            const size_t o = (((size_t)img * p.Ho + oy) * p.Wo + ox) * p.Cout + col;
+            if (col + CH <= p.Cout) *(uint4*)(out + o) = f32_to_chunk<T>(v);
+            else for (int e = 0; e < CH && col + e < p.Cout; ++e) store_elem<T>(out, o + e, v[e]);
+        }
+        // the next iteration's store_patch / staging writes are ordered by the barriers above and below
+        __syncthreads();
+    }
+}
+
+}  // namespace cobevt
+
+using namespace cobevt;
+
+// C-ABI entry point, see include/cobevt_hip.h
+extern "C" int cobevt_stem_conv7x7s2(const float* in, const void* wgt, const float* bias, void* out, const int* dims,
+                                     hipStream_t stream) {
+    // dims: [dtype, N, H, W, Cout, act]
+    if (!in || !wgt || !out || !dims) return COBEVT_ERR_ARG;
+    StemParams p;
+    const int dtype = dims[0];
+    p.in = in; p.wgt = wgt; p.bias = bias; p.out = out;
+    p.N = dims[1]; p.H = dims[2]; p.W = dims[3]; p.Cout = dims[4]; p.act = dims[5];
+    if (dtype != 0 && dtype != 1) return COBEVT_ERR_ARG;
+    if (p.N < 1 || p.H < 2 || p.W < 2 || (p.H & 1) || (p.W & 1) || p.Cout < 1) return COBEVT_ERR_SHAPE;
+    if (p.Cout % (dtype == 0 ? 8 : 4)) return COBEVT_ERR_SHAPE;
+    p.Ho = p.H / 2; p.Wo = p.W / 2;            // (H + 6 - 7) / 2 + 1 for even H
+    p.tiles_y = (p.Ho + 7) / 8; p.tiles_x = (p.Wo + 15) / 16; p.tiles_n = (p.Cout + 63) / 64;
+    const long nt = (long)p.N * p.tiles_y * p.tiles_x * p.tiles_n;
+    if (nt > 0x7fffffffL) return COBEVT_ERR_SHAPE;
+    p.ntiles = (int)nt;
+    const size_t lds = dtype == 0 ? StemCfg<bf16_t>::LDS : StemCfg<float>::LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)stem7x7_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StemCfg<bf16_t>::LDS);
+        (void)hipFuncSetAttribute((const void*)stem7x7_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StemCfg<float>::LDS);
+        attr_set = true;
+    }
+    const int per_cu = dtype == 0 ? 2 : 1;
+    const unsigned blocks = (unsigned)(nt < 256L * per_cu ? nt : 256L * per_cu);
+    if (dtype == 0) hipLaunchKernelGGL(stem7x7_kernel<bf16_t>, dim3(blocks), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL(stem7x7_kernel<float>, dim3(blocks), dim3(256), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}

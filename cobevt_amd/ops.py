@@ -15,6 +15,7 @@ from .lib import CobevtHipError
 BF16, FP32 = 0, 1
 USE_CONV3X3 = True   # route eligible 3x3 convs to the LDS-patch kernel (tests flip this to cover both paths)
 USE_GEMM_ROWS = True  # route 1x1 stride-1 convs / linears to the dense-row GEMM with fused LayerNorm
+USE_STEM = True       # 7x7/s2 image stem through the space-to-depth kernel instead of the generic small-Cin igemm
 USE_ROW_CHAIN = True  # fuse out-proj + skip + pre-norm MLP (+ post-norm) after attention into one launch (bf16)
 
 
@@ -191,6 +192,20 @@ class ConvPlan(object):
                     self.wgt3 = w3.to(torch.float32).to(dtype).to(device).contiguous()
                     self.cc3 = cc
                     break
+        # ResNet stem fast path (stem7x7.hip): 7x7 / stride 2 / pad 3 on 3 channels as a 4x4 conv on the 2x2
+        # space-to-depth image; W'[n][a][b][dy][dx][c] = w[n][c][2a+dy-1][2b+dx-1]
+        self.wgt_stem = None
+        if smallc and kh == 7 and kw == 7 and int(stride) == 2 and int(pad) == 3 and cin == 3 and pre_bn is None \
+                and int(store_mode) == 0 and not upsample and cout % (8 if self.code == BF16 else 4) == 0:
+            ws = torch.zeros(cout, 4, 4, 16, dtype=torch.float64)
+            for a in range(4):
+                for bb in range(4):
+                    for dy in range(2):
+                        for dx in range(2):
+                            ih, iw = 2 * a + dy - 1, 2 * bb + dx - 1
+                            if 0 <= ih < 7 and 0 <= iw < 7:
+                                ws[:, a, bb, dy * 6 + dx * 3:dy * 6 + dx * 3 + 3] = w[:, :, ih, iw]
+            self.wgt_stem = ws.reshape(cout, 256).to(torch.float32).to(dtype).to(device).contiguous()
         # dense-row GEMM fast path (gemm_rows.hip) for 1x1 / stride 1: weights [Cout][K rounded to a 256-byte tile]
         self.wgt_rows, self.kp_rows = None, 0
         if kh == 1 and kw == 1 and int(stride) == 1 and int(pad) == 0 and not smallc and int(store_mode) == 0 \
@@ -260,6 +275,12 @@ def conv2d(x, plan, residual=None, out=None):
             nbytes += residual.numel() * esz
         return 2.0 * m * plan.cout * plan.K, float(nbytes)
 
+    if plan.wgt_stem is not None and USE_STEM and h % 2 == 0 and w % 2 == 0 and residual is None and (out_h, out_w) == (ho, wo):
+        sdims = _ints([plan.code, n, h, w, plan.cout, plan.act])
+        with _timed("stem7x7|%dx%dx%d" % (n, h, w), cost):
+            rc = _L.load().cobevt_stem_conv7x7s2(_p(x), _p(plan.wgt_stem), _p(plan.bias), _p(out), sdims, _stream())
+        _L.check(rc, "cobevt_stem_conv7x7s2")
+        return out
     if plan.wgt_rows is not None and USE_GEMM_ROWS and not (residual is not None and (out_h, out_w) != (ho, wo)):
         ldims = (ctypes.c_long * 13)(plan.code, n * h * w, plan.cout, plan.K, plan.kp_rows, cin, plan.pre_relu, plan.act,
                                      ho, wo, out_h, out_w, int(ln))

@@ -64,6 +64,14 @@ int cobevt_conv3x3_nhwc(const void* in, const void* wgt, const float* bias, cons
                         const int* dims, hipStream_t stream);
 
 /*
+ * ResNet stem: 7x7 / stride 2 / pad 3 conv on the fp32 3-channel channels-last image (+ folded BN, ReLU), computed as a
+ * 4x4 stride-1 conv over the 2x2 space-to-depth image; torchvision resnet conv1/bn1/relu via resnet_ms.py:67-69.
+ * wgt [Cout][16 taps][16] (12 real (dy,dx,c) channels + 4 zeros).  dims (int32[6]): dtype, N, H, W (even), Cout, act.
+ */
+int cobevt_stem_conv7x7s2(const float* in, const void* wgt, const float* bias, void* out, const int* dims,
+                          hipStream_t stream);
+
+/*
  * Dense-row GEMM with fused LayerNorm / pre-activation on the A operand and fused bias / residual / activation:
  * the fast path of every nn.Linear and 1x1 stride-1 convolution (fax_modules.py:189-193,281-292,309-313,411,435,472;
  * swap_fusion_modules.py:45-53; base_transformer.py:102-124).  wgt [N][Kp] (Kp = K rounded up to 128 bf16 / 64 fp32

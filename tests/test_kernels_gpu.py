@@ -128,6 +128,26 @@ def test_conv_7x7_s2_image_stem(cuda, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,h,w", [(3, 128, 96), (1, 38, 50)])
+def test_stem_space_to_depth_kernel(cuda, dtype, n, h, w):
+    """stem7x7.hip (ragged tiles, several images) vs torch, and vs the generic small-Cin igemm on the same plan"""
+    assert ops.USE_STEM
+    _conv_case(cuda, dtype, "st%d" % h, n, 3, h, w, 64, 7, 2, 3, bias=False, bn=True, act=1, smallc=True)
+    x = procedural_input("stg.x", (n, 3, h, w), 0)
+    wt = procedural_input("stg.w", (64, 3, 7, 7), 0) * math.sqrt(3.0 / 147)
+    plan = ops.ConvPlan(wt, None, bn=FakeBN(64, "stg.bn"), stride=2, pad=3, act=1, dtype=dtype, device=cuda, smallc=True)
+    assert plan.wgt_stem is not None
+    xd = nhwc(x).to(cuda)
+    a = ops.conv2d(xd, plan)
+    ops.USE_STEM = False
+    try:
+        b = ops.conv2d(xd, plan)
+    finally:
+        ops.USE_STEM = True
+    check(a, b.float().cpu(), dtype, "stem7x7 vs igemm")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_1x1_preact_bn_relu_padded_out(cuda, dtype):
     _conv_case(cuda, dtype, "c5", 2, 56, 14, 15, 128, 1, 1, 0, bias=False, pre_bn=True, out_pad=(18, 24))
 
