@@ -24,7 +24,12 @@ def init_from_env(device_backend=None):
     if world > 1 and not dist.is_initialized():
         backend = device_backend or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (required by the host driver for RCCL)
+        kwargs = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)                        # bind the GPU before the communicator is created
+            kwargs["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return rank, world, local_rank
 
 

@@ -73,13 +73,56 @@ class CorpBEVT(HipModule):
         b = y.shape[0]
         return self.seg_head(rt.nchw_view(y), b, 1)
 
+    overlap_streams = True   # run each level's key/value path on a side HIP stream under the remaining encoder stages
+
     def encode_agents(self, batch_dict):
         """Per-agent SinBEVT: images -> (N, H, W, C) channels-last BEV features (the tensor V2V sharing transmits).
-        Agents are a pure batch dimension here (corpbevt.py:112-117), which is what the multi-GPU path shards."""
-        x = self.encoder(batch_dict["inputs"])
-        batch_dict.update({"features": x})
-        x = self.fax(batch_dict)                    # (N, 1, C, H, W) channels-last view
-        return rt.to_nhwc(x.squeeze(1))
+        Agents are a pure batch dimension here (corpbevt.py:112-117), which is what the multi-GPU path shards.
+
+        Schedule: the key/value side of pyramid level i (ray embedding, feature projections, K/V projections of both
+        attentions) depends only on encoder stage id_pick[i], not on the BEV query, so it is forked onto a side stream
+        as soon as that stage is done and overlaps the remaining ResNet stages (whose 160-320 workgroups leave CUs
+        idle); the query path joins it right before the level's first attention.  Captured as parallel graph branches."""
+        pick = self.encoder.idx_pick
+        if not (self.overlap_streams and isinstance(pick, list) and batch_dict["inputs"].is_cuda):
+            x = self.encoder(batch_dict["inputs"])
+            batch_dict.update({"features": x})
+            x = self.fax(batch_dict)                    # (N, 1, C, H, W) channels-last view
+            return rt.to_nhwc(x.squeeze(1))
+        self._require_inference(batch_dict["inputs"], batch_dict["intrinsic"], batch_dict["extrinsic"])
+        images = batch_dict["inputs"]
+        b, l, n = images.shape[:3]
+        fax = self.fax
+        I_inv = ops.invert_small(batch_dict["intrinsic"].reshape(b * l * n, 3, 3))
+        E_inv = fax._extrinsic(batch_dict["extrinsic"].reshape(b * l * n, 4, 4).to(torch.float32)).contiguous()
+        main = torch.cuda.current_stream()
+        side = self._plan("side_streams", [fax.bev_embedding.learned_features],
+                          lambda dt, dev: [torch.cuda.Stream(device=dev) for _ in range(len(pick))])
+        feats, kv = {}, {}
+        for stage, x in self.encoder.stages_nhwc(images):
+            if stage not in pick:
+                continue
+            level = pick.index(stage)
+            feats[level] = x
+            s = side[level]
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                kv[level] = fax.cross_views[level].prepare_kv(x, I_inv, E_inv, b * l)
+            x.record_stream(s)
+            for t in kv[level].values():
+                if torch.is_tensor(t):
+                    t.record_stream(main)
+
+        def joined(level):
+            def get():
+                main.wait_stream(side[level])
+                return kv[level]
+            return get
+
+        v = [rt.nchw_view(feats[i]) for i in range(len(pick))]
+        batch_dict.update({"features": [t.reshape(b, l, n, *t.shape[1:]) for t in v]})    # reference side effect (:113)
+        return fax.forward_features([feats[i] for i in range(len(pick))], I_inv, E_inv, b * l,
+                                    kv=[joined(i) for i in range(len(pick))])
 
     def forward(self, batch_dict):
         feats = self.encode_agents(batch_dict)

@@ -143,16 +143,23 @@ class CrossWinAttention(HipModule):
     def _project(self, name, seq, x):
         return ops.linear(x, rt.linear_plan(self, name, seq[1], ln=seq[0]))
 
-    def attend_core(self, q_src, k_src, v_src, qmap, kmap, omap, batch, out_shape):
-        """Projections + fused window attention; returns the head-merged attention output BEFORE self.proj."""
+    def project_kv(self, k_src, v_src):
+        """LayerNorm + Linear of the key / value tokens (independent of the query -> can run ahead on a side stream)."""
+        return self._project("k", self.to_k, k_src), self._project("v", self.to_v, v_src)
+
+    def attend_projected(self, q_src, kt, vt, qmap, kmap, omap, batch, out_shape):
+        """Query projection + fused window attention on already projected keys / values; returns the head-merged
+        attention output BEFORE self.proj."""
         inner = self.heads * self.dim_head
         qt = self._project("q", self.to_q, q_src)
-        kt = self._project("k", self.to_k, k_src)
-        vt = self._project("v", self.to_v, v_src)
         a = torch.empty(tuple(out_shape) + (inner,), device=qt.device, dtype=qt.dtype)
         ops.window_attention(qt, kt, vt, a, qmap, kmap, omap, batch, self.heads, self.scale, inner, inner, inner, inner,
                              mean_q=qmap[1] > 1)
         return a
+
+    def attend_core(self, q_src, k_src, v_src, qmap, kmap, omap, batch, out_shape):
+        kt, vt = self.project_kv(k_src, v_src)
+        return self.attend_projected(q_src, kt, vt, qmap, kmap, omap, batch, out_shape)
 
     def attend(self, q_src, k_src, v_src, qmap, kmap, omap, batch, skip, out_shape):
         """q_src/k_src/v_src: token-major tensors whose rows the maps address; returns proj(attn) (+skip)."""
@@ -226,24 +233,24 @@ class CrossViewSwapAttention(HipModule):
                                   rt.linear_plan(self, name + ".0", mlp[0], act=2, ln=prenorm),
                                   rt.linear_plan(self, name + ".2", mlp[2]), post)
 
-    def forward_nhwc(self, index, x, bev, feature, I_inv, E_inv):
-        """x (b,H,W,d); feature (b*n,h,w,C) compute dtype; I_inv (b*n,3,3), E_inv (b*n,4,4) fp32 -> (b,H,W,d)"""
-        b, H, W, d = x.shape
+    def prepare_kv(self, feature, I_inv, E_inv, batch):
+        """Everything that depends only on the image features and camera geometry (fax_modules.py:346-358,377-396 and
+        the to_k / to_v projections of both attentions): ray embedding, key / value 1x1 projections, zero padding to
+        the window grid, LayerNorm + Linear of K and V.  Independent of the BEV query, so FAXModule may run it ahead
+        of time on a side stream.  feature (b*n,h,w,C); I_inv (b*n,3,3), E_inv (b*n,4,4) fp32."""
         bn, h, w, _ = feature.shape
-        n = bn // b
-        dt = x.dtype
-        W1, W2 = self.q_win_size
+        d, dt = self.dim, feature.dtype
+        n = bn // batch
         w1, w2 = self.feat_win_size
         hp, wp = self._padded_hw(h, w)
         padded = (hp, wp) != (h, w)
-
         plane = rt.f32_param(self, "plane", self.image_plane, (3, h * w))
         w_img = rt.f32_param(self, "w_img", self.img_embed.weight, (d, 4))
         w_cam = rt.f32_param(self, "w_cam", self.cam_embed.weight, (d, 4))
         img = ops.ray_embed(I_inv, E_inv, plane, w_img, w_cam, h * w, d, dt).reshape(bn, h, w, d)
 
         def kv_buffer():
-            return torch.zeros((bn, hp, wp, d), device=x.device, dtype=dt) if padded else None
+            return torch.zeros((bn, hp, wp, d), device=feature.device, dtype=dt) if padded else None
 
         if self.feature_proj is not None:
             key = ops.conv2d(feature, rt.conv_plan(self, "fproj", self.feature_proj[2], pre_bn=self.feature_proj[0]),
@@ -255,31 +262,43 @@ class CrossViewSwapAttention(HipModule):
             key = img
         val = ops.conv2d(feature, rt.conv_plan(self, "flin", self.feature_linear[2], pre_bn=self.feature_linear[0]),
                          out=kv_buffer())
+        k1, v1 = self.cross_win_attend_1.project_kv(key, val)
+        k2, v2 = self.cross_win_attend_2.project_kv(key, val)
+        return {"n": n, "hp": hp, "wp": wp, "k1": k1, "v1": v1, "k2": k2, "v2": v2}
 
+    def forward_query(self, index, x, bev, E_inv, kv):
+        """The query side of fax_modules.py:360-441 given prepare_kv()'s result.  x (b,H,W,d) -> (b,H,W,d)"""
+        b, H, W, d = x.shape
+        n, hp, wp = kv["n"], kv["hp"], kv["wp"]
+        W1, W2 = self.q_win_size
+        w1, w2 = self.feat_win_size
         if self.bev_embed_flag:
             grid = getattr(bev, "grid%d" % index)
             world = rt.f32_param(self, "world%d" % index, grid[:2], (2, H * W))
             w_bev = rt.f32_param(self, "w_bev", self.bev_embed.weight, (d, 2))
             b_bev = rt.f32_param(self, "b_bev", self.bev_embed.bias)
+            w_cam = rt.f32_param(self, "w_cam", self.cam_embed.weight, (d, 4))
             query = ops.bev_embed(E_inv, world, w_bev, b_bev, w_cam, x.reshape(b, H * W, d), n)   # (b, n, HW, d)
             nq = n
         else:
             query, nq = x, 1
-
         qmap_n = ops.tokmap(0, nq, H, W, W1, W2)
         qmap_1 = ops.tokmap(0, 1, H, W, W1, W2)
         kwin = ops.tokmap(0, n, hp, wp, w1, w2)
         kgrid = ops.tokmap(1, n, hp, wp, w1, w2)
         if qmap_1[6] * qmap_1[7] != kwin[6] * kwin[7]:
             raise CobevtHipError("query windows %dx%d != key windows %dx%d" % (qmap_1[6], qmap_1[7], kwin[6], kwin[7]))
-
         # local-to-local: window queries x window keys; per-camera queries are averaged in-kernel
-        a = self.cross_win_attend_1.attend_core(query, key, val, qmap_n, kwin, qmap_1, b, (b, H, W))
+        a = self.cross_win_attend_1.attend_projected(query, kv["k1"], kv["v1"], qmap_n, kwin, qmap_1, b, (b, H, W))
         y = self._proj_mlp("mlp1", self.cross_win_attend_1, a, x if self.skip else None, self.prenorm_1, self.mlp_1)
         # local-to-global: the n query replicas of the reference are identical -> one copy (SURVEY.md §3.2)
-        a = self.cross_win_attend_2.attend_core(y, key, val, qmap_1, kgrid, qmap_1, b, (b, H, W))
+        a = self.cross_win_attend_2.attend_projected(y, kv["k2"], kv["v2"], qmap_1, kgrid, qmap_1, b, (b, H, W))
         return self._proj_mlp("mlp2", self.cross_win_attend_2, a, y if self.skip else None, self.prenorm_2, self.mlp_2,
                               self.postnorm)
+
+    def forward_nhwc(self, index, x, bev, feature, I_inv, E_inv):
+        """x (b,H,W,d); feature (b*n,h,w,C) compute dtype; I_inv (b*n,3,3), E_inv (b*n,4,4) fp32 -> (b,H,W,d)"""
+        return self.forward_query(index, x, bev, E_inv, self.prepare_kv(feature, I_inv, E_inv, x.shape[0]))
 
     def forward(self, index, x, bev, feature, I_inv, E_inv):
         """x (b,d,H,W); feature (b,n,C,h,w); I_inv (b,n,3,3); E_inv (b,n,4,4) -> (b,d,H,W)"""
@@ -341,17 +360,19 @@ class FAXModule(HipModule):
         self.downsample_layers = nn.ModuleList(downsample_layers)
         self.self_attn = Attention(dim[-1], **config["self_attn"])
 
-    def forward_features(self, features, I_inv, E_inv, batch):
-        """features: list of (batch*n, h, w, C) channels-last; returns (batch, H, W, d) channels-last."""
+    def forward_features(self, features, I_inv, E_inv, batch, kv=None):
+        """features: list of (batch*n, h, w, C) channels-last; returns (batch, H, W, d) channels-last.
+        kv: optional list of callables returning each level's prepare_kv() result (computed ahead on side streams)."""
         dt = rt.get_compute_dtype()
         prior = self._plan("prior", [self.bev_embedding.learned_features],
                            lambda d_, dev: self.bev_embedding.learned_features.detach().permute(1, 2, 0).to(dt).contiguous())
         x = prior[None].expand(batch, *prior.shape).contiguous()
         for i, (cross_view, feature, layer) in enumerate(zip(self.cross_views, features, self.layers)):
-            x = cross_view.forward_nhwc(i, x, self.bev_embedding, feature, I_inv, E_inv)
+            kvi = kv[i]() if kv is not None else cross_view.prepare_kv(feature, I_inv, E_inv, batch)
+            x = cross_view.forward_query(i, x, self.bev_embedding, E_inv, kvi)
             for blk in layer:
                 x = blk.forward_nhwc(x)
-            if i < len(features) - 1:
+            if i < len(self.cross_views) - 1:
                 x = self.downsample_layers[i][0].forward_nhwc(x)
         if self.self_attn is not None:
             x = self.self_attn.forward_nhwc(x)

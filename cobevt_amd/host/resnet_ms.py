@@ -96,6 +96,19 @@ class ResnetEncoder(HipModule):
             shapes.append(torch.Size((1, 1, 1, c, h, w)))
         self.output_shapes = [shapes[i] for i in self.idx_pick] if isinstance(self.idx_pick, list) else [shapes[self.idx_pick]]
 
+    def stages_nhwc(self, input_images):
+        """Generator over (stage index 0..3, channels-last feature map) so a caller can overlap work that depends on
+        an early stage with the later stages (CorpBEVT.encode_agents)."""
+        b, l, m, h, w, c = input_images.shape
+        x = input_images.reshape(b * l * m, h, w, c)
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.to(torch.float32).contiguous()
+        x = self.encoder.stem_nhwc(x)
+        for i, layer in enumerate((self.encoder.layer1, self.encoder.layer2, self.encoder.layer3, self.encoder.layer4)):
+            for blk in layer:
+                x = blk.forward_nhwc(x)
+            yield i, x
+
     def forward(self, input_images):
         """(B, L, M, H, W, 3) channels-last fp32 -> list of (B, L, M, C, h, w) (channels-last views)."""
         self._require_inference(input_images)
