@@ -91,14 +91,19 @@ __global__ __launch_bounds__(kConv3Threads) void conv3x3_kernel(Conv3Params p) {
     const T* in = (const T*)p.in;
     const T* wg = (const T*)p.wgt;
 
-    // ---- addresses computed once: patch gather (global element offset of chunk 0, -1 = zero fill) and LDS slots
+    // ---- addresses computed once.  Every prefetch load below is UNCONDITIONAL (invalid items read a clamped, valid
+    // address and are zeroed by a select when they are written to LDS): with loads under per-lane or uniform branches
+    // LLVM's waitcnt insertion falls back to s_waitcnt vmcnt(0) at the control-flow merge, i.e. it also waits for the
+    // prefetch issued in the same step and every tap serialises on a global-load latency (seen in the ISA).
     long pgoff[P_IT];
     int plds[P_IT];
+    bool pzero[P_IT];
 #pragma unroll
     for (int it = 0; it < P_IT; ++it) {
         const int item = tid + it * NT;
-        pgoff[it] = -1;
+        pgoff[it] = 0;
         plds[it] = -1;
+        pzero[it] = true;
         if (item < PATCH_ITEMS) {
             const int pix = item / PIECES, j = item - pix * PIECES;
             const int py = pix / PW, px = pix - py * PW;
@@ -107,18 +112,23 @@ __global__ __launch_bounds__(kConv3Threads) void conv3x3_kernel(Conv3Params p) {
             if (vy >= 0 && vy < p.Ho && vx >= 0 && vx < p.Wo) {
                 const int sy = p.upsample ? (vy >> 1) : vy, sx = p.upsample ? (vx >> 1) : vx;
                 pgoff[it] = (((long)img * p.H + sy) * p.W + sx) * p.Cin + j * CH;
+                pzero[it] = false;
             }
         }
     }
     // weights: [Cout][chunk][tap][CC] -> the slice of step s = chunk*9+tap starts at row_base + s*CC
     const T* wptr[W_IT];
     int wlds[W_IT];
+    bool wzero[W_IT];
 #pragma unroll
     for (int it = 0; it < W_IT; ++it) {
-        const int item = tid + it * NT;
+        const int item = (tid + it * NT) % W_ITEMS;
         const int row = item / PIECES, j = item - row * PIECES;
-        wlds[it] = item < W_ITEMS ? row * WSTR + j * 16 : -1;
-        wptr[it] = (item < W_ITEMS && n0 + row < p.Cout) ? wg + ((size_t)(n0 + row) * nchunk * 9 * CC + j * CH) : nullptr;
+        const bool mine = tid + it * NT < W_ITEMS;
+        wlds[it] = mine ? row * WSTR + j * 16 : -1;
+        wzero[it] = n0 + row >= p.Cout;
+        const int crow = n0 + row < p.Cout ? n0 + row : p.Cout - 1;
+        wptr[it] = wg + ((size_t)crow * nchunk * 9 * CC + j * CH);
     }
 
     uint4 preg[P_IT];
@@ -126,24 +136,22 @@ __global__ __launch_bounds__(kConv3Threads) void conv3x3_kernel(Conv3Params p) {
 
     auto load_patch = [&](int chunk) {
 #pragma unroll
-        for (int it = 0; it < P_IT; ++it)
-            preg[it] = pgoff[it] >= 0 ? *(const uint4*)(in + pgoff[it] + chunk * CC) : make_uint4(0, 0, 0, 0);
+        for (int it = 0; it < P_IT; ++it) preg[it] = *(const uint4*)(in + pgoff[it] + chunk * CC);
     };
     auto store_patch = [&]() {
 #pragma unroll
         for (int it = 0; it < P_IT; ++it)
-            if (plds[it] >= 0) *(uint4*)(patch + plds[it]) = preg[it];
+            if (plds[it] >= 0) *(uint4*)(patch + plds[it]) = pzero[it] ? make_uint4(0, 0, 0, 0) : preg[it];
     };
     auto load_w = [&](uint4 (&wreg)[W_IT], int step) {
 #pragma unroll
-        for (int it = 0; it < W_IT; ++it)
-            wreg[it] = wptr[it] ? *(const uint4*)(wptr[it] + step * CC) : make_uint4(0, 0, 0, 0);
+        for (int it = 0; it < W_IT; ++it) wreg[it] = *(const uint4*)(wptr[it] + step * CC);
     };
     auto store_w = [&](const uint4 (&wreg)[W_IT], int buf) {
         unsigned char* wb = wbuf + buf * C::W_BYTES;
 #pragma unroll
         for (int it = 0; it < W_IT; ++it)
-            if (wlds[it] >= 0) *(uint4*)(wb + wlds[it]) = wreg[it];
+            if (wlds[it] >= 0) *(uint4*)(wb + wlds[it]) = wzero[it] ? make_uint4(0, 0, 0, 0) : wreg[it];
     };
 
     f32x16 acc[2];
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(kConv3Threads) void conv3x3_kernel(Conv3Params p) {
     // one tap: weights two steps ahead in registers (RI: issue for step+2, RS: holds step+1), two LDS weight buffers
     auto body = [&](int step, int chunk, int tap, uint4 (&RI)[W_IT], uint4 (&RS)[W_IT], int buf) {
         const bool next_chunk = chunk + 1 < nchunk;
-        if (step + 2 < nsteps) load_w(RI, step + 2);
+        load_w(RI, step + 2 < nsteps ? step + 2 : nsteps - 1);       // always issued (clamped): keeps the loop branch-free
         if (tap == 6 && next_chunk) load_patch(chunk + 1);
         const int kh = tap / 3, kw = tap - kh * 3;
         const unsigned char* pa = patch + kh * PROW + kw * PSTR + abase;
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(kConv3Threads) void conv3x3_kernel(Conv3Params p) {
     load_w(wregA, 0);
     store_patch();
     store_w(wregA, 0);
-    if (nsteps > 1) load_w(wregB, 1);
+    load_w(wregB, nsteps > 1 ? 1 : 0);
     __syncthreads();
     {
         int chunk = 0, tap = 0;
