@@ -31,6 +31,80 @@ struct Conv3Params {
     int tiles_y, tiles_x, tiles_n;
 };
 
+// NHWC store pass shared by the three kernels: the fp32 staging tile [NPX pixels][BN couts] -> + residual -> activation
+// -> 16-byte stores.  Trip count and item mapping are compile-time, so everything is unrolled and every residual load of
+// a thread is in flight before the first is consumed (a rolled loop serialises one global round trip per item).  It is
+// split in two so a kernel can issue the residual loads (prepare) well before the accumulators are final: with one
+// workgroup per CU all CUs reach their epilogue together and the residual reads + output writes of the whole layer hit
+// HBM as one burst (7-8k cycles for a 160 x 128 tile in the s_memtime trace); loads issued a channel chunk earlier
+// arrive while the MFMA loop still runs.  coord(px, img, oy, ox) returns false for pixels outside the image / past
+// the last strip.  off[] < 0 marks an item with nothing to store.
+template <typename T, int NT, int NPX, int BN> struct Conv3Store {
+    static constexpr int CH = Elem<T>::kChunk;
+    static constexpr int CPP = BN / CH;
+    static constexpr int ITEMS = NPX * CPP;
+    static constexpr int NIT = (ITEMS + NT - 1) / NT;
+    long off[NIT];
+    uint4 rres[NIT];
+
+    template <typename Coord>
+    __device__ __forceinline__ void prepare(const Conv3Params& p, int tid, int n0, Coord coord) {
+        const bool vec = (p.Cout % CH) == 0;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int item = tid + i * NT;
+            const int px = item / CPP, cj = item - px * CPP;
+            const int col = n0 + cj * CH;
+            int img, oy, ox;
+            off[i] = -1;
+            rres[i] = make_uint4(0, 0, 0, 0);
+            if (item < ITEMS && col < p.Cout && coord(px, img, oy, ox)) {
+                off[i] = (((long)img * p.Ho + oy) * p.Wo + ox) * p.Cout + col;
+                if (p.residual && vec) rres[i] = *(const uint4*)((const T*)p.residual + off[i]);
+            }
+        }
+    }
+
+    __device__ __forceinline__ void finish(const Conv3Params& p, const float* stage, int srow, int tid, int n0) {
+        T* out = (T*)p.out;
+        const bool vec = (p.Cout % CH) == 0;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            if (off[i] < 0) continue;
+            const int item = tid + i * NT;
+            const int px = item / CPP, cj = item - px * CPP;
+            float v[8], rv[8];
+#pragma unroll
+            for (int e = 0; e < CH; ++e) v[e] = stage[px * srow + cj * CH + e];
+            if (vec) {
+                if (p.residual) {
+                    chunk_to_f32<T>(rres[i], rv);
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) v[e] += rv[e];
+                }
+#pragma unroll
+                for (int e = 0; e < CH; ++e) v[e] = p.act == 1 ? fmaxf(v[e], 0.f) : (p.act == 2 ? gelu_erf(v[e]) : v[e]);
+                *(uint4*)(out + off[i]) = f32_to_chunk<T>(v);
+            } else {                                      // ragged Cout (not a multiple of the 16-byte chunk): scalar
+                const int col = n0 + cj * CH;
+                for (int e = 0; e < CH && col + e < p.Cout; ++e) {
+                    float x = v[e];
+                    if (p.residual) x += load_elem<T>((const T*)p.residual, off[i] + e);
+                    x = p.act == 1 ? fmaxf(x, 0.f) : (p.act == 2 ? gelu_erf(x) : x);
+                    store_elem<T>(out, off[i] + e, x);
+                }
+            }
+        }
+    }
+};
+
+template <typename T, int NT, int NPX, int BN, typename Coord>
+__device__ __forceinline__ void conv3_store_nhwc(const Conv3Params& p, const float* stage, int srow, int tid, int n0, Coord coord) {
+    Conv3Store<T, NT, NPX, BN> st;
+    st.prepare(p, tid, n0, coord);
+    st.finish(p, stage, srow, tid, n0);
+}
+
 // KG = 32-byte k-groups per chunk (4 -> 128-byte chunks, 2 -> 64-byte chunks for Cin = 32 bf16)
 template <typename T, int BN, int KG> struct Conv3Cfg {
     static constexpr int TW = 16;
@@ -224,35 +298,10 @@ __global__ __launch_bounds__(kConv3Threads) void conv3x3_kernel(Conv3Params p) {
     __syncthreads();
     T* out = (T*)p.out;
     if (p.store_mode == 0) {
-        constexpr int CPP = BN / CH;                     // 16-byte output chunks per pixel
-        for (int item = tid; item < TH * TW * CPP; item += kConv3Threads) {
-            const int px = item / CPP, cj = item - px * CPP;
-            const int oy = oy0 + px / TW, ox = ox0 + (px % TW);
-            const int col = n0 + cj * CH;
-            if (oy >= p.Ho || ox >= p.Wo || col >= p.Cout) continue;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < CH; ++e) v[e] = stage[px * SROW + cj * CH + e];
-            const size_t o = (((size_t)img * p.Ho + oy) * p.Wo + ox) * p.Cout + col;
-            if (col + CH <= p.Cout && (p.Cout % CH) == 0) {
-                if (p.residual) {
-                    float rv[8];
-                    chunk_to_f32<T>(*(const uint4*)((const T*)p.residual + o), rv);
-#pragma unroll
-                    for (int e = 0; e < CH; ++e) v[e] += rv[e];
-                }
-#pragma unroll
-                for (int e = 0; e < CH; ++e) v[e] = p.act == 1 ? fmaxf(v[e], 0.f) : (p.act == 2 ? gelu_erf(v[e]) : v[e]);
-                *(uint4*)(out + o) = f32_to_chunk<T>(v);
-            } else {                                      // ragged Cout tail (Cout not a multiple of the chunk)
-                for (int e = 0; e < CH && col + e < p.Cout; ++e) {
-                    float x = v[e];
-                    if (p.residual) x += load_elem<T>((const T*)p.residual, o + e);
-                    x = p.act == 1 ? fmaxf(x, 0.f) : (p.act == 2 ? gelu_erf(x) : x);
-                    store_elem<T>(out, o + e, x);
-                }
-            }
-        }
+        conv3_store_nhwc<T, kConv3Threads, TH * TW, BN>(p, stage, SROW, tid, n0, [&](int px, int& im, int& oy, int& ox) {
+            im = img; oy = oy0 + px / TW; ox = ox0 + (px % TW);
+            return oy < p.Ho && ox < p.Wo;
+        });
     } else {
         // PixelUnshuffle(2): out[(oy/2, ox/2)][c*4 + (oy&1)*2 + (ox&1)] = conv[(oy, ox)][c]   (no residual here)
         constexpr int QP = (TH / 2) * (TW / 2);          // output pixels per tile
@@ -300,6 +349,359 @@ static int launch_conv3(Conv3Params p, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fragment-ordered weights (cobevt_conv3x3_wfrag_nhwc).
+//
+// The kernel above stages every tap's weight slice through LDS and pays one workgroup barrier per tap.  Here the host
+// lays the weights out in MFMA B-fragment order
+//     [Cout/32][Cin/cc][9 taps][KG k-groups][64 lanes][16 bytes]
+// so the weight operand of one (32-cout tile, tap, k-group) is a single fully coalesced 1-KB wave load that goes
+// straight from L2 into registers: no weight LDS traffic and no per-tap barrier.  LDS only holds the input patch (double
+// buffered across channel chunks -> one barrier per nine taps) and the fragments of the tap two steps ahead are
+// prefetched into a register ring while the current tap runs.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef COBEVT_CONV3_KNOCK
+#define COBEVT_CONV3_KNOCK 0          // tools/conv_probe.py builds knock-out copies of this file (never the product .so)
+#endif
+#ifdef COBEVT_CONV3_TRACE
+__device__ unsigned long long cobevt_conv3_trace[64];
+#define COBEVT_TRACE_MARK(i) do { if (logical == 0 && tid == 0) cobevt_conv3_trace[(i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define COBEVT_TRACE_MARK(i) do {} while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Strip tiling.
+//
+// Measured with s_memtime, one 8-wave workgroup with a fixed 128 px x 128 cout tile already keeps its CU's MFMA pipes
+// ~75-85 % busy (a tap of 64 MFMAs takes 500-700 cycles against 512 of pure MFMA issue); what it loses is the tail:
+// ResNet-34's layers on the 20 camera images of a 5-agent frame make 320 or 160 such tiles for 256 CUs, so the kernel
+// lasts two workgroup lifetimes at 62 % occupancy.  Here the pixel tile is MT independent STRIPS of 2 rows x 16
+// pixels (one 32-row MFMA tile each, with its own 4 x 18 pixel halo patch), strips are numbered across
+// (image, row pair, column block), and MT is picked per launch so that the grid is a whole number of workgroups per
+// CU (MT = 5 on 20 images: 256 or 512 workgroups).  The 8 waves are WN cout tiles x KS k-splits: every wave walks all
+// MT strips for its 32 couts and its share of each tap's four k-groups, so no B fragment is loaded twice in a
+// workgroup; the k-split partial sums meet in the fp32 staging tile of the epilogue.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int MT, int WN, int KS> struct Conv3SCfg {
+    static constexpr int NT = 512, KG = 4, KGW = KG / KS;
+    static constexpr int BN = WN * 32, PW = 18, SROWS = 4;
+    static constexpr int PSTR = KG * 32 + 16;
+    static constexpr int PROW = (PW * PSTR + 255) / 256 * 256;
+    static constexpr int STRIP_BYTES = SROWS * PROW;
+    static constexpr int PATCH_BYTES = MT * STRIP_BYTES;
+    static constexpr int SSTR = BN * 4 + 16;
+    static constexpr int STAGE_BYTES = MT * 32 * SSTR;
+    static constexpr int MAIN_BYTES = 2 * PATCH_BYTES;
+    static constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
+    static_assert(WN * KS == 8, "eight waves");
+};
+
+template <typename T, int MT, int WN, int KS>
+__global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
+    using C = Conv3SCfg<T, MT, WN, KS>;
+    constexpr int NT = C::NT, KG = C::KG, KGW = C::KGW, BN = C::BN, PW = C::PW;
+    constexpr int CH = Elem<T>::kChunk;
+    constexpr int CC = KG * 32 / Elem<T>::kBytes;
+    constexpr int PSTR = C::PSTR, PROW = C::PROW, STRIP = C::STRIP_BYTES;
+    constexpr int PIECES = 2 * KG;
+    constexpr int STRIP_ITEMS = C::SROWS * PW * PIECES;          // 576 16-byte pieces per strip patch
+    constexpr int PATCH_ITEMS = MT * STRIP_ITEMS;
+    constexpr int P_IT = (PATCH_ITEMS + NT - 1) / NT;
+    constexpr int PF = 2, R = 3;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* patch = smem;
+
+    int logical;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+        const int q = nblk >> 3, r = nblk & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int tn = logical % p.tiles_n;
+    const int q0 = (logical / p.tiles_n) * MT;                   // first strip of this workgroup
+    const int n0 = tn * BN;
+    const int per_img = p.tiles_y * p.tiles_x;
+    const int nstrips = p.N * per_img;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, ql = lane & 31;
+    const int wn = wave % WN, ks = wave / WN;
+    const int nchunk = p.Cin / CC;
+    const int nsteps = nchunk * 9;
+    const T* in = (const T*)p.in;
+
+    int pgoff[P_IT];        // element offsets (the host entry guarantees the input has < 2^31 elements)
+    int plds[P_IT];         // < 0: nothing to write; otherwise bit 30 set = write zeros
+#pragma unroll
+    for (int it = 0; it < P_IT; ++it) {
+        const int item = tid + it * NT;
+        pgoff[it] = 0;
+        plds[it] = -1;
+        if (item < PATCH_ITEMS) {
+            const int s = item / STRIP_ITEMS, r = item - s * STRIP_ITEMS;
+            const int pix = r / PIECES, j = r - pix * PIECES;
+            const int py = pix / PW, px = pix - py * PW;
+            int lds = s * STRIP + py * PROW + px * PSTR + j * 16;
+            const int q = q0 + s;
+            bool valid = false;
+            if (q < nstrips) {
+                const int img = q / per_img, rem = q - img * per_img;
+                const int sy = rem / p.tiles_x, sx = rem - sy * p.tiles_x;
+                const int vy = sy * 2 - 1 + py, vx = sx * 16 - 1 + px;
+                if (vy >= 0 && vy < p.Ho && vx >= 0 && vx < p.Wo) {
+                    const int yy = p.upsample ? (vy >> 1) : vy, xx = p.upsample ? (vx >> 1) : vx;
+                    pgoff[it] = ((img * p.H + yy) * p.W + xx) * p.Cin + j * CH;
+                    valid = true;
+                }
+            }
+            plds[it] = valid ? lds : (lds | (1 << 30));
+        }
+    }
+    const uint4* wq = (const uint4*)p.wgt + ((size_t)(n0 / 32 + wn) * nsteps) * (KG * 64) + ks * KGW * 64 + lane;
+
+    uint4 preg[P_IT];
+    auto load_patch = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) preg[it] = *(const uint4*)(in + pgoff[it] + chunk * CC);
+    };
+    auto store_patch = [&](unsigned char* dst) {
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it)
+            if (plds[it] >= 0)
+                *(uint4*)(dst + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : preg[it];
+    };
+    auto load_b = [&](uint4 (&b)[KGW], int step) {
+#pragma unroll
+        for (int g = 0; g < KGW; ++g) b[g] = wq[(size_t)step * (KG * 64) + g * 64];
+    };
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    const int abase = (ql >> 4) * PROW + (ql & 15) * PSTR + h * 16 + ks * KGW * 32;
+
+    uint4 bq[R][KGW];
+    COBEVT_TRACE_MARK(0);
+    load_patch(0);
+#pragma unroll
+    for (int s = 0; s < PF; ++s) load_b(bq[s], s < nsteps ? s : nsteps - 1);
+    store_patch(patch);
+    __syncthreads();
+    COBEVT_TRACE_MARK(1);
+    auto run_chunk = [&](int chunk) {
+        const bool more = chunk + 1 < nchunk;
+        unsigned char* pbuf = patch + (chunk & 1) * C::PATCH_BYTES;
+        unsigned char* pother = patch + ((chunk & 1) ^ 1) * C::PATCH_BYTES;
+        if (!(COBEVT_CONV3_KNOCK & 8)) load_patch(more ? chunk + 1 : chunk);   // unconditional (clamped): counted vmcnt
+        // A fragments run two k-groups ahead of the MFMAs in a three-slot register ring (9 * KGW groups per chunk, a
+        // multiple of 3, so slots are static); sched_group_barrier pins the issue order "one ds_read, one MFMA", i.e. a
+        // fragment is requested 2 * MT MFMAs (>= 320 cycles) before its first use.  A wave alone on its SIMD then
+        // keeps the MFMA pipe busy (the s_memtime trace showed the younger wave of each SIMD finishing a chunk ~2k
+        // cycles after the older one with the A reads only one MFMA ahead of their use).
+        constexpr int NG = 9 * KGW;                      // k-groups of this wave per chunk
+        static_assert(NG % 3 == 0, "A-fragment ring slots must be static");
+        uint4 af[3][MT];
+        auto read_a = [&](uint4 (&dst)[MT], int n) {     // n = group index inside the chunk (compile-time after unrolling)
+            const int t2 = n / KGW, g2 = n - t2 * KGW;
+            const int kh2 = t2 / 3, kw2 = t2 - kh2 * 3;
+            const unsigned char* pn = pbuf + kh2 * PROW + kw2 * PSTR + abase + g2 * 32;
+#pragma unroll
+            for (int a = 0; a < MT; ++a) dst[a] = *(const uint4*)(pn + a * STRIP);
+        };
+        read_a(af[0], 0);
+        read_a(af[1], 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int step = chunk * 9 + tap;
+            if (chunk < 4) COBEVT_TRACE_MARK(2 + chunk * 9 + tap);
+#ifdef COBEVT_CONV3_SETPRIO
+            // issue arbitration favours the older wave of a SIMD; alternate it per tap so both waves of a SIMD reach
+            // the chunk barrier together instead of the younger one finishing its taps alone
+            if ((tap ^ ks) & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+#endif
+            if (!(COBEVT_CONV3_KNOCK & 1) || chunk == 0)
+                load_b(bq[(tap + PF) % R], step + PF < nsteps ? step + PF : nsteps - 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < KGW; ++g) {
+                const int n = tap * KGW + g;
+                if (n + 2 < NG && (!(COBEVT_CONV3_KNOCK & 4) || chunk == 0)) read_a(af[(n + 2) % 3], n + 2);
+#pragma unroll
+                for (int a = 0; a < MT; ++a) {
+                    if (COBEVT_CONV3_KNOCK & 2) acc[a][0] += __uint_as_float((af[n % 3][a].x ^ bq[tap % R][g].x) & 0x3fffffffu);
+                    else mfma_kgroup<T>(bq[tap % R][g], af[n % 3][a], acc[a]);   // D = W X^T: rows = couts, cols = pixels
+                }
+                if (Elem<T>::kIsBf16 && n + 2 < NG) {
+#pragma unroll
+                    for (int a = 0; a < MT; ++a) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one ds_read ...
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // ... then one MFMA
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the other buffer has been free since the last barrier: write the next chunk's patch under taps 7-8
+            if (tap == 6 && more && !(COBEVT_CONV3_KNOCK & 8)) {
+                store_patch(pother);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (chunk < 4) COBEVT_TRACE_MARK(41 + 2 * chunk);
+#ifdef COBEVT_CONV3_TRACE
+        if (logical == 0 && lane == 0 && chunk == 0) {       // per-wave barrier arrival + SIMD placement
+            cobevt_conv3_trace[49 + wave] = __builtin_readcyclecounter();
+            cobevt_conv3_trace[57 + wave > 63 ? 63 : 57 + wave] = 0;
+            unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
+            cobevt_conv3_trace[49 + wave] |= (unsigned long long)((hw >> 4) & 3) << 60;
+        }
+#endif
+        __syncthreads();
+        if (chunk < 4) COBEVT_TRACE_MARK(42 + 2 * chunk);
+    };
+    auto coord = [&](int px, int& im, int& oy, int& ox) {
+        const int q = q0 + (px >> 5);
+        if (q >= nstrips) return false;
+        im = q / per_img;
+        const int rem = q - im * per_img;
+        const int sy = rem / p.tiles_x, sx = rem - sy * p.tiles_x;
+        oy = sy * 2 + ((px >> 4) & 1); ox = sx * 16 + (px & 15);
+        return oy < p.Ho && ox < p.Wo;
+    };
+    // the last chunk is peeled so the residual loads of the store pass can be issued (unconditionally, keeping the
+    // vmcnt waits counted) one chunk of MFMAs before they are needed
+    constexpr bool EARLY_RES = Elem<T>::kIsBf16 && MT <= 5;
+    Conv3Store<T, NT, MT * 32, BN> st;
+    for (int chunk = 0; chunk + 1 < nchunk; ++chunk) run_chunk(chunk);
+    if (EARLY_RES && p.store_mode == 0) st.prepare(p, tid, n0, coord);
+    __builtin_amdgcn_sched_barrier(0);               // keep the residual loads up here
+    run_chunk(nchunk - 1);
+    COBEVT_TRACE_MARK(38);
+
+    // ---- epilogue: the KS k-split partials meet in the fp32 staging tile [MT*32 pixels][BN].  With the operands
+    // swapped a lane holds, per accumulator tile, one pixel (lane & 31) and four runs of four consecutive couts
+    // (8k + 4*(lane>>5) + 0..3), i.e. 16-byte staging accesses instead of sixteen scalar ones.
+    float* stage = (float*)smem;
+    constexpr int SROW = C::SSTR / 4;
+    {
+        const int c0 = wn * 32 + 4 * h;
+        float4 bias4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float bb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = n0 + c0 + 8 * k + e;
+                bb[e] = (p.bias && ks == 0 && c < p.Cout) ? p.bias[c] : 0.f;
+            }
+            bias4[k] = make_float4(bb[0], bb[1], bb[2], bb[3]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            if (ks == kk) {
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float4* d = (float4*)(stage + (a * 32 + ql) * SROW + c0 + 8 * k);
+                        float4 v = make_float4(acc[a][4 * k], acc[a][4 * k + 1], acc[a][4 * k + 2], acc[a][4 * k + 3]);
+                        if (kk == 0) {
+                            v.x += bias4[k].x; v.y += bias4[k].y; v.z += bias4[k].z; v.w += bias4[k].w;
+                        } else {
+                            const float4 o = *d;
+                            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                        }
+                        *d = v;
+                    }
+            }
+            __syncthreads();
+        }
+    }
+    COBEVT_TRACE_MARK(39);
+    T* out = (T*)p.out;
+    if (p.store_mode == 0) {
+        if (!EARLY_RES) st.prepare(p, tid, n0, coord);
+        st.finish(p, stage, SROW, tid, n0);
+    } else {
+        // PixelUnshuffle(2): a strip (2 rows x 16 columns) is one output row of 8 pixels with 4*BN channels of this tile
+        const int cpp = BN * 4 / CH;
+        for (int item = tid; item < MT * 8 * cpp; item += NT) {
+            const int qp = item / cpp, cj = item - qp * cpp;
+            const int s = qp >> 3, qx = qp & 7;
+            const int q = q0 + s;
+            if (q >= nstrips) continue;
+            const int img = q / per_img, rem = q - img * per_img;
+            const int sy = rem / p.tiles_x, sx = rem - sy * p.tiles_x;
+            const int oy2 = sy, ox2 = sx * 8 + qx;
+            if (oy2 >= (p.Ho >> 1) || ox2 >= (p.Wo >> 1)) continue;
+            float v[8];
+            bool any = false;
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                const int oc = cj * CH + e, c = oc >> 2, qd = oc & 3;
+                const int px = s * 32 + (qd >> 1) * 16 + 2 * qx + (qd & 1);
+                float x = stage[px * SROW + c];
+                x = p.act == 1 ? fmaxf(x, 0.f) : (p.act == 2 ? gelu_erf(x) : x);
+                v[e] = x;
+                any |= (n0 + c) < p.Cout;
+            }
+            if (!any) continue;
+            const size_t o = (((size_t)img * (p.Ho >> 1) + oy2) * (p.Wo >> 1) + ox2) * (size_t)(p.Cout * 4) + (size_t)n0 * 4 + cj * CH;
+            if (n0 + ((cj * CH + CH - 1) >> 2) < p.Cout && ((p.Cout * 4) % CH) == 0) *(uint4*)(out + o) = f32_to_chunk<T>(v);
+            else for (int e = 0; e < CH; ++e) if (n0 + ((cj * CH + e) >> 2) < p.Cout) store_elem<T>(out, o + e, v[e]);
+        }
+    }
+    COBEVT_TRACE_MARK(40);
+}
+
+template <typename T, int MT, int WN, int KS>
+static int launch_conv3s(Conv3Params p, int coutp, hipStream_t stream) {
+    using C = Conv3SCfg<T, MT, WN, KS>;
+    if ((long)p.N * p.H * p.W * p.Cin >= 0x7fffffffL) return COBEVT_ERR_UNSUPPORTED;   // 32-bit patch offsets
+    p.tiles_y = (p.Ho + 1) / 2;
+    p.tiles_x = (p.Wo + 15) / 16;
+    p.tiles_n = (p.Cout + C::BN - 1) / C::BN;
+    if (p.tiles_n * C::BN > coutp) return COBEVT_ERR_SHAPE;
+    const long nstrips = (long)p.N * p.tiles_y * p.tiles_x;
+    const long blocks = (nstrips + MT - 1) / MT * p.tiles_n;
+    if (blocks <= 0 || blocks > 0x7fffffffL) return COBEVT_ERR_SHAPE;
+    constexpr size_t lds = C::LDS_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_strips_kernel<T, MT, WN, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_strips_kernel<T, MT, WN, KS>), dim3((unsigned)blocks), dim3(C::NT), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+template <typename T, int MT>
+static int launch_conv3s_bn(const Conv3Params& p, int coutp, int bn64, hipStream_t stream) {
+    return bn64 ? launch_conv3s<T, MT, 2, 4>(p, coutp, stream) : launch_conv3s<T, MT, 4, 2>(p, coutp, stream);
+}
+
+template <typename T>
+static int dispatch_conv3f(const Conv3Params& p, int kg, int coutp, int variant, hipStream_t stream) {
+    if (kg != 4) return COBEVT_ERR_UNSUPPORTED;
+    // variant = 100 + 10*MT + (1 if 64-cout tiles else 0); 0 = a safe default
+    if (variant == 0) variant = p.Cout <= 64 ? 151 : 150;
+    const int mt = (variant - 100) / 10, bn64 = (variant - 100) % 10;
+    if (variant < 100 || bn64 > 1) return COBEVT_ERR_ARG;
+    switch (mt) {
+        case 3: return launch_conv3s_bn<T, 3>(p, coutp, bn64, stream);
+        case 4: return launch_conv3s_bn<T, 4>(p, coutp, bn64, stream);
+        case 5: return launch_conv3s_bn<T, 5>(p, coutp, bn64, stream);
+        case 6: return launch_conv3s_bn<T, 6>(p, coutp, bn64, stream);
+        default: return COBEVT_ERR_ARG;
+    }
+}
+
 }  // namespace cobevt
 
 using namespace cobevt;
@@ -333,3 +735,32 @@ extern "C" int cobevt_conv3x3_nhwc(const void* in, const void* wgt, const float*
     }
     return COBEVT_ERR_SHAPE;
 }
+
+// C-ABI entry point, see include/cobevt_hip.h
+extern "C" int cobevt_conv3x3_wfrag_nhwc(const void* in, const void* wfrag, const float* bias, const void* residual, void* out,
+                                         const int* dims, hipStream_t stream) {
+    // dims: [dtype, N, H, W, Cin, Cout, upsample, act, store_mode, chunk_channels, padded_cout, variant]
+    if (!in || !wfrag || !out || !dims) return COBEVT_ERR_ARG;
+    Conv3Params p;
+    const int dtype = dims[0];
+    p.in = in; p.wgt = wfrag; p.bias = bias; p.residual = residual; p.out = out;
+    p.N = dims[1]; p.H = dims[2]; p.W = dims[3]; p.Cin = dims[4]; p.Cout = dims[5];
+    p.upsample = dims[6]; p.act = dims[7]; p.store_mode = dims[8];
+    const int cc = dims[9], coutp = dims[10], variant = dims[11];
+    p.Ho = p.upsample ? 2 * p.H : p.H;
+    p.Wo = p.upsample ? 2 * p.W : p.W;
+    if (dtype != 0 && dtype != 1) return COBEVT_ERR_ARG;
+    if (p.N < 1 || p.H < 1 || p.W < 1 || p.Cin < 1 || p.Cout < 1 || cc < 1) return COBEVT_ERR_SHAPE;
+    if (p.store_mode != 0 && p.store_mode != 1) return COBEVT_ERR_ARG;
+    if (p.store_mode == 1 && (p.residual || ((p.Ho | p.Wo) & 1))) return COBEVT_ERR_UNSUPPORTED;
+    if (p.Cin % cc != 0 || coutp % 32 != 0 || coutp < p.Cout) return COBEVT_ERR_SHAPE;
+    const int kg = cc * (dtype == 0 ? 2 : 4) / 32;
+    return dtype == 0 ? dispatch_conv3f<bf16_t>(p, kg, coutp, variant, stream)
+                      : dispatch_conv3f<float>(p, kg, coutp, variant, stream);
+}
+
+#ifdef COBEVT_CONV3_TRACE
+extern "C" int cobevt_conv3_read_trace(unsigned long long* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(cobevt_conv3_trace), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : 1;
+}
+#endif

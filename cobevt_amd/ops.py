@@ -14,6 +14,8 @@ from .lib import CobevtHipError
 
 BF16, FP32 = 0, 1
 USE_CONV3X3 = True   # route eligible 3x3 convs to the LDS-patch kernel (tests flip this to cover both paths)
+USE_CONV3_WFRAG = True   # ... and, where the fragment-ordered weight table exists, to the barrier-free-per-tap variant
+CONV3_VARIANT = 0    # 0 = automatic tile choice of cobevt_conv3x3_wfrag_nhwc; >0 pins one (tools/conv_probe.py)
 USE_GEMM_ROWS = True  # route 1x1 stride-1 convs / linears to the dense-row GEMM with fused LayerNorm
 USE_STEM = True       # 7x7/s2 image stem through the space-to-depth kernel instead of the generic small-Cin igemm
 USE_ROW_CHAIN = True  # fuse out-proj + skip + pre-norm MLP (+ post-norm) after attention into one launch (bf16)
@@ -192,6 +194,16 @@ class ConvPlan(object):
                     self.wgt3 = w3.to(torch.float32).to(dtype).to(device).contiguous()
                     self.cc3 = cc
                     break
+        # the same weights in MFMA B-fragment order for cobevt_conv3x3_wfrag_nhwc (128-byte chunks only):
+        # [Cout_p/32][Cin/cc][9][KG][lane = 32*half + cout%32][16 bytes], Cout zero-padded to a multiple of 128
+        self.wfrag, self.coutp3 = None, 0
+        if self.wgt3 is not None and self.cc3 == cands[0]:
+            cc, coutp = self.cc3, (cout + 127) // 128 * 128
+            wp = torch.zeros(coutp, cin // cc, 9, cc, dtype=torch.float64)
+            wp[:cout] = w.permute(0, 2, 3, 1).reshape(cout, 9, cin // cc, cc).permute(0, 2, 1, 3)
+            wf = wp.reshape(coutp // 32, 32, cin // cc, 9, 4, 2, ch).permute(0, 2, 3, 4, 5, 1, 6)
+            self.wfrag = wf.to(torch.float32).to(dtype).to(device).contiguous()
+            self.coutp3 = coutp
         # ResNet stem fast path (stem7x7.hip): 7x7 / stride 2 / pad 3 on 3 channels as a 4x4 conv on the 2x2
         # space-to-depth image; W'[n][a][b][dy][dx][c] = w[n][c][2a+dy-1][2b+dx-1]
         self.wgt_stem = None
@@ -230,6 +242,31 @@ class ConvPlan(object):
 def ln_fusable(plan):
     """The row normalisation can run inside the dense-row GEMM when the row fits one 256-byte K-tile."""
     return USE_GEMM_ROWS and plan.wgt_rows is not None and plan.K <= (128 if plan.code == BF16 else 64)
+
+
+def conv3_tiling(n, ho, wo, cin, cout, cc, cus=256):
+    """Pick the 3x3 kernel / tile shape for one launch: 0 = the LDS-staged kernel (cobevt_conv3x3_nhwc), else the
+    `variant` of cobevt_conv3x3_wfrag_nhwc (100 + 10*MT + bn64: MT strips of 2x16 pixels x 128|64 couts per workgroup).
+    The LDS-staged kernel runs two workgroups per CU and wins once its grid is >= 2 per CU; below that the kernel time
+    is whole workgroup lifetimes, so the strip count MT is chosen to make the grid a whole number of waves of `cus`
+    workgroups (cycle model: 12k fixed + 40 cycles per MFMA-tile-step, both from the s_memtime traces)."""
+    if cout < 64:
+        return 0
+    th, bn = (16, 64) if cout <= 64 else (8, 128)
+    blocks_old = n * (-(-ho // th)) * (-(-wo // 16)) * (-(-cout // bn))
+    if blocks_old >= 2 * cus:
+        return 0
+    nstrips = n * (-(-ho // 2)) * (-(-wo // 16))
+    nsteps = 9 * (cin // cc)
+    best = None
+    for bn64 in ((1,) if cout <= 64 else (0, 1)):
+        tile_n = 64 if bn64 else 128
+        for mt in (3, 4, 5, 6):
+            blocks = -(-nstrips // mt) * -(-cout // tile_n)
+            cost = -(-blocks // cus) * (12000 + nsteps * mt * (tile_n // 32) * 40)
+            if best is None or cost < best[0]:
+                best = (cost, 100 + 10 * mt + bn64)
+    return best[1]
 
 
 def conv2d(x, plan, residual=None, out=None):
@@ -289,6 +326,15 @@ def conv2d(x, plan, residual=None, out=None):
                                               _p(plan.pre_scale), _p(plan.pre_shift), _p(out), ldims,
                                               ctypes.c_float(plan.ln_eps), _stream())
         _L.check(rc, "cobevt_linear_rows")
+        return out
+    variant = 0
+    if plan.wfrag is not None and (out_h, out_w) == (ho, wo) and USE_CONV3X3 and USE_CONV3_WFRAG:
+        variant = CONV3_VARIANT or conv3_tiling(n, ho, wo, cin, plan.cout, plan.cc3)
+    if variant > 0:
+        dims = _ints([plan.code, n, h, w, cin, plan.cout, plan.upsample, plan.act, sm, plan.cc3, plan.coutp3, variant])
+        with _timed("conv3x3|%d->%d %dx%dx%d" % (cin, plan.cout, n, ho, wo), cost):
+            rc = _L.load().cobevt_conv3x3_wfrag_nhwc(_p(x), _p(plan.wfrag), _p(plan.bias), _p(residual), _p(out), dims, _stream())
+        _L.check(rc, "cobevt_conv3x3_wfrag_nhwc")
         return out
     if plan.wgt3 is not None and (out_h, out_w) == (ho, wo) and USE_CONV3X3:
         dims = _ints([plan.code, n, h, w, cin, plan.cout, plan.upsample, plan.act, sm, plan.cc3])

@@ -64,6 +64,20 @@ int cobevt_conv3x3_nhwc(const void* in, const void* wgt, const float* bias, cons
                         const int* dims, hipStream_t stream);
 
 /*
+ * The same 3x3 / stride 1 / pad 1 convolution (same reference call sites as cobevt_conv3x3_nhwc) with the weights
+ * pre-ordered as MFMA B fragments, [Cout_p/32][Cin/cc][9 taps][4 k-groups][64 lanes][16 bytes] where lane = 32*half +
+ * (cout % 32) holds bytes [32*kgroup + 16*half, +16) of that cout's 128-byte channel chunk and Cout_p >= Cout is the
+ * zero-padded row count (multiple of 128): every weight operand is one coalesced 1-KB wave load from L2, LDS only holds
+ * the input patch and there is one barrier per channel chunk instead of one per tap.  A workgroup owns MT strips of
+ * 2 x 16 output pixels (numbered across image, row pair, column block) x 128 or 64 couts.  dims (int32[12]): dtype, N,
+ * H, W, Cin, Cout, upsample, act, store_mode (0 NHWC, 1 PixelUnshuffle(2)), cc (bf16: 64, fp32: 32), Cout_p, variant =
+ * 100 + 10*MT + (1 for 64-cout tiles), MT in 3..6 (0 = MT 5); the host picks MT so that the grid is a whole number of
+ * workgroups per CU (cobevt_amd/ops.py conv3_tiling).  Needs N*H*W*Cin < 2^31.
+ */
+int cobevt_conv3x3_wfrag_nhwc(const void* in, const void* wfrag, const float* bias, const void* residual, void* out,
+                              const int* dims, hipStream_t stream);
+
+/*
  * ResNet stem: 7x7 / stride 2 / pad 3 conv on the fp32 3-channel channels-last image (+ folded BN, ReLU), computed as a
  * 4x4 stride-1 conv over the 2x2 space-to-depth image; torchvision resnet conv1/bn1/relu via resnet_ms.py:67-69.
  * wgt [Cout][16 taps][16] (12 real (dy,dx,c) channels + 4 zeros).  dims (int32[6]): dtype, N, H, W (even), Cout, act.

@@ -182,6 +182,55 @@ def test_conv3x3_patch_kernel_shapes(cuda, dtype, cin, cout, h, w):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("variant", [130, 131, 140, 141, 150, 151, 160, 161])
+def test_conv3x3_wfrag_tile_variants(cuda, dtype, variant):
+    """cobevt_conv3x3_wfrag_nhwc (fragment-ordered weights): every tile shape, ragged tiles and cout tails, 1-3 channel
+    chunks, residual / up-sampled input / PixelUnshuffle epilogues, against torch"""
+    assert ops.USE_CONV3_WFRAG
+    cc = 64 if dtype == torch.bfloat16 else 32
+    cout = 160
+    ops.CONV3_VARIANT = variant
+    try:
+        for i, (nch, h, w, kw) in enumerate([(1, 19, 37, dict(bn=True, act=1, residual=True)),
+                                             (3, 16, 16, dict(act=2)),
+                                             (2, 9, 12, dict(bias=False, upsample=True, act=1)),
+                                             (2, 12, 20, dict(bias=False, store_mode=1))]):
+            plan_probe = ops.ConvPlan(torch.zeros(cout, cc * nch, 3, 3), None, stride=1, pad=1, dtype=dtype, device=cuda)
+            assert plan_probe.wfrag is not None and plan_probe.coutp3 % 128 == 0
+            _conv_case(cuda, dtype, "wf%d_%d" % (variant, i), 2, cc * nch, h, w, cout, 3, 1, 1, **kw)
+    finally:
+        ops.CONV3_VARIANT = 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_wfrag_matches_lds_staged(cuda, dtype):
+    """the two 3x3 kernels on one plan (the LDS-staged one stays the path for 64-byte channel chunks)"""
+    cin = 256 if dtype == torch.bfloat16 else 128
+    x = procedural_input("wl.x", (3, cin, 32, 32), 0)
+    wt = procedural_input("wl.w", (256, cin, 3, 3), 0) * math.sqrt(3.0 / (cin * 9))
+    plan = ops.ConvPlan(wt, None, bn=FakeBN(256, "wl.bn"), stride=1, pad=1, act=1, dtype=dtype, device=cuda)
+    assert plan.wfrag is not None and plan.wgt3 is not None
+    xd = nhwc(x).to(cuda).to(dtype)
+    a = ops.conv2d(xd, plan)
+    ops.USE_CONV3_WFRAG = False
+    try:
+        b = ops.conv2d(xd, plan)
+    finally:
+        ops.USE_CONV3_WFRAG = True
+    check(a, b.float().cpu(), dtype, "conv3x3 wfrag vs lds-staged")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,h,w", [(128, 128, 16, 32), (256, 192, 9, 21), (64, 64, 20, 20)])
+def test_conv3x3_lds_staged_kernel_shapes(cuda, dtype, cin, cout, h, w):
+    ops.USE_CONV3_WFRAG = False
+    try:
+        _conv_case(cuda, dtype, "ps%d_%d" % (cin, cout), 2, cin, h, w, cout, 3, 1, 1, bias=False, bn=True, act=1, residual=True)
+    finally:
+        ops.USE_CONV3_WFRAG = True
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv3x3_matches_generic_igemm(cuda, dtype):
     """same plan through both kernels (the generic implicit GEMM is the fallback for padded outputs / stride 2)"""
     x = procedural_input("pg.x", (3, 128, 24, 40), 0)
