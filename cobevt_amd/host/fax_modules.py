@@ -49,8 +49,13 @@ class Bottleneck(HipModule):
         self.relu = nn.ReLU(inplace=True)
         self.downsample = None
 
-    def forward_nhwc(self, x):
-        y = ops.conv2d(x, rt.conv_plan(self, "c1", self.conv1, self.bn1, act=1))
+    def entry_plan(self):
+        """conv1 + bn1 + ReLU as a row-local GEMM plan: the producer of x may compute it in its own launch
+        (ops.attn_mlp_chain next_plan) and hand the result to forward_nhwc(x, y1=...)."""
+        return rt.conv_plan(self, "c1", self.conv1, self.bn1, act=1)
+
+    def forward_nhwc(self, x, y1=None):
+        y = ops.conv2d(x, self.entry_plan()) if y1 is None else y1
         y = ops.conv2d(y, rt.conv_plan(self, "c2", self.conv2, self.bn2, act=1))
         return ops.conv2d(y, rt.conv_plan(self, "c3", self.conv3, self.bn3, act=1), residual=x)
 
@@ -147,11 +152,16 @@ class CrossWinAttention(HipModule):
         """LayerNorm + Linear of the key / value tokens (independent of the query -> can run ahead on a side stream)."""
         return self._project("k", self.to_k, k_src), self._project("v", self.to_v, v_src)
 
-    def attend_projected(self, q_src, kt, vt, qmap, kmap, omap, batch, out_shape):
-        """Query projection + fused window attention on already projected keys / values; returns the head-merged
-        attention output BEFORE self.proj."""
+    def q_plan(self):
+        """LayerNorm + Linear of the query as a plan (so the producer of the query rows can compute it in its launch)."""
+        return rt.linear_plan(self, "q", self.to_q[1], ln=self.to_q[0])
+
+    def attend_projected(self, q_src, kt, vt, qmap, kmap, omap, batch, out_shape, qt=None):
+        """Query projection (unless `qt` already holds it) + fused window attention on already projected keys / values;
+        returns the head-merged attention output BEFORE self.proj."""
         inner = self.heads * self.dim_head
-        qt = self._project("q", self.to_q, q_src)
+        if qt is None:
+            qt = self._project("q", self.to_q, q_src)
         a = torch.empty(tuple(out_shape) + (inner,), device=qt.device, dtype=qt.dtype)
         ops.window_attention(qt, kt, vt, a, qmap, kmap, omap, batch, self.heads, self.scale, inner, inner, inner, inner,
                              mean_q=qmap[1] > 1)
@@ -223,15 +233,16 @@ class CrossViewSwapAttention(HipModule):
         wp = ((w + ww) // ww) * ww if w % ww != 0 else w
         return hp, wp
 
-    def _proj_mlp(self, name, attn, a, skip, prenorm, mlp, postnorm=None):
-        """proj(a) + skip -> x + mlp(prenorm(x)) -> postnorm : one fused launch in bf16 mode (ops.attn_mlp_chain)."""
+    def _proj_mlp(self, name, attn, a, skip, prenorm, mlp, postnorm=None, next_plan=None):
+        """proj(a) + skip -> x + mlp(prenorm(x)) -> postnorm : one fused launch in bf16 mode (ops.attn_mlp_chain);
+        with next_plan also returns next_plan(result) (same launch when it fits)."""
         post = None
         if postnorm is not None:
             post = (rt.f32_param(self, name + ".post.w", postnorm.weight), rt.f32_param(self, name + ".post.b", postnorm.bias),
                     postnorm.eps)
         return ops.attn_mlp_chain(a, skip, rt.linear_plan(attn, "proj", attn.proj),
                                   rt.linear_plan(self, name + ".0", mlp[0], act=2, ln=prenorm),
-                                  rt.linear_plan(self, name + ".2", mlp[2]), post)
+                                  rt.linear_plan(self, name + ".2", mlp[2]), post, next_plan=next_plan)
 
     def prepare_kv(self, feature, I_inv, E_inv, batch):
         """Everything that depends only on the image features and camera geometry (fax_modules.py:346-358,377-396 and
@@ -266,8 +277,10 @@ class CrossViewSwapAttention(HipModule):
         k2, v2 = self.cross_win_attend_2.project_kv(key, val)
         return {"n": n, "hp": hp, "wp": wp, "k1": k1, "v1": v1, "k2": k2, "v2": v2}
 
-    def forward_query(self, index, x, bev, E_inv, kv):
-        """The query side of fax_modules.py:360-441 given prepare_kv()'s result.  x (b,H,W,d) -> (b,H,W,d)"""
+    def forward_query(self, index, x, bev, E_inv, kv, next_plan=None):
+        """The query side of fax_modules.py:360-441 given prepare_kv()'s result.  x (b,H,W,d) -> (b,H,W,d).
+        next_plan: the row-local plan that consumes the result next (the following ResNetBottleNeck's conv1); when
+        given, returns (result, next_plan(result))."""
         b, H, W, d = x.shape
         n, hp, wp = kv["n"], kv["hp"], kv["wp"]
         W1, W2 = self.q_win_size
@@ -290,11 +303,12 @@ class CrossViewSwapAttention(HipModule):
             raise CobevtHipError("query windows %dx%d != key windows %dx%d" % (qmap_1[6], qmap_1[7], kwin[6], kwin[7]))
         # local-to-local: window queries x window keys; per-camera queries are averaged in-kernel
         a = self.cross_win_attend_1.attend_projected(query, kv["k1"], kv["v1"], qmap_n, kwin, qmap_1, b, (b, H, W))
-        y = self._proj_mlp("mlp1", self.cross_win_attend_1, a, x if self.skip else None, self.prenorm_1, self.mlp_1)
+        y, q2 = self._proj_mlp("mlp1", self.cross_win_attend_1, a, x if self.skip else None, self.prenorm_1, self.mlp_1,
+                               next_plan=self.cross_win_attend_2.q_plan())
         # local-to-global: the n query replicas of the reference are identical -> one copy
-        a = self.cross_win_attend_2.attend_projected(y, kv["k2"], kv["v2"], qmap_1, kgrid, qmap_1, b, (b, H, W))
+        a = self.cross_win_attend_2.attend_projected(y, kv["k2"], kv["v2"], qmap_1, kgrid, qmap_1, b, (b, H, W), qt=q2)
         return self._proj_mlp("mlp2", self.cross_win_attend_2, a, y if self.skip else None, self.prenorm_2, self.mlp_2,
-                              self.postnorm)
+                              self.postnorm, next_plan=next_plan)
 
     def forward_nhwc(self, index, x, bev, feature, I_inv, E_inv):
         """x (b,H,W,d); feature (b*n,h,w,C) compute dtype; I_inv (b*n,3,3), E_inv (b*n,4,4) fp32 -> (b,H,W,d)"""
@@ -369,9 +383,14 @@ class FAXModule(HipModule):
         x = prior[None].expand(batch, *prior.shape).contiguous()
         for i, (cross_view, feature, layer) in enumerate(zip(self.cross_views, features, self.layers)):
             kvi = kv[i]() if kv is not None else cross_view.prepare_kv(feature, I_inv, E_inv, batch)
-            x = cross_view.forward_query(i, x, self.bev_embedding, E_inv, kvi)
-            for blk in layer:
-                x = blk.forward_nhwc(x)
+            blocks = list(layer)
+            y1 = None
+            if blocks:
+                x, y1 = cross_view.forward_query(i, x, self.bev_embedding, E_inv, kvi, next_plan=blocks[0].entry_plan())
+            else:
+                x = cross_view.forward_query(i, x, self.bev_embedding, E_inv, kvi)
+            for j, blk in enumerate(blocks):
+                x = blk.forward_nhwc(x, y1=y1 if j == 0 else None)
             if i < len(self.cross_views) - 1:
                 x = self.downsample_layers[i][0].forward_nhwc(x)
         if self.self_attn is not None:

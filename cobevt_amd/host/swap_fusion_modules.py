@@ -39,9 +39,14 @@ class Attention(HipModule):
                  + (ca[:, None] - ca[None, :] + w - 1) * (2 * w - 1) + (cb[:, None] - cb[None, :] + w - 1))
         self.register_buffer("relative_position_index", index)
 
-    def forward_fused(self, xn, residual=None, mask=None, mode=2, ln=None, core_only=False):
+    def qkv_plan(self, ln=None):
+        """to_qkv (with the PreNormResidual LayerNorm `ln` folded in) as a plan the producer of the rows may run."""
+        return rt.linear_plan(self, "qkv", self.to_qkv, ln=ln)
+
+    def forward_fused(self, xn, residual=None, mask=None, mode=2, ln=None, core_only=False, qkv=None):
         """xn (compute dtype; LayerNorm'ed already, or raw with ln=<nn.LayerNorm container> to fuse it): mode 2 -> (b l X Y w1 w2 d) partitioned, mask (b X Y w1 w2 1 l);
-        mode 0 (window) / 1 (grid) -> (b l H W d), mask (b H W 1 l).  Returns to_out(attn) (+ residual)."""
+        mode 0 (window) / 1 (grid) -> (b l H W d), mask (b H W 1 l).  Returns to_out(attn) (+ residual).
+        qkv: to_qkv(ln(xn)) when the producer of xn already computed it."""
         L, w = self.window_size[0], self.window_size[1]
         if mode == 2:
             b, l, X, Y, w1, w2, d = xn.shape
@@ -52,7 +57,8 @@ class Attention(HipModule):
             m = ops.tokmap(mode, l, H, W, w, w)
         if l != L or w1 != w or w2 != w:
             raise CobevtHipError("swap attention built for %d agents x %dx%d windows, got %d x %dx%d" % (L, w, w, l, w1, w2))
-        qkv = ops.linear(xn, rt.linear_plan(self, "qkv", self.to_qkv, ln=ln))
+        if qkv is None:
+            qkv = ops.linear(xn, self.qkv_plan(ln))
         out = torch.empty(xn.shape, device=xn.device, dtype=xn.dtype)
         table = rt.f32_param(self, "table", self.relative_position_bias_table.weight)
         mk = None
@@ -81,14 +87,27 @@ def _from_blhwc(x):
     return x.permute(0, 1, 4, 2, 3)
 
 
-def _attn_ffd(attn_res, ffd_res, x, mask, mode):
+def _attn_ffd(attn_res, ffd_res, x, mask, mode, qkv=None, next_attn=None):
     """PreNormResidual(Attention) followed by PreNormResidual(FeedForward) on (b, l, h, w, d):
-    attention core, then to_out + residual + LayerNorm + FeedForward + residual as one fused row chain."""
+    attention core, then to_out + residual + LayerNorm + FeedForward + residual as one fused row chain.
+    qkv: this attention's to_qkv(norm(x)) if the previous stage already produced it; next_attn: the PreNormResidual
+    (Attention) that consumes the result - its norm + to_qkv then ride in this stage's launch and (x, qkv) is returned."""
     attn, ffd = attn_res.fn, ffd_res.fn
-    a = attn.forward_fused(x, mask=mask, mode=mode, ln=attn_res.norm, core_only=True)
+    a = attn.forward_fused(x, mask=mask, mode=mode, ln=attn_res.norm, core_only=True, qkv=qkv)
+    nxt = next_attn.fn.qkv_plan(next_attn.norm) if next_attn is not None else None
     return ops.attn_mlp_chain(a, x, rt.linear_plan(attn, "out", attn.to_out[0]),
                               rt.linear_plan(ffd, "fc1", ffd.net[0], act=2, ln=ffd_res.norm),
-                              rt.linear_plan(ffd, "fc2", ffd.net[3]))
+                              rt.linear_plan(ffd, "fc2", ffd.net[3]), next_plan=nxt)
+
+
+def _run_stages(stages, x, mask_of):
+    """stages: [(PreNormResidual(Attention), PreNormResidual(FeedForward), mode)] applied in order."""
+    qkv = None
+    for i, (ar, fr, mode) in enumerate(stages):
+        nxt = stages[i + 1][0] if i + 1 < len(stages) else None
+        r = _attn_ffd(ar, fr, x, mask_of(i), mode, qkv=qkv, next_attn=nxt)
+        x, qkv = r if nxt is not None else (r, None)
+    return x
 
 
 class SwapFusionBlockMask(HipModule):
@@ -102,9 +121,13 @@ class SwapFusionBlockMask(HipModule):
         self.grid_attention = PreNormResidual(input_dim, Attention(input_dim, dim_head, drop_out, agent_size, window_size))
         self.grid_ffd = PreNormResidual(input_dim, FeedForward(input_dim, mlp_dim, drop_out))
 
+    def stages(self):
+        return [(self.window_attention, self.window_ffd, 0), (self.grid_attention, self.grid_ffd, 1)]
+
+    uses_mask = True
+
     def forward_blhwc(self, x, mask):
-        x = _attn_ffd(self.window_attention, self.window_ffd, x, mask, 0)
-        return _attn_ffd(self.grid_attention, self.grid_ffd, x, mask, 1)
+        return _run_stages(self.stages(), x, lambda i: mask)
 
     def forward(self, x, mask):
         """x: (b, l, c, h, w); mask: (b, h, w, 1, l)"""
@@ -127,9 +150,13 @@ class SwapFusionBlock(HipModule):
             PreNormResidual(input_dim, FeedForward(input_dim, mlp_dim, drop_out)),
             nn.Identity())
 
+    def stages(self):
+        return [(self.block[1], self.block[2], 0), (self.block[5], self.block[6], 1)]
+
+    uses_mask = False
+
     def forward_blhwc(self, x, mask=None):
-        x = _attn_ffd(self.block[1], self.block[2], x, None, 0)
-        return _attn_ffd(self.block[5], self.block[6], x, None, 1)
+        return _run_stages(self.stages(), x, lambda i: None)
 
     def forward(self, x, mask=None):
         self._require_inference(x)
@@ -156,8 +183,12 @@ class SwapFusionEncoder(HipModule):
 
     def forward_blhwc(self, x, mask=None):
         """x (b, l, h, w, d) channels-last compute dtype -> (b, h, w, d)"""
-        for stage in self.layers:
-            x = stage.forward_blhwc(x, mask)
+        stages, masks = [], []
+        for layer in self.layers:
+            st = layer.stages()
+            stages += st
+            masks += [mask if layer.uses_mask else None] * len(st)
+        x = _run_stages(stages, x, lambda i: masks[i])
         b, l, h, w, d = x.shape
         ln = self.mlp_head[2]
         y = ops.mean_layernorm(x.reshape(b, l, h * w, d), rt.f32_param(self, "head.ln.w", ln.weight),

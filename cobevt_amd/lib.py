@@ -24,7 +24,7 @@ SIGNATURES = {
     "cobevt_conv3x3_wfrag_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_stem_conv7x7s2": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_linear_rows": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_long_p, ctypes.c_float, _vp]),
-    "cobevt_attn_mlp_chain": (ctypes.c_int, [_vp] * 11 + [_c_int_p, ctypes.c_float, ctypes.c_float, _vp]),
+    "cobevt_attn_mlp_chain": (ctypes.c_int, [_vp] * 14 + [_c_int_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
     "cobevt_window_attention": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int_p, ctypes.c_float, _vp]),
     "cobevt_layernorm": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                         ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_int, _vp]),

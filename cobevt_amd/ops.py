@@ -19,6 +19,7 @@ CONV3_VARIANT = 0    # 0 = automatic tile choice of cobevt_conv3x3_wfrag_nhwc; >
 USE_GEMM_ROWS = True  # route 1x1 stride-1 convs / linears to the dense-row GEMM with fused LayerNorm
 USE_STEM = True       # 7x7/s2 image stem through the space-to-depth kernel instead of the generic small-Cin igemm
 USE_ROW_CHAIN = True  # fuse out-proj + skip + pre-norm MLP (+ post-norm) after attention into one launch (bf16)
+USE_CHAIN_NEXT = True  # ... and let the row-local GEMM that consumes its output next ride in the same launch
 
 
 def dcode(dtype):
@@ -542,10 +543,18 @@ def channel_affine(x, scale, shift):
     return out
 
 
-def attn_mlp_chain(a, skip, plan_p, plan_1, plan_2, post_ln=None):
+def chain_next_fusable(plan_n, c):
+    """Can `plan_n` (a Linear / 1x1 conv plan reading C-channel rows) ride at the end of the fused row chain?"""
+    return (plan_n is not None and plan_n.wgt_rows is not None and plan_n.kp_rows == 128 and plan_n.K == c
+            and plan_n.cout % 8 == 0 and plan_n.cout <= 1024 and plan_n.pre_scale is None and not plan_n.pre_relu)
+
+
+def attn_mlp_chain(a, skip, plan_p, plan_1, plan_2, post_ln=None, next_plan=None):
     """out = postLN( y + fc2(GELU(fc1(LN(y)))) ),  y = proj(a) + skip.   a, skip: (..., C) contiguous.
     plan_1 must be built with ln=<prenorm> (affine folded) and act=GELU; post_ln = (gamma, beta, eps) fp32 or None.
-    One fused launch in bf16 mode when the shapes fit (C <= 128, hidden <= 256); otherwise three GEMM launches."""
+    One fused launch in bf16 mode when the shapes fit (C <= 128, hidden <= 256); otherwise three GEMM launches.
+    next_plan: the Linear / 1x1-conv plan that consumes `out` next (LayerNorm folded via ln=..., BN folded, act); when
+    given the call returns (out, next_plan(out)) - computed inside the same launch when fused."""
     _need_cuda(a, skip)
     c, hd = plan_p.cout, plan_1.cout
     fusable = (USE_ROW_CHAIN and a.dtype == torch.bfloat16 and plan_p.wgt_rows is not None and plan_1.wgt_rows is not None
@@ -557,20 +566,30 @@ def attn_mlp_chain(a, skip, plan_p, plan_1, plan_2, post_ln=None):
     if not fusable:
         y = linear(a, plan_p, residual=skip)
         z = linear(linear(y, plan_1), plan_2, residual=y)
-        return layernorm(z, post_ln[0], post_ln[1], post_ln[2]) if post_ln is not None else z
+        z = layernorm(z, post_ln[0], post_ln[1], post_ln[2]) if post_ln is not None else z
+        return (z, linear(z, next_plan)) if next_plan is not None else z
     m = a.numel() // c
     out = torch.empty_like(a)
-    dims = _ints([0, m, c, hd, plan_2.kp_rows])
+    fuse_next = USE_CHAIN_NEXT and chain_next_fusable(next_plan, c)
+    nn_ = next_plan.cout if fuse_next else 0
+    out_next = torch.empty(a.shape[:-1] + (nn_,), device=a.device, dtype=a.dtype) if fuse_next else None
+    dims = _ints([0, m, c, hd, plan_2.kp_rows, nn_, int(next_plan.has_ln) if fuse_next else 0,
+                  next_plan.act if fuse_next else 0])
     pg, pb, pe = post_ln if post_ln is not None else (None, None, 0.0)
 
     def cost():
-        flops = 2.0 * m * (c * c + 2 * c * hd)
-        return flops, float((3 if skip is not None else 2) * m * c * 2 + (c * c + 2 * c * hd) * 2)
+        flops = 2.0 * m * (c * c + 2 * c * hd + c * nn_)
+        return flops, float((3 if skip is not None else 2) * m * c * 2 + m * nn_ * 2 + (c * c + 2 * c * hd + c * nn_) * 2)
 
-    with _timed("row_chain|C%d H%d M=%d%s" % (c, hd, m, " post" if post_ln is not None else ""), cost):
+    with _timed("row_chain|C%d H%d M=%d%s%s" % (c, hd, m, " post" if post_ln is not None else "",
+                                                  " +next%d" % nn_ if fuse_next else ""), cost):
         rc = _L.load().cobevt_attn_mlp_chain(_p(a), _p(skip), _p(out), _p(plan_p.wgt_rows), _p(plan_p.bias),
                                              _p(plan_1.wgt_rows), _p(plan_1.bias), _p(plan_2.wgt_rows), _p(plan_2.bias),
-                                             _p(pg), _p(pb), dims, ctypes.c_float(plan_1.ln_eps), ctypes.c_float(pe),
-                                             _stream())
+                                             _p(pg), _p(pb), _p(next_plan.wgt_rows) if fuse_next else None,
+                                             _p(next_plan.bias) if fuse_next else None, _p(out_next), dims,
+                                             ctypes.c_float(plan_1.ln_eps), ctypes.c_float(pe),
+                                             ctypes.c_float(next_plan.ln_eps if fuse_next else 0.0), _stream())
     _L.check(rc, "cobevt_attn_mlp_chain")
-    return out
+    if next_plan is None:
+        return out
+    return out, (out_next if fuse_next else linear(out, next_plan))

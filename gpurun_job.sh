@@ -1,3 +1,3 @@
 timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
-timeout 600 python bench.py > gpurun_out/bench15.log 2>&1; tail -2 gpurun_out/bench15.log
-TOP=30 timeout 300 python tools/profile_shapes.py > gpurun_out/shapes10.log 2>&1; head -34 gpurun_out/shapes10.log
+timeout 600 python bench.py --no-cpu-baseline > gpurun_out/bench16.log 2>&1; tail -1 gpurun_out/bench16.log | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['parity'])"

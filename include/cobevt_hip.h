@@ -100,13 +100,19 @@ int cobevt_linear_rows(const void* in, const void* wgt, const float* bias, const
 
 /*
  * Fused row-local chain after an attention (bf16 mode):  y = a.Wp^T (+bp) + skip ;  z = y + fc2(GELU(fc1'(norm(y)))) ;
- * out = post-LayerNorm(z) (optional).  Replaces fax_modules.py:240,246-247 + :411 / :435-437 and
- * swap_fusion_modules.py:126,177 + base_transformer.py:102-124 in one launch (hidden activations stay in LDS).
- * wp [C][128], w1 [Hd][128] (LayerNorm affine folded in), w2 [C][Hdp]; dims (int32[5]): dtype(0), M, C(<=128), Hd(<=256), Hdp.
+ * out = post-LayerNorm(z) (optional) ;  out_next = act(norm?(out).Wn'^T + bn') (optional).  Replaces
+ * fax_modules.py:240,246-247 + :411 / :435-437 and swap_fusion_modules.py:126,177 + base_transformer.py:102-124 in one
+ * launch (hidden activations stay in LDS); the optional next projection is the row-local GEMM that reads `out` next in
+ * the reference graph (to_qkv behind PreNormResidual.norm swap_fusion_modules.py:93, to_q of the second cross attention
+ * fax_modules.py:201, the first 1x1 conv + BN + ReLU of the following ResNetBottleNeck fax_modules.py:472).
+ * wp [C][128], w1 [Hd][128] (LayerNorm affine folded in), w2 [C][Hdp], wnext [Nn][128] (LayerNorm affine / BN folded
+ * in; nullable together with out_next [M][Nn]).  dims (int32[8]): dtype(0), M, C(<=128), Hd(<=256), Hdp, Nn,
+ * next_ln (1 = normalise the stored `out` rows first), next_act (0 none, 1 ReLU, 2 GELU).
  */
 int cobevt_attn_mlp_chain(const void* a, const void* skip, void* out, const void* wp, const float* bp, const void* w1,
                           const float* b1, const void* w2, const float* b2, const float* post_gamma,
-                          const float* post_beta, const int* dims, float eps1, float eps_post, hipStream_t stream);
+                          const float* post_beta, const void* wnext, const float* bnext, void* out_next, const int* dims,
+                          float eps1, float eps_post, float eps_next, hipStream_t stream);
 
 /*
  * Fused gathered attention: window / dilated-grid partition -> QK^T -> (+relative position bias, key mask)

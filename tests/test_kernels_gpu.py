@@ -335,6 +335,52 @@ def test_attn_mlp_chain_fused(cuda, c, hd, rows, post, proj_bias, skip):
     assert (y.float() - y3.float()).abs().max().item() <= 3e-2 * s
 
 
+@pytest.mark.parametrize("c,rows,nn_,next_ln,next_act,post", [(128, 1000, 384, True, 0, False), (128, 130, 128, True, 0, False),
+                                                              (128, 333, 32, False, 1, True), (64, 70, 200, True, 2, True)])
+def test_attn_mlp_chain_next_projection(cuda, c, rows, nn_, next_ln, next_act, post):
+    """the row-local GEMM that consumes the chain's output (to_qkv behind a LayerNorm, to_q, a Bottleneck's conv1 + BN + ReLU)
+    fused into the same launch: `out` identical to the plain chain, `next` vs the separate dense-row GEMM and torch"""
+    dtype, hd = torch.bfloat16, 2 * c
+    a = procedural_input("cn.a", (rows, c), 0, -2, 2)
+    sk = procedural_input("cn.s", (rows, c), 0, -1, 1)
+    mk = lambda key, shape, fan: procedural_input(key, shape, 0) * math.sqrt(3.0 / fan)
+    wp, w1, w2, wn = mk("cn.wp", (c, c), c), mk("cn.w1", (hd, c), c), mk("cn.w2", (c, hd), hd), mk("cn.wn", (nn_, c), c)
+    b1, b2 = procedural_input("cn.b1", (hd,), 0, -0.2, 0.2), procedural_input("cn.b2", (c,), 0, -0.2, 0.2)
+    bn_ = procedural_input("cn.bn", (nn_,), 0, -0.2, 0.2)
+
+    class LN1(object):
+        weight, bias, eps = 0.8 + 0.4 * procedural_input("cn.g1", (c,), 0, 0, 1), procedural_input("cn.be1", (c,), 0, -0.2, 0.2), 1e-5
+
+    class LNn(object):
+        weight, bias, eps = 0.8 + 0.4 * procedural_input("cn.gn", (c,), 0, 0, 1), procedural_input("cn.ben", (c,), 0, -0.2, 0.2), 1e-5
+    g2, be2 = 0.8 + 0.4 * procedural_input("cn.g2", (c,), 0, 0, 1), procedural_input("cn.be2", (c,), 0, -0.2, 0.2)
+    pp = ops.ConvPlan(wp, None, dtype=dtype, device=cuda)
+    p1 = ops.ConvPlan(w1, b1, act=2, dtype=dtype, device=cuda, ln=LN1)
+    p2 = ops.ConvPlan(w2, b2, dtype=dtype, device=cuda)
+    pn = ops.ConvPlan(wn, bn_, act=next_act, dtype=dtype, device=cuda, ln=LNn if next_ln else None)
+    post_ln = (g2.to(cuda), be2.to(cuda), 1e-5) if post else None
+    ad, sd = a.to(cuda).to(dtype), sk.to(cuda).to(dtype)
+    assert ops.USE_ROW_CHAIN and ops.USE_CHAIN_NEXT and ops.chain_next_fusable(pn, c)
+    y0 = ops.attn_mlp_chain(ad, sd, pp, p1, p2, post_ln)
+    y, nx = ops.attn_mlp_chain(ad, sd, pp, p1, p2, post_ln, next_plan=pn)
+    assert torch.equal(y, y0), "the next projection must not change the chain's own output"
+    assert nx.shape == (rows, nn_)
+    ops.USE_CHAIN_NEXT = False
+    try:
+        y_b, nx_b = ops.attn_mlp_chain(ad, sd, pp, p1, p2, post_ln, next_plan=pn)      # separate dense-row GEMM launch
+    finally:
+        ops.USE_CHAIN_NEXT = True
+    assert torch.equal(y_b, y0)
+    xin = y0.float().cpu()
+    if next_ln:
+        xin = F.layer_norm(xin, (c,), LNn.weight, LNn.bias, 1e-5)
+    ref = F.linear(xin, rnd(wn, dtype), bn_)
+    ref = F.relu(ref) if next_act == 1 else (F.gelu(ref) if next_act == 2 else ref)
+    s = ref.abs().max().item()
+    assert (nx.float().cpu() - ref).abs().max().item() <= 3e-2 * s
+    assert (nx.float() - nx_b.float()).abs().max().item() <= 2e-2 * s
+
+
 # ---------------------------------------------------------------------------------------------
 def _attn_ref(q, k, v, scale, bias=None, key_mask=None):
     """q (G, Nq, dh), k/v (G, Nk, dh) fp32 -> (G, Nq, dh)"""

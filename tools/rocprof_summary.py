@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 --kernel-trace results .db (rocpd sqlite) into a per-kernel table (name, calls, total,
-avg, %), optionally listing the N longest dispatches.  Usage: rocprof_summary.py results.db [--top N] [--frames F]"""
+avg, %), optionally listing the N longest dispatches, a per-(kernel, grid) table (--by-grid) and the dispatch timeline
+of the last graph replay (--timeline N: the last N dispatches with start offsets, gaps and overlap).
+Usage: rocprof_summary.py results.db [--top N] [--frames F] [--by-grid] [--timeline N]"""
 import collections
 import re
 import sqlite3
@@ -30,6 +32,32 @@ def main():
     print("%10s %6s %6s %9s  %4s %4s %6s %5s  %s" % ("total_us", "calls", "%", "avg_us", "vgpr", "agpr", "lds", "scr", "kernel"))
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print("%10.1f %6d %6.2f %9.2f  %4d %4d %6d %5d  %s" % (a[1], a[0], 100 * a[1] / tot, a[1] / a[0], a[2], a[3], a[4], a[5], k))
+    if "--by-grid" in sys.argv:
+        g = collections.OrderedDict()
+        for n, s, e, gx, gy, gz, wx, lds, vg, ag, sc in rows:
+            a = g.setdefault((short(n)[:60], gx * gy * gz // max(wx, 1)), [0, 0.0])
+            a[0] += 1
+            a[1] += (e - s) / 1e3
+        print("\nper (kernel, workgroups), us per frame:")
+        for k, a in sorted(g.items(), key=lambda kv: -kv[1][1]):
+            print("%9.1f us/frame %6.2f calls/frame %8.2f us avg  %6d wgs  %s" % (a[1] / frames, a[0] / frames, a[1] / a[0], k[1], k[0]))
+    if "--timeline" in sys.argv:
+        nlast = int(sys.argv[sys.argv.index("--timeline") + 1])
+        last = rows[-nlast:]
+        if "--densest" in sys.argv:          # the N-dispatch window with the smallest span (= a HIP-graph replay)
+            best = min(range(0, len(rows) - nlast), key=lambda i: rows[i + nlast - 1][2] - rows[i][1])
+            last = rows[best:best + nlast]
+        t0 = last[0][1]
+        busy_end = t0
+        idle = 0.0
+        print("\ntimeline of the last %d dispatches (start us, dur us, gap since all earlier kernels ended):" % nlast)
+        for n, s, e, gx, gy, gz, wx, lds, vg, ag, sc in last:
+            gap = (s - busy_end) / 1e3
+            if gap > 0:
+                idle += gap
+            print("%9.1f %7.1f %6.1f  %6d wgs  %s" % ((s - t0) / 1e3, (e - s) / 1e3, gap, gx * gy * gz // max(wx, 1), short(n)[:70]))
+            busy_end = max(busy_end, e)
+        print("span %.1f us, idle (no kernel running) %.1f us" % ((busy_end - t0) / 1e3, idle))
     if top:
         print("\nlongest %d dispatches:" % top)
         for n, s, e, gx, gy, gz, wx, lds, vg, ag, sc in sorted(rows, key=lambda r: r[1] - r[2])[:top]:
