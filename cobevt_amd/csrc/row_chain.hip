@@ -7,17 +7,23 @@
 //
 // i.e. fax_modules.py:240,246-247 (proj + skip) followed by :411 / :435-437 (mlp_1 / mlp_2 + postnorm), and
 // swap_fusion_modules.py:126,177 (to_out + PreNormResidual residual) followed by base_transformer.py:102-124
-// (PreNormResidual(FeedForward)).  Rows are independent, so a workgroup carries a 64-row tile through all three GEMMs
-// with y, LN(y) and the 2C-wide hidden activations resident in LDS; only `a`, `skip` and `out` touch HBM
+// (PreNormResidual(FeedForward)).  Rows are independent, so a workgroup carries a 64-row tile through all the GEMMs
+// with y, LN(y) and the 2C-wide hidden activations resident in LDS; only `a`, `skip`, `out` (and `next`) touch HBM
 // (the unfused path writes and re-reads y and the hidden tensor and costs three launches).  The optional `next` phase
 // is the row-local GEMM that reads `out` in the reference graph - the to_qkv of the following swap-fusion attention
 // (swap_fusion_modules.py:93 behind PreNormResidual.norm), the to_q of the second cross attention (fax_modules.py:201,
 // 420-428) or the first 1x1 conv + BN + ReLU of the ResNetBottleNeck that follows (fax_modules.py:472) - done while the
 // rows are still in LDS: in the latency-bound tail of the frame every separate launch costs 7-12 us for ~2 us of work.
 //
-// 512 threads = 8 waves arranged 2 (rows) x 4 (columns): every wave owns one 32x32 MFMA tile of a 64 x 128 output
-// panel.  Weight panels ([128 rows][256 bytes], gemm_rows layout) stream through one LDS buffer with register
-// prefetch of the next panel.  C <= 128 channels, hidden <= 256.
+// Weights arrive in MFMA fragment order [N/32 tiles][Kp/16 k-groups][64 lanes][16 bytes] (lane = 32*half + n%32 holds
+// bytes [32*kgroup + 16*half, +16) of weight row n), so a wave's operand for one (32-column tile, k-group) is ONE coalesced
+// 1-KB load from L2 straight into registers, prefetched one GEMM ahead in two ping-pong register sets: no weight panel in
+// LDS, no barrier pair per panel, and 67 KB of LDS per workgroup instead of 101 KB -> two workgroups per CU, so one
+// tile's barriers and epilogues hide under the other's MFMAs (the first version ran 95-104 us on the 81,920-row level-0
+// maps with the MFMA pipe ~6 % busy).  The MFMAs are issued as D = W . X^T, so a lane ends up with one ROW of the tile
+// and four runs of four consecutive output columns: every epilogue is 8-byte LDS traffic instead of sixteen 2-byte writes.
+//
+// 512 threads = 8 waves arranged 2 (row halves) x 4 (32-column tiles of a 128-column panel).  C <= 128, hidden <= 256.
 #include "common.hpp"
 
 namespace cobevt {
@@ -26,15 +32,15 @@ struct RowChainParams {
     const bf16_t* a;        // [M][C] attention output
     const bf16_t* skip;     // [M][C] or null
     bf16_t* out;            // [M][C]
-    const bf16_t* wp;       // [C][128]   out-projection
+    const uint4* wp;        // fragment-ordered [4 tiles][8]      out-projection
     const float* bp;        // [C] or null
-    const bf16_t* w1;       // [Hd][128]  fc1 with the LayerNorm affine folded in
+    const uint4* w1;        // fragment-ordered [8 tiles][8]      fc1 with the LayerNorm affine folded in
     const float* b1;        // [Hd]
-    const bf16_t* w2;       // [C][Hdp]   fc2, Hdp = Hd rounded up to 128
+    const uint4* w2;        // fragment-ordered [4 tiles][Hdp/16] fc2
     const float* b2;        // [C]
     const float* post_g;    // post-LayerNorm affine or null
     const float* post_b;
-    const bf16_t* wn;       // [Nn][128]  next projection (LayerNorm affine / BN folded in) or null
+    const uint4* wn;        // fragment-ordered [4*ceil(Nn/128) tiles][8]  next projection or null
     const float* bn;        // [Nn] or null
     bf16_t* out_next;       // [M][Nn]
     int M, C, Hd, Hdp;
@@ -46,40 +52,78 @@ constexpr int kRcThreads = 512;
 constexpr int kRcRows = 64;
 constexpr int kRcRow = 256 + 16;            // 128 bf16 + pad
 constexpr int kRcHRow = 512 + 16;           // 256 bf16 + pad ; also the fp32 staging row of 128 floats
-constexpr int kRcA = 0;                                  // a tile, later LN(y)
-constexpr int kRcY = kRcA + kRcRows * kRcRow;            // y tile (bf16)
-constexpr int kRcW = kRcY + kRcRows * kRcRow;            // weight panel [128][272]
-constexpr int kRcH = kRcW + 128 * kRcRow;                // hidden tile [64][528] ; fp32 staging of z
-constexpr int kRcLds = kRcH + kRcRows * kRcHRow;         // 103,424 bytes
+constexpr int kRcA = 0;                                  // a tile, later LN(y), later the next projection's A operand
+constexpr int kRcY = kRcA + kRcRows * kRcRow;            // y tile (bf16) ; staging of the next projection's output
+constexpr int kRcH = kRcY + kRcRows * kRcRow;            // hidden tile [64][528] ; fp32 staging of z
+constexpr int kRcLds = kRcH + kRcRows * kRcHRow;         // 68,608 bytes
 
-__global__ __launch_bounds__(kRcThreads) void row_chain_kernel(RowChainParams p) {
+// normalise one row held by 8 lanes (16 channels each; channels >= C are zero on entry and on exit)
+__device__ __forceinline__ void rc_normalise(float (&v)[16], int sub, int C, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += v[e];
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { const float d = (sub * 16 + e) < C ? v[e] - mean : 0.f; q += d * d; }
+    q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+    const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = (sub * 16 + e) < C ? (v[e] - mean) * rstd : 0.f;
+}
+
+template <int NPASS>   // 128-column passes over the hidden layer (Hd <= 128 -> 1, else 2)
+__global__ __launch_bounds__(kRcThreads, 4) void row_chain_kernel(RowChainParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem + kRcA;
     unsigned char* Ys = smem + kRcY;
-    unsigned char* Ws = smem + kRcW;
     unsigned char* Hs = smem + kRcH;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, ql = lane & 31;
-    const int wm = wave >> 2, wn = wave & 3;         // 2 x 4 waves, 32 x 32 each
+    const int wm = wave >> 2, wn = wave & 3;         // 2 x 4 waves, 32 rows x 32 columns each
     const int m0 = blockIdx.x * kRcRows;
     const int ngc = (p.C * 2 + 31) / 32;             // 32-byte k-groups covering C channels
+    const int row = wm * 32 + ql;                    // this lane's row of the tile in every MFMA result
+    const bool row_ok = m0 + row < p.M;
 
-    // weight panel staging: thread t -> row t>>2, 64-byte quarter t&3 (4 x 16 bytes)
-    const int wrow = tid >> 2, wsub = tid & 3;
-    uint4 wreg[4];
-    auto load_w = [&](const bf16_t* w, int ld, int row0, int nrows, int k0) {
+    // fragment loads: up to 8 k-groups of one 32-column tile; fully unrolled predicated code so both register sets stay
+    // in VGPRs.  sched_barrier keeps each prefetch where it is written (LLVM otherwise sinks the loads to their first use).
+    auto load_frags = [&](uint4 (&b)[8], const uint4* w, int tile, int nkg, int kg0, int n) {
+        const uint4* src = w + ((size_t)tile * nkg + kg0) * 64 + lane;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            wreg[j] = (row0 + wrow < nrows) ? *(const uint4*)(w + (size_t)(row0 + wrow) * ld + k0 + (wsub * 4 + j) * 8)
-                                            : make_uint4(0, 0, 0, 0);
+        for (int g = 0; g < 8; ++g)
+            if (g < n) b[g] = src[g * 64];
+        __builtin_amdgcn_sched_barrier(0);
     };
-    auto store_w = [&]() {
+    f32x16 acc;
+    auto mma = [&](const unsigned char* A, int a_off, const uint4 (&b)[8], int n, bool zero) {
+        if (zero) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *(uint4*)(Ws + wrow * kRcRow + (wsub * 4 + j) * 16) = wreg[j];
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+            if (g < n) {
+                const uint4 af = *(const uint4*)(A + a_off + g * 32);
+                mfma_kgroup<bf16_t>(b[g], af, acc);  // D = W . X^T : acc register r <-> column acc_row(r), lane <-> row
+            }
     };
+    // this lane's four column runs: run k covers columns cbase + 8k .. +3 of the wave's 128-column panel
+    const int cbase = wn * 32 + 4 * h;
+    auto bias4 = [&](const float* b, int col0, int n) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b && col0 < n) v = *(const float4*)(b + col0);     // n % 8 == 0 and col0 % 4 == 0
+        return v;
+    };
+    auto pack4 = [&](float x, float y, float z, float w) { return make_uint2(pack_bf2(x, y), pack_bf2(z, w)); };
 
-    // ---- phase A: stage a (64 x C) and Wp
+    uint4 fa[8], fb[8];
+    const int abase = row * kRcRow + h * 16;
+
+    // ---- stage a (64 x C) ; first weight fragments in flight meanwhile
+    load_frags(fa, p.wp, wn, 8, 0, ngc);
     {
         const int r = tid >> 3, sub = tid & 7;       // 8 threads per row, 32 bytes each
         const bool ok = m0 + r < p.M;
@@ -91,118 +135,91 @@ __global__ __launch_bounds__(kRcThreads) void row_chain_kernel(RowChainParams p)
             *(uint4*)(As + r * kRcRow + (sub * 2 + j) * 16) = v;
         }
     }
-    load_w(p.wp, 128, 0, p.C, 0);
-    store_w();
-    load_w(p.w1, 128, 0, p.Hd, 0);                   // prefetch the first fc1 panel
+    // skip values of this lane's (row, column runs), straight from global while the tile lands
+    uint2 skp[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int col0 = cbase + 8 * k;
+        skp[k] = make_uint2(0, 0);
+        if (p.skip && row_ok && col0 < p.C) skp[k] = *(const uint2*)(p.skip + (size_t)(m0 + row) * p.C + col0);
+    }
     __syncthreads();
 
-    const int abase = (wm * 32 + ql) * kRcRow + h * 16;
-    const int bbase = (wn * 32 + ql) * kRcRow + h * 16;
-    f32x16 acc;
-    auto zero_acc = [&]() {
+    // ---- phase A: y = a . Wp^T + bp + skip -> Ys (bf16, exactly what the unfused path would have stored)
+    mma(As, abase, fa, ngc, true);
+    load_frags(fb, p.w1, wn, 8, 0, ngc);             // fc1 columns [32 wn, +32) ; needed after phase B
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    };
-    auto mma_panel = [&](const unsigned char* A, int a_off, int ng) {
-        for (int g = 0; g < ng; ++g) {
-            const uint4 af = *(const uint4*)(A + a_off + g * 32);
-            const uint4 bf = *(const uint4*)(Ws + bbase + g * 32);
-            mfma_kgroup<bf16_t>(af, bf, acc);
-        }
-    };
-
-    // y = a . Wp^T + bp + skip  -> Ys (bf16, exactly what the unfused path would have stored)
-    zero_acc();
-    mma_panel(As, abase, ngc);
-    {
-        const int col = wn * 32 + ql;
-        const float bias = (p.bp && col < p.C) ? p.bp[col] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * 32 + acc_row(r, lane);
-            float v = acc[r] + bias;
-            if (p.skip && col < p.C && m0 + row < p.M) v += bf2f(p.skip[(size_t)(m0 + row) * p.C + col].bits);
-            if (col >= p.C) v = 0.f;
-            *(uint16_t*)(Ys + row * kRcRow + col * 2) = f2bf(v);
-        }
+    for (int k = 0; k < 4; ++k) {
+        const int col0 = cbase + 8 * k;
+        const float4 b = bias4(p.bp, col0, p.C);
+        float v0 = acc[4 * k] + b.x + bf2f(skp[k].x & 0xffff), v1 = acc[4 * k + 1] + b.y + bf2f(skp[k].x >> 16);
+        float v2 = acc[4 * k + 2] + b.z + bf2f(skp[k].y & 0xffff), v3 = acc[4 * k + 3] + b.w + bf2f(skp[k].y >> 16);
+        if (col0 >= p.C) v0 = v1 = v2 = v3 = 0.f;
+        *(uint2*)(Ys + row * kRcRow + col0 * 2) = pack4(v0, v1, v2, v3);
     }
-    __syncthreads();                                  // Ys complete; As and Ws free
+    __syncthreads();                                  // Ys complete; As free
 
     // ---- phase B: x_hat = normalise(y) -> As ; 8 threads per row, 32 bytes (16 channels) each
+    if (NPASS == 2) load_frags(fa, p.w1, 4 + wn, 8, 0, ngc);   // fc1 columns [128 + 32 wn, +32)
+    else load_frags(fa, p.w2, wn, p.Hdp / 16, 0, 8);
     {
         const int r = tid >> 3, sub = tid & 7;
         float v[16];
         chunk_to_f32<bf16_t>(*(const uint4*)(Ys + r * kRcRow + sub * 32), v);
         chunk_to_f32<bf16_t>(*(const uint4*)(Ys + r * kRcRow + sub * 32 + 16), v + 8);
-        float s = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s += v[e];       // columns >= C are zero
-        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-        const float mean = s / (float)p.C;
-        float q = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { const float d = (sub * 16 + e) < p.C ? v[e] - mean : 0.f; q += d * d; }
-        q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
-        const float rstd = rsqrtf(q / (float)p.C + p.eps1);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = (sub * 16 + e) < p.C ? (v[e] - mean) * rstd : 0.f;
+        rc_normalise(v, sub, p.C, p.eps1);
         *(uint4*)(As + r * kRcRow + sub * 32) = f32_to_chunk<bf16_t>(v);
         *(uint4*)(As + r * kRcRow + sub * 32 + 16) = f32_to_chunk<bf16_t>(v + 8);
     }
-    store_w();                                        // fc1 panel 0 (prefetched) -> Ws
     __syncthreads();
 
     // ---- phase C: hidden = GELU(x_hat . W1'^T + b1') -> Hs, 128 hidden columns per pass
-    const int npass = (p.Hd + 127) / 128;
-    for (int pass = 0; pass < npass; ++pass) {
-        if (pass + 1 < npass) load_w(p.w1, 128, (pass + 1) * 128, p.Hd, 0);
-        else load_w(p.w2, p.Hdp, 0, p.C, 0);          // prefetch the first fc2 panel
-        zero_acc();
-        mma_panel(As, abase, ngc);
-        const int col = pass * 128 + wn * 32 + ql;
-        const float bias = col < p.Hd ? p.b1[col] : 0.f;
+    auto hidden_epilogue = [&](int pass) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * 32 + acc_row(r, lane);
-            const float v = col < p.Hd ? gelu_erf(acc[r] + bias) : 0.f;
-            *(uint16_t*)(Hs + row * kRcHRow + col * 2) = f2bf(v);
+        for (int k = 0; k < 4; ++k) {
+            const int col0 = pass * 128 + cbase + 8 * k;
+            const float4 b = bias4(p.b1, col0, p.Hd);
+            uint2 o = make_uint2(0, 0);
+            if (col0 < p.Hd) o = pack4(gelu_erf(acc[4 * k] + b.x), gelu_erf(acc[4 * k + 1] + b.y),
+                                       gelu_erf(acc[4 * k + 2] + b.z), gelu_erf(acc[4 * k + 3] + b.w));
+            *(uint2*)(Hs + row * kRcHRow + col0 * 2) = o;
         }
-        __syncthreads();                              // every wave done with Ws (and Hs columns written)
-        store_w();
+    };
+    const int hbase = row * kRcHRow + h * 16;
+    if (NPASS == 2) {
+        mma(As, abase, fb, ngc, true);
+        load_frags(fb, p.w2, wn, p.Hdp / 16, 0, 8);  // fc2 k-groups 0..7 (hidden columns 0..127)
+        hidden_epilogue(0);
+        mma(As, abase, fa, ngc, true);
+        load_frags(fa, p.w2, wn, p.Hdp / 16, 8, 8);  // fc2 k-groups 8..15
+        hidden_epilogue(1);
         __syncthreads();
-    }
-
-    // ---- phase D: z = hidden . W2^T + b2 + y
-    zero_acc();
-    for (int kt = 0; kt < npass; ++kt) {
-        if (kt + 1 < npass) load_w(p.w2, p.Hdp, 0, p.C, (kt + 1) * 128);
-        else if (p.wn) load_w(p.wn, 128, 0, p.Nn, 0);   // prefetch panel 0 of the next projection
-        const int kleft = p.Hd - kt * 128;
-        mma_panel(Hs, (wm * 32 + ql) * kRcHRow + kt * 256 + h * 16, kleft >= 128 ? 8 : (kleft * 2 + 31) / 32);
-        if (kt + 1 < npass) {
-            __syncthreads();
-            store_w();
-            __syncthreads();
-        }
+        // ---- phase D: z = hidden . W2^T
+        mma(Hs, hbase, fb, 8, true);
+        if (p.wn) load_frags(fb, p.wn, wn, 8, 0, ngc);
+        mma(Hs, hbase + 256, fa, 8, false);
+    } else {
+        mma(As, abase, fb, ngc, true);
+        if (p.wn) load_frags(fb, p.wn, wn, 8, 0, ngc);
+        hidden_epilogue(0);
+        __syncthreads();
+        mma(Hs, hbase, fa, (p.Hd * 2 + 31) / 32, true);
     }
     __syncthreads();                                  // Hs no longer read: reuse it as the fp32 staging of z
     float* stage = (float*)Hs;
     constexpr int SROW = kRcHRow / 4;
-    {
-        const int col = wn * 32 + ql;
-        const float bias = col < p.C ? p.b2[col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * 32 + acc_row(r, lane);
-            const float y = bf2f(*(const uint16_t*)(Ys + row * kRcRow + col * 2));
-            stage[row * SROW + col] = col < p.C ? acc[r] + bias + y : 0.f;
-        }
+    for (int k = 0; k < 4; ++k) {
+        const int col0 = cbase + 8 * k;
+        const float4 b = bias4(p.b2, col0, p.C);
+        const uint2 y = *(const uint2*)(Ys + row * kRcRow + col0 * 2);
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col0 < p.C)
+            z = make_float4(acc[4 * k] + b.x + bf2f(y.x & 0xffff), acc[4 * k + 1] + b.y + bf2f(y.x >> 16),
+                            acc[4 * k + 2] + b.z + bf2f(y.y & 0xffff), acc[4 * k + 3] + b.w + bf2f(y.y >> 16));
+        *(float4*)(stage + row * SROW + col0) = z;
     }
     const int npn = p.wn ? (p.Nn + 127) / 128 : 0;    // 128-column passes of the next projection
-    if (npn) {
-        store_w();                                    // every wave is past its last read of Ws (barrier above)
-        load_w(p.wn, 128, 128, p.Nn, 0);              // prefetch panel 1 (zeros past Nn)
-    }
     __syncthreads();
 
     // ---- phase E: optional post-LayerNorm, coalesced 16-byte stores ; 8 threads per row, 16 channels each
@@ -211,22 +228,16 @@ __global__ __launch_bounds__(kRcThreads) void row_chain_kernel(RowChainParams p)
         const bool live = m0 + r < p.M;               // a row group (8 lanes) is entirely inside or outside M
         float v[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = stage[r * SROW + sub * 16 + e];
+        for (int e = 0; e < 16; e += 4) {
+            const float4 t = *(const float4*)(stage + r * SROW + sub * 16 + e);
+            v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
+        }
         if (p.post_g) {
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s += v[e];
-            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-            const float mean = s / (float)p.C;
-            float q = 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { const float d = (sub * 16 + e) < p.C ? v[e] - mean : 0.f; q += d * d; }
-            q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
-            const float rstd = rsqrtf(q / (float)p.C + p.eps_post);
+            rc_normalise(v, sub, p.C, p.eps_post);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int c = sub * 16 + e;
-                v[e] = c < p.C ? (v[e] - mean) * rstd * p.post_g[c] + p.post_b[c] : 0.f;
+                v[e] = c < p.C ? v[e] * p.post_g[c] + p.post_b[c] : 0.f;
             }
         }
         uint4 o[2];
@@ -245,18 +256,7 @@ __global__ __launch_bounds__(kRcThreads) void row_chain_kernel(RowChainParams p)
         if (p.next_ln) {
             chunk_to_f32<bf16_t>(o[0], v);
             chunk_to_f32<bf16_t>(o[1], v + 8);
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s += v[e];
-            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-            const float mean = s / (float)p.C;
-            float q = 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { const float d = (sub * 16 + e) < p.C ? v[e] - mean : 0.f; q += d * d; }
-            q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
-            const float rstd = rsqrtf(q / (float)p.C + p.eps_next);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = (sub * 16 + e) < p.C ? (v[e] - mean) * rstd : 0.f;
+            rc_normalise(v, sub, p.C, p.eps_next);
             o[0] = f32_to_chunk<bf16_t>(v);
             o[1] = f32_to_chunk<bf16_t>(v + 8);
         }
@@ -264,25 +264,20 @@ __global__ __launch_bounds__(kRcThreads) void row_chain_kernel(RowChainParams p)
         *(uint4*)(As + r * kRcRow + sub * 32 + 16) = o[1];
     }
     __syncthreads();
-    for (int pass = 0; pass < npn; ++pass) {
-        zero_acc();
-        mma_panel(As, abase, ngc);
-        {
-            const int col = pass * 128 + wn * 32 + ql;
-            const float bias = (p.bn && col < p.Nn) ? p.bn[col] : 0.f;
+    // one 128-column pass of the next projection from fragment set `cur`; the following pass's fragments go to `nxt`
+    auto next_pass = [&](int pass, const uint4 (&cur)[8], uint4 (&nxt)[8]) {
+        if (pass + 1 < npn) load_frags(nxt, p.wn, (pass + 1) * 4 + wn, 8, 0, ngc);
+        mma(As, abase, cur, ngc, true);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 32 + acc_row(r, lane);
-                float v = acc[r] + bias;
-                v = p.next_act == 1 ? fmaxf(v, 0.f) : (p.next_act == 2 ? gelu_erf(v) : v);
-                *(uint16_t*)(Ys + row * kRcRow + (wn * 32 + ql) * 2) = f2bf(v);
-            }
+        for (int k = 0; k < 4; ++k) {
+            const int col0 = pass * 128 + cbase + 8 * k;
+            const float4 b = bias4(p.bn, col0, p.Nn);
+            float v0 = acc[4 * k] + b.x, v1 = acc[4 * k + 1] + b.y, v2 = acc[4 * k + 2] + b.z, v3 = acc[4 * k + 3] + b.w;
+            if (p.next_act == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            else if (p.next_act == 2) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+            *(uint2*)(Ys + row * kRcRow + (cbase + 8 * k) * 2) = pack4(v0, v1, v2, v3);
         }
-        __syncthreads();                              // panel consumed, 64 x 128 result staged in Ys
-        if (pass + 1 < npn) {
-            store_w();
-            if (pass + 2 < npn) load_w(p.wn, 128, (pass + 2) * 128, p.Nn, 0);
-        }
+        __syncthreads();                              // 64 x 128 result staged in Ys
         {
             const int r = tid >> 3, sub = tid & 7;
             if (m0 + r < p.M) {
@@ -293,7 +288,11 @@ __global__ __launch_bounds__(kRcThreads) void row_chain_kernel(RowChainParams p)
                 }
             }
         }
-        if (pass + 1 < npn) __syncthreads();
+        if (pass + 1 < npn) __syncthreads();          // Ys is rewritten by the next pass
+    };
+    for (int pass = 0; pass < npn; pass += 2) {
+        next_pass(pass, fb, fa);
+        if (pass + 1 < npn) next_pass(pass + 1, fa, fb);
     }
 }
 
@@ -312,23 +311,25 @@ extern "C" int cobevt_attn_mlp_chain(const void* a, const void* skip, void* out,
     if (dims[0] != 0) return COBEVT_ERR_UNSUPPORTED;           // bf16 mode only; fp32 runs the GEMMs separately
     RowChainParams p;
     p.a = (const bf16_t*)a; p.skip = (const bf16_t*)skip; p.out = (bf16_t*)out;
-    p.wp = (const bf16_t*)wp; p.bp = bp; p.w1 = (const bf16_t*)w1; p.b1 = b1; p.w2 = (const bf16_t*)w2; p.b2 = b2;
+    p.wp = (const uint4*)wp; p.bp = bp; p.w1 = (const uint4*)w1; p.b1 = b1; p.w2 = (const uint4*)w2; p.b2 = b2;
     p.post_g = post_gamma; p.post_b = post_beta;
-    p.wn = (const bf16_t*)wnext; p.bn = bnext; p.out_next = (bf16_t*)out_next;
+    p.wn = (const uint4*)wnext; p.bn = bnext; p.out_next = (bf16_t*)out_next;
     p.M = dims[1]; p.C = dims[2]; p.Hd = dims[3]; p.Hdp = dims[4];
     p.Nn = dims[5]; p.next_ln = dims[6]; p.next_act = dims[7];
     p.eps1 = eps1; p.eps_post = eps_post; p.eps_next = eps_next;
     if (p.M < 1 || p.C < 8 || p.C > 128 || p.C % 8 || p.Hd < 8 || p.Hd > 256 || p.Hd % 8) return COBEVT_ERR_SHAPE;
-    if (p.Hdp % 128 || p.Hdp < p.Hd) return COBEVT_ERR_SHAPE;
+    if (p.Hdp % 128 || p.Hdp < p.Hd || p.Hdp > 256) return COBEVT_ERR_SHAPE;
     if ((post_gamma == nullptr) != (post_beta == nullptr)) return COBEVT_ERR_ARG;
     if ((wnext == nullptr) != (out_next == nullptr)) return COBEVT_ERR_ARG;
     if (wnext && (p.Nn < 8 || p.Nn % 8 || p.Nn > 1024 || p.next_act < 0 || p.next_act > 2)) return COBEVT_ERR_SHAPE;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)row_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kRcLds);
+        (void)hipFuncSetAttribute((const void*)row_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kRcLds);
+        (void)hipFuncSetAttribute((const void*)row_chain_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kRcLds);
         attr_set = true;
     }
     const unsigned blocks = (unsigned)((p.M + kRcRows - 1) / kRcRows);
-    hipLaunchKernelGGL(row_chain_kernel, dim3(blocks), dim3(kRcThreads), kRcLds, stream, p);
+    if (p.Hd > 128) hipLaunchKernelGGL(row_chain_kernel<2>, dim3(blocks), dim3(kRcThreads), kRcLds, stream, p);
+    else hipLaunchKernelGGL(row_chain_kernel<1>, dim3(blocks), dim3(kRcThreads), kRcLds, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

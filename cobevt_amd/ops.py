@@ -220,7 +220,7 @@ class ConvPlan(object):
                                 ws[:, a, bb, dy * 6 + dx * 3:dy * 6 + dx * 3 + 3] = w[:, :, ih, iw]
             self.wgt_stem = ws.reshape(cout, 256).to(torch.float32).to(dtype).to(device).contiguous()
         # dense-row GEMM fast path (gemm_rows.hip) for 1x1 / stride 1: weights [Cout][K rounded to a 256-byte tile]
-        self.wgt_rows, self.kp_rows = None, 0
+        self.wgt_rows, self.kp_rows, self.wfrag_rows = None, 0, None
         if kh == 1 and kw == 1 and int(stride) == 1 and int(pad) == 0 and not smallc and int(store_mode) == 0 \
                 and not upsample:
             tk = 128 if self.code == BF16 else 64
@@ -229,6 +229,14 @@ class ConvPlan(object):
             wr[:, :K] = w.reshape(cout, K)
             self.wgt_rows = wr.to(torch.float32).to(dtype).to(device).contiguous()
             self.kp_rows = kp
+            # the same matrix in MFMA fragment order for the fused row chain (row_chain.hip):
+            # [N_p/32 tiles][kp/16 k-groups][lane = 32*half + n%32][8 bf16], N zero-padded to a multiple of 128
+            if self.code == BF16 and kp <= 256:
+                npad = (cout + 127) // 128 * 128
+                wp_ = torch.zeros(npad, kp, dtype=torch.float64)
+                wp_[:cout] = wr
+                wf = wp_.reshape(npad // 32, 32, kp // 16, 2, 8).permute(0, 2, 3, 1, 4)
+                self.wfrag_rows = wf.to(torch.float32).to(dtype).to(device).contiguous()
         self.cin, self.cout, self.kh, self.kw = cin, cout, kh, kw
         self.K, self.kpad = K, kpad
         self.stride, self.pad, self.act = int(stride), int(pad), int(act)
@@ -545,7 +553,7 @@ def channel_affine(x, scale, shift):
 
 def chain_next_fusable(plan_n, c):
     """Can `plan_n` (a Linear / 1x1 conv plan reading C-channel rows) ride at the end of the fused row chain?"""
-    return (plan_n is not None and plan_n.wgt_rows is not None and plan_n.kp_rows == 128 and plan_n.K == c
+    return (plan_n is not None and plan_n.wfrag_rows is not None and plan_n.kp_rows == 128 and plan_n.K == c
             and plan_n.cout % 8 == 0 and plan_n.cout <= 1024 and plan_n.pre_scale is None and not plan_n.pre_relu)
 
 
@@ -557,8 +565,8 @@ def attn_mlp_chain(a, skip, plan_p, plan_1, plan_2, post_ln=None, next_plan=None
     given the call returns (out, next_plan(out)) - computed inside the same launch when fused."""
     _need_cuda(a, skip)
     c, hd = plan_p.cout, plan_1.cout
-    fusable = (USE_ROW_CHAIN and a.dtype == torch.bfloat16 and plan_p.wgt_rows is not None and plan_1.wgt_rows is not None
-               and plan_2.wgt_rows is not None and plan_1.has_ln and plan_1.act == 2 and plan_p.act == 0
+    fusable = (USE_ROW_CHAIN and a.dtype == torch.bfloat16 and plan_p.wfrag_rows is not None and plan_1.wfrag_rows is not None
+               and plan_2.wfrag_rows is not None and plan_1.has_ln and plan_1.act == 2 and plan_p.act == 0
                and plan_2.act == 0 and not plan_p.has_ln and not plan_2.has_ln and plan_p.K == c and plan_1.K == c
                and plan_2.K == hd and plan_2.cout == c and c <= 128 and c % 8 == 0 and hd <= 256 and hd % 8 == 0
                and plan_p.kp_rows == 128 and plan_1.kp_rows == 128 and a.shape[-1] == c and a.is_contiguous()
@@ -583,9 +591,9 @@ def attn_mlp_chain(a, skip, plan_p, plan_1, plan_2, post_ln=None, next_plan=None
 
     with _timed("row_chain|C%d H%d M=%d%s%s" % (c, hd, m, " post" if post_ln is not None else "",
                                                   " +next%d" % nn_ if fuse_next else ""), cost):
-        rc = _L.load().cobevt_attn_mlp_chain(_p(a), _p(skip), _p(out), _p(plan_p.wgt_rows), _p(plan_p.bias),
-                                             _p(plan_1.wgt_rows), _p(plan_1.bias), _p(plan_2.wgt_rows), _p(plan_2.bias),
-                                             _p(pg), _p(pb), _p(next_plan.wgt_rows) if fuse_next else None,
+        rc = _L.load().cobevt_attn_mlp_chain(_p(a), _p(skip), _p(out), _p(plan_p.wfrag_rows), _p(plan_p.bias),
+                                             _p(plan_1.wfrag_rows), _p(plan_1.bias), _p(plan_2.wfrag_rows), _p(plan_2.bias),
+                                             _p(pg), _p(pb), _p(next_plan.wfrag_rows) if fuse_next else None,
                                              _p(next_plan.bias) if fuse_next else None, _p(out_next), dims,
                                              ctypes.c_float(plan_1.ln_eps), ctypes.c_float(pe),
                                              ctypes.c_float(next_plan.ln_eps if fuse_next else 0.0), _stream())
