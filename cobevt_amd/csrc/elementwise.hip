@@ -282,18 +282,32 @@ __device__ __forceinline__ void affine_sample_xy(const Affine& A, int i, int j, 
 
 template <typename T>
 __global__ __launch_bounds__(256) void sttf_warp_kernel(const T* x, const float* tmat, const float* cav_mask, T* out,
-                                                        float* com_mask, int B, int Lc, int H, int W, int C,
+                                                        float* com_mask, const int* record_len, float* cav_out,
+                                                        int B, int Lc, int H, int W, int C,
                                                         float discrete_ratio, float downsample_rate) {
-    // x: (B*L, H, W, C) ; out: (B, L, H, W, C) ; com_mask: (B, H, W, 1, L)
+    // x: (B*L, H, W, C), or with record_len the un-grouped agent batch (sum(record_len), H, W, C) (regroup,
+    // fuse_utils.py:8-61, folded in: sample b's agent l is row sum(record_len[:b]) + l, absent agents warp to zeros);
+    // out: (B, L, H, W, C) ; com_mask: (B, H, W, 1, L) ; cav_out: (B, L) agent mask when regrouping
     const int G = C >> 3;
     const int bl = blockIdx.y;
     const int b = bl / Lc, l = bl - b * Lc;
     __shared__ Affine th_feat, th_mask;
+    __shared__ int src_agent;
     if (threadIdx.x == 0) {
         th_feat = sttf_theta(tmat + (size_t)bl * 16, discrete_ratio, downsample_rate, /*Hd=*/W, /*Wd=*/H);
         th_mask = sttf_theta(tmat + (size_t)bl * 16, discrete_ratio, downsample_rate, /*Hd=*/H, /*Wd=*/W);
+        int src = bl;
+        if (record_len) {
+            int off = 0;
+            for (int bb = 0; bb < b; ++bb) off += record_len[bb];
+            src = l < record_len[b] ? off + l : -1;
+            if (blockIdx.x == 0 && cav_out) cav_out[bl] = src >= 0 ? 1.f : 0.f;
+        }
+        src_agent = src;
     }
     __syncthreads();
+    const int srcb = src_agent;
+    const float present = record_len ? (srcb >= 0 ? 1.f : 0.f) : (cav_mask ? cav_mask[bl] : 1.f);
     const int gid = (blockIdx.x * 256 + threadIdx.x) / G;
     const int gl = threadIdx.x & (G - 1);
     if (gid >= H * W) return;
@@ -307,10 +321,10 @@ __global__ __launch_bounds__(256) void sttf_warp_kernel(const T* x, const float*
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    const T* src = x + (size_t)bl * H * W * C + gl * 8;
+    const T* src = x + (size_t)(srcb >= 0 ? srcb : 0) * H * W * C + gl * 8;
     auto tap = [&](int xx, int yy, float wgt) {
         // (xx, yy) indexes x2 with dims (rows W, cols H)
-        if (xx < 0 || xx >= H || yy < 0 || yy >= W) return;
+        if (srcb < 0 || xx < 0 || xx >= H || yy < 0 || yy >= W) return;
         float v[8];
         load8<T>(src + ((size_t)(H - 1 - xx) * W + yy) * C, v);
 #pragma unroll
@@ -326,7 +340,7 @@ __global__ __launch_bounds__(256) void sttf_warp_kernel(const T* x, const float*
         affine_sample_xy(th_mask, h, w, H, W, mx, my);
         const float rx = nearbyintf(mx), ry = nearbyintf(my);
         const bool inb = rx >= 0.f && rx <= (float)(W - 1) && ry >= 0.f && ry <= (float)(H - 1);
-        com_mask[((size_t)b * H * W + gid) * Lc + l] = inb ? cav_mask[bl] : 0.f;
+        com_mask[((size_t)b * H * W + gid) * Lc + l] = inb ? present : 0.f;
     }
 }
 
@@ -519,15 +533,16 @@ extern "C" int cobevt_regroup(const void* in, const int* record_len, void* out, 
 }
 
 extern "C" int cobevt_sttf_warp(const void* x, const float* tmat, const float* cav_mask, void* out, float* com_mask,
+                                const int* record_len, float* cav_out,
                                 int dtype, int B, int L, int H, int W, int C, float discrete_ratio, float downsample_rate,
                                 hipStream_t stream) {
     if (!x || !tmat || !out) return COBEVT_ERR_ARG;
-    if (com_mask && !cav_mask) return COBEVT_ERR_ARG;
+    if (com_mask && !cav_mask && !record_len) return COBEVT_ERR_ARG;
     if (!group_ok(C) || B < 1 || L < 1 || H < 1 || W < 1 || B * L > 65535) return COBEVT_ERR_SHAPE;
     const long items = (long)H * W * (C >> 3);
     dim3 grid((unsigned)((items + 255) / 256), (unsigned)(B * L));
-    if (dtype == 0) hipLaunchKernelGGL(sttf_warp_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, tmat, cav_mask, (bf16_t*)out, com_mask, B, L, H, W, C, discrete_ratio, downsample_rate);
-    else if (dtype == 1) hipLaunchKernelGGL(sttf_warp_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, tmat, cav_mask, (float*)out, com_mask, B, L, H, W, C, discrete_ratio, downsample_rate);
+    if (dtype == 0) hipLaunchKernelGGL(sttf_warp_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, tmat, cav_mask, (bf16_t*)out, com_mask, record_len, cav_out, B, L, H, W, C, discrete_ratio, downsample_rate);
+    else if (dtype == 1) hipLaunchKernelGGL(sttf_warp_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, tmat, cav_mask, (float*)out, com_mask, record_len, cav_out, B, L, H, W, C, discrete_ratio, downsample_rate);
     else return COBEVT_ERR_ARG;
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

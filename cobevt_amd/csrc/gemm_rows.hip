@@ -36,6 +36,9 @@ struct GemmRowsParams {
     int act;
     // optional spatial remap of output rows into a zero-padded (src_n, out_H, out_W) map
     int src_H, src_W, out_H, out_W;
+    // optional strided row gather (1x1 convolution with stride s): output row (n, oy, ox) of the (src_H, src_W) map reads
+    // input pixel (n, s*oy, s*ox) of an (in_H, in_W) map
+    int in_stride, in_H, in_W;
 };
 
 constexpr int kGrThreads = 512;
@@ -68,7 +71,14 @@ __global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams
     const T* wg = (const T*)p.wgt;
     const bool a_ok = m0 + srow < p.M;
     const bool w_ok = n0 + srow < p.N;
-    const T* arow = in + (size_t)(a_ok ? m0 + srow : 0) * p.lda;
+    size_t arow_idx = a_ok ? m0 + srow : 0;
+    if (p.in_stride > 1) {
+        const int hw = p.src_H * p.src_W;
+        const int n = (int)(arow_idx / hw), rem = (int)(arow_idx - (size_t)n * hw);
+        const int oy = rem / p.src_W, ox = rem - oy * p.src_W;
+        arow_idx = ((size_t)n * p.in_H + (size_t)oy * p.in_stride) * p.in_W + (size_t)ox * p.in_stride;
+    }
+    const T* arow = in + arow_idx * p.lda;
     const T* wrow = wg + (size_t)(w_ok ? n0 + srow : 0) * p.Kp;
     const int nkt = p.Kp / TK;
 
@@ -233,7 +243,7 @@ using namespace cobevt;
 extern "C" int cobevt_linear_rows(const void* in, const void* wgt, const float* bias, const void* residual,
                                   const float* ln_gamma, const float* ln_beta, const float* pre_scale,
                                   const float* pre_shift, void* out, const long* dims, float ln_eps, hipStream_t stream) {
-    // dims: [dtype, M, N, K, Kp, lda, pre_relu, act, src_H, src_W, out_H, out_W, ln]
+    // dims: [dtype, M, N, K, Kp, lda, pre_relu, act, src_H, src_W, out_H, out_W, ln, in_stride, in_H, in_W]
     if (!in || !wgt || !out || !dims) return COBEVT_ERR_ARG;
     GemmRowsParams p;
     const int dtype = (int)dims[0];
@@ -244,6 +254,10 @@ extern "C" int cobevt_linear_rows(const void* in, const void* wgt, const float* 
     p.src_H = (int)dims[8]; p.src_W = (int)dims[9]; p.out_H = (int)dims[10]; p.out_W = (int)dims[11];
     p.ln_eps = ln_eps;
     p.ln = (int)dims[12] || ln_gamma != nullptr;
+    p.in_stride = (int)dims[13]; p.in_H = (int)dims[14]; p.in_W = (int)dims[15];
+    if (p.in_stride < 1) return COBEVT_ERR_ARG;
+    if (p.in_stride > 1 && ((p.src_H - 1) * p.in_stride >= p.in_H || (p.src_W - 1) * p.in_stride >= p.in_W ||
+                            p.M % ((long)p.src_H * p.src_W) != 0)) return COBEVT_ERR_SHAPE;
     if (dtype != 0 && dtype != 1) return COBEVT_ERR_ARG;
     const int tk = dtype == 0 ? 128 : 64, ch = dtype == 0 ? 8 : 4;
     if (p.M < 1 || p.N < 1 || p.K < 1 || p.Kp % tk != 0 || p.Kp < p.K) return COBEVT_ERR_SHAPE;

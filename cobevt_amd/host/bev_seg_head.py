@@ -25,16 +25,23 @@ class BevSegHead(HipModule):
         y = ops.conv2d(x, rt.conv_plan(self, name, conv, store_mode=2))     # (b*l, classes, H, W) fp32
         return y.reshape(b, l, *y.shape[1:])
 
+    def _zeros_like(self, t):
+        """the all-zero map of the head the config does not train (bev_seg_head.py:34-41): one cached read-only buffer
+        per shape instead of a fill kernel per frame"""
+        conv = self.dynamic_head if self.target == "dynamic" else self.static_head
+        return self._plan("zeros:%s" % (tuple(t.shape),), [conv.weight],
+                          lambda dt, dev: torch.zeros(tuple(t.shape), device=t.device, dtype=t.dtype))
+
     def forward(self, x, b, l):
         """x: ((b l), C, H, W) -> {'static_seg', 'dynamic_seg'} each (b, l, classes, H, W) fp32"""
         self._require_inference(x)
         xn = rt.to_nhwc(x)
         if self.target == "dynamic":
             dynamic_map = self._head("dyn", self.dynamic_head, xn, b, l)
-            static_map = torch.zeros_like(dynamic_map)
+            static_map = self._zeros_like(dynamic_map)
         elif self.target == "static":
             static_map = self._head("sta", self.static_head, xn, b, l)
-            dynamic_map = torch.zeros_like(static_map)
+            dynamic_map = self._zeros_like(static_map)
         else:
             dynamic_map = self._head("dyn", self.dynamic_head, xn, b, l)
             static_map = self._head("sta", self.static_head, xn, b, l)

@@ -63,8 +63,10 @@ class CorpBEVT(HipModule):
         output dict.  Split out so the multi-GPU path can all-gather `feats` first (cobevt_amd/dist.py)."""
         dev = feats.device
         rl = torch.as_tensor(record_len).to(device=dev, dtype=torch.int32)
-        x, cav_mask = ops.regroup(feats, rl, self.max_cav)                      # (B, L, H, W, C), (B, L)
-        x, com_mask = self.sttf.warp_blhwc(x, transformation_matrix, cav_mask, want_mask=self.use_roi_mask)
+        tm = transformation_matrix.to(device=dev, dtype=torch.float32).contiguous()
+        # regroup (fuse_utils.py:8-61) + STTF warp + ROI mask in one launch -> (B, L, H, W, C), (B, H, W, 1, L), (B, L)
+        x, com_mask, cav_mask = ops.sttf_warp(feats, tm, None, self.discrete_ratio, self.downsample_rate,
+                                              want_mask=self.use_roi_mask, record_len=rl, max_cav=self.max_cav)
         if not self.use_roi_mask:
             b, l, h, w, _ = x.shape
             com_mask = cav_mask[:, None, None, None, :].expand(b, h, w, 1, l).contiguous()

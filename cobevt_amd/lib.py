@@ -42,7 +42,7 @@ SIGNATURES = {
     "cobevt_invert_small": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "cobevt_resize_nhwc": (ctypes.c_int, [_vp, _vp] + [ctypes.c_int] * 8 + [_vp]),
     "cobevt_channel_affine": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_long, ctypes.c_int, ctypes.c_long, _vp]),
-    "cobevt_sttf_warp": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+    "cobevt_sttf_warp": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp]),
 }
 

@@ -221,7 +221,7 @@ class ConvPlan(object):
             self.wgt_stem = ws.reshape(cout, 256).to(torch.float32).to(dtype).to(device).contiguous()
         # dense-row GEMM fast path (gemm_rows.hip) for 1x1 / stride 1: weights [Cout][K rounded to a 256-byte tile]
         self.wgt_rows, self.kp_rows, self.wfrag_rows = None, 0, None
-        if kh == 1 and kw == 1 and int(stride) == 1 and int(pad) == 0 and not smallc and int(store_mode) == 0 \
+        if kh == 1 and kw == 1 and int(stride) in (1, 2) and int(pad) == 0 and not smallc and int(store_mode) == 0 \
                 and not upsample:
             tk = 128 if self.code == BF16 else 64
             kp = (K + tk - 1) // tk * tk
@@ -328,9 +328,10 @@ def conv2d(x, plan, residual=None, out=None):
         _L.check(rc, "cobevt_stem_conv7x7s2")
         return out
     if plan.wgt_rows is not None and USE_GEMM_ROWS and not (residual is not None and (out_h, out_w) != (ho, wo)):
-        ldims = (ctypes.c_long * 13)(plan.code, n * h * w, plan.cout, plan.K, plan.kp_rows, cin, plan.pre_relu, plan.act,
-                                     ho, wo, out_h, out_w, int(ln))
-        with _timed("gemm_rows|%d->%d M=%d%s" % (cin, plan.cout, n * h * w, " ln" if ln else ""), cost):
+        ldims = (ctypes.c_long * 16)(plan.code, n * ho * wo, plan.cout, plan.K, plan.kp_rows, cin, plan.pre_relu, plan.act,
+                                     ho, wo, out_h, out_w, int(ln), plan.stride, h, w)
+        with _timed("gemm_rows|%d->%d M=%d%s%s" % (cin, plan.cout, n * ho * wo, " ln" if ln else "",
+                                                   " s%d" % plan.stride if plan.stride > 1 else ""), cost):
             rc = _L.load().cobevt_linear_rows(_p(x), _p(plan.wgt_rows), _p(plan.bias), _p(residual), None, None,
                                               _p(plan.pre_scale), _p(plan.pre_shift), _p(out), ldims,
                                               ctypes.c_float(plan.ln_eps), _stream())
@@ -503,18 +504,32 @@ def regroup(x, record_len, max_cav):
     return out, mask
 
 
-def sttf_warp(x, tmat, cav_mask, discrete_ratio, downsample_rate, want_mask=True):
-    """x: (B, L, H, W, C) contiguous ; tmat (B, L, 4, 4) fp32 -> warped (B,L,H,W,C), com_mask (B,H,W,1,L)|None."""
-    _need_cuda(x, tmat, cav_mask)
-    b, l, h, w, c = x.shape
+def sttf_warp(x, tmat, cav_mask, discrete_ratio, downsample_rate, want_mask=True, record_len=None, max_cav=None):
+    """x: (B, L, H, W, C) contiguous ; tmat (B, L, 4, 4) fp32 -> warped (B,L,H,W,C), com_mask (B,H,W,1,L)|None.
+    With record_len (int32 device (B,)) x is the un-grouped agent batch (N, H, W, C): regroup + warp in one launch,
+    returning (warped, com_mask, cav_mask (B, max_cav))."""
+    _need_cuda(x, tmat, cav_mask, record_len)
     if tmat.dtype != torch.float32 or not tmat.is_contiguous() or not x.is_contiguous():
         raise CobevtHipError("sttf_warp: tmat must be contiguous fp32, x contiguous")
-    out = torch.empty_like(x)
+    if record_len is not None:
+        if record_len.dtype != torch.int32 or x.dim() != 4:
+            raise CobevtHipError("sttf_warp: record_len must be int32 on the device and x (N, H, W, C)")
+        b, l = record_len.shape[0], int(max_cav)
+        _, h, w, c = x.shape
+        out = torch.empty((b, l, h, w, c), device=x.device, dtype=x.dtype)
+        cav = torch.empty((b, l), device=x.device, dtype=torch.float32)
+    else:
+        b, l, h, w, c = x.shape
+        out = torch.empty_like(x)
+        cav = None
+    if tuple(tmat.shape[:2]) != (b, l):
+        raise CobevtHipError("sttf_warp: tmat must be (B, L, 4, 4)")
     com = torch.empty((b, h, w, 1, l), device=x.device, dtype=torch.float32) if want_mask else None
-    rc = _L.load().cobevt_sttf_warp(_p(x), _p(tmat), _p(cav_mask), _p(out), _p(com), dcode(x.dtype), b, l, h, w, c,
+    rc = _L.load().cobevt_sttf_warp(_p(x), _p(tmat), _p(cav_mask), _p(out), _p(com), _p(record_len), _p(cav),
+                                    dcode(x.dtype), b, l, h, w, c,
                                     ctypes.c_float(discrete_ratio), ctypes.c_float(downsample_rate), _stream())
     _L.check(rc, "cobevt_sttf_warp")
-    return out, com
+    return (out, com, cav) if record_len is not None else (out, com)
 
 
 def invert_small(m):
@@ -553,7 +568,7 @@ def channel_affine(x, scale, shift):
 
 def chain_next_fusable(plan_n, c):
     """Can `plan_n` (a Linear / 1x1 conv plan reading C-channel rows) ride at the end of the fused row chain?"""
-    return (plan_n is not None and plan_n.wfrag_rows is not None and plan_n.kp_rows == 128 and plan_n.K == c
+    return (plan_n is not None and plan_n.wfrag_rows is not None and plan_n.stride == 1 and plan_n.kp_rows == 128 and plan_n.K == c
             and plan_n.cout % 8 == 0 and plan_n.cout <= 1024 and plan_n.pre_scale is None and not plan_n.pre_relu)
 
 

@@ -1,3 +1,3 @@
 timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
-timeout 600 python bench.py --no-cpu-baseline > gpurun_out/bench17.log 2>&1; tail -1 gpurun_out/bench17.log | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step']); print([ (k['kernel'], k['launches_per_frame'], k['avg_launch_us']) for k in [d['roofline']]+d['roofline_other_kernels']])"
+timeout 600 python bench.py --no-cpu-baseline > gpurun_out/bench18.log 2>&1; tail -1 gpurun_out/bench18.log | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"

@@ -89,9 +89,12 @@ int cobevt_stem_conv7x7s2(const float* in, const void* wgt, const float* bias, v
  * Dense-row GEMM with fused LayerNorm / pre-activation on the A operand and fused bias / residual / activation:
  * the fast path of every nn.Linear and 1x1 stride-1 convolution (fax_modules.py:189-193,281-292,309-313,411,435,472;
  * swap_fusion_modules.py:45-53; base_transformer.py:102-124).  wgt [N][Kp] (Kp = K rounded up to 128 bf16 / 64 fp32
- * elements).  dims (int64[13]): dtype, M, N, K, Kp, lda, pre_relu, act, src_H, src_W, out_H, out_W (these four remap
+ * elements).  dims (int64[16]): dtype, M, N, K, Kp, lda, pre_relu, act, src_H, src_W, out_H, out_W (these four remap
  * output rows into a zero-padded map; equal values = plain rows), ln (1 = normalise each A row over K first; the
- * LayerNorm affine is folded into wgt / bias by the host, or passed as ln_gamma/ln_beta fp32[K]; needs K <= one K-tile).
+ * LayerNorm affine is folded into wgt / bias by the host, or passed as ln_gamma/ln_beta fp32[K]; needs K <= one K-tile),
+ * in_stride, in_H, in_W (in_stride s > 1: a 1x1 / stride-s convolution - the BasicBlock downsample path
+ * resnet_ms.py:67-74 via torchvision resnet.py `downsample` - output row (n, oy, ox) of the (src_H, src_W) map reads
+ * input pixel (n, s*oy, s*ox) of the (in_H, in_W) map; 1 = rows as stored).
  * pre_scale/pre_shift fp32[K] (nullable).
  */
 int cobevt_linear_rows(const void* in, const void* wgt, const float* bias, const void* residual, const float* ln_gamma,
@@ -162,10 +165,13 @@ int cobevt_regroup(const void* in, const int* record_len, void* out, float* mask
                    long elems_per_agent, hipStream_t stream);
 
 /* STTF warp into the ego frame + ROI/agent mask.  x (B*L,H,W,C) -> out (B,L,H,W,C), com_mask (B,H,W,1,L).
- * Replaces corpbevt.py:28-64 and torch_transformation_utils.py:11-134,160-355. tmat: (B,L,4,4) fp32. */
-int cobevt_sttf_warp(const void* x, const float* tmat, const float* cav_mask, void* out, float* com_mask, int dtype,
-                     int B, int L, int H, int W, int C, float discrete_ratio, float downsample_rate,
-                     hipStream_t stream);
+ * Replaces corpbevt.py:28-64 and torch_transformation_utils.py:11-134,160-355. tmat: (B,L,4,4) fp32.
+ * With record_len (device int32[B]) x is the un-grouped agent batch (sum(record_len),H,W,C) and regroup
+ * (fuse_utils.py:8-61) happens inside: agent l of sample b is row sum(record_len[:b]) + l, absent agents warp to zeros and
+ * get mask 0; cav_out (B,L) fp32 (nullable) receives the agent mask; cav_mask is then ignored. */
+int cobevt_sttf_warp(const void* x, const float* tmat, const float* cav_mask, void* out, float* com_mask,
+                     const int* record_len, float* cav_out, int dtype, int B, int L, int H, int W, int C,
+                     float discrete_ratio, float downsample_rate, hipStream_t stream);
 
 /* Batched inverse of n (dim x dim) fp32 matrices, dim in {3, 4}; fax_modules.py:500-501 (intrinsic.inverse()),
  * nuscenes encoder_pyramid_axial.py:538-539. */

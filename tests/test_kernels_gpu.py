@@ -169,7 +169,14 @@ def test_conv_3x3_head_nchw_fp32(cuda, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_1x1_s2_downsample(cuda, dtype):
+    """BasicBlock downsample path: dense-row GEMM with a strided row gather (and the generic igemm on the same plan)"""
     _conv_case(cuda, dtype, "c9", 2, 64, 16, 16, 128, 1, 2, 0, bias=False, bn=True)
+    _conv_case(cuda, dtype, "c9b", 3, 128, 15, 21, 256, 1, 2, 0, bias=False, bn=True, act=1)
+    ops.USE_GEMM_ROWS = False
+    try:
+        _conv_case(cuda, dtype, "c9c", 2, 64, 16, 16, 128, 1, 2, 0, bias=False, bn=True)
+    finally:
+        ops.USE_GEMM_ROWS = True
 
 
 # ---- the LDS-patch 3x3 kernel (conv3x3.hip): both tile configs, chunk widths, ragged tiles, every epilogue
@@ -582,6 +589,28 @@ def test_sttf_warp_and_mask(cuda, dtype, hw):
     if dtype == torch.float32:
         check(y, torch.from_numpy(g["sttf_%dx%d" % (h, w)]), dtype, "sttf vs golden", scale=1.0)
         assert np.array_equal(com.cpu().numpy(), g["mask_%dx%d" % (h, w)])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_regroup_fused_into_sttf_warp(cuda, dtype):
+    """record_len-aware warp (regroup + STTF + ROI mask in one launch) == regroup kernel followed by the warp kernel,
+    bit for bit, for ragged record_len (absent agents -> zeros / mask 0)"""
+    import cases
+    h, w, c, L = 12, 16, 16, 4
+    rl = torch.tensor([3, 1, 4], dtype=torch.int32)
+    n = int(rl.sum())
+    x = procedural_input("rgs.x", (n, h, w, c), 0).to(cuda).to(dtype)
+    _, tm1, _ = cases.sttf_inputs(h, w)                                      # (1, L0, 4, 4)
+    tm = tm1[:, :1].expand(3, L, 4, 4).clone()
+    for b in range(3):
+        for l in range(L):
+            tm[b, l] = tm1[0, (b + l) % tm1.shape[1]]
+    tm = tm.contiguous().to(cuda)
+    s = cases.STTF
+    xg, cav = ops.regroup(x, rl.to(cuda), L)
+    y_ref, com_ref = ops.sttf_warp(xg, tm, cav, s["resolution"], s["downsample_rate"])
+    y, com, cav2 = ops.sttf_warp(x, tm, None, s["resolution"], s["downsample_rate"], record_len=rl.to(cuda), max_cav=L)
+    assert torch.equal(cav2, cav) and torch.equal(y, y_ref) and torch.equal(com, com_ref)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
