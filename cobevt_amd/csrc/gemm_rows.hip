@@ -39,15 +39,24 @@ struct GemmRowsParams {
     // optional strided row gather (1x1 convolution with stride s): output row (n, oy, ox) of the (src_H, src_W) map reads
     // input pixel (n, s*oy, s*ox) of an (in_H, in_W) map
     int in_stride, in_H, in_W;
+    // optional A-row producer: BEV query embedding (fax_modules.py:370-375,387-388) computed on the fly instead of
+    // being read:  A[(bn, pix)] = x[bn / n][pix] + L2norm_c( w_bev . world[pix] + b_bev - w_cam . E_inv[bn][:, 3] )
+    const float* emb_world;  // (2, hw) or null = rows are read from `in`
+    const float* emb_wbev;   // (K, 2)
+    const float* emb_bbev;   // (K)
+    const float* emb_wcam;   // (K, 4)
+    const float* emb_E;      // (B*n, 4, 4)
+    int emb_n, emb_hw;
 };
 
 constexpr int kGrThreads = 512;
 constexpr int kGrRow = 256 + 16;          // LDS row stride (bytes)
 constexpr int kGrTile = 128;              // rows of A and of W per tile
 constexpr int kGrStageRow = 128 * 4 + 16; // fp32 staging row stride
+constexpr int kGrLds = 2 * kGrTile * kGrRow + 128 * 16;   // 69,632 B of tiles + the embedding producer's coefficient table
 
-template <typename T>
-__global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams p) {
+template <typename T, bool EMB>
+__global__ __launch_bounds__(kGrThreads, EMB ? 2 : 4) void gemm_rows_kernel(GemmRowsParams p) {
     constexpr int CH = Elem<T>::kChunk;
     constexpr int TK = 256 / Elem<T>::kBytes;        // elements per K-tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -83,12 +92,65 @@ __global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams
     const int nkt = p.Kp / TK;
 
     uint4 areg[4], wreg[4];
+    // embedding producer: per-channel (w_bev0, w_bev1, b_bev - w_cam . c) of this tile's camera in LDS (one camera per
+    // tile: hw % 128 == 0, checked by the entry point)
+    float4* coef = (float4*)(smem + 2 * kGrTile * kGrRow);
+    if (EMB) {
+        const int bn = m0 / p.emb_hw;
+        if (tid < TK) {
+            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tid < p.K) {
+                const float* E = p.emb_E + (size_t)bn * 16;
+                const float4 wc = *(const float4*)(p.emb_wcam + tid * 4);
+                c.x = p.emb_wbev[tid * 2];
+                c.y = p.emb_wbev[tid * 2 + 1];
+                c.z = p.emb_bbev[tid] - (wc.x * E[3] + wc.y * E[7] + wc.z * E[11] + wc.w * E[15]);
+            }
+            coef[tid] = c;
+        }
+        __syncthreads();
+    }
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = kt * TK + (sub * 4 + j) * CH;
-            areg[j] = (a_ok && k < p.K) ? *(const uint4*)(arow + k) : make_uint4(0, 0, 0, 0);
+            if (!EMB) areg[j] = (a_ok && k < p.K) ? *(const uint4*)(arow + k) : make_uint4(0, 0, 0, 0);
             wreg[j] = w_ok ? *(const uint4*)(wrow + k) : make_uint4(0, 0, 0, 0);
+        }
+        if (EMB) {                                       // single K-tile (K <= TK): the whole row is here
+            const int m = a_ok ? m0 + srow : m0;
+            const int bn = m / p.emb_hw, pix = m - bn * p.emb_hw;
+            const float wx = p.emb_world[pix], wy = p.emb_world[p.emb_hw + pix];
+            const T* xrow = (const T*)p.in + ((size_t)(bn / p.emb_n) * p.emb_hw + pix) * p.K;
+            uint4 xr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = (sub * 4 + j) * CH;
+                xr[j] = k < p.K ? *(const uint4*)(xrow + k) : make_uint4(0, 0, 0, 0);
+            }
+            float v[4][8];
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    const int k = (sub * 4 + j) * CH + e;
+                    const float4 c = coef[k < TK ? k : 0];
+                    const float val = k < p.K ? (c.x * wx + c.y * wy + c.z) : 0.f;
+                    v[j][e] = val;
+                    ss += val * val;
+                }
+            ss += __shfl_xor(ss, 1, 64);
+            ss += __shfl_xor(ss, 2, 64);
+            const float inv = 1.0f / (sqrtf(ss) + 1e-7f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float xv[8];
+                chunk_to_f32<T>(xr[j], xv);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) v[j][e] = v[j][e] * inv + xv[e];
+                areg[j] = a_ok ? f32_to_chunk<T>(v[j]) : make_uint4(0, 0, 0, 0);   // rounded exactly as the stored query
+            }
         }
     };
     // LayerNorm / pre-activation on this thread's 64 bytes (and its 3 neighbours' for the row statistics)
@@ -255,6 +317,8 @@ extern "C" int cobevt_linear_rows(const void* in, const void* wgt, const float* 
     p.ln_eps = ln_eps;
     p.ln = (int)dims[12] || ln_gamma != nullptr;
     p.in_stride = (int)dims[13]; p.in_H = (int)dims[14]; p.in_W = (int)dims[15];
+    p.emb_world = p.emb_wbev = p.emb_bbev = p.emb_wcam = p.emb_E = nullptr;
+    p.emb_n = p.emb_hw = 1;
     if (p.in_stride < 1) return COBEVT_ERR_ARG;
     if (p.in_stride > 1 && ((p.src_H - 1) * p.in_stride >= p.in_H || (p.src_W - 1) * p.in_stride >= p.in_W ||
                             p.M % ((long)p.src_H * p.src_W) != 0)) return COBEVT_ERR_SHAPE;
@@ -269,15 +333,51 @@ extern "C" int cobevt_linear_rows(const void* in, const void* wgt, const float* 
     if (p.residual && (p.out_H != p.src_H || p.out_W != p.src_W)) return COBEVT_ERR_UNSUPPORTED;
     const long blocks = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (blocks > 0x7fffffffL) return COBEVT_ERR_SHAPE;
-    constexpr size_t lds = 2 * kGrTile * kGrRow;   // 69,632 B: A + W tiles; the fp32 staging (128 x 528) fits inside
+    constexpr size_t lds = kGrLds;                 // A + W tiles (the fp32 staging (128 x 528) fits inside) + coefficients
     static_assert(128 * kGrStageRow <= 2 * kGrTile * kGrRow, "staging must fit");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<bf16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    if (dtype == 0) hipLaunchKernelGGL(gemm_rows_kernel<bf16_t>, dim3((unsigned)blocks), dim3(kGrThreads), lds, stream, p);
-    else hipLaunchKernelGGL(gemm_rows_kernel<float>, dim3((unsigned)blocks), dim3(kGrThreads), lds, stream, p);
+    if (dtype == 0) hipLaunchKernelGGL((gemm_rows_kernel<bf16_t, false>), dim3((unsigned)blocks), dim3(kGrThreads), lds, stream, p);
+    else hipLaunchKernelGGL((gemm_rows_kernel<float, false>), dim3((unsigned)blocks), dim3(kGrThreads), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// C-ABI entry point, see include/cobevt_hip.h
+extern "C" int cobevt_bev_embed_linear_rows(const float* E_inv, const float* world, const float* w_bev, const float* b_bev,
+                                            const float* w_cam, const void* x, const void* wgt, const float* bias, void* out,
+                                            const long* dims, float ln_eps, hipStream_t stream) {
+    // dims: [dtype, B, n, hw, D (= K), N, Kp, ln]
+    if (!E_inv || !world || !w_bev || !b_bev || !w_cam || !x || !wgt || !out || !dims) return COBEVT_ERR_ARG;
+    GemmRowsParams p;
+    const int dtype = (int)dims[0];
+    const long B = dims[1], n = dims[2], hw = dims[3];
+    p.in = x; p.wgt = wgt; p.bias = bias; p.residual = nullptr;
+    p.ln_gamma = p.ln_beta = p.pre_scale = p.pre_shift = nullptr; p.out = out;
+    p.K = (int)dims[4]; p.N = (int)dims[5]; p.Kp = (int)dims[6]; p.ln = (int)dims[7];
+    p.lda = p.K; p.pre_relu = 0; p.act = 0;
+    p.ln_eps = ln_eps;
+    if (dtype != 0 && dtype != 1) return COBEVT_ERR_ARG;
+    const int tk = dtype == 0 ? 128 : 64, ch = dtype == 0 ? 8 : 4;
+    if (B < 1 || n < 1 || hw < 1 || hw % 128 != 0 || B * n * hw > 0x7fffffffL) return COBEVT_ERR_SHAPE;   // one camera per tile
+    if (p.N < 1 || p.K < 1 || p.K > tk || p.K % ch != 0 || p.Kp != tk) return COBEVT_ERR_SHAPE;          // whole row in one K-tile
+    p.M = (int)(B * n * hw);
+    p.src_H = p.out_H = 1; p.src_W = p.out_W = p.M;
+    p.in_stride = 1; p.in_H = p.in_W = 1;
+    p.emb_world = world; p.emb_wbev = w_bev; p.emb_bbev = b_bev; p.emb_wcam = w_cam; p.emb_E = E_inv;
+    p.emb_n = (int)n; p.emb_hw = (int)hw;
+    const long blocks = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (blocks > 0x7fffffffL) return COBEVT_ERR_SHAPE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrLds);
+        (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrLds);
+        attr_set = true;
+    }
+    if (dtype == 0) hipLaunchKernelGGL((gemm_rows_kernel<bf16_t, true>), dim3((unsigned)blocks), dim3(kGrThreads), kGrLds, stream, p);
+    else hipLaunchKernelGGL((gemm_rows_kernel<float, true>), dim3((unsigned)blocks), dim3(kGrThreads), kGrLds, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

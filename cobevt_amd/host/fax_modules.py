@@ -291,10 +291,12 @@ class CrossViewSwapAttention(HipModule):
             w_bev = rt.f32_param(self, "w_bev", self.bev_embed.weight, (d, 2))
             b_bev = rt.f32_param(self, "b_bev", self.bev_embed.bias)
             w_cam = rt.f32_param(self, "w_cam", self.cam_embed.weight, (d, 4))
-            query = ops.bev_embed(E_inv, world, w_bev, b_bev, w_cam, x.reshape(b, H * W, d), n)   # (b, n, HW, d)
-            nq = n
+            # query = x + bev embedding, then to_q: one launch, the (b, n, HW, d) query is never materialised
+            q1 = ops.bev_embed_linear(E_inv, world, w_bev, b_bev, w_cam, x.reshape(b, H * W, d), n,
+                                      self.cross_win_attend_1.q_plan())
+            query, nq = None, n
         else:
-            query, nq = x, 1
+            query, nq, q1 = x, 1, None
         qmap_n = ops.tokmap(0, nq, H, W, W1, W2)
         qmap_1 = ops.tokmap(0, 1, H, W, W1, W2)
         kwin = ops.tokmap(0, n, hp, wp, w1, w2)
@@ -302,7 +304,7 @@ class CrossViewSwapAttention(HipModule):
         if qmap_1[6] * qmap_1[7] != kwin[6] * kwin[7]:
             raise CobevtHipError("query windows %dx%d != key windows %dx%d" % (qmap_1[6], qmap_1[7], kwin[6], kwin[7]))
         # local-to-local: window queries x window keys; per-camera queries are averaged in-kernel
-        a = self.cross_win_attend_1.attend_projected(query, kv["k1"], kv["v1"], qmap_n, kwin, qmap_1, b, (b, H, W))
+        a = self.cross_win_attend_1.attend_projected(query, kv["k1"], kv["v1"], qmap_n, kwin, qmap_1, b, (b, H, W), qt=q1)
         y, q2 = self._proj_mlp("mlp1", self.cross_win_attend_1, a, x if self.skip else None, self.prenorm_1, self.mlp_1,
                                next_plan=self.cross_win_attend_2.q_plan())
         # local-to-global: the n query replicas of the reference are identical -> one copy

@@ -19,6 +19,7 @@ CONV3_VARIANT = 0    # 0 = automatic tile choice of cobevt_conv3x3_wfrag_nhwc; >
 USE_GEMM_ROWS = True  # route 1x1 stride-1 convs / linears to the dense-row GEMM with fused LayerNorm
 USE_STEM = True       # 7x7/s2 image stem through the space-to-depth kernel instead of the generic small-Cin igemm
 USE_ROW_CHAIN = True  # fuse out-proj + skip + pre-norm MLP (+ post-norm) after attention into one launch (bf16)
+USE_EMBED_GEMM = True  # compute the BEV query embedding inside the to_q GEMM instead of materialising the query
 USE_CHAIN_NEXT = True  # ... and let the row-local GEMM that consumes its output next ride in the same launch
 
 
@@ -451,6 +452,32 @@ def bev_embed(e_inv, world, w_bev, b_bev, w_cam, x, n):
     rc = _L.load().cobevt_fax_bev_embed(_p(e_inv), _p(world), _p(w_bev), _p(b_bev), _p(w_cam), _p(x), _p(out),
                                         dcode(x.dtype), b, n, hw, d, _stream())
     _L.check(rc, "cobevt_fax_bev_embed")
+    return out
+
+
+def bev_embed_linear(e_inv, world, w_bev, b_bev, w_cam, x, n, plan):
+    """plan(bev_embed(...)) : (B, HW, D) -> (B, n, HW, N) without materialising the (B, n, HW, D) query (the dense-row GEMM
+    produces its A rows on the fly) when plan is a LayerNorm-folded Linear whose row fits one K-tile; otherwise the two
+    launches."""
+    b, hw, d = x.shape
+    fused = (USE_EMBED_GEMM and USE_GEMM_ROWS and plan.has_ln and ln_fusable(plan) and plan.K == d and hw % 128 == 0
+             and plan.stride == 1 and plan.pre_scale is None and plan.act == 0 and x.is_contiguous())
+    if not fused:
+        return linear(bev_embed(e_inv, world, w_bev, b_bev, w_cam, x, n), plan)
+    _need_cuda(e_inv, world, w_bev, b_bev, w_cam, x)
+    out = torch.empty((b, n, hw, plan.cout), device=x.device, dtype=x.dtype)
+    dims = (ctypes.c_long * 8)(plan.code, b, n, hw, d, plan.cout, plan.kp_rows, 1)
+
+    def cost():
+        m = b * n * hw
+        esz = 2 if plan.code == BF16 else 4
+        return 2.0 * m * plan.cout * d, float(x.numel() * esz + plan.cout * d * esz + out.numel() * esz)
+
+    with _timed("gemm_rows|embed %d->%d M=%d ln" % (d, plan.cout, b * n * hw), cost):
+        rc = _L.load().cobevt_bev_embed_linear_rows(_p(e_inv), _p(world), _p(w_bev), _p(b_bev), _p(w_cam), _p(x),
+                                                    _p(plan.wgt_rows), _p(plan.bias), _p(out), dims,
+                                                    ctypes.c_float(plan.ln_eps), _stream())
+    _L.check(rc, "cobevt_bev_embed_linear_rows")
     return out
 
 

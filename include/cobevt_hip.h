@@ -150,6 +150,18 @@ int cobevt_fax_bev_embed(const float* E_inv, const float* world, const float* w_
                          const float* w_cam, const void* x, void* out, int dtype, int B, int n, int hw, int D,
                          hipStream_t stream);
 
+/*
+ * BEV query embedding + prior fused with the to_q LayerNorm + Linear that consumes it (fax_modules.py:370-375,387-388
+ * followed by CrossWinAttention.to_q :193-195,201): the (B, n, hw, D) query never reaches HBM - the dense-row GEMM
+ * computes its A rows  x[b][pix] + L2norm_c(w_bev.world[pix] + b_bev - w_cam.E_inv[b,cam][:,3])  on the fly, rounds them
+ * to the storage type exactly as cobevt_fax_bev_embed would have stored them, normalises (LayerNorm affine folded into
+ * wgt / bias) and multiplies.  out (B*n*hw, N).  wgt [N][Kp] as for cobevt_linear_rows.  dims (int64[8]): dtype, B, n,
+ * hw (multiple of 128), D (= K <= one K-tile), N, Kp, ln.
+ */
+int cobevt_bev_embed_linear_rows(const float* E_inv, const float* world, const float* w_bev, const float* b_bev,
+                                 const float* w_cam, const void* x, const void* wgt, const float* bias, void* out,
+                                 const long* dims, float ln_eps, hipStream_t stream);
+
 /* MaxPool2d(3, 2, 1) channels-last; torchvision ResNet stem reached from resnet_ms.py:71. */
 int cobevt_maxpool3x3s2(const void* in, void* out, int dtype, int N, int H, int W, int C, hipStream_t stream);
 

@@ -592,6 +592,37 @@ def test_sttf_warp_and_mask(cuda, dtype, hw):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_bev_embed_fused_into_q_projection(cuda, dtype):
+    """to_q(LayerNorm(x + bev embedding)) with the embedding produced inside the GEMM == bev_embed kernel + GEMM"""
+    import cases
+    b, n = 2, 3
+    d = 128 if dtype == torch.bfloat16 else 64
+    H, W = 16, 24                                                           # hw = 384 (multiple of 128)
+    _, E = cases.camera_geometry(b * n, n, 112, 120)
+    E = E.reshape(b * n, 4, 4).contiguous().to(cuda)
+    world = procedural_input("be.world", (2, H * W), 0, -40, 40).to(cuda)
+    w_bev = procedural_input("be.wb", (d, 2), 0).to(cuda)
+    b_bev = procedural_input("be.bb", (d,), 0).to(cuda)
+    w_cam = procedural_input("be.wc", (d, 4), 0).to(cuda)
+    x = procedural_input("be.x", (b, H * W, d), 0).to(cuda).to(dtype)
+    wq = procedural_input("be.wq", (96, d), 0) * math.sqrt(3.0 / d)
+
+    class LN(object):
+        weight, bias, eps = 0.8 + 0.4 * procedural_input("be.g", (d,), 0, 0, 1), procedural_input("be.be", (d,), 0, -0.2, 0.2), 1e-5
+    plan = ops.ConvPlan(wq, procedural_input("be.bq", (96,), 0, -0.2, 0.2), dtype=dtype, device=cuda, ln=LN)
+    assert ops.USE_EMBED_GEMM and ops.ln_fusable(plan)
+    y = ops.bev_embed_linear(E, world, w_bev, b_bev, w_cam, x, n, plan)
+    ops.USE_EMBED_GEMM = False
+    try:
+        y2 = ops.bev_embed_linear(E, world, w_bev, b_bev, w_cam, x, n, plan)
+    finally:
+        ops.USE_EMBED_GEMM = True
+    assert y.shape == (b, n, H * W, 96)
+    s = y2.float().abs().max().item()
+    assert (y.float() - y2.float()).abs().max().item() <= (2e-2 if dtype == torch.bfloat16 else 1e-5) * s
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_regroup_fused_into_sttf_warp(cuda, dtype):
     """record_len-aware warp (regroup + STTF + ROI mask in one launch) == regroup kernel followed by the warp kernel,
     bit for bit, for ragged record_len (absent agents -> zeros / mask 0)"""
