@@ -1,0 +1,348 @@
+// Fused ResNet BasicBlock (stride 1, no downsample) on MFMA (gfx950):
+//
+//     out = ReLU( conv3x3_2( ReLU( conv3x3_1(x) + b1 ) ) + b2 + x )        (eval BatchNorms folded into the weights / biases)
+//
+// i.e. torchvision.models.resnet.BasicBlock.forward as reached from opv2v/opencood/models/backbones/resnet_ms.py:67-74
+// (layer1 / layer2 of ResNet-34 on the camera images: 64 and 128 channels on 128x128 and 64x64 maps).  As two launches
+// of the 3x3 kernel these layers are neither MFMA- nor HBM-bound (40 us each against a 20 / 10 us HBM floor): every launch
+// pays a patch prologue, nine barriered taps and an fp32-staged epilogue for 72 MFMAs per wave, and the intermediate map
+// (42 MB on the 64-channel level) is written and read back with its halo.  Here a workgroup owns a TH x 16 output tile (TH = 16 / 8):
+//   1. the (TH+4) x 20 input patch (2-pixel halo) goes to LDS chunk by chunk (128 bytes of channels);
+//   2. conv1 is evaluated on the (TH+2) x 18 region the second conv needs (its pixels linearised into 32-row MFMA
+//      tiles), + b1, ReLU, rounded to the storage type exactly as the unfused path stores it, and written to a second
+//      LDS patch - zeros where the region leaves the image, which is conv2's zero padding;
+//   3. conv2 runs on that patch, + b2 + residual (the block input, re-read coalesced from global), ReLU, 16-byte stores.
+// The intermediate never reaches HBM, one launch / prologue / epilogue instead of two, at the price of recomputing the
+// halo of conv1 (324 instead of 256 pixels at TH = 16).  Weights come in MFMA fragment order straight from L2 (same table as
+// cobevt_conv3x3_wfrag_nhwc), prefetched two taps ahead; D = W . X^T so a lane owns one pixel and runs of four couts
+// (8-byte LDS writes for the intermediate, 16-byte for the staging).  8 waves = cout tiles x pixel-tile groups.
+#include "common.hpp"
+
+namespace cobevt {
+
+struct BasicBlockParams {
+    const void* in;
+    const uint4* w1;        // fragment-ordered [C_p/32][C/cc][9][4][64]
+    const float* b1;
+    const uint4* w2;
+    const float* b2;
+    void* out;
+    int N, H, W;
+    int tiles_y, tiles_x;
+};
+
+template <typename T, int C, int TH_> struct BBCfg {
+    static constexpr int NT = 512;
+    static constexpr int EB = Elem<T>::kBytes, CH = Elem<T>::kChunk;
+    static constexpr int CC = 128 / EB;                  // channels per 128-byte chunk
+    static constexpr int NCH = C / CC;                   // channel chunks
+    static constexpr int NCT = C / 32;                   // 32-cout tiles
+    static constexpr int NPG = 8 / NCT;                  // waves sharing one cout tile
+    static constexpr int TH = TH_, TW = 16;
+    static constexpr int R1H = TH + 2, R1W = TW + 2, R1 = R1H * R1W;   // conv1 region: (TH + 2) x 18 pixels
+    static constexpr int N1 = (R1 + 31) / 32;            // MFMA pixel tiles of the region (6 for TH = 8, 11 for 16)
+    static constexpr int T1W = (N1 + NPG - 1) / NPG;     // conv1 pixel tiles per wave
+    static constexpr int N2 = TH * TW / 32;              // MFMA pixel tiles of the output
+    static constexpr int T2W = N2 / NPG;                 // conv2 pixel tiles per wave
+    static constexpr int P1H = TH + 4, P1W = TW + 4;     // input patch (TH + 4) x 20
+    static constexpr int PSTR1 = 128 + 16;
+    static constexpr int PATCH1 = P1H * P1W * PSTR1;
+    static constexpr int PSTR2 = C * EB + 16;
+    static constexpr int PATCH2 = R1 * PSTR2;
+    static constexpr int SSTR = C * 4 + 16;
+    static constexpr int STAGE = TH * TW * SSTR;
+    static constexpr int MAIN = PATCH1 + PATCH2;
+    static constexpr int LDS = MAIN > STAGE ? MAIN : STAGE;
+    static_assert(NCT >= 2 && NCT <= 8 && 8 % NCT == 0 && N2 % NPG == 0, "wave layout");
+};
+
+// One 128-byte channel chunk of a 3x3 convolution out of an LDS patch: 9 taps x 4 k-groups, NTW pixel tiles per wave.
+// The weight fragments of tap + 2 are requested at the start of every tap (register ring bq, 9 % 3 == 0 keeps the slots
+// static) and the A fragments run two k-groups ahead of the MFMAs in a second ring, with the issue order pinned
+// ("one ds_read, one MFMA"): with two waves per SIMD an LDS round trip in front of every MFMA is the whole runtime.
+template <typename T, int NTW>
+__device__ __forceinline__ void bb_conv_chunk(const unsigned char* patch, const int (&aoff)[NTW], const bool (&ok)[NTW],
+                                              int row_pitch, int pstr, const uint4* wsrc, int step0, int nstep,
+                                              uint4 (&bq)[3][4], f32x16 (&acc)[NTW]) {
+    uint4 af[3][NTW];
+    auto read_a = [&](uint4 (&dst)[NTW], int n) {               // n = tap * 4 + k-group (compile-time after unrolling)
+        const int tap = n >> 2, g = n & 3;
+        const int off = ((tap / 3) * row_pitch + (tap % 3)) * pstr + g * 32;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+            if (ok[t]) dst[t] = *(const uint4*)(patch + aoff[t] + off);
+    };
+    read_a(af[0], 0);
+    read_a(af[1], 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        {
+            const int step = step0 + tap + 2;
+            const uint4* src = wsrc + (size_t)(step < nstep ? step : nstep - 1) * 256;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bq[(tap + 2) % 3][g] = src[g * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = tap * 4 + g;
+            if (n + 2 < 36) read_a(af[(n + 2) % 3], n + 2);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+                if (ok[t]) mfma_kgroup<T>(bq[tap % 3][g], af[n % 3][t], acc[t]);   // D = W . X^T: lane <-> pixel, registers <-> couts
+            if (Elem<T>::kIsBf16 && n + 2 < 36) {
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <typename T, int C, int TH_>
+__global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 : 2) void basicblock_kernel(BasicBlockParams p) {
+    using G = BBCfg<T, C, TH_>;
+    constexpr int NT = G::NT, CH = G::CH, CC = G::CC, NCH = G::NCH, NCT = G::NCT, NPG = G::NPG;
+    constexpr int TH = G::TH, TW = G::TW, R1W = G::R1W, R1 = G::R1, N1 = G::N1, T1W = G::T1W, T2W = G::T2W;
+    constexpr int P1W = G::P1W, PSTR1 = G::PSTR1, PSTR2 = G::PSTR2;
+    constexpr int PIECES = 8;                                   // 16-byte pieces per pixel of a 128-byte chunk
+    constexpr int P1_ITEMS = G::P1H * P1W * PIECES;             // 1920
+    constexpr int P_IT = (P1_ITEMS + NT - 1) / NT;              // 4
+    constexpr int NSTEP = NCH * 9;
+    constexpr int R = 3;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* patch1 = smem;
+    unsigned char* patch2 = smem + G::PATCH1;
+
+    int logical;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+        const int q = nblk >> 3, r = nblk & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int tx = logical % p.tiles_x;
+    const int ty = (logical / p.tiles_x) % p.tiles_y;
+    const int img = logical / (p.tiles_x * p.tiles_y);
+    const int oy0 = ty * TH, ox0 = tx * TW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, ql = lane & 31;
+    const int ct = wave % NCT, pg = wave / NCT;                 // cout tile, pixel-tile group
+    const T* in = (const T*)p.in;
+
+    // ---- input patch addressing (12 x 20 pixels, origin (oy0 - 2, ox0 - 2)), computed once
+    int pgoff[P_IT], plds[P_IT];
+#pragma unroll
+    for (int it = 0; it < P_IT; ++it) {
+        const int item = tid + it * NT;
+        pgoff[it] = 0;
+        plds[it] = -1;
+        if (item < P1_ITEMS) {
+            const int pix = item / PIECES, j = item - pix * PIECES;
+            const int py = pix / P1W, px = pix - py * P1W;
+            const int lds = pix * PSTR1 + j * 16;
+            const int iy = oy0 - 2 + py, ix = ox0 - 2 + px;
+            const bool inside = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            if (inside) pgoff[it] = ((img * p.H + iy) * p.W + ix) * C + j * CH;
+            plds[it] = inside ? lds : (lds | (1 << 30));
+        }
+    }
+    uint4 preg[P_IT];
+    auto load_patch = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) preg[it] = *(const uint4*)(in + pgoff[it] + chunk * CC);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it)
+            if (plds[it] >= 0)
+                *(uint4*)(patch1 + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : preg[it];
+    };
+    // weight fragments of this wave's cout tile: step s = chunk * 9 + tap -> 4 k-groups x 64 lanes
+    uint4 bq[R][4];
+    auto load_b = [&](uint4 (&b)[4], const uint4* w, int step) {
+        const uint4* src = w + ((size_t)ct * NSTEP + (step < NSTEP ? step : NSTEP - 1)) * 256 + lane;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b[g] = src[g * 64];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- conv1 on the 10 x 18 region: pixel p = 32 * tile + ql of the row-major region, tiles pg, pg + NPG, ...
+    int a1[T1W];                     // LDS offset of this lane's region pixel inside patch1 (tap (0,0), k-group 0)
+    bool t1_ok[T1W];
+#pragma unroll
+    for (int t = 0; t < T1W; ++t) {
+        const int tile = pg + t * NPG;
+        t1_ok[t] = tile < N1;                                   // wave-uniform
+        int pr = tile * 32 + ql;
+        if (pr >= R1) pr = R1 - 1;                              // padding lanes of the last tile compute a duplicate
+        const int ry = pr / R1W, rx = pr - ry * R1W;
+        a1[t] = (ry * P1W + rx) * PSTR1 + h * 16;
+    }
+    f32x16 acc1[T1W];
+#pragma unroll
+    for (int t = 0; t < T1W; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
+
+    const uint4* w1src = p.w1 + (size_t)ct * NSTEP * 256 + lane;
+    const uint4* w2src = p.w2 + (size_t)ct * NSTEP * 256 + lane;
+    load_patch(0);
+    load_b(bq[0], p.w1, 0);
+    load_b(bq[1], p.w1, 1);
+#pragma unroll 1
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+        if (chunk > 0) __syncthreads();                         // every wave finished reading the previous chunk
+        store_patch();
+        __syncthreads();
+        if (chunk + 1 < NCH) load_patch(chunk + 1);
+        bb_conv_chunk<T, T1W>(patch1, a1, t1_ok, P1W, PSTR1, w1src, chunk * 9, NSTEP, bq, acc1);
+    }
+    // conv2's first fragments while the intermediate is written (the ring slots 0 / 1 are free: NSTEP % 3 == 0)
+    load_b(bq[0], p.w2, 0);
+    load_b(bq[1], p.w2, 1);
+    // ---- intermediate: ReLU(conv1 + b1) rounded to T -> patch2 [region pixel][C] ; zeros outside the image
+    {
+        const int c0 = ct * 32 + 4 * h;
+        float4 bias[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bias[k] = p.b1 ? *(const float4*)(p.b1 + c0 + 8 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < T1W; ++t) {
+            const int pr = (pg + t * NPG) * 32 + ql;
+            if (!t1_ok[t] || pr >= R1) continue;
+            const int ry = pr / R1W, rx = pr - ry * R1W;
+            const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
+            const bool inside = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v[4] = {acc1[t][4 * k] + bias[k].x, acc1[t][4 * k + 1] + bias[k].y, acc1[t][4 * k + 2] + bias[k].z,
+                              acc1[t][4 * k + 3] + bias[k].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = inside ? fmaxf(v[e], 0.f) : 0.f;
+                unsigned char* d = patch2 + pr * PSTR2 + (c0 + 8 * k) * Elem<T>::kBytes;
+                if constexpr (Elem<T>::kIsBf16) *(uint2*)d = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                else *(float4*)d = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+    // residual = the block input at the output pixels, 16-byte coalesced, in flight under conv2
+    constexpr int CPP = C / CH;
+    constexpr int S_ITEMS = TH * TW * CPP;
+    constexpr int S_IT = S_ITEMS / NT;
+    static_assert(S_ITEMS % NT == 0, "store pass");
+    int soff[S_IT];
+    uint4 rres[S_IT];
+#pragma unroll
+    for (int i = 0; i < S_IT; ++i) {
+        const int item = tid + i * NT;
+        const int px = item / CPP, cj = item - px * CPP;
+        const int oy = oy0 + px / TW, ox = ox0 + (px % TW);
+        soff[i] = -1;
+        rres[i] = make_uint4(0, 0, 0, 0);
+        if (oy < p.H && ox < p.W) {
+            soff[i] = ((img * p.H + oy) * p.W + ox) * C + cj * CH;
+            rres[i] = *(const uint4*)(in + soff[i]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                            // patch2 complete
+
+    // ---- conv2 on the 8 x 16 tile: output pixel tiles pg, pg + NPG, ... (2 rows x 16 columns each)
+    int a2[T2W];
+    bool t2_ok[T2W];
+    f32x16 acc[T2W];
+#pragma unroll
+    for (int t = 0; t < T2W; ++t) {
+        const int tile = pg + t * NPG;
+        a2[t] = ((tile * 2 + (ql >> 4)) * R1W + (ql & 15)) * PSTR2 + h * 16;
+        t2_ok[t] = true;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    }
+#pragma unroll 1
+    for (int chunk = 0; chunk < NCH; ++chunk)
+        bb_conv_chunk<T, T2W>(patch2 + chunk * 128, a2, t2_ok, R1W, PSTR2, w2src, chunk * 9, NSTEP, bq, acc);
+    __syncthreads();                                            // patch2 no longer read: stage over the patches
+
+    // ---- epilogue: fp32 staging [128 pixels][C], then + residual, ReLU, 16-byte stores
+    float* stage = (float*)smem;
+    constexpr int SROW = G::SSTR / 4;
+    {
+        const int c0 = ct * 32 + 4 * h;
+#pragma unroll
+        for (int t = 0; t < T2W; ++t) {
+            const int px = (pg + t * NPG) * 32 + ql;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 b = p.b2 ? *(const float4*)(p.b2 + c0 + 8 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *(float4*)(stage + px * SROW + c0 + 8 * k) =
+                    make_float4(acc[t][4 * k] + b.x, acc[t][4 * k + 1] + b.y, acc[t][4 * k + 2] + b.z, acc[t][4 * k + 3] + b.w);
+            }
+        }
+    }
+    __syncthreads();
+    T* out = (T*)p.out;
+#pragma unroll
+    for (int i = 0; i < S_IT; ++i) {
+        if (soff[i] < 0) continue;
+        const int item = tid + i * NT;
+        const int px = item / CPP, cj = item - px * CPP;
+        float v[8], rv[8];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) v[e] = stage[px * SROW + cj * CH + e];
+        chunk_to_f32<T>(rres[i], rv);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) v[e] = fmaxf(v[e] + rv[e], 0.f);
+        *(uint4*)(out + soff[i]) = f32_to_chunk<T>(v);
+    }
+}
+
+template <typename T, int C, int TH_>
+static int launch_basicblock(BasicBlockParams p, hipStream_t stream) {
+    using G = BBCfg<T, C, TH_>;
+    p.tiles_y = (p.H + G::TH - 1) / G::TH;
+    p.tiles_x = (p.W + G::TW - 1) / G::TW;
+    const long blocks = (long)p.N * p.tiles_y * p.tiles_x;
+    if (blocks <= 0 || blocks > 0x7fffffffL) return COBEVT_ERR_SHAPE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)basicblock_kernel<T, C, TH_>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((basicblock_kernel<T, C, TH_>), dim3((unsigned)blocks), dim3(G::NT), G::LDS, stream, p);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+}  // namespace cobevt
+
+using namespace cobevt;
+
+// C-ABI entry point, see include/cobevt_hip.h
+extern "C" int cobevt_basicblock_nhwc(const void* in, const void* wfrag1, const float* bias1, const void* wfrag2,
+                                      const float* bias2, void* out, const int* dims, hipStream_t stream) {
+    // dims: [dtype, N, H, W, C, tile_rows]
+    if (!in || !wfrag1 || !wfrag2 || !out || !dims) return COBEVT_ERR_ARG;
+    BasicBlockParams p;
+    p.in = in; p.w1 = (const uint4*)wfrag1; p.b1 = bias1; p.w2 = (const uint4*)wfrag2; p.b2 = bias2; p.out = out;
+    const int dtype = dims[0];
+    p.N = dims[1]; p.H = dims[2]; p.W = dims[3];
+    const int c = dims[4];
+    if (dtype != 0 && dtype != 1) return COBEVT_ERR_ARG;
+    if (p.N < 1 || p.H < 1 || p.W < 1) return COBEVT_ERR_SHAPE;
+    if ((long)p.N * p.H * p.W * c >= 0x7fffffffL) return COBEVT_ERR_UNSUPPORTED;        // 32-bit element offsets
+    // 64 channels: 16 x 16 tiles (27 % halo recompute, 180 MFMAs per wave) or 8 x 16 tiles with two workgroups per CU
+    // (dims[5] = 8 | 16, 0 = default); 128 channels: 8 x 16 (LDS, and 640 tiles on the 64 x 64 maps)
+    const int th = dims[5];
+    if (th != 0 && th != 8 && th != 16) return COBEVT_ERR_ARG;
+    if (c == 64 && dtype == 0 && th == 8) return launch_basicblock<bf16_t, 64, 8>(p, stream);
+    if (c == 64) return dtype == 0 ? launch_basicblock<bf16_t, 64, 16>(p, stream) : launch_basicblock<float, 64, 16>(p, stream);
+    if (c == 128) return dtype == 0 ? launch_basicblock<bf16_t, 128, 8>(p, stream) : launch_basicblock<float, 128, 8>(p, stream);
+    return COBEVT_ERR_UNSUPPORTED;
+}

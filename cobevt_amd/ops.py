@@ -19,6 +19,8 @@ CONV3_VARIANT = 0    # 0 = automatic tile choice of cobevt_conv3x3_wfrag_nhwc; >
 USE_GEMM_ROWS = True  # route 1x1 stride-1 convs / linears to the dense-row GEMM with fused LayerNorm
 USE_STEM = True       # 7x7/s2 image stem through the space-to-depth kernel instead of the generic small-Cin igemm
 USE_ROW_CHAIN = True  # fuse out-proj + skip + pre-norm MLP (+ post-norm) after attention into one launch (bf16)
+BASICBLOCK_TILE_ROWS = 0   # 0 = kernel default; 8 | 16 pins the output tile height (tools/bb_probe.py)
+USE_BASICBLOCK = True  # stride-1 BasicBlocks on 64 / 128 channels as one launch (intermediate map stays in LDS)
 USE_EMBED_GEMM = True  # compute the BEV query embedding inside the to_q GEMM instead of materialising the query
 USE_CHAIN_NEXT = True  # ... and let the row-local GEMM that consumes its output next ride in the same launch
 
@@ -359,6 +361,32 @@ def conv2d(x, plan, residual=None, out=None):
         rc = _L.load().cobevt_conv2d_nhwc(_p(x), _p(plan.wgt), _p(plan.bias), _p(residual), _p(plan.pre_scale),
                                           _p(plan.pre_shift), _p(plan.klut), _p(out), dims, _stream())
     _L.check(rc, "cobevt_conv2d_nhwc")
+    return out
+
+
+def basicblock_fusable(x, plan1, plan2):
+    """stride-1 BasicBlock without downsample on 64 / 128 channels: both 3x3 convs in one launch (basicblock.hip)"""
+    return (USE_BASICBLOCK and plan1.wfrag is not None and plan2.wfrag is not None and plan1.cin == plan1.cout == plan2.cin
+            == plan2.cout and plan1.cout in (64, 128) and plan1.act == 1 and plan2.act == 1 and not plan1.upsample
+            and not plan2.upsample and plan1.store_mode == 0 and plan2.store_mode == 0 and x.is_contiguous()
+            and x.dtype == plan1.dtype and x.numel() < 2 ** 31)
+
+
+def basicblock(x, plan1, plan2):
+    """relu(conv2(relu(conv1(x))) + x) for BN-folded 3x3 plans; x (N,H,W,C) channels-last."""
+    _need_cuda(x)
+    n, h, w, c = x.shape
+    out = torch.empty_like(x)
+    dims = _ints([plan1.code, n, h, w, c, BASICBLOCK_TILE_ROWS])
+
+    def cost():
+        esz = 2 if plan1.code == BF16 else 4
+        return 2.0 * 2 * n * h * w * c * 9 * c, float(2 * x.numel() * esz + 2 * c * 9 * c * esz)
+
+    with _timed("basicblock|%d %dx%dx%d" % (c, n, h, w), cost):
+        rc = _L.load().cobevt_basicblock_nhwc(_p(x), _p(plan1.wfrag), _p(plan1.bias), _p(plan2.wfrag), _p(plan2.bias),
+                                              _p(out), dims, _stream())
+    _L.check(rc, "cobevt_basicblock_nhwc")
     return out
 
 

@@ -78,6 +78,18 @@ int cobevt_conv3x3_wfrag_nhwc(const void* in, const void* wfrag, const float* bi
                               const int* dims, hipStream_t stream);
 
 /*
+ * Fused ResNet BasicBlock (stride 1, no downsample, C in {64, 128}): out = ReLU(conv2(ReLU(conv1(x) + b1)) + b2 + x) with
+ * the eval BatchNorms folded into the weights / biases - torchvision resnet.BasicBlock.forward as reached from
+ * resnet_ms.py:67-74 (layer1 / layer2 of the camera encoder).  One launch instead of two 3x3 launches: the intermediate
+ * map stays in LDS (conv1 is recomputed on the 1-pixel halo conv2 needs) and is rounded to the storage type exactly as
+ * the two-launch path stores it.  wfrag1 / wfrag2: the fragment-ordered tables of cobevt_conv3x3_wfrag_nhwc.
+ * dims (int32[6]): dtype, N, H, W, C, tile_rows (0 = default; 8 | 16 pins the output tile height for C = 64 bf16).
+ * Needs N*H*W*C < 2^31.
+ */
+int cobevt_basicblock_nhwc(const void* in, const void* wfrag1, const float* bias1, const void* wfrag2, const float* bias2,
+                           void* out, const int* dims, hipStream_t stream);
+
+/*
  * ResNet stem: 7x7 / stride 2 / pad 3 conv on the fp32 3-channel channels-last image (+ folded BN, ReLU), computed as a
  * 4x4 stride-1 conv over the 2x2 space-to-depth image; torchvision resnet conv1/bn1/relu via resnet_ms.py:67-69.
  * wgt [Cout][16 taps][16] (12 real (dy,dx,c) channels + 4 zeros).  dims (int32[6]): dtype, N, H, W (even), Cout, act.

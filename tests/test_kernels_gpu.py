@@ -238,6 +238,30 @@ def test_conv3x3_lds_staged_kernel_shapes(cuda, dtype, cin, cout, h, w):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c,n,h,w", [(64, 2, 24, 40), (128, 3, 16, 16), (64, 1, 13, 21), (128, 2, 9, 35)])
+def test_basicblock_fused(cuda, dtype, c, n, h, w):
+    """relu(conv2(relu(conv1(x))) + x) in ONE launch (intermediate map in LDS) vs the two 3x3 launches vs torch;
+    ragged tiles exercise the zero padding of the intermediate at the image border"""
+    x = procedural_input("bb.x", (n, c, h, w), 0)
+    w1 = procedural_input("bb.w1", (c, c, 3, 3), 0) * math.sqrt(3.0 / (c * 9))
+    w2 = procedural_input("bb.w2", (c, c, 3, 3), 0) * math.sqrt(3.0 / (c * 9))
+    bn1, bn2 = FakeBN(c, "bb.bn1"), FakeBN(c, "bb.bn2")
+    p1 = ops.ConvPlan(w1, None, bn=bn1, stride=1, pad=1, act=1, dtype=dtype, device=cuda)
+    p2 = ops.ConvPlan(w2, None, bn=bn2, stride=1, pad=1, act=1, dtype=dtype, device=cuda)
+    xd = nhwc(x).to(cuda).to(dtype)
+    assert ops.basicblock_fusable(xd, p1, p2)
+    y = ops.basicblock(xd, p1, p2)
+    y2 = ops.conv2d(ops.conv2d(xd, p1), p2, residual=xd)
+    wr1 = p1.wgt.float().cpu()[:, :p1.K].reshape(c, 3, 3, c).permute(0, 3, 1, 2)
+    wr2 = p2.wgt.float().cpu()[:, :p2.K].reshape(c, 3, 3, c).permute(0, 3, 1, 2)
+    mid = rnd(F.relu(F.conv2d(rnd(x, dtype), wr1, p1.bias.cpu(), padding=1)), dtype)
+    ref = F.relu(F.conv2d(mid, wr2, p2.bias.cpu(), padding=1) + rnd(x, dtype))
+    check(y.permute(0, 3, 1, 2), ref, dtype, "fused basicblock vs torch")
+    s = ref.abs().max().item()
+    assert (y.float() - y2.float()).abs().max().item() <= (2e-2 if dtype == torch.bfloat16 else 1e-5) * s
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv3x3_matches_generic_igemm(cuda, dtype):
     """same plan through both kernels (the generic implicit GEMM is the fallback for padded outputs / stride 2)"""
     x = procedural_input("pg.x", (3, 128, 24, 40), 0)
