@@ -56,7 +56,7 @@ constexpr int kGrStageRow = 128 * 4 + 16; // fp32 staging row stride
 constexpr int kGrLds = 2 * kGrTile * kGrRow + 128 * 16;   // 69,632 B of tiles + the embedding producer's coefficient table
 
 template <typename T, bool EMB>
-__global__ __launch_bounds__(kGrThreads, EMB ? 2 : 4) void gemm_rows_kernel(GemmRowsParams p) {
+__global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams p) {
     constexpr int CH = Elem<T>::kChunk;
     constexpr int TK = 256 / Elem<T>::kBytes;        // elements per K-tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -114,30 +114,26 @@ __global__ __launch_bounds__(kGrThreads, EMB ? 2 : 4) void gemm_rows_kernel(Gemm
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = kt * TK + (sub * 4 + j) * CH;
-            if (!EMB) areg[j] = (a_ok && k < p.K) ? *(const uint4*)(arow + k) : make_uint4(0, 0, 0, 0);
-            wreg[j] = w_ok ? *(const uint4*)(wrow + k) : make_uint4(0, 0, 0, 0);
+            if (!EMB) {
+                areg[j] = (a_ok && k < p.K) ? *(const uint4*)(arow + k) : make_uint4(0, 0, 0, 0);
+                wreg[j] = w_ok ? *(const uint4*)(wrow + k) : make_uint4(0, 0, 0, 0);
+            }
         }
         if (EMB) {                                       // single K-tile (K <= TK): the whole row is here
             const int m = a_ok ? m0 + srow : m0;
             const int bn = m / p.emb_hw, pix = m - bn * p.emb_hw;
             const float wx = p.emb_world[pix], wy = p.emb_world[p.emb_hw + pix];
             const T* xrow = (const T*)p.in + ((size_t)(bn / p.emb_n) * p.emb_hw + pix) * p.K;
-            uint4 xr[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = (sub * 4 + j) * CH;
-                xr[j] = k < p.K ? *(const uint4*)(xrow + k) : make_uint4(0, 0, 0, 0);
-            }
-            float v[4][8];
+            // two passes over the embedding (sum of squares, then scale + add) instead of holding all 32 values:
+            // keeps the kernel at 128 VGPRs = two workgroups per CU like the plain GEMM
             float ss = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j)                   // rolled: the compiler would hoist all 32 coefficient reads
 #pragma unroll
                 for (int e = 0; e < CH; ++e) {
                     const int k = (sub * 4 + j) * CH + e;
                     const float4 c = coef[k < TK ? k : 0];
                     const float val = k < p.K ? (c.x * wx + c.y * wy + c.z) : 0.f;
-                    v[j][e] = val;
                     ss += val * val;
                 }
             ss += __shfl_xor(ss, 1, 64);
@@ -145,11 +141,22 @@ __global__ __launch_bounds__(kGrThreads, EMB ? 2 : 4) void gemm_rows_kernel(Gemm
             const float inv = 1.0f / (sqrtf(ss) + 1e-7f);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float xv[8];
-                chunk_to_f32<T>(xr[j], xv);
+                const int k0 = (sub * 4 + j) * CH;
+                float xv[8], v[8];
+                chunk_to_f32<T>(k0 < p.K ? *(const uint4*)(xrow + k0) : make_uint4(0, 0, 0, 0), xv);
 #pragma unroll
-                for (int e = 0; e < CH; ++e) v[j][e] = v[j][e] * inv + xv[e];
-                areg[j] = a_ok ? f32_to_chunk<T>(v[j]) : make_uint4(0, 0, 0, 0);   // rounded exactly as the stored query
+                for (int e = 0; e < CH; ++e) {
+                    const int k = k0 + e;
+                    const float4 c = coef[k < TK ? k : 0];
+                    v[e] = (k < p.K ? (c.x * wx + c.y * wy + c.z) : 0.f) * inv + xv[e];
+                }
+                areg[j] = a_ok ? f32_to_chunk<T>(v) : make_uint4(0, 0, 0, 0);   // rounded exactly as the stored query
+            }
+            __builtin_amdgcn_sched_barrier(0);           // the weight tile is requested after the register-hungry part
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kt * TK + (sub * 4 + j) * CH;
+                wreg[j] = w_ok ? *(const uint4*)(wrow + k) : make_uint4(0, 0, 0, 0);
             }
         }
     };

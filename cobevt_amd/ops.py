@@ -5,6 +5,7 @@ forward path is a HIP kernel launched through ctypes.  All functions require CUD
 otherwise — there is no CPU path here (the CPU restatement lives in oracle/ and is test infrastructure).
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -21,7 +22,9 @@ USE_STEM = True       # 7x7/s2 image stem through the space-to-depth kernel inst
 USE_ROW_CHAIN = True  # fuse out-proj + skip + pre-norm MLP (+ post-norm) after attention into one launch (bf16)
 BASICBLOCK_TILE_ROWS = 0   # 0 = kernel default; 8 | 16 pins the output tile height (tools/bb_probe.py)
 USE_BASICBLOCK = True  # stride-1 BasicBlocks on 64 / 128 channels as one launch (intermediate map stays in LDS)
-USE_EMBED_GEMM = True  # compute the BEV query embedding inside the to_q GEMM instead of materialising the query
+USE_EMBED_GEMM = False  # compute the BEV query embedding inside the to_q GEMM instead of materialising the query:
+# measured SLOWER on MI355X (119 vs 92 us on the level-0 shape, 361 vs 364 frames/s): the producer's 64 LDS
+# coefficient reads + ~400 VALU per thread cost more than the 170 MB of HBM traffic they save; kept for parity tests
 USE_CHAIN_NEXT = True  # ... and let the row-local GEMM that consumes its output next ride in the same launch
 
 
@@ -31,6 +34,20 @@ def dcode(dtype):
     if dtype == torch.float32:
         return FP32
     raise CobevtHipError("compute dtype must be torch.bfloat16 or torch.float32, got %s" % dtype)
+
+
+def _apply_env_flags():
+    """COBEVT_FLAGS="USE_EMBED_GEMM=0,CONV3_VARIANT=150": A/B switches for bench runs (every flag names a HIP path)."""
+    for item in os.environ.get("COBEVT_FLAGS", "").split(","):
+        if "=" in item:
+            k, v = item.split("=", 1)
+            k = k.strip()
+            if k not in globals() or not (k.startswith("USE_") or k in ("CONV3_VARIANT", "BASICBLOCK_TILE_ROWS")):
+                raise CobevtHipError("COBEVT_FLAGS: unknown switch %r" % k)
+            globals()[k] = int(v) if not k.startswith("USE_") else bool(int(v))
+
+
+_apply_env_flags()
 
 
 def _p(t):

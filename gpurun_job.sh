@@ -1,3 +1,4 @@
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-timeout 600 python bench.py --no-cpu-baseline > gpurun_out/bench20.log 2>&1; tail -1 gpurun_out/bench20.log | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+for f in "USE_EMBED_GEMM=1" "USE_EMBED_GEMM=0"; do
+COBEVT_FLAGS=$f timeout 600 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('$f', d['value'], d['ms_per_step'])"
+done

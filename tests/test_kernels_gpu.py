@@ -634,13 +634,13 @@ def test_bev_embed_fused_into_q_projection(cuda, dtype):
     class LN(object):
         weight, bias, eps = 0.8 + 0.4 * procedural_input("be.g", (d,), 0, 0, 1), procedural_input("be.be", (d,), 0, -0.2, 0.2), 1e-5
     plan = ops.ConvPlan(wq, procedural_input("be.bq", (96,), 0, -0.2, 0.2), dtype=dtype, device=cuda, ln=LN)
-    assert ops.USE_EMBED_GEMM and ops.ln_fusable(plan)
-    y = ops.bev_embed_linear(E, world, w_bev, b_bev, w_cam, x, n, plan)
-    ops.USE_EMBED_GEMM = False
+    assert ops.ln_fusable(plan)
+    y2 = ops.bev_embed_linear(E, world, w_bev, b_bev, w_cam, x, n, plan)    # default: bev_embed kernel + GEMM
+    ops.USE_EMBED_GEMM = True
     try:
-        y2 = ops.bev_embed_linear(E, world, w_bev, b_bev, w_cam, x, n, plan)
+        y = ops.bev_embed_linear(E, world, w_bev, b_bev, w_cam, x, n, plan)
     finally:
-        ops.USE_EMBED_GEMM = True
+        ops.USE_EMBED_GEMM = False
     assert y.shape == (b, n, H * W, 96)
     s = y2.float().abs().max().item()
     assert (y.float() - y2.float()).abs().max().item() <= (2e-2 if dtype == torch.bfloat16 else 1e-5) * s
