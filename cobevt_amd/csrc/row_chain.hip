@@ -48,14 +48,15 @@ struct RowChainParams {
     float eps1, eps_post, eps_next;
 };
 
-constexpr int kRcThreads = 512;
-constexpr int kRcRows = 64;
 constexpr int kRcRow = 256 + 16;            // 128 bf16 + pad
 constexpr int kRcHRow = 512 + 16;           // 256 bf16 + pad ; also the fp32 staging row of 128 floats
-constexpr int kRcA = 0;                                  // a tile, later LN(y), later the next projection's A operand
-constexpr int kRcY = kRcA + kRcRows * kRcRow;            // y tile (bf16) ; staging of the next projection's output
-constexpr int kRcH = kRcY + kRcRows * kRcRow;            // hidden tile [64][528] ; fp32 staging of z
-constexpr int kRcLds = kRcH + kRcRows * kRcHRow;         // 68,608 bytes
+// LDS regions for a ROWS-row tile (ROWS = 64: 8 waves, 68,608 B; ROWS = 32: 4 waves, 34,304 B -> four workgroups per CU)
+template <int ROWS> struct RcLds {
+    static constexpr int A = 0;                          // a tile, later LN(y), later the next projection's A operand
+    static constexpr int Y = A + ROWS * kRcRow;          // y tile (bf16) ; staging of the next projection's output
+    static constexpr int H = Y + ROWS * kRcRow;          // hidden tile [ROWS][528] ; fp32 staging of z
+    static constexpr int TOTAL = H + ROWS * kRcHRow;
+};
 
 // normalise one row held by 8 lanes (16 channels each; channels >= C are zero on entry and on exit)
 __device__ __forceinline__ void rc_normalise(float (&v)[16], int sub, int C, float eps) {
@@ -73,17 +74,18 @@ __device__ __forceinline__ void rc_normalise(float (&v)[16], int sub, int C, flo
     for (int e = 0; e < 16; ++e) v[e] = (sub * 16 + e) < C ? (v[e] - mean) * rstd : 0.f;
 }
 
-template <int NPASS>   // 128-column passes over the hidden layer (Hd <= 128 -> 1, else 2)
-__global__ __launch_bounds__(kRcThreads, 4) void row_chain_kernel(RowChainParams p) {
+// NPASS: 128-column passes over the hidden layer (Hd <= 128 -> 1, else 2).  ROWS: rows per workgroup (8 threads per row).
+template <int NPASS, int ROWS>
+__global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem + kRcA;
-    unsigned char* Ys = smem + kRcY;
-    unsigned char* Hs = smem + kRcH;
+    unsigned char* As = smem + RcLds<ROWS>::A;
+    unsigned char* Ys = smem + RcLds<ROWS>::Y;
+    unsigned char* Hs = smem + RcLds<ROWS>::H;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, ql = lane & 31;
-    const int wm = wave >> 2, wn = wave & 3;         // 2 x 4 waves, 32 rows x 32 columns each
-    const int m0 = blockIdx.x * kRcRows;
+    const int wm = wave >> 2, wn = wave & 3;         // (ROWS / 32) x 4 waves, 32 rows x 32 columns each
+    const int m0 = blockIdx.x * ROWS;
     const int ngc = (p.C * 2 + 31) / 32;             // 32-byte k-groups covering C channels
     const int row = wm * 32 + ql;                    // this lane's row of the tile in every MFMA result
     const bool row_ok = m0 + row < p.M;
@@ -306,7 +308,7 @@ extern "C" int cobevt_attn_mlp_chain(const void* a, const void* skip, void* out,
                                      const float* post_gamma, const float* post_beta, const void* wnext, const float* bnext,
                                      void* out_next, const int* dims, float eps1, float eps_post, float eps_next,
                                      hipStream_t stream) {
-    // dims: [dtype, M, C, Hd, Hdp, Nn, next_ln, next_act]
+    // dims: [dtype, M, C, Hd, Hdp, Nn, next_ln, next_act, rows_per_workgroup]
     if (!a || !out || !wp || !w1 || !b1 || !w2 || !b2 || !dims) return COBEVT_ERR_ARG;
     if (dims[0] != 0) return COBEVT_ERR_UNSUPPORTED;           // bf16 mode only; fp32 runs the GEMMs separately
     RowChainParams p;
@@ -324,12 +326,20 @@ extern "C" int cobevt_attn_mlp_chain(const void* a, const void* skip, void* out,
     if (wnext && (p.Nn < 8 || p.Nn % 8 || p.Nn > 1024 || p.next_act < 0 || p.next_act > 2)) return COBEVT_ERR_SHAPE;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)row_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kRcLds);
-        (void)hipFuncSetAttribute((const void*)row_chain_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kRcLds);
+        (void)hipFuncSetAttribute((const void*)row_chain_kernel<1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<64>::TOTAL);
+        (void)hipFuncSetAttribute((const void*)row_chain_kernel<2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<64>::TOTAL);
+        (void)hipFuncSetAttribute((const void*)row_chain_kernel<1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<32>::TOTAL);
+        (void)hipFuncSetAttribute((const void*)row_chain_kernel<2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<32>::TOTAL);
         attr_set = true;
     }
-    const unsigned blocks = (unsigned)((p.M + kRcRows - 1) / kRcRows);
-    if (p.Hd > 128) hipLaunchKernelGGL(row_chain_kernel<2>, dim3(blocks), dim3(kRcThreads), kRcLds, stream, p);
-    else hipLaunchKernelGGL(row_chain_kernel<1>, dim3(blocks), dim3(kRcThreads), kRcLds, stream, p);
+    const int rows = dims[8] == 64 ? 64 : 32;                  // dims[8]: rows per workgroup (0 = default 32)
+    const unsigned blocks = (unsigned)((p.M + rows - 1) / rows);
+    if (rows == 64) {
+        if (p.Hd > 128) hipLaunchKernelGGL((row_chain_kernel<2, 64>), dim3(blocks), dim3(512), RcLds<64>::TOTAL, stream, p);
+        else hipLaunchKernelGGL((row_chain_kernel<1, 64>), dim3(blocks), dim3(512), RcLds<64>::TOTAL, stream, p);
+    } else {
+        if (p.Hd > 128) hipLaunchKernelGGL((row_chain_kernel<2, 32>), dim3(blocks), dim3(256), RcLds<32>::TOTAL, stream, p);
+        else hipLaunchKernelGGL((row_chain_kernel<1, 32>), dim3(blocks), dim3(256), RcLds<32>::TOTAL, stream, p);
+    }
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

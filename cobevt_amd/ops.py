@@ -19,6 +19,7 @@ USE_CONV3_WFRAG = True   # ... and, where the fragment-ordered weight table exis
 CONV3_VARIANT = 0    # 0 = automatic tile choice of cobevt_conv3x3_wfrag_nhwc; >0 pins one (tools/conv_probe.py)
 USE_GEMM_ROWS = True  # route 1x1 stride-1 convs / linears to the dense-row GEMM with fused LayerNorm
 USE_STEM = True       # 7x7/s2 image stem through the space-to-depth kernel instead of the generic small-Cin igemm
+ROW_CHAIN_ROWS = 0     # rows per workgroup of the fused row chain: 0 = default (32), 64
 USE_ROW_CHAIN = True  # fuse out-proj + skip + pre-norm MLP (+ post-norm) after attention into one launch (bf16)
 BASICBLOCK_TILE_ROWS = 0   # 0 = kernel default; 8 | 16 pins the output tile height (tools/bb_probe.py)
 USE_BASICBLOCK = True  # stride-1 BasicBlocks on 64 / 128 channels as one launch (intermediate map stays in LDS)
@@ -42,7 +43,7 @@ def _apply_env_flags():
         if "=" in item:
             k, v = item.split("=", 1)
             k = k.strip()
-            if k not in globals() or not (k.startswith("USE_") or k in ("CONV3_VARIANT", "BASICBLOCK_TILE_ROWS")):
+            if k not in globals() or not (k.startswith("USE_") or k in ("CONV3_VARIANT", "BASICBLOCK_TILE_ROWS", "ROW_CHAIN_ROWS")):
                 raise CobevtHipError("COBEVT_FLAGS: unknown switch %r" % k)
             globals()[k] = int(v) if not k.startswith("USE_") else bool(int(v))
 
@@ -669,7 +670,7 @@ def attn_mlp_chain(a, skip, plan_p, plan_1, plan_2, post_ln=None, next_plan=None
     nn_ = next_plan.cout if fuse_next else 0
     out_next = torch.empty(a.shape[:-1] + (nn_,), device=a.device, dtype=a.dtype) if fuse_next else None
     dims = _ints([0, m, c, hd, plan_2.kp_rows, nn_, int(next_plan.has_ln) if fuse_next else 0,
-                  next_plan.act if fuse_next else 0])
+                  next_plan.act if fuse_next else 0, ROW_CHAIN_ROWS])
     pg, pb, pe = post_ln if post_ln is not None else (None, None, 0.0)
 
     def cost():
