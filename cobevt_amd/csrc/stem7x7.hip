@@ -183,6 +183,212 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(StemParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stem + MaxPool2d(3, 2, 1) in one kernel (cobevt_stem_conv7x7s2_pool): torchvision resnet conv1/bn1/relu/maxpool,
+// resnet_ms.py:67-71.  Separately the stem writes its 168 MB map (20 images) and the pool reads it back: 123 us for
+// 63 MB of input and 42 MB of pooled output.  Here a workgroup owns a 4 x 8 tile of POOLED pixels: it evaluates the
+// conv on the 9 x 17 region those windows cover (origin (2 py0 - 1, 2 px0 - 1); its 153 pixels linearised into five
+// 32-row MFMA tiles), stages bias + ReLU as the storage type (rounding commutes with max) with zeros for conv pixels
+// outside the map (post-ReLU values are >= 0 and every window holds a valid pixel, so 0 is the max-pool identity),
+// and writes the 3 x 3 / stride 2 maxima.  20 % of the conv is recomputed on tile borders; the kernel stays HBM-bound.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T> struct StemPoolCfg {
+    static constexpr int KG = 16 * Elem<T>::kBytes / 32;
+    static constexpr int PIX = 16 * Elem<T>::kBytes + 16;
+    static constexpr int RH = 9, RW = 17, RPIX = RH * RW;     // conv region
+    static constexpr int NPT = (RPIX + 31) / 32;              // 5 MFMA pixel tiles
+    static constexpr int PH = RH + 3, PW = RW + 3;            // 12 x 20 space-to-depth pixels
+    static constexpr int PROW = (PW * PIX + 255) / 256 * 256;
+    static constexpr int PATCH = PH * PROW;
+    static constexpr int WROW = 16 * 16 * Elem<T>::kBytes + 16;
+    static constexpr int WBYTES = 64 * WROW;
+    static constexpr int SROW = 64 * Elem<T>::kBytes + 16;    // staging row: 64 channels in the storage type
+    static constexpr int STAGE = RPIX * SROW;
+    static constexpr int LDS = PATCH + WBYTES + STAGE;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pool_kernel(StemParams p) {
+    using C = StemPoolCfg<T>;
+    constexpr int KG = C::KG, RW = C::RW, RPIX = C::RPIX;
+    constexpr int NPIECE = C::PH * C::PW * 2 * 3;
+    constexpr int P_IT = (NPIECE + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* patch = smem;
+    unsigned char* wl = smem + C::PATCH;
+    unsigned char* stage = smem + C::PATCH + C::WBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, ql = lane & 31;
+    const int Hp = p.Ho / 2, Wp = p.Wo / 2;                   // pooled map (Ho, Wo even)
+
+    for (int i = tid; i < C::PATCH / 16; i += 256) ((uint4*)patch)[i] = make_uint4(0, 0, 0, 0);
+
+    float2 preg[P_IT];
+    auto decode = [&](int tile, int& img, int& py0, int& px0) {
+        const int tx = tile % p.tiles_x;
+        const int rest = tile / p.tiles_x;
+        const int ty = rest % p.tiles_y;
+        img = rest / p.tiles_y;
+        py0 = ty * 4; px0 = tx * 8;
+    };
+    auto load_patch = [&](int tile) {
+        int img, py0, px0;
+        decode(tile, img, py0, px0);
+        const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;       // conv region origin
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const int item = tid + it * 256;
+            float2 v = make_float2(0.f, 0.f);
+            if (item < NPIECE) {
+                const int pc = item % 3, rest = item / 3;
+                const int dy = rest & 1, pix = rest >> 1;
+                const int py = pix / C::PW, px = pix - py * C::PW;
+                const int iy = 2 * (oy0 - 2 + py) + dy, ix = 2 * (ox0 - 2 + px);
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix + 1 < p.W)
+                    v = *(const float2*)(p.in + (((size_t)img * p.H + iy) * p.W + ix) * 3 + pc * 2);
+            }
+            preg[it] = v;
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const int item = tid + it * 256;
+            if (item < NPIECE) {
+                const int pc = item % 3, rest = item / 3;
+                const int dy = rest & 1, pix = rest >> 1;
+                const int py = pix / C::PW, px = pix - py * C::PW;
+                unsigned char* dst = patch + py * C::PROW + px * C::PIX + (dy * 6 + pc * 2) * Elem<T>::kBytes;
+                if constexpr (Elem<T>::kIsBf16) *(uint32_t*)dst = pack_bf2(preg[it].x, preg[it].y);
+                else *(float2*)dst = preg[it];
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= p.ntiles) return;
+    {
+        constexpr int PIECES = 16 * 16 * Elem<T>::kBytes / 16;
+        for (int i = tid; i < 64 * PIECES; i += 256) {
+            const int row = i / PIECES, j = i - row * PIECES;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < p.Cout) v = *(const uint4*)((const unsigned char*)p.wgt + ((size_t)row * PIECES + j) * 16);
+            *(uint4*)(wl + row * C::WROW + j * 16) = v;
+        }
+    }
+    __syncthreads();
+    load_patch(tile);
+
+    // this lane's conv-region pixels: tile t of wave w is pixel tile w + 4 t (only wave 0 has a second one)
+    int abase[2], rpix[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int pr = (wave + 4 * t) * 32 + ql;
+        rpix[t] = pr;
+        if (pr >= RPIX) pr = RPIX - 1;
+        const int ry = pr / RW, rx = pr - ry * RW;
+        abase[t] = ry * C::PROW + rx * C::PIX + h * 16;
+    }
+    const bool two = wave + 4 < C::NPT;                       // wave-uniform
+    const int bbase = ql * C::WROW + h * 16;
+    float4 bias4[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c0 = b * 32 + 8 * k + 4 * h;
+            bias4[b][k] = p.bias ? *(const float4*)(p.bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+
+    for (; tile < p.ntiles; tile += gridDim.x) {
+        int img, py0, px0;
+        decode(tile, img, py0, px0);
+        const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;
+        store_patch();
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < p.ntiles) load_patch(next);
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][b][r] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const int toff = a * C::PROW + bb * C::PIX;
+                const unsigned char* pw = wl + bbase + (a * 4 + bb) * 16 * Elem<T>::kBytes;
+#pragma unroll
+                for (int g = 0; g < KG; ++g) {
+                    const uint4 b0 = *(const uint4*)(pw + g * 32);
+                    const uint4 b1 = *(const uint4*)(pw + 32 * C::WROW + g * 32);
+                    const uint4 a0 = *(const uint4*)(patch + abase[0] + toff + g * 32);
+                    mfma_kgroup<T>(b0, a0, acc[0][0]);         // D = W . X^T: lane <-> pixel, registers <-> couts
+                    mfma_kgroup<T>(b1, a0, acc[0][1]);
+                    if (two) {
+                        const uint4 a1 = *(const uint4*)(patch + abase[1] + toff + g * 32);
+                        mfma_kgroup<T>(b0, a1, acc[1][0]);
+                        mfma_kgroup<T>(b1, a1, acc[1][1]);
+                    }
+                }
+            }
+        }
+        // ---- bias + ReLU, rounded to T, staged [region pixel][64]; conv pixels outside the map -> 0
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t == 1 && !two) break;
+            const int pr = rpix[t];
+            if (pr >= RPIX) continue;
+            const int ry = pr / RW, rx = pr - ry * RW;
+            const int oy = oy0 + ry, ox = ox0 + rx;
+            const bool inside = oy >= 0 && oy < p.Ho && ox >= 0 && ox < p.Wo;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v[4] = {acc[t][b][4 * k] + bias4[b][k].x, acc[t][b][4 * k + 1] + bias4[b][k].y,
+                                  acc[t][b][4 * k + 2] + bias4[b][k].z, acc[t][b][4 * k + 3] + bias4[b][k].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = inside ? fmaxf(v[e], 0.f) : 0.f;
+                    unsigned char* d = stage + pr * C::SROW + (b * 32 + 8 * k + 4 * h) * Elem<T>::kBytes;
+                    if constexpr (Elem<T>::kIsBf16) *(uint2*)d = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    else *(float4*)d = make_float4(v[0], v[1], v[2], v[3]);
+                }
+        }
+        __syncthreads();      // staging complete; every wave is done with the patch
+        // ---- 3 x 3 / stride 2 maxima: pooled pixel (qy, qx) of the 4 x 8 tile covers region rows 2qy..2qy+2, cols 2qx..2qx+2
+        constexpr int CH = Elem<T>::kChunk;
+        constexpr int CPP = 64 / CH;
+        T* out = (T*)p.out;
+        for (int item = tid; item < 32 * CPP; item += 256) {
+            const int q = item / CPP, cj = item - q * CPP;
+            const int qy = q >> 3, qx = q & 7;
+            const int py = py0 + qy, px = px0 + qx;
+            if (py >= Hp || px >= Wp) continue;
+            float m[8];
+#pragma unroll
+            for (int e = 0; e < CH; ++e) m[e] = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    float v[8];
+                    chunk_to_f32<T>(*(const uint4*)(stage + ((2 * qy + dy) * RW + 2 * qx + dx) * C::SROW + cj * 16), v);
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) m[e] = fmaxf(m[e], v[e]);
+                }
+            *(uint4*)(out + (((size_t)img * Hp + py) * Wp + px) * 64 + cj * CH) = f32_to_chunk<T>(m);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace cobevt
 
 using namespace cobevt;
@@ -215,5 +421,35 @@ extern "C" int cobevt_stem_conv7x7s2(const float* in, const void* wgt, const flo
     const unsigned blocks = (unsigned)(nt < 256L * per_cu ? nt : 256L * per_cu);
     if (dtype == 0) hipLaunchKernelGGL(stem7x7_kernel<bf16_t>, dim3(blocks), dim3(256), lds, stream, p);
     else hipLaunchKernelGGL(stem7x7_kernel<float>, dim3(blocks), dim3(256), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// C-ABI entry point, see include/cobevt_hip.h
+extern "C" int cobevt_stem_conv7x7s2_pool(const float* in, const void* wgt, const float* bias, void* out, const int* dims,
+                                          hipStream_t stream) {
+    // dims: [dtype, N, H, W]   (Cout = 64, ReLU, H and W multiples of 4)
+    if (!in || !wgt || !out || !dims) return COBEVT_ERR_ARG;
+    StemParams p;
+    const int dtype = dims[0];
+    p.in = in; p.wgt = wgt; p.bias = bias; p.out = out;
+    p.N = dims[1]; p.H = dims[2]; p.W = dims[3]; p.Cout = 64; p.act = 1;
+    if (dtype != 0 && dtype != 1) return COBEVT_ERR_ARG;
+    if (p.N < 1 || p.H < 4 || p.W < 4 || (p.H & 3) || (p.W & 3)) return COBEVT_ERR_SHAPE;
+    p.Ho = p.H / 2; p.Wo = p.W / 2;
+    p.tiles_y = (p.Ho / 2 + 3) / 4; p.tiles_x = (p.Wo / 2 + 7) / 8; p.tiles_n = 1;
+    const long nt = (long)p.N * p.tiles_y * p.tiles_x;
+    if (nt > 0x7fffffffL) return COBEVT_ERR_SHAPE;
+    p.ntiles = (int)nt;
+    const size_t lds = dtype == 0 ? StemPoolCfg<bf16_t>::LDS : StemPoolCfg<float>::LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)stem_pool_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StemPoolCfg<bf16_t>::LDS);
+        (void)hipFuncSetAttribute((const void*)stem_pool_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StemPoolCfg<float>::LDS);
+        attr_set = true;
+    }
+    const int per_cu = dtype == 0 ? 2 : 1;
+    const unsigned blocks = (unsigned)(nt < 256L * per_cu ? nt : 256L * per_cu);
+    if (dtype == 0) hipLaunchKernelGGL(stem_pool_kernel<bf16_t>, dim3(blocks), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL(stem_pool_kernel<float>, dim3(blocks), dim3(256), lds, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

@@ -69,8 +69,7 @@ class ResNet(HipModule):
 
     def stem_nhwc(self, images):
         """images: (N, H, W, 3) fp32 channels-last -> (N, H/4, W/4, 64)"""
-        x = ops.conv2d(images, rt.conv_plan(self, "stem", self.conv1, self.bn1, act=1, smallc=True))
-        return ops.maxpool3x3s2(x)
+        return ops.stem_pool(images, rt.conv_plan(self, "stem", self.conv1, self.bn1, act=1, smallc=True))
 
 
 class ResnetEncoder(HipModule):

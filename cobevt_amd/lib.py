@@ -23,6 +23,7 @@ SIGNATURES = {
     "cobevt_conv3x3_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_basicblock_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_conv3x3_wfrag_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _c_int_p, _vp]),
+    "cobevt_stem_conv7x7s2_pool": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_stem_conv7x7s2": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_bev_embed_linear_rows": (ctypes.c_int, [_vp] * 9 + [_c_long_p, ctypes.c_float, _vp]),
     "cobevt_linear_rows": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_long_p, ctypes.c_float, _vp]),

@@ -18,6 +18,7 @@ USE_CONV3X3 = True   # route eligible 3x3 convs to the LDS-patch kernel (tests f
 USE_CONV3_WFRAG = True   # ... and, where the fragment-ordered weight table exists, to the barrier-free-per-tap variant
 CONV3_VARIANT = 0    # 0 = automatic tile choice of cobevt_conv3x3_wfrag_nhwc; >0 pins one (tools/conv_probe.py)
 USE_GEMM_ROWS = True  # route 1x1 stride-1 convs / linears to the dense-row GEMM with fused LayerNorm
+USE_STEM_POOL = True  # stem conv + max pool in one launch (the stem map never reaches HBM)
 USE_STEM = True       # 7x7/s2 image stem through the space-to-depth kernel instead of the generic small-Cin igemm
 ROW_CHAIN_ROWS = 0     # rows per workgroup of the fused row chain: 0 = default (32), 64
 USE_ROW_CHAIN = True  # fuse out-proj + skip + pre-norm MLP (+ post-norm) after attention into one launch (bf16)
@@ -524,6 +525,28 @@ def bev_embed_linear(e_inv, world, w_bev, b_bev, w_cam, x, n, plan):
                                                     _p(plan.wgt_rows), _p(plan.bias), _p(out), dims,
                                                     ctypes.c_float(plan.ln_eps), _stream())
     _L.check(rc, "cobevt_bev_embed_linear_rows")
+    return out
+
+
+def stem_pool(x, plan):
+    """maxpool3x3s2(conv2d(x, plan)) for the ResNet stem plan (7x7 / s2 / pad 3 on the fp32 image, 64 couts, ReLU):
+    one launch when the image sides are multiples of 4, else the two kernels."""
+    _need_cuda(x)
+    n, h, w, cin = x.shape
+    fused = (USE_STEM_POOL and USE_STEM and plan.wgt_stem is not None and plan.cout == 64 and plan.act == 1
+             and h % 4 == 0 and w % 4 == 0 and x.dtype == torch.float32 and x.is_contiguous())
+    if not fused:
+        return maxpool3x3s2(conv2d(x, plan))
+    out = torch.empty((n, h // 4, w // 4, 64), device=x.device, dtype=plan.dtype)
+    dims = _ints([plan.code, n, h, w])
+
+    def cost():
+        esz = 2 if plan.code == BF16 else 4
+        return 2.0 * n * (h // 2) * (w // 2) * 64 * 147, float(x.numel() * 4 + out.numel() * esz)
+
+    with _timed("stem7x7|pool %dx%dx%d" % (n, h, w), cost):
+        rc = _L.load().cobevt_stem_conv7x7s2_pool(_p(x), _p(plan.wgt_stem), _p(plan.bias), _p(out), dims, _stream())
+    _L.check(rc, "cobevt_stem_conv7x7s2_pool")
     return out
 
 

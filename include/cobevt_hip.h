@@ -98,6 +98,15 @@ int cobevt_stem_conv7x7s2(const float* in, const void* wgt, const float* bias, v
                           hipStream_t stream);
 
 /*
+ * The stem followed by MaxPool2d(3, 2, 1) in one launch (torchvision resnet conv1/bn1/relu/maxpool, resnet_ms.py:67-71):
+ * a workgroup computes the conv on the 9 x 17 region a 4 x 8 tile of pooled pixels covers and writes the maxima, so the
+ * (N, H/2, W/2, 64) stem map never reaches HBM.  Cout = 64, ReLU.  out (N, H/4, W/4, 64).
+ * dims (int32[4]): dtype, N, H, W (multiples of 4).
+ */
+int cobevt_stem_conv7x7s2_pool(const float* in, const void* wgt, const float* bias, void* out, const int* dims,
+                               hipStream_t stream);
+
+/*
  * Dense-row GEMM with fused LayerNorm / pre-activation on the A operand and fused bias / residual / activation:
  * the fast path of every nn.Linear and 1x1 stride-1 convolution (fax_modules.py:189-193,281-292,309-313,411,435,472;
  * swap_fusion_modules.py:45-53; base_transformer.py:102-124).  wgt [N][Kp] (Kp = K rounded up to 128 bf16 / 64 fp32

@@ -148,6 +148,30 @@ def test_stem_space_to_depth_kernel(cuda, dtype, n, h, w):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,h,w", [(3, 128, 96), (1, 36, 52), (2, 64, 64)])
+def test_stem_fused_with_maxpool(cuda, dtype, n, h, w):
+    """conv1 + bn1 + relu + maxpool(3, 2, 1) in one launch == stem kernel followed by the pool kernel (bit for bit:
+    rounding commutes with max), and vs torch; ragged pooled tiles"""
+    x = procedural_input("sp.x", (n, 3, h, w), 0)
+    wt = procedural_input("sp.w", (64, 3, 7, 7), 0) * math.sqrt(3.0 / 147)
+    bn = FakeBN(64, "sp.bn")
+    plan = ops.ConvPlan(wt, None, bn=bn, stride=2, pad=3, act=1, dtype=dtype, device=cuda, smallc=True)
+    xd = nhwc(x).to(cuda)
+    assert ops.USE_STEM_POOL
+    y = ops.stem_pool(xd, plan)
+    ops.USE_STEM_POOL = False
+    try:
+        y2 = ops.stem_pool(xd, plan)
+    finally:
+        ops.USE_STEM_POOL = True
+    assert y.shape == (n, h // 4, w // 4, 64)
+    assert torch.equal(y, y2), "fused stem+pool differs from stem -> pool in %d values" % (y != y2).sum()
+    wref = plan.wgt.float().cpu()[:, :plan.K].reshape(64, 7, 7, 3).permute(0, 3, 1, 2)
+    ref = F.max_pool2d(F.relu(F.conv2d(rnd(x, dtype), wref, plan.bias.cpu(), stride=2, padding=3)), 3, 2, 1)
+    check(y.permute(0, 3, 1, 2), ref, dtype, "stem+pool vs torch")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_1x1_preact_bn_relu_padded_out(cuda, dtype):
     _conv_case(cuda, dtype, "c5", 2, 56, 14, 15, 128, 1, 1, 0, bias=False, pre_bn=True, out_pad=(18, 24))
 
