@@ -77,21 +77,17 @@ class CorpBEVT(HipModule):
 
     overlap_streams = True   # run each level's key/value path on a side HIP stream under the remaining encoder stages
 
-    def encode_agents(self, batch_dict):
-        """Per-agent SinBEVT: images -> (N, H, W, C) channels-last BEV features (the tensor V2V sharing transmits).
-        Agents are a pure batch dimension here (corpbevt.py:112-117), which is what the multi-GPU path shards.
+    def encode_trunk(self, batch_dict):
+        """Stage 1 of the per-agent SinBEVT: the camera encoder and everything of the FAX pyramid that depends only on
+        the images and the camera geometry (ray embedding, feature projections, K/V projections of both attentions of
+        every level).  Returns the state `fax_query` needs: {"kv": [per-level dict], "E_inv", "batch"}.
 
-        Schedule: the key/value side of pyramid level i (ray embedding, feature projections, K/V projections of both
-        attentions) depends only on encoder stage id_pick[i], not on the BEV query, so it is forked onto a side stream
-        as soon as that stage is done and overlaps the remaining ResNet stages (whose 160-320 workgroups leave CUs
-        idle); the query path joins it right before the level's first attention.  Captured as parallel graph branches."""
-        pick = self.encoder.idx_pick
-        if not (self.overlap_streams and isinstance(pick, list) and batch_dict["inputs"].is_cuda):
-            x = self.encoder(batch_dict["inputs"])
-            batch_dict.update({"features": x})
-            x = self.fax(batch_dict)                    # (N, 1, C, H, W) channels-last view
-            return rt.to_nhwc(x.squeeze(1))
+        Schedule: the key/value side of pyramid level i depends only on encoder stage id_pick[i], not on the BEV query,
+        so it is forked onto a side stream as soon as that stage is done and overlaps the remaining ResNet stages (whose
+        160-320 workgroups leave CUs idle); the query path joins it right before the level's first attention.
+        Captured as parallel graph branches."""
         self._require_inference(batch_dict["inputs"], batch_dict["intrinsic"], batch_dict["extrinsic"])
+        pick = self.encoder.idx_pick
         images = batch_dict["inputs"]
         b, l, n = images.shape[:3]
         fax = self.fax
@@ -114,17 +110,37 @@ class CorpBEVT(HipModule):
             for t in kv[level].values():
                 if torch.is_tensor(t):
                     t.record_stream(main)
+        v = [rt.nchw_view(feats[i]) for i in range(len(pick))]
+        batch_dict.update({"features": [t.reshape(b, l, n, *t.shape[1:]) for t in v]})    # reference side effect (:113)
+        return {"kv": [kv[i] for i in range(len(pick))], "E_inv": E_inv, "batch": b * l, "side": side}
 
-        def joined(level):
+    def fax_query(self, state, joined=True):
+        """Stage 2: the BEV-query side of the FAX pyramid on the K/V state of `encode_trunk` -> (N, H, W, C) channels-last
+        BEV features (the tensor V2V sharing transmits).  joined=False: the state's tensors are already complete on the
+        current stream (they come from an earlier pipeline step), no side-stream join."""
+        kv, side = state["kv"], state.get("side")
+        main = torch.cuda.current_stream()
+
+        def getter(level):
             def get():
-                main.wait_stream(side[level])
+                if joined and side is not None:
+                    main.wait_stream(side[level])
                 return kv[level]
             return get
 
-        v = [rt.nchw_view(feats[i]) for i in range(len(pick))]
-        batch_dict.update({"features": [t.reshape(b, l, n, *t.shape[1:]) for t in v]})    # reference side effect (:113)
-        return fax.forward_features([feats[i] for i in range(len(pick))], I_inv, E_inv, b * l,
-                                    kv=[joined(i) for i in range(len(pick))])
+        return self.fax.forward_features([None] * len(kv), None, state["E_inv"], state["batch"],
+                                         kv=[getter(i) for i in range(len(kv))])
+
+    def encode_agents(self, batch_dict):
+        """Per-agent SinBEVT: images -> (N, H, W, C) channels-last BEV features (the tensor V2V sharing transmits).
+        Agents are a pure batch dimension here (corpbevt.py:112-117), which is what the multi-GPU path shards."""
+        pick = self.encoder.idx_pick
+        if not (self.overlap_streams and isinstance(pick, list) and batch_dict["inputs"].is_cuda):
+            x = self.encoder(batch_dict["inputs"])
+            batch_dict.update({"features": x})
+            x = self.fax(batch_dict)                    # (N, 1, C, H, W) channels-last view
+            return rt.to_nhwc(x.squeeze(1))
+        return self.fax_query(self.encode_trunk(batch_dict))
 
     def forward(self, batch_dict):
         feats = self.encode_agents(batch_dict)
