@@ -384,23 +384,30 @@ __device__ unsigned long long cobevt_conv3_trace[64];
 // MT strips for its 32 couts and its share of each tap's four k-groups, so no B fragment is loaded twice in a
 // workgroup; the k-split partial sums meet in the fp32 staging tile of the epilogue.
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int MT, int WN, int KS> struct Conv3SCfg {
+// S = convolution stride.  S = 2 (the first conv of a down-sampling BasicBlock, resnet_ms.py:67-74): a strip of 2 x 16
+// output pixels needs 5 x 33 input pixels; they are stored de-interleaved by column parity ([row][parity][17 pixels]) so
+// that a tap's A fragments are again 16 consecutive pixels at the 144-byte stride (conflict-free ds_read_b128), and the
+// patch is single-buffered (25.6 KB per strip; these layers have 1-4 channel chunks, the refill is exposed 0-3 times).
+template <typename T, int MT, int WN, int KS, int S = 1> struct Conv3SCfg {
     static constexpr int NT = 512, KG = 4, KGW = KG / KS;
-    static constexpr int BN = WN * 32, PW = 18, SROWS = 4;
+    static constexpr int BN = WN * 32;
+    static constexpr int PW = S == 1 ? 18 : 33;               // input pixels per patch row
+    static constexpr int SROWS = S == 1 ? 4 : 5;              // input rows per strip
     static constexpr int PSTR = KG * 32 + 16;
-    static constexpr int PROW = (PW * PSTR + 255) / 256 * 256;
+    static constexpr int PLANE = 17 * PSTR;                   // S = 2: one column-parity plane of a patch row
+    static constexpr int PROW = ((S == 1 ? PW * PSTR : 2 * PLANE) + 255) / 256 * 256;
     static constexpr int STRIP_BYTES = SROWS * PROW;
     static constexpr int PATCH_BYTES = MT * STRIP_BYTES;
     static constexpr int SSTR = BN * 4 + 16;
     static constexpr int STAGE_BYTES = MT * 32 * SSTR;
-    static constexpr int MAIN_BYTES = 2 * PATCH_BYTES;
+    static constexpr int MAIN_BYTES = (S == 1 ? 2 : 1) * PATCH_BYTES;
     static constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
     static_assert(WN * KS == 8, "eight waves");
 };
 
-template <typename T, int MT, int WN, int KS>
+template <typename T, int MT, int WN, int KS, int S>
 __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
-    using C = Conv3SCfg<T, MT, WN, KS>;
+    using C = Conv3SCfg<T, MT, WN, KS, S>;
     constexpr int NT = C::NT, KG = C::KG, KGW = C::KGW, BN = C::BN, PW = C::PW;
     constexpr int CH = Elem<T>::kChunk;
     constexpr int CC = KG * 32 / Elem<T>::kBytes;
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
     constexpr int PIECES = 2 * KG;
     constexpr int STRIP_ITEMS = C::SROWS * PW * PIECES;          // 576 16-byte pieces per strip patch
     constexpr int PATCH_ITEMS = MT * STRIP_ITEMS;
-    constexpr int P_IT = (PATCH_ITEMS + NT - 1) / NT;
+    constexpr int P_IT = S == 1 ? (PATCH_ITEMS + NT - 1) / NT : 1;   // S = 2 refills the patch without resident registers
     constexpr int PF = 2, R = 3;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
         const int item = tid + it * NT;
         pgoff[it] = 0;
         plds[it] = -1;
-        if (item < PATCH_ITEMS) {
+        if (S == 1 && item < PATCH_ITEMS) {
             const int s = item / STRIP_ITEMS, r = item - s * STRIP_ITEMS;
             const int pix = r / PIECES, j = r - pix * PIECES;
             const int py = pix / PW, px = pix - py * PW;
@@ -477,6 +484,37 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
 #pragma unroll
         for (int g = 0; g < KGW; ++g) b[g] = wq[(size_t)step * (KG * 64) + g * 64];
     };
+    // S = 2: fill the single patch buffer for one channel chunk, eight 16-byte pieces in flight per thread at a time
+    auto fill_patch_s2 = [&](int chunk) {
+        constexpr int BATCH = 8;
+        for (int base = 0; base < PATCH_ITEMS; base += BATCH * NT) {
+            uint4 v[BATCH];
+            int dst[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int item = base + u * NT + tid;
+                dst[u] = -1;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (item < PATCH_ITEMS) {
+                    const int st = item / STRIP_ITEMS, r = item - st * STRIP_ITEMS;
+                    const int pix = r / PIECES, j = r - pix * PIECES;
+                    const int py = pix / PW, px = pix - py * PW;
+                    dst[u] = st * STRIP + py * PROW + (px & 1) * C::PLANE + (px >> 1) * PSTR + j * 16;
+                    const int q = q0 + st;
+                    if (q < nstrips) {
+                        const int img = q / per_img, rem = q - img * per_img;
+                        const int sy = rem / p.tiles_x, sx = rem - sy * p.tiles_x;
+                        const int vy = sy * 4 - 1 + py, vx = sx * 32 - 1 + px;
+                        if (vy >= 0 && vy < p.H && vx >= 0 && vx < p.W)
+                            v[u] = *(const uint4*)(in + ((img * p.H + vy) * p.W + vx) * p.Cin + j * CH + chunk * CC);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u)
+                if (dst[u] >= 0) *(uint4*)(patch + dst[u]) = v[u];
+        }
+    };
 
     f32x16 acc[MT];
 #pragma unroll
@@ -484,21 +522,22 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
-    const int abase = (ql >> 4) * PROW + (ql & 15) * PSTR + h * 16 + ks * KGW * 32;
+    const int abase = (ql >> 4) * S * PROW + (ql & 15) * PSTR + h * 16 + ks * KGW * 32;
 
     uint4 bq[R][KGW];
     COBEVT_TRACE_MARK(0);
-    load_patch(0);
+    if (S == 1) load_patch(0);
 #pragma unroll
     for (int s = 0; s < PF; ++s) load_b(bq[s], s < nsteps ? s : nsteps - 1);
-    store_patch(patch);
+    if (S == 1) store_patch(patch);
+    else fill_patch_s2(0);
     __syncthreads();
     COBEVT_TRACE_MARK(1);
     auto run_chunk = [&](int chunk) {
         const bool more = chunk + 1 < nchunk;
-        unsigned char* pbuf = patch + (chunk & 1) * C::PATCH_BYTES;
-        unsigned char* pother = patch + ((chunk & 1) ^ 1) * C::PATCH_BYTES;
-        if (!(COBEVT_CONV3_KNOCK & 8)) load_patch(more ? chunk + 1 : chunk);   // unconditional (clamped): counted vmcnt
+        unsigned char* pbuf = patch + (S == 1 ? (chunk & 1) * C::PATCH_BYTES : 0);
+        unsigned char* pother = patch + (S == 1 ? ((chunk & 1) ^ 1) * C::PATCH_BYTES : 0);
+        if (S == 1 && !(COBEVT_CONV3_KNOCK & 8)) load_patch(more ? chunk + 1 : chunk);   // unconditional (clamped): counted vmcnt
         // A fragments run two k-groups ahead of the MFMAs in a three-slot register ring (9 * KGW groups per chunk, a
         // multiple of 3, so slots are static); sched_group_barrier pins the issue order "one ds_read, one MFMA", i.e. a
         // fragment is requested 2 * MT MFMAs (>= 320 cycles) before its first use.  A wave alone on its SIMD then
@@ -510,7 +549,8 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
         auto read_a = [&](uint4 (&dst)[MT], int n) {     // n = group index inside the chunk (compile-time after unrolling)
             const int t2 = n / KGW, g2 = n - t2 * KGW;
             const int kh2 = t2 / 3, kw2 = t2 - kh2 * 3;
-            const unsigned char* pn = pbuf + kh2 * PROW + kw2 * PSTR + abase + g2 * 32;
+            const int toff = S == 1 ? kh2 * PROW + kw2 * PSTR : kh2 * PROW + (kw2 & 1) * C::PLANE + (kw2 >> 1) * PSTR;
+            const unsigned char* pn = pbuf + toff + abase + g2 * 32;
 #pragma unroll
             for (int a = 0; a < MT; ++a) dst[a] = *(const uint4*)(pn + a * STRIP);
         };
@@ -548,7 +588,7 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             // the other buffer has been free since the last barrier: write the next chunk's patch under taps 7-8
-            if (tap == 6 && more && !(COBEVT_CONV3_KNOCK & 8)) {
+            if (S == 1 && tap == 6 && more && !(COBEVT_CONV3_KNOCK & 8)) {
                 store_patch(pother);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -576,12 +616,26 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
     };
     // the last chunk is peeled so the residual loads of the store pass can be issued (unconditionally, keeping the
     // vmcnt waits counted) one chunk of MFMAs before they are needed
-    constexpr bool EARLY_RES = Elem<T>::kIsBf16 && MT <= 5;
+    constexpr bool EARLY_RES = S == 1 && Elem<T>::kIsBf16 && MT <= 5;
     Conv3Store<T, NT, MT * 32, BN> st;
-    for (int chunk = 0; chunk + 1 < nchunk; ++chunk) run_chunk(chunk);
-    if (EARLY_RES && p.store_mode == 0) st.prepare(p, tid, n0, coord);
-    __builtin_amdgcn_sched_barrier(0);               // keep the residual loads up here
-    run_chunk(nchunk - 1);
+    if (S == 1) {
+        for (int chunk = 0; chunk + 1 < nchunk; ++chunk) run_chunk(chunk);
+        if (EARLY_RES && p.store_mode == 0) st.prepare(p, tid, n0, coord);
+        __builtin_amdgcn_sched_barrier(0);           // keep the residual loads up here
+        run_chunk(nchunk - 1);
+    } else {
+        // single patch buffer: refill between two barriers (run_chunk ends with one); ONE call site keeps the fully
+        // unrolled body within the unroller's budget (with two, LLVM left the tap loop rolled and the fragment rings
+        // went to scratch: 3x slower)
+#pragma unroll 1
+        for (int chunk = 0; chunk < nchunk; ++chunk) {
+            if (chunk > 0) {
+                fill_patch_s2(chunk);
+                __syncthreads();
+            }
+            run_chunk(chunk);
+        }
+    }
     COBEVT_TRACE_MARK(38);
 
     // ---- epilogue: the KS k-split partials meet in the fp32 staging tile [MT*32 pixels][BN].  With the operands
@@ -660,9 +714,9 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
     COBEVT_TRACE_MARK(40);
 }
 
-template <typename T, int MT, int WN, int KS>
+template <typename T, int MT, int WN, int KS, int S>
 static int launch_conv3s(Conv3Params p, int coutp, hipStream_t stream) {
-    using C = Conv3SCfg<T, MT, WN, KS>;
+    using C = Conv3SCfg<T, MT, WN, KS, S>;
     if ((long)p.N * p.H * p.W * p.Cin >= 0x7fffffffL) return COBEVT_ERR_UNSUPPORTED;   // 32-bit patch offsets
     p.tiles_y = (p.Ho + 1) / 2;
     p.tiles_x = (p.Wo + 15) / 16;
@@ -674,30 +728,31 @@ static int launch_conv3s(Conv3Params p, int coutp, hipStream_t stream) {
     constexpr size_t lds = C::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_strips_kernel<T, MT, WN, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv3x3_strips_kernel<T, MT, WN, KS, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_strips_kernel<T, MT, WN, KS>), dim3((unsigned)blocks), dim3(C::NT), lds, stream, p);
+    hipLaunchKernelGGL((conv3x3_strips_kernel<T, MT, WN, KS, S>), dim3((unsigned)blocks), dim3(C::NT), lds, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
 template <typename T, int MT>
-static int launch_conv3s_bn(const Conv3Params& p, int coutp, int bn64, hipStream_t stream) {
-    return bn64 ? launch_conv3s<T, MT, 2, 4>(p, coutp, stream) : launch_conv3s<T, MT, 4, 2>(p, coutp, stream);
+static int launch_conv3s_bn(const Conv3Params& p, int coutp, int bn64, int stride, hipStream_t stream) {
+    if (stride == 2) return bn64 ? launch_conv3s<T, MT, 2, 4, 2>(p, coutp, stream) : launch_conv3s<T, MT, 4, 2, 2>(p, coutp, stream);
+    return bn64 ? launch_conv3s<T, MT, 2, 4, 1>(p, coutp, stream) : launch_conv3s<T, MT, 4, 2, 1>(p, coutp, stream);
 }
 
 template <typename T>
-static int dispatch_conv3f(const Conv3Params& p, int kg, int coutp, int variant, hipStream_t stream) {
+static int dispatch_conv3f(const Conv3Params& p, int kg, int coutp, int variant, int stride, hipStream_t stream) {
     if (kg != 4) return COBEVT_ERR_UNSUPPORTED;
     // variant = 100 + 10*MT + (1 if 64-cout tiles else 0); 0 = a safe default
     if (variant == 0) variant = p.Cout <= 64 ? 151 : 150;
     const int mt = (variant - 100) / 10, bn64 = (variant - 100) % 10;
     if (variant < 100 || bn64 > 1) return COBEVT_ERR_ARG;
     switch (mt) {
-        case 3: return launch_conv3s_bn<T, 3>(p, coutp, bn64, stream);
-        case 4: return launch_conv3s_bn<T, 4>(p, coutp, bn64, stream);
-        case 5: return launch_conv3s_bn<T, 5>(p, coutp, bn64, stream);
-        case 6: return launch_conv3s_bn<T, 6>(p, coutp, bn64, stream);
+        case 3: return launch_conv3s_bn<T, 3>(p, coutp, bn64, stride, stream);
+        case 4: return launch_conv3s_bn<T, 4>(p, coutp, bn64, stride, stream);
+        case 5: return launch_conv3s_bn<T, 5>(p, coutp, bn64, stride, stream);
+        case 6: return launch_conv3s_bn<T, 6>(p, coutp, bn64, stride, stream);
         default: return COBEVT_ERR_ARG;
     }
 }
@@ -739,24 +794,26 @@ extern "C" int cobevt_conv3x3_nhwc(const void* in, const void* wgt, const float*
 // C-ABI entry point, see include/cobevt_hip.h
 extern "C" int cobevt_conv3x3_wfrag_nhwc(const void* in, const void* wfrag, const float* bias, const void* residual, void* out,
                                          const int* dims, hipStream_t stream) {
-    // dims: [dtype, N, H, W, Cin, Cout, upsample, act, store_mode, chunk_channels, padded_cout, variant]
+    // dims: [dtype, N, H, W, Cin, Cout, upsample, act, store_mode, chunk_channels, padded_cout, variant, stride]
     if (!in || !wfrag || !out || !dims) return COBEVT_ERR_ARG;
     Conv3Params p;
     const int dtype = dims[0];
     p.in = in; p.wgt = wfrag; p.bias = bias; p.residual = residual; p.out = out;
     p.N = dims[1]; p.H = dims[2]; p.W = dims[3]; p.Cin = dims[4]; p.Cout = dims[5];
     p.upsample = dims[6]; p.act = dims[7]; p.store_mode = dims[8];
-    const int cc = dims[9], coutp = dims[10], variant = dims[11];
-    p.Ho = p.upsample ? 2 * p.H : p.H;
-    p.Wo = p.upsample ? 2 * p.W : p.W;
+    const int cc = dims[9], coutp = dims[10], variant = dims[11], stride = dims[12];
+    if (stride != 1 && stride != 2) return COBEVT_ERR_ARG;
+    if (stride == 2 && (p.upsample || p.store_mode != 0)) return COBEVT_ERR_UNSUPPORTED;
+    p.Ho = stride == 2 ? (p.H - 1) / 2 + 1 : (p.upsample ? 2 * p.H : p.H);
+    p.Wo = stride == 2 ? (p.W - 1) / 2 + 1 : (p.upsample ? 2 * p.W : p.W);
     if (dtype != 0 && dtype != 1) return COBEVT_ERR_ARG;
     if (p.N < 1 || p.H < 1 || p.W < 1 || p.Cin < 1 || p.Cout < 1 || cc < 1) return COBEVT_ERR_SHAPE;
     if (p.store_mode != 0 && p.store_mode != 1) return COBEVT_ERR_ARG;
     if (p.store_mode == 1 && (p.residual || ((p.Ho | p.Wo) & 1))) return COBEVT_ERR_UNSUPPORTED;
     if (p.Cin % cc != 0 || coutp % 32 != 0 || coutp < p.Cout) return COBEVT_ERR_SHAPE;
     const int kg = cc * (dtype == 0 ? 2 : 4) / 32;
-    return dtype == 0 ? dispatch_conv3f<bf16_t>(p, kg, coutp, variant, stream)
-                      : dispatch_conv3f<float>(p, kg, coutp, variant, stream);
+    return dtype == 0 ? dispatch_conv3f<bf16_t>(p, kg, coutp, variant, stride, stream)
+                      : dispatch_conv3f<float>(p, kg, coutp, variant, stride, stream);
 }
 
 #ifdef COBEVT_CONV3_TRACE

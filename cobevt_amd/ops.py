@@ -15,6 +15,7 @@ from .lib import CobevtHipError
 
 BF16, FP32 = 0, 1
 USE_CONV3X3 = True   # route eligible 3x3 convs to the LDS-patch kernel (tests flip this to cover both paths)
+USE_CONV3_S2 = True      # 3x3 / stride-2 convs through the strip kernel instead of the generic implicit GEMM
 USE_CONV3_WFRAG = True   # ... and, where the fragment-ordered weight table exists, to the barrier-free-per-tap variant
 CONV3_VARIANT = 0    # 0 = automatic tile choice of cobevt_conv3x3_wfrag_nhwc; >0 pins one (tools/conv_probe.py)
 USE_GEMM_ROWS = True  # route 1x1 stride-1 convs / linears to the dense-row GEMM with fused LayerNorm
@@ -208,19 +209,20 @@ class ConvPlan(object):
             self.klut = code.to(torch.int32).to(device).contiguous()
         # 3x3 / stride 1 / pad 1 fast path (conv3x3.hip): weights [Cout][Cin/cc][9][cc]
         self.wgt3, self.cc3 = None, 0
-        if kh == 3 and kw == 3 and int(stride) == 1 and int(pad) == 1 and not smallc and pre_bn is None \
-                and int(store_mode) in (0, 1):
+        if kh == 3 and kw == 3 and int(stride) in (1, 2) and int(pad) == 1 and not smallc and pre_bn is None \
+                and int(store_mode) in (0, 1) and not (int(stride) == 2 and (upsample or int(store_mode) != 0)):
             cands = (64, 32) if self.code == BF16 else (32, 16)
             for cc in cands:
                 if cin % cc == 0:
                     w3 = w.permute(0, 2, 3, 1).reshape(cout, 9, cin // cc, cc).permute(0, 2, 1, 3)
-                    self.wgt3 = w3.to(torch.float32).to(dtype).to(device).contiguous()
+                    if int(stride) == 1:          # the LDS-staged kernel is stride 1 only
+                        self.wgt3 = w3.to(torch.float32).to(dtype).to(device).contiguous()
                     self.cc3 = cc
                     break
         # the same weights in MFMA B-fragment order for cobevt_conv3x3_wfrag_nhwc (128-byte chunks only):
         # [Cout_p/32][Cin/cc][9][KG][lane = 32*half + cout%32][16 bytes], Cout zero-padded to a multiple of 128
         self.wfrag, self.coutp3 = None, 0
-        if self.wgt3 is not None and self.cc3 == cands[0]:
+        if self.cc3 and self.cc3 == (64 if self.code == BF16 else 32):
             cc, coutp = self.cc3, (cout + 127) // 128 * 128
             wp = torch.zeros(coutp, cin // cc, 9, cc, dtype=torch.float64)
             wp[:cout] = w.permute(0, 2, 3, 1).reshape(cout, 9, cin // cc, cc).permute(0, 2, 1, 3)
@@ -275,18 +277,19 @@ def ln_fusable(plan):
     return USE_GEMM_ROWS and plan.wgt_rows is not None and plan.K <= (128 if plan.code == BF16 else 64)
 
 
-def conv3_tiling(n, ho, wo, cin, cout, cc, cus=256):
+def conv3_tiling(n, ho, wo, cin, cout, cc, cus=256, stride=1):
     """Pick the 3x3 kernel / tile shape for one launch: 0 = the LDS-staged kernel (cobevt_conv3x3_nhwc), else the
     `variant` of cobevt_conv3x3_wfrag_nhwc (100 + 10*MT + bn64: MT strips of 2x16 pixels x 128|64 couts per workgroup).
     The LDS-staged kernel runs two workgroups per CU and wins once its grid is >= 2 per CU; below that the kernel time
     is whole workgroup lifetimes, so the strip count MT is chosen to make the grid a whole number of waves of `cus`
     workgroups (cycle model: 12k fixed + 40 cycles per MFMA-tile-step, both from the s_memtime traces)."""
-    if cout < 64:
-        return 0
-    th, bn = (16, 64) if cout <= 64 else (8, 128)
-    blocks_old = n * (-(-ho // th)) * (-(-wo // 16)) * (-(-cout // bn))
-    if blocks_old >= 2 * cus:
-        return 0
+    if stride == 1:
+        if cout < 64:
+            return 0
+        th, bn = (16, 64) if cout <= 64 else (8, 128)
+        blocks_old = n * (-(-ho // th)) * (-(-wo // 16)) * (-(-cout // bn))
+        if blocks_old >= 2 * cus:
+            return 0
     nstrips = n * (-(-ho // 2)) * (-(-wo // 16))
     nsteps = 9 * (cin // cc)
     best = None
@@ -294,7 +297,8 @@ def conv3_tiling(n, ho, wo, cin, cout, cc, cus=256):
         tile_n = 64 if bn64 else 128
         for mt in (3, 4, 5, 6):
             blocks = -(-nstrips // mt) * -(-cout // tile_n)
-            cost = -(-blocks // cus) * (12000 + nsteps * mt * (tile_n // 32) * 40)
+            cost = -(-blocks // cus) * (12000 + nsteps * mt * (tile_n // 32) * 40
+                                       + (1500 * mt * (cin // cc) if stride == 2 else 0))   # exposed patch refills
             if best is None or cost < best[0]:
                 best = (cost, 100 + 10 * mt + bn64)
     return best[1]
@@ -360,10 +364,14 @@ def conv2d(x, plan, residual=None, out=None):
         _L.check(rc, "cobevt_linear_rows")
         return out
     variant = 0
-    if plan.wfrag is not None and (out_h, out_w) == (ho, wo) and USE_CONV3X3 and USE_CONV3_WFRAG:
-        variant = CONV3_VARIANT or conv3_tiling(n, ho, wo, cin, plan.cout, plan.cc3)
+    if plan.wfrag is not None and (out_h, out_w) == (ho, wo) and USE_CONV3X3 and USE_CONV3_WFRAG \
+            and (plan.stride == 1 or USE_CONV3_S2):
+        variant = CONV3_VARIANT or conv3_tiling(n, ho, wo, cin, plan.cout, plan.cc3, stride=plan.stride)
+        if variant == 0 and plan.stride == 2:
+            variant = 151 if plan.cout <= 64 else 150
     if variant > 0:
-        dims = _ints([plan.code, n, h, w, cin, plan.cout, plan.upsample, plan.act, sm, plan.cc3, plan.coutp3, variant])
+        dims = _ints([plan.code, n, h, w, cin, plan.cout, plan.upsample, plan.act, sm, plan.cc3, plan.coutp3, variant,
+                      plan.stride])
         with _timed("conv3x3|%d->%d %dx%dx%d" % (cin, plan.cout, n, ho, wo), cost):
             rc = _L.load().cobevt_conv3x3_wfrag_nhwc(_p(x), _p(plan.wfrag), _p(plan.bias), _p(residual), _p(out), dims, _stream())
         _L.check(rc, "cobevt_conv3x3_wfrag_nhwc")

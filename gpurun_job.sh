@@ -1,1 +1,4 @@
-timeout 900 python bench.py > gpurun_out/bench21.log 2>&1; tail -1 gpurun_out/bench21.log
+for f in "USE_CONV3_S2=1" "USE_CONV3_S2=0" "USE_CONV3_S2=1" "USE_CONV3_S2=0"; do
+COBEVT_FLAGS=$f timeout 600 python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('$f', d['value'], d['ms_per_step'], d['one_frame_at_a_time']['ms_per_frame'])"
+done

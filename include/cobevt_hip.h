@@ -69,10 +69,11 @@ int cobevt_conv3x3_nhwc(const void* in, const void* wgt, const float* bias, cons
  * (cout % 32) holds bytes [32*kgroup + 16*half, +16) of that cout's 128-byte channel chunk and Cout_p >= Cout is the
  * zero-padded row count (multiple of 128): every weight operand is one coalesced 1-KB wave load from L2, LDS only holds
  * the input patch and there is one barrier per channel chunk instead of one per tap.  A workgroup owns MT strips of
- * 2 x 16 output pixels (numbered across image, row pair, column block) x 128 or 64 couts.  dims (int32[12]): dtype, N,
+ * 2 x 16 output pixels (numbered across image, row pair, column block) x 128 or 64 couts.  dims (int32[13]): dtype, N,
  * H, W, Cin, Cout, upsample, act, store_mode (0 NHWC, 1 PixelUnshuffle(2)), cc (bf16: 64, fp32: 32), Cout_p, variant =
  * 100 + 10*MT + (1 for 64-cout tiles), MT in 3..6 (0 = MT 5); the host picks MT so that the grid is a whole number of
- * workgroups per CU (cobevt_amd/ops.py conv3_tiling).  Needs N*H*W*Cin < 2^31.
+ * workgroups per CU (cobevt_amd/ops.py conv3_tiling); stride (1, or 2 = the first conv of a down-sampling BasicBlock:
+ * out (Ho, Wo) = ((H-1)/2+1, (W-1)/2+1), plain NHWC store, no up-sampling).  Needs N*H*W*Cin < 2^31.
  */
 int cobevt_conv3x3_wfrag_nhwc(const void* in, const void* wfrag, const float* bias, const void* residual, void* out,
                               const int* dims, hipStream_t stream);

@@ -117,6 +117,21 @@ def test_conv_3x3_s2_bn_residual_relu(cuda, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,n,h,w", [(64, 128, 3, 32, 32), (128, 256, 2, 17, 37), (256, 96, 1, 16, 16), (64, 64, 2, 9, 64)])
+def test_conv_3x3_s2_strip_kernel(cuda, dtype, cin, cout, n, h, w):
+    """stride-2 3x3 conv through the strip kernel (parity-split patch), ragged output maps, 1-4 channel chunks, both cout
+    tile widths; and the generic implicit GEMM on the same case"""
+    c1 = cin if dtype == torch.bfloat16 else cin // 2
+    assert ops.USE_CONV3_S2
+    _conv_case(cuda, dtype, "s2_%d_%d" % (cin, cout), n, c1, h, w, cout, 3, 2, 1, bias=False, bn=True, act=1, residual=True)
+    ops.USE_CONV3_S2 = False
+    try:
+        _conv_case(cuda, dtype, "s2g_%d_%d" % (cin, cout), n, c1, h, w, cout, 3, 2, 1, bias=False, bn=True, act=1)
+    finally:
+        ops.USE_CONV3_S2 = True
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_1x1_big_tile_gelu(cuda, dtype):
     # M = 32768, Cout = 256 -> 512 tiles of 128x128
     _conv_case(cuda, dtype, "c3", 8, 32, 64, 64, 256, 1, 1, 0, act=2)
