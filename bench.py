@@ -138,12 +138,12 @@ class PipelinedRunner(object):
         self.graphs = None
 
     def _s1(self, slot):
-        st = self.model.encode_trunk(dict(self.task_batch))
+        st = self.model.encode_trunk(dict(self.task_batch), kv_out=self.kv[slot])   # K/V land in the slot directly
         main = torch.cuda.current_stream()
         for level, lvl in enumerate(st["kv"]):
             main.wait_stream(st["side"][level])
             for k, v in lvl.items():
-                if torch.is_tensor(v):
+                if torch.is_tensor(v) and v.data_ptr() != self.kv[slot][level][k].data_ptr():
                     self.kv[slot][level][k].copy_(v)
         self.einv[slot].copy_(st["E_inv"])
 

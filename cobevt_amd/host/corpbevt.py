@@ -77,7 +77,7 @@ class CorpBEVT(HipModule):
 
     overlap_streams = True   # run each level's key/value path on a side HIP stream under the remaining encoder stages
 
-    def encode_trunk(self, batch_dict):
+    def encode_trunk(self, batch_dict, kv_out=None):
         """Stage 1 of the per-agent SinBEVT: the camera encoder and everything of the FAX pyramid that depends only on
         the images and the camera geometry (ray embedding, feature projections, K/V projections of both attentions of
         every level).  Returns the state `fax_query` needs: {"kv": [per-level dict], "E_inv", "batch"}.
@@ -105,7 +105,8 @@ class CorpBEVT(HipModule):
             s = side[level]
             s.wait_stream(main)
             with torch.cuda.stream(s):
-                kv[level] = fax.cross_views[level].prepare_kv(x, I_inv, E_inv, b * l)
+                kv[level] = fax.cross_views[level].prepare_kv(x, I_inv, E_inv, b * l,
+                                                              out=kv_out[level] if kv_out is not None else None)
             x.record_stream(s)
             for t in kv[level].values():
                 if torch.is_tensor(t):

@@ -145,12 +145,13 @@ class CrossWinAttention(HipModule):
     def add_rel_pos_emb(self, x):
         return x
 
-    def _project(self, name, seq, x):
-        return ops.linear(x, rt.linear_plan(self, name, seq[1], ln=seq[0]))
+    def _project(self, name, seq, x, out=None):
+        return ops.linear(x, rt.linear_plan(self, name, seq[1], ln=seq[0]), out=out)
 
-    def project_kv(self, k_src, v_src):
-        """LayerNorm + Linear of the key / value tokens (independent of the query -> can run ahead on a side stream)."""
-        return self._project("k", self.to_k, k_src), self._project("v", self.to_v, v_src)
+    def project_kv(self, k_src, v_src, out_k=None, out_v=None):
+        """LayerNorm + Linear of the key / value tokens (independent of the query -> can run ahead on a side stream).
+        out_k / out_v: optional preallocated result buffers (a pipelined caller keeps them across steps)."""
+        return self._project("k", self.to_k, k_src, out_k), self._project("v", self.to_v, v_src, out_v)
 
     def q_plan(self):
         """LayerNorm + Linear of the query as a plan (so the producer of the query rows can compute it in its launch)."""
@@ -244,7 +245,7 @@ class CrossViewSwapAttention(HipModule):
                                   rt.linear_plan(self, name + ".0", mlp[0], act=2, ln=prenorm),
                                   rt.linear_plan(self, name + ".2", mlp[2]), post, next_plan=next_plan)
 
-    def prepare_kv(self, feature, I_inv, E_inv, batch):
+    def prepare_kv(self, feature, I_inv, E_inv, batch, out=None):
         """Everything that depends only on the image features and camera geometry (fax_modules.py:346-358,377-396 and
         the to_k / to_v projections of both attentions): ray embedding, key / value 1x1 projections, zero padding to
         the window grid, LayerNorm + Linear of K and V.  Independent of the BEV query, so FAXModule may run it ahead
@@ -273,8 +274,9 @@ class CrossViewSwapAttention(HipModule):
             key = img
         val = ops.conv2d(feature, rt.conv_plan(self, "flin", self.feature_linear[2], pre_bn=self.feature_linear[0]),
                          out=kv_buffer())
-        k1, v1 = self.cross_win_attend_1.project_kv(key, val)
-        k2, v2 = self.cross_win_attend_2.project_kv(key, val)
+        o = out if out is not None else {}      # optional preallocated {"k1","v1","k2","v2"} buffers
+        k1, v1 = self.cross_win_attend_1.project_kv(key, val, o.get("k1"), o.get("v1"))
+        k2, v2 = self.cross_win_attend_2.project_kv(key, val, o.get("k2"), o.get("v2"))
         return {"n": n, "hp": hp, "wp": wp, "k1": k1, "v1": v1, "k2": k2, "v2": v2}
 
     def forward_query(self, index, x, bev, E_inv, kv, next_plan=None):

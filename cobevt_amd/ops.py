@@ -417,15 +417,21 @@ def basicblock(x, plan1, plan2):
     return out
 
 
-def linear(x, plan, residual=None):
+def linear(x, plan, residual=None, out=None):
     """x: (..., K) contiguous tokens -> (..., Cout).  A Linear is the 1x1 case of the implicit GEMM; plans built
-    with ln=... apply LayerNorm(x) first (fused into the GEMM when the row fits one K-tile)."""
+    with ln=... apply LayerNorm(x) first (fused into the GEMM when the row fits one K-tile).  out: optional
+    preallocated contiguous (..., Cout) result buffer in the compute dtype."""
     lead = x.shape[:-1]
     rows = int(math.prod(lead)) if len(lead) else 1
     x4 = x.reshape(1, 1, rows, x.shape[-1])
     r4 = residual.reshape(1, 1, rows, plan.cout) if residual is not None else None
-    y = conv2d(x4, plan, residual=r4)
-    return y.reshape(*lead, plan.cout)
+    o4 = None
+    if out is not None:
+        if tuple(out.shape) != tuple(lead) + (plan.cout,) or not out.is_contiguous() or out.dtype != x.dtype:
+            raise CobevtHipError("linear: `out` must be a contiguous %s tensor of dtype %s" % (tuple(lead) + (plan.cout,), x.dtype))
+        o4 = out.reshape(1, 1, rows, plan.cout)
+    y = conv2d(x4, plan, residual=r4, out=o4)
+    return out if out is not None else y.reshape(*lead, plan.cout)
 
 
 # ----------------------------------------------------------------------------------------------
