@@ -304,6 +304,225 @@ __global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Version 2 (cobevt_linear_rows_wfrag): persistent workgroups, fragment-ordered weights.
+//
+// Every Linear / 1x1 conv of the hot path is HBM-bound (K <= 512, arithmetic intensity 64-128 FLOP/B) and the kernel above
+// reached 1.6-2.7 TB/s of the ~6.3 achievable: a workgroup requests its 128 x K tile, waits, computes, stages, stores
+// - the memory pipe only carries requests during the first of those phases - and re-reads its 32-KB weight tile from L2
+// into LDS every time.  Here
+//   * a workgroup is persistent over row tiles of ONE 128-column tile: with K <= one K-tile its weight fragments
+//     (MFMA fragment order, one coalesced 1-KB wave load per k-group, as in row_chain.hip) are loaded once and stay in
+//     registers; no weight bytes pass through LDS at all;
+//   * the A rows of the NEXT tile are requested right after this tile's rows are handed to LDS, so loads are in flight
+//     under the MFMAs, the epilogue and the stores of the current tile;
+//   * D = W . X^T: a lane owns one row and runs of four output columns -> bias / residual / activation in registers, the
+//     result is staged in the STORAGE type (8-byte LDS writes, half the staging bytes) for 16-byte coalesced stores.
+// Same options as above (fused LayerNorm with folded affine, pre-activation affine + ReLU, residual, padded-map row
+// remap, strided row gather).  8 waves = 2 row halves (two 32-row MFMA tiles each) x 4 column tiles of 32.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kGrThreads, 2) void gemm_rows2_kernel(GemmRowsParams p) {
+    constexpr int CH = Elem<T>::kChunk;
+    constexpr int EB = Elem<T>::kBytes;
+    constexpr int TK = 256 / EB;                      // elements per K-tile
+    constexpr int CROW = 128 * EB + 16;               // staging row (storage type)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;
+    unsigned char* Cs = smem + kGrTile * kGrRow;
+
+    const int ntn = (p.N + 127) / 128, ntm = (p.M + 127) / 128;
+    const int tn = blockIdx.x % ntn, tm_first = blockIdx.x / ntn, tm_step = gridDim.x / ntn;
+    const int n0 = tn * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, ql = lane & 31;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int srow = tid >> 2, sub = tid & 3;         // staging: row of the tile, 64-byte quarter of the 256-byte row
+    const T* in = (const T*)p.in;
+    const int nkt = p.Kp / TK;
+    const int nkg = p.Kp * EB / 32;                   // k-groups per weight row
+    const uint4* wq = (const uint4*)p.wgt + (size_t)(n0 / 32 + wn) * nkg * 64 + lane;
+
+    uint4 bfrag[8];
+    auto load_b = [&](int kt) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) bfrag[g] = wq[(size_t)(kt * 8 + g) * 64];
+    };
+    uint4 areg[4];
+    auto row_ptr = [&](int tm) {                      // this thread's A row of tile tm (row 0 when past M)
+        size_t idx = (size_t)tm * 128 + srow;
+        if (idx >= (size_t)p.M) idx = 0;
+        if (p.in_stride > 1) {
+            const int hw = p.src_H * p.src_W;
+            const int n = (int)(idx / hw), rem = (int)(idx - (size_t)n * hw);
+            const int oy = rem / p.src_W, ox = rem - oy * p.src_W;
+            idx = ((size_t)n * p.in_H + (size_t)oy * p.in_stride) * p.in_W + (size_t)ox * p.in_stride;
+        }
+        return in + idx * p.lda;
+    };
+    auto load_a = [&](const T* arow, bool ok, int kt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = kt * TK + (sub * 4 + j) * CH;
+            areg[j] = (ok && k < p.K) ? *(const uint4*)(arow + k) : make_uint4(0, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);            // keep the prefetch here (LLVM sinks loads to their first use)
+    };
+    auto transform_a = [&](int kt) {
+        if (p.ln) {
+            float v[4][8];
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                chunk_to_f32<T>(areg[j], v[j]);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) s += v[j][e];
+            }
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            const float mean = s / (float)p.K;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    const int k = (sub * 4 + j) * CH + e;
+                    const float d = k < p.K ? v[j][e] - mean : 0.f;
+                    q += d * d;
+                }
+            q += __shfl_xor(q, 1, 64);
+            q += __shfl_xor(q, 2, 64);
+            const float rstd = rsqrtf(q / (float)p.K + p.ln_eps);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    const int k = (sub * 4 + j) * CH + e;
+                    v[j][e] = k < p.K ? (v[j][e] - mean) * rstd : 0.f;
+                }
+                areg[j] = f32_to_chunk<T>(v[j]);
+            }
+        } else if (p.pre_scale) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k0 = kt * TK + (sub * 4 + j) * CH;
+                if (k0 >= p.K) { areg[j] = make_uint4(0, 0, 0, 0); continue; }
+                float v[8], sc[8], sh[8];
+                chunk_to_f32<T>(areg[j], v);
+#pragma unroll
+                for (int q = 0; q < CH / 4; ++q) {
+                    const float4 a = *(const float4*)(p.pre_scale + k0 + 4 * q), c = *(const float4*)(p.pre_shift + k0 + 4 * q);
+                    sc[4 * q] = a.x; sc[4 * q + 1] = a.y; sc[4 * q + 2] = a.z; sc[4 * q + 3] = a.w;
+                    sh[4 * q] = c.x; sh[4 * q + 1] = c.y; sh[4 * q + 2] = c.z; sh[4 * q + 3] = c.w;
+                }
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    const float x = v[e] * sc[e] + sh[e];
+                    v[e] = p.pre_relu ? fmaxf(x, 0.f) : x;
+                }
+                areg[j] = f32_to_chunk<T>(v);
+            }
+        }
+    };
+
+    if (tm_first >= ntm) return;
+    const bool resident_b = nkt == 1;
+    if (resident_b) load_b(0);
+    const T* arow = row_ptr(tm_first);
+    bool a_ok = (size_t)tm_first * 128 + srow < (size_t)p.M;
+    load_a(arow, a_ok, 0);
+    const int c0w = wn * 32 + 4 * h;                  // this lane's first column of the 128-column tile
+    const bool remap = p.out_H != p.src_H || p.out_W != p.src_W;
+    T* out = (T*)p.out;
+
+    for (int tm = tm_first; tm < ntm; tm += tm_step) {
+        const int m0 = tm * 128;
+        f32x16 acc[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+        for (int kt = 0; kt < nkt; ++kt) {
+            transform_a(kt);
+            if (kt > 0) __syncthreads();              // the previous K-tile is consumed
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(uint4*)(As + srow * kGrRow + (sub * 4 + j) * 16) = areg[j];
+            if (!resident_b) load_b(kt);
+            __syncthreads();
+            // next A rows: the following K-tile of this tile, or the first K-tile of the workgroup's next row tile
+            if (kt + 1 < nkt) load_a(arow, a_ok, kt + 1);
+            else if (tm + tm_step < ntm) {
+                arow = row_ptr(tm + tm_step);
+                a_ok = (size_t)(tm + tm_step) * 128 + srow < (size_t)p.M;
+                load_a(arow, a_ok, 0);
+            }
+            const int kleft = p.K - kt * TK;
+            const int ng = kleft >= TK ? 8 : (kleft * EB + 31) / 32;
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                if (g < ng) {
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {
+                        const uint4 af = *(const uint4*)(As + (wm * 64 + rt * 32 + ql) * kGrRow + h * 16 + g * 32);
+                        mfma_kgroup<T>(bfrag[g], af, acc[rt]);     // D = W . X^T : lane <-> row, registers <-> columns
+                    }
+                }
+        }
+        // ---- epilogue in registers, staged in the storage type
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int row = wm * 64 + rt * 32 + ql;
+            const int m = m0 + row;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int col = n0 + c0w + 8 * k;
+                float v[4] = {acc[rt][4 * k], acc[rt][4 * k + 1], acc[rt][4 * k + 2], acc[rt][4 * k + 3]};
+                if (col < p.N) {
+                    if (p.bias) {
+                        const float4 b = *(const float4*)(p.bias + col);
+                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    }
+                    if (p.residual && m < p.M) {
+                        const T* r = (const T*)p.residual + (size_t)m * p.N + col;
+                        if constexpr (Elem<T>::kIsBf16) {
+                            const uint2 u = *(const uint2*)r;
+                            v[0] += bf2f(u.x & 0xffff); v[1] += bf2f(u.x >> 16); v[2] += bf2f(u.y & 0xffff); v[3] += bf2f(u.y >> 16);
+                        } else {
+                            const float4 u = *(const float4*)r;
+                            v[0] += u.x; v[1] += u.y; v[2] += u.z; v[3] += u.w;
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = p.act == 1 ? fmaxf(v[e], 0.f) : (p.act == 2 ? gelu_erf(v[e]) : v[e]);
+                }
+                unsigned char* d = Cs + row * CROW + (c0w + 8 * k) * EB;
+                if constexpr (Elem<T>::kIsBf16) *(uint2*)d = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                else *(float4*)d = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = 128 / CH;                 // 16-byte chunks per tile row
+        constexpr int NIT = 128 * CPR / kGrThreads;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int item = tid + i * kGrThreads;
+            const int row = item / CPR, cj = item - row * CPR;
+            const int m = m0 + row, col = n0 + cj * CH;
+            if (m >= p.M || col >= p.N) continue;
+            size_t orow = (size_t)m;
+            if (remap) {
+                const int hw = p.src_H * p.src_W;
+                const int n = m / hw, rem = m - n * hw;
+                const int oh = rem / p.src_W, ow = rem - oh * p.src_W;
+                orow = ((size_t)n * p.out_H + oh) * p.out_W + ow;
+            }
+            *(uint4*)(out + orow * p.N + col) = *(const uint4*)(Cs + row * CROW + cj * 16);
+        }
+        // the next iteration's Cs writes come after its own barrier; its As writes after this tile's MFMA reads (barrier above)
+    }
+}
+
 }  // namespace cobevt
 
 using namespace cobevt;
@@ -386,5 +605,52 @@ extern "C" int cobevt_bev_embed_linear_rows(const float* E_inv, const float* wor
     }
     if (dtype == 0) hipLaunchKernelGGL((gemm_rows_kernel<bf16_t, true>), dim3((unsigned)blocks), dim3(kGrThreads), kGrLds, stream, p);
     else hipLaunchKernelGGL((gemm_rows_kernel<float, true>), dim3((unsigned)blocks), dim3(kGrThreads), kGrLds, stream, p);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// C-ABI entry point, see include/cobevt_hip.h
+extern "C" int cobevt_linear_rows_wfrag(const void* in, const void* wfrag, const float* bias, const void* residual,
+                                        const float* pre_scale, const float* pre_shift, void* out, const long* dims,
+                                        float ln_eps, hipStream_t stream) {
+    // dims: as cobevt_linear_rows [dtype, M, N, K, Kp, lda, pre_relu, act, src_H, src_W, out_H, out_W, ln, in_stride, in_H, in_W]
+    if (!in || !wfrag || !out || !dims) return COBEVT_ERR_ARG;
+    GemmRowsParams p;
+    const int dtype = (int)dims[0];
+    p.in = in; p.wgt = wfrag; p.bias = bias; p.residual = residual;
+    p.ln_gamma = p.ln_beta = nullptr; p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.out = out;
+    p.M = (int)dims[1]; p.N = (int)dims[2]; p.K = (int)dims[3]; p.Kp = (int)dims[4]; p.lda = dims[5];
+    p.pre_relu = (int)dims[6]; p.act = (int)dims[7];
+    p.src_H = (int)dims[8]; p.src_W = (int)dims[9]; p.out_H = (int)dims[10]; p.out_W = (int)dims[11];
+    p.ln_eps = ln_eps;
+    p.ln = (int)dims[12];
+    p.in_stride = (int)dims[13]; p.in_H = (int)dims[14]; p.in_W = (int)dims[15];
+    p.emb_world = p.emb_wbev = p.emb_bbev = p.emb_wcam = p.emb_E = nullptr;
+    p.emb_n = p.emb_hw = 1;
+    if (dtype != 0 && dtype != 1) return COBEVT_ERR_ARG;
+    const int tk = dtype == 0 ? 128 : 64, ch = dtype == 0 ? 8 : 4;
+    if (p.M < 1 || p.N < 1 || p.K < 1 || p.Kp % tk != 0 || p.Kp < p.K) return COBEVT_ERR_SHAPE;
+    if (p.K % ch != 0 || p.N % ch != 0 || p.lda % ch != 0 || p.lda < p.K) return COBEVT_ERR_SHAPE;
+    if (p.ln && p.K > tk) return COBEVT_ERR_UNSUPPORTED;
+    if (p.ln && pre_scale) return COBEVT_ERR_UNSUPPORTED;
+    if ((pre_scale == nullptr) != (pre_shift == nullptr)) return COBEVT_ERR_ARG;
+    if (p.residual && (p.out_H != p.src_H || p.out_W != p.src_W)) return COBEVT_ERR_UNSUPPORTED;
+    if (p.in_stride < 1) return COBEVT_ERR_ARG;
+    if (p.in_stride > 1 && ((p.src_H - 1) * p.in_stride >= p.in_H || (p.src_W - 1) * p.in_stride >= p.in_W ||
+                            p.M % ((long)p.src_H * p.src_W) != 0)) return COBEVT_ERR_SHAPE;
+    const long ntn = (p.N + 127) / 128, ntm = (p.M + 127) / 128;
+    long per_col = 256 / ntn;                                   // one 8-wave workgroup per CU (196 VGPRs), persistent over row tiles
+    if (per_col < 1) per_col = 1;
+    if (per_col > ntm) per_col = ntm;
+    const long blocks = ntn * per_col;
+    if (blocks > 0x7fffffffL) return COBEVT_ERR_SHAPE;
+    const size_t lds = (size_t)kGrTile * kGrRow + (size_t)128 * (128 * (dtype == 0 ? 2 : 4) + 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_rows2_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 34816 + 34816);
+        (void)hipFuncSetAttribute((const void*)gemm_rows2_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 34816 + 67584);
+        attr_set = true;
+    }
+    if (dtype == 0) hipLaunchKernelGGL(gemm_rows2_kernel<bf16_t>, dim3((unsigned)blocks), dim3(kGrThreads), lds, stream, p);
+    else hipLaunchKernelGGL(gemm_rows2_kernel<float>, dim3((unsigned)blocks), dim3(kGrThreads), lds, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

@@ -26,6 +26,7 @@ SIGNATURES = {
     "cobevt_stem_conv7x7s2_pool": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_stem_conv7x7s2": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_bev_embed_linear_rows": (ctypes.c_int, [_vp] * 9 + [_c_long_p, ctypes.c_float, _vp]),
+    "cobevt_linear_rows_wfrag": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_long_p, ctypes.c_float, _vp]),
     "cobevt_linear_rows": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_long_p, ctypes.c_float, _vp]),
     "cobevt_attn_mlp_chain": (ctypes.c_int, [_vp] * 14 + [_c_int_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
     "cobevt_window_attention": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int_p, ctypes.c_float, _vp]),

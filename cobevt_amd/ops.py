@@ -19,6 +19,9 @@ USE_CONV3_S2 = True      # 3x3 / stride-2 convs through the strip kernel instead
 USE_CONV3_WFRAG = True   # ... and, where the fragment-ordered weight table exists, to the barrier-free-per-tap variant
 CONV3_VARIANT = 0    # 0 = automatic tile choice of cobevt_conv3x3_wfrag_nhwc; >0 pins one (tools/conv_probe.py)
 USE_GEMM_ROWS = True  # route 1x1 stride-1 convs / linears to the dense-row GEMM with fused LayerNorm
+USE_GEMM_ROWS2 = False  # dense-row GEMMs through the persistent fragment-ordered kernel (cobevt_linear_rows_wfrag):
+# measured 3-20 % SLOWER than two independent workgroups per CU (196 VGPRs -> one workgroup per CU, only one 32-KB tile
+# of loads in flight per CU: latency-bound on HBM); kept for the parity tests and as the base for a deeper prefetch
 USE_STEM_POOL = True  # stem conv + max pool in one launch (the stem map never reaches HBM)
 USE_STEM = True       # 7x7/s2 image stem through the space-to-depth kernel instead of the generic small-Cin igemm
 ROW_CHAIN_ROWS = 0     # rows per workgroup of the fused row chain: 0 = default (32), 64
@@ -255,12 +258,12 @@ class ConvPlan(object):
             self.kp_rows = kp
             # the same matrix in MFMA fragment order for the fused row chain (row_chain.hip):
             # [N_p/32 tiles][kp/16 k-groups][lane = 32*half + n%32][8 bf16], N zero-padded to a multiple of 128
-            if self.code == BF16 and kp <= 256:
-                npad = (cout + 127) // 128 * 128
-                wp_ = torch.zeros(npad, kp, dtype=torch.float64)
-                wp_[:cout] = wr
-                wf = wp_.reshape(npad // 32, 32, kp // 16, 2, 8).permute(0, 2, 3, 1, 4)
-                self.wfrag_rows = wf.to(torch.float32).to(dtype).to(device).contiguous()
+            eg = 8 if self.code == BF16 else 4          # elements per 16 bytes
+            npad = (cout + 127) // 128 * 128
+            wp_ = torch.zeros(npad, kp, dtype=torch.float64)
+            wp_[:cout] = wr
+            wf = wp_.reshape(npad // 32, 32, kp // (2 * eg), 2, eg).permute(0, 2, 3, 1, 4)
+            self.wfrag_rows = wf.to(torch.float32).to(dtype).to(device).contiguous()
         self.cin, self.cout, self.kh, self.kw = cin, cout, kh, kw
         self.K, self.kpad = K, kpad
         self.stride, self.pad, self.act = int(stride), int(pad), int(act)
@@ -356,12 +359,18 @@ def conv2d(x, plan, residual=None, out=None):
     if plan.wgt_rows is not None and USE_GEMM_ROWS and not (residual is not None and (out_h, out_w) != (ho, wo)):
         ldims = (ctypes.c_long * 16)(plan.code, n * ho * wo, plan.cout, plan.K, plan.kp_rows, cin, plan.pre_relu, plan.act,
                                      ho, wo, out_h, out_w, int(ln), plan.stride, h, w)
+        v2 = USE_GEMM_ROWS2 and plan.wfrag_rows is not None and plan.cout % (8 if plan.code == BF16 else 4) == 0
         with _timed("gemm_rows|%d->%d M=%d%s%s" % (cin, plan.cout, n * ho * wo, " ln" if ln else "",
                                                    " s%d" % plan.stride if plan.stride > 1 else ""), cost):
-            rc = _L.load().cobevt_linear_rows(_p(x), _p(plan.wgt_rows), _p(plan.bias), _p(residual), None, None,
-                                              _p(plan.pre_scale), _p(plan.pre_shift), _p(out), ldims,
-                                              ctypes.c_float(plan.ln_eps), _stream())
-        _L.check(rc, "cobevt_linear_rows")
+            if v2:      # persistent workgroups, fragment-ordered weights
+                rc = _L.load().cobevt_linear_rows_wfrag(_p(x), _p(plan.wfrag_rows), _p(plan.bias), _p(residual),
+                                                        _p(plan.pre_scale), _p(plan.pre_shift), _p(out), ldims,
+                                                        ctypes.c_float(plan.ln_eps), _stream())
+            else:
+                rc = _L.load().cobevt_linear_rows(_p(x), _p(plan.wgt_rows), _p(plan.bias), _p(residual), None, None,
+                                                  _p(plan.pre_scale), _p(plan.pre_shift), _p(out), ldims,
+                                                  ctypes.c_float(plan.ln_eps), _stream())
+        _L.check(rc, "cobevt_linear_rows_wfrag" if v2 else "cobevt_linear_rows")
         return out
     variant = 0
     if plan.wfrag is not None and (out_h, out_w) == (ho, wo) and USE_CONV3X3 and USE_CONV3_WFRAG \
@@ -691,7 +700,7 @@ def attn_mlp_chain(a, skip, plan_p, plan_1, plan_2, post_ln=None, next_plan=None
     _need_cuda(a, skip)
     c, hd = plan_p.cout, plan_1.cout
     fusable = (USE_ROW_CHAIN and a.dtype == torch.bfloat16 and plan_p.wfrag_rows is not None and plan_1.wfrag_rows is not None
-               and plan_2.wfrag_rows is not None and plan_1.has_ln and plan_1.act == 2 and plan_p.act == 0
+               and plan_2.wfrag_rows is not None and plan_2.kp_rows <= 256 and plan_1.has_ln and plan_1.act == 2 and plan_p.act == 0
                and plan_2.act == 0 and not plan_p.has_ln and not plan_2.has_ln and plan_p.K == c and plan_1.K == c
                and plan_2.K == hd and plan_2.cout == c and c <= 128 and c % 8 == 0 and hd <= 256 and hd % 8 == 0
                and plan_p.kp_rows == 128 and plan_1.kp_rows == 128 and a.shape[-1] == c and a.is_contiguous()

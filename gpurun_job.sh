@@ -1,5 +1,1 @@
-timeout 900 python -m pytest tests/test_modules_gpu.py -x -q -m gpu 2>&1 | tail -2
-for i in 1 2; do
-timeout 600 python bench.py --no-cpu-baseline --no-roofline 2>&1 | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['one_frame_at_a_time']['ms_per_frame'])"
-done
+timeout 300 python tools/gemm_probe.py 2>&1 | grep -v amdgpu.ids

@@ -124,6 +124,18 @@ int cobevt_linear_rows(const void* in, const void* wgt, const float* bias, const
                        float ln_eps, hipStream_t stream);
 
 /*
+ * The same dense-row GEMM (same reference call sites and dims as cobevt_linear_rows) with the weights in MFMA fragment
+ * order - rows zero-padded to a multiple of 128, [rows/32][Kp*esz/32 k-groups][64 lanes][16 bytes], lane = 32*half +
+ * row%32 holding bytes [32*kgroup + 16*half, +16) of its row - and persistent workgroups: a workgroup walks the row tiles
+ * of one 128-column tile with its weight fragments resident in registers (K <= one K-tile) and the next tile's rows in
+ * flight under the current tile's MFMAs, epilogue and stores.  N % (8 bf16 | 4 fp32) == 0.  No ln_gamma / ln_beta
+ * (the LayerNorm affine is folded into the weights by the host).
+ */
+int cobevt_linear_rows_wfrag(const void* in, const void* wfrag, const float* bias, const void* residual,
+                             const float* pre_scale, const float* pre_shift, void* out, const long* dims, float ln_eps,
+                             hipStream_t stream);
+
+/*
  * Fused row-local chain after an attention (bf16 mode):  y = a.Wp^T (+bp) + skip ;  z = y + fc2(GELU(fc1'(norm(y)))) ;
  * out = post-LayerNorm(z) (optional) ;  out_next = act(norm?(out).Wn'^T + bn') (optional).  Replaces
  * fax_modules.py:240,246-247 + :411 / :435-437 and swap_fusion_modules.py:126,177 + base_transformer.py:102-124 in one

@@ -318,6 +318,31 @@ def test_conv3x3_matches_generic_igemm(cuda, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k,n,rows,ln,res", [(128, 128, 1000, True, False), (128, 384, 130, True, True), (32, 128, 257, False, True),
+                                             (256, 128, 300, False, False), (64, 96, 3000, True, False)])
+def test_gemm_rows_persistent_wfrag(cuda, dtype, k, n, rows, ln, res):
+    """cobevt_linear_rows_wfrag (persistent workgroups, fragment-ordered weights) == cobevt_linear_rows on the same plan"""
+    if ln and dtype == torch.float32 and k > 64:
+        k = 64
+    x = procedural_input("g2.x", (rows, k), 0).to(cuda).to(dtype)
+    w = procedural_input("g2.w", (n, k), 0) * math.sqrt(3.0 / k)
+    b = procedural_input("g2.b", (n,), 0, -0.2, 0.2)
+
+    class LN(object):
+        weight, bias, eps = 0.8 + 0.4 * procedural_input("g2.g", (k,), 0, 0, 1), procedural_input("g2.be", (k,), 0, -0.2, 0.2), 1e-5
+    plan = ops.ConvPlan(w, b, act=2, dtype=dtype, device=cuda, ln=LN if ln else None)
+    r = procedural_input("g2.r", (rows, n), 0).to(cuda).to(dtype) if res else None
+    y1 = ops.linear(x, plan, residual=r)
+    ops.USE_GEMM_ROWS2 = True
+    try:
+        y2 = ops.linear(x, plan, residual=r)
+    finally:
+        ops.USE_GEMM_ROWS2 = False
+    s = y1.float().abs().max().item()
+    assert (y1.float() - y2.float()).abs().max().item() <= (1e-2 if dtype == torch.bfloat16 else 1e-5) * s
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_linear_ragged_rows(cuda, dtype):
     x = procedural_input("l1.x", (3, 100, 128), 0)
     w = procedural_input("l1.w", (384, 128), 0) * math.sqrt(3.0 / 128)
