@@ -157,15 +157,17 @@ class CrossWinAttention(HipModule):
         """LayerNorm + Linear of the query as a plan (so the producer of the query rows can compute it in its launch)."""
         return rt.linear_plan(self, "q", self.to_q[1], ln=self.to_q[0])
 
-    def attend_projected(self, q_src, kt, vt, qmap, kmap, omap, batch, out_shape, qt=None):
+    def attend_projected(self, q_src, kt, vt, qmap, kmap, omap, batch, out_shape, qt=None, ldkv=None, kvoff=0):
         """Query projection (unless `qt` already holds it) + fused window attention on already projected keys / values;
-        returns the head-merged attention output BEFORE self.proj."""
+        returns the head-merged attention output BEFORE self.proj.  ldkv / kvoff: row stride and column offset of this
+        attention's keys / values when kt / vt hold the projections of several attentions side by side."""
         inner = self.heads * self.dim_head
         if qt is None:
             qt = self._project("q", self.to_q, q_src)
+        ld = inner if ldkv is None else ldkv
         a = torch.empty(tuple(out_shape) + (inner,), device=qt.device, dtype=qt.dtype)
-        ops.window_attention(qt, kt, vt, a, qmap, kmap, omap, batch, self.heads, self.scale, inner, inner, inner, inner,
-                             mean_q=qmap[1] > 1)
+        ops.window_attention(qt, kt, vt, a, qmap, kmap, omap, batch, self.heads, self.scale, inner, ld, ld, inner,
+                             koff=kvoff, voff=kvoff, mean_q=qmap[1] > 1)
         return a
 
     def attend_core(self, q_src, k_src, v_src, qmap, kmap, omap, batch, out_shape):
@@ -274,10 +276,29 @@ class CrossViewSwapAttention(HipModule):
             key = img
         val = ops.conv2d(feature, rt.conv_plan(self, "flin", self.feature_linear[2], pre_bn=self.feature_linear[0]),
                          out=kv_buffer())
-        o = out if out is not None else {}      # optional preallocated {"k1","v1","k2","v2"} buffers
-        k1, v1 = self.cross_win_attend_1.project_kv(key, val, o.get("k1"), o.get("v1"))
-        k2, v2 = self.cross_win_attend_2.project_kv(key, val, o.get("k2"), o.get("v2"))
-        return {"n": n, "hp": hp, "wp": wp, "k1": k1, "v1": v1, "k2": k2, "v2": v2}
+        o = out if out is not None else {}      # optional preallocated {"kk", "vv"} buffers
+        # to_k of both attentions read the same `key` rows (to_v: `val`): one GEMM each with the two weight matrices
+        # stacked (each LayerNorm's affine folded into its half; the normalisation itself is shared) -> (.., 2*inner);
+        # attention #1 reads columns [0, inner), attention #2 columns [inner, 2*inner) through its row stride
+        kk = ops.linear(key, self._pair_plan("k"), out=o.get("kk"))
+        vv = ops.linear(val, self._pair_plan("v"), out=o.get("vv"))
+        return {"n": n, "hp": hp, "wp": wp, "kk": kk, "vv": vv}
+
+    def _pair_plan(self, which):
+        a1, a2 = getattr(self.cross_win_attend_1, "to_" + which), getattr(self.cross_win_attend_2, "to_" + which)
+        if a1[0].eps != a2[0].eps:
+            raise CobevtHipError("the two cross attentions normalise their keys / values with different eps")
+
+        def build(dt, dev):
+            ws, bs = [], []
+            for ln, lin in ((a1[0], a1[1]), (a2[0], a2[1])):
+                w = lin.weight.detach().double().cpu()
+                b = lin.bias.detach().double().cpu() if lin.bias is not None else torch.zeros(w.shape[0], dtype=torch.float64)
+                g, be = ln.weight.detach().double().cpu(), ln.bias.detach().double().cpu()
+                bs.append(b + w @ be)
+                ws.append(w * g[None, :])
+            return ops.ConvPlan(torch.cat(ws), torch.cat(bs), dtype=dt, device=dev, ln_folded_eps=a1[0].eps)
+        return self._plan("pair_" + which, rt.module_tensors(a1[0], a1[1], a2[0], a2[1]), build)
 
     def forward_query(self, index, x, bev, E_inv, kv, next_plan=None):
         """The query side of fax_modules.py:360-441 given prepare_kv()'s result.  x (b,H,W,d) -> (b,H,W,d).
@@ -306,11 +327,14 @@ class CrossViewSwapAttention(HipModule):
         if qmap_1[6] * qmap_1[7] != kwin[6] * kwin[7]:
             raise CobevtHipError("query windows %dx%d != key windows %dx%d" % (qmap_1[6], qmap_1[7], kwin[6], kwin[7]))
         # local-to-local: window queries x window keys; per-camera queries are averaged in-kernel
-        a = self.cross_win_attend_1.attend_projected(query, kv["k1"], kv["v1"], qmap_n, kwin, qmap_1, b, (b, H, W), qt=q1)
+        inner = self.cross_win_attend_1.heads * self.cross_win_attend_1.dim_head
+        a = self.cross_win_attend_1.attend_projected(query, kv["kk"], kv["vv"], qmap_n, kwin, qmap_1, b, (b, H, W), qt=q1,
+                                                     ldkv=2 * inner, kvoff=0)
         y, q2 = self._proj_mlp("mlp1", self.cross_win_attend_1, a, x if self.skip else None, self.prenorm_1, self.mlp_1,
                                next_plan=self.cross_win_attend_2.q_plan())
         # local-to-global: the n query replicas of the reference are identical -> one copy
-        a = self.cross_win_attend_2.attend_projected(y, kv["k2"], kv["v2"], qmap_1, kgrid, qmap_1, b, (b, H, W), qt=q2)
+        a = self.cross_win_attend_2.attend_projected(y, kv["kk"], kv["vv"], qmap_1, kgrid, qmap_1, b, (b, H, W), qt=q2,
+                                                     ldkv=2 * inner, kvoff=inner)
         return self._proj_mlp("mlp2", self.cross_win_attend_2, a, y if self.skip else None, self.prenorm_2, self.mlp_2,
                               self.postnorm, next_plan=next_plan)
 

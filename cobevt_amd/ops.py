@@ -160,7 +160,8 @@ class ConvPlan(object):
     """A conv / linear layer lowered to the implicit-GEMM kernel: folded, re-laid-out weights + static params."""
 
     def __init__(self, weight, bias=None, bn=None, pre_bn=None, pre_relu=False, stride=1, pad=0, act=0,
-                 upsample=False, store_mode=0, dtype=torch.bfloat16, device="cuda", smallc=False, ln=None):
+                 upsample=False, store_mode=0, dtype=torch.bfloat16, device="cuda", smallc=False, ln=None,
+                 ln_folded_eps=None):
         """ln = nn.LayerNorm-like (weight, bias, eps) applied to the input rows of a Linear / 1x1 layer: its affine
         is folded here (W' = W diag(gamma), b' = b + W beta) so the kernels only have to normalise."""
         w = weight.detach().double().cpu()
@@ -170,6 +171,10 @@ class ConvPlan(object):
         b = bias.detach().double().cpu() if bias is not None else torch.zeros(cout, dtype=torch.float64)
         has_bias = bias is not None or bn is not None
         self.has_ln, self.ln_eps = False, 0.0
+        if ln_folded_eps is not None:        # the caller already folded a LayerNorm affine into weight / bias: normalise only
+            if ln is not None or kh != 1 or kw != 1 or bn is not None or pre_bn is not None:
+                raise CobevtHipError("ln_folded_eps applies to plain Linear / 1x1 layers without another ln")
+            self.has_ln, self.ln_eps = True, float(ln_folded_eps)
         if ln is not None:
             if kh != 1 or kw != 1 or bn is not None or pre_bn is not None:
                 raise CobevtHipError("LayerNorm folding applies to plain Linear / 1x1 layers")
