@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--agents", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
-    ap.add_argument("--frames-in-flight", type=int, default=3, choices=[1, 3],
+    ap.add_argument("--frames-in-flight", type=int, default=3, choices=[1, 3, 4],
                     help="single-GPU software pipeline: 3 = encoder / FAX query / fusion+decoder of three consecutive frames "
                          "overlap on three HIP streams (throughput mode, default); 1 = one frame at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -109,33 +109,41 @@ class Runner(object):
 
 
 class PipelinedRunner(object):
-    """Three frames in flight on ONE GPU.  A CoBEVT frame is ~1.4 ms of camera encoder that fills the chip followed by
+    """Several frames in flight on ONE GPU.  A CoBEVT frame is ~1.3 ms of camera encoder that fills the chip followed by
     ~1.4 ms of FAX query path, swap fusion and decoder whose ~100 dependent launches are latency-bound and leave most CUs
-    idle.  Step i therefore runs, on three HIP streams inside one captured graph,
-        S1 = encoder + K/V sides of the FAX pyramid of frame i      (CorpBEVT.encode_trunk)
-        S2 = FAX query path of frame i-1                             (CorpBEVT.fax_query)
-        S3 = STTF + swap fusion + decoder + head of frame i-2        (CorpBEVT.fuse_and_decode)
-    with the state that crosses steps (projected K/V of the three levels, the (A,32,32,128) features) in ping-pong
-    buffers - two graphs, replayed alternately.  Every step still takes one frame in and completes one frame; nothing is
-    skipped or cached, the latency of a frame is three steps.  Inputs are the same static tensors every step, so the
-    steady-state output must equal the un-pipelined forward bit for bit (checked by main())."""
+    idle.  Step i therefore runs, on separate HIP streams inside one captured graph,
+        S1  = encoder + K/V sides of the FAX pyramid of frame i          (CorpBEVT.encode_trunk)
+        S2  = FAX query path of frame i-1                                 (CorpBEVT.fax_query)         [depth 3]
+              or S2a = pyramid level 0 of frame i-1 and S2b = levels 1.. + global attention of frame i-2 [depth 4]
+        S3  = STTF + swap fusion + decoder + head of the oldest frame     (CorpBEVT.fuse_and_decode)
+    with the state that crosses steps (projected K/V of the three levels, the level-0 output, the (A,32,32,128)
+    features) in rings of `depth` buffers - `depth` graphs, replayed round-robin.  Every step still takes one frame in and
+    completes one frame; nothing is skipped or cached, the latency of a frame is `depth` steps.  Inputs are the same static
+    tensors every step, so the steady-state output must equal the un-pipelined forward bit for bit (checked by main())."""
 
-    def __init__(self, model, task_batch, pose, record_len, rank=0, world=1, agents=5):
+    def __init__(self, model, task_batch, pose, record_len, rank=0, world=1, agents=5, depth=3):
         self.model, self.task_batch, self.pose, self.record_len = model, task_batch, pose, record_len
-        self.rank, self.world, self.agents = rank, world, agents
+        self.rank, self.world, self.agents, self.depth = rank, world, agents, depth
         self.i = 0
+        D = depth
         st = model.encode_trunk(dict(task_batch))
         torch.cuda.synchronize()
         self.meta = [{k: v for k, v in lvl.items() if not torch.is_tensor(v)} for lvl in st["kv"]]
         self.batch = st["batch"]
-        self.kv = [[{k: torch.empty_like(v) for k, v in lvl.items() if torch.is_tensor(v)} for lvl in st["kv"]] for _ in range(2)]
-        self.einv = [torch.empty_like(st["E_inv"]) for _ in range(2)]
-        feats = model.fax_query(st)
-        self.f = [torch.empty_like(feats) for _ in range(2)]
+        self.kv = [[{k: torch.empty_like(v) for k, v in lvl.items() if torch.is_tensor(v)} for lvl in st["kv"]] for _ in range(D)]
+        self.einv = [torch.empty_like(st["E_inv"]) for _ in range(D)]
+        x0 = model.fax_query(st, levels=(0, 1))
+        self.x = [torch.empty_like(x0) for _ in range(D)] if depth == 4 else None
+        feats = model.fax_query(st, levels=(1, len(st["kv"])), x=x0)
+        self.f = [torch.empty_like(feats) for _ in range(D)]
         # multi-GPU: the frame's agents are gathered (one RCCL all-gather between graph replays) into g; single GPU: g is f
-        self.g = self.f if world == 1 else [torch.empty_like(feats) for _ in range(2)]
+        self.g = self.f if world == 1 else [torch.empty_like(feats) for _ in range(D)]
         self.out = None
         self.graphs = None
+
+    def _state(self, slot):
+        return {"kv": [dict(self.meta[i], **self.kv[slot][i]) for i in range(len(self.meta))],
+                "E_inv": self.einv[slot], "batch": self.batch}
 
     def _s1(self, slot):
         st = self.model.encode_trunk(dict(self.task_batch), kv_out=self.kv[slot])   # K/V land in the slot directly
@@ -147,11 +155,6 @@ class PipelinedRunner(object):
                     self.kv[slot][level][k].copy_(v)
         self.einv[slot].copy_(st["E_inv"])
 
-    def _s2(self, slot_in, slot_out):
-        state = {"kv": [dict(self.meta[i], **self.kv[slot_in][i]) for i in range(len(self.meta))],
-                 "E_inv": self.einv[slot_in], "batch": self.batch}
-        self.f[slot_out].copy_(self.model.fax_query(state, joined=False))
-
     def _s3(self, slot_in):
         return self.model.fuse_and_decode(self.g[slot_in], self.pose, self.record_len)
 
@@ -160,33 +163,46 @@ class PipelinedRunner(object):
             self.g[q].copy_(cdist.exchange_features(self.f[q], self.rank, self.world, self.agents))
 
     def _step_body(self, q):
-        """parity q: S1 -> kv[q] ; S2: kv[1-q] -> f[q] ; S3: f[1-q] -> out"""
+        """slot q = step index mod depth: S1 writes kv[q]; the later stages read the slots written 1, 2, .. steps ago"""
+        D = self.depth
         main = torch.cuda.current_stream()
-        s2, s3 = self.streams
-        s2.wait_stream(main)
-        s3.wait_stream(main)
-        with torch.cuda.stream(s3):
-            out = self._s3(1 - q)
-        with torch.cuda.stream(s2):
-            self._s2(1 - q, q)
+        for s in self.streams:
+            s.wait_stream(main)
+        nlev = len(self.meta)
+        if D == 3:
+            s2, s3 = self.streams
+            with torch.cuda.stream(s3):
+                out = self._s3((q - 1) % D)                                   # features written one step ago
+            with torch.cuda.stream(s2):
+                self.f[q].copy_(self.model.fax_query(self._state((q - 1) % D), joined=False))
+        else:
+            s2a, s2b, s3 = self.streams
+            with torch.cuda.stream(s3):
+                out = self._s3((q - 1) % D)
+            with torch.cuda.stream(s2b):                                      # frame i-2: K/V from two steps ago, x from one
+                self.f[q].copy_(self.model.fax_query(self._state((q - 2) % D), joined=False, levels=(1, nlev),
+                                                     x=self.x[(q - 1) % D]))
+            with torch.cuda.stream(s2a):                                      # frame i-1
+                self.x[q].copy_(self.model.fax_query(self._state((q - 1) % D), joined=False, levels=(0, 1)))
         self._s1(q)
-        main.wait_stream(s2)
-        main.wait_stream(s3)
+        for s in self.streams:
+            main.wait_stream(s)
         return out
 
     def capture(self):
-        self.streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        D = self.depth
+        self.streams = tuple(torch.cuda.Stream() for _ in range(D - 1))
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for q in (0, 1, 0, 1):
-                self._step_body(q)
-                self._exchange(q)
+            for it in range(2 * D):
+                self._step_body(it % D)
+                self._exchange(it % D)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graphs, self.outs = [], []
         pool = None
-        for q in (0, 1):
+        for q in range(D):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool):
                 self.outs.append(self._step_body(q))
@@ -194,7 +210,7 @@ class PipelinedRunner(object):
             self.graphs.append(g)
 
     def step(self):
-        q = self.i & 1
+        q = self.i % self.depth
         self.graphs[q].replay()
         self._exchange(q)
         self.out = self.outs[q]
@@ -308,19 +324,21 @@ def main():
     in_flight = args.frames_in_flight
     timed = runner
     pipeline_note = "none"
-    if in_flight == 3 and graph_ok:
+    if in_flight in (3, 4) and graph_ok:
         try:
-            timed = PipelinedRunner(model, task_batch, pose, record_len, rank, world, A)
+            timed = PipelinedRunner(model, task_batch, pose, record_len, rank, world, A, depth=in_flight)
             timed.capture()
-            for _ in range(4):
+            for _ in range(2 * in_flight):
                 out = timed.step()
             torch.cuda.synchronize()
             for k in ref_out:                  # steady state == un-pipelined forward, bit for bit
                 if not torch.equal(out[k], ref_out[k]):
                     raise RuntimeError("pipelined frame differs from the un-pipelined forward in %r" % k)
-            pipeline_note = ("S1 encoder + K/V | S2 FAX query | S3 fusion + decoder of three consecutive frames on three HIP "
-                             "streams in one captured graph; one frame in, one frame out per step; steady-state output "
-                             "checked bit-identical to the un-pipelined forward")
+            pipeline_note = ("%s of %d consecutive frames on %d HIP streams in one captured graph; one frame in, one frame "
+                             "out per step; steady-state output checked bit-identical to the un-pipelined forward" %
+                             ("S1 encoder + K/V | S2 FAX query | S3 fusion + decoder" if in_flight == 3 else
+                              "S1 encoder + K/V | S2a FAX level 0 | S2b FAX levels 1-2 + global attention | S3 fusion + decoder",
+                              in_flight, in_flight))
         except Exception as e:  # noqa: BLE001 — never lose the measurement: fall back to one frame at a time, say so
             if world == 1:
                 raise

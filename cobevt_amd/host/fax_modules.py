@@ -402,14 +402,21 @@ class FAXModule(HipModule):
         self.downsample_layers = nn.ModuleList(downsample_layers)
         self.self_attn = Attention(dim[-1], **config["self_attn"])
 
-    def forward_features(self, features, I_inv, E_inv, batch, kv=None):
+    def forward_features(self, features, I_inv, E_inv, batch, kv=None, levels=None, x=None):
         """features: list of (batch*n, h, w, C) channels-last; returns (batch, H, W, d) channels-last.
-        kv: optional list of callables returning each level's prepare_kv() result (computed ahead on side streams)."""
-        dt = rt.get_compute_dtype()
-        prior = self._plan("prior", [self.bev_embedding.learned_features],
-                           lambda d_, dev: self.bev_embedding.learned_features.detach().permute(1, 2, 0).to(dt).contiguous())
-        x = prior[None].expand(batch, *prior.shape).contiguous()
+        kv: optional list of callables returning each level's prepare_kv() result (computed ahead on side streams).
+        levels = (first, last): run only pyramid levels first..last-1 (the global self-attention belongs to the last
+        level), starting from `x` when first > 0 - the pieces a frame pipeline runs on different streams."""
+        nlev = len(self.cross_views)
+        first, last = (0, nlev) if levels is None else levels
+        if first == 0:
+            dt = rt.get_compute_dtype()
+            prior = self._plan("prior", [self.bev_embedding.learned_features],
+                               lambda d_, dev: self.bev_embedding.learned_features.detach().permute(1, 2, 0).to(dt).contiguous())
+            x = prior[None].expand(batch, *prior.shape).contiguous()
         for i, (cross_view, feature, layer) in enumerate(zip(self.cross_views, features, self.layers)):
+            if i < first or i >= last:
+                continue
             kvi = kv[i]() if kv is not None else cross_view.prepare_kv(feature, I_inv, E_inv, batch)
             blocks = list(layer)
             y1 = None
@@ -421,7 +428,7 @@ class FAXModule(HipModule):
                 x = blk.forward_nhwc(x, y1=y1 if j == 0 else None)
             if i < len(self.cross_views) - 1:
                 x = self.downsample_layers[i][0].forward_nhwc(x)
-        if self.self_attn is not None:
+        if self.self_attn is not None and last == nlev:
             x = self.self_attn.forward_nhwc(x)
         return x
 
