@@ -46,9 +46,18 @@ template <typename T, int C, int TH_> struct BBCfg {
     static constexpr int T2W = N2 / NPG;                 // conv2 pixel tiles per wave
     static constexpr int P1H = TH + 4, P1W = TW + 4;     // input patch (TH + 4) x 20
     static constexpr int PSTR1 = 128 + 16;
-    static constexpr int PATCH1 = P1H * P1W * PSTR1;
+    // LDS row pitches chosen for conflict-free ds_read_b128 A fragments (16-byte slots, 16 per 256-byte bank row; a pixel
+    // advances 9 slots in patch1 and (C*EB/16 + 1), an odd number, in patch2):
+    //  * conv1 reads 32 CONSECUTIVE region pixels p = 18*ry + rx: with a pitch of 194 slots (== 18*9 mod 16) the slot of a
+    //    region pixel is 9*p + const for every p, i.e. it keeps advancing across the row wrap -> any 16 lanes of a read
+    //    group hit 16 distinct slots (a 180-slot pitch measured 44 % of the LDS-active cycles as bank conflicts);
+    //  * conv2 reads 2 rows x 16 columns: pitch == 0 mod 16 slots, the two rows cover complementary slots.
+    static constexpr int PITCH1 = 194 * 16;                                        // >= P1W * PSTR1 = 2880
+    static constexpr int PATCH1 = P1H * PITCH1;
     static constexpr int PSTR2 = C * EB + 16;
-    static constexpr int PATCH2 = R1 * PSTR2;
+    static constexpr int PITCH2 = (R1W * PSTR2 + 255) / 256 * 256;
+    static constexpr int PATCH2 = R1H * PITCH2;
+    static_assert(PITCH1 >= P1W * PSTR1, "patch1 pitch");
     static constexpr int SSTR = C * 4 + 16;
     static constexpr int STAGE = TH * TW * SSTR;
     static constexpr int MAIN = PATCH1 + PATCH2;
@@ -67,7 +76,7 @@ __device__ __forceinline__ void bb_conv_chunk(const unsigned char* patch, const 
     uint4 af[3][NTW];
     auto read_a = [&](uint4 (&dst)[NTW], int n) {               // n = tap * 4 + k-group (compile-time after unrolling)
         const int tap = n >> 2, g = n & 3;
-        const int off = ((tap / 3) * row_pitch + (tap % 3)) * pstr + g * 32;
+        const int off = (tap / 3) * row_pitch + (tap % 3) * pstr + g * 32;      // row_pitch in bytes
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
             if (ok[t]) dst[t] = *(const uint4*)(patch + aoff[t] + off);
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
         if (item < P1_ITEMS) {
             const int pix = item / PIECES, j = item - pix * PIECES;
             const int py = pix / P1W, px = pix - py * P1W;
-            const int lds = pix * PSTR1 + j * 16;
+            const int lds = py * G::PITCH1 + px * PSTR1 + j * 16;
             const int iy = oy0 - 2 + py, ix = ox0 - 2 + px;
             const bool inside = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             if (inside) pgoff[it] = ((img * p.H + iy) * p.W + ix) * C + j * CH;
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
         int pr = tile * 32 + ql;
         if (pr >= R1) pr = R1 - 1;                              // padding lanes of the last tile compute a duplicate
         const int ry = pr / R1W, rx = pr - ry * R1W;
-        a1[t] = (ry * P1W + rx) * PSTR1 + h * 16;
+        a1[t] = ry * G::PITCH1 + rx * PSTR1 + h * 16;
     }
     f32x16 acc1[T1W];
 #pragma unroll
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
         store_patch();
         __syncthreads();
         if (chunk + 1 < NCH) load_patch(chunk + 1);
-        bb_conv_chunk<T, T1W>(patch1, a1, t1_ok, P1W, PSTR1, w1src, chunk * 9, NSTEP, bq, acc1);
+        bb_conv_chunk<T, T1W>(patch1, a1, t1_ok, G::PITCH1, PSTR1, w1src, chunk * 9, NSTEP, bq, acc1);
     }
     // conv2's first fragments while the intermediate is written (the ring slots 0 / 1 are free: NSTEP % 3 == 0)
     load_b(bq[0], p.w2, 0);
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
                               acc1[t][4 * k + 3] + bias[k].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = inside ? fmaxf(v[e], 0.f) : 0.f;
-                unsigned char* d = patch2 + pr * PSTR2 + (c0 + 8 * k) * Elem<T>::kBytes;
+                unsigned char* d = patch2 + ry * G::PITCH2 + rx * PSTR2 + (c0 + 8 * k) * Elem<T>::kBytes;
                 if constexpr (Elem<T>::kIsBf16) *(uint2*)d = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                 else *(float4*)d = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -261,14 +270,14 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
 #pragma unroll
     for (int t = 0; t < T2W; ++t) {
         const int tile = pg + t * NPG;
-        a2[t] = ((tile * 2 + (ql >> 4)) * R1W + (ql & 15)) * PSTR2 + h * 16;
+        a2[t] = (tile * 2 + (ql >> 4)) * G::PITCH2 + (ql & 15) * PSTR2 + h * 16;
         t2_ok[t] = true;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     }
 #pragma unroll 1
     for (int chunk = 0; chunk < NCH; ++chunk)
-        bb_conv_chunk<T, T2W>(patch2 + chunk * 128, a2, t2_ok, R1W, PSTR2, w2src, chunk * 9, NSTEP, bq, acc);
+        bb_conv_chunk<T, T2W>(patch2 + chunk * 128, a2, t2_ok, G::PITCH2, PSTR2, w2src, chunk * 9, NSTEP, bq, acc);
     __syncthreads();                                            // patch2 no longer read: stage over the patches
 
     // ---- epilogue: fp32 staging [128 pixels][C], then + residual, ReLU, 16-byte stores
