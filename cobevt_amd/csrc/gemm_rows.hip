@@ -55,6 +55,13 @@ constexpr int kGrTile = 128;              // rows of A and of W per tile
 constexpr int kGrStageRow = 128 * 4 + 16; // fp32 staging row stride
 constexpr int kGrLds = 2 * kGrTile * kGrRow + 128 * 16;   // 69,632 B of tiles + the embedding producer's coefficient table
 
+#ifdef COBEVT_GEMM_TRACE      // tools/gemm_trace.py builds a copy of this file with s_memtime marks (never the product .so)
+__device__ unsigned long long cobevt_gemm_trace[16];
+#define COBEVT_GT_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) cobevt_gemm_trace[(i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define COBEVT_GT_MARK(i) do {} while (0)
+#endif
+
 template <typename T, bool EMB>
 __global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams p) {
     constexpr int CH = Elem<T>::kChunk;
@@ -235,12 +242,15 @@ __global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams
     const int abase = (wm * 32 + ql) * kGrRow + h * 16;
     const int bbase = (wn * 64 + ql) * kGrRow + h * 16;
 
+    COBEVT_GT_MARK(0);
     load_tile(0);
     for (int kt = 0; kt < nkt; ++kt) {
         transform_a(kt);
+        COBEVT_GT_MARK(1);
         if (kt > 0) __syncthreads();          // previous tile fully consumed
         store_tile();
         __syncthreads();
+        COBEVT_GT_MARK(2);
         if (kt + 1 < nkt) load_tile(kt + 1);
         const int kleft = p.K - kt * TK;
         const int ng = kleft >= TK ? 8 : (kleft * Elem<T>::kBytes + 31) / 32;
@@ -252,7 +262,9 @@ __global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams
             mfma_kgroup<T>(af, b1, acc[1]);
         }
     }
+    COBEVT_GT_MARK(3);
     __syncthreads();
+    COBEVT_GT_MARK(4);
 
     // ---- epilogue: fp32 staging [128][128] then coalesced 16-byte passes
     float* stage = (float*)smem;
@@ -265,43 +277,73 @@ __global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams
         for (int r = 0; r < 16; ++r) stage[(wm * 32 + acc_row(r, lane)) * SROW + cl] = acc[b][r] + bias;
     }
     __syncthreads();
+    COBEVT_GT_MARK(5);
     T* out = (T*)p.out;
     constexpr int CPR = 128 / CH;                 // 16-byte output chunks per tile row
     const bool remap = p.out_H != p.src_H || p.out_W != p.src_W;
     const bool vec_ok = (p.N % CH) == 0;
-    for (int item = tid; item < 128 * CPR; item += kGrThreads) {
-        const int row = item / CPR, cj = item - row * CPR;
-        const int m = m0 + row, col = n0 + cj * CH;
-        if (m >= p.M || col >= p.N) continue;
-        size_t orow = (size_t)m;
-        if (remap) {
-            const int hw = p.src_H * p.src_W;
-            const int n = m / hw, rem = m - n * hw;
-            const int oh = rem / p.src_W, ow = rem - oh * p.src_W;
-            orow = ((size_t)n * p.out_H + oh) * p.out_W + ow;
-        }
-        float v[8];
+    if (vec_ok) {
+        // unrolled: every residual load and staging read of the thread is in flight before the first store (the rolled loop
+        // serialised one LDS + global round trip per item: 5.3k of a workgroup's 19k cycles in the s_memtime trace)
+        constexpr int NIT = 128 * CPR / kGrThreads;
+        long orow[NIT];
+        uint4 rres[NIT];
 #pragma unroll
-        for (int e = 0; e < CH; ++e) v[e] = stage[row * SROW + cj * CH + e];
-        if (vec_ok && col + CH <= p.N) {
+        for (int i = 0; i < NIT; ++i) {
+            const int item = tid + i * kGrThreads;
+            const int row = item / CPR, cj = item - row * CPR;
+            const int m = m0 + row, col = n0 + cj * CH;
+            orow[i] = -1;
+            rres[i] = make_uint4(0, 0, 0, 0);
+            if (m < p.M && col < p.N) {
+                orow[i] = m;
+                if (remap) {
+                    const int hw = p.src_H * p.src_W;
+                    const int n = m / hw, rem = m - n * hw;
+                    const int oh = rem / p.src_W, ow = rem - oh * p.src_W;
+                    orow[i] = ((long)n * p.out_H + oh) * p.out_W + ow;
+                }
+                if (p.residual) rres[i] = *(const uint4*)((const T*)p.residual + (size_t)m * p.N + col);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            if (orow[i] < 0) continue;
+            const int item = tid + i * kGrThreads;
+            const int row = item / CPR, cj = item - row * CPR;
+            float v[8], rv[8];
+#pragma unroll
+            for (int e = 0; e < CH; ++e) v[e] = stage[row * SROW + cj * CH + e];
             if (p.residual) {
-                float rv[8];
-                chunk_to_f32<T>(*(const uint4*)((const T*)p.residual + (size_t)m * p.N + col), rv);
+                chunk_to_f32<T>(rres[i], rv);
 #pragma unroll
                 for (int e = 0; e < CH; ++e) v[e] += rv[e];
             }
 #pragma unroll
             for (int e = 0; e < CH; ++e) v[e] = p.act == 1 ? fmaxf(v[e], 0.f) : (p.act == 2 ? gelu_erf(v[e]) : v[e]);
-            *(uint4*)(out + orow * p.N + col) = f32_to_chunk<T>(v);
-        } else {
+            *(uint4*)(out + (size_t)orow[i] * p.N + n0 + cj * CH) = f32_to_chunk<T>(v);
+        }
+    } else {                                          // ragged N (not a multiple of the 16-byte chunk): scalar
+        for (int item = tid; item < 128 * CPR; item += kGrThreads) {
+            const int row = item / CPR, cj = item - row * CPR;
+            const int m = m0 + row, col = n0 + cj * CH;
+            if (m >= p.M || col >= p.N) continue;
+            size_t orow = (size_t)m;
+            if (remap) {
+                const int hw = p.src_H * p.src_W;
+                const int n = m / hw, rem = m - n * hw;
+                const int oh = rem / p.src_W, ow = rem - oh * p.src_W;
+                orow = ((size_t)n * p.out_H + oh) * p.out_W + ow;
+            }
             for (int e = 0; e < CH && col + e < p.N; ++e) {
-                float x = v[e];
+                float x = stage[row * SROW + cj * CH + e];
                 if (p.residual) x += load_elem<T>((const T*)p.residual, (size_t)m * p.N + col + e);
                 x = p.act == 1 ? fmaxf(x, 0.f) : (p.act == 2 ? gelu_erf(x) : x);
                 store_elem<T>(out, orow * p.N + col + e, x);
             }
         }
     }
+    COBEVT_GT_MARK(6);
 }
 
 
@@ -346,8 +388,14 @@ __global__ __launch_bounds__(kGrThreads, 2) void gemm_rows2_kernel(GemmRowsParam
 
     uint4 bfrag[8];
     auto load_b = [&](int kt) {
+        // two base addresses + immediate offsets (a global_load immediate reaches +-4 KB): eight 64-bit address pairs
+        // would cost 16 VGPRs in a kernel that has to fit 128
+        const uint4* b0 = wq + (size_t)(kt * 8) * 64;
+        const uint4* b1 = b0 + 4 * 64;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) bfrag[g] = wq[(size_t)(kt * 8 + g) * 64];
+        for (int g = 0; g < 4; ++g) bfrag[g] = b0[g * 64];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bfrag[4 + g] = b1[g * 64];
     };
     uint4 areg[4];
     auto row_ptr = [&](int tm) {                      // this thread's A row of tile tm (row 0 when past M)
@@ -371,37 +419,44 @@ __global__ __launch_bounds__(kGrThreads, 2) void gemm_rows2_kernel(GemmRowsParam
     };
     auto transform_a = [&](int kt) {
         if (p.ln) {
-            float v[4][8];
+            // three passes that unpack one 16-byte chunk at a time (8 live floats instead of 32): this kernel keeps its weight
+            // fragments, the accumulators and the next tile's rows in registers and has to fit 128 VGPRs
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                chunk_to_f32<T>(areg[j], v[j]);
+                float v[8];
+                chunk_to_f32<T>(areg[j], v);
 #pragma unroll
-                for (int e = 0; e < CH; ++e) s += v[j][e];
+                for (int e = 0; e < CH; ++e) s += v[e];
             }
             s += __shfl_xor(s, 1, 64);
             s += __shfl_xor(s, 2, 64);
             const float mean = s / (float)p.K;
             float q = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
+                float v[8];
+                chunk_to_f32<T>(areg[j], v);
 #pragma unroll
                 for (int e = 0; e < CH; ++e) {
                     const int k = (sub * 4 + j) * CH + e;
-                    const float d = k < p.K ? v[j][e] - mean : 0.f;
+                    const float d = k < p.K ? v[e] - mean : 0.f;
                     q += d * d;
                 }
+            }
             q += __shfl_xor(q, 1, 64);
             q += __shfl_xor(q, 2, 64);
             const float rstd = rsqrtf(q / (float)p.K + p.ln_eps);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                float v[8];
+                chunk_to_f32<T>(areg[j], v);
 #pragma unroll
                 for (int e = 0; e < CH; ++e) {
                     const int k = (sub * 4 + j) * CH + e;
-                    v[j][e] = k < p.K ? (v[j][e] - mean) * rstd : 0.f;
+                    v[e] = k < p.K ? (v[e] - mean) * rstd : 0.f;
                 }
-                areg[j] = f32_to_chunk<T>(v[j]);
+                areg[j] = f32_to_chunk<T>(v);
             }
         } else if (p.pre_scale) {
 #pragma unroll
@@ -459,6 +514,7 @@ __global__ __launch_bounds__(kGrThreads, 2) void gemm_rows2_kernel(GemmRowsParam
             }
             const int kleft = p.K - kt * TK;
             const int ng = kleft >= TK ? 8 : (kleft * EB + 31) / 32;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < 8; ++g)
                 if (g < ng) {
@@ -467,6 +523,14 @@ __global__ __launch_bounds__(kGrThreads, 2) void gemm_rows2_kernel(GemmRowsParam
                         const uint4 af = *(const uint4*)(As + (wm * 64 + rt * 32 + ql) * kGrRow + h * 16 + g * 32);
                         mfma_kgroup<T>(bfrag[g], af, acc[rt]);     // D = W . X^T : lane <-> row, registers <-> columns
                     }
+                    if (Elem<T>::kIsBf16) {                        // pin "read, MFMA": unpinned, LLVM hoists all 16 fragment
+#pragma unroll                                                      // reads (64 VGPRs) above the MFMAs
+                        for (int rt = 0; rt < 2; ++rt) {
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
         }
         // ---- epilogue in registers, staged in the storage type
@@ -518,6 +582,7 @@ __global__ __launch_bounds__(kGrThreads, 2) void gemm_rows2_kernel(GemmRowsParam
                 orow = ((size_t)n * p.out_H + oh) * p.out_W + ow;
             }
             *(uint4*)(out + orow * p.N + col) = *(const uint4*)(Cs + row * CROW + cj * 16);
+            __builtin_amdgcn_sched_barrier(0);        // one item at a time: keeps four 64-bit store addresses from living at once
         }
         // the next iteration's Cs writes come after its own barrier; its As writes after this tile's MFMA reads (barrier above)
     }
@@ -638,7 +703,7 @@ extern "C" int cobevt_linear_rows_wfrag(const void* in, const void* wfrag, const
     if (p.in_stride > 1 && ((p.src_H - 1) * p.in_stride >= p.in_H || (p.src_W - 1) * p.in_stride >= p.in_W ||
                             p.M % ((long)p.src_H * p.src_W) != 0)) return COBEVT_ERR_SHAPE;
     const long ntn = (p.N + 127) / 128, ntm = (p.M + 127) / 128;
-    long per_col = 256 / ntn;                                   // one 8-wave workgroup per CU (196 VGPRs), persistent over row tiles
+    long per_col = 256 / ntn;                                   // one 8-wave workgroup per CU (the kernel wants ~190 VGPRs; capped at 128 it spills 50 and is slower still), persistent over row tiles
     if (per_col < 1) per_col = 1;
     if (per_col > ntm) per_col = ntm;
     const long blocks = ntn * per_col;
@@ -654,3 +719,9 @@ extern "C" int cobevt_linear_rows_wfrag(const void* in, const void* wfrag, const
     else hipLaunchKernelGGL(gemm_rows2_kernel<float>, dim3((unsigned)blocks), dim3(kGrThreads), lds, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
+
+#ifdef COBEVT_GEMM_TRACE
+extern "C" int cobevt_gemm_read_trace(unsigned long long* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(cobevt_gemm_trace), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+}
+#endif
