@@ -219,6 +219,8 @@ class PipelinedRunner(object):
 
 
 MFMA_FAMILIES = ("conv3x3", "basicblock", "gemm_rows", "row_chain", "igemm", "attention", "stem7x7")
+HBM_BOUND_FAMILIES = ("gemm_rows", "row_chain", "stem7x7")
+PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s peak (about 6.3 TB/s achievable)
 
 
 def roofline_leg(runner, dtype_name):
@@ -242,12 +244,18 @@ def roofline_leg(runner, dtype_name):
     def entry(fam):
         d = best[fam]
         tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        return {"kernel": fam, "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(tf / peak, 4), "traffic": traffic.get(fam), "launches_per_frame": d["calls"],
-                "avg_launch_us": round(d["ms"] * 1e3 / d["calls"], 2), "total_ms_per_frame": round(d["ms"], 3),
-                "algorithmic_gflop_per_launch": round(d["flops"] / 1e9 / d["calls"], 2),
-                "algorithmic_mbyte_per_launch": round(d["bytes"] / 1e6 / d["calls"], 2),
-                "algorithmic_gbyte_s": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1)}
+        gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        e = {"kernel": fam, "traffic": traffic.get(fam), "launches_per_frame": d["calls"],
+             "avg_launch_us": round(d["ms"] * 1e3 / d["calls"], 2), "total_ms_per_frame": round(d["ms"], 3),
+             "algorithmic_gflop_per_launch": round(d["flops"] / 1e9 / d["calls"], 2),
+             "algorithmic_mbyte_per_launch": round(d["bytes"] / 1e6 / d["calls"], 2),
+             "algorithmic_tflop_s": round(tf, 2), "algorithmic_gbyte_s": round(gbs, 1)}
+        if fam in HBM_BOUND_FAMILIES:      # K <= 512 GEMMs / row chains / the image stem: arithmetic intensity below the ridge
+            e.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                      "frac": round(gbs / PEAK_HBM_GBS, 4)})
+        else:
+            e.update({"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)})
+        return e
     runner.model.overlap_streams = True
     fams = [f for f in MFMA_FAMILIES if f in best]
     fams.sort(key=lambda f: -best[f]["ms"])
