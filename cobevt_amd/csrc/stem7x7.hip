@@ -204,16 +204,26 @@ template <typename T> struct StemPoolCfg {
     static constexpr int WROW = 16 * 16 * Elem<T>::kBytes + 16;
     static constexpr int WBYTES = 64 * WROW;
     static constexpr int SROW = 64 * Elem<T>::kBytes + 16;    // staging row: 64 channels in the storage type
-    static constexpr int STAGE = RPIX * SROW;
-    static constexpr int LDS = PATCH + WBYTES + STAGE;
+    static constexpr int STAGE = (RPIX * SROW + 255) / 256 * 256;
+    static constexpr int LDS = PATCH + WBYTES + STAGE + 256;      // + the 64 bias values
 };
 
+#ifdef COBEVT_STEM_TRACE      // tools/stem_trace.py builds a copy with s_memtime marks (never the product .so)
+__device__ unsigned long long cobevt_stem_trace[16];
+#define COBEVT_ST_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && tile == (int)blockIdx.x + 2 * (int)gridDim.x) cobevt_stem_trace[(i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define COBEVT_ST_MARK(i) do {} while (0)
+#endif
+
+constexpr int kStemPoolThreads = 512;   // 8 waves share the ten (pixel tile, cout half) units of a region: 2,2,1,1,1,1,1,1
+
 template <typename T>
-__global__ __launch_bounds__(256) void stem_pool_kernel(StemParams p) {
+__global__ __launch_bounds__(kStemPoolThreads, 4) void stem_pool_kernel(StemParams p) {
     using C = StemPoolCfg<T>;
-    constexpr int KG = C::KG, RW = C::RW, RPIX = C::RPIX;
+    constexpr int KG = C::KG, RW = C::RW, RPIX = C::RPIX, NT = kStemPoolThreads;
     constexpr int NPIECE = C::PH * C::PW * 2 * 3;
-    constexpr int P_IT = (NPIECE + 255) / 256;
+    constexpr int P_IT = (NPIECE + NT - 1) / NT;
+    constexpr int NUNIT = C::NPT * 2;                         // (pixel tile, 32-cout half)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* patch = smem;
     unsigned char* wl = smem + C::PATCH;
@@ -223,8 +233,24 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(StemParams p) {
     const int h = lane >> 5, ql = lane & 31;
     const int Hp = p.Ho / 2, Wp = p.Wo / 2;                   // pooled map (Ho, Wo even)
 
-    for (int i = tid; i < C::PATCH / 16; i += 256) ((uint4*)patch)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < C::PATCH / 16; i += NT) ((uint4*)patch)[i] = make_uint4(0, 0, 0, 0);
 
+    // patch pieces of this thread: the (pixel, dy, float-pair) decomposition does not depend on the tile
+    int pdst[P_IT], prow[P_IT], pxo[P_IT], pcol[P_IT];        // LDS offset; image row, image column, float offset relative to the region origin
+#pragma unroll
+    for (int it = 0; it < P_IT; ++it) {
+        const int item = tid + it * NT;
+        pdst[it] = -1; prow[it] = 0; pxo[it] = 0; pcol[it] = 0;
+        if (item < NPIECE) {
+            const int pc = item % 3, rest = item / 3;
+            const int dy = rest & 1, pix = rest >> 1;
+            const int py = pix / C::PW, px = pix - py * C::PW;
+            pdst[it] = py * C::PROW + px * C::PIX + (dy * 6 + pc * 2) * Elem<T>::kBytes;
+            prow[it] = 2 * (py - 2) + dy;                     // image row = 2*oy0 + prow
+            pxo[it] = 2 * (px - 2);                           // first image column of the pixel pair = 2*ox0 + pxo
+            pcol[it] = pxo[it] * 3 + pc * 2;                  // float offset inside the image row = 6*ox0 + pcol
+        }
+    }
     float2 preg[P_IT];
     auto decode = [&](int tile, int& img, int& py0, int& px0) {
         const int tx = tile % p.tiles_x;
@@ -237,41 +263,32 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(StemParams p) {
         int img, py0, px0;
         decode(tile, img, py0, px0);
         const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;       // conv region origin
+        const float* base = p.in + (size_t)img * p.H * p.W * 3;
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
-            const int item = tid + it * 256;
             float2 v = make_float2(0.f, 0.f);
-            if (item < NPIECE) {
-                const int pc = item % 3, rest = item / 3;
-                const int dy = rest & 1, pix = rest >> 1;
-                const int py = pix / C::PW, px = pix - py * C::PW;
-                const int iy = 2 * (oy0 - 2 + py) + dy, ix = 2 * (ox0 - 2 + px);
-                if (iy >= 0 && iy < p.H && ix >= 0 && ix + 1 < p.W)
-                    v = *(const float2*)(p.in + (((size_t)img * p.H + iy) * p.W + ix) * 3 + pc * 2);
-            }
+            const int iy = 2 * oy0 + prow[it], ix = 2 * ox0 + pxo[it];
+            // the 6 floats in[iy][ix..ix+1][0..2] are contiguous; columns are valid in pairs (W is even)
+            if (pdst[it] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix + 1 < p.W)
+                v = *(const float2*)(base + (size_t)iy * p.W * 3 + 6 * ox0 + pcol[it]);
             preg[it] = v;
         }
     };
     auto store_patch = [&]() {
 #pragma unroll
-        for (int it = 0; it < P_IT; ++it) {
-            const int item = tid + it * 256;
-            if (item < NPIECE) {
-                const int pc = item % 3, rest = item / 3;
-                const int dy = rest & 1, pix = rest >> 1;
-                const int py = pix / C::PW, px = pix - py * C::PW;
-                unsigned char* dst = patch + py * C::PROW + px * C::PIX + (dy * 6 + pc * 2) * Elem<T>::kBytes;
+        for (int it = 0; it < P_IT; ++it)
+            if (pdst[it] >= 0) {
+                unsigned char* dst = patch + pdst[it];
                 if constexpr (Elem<T>::kIsBf16) *(uint32_t*)dst = pack_bf2(preg[it].x, preg[it].y);
                 else *(float2*)dst = preg[it];
             }
-        }
     };
 
     int tile = blockIdx.x;
     if (tile >= p.ntiles) return;
     {
         constexpr int PIECES = 16 * 16 * Elem<T>::kBytes / 16;
-        for (int i = tid; i < 64 * PIECES; i += 256) {
+        for (int i = tid; i < 64 * PIECES; i += NT) {
             const int row = i / PIECES, j = i - row * PIECES;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (row < p.Cout) v = *(const uint4*)((const unsigned char*)p.wgt + ((size_t)row * PIECES + j) * 16);
@@ -281,64 +298,68 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(StemParams p) {
     __syncthreads();
     load_patch(tile);
 
-    // this lane's conv-region pixels: tile t of wave w is pixel tile w + 4 t (only wave 0 has a second one)
-    int abase[2], rpix[2];
+    // this wave's units: u = wave and u = wave + 8 (waves 0, 1): pixel tile u >> 1, cout half u & 1
+    int abase[2], bbase[2], rpix[2], chalf[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        int pr = (wave + 4 * t) * 32 + ql;
+        const int u = wave + 8 * t;
+        const int pt = (u < NUNIT ? u : 0) >> 1;
+        chalf[t] = u & 1;
+        int pr = pt * 32 + ql;
         rpix[t] = pr;
         if (pr >= RPIX) pr = RPIX - 1;
         const int ry = pr / RW, rx = pr - ry * RW;
         abase[t] = ry * C::PROW + rx * C::PIX + h * 16;
+        bbase[t] = (chalf[t] * 32 + ql) * C::WROW + h * 16;
     }
-    const bool two = wave + 4 < C::NPT;                       // wave-uniform
-    const int bbase = ql * C::WROW + h * 16;
-    float4 bias4[2][4];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c0 = b * 32 + 8 * k + 4 * h;
-            bias4[b][k] = p.bias ? *(const float4*)(p.bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    const bool two = wave + 8 < NUNIT;                        // wave-uniform
+    float* bias_l = (float*)(smem + C::PATCH + C::WBYTES + C::STAGE);     // bias in LDS: 32 VGPRs less than keeping it
+    if (tid < 64) bias_l[tid] = p.bias ? p.bias[tid] : 0.f;
+    __syncthreads();
 
     for (; tile < p.ntiles; tile += gridDim.x) {
         int img, py0, px0;
         decode(tile, img, py0, px0);
         const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;
+        COBEVT_ST_MARK(0);
         store_patch();
         __syncthreads();
+        COBEVT_ST_MARK(1);
         const int next = tile + gridDim.x;
         if (next < p.ntiles) load_patch(next);
+        COBEVT_ST_MARK(2);
 
-        f32x16 acc[2][2];
+        f32x16 acc[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][b][r] = 0.f;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                const int toff = a * C::PROW + bb * C::PIX;
-                const unsigned char* pw = wl + bbase + (a * 4 + bb) * 16 * Elem<T>::kBytes;
-#pragma unroll
-                for (int g = 0; g < KG; ++g) {
-                    const uint4 b0 = *(const uint4*)(pw + g * 32);
-                    const uint4 b1 = *(const uint4*)(pw + 32 * C::WROW + g * 32);
-                    const uint4 a0 = *(const uint4*)(patch + abase[0] + toff + g * 32);
-                    mfma_kgroup<T>(b0, a0, acc[0][0]);         // D = W . X^T: lane <-> pixel, registers <-> couts
-                    mfma_kgroup<T>(b1, a0, acc[0][1]);
-                    if (two) {
-                        const uint4 a1 = *(const uint4*)(patch + abase[1] + toff + g * 32);
-                        mfma_kgroup<T>(b0, a1, acc[1][0]);
-                        mfma_kgroup<T>(b1, a1, acc[1][1]);
-                    }
-                }
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        // 16 taps x KG k-groups, operands one step ahead of the MFMAs in a two-slot register ring with the issue order
+        // pinned (each MFMA had its two ds_read_b128 right in front of it: 3.3k cycles for 32 MFMAs in the s_memtime trace)
+        constexpr int NS = 16 * KG;
+        constexpr int RS = 2;                                 // ring slots (one step ahead keeps the kernel at 128 VGPRs = 2 workgroups / CU)
+        uint4 ra[RS][2], rb[RS][2];
+        auto fetch = [&](int slot, int i) {                  // i = tap * KG + g (compile-time after unrolling)
+            const int tap = i / KG, g = i - tap * KG;
+            const int toff = (tap >> 2) * C::PROW + (tap & 3) * C::PIX + g * 32;
+            const int woff = tap * 16 * Elem<T>::kBytes + g * 32;
+            rb[slot][0] = *(const uint4*)(wl + bbase[0] + woff);
+            ra[slot][0] = *(const uint4*)(patch + abase[0] + toff);
+            if (two) {
+                rb[slot][1] = *(const uint4*)(wl + bbase[1] + woff);
+                ra[slot][1] = *(const uint4*)(patch + abase[1] + toff);
             }
+        };
+        fetch(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            if (i + 1 < NS) fetch((i + 1) % RS, i + 1);
+            mfma_kgroup<T>(rb[i % RS][0], ra[i % RS][0], acc[0]);      // D = W . X^T: lane <-> pixel, registers <-> couts
+            if (two) mfma_kgroup<T>(rb[i % RS][1], ra[i % RS][1], acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        COBEVT_ST_MARK(3);
         // ---- bias + ReLU, rounded to T, staged [region pixel][64]; conv pixels outside the map -> 0
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -349,24 +370,25 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(StemParams p) {
             const int oy = oy0 + ry, ox = ox0 + rx;
             const bool inside = oy >= 0 && oy < p.Ho && ox >= 0 && ox < p.Wo;
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int k = 0; k < 4; ++k) {
+                const int c0 = chalf[t] * 32 + 8 * k + 4 * h;
+                const float4 b = *(const float4*)(bias_l + c0);
+                float v[4] = {acc[t][4 * k] + b.x, acc[t][4 * k + 1] + b.y, acc[t][4 * k + 2] + b.z, acc[t][4 * k + 3] + b.w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float v[4] = {acc[t][b][4 * k] + bias4[b][k].x, acc[t][b][4 * k + 1] + bias4[b][k].y,
-                                  acc[t][b][4 * k + 2] + bias4[b][k].z, acc[t][b][4 * k + 3] + bias4[b][k].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = inside ? fmaxf(v[e], 0.f) : 0.f;
-                    unsigned char* d = stage + pr * C::SROW + (b * 32 + 8 * k + 4 * h) * Elem<T>::kBytes;
-                    if constexpr (Elem<T>::kIsBf16) *(uint2*)d = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                    else *(float4*)d = make_float4(v[0], v[1], v[2], v[3]);
-                }
+                for (int e = 0; e < 4; ++e) v[e] = inside ? fmaxf(v[e], 0.f) : 0.f;
+                unsigned char* d = stage + pr * C::SROW + c0 * Elem<T>::kBytes;
+                if constexpr (Elem<T>::kIsBf16) *(uint2*)d = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                else *(float4*)d = make_float4(v[0], v[1], v[2], v[3]);
+            }
         }
+        COBEVT_ST_MARK(4);
         __syncthreads();      // staging complete; every wave is done with the patch
+        COBEVT_ST_MARK(5);
         // ---- 3 x 3 / stride 2 maxima: pooled pixel (qy, qx) of the 4 x 8 tile covers region rows 2qy..2qy+2, cols 2qx..2qx+2
         constexpr int CH = Elem<T>::kChunk;
         constexpr int CPP = 64 / CH;
         T* out = (T*)p.out;
-        for (int item = tid; item < 32 * CPP; item += 256) {
+        for (int item = tid; item < 32 * CPP; item += NT) {
             const int q = item / CPP, cj = item - q * CPP;
             const int qy = q >> 3, qx = q & 7;
             const int py = py0 + qy, px = px0 + qx;
@@ -385,7 +407,9 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(StemParams p) {
                 }
             *(uint4*)(out + (((size_t)img * Hp + py) * Wp + px) * 64 + cj * CH) = f32_to_chunk<T>(m);
         }
+        COBEVT_ST_MARK(6);
         __syncthreads();
+        COBEVT_ST_MARK(7);
     }
 }
 
@@ -449,7 +473,13 @@ extern "C" int cobevt_stem_conv7x7s2_pool(const float* in, const void* wgt, cons
     }
     const int per_cu = dtype == 0 ? 2 : 1;
     const unsigned blocks = (unsigned)(nt < 256L * per_cu ? nt : 256L * per_cu);
-    if (dtype == 0) hipLaunchKernelGGL(stem_pool_kernel<bf16_t>, dim3(blocks), dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL(stem_pool_kernel<float>, dim3(blocks), dim3(256), lds, stream, p);
+    if (dtype == 0) hipLaunchKernelGGL(stem_pool_kernel<bf16_t>, dim3(blocks), dim3(kStemPoolThreads), lds, stream, p);
+    else hipLaunchKernelGGL(stem_pool_kernel<float>, dim3(blocks), dim3(kStemPoolThreads), lds, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
+
+#ifdef COBEVT_STEM_TRACE
+extern "C" int cobevt_stem_read_trace(unsigned long long* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(cobevt_stem_trace), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+}
+#endif
