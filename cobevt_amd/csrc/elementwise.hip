@@ -124,10 +124,10 @@ __global__ __launch_bounds__(256) void ray_embed_kernel(const float* I_inv, cons
 template <typename T>
 __global__ __launch_bounds__(256) void bev_embed_kernel(const float* E_inv, const float* world, const float* w_bev,
                                                         const float* b_bev, const float* w_cam, const T* x, T* out,
-                                                        int B, int n, int hw, int D) {
+                                                        int B, int n, int hw, int D, int x_bcast) {
     const int G = D >> 3;
     const int gl = threadIdx.x & (G - 1), gp = threadIdx.x / G, ngroups = 256 / G;
-    const int bn = blockIdx.y, b = bn / n;
+    const int bn = blockIdx.y, b = x_bcast ? 0 : bn / n;     // x_bcast: one (HW, D) prior shared by every b
     const float* E = E_inv + bn * 16;
     float wb[8][2], off[8];                     // off = bias - c_embed
 #pragma unroll
@@ -472,13 +472,13 @@ extern "C" int cobevt_fax_ray_embed(const float* I_inv, const float* E_inv, cons
 
 extern "C" int cobevt_fax_bev_embed(const float* E_inv, const float* world, const float* w_bev, const float* b_bev,
                                     const float* w_cam, const void* x, void* out, int dtype, int B, int n, int hw, int D,
-                                    hipStream_t stream) {
+                                    int x_bcast, hipStream_t stream) {
     if (!E_inv || !world || !w_bev || !b_bev || !w_cam || !x || !out) return COBEVT_ERR_ARG;
     if (!group_ok(D) || B < 1 || n < 1 || hw < 1) return COBEVT_ERR_SHAPE;
     if ((long)B * n > 65535) return COBEVT_ERR_SHAPE;
     const dim3 grid((hw + kEmbedPixPerBlock - 1) / kEmbedPixPerBlock, B * n), block(256);
-    if (dtype == 0) hipLaunchKernelGGL(bev_embed_kernel<bf16_t>, grid, block, 0, stream, E_inv, world, w_bev, b_bev, w_cam, (const bf16_t*)x, (bf16_t*)out, B, n, hw, D);
-    else if (dtype == 1) hipLaunchKernelGGL(bev_embed_kernel<float>, grid, block, 0, stream, E_inv, world, w_bev, b_bev, w_cam, (const float*)x, (float*)out, B, n, hw, D);
+    if (dtype == 0) hipLaunchKernelGGL(bev_embed_kernel<bf16_t>, grid, block, 0, stream, E_inv, world, w_bev, b_bev, w_cam, (const bf16_t*)x, (bf16_t*)out, B, n, hw, D, x_bcast);
+    else if (dtype == 1) hipLaunchKernelGGL(bev_embed_kernel<float>, grid, block, 0, stream, E_inv, world, w_bev, b_bev, w_cam, (const float*)x, (float*)out, B, n, hw, D, x_bcast);
     else return COBEVT_ERR_ARG;
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

@@ -30,7 +30,7 @@ namespace cobevt {
 
 struct RowChainParams {
     const bf16_t* a;        // [M][C] attention output
-    const bf16_t* skip;     // [M][C] or null
+    const bf16_t* skip;     // [skip_rows][C] or null; row m adds skip[m % skip_rows] (skip_rows = M: plain; < M: broadcast)
     bf16_t* out;            // [M][C]
     const uint4* wp;        // fragment-ordered [4 tiles][8]      out-projection
     const float* bp;        // [C] or null
@@ -44,7 +44,7 @@ struct RowChainParams {
     const float* bn;        // [Nn] or null
     bf16_t* out_next;       // [M][Nn]
     int M, C, Hd, Hdp;
-    int Nn, next_ln, next_act;
+    int Nn, next_ln, next_act, skip_rows;
     float eps1, eps_post, eps_next;
 };
 
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
     for (int k = 0; k < 4; ++k) {
         const int col0 = cbase + 8 * k;
         skp[k] = make_uint2(0, 0);
-        if (p.skip && row_ok && col0 < p.C) skp[k] = *(const uint2*)(p.skip + (size_t)(m0 + row) * p.C + col0);
+        if (p.skip && row_ok && col0 < p.C) skp[k] = *(const uint2*)(p.skip + (size_t)((m0 + row) % p.skip_rows) * p.C + col0);
     }
     __syncthreads();
 
@@ -308,7 +308,7 @@ extern "C" int cobevt_attn_mlp_chain(const void* a, const void* skip, void* out,
                                      const float* post_gamma, const float* post_beta, const void* wnext, const float* bnext,
                                      void* out_next, const int* dims, float eps1, float eps_post, float eps_next,
                                      hipStream_t stream) {
-    // dims: [dtype, M, C, Hd, Hdp, Nn, next_ln, next_act, rows_per_workgroup]
+    // dims: [dtype, M, C, Hd, Hdp, Nn, next_ln, next_act, rows_per_workgroup, skip_rows]
     if (!a || !out || !wp || !w1 || !b1 || !w2 || !b2 || !dims) return COBEVT_ERR_ARG;
     if (dims[0] != 0) return COBEVT_ERR_UNSUPPORTED;           // bf16 mode only; fp32 runs the GEMMs separately
     RowChainParams p;
@@ -318,9 +318,11 @@ extern "C" int cobevt_attn_mlp_chain(const void* a, const void* skip, void* out,
     p.wn = (const uint4*)wnext; p.bn = bnext; p.out_next = (bf16_t*)out_next;
     p.M = dims[1]; p.C = dims[2]; p.Hd = dims[3]; p.Hdp = dims[4];
     p.Nn = dims[5]; p.next_ln = dims[6]; p.next_act = dims[7];
+    p.skip_rows = dims[9] > 0 ? dims[9] : p.M;                 // dims[9]: rows of `skip` (0 = M), M % skip_rows == 0
     p.eps1 = eps1; p.eps_post = eps_post; p.eps_next = eps_next;
     if (p.M < 1 || p.C < 8 || p.C > 128 || p.C % 8 || p.Hd < 8 || p.Hd > 256 || p.Hd % 8) return COBEVT_ERR_SHAPE;
     if (p.Hdp % 128 || p.Hdp < p.Hd || p.Hdp > 256) return COBEVT_ERR_SHAPE;
+    if (p.skip_rows > p.M || p.M % p.skip_rows) return COBEVT_ERR_SHAPE;
     if ((post_gamma == nullptr) != (post_beta == nullptr)) return COBEVT_ERR_ARG;
     if ((wnext == nullptr) != (out_next == nullptr)) return COBEVT_ERR_ARG;
     if (wnext && (p.Nn < 8 || p.Nn % 8 || p.Nn > 1024 || p.next_act < 0 || p.next_act > 2)) return COBEVT_ERR_SHAPE;

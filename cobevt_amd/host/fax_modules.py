@@ -319,6 +319,7 @@ class CrossViewSwapAttention(HipModule):
                                       self.cross_win_attend_1.q_plan())
             query, nq = None, n
         else:
+            x = x.contiguous()
             query, nq, q1 = x, 1, None
         qmap_n = ops.tokmap(0, nq, H, W, W1, W2)
         qmap_1 = ops.tokmap(0, 1, H, W, W1, W2)
@@ -413,7 +414,7 @@ class FAXModule(HipModule):
             dt = rt.get_compute_dtype()
             prior = self._plan("prior", [self.bev_embedding.learned_features],
                                lambda d_, dev: self.bev_embedding.learned_features.detach().permute(1, 2, 0).to(dt).contiguous())
-            x = prior[None].expand(batch, *prior.shape).contiguous()
+            x = prior[None].expand(batch, *prior.shape)     # stride-0 batch view: the kernels broadcast it, no copy
         for i, (cross_view, feature, layer) in enumerate(zip(self.cross_views, features, self.layers)):
             if i < first or i >= last:
                 continue

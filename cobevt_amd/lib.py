@@ -35,7 +35,7 @@ SIGNATURES = {
     "cobevt_fax_ray_embed": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, _vp]),
     "cobevt_fax_bev_embed": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                            ctypes.c_int, ctypes.c_int, _vp]),
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "cobevt_maxpool3x3s2": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            _vp]),
     "cobevt_to_nhwc": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

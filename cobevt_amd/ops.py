@@ -519,13 +519,21 @@ def ray_embed(i_inv, e_inv, image_plane, w_img, w_cam, hw, dim, dtype):
     return out
 
 
+def batch_broadcast(x):
+    """True for expand()-ed views whose leading dimension has stride 0 over one contiguous slice."""
+    return x.dim() >= 2 and x.shape[0] > 1 and x.stride(0) == 0 and x[0].is_contiguous()
+
+
 def bev_embed(e_inv, world, w_bev, b_bev, w_cam, x, n):
-    """x: (B, HW, D) -> query (B, n, HW, D)"""
+    """x: (B, HW, D), or a batch-broadcast view (stride 0 over B) of one (HW, D) prior -> query (B, n, HW, D)"""
     _need_cuda(e_inv, world, w_bev, b_bev, w_cam, x)
     b, hw, d = x.shape
+    bcast = batch_broadcast(x)
+    if not bcast:
+        x = x.contiguous()
     out = torch.empty((b, n, hw, d), device=x.device, dtype=x.dtype)
     rc = _L.load().cobevt_fax_bev_embed(_p(e_inv), _p(world), _p(w_bev), _p(b_bev), _p(w_cam), _p(x), _p(out),
-                                        dcode(x.dtype), b, n, hw, d, _stream())
+                                        dcode(x.dtype), b, n, hw, d, int(bcast), _stream())
     _L.check(rc, "cobevt_fax_bev_embed")
     return out
 
@@ -704,14 +712,17 @@ def attn_mlp_chain(a, skip, plan_p, plan_1, plan_2, post_ln=None, next_plan=None
     given the call returns (out, next_plan(out)) - computed inside the same launch when fused."""
     _need_cuda(a, skip)
     c, hd = plan_p.cout, plan_1.cout
+    skip_rows = 0
+    if skip is not None and batch_broadcast(skip) and skip.shape == a.shape:
+        skip_rows = skip[0].numel() // c           # one slice shared by the whole batch: the kernel indexes it modulo
     fusable = (USE_ROW_CHAIN and a.dtype == torch.bfloat16 and plan_p.wfrag_rows is not None and plan_1.wfrag_rows is not None
                and plan_2.wfrag_rows is not None and plan_2.kp_rows <= 256 and plan_1.has_ln and plan_1.act == 2 and plan_p.act == 0
                and plan_2.act == 0 and not plan_p.has_ln and not plan_2.has_ln and plan_p.K == c and plan_1.K == c
                and plan_2.K == hd and plan_2.cout == c and c <= 128 and c % 8 == 0 and hd <= 256 and hd % 8 == 0
                and plan_p.kp_rows == 128 and plan_1.kp_rows == 128 and a.shape[-1] == c and a.is_contiguous()
-               and (skip is None or (skip.is_contiguous() and skip.shape == a.shape)))
+               and (skip is None or skip_rows or (skip.is_contiguous() and skip.shape == a.shape)))
     if not fusable:
-        y = linear(a, plan_p, residual=skip)
+        y = linear(a, plan_p, residual=skip.contiguous() if skip is not None else None)
         z = linear(linear(y, plan_1), plan_2, residual=y)
         z = layernorm(z, post_ln[0], post_ln[1], post_ln[2]) if post_ln is not None else z
         return (z, linear(z, next_plan)) if next_plan is not None else z
@@ -721,12 +732,12 @@ def attn_mlp_chain(a, skip, plan_p, plan_1, plan_2, post_ln=None, next_plan=None
     nn_ = next_plan.cout if fuse_next else 0
     out_next = torch.empty(a.shape[:-1] + (nn_,), device=a.device, dtype=a.dtype) if fuse_next else None
     dims = _ints([0, m, c, hd, plan_2.kp_rows, nn_, int(next_plan.has_ln) if fuse_next else 0,
-                  next_plan.act if fuse_next else 0, ROW_CHAIN_ROWS])
+                  next_plan.act if fuse_next else 0, ROW_CHAIN_ROWS, skip_rows])
     pg, pb, pe = post_ln if post_ln is not None else (None, None, 0.0)
 
     def cost():
         flops = 2.0 * m * (c * c + 2 * c * hd + c * nn_)
-        return flops, float((3 if skip is not None else 2) * m * c * 2 + m * nn_ * 2 + (c * c + 2 * c * hd + c * nn_) * 2)
+        return flops, float((2 * m + (0 if skip is None else skip_rows or m)) * c * 2 + m * nn_ * 2 + (c * c + 2 * c * hd + c * nn_) * 2)
 
     with _timed("row_chain|C%d H%d M=%d%s%s" % (c, hd, m, " post" if post_ln is not None else "",
                                                   " +next%d" % nn_ if fuse_next else ""), cost):

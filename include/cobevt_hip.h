@@ -145,8 +145,10 @@ int cobevt_linear_rows_wfrag(const void* in, const void* wfrag, const float* bia
  * wp (C x 128), w1 (Hd x 128, LayerNorm affine folded in), w2 (C x Hdp), wnext (Nn x 128, LayerNorm affine / BN folded
  * in; nullable together with out_next [M][Nn]) are given in MFMA fragment order: rows zero-padded to a multiple of 128,
  * [rows/32][Kp/16][64 lanes][16 bytes] with lane = 32*half + row%32 holding bytes [32*kgroup + 16*half, +16) of its row,
- * so a wave's weight operand is one coalesced 1-KB load and no weight panel passes through LDS.  dims (int32[9]): dtype(0), M, C(<=128), Hd(<=256), Hdp, Nn,
- * next_ln (1 = normalise the stored `out` rows first), next_act (0 none, 1 ReLU, 2 GELU), rows per workgroup (0 = 32; 64).
+ * so a wave's weight operand is one coalesced 1-KB load and no weight panel passes through LDS.  dims (int32[10]): dtype(0), M, C(<=128), Hd(<=256), Hdp, Nn,
+ * next_ln (1 = normalise the stored `out` rows first), next_act (0 none, 1 ReLU, 2 GELU), rows per workgroup (0 = 32; 64),
+ * skip_rows (0 = M; a divisor of M: `skip` has that many rows and row m adds skip[m % skip_rows] - the learned prior
+ * broadcast over the batch, fax_modules.py:509-510).
  */
 int cobevt_attn_mlp_chain(const void* a, const void* skip, void* out, const void* wp, const float* bp, const void* w1,
                           const float* b1, const void* w2, const float* b2, const float* post_gamma,
@@ -179,10 +181,11 @@ int cobevt_layernorm(const void* in, const float* gamma, const float* beta, void
 int cobevt_fax_ray_embed(const float* I_inv, const float* E_inv, const float* image_plane, const float* w_img,
                          const float* w_cam, void* out, int dtype, int BN, int hw, int D, hipStream_t stream);
 
-/* BEV query embedding + prior, fax_modules.py:370-375,387-388.  out (B, n, hw, D). */
+/* BEV query embedding + prior, fax_modules.py:370-375,387-388.  out (B, n, hw, D).  x (B, hw, D), or with x_bcast = 1
+ * one (hw, D) prior shared by every b (the first pyramid level, fax_modules.py:509-510 repeat of the learned prior). */
 int cobevt_fax_bev_embed(const float* E_inv, const float* world, const float* w_bev, const float* b_bev,
                          const float* w_cam, const void* x, void* out, int dtype, int B, int n, int hw, int D,
-                         hipStream_t stream);
+                         int x_bcast, hipStream_t stream);
 
 /*
  * BEV query embedding + prior fused with the to_q LayerNorm + Linear that consumes it (fax_modules.py:370-375,387-388

@@ -390,6 +390,39 @@ def test_gemm_rows_fused_layernorm(cuda, dtype, k, n, rows):
     check(y, y2.float().cpu(), dtype, "gemm_rows vs igemm")
 
 
+@pytest.mark.parametrize("c,rows,batch,nn_", [(128, 96, 3, 128), (64, 50, 4, 0), (128, 1000, 2, 0)])
+def test_attn_mlp_chain_broadcast_skip(cuda, c, rows, batch, nn_):
+    """skip = one (rows, C) slice shared by every batch entry (the learned BEV prior at the first pyramid level,
+    fax_modules.py:509-510), passed as a stride-0 view: bit-identical to the materialised repeat"""
+    dtype, hd = torch.bfloat16, 2 * c
+    mk = lambda key, shape, fan: procedural_input(key, shape, 0) * math.sqrt(3.0 / fan)
+    g1, be1 = 0.8 + 0.4 * procedural_input("cb.g1", (c,), 0, 0, 1), procedural_input("cb.be1", (c,), 0, -0.2, 0.2)
+
+    class LN1(object):
+        weight, bias, eps = g1, be1, 1e-5
+    pp = ops.ConvPlan(mk("cb.wp", (c, c), c), None, dtype=dtype, device=cuda)
+    p1 = ops.ConvPlan(mk("cb.w1", (hd, c), c), procedural_input("cb.b1", (hd,), 0, -0.2, 0.2), act=2, dtype=dtype, device=cuda, ln=LN1)
+    p2 = ops.ConvPlan(mk("cb.w2", (c, hd), hd), procedural_input("cb.b2", (c,), 0, -0.2, 0.2), dtype=dtype, device=cuda)
+    pn = ops.ConvPlan(mk("cb.wn", (nn_, c), c), None, dtype=dtype, device=cuda, ln=LN1) if nn_ else None
+    a = procedural_input("cb.a", (batch, rows, c), 0, -2, 2).to(cuda).to(dtype)
+    prior = procedural_input("cb.s", (rows, c), 0, -1, 1).to(cuda).to(dtype)
+    view = prior[None].expand(batch, rows, c)
+    assert ops.batch_broadcast(view)
+    yb = ops.attn_mlp_chain(a, view, pp, p1, p2, None, next_plan=pn)
+    yc = ops.attn_mlp_chain(a, view.contiguous(), pp, p1, p2, None, next_plan=pn)
+    if nn_:
+        assert torch.equal(yb[0], yc[0]) and torch.equal(yb[1], yc[1])
+    else:
+        assert torch.equal(yb, yc)
+    ops.USE_ROW_CHAIN = False
+    try:
+        y3 = ops.attn_mlp_chain(a, view, pp, p1, p2, None)            # the three-GEMM path copes with the view too
+    finally:
+        ops.USE_ROW_CHAIN = True
+    y = yb[0] if nn_ else yb
+    assert (y.float() - y3.float()).abs().max().item() <= 3e-2 * y3.float().abs().max().item()
+
+
 @pytest.mark.parametrize("c,hd,rows,post,proj_bias,skip", [(128, 256, 1000, True, True, True), (128, 256, 130, False, False, True),
                                                            (64, 128, 70, False, False, True), (32, 64, 333, True, True, False)])
 def test_attn_mlp_chain_fused(cuda, c, hd, rows, post, proj_bias, skip):
@@ -762,3 +795,9 @@ def test_ray_and_bev_embed(cuda, dtype):
     we = we / (we.norm(dim=1, keepdim=True) + 1e-7)
     ref = nhwc(we).reshape(b, n, H, W, d) + rnd(x, dtype)[:, None]
     check(q.reshape(b, n, H, W, d), ref, dtype, "bev embed")
+    # the first pyramid level's x is one learned prior repeated over the batch: a stride-0 view, never materialised
+    prior = x[0].reshape(H * W, d).to(cuda).to(dtype)
+    args = (E.to(cuda), grid[:2].reshape(2, -1).contiguous().to(cuda), w_bev.to(cuda), b_bev.to(cuda), w_cam.to(cuda))
+    qb = ops.bev_embed(*args, prior[None].expand(b, H * W, d), n)
+    qc = ops.bev_embed(*args, prior[None].expand(b, H * W, d).contiguous(), n)
+    assert torch.equal(qb, qc)
