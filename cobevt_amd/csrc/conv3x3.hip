@@ -366,9 +366,12 @@ static int launch_conv3(Conv3Params p, hipStream_t stream) {
 #endif
 #ifdef COBEVT_CONV3_TRACE
 __device__ unsigned long long cobevt_conv3_trace[64];
+__device__ unsigned long long cobevt_conv3_rt[3 * 2048];    // per workgroup: s_memrealtime (100 MHz) at entry / exit, XCC id
 #define COBEVT_TRACE_MARK(i) do { if (logical == 0 && tid == 0) cobevt_conv3_trace[(i)] = __builtin_readcyclecounter(); } while (0)
+#define COBEVT_TRACE_RT(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) cobevt_conv3_rt[blockIdx.x * 3 + (i)] = (i) == 2 ? (unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15) : __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define COBEVT_TRACE_MARK(i) do {} while (0)
+#define COBEVT_TRACE_RT(i) do {} while (0)
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -420,6 +423,8 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* patch = smem;
+    COBEVT_TRACE_RT(0);
+    COBEVT_TRACE_RT(2);
 
     int logical;
     {
@@ -712,6 +717,7 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
         }
     }
     COBEVT_TRACE_MARK(40);
+    COBEVT_TRACE_RT(1);
 }
 
 template <typename T, int MT, int WN, int KS, int S>
@@ -819,5 +825,8 @@ extern "C" int cobevt_conv3x3_wfrag_nhwc(const void* in, const void* wfrag, cons
 #ifdef COBEVT_CONV3_TRACE
 extern "C" int cobevt_conv3_read_trace(unsigned long long* dst) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(cobevt_conv3_trace), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : 1;
+}
+extern "C" int cobevt_conv3_read_rt(unsigned long long* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(cobevt_conv3_rt), sizeof(unsigned long long) * 3 * 2048) == hipSuccess ? 0 : 1;
 }
 #endif

@@ -11,3 +11,9 @@ from .bev_seg_head import BevSegHead  # noqa: F401
 from .fuse_utils import regroup  # noqa: F401
 from .corpbevt import STTF, CorpBEVT  # noqa: F401
 from .fax_fused_transformer import FaxFusedTransformer  # noqa: F401
+# the data formats either side of the path
+from .camera_bev_postprocessor import CameraBevPostprocessor  # noqa: F401
+from .rgb_preprocessor import RgbPreProcessor  # noqa: F401
+from .intermediate_fusion_dataset import collate_batch  # noqa: F401
+from .train_utils import load_saved_model  # noqa: F401
+from .seg_utils import cal_iou_training, mean_IU, mean_precision  # noqa: F401

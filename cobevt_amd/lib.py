@@ -48,6 +48,8 @@ SIGNATURES = {
     "cobevt_channel_affine": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_long, ctypes.c_int, ctypes.c_long, _vp]),
     "cobevt_sttf_warp": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp]),
+    "cobevt_softmax_argmax": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    "cobevt_seg_class_counts": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
 }
 
 _lib = None

@@ -751,3 +751,39 @@ def attn_mlp_chain(a, skip, plan_p, plan_1, plan_2, post_ln=None, next_plan=None
     if next_plan is None:
         return out
     return out, (out_next if fuse_next else linear(out, next_plan))
+
+
+# ----------------------------------------------------------------------------------------------
+# downstream of the hot path: logits -> probabilities / class maps -> per-class pixel counts
+# ----------------------------------------------------------------------------------------------
+def softmax_argmax(seg_logits):
+    """(N, C, H, W) logits -> (softmax(dim=1) fp32 (N, C, H, W), argmax of the probabilities int64 (N, H, W));
+    CameraBevPostprocessor.softmax_argmax, camera_bev_postprocessor.py:55-59."""
+    _need_cuda(seg_logits)
+    if seg_logits.dim() != 4:
+        raise CobevtHipError("softmax_argmax expects (N, C, H, W) logits, got %s" % (tuple(seg_logits.shape),))
+    x = seg_logits.contiguous()
+    n, c, h, w = x.shape
+    prob = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+    seg_map = torch.empty((n, h, w), device=x.device, dtype=torch.int64)
+    rc = _L.load().cobevt_softmax_argmax(_p(x), _p(prob), _p(seg_map), dcode(x.dtype), n, c, h * w, _stream())
+    _L.check(rc, "cobevt_softmax_argmax")
+    return prob, seg_map
+
+
+def seg_class_counts(pred, gt, num_classes):
+    """pred, gt: (N, H, W) integer label maps -> (N, num_classes, 3) int64 counts (n_ii, t_i, n_ij) per class - what
+    seg_utils.py:25-50 (mean_IU) and :6-21 (mean_precision) reduce their masks to.  Labels outside [0, num_classes)
+    raise (the reference would treat them as further classes)."""
+    _need_cuda(pred, gt)
+    if pred.shape != gt.shape or pred.dim() != 3:
+        raise CobevtHipError("seg_class_counts expects two (N, H, W) maps, got %s and %s" % (tuple(pred.shape), tuple(gt.shape)))
+    p64, g64 = pred.to(torch.int64).contiguous(), gt.to(torch.int64).contiguous()
+    n, h, w = p64.shape
+    counts = torch.empty((n, num_classes + 1, 3), device=pred.device, dtype=torch.int64)
+    rc = _L.load().cobevt_seg_class_counts(_p(p64), _p(g64), _p(counts), n, h * w, num_classes, _stream())
+    _L.check(rc, "cobevt_seg_class_counts")
+    host = counts.cpu()
+    if int(host[:, num_classes, 0].sum()) or int(host[:, num_classes, 1].sum()):
+        raise CobevtHipError("seg_class_counts: labels outside [0, %d)" % num_classes)
+    return host[:, :num_classes]

@@ -235,6 +235,21 @@ int cobevt_resize_nhwc(const void* in, void* out, int dtype, int N, int H, int W
 int cobevt_channel_affine(const float* in, const float* scale, const float* shift, float* out, long N, int C, long HW,
                           hipStream_t stream);
 
+/* ---- downstream of the hot path: the logits -> scored maps -------------------------------------- */
+
+/* CameraBevPostprocessor.softmax_argmax, opv2v/opencood/data_utils/post_processor/camera_bev_postprocessor.py:55-59:
+ * prob = Softmax(dim=1)(logits) (fp32) and map = argmax(prob, dim=1) (int64; the first maximum wins, and it is the
+ * argmax of the rounded probabilities as in the reference, not of the logits).  logits (N, C, hw) planar, dtype 0 bf16 /
+ * 1 fp32, C <= 8; prob (N, C, hw) fp32; map (N, hw) int64. */
+int cobevt_softmax_argmax(const void* logits, float* prob, long long* map, int dtype, int N, int C, int hw,
+                          hipStream_t stream);
+
+/* The pixel counts mean_IU / mean_precision reduce their class masks to, opv2v/opencood/utils/seg_utils.py:6-50:
+ * counts[n][c] = (n_ii = |pred==c & gt==c|, t_i = |gt==c|, n_ij = |pred==c|) for c < K, and counts[n][K] =
+ * (|pred outside [0,K)|, |gt outside [0,K)|, 0).  pred, gt (N, hw) int64; counts (N, K + 1, 3) uint64, zeroed here. */
+int cobevt_seg_class_counts(const long long* pred, const long long* gt, unsigned long long* counts, int N, int hw, int K,
+                            hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,135 @@
+"""CPU restatement of the data formats either side of the hot path — TEST INFRASTRUCTURE ONLY
+(see oracle/__init__.py): the product never imports this.
+
+Follows, function by function:
+  standardize_rgb      opv2v/opencood/data_utils/pre_processor/rgb_preprocessor.py:16-33,35-44 (channel swap, /255.,
+                       (x - mean) / std in float64; the resize step :46-55 is cv2.resize and is NOT restated — cv2 is
+                       absent from the build image, "parity unpinned" for it)
+  bgr_to_gray_u8       cv2.cvtColor(BGR2GRAY) on uint8 as camera_bev_postprocessor.py:33 uses it: OpenCV's published
+                       fixed-point formula (B*1868 + G*9617 + R*4899 + 8192) >> 14.  Third-party (opencv-python, not
+                       pinned by the reference's requirements): parity unpinned.
+  generate_label       camera_bev_postprocessor.py:24-37
+  merge_label          camera_bev_postprocessor.py:39-53
+  softmax_argmax       camera_bev_postprocessor.py:55-59
+  post_process_train   camera_bev_postprocessor.py:61-89
+  mean_iu              opv2v/opencood/utils/seg_utils.py:25-50 (+ helpers :57-112)
+  mean_precision       seg_utils.py:6-21
+  cal_iou_training     seg_utils.py:115-155 (returns inside the loop: only sample 0 is scored)
+  collate_batch        opv2v/opencood/data_utils/datasets/camera_only/intermediate_fusion_dataset.py:231-317
+  find_last_checkpoint / load_saved_model   opv2v/opencood/tools/train_utils.py:24-65
+"""
+import glob
+import os
+import re
+
+import numpy as np
+import torch
+
+
+def standardize_rgb(image_u8, mean, std, bgr2rgb):
+    img = image_u8[..., ::-1] if bgr2rgb else image_u8
+    x = np.asarray(img, dtype=np.float64) / 255.0
+    return (x - np.asarray(mean, dtype=np.float64)) / np.asarray(std, dtype=np.float64)
+
+
+def bgr_to_gray_u8(bgr):
+    b = bgr[..., 0].astype(np.int64)
+    g = bgr[..., 1].astype(np.int64)
+    r = bgr[..., 2].astype(np.int64)
+    return ((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+
+
+def generate_label(bev_map_bgr_u8):
+    gray = bgr_to_gray_u8(bev_map_bgr_u8).astype(np.float64) / 255.0
+    return np.where(gray > 0, 1.0, gray)
+
+
+def merge_label(road_map, lane_map):
+    out = np.zeros(road_map.shape[:2], dtype=np.float64)
+    out[road_map == 1] = 1
+    out[lane_map == 1] = 2
+    return out
+
+
+def softmax_argmax(seg_logits):
+    prob = torch.softmax(seg_logits.float(), dim=1)
+    return prob, torch.argmax(prob, dim=1)
+
+
+def post_process_train(output_dict):
+    sp, sm = softmax_argmax(output_dict["static_seg"][:, 0])
+    dp, dm = softmax_argmax(output_dict["dynamic_seg"][:, 0])
+    out = dict(output_dict)
+    out.update({"static_prob": sp, "static_map": sm, "dynamic_prob": dp, "dynamic_map": dm})
+    return out
+
+
+def _classes(*maps):
+    return np.unique(np.concatenate([np.unique(m) for m in maps]))
+
+
+def mean_iu(pred, gt):
+    if pred.shape[:2] != gt.shape[:2]:
+        raise ValueError("DiffDim: Different dimensions of matrices!")
+    res = []
+    for c in _classes(pred, gt):
+        pm, gm = pred == c, gt == c
+        n_pred, n_gt = int(pm.sum()), int(gm.sum())
+        if n_pred == 0 or n_gt == 0:
+            res.append(0)
+            continue
+        inter = int(np.logical_and(pm, gm).sum())
+        res.append(inter / (n_gt + n_pred - inter))
+    return res
+
+
+def mean_precision(pred, gt):
+    if pred.shape[:2] != gt.shape[:2]:
+        raise ValueError("DiffDim: Different dimensions of matrices!")
+    res = []
+    for c in np.unique(gt):
+        pm, gm = pred == c, gt == c
+        n_pred = int(pm.sum())
+        res.append(0.0 if n_pred == 0 else int(np.logical_and(pm, gm).sum()) / float(n_pred))
+    return res
+
+
+def cal_iou_training(batch_dict, output_dict):
+    as_int = lambda t: np.asarray(t.detach().cpu().numpy(), dtype=np.int64)
+    gt_static = as_int(batch_dict["ego"]["gt_static"])[0, 0]
+    gt_dynamic = as_int(batch_dict["ego"]["gt_dynamic"])[0, 0]
+    return mean_iu(as_int(output_dict["dynamic_map"])[0], gt_dynamic), mean_iu(as_int(output_dict["static_map"])[0], gt_static)
+
+
+def collate_batch(batch, train=True):
+    if not train:
+        assert len(batch) == 1
+    egos = [b["ego"] for b in batch]
+    for e in egos:
+        assert e["camera_data"].shape[0] == e["camera_intrinsic"].shape[0] == e["camera_extrinsic"].shape[0]
+    cat = lambda key: torch.from_numpy(np.concatenate([e[key] for e in egos], axis=0)).unsqueeze(1).float()
+    stack = lambda key: torch.from_numpy(np.stack([e[key] for e in egos]))
+    return {"ego": {
+        "inputs": cat("camera_data"),
+        "extrinsic": cat("camera_extrinsic"),
+        "intrinsic": cat("camera_intrinsic"),
+        "gt_static": stack("gt_static").long(),
+        "gt_dynamic": stack("gt_dynamic").long(),
+        "transformation_matrix": stack("transformation_matrix").float(),
+        "pairwise_t_matrix": stack("pairwise_t_matrix").float(),
+        "record_len": torch.from_numpy(np.array([e["camera_data"].shape[0] for e in egos], dtype=int)),
+    }}
+
+
+def find_last_checkpoint(save_dir):
+    epochs = [int(re.findall(".*epoch(.*).pth.*", f)[0]) for f in glob.glob(os.path.join(save_dir, "*epoch*.pth"))]
+    return max(epochs) if epochs else 0
+
+
+def load_saved_model(saved_path, model):
+    assert os.path.exists(saved_path), "{} not found".format(saved_path)
+    epoch = find_last_checkpoint(saved_path)
+    if epoch > 0:
+        state = torch.load(os.path.join(saved_path, "net_epoch%d.pth" % epoch), map_location="cpu")
+        model.load_state_dict(state, strict=False)
+    return epoch, model

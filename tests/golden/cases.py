@@ -188,3 +188,55 @@ def nuscenes_inputs():
         ext[:, k] = np.linalg.inv(rz @ t @ axes)
     I = np.broadcast_to(intr, (c["b"], c["n"], 3, 3)).copy()
     return feats, image, torch.from_numpy(I.astype(np.float32)), torch.from_numpy(ext.astype(np.float32))
+
+
+# ---- data formats either side of the hot path: pre-processor, collate, post-processor, scores ----
+PRE_POST = dict(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225], image_hw=(12, 16), seg_hw=(24, 20))
+
+
+def pre_post_inputs():
+    """Deterministic inputs of gv12 (numpy RandomState is stable across numpy versions)."""
+    import numpy as np
+    rs = np.random.RandomState(1234)
+    h, w = PRE_POST["image_hw"]
+    sh, sw = PRE_POST["seg_hw"]
+    out = {"image_u8": rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8)}
+    # logits with exact ties, near ties, large magnitudes and a constant pixel
+    for name, c in (("static", 3), ("dynamic", 2)):
+        x = (rs.standard_normal((2, c, sh, sw)) * 3.0).astype(np.float32)
+        x[0, :, 0, 0] = 1.25                    # all classes tie -> class 0
+        x[0, 1:, 0, 1] = 2.5
+        x[0, 0, 0, 1] = -1.0                    # classes 1.. tie -> class 1
+        x[1, :, 1, 0] = np.float32(80.0)        # large equal logits
+        x[1, 0, 1, 1], x[1, c - 1, 1, 1] = np.float32(1.0), np.nextafter(np.float32(1.0), np.float32(2.0))   # one ulp apart
+        x[1, 0, 2, 2], x[1, 1, 2, 2] = np.float32(-90.0), np.float32(60.0)                                   # exp underflow
+        out[name + "_logits"] = x
+    # label maps: road / lane renderings and prediction / ground-truth pairs (one with a class missing from the prediction)
+    out["road"] = (rs.rand(sh, sw) > 0.5).astype(np.float64)
+    out["lane"] = (rs.rand(sh, sw) > 0.8).astype(np.float64)
+    out["bev_bgr"] = (rs.randint(0, 256, size=(sh, sw, 3)) * (rs.rand(sh, sw, 1) > 0.6)).astype(np.uint8)
+    out["bev_bgr"][0, :6] = [[0, 0, 0], [4, 0, 0], [5, 0, 0], [1, 0, 1], [2, 0, 1], [0, 1, 0]]     # around the gray > 0 threshold
+    pairs = []
+    for k, ncls in enumerate((3, 2, 3, 3)):
+        pred = rs.randint(0, ncls, size=(sh, sw)).astype(np.int64)
+        gt = rs.randint(0, ncls, size=(sh, sw)).astype(np.int64)
+        if k == 2:
+            pred[pred == 2] = 0                 # class 2 never predicted
+        if k == 3:
+            gt[:] = 1                           # single-class ground truth
+        pairs.append((pred, gt))
+    out["pairs"] = pairs
+    # two scenarios with 2 and 3 agents, 4 cameras of 6x8 pixels, max_cav 5
+    samples = []
+    for agents in (2, 3):
+        samples.append({"ego": {
+            "camera_data": rs.rand(agents, 4, 6, 8, 3),
+            "camera_intrinsic": rs.rand(agents, 4, 3, 3),
+            "camera_extrinsic": rs.rand(agents, 4, 4, 4),
+            "gt_static": rs.randint(0, 3, size=(1, sh, sw)),
+            "gt_dynamic": rs.randint(0, 2, size=(1, sh, sw)),
+            "transformation_matrix": rs.rand(5, 4, 4),
+            "pairwise_t_matrix": rs.rand(5, 5, 4, 4),
+        }})
+    out["samples"] = samples
+    return out

@@ -10,6 +10,7 @@ the reference never does.
 """
 import os
 import sys
+import types
 
 import numpy as np
 import torch
@@ -305,8 +306,75 @@ def gv11():
          keys=np.array(list(sd.keys())), shapes=np.array([",".join(str(int(d)) for d in v.shape) for v in sd.values()]))
 
 
+def gv12():
+    """Pre-processor / collate / post-processor / scores, from the reference's own functions.
+    Their modules import packages this image lacks (cv2, timm, open3d, matplotlib ...): those imports are satisfied with
+    inert mock modules - none of the functions replayed here calls into them (cv2.resize / cvtColor paths are NOT pinned)."""
+    import importlib
+    import tempfile
+    from unittest import mock
+    import torch.nn as nn
+    import oracle.pre_post as o_pp
+    for name in ("cv2", "timm", "timm.scheduler", "timm.scheduler.cosine_lr", "open3d", "matplotlib", "matplotlib.pyplot",
+                 "tensorboardX"):
+        try:
+            importlib.import_module(name)
+        except Exception:
+            sys.modules[name] = mock.MagicMock(name=name)
+    from opencood.data_utils.pre_processor.rgb_preprocessor import RgbPreProcessor as R_Rgb
+    from opencood.data_utils.post_processor.camera_bev_postprocessor import CameraBevPostprocessor as R_Post
+    from opencood.utils import seg_utils as R_seg
+    from opencood.tools import train_utils as R_train
+    from opencood.data_utils.datasets.camera_only.intermediate_fusion_dataset import CamIntermediateFusionDataset as R_Data
+
+    c, inp, out = cases.PRE_POST, cases.pre_post_inputs(), {}
+    # pre-processor (no channel swap / resize: both are cv2 calls)
+    pre = R_Rgb({"args": {"mean": c["mean"], "std": c["std"], "bgr2rgb": False, "resize_x": 0, "resize_y": 0}}, train=False)
+    std_img = pre.standalize(pre.normalize(inp["image_u8"]))
+    assert np.array_equal(std_img, o_pp.standardize_rgb(inp["image_u8"], c["mean"], c["std"], False))
+    out["standardized"] = std_img
+    # post-processor
+    post = R_Post({}, train=False)
+    logits = {k: torch.from_numpy(inp[k + "_logits"]) for k in ("static", "dynamic")}
+    ref = post.post_process_train({"static_seg": logits["static"][:, None], "dynamic_seg": logits["dynamic"][:, None]})
+    mine = o_pp.post_process_train({"static_seg": logits["static"][:, None], "dynamic_seg": logits["dynamic"][:, None]})
+    for k in ("static_prob", "static_map", "dynamic_prob", "dynamic_map"):
+        assert torch.equal(ref[k], mine[k]), k
+        out[k] = _np(ref[k])
+    merged = post.merge_label(inp["road"], inp["lane"])
+    assert np.array_equal(merged, o_pp.merge_label(inp["road"], inp["lane"]))
+    out["merged"] = merged
+    # scores
+    for i, (pred, gt) in enumerate(inp["pairs"]):
+        iu, mp = R_seg.mean_IU(pred, gt), R_seg.mean_precision(pred, gt)
+        assert list(iu) == o_pp.mean_iu(pred, gt) and list(mp) == o_pp.mean_precision(pred, gt)
+        out["iu%d" % i], out["precision%d" % i] = np.array(iu, dtype=np.float64), np.array(mp, dtype=np.float64)
+    # collate
+    holder = types.SimpleNamespace(train=True)
+    ref_b = R_Data.collate_batch(holder, inp["samples"])["ego"]
+    my_b = o_pp.collate_batch(inp["samples"], train=True)["ego"]
+    for k, v in ref_b.items():
+        assert v.dtype == my_b[k].dtype and torch.equal(v, my_b[k]), k
+        out["collate_" + k] = _np(v)
+        out["collate_dtype_" + k] = np.array(str(v.dtype))
+    # checkpoint discovery + non-strict load
+    with tempfile.TemporaryDirectory() as d:
+        net = nn.Linear(3, 2)
+        for ep in (3, 12, 7):
+            torch.save({"weight": torch.full((2, 3), float(ep)), "stray.key": torch.zeros(1)}, os.path.join(d, "net_epoch%d.pth" % ep))
+        ep, net = R_train.load_saved_model(d, net)
+        ep2, net2 = o_pp.load_saved_model(d, nn.Linear(3, 2))
+        assert ep == ep2 == 12 and torch.equal(net.weight, net2.weight)
+        out["loaded_epoch"], out["loaded_weight"] = np.array(ep), _np(net.weight)
+    with tempfile.TemporaryDirectory() as d:
+        ep, _ = R_train.load_saved_model(d, nn.Linear(3, 2))
+        assert ep == 0 == o_pp.load_saved_model(d, nn.Linear(3, 2))[0]
+        out["empty_epoch"] = np.array(ep)
+    save("gv12_pre_post", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gv0", "gv1", "gv2", "gv3", "gv4", "gv5", "gv6", "gv7", "gv8", "gv9", "gv10", "gv11"]
+    which = sys.argv[1:] or ["gv0", "gv1", "gv2", "gv3", "gv4", "gv5", "gv6", "gv7", "gv8", "gv9", "gv10", "gv11", "gv12"]
     for name in which:
         print("== " + name)
         globals()[name]()

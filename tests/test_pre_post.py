@@ -1,0 +1,197 @@
+"""The data formats either side of the hot path: RgbPreProcessor, collate_batch,
+CameraBevPostprocessor, seg_utils scores, load_saved_model.
+
+CPU part: oracle/pre_post.py and the host mirrors replayed against tests/golden/gv12_pre_post.npz (outputs of the
+REFERENCE's own functions, tests/golden/make_golden.py gv12).  Integer / index work bit-exact; float64 host arithmetic
+bit-exact (same numpy formulas); softmax probabilities 1e-6 absolute (fp32 exp of a different libm).
+GPU part (-m gpu): the HIP softmax+argmax and per-class count kernels through the C-ABI against the same fixtures."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import cases
+from cobevt_amd.host import camera_bev_postprocessor as h_post
+from cobevt_amd.host import intermediate_fusion_dataset as h_data
+from cobevt_amd.host import rgb_preprocessor as h_rgb
+from cobevt_amd.host import seg_utils as h_seg
+from cobevt_amd.host import train_utils as h_train
+from cobevt_amd.lib import CobevtHipError
+import oracle.pre_post as o_pp
+from util import golden
+
+PROB_TOL = 1e-6
+torch.set_grad_enabled(False)
+
+
+def _params(bgr2rgb=False, hw=None):
+    c = cases.PRE_POST
+    h, w = hw or c["image_hw"]
+    return {"args": {"mean": c["mean"], "std": c["std"], "bgr2rgb": bgr2rgb, "resize_x": w, "resize_y": h}}
+
+
+def test_oracle_matches_reference_fixtures():
+    g, inp, c = golden("gv12_pre_post"), cases.pre_post_inputs(), cases.PRE_POST
+    assert np.array_equal(g["standardized"], o_pp.standardize_rgb(inp["image_u8"], c["mean"], c["std"], False))
+    logits = {k: torch.from_numpy(inp[k + "_logits"]) for k in ("static", "dynamic")}
+    out = o_pp.post_process_train({"static_seg": logits["static"][:, None], "dynamic_seg": logits["dynamic"][:, None]})
+    for k in ("static_map", "dynamic_map"):
+        assert np.array_equal(g[k], out[k].numpy()), k
+    for k in ("static_prob", "dynamic_prob"):
+        assert np.abs(g[k] - out[k].numpy()).max() <= PROB_TOL, k
+    assert np.array_equal(g["merged"], o_pp.merge_label(inp["road"], inp["lane"]))
+    for i, (pred, gt) in enumerate(inp["pairs"]):
+        assert np.array_equal(g["iu%d" % i], np.array(o_pp.mean_iu(pred, gt), dtype=np.float64))
+        assert np.array_equal(g["precision%d" % i], np.array(o_pp.mean_precision(pred, gt), dtype=np.float64))
+    got = o_pp.collate_batch(inp["samples"], train=True)["ego"]
+    for k, v in got.items():
+        assert str(v.dtype) == str(g["collate_dtype_" + k]) and np.array_equal(g["collate_" + k], v.numpy()), k
+
+
+def test_rgb_preprocessor_host_mirror():
+    g, inp = golden("gv12_pre_post"), cases.pre_post_inputs()
+    pre = h_rgb.RgbPreProcessor(_params(), train=False)
+    assert np.array_equal(g["standardized"], pre.preprocess(inp["image_u8"]))
+    assert pre.preprocess(inp["image_u8"]).dtype == np.float64
+    # BGR -> RGB is a channel reversal; standardisation is per channel so it commutes with it
+    swapped = h_rgb.RgbPreProcessor(_params(bgr2rgb=True), train=False).preprocess(inp["image_u8"])
+    c = cases.PRE_POST
+    assert np.array_equal(swapped, o_pp.standardize_rgb(inp["image_u8"], c["mean"], c["std"], True))
+    # a resize needs OpenCV, which this image lacks: loud error, not a silent different interpolation
+    try:
+        import cv2  # noqa: F401
+    except ImportError:
+        with pytest.raises(CobevtHipError):
+            h_rgb.RgbPreProcessor(_params(hw=(6, 8)), train=False).preprocess(inp["image_u8"])
+
+
+def test_label_generation_host_mirror():
+    g, inp = golden("gv12_pre_post"), cases.pre_post_inputs()
+    post = h_post.CameraBevPostprocessor({}, train=False)
+    assert np.array_equal(g["merged"], post.merge_label(inp["road"], inp["lane"]))
+    lab = post.generate_label(inp["bev_bgr"])
+    assert lab.dtype == np.float64 and np.array_equal(lab, o_pp.generate_label(inp["bev_bgr"]))
+    # the crafted pixels around the gray > 0 threshold: B=4 -> 0, B=5 -> 1, (B,R)=(1,1) -> 0, (2,1) -> 1, G=1 -> 1
+    assert lab[0, :6].tolist() == [0.0, 0.0, 1.0, 0.0, 1.0, 1.0]
+
+
+def test_scores_host_arrays():
+    g, inp = golden("gv12_pre_post"), cases.pre_post_inputs()
+    for i, (pred, gt) in enumerate(inp["pairs"]):
+        assert np.array_equal(g["iu%d" % i], np.array(h_seg.mean_IU(pred, gt), dtype=np.float64))
+        assert np.array_equal(g["precision%d" % i], np.array(h_seg.mean_precision(pred, gt), dtype=np.float64))
+    with pytest.raises(h_seg.EvalSegErr):
+        h_seg.mean_IU(np.zeros((4, 5), dtype=np.int64), np.zeros((4, 6), dtype=np.int64))
+
+
+def test_collate_batch_host_mirror():
+    g, inp = golden("gv12_pre_post"), cases.pre_post_inputs()
+    got = h_data.collate_batch(inp["samples"], train=True)["ego"]
+    assert sorted(got.keys()) == sorted(k[len("collate_dtype_"):] for k in g.files if k.startswith("collate_dtype_"))
+    for k, v in got.items():
+        assert str(v.dtype) == str(g["collate_dtype_" + k]) and np.array_equal(g["collate_" + k], v.numpy()), k
+    assert got["inputs"].shape == (5, 1, 4, 6, 8, 3) and got["record_len"].tolist() == [2, 3]
+    with pytest.raises(AssertionError):
+        h_data.collate_batch(inp["samples"], train=False)            # evaluation batches hold one scenario
+
+
+def test_load_saved_model_host_mirror():
+    g = golden("gv12_pre_post")
+    with tempfile.TemporaryDirectory() as d:
+        for ep in (3, 12, 7):
+            torch.save({"weight": torch.full((2, 3), float(ep)), "stray.key": torch.zeros(1)}, os.path.join(d, "net_epoch%d.pth" % ep))
+        ep, net = h_train.load_saved_model(d, nn.Linear(3, 2))
+        assert ep == int(g["loaded_epoch"]) and np.array_equal(g["loaded_weight"], net.weight.detach().numpy())
+    with tempfile.TemporaryDirectory() as d:
+        assert h_train.load_saved_model(d, nn.Linear(3, 2))[0] == int(g["empty_epoch"]) == 0
+    with pytest.raises(AssertionError):
+        h_train.load_saved_model("/nonexistent/run/dir", nn.Linear(3, 2))
+
+
+def test_logit_side_has_no_cpu_fallback():
+    post = h_post.CameraBevPostprocessor({}, train=False)
+    with pytest.raises(CobevtHipError):
+        post.softmax_argmax(torch.zeros(1, 2, 4, 4))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_softmax_argmax_kernel(cuda, dtype):
+    g, inp = golden("gv12_pre_post"), cases.pre_post_inputs()
+    post = h_post.CameraBevPostprocessor({}, train=False)
+    for name in ("static", "dynamic"):
+        x = torch.from_numpy(inp[name + "_logits"])
+        prob, seg = post.softmax_argmax(x.to(cuda).to(dtype))
+        assert prob.dtype == torch.float32 and seg.dtype == torch.int64 and seg.shape == (x.shape[0],) + x.shape[2:]
+        if dtype == torch.float32:
+            ref_p, ref_m = g[name + "_prob"], g[name + "_map"]           # the reference's own outputs
+        else:
+            o_p, o_m = o_pp.softmax_argmax(x.to(dtype))                    # the oracle on the bf16-rounded logits
+            ref_p, ref_m = o_p.numpy(), o_m.numpy()
+        assert np.abs(prob.cpu().numpy() - ref_p).max() <= PROB_TOL
+        got = seg.cpu().numpy()
+        # the arg-max is taken over rounded probabilities: identical wherever the reference's top two differ by more than
+        # the probability tolerance, and on every exact tie (first class wins)
+        top2 = np.sort(ref_p, axis=1)[:, -2:]
+        decided = (top2[:, 1] - top2[:, 0]) > 2 * PROB_TOL
+        exact_tie = top2[:, 1] == top2[:, 0]
+        assert np.array_equal(got[decided], ref_m[decided])
+        assert np.array_equal(got[exact_tie], ref_m[exact_tie])
+        assert (got != ref_m).sum() <= 1                                  # at most the crafted one-ulp pixel
+        # the map IS the arg-max of the returned probabilities (first maximum)
+        assert torch.equal(seg, torch.argmax(prob, dim=1))
+
+
+@pytest.mark.gpu
+def test_softmax_argmax_full_size_properties(cuda):
+    """BASELINE-size head output (256 x 256, 2 and 3 classes): rows sum to 1, map == arg-max of prob, and the
+    probabilities agree with the oracle."""
+    for c in (2, 3):
+        x = torch.randn(2, c, 256, 256, generator=torch.Generator().manual_seed(c)) * 4
+        prob, seg = h_post.CameraBevPostprocessor({}, False).softmax_argmax(x.to(cuda))
+        assert (prob.sum(1) - 1).abs().max().item() <= 1e-6
+        assert torch.equal(seg, torch.argmax(prob, dim=1))
+        o_p, o_m = o_pp.softmax_argmax(x)
+        assert (prob.cpu() - o_p).abs().max().item() <= PROB_TOL
+        assert (seg.cpu() != o_m).float().mean().item() <= 1e-5
+
+
+@pytest.mark.gpu
+def test_scores_on_device_maps(cuda):
+    g, inp = golden("gv12_pre_post"), cases.pre_post_inputs()
+    for i, (pred, gt) in enumerate(inp["pairs"]):
+        p, t = torch.from_numpy(pred).to(cuda), torch.from_numpy(gt).to(cuda)
+        assert np.array_equal(g["iu%d" % i], np.array(h_seg.mean_IU(p, t), dtype=np.float64))
+        assert np.array_equal(g["precision%d" % i], np.array(h_seg.mean_precision(p, t), dtype=np.float64))
+        assert np.array_equal(g["iu%d" % i], np.array(h_seg.mean_IU(p, gt), dtype=np.float64))     # host ground truth is fine
+    # counts are exact at full size: compare with numpy bincount of the joint histogram
+    from cobevt_amd import ops
+    rs = np.random.RandomState(7)
+    pred, gt = rs.randint(0, 3, size=(3, 256, 256)), rs.randint(0, 3, size=(3, 256, 256))
+    counts = ops.seg_class_counts(torch.from_numpy(pred).to(cuda), torch.from_numpy(gt).to(cuda), 3).numpy()
+    for n in range(3):
+        for c in range(3):
+            assert counts[n, c].tolist() == [int(((pred[n] == c) & (gt[n] == c)).sum()), int((gt[n] == c).sum()), int((pred[n] == c).sum())]
+    with pytest.raises(CobevtHipError):
+        ops.seg_class_counts(torch.full((1, 8, 8), 5, device=cuda), torch.zeros((1, 8, 8), dtype=torch.int64, device=cuda), 3)
+
+
+@pytest.mark.gpu
+def test_post_process_and_iou_end_to_end(cuda):
+    """inference_camera.py:60-76: model output dict -> post_process -> cal_iou_training, device tensors throughout"""
+    inp = cases.pre_post_inputs()
+    sta, dyn = torch.from_numpy(inp["static_logits"]), torch.from_numpy(inp["dynamic_logits"])
+    batch = h_data.collate_batch(inp["samples"], train=True)
+    out = h_post.CameraBevPostprocessor({}, False).post_process(
+        batch["ego"], {"static_seg": sta[:, None].to(cuda), "dynamic_seg": dyn[:, None].to(cuda)})
+    iou_dynamic, iou_static = h_seg.cal_iou_training(batch, out)
+    ref = o_pp.post_process_train({"static_seg": sta[:, None], "dynamic_seg": dyn[:, None]})
+    # score the oracle's scores on OUR maps (they may differ from the oracle's on the one crafted near-tie pixel)
+    ref_dyn = o_pp.mean_iu(out["dynamic_map"][0].cpu().numpy(), batch["ego"]["gt_dynamic"][0, 0].numpy())
+    ref_sta = o_pp.mean_iu(out["static_map"][0].cpu().numpy(), batch["ego"]["gt_static"][0, 0].numpy())
+    assert iou_dynamic == ref_dyn and iou_static == ref_sta
+    assert (out["static_map"].cpu() != ref["static_map"]).sum().item() <= 1
