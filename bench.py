@@ -103,7 +103,7 @@ class Runner(object):
             return self.eager_step()
         self.graphs[0].replay()
         if self.world > 1:
-            self.fuse_in.copy_(cdist.exchange_features(self.feats, self.rank, self.world, self.agents))
+            cdist.exchange_features(self.feats, self.rank, self.world, self.agents, out=self.fuse_in)
         self.graphs[1].replay()
         return self.out
 
@@ -160,7 +160,7 @@ class PipelinedRunner(object):
 
     def _exchange(self, q):
         if self.world > 1:
-            self.g[q].copy_(cdist.exchange_features(self.f[q], self.rank, self.world, self.agents))
+            cdist.exchange_features(self.f[q], self.rank, self.world, self.agents, out=self.g[q])
 
     def _step_body(self, q):
         """slot q = step index mod depth: S1 writes kv[q]; the later stages read the slots written 1, 2, .. steps ago"""

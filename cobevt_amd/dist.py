@@ -47,17 +47,36 @@ def gather_index(frame, world, agents):
     return idx
 
 
-def exchange_features(local_feats, rank, world, agents, group=None):
-    """local_feats: (agents, ...) features of this rank's tasks -> (agents, ...) features of frame `rank`.
-    One all-gather; works for CPU (gloo) and device (RCCL) tensors."""
+_index_cache = {}
+
+
+def _gather_index_tensor(rank, world, agents, device):
+    """gather_index(...) as a device tensor, uploaded once: a per-step host->device copy from pageable memory would make
+    the host wait for the stream (i.e. for the previous graph replay) before it can enqueue the next step."""
+    key = (rank, world, agents, str(device))
+    idx = _index_cache.get(key)
+    if idx is None:
+        idx = torch.tensor(gather_index(rank, world, agents), dtype=torch.long).to(device)
+        _index_cache[key] = idx
+    return idx
+
+
+def exchange_features(local_feats, rank, world, agents, group=None, out=None):
+    """local_feats: (agents, ...) features of this rank's tasks -> (agents, ...) features of frame `rank` (written into
+    `out` when given).  One all-gather; works for CPU (gloo) and device (RCCL) tensors."""
     if world == 1:
+        if out is not None and out.data_ptr() != local_feats.data_ptr():
+            out.copy_(local_feats)
+            return out
         return local_feats
     assert local_feats.shape[0] == agents
     local_feats = local_feats.contiguous()
     gathered = torch.empty((world * agents,) + tuple(local_feats.shape[1:]), dtype=local_feats.dtype,
                            device=local_feats.device)
     dist.all_gather_into_tensor(gathered, local_feats, group=group)
-    idx = torch.tensor(gather_index(rank, world, agents), device=local_feats.device, dtype=torch.long)
+    idx = _gather_index_tensor(rank, world, agents, local_feats.device)
+    if out is not None:
+        return torch.index_select(gathered, 0, idx, out=out)
     return gathered.index_select(0, idx)
 
 
