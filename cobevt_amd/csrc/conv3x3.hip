@@ -55,19 +55,35 @@ template <typename T, int NT, int NPX, int BN> struct Conv3Store {
             const int item = tid + i * NT;
             const int px = item / CPP, cj = item - px * CPP;
             const int col = n0 + cj * CH;
-            int img, oy, ox;
-            off[i] = -1;
+            int img = 0, oy = 0, ox = 0;
             rres[i] = make_uint4(0, 0, 0, 0);
-            if (item < ITEMS && col < p.Cout && coord(px, img, oy, ox)) {
-                off[i] = (((long)img * p.Ho + oy) * p.Wo + ox) * p.Cout + col;
-                if (p.residual && vec) rres[i] = *(const uint4*)((const T*)p.residual + off[i]);
-            }
+            const bool ok = coord(px < NPX ? px : 0, img, oy, ox) & (item < ITEMS) & (col < p.Cout);
+            const long o = (((long)img * p.Ho + oy) * p.Wo + ox) * p.Cout + col;
+            off[i] = ok ? o : -1;
+        }
+        // all residual loads of the thread in flight together: unconditional (address clamped to element 0 for the
+        // lanes that store nothing) - a load under a divergent branch makes LLVM wait for vmcnt(0) right after it, which
+        // serialised these HBM round trips (3.4k cycles in the s_memtime trace of the strip kernel)
+        if (p.residual && vec) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) rres[i] = *(const uint4*)((const T*)p.residual + (off[i] < 0 ? 0 : off[i]));
         }
     }
 
     __device__ __forceinline__ void finish(const Conv3Params& p, const float* stage, int srow, int tid, int n0) {
         T* out = (T*)p.out;
         const bool vec = (p.Cout % CH) == 0;
+        // all staging reads of the thread first (unconditional, row clamped), then the arithmetic and the stores: under
+        // the per-item `off < 0` branch every item paid its own LDS round trip
+        float sv[NIT][CH];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int item = tid + i * NT;
+            const int px = item / CPP, cj = item - px * CPP;
+            const float* src = stage + (px < NPX ? px : 0) * srow + cj * CH;
+#pragma unroll
+            for (int e = 0; e < CH; ++e) sv[i][e] = src[e];
+        }
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             if (off[i] < 0) continue;
@@ -75,7 +91,7 @@ template <typename T, int NT, int NPX, int BN> struct Conv3Store {
             const int px = item / CPP, cj = item - px * CPP;
             float v[8], rv[8];
 #pragma unroll
-            for (int e = 0; e < CH; ++e) v[e] = stage[px * srow + cj * CH + e];
+            for (int e = 0; e < CH; ++e) v[e] = sv[i][e];
             if (vec) {
                 if (p.residual) {
                     chunk_to_f32<T>(rres[i], rv);
@@ -445,6 +461,24 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
     const int nsteps = nchunk * 9;
     const T* in = (const T*)p.in;
 
+    // (image, strip row, strip column) of the workgroup's MT strips, divided once by MT lanes: a runtime integer division
+    // is ~50 VALU instructions and the patch / store address set-up used to do two per 16-byte piece (the s_memtime
+    // trace showed 3.2k cycles in the store set-up alone)
+    __shared__ __attribute__((aligned(16))) int stab[8 * 4];
+    __shared__ __attribute__((aligned(16))) float sbias[BN];               // this tile's bias, fetched now: the epilogue must not start with a global round trip
+    if (tid >= NT - BN) {
+        const int c = n0 + tid - (NT - BN);
+        sbias[tid - (NT - BN)] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
+    }
+    if (tid < MT) {
+        const int q = q0 + tid;
+        const bool ok = q < nstrips;
+        const int img = ok ? q / per_img : 0, rem = ok ? q - img * per_img : 0;
+        const int sy = rem / p.tiles_x, sx = rem - sy * p.tiles_x;
+        *(int4*)&stab[tid * 4] = make_int4(img, sy, sx, ok ? 1 : 0);
+    }
+    __syncthreads();
+
     int pgoff[P_IT];        // element offsets (the host entry guarantees the input has < 2^31 elements)
     int plds[P_IT];         // < 0: nothing to write; otherwise bit 30 set = write zeros
 #pragma unroll
@@ -457,18 +491,12 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
             const int pix = r / PIECES, j = r - pix * PIECES;
             const int py = pix / PW, px = pix - py * PW;
             int lds = s * STRIP + py * PROW + px * PSTR + j * 16;
-            const int q = q0 + s;
-            bool valid = false;
-            if (q < nstrips) {
-                const int img = q / per_img, rem = q - img * per_img;
-                const int sy = rem / p.tiles_x, sx = rem - sy * p.tiles_x;
-                const int vy = sy * 2 - 1 + py, vx = sx * 16 - 1 + px;
-                if (vy >= 0 && vy < p.Ho && vx >= 0 && vx < p.Wo) {
-                    const int yy = p.upsample ? (vy >> 1) : vy, xx = p.upsample ? (vx >> 1) : vx;
-                    pgoff[it] = ((img * p.H + yy) * p.W + xx) * p.Cin + j * CH;
-                    valid = true;
-                }
-            }
+            const int4 sc = *(const int4*)&stab[s * 4];
+            const int img = sc.x, sy = sc.y, sx = sc.z;
+            const int vy = sy * 2 - 1 + py, vx = sx * 16 - 1 + px;
+            const bool valid = (sc.w != 0) & (vy >= 0) & (vy < p.Ho) & (vx >= 0) & (vx < p.Wo);
+            const int yy = p.upsample ? (vy >> 1) : vy, xx = p.upsample ? (vx >> 1) : vx;
+            pgoff[it] = valid ? ((img * p.H + yy) * p.W + xx) * p.Cin + j * CH : 0;
             plds[it] = valid ? lds : (lds | (1 << 30));
         }
     }
@@ -505,10 +533,9 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
                     const int pix = r / PIECES, j = r - pix * PIECES;
                     const int py = pix / PW, px = pix - py * PW;
                     dst[u] = st * STRIP + py * PROW + (px & 1) * C::PLANE + (px >> 1) * PSTR + j * 16;
-                    const int q = q0 + st;
-                    if (q < nstrips) {
-                        const int img = q / per_img, rem = q - img * per_img;
-                        const int sy = rem / p.tiles_x, sx = rem - sy * p.tiles_x;
+                    const int4 sc = *(const int4*)&stab[st * 4];
+                    if (sc.w) {
+                        const int img = sc.x, sy = sc.y, sx = sc.z;
                         const int vy = sy * 4 - 1 + py, vx = sx * 32 - 1 + px;
                         if (vy >= 0 && vy < p.H && vx >= 0 && vx < p.W)
                             v[u] = *(const uint4*)(in + ((img * p.H + vy) * p.W + vx) * p.Cin + j * CH + chunk * CC);
@@ -611,13 +638,10 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
         if (chunk < 4) COBEVT_TRACE_MARK(42 + 2 * chunk);
     };
     auto coord = [&](int px, int& im, int& oy, int& ox) {
-        const int q = q0 + (px >> 5);
-        if (q >= nstrips) return false;
-        im = q / per_img;
-        const int rem = q - im * per_img;
-        const int sy = rem / p.tiles_x, sx = rem - sy * p.tiles_x;
-        oy = sy * 2 + ((px >> 4) & 1); ox = sx * 16 + (px & 15);
-        return oy < p.Ho && ox < p.Wo;
+        const int4 sc = *(const int4*)&stab[(px >> 5) * 4];      // branch-free: one 16-byte LDS read, no dependent waits
+        im = sc.x;
+        oy = sc.y * 2 + ((px >> 4) & 1); ox = sc.z * 16 + (px & 15);
+        return (sc.w != 0) & (oy < p.Ho) & (ox < p.Wo);
     };
     // the last chunk is peeled so the residual loads of the store pass can be issued (unconditionally, keeping the
     // vmcnt waits counted) one chunk of MFMAs before they are needed
@@ -645,41 +669,38 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
 
     // ---- epilogue: the KS k-split partials meet in the fp32 staging tile [MT*32 pixels][BN].  With the operands
     // swapped a lane holds, per accumulator tile, one pixel (lane & 31) and four runs of four consecutive couts
-    // (8k + 4*(lane>>5) + 0..3), i.e. 16-byte staging accesses instead of sixteen scalar ones.
+    // (8k + 4*(lane>>5) + 0..3), i.e. 16-byte staging accesses instead of sixteen scalar ones.  The KS rounds rotate over
+    // the accumulator tiles - in round r the waves of k-split ks handle the tiles a with (a - r) mod KS == ks, storing
+    // partial + bias in round 0 and adding into the tile afterwards - so all eight waves work in every round (with
+    // "split kk stores / adds its whole accumulator in round kk" four, then two, of the eight idled: 4.3k-5.8k cycles).
     float* stage = (float*)smem;
     constexpr int SROW = C::SSTR / 4;
     {
         const int c0 = wn * 32 + 4 * h;
         float4 bias4[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float bb[4];
+        for (int k = 0; k < 4; ++k) bias4[k] = *(const float4*)&sbias[c0 + 8 * k];
+        COBEVT_TRACE_MARK(57);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = n0 + c0 + 8 * k + e;
-                bb[e] = (p.bias && ks == 0 && c < p.Cout) ? p.bias[c] : 0.f;
-            }
-            bias4[k] = make_float4(bb[0], bb[1], bb[2], bb[3]);
-        }
+        for (int r = 0; r < KS; ++r) {
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            if (ks == kk) {
+            for (int a = 0; a < MT; ++a) {
+                if (((a + KS - r) % KS) != ks) continue;
 #pragma unroll
-                for (int a = 0; a < MT; ++a)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        float4* d = (float4*)(stage + (a * 32 + ql) * SROW + c0 + 8 * k);
-                        float4 v = make_float4(acc[a][4 * k], acc[a][4 * k + 1], acc[a][4 * k + 2], acc[a][4 * k + 3]);
-                        if (kk == 0) {
-                            v.x += bias4[k].x; v.y += bias4[k].y; v.z += bias4[k].z; v.w += bias4[k].w;
-                        } else {
-                            const float4 o = *d;
-                            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                        }
-                        *d = v;
+                for (int k = 0; k < 4; ++k) {
+                    float4* d = (float4*)(stage + (a * 32 + ql) * SROW + c0 + 8 * k);
+                    float4 v = make_float4(acc[a][4 * k], acc[a][4 * k + 1], acc[a][4 * k + 2], acc[a][4 * k + 3]);
+                    if (r == 0) {
+                        v.x += bias4[k].x; v.y += bias4[k].y; v.z += bias4[k].z; v.w += bias4[k].w;
+                    } else {
+                        const float4 o = *d;
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                     }
+                    *d = v;
+                }
             }
             __syncthreads();
+            if (r == 0) COBEVT_TRACE_MARK(58);
         }
     }
     COBEVT_TRACE_MARK(39);
@@ -693,10 +714,9 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
         for (int item = tid; item < MT * 8 * cpp; item += NT) {
             const int qp = item / cpp, cj = item - qp * cpp;
             const int s = qp >> 3, qx = qp & 7;
-            const int q = q0 + s;
-            if (q >= nstrips) continue;
-            const int img = q / per_img, rem = q - img * per_img;
-            const int sy = rem / p.tiles_x, sx = rem - sy * p.tiles_x;
+            const int4 sc = *(const int4*)&stab[s * 4];
+            if (!sc.w) continue;
+            const int img = sc.x, sy = sc.y, sx = sc.z;
             const int oy2 = sy, ox2 = sx * 8 + qx;
             if (oy2 >= (p.Ho >> 1) || ox2 >= (p.Wo >> 1)) continue;
             float v[8];

@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tools", "_probe")
-MASKS = [0, 100]
+MASKS = [int(m) for m in os.environ.get("MASKS", "0,15,13,2").split(",")]
 
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     os.makedirs(OUT, exist_ok=True)
@@ -28,14 +28,14 @@ from cobevt_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 dtype = torch.bfloat16
-SHAPES = [(20, 32, 32, 256, 256), (20, 128, 128, 64, 64), (20, 16, 16, 512, 512)]
-VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "5,150,151").split(",")]
+SHAPES = [(20, 32, 32, 256, 256)]
+VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "150").split(",")]
 vp = ctypes.c_void_p
 
 
 def call(lib, x, plan, res, out, variant):
     n, h, w, cin = x.shape
-    dims = (ctypes.c_int * 12)(0, n, h, w, cin, plan.cout, 0, 1, 0, plan.cc3, plan.coutp3, variant)
+    dims = (ctypes.c_int * 13)(0, n, h, w, cin, plan.cout, 0, 1, 0, plan.cc3, plan.coutp3, variant, 1)
     rc = lib.cobevt_conv3x3_wfrag_nhwc(vp(x.data_ptr()), vp(plan.wfrag.data_ptr()), vp(plan.bias.data_ptr()),
                                        vp(res.data_ptr()), vp(out.data_ptr()), dims, vp(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, rc
@@ -62,14 +62,14 @@ for (n, h, w, cin, cout) in SHAPES:
             torch.cuda.synchronize()
             us = t0.elapsed_time(t1) / 20 * 1e3
             line = "%dx%dx%d %d->%d v%d knock %2d: %7.1f us %7.1f TF/s-equiv" % (n, h, w, cin, cout, variant, m, us, flops / us / 1e6)
-            if m % 100 == 0:
+            if True:
                 tr = (ctypes.c_ulonglong * 64)()
                 lib.cobevt_conv3_read_trace(tr)
                 t = list(tr)
                 nst = min(cin // 64 * 9, 36)
                 taps = [t[2 + i + 1] - t[2 + i] for i in range(nst - 1)]
-                line += "\n    trace (cycles): prologue %d, taps %s, main loop total %d, k-split reduce %d, store pass %d" % (
-                    t[1] - t[0], taps, t[38] - t[1], t[39] - t[38], t[40] - t[39])
+                line += "\n    trace (cycles): prologue %d, taps %s, main loop total %d, k-split reduce %d (bias ready %d, round 0 done %d), store pass %d" % (
+                    t[1] - t[0], taps, t[38] - t[1], t[39] - t[38], t[57] - t[38], t[58] - t[38], t[40] - t[39])
                 if variant >= 100:
                     nch = min(cin // 64, 4)
                     line += "\n    per chunk: tap8 start -> before barrier %s, barrier wait %s, after barrier -> next tap0 %s" % (
