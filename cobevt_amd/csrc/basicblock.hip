@@ -205,6 +205,13 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
     load_patch(0);
     load_b(bq[0], p.w1, 0);
     load_b(bq[1], p.w1, 1);
+    // both folded-BN biases into LDS now (visible after the chunk loop's barriers): neither epilogue starts with a global
+    // round trip
+    __shared__ __attribute__((aligned(16))) float sbias[2 * C];
+    if (tid < 2 * C) {
+        const float* b = tid < C ? p.b1 : p.b2;
+        sbias[tid] = b ? b[tid < C ? tid : tid - C] : 0.f;
+    }
 #pragma unroll 1
     for (int chunk = 0; chunk < NCH; ++chunk) {
         if (chunk > 0) __syncthreads();                         // every wave finished reading the previous chunk
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
         const int c0 = ct * 32 + 4 * h;
         float4 bias[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) bias[k] = p.b1 ? *(const float4*)(p.b1 + c0 + 8 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < 4; ++k) bias[k] = *(const float4*)&sbias[c0 + 8 * k];
 #pragma unroll
         for (int t = 0; t < T1W; ++t) {
             const int pr = (pg + t * NPG) * 32 + ql;
@@ -253,12 +260,9 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
         const int item = tid + i * NT;
         const int px = item / CPP, cj = item - px * CPP;
         const int oy = oy0 + px / TW, ox = ox0 + (px % TW);
-        soff[i] = -1;
-        rres[i] = make_uint4(0, 0, 0, 0);
-        if (oy < p.H && ox < p.W) {
-            soff[i] = ((img * p.H + oy) * p.W + ox) * C + cj * CH;
-            rres[i] = *(const uint4*)(in + soff[i]);
-        }
+        const bool ok = (oy < p.H) & (ox < p.W);
+        soff[i] = ok ? ((img * p.H + oy) * p.W + ox) * C + cj * CH : -1;
+        rres[i] = *(const uint4*)(in + (ok ? soff[i] : 0));      // unconditional (clamped): no vmcnt(0) after each load
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();                                            // patch2 complete
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
             const int px = (pg + t * NPG) * 32 + ql;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float4 b = p.b2 ? *(const float4*)(p.b2 + c0 + 8 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 b = *(const float4*)&sbias[C + c0 + 8 * k];
                 *(float4*)(stage + px * SROW + c0 + 8 * k) =
                     make_float4(acc[t][4 * k] + b.x, acc[t][4 * k + 1] + b.y, acc[t][4 * k + 2] + b.z, acc[t][4 * k + 3] + b.w);
             }
@@ -298,14 +302,20 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
     }
     __syncthreads();
     T* out = (T*)p.out;
+    float sv[S_IT][CH];                                          // every staging read of the thread in flight at once
+#pragma unroll
+    for (int i = 0; i < S_IT; ++i) {
+        const int item = tid + i * NT;
+        const int px = item / CPP, cj = item - px * CPP;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) sv[i][e] = stage[px * SROW + cj * CH + e];
+    }
 #pragma unroll
     for (int i = 0; i < S_IT; ++i) {
         if (soff[i] < 0) continue;
-        const int item = tid + i * NT;
-        const int px = item / CPP, cj = item - px * CPP;
         float v[8], rv[8];
 #pragma unroll
-        for (int e = 0; e < CH; ++e) v[e] = stage[px * SROW + cj * CH + e];
+        for (int e = 0; e < CH; ++e) v[e] = sv[i][e];
         chunk_to_f32<T>(rres[i], rv);
 #pragma unroll
         for (int e = 0; e < CH; ++e) v[e] = fmaxf(v[e] + rv[e], 0.f);

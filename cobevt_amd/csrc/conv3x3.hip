@@ -180,6 +180,13 @@ __global__ __launch_bounds__(kConv3Threads) void conv3x3_kernel(Conv3Params p) {
     const int nchunk = p.Cin / CC;
     const T* in = (const T*)p.in;
     const T* wg = (const T*)p.wgt;
+    float ebias[2];                                      // the epilogue's two bias values per lane, fetched up front
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int c = n0 + wn * 64 + b * 32 + ql;
+        ebias[b] = p.bias ? p.bias[p.bias && c < p.Cout ? c : 0] : 0.f;
+        if (c >= p.Cout) ebias[b] = 0.f;
+    }
 
     // ---- addresses computed once.  Every prefetch load below is UNCONDITIONAL (invalid items read a clamped, valid
     // address and are zeroed by a select when they are written to LDS): with loads under per-lane or uniform branches
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(kConv3Threads) void conv3x3_kernel(Conv3Params p) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int cl = wn * 64 + b * 32 + ql;            // column inside the BN tile
-        const float bias = (p.bias && n0 + cl < p.Cout) ? p.bias[n0 + cl] : 0.f;
+        const float bias = ebias[b];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = acc_row(r, lane);

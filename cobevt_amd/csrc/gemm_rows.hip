@@ -82,6 +82,13 @@ __global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, ql = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
+    float ebias[2];                                  // the epilogue's two bias values per lane, fetched up front (the
+#pragma unroll                                       // epilogue would otherwise start with a global round trip)
+    for (int b = 0; b < 2; ++b) {
+        const int c = n0 + wn * 64 + b * 32 + ql;
+        ebias[b] = p.bias ? p.bias[c < p.N ? c : 0] : 0.f;
+        if (c >= p.N) ebias[b] = 0.f;
+    }
     const int srow = tid >> 2, sub = tid & 3;        // staging: row of the tile, 64-byte quarter of the 256-byte row
     const T* in = (const T*)p.in;
     const T* wg = (const T*)p.wgt;
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int cl = wn * 64 + b * 32 + ql;
-        const float bias = (p.bias && n0 + cl < p.N) ? p.bias[n0 + cl] : 0.f;
+        const float bias = ebias[b];
 #pragma unroll
         for (int r = 0; r < 16; ++r) stage[(wm * 32 + acc_row(r, lane)) * SROW + cl] = acc[b][r] + bias;
     }
@@ -293,27 +300,41 @@ __global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams
             const int item = tid + i * kGrThreads;
             const int row = item / CPR, cj = item - row * CPR;
             const int m = m0 + row, col = n0 + cj * CH;
-            orow[i] = -1;
+            const bool ok = (m < p.M) & (col < p.N);
+            orow[i] = ok ? m : -1;
             rres[i] = make_uint4(0, 0, 0, 0);
-            if (m < p.M && col < p.N) {
-                orow[i] = m;
-                if (remap) {
-                    const int hw = p.src_H * p.src_W;
-                    const int n = m / hw, rem = m - n * hw;
-                    const int oh = rem / p.src_W, ow = rem - oh * p.src_W;
-                    orow[i] = ((long)n * p.out_H + oh) * p.out_W + ow;
-                }
-                if (p.residual) rres[i] = *(const uint4*)((const T*)p.residual + (size_t)m * p.N + col);
+            if (remap && ok) {
+                const int hw = p.src_H * p.src_W;
+                const int n = m / hw, rem = m - n * hw;
+                const int oh = rem / p.src_W, ow = rem - oh * p.src_W;
+                orow[i] = ((long)n * p.out_H + oh) * p.out_W + ow;
             }
+        }
+        if (p.residual) {                     // unconditional, clamped: all of the thread's residual loads in flight at once
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int item = tid + i * kGrThreads;
+                const int row = item / CPR, cj = item - row * CPR;
+                const int m = m0 + row, col = n0 + cj * CH;
+                const bool ok = (m < p.M) & (col < p.N);
+                rres[i] = *(const uint4*)((const T*)p.residual + (ok ? (size_t)m * p.N + col : 0));
+            }
+        }
+        float sv[NIT][CH];                    // and all staging reads
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int item = tid + i * kGrThreads;
+            const int row = item / CPR, cj = item - row * CPR;
+#pragma unroll
+            for (int e = 0; e < CH; ++e) sv[i][e] = stage[row * SROW + cj * CH + e];
         }
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             if (orow[i] < 0) continue;
-            const int item = tid + i * kGrThreads;
-            const int row = item / CPR, cj = item - row * CPR;
+            const int cj = (tid + i * kGrThreads) % CPR;
             float v[8], rv[8];
 #pragma unroll
-            for (int e = 0; e < CH; ++e) v[e] = stage[row * SROW + cj * CH + e];
+            for (int e = 0; e < CH; ++e) v[e] = sv[i][e];
             if (p.residual) {
                 chunk_to_f32<T>(rres[i], rv);
 #pragma unroll

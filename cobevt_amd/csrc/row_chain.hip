@@ -56,7 +56,14 @@ template <int ROWS> struct RcLds {
     static constexpr int Y = A + ROWS * kRcRow;          // y tile (bf16) ; staging of the next projection's output
     static constexpr int H = Y + ROWS * kRcRow;          // hidden tile [ROWS][528] ; fp32 staging of z
     static constexpr int TOTAL = H + ROWS * kRcHRow;
+    static constexpr int BIAS = TOTAL;                   // fp32 table of every bias / affine vector of the chain (below)
+    static constexpr int BYTES = TOTAL + 4 * 1536;       // 40,448 B at ROWS = 32: still four workgroups per CU
 };
+// bias table (floats): [0,128) bp, [128,384) b1, [384,512) b2, [512,640) post gamma, [640,768) post beta, [768,1536) bnext.
+// Filled once per workgroup, zero where a vector is absent or shorter: the phase epilogues read it with unconditional
+// ds_read_b128 instead of starting with a (branch-guarded -> vmcnt(0)) global round trip that also waited for the next
+// phase's weight-fragment prefetch.
+constexpr int kRcBp = 0, kRcB1 = 128, kRcB2 = 384, kRcPg = 512, kRcPb = 640, kRcBn = 768, kRcBnMax = 768, kRcBiasFloats = 1536;
 
 // normalise one row held by 8 lanes (16 channels each; channels >= C are zero on entry and on exit)
 __device__ __forceinline__ void rc_normalise(float (&v)[16], int sub, int C, float eps) {
@@ -114,11 +121,28 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
     };
     // this lane's four column runs: run k covers columns cbase + 8k .. +3 of the wave's 128-column panel
     const int cbase = wn * 32 + 4 * h;
-    auto bias4 = [&](const float* b, int col0, int n) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (b && col0 < n) v = *(const float4*)(b + col0);     // n % 8 == 0 and col0 % 4 == 0
-        return v;
-    };
+    const float* sb = (const float*)(smem + RcLds<ROWS>::BIAS);
+    {
+        // branch-free and unconditional (absent vectors read bp / b1, which are never null; out-of-range entries read
+        // element 0; both are zeroed by the select): all of a thread's loads are in flight together
+        float* w = (float*)(smem + RcLds<ROWS>::BIAS);
+        constexpr int NT = ROWS * 8, NIT = kRcBiasFloats / NT;
+        static_assert(kRcBiasFloats % NT == 0, "bias table fill");
+        float val[NIT];
+        bool keep[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * NT;
+            const float* src = i < kRcB1 ? p.bp : i < kRcB2 ? p.b1 : i < kRcPg ? p.b2 : i < kRcPb ? p.post_g : i < kRcBn ? p.post_b : p.bn;
+            const int j = i < kRcB1 ? i : i < kRcB2 ? i - kRcB1 : i < kRcPg ? i - kRcB2 : i < kRcPb ? i - kRcPg : i < kRcBn ? i - kRcPb : i - kRcBn;
+            const int n = i < kRcB1 ? p.C : i < kRcB2 ? p.Hd : i < kRcBn ? p.C : p.Nn;
+            keep[it] = (src != nullptr) & (j < n);
+            val[it] = (src ? src : p.b1)[keep[it] ? j : 0];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) w[tid + it * NT] = keep[it] ? val[it] : 0.f;
+    }
+    auto bias4 = [&](int table, int col0) { return *(const float4*)(sb + table + col0); };   // col0 % 4 == 0, inside the table
     auto pack4 = [&](float x, float y, float z, float w) { return make_uint2(pack_bf2(x, y), pack_bf2(z, w)); };
 
     uint4 fa[8], fb[8];
@@ -153,7 +177,7 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int col0 = cbase + 8 * k;
-        const float4 b = bias4(p.bp, col0, p.C);
+        const float4 b = bias4(kRcBp, col0);
         float v0 = acc[4 * k] + b.x + bf2f(skp[k].x & 0xffff), v1 = acc[4 * k + 1] + b.y + bf2f(skp[k].x >> 16);
         float v2 = acc[4 * k + 2] + b.z + bf2f(skp[k].y & 0xffff), v3 = acc[4 * k + 3] + b.w + bf2f(skp[k].y >> 16);
         if (col0 >= p.C) v0 = v1 = v2 = v3 = 0.f;
@@ -180,7 +204,7 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int col0 = pass * 128 + cbase + 8 * k;
-            const float4 b = bias4(p.b1, col0, p.Hd);
+            const float4 b = bias4(kRcB1, col0);
             uint2 o = make_uint2(0, 0);
             if (col0 < p.Hd) o = pack4(gelu_erf(acc[4 * k] + b.x), gelu_erf(acc[4 * k + 1] + b.y),
                                        gelu_erf(acc[4 * k + 2] + b.z), gelu_erf(acc[4 * k + 3] + b.w));
@@ -213,7 +237,7 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int col0 = cbase + 8 * k;
-        const float4 b = bias4(p.b2, col0, p.C);
+        const float4 b = bias4(kRcB2, col0);
         const uint2 y = *(const uint2*)(Ys + row * kRcRow + col0 * 2);
         float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         if (col0 < p.C)
@@ -237,9 +261,10 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
         if (p.post_g) {
             rc_normalise(v, sub, p.C, p.eps_post);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int c = sub * 16 + e;
-                v[e] = c < p.C ? v[e] * p.post_g[c] + p.post_b[c] : 0.f;
+            for (int e = 0; e < 16; e += 4) {          // channels >= C: gamma = beta = 0 in the table -> 0
+                const float4 g = *(const float4*)(sb + kRcPg + sub * 16 + e), b = *(const float4*)(sb + kRcPb + sub * 16 + e);
+                v[e] = v[e] * g.x + b.x; v[e + 1] = v[e + 1] * g.y + b.y;
+                v[e + 2] = v[e + 2] * g.z + b.z; v[e + 3] = v[e + 3] * g.w + b.w;
             }
         }
         uint4 o[2];
@@ -273,7 +298,7 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int col0 = pass * 128 + cbase + 8 * k;
-            const float4 b = bias4(p.bn, col0, p.Nn);
+            const float4 b = bias4(kRcBn, col0);
             float v0 = acc[4 * k] + b.x, v1 = acc[4 * k + 1] + b.y, v2 = acc[4 * k + 2] + b.z, v3 = acc[4 * k + 3] + b.w;
             if (p.next_act == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
             else if (p.next_act == 2) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
@@ -325,23 +350,23 @@ extern "C" int cobevt_attn_mlp_chain(const void* a, const void* skip, void* out,
     if (p.skip_rows > p.M || p.M % p.skip_rows) return COBEVT_ERR_SHAPE;
     if ((post_gamma == nullptr) != (post_beta == nullptr)) return COBEVT_ERR_ARG;
     if ((wnext == nullptr) != (out_next == nullptr)) return COBEVT_ERR_ARG;
-    if (wnext && (p.Nn < 8 || p.Nn % 8 || p.Nn > 1024 || p.next_act < 0 || p.next_act > 2)) return COBEVT_ERR_SHAPE;
+    if (wnext && (p.Nn < 8 || p.Nn % 8 || p.Nn > kRcBnMax || p.next_act < 0 || p.next_act > 2)) return COBEVT_ERR_SHAPE;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)row_chain_kernel<1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<64>::TOTAL);
-        (void)hipFuncSetAttribute((const void*)row_chain_kernel<2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<64>::TOTAL);
-        (void)hipFuncSetAttribute((const void*)row_chain_kernel<1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<32>::TOTAL);
-        (void)hipFuncSetAttribute((const void*)row_chain_kernel<2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<32>::TOTAL);
+        (void)hipFuncSetAttribute((const void*)row_chain_kernel<1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<64>::BYTES);
+        (void)hipFuncSetAttribute((const void*)row_chain_kernel<2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<64>::BYTES);
+        (void)hipFuncSetAttribute((const void*)row_chain_kernel<1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<32>::BYTES);
+        (void)hipFuncSetAttribute((const void*)row_chain_kernel<2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<32>::BYTES);
         attr_set = true;
     }
     const int rows = dims[8] == 64 ? 64 : 32;                  // dims[8]: rows per workgroup (0 = default 32)
     const unsigned blocks = (unsigned)((p.M + rows - 1) / rows);
     if (rows == 64) {
-        if (p.Hd > 128) hipLaunchKernelGGL((row_chain_kernel<2, 64>), dim3(blocks), dim3(512), RcLds<64>::TOTAL, stream, p);
-        else hipLaunchKernelGGL((row_chain_kernel<1, 64>), dim3(blocks), dim3(512), RcLds<64>::TOTAL, stream, p);
+        if (p.Hd > 128) hipLaunchKernelGGL((row_chain_kernel<2, 64>), dim3(blocks), dim3(512), RcLds<64>::BYTES, stream, p);
+        else hipLaunchKernelGGL((row_chain_kernel<1, 64>), dim3(blocks), dim3(512), RcLds<64>::BYTES, stream, p);
     } else {
-        if (p.Hd > 128) hipLaunchKernelGGL((row_chain_kernel<2, 32>), dim3(blocks), dim3(256), RcLds<32>::TOTAL, stream, p);
-        else hipLaunchKernelGGL((row_chain_kernel<1, 32>), dim3(blocks), dim3(256), RcLds<32>::TOTAL, stream, p);
+        if (p.Hd > 128) hipLaunchKernelGGL((row_chain_kernel<2, 32>), dim3(blocks), dim3(256), RcLds<32>::BYTES, stream, p);
+        else hipLaunchKernelGGL((row_chain_kernel<1, 32>), dim3(blocks), dim3(256), RcLds<32>::BYTES, stream, p);
     }
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

@@ -701,7 +701,7 @@ def channel_affine(x, scale, shift):
 def chain_next_fusable(plan_n, c):
     """Can `plan_n` (a Linear / 1x1 conv plan reading C-channel rows) ride at the end of the fused row chain?"""
     return (plan_n is not None and plan_n.wfrag_rows is not None and plan_n.stride == 1 and plan_n.kp_rows == 128 and plan_n.K == c
-            and plan_n.cout % 8 == 0 and plan_n.cout <= 1024 and plan_n.pre_scale is None and not plan_n.pre_relu)
+            and plan_n.cout % 8 == 0 and plan_n.cout <= 768 and plan_n.pre_scale is None and not plan_n.pre_relu)
 
 
 def attn_mlp_chain(a, skip, plan_p, plan_1, plan_2, post_ln=None, next_plan=None):

@@ -145,7 +145,7 @@ int cobevt_linear_rows_wfrag(const void* in, const void* wfrag, const float* bia
  * wp (C x 128), w1 (Hd x 128, LayerNorm affine folded in), w2 (C x Hdp), wnext (Nn x 128, LayerNorm affine / BN folded
  * in; nullable together with out_next [M][Nn]) are given in MFMA fragment order: rows zero-padded to a multiple of 128,
  * [rows/32][Kp/16][64 lanes][16 bytes] with lane = 32*half + row%32 holding bytes [32*kgroup + 16*half, +16) of its row,
- * so a wave's weight operand is one coalesced 1-KB load and no weight panel passes through LDS.  dims (int32[10]): dtype(0), M, C(<=128), Hd(<=256), Hdp, Nn,
+ * so a wave's weight operand is one coalesced 1-KB load and no weight panel passes through LDS.  dims (int32[10]): dtype(0), M, C(<=128), Hd(<=256), Hdp, Nn (<= 768),
  * next_ln (1 = normalise the stored `out` rows first), next_act (0 none, 1 ReLU, 2 GELU), rows per workgroup (0 = 32; 64),
  * skip_rows (0 = M; a divisor of M: `skip` has that many rows and row m adds skip[m % skip_rows] - the learned prior
  * broadcast over the batch, fax_modules.py:509-510).
