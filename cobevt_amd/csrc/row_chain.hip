@@ -82,7 +82,9 @@ __device__ __forceinline__ void rc_normalise(float (&v)[16], int sub, int C, flo
 }
 
 // NPASS: 128-column passes over the hidden layer (Hd <= 128 -> 1, else 2).  ROWS: rows per workgroup (8 threads per row).
-template <int NPASS, int ROWS>
+// FULL: C == 128, i.e. every operand row holds all eight 32-byte k-groups - the per-k-group `g < n` tests fold away and the
+// fragment loads / MFMAs become straight-line code (with runtime n each group sat behind its own uniform branch).
+template <int NPASS, int ROWS, bool FULL>
 __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem + RcLds<ROWS>::A;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
     const int h = lane >> 5, ql = lane & 31;
     const int wm = wave >> 2, wn = wave & 3;         // (ROWS / 32) x 4 waves, 32 rows x 32 columns each
     const int m0 = blockIdx.x * ROWS;
-    const int ngc = (p.C * 2 + 31) / 32;             // 32-byte k-groups covering C channels
+    const int ngc = FULL ? 8 : (p.C * 2 + 31) / 32;  // 32-byte k-groups covering C channels
     const int row = wm * 32 + ql;                    // this lane's row of the tile in every MFMA result
     const bool row_ok = m0 + row < p.M;
 
@@ -222,11 +224,11 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
         __syncthreads();
         // ---- phase D: z = hidden . W2^T
         mma(Hs, hbase, fb, 8, true);
-        if (p.wn) load_frags(fb, p.wn, wn, 8, 0, ngc);
+        load_frags(fb, p.wn ? p.wn : p.w1, wn, 8, 0, ngc);   // unconditional (w1 stands in when there is no next projection)
         mma(Hs, hbase + 256, fa, 8, false);
     } else {
         mma(As, abase, fb, ngc, true);
-        if (p.wn) load_frags(fb, p.wn, wn, 8, 0, ngc);
+        load_frags(fb, p.wn ? p.wn : p.w1, wn, 8, 0, ngc);   // unconditional (w1 stands in when there is no next projection)
         hidden_epilogue(0);
         __syncthreads();
         mma(Hs, hbase, fa, (p.Hd * 2 + 31) / 32, true);
@@ -323,6 +325,17 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
     }
 }
 
+template <int NPASS, int ROWS, bool FULL>
+static void launch_chain(const RowChainParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)row_chain_kernel<NPASS, ROWS, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<ROWS>::BYTES);
+        attr_set = true;
+    }
+    const unsigned blocks = (unsigned)((p.M + ROWS - 1) / ROWS);
+    hipLaunchKernelGGL((row_chain_kernel<NPASS, ROWS, FULL>), dim3(blocks), dim3(ROWS * 8), RcLds<ROWS>::BYTES, stream, p);
+}
+
 }  // namespace cobevt
 
 using namespace cobevt;
@@ -351,22 +364,14 @@ extern "C" int cobevt_attn_mlp_chain(const void* a, const void* skip, void* out,
     if ((post_gamma == nullptr) != (post_beta == nullptr)) return COBEVT_ERR_ARG;
     if ((wnext == nullptr) != (out_next == nullptr)) return COBEVT_ERR_ARG;
     if (wnext && (p.Nn < 8 || p.Nn % 8 || p.Nn > kRcBnMax || p.next_act < 0 || p.next_act > 2)) return COBEVT_ERR_SHAPE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)row_chain_kernel<1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<64>::BYTES);
-        (void)hipFuncSetAttribute((const void*)row_chain_kernel<2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<64>::BYTES);
-        (void)hipFuncSetAttribute((const void*)row_chain_kernel<1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<32>::BYTES);
-        (void)hipFuncSetAttribute((const void*)row_chain_kernel<2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<32>::BYTES);
-        attr_set = true;
-    }
     const int rows = dims[8] == 64 ? 64 : 32;                  // dims[8]: rows per workgroup (0 = default 32)
-    const unsigned blocks = (unsigned)((p.M + rows - 1) / rows);
+    const bool two = p.Hd > 128, full = p.C == 128;
     if (rows == 64) {
-        if (p.Hd > 128) hipLaunchKernelGGL((row_chain_kernel<2, 64>), dim3(blocks), dim3(512), RcLds<64>::BYTES, stream, p);
-        else hipLaunchKernelGGL((row_chain_kernel<1, 64>), dim3(blocks), dim3(512), RcLds<64>::BYTES, stream, p);
+        if (two) { if (full) launch_chain<2, 64, true>(p, stream); else launch_chain<2, 64, false>(p, stream); }
+        else { if (full) launch_chain<1, 64, true>(p, stream); else launch_chain<1, 64, false>(p, stream); }
     } else {
-        if (p.Hd > 128) hipLaunchKernelGGL((row_chain_kernel<2, 32>), dim3(blocks), dim3(256), RcLds<32>::BYTES, stream, p);
-        else hipLaunchKernelGGL((row_chain_kernel<1, 32>), dim3(blocks), dim3(256), RcLds<32>::BYTES, stream, p);
+        if (two) { if (full) launch_chain<2, 32, true>(p, stream); else launch_chain<2, 32, false>(p, stream); }
+        else { if (full) launch_chain<1, 32, true>(p, stream); else launch_chain<1, 32, false>(p, stream); }
     }
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
