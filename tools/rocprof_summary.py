@@ -2,7 +2,7 @@
 """Summarise a rocprofv3 --kernel-trace results .db (rocpd sqlite) into a per-kernel table (name, calls, total,
 avg, %), optionally listing the N longest dispatches, a per-(kernel, grid) table (--by-grid) and the dispatch timeline
 of the last graph replay (--timeline N: the last N dispatches with start offsets, gaps and overlap).
-Usage: rocprof_summary.py results.db [--top N] [--frames F] [--by-grid] [--timeline N]"""
+Usage: rocprof_summary.py results.db [--top N] [--frames F] [--by-grid] [--timeline N [--densest]] [--busy MS]"""
 import collections
 import re
 import sqlite3
@@ -58,6 +58,32 @@ def main():
             print("%9.1f %7.1f %6.1f  %6d wgs  %s" % ((s - t0) / 1e3, (e - s) / 1e3, gap, gx * gy * gz // max(wx, 1), short(n)[:70]))
             busy_end = max(busy_end, e)
         print("span %.1f us, idle (no kernel running) %.1f us" % ((busy_end - t0) / 1e3, idle))
+    if "--busy" in sys.argv:
+        # steady-state occupancy of the device over the last MS milliseconds of the trace: how much of the wall time has at
+        # least one kernel running, the average number of kernels in flight, and the CU-weighted occupancy (a dispatch
+        # with W workgroups is taken to occupy min(W, 256) / 256 of the chip for its duration - an upper bound)
+        ms = float(sys.argv[sys.argv.index("--busy") + 1])
+        skip = float(sys.argv[sys.argv.index("--busy-skip") + 1]) if "--busy-skip" in sys.argv else 0.0   # ms before the end
+        t_end = rows[-1][2] - skip * 1e6
+        win = [r for r in rows if t_end - ms * 1e6 <= r[1] and r[2] <= t_end]
+        t_end = win[-1][2]
+        t0 = win[0][1]
+        span = (t_end - t0) / 1e3
+        busy_end, union, gaps = t0, 0.0, []
+        for n, s, e, gx, gy, gz, wx, lds, vg, ag, sc in win:
+            if s > busy_end:
+                gaps.append((s - busy_end) / 1e3)
+                union += 0.0
+                busy_end_prev = busy_end
+            union += max(0.0, (e - max(s, busy_end)) / 1e3)
+            busy_end = max(busy_end, e)
+        total = sum((r[2] - r[1]) / 1e3 for r in win)
+        cu = sum((r[2] - r[1]) / 1e3 * min(r[3] * r[4] * r[5] // max(r[6], 1), 256) / 256.0 for r in win)
+        print("\nlast %.1f ms: %d dispatches over %.1f us; a kernel is running %.1f %% of the time (%d idle gaps, %.1f us in total, "
+              "longest %.1f us); kernels in flight on average %.2f; CU-weighted occupancy <= %.1f %%" %
+              (ms, len(win), span, 100.0 * union / span, len(gaps), sum(gaps), max(gaps) if gaps else 0.0, total / span, 100.0 * cu / span))
+        big = sorted(gaps, reverse=True)[:10]
+        print("largest idle gaps (us): %s" % ", ".join("%.1f" % g for g in big))
     if top:
         print("\nlongest %d dispatches:" % top)
         for n, s, e, gx, gy, gz, wx, lds, vg, ag, sc in sorted(rows, key=lambda r: r[1] - r[2])[:top]:
