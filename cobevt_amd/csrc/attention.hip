@@ -103,6 +103,10 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
     constexpr bool INFO = BIAS || MASK;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* bias_col = (float*)(smem + L::kFixed);
+    // per-key (row index, cam << 16 | i << 8 | j) of this window, computed ONCE per workgroup: the token -> row arithmetic
+    // is two runtime integer divisions (~50 VALU instructions each) and used to be redone by every staging item of every
+    // key tile - twelve times per key, ~330 integer VALU instructions per tile against ~250 for the softmax itself
+    int2* ktab = (int2*)(smem + L::kFixed + (BIAS ? ((p.bias_rows * 4 + 15) & ~15) : 0));
     float* red = (float*)smem;  // aliases the K/V tiles after the key loop (mean mode)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
@@ -132,6 +136,11 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
     if (BIAS) {
         for (int i = tid; i < p.bias_rows; i += nthr) bias_col[i] = p.bias_table[(size_t)i * p.heads + head];
     }
+    for (int tk = tid; tk < p.Nk; tk += nthr) {
+        const TokCoord kc = tok_coord(p.kmap, tk);
+        ktab[tk] = make_int2((int)tok_row(p.kmap, b, l, kc), (kc.cam << 16) | (kc.i << 8) | kc.j);
+    }
+    __syncthreads();
 
     // ---- staging registers (threads 0..255 stage; K_IT / V_IT items each)
     uint4 kreg[K_IT];
@@ -148,8 +157,10 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
             const int kk = item / CPR, cj = item - kk * CPR;
             const int tk = kt * kKeysPerTile + kk;
             const bool ok = tk < p.Nk;
-            const TokCoord kc = tok_coord(p.kmap, ok ? tk : 0);
-            const size_t row = tok_row(p.kmap, b, l, kc);
+            const int2 ke = ktab[ok ? tk : 0];
+            const size_t row = (size_t)ke.x;
+            TokCoord kc;
+            kc.cam = ke.y >> 16; kc.i = (ke.y >> 8) & 0xff; kc.j = ke.y & 0xff;
             kreg[it] = ok ? *(const uint4*)((const T*)p.k + row * p.ldk + p.koff + head * 32 + cj * CH) : make_uint4(0, 0, 0, 0);
             if (INFO) {
                 int info = -1;
@@ -177,11 +188,11 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
                 uint2 r0 = make_uint2(0, 0), r1 = make_uint2(0, 0);
                 const int tk = kt * kKeysPerTile + 2 * kp;
                 if (tk < p.Nk) {
-                    const size_t row = tok_row(p.kmap, b, l, tok_coord(p.kmap, tk));
+                    const size_t row = (size_t)ktab[tk].x;
                     r0 = *(const uint2*)((const T*)p.v + row * p.ldv + p.voff + head * 32 + dq * 4);
                 }
                 if (tk + 1 < p.Nk) {
-                    const size_t row = tok_row(p.kmap, b, l, tok_coord(p.kmap, tk + 1));
+                    const size_t row = (size_t)ktab[tk + 1].x;
                     r1 = *(const uint2*)((const T*)p.v + row * p.ldv + p.voff + head * 32 + dq * 4);
                 }
                 vreg[it] = make_uint4(r0.x, r0.y, r1.x, r1.y);
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
                 const int tk = kt * kKeysPerTile + kk;
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (tk < p.Nk) {
-                    const size_t row = tok_row(p.kmap, b, l, tok_coord(p.kmap, tk));
+                    const size_t row = (size_t)ktab[tk].x;
                     v = *(const uint4*)((const T*)p.v + row * p.ldv + p.voff + head * 32 + dq * 4);
                 }
                 vreg[it] = v;
@@ -430,7 +441,10 @@ extern "C" int cobevt_window_attention(const void* q, const void* k, const void*
     else { block = dim3(256); grid = dim3(p.L * p.heads, (p.Nq + 127) / 128, p.B); }
     if (grid.y > 65535 || grid.z > 65535) return COBEVT_ERR_SHAPE;
     size_t lds = dtype == 0 ? AttnLds<bf16_t>::kFixed : AttnLds<float>::kFixed;
-    if (p.bias_mode) lds += (size_t)p.bias_rows * 4;
+    if (p.bias_mode) lds += ((size_t)p.bias_rows * 4 + 15) & ~(size_t)15;
+    lds += (size_t)p.Nk * 8;                        // per-key row / coordinate table
+    if ((long)p.B * p.kmap.ncam * (p.kmap.mode == 2 ? (long)p.L * p.kmap.w1 * p.kmap.w2 : (long)p.kmap.HH * p.kmap.WW) >= 0x7fffffffL)
+        return COBEVT_ERR_UNSUPPORTED;              // the table holds 32-bit row indices
     if (p.mean_q) { const size_t need = (size_t)p.qmap.ncam * 16 * 64 * 4; if (need > lds) lds = need; }
     if (lds > 64 * 1024) return COBEVT_ERR_UNSUPPORTED;
     const bool hb = p.bias_mode != 0, hm = p.mask != nullptr;
