@@ -134,7 +134,8 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
             qf[g] = q_ok ? *(const uint4*)(qrow + g * (2 * CH) + h * CH) : make_uint4(0, 0, 0, 0);
     }
     if (BIAS) {
-        for (int i = tid; i < p.bias_rows; i += nthr) bias_col[i] = p.bias_table[(size_t)i * p.heads + head];
+        for (int i = tid; i < p.bias_rows; i += nthr)            // in the base-2 softmax domain already
+            bias_col[i] = p.bias_table[(size_t)i * p.heads + head] * 1.4426950408889634f;
     }
     for (int tk = tid; tk < p.Nk; tk += nthr) {
         const TokCoord kc = tok_coord(p.kmap, tk);
@@ -175,7 +176,9 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
                             valid = p.mask[(((size_t)b * p.kmap.HH + ph) * p.kmap.WW + pw) * p.kmap.ncam + kc.cam] != 0.f;
                         }
                     }
-                    if (valid) info = (kc.cam << 16) | (kc.i << 8) | kc.j;
+                    // the key's share of the relative-position index (the table index is linear in the coordinates:
+                    // index = query term - key term), -1 = masked out
+                    if (valid) info = BIAS ? (kc.cam * (2 * p.kmap.w1 - 1) + kc.i) * (2 * p.kmap.w2 - 1) + kc.j : 0;
                 }
                 ireg[it] = info;
             }
@@ -245,6 +248,10 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) ot[r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const float sl2 = p.scale * 1.4426950408889634f;  // softmax in base 2
+    // this lane's query term of the relative-position index (swap_fusion_modules.py:55-85, fax_modules.py:121-130):
+    // ((dl + L-1)(2 w1 - 1) + (di + w1-1))(2 w2 - 1) + (dj + w2-1) with d = query - key coordinate
+    const int bias_q = BIAS ? ((qc.cam + p.bias_L - 1) * (2 * p.kmap.w1 - 1) + qc.i + p.kmap.w1 - 1) * (2 * p.kmap.w2 - 1) +
+                                  qc.j + p.kmap.w2 - 1 : 0;
 
     load_tile(0);
     store_tile(0);
@@ -277,13 +284,12 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int info = kinfo[s * 32 + acc_row(r, lane)];
-                    float v = st[s][r] * sl2;
+                    float v;
                     if (BIAS) {
-                        const int lk = (info >> 16) & 0x7fff, ak = (info >> 8) & 0xff, bk = info & 0xff;
-                        int idx = ((qc.cam - lk + p.bias_L - 1) * (2 * p.kmap.w1 - 1) + (qc.i - ak + p.kmap.w1 - 1)) *
-                                      (2 * p.kmap.w2 - 1) + (qc.j - bk + p.kmap.w2 - 1);
-                        idx = info < 0 ? 0 : idx;
-                        v = fmaf(bias_col[idx], 1.4426950408889634f, v);
+                        const int idx = info < 0 ? 0 : bias_q - info;
+                        v = fmaf(st[s][r], sl2, bias_col[idx]);
+                    } else {
+                        v = st[s][r] * sl2;
                     }
                     v = info < 0 ? -INFINITY : v;
                     st[s][r] = v;
