@@ -134,8 +134,22 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
             qf[g] = q_ok ? *(const uint4*)(qrow + g * (2 * CH) + h * CH) : make_uint4(0, 0, 0, 0);
     }
     if (BIAS) {
-        for (int i = tid; i < p.bias_rows; i += nthr)            // in the base-2 softmax domain already
-            bias_col[i] = p.bias_table[(size_t)i * p.heads + head] * 1.4426950408889634f;
+        // in the base-2 softmax domain already.  Eight strided loads per thread in flight at a time: the rolled loop paid one
+        // global round trip per iteration (8 of them for the 2025-row 3-D table) before the first key tile could start
+        constexpr int BI = 8;
+        for (int base = 0; base < p.bias_rows; base += nthr * BI) {
+            float tv[BI];
+#pragma unroll
+            for (int u = 0; u < BI; ++u) {
+                const int i = base + u * nthr + tid;
+                tv[u] = p.bias_table[(size_t)(i < p.bias_rows ? i : p.bias_rows - 1) * p.heads + head];
+            }
+#pragma unroll
+            for (int u = 0; u < BI; ++u) {
+                const int i = base + u * nthr + tid;
+                if (i < p.bias_rows) bias_col[i] = tv[u] * 1.4426950408889634f;
+            }
+        }
     }
     for (int tk = tid; tk < p.Nk; tk += nthr) {
         const TokCoord kc = tok_coord(p.kmap, tk);
