@@ -287,16 +287,27 @@ __global__ __launch_bounds__(kStemPoolThreads, 4) void stem_pool_kernel(StemPara
     int tile = blockIdx.x;
     if (tile >= p.ntiles) return;
     {
+        // the first image patch is requested before the weights, and the weight pieces of a thread are all in flight at
+        // once (unconditional, row clamped): the rolled, branch-guarded loop paid one L2 round trip per iteration before the
+        // patch load could even be issued
+        load_patch(tile);
         constexpr int PIECES = 16 * 16 * Elem<T>::kBytes / 16;
-        for (int i = tid; i < 64 * PIECES; i += NT) {
+        constexpr int W_IT = (64 * PIECES + NT - 1) / NT;
+        uint4 wv[W_IT];
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int i = tid + it * NT;
             const int row = i / PIECES, j = i - row * PIECES;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row < p.Cout) v = *(const uint4*)((const unsigned char*)p.wgt + ((size_t)row * PIECES + j) * 16);
-            *(uint4*)(wl + row * C::WROW + j * 16) = v;
+            wv[it] = *(const uint4*)((const unsigned char*)p.wgt + ((size_t)(row < p.Cout ? row : 0) * PIECES + j) * 16);
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int i = tid + it * NT;
+            const int row = i / PIECES, j = i - row * PIECES;
+            if (i < 64 * PIECES) *(uint4*)(wl + row * C::WROW + j * 16) = row < p.Cout ? wv[it] : make_uint4(0, 0, 0, 0);
         }
     }
     __syncthreads();
-    load_patch(tile);
 
     // this wave's units: u = wave and u = wave + 8 (waves 0, 1): pixel tile u >> 1, cout half u & 1
     int abase[2], bbase[2], rpix[2], chalf[2];
