@@ -94,8 +94,19 @@ __global__ __launch_bounds__(256) void ray_embed_kernel(const float* I_inv, cons
         ce[e] = c.x * E[3] + c.y * E[7] + c.z * E[11] + c.w * E[15];
     }
     const int p0 = blockIdx.x * kEmbedPixPerBlock;
-    for (int pix = p0 + gp; pix < min(p0 + kEmbedPixPerBlock, hw); pix += ngroups) {
-        const float px = plane[pix], py = plane[hw + pix], pz = plane[2 * hw + pix];
+    constexpr int U = 4;                        // pixels of a lane group in flight together (the rolled loop paid one global
+    for (int pb = p0 + gp; pb < min(p0 + kEmbedPixPerBlock, hw); pb += ngroups * U) {   // round trip per pixel)
+        float pxs[U], pys[U], pzs[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = min(pb + u * ngroups, hw - 1);
+            pxs[u] = plane[q]; pys[u] = plane[hw + q]; pzs[u] = plane[2 * hw + q];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+        const int pix = pb + u * ngroups;
+        if (pix >= min(p0 + kEmbedPixPerBlock, hw)) break;
+        const float px = pxs[u], py = pys[u], pz = pzs[u];
         float cam[4];
 #pragma unroll
         for (int r = 0; r < 3; ++r) cam[r] = I[r * 3 + 0] * px + I[r * 3 + 1] * py + I[r * 3 + 2] * pz;
@@ -116,6 +127,7 @@ __global__ __launch_bounds__(256) void ray_embed_kernel(const float* I_inv, cons
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= inv;
         store8<T>(out + ((size_t)bn * hw + pix) * D + gl * 8, v);
+        }
     }
 }
 
@@ -141,8 +153,20 @@ __global__ __launch_bounds__(256) void bev_embed_kernel(const float* E_inv, cons
 #pragma unroll
     for (int e = 0; e < 8; ++e) bb[e] = b_bev[gl * 8 + e];
     const int p0 = blockIdx.x * kEmbedPixPerBlock;
-    for (int pix = p0 + gp; pix < min(p0 + kEmbedPixPerBlock, hw); pix += ngroups) {
-        const float wx = world[pix], wy = world[hw + pix];
+    constexpr int U = 4;                        // pixels of a lane group in flight together
+    for (int pb = p0 + gp; pb < min(p0 + kEmbedPixPerBlock, hw); pb += ngroups * U) {
+        float wxs[U], wys[U], xvs[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = min(pb + u * ngroups, hw - 1);
+            wxs[u] = world[q]; wys[u] = world[hw + q];
+            load8<T>(x + ((size_t)b * hw + q) * D + gl * 8, xvs[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+        const int pix = pb + u * ngroups;
+        if (pix >= min(p0 + kEmbedPixPerBlock, hw)) break;
+        const float wx = wxs[u], wy = wys[u];
         float v[8], ss = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -152,11 +176,10 @@ __global__ __launch_bounds__(256) void bev_embed_kernel(const float* E_inv, cons
         }
         ss = wave_sum_xor(ss, G);
         const float inv = 1.0f / (sqrtf(ss) + 1e-7f);
-        float xv[8];
-        load8<T>(x + ((size_t)b * hw + pix) * D + gl * 8, xv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * inv + xv[e];
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * inv + xvs[u][e];
         store8<T>(out + ((size_t)bn * hw + pix) * D + gl * 8, v);
+        }
     }
 }
 
