@@ -112,6 +112,13 @@ __device__ __forceinline__ void bb_conv_chunk(const unsigned char* patch, const 
     }
 }
 
+#ifdef COBEVT_BB_TRACE       // tools/bb_trace.py builds a copy of this file with s_memtime marks (never the product .so)
+__device__ unsigned long long cobevt_bb_trace[32];
+#define COBEVT_BB_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) cobevt_bb_trace[(i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define COBEVT_BB_MARK(i) do {} while (0)
+#endif
+
 template <typename T, int C, int TH_>
 __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 : 2) void basicblock_kernel(BasicBlockParams p) {
     using G = BBCfg<T, C, TH_>;
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
 
     const uint4* w1src = p.w1 + (size_t)ct * NSTEP * 256 + lane;
     const uint4* w2src = p.w2 + (size_t)ct * NSTEP * 256 + lane;
+    COBEVT_BB_MARK(0);
     load_patch(0);
     load_b(bq[0], p.w1, 0);
     load_b(bq[1], p.w1, 1);
@@ -218,7 +226,9 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
         store_patch();
         __syncthreads();
         if (chunk + 1 < NCH) load_patch(chunk + 1);
+        COBEVT_BB_MARK(1 + 2 * chunk);
         bb_conv_chunk<T, T1W>(patch1, a1, t1_ok, G::PITCH1, PSTR1, w1src, chunk * 9, NSTEP, bq, acc1);
+        COBEVT_BB_MARK(2 + 2 * chunk);
     }
     // conv2's first fragments while the intermediate is written (the ring slots 0 / 1 are free: NSTEP % 3 == 0)
     load_b(bq[0], p.w2, 0);
@@ -265,7 +275,9 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
         rres[i] = *(const uint4*)(in + (ok ? soff[i] : 0));      // unconditional (clamped): no vmcnt(0) after each load
     }
     __builtin_amdgcn_sched_barrier(0);
+    COBEVT_BB_MARK(8);
     __syncthreads();                                            // patch2 complete
+    COBEVT_BB_MARK(9);
 
     // ---- conv2 on the 8 x 16 tile: output pixel tiles pg, pg + NPG, ... (2 rows x 16 columns each)
     int a2[T2W];
@@ -282,7 +294,9 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
 #pragma unroll 1
     for (int chunk = 0; chunk < NCH; ++chunk)
         bb_conv_chunk<T, T2W>(patch2 + chunk * 128, a2, t2_ok, G::PITCH2, PSTR2, w2src, chunk * 9, NSTEP, bq, acc);
+    COBEVT_BB_MARK(10);
     __syncthreads();                                            // patch2 no longer read: stage over the patches
+    COBEVT_BB_MARK(11);
 
     // ---- epilogue: fp32 staging [128 pixels][C], then + residual, ReLU, 16-byte stores
     float* stage = (float*)smem;
@@ -301,6 +315,7 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
         }
     }
     __syncthreads();
+    COBEVT_BB_MARK(12);
     T* out = (T*)p.out;
     float sv[S_IT][CH];                                          // every staging read of the thread in flight at once
 #pragma unroll
@@ -321,6 +336,7 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
         for (int e = 0; e < CH; ++e) v[e] = fmaxf(v[e] + rv[e], 0.f);
         *(uint4*)(out + soff[i]) = f32_to_chunk<T>(v);
     }
+    COBEVT_BB_MARK(13);
 }
 
 template <typename T, int C, int TH_>
@@ -365,3 +381,9 @@ extern "C" int cobevt_basicblock_nhwc(const void* in, const void* wfrag1, const 
     if (c == 128) return dtype == 0 ? launch_basicblock<bf16_t, 128, 8>(p, stream) : launch_basicblock<float, 128, 8>(p, stream);
     return COBEVT_ERR_UNSUPPORTED;
 }
+
+#ifdef COBEVT_BB_TRACE
+extern "C" int cobevt_bb_read_trace(unsigned long long* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(cobevt_bb_trace), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : 1;
+}
+#endif
