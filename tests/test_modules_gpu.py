@@ -187,6 +187,35 @@ def test_corpbevt_small_end_to_end(cuda, dtype, tol):
     assert_close(out2["dynamic_seg"], golden("gv8_fax_fused_small")["dynamic_seg"], tol, "FaxFusedTransformer.small")
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+def test_corpbevt_ragged_scenarios_vs_oracle(cuda, dtype, tol):
+    """a training-style batch of several scenarios with different agent counts (collate_batch concatenates the agents of
+    all scenarios, record_len says how many belong to each, intermediate_fusion_dataset.py:261-295): regroup pads every
+    scenario to max_cav and the masks keep the absent agents out of the fusion attention.  Reduced config, oracle on the
+    CPU; includes a single-agent scenario and one that fills max_cav."""
+    cfg = synth.corpbevt_small_config()
+    m = fill_module_(host.CorpBEVT(copy.deepcopy(cfg)), cases.SEED).eval()
+    record_len = [2, 1, 3]
+    full = synth.opv2v_batch(agents=3, cams=2, image=128, max_cav=3, seed=cases.SEED + 1, batch=len(record_len))
+    keep = [s * 3 + a for s, n in enumerate(record_len) for a in range(n)]          # drop the agents a scenario lacks
+    batch = {k: full[k][keep] for k in ("inputs", "intrinsic", "extrinsic")}
+    batch["transformation_matrix"] = full["transformation_matrix"]
+    batch["record_len"] = torch.tensor(record_len, dtype=torch.int64)
+    ref = o_model.corpbevt_forward(m.state_dict(), cfg, batch)["dynamic_seg"]
+    m = m.to(cuda)
+    with host.compute_dtype(dtype):
+        out = m({k: v.to(cuda) for k, v in batch.items()})["dynamic_seg"]
+    assert tuple(out.shape) == tuple(ref.shape) and out.shape[0] == len(record_len)
+    assert_close(out, ref.numpy(), tol, "CorpBEVT ragged scenarios")
+    # a scenario's result does not depend on its neighbours in the batch: scenario 1 alone gives the same logits
+    solo = {k: batch[k][2:3] for k in ("inputs", "intrinsic", "extrinsic")}
+    solo["transformation_matrix"] = batch["transformation_matrix"][1:2]
+    solo["record_len"] = torch.tensor([1], dtype=torch.int64)
+    with host.compute_dtype(dtype):
+        alone = m({k: v.to(cuda) for k, v in solo.items()})["dynamic_seg"]
+    assert_close(alone[0], out[1].cpu().numpy(), tol, "scenario independent of its batch neighbours")
+
+
 def test_corpbevt_full_config_two_agents_vs_oracle(cuda):
     """BASELINE config[2] shape (2 agents x 4 cams x 512^2 -> 256^2 BEV, ResNet-34, full corpbevt.yaml) against the
     oracle run on the host CPU: fp32 mode <= 1e-3 rel, bf16 mode <= 5e-2 rel + arg-max agreement."""
