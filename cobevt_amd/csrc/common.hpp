@@ -112,6 +112,16 @@ __device__ __forceinline__ float erf_as(float x) {
 // exact (erf) GELU of the reference: nn.GELU() default
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 
+// epilogue activations by code: 0 none, 1 ReLU, 2 exact GELU, 3 swish x * sigmoid(x) (EfficientNet MBConv), 4 sigmoid
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float apply_act(float x, int act) {
+    if (act == 1) return fmaxf(x, 0.f);
+    if (act == 2) return gelu_erf(x);
+    if (act == 3) return x * sigmoid_f(x);
+    if (act == 4) return sigmoid_f(x);
+    return x;
+}
+
 __device__ __forceinline__ float wave_sum_xor(float v, int width) {
     for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;

@@ -4,3 +4,4 @@ from .encoder_pyramid_axial import Normalize, PyramidAxialEncoder  # noqa: F401
 from .decoder import Decoder, DecoderBlock  # noqa: F401
 from .cvt import CrossViewTransformer  # noqa: F401
 from .backbones import FeatureMapBackbone  # noqa: F401
+from .efficientnet import EfficientNetExtractor  # noqa: F401

@@ -1,11 +1,12 @@
 """Backbone contract of PyramidAxialEncoder: any module with `.output_shapes` (list of (1, C, h, w)) whose forward
 maps normalised images (b*n, 3, H, W) to that list of feature maps (efficientnet.py:24-110).
 
-EfficientNet-B4 (efficientnet-pytorch 0.7.1) is not in the reference tree nor in this environment, and its
-arithmetic is not restated ("parity unpinned").  FeatureMapBackbone stands in for it wherever
-a backbone object is needed: it returns fixed feature maps of the shapes the shipped config produces
-(reduction_2..4 of EfficientNet-B4 at 224x480: (32,56,120), (56,28,60), (112,14,30)), so the FAX encoder / decoder —
-the part this repository accelerates — can be exercised and measured end to end."""
+The real backbone of the shipped config is EfficientNetExtractor (efficientnet.py in this package: EfficientNet-B4 of
+efficientnet-pytorch 0.7.1 restated from its published definition, "parity unpinned" for that third-party arithmetic).
+FeatureMapBackbone returns fixed feature maps of the shapes the shipped config produces (the extractor's outputs at
+224x480: (32,56,120), (56,28,60), (112,14,30)); it is what the reference-generated fixture gv11 was made with (the
+reference itself could only be run with stand-in features here), so the FAX encoder / decoder can be replayed against the
+reference's own outputs."""
 import torch
 import torch.nn as nn
 

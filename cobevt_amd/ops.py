@@ -161,13 +161,18 @@ class ConvPlan(object):
 
     def __init__(self, weight, bias=None, bn=None, pre_bn=None, pre_relu=False, stride=1, pad=0, act=0,
                  upsample=False, store_mode=0, dtype=torch.bfloat16, device="cuda", smallc=False, ln=None,
-                 ln_folded_eps=None):
+                 ln_folded_eps=None, pad_br=None):
         """ln = nn.LayerNorm-like (weight, bias, eps) applied to the input rows of a Linear / 1x1 layer: its affine
         is folded here (W' = W diag(gamma), b' = b + W beta) so the kernels only have to normalise."""
         w = weight.detach().double().cpu()
         if w.dim() == 2:
             w = w[:, :, None, None]
         cout, cin, kh, kw = w.shape
+        # pad = zero rows / columns before the first input pixel (top, left); pad_br = after the last one (bottom, right) when
+        # it differs - TensorFlow-"same" padding of the EfficientNet stem.  Only the generic implicit GEMM takes the
+        # asymmetric form (its gather bounds-checks every tap).
+        asym = pad_br is not None and int(pad_br) != int(pad)
+        self.pad_br = int(pad if pad_br is None else pad_br)
         b = bias.detach().double().cpu() if bias is not None else torch.zeros(cout, dtype=torch.float64)
         has_bias = bias is not None or bn is not None
         self.has_ln, self.ln_eps = False, 0.0
@@ -217,7 +222,7 @@ class ConvPlan(object):
             self.klut = code.to(torch.int32).to(device).contiguous()
         # 3x3 / stride 1 / pad 1 fast path (conv3x3.hip): weights [Cout][Cin/cc][9][cc]
         self.wgt3, self.cc3 = None, 0
-        if kh == 3 and kw == 3 and int(stride) in (1, 2) and int(pad) == 1 and not smallc and pre_bn is None \
+        if kh == 3 and kw == 3 and int(stride) in (1, 2) and int(pad) == 1 and not asym and int(act) <= 2 and not smallc and pre_bn is None \
                 and int(store_mode) in (0, 1) and not (int(stride) == 2 and (upsample or int(store_mode) != 0)):
             cands = (64, 32) if self.code == BF16 else (32, 16)
             for cc in cands:
@@ -240,7 +245,7 @@ class ConvPlan(object):
         # ResNet stem fast path (stem7x7.hip): 7x7 / stride 2 / pad 3 on 3 channels as a 4x4 conv on the 2x2
         # space-to-depth image; W'[n][a][b][dy][dx][c] = w[n][c][2a+dy-1][2b+dx-1]
         self.wgt_stem = None
-        if smallc and kh == 7 and kw == 7 and int(stride) == 2 and int(pad) == 3 and cin == 3 and pre_bn is None \
+        if smallc and kh == 7 and kw == 7 and int(stride) == 2 and int(pad) == 3 and not asym and int(act) <= 2 and cin == 3 and pre_bn is None \
                 and int(store_mode) == 0 and not upsample and cout % (8 if self.code == BF16 else 4) == 0:
             ws = torch.zeros(cout, 4, 4, 16, dtype=torch.float64)
             for a in range(4):
@@ -253,7 +258,7 @@ class ConvPlan(object):
             self.wgt_stem = ws.reshape(cout, 256).to(torch.float32).to(dtype).to(device).contiguous()
         # dense-row GEMM fast path (gemm_rows.hip) for 1x1 / stride 1: weights [Cout][K rounded to a 256-byte tile]
         self.wgt_rows, self.kp_rows, self.wfrag_rows = None, 0, None
-        if kh == 1 and kw == 1 and int(stride) in (1, 2) and int(pad) == 0 and not smallc and int(store_mode) == 0 \
+        if kh == 1 and kw == 1 and int(stride) in (1, 2) and int(pad) == 0 and not asym and not smallc and int(store_mode) == 0 \
                 and not upsample:
             tk = 128 if self.code == BF16 else 64
             kp = (K + tk - 1) // tk * tk
@@ -277,7 +282,8 @@ class ConvPlan(object):
 
     def out_hw(self, h, w):
         hv, wv = (2 * h, 2 * w) if self.upsample else (h, w)
-        return (hv + 2 * self.pad - self.kh) // self.stride + 1, (wv + 2 * self.pad - self.kw) // self.stride + 1
+        return ((hv + self.pad + self.pad_br - self.kh) // self.stride + 1,
+                (wv + self.pad + self.pad_br - self.kw) // self.stride + 1)
 
 
 def ln_fusable(plan):
@@ -701,7 +707,8 @@ def channel_affine(x, scale, shift):
 def chain_next_fusable(plan_n, c):
     """Can `plan_n` (a Linear / 1x1 conv plan reading C-channel rows) ride at the end of the fused row chain?"""
     return (plan_n is not None and plan_n.wfrag_rows is not None and plan_n.stride == 1 and plan_n.kp_rows == 128 and plan_n.K == c
-            and plan_n.cout % 8 == 0 and plan_n.cout <= 768 and plan_n.pre_scale is None and not plan_n.pre_relu)
+            and plan_n.cout % 8 == 0 and plan_n.cout <= 768 and plan_n.pre_scale is None and not plan_n.pre_relu
+            and plan_n.act <= 2)
 
 
 def attn_mlp_chain(a, skip, plan_p, plan_1, plan_2, post_ln=None, next_plan=None):
@@ -787,3 +794,90 @@ def seg_class_counts(pred, gt, num_classes):
     if int(host[:, num_classes, 0].sum()) or int(host[:, num_classes, 1].sum()):
         raise CobevtHipError("seg_class_counts: labels outside [0, %d)" % num_classes)
     return host[:, :num_classes]
+
+
+# ----------------------------------------------------------------------------------------------
+# MBConv pieces of the nuScenes EfficientNet backbone
+# ----------------------------------------------------------------------------------------------
+class DepthwisePlan(object):
+    """k x k depthwise conv (groups == channels) + folded BatchNorm + activation, TensorFlow-"same" static padding:
+    `pad` = (before, after) zero rows / columns, the kernel takes the before part and bounds-checks the rest."""
+
+    def __init__(self, weight, bn=None, stride=1, pad=(0, 0), act=0, dtype=torch.bfloat16, device="cuda"):
+        w = weight.detach().double().cpu()                      # (C, 1, k, k)
+        c, one, kh, kw = w.shape
+        if one != 1 or kh != kw:
+            raise CobevtHipError("DepthwisePlan expects a (C, 1, k, k) weight")
+        b = torch.zeros(c, dtype=torch.float64)
+        if bn is not None:
+            s_, sh = bn_affine(bn)
+            w = w * s_.cpu()[:, None, None, None]
+            b = sh.cpu().double()
+        if c % 8 != 0:
+            raise CobevtHipError("depthwise conv needs a multiple of 8 channels, got %d" % c)
+        self.c, self.k, self.stride, self.act = c, kh, int(stride), int(act)
+        self.pad0, self.pad1 = int(pad[0]), int(pad[1])
+        self.dtype, self.code = dtype, dcode(dtype)
+        self.wgt = w[:, 0].permute(1, 2, 0).reshape(kh * kw, c).to(torch.float32).to(device).contiguous()     # [tap][C]
+        self.bias = b.to(torch.float32).to(device).contiguous()
+
+    def out_hw(self, h, w):
+        return ((h + self.pad0 + self.pad1 - self.k) // self.stride + 1, (w + self.pad0 + self.pad1 - self.k) // self.stride + 1)
+
+
+def depthwise_conv(x, plan):
+    """x (N, H, W, C) channels-last in plan.dtype -> (N, Ho, Wo, C)"""
+    _need_cuda(x)
+    n, h, w, c = x.shape
+    if c != plan.c or x.dtype != plan.dtype or not x.is_contiguous():
+        raise CobevtHipError("depthwise_conv: bad input %s %s for C=%d %s" % (tuple(x.shape), x.dtype, plan.c, plan.dtype))
+    ho, wo = plan.out_hw(h, w)
+    out = torch.empty((n, ho, wo, c), device=x.device, dtype=plan.dtype)
+    dims = _ints([plan.code, n, h, w, c, plan.k, plan.stride, plan.pad0, plan.pad0, ho, wo, plan.act])
+
+    def cost():
+        esz = 2 if plan.code == BF16 else 4
+        return 2.0 * n * ho * wo * c * plan.k * plan.k, float((x.numel() + out.numel()) * esz)
+
+    with _timed("depthwise|%dx%d s%d C%d %dx%d" % (plan.k, plan.k, plan.stride, c, h, w), cost):
+        rc = _L.load().cobevt_depthwise_conv_nhwc(_p(x), _p(plan.wgt), _p(plan.bias), _p(out), dims, _stream())
+    _L.check(rc, "cobevt_depthwise_conv_nhwc")
+    return out
+
+
+def spatial_mean(x):
+    """(N, H, W, C) -> (N, C) fp32 mean over the pixels (the squeeze of squeeze-and-excitation), deterministic order"""
+    _need_cuda(x)
+    n, h, w, c = x.shape
+    if not x.is_contiguous():
+        raise CobevtHipError("spatial_mean: input must be contiguous channels-last")
+    out = torch.empty((n, c), device=x.device, dtype=torch.float32)
+    rc = _L.load().cobevt_spatial_mean_nhwc(_p(x), _p(out), dcode(x.dtype), n, h * w, c, _stream())
+    _L.check(rc, "cobevt_spatial_mean_nhwc")
+    return out
+
+
+def se_gate(mean, w_reduce, b_reduce, w_expand, b_expand):
+    """mean (N, C) fp32; w_reduce (Cs, C), b_reduce (Cs,), w_expand (C, Cs), b_expand (C,) fp32 ->
+    sigmoid(w_expand . swish(w_reduce . mean + b_reduce) + b_expand)  (N, C) fp32"""
+    _need_cuda(mean, w_reduce, b_reduce, w_expand, b_expand)
+    n, c = mean.shape
+    cs = w_reduce.shape[0]
+    if tuple(w_reduce.shape) != (cs, c) or tuple(w_expand.shape) != (c, cs) or b_reduce.numel() != cs or b_expand.numel() != c:
+        raise CobevtHipError("se_gate: inconsistent shapes")
+    gate = torch.empty((n, c), device=mean.device, dtype=torch.float32)
+    rc = _L.load().cobevt_se_gate(_p(mean), _p(w_reduce), _p(b_reduce), _p(w_expand), _p(b_expand), _p(gate), n, c, cs, _stream())
+    _L.check(rc, "cobevt_se_gate")
+    return gate
+
+
+def channel_gate(x, gate):
+    """x (N, H, W, C) * gate (N, C) fp32 -> (N, H, W, C)"""
+    _need_cuda(x, gate)
+    n, h, w, c = x.shape
+    if tuple(gate.shape) != (n, c) or gate.dtype != torch.float32 or not x.is_contiguous() or not gate.is_contiguous():
+        raise CobevtHipError("channel_gate: gate must be (N, C) fp32 for a contiguous (N, H, W, C) map")
+    out = torch.empty_like(x)
+    rc = _L.load().cobevt_channel_gate_nhwc(_p(x), _p(gate), _p(out), dcode(x.dtype), n, h * w, c, _stream())
+    _L.check(rc, "cobevt_channel_gate_nhwc")
+    return out

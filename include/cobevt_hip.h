@@ -250,6 +250,28 @@ int cobevt_softmax_argmax(const void* logits, float* prob, long long* map, int d
 int cobevt_seg_class_counts(const long long* pred, const long long* gt, unsigned long long* counts, int N, int hw, int K,
                             hipStream_t stream);
 
+/* ---- upstream of the nuScenes path: MBConv pieces of the EfficientNet image backbone wrapped by
+ * nuscenes/cross_view_transformer/model/backbones/efficientnet.py:24-96 (efficientnet-pytorch 0.7.1 MBConvBlock.forward;
+ * the 1x1 convolutions of a block go through cobevt_linear_rows / cobevt_conv2d_nhwc with act 3 = swish) -------------- */
+
+/* k x k depthwise convolution (groups == channels) + folded BatchNorm + activation on a channels-last map.  wgt [k*k][C]
+ * fp32 (BN scale folded), bias [C] fp32.  dims (int32[12]): dtype, N, H, W, C (multiple of 8), k (<= 7), stride, pad_top,
+ * pad_left (the TensorFlow-"same" extra row / column at the bottom / right is implicit: taps outside the map read zero),
+ * Ho, Wo, act (0 none, 1 ReLU, 2 GELU, 3 swish, 4 sigmoid). */
+int cobevt_depthwise_conv_nhwc(const void* in, const float* wgt, const float* bias, void* out, const int* dims,
+                               hipStream_t stream);
+
+/* Squeeze: out[n][c] = mean over the hw pixels of in (N, hw, C), fp32, fixed summation order. */
+int cobevt_spatial_mean_nhwc(const void* in, float* out, int dtype, int N, int hw, int C, hipStream_t stream);
+
+/* Excitation: gate (N, C) = sigmoid(w_expand (C x Cs) . swish(w_reduce (Cs x C) . mean (N, C) + b_reduce) + b_expand), fp32. */
+int cobevt_se_gate(const float* mean, const float* w_reduce, const float* b_reduce, const float* w_expand,
+                   const float* b_expand, float* gate, int N, int C, int Cs, hipStream_t stream);
+
+/* out (N, hw, C) = in * gate (N, C). */
+int cobevt_channel_gate_nhwc(const void* in, const float* gate, void* out, int dtype, int N, int hw, int C,
+                             hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
