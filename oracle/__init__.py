@@ -15,5 +15,6 @@ torchvision / shapely stand-ins) and committed as fixtures under tests/golden/*.
 tests/test_oracle_golden.py replays them.  Arithmetic that lives in third-party code absent from the
 reference tree (torchvision 0.12 ResNet / Bottleneck) is restated from its public definition in
 oracle/resnet.py and is pinned only self-consistently (same stand-in on both sides): "parity unpinned" for
-torchvision's own arithmetic.  EfficientNet (nuScenes backbone) is not restated at all.
+torchvision's own arithmetic.  EfficientNet-B4 (efficientnet-pytorch 0.7.1, nuScenes backbone) is restated in
+oracle/efficientnet.py the same way and is equally unpinned.
 """
