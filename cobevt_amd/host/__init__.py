@@ -7,6 +7,7 @@ from .swap_fusion_modules import (Attention as SwapAttention, SwapFusionBlock, S
 from .base_transformer import FeedForward, PreNormResidual  # noqa: F401
 from .resnet_ms import ResnetEncoder  # noqa: F401
 from .naive_decoder import NaiveDecoder  # noqa: F401
+from .naive_compress import NaiveCompressor  # noqa: F401
 from .bev_seg_head import BevSegHead  # noqa: F401
 from .fuse_utils import regroup  # noqa: F401
 from .corpbevt import STTF, CorpBEVT  # noqa: F401

@@ -8,6 +8,7 @@ from ..lib import CobevtHipError
 from . import runtime as rt
 from .bev_seg_head import BevSegHead
 from .fax_modules import FAXModule
+from .naive_compress import NaiveCompressor
 from .naive_decoder import NaiveDecoder
 from .resnet_ms import ResnetEncoder
 from .runtime import HipModule
@@ -45,10 +46,11 @@ class CorpBEVT(HipModule):
         fax_params = config["fax"]
         fax_params["backbone_output_shape"] = self.encoder.output_shapes
         self.fax = FAXModule(fax_params)
-        if config["compression"] > 0:
-            raise CobevtHipError("NaiveCompressor (compression > 0) is outside the FAX hot path; every shipped "
-                                 "config uses compression: 0 (corpbevt.yaml:58)")
-        self.compression = False
+        if config["compression"] > 0:                      # corpbevt.py:79-83 (0 in every shipped config, corpbevt.yaml:58)
+            self.compression = True
+            self.naive_compressor = NaiveCompressor(128, config["compression"])
+        else:
+            self.compression = False
         self.downsample_rate = config["sttf"]["downsample_rate"]
         self.discrete_ratio = config["sttf"]["resolution"]
         self.use_roi_mask = config["sttf"]["use_roi_mask"]
@@ -62,6 +64,8 @@ class CorpBEVT(HipModule):
         """feats: (N, H, W, C) channels-last per-agent BEV features (what V2V sharing transmits) ->
         output dict.  Split out so the multi-GPU path can all-gather `feats` first (cobevt_amd/dist.py)."""
         dev = feats.device
+        if self.compression:                                # what each agent would transmit and the receiver's reconstruction
+            feats = self.naive_compressor.forward_nhwc(feats)
         rl = torch.as_tensor(record_len).to(device=dev, dtype=torch.int32)
         tm = transformation_matrix.to(device=dev, dtype=torch.float32).contiguous()
         # regroup (fuse_utils.py:8-61) + STTF warp + ROI mask in one launch -> (B, L, H, W, C), (B, H, W, 1, L), (B, L)

@@ -203,3 +203,16 @@ def corpbevt_small_config():
         "seg_head_dim": 8,
         "output_class": 2,
     }
+
+
+def corpbevt_small_compressed_config(ratio=2):
+    """The reduced CorpBEVT widened to 128 channels after the FAX pyramid (the reference hard-codes NaiveCompressor(128, ratio),
+    corpbevt.py:81) with `compression: ratio`."""
+    cfg = corpbevt_small_config()
+    cfg["compression"] = ratio
+    cfg["fax"]["dim"] = [128, 128, 128]        # the pyramid's down-sampling needs equal dims (fax_modules.py:477-481)
+    cfg["fax"]["cross_view"]["heads"] = [4, 4, 4]
+    cfg["decoder"] = {"input_dim": 128, "num_layer": 3, "num_ch_dec": [8, 16, 32]}
+    cfg["fax_fusion"]["input_dim"] = 128
+    cfg["fax_fusion"]["mlp_dim"] = 128
+    return cfg

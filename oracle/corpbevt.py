@@ -43,6 +43,15 @@ def bev_seg_head(sd, pfx, target, x, b, l):
     return {"static_seg": head("static_head"), "dynamic_seg": head("dynamic_head")}
 
 
+def naive_compressor(sd, prefix, x):
+    """NaiveCompressor.forward, sub_modules/naive_compress.py:5-31: (conv3x3 + BN(eps 1e-3) + ReLU) x 3, C -> C/r -> C -> C."""
+    for conv, bn in (("encoder.0", "encoder.1"), ("decoder.0", "decoder.1"), ("decoder.3", "decoder.4")):
+        x = F.conv2d(x, sd[prefix + conv + ".weight"], sd[prefix + conv + ".bias"], padding=1)
+        x = F.relu(F.batch_norm(x, sd[prefix + bn + ".running_mean"], sd[prefix + bn + ".running_var"], sd[prefix + bn + ".weight"],
+                                sd[prefix + bn + ".bias"], False, 0.0, 1e-3))
+    return x
+
+
 def encode_agents(sd, config, batch):
     """Per-agent part of CorpBEVT.forward (corpbevt.py:112-117): encoder + FAX -> (N, C, H, W)."""
     feats = resnet_encoder(sd, "encoder.encoder.", config["encoder"], batch["inputs"])
@@ -52,7 +61,8 @@ def encode_agents(sd, config, batch):
 
 def fuse_and_decode(sd, config, f, tm, record_len, return_intermediates=False):
     """Cross-agent part of CorpBEVT.forward (corpbevt.py:119-145): regroup, STTF, mask, swap fusion, decoder, head."""
-    assert config["compression"] == 0, "NaiveCompressor is out of scope (SURVEY.md §2 O11)"
+    if config["compression"] > 0:                         # corpbevt.py:119-121
+        f = naive_compressor(sd, "naive_compressor.", f)
     g, mask = regroup(f, record_len, config["max_cav"])
     st = config["sttf"]
     w = sttf(g, tm, st["resolution"], st["downsample_rate"])                       # b l h w c

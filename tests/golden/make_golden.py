@@ -373,8 +373,28 @@ def gv12():
     save("gv12_pre_post", **out)
 
 
+def gv13():
+    """NaiveCompressor (sub_modules/naive_compress.py) alone and inside the reduced CorpBEVT with compression = 2."""
+    import copy
+    from opencood.models.sub_modules.naive_compress import NaiveCompressor as R_Comp
+    comp = fill_module_(R_Comp(32, 4).eval(), cases.SEED)
+    x = synth.procedural_input("gv13.x", (3, 32, 12, 16), cases.SEED, -2.0, 2.0)
+    ref = comp(x)
+    got = o_model.naive_compressor({"c." + k: v for k, v in comp.state_dict().items()}, "c.", x)
+    _close("NaiveCompressor", got, ref)
+    cfg = synth.corpbevt_small_compressed_config(2)
+    m = R_corpbevt.CorpBEVT(copy.deepcopy(cfg)).eval()
+    fill_module_(m, cases.SEED)
+    batch = synth.opv2v_batch(agents=2, cams=2, image=128, max_cav=3, seed=cases.SEED)
+    out = m({k: v.clone() for k, v in batch.items()})
+    mine = o_model.corpbevt_forward(m.state_dict(), cfg, batch)
+    _close("CorpBEVT.small compression=2", mine["dynamic_seg"], out["dynamic_seg"])
+    save("gv13_naive_compressor", compressor=_np(ref), dynamic_seg=_np(out["dynamic_seg"]),
+         keys=np.array([k for k in m.state_dict().keys() if k.startswith("naive_compressor.")]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gv0", "gv1", "gv2", "gv3", "gv4", "gv5", "gv6", "gv7", "gv8", "gv9", "gv10", "gv11", "gv12"]
+    which = sys.argv[1:] or ["gv0", "gv1", "gv2", "gv3", "gv4", "gv5", "gv6", "gv7", "gv8", "gv9", "gv10", "gv11", "gv12", "gv13"]
     for name in which:
         print("== " + name)
         globals()[name]()

@@ -68,8 +68,9 @@ def test_no_cpu_fallback_and_eval_only():
         m.eval()(x)
     with pytest.raises(ValueError):
         host.ResnetEncoder({"num_layers": 19, "pretrained": False, "image_height": 64, "image_width": 64, "id_pick": [1]})
-    with pytest.raises(CobevtHipError):
-        host.CorpBEVT(dict(synth.corpbevt_small_config(), compression=4))
+    m = host.CorpBEVT(dict(synth.corpbevt_small_config(), compression=4))       # corpbevt.py:79-81: NaiveCompressor(128, ratio)
+    assert m.compression and tuple(m.naive_compressor.encoder[0].weight.shape) == (32, 128, 3, 3)
+    assert not host.CorpBEVT(synth.corpbevt_small_config()).compression
 
 
 def test_product_does_not_import_oracle():

@@ -216,6 +216,24 @@ def test_corpbevt_ragged_scenarios_vs_oracle(cuda, dtype, tol):
     assert_close(alone[0], out[1].cpu().numpy(), tol, "scenario independent of its batch neighbours")
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+def test_naive_compressor_and_compressed_corpbevt(cuda, dtype, tol):
+    """GV13: the reference's NaiveCompressor output and its reduced CorpBEVT with compression = 2"""
+    g = golden("gv13_naive_compressor")
+    comp = dev(fill_module_(host.NaiveCompressor(32, 4), cases.SEED), cuda)
+    x = synth.procedural_input("gv13.x", (3, 32, 12, 16), cases.SEED, -2.0, 2.0)
+    with host.compute_dtype(dtype):
+        y = comp(x.to(cuda))
+    assert y.dtype == torch.float32
+    assert_close(y, g["compressor"], 3e-2 if dtype == torch.bfloat16 else tol, "NaiveCompressor")
+    cfg = synth.corpbevt_small_compressed_config(2)
+    m = dev(fill_module_(host.CorpBEVT(copy.deepcopy(cfg)), cases.SEED), cuda)
+    batch = synth.opv2v_batch(agents=2, cams=2, image=128, max_cav=3, seed=cases.SEED)
+    with host.compute_dtype(dtype):
+        out = m({k: v.to(cuda) for k, v in batch.items()})
+    assert_close(out["dynamic_seg"], g["dynamic_seg"], tol, "CorpBEVT.small compression=2")
+
+
 def test_corpbevt_full_config_two_agents_vs_oracle(cuda):
     """BASELINE config[2] shape (2 agents x 4 cams x 512^2 -> 256^2 BEV, ResNet-34, full corpbevt.yaml) against the
     oracle run on the host CPU: fp32 mode <= 1e-3 rel, bf16 mode <= 5e-2 rel + arg-max agreement."""

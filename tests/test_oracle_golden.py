@@ -201,3 +201,18 @@ def test_gv11_nuscenes_sinbevt():
     assert_close(out["bev"], g["bev"], TOL, "bev")
     assert_close(out["center"], g["center"], TOL, "center")
     assert np.allclose(o_nu.normalize(image.flatten(0, 1))[:, :, ::37, ::41].numpy(), g["normalized_image_sample"], atol=1e-6)
+
+
+def test_gv13_naive_compressor():
+    """NaiveCompressor alone and inside the reduced CorpBEVT with `compression: 2` (corpbevt.py:79-81,119-121)"""
+    g = golden("gv13_naive_compressor")
+    comp = fill_module_(host.NaiveCompressor(32, 4), cases.SEED).eval()
+    x = synth.procedural_input("gv13.x", (3, 32, 12, 16), cases.SEED, -2.0, 2.0)
+    got = o_model.naive_compressor({"c." + k: v for k, v in comp.state_dict().items()}, "c.", x)
+    assert_close(got, g["compressor"], TOL, "NaiveCompressor")
+    cfg = synth.corpbevt_small_compressed_config(2)
+    m = fill_module_(host.CorpBEVT(copy.deepcopy(cfg)), cases.SEED).eval()
+    assert [k for k in m.state_dict().keys() if k.startswith("naive_compressor.")] == list(g["keys"])
+    batch = synth.opv2v_batch(agents=2, cams=2, image=128, max_cav=3, seed=cases.SEED)
+    out = o_model.corpbevt_forward(m.state_dict(), cfg, batch)
+    assert_close(out["dynamic_seg"], g["dynamic_seg"], TOL, "CorpBEVT.small compression=2")
