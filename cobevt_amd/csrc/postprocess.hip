@@ -124,3 +124,97 @@ extern "C" int cobevt_seg_class_counts(const long long* pred, const long long* g
     hipLaunchKernelGGL(seg_counts_kernel, grid, block, 0, stream, pred, gt, counts, hw, K, per_thread);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Class-weighted cross entropy of planar logits against an integer label map, the reduction nn.CrossEntropyLoss(weight=w)
+// applies in VanillaSegLoss (opv2v/opencood/loss/vanilla_seg_loss.py:18-23,58-70):
+//     loss = sum_i w[y_i] * (logsumexp_c x_i[c] - x_i[y_i]) / sum_i w[y_i]
+// Two launches with a fixed summation order (bit-reproducible): per-workgroup partial (numerator, denominator) pairs, then
+// one workgroup adds them in order and divides.
+namespace cobevt {
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void wce_partial_kernel(const T* logits, const long long* target, const float* weight,
+                                                          float* partial, int hw, int per_thread) {
+    __shared__ float sn[256], sd[256];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const size_t base = (size_t)n * C * hw;
+    float num = 0.f, den = 0.f;
+    const int p0 = blockIdx.x * 256 * per_thread;
+    for (int j = 0; j < per_thread; ++j) {
+        const int pix = p0 + j * 256 + tid;
+        if (pix >= hw) break;
+        float x[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) x[c] = post_load<T>(logits, base + (size_t)c * hw + pix);
+        float m = x[0];
+#pragma unroll
+        for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) s += expf(x[c] - m);
+        const long long y = target[(size_t)n * hw + pix];
+        float xy = 0.f, wy = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            if (y == c) { xy = x[c]; wy = weight[c]; }
+        num += wy * (m + logf(s) - xy);               // labels outside [0, C) contribute nothing (the host refuses them)
+        den += wy;
+    }
+    sn[tid] = num; sd[tid] = den;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { sn[tid] += sn[tid + s]; sd[tid] += sd[tid + s]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        partial[2 * b] = sn[0];
+        partial[2 * b + 1] = sd[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void wce_final_kernel(const float* partial, float* out, int nparts) {
+    __shared__ float sn[256], sd[256];
+    const int tid = threadIdx.x;
+    float num = 0.f, den = 0.f;
+    for (int i = tid; i < nparts; i += 256) { num += partial[2 * i]; den += partial[2 * i + 1]; }
+    sn[tid] = num; sd[tid] = den;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { sn[tid] += sn[tid + s]; sd[tid] += sd[tid + s]; }
+        __syncthreads();
+    }
+    if (tid == 0) { out[0] = sn[0] / sd[0]; out[1] = sn[0]; out[2] = sd[0]; }
+}
+
+template <typename T>
+static int launch_wce(const void* logits, const long long* target, const float* weight, float* partial, int N, int C, int hw,
+                      int per_thread, hipStream_t stream) {
+    const dim3 grid((hw + 256 * per_thread - 1) / (256 * per_thread), N), block(256);
+    switch (C) {
+#define COBEVT_WCE_CASE(c) case c: hipLaunchKernelGGL((wce_partial_kernel<T, c>), grid, block, 0, stream, (const T*)logits, target, weight, partial, hw, per_thread); break;
+        COBEVT_WCE_CASE(2) COBEVT_WCE_CASE(3) COBEVT_WCE_CASE(4) COBEVT_WCE_CASE(5) COBEVT_WCE_CASE(6) COBEVT_WCE_CASE(7) COBEVT_WCE_CASE(8)
+#undef COBEVT_WCE_CASE
+        default: return COBEVT_ERR_SHAPE;
+    }
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+}  // namespace cobevt
+
+// out[0] = loss, out[1] = weighted numerator, out[2] = sum of weights; scratch >= 2 * ceil(hw / 4096) * N floats
+extern "C" int cobevt_weighted_cross_entropy(const void* logits, const long long* target, const float* weight, float* scratch,
+                                             float* out, int dtype, int N, int C, int hw, hipStream_t stream) {
+    if (!logits || !target || !weight || !scratch || !out) return COBEVT_ERR_ARG;
+    if (N < 1 || N > 65535 || hw < 1 || C < 2 || C > kPostMaxClasses) return COBEVT_ERR_SHAPE;
+    const int per_thread = 16;
+    const int nparts = ((hw + 256 * per_thread - 1) / (256 * per_thread)) * N;
+    int rc;
+    if (dtype == 0) rc = launch_wce<bf16_t>(logits, target, weight, scratch, N, C, hw, per_thread, stream);
+    else if (dtype == 1) rc = launch_wce<float>(logits, target, weight, scratch, N, C, hw, per_thread, stream);
+    else return COBEVT_ERR_ARG;
+    if (rc != COBEVT_OK) return rc;
+    hipLaunchKernelGGL(wce_final_kernel, dim3(1), dim3(256), 0, stream, scratch, out, nparts);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}

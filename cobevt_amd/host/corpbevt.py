@@ -46,7 +46,9 @@ class CorpBEVT(HipModule):
         fax_params = config["fax"]
         fax_params["backbone_output_shape"] = self.encoder.output_shapes
         self.fax = FAXModule(fax_params)
-        if config["compression"] > 0:                      # corpbevt.py:79-83 (0 in every shipped config, corpbevt.yaml:58)
+        # corpbevt.py:79-83.  0 in corpbevt.yaml:58; corpbevt_static.yaml has no such key at all (the reference raises a
+        # KeyError there) - read as 0
+        if config.get("compression", 0) > 0:
             self.compression = True
             self.naive_compressor = NaiveCompressor(128, config["compression"])
         else:

@@ -1,0 +1,40 @@
+"""VanillaSegLoss — forward-only mirror of opv2v/opencood/loss/vanilla_seg_loss.py:7-76: the class-weighted cross entropy
+the reference reports as validation loss (train_camera.py:182-196 under no_grad) and optimises in training.  Same
+constructor arguments (`d_weights`, `s_weights`, optional `l_weights` (default 50), `d_coe`, `s_coe`, `target`), same
+`forward(output_dict, gt_dict)` -> total loss and `loss_dict` entries; the cross entropies run on the logits where they are
+(cobevt_weighted_cross_entropy).  Back-propagation is out of scope: the result carries no graph."""
+import torch
+
+from .. import ops
+
+
+class VanillaSegLoss(object):
+    def __init__(self, args):
+        self.d_weights = args["d_weights"]
+        self.s_weights = args["s_weights"]
+        self.l_weights = 50 if "l_weights" not in args else args["l_weights"]
+        self.d_coe = args["d_coe"]
+        self.s_coe = args["s_coe"]
+        self.target = args["target"]
+        self.static_weight = torch.tensor([1.0, self.s_weights, self.l_weights], dtype=torch.float32)
+        self.dynamic_weight = torch.tensor([1.0, self.d_weights], dtype=torch.float32)
+        self.loss_dict = {}
+
+    def __call__(self, output_dict, gt_dict):
+        return self.forward(output_dict, gt_dict)
+
+    def forward(self, output_dict, gt_dict):
+        """output_dict: static_seg / dynamic_seg (b, l, c, h, w); gt_dict: gt_static / gt_dynamic (b, l, h, w) integer maps"""
+        static_pred, dynamic_pred = output_dict["static_seg"], output_dict["dynamic_seg"]
+        static_loss = torch.tensor(0, device=static_pred.device)
+        dynamic_loss = torch.tensor(0, device=dynamic_pred.device)
+        flat = lambda t: t.reshape(t.shape[0] * t.shape[1], *t.shape[2:])
+        if self.target != "static":
+            dynamic_loss = ops.weighted_cross_entropy(flat(dynamic_pred), flat(gt_dict["gt_dynamic"]).to(dynamic_pred.device),
+                                                      self.dynamic_weight)
+        if self.target != "dynamic":
+            static_loss = ops.weighted_cross_entropy(flat(static_pred), flat(gt_dict["gt_static"]).to(static_pred.device),
+                                                     self.static_weight)
+        total_loss = self.s_coe * static_loss + self.d_coe * dynamic_loss
+        self.loss_dict.update({"total_loss": total_loss, "static_loss": static_loss, "dynamic_loss": dynamic_loss})
+        return total_loss

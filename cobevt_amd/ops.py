@@ -881,3 +881,21 @@ def channel_gate(x, gate):
     rc = _L.load().cobevt_channel_gate_nhwc(_p(x), _p(gate), _p(out), dcode(x.dtype), n, h * w, c, _stream())
     _L.check(rc, "cobevt_channel_gate_nhwc")
     return out
+
+
+def weighted_cross_entropy(logits, target, weight):
+    """nn.CrossEntropyLoss(weight=weight)(logits (N, C, H, W), target (N, H, W) int64) -> 0-d fp32 tensor on the device
+    (vanilla_seg_loss.py:18-23,58-70); forward only."""
+    _need_cuda(logits, target)
+    if logits.dim() != 4 or tuple(target.shape) != (logits.shape[0],) + tuple(logits.shape[2:]):
+        raise CobevtHipError("weighted_cross_entropy expects (N, C, H, W) logits and an (N, H, W) target")
+    x, y = logits.contiguous(), target.to(torch.int64).contiguous()
+    n, c, h, w = x.shape
+    wt = weight.to(device=x.device, dtype=torch.float32).contiguous()
+    if wt.numel() != c:
+        raise CobevtHipError("weighted_cross_entropy: %d class weights for %d classes" % (wt.numel(), c))
+    scratch = torch.empty(2 * n * ((h * w + 4095) // 4096), device=x.device, dtype=torch.float32)
+    out = torch.empty(3, device=x.device, dtype=torch.float32)
+    rc = _L.load().cobevt_weighted_cross_entropy(_p(x), _p(y), _p(wt), _p(scratch), _p(out), dcode(x.dtype), n, c, h * w, _stream())
+    _L.check(rc, "cobevt_weighted_cross_entropy")
+    return out[0]

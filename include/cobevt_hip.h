@@ -250,6 +250,13 @@ int cobevt_softmax_argmax(const void* logits, float* prob, long long* map, int d
 int cobevt_seg_class_counts(const long long* pred, const long long* gt, unsigned long long* counts, int N, int hw, int K,
                             hipStream_t stream);
 
+/* Class-weighted cross entropy nn.CrossEntropyLoss(weight=w) computes in VanillaSegLoss (validation loss of
+ * train_camera.py:182-196; opv2v/opencood/loss/vanilla_seg_loss.py:18-23,58-70): out[0] = sum_i w[y_i] (logsumexp(x_i) - x_i[y_i])
+ * / sum_i w[y_i], out[1] / out[2] = numerator / denominator.  logits (N, C, hw) planar (dtype 0 bf16 / 1 fp32, 2 <= C <= 8),
+ * target (N, hw) int64, weight [C] fp32, scratch >= 2 * N * ceil(hw / 4096) floats, fixed summation order. */
+int cobevt_weighted_cross_entropy(const void* logits, const long long* target, const float* weight, float* scratch, float* out,
+                                  int dtype, int N, int C, int hw, hipStream_t stream);
+
 /* ---- upstream of the nuScenes path: MBConv pieces of the EfficientNet image backbone wrapped by
  * nuscenes/cross_view_transformer/model/backbones/efficientnet.py:24-96 (efficientnet-pytorch 0.7.1 MBConvBlock.forward;
  * the 1x1 convolutions of a block go through cobevt_linear_rows / cobevt_conv2d_nhwc with act 3 = swish) -------------- */

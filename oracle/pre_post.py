@@ -17,6 +17,7 @@ Follows, function by function:
   cal_iou_training     seg_utils.py:115-155 (returns inside the loop: only sample 0 is scored)
   collate_batch        opv2v/opencood/data_utils/datasets/camera_only/intermediate_fusion_dataset.py:231-317
   find_last_checkpoint / load_saved_model   opv2v/opencood/tools/train_utils.py:24-65
+  vanilla_seg_loss     opv2v/opencood/loss/vanilla_seg_loss.py:7-76 (forward; nn.CrossEntropyLoss(weight) = weighted mean)
 """
 import glob
 import os
@@ -133,3 +134,19 @@ def load_saved_model(saved_path, model):
         state = torch.load(os.path.join(saved_path, "net_epoch%d.pth" % epoch), map_location="cpu")
         model.load_state_dict(state, strict=False)
     return epoch, model
+
+
+def vanilla_seg_loss(args, output_dict, gt_dict):
+    """-> dict(total_loss, static_loss, dynamic_loss) of 0-d tensors"""
+    import torch.nn.functional as F
+    flat = lambda t: t.reshape(t.shape[0] * t.shape[1], *t.shape[2:])
+    zero = torch.tensor(0)
+    static_loss, dynamic_loss = zero, zero
+    if args["target"] != "static":
+        dynamic_loss = F.cross_entropy(flat(output_dict["dynamic_seg"]).float(), flat(gt_dict["gt_dynamic"]),
+                                       weight=torch.tensor([1.0, args["d_weights"]]))
+    if args["target"] != "dynamic":
+        static_loss = F.cross_entropy(flat(output_dict["static_seg"]).float(), flat(gt_dict["gt_static"]),
+                                      weight=torch.tensor([1.0, args["s_weights"], args.get("l_weights", 50)]))
+    return {"total_loss": args["s_coe"] * static_loss + args["d_coe"] * dynamic_loss, "static_loss": static_loss,
+            "dynamic_loss": dynamic_loss}

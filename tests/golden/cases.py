@@ -240,3 +240,20 @@ def pre_post_inputs():
         }})
     out["samples"] = samples
     return out
+
+
+# loss arguments of the shipped configs: corpbevt.yaml:117-123 (dynamic) and corpbevt_static.yaml:115-122 (static), plus "both"
+SEG_LOSS = [dict(target="dynamic", d_weights=75.0, s_weights=15.0, d_coe=2.0, s_coe=0.0),
+            dict(target="static", d_weights=75.0, s_weights=2.0, l_weights=4.0, d_coe=2.0, s_coe=1.0),
+            dict(target="both", d_weights=10.0, s_weights=3.0, d_coe=0.5, s_coe=1.5)]
+
+
+def seg_loss_inputs():
+    """logits (b, 1, c, h, w) and ground truth (b, 1, h, w) for the three loss configurations"""
+    import numpy as np
+    rs = np.random.RandomState(4321)
+    b, h, w = 3, 20, 28
+    return {"dynamic_seg": (rs.standard_normal((b, 1, 2, h, w)) * 2.5).astype(np.float32),
+            "static_seg": (rs.standard_normal((b, 1, 3, h, w)) * 2.5).astype(np.float32),
+            "gt_dynamic": rs.randint(0, 2, size=(b, 1, h, w)).astype(np.int64),
+            "gt_static": rs.randint(0, 3, size=(b, 1, h, w)).astype(np.int64)}

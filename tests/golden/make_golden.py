@@ -373,6 +373,34 @@ def gv12():
     save("gv12_pre_post", **out)
 
 
+def gv14():
+    """VanillaSegLoss (loss/vanilla_seg_loss.py) forward on the three target modes.  Its constructor moves the class weights
+    with .cuda(); there is no GPU in the build container, so Tensor.cuda is an identity for the duration of the call."""
+    import importlib
+    from unittest import mock
+    import oracle.pre_post as o_pp
+    for name in ("cv2", "timm", "timm.scheduler", "timm.scheduler.cosine_lr", "open3d", "matplotlib", "matplotlib.pyplot", "tensorboardX"):
+        try:
+            importlib.import_module(name)
+        except Exception:
+            sys.modules[name] = mock.MagicMock(name=name)
+    from opencood.loss.vanilla_seg_loss import VanillaSegLoss as R_Loss
+    inp = {k: torch.from_numpy(v) for k, v in cases.seg_loss_inputs().items()}
+    out = {}
+    for i, args in enumerate(cases.SEG_LOSS):
+        with mock.patch.object(torch.Tensor, "cuda", lambda self, *a, **k: self):
+            crit = R_Loss(dict(args))
+        total = crit({"static_seg": inp["static_seg"], "dynamic_seg": inp["dynamic_seg"]}, inp)
+        mine = o_pp.vanilla_seg_loss(args, inp, inp)
+        for k in ("total_loss", "static_loss", "dynamic_loss"):
+            assert abs(float(crit.loss_dict[k]) - float(mine[k])) <= 1e-6 * max(1.0, abs(float(mine[k]))), (k, args)
+            out["%s%d" % (k, i)] = np.array(float(crit.loss_dict[k]), dtype=np.float64)
+        assert float(total) == float(crit.loss_dict["total_loss"])
+        print("  VanillaSegLoss %-8s total %.6f static %.6f dynamic %.6f" % (args["target"], float(total), float(crit.loss_dict["static_loss"]),
+                                                                             float(crit.loss_dict["dynamic_loss"])))
+    save("gv14_vanilla_seg_loss", **out)
+
+
 def gv13():
     """NaiveCompressor (sub_modules/naive_compress.py) alone and inside the reduced CorpBEVT with compression = 2."""
     import copy
@@ -394,7 +422,7 @@ def gv13():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gv0", "gv1", "gv2", "gv3", "gv4", "gv5", "gv6", "gv7", "gv8", "gv9", "gv10", "gv11", "gv12", "gv13"]
+    which = sys.argv[1:] or ["gv0", "gv1", "gv2", "gv3", "gv4", "gv5", "gv6", "gv7", "gv8", "gv9", "gv10", "gv11", "gv12", "gv13", "gv14"]
     for name in which:
         print("== " + name)
         globals()[name]()

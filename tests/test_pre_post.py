@@ -111,6 +111,15 @@ def test_load_saved_model_host_mirror():
         h_train.load_saved_model("/nonexistent/run/dir", nn.Linear(3, 2))
 
 
+def test_vanilla_seg_loss_oracle_matches_reference():
+    g = golden("gv14_vanilla_seg_loss")
+    inp = {k: torch.from_numpy(v) for k, v in cases.seg_loss_inputs().items()}
+    for i, args in enumerate(cases.SEG_LOSS):
+        mine = o_pp.vanilla_seg_loss(args, inp, inp)
+        for k in ("total_loss", "static_loss", "dynamic_loss"):
+            assert abs(float(mine[k]) - float(g["%s%d" % (k, i)])) <= 1e-6 * max(1.0, abs(float(g["%s%d" % (k, i)])))
+
+
 def test_logit_side_has_no_cpu_fallback():
     post = h_post.CameraBevPostprocessor({}, train=False)
     with pytest.raises(CobevtHipError):
@@ -195,3 +204,34 @@ def test_post_process_and_iou_end_to_end(cuda):
     ref_sta = o_pp.mean_iu(out["static_map"][0].cpu().numpy(), batch["ego"]["gt_static"][0, 0].numpy())
     assert iou_dynamic == ref_dyn and iou_static == ref_sta
     assert (out["static_map"].cpu() != ref["static_map"]).sum().item() <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vanilla_seg_loss_forward(cuda, dtype):
+    """validation loss of train_camera.py:182-196 on device logits vs the reference's own values (gv14); bf16 logits vs the
+    oracle on the rounded logits.  1e-5 rel: a 1680-term fp32 sum in a different order and a different libm."""
+    from cobevt_amd.host.vanilla_seg_loss import VanillaSegLoss
+    g = golden("gv14_vanilla_seg_loss")
+    inp = {k: torch.from_numpy(v) for k, v in cases.seg_loss_inputs().items()}
+    for i, args in enumerate(cases.SEG_LOSS):
+        crit = VanillaSegLoss(dict(args))
+        out = {"static_seg": inp["static_seg"].to(cuda).to(dtype), "dynamic_seg": inp["dynamic_seg"].to(cuda).to(dtype)}
+        gt = {"gt_static": inp["gt_static"].to(cuda), "gt_dynamic": inp["gt_dynamic"]}            # host ground truth is accepted
+        total = crit(out, gt)
+        assert total.is_cuda and float(total) == float(crit.loss_dict["total_loss"])
+        if dtype == torch.float32:
+            ref = {k: float(g["%s%d" % (k, i)]) for k in ("total_loss", "static_loss", "dynamic_loss")}
+        else:
+            ref = {k: float(v) for k, v in o_pp.vanilla_seg_loss(args, {k2: v2.cpu().float() for k2, v2 in out.items()}, inp).items()}
+        for k, r in ref.items():
+            assert abs(float(crit.loss_dict[k]) - r) <= 1e-5 * max(1.0, abs(r)), (k, args["target"], float(crit.loss_dict[k]), r)
+    # full-size head output: equals the oracle, and is bit-reproducible (fixed summation order)
+    from cobevt_amd import ops
+    x = torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(3)) * 3
+    y = torch.randint(0, 3, (2, 256, 256), generator=torch.Generator().manual_seed(4))
+    wt = torch.tensor([1.0, 2.0, 4.0])
+    a = ops.weighted_cross_entropy(x.to(cuda), y.to(cuda), wt)
+    assert torch.equal(a, ops.weighted_cross_entropy(x.to(cuda), y.to(cuda), wt))
+    ref = torch.nn.functional.cross_entropy(x, y, weight=wt)
+    assert abs(float(a) - float(ref)) <= 1e-5 * float(ref)
