@@ -298,6 +298,7 @@ def main():
             print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    local_rank %= torch.cuda.device_count()          # (several ranks share a GPU only in the gloo dry-run mode of cobevt_amd/dist.py)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     torch.set_grad_enabled(False)

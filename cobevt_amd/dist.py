@@ -22,7 +22,9 @@ def init_from_env(device_backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
-        backend = device_backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # COBEVT_DIST_BACKEND=gloo: dry-run the multi-rank control flow with several ranks sharing one GPU (a one-GPU box
+        # cannot host two RCCL ranks); the measured configuration is always RCCL
+        backend = device_backend or os.environ.get("COBEVT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (required by the host driver for RCCL)
         kwargs = {}
@@ -73,7 +75,12 @@ def exchange_features(local_feats, rank, world, agents, group=None, out=None):
     local_feats = local_feats.contiguous()
     gathered = torch.empty((world * agents,) + tuple(local_feats.shape[1:]), dtype=local_feats.dtype,
                            device=local_feats.device)
-    dist.all_gather_into_tensor(gathered, local_feats, group=group)
+    if local_feats.is_cuda and dist.get_backend(group) == "gloo":     # dry-run mode only: gloo gathers through the host
+        host = torch.empty(gathered.shape, dtype=gathered.dtype)
+        dist.all_gather_into_tensor(host, local_feats.cpu(), group=group)
+        gathered.copy_(host)
+    else:
+        dist.all_gather_into_tensor(gathered, local_feats, group=group)
     idx = _gather_index_tensor(rank, world, agents, local_feats.device)
     if out is not None:
         return torch.index_select(gathered, 0, idx, out=out)
