@@ -138,6 +138,11 @@ class PipelinedRunner(object):
         self.f = [torch.empty_like(feats) for _ in range(D)]
         # multi-GPU: the frame's agents are gathered (one RCCL all-gather between graph replays) into g; single GPU: g is f
         self.g = self.f if world == 1 else [torch.empty_like(feats) for _ in range(D)]
+        # multi-GPU: the gather of step q's features runs on its own stream UNDER step q+1 and is consumed by the fusion
+        # stage of step q+2 (one more step of latency than on one GPU), so the collective is off the critical path
+        self.lag = 1 if world == 1 else 2
+        self.comm = torch.cuda.Stream() if world > 1 else None
+        self.gathered = [None] * D
         self.out = None
         self.graphs = None
 
@@ -159,8 +164,22 @@ class PipelinedRunner(object):
         return self.model.fuse_and_decode(self.g[slot_in], self.pose, self.record_len)
 
     def _exchange(self, q):
+        """after step q: gather f[q] into g[q] on the communication stream (it waits for the step, the next step does not
+        wait for it)"""
         if self.world > 1:
-            cdist.exchange_features(self.f[q], self.rank, self.world, self.agents, out=self.g[q])
+            self.comm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm):
+                cdist.exchange_features(self.f[q], self.rank, self.world, self.agents, out=self.g[q])
+                ev = torch.cuda.Event()
+                ev.record(self.comm)
+            self.gathered[q] = ev
+
+    def _await_gather(self, q):
+        """before step q: its fusion stage reads the features gathered after step q - lag"""
+        if self.world > 1:
+            ev = self.gathered[(q - self.lag) % self.depth]
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
 
     def _step_body(self, q):
         """slot q = step index mod depth: S1 writes kv[q]; the later stages read the slots written 1, 2, .. steps ago"""
@@ -172,13 +191,13 @@ class PipelinedRunner(object):
         if D == 3:
             s2, s3 = self.streams
             with torch.cuda.stream(s3):
-                out = self._s3((q - 1) % D)                                   # features written one step ago
+                out = self._s3((q - self.lag) % D)                            # features written `lag` steps ago
             with torch.cuda.stream(s2):
                 self.f[q].copy_(self.model.fax_query(self._state((q - 1) % D), joined=False))
         else:
             s2a, s2b, s3 = self.streams
             with torch.cuda.stream(s3):
-                out = self._s3((q - 1) % D)
+                out = self._s3((q - self.lag) % D)
             with torch.cuda.stream(s2b):                                      # frame i-2: K/V from two steps ago, x from one
                 self.f[q].copy_(self.model.fax_query(self._state((q - 2) % D), joined=False, levels=(1, nlev),
                                                      x=self.x[(q - 1) % D]))
@@ -196,6 +215,7 @@ class PipelinedRunner(object):
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for it in range(2 * D):
+                self._await_gather(it % D)
                 self._step_body(it % D)
                 self._exchange(it % D)
         torch.cuda.current_stream().wait_stream(s)
@@ -211,6 +231,7 @@ class PipelinedRunner(object):
 
     def step(self):
         q = self.i % self.depth
+        self._await_gather(q)
         self.graphs[q].replay()
         self._exchange(q)
         self.out = self.outs[q]
@@ -391,7 +412,8 @@ def main():
         "frames_per_sec_per_gpu": round(fps / world, 3),
         "config": {"workload": "OPV2V-camera CoBEVT (corpbevt.yaml): %d agents x 4 cams x 512x512 -> 256x256 BEV, "
                                "ResNet-34 + FAX + swap fusion, batch 1 frame per GPU" % A,
-                   "agents": A, "frames_in_flight": world * in_flight, "frame_latency_steps": in_flight,
+                   "agents": A, "frames_in_flight": world * in_flight,
+                   "frame_latency_steps": in_flight + (1 if (world > 1 and in_flight > 1) else 0),   # + the step the gather hides under
                    "pipeline": pipeline_note,
                    "parallelism": "agent-shard x%d + 1 all-gather" % world if world > 1 else "single GPU",
                    "hip_graph": graph_ok, "weights": "procedural (cobevt_amd.synth)"},
