@@ -1,6 +1,8 @@
 """CorpBEVT (CoBEVT = SinBEVT per agent + FuseBEVT across agents) — mirror of
 opv2v/opencood/models/corpbevt.py: STTF :22-64, CorpBEVT :67-145 (constructor config keys, state_dict keys,
 forward(batch_dict) -> {'static_seg', 'dynamic_seg'}, the `batch_dict['features']` side effect :113)."""
+import os
+
 import torch
 
 from .. import ops
@@ -82,6 +84,7 @@ class CorpBEVT(HipModule):
         return self.seg_head(rt.nchw_view(y), b, 1)
 
     overlap_streams = True   # run each level's key/value path on a side HIP stream under the remaining encoder stages
+    overlap_kv = os.environ.get("COBEVT_OVERLAP_KV", "1") != "0"
 
     def encode_trunk(self, batch_dict, kv_out=None):
         """Stage 1 of the per-agent SinBEVT: the camera encoder and everything of the FAX pyramid that depends only on
@@ -108,7 +111,7 @@ class CorpBEVT(HipModule):
                 continue
             level = pick.index(stage)
             feats[level] = x
-            s = side[level]
+            s = side[level] if self.overlap_kv else main          # overlap_kv False: K/V work in line on the encoder's stream
             s.wait_stream(main)
             with torch.cuda.stream(s):
                 kv[level] = fax.cross_views[level].prepare_kv(x, I_inv, E_inv, b * l,
