@@ -218,3 +218,73 @@ extern "C" int cobevt_weighted_cross_entropy(const void* logits, const long long
     hipLaunchKernelGGL(wce_final_kernel, dim3(1), dim3(256), 0, stream, scratch, out, nparts);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// nuScenes IoU metric counts (nuscenes/cross_view_transformer/metrics.py:22-31,56-72): per threshold t,
+//   tp += |sigmoid(pred) >= t & label|, fp += |sigmoid(pred) >= t & !label|, fn += |sigmoid(pred) < t & label|
+// over the pixels whose visibility is at least min_visibility (all pixels when min_visibility < 0).  The label of an
+// output channel is the maximum (any non-zero) of a set of ground-truth channels given as a bit mask per output channel.
+// Integer counts, exact; the comparison is done on the fp32 sigmoid as in the reference.
+namespace cobevt {
+
+constexpr int kIouMaxThr = 8;
+
+__global__ __launch_bounds__(256) void iou_counts_kernel(const float* pred, const float* label, const unsigned char* visibility,
+                                                         const unsigned int* label_mask, const float* thresholds,
+                                                         unsigned long long* counts, int C, int NL, int hw, int T,
+                                                         int min_visibility, int per_thread) {
+    __shared__ unsigned int sh[kIouMaxThr * 3];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    if (tid < kIouMaxThr * 3) sh[tid] = 0;
+    __syncthreads();
+    unsigned int loc[kIouMaxThr * 3];
+#pragma unroll
+    for (int i = 0; i < kIouMaxThr * 3; ++i) loc[i] = 0;
+    const int p0 = blockIdx.x * 256 * per_thread;
+    for (int j = 0; j < per_thread; ++j) {
+        const int pix = p0 + j * 256 + tid;
+        if (pix >= hw) break;
+        if (min_visibility >= 0 && (int)visibility[(size_t)n * hw + pix] < min_visibility) continue;
+        unsigned int present = 0;                              // bit l: ground-truth channel l is non-zero here
+        for (int l = 0; l < NL; ++l) present |= (label[((size_t)n * NL + l) * hw + pix] != 0.f ? 1u : 0u) << l;
+        for (int c = 0; c < C; ++c) {
+            const float x = pred[((size_t)n * C + c) * hw + pix];
+            const float s = 1.0f / (1.0f + expf(-x));
+            const bool lab = (present & label_mask[c]) != 0;
+#pragma unroll
+            for (int t = 0; t < kIouMaxThr; ++t) {
+                if (t < T) {
+                    const bool pr = s >= thresholds[t];
+                    loc[t * 3 + 0] += (pr && lab) ? 1u : 0u;
+                    loc[t * 3 + 1] += (pr && !lab) ? 1u : 0u;
+                    loc[t * 3 + 2] += (!pr && lab) ? 1u : 0u;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kIouMaxThr * 3; ++i) {
+        unsigned int v = loc[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((tid & 63) == 0 && v) atomicAdd(&sh[i], v);
+    }
+    __syncthreads();
+    if (tid < T * 3 && sh[tid]) atomicAdd(&counts[tid], (unsigned long long)sh[tid]);
+}
+
+}  // namespace cobevt
+
+// counts[T][3] += (tp, fp, fn) (NOT zeroed here: the metric accumulates over batches).  pred (N, C, hw) fp32 logits, label
+// (N, NL, hw) fp32 (NL <= 32), visibility (N, hw) uint8 or null, label_mask [C] uint32, thresholds [T <= 8] fp32.
+extern "C" int cobevt_iou_counts(const float* pred, const float* label, const unsigned char* visibility,
+                                 const unsigned int* label_mask, const float* thresholds, unsigned long long* counts, int N,
+                                 int C, int NL, int hw, int T, int min_visibility, hipStream_t stream) {
+    if (!pred || !label || !label_mask || !thresholds || !counts) return COBEVT_ERR_ARG;
+    if (min_visibility >= 0 && !visibility) return COBEVT_ERR_ARG;
+    if (N < 1 || N > 65535 || C < 1 || NL < 1 || NL > 32 || hw < 1 || T < 1 || T > kIouMaxThr) return COBEVT_ERR_SHAPE;
+    const int per_thread = 8;
+    const dim3 grid((hw + 256 * per_thread - 1) / (256 * per_thread), N), block(256);
+    hipLaunchKernelGGL(iou_counts_kernel, grid, block, 0, stream, pred, label, visibility, label_mask, thresholds, counts, C, NL, hw,
+                       T, min_visibility, per_thread);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}

@@ -5,3 +5,4 @@ from .decoder import Decoder, DecoderBlock  # noqa: F401
 from .cvt import CrossViewTransformer  # noqa: F401
 from .backbones import FeatureMapBackbone  # noqa: F401
 from .efficientnet import EfficientNetExtractor  # noqa: F401
+from .metrics import BaseIoUMetric, IoUMetric  # noqa: F401

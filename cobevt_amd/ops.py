@@ -899,3 +899,27 @@ def weighted_cross_entropy(logits, target, weight):
     rc = _L.load().cobevt_weighted_cross_entropy(_p(x), _p(y), _p(wt), _p(scratch), _p(out), dcode(x.dtype), n, c, h * w, _stream())
     _L.check(rc, "cobevt_weighted_cross_entropy")
     return out[0]
+
+
+def iou_counts(pred, label, visibility, label_indices, thresholds, min_visibility):
+    """(T, 3) int64 host tensor of (tp, fp, fn) per threshold; nuscenes metrics.py:22-31,56-72.  pred (N, C, hw) fp32 logits on
+    the device, label (N, NL, hw), visibility (N, hw) uint8 / None, label_indices: list (length C) of lists of label channels."""
+    _need_cuda(pred)
+    n, c, hw = pred.shape
+    dev = pred.device
+    label = label.to(device=dev, dtype=torch.float32).contiguous()
+    nl = label.shape[1]
+    if len(label_indices) != c or nl > 32 or tuple(label.shape) != (n, nl, hw):
+        raise CobevtHipError("iou_counts: %d prediction channels need %d label groups over at most 32 label channels" % (c, c))
+    masks = torch.tensor([sum(1 << int(l) for l in group) for group in label_indices], dtype=torch.int64).to(torch.int32).to(dev)
+    thr = torch.as_tensor(thresholds, dtype=torch.float32).to(dev).contiguous()
+    counts = torch.zeros((thr.numel(), 3), device=dev, dtype=torch.int64)
+    vis = None
+    mv = -1
+    if min_visibility is not None:
+        vis = visibility.to(device=dev, dtype=torch.uint8).contiguous()
+        mv = int(min_visibility)
+    rc = _L.load().cobevt_iou_counts(_p(pred.contiguous()), _p(label), _p(vis), _p(masks), _p(thr), _p(counts), n, c, nl, hw,
+                                     thr.numel(), mv, _stream())
+    _L.check(rc, "cobevt_iou_counts")
+    return counts.cpu()

@@ -257,6 +257,14 @@ int cobevt_seg_class_counts(const long long* pred, const long long* gt, unsigned
 int cobevt_weighted_cross_entropy(const void* logits, const long long* target, const float* weight, float* scratch, float* out,
                                   int dtype, int N, int C, int hw, hipStream_t stream);
 
+/* nuScenes IoU metric, nuscenes/cross_view_transformer/metrics.py:22-31,56-72: counts[t] += (tp, fp, fn) of
+ * sigmoid(pred) >= thresholds[t] against label_c = any(label[l] != 0 for l in the bit mask label_mask[c]) over the pixels with
+ * visibility >= min_visibility (min_visibility < 0: all pixels, visibility may be null).  pred (N, C, hw) fp32 logits, label
+ * (N, NL <= 32, hw) fp32, visibility (N, hw) uint8, thresholds [T <= 8] fp32, counts (T, 3) uint64 - accumulated, not zeroed. */
+int cobevt_iou_counts(const float* pred, const float* label, const unsigned char* visibility, const unsigned int* label_mask,
+                      const float* thresholds, unsigned long long* counts, int N, int C, int NL, int hw, int T,
+                      int min_visibility, hipStream_t stream);
+
 /* ---- upstream of the nuScenes path: MBConv pieces of the EfficientNet image backbone wrapped by
  * nuscenes/cross_view_transformer/model/backbones/efficientnet.py:24-96 (efficientnet-pytorch 0.7.1 MBConvBlock.forward;
  * the 1x1 convolutions of a block go through cobevt_linear_rows / cobevt_conv2d_nhwc with act 3 = swish) -------------- */

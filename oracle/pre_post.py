@@ -18,6 +18,7 @@ Follows, function by function:
   collate_batch        opv2v/opencood/data_utils/datasets/camera_only/intermediate_fusion_dataset.py:231-317
   find_last_checkpoint / load_saved_model   opv2v/opencood/tools/train_utils.py:24-65
   vanilla_seg_loss     opv2v/opencood/loss/vanilla_seg_loss.py:7-76 (forward; nn.CrossEntropyLoss(weight) = weighted mean)
+  iou_metric           nuscenes/cross_view_transformer/metrics.py:7-72 (BaseIoUMetric / IoUMetric update + compute)
 """
 import glob
 import os
@@ -150,3 +151,22 @@ def vanilla_seg_loss(args, output_dict, gt_dict):
                                       weight=torch.tensor([1.0, args["s_weights"], args.get("l_weights", 50)]))
     return {"total_loss": args["s_coe"] * static_loss + args["d_coe"] * dynamic_loss, "static_loss": static_loss,
             "dynamic_loss": dynamic_loss}
+
+
+def iou_metric(updates, label_indices, min_visibility, thresholds=(0.4, 0.5)):
+    """updates: list of (pred (b, c, h, w) logits, batch dict with 'bev' (b, n, h, w) and 'visibility' (b, h, w)) ->
+    (tp, fp, fn float tensors per threshold, {'@0.40': iou, ...})"""
+    thr = torch.FloatTensor(list(thresholds))
+    tp, fp, fn = torch.zeros_like(thr), torch.zeros_like(thr), torch.zeros_like(thr)
+    for pred, batch in updates:
+        label = torch.cat([batch["bev"][:, idx].max(1, keepdim=True).values for idx in label_indices], 1)
+        if min_visibility is not None:
+            mask = (batch["visibility"] >= min_visibility)[:, None].expand_as(pred)
+            pred, label = pred[mask], label[mask]
+        p = pred.detach().sigmoid().reshape(-1)[:, None] >= thr[None]
+        l = label.detach().bool().reshape(-1)[:, None]
+        tp += (p & l).sum(0)
+        fp += (p & ~l).sum(0)
+        fn += (~p & l).sum(0)
+    ious = tp / (tp + fp + fn + 1e-7)
+    return tp, fp, fn, {"@%.2f" % t.item(): i.item() for t, i in zip(thr, ious)}

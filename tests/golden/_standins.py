@@ -125,3 +125,21 @@ def install():
         sh.geometry = geo
         sys.modules["shapely"] = sh
         sys.modules["shapely.geometry"] = geo
+
+
+def install_torchmetrics():
+    """`torchmetrics.Metric` as far as nuscenes/cross_view_transformer/metrics.py uses it: constructor keywords ignored,
+    add_state(name, default, ...) sets an attribute.  (torchmetrics is not installed; the metric's arithmetic is the
+    reference's own update / compute code, which this base class does not touch.)"""
+    if "torchmetrics" in sys.modules:
+        return
+    tm = types.ModuleType("torchmetrics")
+
+    class Metric(object):
+        def __init__(self, **kwargs):
+            pass
+
+        def add_state(self, name, default, dist_reduce_fx=None):
+            setattr(self, name, default.clone())
+    tm.Metric = Metric
+    sys.modules["torchmetrics"] = tm

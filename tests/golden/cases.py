@@ -257,3 +257,23 @@ def seg_loss_inputs():
             "static_seg": (rs.standard_normal((b, 1, 3, h, w)) * 2.5).astype(np.float32),
             "gt_dynamic": rs.randint(0, 2, size=(b, 1, h, w)).astype(np.int64),
             "gt_static": rs.randint(0, 3, size=(b, 1, h, w)).astype(np.int64)}
+
+
+# nuScenes IoU metric: config/experiment/cvt_nuscenes_vehicle.yaml groups label channels [4..11] into one output channel with
+# min_visibility 2; a two-channel grouping exercises the bit masks
+IOU_METRIC = [dict(label_indices=[[4, 5, 6, 7, 8, 9, 10, 11]], min_visibility=2, channels=1),
+              dict(label_indices=[[0, 1], [2, 3]], min_visibility=None, channels=2)]
+
+
+def iou_metric_inputs(channels):
+    """two update() calls: (pred (b, channels, h, w), bev labels (b, 12, h, w), visibility (b, h, w))"""
+    import numpy as np
+    rs = np.random.RandomState(777 + channels)
+    out = []
+    for b in (2, 1):
+        pred = (rs.standard_normal((b, channels, 40, 56)) * 2.0).astype(np.float32)
+        pred[0, 0, 0, :4] = [0.0, np.log(0.4 / 0.6), -np.log(0.4 / 0.6), 1e-7]          # on and next to the thresholds
+        bev = (rs.rand(b, 12, 40, 56) > 0.93).astype(np.float32)
+        vis = rs.choice(np.array([1, 2, 3, 4, 255], dtype=np.uint8), size=(b, 40, 56))
+        out.append((pred, bev, vis))
+    return out

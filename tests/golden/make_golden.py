@@ -401,6 +401,30 @@ def gv14():
     save("gv14_vanilla_seg_loss", **out)
 
 
+def gv15():
+    """nuScenes IoUMetric (cross_view_transformer/metrics.py) over two update() calls, with the vehicle experiment's label
+    grouping + visibility mask and with a two-channel grouping."""
+    import importlib.util
+    import oracle.pre_post as o_pp
+    _standins.install_torchmetrics()
+    spec = importlib.util.spec_from_file_location("ref_nuscenes_metrics", "/root/reference/nuscenes/cross_view_transformer/metrics.py")
+    R = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(R)
+    out = {}
+    for i, c in enumerate(cases.IOU_METRIC):
+        ups = [(torch.from_numpy(p), {"bev": torch.from_numpy(b), "visibility": torch.from_numpy(v)}) for p, b, v in cases.iou_metric_inputs(c["channels"])]
+        m = R.IoUMetric(c["label_indices"], c["min_visibility"])
+        for pred, batch in ups:
+            m.update({"bev": pred}, batch)
+        res = m.compute()
+        tp, fp, fn, mine = o_pp.iou_metric(ups, c["label_indices"], c["min_visibility"])
+        assert torch.equal(tp, m.tp) and torch.equal(fp, m.fp) and torch.equal(fn, m.fn) and mine == res, (mine, res)
+        out["tp%d" % i], out["fp%d" % i], out["fn%d" % i] = _np(m.tp), _np(m.fp), _np(m.fn)
+        out["iou%d" % i] = np.array([res[k] for k in sorted(res)], dtype=np.float64)
+        print("  IoUMetric %s -> %s" % (c, res))
+    save("gv15_nuscenes_iou_metric", **out)
+
+
 def gv13():
     """NaiveCompressor (sub_modules/naive_compress.py) alone and inside the reduced CorpBEVT with compression = 2."""
     import copy
@@ -422,7 +446,7 @@ def gv13():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gv0", "gv1", "gv2", "gv3", "gv4", "gv5", "gv6", "gv7", "gv8", "gv9", "gv10", "gv11", "gv12", "gv13", "gv14"]
+    which = sys.argv[1:] or ["gv0", "gv1", "gv2", "gv3", "gv4", "gv5", "gv6", "gv7", "gv8", "gv9", "gv10", "gv11", "gv12", "gv13", "gv14", "gv15"]
     for name in which:
         print("== " + name)
         globals()[name]()

@@ -120,6 +120,18 @@ def test_vanilla_seg_loss_oracle_matches_reference():
             assert abs(float(mine[k]) - float(g["%s%d" % (k, i)])) <= 1e-6 * max(1.0, abs(float(g["%s%d" % (k, i)])))
 
 
+def _iou_updates(channels):
+    return [(torch.from_numpy(p), {"bev": torch.from_numpy(b), "visibility": torch.from_numpy(v)}) for p, b, v in cases.iou_metric_inputs(channels)]
+
+
+def test_nuscenes_iou_metric_oracle_matches_reference():
+    g = golden("gv15_nuscenes_iou_metric")
+    for i, c in enumerate(cases.IOU_METRIC):
+        tp, fp, fn, res = o_pp.iou_metric(_iou_updates(c["channels"]), c["label_indices"], c["min_visibility"])
+        assert np.array_equal(tp.numpy(), g["tp%d" % i]) and np.array_equal(fp.numpy(), g["fp%d" % i]) and np.array_equal(fn.numpy(), g["fn%d" % i])
+        assert np.allclose([res[k] for k in sorted(res)], g["iou%d" % i], rtol=0, atol=1e-7)
+
+
 def test_logit_side_has_no_cpu_fallback():
     post = h_post.CameraBevPostprocessor({}, train=False)
     with pytest.raises(CobevtHipError):
@@ -235,3 +247,31 @@ def test_vanilla_seg_loss_forward(cuda, dtype):
     assert torch.equal(a, ops.weighted_cross_entropy(x.to(cuda), y.to(cuda), wt))
     ref = torch.nn.functional.cross_entropy(x, y, weight=wt)
     assert abs(float(a) - float(ref)) <= 1e-5 * float(ref)
+
+
+@pytest.mark.gpu
+def test_nuscenes_iou_metric_on_device(cuda):
+    """IoUMetric.update / compute with the prediction on the GPU: integer tp / fp / fn equal to the reference's (gv15) -
+    including the pixels crafted to sit exactly on the 0.5 threshold; the three next to a threshold may flip with the exp
+    implementation, so the counts are allowed to differ by that many."""
+    from cobevt_amd.host.nuscenes.metrics import BaseIoUMetric, IoUMetric
+    g = golden("gv15_nuscenes_iou_metric")
+    for i, c in enumerate(cases.IOU_METRIC):
+        m = IoUMetric(c["label_indices"], c["min_visibility"])
+        for pred, batch in _iou_updates(c["channels"]):
+            m.update({"bev": pred.to(cuda)}, {k: v.to(cuda) for k, v in batch.items()})
+        for name in ("tp", "fp", "fn"):
+            assert np.abs(getattr(m, name).numpy() - g["%s%d" % (name, i)]).max() <= 3, name
+        res = m.compute()
+        assert sorted(res) == ["@0.40", "@0.50"]
+        assert np.allclose([res[k] for k in sorted(res)], g["iou%d" % i], rtol=0, atol=2e-3)
+        m.reset()
+        assert float(m.tp.sum()) == 0
+    # BaseIoUMetric.update(pred, label) on flat tensors, vs the oracle on the same data
+    pred, batch = _iou_updates(1)[0]
+    label = batch["bev"][:, 4:5]
+    base = BaseIoUMetric()
+    base.update(pred.to(cuda), label.to(cuda))
+    p = pred.sigmoid().reshape(-1)[:, None] >= base.thresholds[None]
+    l = label.bool().reshape(-1)[:, None]
+    assert np.abs(base.tp.numpy() - (p & l).sum(0).numpy()).max() <= 3 and np.abs(base.fn.numpy() - (~p & l).sum(0).numpy()).max() <= 3
