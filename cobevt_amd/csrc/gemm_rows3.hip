@@ -1,4 +1,4 @@
-// Dense-row GEMM for K <= 128, the row chain's way (gfx950, bf16):
+// Dense-row GEMM for K <= 512, the row chain's way (gfx950, bf16):
 //   out[m][n] = act( f(A[m][:]) . W[n][:] + bias[n] + residual[m][n] ),   f = LayerNorm | per-channel affine (+ReLU) | id
 // reference: the same Linear / 1x1-conv sites as gemm_rows.hip (to_q / to_k / to_v / to_qkv behind a LayerNorm, feature_proj /
 // feature_linear behind BN + ReLU, the Bottleneck 1x1 convs; fax_modules.py:193-203,283-300,472, swap_fusion_modules.py:93).
@@ -24,115 +24,133 @@ struct Gr3Params {
     const float* pre_scale; // [K] or null (with pre_shift)
     const float* pre_shift;
     bf16_t* out;            // [M][N]
-    int M, N, K;
+    int M, N, K, Kp;        // Kp = K rounded up to 128 (<= 512): the fragment array has Kp / 16 k-groups per 32-column tile
     long lda;
     int pre_relu, act, ln;
     float ln_eps;
-};
+    int in_stride, src_H, src_W, in_H, in_W;   // in_stride > 1: row m = (n, oy, ox) of an (src_H, src_W) map reads input pixel
+};                                             // (oy * in_stride, ox * in_stride) of an (in_H, in_W) map (1x1 / stride-2 conv)
 
-constexpr int kG3Row = 256 + 16;            // 128 bf16 + pad
+constexpr int kG3Row = 256 + 16;            // staged output row: 128 bf16 + pad
 constexpr int kG3Rows = 32;
-constexpr int kG3A = 0, kG3Y = kG3Rows * kG3Row, kG3Bias = 2 * kG3Rows * kG3Row;   // + N_p floats of bias
+// LDS: A rows [32][Kp * 2 + 16] | output tile [32][272] | N_p floats of bias
 
 __global__ __launch_bounds__(256, 4) void gemm_rows3_kernel(Gr3Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem + kG3A;
-    unsigned char* Ys = smem + kG3Y;
-    float* sb = (float*)(smem + kG3Bias);
+    const int arow = p.Kp * 2 + 16;
+    unsigned char* As = smem;
+    unsigned char* Ys = smem + kG3Rows * arow;
+    float* sb = (float*)(Ys + kG3Rows * kG3Row);
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int h = lane >> 5, ql = lane & 31;
     const int m0 = blockIdx.x * kG3Rows;
     const int row = ql;
     const bool row_ok = m0 + row < p.M;
-    const int npn = (p.N + 127) / 128;
+    const int npn = (p.N + 127) / 128, nkt = p.Kp >> 7, nkg = p.Kp >> 4;
+    const int nsteps = npn * nkt;
     const int cbase = wn * 32 + 4 * h;
 
-    auto load_frags = [&](uint4 (&b)[8], int tile) {
-        const uint4* src = p.wfrag + (size_t)tile * 8 * 64 + lane;
+    // step s = (pass, k-tile): the eight fragments of columns [128 pass + 32 wn, +32) x k-groups [8 kt, +8)
+    auto load_frags = [&](uint4 (&b)[8], int step) {
+        const int pass = step / nkt, kt = step - pass * nkt;
+        const uint4* src = p.wfrag + ((size_t)(pass * 4 + wn) * nkg + kt * 8) * 64 + lane;
 #pragma unroll
         for (int g = 0; g < 8; ++g) b[g] = src[g * 64];
         __builtin_amdgcn_sched_barrier(0);
     };
     uint4 fa[8], fb[8];
-    load_frags(fa, wn);
+    load_frags(fa, 0);
 
     // bias of all passes into LDS (zero padded), unconditional clamped loads
     for (int i = tid; i < npn * 128; i += 256) {
         const float b = p.bias ? p.bias[i < p.N ? i : 0] : 0.f;
         sb[i] = i < p.N ? b : 0.f;
     }
-    // ---- stage the 32 A rows: 8 threads per row, 16 channels each; LayerNorm / pre-activation in flight
+    // ---- stage the 32 A rows: 8 threads per row, 16 channels per 128-channel tile each; LayerNorm (single tile) or the
+    // per-channel pre-activation in flight
     {
         const int r = tid >> 3, sub = tid & 7;
         const bool ok = m0 + r < p.M;
-        const bf16_t* src = p.in + (size_t)(ok ? m0 + r : 0) * p.lda;
-        uint4 raw[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int k = sub * 16 + j * 8;
-            raw[j] = *(const uint4*)(src + (k < p.K ? k : 0));
+        size_t arow_idx = ok ? m0 + r : 0;
+        if (p.in_stride > 1) {
+            const int hw = p.src_H * p.src_W;
+            const int n = (int)(arow_idx / hw), rem = (int)(arow_idx - (size_t)n * hw);
+            const int oy = rem / p.src_W, ox = rem - oy * p.src_W;
+            arow_idx = ((size_t)n * p.in_H + (size_t)oy * p.in_stride) * p.in_W + (size_t)ox * p.in_stride;
         }
-        float v[16];
-        chunk_to_f32<bf16_t>(raw[0], v);
-        chunk_to_f32<bf16_t>(raw[1], v + 8);
+        const bf16_t* src = p.in + arow_idx * p.lda;
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int kb = kt * 128 + sub * 16;
+            uint4 raw[2];
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-            if (!ok || sub * 16 + e >= p.K) v[e] = 0.f;
-        if (p.ln) {
-            float s = 0.f;
+            for (int j = 0; j < 2; ++j) raw[j] = *(const uint4*)(src + (kb + j * 8 < p.K ? kb + j * 8 : 0));
+            float v[16];
+            chunk_to_f32<bf16_t>(raw[0], v);
+            chunk_to_f32<bf16_t>(raw[1], v + 8);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s += v[e];
-            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-            const float mean = s / (float)p.K;
-            float q = 0.f;
+            for (int e = 0; e < 16; ++e)
+                if (!ok || kb + e >= p.K) v[e] = 0.f;
+            if (p.ln) {                                   // Kp == 128 (checked by the entry point): the row is here
+                float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { const float d = (sub * 16 + e) < p.K ? v[e] - mean : 0.f; q += d * d; }
-            q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
-            const float rstd = rsqrtf(q / (float)p.K + p.ln_eps);
+                for (int e = 0; e < 16; ++e) s += v[e];
+                s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+                const float mean = s / (float)p.K;
+                float q = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = (sub * 16 + e) < p.K ? (v[e] - mean) * rstd : 0.f;
-        } else if (p.pre_scale) {
+                for (int e = 0; e < 16; ++e) { const float d = (kb + e) < p.K ? v[e] - mean : 0.f; q += d * d; }
+                q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+                const float rstd = rsqrtf(q / (float)p.K + p.ln_eps);
 #pragma unroll
-            for (int e = 0; e < 16; e += 4) {
-                const int k = sub * 16 + e;
-                const float4 sc = *(const float4*)(p.pre_scale + (k < p.K ? k : 0)), sh = *(const float4*)(p.pre_shift + (k < p.K ? k : 0));
-                const float x0 = v[e] * sc.x + sh.x, x1 = v[e + 1] * sc.y + sh.y, x2 = v[e + 2] * sc.z + sh.z, x3 = v[e + 3] * sc.w + sh.w;
-                const bool in = ok && k < p.K;                      // K % 8 == 0: a run of four is inside or outside
-                v[e] = in ? (p.pre_relu ? fmaxf(x0, 0.f) : x0) : 0.f;
-                v[e + 1] = in ? (p.pre_relu ? fmaxf(x1, 0.f) : x1) : 0.f;
-                v[e + 2] = in ? (p.pre_relu ? fmaxf(x2, 0.f) : x2) : 0.f;
-                v[e + 3] = in ? (p.pre_relu ? fmaxf(x3, 0.f) : x3) : 0.f;
+                for (int e = 0; e < 16; ++e) v[e] = (kb + e) < p.K ? (v[e] - mean) * rstd : 0.f;
+            } else if (p.pre_scale) {
+#pragma unroll
+                for (int e = 0; e < 16; e += 4) {
+                    const int k = kb + e;
+                    const float4 sc = *(const float4*)(p.pre_scale + (k < p.K ? k : 0)), sh = *(const float4*)(p.pre_shift + (k < p.K ? k : 0));
+                    const float x0 = v[e] * sc.x + sh.x, x1 = v[e + 1] * sc.y + sh.y, x2 = v[e + 2] * sc.z + sh.z, x3 = v[e + 3] * sc.w + sh.w;
+                    const bool in = ok && k < p.K;                  // K % 8 == 0: a run of four is inside or outside
+                    v[e] = in ? (p.pre_relu ? fmaxf(x0, 0.f) : x0) : 0.f;
+                    v[e + 1] = in ? (p.pre_relu ? fmaxf(x1, 0.f) : x1) : 0.f;
+                    v[e + 2] = in ? (p.pre_relu ? fmaxf(x2, 0.f) : x2) : 0.f;
+                    v[e + 3] = in ? (p.pre_relu ? fmaxf(x3, 0.f) : x3) : 0.f;
+                }
             }
+            *(uint4*)(As + r * arow + kb * 2) = f32_to_chunk<bf16_t>(v);
+            *(uint4*)(As + r * arow + kb * 2 + 16) = f32_to_chunk<bf16_t>(v + 8);
         }
-        *(uint4*)(As + r * kG3Row + sub * 32) = f32_to_chunk<bf16_t>(v);
-        *(uint4*)(As + r * kG3Row + sub * 32 + 16) = f32_to_chunk<bf16_t>(v + 8);
     }
     __syncthreads();
 
-    const int abase = row * kG3Row + h * 16;
-    const int ng = (p.K * 2 + 31) / 32;
+    const int abase = row * arow + h * 16;
     f32x16 acc;
-    auto pass_body = [&](int pass, const uint4 (&cur)[8], uint4 (&nxt)[8]) {
-        if (pass + 1 < npn) load_frags(nxt, (pass + 1) * 4 + wn);
-        // residual pieces of this lane's (row, column runs): in flight under the MFMAs
-        uint2 rs[4];
+    uint2 rs[4];
+    auto step_body = [&](int step, const uint4 (&cur)[8], uint4 (&nxt)[8]) {
+        const int pass = step / nkt, kt = step - pass * nkt;
+        if (step + 1 < nsteps) load_frags(nxt, step + 1);
+        if (kt == 0) {
+            // residual pieces of this lane's (row, column runs): in flight under the MFMAs
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int col0 = pass * 128 + cbase + 8 * k;
-            const bool ok = p.residual && row_ok && col0 < p.N;
-            rs[k] = make_uint2(0, 0);
-            if (p.residual) rs[k] = *(const uint2*)(p.residual + (ok ? (size_t)(m0 + row) * p.N + col0 : 0));
-            if (!ok) rs[k] = make_uint2(0, 0);
+            for (int k = 0; k < 4; ++k) {
+                const int col0 = pass * 128 + cbase + 8 * k;
+                const bool ok = p.residual && row_ok && col0 < p.N;
+                rs[k] = make_uint2(0, 0);
+                if (p.residual) rs[k] = *(const uint2*)(p.residual + (ok ? (size_t)(m0 + row) * p.N + col0 : 0));
+                if (!ok) rs[k] = make_uint2(0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int kleft = p.K - kt * 128;
+        const int ng = kleft >= 128 ? 8 : (kleft * 2 + 31) / 32;
 #pragma unroll
         for (int g = 0; g < 8; ++g)
             if (g < ng) {
-                const uint4 af = *(const uint4*)(As + abase + g * 32);
+                const uint4 af = *(const uint4*)(As + abase + (kt * 8 + g) * 32);
                 mfma_kgroup<bf16_t>(cur[g], af, acc);
             }
+        if (kt + 1 < nkt) return;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int col0 = pass * 128 + cbase + 8 * k;
@@ -155,9 +173,9 @@ __global__ __launch_bounds__(256, 4) void gemm_rows3_kernel(Gr3Params p) {
         }
         if (pass + 1 < npn) __syncthreads();          // Ys is rewritten by the next pass
     };
-    for (int pass = 0; pass < npn; pass += 2) {
-        pass_body(pass, fa, fb);
-        if (pass + 1 < npn) pass_body(pass + 1, fb, fa);
+    for (int step = 0; step < nsteps; step += 2) {
+        step_body(step, fa, fb);
+        if (step + 1 < nsteps) step_body(step + 1, fb, fa);
     }
 }
 
@@ -169,7 +187,7 @@ using namespace cobevt;
 extern "C" int cobevt_linear_rows_small_k(const void* in, const void* wfrag, const float* bias, const void* residual,
                                           const float* pre_scale, const float* pre_shift, void* out, const long* dims, float ln_eps,
                                           hipStream_t stream) {
-    // dims: [dtype(0), M, N, K, lda, pre_relu, act, ln]
+    // dims: [dtype(0), M, N, K, lda, pre_relu, act, ln, in_stride, src_H, src_W, in_H, in_W]
     if (!in || !wfrag || !out || !dims) return COBEVT_ERR_ARG;
     if (dims[0] != 0) return COBEVT_ERR_UNSUPPORTED;
     Gr3Params p;
@@ -177,11 +195,17 @@ extern "C" int cobevt_linear_rows_small_k(const void* in, const void* wfrag, con
     p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.out = (bf16_t*)out;
     p.M = (int)dims[1]; p.N = (int)dims[2]; p.K = (int)dims[3]; p.lda = dims[4];
     p.pre_relu = (int)dims[5]; p.act = (int)dims[6]; p.ln = (int)dims[7]; p.ln_eps = ln_eps;
-    if (p.M < 1 || p.N < 8 || p.N % 8 || p.N > 4096 || p.K < 8 || p.K > 128 || p.K % 8 || p.lda < p.K || p.lda % 8) return COBEVT_ERR_SHAPE;
+    p.in_stride = (int)dims[8]; p.src_H = (int)dims[9]; p.src_W = (int)dims[10]; p.in_H = (int)dims[11]; p.in_W = (int)dims[12];
+    p.Kp = (p.K + 127) / 128 * 128;
+    if (p.M < 1 || p.N < 8 || p.N % 8 || p.N > 4096 || p.K < 8 || p.K > 512 || p.K % 8 || p.lda < p.K || p.lda % 8) return COBEVT_ERR_SHAPE;
+    if (p.ln && p.K > 128) return COBEVT_ERR_UNSUPPORTED;          // LayerNorm fusion needs the row in one 128-channel tile
+    if (p.in_stride < 1 || (p.in_stride > 1 && (p.src_H < 1 || p.src_W < 1 || p.in_H < 1 || p.in_W < 1 || p.M % (p.src_H * p.src_W))))
+        return COBEVT_ERR_SHAPE;
+    if (p.in_stride > 1 && residual) return COBEVT_ERR_UNSUPPORTED;
     if ((pre_scale == nullptr) != (pre_shift == nullptr)) return COBEVT_ERR_ARG;
     if (p.ln && pre_scale) return COBEVT_ERR_UNSUPPORTED;
     if (p.act < 0 || p.act > 4) return COBEVT_ERR_ARG;
-    const size_t lds = (size_t)kG3Bias + (size_t)((p.N + 127) / 128) * 128 * 4;
+    const size_t lds = (size_t)kG3Rows * (p.Kp * 2 + 16) + (size_t)kG3Rows * kG3Row + (size_t)((p.N + 127) / 128) * 128 * 4;
     const unsigned blocks = (unsigned)((p.M + kG3Rows - 1) / kG3Rows);
     hipLaunchKernelGGL(gemm_rows3_kernel, dim3(blocks), dim3(256), lds, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;

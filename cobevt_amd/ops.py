@@ -22,6 +22,8 @@ USE_GEMM_ROWS = True  # route 1x1 stride-1 convs / linears to the dense-row GEMM
 USE_GEMM_ROWS2 = False  # dense-row GEMMs through the persistent fragment-ordered kernel (cobevt_linear_rows_wfrag):
 USE_GEMM_ROWS3 = True     # K <= 128 bf16 dense rows on the row-chain-style kernel (gemm_rows3.hip)
 GEMM_ROWS3_MIN_M = 0
+GEMM_ROWS3_MAX_K = 512     # 128: only single-tile rows take the 32-row kernel
+GEMM_ROWS3_STRIDED = 1     # stride-2 1x1 convs (ResNet down-sampling) too
 # measured 3-20 % SLOWER than two independent workgroups per CU (196 VGPRs -> one workgroup per CU, only one 32-KB tile
 # of loads in flight per CU: latency-bound on HBM); kept for the parity tests and as the base for a deeper prefetch
 USE_STEM_POOL = True  # stem conv + max pool in one launch (the stem map never reaches HBM)
@@ -50,7 +52,7 @@ def _apply_env_flags():
         if "=" in item:
             k, v = item.split("=", 1)
             k = k.strip()
-            if k not in globals() or not (k.startswith("USE_") or k in ("CONV3_VARIANT", "BASICBLOCK_TILE_ROWS", "ROW_CHAIN_ROWS", "GEMM_ROWS3_MIN_M")):
+            if k not in globals() or not (k.startswith("USE_") or k in ("CONV3_VARIANT", "BASICBLOCK_TILE_ROWS", "ROW_CHAIN_ROWS", "GEMM_ROWS3_MIN_M", "GEMM_ROWS3_MAX_K", "GEMM_ROWS3_STRIDED")):
                 raise CobevtHipError("COBEVT_FLAGS: unknown switch %r" % k)
             globals()[k] = int(v) if not k.startswith("USE_") else bool(int(v))
 
@@ -374,12 +376,15 @@ def conv2d(x, plan, residual=None, out=None):
                                      ho, wo, out_h, out_w, int(ln), plan.stride, h, w)
         v2 = USE_GEMM_ROWS2 and plan.wfrag_rows is not None and plan.cout % (8 if plan.code == BF16 else 4) == 0
         # K <= 128 bf16 rows: the row-chain-style kernel (32-row workgroups, fragment-ordered weights from L2)
-        v3 = (USE_GEMM_ROWS3 and plan.code == BF16 and plan.wfrag_rows is not None and plan.kp_rows == 128 and plan.K % 8 == 0
-              and plan.stride == 1 and (out_h, out_w) == (ho, wo) and plan.cout % 8 == 0 and plan.cout <= 4096 and sm == 0
-              and n * ho * wo >= GEMM_ROWS3_MIN_M)
+        v3 = (USE_GEMM_ROWS3 and plan.code == BF16 and plan.wfrag_rows is not None and plan.kp_rows <= GEMM_ROWS3_MAX_K
+              and plan.K % 8 == 0 and (out_h, out_w) == (ho, wo) and plan.cout % 8 == 0 and plan.cout <= 4096 and sm == 0
+              and not (plan.stride > 1 and (residual is not None or not GEMM_ROWS3_STRIDED))
+              and not (ln and plan.kp_rows > 128) and n * ho * wo >= GEMM_ROWS3_MIN_M)
         if v3:
-            d3 = (ctypes.c_long * 8)(plan.code, n * ho * wo, plan.cout, plan.K, cin, plan.pre_relu, plan.act, int(ln))
-            with _timed("gemm_rows|%d->%d M=%d%s k128" % (cin, plan.cout, n * ho * wo, " ln" if ln else ""), cost):
+            d3 = (ctypes.c_long * 13)(plan.code, n * ho * wo, plan.cout, plan.K, cin, plan.pre_relu, plan.act, int(ln),
+                                      plan.stride, ho, wo, h, w)
+            with _timed("gemm_rows|%d->%d M=%d%s%s r32" % (cin, plan.cout, n * ho * wo, " ln" if ln else "",
+                                                        " s%d" % plan.stride if plan.stride > 1 else ""), cost):
                 rc = _L.load().cobevt_linear_rows_small_k(_p(x), _p(plan.wfrag_rows), _p(plan.bias), _p(residual), _p(plan.pre_scale),
                                                           _p(plan.pre_shift), _p(out), d3, ctypes.c_float(plan.ln_eps), _stream())
             _L.check(rc, "cobevt_linear_rows_small_k")

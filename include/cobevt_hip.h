@@ -257,11 +257,13 @@ int cobevt_seg_class_counts(const long long* pred, const long long* gt, unsigned
 int cobevt_weighted_cross_entropy(const void* logits, const long long* target, const float* weight, float* scratch, float* out,
                                   int dtype, int N, int C, int hw, hipStream_t stream);
 
-/* The same GEMM as cobevt_linear_rows for K <= 128 in bf16 (the to_q / to_k / to_v / to_qkv projections behind a LayerNorm,
+/* The same GEMM as cobevt_linear_rows for K <= 512 in bf16 (the to_q / to_k / to_v / to_qkv projections behind a LayerNorm,
  * feature_proj / feature_linear behind BN + ReLU, the Bottleneck 1x1 convs), on the row chain's structure: 32-row workgroups,
  * weights as MFMA fragments straight from L2.  wfrag: [N_p/32][8][64 lanes][16 bytes] as for cobevt_attn_mlp_chain (rows
- * zero-padded to 128 columns, N_p = N rounded up to 128).  dims (int64[8]): dtype (0), M, N (multiple of 8, <= 4096), K
- * (multiple of 8, <= 128), lda, pre_relu, act (0..4), ln.  residual [M][N], pre_scale / pre_shift [K], bias [N] nullable. */
+ * zero-padded to a multiple of 128 columns K_p, K_p / 16 k-groups per tile, N_p = N rounded up to 128).  dims (int64[13]):
+ * dtype (0), M, N (multiple of 8, <= 4096), K (multiple of 8, <= 512; ln needs K <= 128), lda, pre_relu, act (0..4), ln,
+ * in_stride, src_H, src_W, in_H, in_W (strided row gather of a 1x1 / stride-2 conv as in cobevt_linear_rows; 1 = dense rows).
+ * residual [M][N] (dense rows only), pre_scale / pre_shift [K], bias [N] nullable. */
 int cobevt_linear_rows_small_k(const void* in, const void* wfrag, const float* bias, const void* residual, const float* pre_scale,
                                const float* pre_shift, void* out, const long* dims, float ln_eps, hipStream_t stream);
 
