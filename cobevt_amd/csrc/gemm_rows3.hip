@@ -29,12 +29,18 @@ struct Gr3Params {
     int pre_relu, act, ln;
     float ln_eps;
     int in_stride, src_H, src_W, in_H, in_W;   // in_stride > 1: row m = (n, oy, ox) of an (src_H, src_W) map reads input pixel
-};                                             // (oy * in_stride, ox * in_stride) of an (in_H, in_W) map (1x1 / stride-2 conv)
+                                               // (oy * in_stride, ox * in_stride) of an (in_H, in_W) map (1x1 / stride-2 conv)
+    // EMB: the A rows are the BEV query  x[b][pix] + L2norm_c(w_bev . world[pix] + b_bev - w_cam . E_inv[b, cam][:, 3])
+    // (fax_modules.py:370-375,387-388) of row m = ((b * n + cam) * hw + pix), produced while staging; `in` is x (B | 1, hw, K)
+    const float* emb_E; const float* emb_world; const float* emb_wbev; const float* emb_bbev; const float* emb_wcam;
+    int emb_n, emb_hw, emb_xbcast;
+};
 
 constexpr int kG3Row = 256 + 16;            // staged output row: 128 bf16 + pad
 constexpr int kG3Rows = 32;
 // LDS: A rows [32][Kp * 2 + 16] | output tile [32][272] | N_p floats of bias
 
+template <bool EMB>
 __global__ __launch_bounds__(256, 4) void gemm_rows3_kernel(Gr3Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int arow = p.Kp * 2 + 16;
@@ -67,6 +73,22 @@ __global__ __launch_bounds__(256, 4) void gemm_rows3_kernel(Gr3Params p) {
         const float b = p.bias ? p.bias[i < p.N ? i : 0] : 0.f;
         sb[i] = i < p.N ? b : 0.f;
     }
+    // EMB: per-channel (w_bev0, w_bev1, b_bev - w_cam . c) of this workgroup's camera (hw % 32 == 0: one camera per workgroup)
+    float4* coef = (float4*)(sb + npn * 128);
+    if (EMB) {
+        const int bn = m0 / p.emb_hw;
+        if (tid < 128) {
+            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int k = tid < p.K ? tid : 0;
+            const float* E = p.emb_E + (size_t)bn * 16;
+            const float4 wc = *(const float4*)(p.emb_wcam + k * 4);
+            c.x = p.emb_wbev[k * 2];
+            c.y = p.emb_wbev[k * 2 + 1];
+            c.z = p.emb_bbev[k] - (wc.x * E[3] + wc.y * E[7] + wc.z * E[11] + wc.w * E[15]);
+            coef[tid] = tid < p.K ? c : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+    }
     // ---- stage the 32 A rows: 8 threads per row, 16 channels per 128-channel tile each; LayerNorm (single tile) or the
     // per-channel pre-activation in flight
     {
@@ -78,6 +100,13 @@ __global__ __launch_bounds__(256, 4) void gemm_rows3_kernel(Gr3Params p) {
             const int n = (int)(arow_idx / hw), rem = (int)(arow_idx - (size_t)n * hw);
             const int oy = rem / p.src_W, ox = rem - oy * p.src_W;
             arow_idx = ((size_t)n * p.in_H + (size_t)oy * p.in_stride) * p.in_W + (size_t)ox * p.in_stride;
+        }
+        float wx = 0.f, wy = 0.f;
+        if (EMB) {                                            // x row of (b, pix); world coordinates of pix
+            const int m = (int)arow_idx, bn = m / p.emb_hw, pix = m - bn * p.emb_hw;
+            wx = p.emb_world[pix];
+            wy = p.emb_world[p.emb_hw + pix];
+            arow_idx = (size_t)(p.emb_xbcast ? 0 : bn / p.emb_n) * p.emb_hw + pix;
         }
         const bf16_t* src = p.in + arow_idx * p.lda;
         for (int kt = 0; kt < nkt; ++kt) {
@@ -91,6 +120,22 @@ __global__ __launch_bounds__(256, 4) void gemm_rows3_kernel(Gr3Params p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 if (!ok || kb + e >= p.K) v[e] = 0.f;
+            if (EMB) {                                        // single tile (K <= 128): v holds x, add the normalised embedding
+                float em[16], ss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float4 c = coef[kb + e];
+                    em[e] = (kb + e) < p.K ? (c.x * wx + c.y * wy + c.z) : 0.f;
+                    ss += em[e] * em[e];
+                }
+                ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+                const float inv = 1.0f / (sqrtf(ss) + 1e-7f);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = ok ? em[e] * inv + v[e] : 0.f;
+                // rounded exactly as cobevt_fax_bev_embed would have stored the query, then normalised
+                chunk_to_f32<bf16_t>(f32_to_chunk<bf16_t>(v), v);
+                chunk_to_f32<bf16_t>(f32_to_chunk<bf16_t>(v + 8), v + 8);
+            }
             if (p.ln) {                                   // Kp == 128 (checked by the entry point): the row is here
                 float s = 0.f;
 #pragma unroll
@@ -207,6 +252,33 @@ extern "C" int cobevt_linear_rows_small_k(const void* in, const void* wfrag, con
     if (p.act < 0 || p.act > 4) return COBEVT_ERR_ARG;
     const size_t lds = (size_t)kG3Rows * (p.Kp * 2 + 16) + (size_t)kG3Rows * kG3Row + (size_t)((p.N + 127) / 128) * 128 * 4;
     const unsigned blocks = (unsigned)((p.M + kG3Rows - 1) / kG3Rows);
-    hipLaunchKernelGGL(gemm_rows3_kernel, dim3(blocks), dim3(256), lds, stream, p);
+    p.emb_E = p.emb_world = p.emb_wbev = p.emb_bbev = p.emb_wcam = nullptr;
+    p.emb_n = p.emb_hw = 1; p.emb_xbcast = 0;
+    hipLaunchKernelGGL(gemm_rows3_kernel<false>, dim3(blocks), dim3(256), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// C-ABI entry point, see include/cobevt_hip.h
+extern "C" int cobevt_bev_embed_linear_rows_small_k(const float* E_inv, const float* world, const float* w_bev, const float* b_bev,
+                                                    const float* w_cam, const void* x, const void* wfrag, const float* bias, void* out,
+                                                    const long* dims, float ln_eps, hipStream_t stream) {
+    // dims: [dtype(0), B, n, hw, D (= K <= 128), N, ln, x_bcast]
+    if (!E_inv || !world || !w_bev || !b_bev || !w_cam || !x || !wfrag || !out || !dims) return COBEVT_ERR_ARG;
+    if (dims[0] != 0) return COBEVT_ERR_UNSUPPORTED;
+    const long B = dims[1], n = dims[2], hw = dims[3];
+    Gr3Params p;
+    p.in = (const bf16_t*)x; p.wfrag = (const uint4*)wfrag; p.bias = bias; p.residual = nullptr;
+    p.pre_scale = p.pre_shift = nullptr; p.out = (bf16_t*)out;
+    p.K = (int)dims[4]; p.N = (int)dims[5]; p.ln = (int)dims[6]; p.ln_eps = ln_eps;
+    p.Kp = 128; p.lda = p.K; p.pre_relu = 0; p.act = 0;
+    p.in_stride = 1; p.src_H = p.src_W = p.in_H = p.in_W = 1;
+    if (B < 1 || n < 1 || hw < 1 || hw % kG3Rows != 0 || B * n * hw > 0x7fffffffL) return COBEVT_ERR_SHAPE;   // one camera per workgroup
+    if (p.N < 8 || p.N % 8 || p.N > 4096 || p.K < 8 || p.K > 128 || p.K % 8) return COBEVT_ERR_SHAPE;
+    p.M = (int)(B * n * hw);
+    p.emb_E = E_inv; p.emb_world = world; p.emb_wbev = w_bev; p.emb_bbev = b_bev; p.emb_wcam = w_cam;
+    p.emb_n = (int)n; p.emb_hw = (int)hw; p.emb_xbcast = (int)dims[7];
+    const size_t lds = (size_t)kG3Rows * (p.Kp * 2 + 16) + (size_t)kG3Rows * kG3Row + (size_t)((p.N + 127) / 128) * 128 * 4 + 128 * 16;
+    const unsigned blocks = (unsigned)((p.M + kG3Rows - 1) / kG3Rows);
+    hipLaunchKernelGGL(gemm_rows3_kernel<true>, dim3(blocks), dim3(256), lds, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

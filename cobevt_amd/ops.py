@@ -33,6 +33,8 @@ USE_ROW_CHAIN = True  # fuse out-proj + skip + pre-norm MLP (+ post-norm) after 
 BASICBLOCK_TILE_ROWS = 0   # 0 = kernel default; 8 | 16 pins the output tile height (tools/bb_probe.py)
 USE_BASICBLOCK = True  # stride-1 BasicBlocks on 64 / 128 channels as one launch (intermediate map stays in LDS)
 USE_EMBED_GEMM = False  # compute the BEV query embedding inside the to_q GEMM instead of materialising the query:
+USE_EMBED_GEMM3 = False   # the BEV query produced inside the 32-row GEMM that projects it (gemm_rows3.hip): measured 3 % slower
+                          # end to end than the embedding kernel + GEMM (the staging threads become VALU-bound), kept off
 # measured SLOWER on MI355X (119 vs 92 us on the level-0 shape, 361 vs 364 frames/s): the producer's 64 LDS
 # coefficient reads + ~400 VALU per thread cost more than the 170 MB of HBM traffic they save; kept for parity tests
 USE_CHAIN_NEXT = True  # ... and let the row-local GEMM that consumes its output next ride in the same launch
@@ -567,6 +569,25 @@ def bev_embed_linear(e_inv, world, w_bev, b_bev, w_cam, x, n, plan):
     produces its A rows on the fly) when plan is a LayerNorm-folded Linear whose row fits one K-tile; otherwise the two
     launches."""
     b, hw, d = x.shape
+    bcast = batch_broadcast(x)
+    fused3 = (USE_EMBED_GEMM3 and USE_GEMM_ROWS3 and plan.code == BF16 and plan.has_ln and plan.K == d and d <= 128 and d % 8 == 0
+              and plan.kp_rows == 128 and plan.wfrag_rows is not None and hw % 32 == 0 and plan.stride == 1
+              and plan.pre_scale is None and plan.act == 0 and plan.cout % 8 == 0 and (bcast or x.is_contiguous()))
+    if fused3:
+        _need_cuda(e_inv, world, w_bev, b_bev, w_cam, x)
+        out = torch.empty((b, n, hw, plan.cout), device=x.device, dtype=x.dtype)
+        dims = (ctypes.c_long * 8)(plan.code, b, n, hw, d, plan.cout, 1, int(bcast))
+
+        def cost3():
+            m = b * n * hw
+            return 2.0 * m * plan.cout * d, float((hw if bcast else x.numel() // d) * d * 2 + plan.cout * d * 2 + out.numel() * 2)
+
+        with _timed("gemm_rows|embed %d->%d M=%d ln r32" % (d, plan.cout, b * n * hw), cost3):
+            rc = _L.load().cobevt_bev_embed_linear_rows_small_k(_p(e_inv), _p(world), _p(w_bev), _p(b_bev), _p(w_cam), _p(x),
+                                                                _p(plan.wfrag_rows), _p(plan.bias), _p(out), dims,
+                                                                ctypes.c_float(plan.ln_eps), _stream())
+        _L.check(rc, "cobevt_bev_embed_linear_rows_small_k")
+        return out
     fused = (USE_EMBED_GEMM and USE_GEMM_ROWS and plan.has_ln and ln_fusable(plan) and plan.K == d and hw % 128 == 0
              and plan.stride == 1 and plan.pre_scale is None and plan.act == 0 and x.is_contiguous())
     if not fused:

@@ -267,6 +267,15 @@ int cobevt_weighted_cross_entropy(const void* logits, const long long* target, c
 int cobevt_linear_rows_small_k(const void* in, const void* wfrag, const float* bias, const void* residual, const float* pre_scale,
                                const float* pre_shift, void* out, const long* dims, float ln_eps, hipStream_t stream);
 
+/* cobevt_bev_embed_linear_rows on the 32-row kernel: the BEV query  x[b][pix] + L2norm_c(w_bev . world[pix] + b_bev -
+ * w_cam . E_inv[b, cam][:, 3])  (fax_modules.py:370-375,387-388) is produced while the A rows are staged, rounded as
+ * cobevt_fax_bev_embed would have stored it, normalised and multiplied by to_q (fax_modules.py:193-195,201) - the
+ * (B, n, hw, D) query never reaches HBM.  wfrag as cobevt_linear_rows_small_k.  dims (int64[8]): dtype (0), B, n, hw (multiple
+ * of 32), D (= K <= 128), N, ln, x_bcast (1: x is one (hw, D) prior shared by every b).  out (B*n*hw, N). */
+int cobevt_bev_embed_linear_rows_small_k(const float* E_inv, const float* world, const float* w_bev, const float* b_bev,
+                                         const float* w_cam, const void* x, const void* wfrag, const float* bias, void* out,
+                                         const long* dims, float ln_eps, hipStream_t stream);
+
 /* nuScenes IoU metric, nuscenes/cross_view_transformer/metrics.py:22-31,56-72: counts[t] += (tp, fp, fn) of
  * sigmoid(pred) >= thresholds[t] against label_c = any(label[l] != 0 for l in the bit mask label_mask[c]) over the pixels with
  * visibility >= min_visibility (min_visibility < 0: all pixels, visibility may be null).  pred (N, C, hw) fp32 logits, label

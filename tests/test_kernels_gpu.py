@@ -732,15 +732,33 @@ def test_bev_embed_fused_into_q_projection(cuda, dtype):
         weight, bias, eps = 0.8 + 0.4 * procedural_input("be.g", (d,), 0, 0, 1), procedural_input("be.be", (d,), 0, -0.2, 0.2), 1e-5
     plan = ops.ConvPlan(wq, procedural_input("be.bq", (96,), 0, -0.2, 0.2), dtype=dtype, device=cuda, ln=LN)
     assert ops.ln_fusable(plan)
-    y2 = ops.bev_embed_linear(E, world, w_bev, b_bev, w_cam, x, n, plan)    # default: bev_embed kernel + GEMM
-    ops.USE_EMBED_GEMM = True
+    keep = (ops.USE_EMBED_GEMM, ops.USE_EMBED_GEMM3)
+    ops.USE_EMBED_GEMM = ops.USE_EMBED_GEMM3 = False
     try:
-        y = ops.bev_embed_linear(E, world, w_bev, b_bev, w_cam, x, n, plan)
+        y2 = ops.bev_embed_linear(E, world, w_bev, b_bev, w_cam, x, n, plan)    # bev_embed kernel + GEMM
+        ops.USE_EMBED_GEMM = True
+        y = ops.bev_embed_linear(E, world, w_bev, b_bev, w_cam, x, n, plan)     # produced inside the 128-row GEMM
     finally:
-        ops.USE_EMBED_GEMM = False
+        ops.USE_EMBED_GEMM, ops.USE_EMBED_GEMM3 = keep
     assert y.shape == (b, n, H * W, 96)
     s = y2.float().abs().max().item()
     assert (y.float() - y2.float()).abs().max().item() <= (2e-2 if dtype == torch.bfloat16 else 1e-5) * s
+    if dtype == torch.bfloat16:
+        # produced inside the 32-row GEMM, also with the batch-broadcast prior of pyramid level 0
+        prior = x[0]
+        view = prior[None].expand(b, H * W, d)
+        yr = ops.bev_embed_linear(E, world, w_bev, b_bev, w_cam, view, n, plan)       # two launches
+        ops.USE_EMBED_GEMM3 = True
+        try:
+            y3 = ops.bev_embed_linear(E, world, w_bev, b_bev, w_cam, x, n, plan)
+            yb = ops.bev_embed_linear(E, world, w_bev, b_bev, w_cam, view, n, plan)
+            yc = ops.bev_embed_linear(E, world, w_bev, b_bev, w_cam, view.contiguous(), n, plan)
+        finally:
+            ops.USE_EMBED_GEMM3 = keep[1]
+        assert y3.shape == (b, n, H * W, 96)
+        assert (y3.float() - y2.float()).abs().max().item() <= 2e-2 * s
+        assert torch.equal(yb, yc)
+        assert (yb.float() - yr.float()).abs().max().item() <= 2e-2 * yr.float().abs().max().item()
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
