@@ -40,18 +40,19 @@ constexpr int kG3Row = 256 + 16;            // staged output row: 128 bf16 + pad
 constexpr int kG3Rows = 32;
 // LDS: A rows [32][Kp * 2 + 16] | output tile [32][272] | N_p floats of bias
 
-template <bool EMB>
-__global__ __launch_bounds__(256, 4) void gemm_rows3_kernel(Gr3Params p) {
+// ROWS = 32 (4 waves) or 64 (8 waves = 2 row halves x 4 column tiles: every weight fragment serves twice the rows)
+template <bool EMB, int ROWS = 32>
+__global__ __launch_bounds__(ROWS * 8, 4) void gemm_rows3_kernel(Gr3Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int arow = p.Kp * 2 + 16;
     unsigned char* As = smem;
-    unsigned char* Ys = smem + kG3Rows * arow;
-    float* sb = (float*)(Ys + kG3Rows * kG3Row);
+    unsigned char* Ys = smem + ROWS * arow;
+    float* sb = (float*)(Ys + ROWS * kG3Row);
 
-    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave & 3, wm = wave >> 2;
     const int h = lane >> 5, ql = lane & 31;
-    const int m0 = blockIdx.x * kG3Rows;
-    const int row = ql;
+    const int m0 = blockIdx.x * ROWS;
+    const int row = wm * 32 + ql;
     const bool row_ok = m0 + row < p.M;
     const int npn = (p.N + 127) / 128, nkt = p.Kp >> 7, nkg = p.Kp >> 4;
     const int nsteps = npn * nkt;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256, 4) void gemm_rows3_kernel(Gr3Params p) {
     load_frags(fa, 0);
 
     // bias of all passes into LDS (zero padded), unconditional clamped loads
-    for (int i = tid; i < npn * 128; i += 256) {
+    for (int i = tid; i < npn * 128; i += ROWS * 8) {
         const float b = p.bias ? p.bias[i < p.N ? i : 0] : 0.f;
         sb[i] = i < p.N ? b : 0.f;
     }
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256, 4) void gemm_rows3_kernel(Gr3Params p) {
             if (p.act) { v0 = apply_act(v0, p.act); v1 = apply_act(v1, p.act); v2 = apply_act(v2, p.act); v3 = apply_act(v3, p.act); }
             *(uint2*)(Ys + row * kG3Row + (cbase + 8 * k) * 2) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
         }
-        __syncthreads();                              // 32 x 128 result staged in Ys
+        __syncthreads();                              // ROWS x 128 result staged in Ys
         {
             const int r = tid >> 3, sub = tid & 7;
             if (m0 + r < p.M) {
@@ -232,7 +233,7 @@ using namespace cobevt;
 extern "C" int cobevt_linear_rows_small_k(const void* in, const void* wfrag, const float* bias, const void* residual,
                                           const float* pre_scale, const float* pre_shift, void* out, const long* dims, float ln_eps,
                                           hipStream_t stream) {
-    // dims: [dtype(0), M, N, K, lda, pre_relu, act, ln, in_stride, src_H, src_W, in_H, in_W]
+    // dims: [dtype(0), M, N, K, lda, pre_relu, act, ln, in_stride, src_H, src_W, in_H, in_W, rows_per_workgroup]
     if (!in || !wfrag || !out || !dims) return COBEVT_ERR_ARG;
     if (dims[0] != 0) return COBEVT_ERR_UNSUPPORTED;
     Gr3Params p;
@@ -250,11 +251,21 @@ extern "C" int cobevt_linear_rows_small_k(const void* in, const void* wfrag, con
     if ((pre_scale == nullptr) != (pre_shift == nullptr)) return COBEVT_ERR_ARG;
     if (p.ln && pre_scale) return COBEVT_ERR_UNSUPPORTED;
     if (p.act < 0 || p.act > 4) return COBEVT_ERR_ARG;
-    const size_t lds = (size_t)kG3Rows * (p.Kp * 2 + 16) + (size_t)kG3Rows * kG3Row + (size_t)((p.N + 127) / 128) * 128 * 4;
-    const unsigned blocks = (unsigned)((p.M + kG3Rows - 1) / kG3Rows);
+    const int rows = dims[13] == 64 ? 64 : 32;                     // dims[13]: rows per workgroup (0 = 32)
+    const size_t lds = (size_t)rows * (p.Kp * 2 + 16) + (size_t)rows * kG3Row + (size_t)((p.N + 127) / 128) * 128 * 4;
+    const unsigned blocks = (unsigned)((p.M + rows - 1) / rows);
     p.emb_E = p.emb_world = p.emb_wbev = p.emb_bbev = p.emb_wcam = nullptr;
     p.emb_n = p.emb_hw = 1; p.emb_xbcast = 0;
-    hipLaunchKernelGGL(gemm_rows3_kernel<false>, dim3(blocks), dim3(256), lds, stream, p);
+    if (rows == 64) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)gemm_rows3_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1040 + 64 * kG3Row + 4096 * 4);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm_rows3_kernel<false, 64>), dim3(blocks), dim3(512), lds, stream, p);
+    } else {
+        hipLaunchKernelGGL((gemm_rows3_kernel<false, 32>), dim3(blocks), dim3(256), lds, stream, p);
+    }
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
@@ -279,6 +290,6 @@ extern "C" int cobevt_bev_embed_linear_rows_small_k(const float* E_inv, const fl
     p.emb_n = (int)n; p.emb_hw = (int)hw; p.emb_xbcast = (int)dims[7];
     const size_t lds = (size_t)kG3Rows * (p.Kp * 2 + 16) + (size_t)kG3Rows * kG3Row + (size_t)((p.N + 127) / 128) * 128 * 4 + 128 * 16;
     const unsigned blocks = (unsigned)((p.M + kG3Rows - 1) / kG3Rows);
-    hipLaunchKernelGGL(gemm_rows3_kernel<true>, dim3(blocks), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((gemm_rows3_kernel<true, 32>), dim3(blocks), dim3(256), lds, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

@@ -24,6 +24,7 @@ USE_GEMM_ROWS3 = True     # K <= 128 bf16 dense rows on the row-chain-style kern
 GEMM_ROWS3_MIN_M = 0
 GEMM_ROWS3_MAX_K = 512     # 128: only single-tile rows take the 32-row kernel
 GEMM_ROWS3_STRIDED = 1     # stride-2 1x1 convs (ResNet down-sampling) too
+GEMM_ROWS3_ROWS64_MIN_M = 0   # > 0: launches with at least this many rows use 64-row workgroups
 # measured 3-20 % SLOWER than two independent workgroups per CU (196 VGPRs -> one workgroup per CU, only one 32-KB tile
 # of loads in flight per CU: latency-bound on HBM); kept for the parity tests and as the base for a deeper prefetch
 USE_STEM_POOL = True  # stem conv + max pool in one launch (the stem map never reaches HBM)
@@ -54,7 +55,7 @@ def _apply_env_flags():
         if "=" in item:
             k, v = item.split("=", 1)
             k = k.strip()
-            if k not in globals() or not (k.startswith("USE_") or k in ("CONV3_VARIANT", "BASICBLOCK_TILE_ROWS", "ROW_CHAIN_ROWS", "GEMM_ROWS3_MIN_M", "GEMM_ROWS3_MAX_K", "GEMM_ROWS3_STRIDED")):
+            if k not in globals() or not (k.startswith("USE_") or k in ("CONV3_VARIANT", "BASICBLOCK_TILE_ROWS", "ROW_CHAIN_ROWS", "GEMM_ROWS3_MIN_M", "GEMM_ROWS3_MAX_K", "GEMM_ROWS3_STRIDED", "GEMM_ROWS3_ROWS64_MIN_M")):
                 raise CobevtHipError("COBEVT_FLAGS: unknown switch %r" % k)
             globals()[k] = int(v) if not k.startswith("USE_") else bool(int(v))
 
@@ -383,8 +384,9 @@ def conv2d(x, plan, residual=None, out=None):
               and not (plan.stride > 1 and (residual is not None or not GEMM_ROWS3_STRIDED))
               and not (ln and plan.kp_rows > 128) and n * ho * wo >= GEMM_ROWS3_MIN_M)
         if v3:
-            d3 = (ctypes.c_long * 13)(plan.code, n * ho * wo, plan.cout, plan.K, cin, plan.pre_relu, plan.act, int(ln),
-                                      plan.stride, ho, wo, h, w)
+            d3 = (ctypes.c_long * 14)(plan.code, n * ho * wo, plan.cout, plan.K, cin, plan.pre_relu, plan.act, int(ln),
+                                      plan.stride, ho, wo, h, w,
+                                      64 if (GEMM_ROWS3_ROWS64_MIN_M and n * ho * wo >= GEMM_ROWS3_ROWS64_MIN_M) else 32)
             with _timed("gemm_rows|%d->%d M=%d%s%s r32" % (cin, plan.cout, n * ho * wo, " ln" if ln else "",
                                                         " s%d" % plan.stride if plan.stride > 1 else ""), cost):
                 rc = _L.load().cobevt_linear_rows_small_k(_p(x), _p(plan.wfrag_rows), _p(plan.bias), _p(residual), _p(plan.pre_scale),

@@ -819,3 +819,37 @@ def test_ray_and_bev_embed(cuda, dtype):
     qb = ops.bev_embed(*args, prior[None].expand(b, H * W, d), n)
     qc = ops.bev_embed(*args, prior[None].expand(b, H * W, d).contiguous(), n)
     assert torch.equal(qb, qc)
+
+
+def test_small_block_gemm_row_tiles_agree(cuda):
+    """cobevt_linear_rows_small_k with 32- and 64-row workgroups: the same MFMAs on the same operands, bit-identical results
+    (K = 128 with LayerNorm, K = 320 with the BN -> ReLU pre-activation and a ragged last row tile)"""
+    dtype = torch.bfloat16
+    for (m, k, n_, ln, pre) in ((1000, 128, 256, True, False), (333, 320, 96, False, True)):
+        x = procedural_input("g3.x", (m, k), 0, -2, 2).to(cuda).to(dtype)
+        w = procedural_input("g3.w", (n_, k), 0) * math.sqrt(3.0 / k)
+
+        class LN(object):
+            weight, bias, eps = 0.8 + 0.4 * procedural_input("g3.g", (k,), 0, 0, 1), procedural_input("g3.b", (k,), 0, -0.2, 0.2), 1e-5
+        bn = None
+        if pre:
+            bn = torch.nn.BatchNorm2d(k).eval()
+            bn.weight.data.copy_(0.8 + 0.4 * procedural_input("g3.bg", (k,), 0, 0, 1))
+            bn.running_mean.data.copy_(procedural_input("g3.bm", (k,), 0, -0.3, 0.3))
+        plan = ops.ConvPlan(w, procedural_input("g3.bias", (n_,), 0, -0.2, 0.2), dtype=dtype, device=cuda, ln=LN if ln else None,
+                            pre_bn=bn, pre_relu=pre)
+        keep = ops.GEMM_ROWS3_ROWS64_MIN_M
+        try:
+            ops.GEMM_ROWS3_ROWS64_MIN_M = 0
+            y32 = ops.linear(x, plan)
+            ops.GEMM_ROWS3_ROWS64_MIN_M = 1
+            y64 = ops.linear(x, plan)
+        finally:
+            ops.GEMM_ROWS3_ROWS64_MIN_M = keep
+        assert torch.equal(y32, y64)
+        ops.USE_GEMM_ROWS3 = False
+        try:
+            y1 = ops.linear(x, plan)                        # the 128 x 128-tile kernel
+        finally:
+            ops.USE_GEMM_ROWS3 = True
+        assert (y32.float() - y1.float()).abs().max().item() <= 2e-2 * y1.float().abs().max().item()
