@@ -288,3 +288,74 @@ extern "C" int cobevt_iou_counts(const float* pred, const float* label, const un
                        T, min_visibility, per_thread);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Sigmoid focal loss with label grouping and visibility masking, mean over the kept elements: the forward of
+// BinarySegmentationLoss / CenterLoss (nuscenes/cross_view_transformer/losses.py:27-84) around fvcore's sigmoid_focal_loss
+// (third-party, absent here; published definition: ce = BCE-with-logits(x, t), p_t = p t + (1 - p)(1 - t),
+// loss = ce (1 - p_t)^gamma, times alpha t + (1 - alpha)(1 - t) when alpha >= 0).  Two launches, fixed summation order.
+namespace cobevt {
+
+__global__ __launch_bounds__(256) void focal_partial_kernel(const float* pred, const float* label, const unsigned char* visibility,
+                                                            const unsigned int* label_mask, float* partial, int C, int NL, int hw,
+                                                            int min_visibility, float alpha, float gamma, int soft_label,
+                                                            int per_thread) {
+    __shared__ float sn[256], sd[256];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    float num = 0.f, den = 0.f;
+    const int p0 = blockIdx.x * 256 * per_thread;
+    for (int j = 0; j < per_thread; ++j) {
+        const int pix = p0 + j * 256 + tid;
+        if (pix >= hw) break;
+        if (min_visibility >= 0 && (int)visibility[(size_t)n * hw + pix] < min_visibility) continue;
+        for (int c = 0; c < C; ++c) {
+            float t;
+            if (soft_label) {                         // the label channel itself (CenterLoss: a heat map in [0, 1])
+                t = label[((size_t)n * NL + c) * hw + pix];
+            } else {                                  // max over the grouped binary channels
+                t = 0.f;
+                for (int l = 0; l < NL; ++l)
+                    if ((label_mask[c] >> l) & 1u) t = fmaxf(t, label[((size_t)n * NL + l) * hw + pix]);
+            }
+            const float x = pred[((size_t)n * C + c) * hw + pix];
+            const float p = 1.0f / (1.0f + expf(-x));
+            const float ce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));       // binary_cross_entropy_with_logits
+            const float pt = p * t + (1.f - p) * (1.f - t);
+            float l = ce * powf(1.f - pt, gamma);
+            if (alpha >= 0.f) l *= alpha * t + (1.f - alpha) * (1.f - t);
+            num += l;
+            den += 1.f;
+        }
+    }
+    sn[tid] = num; sd[tid] = den;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { sn[tid] += sn[tid + s]; sd[tid] += sd[tid + s]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        partial[2 * b] = sn[0];
+        partial[2 * b + 1] = sd[0];
+    }
+}
+
+}  // namespace cobevt
+
+// out[0] = mean loss over the kept elements, out[1] = sum, out[2] = count.  pred (N, C, hw) fp32 logits; label (N, NL, hw) fp32;
+// label_mask [C] (bit l: label channel l belongs to output channel c) unless soft_label (then NL == C and label is used as is);
+// visibility (N, hw) uint8 or null with min_visibility < 0; scratch >= 2 * N * ceil(hw / 2048) floats.
+extern "C" int cobevt_sigmoid_focal_loss(const float* pred, const float* label, const unsigned char* visibility,
+                                         const unsigned int* label_mask, float* scratch, float* out, int N, int C, int NL, int hw,
+                                         int min_visibility, float alpha, float gamma, int soft_label, hipStream_t stream) {
+    if (!pred || !label || !scratch || !out) return COBEVT_ERR_ARG;
+    if (!soft_label && !label_mask) return COBEVT_ERR_ARG;
+    if (min_visibility >= 0 && !visibility) return COBEVT_ERR_ARG;
+    if (N < 1 || N > 65535 || C < 1 || NL < 1 || NL > 32 || hw < 1 || (soft_label && NL != C)) return COBEVT_ERR_SHAPE;
+    const int per_thread = 8;
+    const int gx = (hw + 256 * per_thread - 1) / (256 * per_thread);
+    hipLaunchKernelGGL(focal_partial_kernel, dim3(gx, N), dim3(256), 0, stream, pred, label, visibility, label_mask, scratch, C, NL, hw,
+                       min_visibility, alpha, gamma, soft_label, per_thread);
+    hipLaunchKernelGGL(wce_final_kernel, dim3(1), dim3(256), 0, stream, scratch, out, gx * N);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}

@@ -6,3 +6,4 @@ from .cvt import CrossViewTransformer  # noqa: F401
 from .backbones import FeatureMapBackbone  # noqa: F401
 from .efficientnet import EfficientNetExtractor  # noqa: F401
 from .metrics import BaseIoUMetric, IoUMetric  # noqa: F401
+from .losses import BinarySegmentationLoss, CenterLoss, MultipleLoss, SigmoidFocalLoss  # noqa: F401

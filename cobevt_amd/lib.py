@@ -56,6 +56,8 @@ SIGNATURES = {
     "cobevt_weighted_cross_entropy": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "cobevt_linear_rows_small_k": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_long_p, ctypes.c_float, _vp]),
     "cobevt_bev_embed_linear_rows_small_k": (ctypes.c_int, [_vp] * 9 + [_c_long_p, ctypes.c_float, _vp]),
+    "cobevt_sigmoid_focal_loss": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, _vp]),
     "cobevt_iou_counts": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, _vp]),
     "cobevt_depthwise_conv_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp]),

@@ -964,3 +964,28 @@ def iou_counts(pred, label, visibility, label_indices, thresholds, min_visibilit
                                      thr.numel(), mv, _stream())
     _L.check(rc, "cobevt_iou_counts")
     return counts.cpu()
+
+
+def sigmoid_focal_loss_mean(pred, label, visibility, label_indices, min_visibility, alpha, gamma):
+    """mean sigmoid focal loss over the visible pixels (nuscenes losses.py:27-84, forward).  pred (N, C, hw) fp32 logits on the
+    device; label (N, NL, hw); label_indices: list (length C) of label-channel lists, or None = use label channel c as is."""
+    _need_cuda(pred)
+    n, c, hw = pred.shape
+    dev = pred.device
+    label = label.to(device=dev, dtype=torch.float32).contiguous()
+    nl = label.shape[1]
+    soft = label_indices is None
+    if (soft and nl != c) or (not soft and len(label_indices) != c) or nl > 32 or tuple(label.shape) != (n, nl, hw):
+        raise CobevtHipError("sigmoid_focal_loss_mean: inconsistent prediction / label channels")
+    masks = None
+    if not soft:
+        masks = torch.tensor([sum(1 << int(l) for l in g) for g in label_indices], dtype=torch.int64).to(torch.int32).to(dev)
+    vis, mv = None, -1
+    if min_visibility is not None:
+        vis, mv = visibility.to(device=dev, dtype=torch.uint8).contiguous(), int(min_visibility)
+    scratch = torch.empty(2 * n * ((hw + 2047) // 2048), device=dev, dtype=torch.float32)
+    out = torch.empty(3, device=dev, dtype=torch.float32)
+    rc = _L.load().cobevt_sigmoid_focal_loss(_p(pred.float().contiguous()), _p(label), _p(vis), _p(masks), _p(scratch), _p(out), n, c, nl,
+                                             hw, mv, ctypes.c_float(alpha), ctypes.c_float(gamma), int(soft), _stream())
+    _L.check(rc, "cobevt_sigmoid_focal_loss")
+    return out[0]

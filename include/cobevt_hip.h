@@ -276,6 +276,14 @@ int cobevt_bev_embed_linear_rows_small_k(const float* E_inv, const float* world,
                                          const float* w_cam, const void* x, const void* wfrag, const float* bias, void* out,
                                          const long* dims, float ln_eps, hipStream_t stream);
 
+/* Forward of BinarySegmentationLoss / CenterLoss, nuscenes/cross_view_transformer/losses.py:27-84: sigmoid focal loss (fvcore's
+ * published definition) of pred (N, C, hw) fp32 logits against label_c = max over the label channels in label_mask[c]
+ * (soft_label: label channel c itself, NL == C), over the pixels with visibility >= min_visibility (< 0: all), mean.
+ * out[0] = mean, out[1] = sum, out[2] = count; scratch >= 2 * N * ceil(hw / 2048) floats; fixed summation order. */
+int cobevt_sigmoid_focal_loss(const float* pred, const float* label, const unsigned char* visibility, const unsigned int* label_mask,
+                              float* scratch, float* out, int N, int C, int NL, int hw, int min_visibility, float alpha,
+                              float gamma, int soft_label, hipStream_t stream);
+
 /* nuScenes IoU metric, nuscenes/cross_view_transformer/metrics.py:22-31,56-72: counts[t] += (tp, fp, fn) of
  * sigmoid(pred) >= thresholds[t] against label_c = any(label[l] != 0 for l in the bit mask label_mask[c]) over the pixels with
  * visibility >= min_visibility (min_visibility < 0: all pixels, visibility may be null).  pred (N, C, hw) fp32 logits, label

@@ -19,6 +19,8 @@ Follows, function by function:
   find_last_checkpoint / load_saved_model   opv2v/opencood/tools/train_utils.py:24-65
   vanilla_seg_loss     opv2v/opencood/loss/vanilla_seg_loss.py:7-76 (forward; nn.CrossEntropyLoss(weight) = weighted mean)
   iou_metric           nuscenes/cross_view_transformer/metrics.py:7-72 (BaseIoUMetric / IoUMetric update + compute)
+  sigmoid_focal_loss   fvcore.nn.sigmoid_focal_loss (third-party, absent: restated from its published definition, parity unpinned)
+  binary_segmentation_loss / center_loss   nuscenes/cross_view_transformer/losses.py:27-84 (forward)
 """
 import glob
 import os
@@ -170,3 +172,34 @@ def iou_metric(updates, label_indices, min_visibility, thresholds=(0.4, 0.5)):
         fn += (~p & l).sum(0)
     ious = tp / (tp + fp + fn + 1e-7)
     return tp, fp, fn, {"@%.2f" % t.item(): i.item() for t, i in zip(thr, ious)}
+
+
+def sigmoid_focal_loss(inputs, targets, alpha=-1.0, gamma=2.0):
+    """element-wise (reduction 'none')"""
+    import torch.nn.functional as F
+    p = torch.sigmoid(inputs)
+    ce = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    p_t = p * targets + (1 - p) * (1 - targets)
+    loss = ce * ((1 - p_t) ** gamma)
+    if alpha >= 0:
+        loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+    return loss
+
+
+def binary_segmentation_loss(pred, batch, label_indices=None, min_visibility=None, alpha=-1.0, gamma=2.0):
+    if isinstance(pred, dict):
+        pred = pred["bev"]
+    label = batch["bev"]
+    if label_indices is not None:
+        label = torch.cat([label[:, idx].max(1, keepdim=True).values for idx in label_indices], 1)
+    loss = sigmoid_focal_loss(pred, label, alpha, gamma)
+    if min_visibility is not None:
+        loss = loss[(batch["visibility"] >= min_visibility)[:, None]]
+    return loss.mean()
+
+
+def center_loss(pred, batch, min_visibility=None, alpha=-1.0, gamma=2.0):
+    loss = sigmoid_focal_loss(pred["center"], batch["center"], alpha, gamma)
+    if min_visibility is not None:
+        loss = loss[(batch["visibility"] >= min_visibility)[:, None]]
+    return loss.mean()

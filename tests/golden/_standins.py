@@ -143,3 +143,30 @@ def install_torchmetrics():
             setattr(self, name, default.clone())
     tm.Metric = Metric
     sys.modules["torchmetrics"] = tm
+
+
+def install_fvcore():
+    """`fvcore.nn.sigmoid_focal_loss` (the only fvcore symbol nuscenes/cross_view_transformer/losses.py uses), written from its
+    published definition: third-party arithmetic, parity unpinned.  The label grouping, visibility masking and reductions
+    around it are the reference's own code."""
+    if "fvcore" in sys.modules:
+        return
+    import torch.nn.functional as F
+
+    def sigmoid_focal_loss(inputs, targets, alpha=-1, gamma=2, reduction="none"):
+        p = torch.sigmoid(inputs)
+        ce_loss = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+        p_t = p * targets + (1 - p) * (1 - targets)
+        loss = ce_loss * ((1 - p_t) ** gamma)
+        if alpha >= 0:
+            loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+        if reduction == "mean":
+            loss = loss.mean()
+        elif reduction == "sum":
+            loss = loss.sum()
+        return loss
+    fv, fvnn = types.ModuleType("fvcore"), types.ModuleType("fvcore.nn")
+    fvnn.sigmoid_focal_loss = sigmoid_focal_loss
+    fv.nn = fvnn
+    sys.modules["fvcore"] = fv
+    sys.modules["fvcore.nn"] = fvnn

@@ -277,3 +277,22 @@ def iou_metric_inputs(channels):
         vis = rs.choice(np.array([1, 2, 3, 4, 255], dtype=np.uint8), size=(b, 40, 56))
         out.append((pred, bev, vis))
     return out
+
+
+# nuScenes losses: config/loss/* use BinarySegmentationLoss(label_indices, min_visibility=2, alpha=-1, gamma=2) and
+# CenterLoss(min_visibility=2, alpha=-1, gamma=2); a weighted (alpha >= 0) variant exercises the other branch
+FOCAL_LOSS = [dict(kind="bev", label_indices=[[4, 5, 6, 7, 8, 9, 10, 11]], min_visibility=2, alpha=-1.0, gamma=2.0),
+              dict(kind="bev", label_indices=[[0, 1]], min_visibility=None, alpha=0.25, gamma=1.5),
+              dict(kind="center", min_visibility=2, alpha=-1.0, gamma=2.0),
+              dict(kind="center", min_visibility=None, alpha=0.75, gamma=2.0)]
+
+
+def focal_loss_inputs():
+    import numpy as np
+    rs = np.random.RandomState(99)
+    b, h, w = 2, 40, 56
+    return {"bev_pred": (rs.standard_normal((b, 1, h, w)) * 2.5).astype(np.float32),
+            "center_pred": (rs.standard_normal((b, 1, h, w)) * 2.5).astype(np.float32),
+            "bev": (rs.rand(b, 12, h, w) > 0.9).astype(np.float32),
+            "center": np.clip(rs.rand(b, 1, h, w) * 1.2 - 0.1, 0, 1).astype(np.float32),
+            "visibility": rs.choice(np.array([1, 2, 3, 4, 255], dtype=np.uint8), size=(b, h, w))}

@@ -425,6 +425,34 @@ def gv15():
     save("gv15_nuscenes_iou_metric", **out)
 
 
+def gv16():
+    """nuScenes BinarySegmentationLoss / CenterLoss forward (cross_view_transformer/losses.py) with fvcore's sigmoid_focal_loss
+    supplied by a restated stand-in."""
+    import importlib.util
+    import oracle.pre_post as o_pp
+    _standins.install_fvcore()
+    spec = importlib.util.spec_from_file_location("ref_nuscenes_losses", "/root/reference/nuscenes/cross_view_transformer/losses.py")
+    R = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(R)
+    inp = {k: torch.from_numpy(v) for k, v in cases.focal_loss_inputs().items()}
+    batch = {"bev": inp["bev"], "center": inp["center"], "visibility": inp["visibility"]}
+    out = {}
+    for i, c in enumerate(cases.FOCAL_LOSS):
+        if c["kind"] == "bev":
+            ref = R.BinarySegmentationLoss(c["label_indices"], c["min_visibility"], c["alpha"], c["gamma"])({"bev": inp["bev_pred"]}, batch)
+            mine = o_pp.binary_segmentation_loss({"bev": inp["bev_pred"]}, batch, c["label_indices"], c["min_visibility"], c["alpha"], c["gamma"])
+        else:
+            ref = R.CenterLoss(c["min_visibility"], c["alpha"], c["gamma"])({"center": inp["center_pred"]}, batch)
+            mine = o_pp.center_loss({"center": inp["center_pred"]}, batch, c["min_visibility"], c["alpha"], c["gamma"])
+        assert abs(float(ref) - float(mine)) <= 1e-7 * max(1.0, abs(float(ref))), (c, float(ref), float(mine))
+        out["loss%d" % i] = np.array(float(ref), dtype=np.float64)
+        print("  %s -> %.7f" % (c, float(ref)))
+    total, parts = R.MultipleLoss({"bev": R.BinarySegmentationLoss([[4, 5]], 2), "bev_weight": 1.0,
+                                   "center": R.CenterLoss(2), "center_weight": 0.1})({"bev": inp["bev_pred"], "center": inp["center_pred"]}, batch)
+    out["multi_total"] = np.array(float(total), dtype=np.float64)
+    save("gv16_nuscenes_losses", **out)
+
+
 def gv13():
     """NaiveCompressor (sub_modules/naive_compress.py) alone and inside the reduced CorpBEVT with compression = 2."""
     import copy
@@ -446,7 +474,7 @@ def gv13():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gv0", "gv1", "gv2", "gv3", "gv4", "gv5", "gv6", "gv7", "gv8", "gv9", "gv10", "gv11", "gv12", "gv13", "gv14", "gv15"]
+    which = sys.argv[1:] or ["gv0", "gv1", "gv2", "gv3", "gv4", "gv5", "gv6", "gv7", "gv8", "gv9", "gv10", "gv11", "gv12", "gv13", "gv14", "gv15", "gv16"]
     for name in which:
         print("== " + name)
         globals()[name]()

@@ -132,6 +132,22 @@ def test_nuscenes_iou_metric_oracle_matches_reference():
         assert np.allclose([res[k] for k in sorted(res)], g["iou%d" % i], rtol=0, atol=1e-7)
 
 
+def _focal_batch():
+    inp = {k: torch.from_numpy(v) for k, v in cases.focal_loss_inputs().items()}
+    return inp, {"bev": inp["bev"], "center": inp["center"], "visibility": inp["visibility"]}
+
+
+def test_nuscenes_losses_oracle_matches_reference():
+    g = golden("gv16_nuscenes_losses")
+    inp, batch = _focal_batch()
+    for i, c in enumerate(cases.FOCAL_LOSS):
+        if c["kind"] == "bev":
+            mine = o_pp.binary_segmentation_loss({"bev": inp["bev_pred"]}, batch, c["label_indices"], c["min_visibility"], c["alpha"], c["gamma"])
+        else:
+            mine = o_pp.center_loss({"center": inp["center_pred"]}, batch, c["min_visibility"], c["alpha"], c["gamma"])
+        assert abs(float(mine) - float(g["loss%d" % i])) <= 1e-6 * max(1.0, float(g["loss%d" % i]))
+
+
 def test_logit_side_has_no_cpu_fallback():
     post = h_post.CameraBevPostprocessor({}, train=False)
     with pytest.raises(CobevtHipError):
@@ -275,3 +291,29 @@ def test_nuscenes_iou_metric_on_device(cuda):
     p = pred.sigmoid().reshape(-1)[:, None] >= base.thresholds[None]
     l = label.bool().reshape(-1)[:, None]
     assert np.abs(base.tp.numpy() - (p & l).sum(0).numpy()).max() <= 3 and np.abs(base.fn.numpy() - (~p & l).sum(0).numpy()).max() <= 3
+
+
+@pytest.mark.gpu
+def test_nuscenes_losses_forward_on_device(cuda):
+    """BinarySegmentationLoss / CenterLoss / MultipleLoss forward with the predictions on the GPU vs the reference's values
+    (gv16; fvcore's focal loss restated).  1e-5 rel: fp32 sums of ~4000 terms in a different order, different libm."""
+    from cobevt_amd.host.nuscenes.losses import BinarySegmentationLoss, CenterLoss, MultipleLoss, SigmoidFocalLoss
+    g = golden("gv16_nuscenes_losses")
+    inp, batch = _focal_batch()
+    dbatch = {k: v.to(cuda) for k, v in batch.items()}
+    pred = {"bev": inp["bev_pred"].to(cuda), "center": inp["center_pred"].to(cuda)}
+    for i, c in enumerate(cases.FOCAL_LOSS):
+        if c["kind"] == "bev":
+            val = BinarySegmentationLoss(c["label_indices"], c["min_visibility"], c["alpha"], c["gamma"])(pred, dbatch)
+        else:
+            val = CenterLoss(c["min_visibility"], c["alpha"], c["gamma"])(pred, dbatch)
+        ref = float(g["loss%d" % i])
+        assert val.is_cuda and abs(float(val) - ref) <= 1e-5 * max(1.0, ref), (c, float(val), ref)
+    total, parts = MultipleLoss({"bev": BinarySegmentationLoss([[4, 5]], 2), "bev_weight": 1.0,
+                                 "center": CenterLoss(2), "center_weight": 0.1})(pred, dbatch)
+    assert sorted(parts) == ["bev", "center"] and abs(float(total) - float(g["multi_total"])) <= 1e-5 * max(1.0, float(g["multi_total"]))
+    # plain SigmoidFocalLoss(pred, label) == the oracle's element-wise definition, mean
+    x, t = inp["center_pred"], inp["center"]
+    val = SigmoidFocalLoss(alpha=0.25, gamma=2.0)(x.to(cuda), t.to(cuda))
+    ref = float(o_pp.sigmoid_focal_loss(x, t, 0.25, 2.0).mean())
+    assert abs(float(val) - ref) <= 1e-5 * max(1.0, ref)
