@@ -90,3 +90,25 @@ def test_procedural_weights_are_reproducible():
     # pinned values: a silent change of the generator would invalidate every fixture
     assert np.allclose(a.flatten()[:3].numpy(), synth.procedural_tensor("fax.cross_views.0.mlp_1.0.weight", (256, 128)).flatten()[:3].numpy())
     assert synth.procedural_tensor("x.num_batches_tracked", ()) is None
+
+
+def test_kernel_plans_follow_the_parameters():
+    """a module's cached kernel plans (folded / re-laid-out weights) are rebuilt when its parameters change - in-place
+    updates and load_state_dict of a reference checkpoint (train_utils.py:54-63) - and are per compute dtype"""
+    from cobevt_amd.host import runtime as rt
+    m = host.NaiveCompressor(16, 2).eval()
+    conv, bn = m.encoder[0], m.encoder[1]
+    with host.compute_dtype(torch.float32):
+        p1 = rt.conv_plan(m, "enc", conv, bn, act=1)
+        assert rt.conv_plan(m, "enc", conv, bn, act=1) is p1                    # cached
+        with torch.no_grad():
+            conv.weight.mul_(2.0)                                               # in-place update bumps the version
+        p2 = rt.conv_plan(m, "enc", conv, bn, act=1)
+        assert p2 is not p1 and torch.allclose(p2.wgt, 2 * p1.wgt)
+        sd = {k: (v * 0 + 1 if v.dtype.is_floating_point else v) for k, v in m.state_dict().items()}
+        m.load_state_dict(sd)
+        p3 = rt.conv_plan(m, "enc", conv, bn, act=1)
+        assert p3 is not p2 and float(p3.wgt.abs().max()) > 0 and not torch.allclose(p3.wgt, p2.wgt)
+    with host.compute_dtype(torch.bfloat16):
+        p4 = rt.conv_plan(m, "enc", conv, bn, act=1)
+        assert p4 is not p3 and p4.wgt.dtype == torch.bfloat16
