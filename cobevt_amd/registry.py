@@ -1,7 +1,27 @@
-"""create_model — the reference's model registry contract (opv2v/opencood/tools/train_utils.py:102-135):
-hypes['model']['core_method'] names a module, the class whose lower-cased name equals the name without
-underscores is instantiated with hypes['model']['args']."""
+"""create_model / create_loss — the reference's registry contracts (opv2v/opencood/tools/train_utils.py:102-135 and
+:138-170): hypes['model' | 'loss']['core_method'] names a module, the class whose lower-cased name equals the name without
+underscores is instantiated with hypes[...]['args']."""
 import importlib
+
+
+def _lookup(package, module_name, what):
+    try:
+        lib = importlib.import_module(package + "." + module_name)
+    except ImportError:
+        lib = None
+    target = module_name.replace("_", "").lower()
+    if lib is not None:
+        for name, cls in lib.__dict__.items():
+            if name.lower() == target and isinstance(cls, type):
+                return cls
+    # the reference prints and exit(0)s; a missing class is an error here
+    raise ValueError("%s not found in %s: a module named %s with a class named %s (ignoring case) is required"
+                     % (what, package, module_name, target))
+
+
+def create_loss(hypes):
+    """hypes['loss'] = {core_method: 'vanilla_seg_loss', args: {...}} -> the forward-only loss mirror (validation loss)"""
+    return _lookup("cobevt_amd.host", hypes["loss"]["core_method"], "loss function")(hypes["loss"]["args"])
 
 
 def create_model(hypes):

@@ -44,6 +44,15 @@ def test_registry_contract():
         create_model({"model": {"core_method": "no_such_model", "args": {}}})
 
 
+def test_loss_registry_contract():
+    from cobevt_amd.registry import create_loss
+    crit = create_loss({"loss": {"core_method": "vanilla_seg_loss",
+                                 "args": {"d_weights": 75.0, "s_weights": 15.0, "d_coe": 2.0, "s_coe": 0.0, "target": "dynamic"}}})
+    assert type(crit).__name__ == "VanillaSegLoss" and crit.l_weights == 50 and crit.target == "dynamic"
+    with pytest.raises(ValueError):
+        create_loss({"loss": {"core_method": "no_such_loss", "args": {}}})
+
+
 def test_c_abi_exports_every_declared_symbol():
     """the shared library loads and exports exactly what include/cobevt_hip.h declares (no compute here)."""
     header = open(os.path.join(ROOT, "include", "cobevt_hip.h")).read()
