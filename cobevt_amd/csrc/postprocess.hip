@@ -136,10 +136,10 @@ namespace cobevt {
 template <typename T, int C>
 __global__ __launch_bounds__(256) void wce_partial_kernel(const T* logits, const long long* target, const float* weight,
                                                           float* partial, int hw, int per_thread) {
-    __shared__ float sn[256], sd[256];
+    __shared__ float sn[256], sd[256], sb[256];
     const int n = blockIdx.y, tid = threadIdx.x;
     const size_t base = (size_t)n * C * hw;
-    float num = 0.f, den = 0.f;
+    float num = 0.f, den = 0.f, bad = 0.f;
     const int p0 = blockIdx.x * 256 * per_thread;
     for (int j = 0; j < per_thread; ++j) {
         const int pix = p0 + j * 256 + tid;
@@ -158,34 +158,38 @@ __global__ __launch_bounds__(256) void wce_partial_kernel(const T* logits, const
 #pragma unroll
         for (int c = 0; c < C; ++c)
             if (y == c) { xy = x[c]; wy = weight[c]; }
-        num += wy * (m + logf(s) - xy);               // labels outside [0, C) contribute nothing (the host refuses them)
+        num += wy * (m + logf(s) - xy);
         den += wy;
+        // -100 = nn.CrossEntropyLoss's ignore_index: out of numerator and denominator.  Any other label outside [0, C) is an
+        // error in the reference (it raises); counted here and refused by the host (ops.weighted_cross_entropy)
+        if ((y < 0 || y >= C) && y != -100) bad += 1.f;
     }
-    sn[tid] = num; sd[tid] = den;
+    sn[tid] = num; sd[tid] = den; sb[tid] = bad;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) { sn[tid] += sn[tid + s]; sd[tid] += sd[tid + s]; }
+        if (tid < s) { sn[tid] += sn[tid + s]; sd[tid] += sd[tid + s]; sb[tid] += sb[tid + s]; }
         __syncthreads();
     }
     if (tid == 0) {
         const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-        partial[2 * b] = sn[0];
-        partial[2 * b + 1] = sd[0];
+        partial[3 * b] = sn[0];
+        partial[3 * b + 1] = sd[0];
+        partial[3 * b + 2] = sb[0];
     }
 }
 
 __global__ __launch_bounds__(256) void wce_final_kernel(const float* partial, float* out, int nparts) {
-    __shared__ float sn[256], sd[256];
+    __shared__ float sn[256], sd[256], sb[256];
     const int tid = threadIdx.x;
-    float num = 0.f, den = 0.f;
-    for (int i = tid; i < nparts; i += 256) { num += partial[2 * i]; den += partial[2 * i + 1]; }
-    sn[tid] = num; sd[tid] = den;
+    float num = 0.f, den = 0.f, bad = 0.f;
+    for (int i = tid; i < nparts; i += 256) { num += partial[3 * i]; den += partial[3 * i + 1]; bad += partial[3 * i + 2]; }
+    sn[tid] = num; sd[tid] = den; sb[tid] = bad;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) { sn[tid] += sn[tid + s]; sd[tid] += sd[tid + s]; }
+        if (tid < s) { sn[tid] += sn[tid + s]; sd[tid] += sd[tid + s]; sb[tid] += sb[tid + s]; }
         __syncthreads();
     }
-    if (tid == 0) { out[0] = sn[0] / sd[0]; out[1] = sn[0]; out[2] = sd[0]; }
+    if (tid == 0) { out[0] = sn[0] / sd[0]; out[1] = sn[0]; out[2] = sd[0]; out[3] = sb[0]; }
 }
 
 template <typename T>
@@ -203,7 +207,8 @@ static int launch_wce(const void* logits, const long long* target, const float* 
 
 }  // namespace cobevt
 
-// out[0] = loss, out[1] = weighted numerator, out[2] = sum of weights; scratch >= 2 * ceil(hw / 4096) * N floats
+// out[0] = loss, out[1] = weighted numerator, out[2] = sum of weights, out[3] = number of labels outside [0, C) other than the
+// ignore index -100 (the caller must refuse the result when it is non-zero); scratch >= 3 * ceil(hw / 4096) * N floats
 extern "C" int cobevt_weighted_cross_entropy(const void* logits, const long long* target, const float* weight, float* scratch,
                                              float* out, int dtype, int N, int C, int hw, hipStream_t stream) {
     if (!logits || !target || !weight || !scratch || !out) return COBEVT_ERR_ARG;

@@ -117,6 +117,10 @@ class CorpBEVT(HipModule):
                 kv[level] = fax.cross_views[level].prepare_kv(x, I_inv, E_inv, b * l,
                                                               out=kv_out[level] if kv_out is not None else None)
             x.record_stream(s)
+            # I_inv / E_inv are allocated on the main stream and read by ray_embed on the side stream: without this the
+            # caching allocator may hand I_inv's block to a later main-stream allocation while the side stream still reads it
+            I_inv.record_stream(s)
+            E_inv.record_stream(s)
             for t in kv[level].values():
                 if torch.is_tensor(t):
                     t.record_stream(main)

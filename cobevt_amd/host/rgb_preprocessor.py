@@ -23,7 +23,7 @@ class RgbPreProcessor(object):
 
     def channel_swap(self, rgb_image):
         """BGR -> RGB when the config asks for it (cv2.COLOR_BGR2RGB is a pure channel reversal)"""
-        return rgb_image[..., ::-1] if self.params["args"]["bgr2rgb"] else rgb_image
+        return np.ascontiguousarray(rgb_image[..., ::-1]) if self.params["args"]["bgr2rgb"] else rgb_image
 
     def resize_image(self, rgb_image):
         """cv2.resize to (resize_x, resize_y) (:46-55).  OpenCV is third-party and not in this image: frames already at

@@ -52,6 +52,19 @@ class HipModule(nn.Module):
             self._plan_cache[key] = ent
         return ent[1]
 
+    def invalidate_plans(self):
+        """Drop every cached plan of this module and its children.  The cache key sees in-place updates of a parameter
+        (`p.mul_()`, optimizer steps, load_state_dict) through its version counter, but NOT writes that go through `.data`
+        (`p.data.copy_()`, EMA / weight-surgery code, some checkpoint loaders): call this after such writes."""
+        for m in self.modules():
+            if isinstance(m, HipModule):
+                m._plan_cache.clear()
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_plans()
+        return out
+
     def _require_inference(self, *tensors):
         if self.training:
             raise CobevtHipError("%s implements the inference hot path only: call .eval() first (training is out "

@@ -935,10 +935,13 @@ def weighted_cross_entropy(logits, target, weight):
     wt = weight.to(device=x.device, dtype=torch.float32).contiguous()
     if wt.numel() != c:
         raise CobevtHipError("weighted_cross_entropy: %d class weights for %d classes" % (wt.numel(), c))
-    scratch = torch.empty(2 * n * ((h * w + 4095) // 4096), device=x.device, dtype=torch.float32)
-    out = torch.empty(3, device=x.device, dtype=torch.float32)
+    scratch = torch.empty(3 * n * ((h * w + 4095) // 4096), device=x.device, dtype=torch.float32)
+    out = torch.empty(4, device=x.device, dtype=torch.float32)
     rc = _L.load().cobevt_weighted_cross_entropy(_p(x), _p(y), _p(wt), _p(scratch), _p(out), dcode(x.dtype), n, c, h * w, _stream())
     _L.check(rc, "cobevt_weighted_cross_entropy")
+    bad = int(out[3].item())          # nn.CrossEntropyLoss raises for targets outside [0, C) other than ignore_index = -100
+    if bad:
+        raise CobevtHipError("weighted_cross_entropy: %d target labels outside [0, %d) (only -100 is ignored)" % (bad, c))
     return out[0]
 
 

@@ -252,8 +252,10 @@ int cobevt_seg_class_counts(const long long* pred, const long long* gt, unsigned
 
 /* Class-weighted cross entropy nn.CrossEntropyLoss(weight=w) computes in VanillaSegLoss (validation loss of
  * train_camera.py:182-196; opv2v/opencood/loss/vanilla_seg_loss.py:18-23,58-70): out[0] = sum_i w[y_i] (logsumexp(x_i) - x_i[y_i])
- * / sum_i w[y_i], out[1] / out[2] = numerator / denominator.  logits (N, C, hw) planar (dtype 0 bf16 / 1 fp32, 2 <= C <= 8),
- * target (N, hw) int64, weight [C] fp32, scratch >= 2 * N * ceil(hw / 4096) floats, fixed summation order. */
+ * / sum_i w[y_i], out[1] / out[2] = numerator / denominator, out[3] = number of labels outside [0, C) other than -100 (the
+ * ignore_index of nn.CrossEntropyLoss, which contributes to neither sum); the reference raises for such labels, so the caller
+ * must refuse a result with out[3] != 0.  logits (N, C, hw) planar (dtype 0 bf16 / 1 fp32, 2 <= C <= 8), target (N, hw) int64,
+ * weight [C] fp32, out >= 4 floats, scratch >= 3 * N * ceil(hw / 4096) floats, fixed summation order. */
 int cobevt_weighted_cross_entropy(const void* logits, const long long* target, const float* weight, float* scratch, float* out,
                                   int dtype, int N, int C, int hw, hipStream_t stream);
 

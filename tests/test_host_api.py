@@ -10,6 +10,7 @@ import torch
 
 from cobevt_amd import host, lib, synth
 from cobevt_amd.lib import CobevtHipError
+from cobevt_amd import registry
 from cobevt_amd.registry import create_model
 from util import golden
 
@@ -121,3 +122,45 @@ def test_kernel_plans_follow_the_parameters():
     with host.compute_dtype(torch.bfloat16):
         p4 = rt.conv_plan(m, "enc", conv, bn, act=1)
         assert p4 is not p3 and p4.wgt.dtype == torch.bfloat16
+
+
+def test_registry_reports_real_import_errors(tmp_path, monkeypatch):
+    """A module that exists but fails to import must surface its own error, not 'backbone not found'."""
+    import cobevt_amd.host as hostpkg
+    broken = os.path.join(os.path.dirname(hostpkg.__file__), "zz_broken_for_test.py")
+    with open(broken, "w") as f:
+        f.write("import a_dependency_that_does_not_exist_xyz\n")
+    try:
+        with pytest.raises(ModuleNotFoundError, match="a_dependency_that_does_not_exist_xyz"):
+            registry.create_model({"model": {"core_method": "zz_broken_for_test", "args": {}}})
+    finally:
+        os.remove(broken)
+    with pytest.raises(ValueError, match="not found"):
+        registry.create_model({"model": {"core_method": "no_such_model", "args": {}}})
+
+
+def test_invalidate_plans_sees_dot_data_writes():
+    """Plan caches are keyed on the parameter version; `.data` writes bypass it -> invalidate_plans() is the documented hook,
+    and load_state_dict() calls it."""
+    from cobevt_amd.host.runtime import HipModule
+
+    class M(HipModule):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(4, 4)
+            self.child = None
+
+    m, c = M(), M()
+    m.child = c
+    built = []
+    for mod in (m, c):
+        mod._plan("p", [mod.lin.weight], lambda dt, dev: built.append(1) or object())
+    m.lin.weight.data.mul_(2.0)                                   # invisible to the version counter
+    m._plan("p", [m.lin.weight], lambda dt, dev: built.append(1) or object())
+    assert len(built) == 2
+    m.invalidate_plans()
+    assert not m._plan_cache and not c._plan_cache
+    m._plan("p", [m.lin.weight], lambda dt, dev: built.append(1) or object())
+    assert len(built) == 3
+    m.load_state_dict(m.state_dict())
+    assert not m._plan_cache

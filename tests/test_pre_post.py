@@ -263,6 +263,17 @@ def test_vanilla_seg_loss_forward(cuda, dtype):
     assert torch.equal(a, ops.weighted_cross_entropy(x.to(cuda), y.to(cuda), wt))
     ref = torch.nn.functional.cross_entropy(x, y, weight=wt)
     assert abs(float(a) - float(ref)) <= 1e-5 * float(ref)
+    # ignore_index -100 drops the pixel from numerator and denominator like nn.CrossEntropyLoss; any other label outside
+    # [0, C) raises as the reference does (it used to be dropped silently)
+    y2 = y.clone()
+    y2[0, :7, :9] = -100
+    a2 = ops.weighted_cross_entropy(x.to(cuda), y2.to(cuda), wt)
+    ref2 = torch.nn.functional.cross_entropy(x, y2, weight=wt)
+    assert abs(float(a2) - float(ref2)) <= 1e-5 * float(ref2)
+    y3 = y.clone()
+    y3[1, 200, 100] = 255
+    with pytest.raises(Exception, match="outside"):
+        ops.weighted_cross_entropy(x.to(cuda), y3.to(cuda), wt)
 
 
 @pytest.mark.gpu
