@@ -60,6 +60,17 @@ __device__ __forceinline__ size_t tok_row(const TokMap& m, int b, int l, const T
     return ((size_t)(b * m.ncam + c.cam) * m.HH + ph) * m.WW + pw;
 }
 
+// Relative-position bias index split into a query term and a key term (the table index is linear in the coordinates):
+//   index = ((dl + L-1)(2 w1 - 1) + (di + w1-1))(2 w2 - 1) + (dj + w2-1),  d = query - key coordinate
+// swap_fusion_modules.py:55-85 (3-D, agent extent L) and fax_modules.py:121-130 (2-D: L = 1, cam = 0).  Integer arithmetic that
+// must be bit-exact: cobevt_attention_bias_index dumps query_term - key_term through these same two functions.
+__device__ __forceinline__ int rel_bias_query_term(const TokMap& km, int bias_L, const TokCoord& qc) {
+    return ((qc.cam + bias_L - 1) * (2 * km.w1 - 1) + qc.i + km.w1 - 1) * (2 * km.w2 - 1) + qc.j + km.w2 - 1;
+}
+__device__ __forceinline__ int rel_bias_key_term(const TokMap& km, const TokCoord& kc) {
+    return (kc.cam * (2 * km.w1 - 1) + kc.i) * (2 * km.w2 - 1) + kc.j;
+}
+
 struct AttnParams {
     const void* q; const void* k; const void* v; void* out;
     int ldq, ldk, ldv, ldo;
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
                     }
                     // the key's share of the relative-position index (the table index is linear in the coordinates:
                     // index = query term - key term), -1 = masked out
-                    if (valid) info = BIAS ? (kc.cam * (2 * p.kmap.w1 - 1) + kc.i) * (2 * p.kmap.w2 - 1) + kc.j : 0;
+                    if (valid) info = BIAS ? rel_bias_key_term(p.kmap, kc) : 0;
                 }
                 ireg[it] = info;
             }
@@ -264,8 +275,7 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
     const float sl2 = p.scale * 1.4426950408889634f;  // softmax in base 2
     // this lane's query term of the relative-position index (swap_fusion_modules.py:55-85, fax_modules.py:121-130):
     // ((dl + L-1)(2 w1 - 1) + (di + w1-1))(2 w2 - 1) + (dj + w2-1) with d = query - key coordinate
-    const int bias_q = BIAS ? ((qc.cam + p.bias_L - 1) * (2 * p.kmap.w1 - 1) + qc.i + p.kmap.w1 - 1) * (2 * p.kmap.w2 - 1) +
-                                  qc.j + p.kmap.w2 - 1 : 0;
+    const int bias_q = BIAS ? rel_bias_query_term(p.kmap, p.bias_L, qc) : 0;
 
     load_tile(0);
     store_tile(0);
@@ -412,6 +422,25 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
     }
 }
 
+// Debug / test entry points: the token -> row map and the relative-position index exactly as the attention kernels compute them
+__global__ void attn_index_dump_kernel(TokMap m, int B, int L, int ntok, int* rows) {
+    const long total = (long)B * L * ntok;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % ntok);
+        const int l = (int)((i / ntok) % L);
+        const int b = (int)(i / ((long)ntok * L));
+        rows[i] = (int)tok_row(m, b, l, tok_coord(m, t));
+    }
+}
+
+__global__ void attn_bias_index_dump_kernel(TokMap qm, TokMap km, int bias_L, int nq, int nk, int* idx) {
+    const long total = (long)nq * nk;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int tq = (int)(i / nk), tk = (int)(i % nk);
+        idx[i] = rel_bias_query_term(km, bias_L, tok_coord(qm, tq)) - rel_bias_key_term(km, tok_coord(km, tk));
+    }
+}
+
 static bool map_ok(const TokMap& m) {
     if (m.mode < 0 || m.mode > 2 || m.ncam < 1 || m.w1 < 1 || m.w2 < 1 || m.X < 1 || m.Y < 1) return false;
     if (m.mode != 2 && (m.HH != m.X * m.w1 || m.WW != m.Y * m.w2)) return false;
@@ -478,5 +507,28 @@ extern "C" int cobevt_window_attention(const void* q, const void* k, const void*
     if (dtype == 0) COBEVT_ATTN_LAUNCH(bf16_t);
     else COBEVT_ATTN_LAUNCH(float);
 #undef COBEVT_ATTN_LAUNCH
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// Test hooks (tests/test_kernels_gpu.py: bit-exact against tests/golden/gv1_index_maps.npz), see include/cobevt_hip.h
+extern "C" int cobevt_attention_index_map(const int* map8, int B, int* rows, hipStream_t stream) {
+    if (!map8 || !rows || B < 1) return COBEVT_ERR_ARG;
+    const TokMap m = read_map(map8);
+    if (!map_ok(m)) return COBEVT_ERR_SHAPE;
+    const int L = m.X * m.Y, ntok = m.ncam * m.w1 * m.w2;
+    const long total = (long)B * L * ntok;
+    hipLaunchKernelGGL(attn_index_dump_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0,
+                       stream, m, B, L, ntok, rows);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+extern "C" int cobevt_attention_bias_index(const int* qmap8, const int* kmap8, int bias_L, int* idx, hipStream_t stream) {
+    if (!qmap8 || !kmap8 || !idx || bias_L < 1) return COBEVT_ERR_ARG;
+    const TokMap qm = read_map(qmap8), km = read_map(kmap8);
+    if (!map_ok(qm) || !map_ok(km)) return COBEVT_ERR_SHAPE;
+    const int nq = qm.ncam * qm.w1 * qm.w2, nk = km.ncam * km.w1 * km.w2;
+    const long total = (long)nq * nk;
+    hipLaunchKernelGGL(attn_bias_index_dump_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256),
+                       0, stream, qm, km, bias_L, nq, nk, idx);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

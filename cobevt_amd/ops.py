@@ -537,6 +537,26 @@ def window_attention(q, k, v, out, qmap, kmap, omap, batch, heads, scale, ldq, l
     return out
 
 
+def attention_index_map(tmap, batch, device):
+    """int32 (batch, X*Y, ncam*w1*w2): the token -> row map of cobevt_window_attention for one token map (test hook)."""
+    L, ntok = tmap[6] * tmap[7], tmap[1] * tmap[4] * tmap[5]
+    rows = torch.empty((batch, L, ntok), device=device, dtype=torch.int32)
+    _need_cuda(rows)
+    rc = _L.load().cobevt_attention_index_map(_ints(tmap), batch, _p(rows), _stream())
+    _L.check(rc, "cobevt_attention_index_map")
+    return rows
+
+
+def attention_bias_index(qmap, kmap, bias_L, device):
+    """int32 (Nq, Nk): the relative-position table row the attention kernels use for every (query, key) pair (test hook)."""
+    nq, nk = qmap[1] * qmap[4] * qmap[5], kmap[1] * kmap[4] * kmap[5]
+    idx = torch.empty((nq, nk), device=device, dtype=torch.int32)
+    _need_cuda(idx)
+    rc = _L.load().cobevt_attention_bias_index(_ints(qmap), _ints(kmap), int(bias_L), _p(idx), _stream())
+    _L.check(rc, "cobevt_attention_bias_index")
+    return idx
+
+
 def ray_embed(i_inv, e_inv, image_plane, w_img, w_cam, hw, dim, dtype):
     _need_cuda(i_inv, e_inv, image_plane, w_img, w_cam)
     bn = i_inv.shape[0]

@@ -170,6 +170,15 @@ int cobevt_attn_mlp_chain(const void* a, const void* skip, void* out, const void
 int cobevt_window_attention(const void* q, const void* k, const void* v, void* out, const float* bias_table,
                             const float* mask, const int* dims, float scale, hipStream_t stream);
 
+/* Test hooks for the integer part of the attention kernels (north-star: window index arithmetic bit-exact), computed by the
+ * same device functions the attention kernels use.  cobevt_attention_index_map: rows[b][l][t] (int32, B * X*Y * ncam*w1*w2) =
+ * row of token t of window l in the (B*ncam, HH, WW) token matrix, for one token map {mode, ncam, HH, WW, w1, w2, X, Y}:
+ * the einops partitions of fax_modules.py:399-404 (window), :417-424 (grid), swap_fusion_modules.py:172-190.
+ * cobevt_attention_bias_index: idx[tq][tk] (int32, Nq * Nk) = relative-position table row for query token tq / key token tk
+ * (swap_fusion_modules.py:63-85 with bias_L = agent_size; fax_modules.py:123-130 with bias_L = 1). */
+int cobevt_attention_index_map(const int* map8, int B, int* rows, hipStream_t stream);
+int cobevt_attention_bias_index(const int* qmap8, const int* kmap8, int bias_L, int* idx, hipStream_t stream);
+
 /* LayerNorm over channels (gamma/beta both null = normalisation only), optionally after a mean over `navg` slices (mlp_head).
  * Replaces: nn.LayerNorm of fax_modules.py:189-191,309-313,435-437; swap_fusion_modules.py:275-279;
  *   base_transformer.py:102-109. */

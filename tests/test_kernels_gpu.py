@@ -520,6 +520,49 @@ def _attn_ref(q, k, v, scale, bias=None, key_mask=None):
     return torch.matmul(s.softmax(-1), v)
 
 
+def test_attention_index_maps_bit_exact_on_gpu(cuda):
+    """The integer part of the attention kernels - token -> row (window / grid partition and reverse) and the relative-position
+    table index - dumped by the device functions the kernels use, int32-equal to the REFERENCE's einops / index buffers
+    (tests/golden/gv1_index_maps.npz: fax_modules.py:399-404,417-424,123-130; swap_fusion_modules.py:63-85) for every shape of
+    the shipped configs, including non-square windows, several cameras per window and a batch offset."""
+    import cases
+    from util import golden
+    g = golden("gv1_index_maps")
+    B, ncam = 2, 3
+    for (H, W, w1, w2) in cases.INDEX_MAP_SHAPES:
+        for mode, key in ((0, "win"), (1, "grid")):
+            ref = torch.from_numpy(g["%s_%d_%d_%d_%d" % (key, H, W, w1, w2)].astype(np.int64))       # [l][t] -> flat pixel
+            L, ws = ref.shape
+            # token t = cam * ws + local (camera-major inside a window, fax_modules.py:211-213); row = (b*ncam + cam)*H*W + pixel
+            plane = (torch.arange(B)[:, None] * ncam + torch.arange(ncam)[None, :]) * (H * W)              # [b][cam]
+            want = (plane[:, None, :, None] + ref[None, :, None, :]).reshape(B, L, ncam * ws).to(torch.int32)
+            got = ops.attention_index_map(ops.tokmap(mode, ncam, H, W, w1, w2), B, cuda).cpu()
+            assert torch.equal(got, want), "%s partition %dx%d / %dx%d" % (key, H, W, w1, w2)
+        # mode 2 (rows already stored partitioned, the CrossWinAttention.forward API): the identity
+        m2 = (2, ncam, H, W, w1, w2, H // w1, W // w2)
+        got = ops.attention_index_map(m2, B, cuda).cpu()
+        L, ws = (H // w1) * (W // w2), w1 * w2
+        b_, l_, c_, t_ = torch.meshgrid(torch.arange(B), torch.arange(L), torch.arange(ncam), torch.arange(ws), indexing="ij")
+        want = (((b_ * ncam + c_) * L + l_) * ws + t_).reshape(B, L, ncam * ws).to(torch.int32)
+        assert torch.equal(got, want)
+    for (L, w) in cases.REL_POS_3D:
+        m = ops.tokmap(0, L, w, w, w, w)
+        got = ops.attention_bias_index(m, m, L, cuda).cpu()
+        assert torch.equal(got, torch.from_numpy(g["rel3d_%d_%d" % (L, w)]).to(torch.int32)), "3-D rel-pos index L=%d w=%d" % (L, w)
+        mg = ops.tokmap(1, L, 4 * w, 4 * w, w, w)           # the grid pass uses the same window-local coordinates
+        assert torch.equal(ops.attention_bias_index(mg, mg, L, cuda).cpu(), got)
+    m8 = ops.tokmap(0, 1, 8, 8, 8, 8)
+    assert torch.equal(ops.attention_bias_index(m8, m8, 1, cuda).cpu(), torch.from_numpy(g["rel2d_8"]).to(torch.int32))
+    m32 = ops.tokmap(0, 1, 32, 32, 32, 32)
+    i32 = ops.attention_bias_index(m32, m32, 1, cuda).cpu()
+    assert torch.equal(i32[::37, ::41], torch.from_numpy(g["rel2d_32_sample"]).to(torch.int32))
+    assert int(i32.to(torch.int64).sum()) == int(g["rel2d_32_sum"][0])
+    # LiDAR FuseBEVT table (8 agents, window 8: 3375 rows) against the oracle's restatement of the same buffer
+    ml = ops.tokmap(0, 8, 8, 8, 8, 8)
+    assert torch.equal(ops.attention_bias_index(ml, ml, 8, cuda).cpu(),
+                       torch.from_numpy(o_swap.relative_position_index_3d(8, 8)).to(torch.int32))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("kmode", [0, 1])
 @pytest.mark.parametrize("mean_q", [True, False])

@@ -234,12 +234,14 @@ def test_naive_compressor_and_compressed_corpbevt(cuda, dtype, tol):
     assert_close(out["dynamic_seg"], g["dynamic_seg"], tol, "CorpBEVT.small compression=2")
 
 
-def test_corpbevt_full_config_two_agents_vs_oracle(cuda):
-    """BASELINE config[2] shape (2 agents x 4 cams x 512^2 -> 256^2 BEV, ResNet-34, full corpbevt.yaml) against the
-    oracle run on the host CPU: fp32 mode <= 1e-3 rel, bf16 mode <= 5e-2 rel + arg-max agreement."""
+@pytest.mark.parametrize("agents", [2, 5])
+def test_corpbevt_full_config_vs_oracle(cuda, agents):
+    """BASELINE configs[2] (2 agents) and configs[3] (5 agents - the bench workload) at full size: agents x 4 cams x 512^2 ->
+    256^2 BEV, ResNet-34, the shipped corpbevt.yaml (corpbevt.py:104-145, hypes_yaml/opcamera/corpbevt.yaml:11,47-58), against
+    the oracle run on the host CPU: fp32 mode <= 1e-3 rel, bf16 mode <= 5e-2 rel + arg-max agreement."""
     cfg = synth.corpbevt_config()
     m = fill_module_(host.CorpBEVT(copy.deepcopy(cfg)), cases.SEED).eval()
-    batch = synth.opv2v_batch(agents=2, seed=cases.SEED)
+    batch = synth.opv2v_batch(agents=agents, seed=cases.SEED)
     ref = o_model.corpbevt_forward(m.state_dict(), cfg, batch)["dynamic_seg"]
     m = m.to(cuda)
     b = {k: v.to(cuda) for k, v in batch.items()}
@@ -249,7 +251,7 @@ def test_corpbevt_full_config_two_agents_vs_oracle(cuda):
         y16 = m(dict(b))["dynamic_seg"]
     e32, e16 = rel_err(y32, ref), rel_err(y16, ref)
     a32, a16 = _argmax_agreement(y32.cpu(), ref), _argmax_agreement(y16.cpu(), ref)
-    print("full CorpBEVT 2 agents: fp32 rel %.2e argmax %.5f | bf16 rel %.2e argmax %.5f" % (e32, a32, e16, a16))
+    print("full CorpBEVT %d agents: fp32 rel %.2e argmax %.5f | bf16 rel %.2e argmax %.5f" % (agents, e32, a32, e16, a16))
     assert e32 <= 1e-3 and a32 >= 0.999
     assert e16 <= 5e-2 and a16 >= 0.98
 
@@ -292,3 +294,47 @@ def test_lidar_shaped_fusebevt(cuda, dtype, tol):
     with host.compute_dtype(dtype):
         y = enc(x.to(cuda), mask.to(cuda))
     assert_close(y, ref, tol, "LiDAR-shaped SwapFusionEncoder")
+
+
+def _lidar_encoder_and_inputs():
+    args = dict(input_dim=64, mlp_dim=128, agent_size=8, window_size=8, dim_head=32, drop_out=0.1, depth=3, mask=True)
+    enc = fill_module_(host.SwapFusionEncoder(args), cases.SEED).eval()
+    x = synth.procedural_input("lidar.x", (1, 8, 64, 256, 256), cases.SEED)
+    mask = torch.ones(1, 256, 256, 1, 8)
+    mask[0, :, :, :, 6:] = 0                          # two padded agents
+    ii, jj = torch.meshgrid(torch.arange(256), torch.arange(256), indexing="ij")
+    mask[0, :, :, 0, 3] = (jj > ii // 2).float()      # an ROI wedge for agent 3
+    return args, enc, x, mask
+
+
+def test_lidar_fusebevt_full_size(cuda):
+    """BASELINE configs[4] at its real size: SwapFusionEncoder(input_dim 64, 8 agents, window 8, depth 3, mask) on
+    x (1, 8, 64, 256, 256) - 1024 windows x 512 tokens x 2 heads per attention, the 3375-row 3-D bias table in LDS
+    (swap_fusion_modules.py:233-310).  Full-size comparison with the oracle (about 25 s of host CPU) in both modes, plus
+    properties that need no reference: finite output; rows of real agents never read a masked agent's features (key mask,
+    swap_fusion_modules.py:110-115) - bit-identical when the padded agents' features change."""
+    import oracle.swap_fusion as o_swap
+    args, enc, x, mask = _lidar_encoder_and_inputs()
+    ref = o_swap.swap_fusion_encoder(enc.state_dict(), "", args, x, mask)
+    enc = enc.to(cuda)
+    xd, md = x.to(cuda), mask.to(cuda)
+    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, 3e-2)):
+        with host.compute_dtype(dtype):
+            y = enc(xd, md)
+        assert tuple(y.shape) == (1, 64, 256, 256)
+        e = assert_close(y, ref, tol, "LiDAR FuseBEVT 8x64x256x256 %s" % dtype)
+        print("LiDAR FuseBEVT full size %s: rel err %.2e" % (dtype, e))
+    # masked agents are never read as keys: the block stack's output rows of the real agents do not depend on them
+    from cobevt_amd.host import swap_fusion_modules as sfm
+    x2 = x.clone()
+    x2[:, 6:] = synth.procedural_input("lidar.other", (1, 2, 64, 256, 256), cases.SEED + 1)
+    with host.compute_dtype(torch.bfloat16):
+        outs = []
+        for inp in (x, x2):
+            t = sfm._to_blhwc(inp.to(cuda))
+            for layer in enc.layers:
+                t = layer.forward_blhwc(t, md)
+            outs.append(t)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0][:, :6], outs[1][:, :6])
+    assert not torch.equal(outs[0][:, 6:], outs[1][:, 6:])
