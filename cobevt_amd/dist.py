@@ -100,3 +100,204 @@ class AgentShardedCoBEVT(object):
         feats = self.model.encode_agents(task_batch)
         mine = exchange_features(feats, self.rank, self.world, self.agents, self.group)
         return self.model.fuse_and_decode(mine, frame_pose, record_len)
+
+
+# ----------------------------------------------------------------------------------------------
+# Strong scaling ("latency mode"): ONE frame, its agents spread over the ranks (rank r owns the agents
+# {a : a mod G = r}; one all-gather of the (H, W, C) feature blocks; STTF + fusion + decoder replicated on every rank -
+# 18 GF, cheaper than a second exchange).  With more ranks than agents the surplus ranks contribute zero blocks.
+# ----------------------------------------------------------------------------------------------
+def agents_of_rank(rank, world, agents):
+    """agent ids encoded by `rank` for one frame"""
+    return list(range(rank, agents, world))
+
+
+def slots_per_rank(world, agents):
+    """feature blocks every rank contributes to the all-gather (equal sizes; ranks with fewer agents pad with zeros)"""
+    return max(1, -(-agents // world))
+
+
+def strong_gather_index(world, agents):
+    """flat indices into the all-gathered (world * slots) blocks holding agents 0..A-1 of the frame"""
+    s = slots_per_rank(world, agents)
+    return [(a % world) * s + a // world for a in range(agents)]
+
+
+def take_agents(batch, ids):
+    """sub-batch (inputs / intrinsic / extrinsic) of the agents `ids` of a one-frame batch"""
+    idx = torch.as_tensor(ids, dtype=torch.long, device=batch["inputs"].device)
+    return {k: batch[k].index_select(0, idx) for k in ("inputs", "intrinsic", "extrinsic")}
+
+
+_strong_index_cache = {}
+
+
+def exchange_features_strong(local_feats, n_local, rank, world, agents, group=None, out=None, staging=None):
+    """local_feats: (>= n_local, H, W, C) features of this rank's agents (agents_of_rank order) -> (agents, H, W, C) features
+    of the whole frame in agent order on EVERY rank.  One all-gather of `slots_per_rank` blocks per rank."""
+    if world == 1:
+        if out is not None and out.data_ptr() != local_feats.data_ptr():
+            out.copy_(local_feats)
+            return out
+        return local_feats
+    s = slots_per_rank(world, agents)
+    block = tuple(local_feats.shape[1:])
+    send = staging if staging is not None else torch.zeros((s,) + block, dtype=local_feats.dtype, device=local_feats.device)
+    if n_local:
+        send[:n_local].copy_(local_feats[:n_local])
+    if n_local < s:
+        send[n_local:].zero_()
+    gathered = torch.empty((world * s,) + block, dtype=send.dtype, device=send.device)
+    if send.is_cuda and dist.get_backend(group) == "gloo":            # dry-run mode only
+        host = torch.empty(gathered.shape, dtype=gathered.dtype)
+        dist.all_gather_into_tensor(host, send.cpu(), group=group)
+        gathered.copy_(host)
+    else:
+        dist.all_gather_into_tensor(gathered, send, group=group)
+    key = (world, agents, str(send.device))
+    idx = _strong_index_cache.get(key)
+    if idx is None:
+        idx = torch.tensor(strong_gather_index(world, agents), dtype=torch.long).to(send.device)
+        _strong_index_cache[key] = idx
+    if out is not None:
+        return torch.index_select(gathered, 0, idx, out=out)
+    return gathered.index_select(0, idx)
+
+
+class FrameShardedCoBEVT(object):
+    """One frame across the ranks (strong scaling): rank r encodes agents r, r+G, ..; all-gather; fusion replicated."""
+
+    def __init__(self, model, rank, world, agents, group=None):
+        self.model, self.rank, self.world, self.agents, self.group = model, rank, world, agents, group
+        self.mine = agents_of_rank(rank, world, agents)
+        self._zero_block = None
+
+    def step(self, frame_batch):
+        """frame_batch: the WHOLE frame's batch dict (every rank sees the same host-side inputs; only its agents' images
+        are read).  Returns the frame's output dict on every rank."""
+        feats = None
+        if self.mine:
+            feats = self.model.encode_agents(take_agents(frame_batch, self.mine))
+        if feats is None:             # a surplus rank (more GPUs than agents): contributes zero blocks of the right shape
+            if self._zero_block is None:      # learn shape / dtype / device once by encoding one agent
+                ref = self.model.encode_agents(take_agents(frame_batch, [0]))
+                self._zero_block = ref.new_zeros((0,) + tuple(ref.shape[1:]))
+            feats = self._zero_block
+        full = exchange_features_strong(feats, len(self.mine), self.rank, self.world, self.agents, self.group) \
+            if self.world > 1 else feats
+        return self.model.fuse_and_decode(full, frame_batch["transformation_matrix"], frame_batch["record_len"])
+
+
+# ----------------------------------------------------------------------------------------------
+# LiDAR FuseBEVT (SwapFusionEncoder on (1, L, C, H, W) with L agents, SURVEY.md §8e "larger fusion inputs"): the window
+# pass is independent per window and the dilated-grid pass per grid group, so the map is sharded by ROWS:
+#   band layout  rank r owns rows [r*H/G, (r+1)*H/G)                       - whole windows (H/G a multiple of w)
+#   grid layout  rank s owns rows {i*X + x : x in [s*X/G, (s+1)*X/G)}, X = H/w - whole grid groups; as a local map of
+#                w*X/G rows in (i, x_local) order this is again a plain dilated grid of stride X/G
+# with one all-to-all between the two halves of every block (and one back), an agent->band all-to-all in front (rank a
+# holds agent a's map: "agent-per-GPU") and an all-gather of the fused bands at the end.
+# ----------------------------------------------------------------------------------------------
+def _all_to_all(send, group=None):
+    recv = torch.empty_like(send)
+    if send.is_cuda and dist.get_backend(group) == "gloo":            # dry-run mode only
+        h = torch.empty(send.shape, dtype=send.dtype)
+        dist.all_to_all_single(h, send.cpu(), group=group)
+        recv.copy_(h)
+    else:
+        dist.all_to_all_single(recv, send, group=group)
+    return recv
+
+
+def shard_check(H, window, world, agents):
+    X = H // window
+    if H % window or window % world or X % world or agents % world:
+        raise ValueError("row sharding needs window %% world == 0, (H / window) %% world == 0 and agents %% world == 0 "
+                         "(H=%d window=%d agents=%d world=%d)" % (H, window, agents, world))
+
+
+def agents_to_bands(x_agents, world, group=None):
+    """(b, L/G, H, W, d) maps of this rank's agents [r*L/G, (r+1)*L/G) -> (b, L, H/G, W, d) band r of every agent"""
+    if world == 1:
+        return x_agents
+    b, ll, H, W, d = x_agents.shape
+    send = x_agents.reshape(b, ll, world, H // world, W, d).permute(2, 0, 1, 3, 4, 5).contiguous()
+    recv = _all_to_all(send, group)                                   # (src, b, ll, Hb, W, d)
+    return recv.permute(1, 0, 2, 3, 4, 5).reshape(b, world * ll, H // world, W, d)
+
+
+def bands_to_grid(x_band, world, window, group=None):
+    """band layout (b, L, H/G, W, d) -> grid layout (b, L, w*X/G, W, d), rows in (i, x_local) order"""
+    if world == 1:
+        return x_band
+    b, l, Hb, W, d = x_band.shape
+    XG = Hb // window                           # X / G rows per (i, rank) block: X/G = (H/w)/G = Hb/w
+    wi = window // world                        # i values per band
+    send = x_band.reshape(b, l, wi, world, XG, W, d).permute(3, 0, 1, 2, 4, 5, 6).contiguous()
+    recv = _all_to_all(send, group)                                   # (src, b, l, wi, X/G, W, d)
+    return recv.permute(1, 2, 0, 3, 4, 5, 6).reshape(b, l, window * XG, W, d)
+
+
+def grid_to_bands(x_grid, world, window, group=None):
+    """inverse of bands_to_grid"""
+    if world == 1:
+        return x_grid
+    b, l, Hg, W, d = x_grid.shape
+    XG = Hg // window
+    wi = window // world
+    send = x_grid.reshape(b, l, world, wi, XG, W, d).permute(2, 0, 1, 3, 4, 5, 6).contiguous()
+    recv = _all_to_all(send, group)                                   # (src s, b, l, wi, X/G, W, d)
+    return recv.permute(1, 2, 3, 0, 4, 5, 6).reshape(b, l, wi * world * XG, W, d)
+
+
+def mask_band(mask, rank, world):
+    """(b, H, W, 1, L) -> this rank's band rows"""
+    Hb = mask.shape[1] // world
+    return mask[:, rank * Hb:(rank + 1) * Hb].contiguous()
+
+
+def mask_grid(mask, rank, world, window):
+    """(b, H, W, 1, L) -> this rank's grid-layout rows ((i, x_local) order)"""
+    b, H, W, e, l = mask.shape
+    X = H // window
+    XG = X // world
+    return mask.reshape(b, window, X, W, e, l)[:, :, rank * XG:(rank + 1) * XG].reshape(b, window * XG, W, e, l).contiguous()
+
+
+class RowShardedFuseBEVT(object):
+    """SwapFusionEncoder over row-sharded maps.  `stages`: list of (mode, fn) in network order with
+    fn(x_local (b, L, h_local, W, d), mask_local (b, h_local, W, 1, L) | None) -> x_local, mode 0 = window pass (band
+    layout), 1 = grid pass (grid layout); `head(x_band) -> (b, Hb, W, d)`.  The HIP product passes its own stage functions
+    (cobevt_amd.host.swap_fusion_modules.sharded_stages); the CPU tests inject the oracle."""
+
+    def __init__(self, stages, head, rank, world, window, group=None):
+        self.stages, self.head, self.rank, self.world, self.window, self.group = stages, head, rank, world, window, group
+
+    def step(self, x_agents, mask):
+        """x_agents (b, L/G, H, W, d): this rank's agents; mask (b, H, W, 1, L) replicated or None -> (b, H, W, d) fused"""
+        G, w = self.world, self.window
+        if G > 1:
+            shard_check(x_agents.shape[2], w, G, x_agents.shape[1] * G)
+        x = agents_to_bands(x_agents, G, self.group)
+        mb = mask_band(mask, self.rank, G) if mask is not None else None
+        mg = mask_grid(mask, self.rank, G, w) if mask is not None else None
+        layout = 0
+        for mode, fn in self.stages:
+            if mode != layout:
+                x = bands_to_grid(x, G, w, self.group) if mode == 1 else grid_to_bands(x, G, w, self.group)
+                layout = mode
+            x = fn(x, mb if mode == 0 else mg)
+        if layout == 1:
+            x = grid_to_bands(x, G, w, self.group)
+        y = self.head(x)                                              # (b, Hb, W, d)
+        if G == 1:
+            return y
+        y = y.contiguous()
+        b, Hb, W, d = y.shape
+        out = torch.empty((G * b, Hb, W, d), dtype=y.dtype, device=y.device)
+        if y.is_cuda and dist.get_backend(self.group) == "gloo":
+            h = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(h, y.cpu(), group=self.group)
+            out.copy_(h)
+        else:
+            dist.all_gather_into_tensor(out, y, group=self.group)
+        return out.reshape(G, b, Hb, W, d).permute(1, 0, 2, 3, 4).reshape(b, G * Hb, W, d)

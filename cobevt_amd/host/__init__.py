@@ -12,6 +12,7 @@ from .bev_seg_head import BevSegHead  # noqa: F401
 from .fuse_utils import regroup  # noqa: F401
 from .corpbevt import STTF, CorpBEVT  # noqa: F401
 from .fax_fused_transformer import FaxFusedTransformer  # noqa: F401
+from .pipeline import CapturedCall, CapturedCorpBEVT, PipelinedCorpBEVT  # noqa: F401
 # the data formats either side of the path
 from .camera_bev_postprocessor import CameraBevPostprocessor  # noqa: F401
 from .rgb_preprocessor import RgbPreProcessor  # noqa: F401

@@ -128,11 +128,12 @@ class CorpBEVT(HipModule):
         batch_dict.update({"features": [t.reshape(b, l, n, *t.shape[1:]) for t in v]})    # reference side effect (:113)
         return {"kv": [kv[i] for i in range(len(pick))], "E_inv": E_inv, "batch": b * l, "side": side}
 
-    def fax_query(self, state, joined=True, levels=None, x=None):
+    def fax_query(self, state, joined=True, levels=None, x=None, out=None):
         """Stage 2: the BEV-query side of the FAX pyramid on the K/V state of `encode_trunk` -> (N, H, W, C) channels-last
         BEV features (the tensor V2V sharing transmits).  joined=False: the state's tensors are already complete on the
         current stream (they come from an earlier pipeline step), no side-stream join.  levels / x: run only part of the pyramid
-        (FAXModule.forward_features) - a deeper pipeline puts level 0 and levels 1.. on different streams."""
+        (FAXModule.forward_features) - a deeper pipeline puts level 0 and levels 1.. on different streams.
+        out: optional preallocated result buffer (a pipeline's ring slot) the last kernel writes into."""
         kv, side = state["kv"], state.get("side")
         main = torch.cuda.current_stream()
 
@@ -144,7 +145,7 @@ class CorpBEVT(HipModule):
             return get
 
         return self.fax.forward_features([None] * len(kv), None, state["E_inv"], state["batch"],
-                                         kv=[getter(i) for i in range(len(kv))], levels=levels, x=x)
+                                         kv=[getter(i) for i in range(len(kv))], levels=levels, x=x, out=out)
 
     def encode_agents(self, batch_dict):
         """Per-agent SinBEVT: images -> (N, H, W, C) channels-last BEV features (the tensor V2V sharing transmits).

@@ -109,17 +109,17 @@ class Attention(HipModule):
         rel_pos_indices = (rel_pos * torch.tensor([2 * window_size - 1, 1])).sum(dim=-1)
         self.register_buffer("rel_pos_indices", rel_pos_indices, persistent=False)
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, out=None):
         b, h, w, d = x.shape
         if h != self.window_size or w != self.window_size:
             raise CobevtHipError("FAX global attention expects a %dx%d map" % (self.window_size, self.window_size))
         qkv = ops.linear(x, rt.linear_plan(self, "qkv", self.to_qkv))
-        out = torch.empty((b, h, w, d), device=x.device, dtype=x.dtype)
+        a = torch.empty((b, h, w, d), device=x.device, dtype=x.dtype)
         m = ops.tokmap(0, 1, h, w, h, w)
         table = rt.f32_param(self, "bias", self.rel_pos_bias.weight)
-        ops.window_attention(qkv, qkv, qkv, out, m, m, m, b, self.heads, self.scale, 3 * d, 3 * d, 3 * d, d, koff=d,
+        ops.window_attention(qkv, qkv, qkv, a, m, m, m, b, self.heads, self.scale, 3 * d, 3 * d, 3 * d, d, koff=d,
                              voff=2 * d, bias_table=table, bias_L=1)
-        return ops.linear(out, rt.linear_plan(self, "out", self.to_out[0]))
+        return ops.linear(a, rt.linear_plan(self, "out", self.to_out[0]), out=out)
 
     def forward(self, x):
         self._require_inference(x)
@@ -369,10 +369,10 @@ class _Downsample(HipModule):
     def __getitem__(self, i):
         return getattr(self, str(i))
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, out=None):
         y = ops.conv2d(x, rt.conv_plan(self, "c0", self[0], store_mode=1))          # conv + PixelUnshuffle(2)
         y = ops.conv2d(y, rt.conv_plan(self, "c2", self[2], self[3], act=1))
-        return ops.conv2d(y, rt.conv_plan(self, "c5", self[5], self[6]))
+        return ops.conv2d(y, rt.conv_plan(self, "c5", self[5], self[6]), out=out)
 
 
 class FAXModule(HipModule):
@@ -403,11 +403,12 @@ class FAXModule(HipModule):
         self.downsample_layers = nn.ModuleList(downsample_layers)
         self.self_attn = Attention(dim[-1], **config["self_attn"])
 
-    def forward_features(self, features, I_inv, E_inv, batch, kv=None, levels=None, x=None):
+    def forward_features(self, features, I_inv, E_inv, batch, kv=None, levels=None, x=None, out=None):
         """features: list of (batch*n, h, w, C) channels-last; returns (batch, H, W, d) channels-last.
         kv: optional list of callables returning each level's prepare_kv() result (computed ahead on side streams).
         levels = (first, last): run only pyramid levels first..last-1 (the global self-attention belongs to the last
-        level), starting from `x` when first > 0 - the pieces a frame pipeline runs on different streams."""
+        level), starting from `x` when first > 0 - the pieces a frame pipeline runs on different streams.
+        out: optional preallocated (batch, H, W, d) buffer for the result (written by the last kernel, no copy)."""
         nlev = len(self.cross_views)
         first, last = (0, nlev) if levels is None else levels
         if first == 0:
@@ -428,9 +429,13 @@ class FAXModule(HipModule):
             for j, blk in enumerate(blocks):
                 x = blk.forward_nhwc(x, y1=y1 if j == 0 else None)
             if i < len(self.cross_views) - 1:
-                x = self.downsample_layers[i][0].forward_nhwc(x)
+                final = out is not None and i == last - 1 and not (self.self_attn is not None and last == nlev)
+                x = self.downsample_layers[i][0].forward_nhwc(x, out=out if final else None)
         if self.self_attn is not None and last == nlev:
-            x = self.self_attn.forward_nhwc(x)
+            x = self.self_attn.forward_nhwc(x, out=out)
+        if out is not None and x.data_ptr() != out.data_ptr():
+            out.copy_(x)
+            x = out
         return x
 
     def forward(self, batch):

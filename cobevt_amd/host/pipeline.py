@@ -1,0 +1,304 @@
+"""HIP-graph runners for CorpBEVT inference: what `bench.py` times and what a serving loop uses.
+
+The reference's inference loop (opv2v/opencood/tools/inference_camera.py:38-60) calls `model(batch_data['ego'])` once per
+frame on the default stream.  The eager `CorpBEVT.forward` mirror does the same through ~105 ctypes launches; these runners
+keep that forward bit for bit and remove the launch overhead / expose the frame-level parallelism:
+
+* `CapturedCorpBEVT(model, example_batch)`     one frame at a time, the whole forward replayed from captured HIP graphs
+  (encode | [agent all-gather between the two graphs when world > 1] | fuse + decode).  `step(batch)` == `model(batch)`.
+* `PipelinedCorpBEVT(model, example_batch, depth=3)`   several frames in flight on ONE GPU: step i runs the camera encoder
+  + K/V sides of frame i, the FAX query path of frame i-1 and fusion + decoder of frame i-2 on three HIP streams inside one
+  captured graph.  One frame in, one frame out per step; `step(batch)` returns the output of the frame submitted
+  `latency_steps - 1` calls earlier (None while the pipeline fills).  Nothing is skipped or cached.
+
+Both take the batch through STATIC device buffers (`runner.static_batch`): a captured graph reads fixed addresses, so
+`step(batch)` first copies the caller's tensors into them (skipped for tensors that already ARE the static buffers - a
+data loader can write into `runner.static_batch[...]` directly).  Multi-GPU (`rank`, `world`): see cobevt_amd/dist.py.
+"""
+import torch
+
+from .. import dist as cdist
+from ..lib import CobevtHipError
+
+_IMAGE_KEYS = ("inputs", "intrinsic", "extrinsic")
+
+
+def _static_copy(batch, dev):
+    out = {k: batch[k].to(dev).clone() for k in _IMAGE_KEYS}
+    out["transformation_matrix"] = batch["transformation_matrix"].to(device=dev, dtype=torch.float32).clone()
+    out["record_len"] = torch.as_tensor(batch["record_len"]).to(device=dev, dtype=torch.int32).clone()
+    return out
+
+
+class _RunnerBase(object):
+    def __init__(self, model, example_batch, rank=0, world=1, agents=None):
+        if model.training:
+            raise CobevtHipError("graph runners implement inference: call model.eval() first")
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise CobevtHipError("graph runners need the model on a ROCm device")
+        self.model, self.rank, self.world = model, rank, world
+        self.static_batch = _static_copy(example_batch, dev)
+        self.agents = int(self.static_batch["inputs"].shape[0]) if agents is None else int(agents)
+
+    @property
+    def _images(self):
+        return {k: self.static_batch[k] for k in _IMAGE_KEYS}
+
+    def load(self, batch):
+        """copy the caller's frame into the static input buffers (no-op for tensors that already are those buffers)"""
+        if batch is None:
+            return
+        for k, dst in self.static_batch.items():
+            src = batch[k]
+            src = torch.as_tensor(src) if not torch.is_tensor(src) else src
+            if src.data_ptr() == dst.data_ptr():
+                continue
+            if tuple(src.shape) != tuple(dst.shape):
+                raise CobevtHipError("graph runner captured %s of shape %s, got %s (re-capture for a new shape)"
+                                     % (k, tuple(dst.shape), tuple(src.shape)))
+            dst.copy_(src, non_blocking=True)
+
+
+class CapturedCorpBEVT(_RunnerBase):
+    """One frame at a time from captured HIP graphs; `step(batch)` equals `model(batch)` bit for bit."""
+
+    latency_steps = 1
+
+    def __init__(self, model, example_batch, rank=0, world=1, agents=None, use_graph=True):
+        super().__init__(model, example_batch, rank, world, agents)
+        self.graphs, self.out = None, None
+        self.eager_step()                       # builds every weight plan outside the capture
+        torch.cuda.synchronize()
+        if use_graph:
+            self.capture()
+
+    def _encode(self):
+        return self.model.encode_agents(dict(self._images))
+
+    def _fuse(self, feats):
+        return self.model.fuse_and_decode(feats, self.static_batch["transformation_matrix"], self.static_batch["record_len"])
+
+    def eager_step(self, batch=None):
+        self.load(batch)
+        feats = self._encode()
+        mine = cdist.exchange_features(feats, self.rank, self.world, self.agents)
+        self.out = self._fuse(mine)
+        return self.out
+
+    def capture(self):
+        """encode and fuse as two HIP graphs (the collective, if any, stays eager between them)"""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self.eager_step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            feats = self._encode()
+        self.feats = feats
+        self.fuse_in = feats if self.world == 1 else torch.empty_like(feats)
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            self.out = self._fuse(self.fuse_in)
+        self.graphs = (g1, g2)
+
+    def step(self, batch=None):
+        if self.graphs is None:
+            return self.eager_step(batch)
+        self.load(batch)
+        self.graphs[0].replay()
+        if self.world > 1:
+            cdist.exchange_features(self.feats, self.rank, self.world, self.agents, out=self.fuse_in)
+        self.graphs[1].replay()
+        return self.out
+
+
+class PipelinedCorpBEVT(_RunnerBase):
+    """Several frames in flight on ONE GPU.  A CoBEVT frame is ~1.2 ms of camera encoder that fills the chip followed by
+    ~1 ms of FAX query path, swap fusion and decoder whose ~100 dependent launches are latency-bound and leave most CUs idle.
+    Step i therefore runs, on separate HIP streams inside one captured graph,
+        S1  = encoder + K/V sides of the FAX pyramid of frame i          (CorpBEVT.encode_trunk)
+        S2  = FAX query path of frame i-1                                 (CorpBEVT.fax_query)         [depth 3]
+              or S2a = pyramid level 0 of frame i-1 and S2b = levels 1.. + global attention of frame i-2 [depth 4]
+        S3  = STTF + swap fusion + decoder + head of the oldest frame     (CorpBEVT.fuse_and_decode)
+    with the state that crosses steps (projected K/V of the three levels, the level-0 output, the (A,32,32,128) features,
+    the poses) in rings of `depth` buffers - `depth` graphs, replayed round-robin.  Every step takes one frame in and
+    completes one frame; the latency of a frame is `latency_steps` steps (depth on one GPU; one more with the agent
+    all-gather of cobevt_amd/dist.py, which runs under the following step)."""
+
+    def __init__(self, model, example_batch, rank=0, world=1, agents=None, depth=3):
+        super().__init__(model, example_batch, rank, world, agents)
+        if depth not in (3, 4):
+            raise CobevtHipError("PipelinedCorpBEVT: depth must be 3 or 4")
+        self.depth = D = depth
+        st = model.encode_trunk(dict(self._images))
+        torch.cuda.synchronize()
+        self.meta = [{k: v for k, v in lvl.items() if not torch.is_tensor(v)} for lvl in st["kv"]]
+        self.batch = st["batch"]
+        self.kv = [[{k: torch.empty_like(v) for k, v in lvl.items() if torch.is_tensor(v)} for lvl in st["kv"]] for _ in range(D)]
+        self.einv = [torch.empty_like(st["E_inv"]) for _ in range(D)]
+        x0 = model.fax_query(st, levels=(0, 1))
+        self.x = [torch.empty_like(x0) for _ in range(D)] if depth == 4 else None
+        feats = model.fax_query(st, levels=(1, len(st["kv"])), x=x0)
+        self.f = [torch.empty_like(feats) for _ in range(D)]
+        # multi-GPU: the frame's agents are gathered (one RCCL all-gather between graph replays) into g; single GPU: g is f.
+        # The gather of step q's features runs on its own stream UNDER step q+1 and is consumed by the fusion stage of step
+        # q+2 (one more step of latency than on one GPU), so the collective is off the critical path
+        self.g = self.f if world == 1 else [torch.empty_like(feats) for _ in range(D)]
+        self.lag = 1 if world == 1 else 2                     # fusion of step q reads the features of slot q - lag
+        self.latency_steps = D if world == 1 else D + 1
+        # pose / record_len of a frame are consumed latency_steps - 1 steps after its images: S1 parks them in ring `pose`;
+        # with the gather's extra step the consumer's slot is the one S1 rewrites in the same step -> staged copy `pose_s3`
+        self.pose = [self.static_batch["transformation_matrix"].clone() for _ in range(D)]
+        self.rlen = [self.static_batch["record_len"].clone() for _ in range(D)]
+        self.pose_s3 = [t.clone() for t in self.pose] if world > 1 else None
+        self.rlen_s3 = [t.clone() for t in self.rlen] if world > 1 else None
+        self.comm = torch.cuda.Stream() if world > 1 else None
+        self.gathered = [None] * D
+        self.out, self.graphs = None, None
+        self.i = self.filled = 0
+        self.capture()
+
+    def _state(self, slot):
+        return {"kv": [dict(self.meta[i], **self.kv[slot][i]) for i in range(len(self.meta))],
+                "E_inv": self.einv[slot], "batch": self.batch}
+
+    def _s1(self, slot):
+        st = self.model.encode_trunk(dict(self._images), kv_out=self.kv[slot])      # K/V land in the slot directly
+        main = torch.cuda.current_stream()
+        for level, lvl in enumerate(st["kv"]):
+            main.wait_stream(st["side"][level])
+            for k, v in lvl.items():
+                if torch.is_tensor(v) and v.data_ptr() != self.kv[slot][level][k].data_ptr():
+                    self.kv[slot][level][k].copy_(v)
+        self.einv[slot].copy_(st["E_inv"])       # E_inv may alias the static input buffer the next frame overwrites
+        self.pose[slot].copy_(self.static_batch["transformation_matrix"])
+        self.rlen[slot].copy_(self.static_batch["record_len"])
+
+    def _s3(self, q):
+        """fusion + decoder of the frame whose images were submitted latency_steps - 1 steps before step q"""
+        feats = self.g[(q - self.lag) % self.depth]
+        if self.world == 1:
+            src = (q - (self.latency_steps - 1)) % self.depth          # written by S1 one graph replay (or more) ago
+            return self.model.fuse_and_decode(feats, self.pose[src], self.rlen[src])
+        return self.model.fuse_and_decode(feats, self.pose_s3[q], self.rlen_s3[q])
+
+    def _exchange(self, q):
+        """after step q: gather f[q] into g[q] on the communication stream (it waits for the step, the next step does not
+        wait for it)"""
+        if self.world > 1:
+            self.comm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm):
+                cdist.exchange_features(self.f[q], self.rank, self.world, self.agents, out=self.g[q])
+                ev = torch.cuda.Event()
+                ev.record(self.comm)
+            self.gathered[q] = ev
+
+    def _await_gather(self, q):
+        """before step q: its fusion stage reads the features gathered after step q - lag"""
+        if self.world > 1:
+            ev = self.gathered[(q - self.lag) % self.depth]
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+
+    def _step_body(self, q):
+        """slot q = step index mod depth: S1 writes kv[q]; the later stages read the slots written 1, 2, .. steps ago"""
+        D = self.depth
+        main = torch.cuda.current_stream()
+        if self.world > 1:        # pose slot q still holds the frame of `depth` steps ago until S1 (below) rewrites it
+            self.pose_s3[q].copy_(self.pose[q])
+            self.rlen_s3[q].copy_(self.rlen[q])
+        for s in self.streams:
+            s.wait_stream(main)
+        nlev = len(self.meta)
+        if D == 3:
+            s2, s3 = self.streams
+            with torch.cuda.stream(s3):
+                out = self._s3(q)
+            with torch.cuda.stream(s2):                                       # frame i-1 -> its features into slot q
+                self.model.fax_query(self._state((q - 1) % D), joined=False, out=self.f[q])
+        else:
+            s2a, s2b, s3 = self.streams
+            with torch.cuda.stream(s3):
+                out = self._s3(q)
+            with torch.cuda.stream(s2b):                                      # frame i-2: K/V from two steps ago, x from one
+                self.model.fax_query(self._state((q - 2) % D), joined=False, levels=(1, nlev), x=self.x[(q - 1) % D],
+                                     out=self.f[q])
+            with torch.cuda.stream(s2a):                                      # frame i-1
+                self.model.fax_query(self._state((q - 1) % D), joined=False, levels=(0, 1), out=self.x[q])
+        self._s1(q)
+        for s in self.streams:
+            main.wait_stream(s)
+        return out
+
+    def capture(self):
+        D = self.depth
+        self.streams = tuple(torch.cuda.Stream() for _ in range(D - 1))
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for it in range(2 * D):
+                self._await_gather(it % D)
+                self._step_body(it % D)
+                self._exchange(it % D)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graphs, self.outs = [], []
+        pool = None
+        for q in range(D):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                self.outs.append(self._step_body(q))
+            pool = g.pool()
+            self.graphs.append(g)
+        self.i = self.filled = 0
+
+    def step(self, batch=None):
+        """submit one frame, complete one frame.  Returns the output dict of the frame submitted latency_steps - 1 calls ago
+        (buffers the same graph overwrites `depth` steps later), or None while the pipeline is still filling."""
+        self.load(batch)
+        q = self.i % self.depth
+        self._await_gather(q)
+        self.graphs[q].replay()
+        self._exchange(q)
+        self.out = self.outs[q]
+        self.i += 1
+        self.filled += 1
+        return self.out if self.filled >= self.latency_steps else None
+
+
+class CapturedCall(object):
+    """`fn(*args)` replayed from one captured HIP graph; the arguments are held in static device buffers (`self.args`,
+    refreshed by `step(*new_args)`), the result tensors are the graph's own output buffers.  Used for the operator-level
+    workloads (LiDAR FuseBEVT `SwapFusionEncoder`, nuScenes SinBEVT) whose forward is a single stage."""
+
+    def __init__(self, fn, *args, use_graph=True, warmup=2):
+        self.fn = fn
+        self.args = tuple(a.clone() if torch.is_tensor(a) else a for a in args)
+        self.out = fn(*self.args)               # builds the weight plans outside the capture
+        torch.cuda.synchronize()
+        self.graph = None
+        if use_graph:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(warmup):
+                    fn(*self.args)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = fn(*self.args)
+
+    def step(self, *args):
+        for dst, src in zip(self.args, args):
+            if torch.is_tensor(dst) and src is not None and src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        if self.graph is None:
+            self.out = self.fn(*self.args)
+        else:
+            self.graph.replay()
+        return self.out

@@ -200,3 +200,25 @@ class SwapFusionEncoder(HipModule):
         """x: (b, m, d, h, w); mask: (b, h, w, 1, m) -> (b, d, h, w)"""
         self._require_inference(x, mask)
         return rt.like_input(rt.nchw_view(self.forward_blhwc(_to_blhwc(x), mask)), x)
+
+
+def sharded_stages(encoder):
+    """The encoder as the stage list cobevt_amd.dist.RowShardedFuseBEVT runs over row-sharded maps: [(mode, fn)] with
+    fn(x (b, l, h_local, W, d) compute dtype, mask (b, h_local, W, 1, l) | None) -> same shape, and head(x) -> (b, h_local, W, d).
+    Window passes see bands of whole windows, grid passes the (i, x_local) re-ordered rows that form whole grid groups -
+    both are plain window / dilated-grid partitions of the LOCAL map, so the kernels are the single-GPU ones."""
+    stages = []
+    for layer in encoder.layers:
+        for ar, fr, mode in layer.stages():
+            def fn(x, mask, ar=ar, fr=fr, mode=mode, use=layer.uses_mask):
+                return _attn_ffd(ar, fr, x.contiguous(), mask if use else None, mode)
+            stages.append((mode, fn))
+
+    def head(x):
+        b, l, h, w, d = x.shape
+        ln = encoder.mlp_head[2]
+        y = ops.mean_layernorm(x.contiguous().reshape(b, l, h * w, d), rt.f32_param(encoder, "head.ln.w", ln.weight),
+                               rt.f32_param(encoder, "head.ln.b", ln.bias), ln.eps)
+        y = ops.linear(y, rt.linear_plan(encoder, "head.fc", encoder.mlp_head[3]))
+        return y.reshape(b, h, w, d)
+    return stages, head

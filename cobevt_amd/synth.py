@@ -216,3 +216,45 @@ def corpbevt_small_compressed_config(ratio=2):
     cfg["fax_fusion"]["input_dim"] = 128
     cfg["fax_fusion"]["mlp_dim"] = 128
     return cfg
+
+
+# ----------------------------------------------------------------------------------------------
+# nuScenes SinBEVT shaped synthetic case (nuscenes/config/model/cvt_pyramid_axial.yaml shapes)
+# ----------------------------------------------------------------------------------------------
+def nuscenes_config():
+    """CrossViewTransformer / PyramidAxialEncoder / Decoder arguments of the shipped cvt_pyramid_axial experiment, with the
+    EfficientNet-B4 feature shapes of 224x480 images."""
+    return dict(
+        b=1, n=6, image=(224, 480),
+        feature_shapes=[(32, 56, 120), (56, 28, 60), (112, 14, 30)],
+        encoder=dict(
+            dim=[32, 64, 128], middle=[2, 2, 2], scale=1.0,
+            self_attn=dict(dim_head=32, dropout=0.1, window_size=25),
+            cross_view=dict(heads=[1, 2, 4], dim_head=[32, 32, 32], qkv_bias=True, skip=True, no_image_features=False,
+                            image_height=224, image_width=480),
+            cross_view_swap=dict(rel_pos_emb=False, q_win_size=[[10, 10], [10, 10], [25, 25]],
+                                 feat_win_size=[[6, 12], [6, 12], [14, 30]], bev_embedding_flag=[True, False, False]),
+            bev_embedding=dict(sigma=1.0, bev_height=200, bev_width=200, h_meters=100.0, w_meters=100.0, offset=0.0,
+                               upsample_scales=[2, 4, 8])),
+        decoder=dict(dim=128, blocks=[128, 128, 64], residual=True, factor=2),
+        dim_last=64, outputs={"bev": [0, 1], "center": [1, 2]})
+
+
+def nuscenes_inputs(key="gv11", seed=0):
+    """(backbone feature maps, image, intrinsics, extrinsics) - nuScenes-like pin-hole cameras every 60 degrees;
+    extrinsics are ego->camera (the encoder inverts them)."""
+    c = nuscenes_config()
+    bn = c["b"] * c["n"]
+    feats = [procedural_input("%s.feature%d" % (key, i), (bn,) + tuple(s), seed) for i, s in enumerate(c["feature_shapes"])]
+    image = procedural_input(key + ".image", (c["b"], c["n"], 3) + tuple(c["image"]), seed, 0.0, 1.0)
+    f = 266.0
+    intr = np.array([[f, 0, c["image"][1] / 2.0], [0, f, c["image"][0] / 2.0], [0, 0, 1]], dtype=np.float64)
+    ext = np.zeros((c["b"], c["n"], 4, 4))
+    for k in range(c["n"]):
+        a = math.radians(60.0 * k)
+        rz = np.array([[math.cos(a), -math.sin(a), 0, 0], [math.sin(a), math.cos(a), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+        t = np.eye(4)
+        t[:3, 3] = (1.5, 0.0, 1.6)
+        ext[:, k] = np.linalg.inv(rz @ t @ _CAM2EGO_AXES)
+    I = np.broadcast_to(intr, (c["b"], c["n"], 3, 3)).copy()
+    return feats, image, torch.from_numpy(I.astype(np.float32)), torch.from_numpy(ext.astype(np.float32))

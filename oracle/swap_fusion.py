@@ -55,32 +55,47 @@ def _ffn(sd, pfx, x):
     return F.linear(y, sd[pfx + "net.3.weight"], sd[pfx + "net.3.bias"])
 
 
+def swap_stage(sd, attn_pfx, ffd_pfx, xl, mask, mode, dim_head, agent_size, window_size):
+    """One half of a block on a channels-last map: PreNormResidual(Attention) + PreNormResidual(FeedForward) over the window
+    (mode 0, :172-179) or dilated-grid (mode 1, :181-190) partition.  xl (b l h w d); mask (b h w 1 l) | None -> (b l h w d)."""
+    w = window_size
+    b, l, h, wd, d = xl.shape
+    X, Y = h // w, wd // w
+    e = mask.shape[3] if mask is not None else 1
+    if mode == 0:       # 'b m d (x w1) (y w2) -> b m x y w1 w2 d' ; mask 'b (x w1) (y w2) e l -> b x y w1 w2 e l'
+        xp = xl.reshape(b, l, X, w, Y, w, d).permute(0, 1, 2, 4, 3, 5, 6)
+        mp = mask.reshape(b, X, w, Y, w, e, l).permute(0, 1, 3, 2, 4, 5, 6) if mask is not None else None
+    else:               # 'b m d (w1 x) (w2 y) -> b m x y w1 w2 d' ; mask 'b (w1 x) (w2 y) e l -> b x y w1 w2 e l'
+        xp = xl.reshape(b, l, w, X, w, Y, d).permute(0, 1, 3, 5, 2, 4, 6)
+        mp = mask.reshape(b, w, X, w, Y, e, l).permute(0, 2, 4, 1, 3, 5, 6) if mask is not None else None
+    xp = swap_attention(sd, attn_pfx + "fn.", _ln(xp, sd, attn_pfx + "norm"), mp, dim_head, agent_size, w) + xp
+    xp = _ffn(sd, ffd_pfx + "fn.", _ln(xp, sd, ffd_pfx + "norm")) + xp
+    if mode == 0:
+        return xp.permute(0, 1, 2, 4, 3, 5, 6).reshape(b, l, h, wd, d)
+    return xp.permute(0, 1, 4, 2, 5, 3, 6).reshape(b, l, h, wd, d)                    # 'b m x y w1 w2 d -> (w1 x) (w2 y)'
+
+
 def swap_fusion_block(sd, names, x, mask, dim_head, agent_size, window_size):
     """SwapFusionBlockMask.forward (:165-192) / SwapFusionBlock (:209-225).  x (b l d h w); mask (b h w 1 l)|None.
     names = key prefixes of (window_attention, window_ffd, grid_attention, grid_ffd) PreNormResidual modules."""
-    w = window_size
-    b, l, d, h, wd = x.shape
-    X, Y = h // w, wd // w
     xl = x.permute(0, 1, 3, 4, 2)                                                     # b l h w d
-    # window partition 'b m d (x w1) (y w2) -> b m x y w1 w2 d'
-    xw = xl.reshape(b, l, X, w, Y, w, d).permute(0, 1, 2, 4, 3, 5, 6)
-    mw = None
-    if mask is not None:  # 'b (x w1) (y w2) e l -> b x y w1 w2 e l'
-        e = mask.shape[3]
-        mw = mask.reshape(b, X, w, Y, w, e, l).permute(0, 1, 3, 2, 4, 5, 6)
-    xw = swap_attention(sd, names[0] + "fn.", _ln(xw, sd, names[0] + "norm"), mw, dim_head, agent_size, w) + xw
-    xw = _ffn(sd, names[1] + "fn.", _ln(xw, sd, names[1] + "norm")) + xw
-    xl = xw.permute(0, 1, 2, 4, 3, 5, 6).reshape(b, l, h, wd, d)                      # reverse
-    # grid partition 'b m d (w1 x) (w2 y) -> b m x y w1 w2 d'
-    xg = xl.reshape(b, l, w, X, w, Y, d).permute(0, 1, 3, 5, 2, 4, 6)
-    mg = None
-    if mask is not None:  # 'b (w1 x) (w2 y) e l -> b x y w1 w2 e l'
-        e = mask.shape[3]
-        mg = mask.reshape(b, w, X, w, Y, e, l).permute(0, 2, 4, 1, 3, 5, 6)
-    xg = swap_attention(sd, names[2] + "fn.", _ln(xg, sd, names[2] + "norm"), mg, dim_head, agent_size, w) + xg
-    xg = _ffn(sd, names[3] + "fn.", _ln(xg, sd, names[3] + "norm")) + xg
-    xl = xg.permute(0, 1, 4, 2, 5, 3, 6).reshape(b, l, h, wd, d)                      # 'b m x y w1 w2 d -> (w1 x) (w2 y)'
+    xl = swap_stage(sd, names[0], names[1], xl, mask, 0, dim_head, agent_size, window_size)
+    xl = swap_stage(sd, names[2], names[3], xl, mask, 1, dim_head, agent_size, window_size)
     return xl.permute(0, 1, 4, 2, 3)
+
+
+def block_names(pfx, i, use_mask):
+    base = "%slayers.%d." % (pfx, i)
+    if use_mask:
+        return [base + "window_attention.", base + "window_ffd.", base + "grid_attention.", base + "grid_ffd."]
+    return [base + "block.1.", base + "block.2.", base + "block.5.", base + "block.6."]
+
+
+def mlp_head(sd, pfx, xl):
+    """mlp_head :275-281 on a channels-last map: mean over agents, LayerNorm, Linear.  xl (b l h w d) -> (b h w d)"""
+    y = xl.mean(dim=1)
+    y = F.layer_norm(y, (y.shape[-1],), sd[pfx + "mlp_head.2.weight"], sd[pfx + "mlp_head.2.bias"], 1e-5)
+    return F.linear(y, sd[pfx + "mlp_head.3.weight"], sd[pfx + "mlp_head.3.bias"])
 
 
 def swap_fusion_encoder(sd, pfx, args, x, mask=None):
