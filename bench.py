@@ -1,23 +1,31 @@
 #!/usr/bin/env python
 """bench.py — BEV frames/s of the MI355X-native CoBEVT hot path on synthetic OPV2V-shaped inputs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--agents 5] [--no-graph]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--agents 5] [--workload camera|lidar]
+                    [--mode throughput|latency] [--frames-in-flight 3|4|1] [--no-graph]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one full CorpBEVT forward per GPU: `agents` x 4 cameras x 512x512 fp32 images (resident in HBM) ->
-ResNet-34 -> FAX pyramid -> [all-gather of agent features] -> STTF -> swap fusion -> decoder -> 256x256 logits.
-N = 1 is the configuration BASELINE.json's metric is quoted on (OPV2V-camera CoBEVT, 5 agents).  For N > 1, N
-frames are in flight per step with the N*agents agent tasks dealt round-robin over the ranks and exchanged by ONE
-RCCL all-gather before fusion (cobevt_amd/dist.py) — per-GPU work is fixed ("weak" scaling) and
-value = N frames / step time.  Rank 0 prints ONE JSON line.
+`--workload camera` (default; the configuration BASELINE.json's metric is quoted on): one "step" = one full CorpBEVT forward
+per GPU: `agents` x 4 cameras x 512x512 fp32 images (resident in HBM) -> ResNet-34 -> FAX pyramid -> [all-gather of agent
+features] -> STTF -> swap fusion -> decoder -> 256x256 logits, through cobevt_amd.host.pipeline (HIP graphs, three frames
+in flight).  N > 1, `--mode throughput` (default, "weak" scaling): N frames per step, the N*agents agent tasks dealt
+round-robin over the ranks and exchanged by ONE RCCL all-gather before fusion; value = N frames / step time.
+`--mode latency` ("strong" scaling): ONE frame per step, rank r encodes agents r, r+N, .., one all-gather, fusion replicated;
+value = 1 frame / step time.
+`--workload lidar` (BASELINE configs[4]): one step = SwapFusionEncoder(64 ch, 8 agents, window 8, depth 3, mask) on
+x (1, 8, 64, 256, 256); N > 1 throughput = one frame per rank (replicas), latency = the map row-sharded over the ranks with
+an all-to-all between the window and grid halves of every block (cobevt_amd/dist.py).
+Rank 0 prints ONE JSON line.  Timing: W warm-up steps, then K steps between barrier + synchronize, MAX over ranks; the per-step
+median / p95 come from HIP events recorded after every step.
 
-Extra legs at N = 1 (rank 0): `roofline` — algorithmic FLOPs / HIP-event time of the dominant kernel family
-(implicit-GEMM) measured live over one frame, plus the FAX attention kernel; `cpu_baseline` — the oracle
-(oracle/, a CPU restatement of the reference, kind "port") timed on the host cores on ONE frame of the same
-workload, which also yields the parity numbers (rel. error of the logits, arg-max agreement, mIoU vs oracle).
+Extra legs at N = 1 (rank 0): `one_frame_at_a_time`, `eager_model_call` (the plain `model(batch)` a drop-in user calls),
+`fp32_parity_mode` (same frame in the exact-fp32 mode), `other_configs` (2-agent OPV2V, nuScenes SinBEVT), `roofline` (+ the
+level-0 FAX attention launch on its own) from HIP-event timings of one eager frame and the committed rocprofv3 PMC summary
+(profiles/pmc_*.json), `cpu_baseline` (the oracle on the host cores, kind "port") and `parity` against it.
 """
 import argparse
 import copy
+import glob
 import json
 import os
 import sys
@@ -31,223 +39,111 @@ if ROOT not in sys.path:
 
 from cobevt_amd import dist as cdist  # noqa: E402
 from cobevt_amd import host, ops, synth  # noqa: E402
+from cobevt_amd.host import pipeline  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic FLOPs per frame (SURVEY.md §8a ledger, de-duplicated query replicas): per agent ResNet-34 x4 cams
 # 153.1 GF + FAX 34.65 GF; per frame fusion 13.12 GF + decoder/head 5.21 GF
 GF_PER_AGENT, GF_PER_FRAME = 153.1 + 34.65, 13.12 + 5.21
+LIDAR_GF = 619.0                                  # SwapFusionEncoder on (1, 8, 64, 256, 256) as implemented
+LIDAR_ARGS = dict(input_dim=64, mlp_dim=128, agent_size=8, window_size=8, dim_head=32, drop_out=0.1, depth=3, mask=True)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)     # SURVEY.md §8d protocol: 50 warm-up, 200 timed, median and p95
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--agents", type=int, default=5)
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
+    ap.add_argument("--workload", default="camera", choices=["camera", "lidar"])
+    ap.add_argument("--mode", default="throughput", choices=["throughput", "latency"],
+                    help="N > 1: throughput = N frames in flight (weak scaling), latency = one frame over N GPUs (strong scaling)")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying captured HIP graphs")
     ap.add_argument("--frames-in-flight", type=int, default=3, choices=[1, 3, 4],
                     help="single-GPU software pipeline: 3 = encoder / FAX query / fusion+decoder of three consecutive frames "
                          "overlap on three HIP streams (throughput mode, default); 1 = one frame at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the eager / fp32 / other-config legs")
     return ap.parse_args()
 
 
-class Runner(object):
-    """Holds static inputs and (optionally) the captured HIP graphs of one step."""
+# ----------------------------------------------------------------------------------------------
+# timing
+# ----------------------------------------------------------------------------------------------
+def timed_loop(step, warmup, steps, world, dev):
+    """W warm-up steps, then exactly K steps between barrier + synchronize; MAX over ranks.  Returns (elapsed seconds,
+    per-step milliseconds from HIP events recorded after each step)."""
+    for _ in range(warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    events = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    events[0].record()
+    for i in range(steps):
+        step()
+        events[i + 1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+    per = sorted(events[i].elapsed_time(events[i + 1]) for i in range(steps))
+    return elapsed, per
 
-    def __init__(self, model, task_batch, pose, record_len, rank, world, agents, use_graph):
-        self.model, self.rank, self.world, self.agents = model, rank, world, agents
-        self.task_batch, self.pose, self.record_len = task_batch, pose, record_len
-        self.use_graph = use_graph
-        self.graphs = None
-        self.out = None
 
-    def _encode(self):
-        return self.model.encode_agents(dict(self.task_batch))
+def pct(sorted_ms, q):
+    return sorted_ms[min(len(sorted_ms) - 1, int(round(q * (len(sorted_ms) - 1))))]
 
-    def _fuse(self, feats):
-        return self.model.fuse_and_decode(feats, self.pose, self.record_len)
 
-    def eager_step(self):
-        feats = self._encode()
-        mine = cdist.exchange_features(feats, self.rank, self.world, self.agents)
-        self.out = self._fuse(mine)
-        return self.out
-
-    def capture(self):
-        """Capture encode and fuse as HIP graphs (the collective stays eager between them)."""
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(2):
-                self.eager_step()
-        torch.cuda.current_stream().wait_stream(s)
+def safe(result, key, fn):
+    """side legs must never cost the main measurement: record the error instead"""
+    try:
+        result[key] = fn()
+    except Exception as e:  # noqa: BLE001
+        result[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         torch.cuda.synchronize()
-        g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
-            feats = self._encode()
-        self.feats = feats
-        if self.world == 1:
-            self.fuse_in = feats
-        else:
-            self.fuse_in = torch.empty_like(feats)
-        g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2):
-            self.out = self._fuse(self.fuse_in)
-        self.graphs = (g1, g2)
-
-    def step(self):
-        if self.graphs is None:
-            return self.eager_step()
-        self.graphs[0].replay()
-        if self.world > 1:
-            cdist.exchange_features(self.feats, self.rank, self.world, self.agents, out=self.fuse_in)
-        self.graphs[1].replay()
-        return self.out
 
 
-class PipelinedRunner(object):
-    """Several frames in flight on ONE GPU.  A CoBEVT frame is ~1.3 ms of camera encoder that fills the chip followed by
-    ~1.4 ms of FAX query path, swap fusion and decoder whose ~100 dependent launches are latency-bound and leave most CUs
-    idle.  Step i therefore runs, on separate HIP streams inside one captured graph,
-        S1  = encoder + K/V sides of the FAX pyramid of frame i          (CorpBEVT.encode_trunk)
-        S2  = FAX query path of frame i-1                                 (CorpBEVT.fax_query)         [depth 3]
-              or S2a = pyramid level 0 of frame i-1 and S2b = levels 1.. + global attention of frame i-2 [depth 4]
-        S3  = STTF + swap fusion + decoder + head of the oldest frame     (CorpBEVT.fuse_and_decode)
-    with the state that crosses steps (projected K/V of the three levels, the level-0 output, the (A,32,32,128)
-    features) in rings of `depth` buffers - `depth` graphs, replayed round-robin.  Every step still takes one frame in and
-    completes one frame; nothing is skipped or cached, the latency of a frame is `depth` steps.  Inputs are the same static
-    tensors every step, so the steady-state output must equal the un-pipelined forward bit for bit (checked by main())."""
-
-    def __init__(self, model, task_batch, pose, record_len, rank=0, world=1, agents=5, depth=3):
-        self.model, self.task_batch, self.pose, self.record_len = model, task_batch, pose, record_len
-        self.rank, self.world, self.agents, self.depth = rank, world, agents, depth
-        self.i = 0
-        D = depth
-        st = model.encode_trunk(dict(task_batch))
-        torch.cuda.synchronize()
-        self.meta = [{k: v for k, v in lvl.items() if not torch.is_tensor(v)} for lvl in st["kv"]]
-        self.batch = st["batch"]
-        self.kv = [[{k: torch.empty_like(v) for k, v in lvl.items() if torch.is_tensor(v)} for lvl in st["kv"]] for _ in range(D)]
-        self.einv = [torch.empty_like(st["E_inv"]) for _ in range(D)]
-        x0 = model.fax_query(st, levels=(0, 1))
-        self.x = [torch.empty_like(x0) for _ in range(D)] if depth == 4 else None
-        feats = model.fax_query(st, levels=(1, len(st["kv"])), x=x0)
-        self.f = [torch.empty_like(feats) for _ in range(D)]
-        # multi-GPU: the frame's agents are gathered (one RCCL all-gather between graph replays) into g; single GPU: g is f
-        self.g = self.f if world == 1 else [torch.empty_like(feats) for _ in range(D)]
-        # multi-GPU: the gather of step q's features runs on its own stream UNDER step q+1 and is consumed by the fusion
-        # stage of step q+2 (one more step of latency than on one GPU), so the collective is off the critical path
-        self.lag = 1 if world == 1 else 2
-        self.comm = torch.cuda.Stream() if world > 1 else None
-        self.gathered = [None] * D
-        self.out = None
-        self.graphs = None
-
-    def _state(self, slot):
-        return {"kv": [dict(self.meta[i], **self.kv[slot][i]) for i in range(len(self.meta))],
-                "E_inv": self.einv[slot], "batch": self.batch}
-
-    def _s1(self, slot):
-        st = self.model.encode_trunk(dict(self.task_batch), kv_out=self.kv[slot])   # K/V land in the slot directly
-        main = torch.cuda.current_stream()
-        for level, lvl in enumerate(st["kv"]):
-            main.wait_stream(st["side"][level])
-            for k, v in lvl.items():
-                if torch.is_tensor(v) and v.data_ptr() != self.kv[slot][level][k].data_ptr():
-                    self.kv[slot][level][k].copy_(v)
-        self.einv[slot].copy_(st["E_inv"])
-
-    def _s3(self, slot_in):
-        return self.model.fuse_and_decode(self.g[slot_in], self.pose, self.record_len)
-
-    def _exchange(self, q):
-        """after step q: gather f[q] into g[q] on the communication stream (it waits for the step, the next step does not
-        wait for it)"""
-        if self.world > 1:
-            self.comm.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.comm):
-                cdist.exchange_features(self.f[q], self.rank, self.world, self.agents, out=self.g[q])
-                ev = torch.cuda.Event()
-                ev.record(self.comm)
-            self.gathered[q] = ev
-
-    def _await_gather(self, q):
-        """before step q: its fusion stage reads the features gathered after step q - lag"""
-        if self.world > 1:
-            ev = self.gathered[(q - self.lag) % self.depth]
-            if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
-
-    def _step_body(self, q):
-        """slot q = step index mod depth: S1 writes kv[q]; the later stages read the slots written 1, 2, .. steps ago"""
-        D = self.depth
-        main = torch.cuda.current_stream()
-        for s in self.streams:
-            s.wait_stream(main)
-        nlev = len(self.meta)
-        if D == 3:
-            s2, s3 = self.streams
-            with torch.cuda.stream(s3):
-                out = self._s3((q - self.lag) % D)                            # features written `lag` steps ago
-            with torch.cuda.stream(s2):
-                self.f[q].copy_(self.model.fax_query(self._state((q - 1) % D), joined=False))
-        else:
-            s2a, s2b, s3 = self.streams
-            with torch.cuda.stream(s3):
-                out = self._s3((q - self.lag) % D)
-            with torch.cuda.stream(s2b):                                      # frame i-2: K/V from two steps ago, x from one
-                self.f[q].copy_(self.model.fax_query(self._state((q - 2) % D), joined=False, levels=(1, nlev),
-                                                     x=self.x[(q - 1) % D]))
-            with torch.cuda.stream(s2a):                                      # frame i-1
-                self.x[q].copy_(self.model.fax_query(self._state((q - 1) % D), joined=False, levels=(0, 1)))
-        self._s1(q)
-        for s in self.streams:
-            main.wait_stream(s)
-        return out
-
-    def capture(self):
-        D = self.depth
-        self.streams = tuple(torch.cuda.Stream() for _ in range(D - 1))
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for it in range(2 * D):
-                self._await_gather(it % D)
-                self._step_body(it % D)
-                self._exchange(it % D)
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        self.graphs, self.outs = [], []
-        pool = None
-        for q in range(D):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
-                self.outs.append(self._step_body(q))
-            pool = g.pool()
-            self.graphs.append(g)
-
-    def step(self):
-        q = self.i % self.depth
-        self._await_gather(q)
-        self.graphs[q].replay()
-        self._exchange(q)
-        self.out = self.outs[q]
-        self.i += 1
-        return self.out
+def quick(step, warmup=3, steps=20):
+    """small timed loop for the side legs -> {ms_median, ms_p95, frames_per_sec (1 / median)}"""
+    _, per = timed_loop(step, warmup, steps, 1, None)
+    med = pct(per, 0.5)
+    return {"ms_median": round(med, 4), "ms_p95": round(pct(per, 0.95), 4), "frames_per_sec": round(1e3 / med, 2), "steps": steps}
 
 
-MFMA_FAMILIES = ("conv3x3", "basicblock", "gemm_rows", "row_chain", "igemm", "attention", "stem7x7")
+# ----------------------------------------------------------------------------------------------
+# roofline leg
+# ----------------------------------------------------------------------------------------------
+MFMA_FAMILIES = ("conv3x3", "basicblock", "bottleneck", "gemm_rows", "row_chain", "igemm", "attention", "stem7x7")
 HBM_BOUND_FAMILIES = ("gemm_rows", "row_chain", "stem7x7")
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s peak (about 6.3 TB/s achievable)
 
 
+def load_pmc(dtype_name):
+    """newest committed rocprofv3 PMC summary (tools/pmc_collect.sh -> tools/pmc_roofline.py), or the round-1 traffic file"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_r*.json")))
+    if files and dtype_name == "bf16":
+        d = json.load(open(files[-1]))
+        return d.get("families", {}), d.get("attention_launches", {}), os.path.basename(files[-1])
+    old = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(old):
+        t = json.load(open(old)).get(dtype_name, {})
+        return {k: {"hbm_bytes": v} for k, v in t.items()}, {}, "pmc_traffic.json"
+    return {}, {}, None
+
+
 def roofline_leg(runner, dtype_name):
     """HIP events (launch stream) around every C-ABI call of one eager frame, best of 3 frames.  Returns the roofline
-    entry of the kernel family with the largest measured time ("dominant kernel") and one entry per other family."""
-    best, best_tot = None, None
+    entry of the kernel family with the largest measured time ("dominant kernel"), one entry per other family, and the
+    level-0 FAX attention launch (the north-star's kernel) on its own."""
+    best, best_tot, best_shapes = None, None, None
     runner.model.overlap_streams = False       # time every launch alone (side-stream K/V work would share the CUs)
     for _ in range(3):
         with ops.LaunchProfile() as prof:
@@ -255,36 +151,48 @@ def roofline_leg(runner, dtype_name):
         summ = prof.summary()
         tot = sum(d["ms"] for d in summ.values())
         if best is None or tot < best_tot:
-            best, best_tot = summ, tot
+            best, best_tot, best_shapes = summ, tot, prof.summary(by_shape=True)
+    runner.model.overlap_streams = True
     peak = PEAK_TFLOPS[dtype_name]
-    traffic = {}
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from rocprofv3 --pmc runs
-    if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get(dtype_name, {})
+    fam_pmc, attn_pmc, pmc_file = load_pmc(dtype_name)
 
-    def entry(fam):
-        d = best[fam]
+    def entry(name, d, pmc, bound=None):
         tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
         gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-        e = {"kernel": fam, "traffic": traffic.get(fam), "launches_per_frame": d["calls"],
+        e = {"kernel": name, "traffic": pmc.get("hbm_bytes"), "mfma_util_pmc": pmc.get("mfma_util"),
+             "launches_per_frame": d["calls"],
              "avg_launch_us": round(d["ms"] * 1e3 / d["calls"], 2), "total_ms_per_frame": round(d["ms"], 3),
              "algorithmic_gflop_per_launch": round(d["flops"] / 1e9 / d["calls"], 2),
              "algorithmic_mbyte_per_launch": round(d["bytes"] / 1e6 / d["calls"], 2),
              "algorithmic_tflop_s": round(tf, 2), "algorithmic_gbyte_s": round(gbs, 1)}
-        if fam in HBM_BOUND_FAMILIES:      # K <= 512 GEMMs / row chains / the image stem: arithmetic intensity below the ridge
+        hbm = (name in HBM_BOUND_FAMILIES) if bound is None else bound == "hbm"
+        if hbm:      # K <= 512 GEMMs / row chains / the image stem: arithmetic intensity below the ridge
             e.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                       "frac": round(gbs / PEAK_HBM_GBS, 4)})
         else:
             e.update({"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)})
         return e
-    runner.model.overlap_streams = True
+
     fams = [f for f in MFMA_FAMILIES if f in best]
     fams.sort(key=lambda f: -best[f]["ms"])
-    return entry(fams[0]), [entry(f) for f in fams[1:]], round(best_tot, 3)
+    dom = entry(fams[0], best[fams[0]], fam_pmc.get(fams[0], {}))
+    dom["pmc_source"] = pmc_file
+    others = [entry(f, best[f], fam_pmc.get(f, {})) for f in fams[1:]]
+    # the largest attention launch = level-0 cross attention #1 (64 windows x 4 cameras x 256 queries x 256 keys per agent)
+    attn = {k: v for k, v in best_shapes.items() if k.startswith("attention|")}
+    fax0 = None
+    if attn:
+        k0 = max(attn, key=lambda k: attn[k]["flops"] / attn[k]["calls"])
+        pm = {}
+        big = [v for kk, v in attn_pmc.items() if v.get("counters_per_launch")]
+        if big:                   # the PMC record with the most MFMA work per launch is the same launch
+            pm = max(big, key=lambda v: v["counters_per_launch"].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0))
+        fax0 = entry("fax_attention_level0 (%s)" % k0.split("|", 1)[1], attn[k0], pm, bound="mfma")
+    return dom, others, fax0, round(best_tot, 3)
 
 
 def cpu_baseline_leg(model, cfg, batch_cpu, gpu_out):
-    """Time the oracle (CPU restatement, parity-pinned to the reference's golden vectors) on one frame and use its
+    """Time the oracle (CPU restatement, parity-pinned to the reference's golden vectors) on the bench frame and use its
     output as the parity reference for the GPU logits."""
     import numpy as np
     import oracle.corpbevt as o_model
@@ -299,16 +207,82 @@ def cpu_baseline_leg(model, cfg, batch_cpu, gpu_out):
         for _ in range(reps):
             ref = o_model.corpbevt_forward(sd, cfg, batch_cpu)["dynamic_seg"]
     dt = (time.time() - t0) / reps
-    got = gpu_out["dynamic_seg"].detach().float().cpu()
-    rel = ((got - ref).abs().max() / ref.abs().max()).item()
-    pa, pr = got.argmax(2).numpy(), ref.argmax(2).numpy()
-    ious = o_model.mean_iu(pa[0, 0], pr[0, 0])
     base = {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "%d frames (%d agents x 4 cams x 512x512 -> 256x256 BEV) of the bench workload, fp32, oracle/ "
                       "(plain PyTorch CPU restatement of the reference forward), %.1f s per frame" % (reps, batch_cpu["inputs"].shape[0], dt)}
-    parity = {"logits_rel_err_vs_oracle": float("%.3e" % rel), "argmax_agreement": round(float((pa == pr).mean()), 5),
-              "miou_vs_oracle_argmax": round(float(np.mean(ious)), 5)}
-    return base, parity
+
+    def parity(out):
+        got = out["dynamic_seg"].detach().float().cpu()
+        rel = ((got - ref).abs().max() / ref.abs().max()).item()
+        pa, pr = got.argmax(2).numpy(), ref.argmax(2).numpy()
+        ious = o_model.mean_iu(pa[0, 0], pr[0, 0])
+        return {"logits_rel_err_vs_oracle": float("%.3e" % rel), "argmax_agreement": round(float((pa == pr).mean()), 5),
+                "miou_vs_oracle_argmax": round(float(np.mean(ious)), 5),
+                "metric": "max|got - ref| / max|ref| over the logits (tests/util.py rel_err), arg-max agreement, mIoU of arg-max maps"}
+    return base, {k: parity(v) for k, v in gpu_out.items()}
+
+
+# ----------------------------------------------------------------------------------------------
+# workloads
+# ----------------------------------------------------------------------------------------------
+def lidar_inputs(dev, seed=0):
+    x = synth.procedural_input("lidar.x", (1, 8, 64, 256, 256), seed).to(dev)
+    mask = torch.ones(1, 256, 256, 1, 8)
+    mask[0, :, :, :, 6:] = 0
+    ii, jj = torch.meshgrid(torch.arange(256), torch.arange(256), indexing="ij")
+    mask[0, :, :, 0, 3] = (jj > ii // 2).float()
+    return x, mask.to(dev)
+
+
+def run_lidar(args, rank, world, dev):
+    enc = synth.fill_module_(host.SwapFusionEncoder(dict(LIDAR_ARGS)), 0).eval().to(dev)
+    x, mask = lidar_inputs(dev, seed=rank)
+    note = "SwapFusionEncoder.forward(x fp32 (1,8,64,256,256), mask) incl. the layout / dtype conversion at the module boundary"
+    if world > 1 and args.mode == "latency":
+        from cobevt_amd.host import swap_fusion_modules as sfm
+        stages, head = sfm.sharded_stages(enc)
+        pipe = cdist.RowShardedFuseBEVT(stages, head, rank, world, LIDAR_ARGS["window_size"])
+        xf, _ = lidar_inputs(dev, seed=0)                      # every rank works on the SAME frame; rank r owns its agents
+        per = 8 // world
+        mine = sfm._to_blhwc(xf[:, rank * per:(rank + 1) * per].contiguous())
+        step = lambda: pipe.step(mine, mask)                   # noqa: E731
+        frames_per_step, scaling = 1, "strong"
+        par = "row-sharded x%d: agent->band all-to-all, band<->grid all-to-all per half block, all-gather of fused bands" % world
+        note = "channels-last compute-dtype agent maps resident on their owner GPU (agent-per-GPU), eager launches"
+    else:
+        run = pipeline.CapturedCall(lambda a, m: enc(a, m), x, mask, use_graph=not args.no_graph)
+        step = run.step
+        frames_per_step, scaling = world, "weak"
+        par = "single GPU" if world == 1 else "replicas x%d (one LiDAR frame per GPU, no collective)" % world
+    elapsed, per_ms = timed_loop(step, args.warmup, args.steps, world, dev)
+    ms = elapsed / args.steps * 1e3
+    fps = frames_per_step / (ms * 1e-3)
+    res = {"metric": "bev_frames_per_sec", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(ms, 4), "ms_per_step_median": round(pct(per_ms, 0.5), 4),
+           "ms_per_step_p95": round(pct(per_ms, 0.95), 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+           "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "OPV2V-LiDAR FuseBEVT: SwapFusionEncoder(input_dim 64, 8 agents, window 8, depth 3, mask) on "
+                                  "voxel-BEV features (1, 8, 64, 256, 256) -> (1, 64, 256, 256)", "parallelism": par,
+                      "hip_graph": not args.no_graph and not (world > 1 and args.mode == "latency"), "timed": note,
+                      "weights": "procedural (cobevt_amd.synth)"},
+           "achieved_tflops_end_to_end": round(LIDAR_GF * frames_per_step / (ms * 1e-3) / 1e3, 2)}
+    if rank == 0 and world == 1 and not args.no_roofline:
+        with ops.LaunchProfile() as prof:
+            enc(x, mask)
+        summ = prof.summary()
+        peak = PEAK_TFLOPS[args.dtype]
+        fams = sorted(summ, key=lambda f: -summ[f]["ms"])
+        ent = []
+        for f in fams:
+            d = summ[f]
+            tf, gbs = d["flops"] / (d["ms"] * 1e-3) / 1e12, d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            hbm = f in HBM_BOUND_FAMILIES
+            ent.append({"kernel": f, "traffic": None, "launches_per_frame": d["calls"], "avg_launch_us": round(d["ms"] * 1e3 / d["calls"], 2),
+                        "bound": "hbm" if hbm else "mfma", "achieved": round(gbs if hbm else tf, 2),
+                        "peak": PEAK_HBM_GBS if hbm else peak, "unit": "GB/s" if hbm else "TFLOP/s",
+                        "frac": round((gbs / PEAK_HBM_GBS) if hbm else (tf / peak), 4)})
+        res["roofline"], res["roofline_other_kernels"] = ent[0], ent[1:]
+    return res
 
 
 def main():
@@ -326,123 +300,160 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     host.set_compute_dtype(dtype)
 
+    if args.workload == "lidar":
+        result = run_lidar(args, rank, world, dev)
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
     A = args.agents
     cfg = synth.corpbevt_config(max_cav=max(5, A))
     model = synth.fill_module_(host.CorpBEVT(copy.deepcopy(cfg)), 0).eval().to(dev)
+    strong = world > 1 and args.mode == "latency"
 
-    # this rank's A agent tasks (images differ per rank), the pose / record_len of frame `rank`
-    full = synth.opv2v_batch(agents=A, max_cav=cfg["max_cav"], seed=rank)
-    task_batch = {k: full[k].to(dev) for k in ("inputs", "intrinsic", "extrinsic")}
-    pose = full["transformation_matrix"].to(dev)
-    record_len = full["record_len"].to(device=dev, dtype=torch.int32)
+    # throughput mode: this rank's A agent tasks (images differ per rank) + the pose / record_len of frame `rank`;
+    # latency mode: every rank sees frame 0 and encodes only its agents
+    full = synth.opv2v_batch(agents=A, max_cav=cfg["max_cav"], seed=0 if strong else rank)
+    batch = {k: v.to(dev) for k, v in full.items()}
+    in_flight, pipeline_note, graph_ok = 1, "none", False
 
-    runner = Runner(model, task_batch, pose, record_len, rank, world, A, not args.no_graph)
-    graph_ok = False
-    ref_out = runner.eager_step()             # builds every weight plan
-    ref_out = {k: v.clone() for k, v in ref_out.items()}
-    torch.cuda.synchronize()
-    if not args.no_graph:
-        try:
-            runner.capture()
-            graph_ok = True
-        except Exception as e:  # noqa: BLE001 — fall back to eager launches, say so in the JSON
-            runner.graphs = None
-            if rank == 0:
-                print("HIP graph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
-            torch.cuda.synchronize()
-    # single-GPU default: three frames in flight (software pipeline over the three stages of a frame)
-    in_flight = args.frames_in_flight
-    timed = runner
-    pipeline_note = "none"
-    if in_flight in (3, 4) and graph_ok:
-        try:
-            timed = PipelinedRunner(model, task_batch, pose, record_len, rank, world, A, depth=in_flight)
-            timed.capture()
-            for _ in range(2 * in_flight):
-                out = timed.step()
-            torch.cuda.synchronize()
-            for k in ref_out:                  # steady state == un-pipelined forward, bit for bit
-                if not torch.equal(out[k], ref_out[k]):
-                    raise RuntimeError("pipelined frame differs from the un-pipelined forward in %r" % k)
-            pipeline_note = ("%s of %d consecutive frames on %d HIP streams in one captured graph; one frame in, one frame "
-                             "out per step; steady-state output checked bit-identical to the un-pipelined forward" %
-                             ("S1 encoder + K/V | S2 FAX query | S3 fusion + decoder" if in_flight == 3 else
-                              "S1 encoder + K/V | S2a FAX level 0 | S2b FAX levels 1-2 + global attention | S3 fusion + decoder",
-                              in_flight, in_flight))
-        except Exception as e:  # noqa: BLE001 — never lose the measurement: fall back to one frame at a time, say so
-            if world == 1:
-                raise
-            timed, in_flight = runner, 1
-            pipeline_note = "pipelined mode failed (%s: %s); one frame at a time" % (type(e).__name__, e)
-            torch.cuda.synchronize()
+    if strong:
+        mine = cdist.agents_of_rank(rank, world, A)
+        sub = dict(cdist.take_agents(batch, mine if mine else [0]), transformation_matrix=batch["transformation_matrix"],
+                   record_len=batch["record_len"])
+        timed = pipeline.FrameShardedCorpBEVT(model, sub, batch, rank, world, A, use_graph=not args.no_graph)
+        graph_ok = timed.graphs is not None
+        runner = timed
+        frames_per_step = 1
     else:
-        in_flight = 1
-    if world > 1:                              # every rank must take the same path
-        flag = torch.tensor([in_flight], device=dev)
-        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-        if int(flag.item()) != in_flight:
-            timed, in_flight = runner, 1
-            pipeline_note = "pipelined mode failed on another rank; one frame at a time"
+        runner = pipeline.CapturedCorpBEVT(model, batch, rank, world, A, use_graph=False)
+        ref_out = {k: v.clone() for k, v in runner.eager_step().items()}
+        torch.cuda.synchronize()
+        if not args.no_graph:
+            try:
+                runner.capture()
+                graph_ok = True
+            except Exception as e:  # noqa: BLE001 — fall back to eager launches, say so in the JSON
+                runner.graphs = None
+                if rank == 0:
+                    print("HIP graph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
+                torch.cuda.synchronize()
+        timed = runner
+        # default: three frames in flight (software pipeline over the three stages of a frame)
+        if args.frames_in_flight in (3, 4) and graph_ok:
+            try:
+                timed = pipeline.PipelinedCorpBEVT(model, batch, rank, world, A, depth=args.frames_in_flight)
+                for _ in range(2 * args.frames_in_flight + 2):
+                    out = timed.step()
+                torch.cuda.synchronize()
+                for k in ref_out:                  # steady state == un-pipelined forward, bit for bit
+                    if not torch.equal(out[k], ref_out[k]):
+                        raise RuntimeError("pipelined frame differs from the un-pipelined forward in %r" % k)
+                in_flight = args.frames_in_flight
+                pipeline_note = ("%s of %d consecutive frames on %d HIP streams in one captured graph; one frame in, one frame "
+                                 "out per step; steady-state output checked bit-identical to the un-pipelined forward" %
+                                 ("S1 encoder + K/V | S2 FAX query | S3 fusion + decoder" if in_flight == 3 else
+                                  "S1 encoder + K/V | S2a FAX level 0 | S2b FAX levels 1-2 + global attention | S3 fusion + decoder",
+                                  in_flight, in_flight))
+            except Exception as e:  # noqa: BLE001 — never lose the measurement: fall back to one frame at a time, say so
+                if world == 1:
+                    raise
+                timed, in_flight = runner, 1
+                pipeline_note = "pipelined mode failed (%s: %s); one frame at a time" % (type(e).__name__, e)
+                torch.cuda.synchronize()
+        if world > 1:                              # every rank must take the same path
+            flag = torch.tensor([in_flight], device=dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            if int(flag.item()) != in_flight:
+                timed, in_flight = runner, 1
+                pipeline_note = "pipelined mode failed on another rank; one frame at a time"
+        frames_per_step = world
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-
-    for _ in range(args.warmup):
-        timed.step()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        timed.step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = t.item()
+    elapsed, per_ms = timed_loop(timed.step, args.warmup, args.steps, world, dev)
     ms_per_step = elapsed / args.steps * 1e3
-    fps = world / (ms_per_step * 1e-3)
+    fps = frames_per_step / (ms_per_step * 1e-3)
 
     result = {
         "metric": "bev_frames_per_sec", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "frames_per_sec_per_gpu": round(fps / world, 3),
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "ms_per_step_median": round(pct(per_ms, 0.5), 4), "ms_per_step_p95": round(pct(per_ms, 0.95), 4),
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype,
+        "data": "synthetic", "frames_per_sec_per_gpu": round(fps / world, 3),
         "config": {"workload": "OPV2V-camera CoBEVT (corpbevt.yaml): %d agents x 4 cams x 512x512 -> 256x256 BEV, "
                                "ResNet-34 + FAX + swap fusion, batch 1 frame per GPU" % A,
-                   "agents": A, "frames_in_flight": world * in_flight,
-                   "frame_latency_steps": in_flight + (1 if (world > 1 and in_flight > 1) else 0),   # + the step the gather hides under
+                   "agents": A, "frames_in_flight": 1 if strong else world * in_flight,
+                   "frame_latency_steps": 1 if strong else getattr(timed, "latency_steps", 1),
                    "pipeline": pipeline_note,
-                   "parallelism": "agent-shard x%d + 1 all-gather" % world if world > 1 else "single GPU",
+                   "parallelism": ("single GPU" if world == 1 else
+                                   "one frame over %d GPUs: rank r encodes agents r, r+%d, ..; 1 all-gather; fusion replicated" % (world, world)
+                                   if strong else "agent-shard x%d + 1 all-gather" % world),
+                   "runner": type(timed).__module__ + "." + type(timed).__name__,
                    "hip_graph": graph_ok, "weights": "procedural (cobevt_amd.synth)"},
-        "achieved_tflops_end_to_end": round((GF_PER_AGENT * A + GF_PER_FRAME) * world / (ms_per_step * 1e-3) / 1e3, 2),
+        "achieved_tflops_end_to_end": round((GF_PER_AGENT * A + GF_PER_FRAME) * frames_per_step / (ms_per_step * 1e-3) / 1e3, 2),
     }
-    if rank == 0 and world == 1 and in_flight > 1:
-        for _ in range(3):
-            runner.step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(10):
-            runner.step()
-        torch.cuda.synchronize()
-        ms1 = (time.perf_counter() - t1) / 10 * 1e3
-        result["one_frame_at_a_time"] = {"ms_per_frame": round(ms1, 4), "frames_per_sec": round(1e3 / ms1, 3),
-                                         "note": "same captured graph path without the cross-frame pipeline = the latency of a frame"}
     if rank == 0 and world == 1:
+        if in_flight > 1:
+            safe(result, "one_frame_at_a_time", lambda: dict(
+                quick(runner.step, 5, 50), note="cobevt_amd.host.pipeline.CapturedCorpBEVT: the same forward from captured graphs "
+                                               "without the cross-frame pipeline = the latency of a frame"))
+        if not args.no_extra:
+            safe(result, "eager_model_call", lambda: dict(
+                quick(lambda: model(dict(batch)), 3, 20), note="plain `model(batch_dict)` as INTEGRATION.md §1 documents it: ~100 "
+                                                                "ctypes launches per frame from Python, no HIP graph"))
         if not args.no_roofline:
-            dom, others, timed_ms = roofline_leg(runner, args.dtype)
-            result["roofline"] = dom
-            result["roofline_other_kernels"] = others
-            result["timed_launch_ms_per_frame"] = timed_ms
+            def roof():
+                dom, others, fax0, timed_ms = roofline_leg(runner, args.dtype)
+                result["roofline_other_kernels"] = others
+                if fax0 is not None:
+                    result["roofline_fax_attention"] = fax0
+                result["timed_launch_ms_per_frame"] = timed_ms
+                return dom
+            safe(result, "roofline", roof)
+        outs = {args.dtype: {k: v.clone() for k, v in runner.eager_step().items()}}
+        if not args.no_extra:
+            other = "fp32" if args.dtype == "bf16" else "bf16"
+
+            def other_dtype():
+                with host.compute_dtype(torch.float32 if other == "fp32" else torch.bfloat16):
+                    r2 = pipeline.CapturedCorpBEVT(model, batch, use_graph=not args.no_graph)
+                    q = dict(quick(r2.step, 2, 10), note="one frame at a time from captured graphs, %s storage + %s MFMA" %
+                             (other, "exact v_mfma_f32_32x32x2_f32" if other == "fp32" else "v_mfma_f32_32x32x16_bf16"))
+                    outs[other] = {k: v.clone() for k, v in r2.step().items()}
+                return q
+            safe(result, "%s_%s" % (other, "parity_mode" if other == "fp32" else "mode"), other_dtype)
+
+            # the other single-GPU configurations of BASELINE.json (parity-tested in tests/; timed here for SURVEY.md §8d)
+            def two_agents():
+                b2 = {k: v.to(dev) for k, v in synth.opv2v_batch(agents=2, max_cav=cfg["max_cav"], seed=0).items()}
+                r3 = pipeline.CapturedCorpBEVT(model, b2, use_graph=not args.no_graph)
+                return dict(quick(r3.step, 3, 30), config="OPV2V-camera CoBEVT: 2 agents x 4 cams 512x512, 256x256 BEV, one frame at "
+                                                           "a time", algorithmic_gflop=round(GF_PER_AGENT * 2 + GF_PER_FRAME, 1))
+
+            def nuscenes():
+                from cobevt_amd.host import nuscenes as nu
+                c = synth.nuscenes_config()
+                feats, image, intr, ext = synth.nuscenes_inputs("bench.nuscenes", 0)
+                encn = nu.PyramidAxialEncoder(nu.FeatureMapBackbone(feats), **copy.deepcopy(c["encoder"]))
+                sin = synth.fill_module_(nu.CrossViewTransformer(encn, nu.Decoder(**c["decoder"]), c["dim_last"], c["outputs"]), 0)
+                sin = sin.eval().to(dev)
+                r4 = pipeline.CapturedCall(lambda im, ii, ee: sin({"image": im, "intrinsics": ii, "extrinsics": ee}),
+                                           image.to(dev), intr.to(dev), ext.to(dev), use_graph=not args.no_graph)
+                return dict(quick(r4.step, 3, 30), config="nuScenes SinBEVT: 1 ego x 6 cams 224x480, 200x200 BEV, FAX encoder + decoder "
+                                                           "on synthetic EfficientNet-B4-shaped backbone features (SURVEY.md §8d)",
+                            algorithmic_gflop=26.2)
+            oc = {}
+            safe(oc, "opv2v_2_agents", two_agents)
+            safe(oc, "nuscenes_sinbevt", nuscenes)
+            result["other_configs"] = oc
         if not args.no_cpu_baseline:
-            out = runner.eager_step()
-            torch.cuda.synchronize()
-            batch_cpu = {k: v for k, v in full.items()}
-            base, parity = cpu_baseline_leg(model, cfg, batch_cpu, out)
+            base, parity = cpu_baseline_leg(model, cfg, dict(full), outs)
             result["cpu_baseline"] = base
-            result["parity"] = parity
+            result["parity"] = parity[args.dtype]
+            for k, v in parity.items():
+                if k != args.dtype:
+                    result["parity_" + k] = v
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

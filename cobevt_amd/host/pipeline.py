@@ -302,3 +302,76 @@ class CapturedCall(object):
         else:
             self.graph.replay()
         return self.out
+
+
+class FrameShardedCorpBEVT(object):
+    """Strong scaling ("latency mode"): ONE frame over `world` GPUs.  Rank r encodes the agents r, r + world, ..
+    of the frame (its sub-batch is `static_sub`), one all-gather hands every rank all agents' (H, W, C) features, and the
+    18-GF STTF + fusion + decoder tail runs replicated on every rank (cheaper than a second exchange).  The two halves are
+    captured HIP graphs with the RCCL all-gather eager between them."""
+
+    latency_steps = 1
+
+    def __init__(self, model, sub_batch, frame_batch, rank, world, agents, use_graph=True):
+        if model.training:
+            raise CobevtHipError("graph runners implement inference: call model.eval() first")
+        dev = next(model.parameters()).device
+        self.model, self.rank, self.world, self.agents = model, rank, world, int(agents)
+        self.mine = cdist.agents_of_rank(rank, world, self.agents)
+        self.static_sub = {k: sub_batch[k].to(dev).clone() for k in _IMAGE_KEYS}
+        self.pose = frame_batch["transformation_matrix"].to(device=dev, dtype=torch.float32).clone()
+        self.rlen = torch.as_tensor(frame_batch["record_len"]).to(device=dev, dtype=torch.int32).clone()
+        self.graphs, self.out = None, None
+        feats = self._encode()                  # also for a surplus rank (one agent): fixes the block shape, builds the plans
+        self.slots = cdist.slots_per_rank(world, self.agents)
+        self.staging = torch.zeros((self.slots,) + tuple(feats.shape[1:]), device=dev, dtype=feats.dtype)
+        self.full = torch.empty((self.agents,) + tuple(feats.shape[1:]), device=dev, dtype=feats.dtype)
+        self.eager_step()
+        torch.cuda.synchronize()
+        if use_graph:
+            self.capture()
+
+    def _encode(self):
+        return self.model.encode_agents(dict(self.static_sub))
+
+    def _exchange(self, feats):
+        n = len(self.mine)
+        return cdist.exchange_features_strong(feats, n, self.rank, self.world, self.agents, out=self.full,
+                                              staging=self.staging)
+
+    def _fuse(self):
+        return self.model.fuse_and_decode(self.full, self.pose, self.rlen)
+
+    def eager_step(self):
+        feats = self._encode() if self.mine else self.staging[:0]
+        self._exchange(feats)
+        self.out = self._fuse()
+        return self.out
+
+    def capture(self):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.eager_step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g1 = None
+        if self.mine:
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self.feats = self._encode()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            self.out = self._fuse()
+        self.graphs = (g1, g2)
+
+    def step(self, batch=None):
+        if self.graphs is None:
+            return self.eager_step()
+        if self.graphs[0] is not None:
+            self.graphs[0].replay()
+            self._exchange(self.feats)
+        else:
+            self._exchange(self.staging[:0])
+        self.graphs[1].replay()
+        return self.out
