@@ -178,18 +178,26 @@ __global__ __launch_bounds__(256) void wce_partial_kernel(const T* logits, const
     }
 }
 
-__global__ __launch_bounds__(256) void wce_final_kernel(const float* partial, float* out, int nparts) {
+// `stride` floats per partial record: 3 = {numerator, denominator, bad-label count} (cross entropy), 2 = {numerator, denominator}
+__global__ __launch_bounds__(256) void wce_final_kernel(const float* partial, float* out, int nparts, int stride) {
     __shared__ float sn[256], sd[256], sb[256];
     const int tid = threadIdx.x;
     float num = 0.f, den = 0.f, bad = 0.f;
-    for (int i = tid; i < nparts; i += 256) { num += partial[3 * i]; den += partial[3 * i + 1]; bad += partial[3 * i + 2]; }
+    for (int i = tid; i < nparts; i += 256) {
+        num += partial[stride * i];
+        den += partial[stride * i + 1];
+        if (stride > 2) bad += partial[stride * i + 2];
+    }
     sn[tid] = num; sd[tid] = den; sb[tid] = bad;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if (tid < s) { sn[tid] += sn[tid + s]; sd[tid] += sd[tid + s]; sb[tid] += sb[tid + s]; }
         __syncthreads();
     }
-    if (tid == 0) { out[0] = sn[0] / sd[0]; out[1] = sn[0]; out[2] = sd[0]; out[3] = sb[0]; }
+    if (tid == 0) {
+        out[0] = sn[0] / sd[0]; out[1] = sn[0]; out[2] = sd[0];
+        if (stride > 2) out[3] = sb[0];
+    }
 }
 
 template <typename T>
@@ -220,7 +228,7 @@ extern "C" int cobevt_weighted_cross_entropy(const void* logits, const long long
     else if (dtype == 1) rc = launch_wce<float>(logits, target, weight, scratch, N, C, hw, per_thread, stream);
     else return COBEVT_ERR_ARG;
     if (rc != COBEVT_OK) return rc;
-    hipLaunchKernelGGL(wce_final_kernel, dim3(1), dim3(256), 0, stream, scratch, out, nparts);
+    hipLaunchKernelGGL(wce_final_kernel, dim3(1), dim3(256), 0, stream, scratch, out, nparts, 3);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
@@ -361,6 +369,6 @@ extern "C" int cobevt_sigmoid_focal_loss(const float* pred, const float* label, 
     const int gx = (hw + 256 * per_thread - 1) / (256 * per_thread);
     hipLaunchKernelGGL(focal_partial_kernel, dim3(gx, N), dim3(256), 0, stream, pred, label, visibility, label_mask, scratch, C, NL, hw,
                        min_visibility, alpha, gamma, soft_label, per_thread);
-    hipLaunchKernelGGL(wce_final_kernel, dim3(1), dim3(256), 0, stream, scratch, out, gx * N);
+    hipLaunchKernelGGL(wce_final_kernel, dim3(1), dim3(256), 0, stream, scratch, out, gx * N, 2);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

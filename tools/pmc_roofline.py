@@ -82,8 +82,6 @@ def main():
             e["launches_sampled"] = s["_dur"][1]
         if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and avg.get("SQ_BUSY_CYCLES"):
             e["mfma_util"] = round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (N_SIMD * avg["SQ_BUSY_CYCLES"] / N_SE), 4)
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and avg.get("GRBM_GUI_ACTIVE"):
-            e["mfma_util_vs_gui_active"] = round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (N_SIMD * avg["GRBM_GUI_ACTIVE"]), 4)
         if avg.get("SQ_INSTS_MFMA") and "SQ_INSTS_VALU" in avg:
             e["valu_per_mfma"] = round(avg["SQ_INSTS_VALU"] / avg["SQ_INSTS_MFMA"], 2)
         if avg.get("SQ_WAVE_CYCLES") and "SQ_ACTIVE_INST_VALU" in avg:
