@@ -19,72 +19,9 @@
 // so lane (q = lane&31, half h) holds 16 of the 32 key scores of its query -> softmax reductions are
 // lane-local plus one xor-32 exchange.  O^T += V^T.P^T uses the score registers directly as the B
 // operand; the key <-> k-slot permutation this implies is applied identically when reading V^T from LDS.
-#include "common.hpp"
+#include "attn_common.hpp"
 
 namespace cobevt {
-
-struct TokMap {
-    int mode;  // 0 window partition, 1 grid partition, 2 rows already stored window-partitioned
-    int ncam;  // cameras / agents concatenated inside a window
-    int HH, WW;
-    int w1, w2;
-    int X, Y;  // windows along H and W (HH == X*w1, WW == Y*w2)
-};
-
-struct TokCoord { int cam, i, j; };
-
-__device__ __forceinline__ TokCoord tok_coord(const TokMap& m, int t) {
-    const int ws = m.w1 * m.w2;
-    TokCoord c;
-    c.cam = t / ws;
-    const int rem = t - c.cam * ws;
-    c.i = rem / m.w2;
-    c.j = rem - c.i * m.w2;
-    return c;
-}
-
-// (ph, pw) pixel of the token in the un-partitioned map; reference fax_modules.py:399-404 (window),
-// :420-424 (grid: 'b n (w1 x) (w2 y) d -> b n x y w1 w2 d')
-__device__ __forceinline__ void tok_pixel(const TokMap& m, int l, const TokCoord& c, int& ph, int& pw) {
-    const int x = l / m.Y, y = l - x * m.Y;
-    if (m.mode == 1) { ph = c.i * m.X + x; pw = c.j * m.Y + y; }
-    else { ph = x * m.w1 + c.i; pw = y * m.w2 + c.j; }
-}
-
-__device__ __forceinline__ size_t tok_row(const TokMap& m, int b, int l, const TokCoord& c) {
-    if (m.mode == 2) {
-        return (((size_t)(b * m.ncam + c.cam) * (m.X * m.Y) + l) * m.w1 + c.i) * m.w2 + c.j;
-    }
-    int ph, pw;
-    tok_pixel(m, l, c, ph, pw);
-    return ((size_t)(b * m.ncam + c.cam) * m.HH + ph) * m.WW + pw;
-}
-
-// Relative-position bias index split into a query term and a key term (the table index is linear in the coordinates):
-//   index = ((dl + L-1)(2 w1 - 1) + (di + w1-1))(2 w2 - 1) + (dj + w2-1),  d = query - key coordinate
-// swap_fusion_modules.py:55-85 (3-D, agent extent L) and fax_modules.py:121-130 (2-D: L = 1, cam = 0).  Integer arithmetic that
-// must be bit-exact: cobevt_attention_bias_index dumps query_term - key_term through these same two functions.
-__device__ __forceinline__ int rel_bias_query_term(const TokMap& km, int bias_L, const TokCoord& qc) {
-    return ((qc.cam + bias_L - 1) * (2 * km.w1 - 1) + qc.i + km.w1 - 1) * (2 * km.w2 - 1) + qc.j + km.w2 - 1;
-}
-__device__ __forceinline__ int rel_bias_key_term(const TokMap& km, const TokCoord& kc) {
-    return (kc.cam * (2 * km.w1 - 1) + kc.i) * (2 * km.w2 - 1) + kc.j;
-}
-
-struct AttnParams {
-    const void* q; const void* k; const void* v; void* out;
-    int ldq, ldk, ldv, ldo;
-    int qoff, koff, voff, ooff;
-    TokMap qmap, kmap, omap;
-    int B, L, heads, Nq, Nk;
-    float scale;
-    int bias_mode;            // 0 none, 1 relative-position table lookup
-    const float* bias_table;  // [rows][heads]
-    int bias_rows;
-    int bias_L;               // agent extent of the 3-D table (1 => 2-D table)
-    const float* mask;        // key mask fp32, 0 => key masked out; (B,HH,WW,ncam), or (B,L,w1,w2,ncam) for mode 2; may be null
-    int mean_q;
-};
 
 constexpr int kKeysPerTile = 64;
 
@@ -441,18 +378,6 @@ __global__ void attn_bias_index_dump_kernel(TokMap qm, TokMap km, int bias_L, in
     }
 }
 
-static bool map_ok(const TokMap& m) {
-    if (m.mode < 0 || m.mode > 2 || m.ncam < 1 || m.w1 < 1 || m.w2 < 1 || m.X < 1 || m.Y < 1) return false;
-    if (m.mode != 2 && (m.HH != m.X * m.w1 || m.WW != m.Y * m.w2)) return false;
-    return m.w1 < 256 && m.w2 < 256 && m.ncam < 32768;
-}
-
-static TokMap read_map(const int* d) {
-    TokMap m;
-    m.mode = d[0]; m.ncam = d[1]; m.HH = d[2]; m.WW = d[3]; m.w1 = d[4]; m.w2 = d[5]; m.X = d[6]; m.Y = d[7];
-    return m;
-}
-
 }  // namespace cobevt
 
 using namespace cobevt;
@@ -465,7 +390,9 @@ extern "C" int cobevt_window_attention(const void* q, const void* k, const void*
     //        mean_q, qmap[8], kmap[8], omap[8]]
     if (!q || !k || !v || !out || !dims) return COBEVT_ERR_ARG;
     AttnParams p;
-    const int dtype = dims[0];
+    // dims[0] = dtype | variant << 8 | query split << 16: variant 0 = automatic (K/V-resident kernel where it applies), 1 = force
+    // the streaming kernel (A/B runs, parity tests of both paths); query split 0 = automatic
+    const int dtype = dims[0] & 0xff, variant = (dims[0] >> 8) & 0xff, qsplit_hint = (dims[0] >> 16) & 0xff;
     p.q = q; p.k = k; p.v = v; p.out = out;
     p.B = dims[1]; p.L = dims[2]; p.heads = dims[3];
     p.ldq = dims[4]; p.ldk = dims[5]; p.ldv = dims[6]; p.ldo = dims[7];
@@ -484,6 +411,10 @@ extern "C" int cobevt_window_attention(const void* q, const void* k, const void*
     p.Nk = p.kmap.ncam * p.kmap.w1 * p.kmap.w2;
     if (p.mean_q && p.qmap.ncam == 1) p.mean_q = 0;
     if (p.mean_q && (p.qmap.ncam > 8 || p.omap.ncam != 1)) return COBEVT_ERR_UNSUPPORTED;
+    if (dtype == 0 && variant != 1) {
+        const int rc = launch_attn_resident(p, qsplit_hint, stream);
+        if (rc >= 0) return rc;
+    }
     const int P = p.qmap.w1 * p.qmap.w2;
     dim3 grid, block;
     if (p.mean_q) { block = dim3(64 * (p.qmap.ncam < 4 ? 4 : p.qmap.ncam)); grid = dim3(p.L * p.heads, (P + 31) / 32, p.B); }

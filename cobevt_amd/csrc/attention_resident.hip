@@ -1,0 +1,418 @@
+// Gathered window / dilated-grid attention with the K / V of one (window, head) RESIDENT in LDS (gfx950, bf16).
+//
+// Same contract as attn_gather_kernel (attention.hip; reference fax_modules.py:211-237,243 / swap_fusion_modules.py:93-123 /
+// fax_modules.py:137-171) for windows of at most 512 keys - every cross attention of FAX levels 0 and 1 and the swap-fusion
+// attentions.  Differences that matter on MI355X:
+//   * a workgroup loads its window's projected K rows and V^T ONCE (key table -> coalesced 16-byte gathers -> LDS), then every
+//     wave walks its query tiles with NO further barrier: the streaming kernel re-staged the same K / V per 32-query tile
+//     through a double buffer with a barrier per 64 keys (2.1x the algorithmic HBM bytes, 36 VALU per MFMA in rocprofv3);
+//   * in "mean" mode (level-0 cross attention: one query copy per camera) a wave runs the cameras of its 32 BEV positions back
+//     to back and keeps z.mean(1) (fax_modules.py:243) in registers - no LDS reduction, no barrier;
+//   * LDS images are XOR-swizzled instead of padded, so K rows are 64 B and V^T rows Nk * 2 B (32 KB for 256 keys: 4 workgroups
+//     per CU); every ds_read_b128 is conflict free and all its addressing is an immediate offset from a per-lane base;
+//   * V^T keeps the 16 keys of an MFMA k-block in the order the score registers hold them (bits 2 and 3 of the key index
+//     swapped), so one ds_read_b128 feeds one PV MFMA straight from the packed P registers;
+//   * online softmax with a deferred rescale (the running maximum only moves when a tile exceeds it by more than 2^8), row
+//     maxima by v_max3 + one v_permlane32_swap.
+// MFMA mapping as in attention.hip: S^T = K.Q^T (lane = query), O^T += V^T.P^T.
+#include "attn_common.hpp"
+
+namespace cobevt {
+
+namespace {
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kDeferLog2 = 8.0f;      // P <= 2^8 between rescales: exact in fp32 accumulators, bf16 keeps its relative precision
+
+__device__ __forceinline__ int perm16(int k) {   // swap bits 2 and 3: key order inside a 16-key MFMA k-block
+    return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1);
+}
+
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// a single v_add_f32 the SLP vectoriser cannot fuse into v_pk_add_f32 (packed fp32 VALU issues slower beside MFMAs on gfx950,
+// MI355X_MICROARCH.md "price of one filler")
+__device__ __forceinline__ float add1(float a, float b) {
+    float d;
+    asm("v_add_f32_e32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// max / sum across the two half-waves (lane ^ 32) without LDS: v_permlane32_swap exchanges the upper half of the first
+// operand with the lower half of the second, so {r0, r1} = {own, partner} in one order or the other on every lane
+__device__ __forceinline__ float xor32_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <int NT> struct ResLds {
+    static constexpr int kNkp = NT * 64;
+    static constexpr int kVRow = kNkp * 2;
+    static constexpr int kKBytes = kNkp * 64;
+    static constexpr int kVBytes = 32 * kVRow;
+};
+
+// NT: 64-key tiles (keys padded to NT * 64; NT even so a V^T row is a whole number of 256-byte swizzle groups)
+// NW: waves per workgroup.  MEAN: per-camera queries averaged (mean_q).  BIAS / MASK as in attn_gather_kernel.
+// RAGGED: Nk is not a multiple of 128 and there is no per-key metadata (BIAS / MASK) to carry the padding: the padded keys are
+// taken out of the softmax by a compare + select per score (a template parameter: as a run-time branch the compiler turns it
+// into 64 always-executed compare / select pairs per tile).
+template <int NT, int NW, bool MEAN, bool BIAS, bool MASK, bool RAGGED>
+__global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p, int qsplit) {
+    using L = ResLds<NT>;
+    constexpr int NKP = L::kNkp;
+    constexpr int NTHR = NW * 64;
+    constexpr bool INFO = BIAS || MASK;
+    constexpr int NITEM = NKP * 4 / NTHR;              // staging items per thread (K: 16-byte chunks; V: key pair x dh quad)
+    static_assert(NKP * 4 % NTHR == 0 && NITEM >= 1, "tile / workgroup shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ks = smem;
+    unsigned char* Vts = smem + L::kKBytes;
+    int* ktab = (int*)(smem + L::kKBytes + L::kVBytes);    // [NKP] row of key tk, -1 = padding
+    int* kinfo = ktab + NKP;                                // [NKP] (INFO) key term of the bias index, -1 = masked / padding
+    const int P = p.qmap.w1 * p.qmap.w2;
+    const int NQ = MEAN ? P : p.Nq;                         // table entries: mean mode keeps camera 0 and strides over cameras
+    int* qtab = kinfo + (INFO ? NKP : 0);                   // [NQ] row of query token
+    int* otab = qtab + NQ;                                  // [NQ] row of its output
+    int* qbias = otab + NQ;                                 // [NQ] (BIAS) query term of the bias index
+    float* bias_col = (float*)(qbias + (BIAS ? NQ : 0));    // [bias_rows] this head's table column, base-2 domain
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, ql = lane & 31;
+    const int b = blockIdx.y;
+    // grid.x = qsplit x (windows * heads), query split OUTER: the workgroups sharing a (window, head) are L * heads apart in
+    // dispatch order = on the same XCD for the usual multiple-of-8 counts, so its L2 serves their common K / V
+    const int LH = p.L * p.heads;
+    const int qs = blockIdx.x / LH, lh = blockIdx.x - qs * LH;
+    const int l = lh / p.heads, head = lh - l * p.heads;
+
+    // ---- tables (one token -> row computation per thread instead of one per staging item / per task)
+    for (int tk = tid; tk < NKP; tk += NTHR) {
+        int row = -1, info = -1;
+        if (tk < p.Nk) {
+            const TokCoord kc = tok_coord(p.kmap, tk);
+            row = (int)tok_row(p.kmap, b, l, kc);
+            if (INFO) {
+                bool valid = true;
+                if (MASK) {
+                    if (p.kmap.mode == 2) {
+                        valid = p.mask[((((size_t)b * p.L + l) * p.kmap.w1 + kc.i) * p.kmap.w2 + kc.j) * p.kmap.ncam + kc.cam] != 0.f;
+                    } else {
+                        int ph, pw;
+                        tok_pixel(p.kmap, l, kc, ph, pw);
+                        valid = p.mask[(((size_t)b * p.kmap.HH + ph) * p.kmap.WW + pw) * p.kmap.ncam + kc.cam] != 0.f;
+                    }
+                }
+                if (valid) info = BIAS ? rel_bias_key_term(p.kmap, kc) : 0;
+            }
+        }
+        ktab[tk] = row;
+        if (INFO) kinfo[tk] = info;
+    }
+    for (int t = tid; t < NQ; t += NTHR) {
+        const TokCoord qc = tok_coord(p.qmap, t);           // mean mode: t < P -> camera 0
+        qtab[t] = (int)tok_row(p.qmap, b, l, qc);
+        otab[t] = (int)tok_row(p.omap, b, l, qc);
+        if (BIAS) qbias[t] = rel_bias_query_term(p.kmap, p.bias_L, qc);
+    }
+    if (BIAS) {
+        constexpr int BI = 8;
+        for (int base = 0; base < p.bias_rows; base += NTHR * BI) {
+            float tv[BI];
+#pragma unroll
+            for (int u = 0; u < BI; ++u) {
+                const int i = base + u * NTHR + tid;
+                tv[u] = p.bias_table[(size_t)(i < p.bias_rows ? i : p.bias_rows - 1) * p.heads + head];
+            }
+#pragma unroll
+            for (int u = 0; u < BI; ++u) {
+                const int i = base + u * NTHR + tid;
+                if (i < p.bias_rows) bias_col[i] = tv[u] * kLog2e;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- stage K (rows, 16-byte chunks XOR-swizzled by (key >> 2) & 3) and V^T (dh rows, 16-byte chunks XOR-swizzled by dh & 15)
+    {
+        const bf16_t* kbase = (const bf16_t*)p.k + p.koff + head * 32;
+        const bf16_t* vbase = (const bf16_t*)p.v + p.voff + head * 32;
+        uint4 kreg[NITEM];
+        uint2 v0[NITEM], v1[NITEM];
+#pragma unroll
+        for (int it = 0; it < NITEM; ++it) {
+            const int item = tid + it * NTHR;
+            const int kk = item >> 2, cj = item & 3;
+            const int row = ktab[kk];
+            kreg[it] = row >= 0 ? *(const uint4*)(kbase + (size_t)row * p.ldk + cj * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < NITEM; ++it) {
+            const int item = tid + it * NTHR;
+            const int kp = item >> 3, dq = item & 7;
+            const int r0 = ktab[2 * kp], r1 = ktab[2 * kp + 1];
+            v0[it] = r0 >= 0 ? *(const uint2*)(vbase + (size_t)r0 * p.ldv + dq * 4) : make_uint2(0, 0);
+            v1[it] = r1 >= 0 ? *(const uint2*)(vbase + (size_t)r1 * p.ldv + dq * 4) : make_uint2(0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < NITEM; ++it) {
+            const int item = tid + it * NTHR;
+            const int kk = item >> 2, cj = item & 3;
+            *(uint4*)(Ks + kk * 64 + ((cj ^ ((kk >> 2) & 3)) << 4)) = kreg[it];
+        }
+#pragma unroll
+        for (int it = 0; it < NITEM; ++it) {
+            const int item = tid + it * NTHR;
+            const int kp = item >> 3, dq = item & 7;
+            const int pos = ((2 * kp) & ~15) | perm16((2 * kp) & 15);     // even key of the pair; its partner sits at pos + 1
+            const uint32_t a[2] = {v0[it].x, v0[it].y}, c[2] = {v1[it].x, v1[it].y};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int dh = dq * 4 + e;
+                const uint32_t lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xffffu, hi = (c[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+                *(uint32_t*)(Vts + dh * L::kVRow + ((((pos >> 3) ^ (dh & 15))) << 4) + (pos & 7) * 2) = lo | (hi << 16);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- per-lane LDS read bases (everything else is an immediate offset)
+    const uint32_t kx = (ql >> 2) & 3;
+    const unsigned char* kptr0 = Ks + ql * 64 + ((h ^ kx) << 4);           // k-group 0: chunk h
+    const unsigned char* kptr1 = Ks + ql * 64 + (((2 + h) ^ kx) << 4);     // k-group 1: chunk 2 + h
+    const uint32_t vlow = (uint32_t)(ql & 15) << 4;                          // swizzle term, pre-shifted
+    const unsigned char* vrow = Vts + ql * L::kVRow;                         // multiple of 256 B: the low byte is free for the XOR
+    const float sl2 = p.scale * kLog2e;
+
+    const int ntiles = (NQ + 31) >> 5;                  // 32-query tiles (mean mode: position tiles)
+    const int ncam = MEAN ? p.qmap.ncam : 1;
+    const size_t qcam_stride = MEAN ? (p.qmap.mode == 2 ? (size_t)p.L * P : (size_t)p.qmap.HH * p.qmap.WW) : 0;
+    const bf16_t* qbase = (const bf16_t*)p.q + p.qoff + head * 32 + h * 8;
+    const float inv_ncam = 1.0f / (float)ncam;
+
+    for (int tile = qs + qsplit * wave; tile < ntiles; tile += qsplit * NW) {
+        const int t = tile * 32 + ql;
+        const bool q_ok = t < NQ;
+        const int tq = q_ok ? t : 0;
+        const size_t qrow0 = (size_t)(unsigned)qtab[tq];
+        const int bias_q = BIAS ? qbias[tq] : 0;
+        f32x16 osum;
+        if (MEAN) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) osum[r] = 0.f;
+        }
+        uint4 qf[2];
+        {
+            const bf16_t* qrow = qbase + qrow0 * p.ldq;
+            qf[0] = q_ok ? *(const uint4*)(qrow) : make_uint4(0, 0, 0, 0);
+            qf[1] = q_ok ? *(const uint4*)(qrow + 16) : make_uint4(0, 0, 0, 0);
+        }
+        f32x16 ot;
+        for (int cam = 0; cam < ncam; ++cam) {
+            uint4 qn[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+            if (MEAN && cam + 1 < ncam && q_ok) {          // next camera's query rows: in flight under this camera's tiles
+                const bf16_t* qrow = qbase + (qrow0 + (size_t)(cam + 1) * qcam_stride) * p.ldq;
+                qn[0] = *(const uint4*)(qrow);
+                qn[1] = *(const uint4*)(qrow + 16);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+            float m_run = -INFINITY, l_run = 0.f;
+            // two 64-key tiles per iteration: inside a pair every LDS address is a per-lane base + an immediate (the V^T swizzle
+            // flips with the tile parity); rolled over the pairs, so the register footprint does not grow with the window size
+#pragma unroll 1
+            for (int kp2 = 0; kp2 < NT / 2; ++kp2) {
+                const unsigned char* kp0 = kptr0 + kp2 * (128 * 64);
+                const unsigned char* kp1 = kptr1 + kp2 * (128 * 64);
+                const unsigned char* vp = vrow + kp2 * 256;
+#pragma unroll
+                for (int par = 0; par < 2; ++par) {
+                    const int key0 = kp2 * 128 + par * 64;      // first key of this tile
+                    // ---- S^T = K . Q^T for the two 32-key sub-tiles
+                    f32x16 st[2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) st[s][r] = 0.f;
+                        const int off = (par * 64 + s * 32) * 64;
+                        const uint4 a0 = *(const uint4*)(kp0 + off);
+                        const uint4 a1 = *(const uint4*)(kp1 + off);
+                        mfma_kgroup<bf16_t>(a0, qf[0], st[s]);
+                        mfma_kgroup<bf16_t>(a1, qf[1], st[s]);
+                    }
+                    // ---- V^T fragments of this tile (issued early: they only depend on the tile index)
+                    uint4 va[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {            // j = s * 2 + u: keys key0 + s*32 + u*16 .. +15, this half's 8 slots
+                        const uint32_t lowc = (uint32_t)(par * 8 + j * 2) << 4;      // chunk within the 256-byte group (+ h)
+                        va[j] = *(const uint4*)(vp + ((lowc | ((uint32_t)h << 4)) ^ vlow));
+                    }
+                    // ---- scores -> base-2 logits, tile maximum
+                    float mloc;
+                    if (INFO) {
+                        mloc = -INFINITY;
+                        const int* ki = kinfo + key0 + 4 * h;
+#pragma unroll
+                        for (int s = 0; s < 2; ++s)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int info = ki[s * 32 + (r & 3) + 8 * (r >> 2)];
+                                float v;
+                                if (BIAS) v = fmaf(st[s][r], sl2, bias_col[info < 0 ? 0 : bias_q - info]);
+                                else v = st[s][r] * sl2;
+                                v = info < 0 ? -INFINITY : v;
+                                st[s][r] = v;
+                                mloc = fmaxf(mloc, v);
+                            }
+                    } else {
+                        if (RAGGED) {                           // padded keys out of the softmax
+                            const int nv = p.Nk - key0 - 4 * h;
+#pragma unroll
+                            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r)
+                                    if (s * 32 + (r & 3) + 8 * (r >> 2) >= nv) st[s][r] = -INFINITY;
+                        }
+                        float m0 = max3(st[0][0], st[0][1], st[0][2]), m1 = max3(st[1][0], st[1][1], st[1][2]);
+#pragma unroll
+                        for (int r = 3; r < 15; r += 2) {
+                            m0 = max3(m0, st[0][r], st[0][r + 1]);
+                            m1 = max3(m1, st[1][r], st[1][r + 1]);
+                        }
+                        mloc = max3(m0, m1, fmaxf(st[0][15], st[1][15])) * sl2;   // scale > 0: max commutes with the scaling
+                    }
+                    const float mtile = xor32_max(mloc);
+                    // deferred rescale: keep the running maximum while no query of the wave exceeds it by more than 2^kDeferLog2
+                    if (!__all(mtile <= m_run + kDeferLog2)) {
+                        const float m_new = fmaxf(m_run, mtile);
+                        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+                        const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);       // first tile: exp2(-inf) = 0
+                        m_run = m_new;
+                        l_run *= alpha;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ot[r] *= alpha;
+                    }
+                    const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
+                    float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float e = INFO ? __builtin_amdgcn_exp2f(st[s][r] - m_use)
+                                                 : __builtin_amdgcn_exp2f(fmaf(st[s][r], sl2, -m_use));
+                            st[s][r] = e;
+                            if (r & 1) ps1 = add1(ps1, e); else ps0 = add1(ps0, e);
+                        }
+                    l_run += ps0 + ps1;
+                    // ---- O^T += V^T . P^T
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            uint4 pb;
+                            pb.x = pack_bf2(st[s][8 * u + 0], st[s][8 * u + 1]);
+                            pb.y = pack_bf2(st[s][8 * u + 2], st[s][8 * u + 3]);
+                            pb.z = pack_bf2(st[s][8 * u + 4], st[s][8 * u + 5]);
+                            pb.w = pack_bf2(st[s][8 * u + 6], st[s][8 * u + 7]);
+                            mfma_kgroup<bf16_t>(va[s * 2 + u], pb, ot);
+                        }
+                }
+            }
+            const float inv = 1.0f / xor32_sum(l_run);     // an all-masked row yields NaN like the reference softmax
+            if (MEAN) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) osum[r] = fmaf(ot[r], inv, osum[r]);
+                qf[0] = qn[0];
+                qf[1] = qn[1];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[r] *= inv;
+            }
+        }
+        if (MEAN) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[r] = osum[r] * inv_ncam;
+        }
+        if (q_ok) {
+            bf16_t* orow = (bf16_t*)p.out + (size_t)(unsigned)otab[tq] * p.ldo + p.ooff + head * 32;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint2 w;
+                w.x = pack_bf2(ot[4 * g4 + 0], ot[4 * g4 + 1]);
+                w.y = pack_bf2(ot[4 * g4 + 2], ot[4 * g4 + 3]);
+                *(uint2*)(orow + 8 * g4 + 4 * h) = w;
+            }
+        }
+    }
+}
+
+template <int NT, int NW>
+int launch_nt(const AttnParams& p, int qsplit, size_t lds, dim3 grid, hipStream_t stream) {
+    const bool hb = p.bias_mode != 0, hm = p.mask != nullptr, mean = p.mean_q != 0;
+    const bool ragged = p.Nk != NT * 64;
+#define COBEVT_RES_LAUNCH(M, B, K, R) \
+    hipLaunchKernelGGL((attn_resident_kernel<NT, NW, M, B, K, R>), grid, dim3(NW * 64), lds, stream, p, qsplit)
+    if (mean) {
+        if (hb || hm) return -1;                       // the camera mean only occurs in the plain cross attention
+        if (ragged) COBEVT_RES_LAUNCH(true, false, false, true);
+        else COBEVT_RES_LAUNCH(true, false, false, false);
+    } else if (hb && hm) COBEVT_RES_LAUNCH(false, true, true, false);
+    else if (hb) COBEVT_RES_LAUNCH(false, true, false, false);
+    else if (hm) COBEVT_RES_LAUNCH(false, false, true, false);
+    else if (ragged) COBEVT_RES_LAUNCH(false, false, false, true);
+    else COBEVT_RES_LAUNCH(false, false, false, false);
+#undef COBEVT_RES_LAUNCH
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+}  // namespace
+
+int launch_attn_resident(const AttnParams& p, int qsplit_hint, hipStream_t stream) {
+    if (p.Nk < 65 || p.Nk > 512) return -1;            // <= 64 keys: one streaming tile is already optimal; > 512: LDS
+    const int nt = ((p.Nk + 127) / 128) * 2;           // 64-key tiles, even
+    const int P = p.qmap.w1 * p.qmap.w2;
+    const bool mean = p.mean_q != 0;
+    if (!mean && p.omap.ncam != p.qmap.ncam) return -1;
+    if (mean && p.omap.ncam != 1) return -1;
+    const int NQ = mean ? P : p.Nq;
+    const bool info = p.bias_mode != 0 || p.mask != nullptr;
+    size_t lds = (size_t)nt * 64 * 128 + (size_t)nt * 64 * 4 * (info ? 2 : 1) + (size_t)NQ * 4 * (p.bias_mode ? 3 : 2);
+    if (p.bias_mode) lds += ((size_t)p.bias_rows * 4 + 15) & ~(size_t)15;
+    lds = (lds + 15) & ~(size_t)15;
+    if (lds > 160 * 1024) return -1;
+    if ((long)p.B * p.qmap.ncam * (p.qmap.mode == 2 ? (long)p.L * P : (long)p.qmap.HH * p.qmap.WW) >= 0x7fffffffL) return -1;
+    const int ntiles = (NQ + 31) / 32;
+    // waves per workgroup: 8 when the LDS footprint leaves room for one or two workgroups per CU only and the window has the
+    // query tiles to feed them (LiDAR FuseBEVT: 512 tokens per window)
+    const int nw = (lds > 40 * 1024 && ntiles >= 16) ? 8 : 4;
+    // query split: enough workgroups to fill 256 CUs x (4 | 2 | 1 resident workgroups), every wave keeping >= 1 tile
+    int qsplit = qsplit_hint;
+    if (qsplit <= 0) {
+        const long base = (long)p.B * p.L * p.heads;
+        const int resident = lds > 80 * 1024 ? 1 : (lds > 40 * 1024 ? 2 : 4);
+        qsplit = 1;
+        while (base * qsplit < 256L * resident && ntiles >= 2 * qsplit * nw) qsplit *= 2;
+        if (base * qsplit < 256L && ntiles >= 2 * qsplit * nw - nw) qsplit *= 2;     // fewer workgroups than CUs: one tile per wave
+    }
+    if (qsplit > ntiles) qsplit = ntiles;
+    if (qsplit < 1) qsplit = 1;
+    dim3 grid(p.L * p.heads * qsplit, p.B);
+    if (grid.y > 65535) return -1;
+    switch (nt * 10 + nw) {
+        case 24: return launch_nt<2, 4>(p, qsplit, lds, grid, stream);
+        case 44: return launch_nt<4, 4>(p, qsplit, lds, grid, stream);
+        case 64: return launch_nt<6, 4>(p, qsplit, lds, grid, stream);
+        case 84: return launch_nt<8, 4>(p, qsplit, lds, grid, stream);
+        case 28: return launch_nt<2, 8>(p, qsplit, lds, grid, stream);
+        case 48: return launch_nt<4, 8>(p, qsplit, lds, grid, stream);
+        case 68: return launch_nt<6, 8>(p, qsplit, lds, grid, stream);
+        case 88: return launch_nt<8, 8>(p, qsplit, lds, grid, stream);
+        default: return -1;
+    }
+}
+
+}  // namespace cobevt

@@ -1,0 +1,88 @@
+// Shared declarations of the gathered-attention kernels (attention.hip: streaming K/V tiles; attention_resident.hip: the
+// K / V of a window held in LDS for all of its query tiles): token maps = the einops window / grid partitions as index
+// arithmetic, the relative-position index split, the kernel parameter block.
+#pragma once
+#include "common.hpp"
+
+namespace cobevt {
+
+struct TokMap {
+    int mode;  // 0 window partition, 1 grid partition, 2 rows already stored window-partitioned
+    int ncam;  // cameras / agents concatenated inside a window
+    int HH, WW;
+    int w1, w2;
+    int X, Y;  // windows along H and W (HH == X*w1, WW == Y*w2)
+};
+
+struct TokCoord { int cam, i, j; };
+
+__device__ __forceinline__ TokCoord tok_coord(const TokMap& m, int t) {
+    const int ws = m.w1 * m.w2;
+    TokCoord c;
+    c.cam = t / ws;
+    const int rem = t - c.cam * ws;
+    c.i = rem / m.w2;
+    c.j = rem - c.i * m.w2;
+    return c;
+}
+
+// (ph, pw) pixel of the token in the un-partitioned map; reference fax_modules.py:399-404 (window),
+// :420-424 (grid: 'b n (w1 x) (w2 y) d -> b n x y w1 w2 d')
+__device__ __forceinline__ void tok_pixel(const TokMap& m, int l, const TokCoord& c, int& ph, int& pw) {
+    const int x = l / m.Y, y = l - x * m.Y;
+    if (m.mode == 1) { ph = c.i * m.X + x; pw = c.j * m.Y + y; }
+    else { ph = x * m.w1 + c.i; pw = y * m.w2 + c.j; }
+}
+
+__device__ __forceinline__ size_t tok_row(const TokMap& m, int b, int l, const TokCoord& c) {
+    if (m.mode == 2) {
+        return (((size_t)(b * m.ncam + c.cam) * (m.X * m.Y) + l) * m.w1 + c.i) * m.w2 + c.j;
+    }
+    int ph, pw;
+    tok_pixel(m, l, c, ph, pw);
+    return ((size_t)(b * m.ncam + c.cam) * m.HH + ph) * m.WW + pw;
+}
+
+// Relative-position bias index split into a query term and a key term (the table index is linear in the coordinates):
+//   index = ((dl + L-1)(2 w1 - 1) + (di + w1-1))(2 w2 - 1) + (dj + w2-1),  d = query - key coordinate
+// swap_fusion_modules.py:55-85 (3-D, agent extent L) and fax_modules.py:121-130 (2-D: L = 1, cam = 0).  Integer arithmetic that
+// must be bit-exact: cobevt_attention_bias_index dumps query_term - key_term through these same two functions.
+__device__ __forceinline__ int rel_bias_query_term(const TokMap& km, int bias_L, const TokCoord& qc) {
+    return ((qc.cam + bias_L - 1) * (2 * km.w1 - 1) + qc.i + km.w1 - 1) * (2 * km.w2 - 1) + qc.j + km.w2 - 1;
+}
+__device__ __forceinline__ int rel_bias_key_term(const TokMap& km, const TokCoord& kc) {
+    return (kc.cam * (2 * km.w1 - 1) + kc.i) * (2 * km.w2 - 1) + kc.j;
+}
+
+struct AttnParams {
+    const void* q; const void* k; const void* v; void* out;
+    int ldq, ldk, ldv, ldo;
+    int qoff, koff, voff, ooff;
+    TokMap qmap, kmap, omap;
+    int B, L, heads, Nq, Nk;
+    float scale;
+    int bias_mode;            // 0 none, 1 relative-position table lookup
+    const float* bias_table;  // [rows][heads]
+    int bias_rows;
+    int bias_L;               // agent extent of the 3-D table (1 => 2-D table)
+    const float* mask;        // key mask fp32, 0 => key masked out; (B,HH,WW,ncam), or (B,L,w1,w2,ncam) for mode 2; may be null
+    int mean_q;
+};
+
+static inline bool map_ok(const TokMap& m) {
+    if (m.mode < 0 || m.mode > 2 || m.ncam < 1 || m.w1 < 1 || m.w2 < 1 || m.X < 1 || m.Y < 1) return false;
+    if (m.mode != 2 && (m.HH != m.X * m.w1 || m.WW != m.Y * m.w2)) return false;
+    return m.w1 < 256 && m.w2 < 256 && m.ncam < 32768;
+}
+
+static inline TokMap read_map(const int* d) {
+    TokMap m;
+    m.mode = d[0]; m.ncam = d[1]; m.HH = d[2]; m.WW = d[3]; m.w1 = d[4]; m.w2 = d[5]; m.X = d[6]; m.Y = d[7];
+    return m;
+}
+
+// attention_resident.hip: launches the K/V-resident kernel when the problem qualifies; returns COBEVT_OK, an error code, or
+// -1 when it does not apply (the caller then uses the streaming kernel).  hint: 0 auto, >0 = query split to use
+int launch_attn_resident(const AttnParams& p, int qsplit_hint, hipStream_t stream);
+
+}  // namespace cobevt

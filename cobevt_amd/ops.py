@@ -39,6 +39,8 @@ USE_EMBED_GEMM3 = False   # the BEV query produced inside the 32-row GEMM that p
 # measured SLOWER on MI355X (119 vs 92 us on the level-0 shape, 361 vs 364 frames/s): the producer's 64 LDS
 # coefficient reads + ~400 VALU per thread cost more than the 170 MB of HBM traffic they save; kept for parity tests
 USE_CHAIN_NEXT = True  # ... and let the row-local GEMM that consumes its output next ride in the same launch
+ATTN_VARIANT = 0    # 0 = automatic (K/V-resident attention kernel where it applies), 1 = always the streaming kernel (A/B runs)
+ATTN_QSPLIT = 0     # 0 = automatic query split of the resident attention kernel; > 0 pins it (tools/attn_probe.py)
 
 
 def dcode(dtype):
@@ -55,7 +57,7 @@ def _apply_env_flags():
         if "=" in item:
             k, v = item.split("=", 1)
             k = k.strip()
-            if k not in globals() or not (k.startswith("USE_") or k in ("CONV3_VARIANT", "BASICBLOCK_TILE_ROWS", "ROW_CHAIN_ROWS", "GEMM_ROWS3_MIN_M", "GEMM_ROWS3_MAX_K", "GEMM_ROWS3_STRIDED", "GEMM_ROWS3_ROWS64_MIN_M")):
+            if k not in globals() or not (k.startswith("USE_") or k in ("CONV3_VARIANT", "BASICBLOCK_TILE_ROWS", "ROW_CHAIN_ROWS", "GEMM_ROWS3_MIN_M", "GEMM_ROWS3_MAX_K", "GEMM_ROWS3_STRIDED", "GEMM_ROWS3_ROWS64_MIN_M", "ATTN_VARIANT", "ATTN_QSPLIT")):
                 raise CobevtHipError("COBEVT_FLAGS: unknown switch %r" % k)
             globals()[k] = int(v) if not k.startswith("USE_") else bool(int(v))
 
@@ -513,9 +515,10 @@ def tokmap(mode, ncam, hh, ww, w1, w2):
 
 
 def window_attention(q, k, v, out, qmap, kmap, omap, batch, heads, scale, ldq, ldk, ldv, ldo, qoff=0, koff=0, voff=0,
-                     ooff=0, bias_table=None, bias_L=1, mask=None, mean_q=False):
+                     ooff=0, bias_table=None, bias_L=1, mask=None, mean_q=False, variant=None, qsplit=None):
     _need_cuda(q, k, v, out, bias_table, mask)
-    code = dcode(q.dtype)
+    code = dcode(q.dtype) | ((ATTN_VARIANT if variant is None else int(variant)) << 8) | \
+        ((ATTN_QSPLIT if qsplit is None else int(qsplit)) << 16)
     if k.dtype != q.dtype or v.dtype != q.dtype or out.dtype != q.dtype:
         raise CobevtHipError("window_attention: q/k/v/out dtypes differ")
     L = qmap[6] * qmap[7]

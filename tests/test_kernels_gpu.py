@@ -563,10 +563,11 @@ def test_attention_index_maps_bit_exact_on_gpu(cuda):
                        torch.from_numpy(o_swap.relative_position_index_3d(8, 8)).to(torch.int32))
 
 
+@pytest.mark.parametrize("variant", [0, 1])          # 0 = K/V-resident kernel (bf16, 216 keys padded to 256), 1 = streaming
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("kmode", [0, 1])
 @pytest.mark.parametrize("mean_q", [True, False])
-def test_cross_window_attention(cuda, dtype, kmode, mean_q):
+def test_cross_window_attention(cuda, dtype, kmode, mean_q, variant):
     B, n, heads, dh = 2, 3, 4, 32
     d = heads * dh
     H = W = 8
@@ -582,7 +583,7 @@ def test_cross_window_attention(cuda, dtype, kmode, mean_q):
     qmap = ops.tokmap(0, nq, H, W, W1, W2)
     kmap = ops.tokmap(kmode, n, h, w, w1, w2)
     omap = ops.tokmap(0, 1, H, W, W1, W2)
-    ops.window_attention(qd, kd, vd, out, qmap, kmap, omap, B, heads, scale, d, d, d, d, mean_q=mean_q)
+    ops.window_attention(qd, kd, vd, out, qmap, kmap, omap, B, heads, scale, d, d, d, d, mean_q=mean_q, variant=variant)
     torch.cuda.synchronize()
     # reference through the oracle's partitions
     qp = o_fax._window_partition(rnd(q, dtype), W1, W2)                     # b nq X Y W1 W2 d
@@ -658,6 +659,85 @@ def test_swap_attention_bias_mask(cuda, dtype, mode):
     else:
         ref = o.permute(0, 1, 4, 2, 5, 3, 6).reshape(B, L, H, W, d)
     check(out, ref, dtype, "swap attention mode=%d" % mode)
+
+
+@pytest.mark.parametrize("qsplit", [0, 1, 2, 4])
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("L,w,H,use_mask", [(5, 8, 16, True), (8, 8, 16, True), (2, 8, 24, False), (3, 8, 16, True)])
+def test_resident_attention_bias_mask(cuda, L, w, H, use_mask, mode, qsplit):
+    """K/V-resident kernel with the 3-D relative-position bias (+ key mask) on swap-fusion shapes: 320 keys (the 5-agent
+    fusion), 512 keys (LiDAR: 8 waves per workgroup), 128 and 192 keys (padded), every query split - against the fp32 torch
+    computation AND the streaming kernel (same bf16 operands: equal to rounding)."""
+    B, heads, dh = 2, 2, 32
+    d = heads * dh
+    W = H
+    dtype = torch.bfloat16
+    qkv = procedural_input("rsw.qkv", (B, L, H, W, 3 * d), L)
+    table = procedural_input("rsw.table", ((2 * L - 1) * (2 * w - 1) ** 2, heads), L)
+    mask = torch.ones(B, H, W, 1, L)
+    mask[1, :, :, :, L - 1] = 0
+    mask[0, :3, :, :, 1] = 0
+    mask[0, :, W - 5:, :, L - 1] = 0
+    outs = [torch.empty((B, L, H, W, d), device=cuda, dtype=dtype) for _ in range(2)]
+    m = ops.tokmap(mode, L, H, W, w, w)
+    qd = qkv.to(cuda).to(dtype)
+    mk = mask.to(cuda).contiguous() if use_mask else None
+    for o, variant in zip(outs, (0, 1)):
+        ops.window_attention(qd, qd, qd, o, m, m, m, B, heads, dh ** -0.5, 3 * d, 3 * d, 3 * d, d, qoff=0, koff=d,
+                             voff=2 * d, bias_table=table.to(cuda), bias_L=L, mask=mk, variant=variant, qsplit=qsplit)
+    torch.cuda.synchronize()
+    x = rnd(qkv, dtype)
+    X = Y = H // w
+    part = (lambda t: t.reshape(B, L, X, w, Y, w, -1).permute(0, 1, 2, 4, 3, 5, 6)) if mode == 0 else \
+           (lambda t: t.reshape(B, L, w, X, w, Y, -1).permute(0, 1, 3, 5, 2, 4, 6))
+    t = part(x).permute(0, 2, 3, 1, 4, 5, 6).reshape(B * X * Y, L * w * w, 3 * d)
+    qf, kf, vf = [z.reshape(B * X * Y, L * w * w, heads, dh).permute(0, 2, 1, 3) for z in t.chunk(3, -1)]
+    bias = table[torch.from_numpy(o_swap.relative_position_index_3d(L, w))].permute(2, 0, 1)
+    sc = torch.matmul(qf, kf.transpose(-1, -2)) * dh ** -0.5 + bias
+    if use_mask:
+        mp = mask.reshape(B, X, w, Y, w, 1, L).permute(0, 1, 3, 2, 4, 5, 6) if mode == 0 else \
+            mask.reshape(B, w, X, w, Y, 1, L).permute(0, 2, 4, 1, 3, 5, 6)
+        mk_ = mp.permute(0, 1, 2, 5, 6, 3, 4).reshape(B * X * Y, 1, L * w * w)
+        sc = sc.masked_fill(mk_.unsqueeze(1) == 0, -float("inf"))
+    o = torch.matmul(sc.softmax(-1), vf).permute(0, 2, 1, 3).reshape(B, X, Y, L, w, w, d).permute(0, 3, 1, 2, 4, 5, 6)
+    ref = o.permute(0, 1, 2, 4, 3, 5, 6).reshape(B, L, H, W, d) if mode == 0 else o.permute(0, 1, 4, 2, 5, 3, 6).reshape(B, L, H, W, d)
+    check(outs[0], ref, dtype, "resident swap attention L=%d mode=%d qsplit=%d" % (L, mode, qsplit))
+    check(outs[1], ref, dtype, "streaming swap attention L=%d mode=%d" % (L, mode))
+    assert (outs[0].float() - outs[1].float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("nq_cams,mean", [(4, True), (1, False)])
+def test_resident_attention_level0_shape_and_outlier_keys(cuda, nq_cams, mean):
+    """The level-0 launch shape of the bench (256 queries x 4 cameras x 256 keys per window) at reduced batch, with score
+    outliers that force the deferred softmax rescale both ways: a key tile whose scores exceed the running maximum by far more
+    than the 2^8 threshold late in the window, and one early; against the fp32 torch result."""
+    B, n, heads, dh = 1, 4, 4, 32
+    d = heads * dh
+    H = W = 32
+    W1 = W2 = 16
+    h = w = 16
+    w1 = w2 = 8
+    q = procedural_input("l0.q", (B, nq_cams, H, W, d), 0)
+    k = procedural_input("l0.k", (B, n, h, w, d), 0)
+    v = procedural_input("l0.v", (B, n, h, w, d), 0)
+    k[0, 3, 5, 3] *= 60.0          # camera 3 = the last key tile of its window: a late spike
+    k[0, 0, 9, 9] *= 45.0          # camera 0 = the first key tile: an early spike
+    scale = dh ** -0.5
+    dtype = torch.bfloat16
+    qd, kd, vd = [t.to(cuda).to(dtype) for t in (q, k, v)]
+    out = torch.empty((B, H, W, d), device=cuda, dtype=dtype)
+    qmap, kmap, omap = ops.tokmap(0, nq_cams, H, W, W1, W2), ops.tokmap(0, n, h, w, w1, w2), ops.tokmap(0, 1, H, W, W1, W2)
+    ops.window_attention(qd, kd, vd, out, qmap, kmap, omap, B, heads, scale, d, d, d, d, mean_q=mean, variant=0)
+    torch.cuda.synchronize()
+    qp = o_fax._window_partition(rnd(q, dtype), W1, W2)
+    kp, vp = o_fax._window_partition(rnd(k, dtype), w1, w2), o_fax._window_partition(rnd(v, dtype), w1, w2)
+    X, Y = H // W1, W // W2
+    qf = qp.permute(0, 2, 3, 1, 4, 5, 6).reshape(B, X * Y, nq_cams * W1 * W2, heads, dh).permute(0, 3, 1, 2, 4)
+    kf = kp.permute(0, 2, 3, 1, 4, 5, 6).reshape(B, X * Y, n * w1 * w2, heads, dh).permute(0, 3, 1, 2, 4)
+    vf = vp.permute(0, 2, 3, 1, 4, 5, 6).reshape(B, X * Y, n * w1 * w2, heads, dh).permute(0, 3, 1, 2, 4)
+    a = torch.matmul((torch.matmul(qf, kf.transpose(-1, -2)) * scale).softmax(-1), vf)
+    a = a.permute(0, 2, 3, 1, 4).reshape(B, X, Y, nq_cams, W1, W2, d).mean(3)
+    check(out, o_fax._window_reverse(a), dtype, "level-0 resident attention with outlier keys")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
