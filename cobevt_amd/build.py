@@ -12,6 +12,10 @@ LIB = os.path.join(CSRC, "libcobevt_hip.so")
 SOURCES = ["igemm.hip", "conv3x3.hip", "basicblock.hip", "gemm_rows.hip", "gemm_rows3.hip", "row_chain.hip", "stem7x7.hip", "attention.hip", "attention_resident.hip", "elementwise.hip", "postprocess.hip", "depthwise.hip"]
 HEADERS = ["common.hpp", "attn_common.hpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"]
+# per-source extras.  attention_resident.hip: no SLP vectorisation - hipcc otherwise packs the softmax's independent fp32 adds /
+# multiplies into v_pk_add_f32 / v_pk_mul_f32, which issue slower than two plain VALU ops beside MFMAs on gfx950
+# (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+EXTRA_FLAGS = {"attention_resident.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -38,7 +42,7 @@ def build(force=False, verbose=True):
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -30,14 +30,6 @@ __device__ __forceinline__ int perm16(int k) {   // swap bits 2 and 3: key order
 
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
-// a single v_add_f32 the SLP vectoriser cannot fuse into v_pk_add_f32 (packed fp32 VALU issues slower beside MFMAs on gfx950,
-// MI355X_MICROARCH.md "price of one filler")
-__device__ __forceinline__ float add1(float a, float b) {
-    float d;
-    asm("v_add_f32_e32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-
 // max / sum across the two half-waves (lane ^ 32) without LDS: v_permlane32_swap exchanges the upper half of the first
 // operand with the lower half of the second, so {r0, r1} = {own, partner} in one order or the other on every lane
 __device__ __forceinline__ float xor32_max(float v) {
@@ -88,7 +80,17 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
     // dispatch order = on the same XCD for the usual multiple-of-8 counts, so its L2 serves their common K / V
     const int LH = p.L * p.heads;
     const int qs = blockIdx.x / LH, lh = blockIdx.x - qs * LH;
-    const int l = lh / p.heads, head = lh - l * p.heads;
+    // ... and the heads of one window too (they read the same 128-byte lines of the K / V / Q rows: a row holds all heads):
+    // workgroup lh -> (window, head) such that the heads of a window are 8 apart in dispatch order (8 XCDs, round-robin)
+    int l, head;
+    if ((p.L & 7) == 0) {
+        const int grp = lh / (8 * p.heads), within = lh - grp * (8 * p.heads);
+        head = within >> 3;
+        l = grp * 8 + (within & 7);
+    } else {
+        l = lh / p.heads;
+        head = lh - l * p.heads;
+    }
 
     // ---- tables (one token -> row computation per thread instead of one per staging item / per task)
     for (int tk = tid; tk < NKP; tk += NTHR) {
@@ -147,16 +149,21 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
         for (int it = 0; it < NITEM; ++it) {
             const int item = tid + it * NTHR;
             const int kk = item >> 2, cj = item & 3;
+            // unconditional loads from a clamped row, zeroed afterwards: a load under a branch makes hipcc wait for it inside the
+            // branch (vmcnt(0) per load = one serialised HBM round trip per staging item)
             const int row = ktab[kk];
-            kreg[it] = row >= 0 ? *(const uint4*)(kbase + (size_t)row * p.ldk + cj * 8) : make_uint4(0, 0, 0, 0);
+            const uint4 kv = *(const uint4*)(kbase + (size_t)(row < 0 ? 0 : row) * p.ldk + cj * 8);
+            kreg[it] = row >= 0 ? kv : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int it = 0; it < NITEM; ++it) {
             const int item = tid + it * NTHR;
             const int kp = item >> 3, dq = item & 7;
             const int r0 = ktab[2 * kp], r1 = ktab[2 * kp + 1];
-            v0[it] = r0 >= 0 ? *(const uint2*)(vbase + (size_t)r0 * p.ldv + dq * 4) : make_uint2(0, 0);
-            v1[it] = r1 >= 0 ? *(const uint2*)(vbase + (size_t)r1 * p.ldv + dq * 4) : make_uint2(0, 0);
+            const uint2 a0 = *(const uint2*)(vbase + (size_t)(r0 < 0 ? 0 : r0) * p.ldv + dq * 4);
+            const uint2 a1 = *(const uint2*)(vbase + (size_t)(r1 < 0 ? 0 : r1) * p.ldv + dq * 4);
+            v0[it] = r0 >= 0 ? a0 : make_uint2(0, 0);
+            v1[it] = r1 >= 0 ? a1 : make_uint2(0, 0);
         }
 #pragma unroll
         for (int it = 0; it < NITEM; ++it) {
@@ -208,14 +215,15 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
         uint4 qf[2];
         {
             const bf16_t* qrow = qbase + qrow0 * p.ldq;
-            qf[0] = q_ok ? *(const uint4*)(qrow) : make_uint4(0, 0, 0, 0);
-            qf[1] = q_ok ? *(const uint4*)(qrow + 16) : make_uint4(0, 0, 0, 0);
+            qf[0] = *(const uint4*)(qrow);                 // tq is clamped: rows of lanes past the end are loaded but never stored
+            qf[1] = *(const uint4*)(qrow + 16);
         }
         f32x16 ot;
         for (int cam = 0; cam < ncam; ++cam) {
-            uint4 qn[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-            if (MEAN && cam + 1 < ncam && q_ok) {          // next camera's query rows: in flight under this camera's tiles
-                const bf16_t* qrow = qbase + (qrow0 + (size_t)(cam + 1) * qcam_stride) * p.ldq;
+            uint4 qn[2];
+            if (MEAN) {            // next camera's query rows (clamped, unconditional): in flight under this camera's tiles
+                const int cn = cam + 1 < ncam ? cam + 1 : cam;
+                const bf16_t* qrow = qbase + (qrow0 + (size_t)cn * qcam_stride) * p.ldq;
                 qn[0] = *(const uint4*)(qrow);
                 qn[1] = *(const uint4*)(qrow + 16);
             }
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
                             const float e = INFO ? __builtin_amdgcn_exp2f(st[s][r] - m_use)
                                                  : __builtin_amdgcn_exp2f(fmaf(st[s][r], sl2, -m_use));
                             st[s][r] = e;
-                            if (r & 1) ps1 = add1(ps1, e); else ps0 = add1(ps0, e);
+                            if (r & 1) ps1 += e; else ps0 += e;
                         }
                     l_run += ps0 + ps1;
                     // ---- O^T += V^T . P^T
