@@ -65,10 +65,11 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
     unsigned char* Ks = smem;
     unsigned char* Vts = smem + L::kKBytes;
     int* ktab = (int*)(smem + L::kKBytes + L::kVBytes);    // [NKP] row of key tk, -1 = padding
-    int* kinfo = ktab + NKP;                                // [NKP] (INFO) key term of the bias index, -1 = masked / padding
+    float* kmadd = (float*)(ktab + NKP);                    // [NKP] (INFO) additive key mask: 0, or -inf for masked / padded keys
+    int* kinfo4 = (int*)(kmadd + (INFO ? NKP : 0));         // [NKP] (BIAS) 4 x the key term of the bias index (a byte offset)
     const int P = p.qmap.w1 * p.qmap.w2;
     const int NQ = MEAN ? P : p.Nq;                         // table entries: mean mode keeps camera 0 and strides over cameras
-    int* qtab = kinfo + (INFO ? NKP : 0);                   // [NQ] row of query token
+    int* qtab = kinfo4 + (BIAS ? NKP : 0);                  // [NQ] row of query token
     int* otab = qtab + NQ;                                  // [NQ] row of its output
     int* qbias = otab + NQ;                                 // [NQ] (BIAS) query term of the bias index
     float* bias_col = (float*)(qbias + (BIAS ? NQ : 0));    // [bias_rows] this head's table column, base-2 domain
@@ -94,12 +95,13 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
 
     // ---- tables (one token -> row computation per thread instead of one per staging item / per task)
     for (int tk = tid; tk < NKP; tk += NTHR) {
-        int row = -1, info = -1;
+        int row = -1, info = 0;
+        bool valid = false;
         if (tk < p.Nk) {
             const TokCoord kc = tok_coord(p.kmap, tk);
             row = (int)tok_row(p.kmap, b, l, kc);
+            valid = true;
             if (INFO) {
-                bool valid = true;
                 if (MASK) {
                     if (p.kmap.mode == 2) {
                         valid = p.mask[((((size_t)b * p.L + l) * p.kmap.w1 + kc.i) * p.kmap.w2 + kc.j) * p.kmap.ncam + kc.cam] != 0.f;
@@ -109,11 +111,12 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
                         valid = p.mask[(((size_t)b * p.kmap.HH + ph) * p.kmap.WW + pw) * p.kmap.ncam + kc.cam] != 0.f;
                     }
                 }
-                if (valid) info = BIAS ? rel_bias_key_term(p.kmap, kc) : 0;
+                if (BIAS) info = 4 * rel_bias_key_term(p.kmap, kc);     // also for masked keys: the lookup stays in range
             }
         }
         ktab[tk] = row;
-        if (INFO) kinfo[tk] = info;
+        if (INFO) kmadd[tk] = valid ? 0.f : -INFINITY;
+        if (BIAS) kinfo4[tk] = info;
     }
     for (int t = tid; t < NQ; t += NTHR) {
         const TokCoord qc = tok_coord(p.qmap, t);           // mean mode: t < P -> camera 0
@@ -206,7 +209,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
         const bool q_ok = t < NQ;
         const int tq = q_ok ? t : 0;
         const size_t qrow0 = (size_t)(unsigned)qtab[tq];
-        const int bias_q = BIAS ? qbias[tq] : 0;
+        // byte address (in LDS) of bias_col[query term]: the gather address of a score is this minus the key's 4 x key term
+        const uint32_t bias_q4 = BIAS ? (uint32_t)((const unsigned char*)bias_col - smem) + 4u * (uint32_t)qbias[tq] : 0u;
         f32x16 osum;
         if (MEAN) {
 #pragma unroll
@@ -262,20 +266,36 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
                     // ---- scores -> base-2 logits, tile maximum
                     float mloc;
                     if (INFO) {
-                        mloc = -INFINITY;
-                        const int* ki = kinfo + key0 + 4 * h;
+                        // per-key metadata of this lane's 16 keys per sub-tile: 4 x 16-byte reads each (keys 8g + 4h .. + 3)
 #pragma unroll
-                        for (int s = 0; s < 2; ++s)
+                        for (int s = 0; s < 2; ++s) {
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int info = ki[s * 32 + (r & 3) + 8 * (r >> 2)];
-                                float v;
-                                if (BIAS) v = fmaf(st[s][r], sl2, bias_col[info < 0 ? 0 : bias_q - info]);
-                                else v = st[s][r] * sl2;
-                                v = info < 0 ? -INFINITY : v;
-                                st[s][r] = v;
-                                mloc = fmaxf(mloc, v);
+                            for (int g = 0; g < 4; ++g) {
+                                const int kb = key0 + s * 32 + 8 * g + 4 * h;
+                                const f32x4 ma = *(const f32x4*)(kmadd + kb);
+                                f32x4 v;
+                                if (BIAS) {
+                                    const uint4 ki = *(const uint4*)(kinfo4 + kb);
+                                    const float b0 = *(const float*)(smem + (bias_q4 - ki.x)), b1 = *(const float*)(smem + (bias_q4 - ki.y));
+                                    const float b2 = *(const float*)(smem + (bias_q4 - ki.z)), b3 = *(const float*)(smem + (bias_q4 - ki.w));
+                                    const f32x2 sl22 = {sl2, sl2};
+                                    const f32x2 lo = __builtin_elementwise_fma(f32x2{st[s][4 * g], st[s][4 * g + 1]}, sl22, f32x2{b0, b1});
+                                    const f32x2 hi = __builtin_elementwise_fma(f32x2{st[s][4 * g + 2], st[s][4 * g + 3]}, sl22, f32x2{b2, b3});
+                                    v = f32x4{lo.x, lo.y, hi.x, hi.y} + ma;
+                                } else {
+                                    const f32x4 sl24 = {sl2, sl2, sl2, sl2};
+                                    v = __builtin_elementwise_fma(f32x4{st[s][4 * g], st[s][4 * g + 1], st[s][4 * g + 2], st[s][4 * g + 3]}, sl24, ma);
+                                }
+                                st[s][4 * g] = v.x; st[s][4 * g + 1] = v.y; st[s][4 * g + 2] = v.z; st[s][4 * g + 3] = v.w;
                             }
+                        }
+                        float m0 = max3(st[0][0], st[0][1], st[0][2]), m1 = max3(st[1][0], st[1][1], st[1][2]);
+#pragma unroll
+                        for (int r = 3; r < 15; r += 2) {
+                            m0 = max3(m0, st[0][r], st[0][r + 1]);
+                            m1 = max3(m1, st[1][r], st[1][r + 1]);
+                        }
+                        mloc = max3(m0, m1, fmaxf(st[0][15], st[1][15]));
                     } else {
                         if (RAGGED) {                           // padded keys out of the softmax
                             const int nv = p.Nk - key0 - 4 * h;
@@ -301,21 +321,28 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
                         const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);       // first tile: exp2(-inf) = 0
                         m_run = m_new;
                         l_run *= alpha;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) ot[r] *= alpha;
+                        ot *= alpha;                                   // v_pk_mul_f32 x 8
                     }
+                    // The kernel is VALU-bound (rocprofv3: 4 cycles per plain VALU wave-instruction, ~8 per v_exp_f32; 8 MFMAs = 256
+                    // cycles per tile against > 800 cycles of softmax arithmetic), so everything that has a packed form runs on
+                    // register PAIRS: v_pk_fma_f32 for scale - max, v_pk_add_f32 for the row sums (2 values per lane per issue)
                     const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
-                    float ps0 = 0.f, ps1 = 0.f;
+                    const f32x2 nm2 = {-m_use, -m_use}, sl22 = {sl2, sl2};
+                    f32x2 psv = {0.f, 0.f};
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float e = INFO ? __builtin_amdgcn_exp2f(st[s][r] - m_use)
-                                                 : __builtin_amdgcn_exp2f(fmaf(st[s][r], sl2, -m_use));
-                            st[s][r] = e;
-                            if (r & 1) ps1 += e; else ps0 += e;
+                        for (int r = 0; r < 16; r += 2) {
+                            f32x2 x = {st[s][r], st[s][r + 1]};
+                            x = INFO ? x + nm2 : __builtin_elementwise_fma(x, sl22, nm2);
+                            f32x2 e;
+                            e.x = __builtin_amdgcn_exp2f(x.x);
+                            e.y = __builtin_amdgcn_exp2f(x.y);
+                            st[s][r] = e.x;
+                            st[s][r + 1] = e.y;
+                            psv += e;
                         }
-                    l_run += ps0 + ps1;
+                    l_run += psv.x + psv.y;
                     // ---- O^T += V^T . P^T
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
@@ -332,19 +359,14 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
             }
             const float inv = 1.0f / xor32_sum(l_run);     // an all-masked row yields NaN like the reference softmax
             if (MEAN) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) osum[r] = fmaf(ot[r], inv, osum[r]);
+                osum += ot * inv;                              // v_pk_fma_f32 x 8
                 qf[0] = qn[0];
                 qf[1] = qn[1];
             } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ot[r] *= inv;
+                ot *= inv;
             }
         }
-        if (MEAN) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ot[r] = osum[r] * inv_ncam;
-        }
+        if (MEAN) ot = osum * inv_ncam;
         if (q_ok) {
             bf16_t* orow = (bf16_t*)p.out + (size_t)(unsigned)otab[tq] * p.ldo + p.ooff + head * 32;
 #pragma unroll
@@ -388,7 +410,8 @@ int launch_attn_resident(const AttnParams& p, int qsplit_hint, hipStream_t strea
     if (mean && p.omap.ncam != 1) return -1;
     const int NQ = mean ? P : p.Nq;
     const bool info = p.bias_mode != 0 || p.mask != nullptr;
-    size_t lds = (size_t)nt * 64 * 128 + (size_t)nt * 64 * 4 * (info ? 2 : 1) + (size_t)NQ * 4 * (p.bias_mode ? 3 : 2);
+    size_t lds = (size_t)nt * 64 * 128 + (size_t)nt * 64 * 4 * (1 + (info ? 1 : 0) + (p.bias_mode ? 1 : 0)) +
+                 (size_t)NQ * 4 * (p.bias_mode ? 3 : 2);
     if (p.bias_mode) lds += ((size_t)p.bias_rows * 4 + 15) & ~(size_t)15;
     lds = (lds + 15) & ~(size_t)15;
     if (lds > 160 * 1024) return -1;
