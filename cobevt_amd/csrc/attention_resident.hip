@@ -209,8 +209,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
         const bool q_ok = t < NQ;
         const int tq = q_ok ? t : 0;
         const size_t qrow0 = (size_t)(unsigned)qtab[tq];
-        // byte address (in LDS) of bias_col[query term]: the gather address of a score is this minus the key's 4 x key term
-        const uint32_t bias_q4 = BIAS ? (uint32_t)((const unsigned char*)bias_col - smem) + 4u * (uint32_t)qbias[tq] : 0u;
+        // LDS address of bias_col[query term]: the gather address of a score is this minus the key's 4 x key term (one v_sub)
+        const unsigned char* bias_qp = (const unsigned char*)bias_col + (BIAS ? 4 * qbias[tq] : 0);
         f32x16 osum;
         if (MEAN) {
 #pragma unroll
@@ -276,8 +276,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
                                 f32x4 v;
                                 if (BIAS) {
                                     const uint4 ki = *(const uint4*)(kinfo4 + kb);
-                                    const float b0 = *(const float*)(smem + (bias_q4 - ki.x)), b1 = *(const float*)(smem + (bias_q4 - ki.y));
-                                    const float b2 = *(const float*)(smem + (bias_q4 - ki.z)), b3 = *(const float*)(smem + (bias_q4 - ki.w));
+                                    const float b0 = *(const float*)(bias_qp - ki.x), b1 = *(const float*)(bias_qp - ki.y);
+                                    const float b2 = *(const float*)(bias_qp - ki.z), b3 = *(const float*)(bias_qp - ki.w);
                                     const f32x2 sl22 = {sl2, sl2};
                                     const f32x2 lo = __builtin_elementwise_fma(f32x2{st[s][4 * g], st[s][4 * g + 1]}, sl22, f32x2{b0, b1});
                                     const f32x2 hi = __builtin_elementwise_fma(f32x2{st[s][4 * g + 2], st[s][4 * g + 3]}, sl22, f32x2{b2, b3});
