@@ -22,13 +22,26 @@ namespace cobevt {
 namespace {
 
 constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kDeferLog2 = 8.0f;      // P <= 2^8 between rescales: exact in fp32 accumulators, bf16 keeps its relative precision
+constexpr float kHeadroom = 1.099511627776e12f;   // 2^40: a tile is redone against its exact maximum when a row sum exceeds this
+constexpr float kTiny = 8.271806125530277e-25f;   // 2^-80: a task is redone exactly when a row's total sum ends up below this
 
 __device__ __forceinline__ int perm16(int k) {   // swap bits 2 and 3: key order inside a 16-key MFMA k-block
     return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1);
 }
 
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// 8 bf16 values times a scalar, rounded back to bf16 (v_pk_mul_f32 + v_cvt_pk_bf16_f32 per pair)
+__device__ __forceinline__ uint4 scale_bf16x8(const uint4& v, float sc) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 f = f32x2{__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)} * sc;
+        o[i] = pack_bf2(f.x, f.y);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
 
 // max / sum across the two half-waves (lane ^ 32) without LDS: v_permlane32_swap exchanges the upper half of the first
 // operand with the lower half of the second, so {r0, r1} = {own, partner} in one order or the other on every lane
@@ -40,6 +53,18 @@ __device__ __forceinline__ float xor32_sum(float v) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+
+#ifdef COBEVT_RES_TRACE
+// probe builds only (tools/attn_trace.py): s_memtime marks of wave 0 of the first workgroups: start, tables done, K / V staged, end
+__device__ unsigned long long g_res_trace[4 * 8192];
+#define RES_MARK(i)                                                                                   \
+    do {                                                                                               \
+        const unsigned wgid = blockIdx.x + gridDim.x * blockIdx.y;                                     \
+        if (threadIdx.x == 0 && wgid < 8192) g_res_trace[4 * wgid + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define RES_MARK(i) do { } while (0)
+#endif
 
 template <int NT> struct ResLds {
     static constexpr int kNkp = NT * 64;
@@ -54,7 +79,9 @@ template <int NT> struct ResLds {
 // taken out of the softmax by a compare + select per score (a template parameter: as a run-time branch the compiler turns it
 // into 64 always-executed compare / select pairs per tile).
 template <int NT, int NW, bool MEAN, bool BIAS, bool MASK, bool RAGGED>
-__global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p, int qsplit) {
+// Register budget: the plain variants keep 4 waves per SIMD (35 KB of LDS -> 4 workgroups per CU); with a bias table / mask the
+// LDS footprint (>= 56 KB for the shipped windows) allows 2 waves per SIMD at most, so those variants may use 256 VGPRs.
+__global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : 4) void attn_resident_kernel(AttnParams p, int qsplit) {
     using L = ResLds<NT>;
     constexpr int NKP = L::kNkp;
     constexpr int NTHR = NW * 64;
@@ -93,6 +120,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
         head = lh - l * p.heads;
     }
 
+    RES_MARK(0);
     // ---- tables (one token -> row computation per thread instead of one per staging item / per task)
     for (int tk = tid; tk < NKP; tk += NTHR) {
         int row = -1, info = 0;
@@ -141,6 +169,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
         }
     }
     __syncthreads();
+    RES_MARK(1);
+    const float sl2 = p.scale * kLog2e;
 
     // ---- stage K (rows, 16-byte chunks XOR-swizzled by (key >> 2) & 3) and V^T (dh rows, 16-byte chunks XOR-swizzled by dh & 15)
     {
@@ -156,7 +186,9 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
             // branch (vmcnt(0) per load = one serialised HBM round trip per staging item)
             const int row = ktab[kk];
             const uint4 kv = *(const uint4*)(kbase + (size_t)(row < 0 ? 0 : row) * p.ldk + cj * 8);
-            kreg[it] = row >= 0 ? kv : make_uint4(0, 0, 0, 0);
+            // K pre-scaled by scale * log2(e) (one extra bf16 rounding, once per workgroup): the score MFMA then delivers base-2
+            // logits and, with C = -reference maximum, the exponent's argument itself - no per-score VALU before v_exp_f32
+            kreg[it] = row >= 0 ? scale_bf16x8(kv, sl2) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int it = 0; it < NITEM; ++it) {
@@ -189,6 +221,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
         }
     }
     __syncthreads();
+    RES_MARK(2);
 
     // ---- per-lane LDS read bases (everything else is an immediate offset)
     const uint32_t kx = (ql >> 2) & 3;
@@ -196,7 +229,6 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
     const unsigned char* kptr1 = Ks + ql * 64 + (((2 + h) ^ kx) << 4);     // k-group 1: chunk 2 + h
     const uint32_t vlow = (uint32_t)(ql & 15) << 4;                          // swizzle term, pre-shifted
     const unsigned char* vrow = Vts + ql * L::kVRow;                         // multiple of 256 B: the low byte is free for the XOR
-    const float sl2 = p.scale * kLog2e;
 
     const int ntiles = (NQ + 31) >> 5;                  // 32-query tiles (mean mode: position tiles)
     const int ncam = MEAN ? p.qmap.ncam : 1;
@@ -204,6 +236,10 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
     const bf16_t* qbase = (const bf16_t*)p.q + p.qoff + head * 32 + h * 8;
     const float inv_ncam = 1.0f / (float)ncam;
 
+    float m_run = 0.f;                             // softmax reference value, carried across this lane's tasks
+    f32x16 mneg;                                   // splat(-m_run): the C operand of the score MFMAs
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mneg[r] = 0.f;
     for (int tile = qs + qsplit * wave; tile < ntiles; tile += qsplit * NW) {
         const int t = tile * 32 + ql;
         const bool q_ok = t < NQ;
@@ -231,9 +267,19 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
                 qn[0] = *(const uint4*)(qrow);
                 qn[1] = *(const uint4*)(qrow + 16);
             }
+            const uint4 qs0 = qf[0], qs1 = qf[1];
+            float l_run;
+            // The softmax reference value m_run is carried over from the previous task of this lane (scores of neighbouring
+            // queries live on the same scale) instead of being measured per tile: probabilities are 2^(s - m_run) in fp32 /
+            // bf16, whose exponent range makes any reference within ~2^+-40 of the true maximum exact.  A tile whose row sum
+            // leaves that range is redone against its exact maximum (`need_max`), a task whose total sum ends up tiny is redone
+            // from an exact first tile (`exact`) - both wave-uniform and rare.
+            for (int exact = 0; exact < 2; ++exact) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) ot[r] = 0.f;
-            float m_run = -INFINITY, l_run = 0.f;
+            l_run = 0.f;
+            bool have_m = exact == 0;
+            if (exact) m_run = -INFINITY;
             // two 64-key tiles per iteration: inside a pair every LDS address is a per-lane base + an immediate (the V^T swizzle
             // flips with the tile parity); rolled over the pairs, so the register footprint does not grow with the window size
 #pragma unroll 1
@@ -244,120 +290,106 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
 #pragma unroll
                 for (int par = 0; par < 2; ++par) {
                     const int key0 = kp2 * 128 + par * 64;      // first key of this tile
-                    // ---- S^T = K . Q^T for the two 32-key sub-tiles
-                    f32x16 st[2];
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) st[s][r] = 0.f;
+                    // scores of one 32-key sub-tile on top of the accumulator image `c` (+ bias, + additive key mask)
+                    auto scores = [&](int s, const f32x16& c) -> f32x16 {
+                        f32x16 st = c;
                         const int off = (par * 64 + s * 32) * 64;
                         const uint4 a0 = *(const uint4*)(kp0 + off);
                         const uint4 a1 = *(const uint4*)(kp1 + off);
-                        mfma_kgroup<bf16_t>(a0, qf[0], st[s]);
-                        mfma_kgroup<bf16_t>(a1, qf[1], st[s]);
-                    }
-                    // ---- V^T fragments of this tile (issued early: they only depend on the tile index)
-                    uint4 va[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {            // j = s * 2 + u: keys key0 + s*32 + u*16 .. +15, this half's 8 slots
-                        const uint32_t lowc = (uint32_t)(par * 8 + j * 2) << 4;      // chunk within the 256-byte group (+ h)
-                        va[j] = *(const uint4*)(vp + ((lowc | ((uint32_t)h << 4)) ^ vlow));
-                    }
-                    // ---- scores -> base-2 logits, tile maximum
-                    float mloc;
-                    if (INFO) {
-                        // per-key metadata of this lane's 16 keys per sub-tile: 4 x 16-byte reads each (keys 8g + 4h .. + 3)
-#pragma unroll
-                        for (int s = 0; s < 2; ++s) {
+                        mfma_kgroup<bf16_t>(a0, qs0, st);
+                        mfma_kgroup<bf16_t>(a1, qs1, st);
+                        if (INFO) {        // this lane's 16 keys of the sub-tile: 4 x (4 consecutive keys 8g + 4h ..)
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
                                 const int kb = key0 + s * 32 + 8 * g + 4 * h;
-                                const f32x4 ma = *(const f32x4*)(kmadd + kb);
-                                f32x4 v;
+                                f32x4 add = *(const f32x4*)(kmadd + kb);
                                 if (BIAS) {
                                     const uint4 ki = *(const uint4*)(kinfo4 + kb);
-                                    const float b0 = *(const float*)(bias_qp - ki.x), b1 = *(const float*)(bias_qp - ki.y);
-                                    const float b2 = *(const float*)(bias_qp - ki.z), b3 = *(const float*)(bias_qp - ki.w);
-                                    const f32x2 sl22 = {sl2, sl2};
-                                    const f32x2 lo = __builtin_elementwise_fma(f32x2{st[s][4 * g], st[s][4 * g + 1]}, sl22, f32x2{b0, b1});
-                                    const f32x2 hi = __builtin_elementwise_fma(f32x2{st[s][4 * g + 2], st[s][4 * g + 3]}, sl22, f32x2{b2, b3});
-                                    v = f32x4{lo.x, lo.y, hi.x, hi.y} + ma;
-                                } else {
-                                    const f32x4 sl24 = {sl2, sl2, sl2, sl2};
-                                    v = __builtin_elementwise_fma(f32x4{st[s][4 * g], st[s][4 * g + 1], st[s][4 * g + 2], st[s][4 * g + 3]}, sl24, ma);
+                                    const f32x4 bb = {*(const float*)(bias_qp - ki.x), *(const float*)(bias_qp - ki.y),
+                                                      *(const float*)(bias_qp - ki.z), *(const float*)(bias_qp - ki.w)};
+                                    add += bb;
                                 }
-                                st[s][4 * g] = v.x; st[s][4 * g + 1] = v.y; st[s][4 * g + 2] = v.z; st[s][4 * g + 3] = v.w;
+                                const f32x2 lo = f32x2{st[4 * g], st[4 * g + 1]} + f32x2{add.x, add.y};          // v_pk_add_f32
+                                const f32x2 hi = f32x2{st[4 * g + 2], st[4 * g + 3]} + f32x2{add.z, add.w};
+                                st[4 * g] = lo.x; st[4 * g + 1] = lo.y; st[4 * g + 2] = hi.x; st[4 * g + 3] = hi.y;
+                            }
+                        } else if (RAGGED) {                    // padded keys out of the softmax
+                            const int nv = p.Nk - key0 - s * 32 - 4 * h;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                if ((r & 3) + 8 * (r >> 2) >= nv) st[r] = -INFINITY;
+                        }
+                        return st;
+                    };
+                    uint4 pb[4];
+                    float psum;
+                    bool need_max = !have_m;
+                    for (;;) {
+                        if (need_max) {
+                            // exact maximum of this tile (first tile of a task, or a tile that outgrew the running maximum):
+                            // throw-away score MFMAs, then the rescale; the regular pass below then runs against the new maximum
+                            f32x16 zero;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+                            float mloc = -INFINITY;
+#pragma unroll
+                            for (int s = 0; s < 2; ++s) {
+                                const f32x16 st = scores(s, zero);
+                                float m0 = max3(st[0], st[1], st[2]);
+#pragma unroll
+                                for (int r = 3; r < 15; r += 2) m0 = max3(m0, st[r], st[r + 1]);
+                                mloc = max3(mloc, m0, st[15]);
+                            }
+                            const float m_new = fmaxf(m_run, xor32_max(mloc));
+                            const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+                            const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);       // first tile: exp2(-inf) = 0
+                            m_run = m_new;
+                            l_run *= alpha;
+                            ot *= alpha;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) mneg[r] = -m_safe;
+                            have_m = true;
+                        }
+                        // ---- regular pass: P = exp2(S - m_run) straight from the MFMA result, packed to bf16, row sums
+                        f32x2 psv = {0.f, 0.f};
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const f32x16 st = scores(s, mneg);
+                            float e[16];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(st[r]);
+#pragma unroll
+                            for (int r = 0; r < 16; r += 2) psv += f32x2{e[r], e[r + 1]};
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                pb[s * 2 + u].x = pack_bf2(e[8 * u + 0], e[8 * u + 1]);
+                                pb[s * 2 + u].y = pack_bf2(e[8 * u + 2], e[8 * u + 3]);
+                                pb[s * 2 + u].z = pack_bf2(e[8 * u + 4], e[8 * u + 5]);
+                                pb[s * 2 + u].w = pack_bf2(e[8 * u + 6], e[8 * u + 7]);
                             }
                         }
-                        float m0 = max3(st[0][0], st[0][1], st[0][2]), m1 = max3(st[1][0], st[1][1], st[1][2]);
-#pragma unroll
-                        for (int r = 3; r < 15; r += 2) {
-                            m0 = max3(m0, st[0][r], st[0][r + 1]);
-                            m1 = max3(m1, st[1][r], st[1][r + 1]);
-                        }
-                        mloc = max3(m0, m1, fmaxf(st[0][15], st[1][15]));
-                    } else {
-                        if (RAGGED) {                           // padded keys out of the softmax
-                            const int nv = p.Nk - key0 - 4 * h;
-#pragma unroll
-                            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                                for (int r = 0; r < 16; ++r)
-                                    if (s * 32 + (r & 3) + 8 * (r >> 2) >= nv) st[s][r] = -INFINITY;
-                        }
-                        float m0 = max3(st[0][0], st[0][1], st[0][2]), m1 = max3(st[1][0], st[1][1], st[1][2]);
-#pragma unroll
-                        for (int r = 3; r < 15; r += 2) {
-                            m0 = max3(m0, st[0][r], st[0][r + 1]);
-                            m1 = max3(m1, st[1][r], st[1][r + 1]);
-                        }
-                        mloc = max3(m0, m1, fmaxf(st[0][15], st[1][15])) * sl2;   // scale > 0: max commutes with the scaling
+                        psum = psv.x + psv.y;
+                        // no per-tile maximum: the running maximum is kept as long as no probability of the tile exceeds
+                        // 2^kHeadroomLog2 (fp32 / bf16 share the exponent range, so nothing is lost below that); inf / NaN
+                        // fail the comparison too
+                        if (need_max || !__any(!(psum <= kHeadroom))) break;
+                        need_max = true;
                     }
-                    const float mtile = xor32_max(mloc);
-                    // deferred rescale: keep the running maximum while no query of the wave exceeds it by more than 2^kDeferLog2
-                    if (!__all(mtile <= m_run + kDeferLog2)) {
-                        const float m_new = fmaxf(m_run, mtile);
-                        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-                        const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);       // first tile: exp2(-inf) = 0
-                        m_run = m_new;
-                        l_run *= alpha;
-                        ot *= alpha;                                   // v_pk_mul_f32 x 8
-                    }
-                    // The kernel is VALU-bound (rocprofv3: 4 cycles per plain VALU wave-instruction, ~8 per v_exp_f32; 8 MFMAs = 256
-                    // cycles per tile against > 800 cycles of softmax arithmetic), so everything that has a packed form runs on
-                    // register PAIRS: v_pk_fma_f32 for scale - max, v_pk_add_f32 for the row sums (2 values per lane per issue)
-                    const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
-                    const f32x2 nm2 = {-m_use, -m_use}, sl22 = {sl2, sl2};
-                    f32x2 psv = {0.f, 0.f};
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-#pragma unroll
-                        for (int r = 0; r < 16; r += 2) {
-                            f32x2 x = {st[s][r], st[s][r + 1]};
-                            x = INFO ? x + nm2 : __builtin_elementwise_fma(x, sl22, nm2);
-                            f32x2 e;
-                            e.x = __builtin_amdgcn_exp2f(x.x);
-                            e.y = __builtin_amdgcn_exp2f(x.y);
-                            st[s][r] = e.x;
-                            st[s][r + 1] = e.y;
-                            psv += e;
-                        }
-                    l_run += psv.x + psv.y;
+                    have_m = true;
+                    l_run += psum;
                     // ---- O^T += V^T . P^T
 #pragma unroll
-                    for (int s = 0; s < 2; ++s)
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            uint4 pb;
-                            pb.x = pack_bf2(st[s][8 * u + 0], st[s][8 * u + 1]);
-                            pb.y = pack_bf2(st[s][8 * u + 2], st[s][8 * u + 3]);
-                            pb.z = pack_bf2(st[s][8 * u + 4], st[s][8 * u + 5]);
-                            pb.w = pack_bf2(st[s][8 * u + 6], st[s][8 * u + 7]);
-                            mfma_kgroup<bf16_t>(va[s * 2 + u], pb, ot);
-                        }
+                    for (int j = 0; j < 4; ++j) {            // j = s * 2 + u: keys key0 + s*32 + u*16 .. +15, this half's 8 slots
+                        const uint32_t lowc = (uint32_t)(par * 8 + j * 2) << 4;      // chunk within the 256-byte group (+ h)
+                        const uint4 va = *(const uint4*)(vp + ((lowc | ((uint32_t)h << 4)) ^ vlow));
+                        mfma_kgroup<bf16_t>(va, pb[j], ot);
+                    }
                 }
             }
-            const float inv = 1.0f / xor32_sum(l_run);     // an all-masked row yields NaN like the reference softmax
+            l_run = xor32_sum(l_run);
+            if (exact || !__any(!(l_run >= kTiny))) break;  // reference too far above this task's scores: redo it exactly
+            }
+            const float inv = 1.0f / l_run;                // an all-masked row yields NaN like the reference softmax
             if (MEAN) {
                 osum += ot * inv;                              // v_pk_fma_f32 x 8
                 qf[0] = qn[0];
@@ -378,6 +410,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_resident_kernel(AttnParams p,
             }
         }
     }
+    RES_MARK(3);
 }
 
 template <int NT, int NW>
@@ -419,6 +452,7 @@ int launch_attn_resident(const AttnParams& p, int qsplit_hint, hipStream_t strea
     const int ntiles = (NQ + 31) / 32;
     // waves per workgroup: 8 when the LDS footprint leaves room for one or two workgroups per CU only and the window has the
     // query tiles to feed them (LiDAR FuseBEVT: 512 tokens per window)
+    // (16 waves = 4 per SIMD at one workgroup per CU was measured 2x slower for the 512-key bias + mask windows: 128 VGPRs spill)
     const int nw = (lds > 40 * 1024 && ntiles >= 16) ? 8 : 4;
     // query split: enough workgroups to fill 256 CUs x (4 | 2 | 1 resident workgroups), every wave keeping >= 1 tile
     int qsplit = qsplit_hint;
@@ -431,6 +465,9 @@ int launch_attn_resident(const AttnParams& p, int qsplit_hint, hipStream_t strea
     }
     if (qsplit > ntiles) qsplit = ntiles;
     if (qsplit < 1) qsplit = 1;
+    // fewer workgroups than CUs (nuScenes: 100 windows x 1 head; the 5-agent fusion: 16 windows x 4 heads): the streaming kernel's
+    // finer query split fills the chip better than one staging per (window, head) can (measured: 31 vs 52 us, 25 vs 29 us)
+    if (qsplit_hint <= 0 && (long)p.B * p.L * p.heads * qsplit < 256) return -1;
     dim3 grid(p.L * p.heads * qsplit, p.B);
     if (grid.y > 65535) return -1;
     switch (nt * 10 + nw) {
@@ -447,3 +484,9 @@ int launch_attn_resident(const AttnParams& p, int qsplit_hint, hipStream_t strea
 }
 
 }  // namespace cobevt
+
+#ifdef COBEVT_RES_TRACE
+extern "C" int cobevt_res_trace_read(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cobevt::g_res_trace), sizeof(unsigned long long) * n);
+}
+#endif

@@ -14,6 +14,7 @@ from cobevt_amd import ops  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--qsplits", default="0")
+ap.add_argument("--cases", default="", help="comma-separated substrings of the case names to run (default: all)")
 args = ap.parse_args()
 dev = torch.device("cuda")
 torch.manual_seed(0)
@@ -35,7 +36,13 @@ def timed(fn, reps):
     return ts[len(ts) // 2]
 
 
+def wanted(name):
+    return not args.cases or any(c in name for c in args.cases.split(","))
+
+
 def cross_case(name, B, n, H, W, W1, W2, h, w, w1, w2, kmode, mean, heads=4):
+    if not wanted(name):
+        return
     d = heads * 32
     nq = n if mean else 1
     q = torch.randn(B, nq, H, W, d, device=dev).to(torch.bfloat16)
@@ -59,6 +66,8 @@ def cross_case(name, B, n, H, W, W1, W2, h, w, w1, w2, kmode, mean, heads=4):
 
 
 def swap_case(name, B, Lag, H, W, w, mode, heads):
+    if not wanted(name):
+        return
     d = heads * 32
     qkv = torch.randn(B, Lag, H, W, 3 * d, device=dev).to(torch.bfloat16)
     table = torch.randn((2 * Lag - 1) * (2 * w - 1) ** 2, heads, device=dev)
