@@ -54,7 +54,19 @@ class Bottleneck(HipModule):
         (ops.attn_mlp_chain next_plan) and hand the result to forward_nhwc(x, y1=...)."""
         return rt.conv_plan(self, "c1", self.conv1, self.bn1, act=1)
 
+    def fused_plan(self):
+        """the whole block as one launch (bf16, Bottleneck(128, 32)): ops.BottleneckPlan, or None when the kernel does not apply"""
+        if self.conv1.weight.shape[:2] != (32, 128) or self.downsample is not None:
+            return None
+        return self._plan("fused", rt.module_tensors(self.conv1, self.bn1, self.conv2, self.bn2, self.conv3, self.bn3),
+                          lambda dt, dev: ops.BottleneckPlan(self.conv1, self.bn1, self.conv2, self.bn2, self.conv3, self.bn3, dev))
+
+    def fusable(self, x):
+        return ops.bottleneck_fusable(x) and self.conv1.weight.shape[:2] == (32, 128)
+
     def forward_nhwc(self, x, y1=None):
+        if y1 is None and self.fusable(x):
+            return ops.bottleneck(x, self.fused_plan())
         y = ops.conv2d(x, self.entry_plan()) if y1 is None else y1
         y = ops.conv2d(y, rt.conv_plan(self, "c2", self.conv2, self.bn2, act=1))
         return ops.conv2d(y, rt.conv_plan(self, "c3", self.conv3, self.bn3, act=1), residual=x)
@@ -422,7 +434,9 @@ class FAXModule(HipModule):
             kvi = kv[i]() if kv is not None else cross_view.prepare_kv(feature, I_inv, E_inv, batch)
             blocks = list(layer)
             y1 = None
-            if blocks:
+            if blocks and not (x.dtype == torch.bfloat16 and ops.USE_BOTTLENECK and x.shape[-1] == 128
+                               and blocks[0].conv1.weight.shape[:2] == (32, 128)):
+                # conv1 of the first Bottleneck rides in the row chain's launch (the fused Bottleneck kernel computes it itself)
                 x, y1 = cross_view.forward_query(i, x, self.bev_embedding, E_inv, kvi, next_plan=blocks[0].entry_plan())
             else:
                 x = cross_view.forward_query(i, x, self.bev_embedding, E_inv, kvi)

@@ -39,6 +39,7 @@ USE_EMBED_GEMM3 = False   # the BEV query produced inside the 32-row GEMM that p
 # measured SLOWER on MI355X (119 vs 92 us on the level-0 shape, 361 vs 364 frames/s): the producer's 64 LDS
 # coefficient reads + ~400 VALU per thread cost more than the 170 MB of HBM traffic they save; kept for parity tests
 USE_CHAIN_NEXT = True  # ... and let the row-local GEMM that consumes its output next ride in the same launch
+USE_BOTTLENECK = True   # FAX ResNetBottleNeck (128 -> 32 -> 32 -> 128) as one launch (bottleneck.hip) instead of three
 ATTN_VARIANT = 0    # 0 = automatic (K/V-resident attention kernel where it applies), 1 = always the streaming kernel (A/B runs)
 ATTN_QSPLIT = 0     # 0 = automatic query split of the resident attention kernel; > 0 pins it (tools/attn_probe.py)
 
@@ -458,6 +459,69 @@ def basicblock(x, plan1, plan2):
         rc = _L.load().cobevt_basicblock_nhwc(_p(x), _p(plan1.wfrag), _p(plan1.bias), _p(plan2.wfrag), _p(plan2.bias),
                                               _p(out), dims, _stream())
     _L.check(rc, "cobevt_basicblock_nhwc")
+    return out
+
+
+class BottleneckPlan(object):
+    """torchvision Bottleneck(128, 32) lowered for cobevt_bottleneck_nhwc: the three convolutions with their eval BatchNorms
+    folded, as MFMA A-operand fragments ([.., 64 lanes, 8 values]: lane = 32 * half + output row, the 8 values are the
+    contraction slots 8 * half .. + 7 of a 16-wide k-block).  W3's contraction index is stored in the order the kernel's
+    accumulator registers hand conv2's result over: slot 8 * half + j of k-block u <-> mid channel 16u + (j & 3) + 8 (j >> 2) +
+    4 * half (bottleneck.hip)."""
+
+    def __init__(self, conv1, bn1, conv2, bn2, conv3, bn3, device="cuda"):
+        def fold(conv, bn):
+            w = conv.weight.detach().double().cpu()
+            s, sh = bn_affine(bn)
+            b = conv.bias.detach().double().cpu() * s.cpu() + sh.cpu() if conv.bias is not None else sh.cpu()
+            return w * s.cpu()[:, None, None, None], b
+        w1, b1 = fold(conv1, bn1)
+        w2, b2 = fold(conv2, bn2)
+        w3, b3 = fold(conv3, bn3)
+        mid, cin = w1.shape[0], w1.shape[1]
+        ok = (tuple(w1.shape) == (32, 128, 1, 1) and tuple(w2.shape) == (32, 32, 3, 3) and tuple(w3.shape) == (128, 32, 1, 1)
+              and conv1.stride == (1, 1) and conv2.stride == (1, 1) and conv3.stride == (1, 1) and conv2.padding == (1, 1))
+        if not ok:
+            raise CobevtHipError("the fused Bottleneck kernel is built for Bottleneck(128, 32), stride 1 (got %d -> %d)" % (cin, mid))
+        lane = torch.arange(64)
+        row, half = lane % 32, lane // 32
+        j = torch.arange(8)
+        # W1 [8 k-groups][64][8]: W1[row][16 g + 8 half + j]
+        g = torch.arange(8)
+        k1 = 16 * g[:, None, None] + 8 * half[None, :, None] + j[None, None, :]
+        f1 = w1[:, :, 0, 0][row[None, :, None].expand(8, 64, 8), k1]
+        # W2 [9 taps][2][64][8]: W2[row][16 u + 8 half + j][ky][kx]
+        u = torch.arange(2)
+        k2 = 16 * u[:, None, None] + 8 * half[None, :, None] + j[None, None, :]
+        w2t = w2.reshape(32, 32, 9)
+        f2 = torch.stack([w2t[:, :, t][row[None, :, None].expand(2, 64, 8), k2] for t in range(9)])
+        # W3 [4 cout tiles][2][64][8]: W3[32 ct + row][16 u + (j & 3) + 8 (j >> 2) + 4 half]
+        k3 = 16 * u[:, None, None] + (j & 3)[None, None, :] + 8 * (j >> 2)[None, None, :] + 4 * half[None, :, None]
+        f3 = torch.stack([w3[32 * ct:32 * ct + 32, :, 0, 0][row[None, :, None].expand(2, 64, 8), k3] for ct in range(4)])
+        bf = lambda t: t.to(torch.float32).to(torch.bfloat16).to(device).contiguous()      # noqa: E731
+        self.w1, self.w2, self.w3 = bf(f1), bf(f2), bf(f3)
+        self.b1, self.b2, self.b3 = [t.to(torch.float32).to(device).contiguous() for t in (b1, b2, b3)]
+
+
+def bottleneck_fusable(x):
+    return USE_BOTTLENECK and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[3] == 128 and x.is_contiguous()
+
+
+def bottleneck(x, plan, tile_rows=0):
+    """relu(conv3(relu(conv2(relu(conv1(x))))) + x) for a BottleneckPlan; x (N, H, W, 128) channels-last bf16."""
+    _need_cuda(x)
+    n, h, w, c = x.shape
+    out = torch.empty_like(x)
+    dims = _ints([BF16, n, h, w, c, 32, tile_rows])
+
+    def cost():
+        m = n * h * w
+        return 2.0 * m * (128 * 32 + 32 * 32 * 9 + 32 * 128), float(2 * x.numel() * 2 + (128 * 32 * 2 + 32 * 32 * 9) * 2)
+
+    with _timed("bottleneck|%dx%dx%d" % (n, h, w), cost):
+        rc = _L.load().cobevt_bottleneck_nhwc(_p(x), _p(plan.w1), _p(plan.w2), _p(plan.w3), _p(plan.b1), _p(plan.b2), _p(plan.b3),
+                                              _p(out), dims, _stream())
+    _L.check(rc, "cobevt_bottleneck_nhwc")
     return out
 
 

@@ -170,6 +170,14 @@ int cobevt_attn_mlp_chain(const void* a, const void* skip, void* out, const void
 int cobevt_window_attention(const void* q, const void* k, const void* v, void* out, const float* bias_table,
                             const float* mask, const int* dims, float scale, hipStream_t stream);
 
+/* Fused torchvision Bottleneck(128, 32) (1x1 128->32, 3x3 32->32, 1x1 32->128, eval BatchNorms folded, ReLUs, identity skip) on
+ * a channels-last bf16 map: ResNetBottleNeck(dim) of the FAX pyramid, fax_modules.py:10,472,512.  w1 / w2 / w3: MFMA fragment
+ * tables [8][64][8] / [9][2][64][8] / [4][2][64][8] bf16 (layout: cobevt_amd/ops.py BottleneckPlan; w3's contraction index in
+ * accumulator-register order), b1[32] / b2[32] / b3[128] fp32.  dims (int32[7]): dtype (0), N, H, W, C (128), mid (32),
+ * tile rows (0 = automatic | 8 | 16). */
+int cobevt_bottleneck_nhwc(const void* in, const void* w1, const void* w2, const void* w3, const float* b1, const float* b2,
+                           const float* b3, void* out, const int* dims, hipStream_t stream);
+
 /* Test hooks for the integer part of the attention kernels (north-star: window index arithmetic bit-exact), computed by the
  * same device functions the attention kernels use.  cobevt_attention_index_map: rows[b][l][t] (int32, B * X*Y * ncam*w1*w2) =
  * row of token t of window l in the (B*ncam, HH, WW) token matrix, for one token map {mode, ncam, HH, WW, w1, w2, X, Y}:

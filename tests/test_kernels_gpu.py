@@ -276,6 +276,47 @@ def test_conv3x3_lds_staged_kernel_shapes(cuda, dtype, cin, cout, h, w):
         ops.USE_CONV3_WFRAG = True
 
 
+@pytest.mark.parametrize("tile_rows", [0, 8, 16])
+@pytest.mark.parametrize("n,h,w", [(2, 32, 32), (1, 21, 37), (3, 16, 48), (1, 5, 3)])
+def test_bottleneck_fused(cuda, n, h, w, tile_rows):
+    """cobevt_bottleneck_nhwc (FAX ResNetBottleNeck(128), fax_modules.py:10,472) against torchvision's Bottleneck arithmetic in
+    fp32 on the bf16-rounded operands with the intermediates rounded where the kernel rounds them, and against the three
+    unfused launches; ragged maps cover the zero padding and the partial tiles."""
+    import torch.nn as nn
+    from cobevt_amd.synth import fill_module_
+
+    class B(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1, self.bn1 = nn.Conv2d(128, 32, 1, bias=False), nn.BatchNorm2d(32)
+            self.conv2, self.bn2 = nn.Conv2d(32, 32, 3, 1, 1, bias=False), nn.BatchNorm2d(32)
+            self.conv3, self.bn3 = nn.Conv2d(32, 128, 1, bias=False), nn.BatchNorm2d(128)
+    m = fill_module_(B(), 5).eval()
+    dtype = torch.bfloat16
+    plan = ops.BottleneckPlan(m.conv1, m.bn1, m.conv2, m.bn2, m.conv3, m.bn3, device=cuda)
+    x = procedural_input("bnk.x", (n, 128, h, w), 0)
+    xd = nhwc(x).to(cuda).to(dtype)
+    y = ops.bottleneck(xd, plan, tile_rows)
+    torch.cuda.synchronize()
+    # reference on what the kernel sees: folded weights rounded to bf16, intermediates rounded to bf16
+    def fold(conv, bn):
+        sc, sh = ops.bn_affine(bn)
+        return (conv.weight.double() * sc[:, None, None, None]).float().to(dtype).float(), sh.float()
+    (w1, b1), (w2, b2), (w3, b3) = fold(m.conv1, m.bn1), fold(m.conv2, m.bn2), fold(m.conv3, m.bn3)
+    xr = rnd(x, dtype)
+    y1 = rnd(F.relu(F.conv2d(xr, w1, b1)), dtype)
+    y2 = rnd(F.relu(F.conv2d(y1, w2, b2, padding=1)), dtype)
+    ref = F.relu(F.conv2d(y2, w3, b3) + xr)
+    check(y.permute(0, 3, 1, 2), ref, dtype, "fused bottleneck %dx%dx%d rows=%d" % (n, h, w, tile_rows))
+    # the three-launch path computes the same thing
+    p1 = ops.ConvPlan(m.conv1.weight, None, bn=m.bn1, act=1, dtype=dtype, device=cuda)
+    p2 = ops.ConvPlan(m.conv2.weight, None, bn=m.bn2, stride=1, pad=1, act=1, dtype=dtype, device=cuda)
+    p3 = ops.ConvPlan(m.conv3.weight, None, bn=m.bn3, act=1, dtype=dtype, device=cuda)
+    z = ops.conv2d(ops.conv2d(ops.conv2d(xd, p1), p2), p3, residual=xd)
+    torch.cuda.synchronize()
+    assert (y.float() - z.float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("c,n,h,w", [(64, 2, 24, 40), (128, 3, 16, 16), (64, 1, 13, 21), (128, 2, 9, 35)])
 def test_basicblock_fused(cuda, dtype, c, n, h, w):

@@ -4,6 +4,7 @@ import numpy as np
 import torch
 
 from cobevt_amd import ops
+from cobevt_amd.synth import procedural_input
 
 
 def _w(shape, seed):
@@ -100,3 +101,63 @@ def test_conv3_tiling_picks_whole_workgroups_per_cu():
         strips = n * ((ho + 1) // 2) * ((wo + 15) // 16)
         blocks = (strips + mt - 1) // mt * ((cout + (64 if bn64 else 128) - 1) // (64 if bn64 else 128))
         assert blocks % 256 == 0, (v, blocks)
+
+
+def test_bottleneck_fragment_tables():
+    """ops.BottleneckPlan: the three fragment tables reproduce the folded convolutions when contracted the way bottleneck.hip does
+    (lane = 32 * half + output row; W3's contraction slots in the accumulator-register order of conv2's result)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from cobevt_amd.synth import fill_module_
+
+    class B(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1, self.bn1 = nn.Conv2d(128, 32, 1, bias=False), nn.BatchNorm2d(32)
+            self.conv2, self.bn2 = nn.Conv2d(32, 32, 3, 1, 1, bias=False), nn.BatchNorm2d(32)
+            self.conv3, self.bn3 = nn.Conv2d(32, 128, 1, bias=False), nn.BatchNorm2d(128)
+    m = fill_module_(B(), 3).eval()
+    plan = ops.BottleneckPlan(m.conv1, m.bn1, m.conv2, m.bn2, m.conv3, m.bn3, device="cpu")
+    f1, f2, f3 = plan.w1.float(), plan.w2.float(), plan.w3.float()
+    assert tuple(f1.shape) == (8, 64, 8) and tuple(f2.shape) == (9, 2, 64, 8) and tuple(f3.shape) == (4, 2, 64, 8)
+    x = procedural_input("bn.x", (1, 128, 6, 7), 0)
+    xr = x.to(torch.bfloat16).float()
+    lane = torch.arange(64)
+    row, half = lane % 32, lane // 32
+    j = torch.arange(8)
+    # conv1: acc[m][pix] = sum_g sum_lane(row == m) sum_j f1[g][lane][j] * x[pix][16 g + 8 half + j]
+    xp = xr[0].permute(1, 2, 0).reshape(-1, 128)                                   # [pix][c]
+    y1 = torch.zeros(32, xp.shape[0])
+    for g in range(8):
+        ch = 16 * g + 8 * half[:, None] + j[None, :]                               # [lane][j]
+        contrib = torch.einsum("lj,plj->lp", f1[g], xp[:, ch])                     # [lane][pix]
+        y1.index_add_(0, row, contrib)
+    s1, sh1 = ops.bn_affine(m.bn1)
+    ref1 = F.conv2d(xr, (m.conv1.weight.double() * s1[:, None, None, None]).float().to(torch.bfloat16).float())
+    assert torch.allclose(y1, ref1[0].reshape(32, -1), atol=1e-4)
+    # conv3 with the permuted contraction index: y2 registers of lane (pix, half): r = 8 u + j <-> channel 16u + (j&3) + 8(j>>2) + 4 half
+    y2 = procedural_input("bn.y2", (5, 32), 0).to(torch.bfloat16).float()          # [pix][mid]
+    out = torch.zeros(128, 5)
+    for ct in range(4):
+        for u in range(2):
+            ch = 16 * u + (j & 3)[None, :] + 8 * (j >> 2)[None, :] + 4 * half[:, None]
+            contrib = torch.einsum("lj,plj->lp", f3[ct, u], y2[:, ch])
+            out.index_add_(0, 32 * ct + row, contrib)
+    s3, _ = ops.bn_affine(m.bn3)
+    w3 = (m.conv3.weight.double()[:, :, 0, 0] * s3[:, None]).float().to(torch.bfloat16).float()
+    assert torch.allclose(out, w3 @ y2.t(), atol=1e-4)
+    # conv2: tap-major fragments, standard slot order
+    y1p = procedural_input("bn.y1", (32, 5, 6), 0).to(torch.bfloat16).float()      # [c][h][w]
+    s2, _ = ops.bn_affine(m.bn2)
+    w2 = (m.conv2.weight.double() * s2[:, None, None, None]).float().to(torch.bfloat16).float()
+    ref2 = F.conv2d(y1p[None], w2, padding=1)[0]                                    # [32][5][6]
+    pad = F.pad(y1p, (1, 1, 1, 1))
+    acc = torch.zeros(32, 5, 6)
+    for tap in range(9):
+        dy, dx = tap // 3, tap % 3
+        win = pad[:, dy:dy + 5, dx:dx + 6].reshape(32, -1).t()                      # [pix][c]
+        for u in range(2):
+            ch = 16 * u + 8 * half[:, None] + j[None, :]
+            contrib = torch.einsum("lj,plj->lp", f2[tap, u], win[:, ch])
+            acc.reshape(32, -1).index_add_(0, row, contrib)
+    assert torch.allclose(acc, ref2, atol=1e-4)
