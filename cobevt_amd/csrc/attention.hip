@@ -70,17 +70,23 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
     const int P = p.qmap.w1 * p.qmap.w2;
     int tq;
     bool q_ok;
-    if (p.mean_q) { const int pos = qtile * 32 + ql; q_ok = pos < P && wave < p.qmap.ncam; tq = wave * P + pos; }
-    else { tq = qtile * 32 * (nthr >> 6) + wave * 32 + ql; q_ok = tq < p.Nq; }
-    const TokCoord qc = tok_coord(p.qmap, q_ok ? tq : 0);
+    const bool pair = p.mean_q == 2;      // CVT: the key tile's camera selects the query copy (one softmax over all cameras)
+    if (p.mean_q == 1) { const int pos = qtile * 32 + ql; q_ok = pos < P && wave < p.qmap.ncam; tq = wave * P + pos; }
+    else { tq = qtile * 32 * (nthr >> 6) + wave * 32 + ql; q_ok = tq < (pair ? P : p.Nq); }
+    const TokCoord qc = tok_coord(p.qmap, q_ok ? tq : 0);          // pair mode: tq < P -> camera 0
 
     uint4 qf[NG];
-    {
-        const T* qrow = (const T*)p.q + tok_row(p.qmap, b, l, qc) * p.ldq + p.qoff + head * 32;
+    auto load_q = [&](int cam) {
+        TokCoord c = qc;
+        c.cam += cam;
+        const T* qrow = (const T*)p.q + tok_row(p.qmap, b, l, c) * p.ldq + p.qoff + head * 32;
 #pragma unroll
         for (int g = 0; g < NG; ++g)
             qf[g] = q_ok ? *(const uint4*)(qrow + g * (2 * CH) + h * CH) : make_uint4(0, 0, 0, 0);
-    }
+    };
+    load_q(0);
+    int q_cam = 0;
+    const int keys_per_cam = p.kmap.w1 * p.kmap.w2;
     if (BIAS) {
         // in the base-2 softmax domain already.  Eight strided loads per thread in flight at a time: the rolled loop paid one
         // global round trip per iteration (8 of them for the 2025-row 3-D table) before the first key tile could start
@@ -99,10 +105,14 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
             }
         }
     }
-    for (int tk = tid; tk < p.Nk; tk += nthr) {
-        const TokCoord kc = tok_coord(p.kmap, tk);
-        ktab[tk] = make_int2((int)tok_row(p.kmap, b, l, kc), (kc.cam << 16) | (kc.i << 8) | kc.j);
+    const bool klin = p.klinear != 0;      // one window = the whole key map in row-major order: row = b * Nk + tk, no table
+    if (!klin) {
+        for (int tk = tid; tk < p.Nk; tk += nthr) {
+            const TokCoord kc = tok_coord(p.kmap, tk);
+            ktab[tk] = make_int2((int)tok_row(p.kmap, b, l, kc), (kc.cam << 16) | (kc.i << 8) | kc.j);
+        }
     }
+    const int klin_base = b * p.Nk;
     __syncthreads();
 
     // ---- staging registers (threads 0..255 stage; K_IT / V_IT items each)
@@ -110,17 +120,30 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
     uint4 vreg[V_IT];          // bf16: {row0 lo, row0 hi, row1 lo, row1 hi} (8 bytes of 2 key rows); fp32: 16 bytes of 1 row
     int ireg[K_IT];
     const bool stager = tid < 256;
-    const int nkt = (p.Nk + kKeysPerTile - 1) / kKeysPerTile;
+    // key tiles: 64 consecutive key tokens; in pair mode every camera's keys start a new tile (a tile never mixes cameras), so
+    // tile kt covers tokens [tile_base, tile_base + tile_valid) with tile_valid <= 64
+    const int tiles_per_cam = (keys_per_cam + kKeysPerTile - 1) / kKeysPerTile;
+    const int nkt = pair ? p.kmap.ncam * tiles_per_cam : (p.Nk + kKeysPerTile - 1) / kKeysPerTile;
+    auto tile_base = [&](int kt) {
+        if (!pair) return kt * kKeysPerTile;
+        const int cam = kt / tiles_per_cam;
+        return cam * keys_per_cam + (kt - cam * tiles_per_cam) * kKeysPerTile;
+    };
+    auto tile_valid = [&](int kt) {
+        if (!pair) return p.Nk - kt * kKeysPerTile;
+        return keys_per_cam - (kt % tiles_per_cam) * kKeysPerTile;
+    };
 
     auto load_tile = [&](int kt) {
         if (!stager) return;
+        const int tbase = tile_base(kt), tvalid = tile_valid(kt);
 #pragma unroll
         for (int it = 0; it < K_IT; ++it) {
             const int item = tid + it * 256;
             const int kk = item / CPR, cj = item - kk * CPR;
-            const int tk = kt * kKeysPerTile + kk;
-            const bool ok = tk < p.Nk;
-            const int2 ke = ktab[ok ? tk : 0];
+            const int tk = tbase + kk;
+            const bool ok = kk < tvalid;
+            const int2 ke = klin ? make_int2(klin_base + (ok ? tk : 0), 0) : ktab[ok ? tk : 0];
             const size_t row = (size_t)ke.x;
             TokCoord kc;
             kc.cam = ke.y >> 16; kc.i = (ke.y >> 8) & 0xff; kc.j = ke.y & 0xff;
@@ -151,22 +174,22 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
             if constexpr (Elem<T>::kIsBf16) {
                 const int kp = item >> 3, dq = item & 7;               // key pair, dh quad
                 uint2 r0 = make_uint2(0, 0), r1 = make_uint2(0, 0);
-                const int tk = kt * kKeysPerTile + 2 * kp;
-                if (tk < p.Nk) {
-                    const size_t row = (size_t)ktab[tk].x;
+                const int tk = tbase + 2 * kp;
+                if (2 * kp < tvalid) {
+                    const size_t row = (size_t)(klin ? klin_base + tk : ktab[tk].x);
                     r0 = *(const uint2*)((const T*)p.v + row * p.ldv + p.voff + head * 32 + dq * 4);
                 }
-                if (tk + 1 < p.Nk) {
-                    const size_t row = (size_t)ktab[tk + 1].x;
+                if (2 * kp + 1 < tvalid) {
+                    const size_t row = (size_t)(klin ? klin_base + tk + 1 : ktab[tk + 1].x);
                     r1 = *(const uint2*)((const T*)p.v + row * p.ldv + p.voff + head * 32 + dq * 4);
                 }
                 vreg[it] = make_uint4(r0.x, r0.y, r1.x, r1.y);
             } else {
                 const int kk = item >> 3, dq = item & 7;
-                const int tk = kt * kKeysPerTile + kk;
+                const int tk = tbase + kk;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (tk < p.Nk) {
-                    const size_t row = (size_t)ktab[tk].x;
+                if (kk < tvalid) {
+                    const size_t row = (size_t)(klin ? klin_base + tk : ktab[tk].x);
                     v = *(const uint4*)((const T*)p.v + row * p.ldv + p.voff + head * 32 + dq * 4);
                 }
                 vreg[it] = v;
@@ -219,6 +242,10 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
+        if (pair) {                                   // (keys per camera is a multiple of the tile: one camera per tile)
+            const int cam = kt / tiles_per_cam;
+            if (cam != q_cam) { q_cam = cam; load_q(cam); }
+        }
         if (kt + 1 < nkt) load_tile(kt + 1);
         const unsigned char* Ks = smem + buf * L::kBuf;
         const unsigned char* Vts = Ks + L::kKBytes;
@@ -238,7 +265,7 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
         }
         // ---- softmax numerators in the base-2 domain: p = 2^(s*scale*log2e [+ bias*log2e] - m)
         float mloc = -INFINITY;
-        const int nvalid = p.Nk - kt * kKeysPerTile;     // >= 64 except in the last tile
+        const int nvalid = tile_valid(kt);               // >= 64 except in the last tile (of a camera, in pair mode)
         if (INFO) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -325,7 +352,7 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) ot[r] *= inv;
 
-    if (p.mean_q) {
+    if (p.mean_q == 1) {
         const int nw = p.qmap.ncam;
         if (wave < nw) {
 #pragma unroll
@@ -409,23 +436,29 @@ extern "C" int cobevt_window_attention(const void* q, const void* k, const void*
     if ((p.ldq | p.ldk | p.ldv | p.ldo | p.qoff | p.koff | p.voff | p.ooff) % ch) return COBEVT_ERR_SHAPE;
     p.Nq = p.qmap.ncam * p.qmap.w1 * p.qmap.w2;
     p.Nk = p.kmap.ncam * p.kmap.w1 * p.kmap.w2;
+    if (p.mean_q < 0 || p.mean_q > 2) return COBEVT_ERR_ARG;
     if (p.mean_q && p.qmap.ncam == 1) p.mean_q = 0;
-    if (p.mean_q && (p.qmap.ncam > 8 || p.omap.ncam != 1)) return COBEVT_ERR_UNSUPPORTED;
-    if (dtype == 0 && variant != 1) {
+    if (p.mean_q == 1 && (p.qmap.ncam > 8 || p.omap.ncam != 1)) return COBEVT_ERR_UNSUPPORTED;
+    if (p.mean_q == 2) {     // camera-paired queries: cameras on both sides, whole tiles per camera, no bias / mask
+        if (p.omap.ncam != 1 || p.qmap.ncam != p.kmap.ncam || p.bias_mode || mask) return COBEVT_ERR_UNSUPPORTED;
+    }
+    // keys of a single window that covers the whole map are rows b * Nk + tk: no table (CVT attends to 4 x 64 x 64 keys)
+    p.klinear = (p.kmap.mode != 2 && p.kmap.X == 1 && p.kmap.Y == 1 && !p.bias_mode && !mask) ? 1 : 0;
+    if (dtype == 0 && variant != 1 && p.mean_q != 2) {
         const int rc = launch_attn_resident(p, qsplit_hint, stream);
         if (rc >= 0) return rc;
     }
     const int P = p.qmap.w1 * p.qmap.w2;
     dim3 grid, block;
-    if (p.mean_q) { block = dim3(64 * (p.qmap.ncam < 4 ? 4 : p.qmap.ncam)); grid = dim3(p.L * p.heads, (P + 31) / 32, p.B); }
-    else { block = dim3(256); grid = dim3(p.L * p.heads, (p.Nq + 127) / 128, p.B); }
+    if (p.mean_q == 1) { block = dim3(64 * (p.qmap.ncam < 4 ? 4 : p.qmap.ncam)); grid = dim3(p.L * p.heads, (P + 31) / 32, p.B); }
+    else { block = dim3(256); grid = dim3(p.L * p.heads, ((p.mean_q == 2 ? P : p.Nq) + 127) / 128, p.B); }
     if (grid.y > 65535 || grid.z > 65535) return COBEVT_ERR_SHAPE;
     size_t lds = dtype == 0 ? AttnLds<bf16_t>::kFixed : AttnLds<float>::kFixed;
     if (p.bias_mode) lds += ((size_t)p.bias_rows * 4 + 15) & ~(size_t)15;
-    lds += (size_t)p.Nk * 8;                        // per-key row / coordinate table
+    if (!p.klinear) lds += (size_t)p.Nk * 8;        // per-key row / coordinate table
     if ((long)p.B * p.kmap.ncam * (p.kmap.mode == 2 ? (long)p.L * p.kmap.w1 * p.kmap.w2 : (long)p.kmap.HH * p.kmap.WW) >= 0x7fffffffL)
         return COBEVT_ERR_UNSUPPORTED;              // the table holds 32-bit row indices
-    if (p.mean_q) { const size_t need = (size_t)p.qmap.ncam * 16 * 64 * 4; if (need > lds) lds = need; }
+    if (p.mean_q == 1) { const size_t need = (size_t)p.qmap.ncam * 16 * 64 * 4; if (need > lds) lds = need; }
     if (lds > 64 * 1024) return COBEVT_ERR_UNSUPPORTED;
     const bool hb = p.bias_mode != 0, hm = p.mask != nullptr;
 #define COBEVT_ATTN_LAUNCH(TT)                                                                                   \

@@ -66,7 +66,10 @@ struct AttnParams {
     int bias_rows;
     int bias_L;               // agent extent of the 3-D table (1 => 2-D table)
     const float* mask;        // key mask fp32, 0 => key masked out; (B,HH,WW,ncam), or (B,L,w1,w2,ncam) for mode 2; may be null
-    int mean_q;
+    int mean_q;               // 0: every query token on its own; 1: per-camera query copies, outputs averaged over the cameras
+                              // (fax_modules.py:243); 2: per-camera query copies, camera c's query scores camera c's keys only,
+                              // ONE softmax over all cameras' keys (CVT CrossAttention, cvt_modules.py:142-153)
+    int klinear;              // streaming kernel: key token tk of the (single) window is row b * Nk + tk - no key table in LDS
 };
 
 static inline bool map_ok(const TokMap& m) {

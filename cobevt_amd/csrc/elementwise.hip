@@ -184,6 +184,25 @@ __global__ __launch_bounds__(256) void bev_embed_kernel(const float* E_inv, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// F-Cooper max-out over the agent slots: out[b][i] = max_l in[b][l][i], 8 elements per thread.
+// reference: opv2v/opencood/models/fusion_modules/f_cooper_fuse.py:30-36 (SpatialFusionMask: torch.max(x, dim=1)[0])
+template <typename T>
+__global__ __launch_bounds__(256) void agent_max_kernel(const T* in, T* out, int B, int L, long per8) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)B * per8) return;
+    const long b = gid / per8, i = gid - b * per8;
+    float m[8];
+    load8<T>(in + ((size_t)b * L * per8 + i) * 8, m);
+    for (int l = 1; l < L; ++l) {
+        float v[8];
+        load8<T>(in + (((size_t)b * L + l) * per8 + i) * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+    }
+    store8<T>(out + (size_t)gid * 8, m);
+}
+
+// ---------------------------------------------------------------------------------------------
 // MaxPool2d(kernel 3, stride 2, padding 1) channels-last.  reference: resnet_ms.py:71 (torchvision resnet maxpool)
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* in, T* out, int N, int H, int W, int C, int Ho,
@@ -504,6 +523,15 @@ extern "C" int cobevt_fax_bev_embed(const float* E_inv, const float* world, cons
     else if (dtype == 1) hipLaunchKernelGGL(bev_embed_kernel<float>, grid, block, 0, stream, E_inv, world, w_bev, b_bev, w_cam, (const float*)x, (float*)out, B, n, hw, D, x_bcast);
     else return COBEVT_ERR_ARG;
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+extern "C" int cobevt_agent_max(const void* in, void* out, int dtype, int B, int L, long per, hipStream_t stream) {
+    if (!in || !out) return COBEVT_ERR_ARG;
+    if (B < 1 || L < 1 || per < 8 || per % 8) return COBEVT_ERR_SHAPE;
+    const long items = (long)B * (per / 8);
+    if (dtype == 0) return launch1d(agent_max_kernel<bf16_t>, items, stream, (const bf16_t*)in, (bf16_t*)out, B, L, per / 8);
+    if (dtype == 1) return launch1d(agent_max_kernel<float>, items, stream, (const float*)in, (float*)out, B, L, per / 8);
+    return COBEVT_ERR_ARG;
 }
 
 extern "C" int cobevt_maxpool3x3s2(const void* in, void* out, int dtype, int N, int H, int W, int C, hipStream_t stream) {

@@ -12,6 +12,10 @@ from .bev_seg_head import BevSegHead  # noqa: F401
 from .fuse_utils import regroup  # noqa: F401
 from .corpbevt import STTF, CorpBEVT  # noqa: F401
 from .fax_fused_transformer import FaxFusedTransformer  # noqa: F401
+from .cvt_modules import CrossAttention, CrossViewAttention, CrossViewModule  # noqa: F401
+from .cross_view_transformer import CrossViewTransformer  # noqa: F401
+from .cross_view_transformer_swap_fuse import CrossViewTransformerSwapFuse  # noqa: F401
+from .cross_view_transformer_fcooper import CrossViewTransformerFcooper  # noqa: F401
 from .pipeline import CapturedCall, CapturedCorpBEVT, PipelinedCorpBEVT  # noqa: F401
 # the data formats either side of the path
 from .camera_bev_postprocessor import CameraBevPostprocessor  # noqa: F401

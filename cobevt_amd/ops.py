@@ -588,14 +588,15 @@ def window_attention(q, k, v, out, qmap, kmap, omap, batch, heads, scale, ldq, l
     L = qmap[6] * qmap[7]
     dims = _ints([code, batch, L, heads, ldq, ldk, ldv, ldo, qoff, koff, voff, ooff,
                   0 if bias_table is None else 1, 0 if bias_table is None else bias_table.shape[0], bias_L,
-                  int(bool(mean_q))] + list(qmap) + list(kmap) + list(omap))
+                  int(mean_q)] + list(qmap) + list(kmap) + list(omap))
     def cost():
         nq = qmap[1] * qmap[4] * qmap[5]
         nk = kmap[1] * kmap[4] * kmap[5]
         esz = q.element_size()
         d = heads * 32
         nbytes = batch * L * (nq + 2 * nk + nq // (qmap[1] if mean_q else 1)) * d * esz
-        return 4.0 * batch * L * heads * nq * nk * 32, float(nbytes)
+        pairs = nq * nk // (qmap[1] if int(mean_q) == 2 else 1)      # camera-paired: a query copy scores its own camera's keys
+        return 4.0 * batch * L * heads * pairs * 32, float(nbytes)
 
     with _timed("attention|B%d L%d h%d Nq%d Nk%d" % (batch, L, heads, qmap[1] * qmap[4] * qmap[5], kmap[1] * kmap[4] * kmap[5]), cost):
         rc = _L.load().cobevt_window_attention(_p(q), _p(k), _p(v), _p(out), _p(bias_table), _p(mask), dims,
@@ -622,6 +623,19 @@ def attention_bias_index(qmap, kmap, bias_L, device):
     rc = _L.load().cobevt_attention_bias_index(_ints(qmap), _ints(kmap), int(bias_L), _p(idx), _stream())
     _L.check(rc, "cobevt_attention_bias_index")
     return idx
+
+
+def agent_max(x):
+    """(B, L, ...) contiguous -> max over L: (B, ...)   (F-Cooper max-out, fusion_modules/f_cooper_fuse.py:30-36)"""
+    _need_cuda(x)
+    if not x.is_contiguous():
+        raise CobevtHipError("agent_max: input must be contiguous")
+    b, l = x.shape[:2]
+    out = torch.empty((b,) + tuple(x.shape[2:]), device=x.device, dtype=x.dtype)
+    per = out[0].numel()
+    rc = _L.load().cobevt_agent_max(_p(x), _p(out), dcode(x.dtype), b, l, per, _stream())
+    _L.check(rc, "cobevt_agent_max")
+    return out
 
 
 def ray_embed(i_inv, e_inv, image_plane, w_img, w_cam, hw, dim, dtype):

@@ -258,3 +258,57 @@ def nuscenes_inputs(key="gv11", seed=0):
         ext[:, k] = np.linalg.inv(rz @ t @ _CAM2EGO_AXES)
     I = np.broadcast_to(intr, (c["b"], c["n"], 3, 3)).copy()
     return feats, image, torch.from_numpy(I.astype(np.float32)), torch.from_numpy(ext.astype(np.float32))
+
+
+# ----------------------------------------------------------------------------------------------
+# CVT baseline models: reduced configs verified to run on the reference (make_golden.py gv17)
+# ----------------------------------------------------------------------------------------------
+def cvt_small_config(kind="single"):
+    """Reduced opv2v/opencood/hypes_yaml/opcamera/cvt*.yaml: resnet18, 128^2 images, 2 cams, id_pick [1, 3], dim 32, 1 head, BEV
+    64 with three decoder blocks -> 8x8 BEV queries.  kind: 'single' (cross_view_transformer), 'swap_fuse', 'fcooper'."""
+    cfg = {
+        "target": "dynamic",
+        "encoder": {"num_layers": 18, "pretrained": False, "image_width": 128, "image_height": 128, "id_pick": [1, 3]},
+        "decoder": {"input_dim": 32, "num_layer": 3, "num_ch_dec": [8, 16, 32]},
+        "cvm": {
+            "dim": 32, "middle": [1, 1],
+            "bev_embedding": {"sigma": 1.0, "bev_height": 64, "bev_width": 64, "h_meters": 100, "w_meters": 100, "offset": 0.0,
+                              "decoder_blocks": [8, 16, 32]},
+            "cross_view": {"image_height": 128, "image_width": 128, "no_image_features": False, "skip": True, "heads": 1,
+                           "dim_head": 32, "qkv_bias": True},
+        },
+        "seg_head_dim": 8,
+        "output_class": 2,
+    }
+    if kind != "single":
+        cfg["max_cav"] = 3
+        cfg["sttf"] = {"resolution": 1.5625, "downsample_rate": 8, "use_roi_mask": True}
+    if kind == "swap_fuse":
+        cfg["swap_fusion"] = {"input_dim": 32, "mlp_dim": 64, "agent_size": 3, "window_size": 4, "dim_head": 32, "drop_out": 0.1,
+                              "depth": 2, "mask": True}
+    return cfg
+
+
+def cvt_config(kind="single", max_cav=5, image=512):
+    """model.args of cvt.yaml / cvt_swap_fuse.yaml / cvt_fcooper.yaml (opv2v/opencood/hypes_yaml/opcamera) as plain dicts."""
+    cfg = {
+        "target": "dynamic",
+        "encoder": {"num_layers": 34, "pretrained": False, "image_width": image, "image_height": image, "id_pick": [1, 3]},
+        "decoder": {"input_dim": 128, "num_layer": 3, "num_ch_dec": [32, 64, 128]},
+        "cvm": {
+            "dim": 128, "middle": [2, 2],
+            "bev_embedding": {"sigma": 1.0, "bev_height": 256, "bev_width": 256, "h_meters": 100, "w_meters": 100, "offset": 0.0,
+                              "decoder_blocks": [32, 64, 128]},
+            "cross_view": {"image_height": image, "image_width": image, "no_image_features": False, "skip": True, "heads": 4,
+                           "dim_head": 32, "qkv_bias": True},
+        },
+        "seg_head_dim": 32,
+        "output_class": 2,
+    }
+    if kind != "single":
+        cfg["max_cav"] = max_cav
+        cfg["sttf"] = {"resolution": 0.390625, "downsample_rate": 8, "use_roi_mask": True}
+    if kind == "swap_fuse":
+        cfg["swap_fusion"] = {"input_dim": 128, "mlp_dim": 256, "agent_size": max_cav, "window_size": 8, "dim_head": 32,
+                              "drop_out": 0.1, "depth": 3, "mask": True}
+    return cfg

@@ -162,13 +162,19 @@ int cobevt_attn_mlp_chain(const void* a, const void* skip, void* out, const void
  *   reverses of :409,:433; swap Attention core, swap_fusion_modules.py:93-123 with :172-190;
  *   FAX global Attention core, fax_modules.py:137-171.
  * dims (int32[40]): dtype, B, L(windows), heads, ldq, ldk, ldv, ldo, qoff, koff, voff, ooff,
- *   bias_mode(0/1), bias_rows, bias_L, mean_q, then three token maps {mode(0 window,1 grid,2 stored
+ *   bias_mode(0/1), bias_rows, bias_L, mean_q (0 none | 1 camera mean of per-camera query copies, fax_modules.py:243 | 2 per-camera
+ *   query copies scored against their own camera's keys under ONE softmax over all cameras: CVT CrossAttention,
+ *   cvt_modules.py:142-153), then three token maps {mode(0 window,1 grid,2 stored
  *   partitioned), ncam, HH, WW, w1, w2, X, Y} for q, k/v and out.  Head dim is 32.
  * bias_table fp32[bias_rows][heads] indexed ((dl+bias_L-1)(2w1-1)+(di+w1-1))(2w2-1)+(dj+w2-1);
  * mask fp32 (B,HH,WW,ncam) over the key map, 0 = masked (nullable).  `scale` multiplies QK^T.
  */
 int cobevt_window_attention(const void* q, const void* k, const void* v, void* out, const float* bias_table,
                             const float* mask, const int* dims, float scale, hipStream_t stream);
+
+/* out[b][i] = max over l of in[b][l][i] (F-Cooper max-out fusion over the max_cav agent slots, SpatialFusionMask,
+ * opv2v/opencood/models/fusion_modules/f_cooper_fuse.py:30-36).  in (B, L, per) contiguous, dtype 0 bf16 / 1 fp32, per % 8 == 0. */
+int cobevt_agent_max(const void* in, void* out, int dtype, int B, int L, long per, hipStream_t stream);
 
 /* Fused torchvision Bottleneck(128, 32) (1x1 128->32, 3x3 32->32, 1x1 32->128, eval BatchNorms folded, ReLUs, identity skip) on
  * a channels-last bf16 map: ResNetBottleNeck(dim) of the FAX pyramid, fax_modules.py:10,472,512.  w1 / w2 / w3: MFMA fragment

@@ -473,8 +473,39 @@ def gv13():
          keys=np.array([k for k in m.state_dict().keys() if k.startswith("naive_compressor.")]))
 
 
+def gv17():
+    """CVT baseline models at reduced size from the reference's own classes: CrossViewTransformer
+    (single agent), CrossViewTransformerSwapFuse, CrossViewTransformerFcooper + the per-agent CrossViewModule output."""
+    import copy
+    import oracle.cvt as o_cvt
+    from opencood.models.cross_view_transformer import CrossViewTransformer as R_Cvt
+    from opencood.models.cross_view_transformer_swap_fuse import CrossViewTransformerSwapFuse as R_CvtSwap
+    from opencood.models.cross_view_transformer_fcooper import CrossViewTransformerFcooper as R_CvtFcooper
+    out = {}
+    single = synth.opv2v_batch(agents=1, cams=2, image=128, max_cav=3, seed=cases.SEED)
+    single_b = {k: single[k] for k in ("inputs", "intrinsic", "extrinsic")}
+    multi = synth.opv2v_batch(agents=2, cams=2, image=128, max_cav=3, seed=cases.SEED)
+    for kind, cls, fwd, batch in (("single", R_Cvt, o_cvt.cross_view_transformer_forward, single_b),
+                                  ("swap_fuse", R_CvtSwap, o_cvt.cross_view_transformer_swap_fuse_forward, multi),
+                                  ("fcooper", R_CvtFcooper, o_cvt.cross_view_transformer_fcooper_forward, multi)):
+        cfg = synth.cvt_small_config(kind)
+        m = fill_module_(cls(copy.deepcopy(cfg)).eval(), cases.SEED)
+        ref = m(dict(batch))
+        got = fwd(m.state_dict(), cfg, dict(batch))
+        _close("CVT %s dynamic_seg" % kind, got["dynamic_seg"], ref["dynamic_seg"])
+        out[kind + "_dynamic_seg"] = _np(ref["dynamic_seg"])
+        out[kind + "_keys"] = np.array(list(m.state_dict().keys()))
+        out[kind + "_shapes"] = np.array([",".join(str(int(d)) for d in v.shape) for v in m.state_dict().values()])
+        if kind == "single":
+            feats = m.encoder(batch["inputs"])
+            cvm = m.cvm({"inputs": batch["inputs"], "intrinsic": batch["intrinsic"], "extrinsic": batch["extrinsic"], "features": feats})
+            _close("CrossViewModule", o_cvt.encode_agents(m.state_dict(), cfg, dict(batch)), cvm)
+            out["single_cvm"] = _np(cvm)
+    save("gv17_cvt_baselines", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gv0", "gv1", "gv2", "gv3", "gv4", "gv5", "gv6", "gv7", "gv8", "gv9", "gv10", "gv11", "gv12", "gv13", "gv14", "gv15", "gv16"]
+    which = sys.argv[1:] or ["gv0", "gv1", "gv2", "gv3", "gv4", "gv5", "gv6", "gv7", "gv8", "gv9", "gv10", "gv11", "gv12", "gv13", "gv14", "gv15", "gv16", "gv17"]
     for name in which:
         print("== " + name)
         globals()[name]()

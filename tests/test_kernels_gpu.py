@@ -641,6 +641,31 @@ def test_cross_window_attention(cuda, dtype, kmode, mean_q, variant):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,H,W,h,w", [(3, 8, 8, 5, 7), (2, 16, 8, 16, 16), (4, 4, 4, 24, 24)])
+def test_camera_paired_attention(cuda, dtype, n, H, W, h, w):
+    """mean_q = 2 (CVT CrossAttention, cvt_modules.py:142-153): camera c's query copy scores camera c's keys, one softmax over all
+    cameras' keys; key counts per camera that are not a multiple of the 64-key tile (35), equal to several tiles (256), and
+    ragged (576 = 9 tiles); keys addressed without a table (one window = the whole map)."""
+    B, heads, dh = 2, 2, 32
+    d = heads * dh
+    q = procedural_input("pair.q", (B, n, H * W, d), n)
+    k = procedural_input("pair.k", (B * n, h, w, d), n)
+    v = procedural_input("pair.v", (B * n, h, w, d), n)
+    out = torch.empty((B, H, W, d), device=cuda, dtype=dtype)
+    qmap, kmap, omap = ops.tokmap(0, n, H, W, H, W), ops.tokmap(0, n, h, w, h, w), ops.tokmap(0, 1, H, W, H, W)
+    ops.window_attention(q.to(cuda).to(dtype), k.to(cuda).to(dtype), v.to(cuda).to(dtype), out, qmap, kmap, omap, B, heads,
+                         dh ** -0.5, d, d, d, d, mean_q=2)
+    torch.cuda.synchronize()
+    qf = rnd(q, dtype).reshape(B, n, H * W, heads, dh).permute(0, 3, 1, 2, 4)            # b m n Q dh
+    kf = rnd(k, dtype).reshape(B, n, h * w, heads, dh).permute(0, 3, 1, 2, 4)            # b m n K dh
+    vf = rnd(v, dtype).reshape(B, n * h * w, heads, dh).permute(0, 2, 1, 3)              # b m (n K) dh
+    dot = dh ** -0.5 * torch.matmul(qf, kf.transpose(-1, -2))                            # b m n Q K
+    att = dot.permute(0, 1, 3, 2, 4).reshape(B, heads, H * W, n * h * w).softmax(-1)
+    ref = torch.matmul(att, vf).permute(0, 2, 1, 3).reshape(B, H, W, d)
+    check(out, ref, dtype, "camera-paired attention n=%d keys/cam=%d" % (n, h * w))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_prepartitioned_long_keys(cuda, dtype):
     """mode-2 (stored partitioned) maps, Nq = 1024 rows in one window, Nk = 1024 keys (16 key tiles)."""
     B, heads, dh = 1, 2, 32
@@ -779,6 +804,14 @@ def test_resident_attention_level0_shape_and_outlier_keys(cuda, nq_cams, mean):
     a = torch.matmul((torch.matmul(qf, kf.transpose(-1, -2)) * scale).softmax(-1), vf)
     a = a.permute(0, 2, 3, 1, 4).reshape(B, X, Y, nq_cams, W1, W2, d).mean(3)
     check(out, o_fax._window_reverse(a), dtype, "level-0 resident attention with outlier keys")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_agent_max(cuda, dtype):
+    x = procedural_input("amax.x", (2, 5, 9, 7, 32), 0)
+    y = ops.agent_max(x.to(cuda).to(dtype))
+    torch.cuda.synchronize()
+    assert torch.equal(y.float().cpu(), rnd(x, dtype).max(dim=1)[0])
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -338,3 +338,47 @@ def test_lidar_fusebevt_full_size(cuda):
     assert torch.isfinite(outs[0].float()).all()
     assert torch.equal(outs[0][:, :6], outs[1][:, :6])
     assert not torch.equal(outs[0][:, 6:], outs[1][:, 6:])
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize("kind,core", [("single", "cross_view_transformer"), ("swap_fuse", "cross_view_transformer_swap_fuse"),
+                                       ("fcooper", "cross_view_transformer_fcooper")])
+def test_cvt_baseline_models(cuda, dtype, tol, kind, core):
+    """the CVT baselines behind the reference's registry names, against the reference's own logits (gv17):
+    CVT per-agent encoder (camera-paired global cross attention), + swap fusion, + F-Cooper max-out."""
+    from cobevt_amd.registry import create_model
+    g = golden("gv17_cvt_baselines")
+    cfg = synth.cvt_small_config(kind)
+    m = dev(create_model({"model": {"core_method": core, "args": copy.deepcopy(cfg)}}), cuda)
+    agents = 1 if kind == "single" else 2
+    batch = synth.opv2v_batch(agents=agents, cams=2, image=128, max_cav=3, seed=cases.SEED)
+    b = {k: v.to(cuda) for k, v in batch.items()}
+    with host.compute_dtype(dtype):
+        out = m(dict(b))
+        if kind == "single":
+            feats = m.encoder(b["inputs"])
+            cvm = m.cvm({"inputs": b["inputs"], "intrinsic": b["intrinsic"], "extrinsic": b["extrinsic"], "features": feats})
+            assert_close(cvm, g["single_cvm"], 3e-2 if dtype == torch.bfloat16 else tol, "CrossViewModule")
+    assert out["dynamic_seg"].dtype == torch.float32
+    assert_close(out["dynamic_seg"], g[kind + "_dynamic_seg"], tol, "CVT %s logits" % kind)
+
+
+def test_cvt_full_config_vs_oracle(cuda):
+    """cvt_swap_fuse.yaml at its real size (2 agents x 4 cams x 512^2, 32x32 BEV queries against 4 x 64 x 64 and 4 x 16 x 16 keys -
+    the 16384-key attention runs without a key table) against the oracle on the host CPU."""
+    import oracle.cvt as o_cvt
+    from cobevt_amd.registry import create_model
+    cfg = synth.cvt_config("swap_fuse")
+    m = fill_module_(create_model({"model": {"core_method": "cross_view_transformer_swap_fuse", "args": copy.deepcopy(cfg)}}),
+                     cases.SEED).eval()
+    batch = synth.opv2v_batch(agents=2, seed=cases.SEED)
+    ref = o_cvt.cross_view_transformer_swap_fuse_forward(m.state_dict(), cfg, dict(batch))["dynamic_seg"]
+    m = m.to(cuda)
+    b = {k: v.to(cuda) for k, v in batch.items()}
+    with host.compute_dtype(torch.float32):
+        y32 = m(dict(b))["dynamic_seg"]
+    with host.compute_dtype(torch.bfloat16):
+        y16 = m(dict(b))["dynamic_seg"]
+    e32, e16 = rel_err(y32, ref), rel_err(y16, ref)
+    print("CVT swap-fuse full config: fp32 rel %.2e | bf16 rel %.2e" % (e32, e16))
+    assert e32 <= 1e-3 and e16 <= 5e-2

@@ -216,3 +216,25 @@ def test_gv13_naive_compressor():
     batch = synth.opv2v_batch(agents=2, cams=2, image=128, max_cav=3, seed=cases.SEED)
     out = o_model.corpbevt_forward(m.state_dict(), cfg, batch)
     assert_close(out["dynamic_seg"], g["dynamic_seg"], TOL, "CorpBEVT.small compression=2")
+
+
+@pytest.mark.parametrize("kind,core", [("single", "cross_view_transformer"), ("swap_fuse", "cross_view_transformer_swap_fuse"),
+                                       ("fcooper", "cross_view_transformer_fcooper")])
+def test_gv17_cvt_baselines(kind, core):
+    """CVT baseline models: the host mirrors' state_dict schema equals the reference's key for key, the
+    registry resolves the reference's core_method names, and the oracle reproduces the reference's logits."""
+    import oracle.cvt as o_cvt
+    from cobevt_amd.registry import create_model
+    g = golden("gv17_cvt_baselines")
+    cfg = synth.cvt_small_config(kind)
+    m = fill_module_(create_model({"model": {"core_method": core, "args": copy.deepcopy(cfg)}}), cases.SEED).eval()
+    sd = m.state_dict()
+    mine = {k: ",".join(str(int(d)) for d in v.shape) for k, v in sd.items()}
+    assert mine == dict(zip([str(k) for k in g[kind + "_keys"]], [str(v) for v in g[kind + "_shapes"]]))   # (registration order aside)
+    agents = 1 if kind == "single" else 2
+    batch = synth.opv2v_batch(agents=agents, cams=2, image=128, max_cav=3, seed=cases.SEED)
+    fwd = {"single": o_cvt.cross_view_transformer_forward, "swap_fuse": o_cvt.cross_view_transformer_swap_fuse_forward,
+           "fcooper": o_cvt.cross_view_transformer_fcooper_forward}[kind]
+    assert_close(fwd(sd, cfg, dict(batch))["dynamic_seg"], g[kind + "_dynamic_seg"], TOL, "CVT " + kind)
+    if kind == "single":
+        assert_close(o_cvt.encode_agents(sd, cfg, dict(batch)), g["single_cvm"], TOL, "CrossViewModule")
