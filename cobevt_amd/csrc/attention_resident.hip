@@ -81,7 +81,7 @@ template <int NT> struct ResLds {
 template <int NT, int NW, bool MEAN, bool BIAS, bool MASK, bool RAGGED>
 // Register budget: the plain variants keep 4 waves per SIMD (35 KB of LDS -> 4 workgroups per CU); with a bias table / mask the
 // LDS footprint (>= 56 KB for the shipped windows) allows 2 waves per SIMD at most, so those variants may use 256 VGPRs.
-__global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : 4) void attn_resident_kernel(AttnParams p, int qsplit) {
+__global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void attn_resident_kernel(AttnParams p, int qsplit) {
     using L = ResLds<NT>;
     constexpr int NKP = L::kNkp;
     constexpr int NTHR = NW * 64;
@@ -350,8 +350,13 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : 4) void attn_resident
                             for (int r = 0; r < 16; ++r) mneg[r] = -m_safe;
                             have_m = true;
                         }
-                        // ---- regular pass: P = exp2(S - m_run) straight from the MFMA result, packed to bf16, row sums
-                        f32x2 psv = {0.f, 0.f};
+                        // ---- regular pass: P = exp2(S - m_run) straight from the MFMA result, packed to bf16.  Row sums on the
+                        // matrix pipe too (it has the slack, the VALU does not): ones(32 x 16) . P^T sums the 16 keys of a k-block
+                        // for every query into all 16 accumulator rows - 4 MFMAs replace 32 v_add_f32 and the half-wave exchange
+                        f32x16 lt;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) lt[r] = 0.f;
+                        const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
 #pragma unroll
                         for (int s = 0; s < 2; ++s) {
                             const f32x16 st = scores(s, mneg);
@@ -359,16 +364,15 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : 4) void attn_resident
 #pragma unroll
                             for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(st[r]);
 #pragma unroll
-                            for (int r = 0; r < 16; r += 2) psv += f32x2{e[r], e[r + 1]};
-#pragma unroll
                             for (int u = 0; u < 2; ++u) {
                                 pb[s * 2 + u].x = pack_bf2(e[8 * u + 0], e[8 * u + 1]);
                                 pb[s * 2 + u].y = pack_bf2(e[8 * u + 2], e[8 * u + 3]);
                                 pb[s * 2 + u].z = pack_bf2(e[8 * u + 4], e[8 * u + 5]);
                                 pb[s * 2 + u].w = pack_bf2(e[8 * u + 6], e[8 * u + 7]);
+                                mfma_kgroup<bf16_t>(ones, pb[s * 2 + u], lt);
                             }
                         }
-                        psum = psv.x + psv.y;
+                        psum = lt[0];                       // the whole tile's row sum of this lane's query (both key halves)
                         // no per-tile maximum: the running maximum is kept as long as no probability of the tile exceeds
                         // 2^kHeadroomLog2 (fp32 / bf16 share the exponent range, so nothing is lost below that); inf / NaN
                         // fail the comparison too
@@ -386,7 +390,6 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : 4) void attn_resident
                     }
                 }
             }
-            l_run = xor32_sum(l_run);
             if (exact || !__any(!(l_run >= kTiny))) break;  // reference too far above this task's scores: redo it exactly
             }
             const float inv = 1.0f / l_run;                // an all-masked row yields NaN like the reference softmax
