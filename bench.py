@@ -234,6 +234,11 @@ def lidar_inputs(dev, seed=0):
     return x, mask.to(dev)
 
 
+def rt_nchw(y):
+    """(b, h, w, d) channels-last -> (b, d, h, w) view"""
+    return y.permute(0, 3, 1, 2)
+
+
 def run_lidar(args, rank, world, dev):
     enc = synth.fill_module_(host.SwapFusionEncoder(dict(LIDAR_ARGS)), 0).eval().to(dev)
     x, mask = lidar_inputs(dev, seed=rank)
@@ -247,6 +252,13 @@ def run_lidar(args, rank, world, dev):
         mine = sfm._to_blhwc(xf[:, rank * per:(rank + 1) * per].contiguous())
         step = lambda: pipe.step(mine, mask)                   # noqa: E731
         frames_per_step, scaling = 1, "strong"
+        with torch.no_grad():       # the sharded result must equal the single-process encoder on the whole map (bf16 rounding apart)
+            ref = enc(xf, mask)
+            got = rt_nchw(pipe.step(mine, mask))
+            torch.cuda.synchronize()
+            err = float(((got.float() - ref.float()).abs().max() / ref.float().abs().max()).item())
+        if err > 3e-2:
+            raise RuntimeError("rank %d: row-sharded FuseBEVT differs from the single-process encoder (rel %.3e)" % (rank, err))
         par = "row-sharded x%d: agent->band all-to-all, band<->grid all-to-all per half block, all-gather of fused bands" % world
         note = "channels-last compute-dtype agent maps resident on their owner GPU (agent-per-GPU), eager launches"
     else:
@@ -327,6 +339,14 @@ def main():
         graph_ok = timed.graphs is not None
         runner = timed
         frames_per_step = 1
+        # every rank must reproduce the un-sharded forward of the whole frame (agents are a pure batch dimension up to the gather;
+        # not bit for bit in bf16: the conv tile shapes - hence the summation order - are chosen per batch size)
+        ref = model(dict(batch))["dynamic_seg"]
+        got = timed.step()["dynamic_seg"]
+        torch.cuda.synchronize()
+        shard_check = float(((got - ref).abs().max() / ref.abs().max()).item())
+        if shard_check > (5e-2 if args.dtype == "bf16" else 1e-4):
+            raise RuntimeError("rank %d: frame-sharded output differs from the single-process forward (rel %.3e)" % (rank, shard_check))
     else:
         runner = pipeline.CapturedCorpBEVT(model, batch, rank, world, A, use_graph=False)
         ref_out = {k: v.clone() for k, v in runner.eager_step().items()}
