@@ -349,6 +349,8 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;  // an all-masked row yields NaN like the reference softmax
+    if (p.lse && q_ok && h == 0)     // training forward: what the backward kernel needs to recompute the probabilities
+        p.lse[(((size_t)b * p.L + l) * p.heads + head) * p.Nq + tq] = m_run + __builtin_amdgcn_logf(l_tot);
 #pragma unroll
     for (int r = 0; r < 16; ++r) ot[r] *= inv;
 
@@ -410,9 +412,9 @@ __global__ void attn_bias_index_dump_kernel(TokMap qm, TokMap km, int bias_L, in
 using namespace cobevt;
 
 // C-ABI entry point, see include/cobevt_hip.h
-extern "C" int cobevt_window_attention(const void* q, const void* k, const void* v, void* out,
-                                       const float* bias_table, const float* mask, const int* dims, float scale,
-                                       hipStream_t stream) {
+static int window_attention_impl(const void* q, const void* k, const void* v, void* out, float* lse,
+                                 const float* bias_table, const float* mask, const int* dims, float scale,
+                                 hipStream_t stream) {
     // dims: [dtype, B, L, heads, ldq, ldk, ldv, ldo, qoff, koff, voff, ooff, bias_mode, bias_rows, bias_L,
     //        mean_q, qmap[8], kmap[8], omap[8]]
     if (!q || !k || !v || !out || !dims) return COBEVT_ERR_ARG;
@@ -427,7 +429,7 @@ extern "C" int cobevt_window_attention(const void* q, const void* k, const void*
     p.bias_mode = dims[12]; p.bias_rows = dims[13]; p.bias_L = dims[14];
     p.mean_q = dims[15];
     p.qmap = read_map(dims + 16); p.kmap = read_map(dims + 24); p.omap = read_map(dims + 32);
-    p.bias_table = bias_table; p.mask = mask; p.scale = scale;
+    p.bias_table = bias_table; p.mask = mask; p.scale = scale; p.lse = lse;
     if (dtype != 0 && dtype != 1) return COBEVT_ERR_ARG;
     if (!map_ok(p.qmap) || !map_ok(p.kmap) || !map_ok(p.omap)) return COBEVT_ERR_SHAPE;
     if (p.B < 1 || p.heads < 1 || p.L != p.qmap.X * p.qmap.Y || p.L != p.kmap.X * p.kmap.Y) return COBEVT_ERR_SHAPE;
@@ -444,7 +446,8 @@ extern "C" int cobevt_window_attention(const void* q, const void* k, const void*
     }
     // keys of a single window that covers the whole map are rows b * Nk + tk: no table (CVT attends to 4 x 64 x 64 keys)
     p.klinear = (p.kmap.mode != 2 && p.kmap.X == 1 && p.kmap.Y == 1 && !p.bias_mode && !mask) ? 1 : 0;
-    if (dtype == 0 && variant != 1 && p.mean_q != 2) {
+    if (lse && p.mean_q) return COBEVT_ERR_UNSUPPORTED;     // (the training path averages cameras outside the kernel)
+    if (dtype == 0 && variant != 1 && p.mean_q != 2 && !lse) {
         const int rc = launch_attn_resident(p, qsplit_hint, stream);
         if (rc >= 0) return rc;
     }
@@ -472,6 +475,20 @@ extern "C" int cobevt_window_attention(const void* q, const void* k, const void*
     else COBEVT_ATTN_LAUNCH(float);
 #undef COBEVT_ATTN_LAUNCH
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// C-ABI entry points, see include/cobevt_hip.h
+extern "C" int cobevt_window_attention(const void* q, const void* k, const void* v, void* out,
+                                       const float* bias_table, const float* mask, const int* dims, float scale,
+                                       hipStream_t stream) {
+    return window_attention_impl(q, k, v, out, nullptr, bias_table, mask, dims, scale, stream);
+}
+
+extern "C" int cobevt_window_attention_lse(const void* q, const void* k, const void* v, void* out, float* lse,
+                                           const float* bias_table, const float* mask, const int* dims, float scale,
+                                           hipStream_t stream) {
+    if (!lse) return COBEVT_ERR_ARG;
+    return window_attention_impl(q, k, v, out, lse, bias_table, mask, dims, scale, stream);
 }
 
 // Test hooks (tests/test_kernels_gpu.py: bit-exact against tests/golden/gv1_index_maps.npz), see include/cobevt_hip.h

@@ -1,0 +1,280 @@
+// Backward of the gathered window / dilated-grid attention (fp32 storage, exact-fp32 MFMA): dQ, dK, dV (+ the gradient of the
+// relative-position bias table) for cobevt_window_attention, with the probabilities recomputed from the saved log-sum-exp.
+//
+// First slice of the training path (the reference trains through torch autograd: the einsum -> softmax ->
+// einsum of fax_modules.py:219-237 and swap_fusion_modules.py:100-121 under train_camera.py:143-179).  For one (window, head):
+//     P = softmax(scale * Q K^T + bias (+ mask)),  O = P V
+//     dV = P^T dO,   dP = dO V^T,   dZ = P o (dP - rowsum(dO o O)),   dQ = scale * dZ K,   dK = scale * dZ^T Q,   dbias = dZ
+// Work decomposition: one workgroup = (batch, window, head, 32-key tile); its four waves walk the window's 32-query tiles.  With
+// D = A.B on v_mfma_f32_32x32x2_f32 a lane owns one COLUMN of the 32 x 32 result, so
+//   * S = Q K^T and dP = dO V^T are computed with lane = key: the key's K / V rows are the B operands and stay in registers for
+//     the whole kernel; P, dP, dZ live as [query row registers][key lane];
+//   * dV^T += dO^T P and dK^T += Q^T dZ contract over the query rows: the A operands are read (transposed, for free: a lane reads
+//     one element) from the wave's LDS copies of the dO / Q tiles, the B operand is the P / dZ register itself - the two half-waves
+//     supply rows (j & 3) + 8 (j >> 2) + 4 half in step j, on both operands;
+//   * dQ += dZ K contracts over the keys, i.e. over the lanes: dZ makes one round trip through a wave-private LDS tile to become an
+//     A operand; the result is added to dq with fp32 atomics (the other key tiles of the window add to the same rows);
+//   * dK / dV rows belong to this workgroup alone (a key token is in exactly one window): the four waves' partial sums are reduced
+//     through LDS and stored plainly.
+// The partitions / reverses are the forward's index arithmetic (attn_common.hpp); dq must be zero-initialised by the caller.
+#include "attn_common.hpp"
+
+namespace cobevt {
+
+struct AttnBwdParams {
+    AttnParams a;             // q, k, v, out (= O of the forward), maps, bias / mask, scale, lse (base-2, [B][L][heads][Nq])
+    const float* dout;        // same layout as out
+    float* dq;                // same layouts as q / k / v (ld and column offsets shared with the forward tensors)
+    float* dk;
+    float* dv;
+    float* dbias;             // [bias_rows][heads], zero-initialised by the caller (nullable without bias)
+};
+
+namespace {
+
+constexpr int kPad = 33;      // floats per row of the 32 x 32 LDS tiles
+constexpr float kLog2eB = 1.4426950408889634f;
+
+template <bool BIAS, bool MASK>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdParams bp) {
+    const AttnParams& p = bp.a;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = (float*)smem_raw;
+    float* Ks = smem;                                   // [32][33] this tile's K rows (head slice)
+    float* wbase = smem + 32 * kPad;                    // per wave: Qs, dOs, dSs [32][33] + lse, D, qrow, obias [32] each
+    constexpr int kWaveFloats = 3 * 32 * kPad + 4 * 32;
+    float* red = wbase + 4 * kWaveFloats;               // [3][16][64] cross-wave reduction of dK^T / dV^T
+    float* bias_col = red + 3 * 16 * 64;                // [bias_rows] forward bias (x log2e)   (BIAS)
+    float* dtab = bias_col + (BIAS ? p.bias_rows : 0);  // [bias_rows] gradient accumulator      (BIAS)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, ql = lane & 31;
+    const int b = blockIdx.z, kt = blockIdx.y;
+    const int l = blockIdx.x / p.heads, head = blockIdx.x - l * p.heads;
+    float* Qs = wbase + wave * kWaveFloats;
+    float* dOs = Qs + 32 * kPad;
+    float* dSs = dOs + 32 * kPad;
+    float* lse_s = dSs + 32 * kPad;
+    float* D_s = lse_s + 32;
+    int* qrow_s = (int*)(D_s + 32);
+    int* qb_s = qrow_s + 32;
+
+    // ---- this lane's key: K / V rows as B operands (element 2 i + half of step i), mask, bias key term
+    const int tk = kt * 32 + ql;
+    const bool k_in = tk < p.Nk;
+    const TokCoord kc = tok_coord(p.kmap, k_in ? tk : 0);
+    const size_t krow = tok_row(p.kmap, b, l, kc);
+    bool k_ok = k_in;
+    if (MASK && k_in) {
+        if (p.kmap.mode == 2) {
+            k_ok = p.mask[((((size_t)b * p.L + l) * p.kmap.w1 + kc.i) * p.kmap.w2 + kc.j) * p.kmap.ncam + kc.cam] != 0.f;
+        } else {
+            int ph, pw;
+            tok_pixel(p.kmap, l, kc, ph, pw);
+            k_ok = p.mask[(((size_t)b * p.kmap.HH + ph) * p.kmap.WW + pw) * p.kmap.ncam + kc.cam] != 0.f;
+        }
+    }
+    const int kterm = BIAS ? rel_bias_key_term(p.kmap, kc) : 0;
+    float kreg[16], vreg[16];
+    {
+        const float* kr = (const float*)p.k + krow * p.ldk + p.koff + head * 32 + h;
+        const float* vr = (const float*)p.v + krow * p.ldv + p.voff + head * 32 + h;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            kreg[i] = k_in ? kr[2 * i] : 0.f;
+            vreg[i] = k_in ? vr[2 * i] : 0.f;
+        }
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Ks[ql * kPad + 2 * i + h] = kreg[i];
+    }
+    if (BIAS) {
+        for (int i = tid; i < p.bias_rows; i += 256) {
+            bias_col[i] = p.bias_table[(size_t)i * p.heads + head] * kLog2eB;
+            dtab[i] = 0.f;
+        }
+    }
+    __syncthreads();
+
+    f32x16 dKT, dVT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dKT[r] = 0.f; dVT[r] = 0.f; }
+    const float sl2 = p.scale * kLog2eB;
+    const int nqt = (p.Nq + 31) / 32;
+    const int nit = (nqt + 3) / 4;                      // uniform trip count: the loop contains workgroup barriers
+    for (int it = 0; it < nit; ++it) {
+        const int qt = it * 4 + wave;
+        const bool t_ok = qt < nqt;
+        // ---- stage the Q and dO tiles (two lanes per query row, 16 floats each), D = rowsum(dO o O), lse, row indices
+        {
+            const int r = lane >> 1, half = lane & 1;
+            const int tq = qt * 32 + r;
+            const bool ok = t_ok && tq < p.Nq;
+            const TokCoord qc = tok_coord(p.qmap, ok ? tq : 0);
+            const size_t qrow = tok_row(p.qmap, b, l, qc);
+            const size_t orow = tok_row(p.omap, b, l, qc);
+            const float* qp = (const float*)p.q + qrow * p.ldq + p.qoff + head * 32 + half * 16;
+            const float* op = (const float*)p.out + orow * p.ldo + p.ooff + head * 32 + half * 16;
+            const float* dp = bp.dout + orow * p.ldo + p.ooff + head * 32 + half * 16;
+            float dsum = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 qv = ok ? *(const float4*)(qp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 dv = ok ? *(const float4*)(dp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 ov = ok ? *(const float4*)(op + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float* qd = Qs + r * kPad + half * 16 + 4 * c;
+                float* dd = dOs + r * kPad + half * 16 + 4 * c;
+                qd[0] = qv.x; qd[1] = qv.y; qd[2] = qv.z; qd[3] = qv.w;
+                dd[0] = dv.x; dd[1] = dv.y; dd[2] = dv.z; dd[3] = dv.w;
+                dsum += dv.x * ov.x + dv.y * ov.y + dv.z * ov.z + dv.w * ov.w;
+            }
+            dsum += __shfl_xor(dsum, 1, 64);
+            if (half == 0) {
+                D_s[r] = dsum;
+                // invalid rows: lse = +inf -> P = exp2(-inf) = 0
+                lse_s[r] = ok ? p.lse[(((size_t)b * p.L + l) * p.heads + head) * p.Nq + tq] : INFINITY;
+                qrow_s[r] = ok ? (int)qrow : -1;
+                qb_s[r] = BIAS ? rel_bias_query_term(p.kmap, p.bias_L, qc) : 0;
+            }
+        }
+        __syncthreads();
+        // ---- S = Q K^T and dP = dO V^T  (lane = key column, register r <-> query row (r & 3) + 8 (r >> 2) + 4 h)
+        f32x16 S, dP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            S = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[ql * kPad + 2 * i + h], kreg[i], S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_32x32x2f32(dOs[ql * kPad + 2 * i + h], vreg[i], dP, 0, 0, 0);
+        }
+        // ---- P = exp2(z log2e - lse2),  dZ = P (dP - D)
+        f32x16 P, dZ;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, lane);
+            float z = S[r] * sl2;
+            int bidx = 0;
+            if (BIAS) { bidx = qb_s[row] - kterm; z += bias_col[k_ok ? bidx : 0]; }
+            const float pr = k_ok ? __builtin_amdgcn_exp2f(z - lse_s[row]) : 0.f;
+            P[r] = pr;
+            dZ[r] = pr * (dP[r] - D_s[row]);
+            if (BIAS && k_ok && dZ[r] != 0.f) atomicAdd(&dtab[bidx], dZ[r]);
+        }
+        // ---- dV^T += dO^T P,  dK^T += Q^T dZ  (contraction over the query rows; step j pairs rows qj(0) and qj(1))
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int qj = (j & 3) + 8 * (j >> 2) + 4 * h;
+            dVT = __builtin_amdgcn_mfma_f32_32x32x2f32(dOs[qj * kPad + ql], P[j], dVT, 0, 0, 0);
+            dKT = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[qj * kPad + ql], dZ[j], dKT, 0, 0, 0);
+        }
+        // ---- dQ += dZ K : dZ through LDS to become the A operand (rows = queries, contraction over the keys = lanes)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dSs[acc_row(r, lane) * kPad + ql] = dZ[r];
+        __syncthreads();
+        f32x16 dQ;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dQ[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            dQ = __builtin_amdgcn_mfma_f32_32x32x2f32(dSs[ql * kPad + 2 * j + h], Ks[(2 * j + h) * kPad + ql], dQ, 0, 0, 0);
+        // dQ: lane = dh column, register r <-> query row
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = qrow_s[acc_row(r, lane)];
+            if (qr >= 0) atomicAdd(bp.dq + (size_t)qr * p.ldq + p.qoff + head * 32 + ql, dQ[r] * p.scale);
+        }
+        __syncthreads();                                // the next iteration overwrites the wave tiles
+    }
+
+    // ---- reduce dK^T / dV^T over the four waves, store (lane = key column, register r <-> dh row)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (wave > 0) {
+            red[((wave - 1) * 16 + r) * 64 + lane] = dKT[r];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dKT[r] += red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (wave > 0) red[((wave - 1) * 16 + r) * 64 + lane] = dVT[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dVT[r] += red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane];
+        if (k_in) {
+            float* dkr = bp.dk + krow * p.ldk + p.koff + head * 32 + 4 * h;
+            float* dvr = bp.dv + krow * p.ldv + p.voff + head * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {               // dh rows 8 g + 4 h .. + 3
+                *(float4*)(dkr + 8 * g) = make_float4(dKT[4 * g] * p.scale, dKT[4 * g + 1] * p.scale, dKT[4 * g + 2] * p.scale,
+                                                      dKT[4 * g + 3] * p.scale);
+                *(float4*)(dvr + 8 * g) = make_float4(dVT[4 * g], dVT[4 * g + 1], dVT[4 * g + 2], dVT[4 * g + 3]);
+            }
+        }
+    }
+    if (BIAS) {
+        __syncthreads();
+        for (int i = tid; i < p.bias_rows; i += 256) {
+            const float g = dtab[i];
+            if (g != 0.f) atomicAdd(bp.dbias + (size_t)i * p.heads + head, g);
+        }
+    }
+}
+
+}  // namespace
+}  // namespace cobevt
+
+using namespace cobevt;
+
+// C-ABI entry point, see include/cobevt_hip.h
+extern "C" int cobevt_window_attention_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
+                                           const void* dout, void* dq, void* dk, void* dv, float* dbias,
+                                           const float* bias_table, const float* mask, const int* dims, float scale,
+                                           hipStream_t stream) {
+    if (!q || !k || !v || !out || !lse || !dout || !dq || !dk || !dv || !dims) return COBEVT_ERR_ARG;
+    AttnBwdParams bp;
+    AttnParams& p = bp.a;
+    const int dtype = dims[0] & 0xff;
+    if (dtype != 1) return COBEVT_ERR_UNSUPPORTED;          // fp32 storage (the parity / training mode)
+    p.q = q; p.k = k; p.v = v; p.out = const_cast<void*>(out);
+    p.B = dims[1]; p.L = dims[2]; p.heads = dims[3];
+    p.ldq = dims[4]; p.ldk = dims[5]; p.ldv = dims[6]; p.ldo = dims[7];
+    p.qoff = dims[8]; p.koff = dims[9]; p.voff = dims[10]; p.ooff = dims[11];
+    p.bias_mode = dims[12]; p.bias_rows = dims[13]; p.bias_L = dims[14];
+    p.mean_q = dims[15];
+    p.qmap = read_map(dims + 16); p.kmap = read_map(dims + 24); p.omap = read_map(dims + 32);
+    p.bias_table = bias_table; p.mask = mask; p.scale = scale; p.lse = const_cast<float*>(lse); p.klinear = 0;
+    bp.dout = (const float*)dout; bp.dq = (float*)dq; bp.dk = (float*)dk; bp.dv = (float*)dv; bp.dbias = dbias;
+    if (!map_ok(p.qmap) || !map_ok(p.kmap) || !map_ok(p.omap)) return COBEVT_ERR_SHAPE;
+    if (p.B < 1 || p.heads < 1 || p.L != p.qmap.X * p.qmap.Y || p.L != p.kmap.X * p.kmap.Y) return COBEVT_ERR_SHAPE;
+    if (p.mean_q || p.omap.ncam != p.qmap.ncam) return COBEVT_ERR_UNSUPPORTED;   // (camera mean: done outside the kernel when training)
+    if (p.bias_mode && (!bias_table || !dbias || p.bias_rows < 1 || p.bias_L < 1)) return COBEVT_ERR_ARG;
+    if ((p.ldq | p.ldk | p.ldv | p.ldo | p.qoff | p.koff | p.voff | p.ooff) % 4) return COBEVT_ERR_SHAPE;
+    p.Nq = p.qmap.ncam * p.qmap.w1 * p.qmap.w2;
+    p.Nk = p.kmap.ncam * p.kmap.w1 * p.kmap.w2;
+    const dim3 grid(p.L * p.heads, (p.Nk + 31) / 32, p.B), block(256);
+    if (grid.y > 65535 || grid.z > 65535) return COBEVT_ERR_SHAPE;
+    size_t lds = (size_t)(32 * kPad + 4 * (3 * 32 * kPad + 4 * 32) + 3 * 16 * 64) * 4;
+    if (p.bias_mode) lds += (size_t)p.bias_rows * 8;
+    if (lds > 160 * 1024) return COBEVT_ERR_UNSUPPORTED;
+    const bool hb = p.bias_mode != 0, hm = mask != nullptr;
+#define COBEVT_BWD_LAUNCH(B_, M_)                                                                                              \
+    do {                                                                                                                       \
+        static bool attr = false;                                                                                              \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<B_, M_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL((attn_bwd_kernel<B_, M_>), grid, block, lds, stream, bp);                                          \
+    } while (0)
+    if (hb && hm) COBEVT_BWD_LAUNCH(true, true);
+    else if (hb) COBEVT_BWD_LAUNCH(true, false);
+    else if (hm) COBEVT_BWD_LAUNCH(false, true);
+    else COBEVT_BWD_LAUNCH(false, false);
+#undef COBEVT_BWD_LAUNCH
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}

@@ -69,6 +69,7 @@ struct AttnParams {
     int mean_q;               // 0: every query token on its own; 1: per-camera query copies, outputs averaged over the cameras
                               // (fax_modules.py:243); 2: per-camera query copies, camera c's query scores camera c's keys only,
                               // ONE softmax over all cameras' keys (CVT CrossAttention, cvt_modules.py:142-153)
+    float* lse;               // training forward: base-2 log-sum-exp of every query's logits, [B][L][heads][Nq] (nullable)
     int klinear;              // streaming kernel: key token tk of the (single) window is row b * Nk + tk - no key table in LDS
 };
 

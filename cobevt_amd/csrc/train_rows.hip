@@ -1,0 +1,146 @@
+// Row-local backward kernels of the training slice (fp32): LayerNorm backward and exact-erf GELU forward / backward.
+// The reference gets these from torch autograd (nn.LayerNorm / nn.GELU of base_transformer.py:102-124,
+// swap_fusion_modules.py:275-279, fax_modules.py:189-191,309-313) under train_camera.py:143-179.  HBM-bound elementwise work:
+// one wave per row, 16-byte accesses, the per-channel sums (dgamma, dbeta) accumulated in registers over a workgroup's rows
+// and added to the global fp32 vectors once per workgroup.
+#include "common.hpp"
+
+namespace cobevt {
+namespace {
+
+constexpr int kLnMaxPerLane = 4;                         // float4 groups per lane: C <= 64 * 4 * 4 = 1024
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// y = LN(x) gamma + beta.  dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma; dgamma += dy xhat; dbeta += dy.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ gamma, float* __restrict__ dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C,
+                                                            float eps, int rows_per_block) {
+    __shared__ float red[2][4][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int groups = C >> 2;                           // float4 groups per row
+    float4 gam[kLnMaxPerLane], dg[kLnMaxPerLane], db[kLnMaxPerLane];
+#pragma unroll
+    for (int i = 0; i < kLnMaxPerLane; ++i) {
+        const int g = lane + 64 * i;
+        gam[i] = (gamma && g < groups) ? *(const float4*)(gamma + 4 * g) : make_float4(1.f, 1.f, 1.f, 1.f);
+        dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int row0 = blockIdx.x * rows_per_block;
+    const int row1 = min(rows, row0 + rows_per_block);
+    const float invC = 1.f / (float)C;
+    for (int row = row0 + wave; row < row1; row += 4) {
+        float4 xv[kLnMaxPerLane], dv[kLnMaxPerLane];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < kLnMaxPerLane; ++i) {
+            const int g = lane + 64 * i;
+            const bool ok = g < groups;
+            xv[i] = ok ? *(const float4*)(x + (size_t)row * C + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            dv[i] = ok ? *(const float4*)(dy + (size_t)row * C + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += xv[i].x + xv[i].y + xv[i].z + xv[i].w;
+        }
+        const float mean = wave_sum(s) * invC;
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < kLnMaxPerLane; ++i) {
+            if (lane + 64 * i < groups) {
+                const float a = xv[i].x - mean, b = xv[i].y - mean, c = xv[i].z - mean, d = xv[i].w - mean;
+                v += a * a + b * b + c * c + d * d;
+            }
+        }
+        const float rstd = 1.f / sqrtf(wave_sum(v) * invC + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < kLnMaxPerLane; ++i) {
+            if (lane + 64 * i < groups) {
+                // xv becomes xhat, dv becomes g = dy gamma
+                xv[i].x = (xv[i].x - mean) * rstd; xv[i].y = (xv[i].y - mean) * rstd;
+                xv[i].z = (xv[i].z - mean) * rstd; xv[i].w = (xv[i].w - mean) * rstd;
+                dg[i].x += dv[i].x * xv[i].x; dg[i].y += dv[i].y * xv[i].y; dg[i].z += dv[i].z * xv[i].z; dg[i].w += dv[i].w * xv[i].w;
+                db[i].x += dv[i].x; db[i].y += dv[i].y; db[i].z += dv[i].z; db[i].w += dv[i].w;
+                dv[i].x *= gam[i].x; dv[i].y *= gam[i].y; dv[i].z *= gam[i].z; dv[i].w *= gam[i].w;
+                sg += dv[i].x + dv[i].y + dv[i].z + dv[i].w;
+                sgx += dv[i].x * xv[i].x + dv[i].y * xv[i].y + dv[i].z * xv[i].z + dv[i].w * xv[i].w;
+            }
+        }
+        const float mg = wave_sum(sg) * invC, mgx = wave_sum(sgx) * invC;
+#pragma unroll
+        for (int i = 0; i < kLnMaxPerLane; ++i) {
+            const int g = lane + 64 * i;
+            if (g < groups) {
+                float4 o;
+                o.x = rstd * (dv[i].x - mg - xv[i].x * mgx); o.y = rstd * (dv[i].y - mg - xv[i].y * mgx);
+                o.z = rstd * (dv[i].z - mg - xv[i].z * mgx); o.w = rstd * (dv[i].w - mg - xv[i].w * mgx);
+                *(float4*)(dx + (size_t)row * C + 4 * g) = o;
+            }
+        }
+    }
+    if (!dgamma) return;
+    // workgroup reduction of the per-channel sums, then one atomic per channel
+#pragma unroll
+    for (int i = 0; i < kLnMaxPerLane; ++i) {
+        const int g = lane + 64 * i;
+        if (g < groups) {
+            *(float4*)&red[0][wave][4 * g] = dg[i];
+            *(float4*)&red[1][wave][4 * g] = db[i];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+__global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out,
+                                                   long n4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = ((const float4*)x)[i];
+    float4 o;
+    if (dy) {
+        const float4 d = ((const float4*)dy)[i];
+        o = make_float4(d.x * gelu_grad(v.x), d.y * gelu_grad(v.y), d.z * gelu_grad(v.z), d.w * gelu_grad(v.w));
+    } else {
+        o = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+    }
+    ((float4*)out)[i] = o;
+}
+
+}  // namespace
+}  // namespace cobevt
+
+using namespace cobevt;
+
+// C-ABI entry points, see include/cobevt_hip.h
+extern "C" int cobevt_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                                    int rows, int C, float eps, hipStream_t stream) {
+    if (!x || !dy || !dx || ((dgamma == nullptr) != (dbeta == nullptr))) return COBEVT_ERR_ARG;
+    if (rows < 1 || C < 4 || C % 4 || C > 1024) return COBEVT_ERR_SHAPE;
+    // enough workgroups to fill the chip, few enough that the per-channel atomics stay cheap
+    int rpb = (rows + 1023) / 1024;
+    rpb = ((rpb + 3) / 4) * 4;
+    const int blocks = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, stream, x, dy, gamma, dx, dgamma, dbeta, rows, C, eps, rpb);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+extern "C" int cobevt_gelu(const float* x, const float* dy, float* out, long n, hipStream_t stream) {
+    if (!x || !out) return COBEVT_ERR_ARG;
+    if (n < 4 || n % 4) return COBEVT_ERR_SHAPE;
+    const long n4 = n / 4;
+    hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, dy, out, n4);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}

@@ -4,6 +4,7 @@ import torch.nn as nn
 
 from .. import ops
 from . import runtime as rt
+from . import training
 from .runtime import HipModule
 
 
@@ -20,6 +21,10 @@ class PreNormResidual(HipModule):
         return self.fn.forward_fused(x, residual=x, ln=self.norm, **kwargs)
 
     def forward(self, x, **kwargs):
+        if self.training:
+            if isinstance(self.fn, FeedForward):
+                return training.feed_forward(self.fn, x, norm=self.norm)
+            return training.swap_attention(self.fn, x, kwargs.get("mask"), 2, norm=self.norm)
         self._require_inference(x)
         return rt.like_input(self.forward_fused(rt.as_compute(x), **kwargs), x)
 
@@ -37,5 +42,7 @@ class FeedForward(HipModule):
         return ops.linear(t, rt.linear_plan(self, "fc2", self.net[3]), residual=residual)
 
     def forward(self, x):
+        if self.training:
+            return training.feed_forward(self, x)
         self._require_inference(x)
         return rt.like_input(self.forward_fused(rt.as_compute(x)), x)

@@ -13,6 +13,7 @@ import torch.nn as nn
 from .. import ops
 from ..lib import CobevtHipError
 from . import runtime as rt
+from . import training
 from .runtime import HipModule
 
 
@@ -134,6 +135,8 @@ class Attention(HipModule):
         return ops.linear(a, rt.linear_plan(self, "out", self.to_out[0]), out=out)
 
     def forward(self, x):
+        if self.training:
+            return training.global_attention(self, x)
         self._require_inference(x)
         return rt.like_input(rt.nchw_view(self.forward_nhwc(rt.to_nhwc(x))), x)
 
@@ -193,6 +196,8 @@ class CrossWinAttention(HipModule):
 
     def forward(self, q, k, v, skip=None):
         """q: (b n X Y W1 W2 d); k, v: (b n x y w1 w2 d); skip (b X Y W1 W2 d) -> (b X Y W1 W2 d)"""
+        if self.training:
+            return training.cross_win_attention(self, q, k, v, skip)
         self._require_inference(q, k, v, skip)
         assert k.shape == v.shape
         b, n, X, Y, W1, W2, _ = q.shape

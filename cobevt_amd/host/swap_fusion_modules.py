@@ -12,6 +12,7 @@ import torch.nn as nn
 from .. import ops
 from ..lib import CobevtHipError
 from . import runtime as rt
+from . import training
 from .base_transformer import FeedForward, PreNormResidual
 from .runtime import HipModule
 
@@ -73,6 +74,8 @@ class Attention(HipModule):
 
     def forward(self, x, mask=None):
         """x: (b, l, X, Y, w1, w2, c); mask: (b, X, Y, w1, w2, 1, l) or None"""
+        if self.training:
+            return training.swap_attention(self, x, mask, 2)
         self._require_inference(x, mask)
         return rt.like_input(self.forward_fused(rt.as_compute(x), mask=mask, mode=2), x)
 
@@ -131,6 +134,8 @@ class SwapFusionBlockMask(HipModule):
 
     def forward(self, x, mask):
         """x: (b, l, c, h, w); mask: (b, h, w, 1, l)"""
+        if self.training:
+            return training.swap_fusion_block(self, x, mask)
         self._require_inference(x, mask)
         return rt.like_input(_from_blhwc(self.forward_blhwc(_to_blhwc(x), mask)), x)
 
@@ -159,6 +164,8 @@ class SwapFusionBlock(HipModule):
         return _run_stages(self.stages(), x, lambda i: None)
 
     def forward(self, x, mask=None):
+        if self.training:
+            return training.swap_fusion_block(self, x, None)
         self._require_inference(x)
         return rt.like_input(_from_blhwc(self.forward_blhwc(_to_blhwc(x))), x)
 
@@ -197,7 +204,10 @@ class SwapFusionEncoder(HipModule):
         return y.reshape(b, h, w, d)
 
     def forward(self, x, mask=None):
-        """x: (b, m, d, h, w); mask: (b, h, w, 1, m) -> (b, d, h, w)"""
+        """x: (b, m, d, h, w); mask: (b, h, w, 1, m) -> (b, d, h, w).  In train() mode: the differentiable fp32 graph of
+        host/training.py (HIP attention / LayerNorm / GELU kernels in both directions)."""
+        if self.training:
+            return training.swap_fusion_encoder(self, x, mask)
         self._require_inference(x, mask)
         return rt.like_input(rt.nchw_view(self.forward_blhwc(_to_blhwc(x), mask)), x)
 

@@ -33,6 +33,10 @@ SIGNATURES = {
     "cobevt_linear_rows": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_long_p, ctypes.c_float, _vp]),
     "cobevt_attn_mlp_chain": (ctypes.c_int, [_vp] * 14 + [_c_int_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
     "cobevt_window_attention": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int_p, ctypes.c_float, _vp]),
+    "cobevt_window_attention_lse": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int_p, ctypes.c_float, _vp]),
+    "cobevt_layernorm_bwd": (ctypes.c_int, [_vp] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp]),
+    "cobevt_gelu": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_long, _vp]),
+    "cobevt_window_attention_bwd": (ctypes.c_int, [_vp] * 12 + [_c_int_p, ctypes.c_float, _vp]),
     "cobevt_layernorm": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                         ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_int, _vp]),
     "cobevt_fax_ray_embed": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,

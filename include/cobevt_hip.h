@@ -172,6 +172,26 @@ int cobevt_attn_mlp_chain(const void* a, const void* skip, void* out, const void
 int cobevt_window_attention(const void* q, const void* k, const void* v, void* out, const float* bias_table,
                             const float* mask, const int* dims, float scale, hipStream_t stream);
 
+/* Training slice (fp32 storage, dims[0] dtype = 1).  cobevt_window_attention_lse: the forward above that also stores the base-2
+ * log-sum-exp of every query's logits, lse[B][L][heads][Nq] (mean_q must be 0).  cobevt_window_attention_bwd: given the forward
+ * tensors, `out`, lse and dout (layout of out), writes dk, dv (layouts of k, v), ADDS dq into a zero-initialised buffer
+ * (layout of q) and ADDS the bias-table gradient into dbias[bias_rows][heads] (zero-initialised; nullable without bias).
+ * Replaces torch autograd through the einsum / softmax / einsum of fax_modules.py:219-237, swap_fusion_modules.py:100-121
+ * (train_camera.py:143-179 loss.backward()). */
+int cobevt_window_attention_lse(const void* q, const void* k, const void* v, void* out, float* lse, const float* bias_table,
+                                const float* mask, const int* dims, float scale, hipStream_t stream);
+int cobevt_window_attention_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
+                                const void* dout, void* dq, void* dk, void* dv, float* dbias, const float* bias_table,
+                                const float* mask, const int* dims, float scale, hipStream_t stream);
+
+/* Row-local backward kernels of the training slice (fp32).  cobevt_layernorm_bwd: x, dy (rows, C) -> dx; ADDS dy * xhat / dy
+ * column sums into zero-initialised dgamma[C] / dbeta[C] (both nullable together); gamma nullable (= 1).  C % 4 == 0, C <= 1024.
+ * cobevt_gelu: out = GELU(x) (dy null) or dy * GELU'(x) (exact erf form, nn.GELU()); n % 4 == 0.
+ * (nn.LayerNorm / nn.GELU under autograd: base_transformer.py:102-124, swap_fusion_modules.py:275-279, fax_modules.py:189-191.) */
+int cobevt_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, int rows,
+                         int C, float eps, hipStream_t stream);
+int cobevt_gelu(const float* x, const float* dy, float* out, long n, hipStream_t stream);
+
 /* out[b][i] = max over l of in[b][l][i] (F-Cooper max-out fusion over the max_cav agent slots, SpatialFusionMask,
  * opv2v/opencood/models/fusion_modules/f_cooper_fuse.py:30-36).  in (B, L, per) contiguous, dtype 0 bf16 / 1 fp32, per % 8 == 0. */
 int cobevt_agent_max(const void* in, void* out, int dtype, int B, int L, long per, hipStream_t stream);

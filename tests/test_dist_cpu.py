@@ -185,3 +185,50 @@ def test_row_sharded_fusebevt_gloo(world):
     (i, x_local) re-ordered rows (one all-to-all each way per block), all-gather of the fused bands == the single-process run"""
     for r, err in _spawn(_lidar_worker, world).items():
         assert err <= 1e-5, "rank %d: row-sharded FuseBEVT differs from the single-process result by %.3e" % (r, err)
+
+
+def _grad_worker(rank, world, port, bucket_bytes, ret):
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    torch.set_num_threads(1)
+    cdist.init_from_env("gloo")
+    torch.manual_seed(0)                                   # same initial weights on every rank
+    net = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.GELU(), torch.nn.Linear(64, 64), torch.nn.LayerNorm(64),
+                              torch.nn.Linear(64, 8))
+    unused = torch.nn.Parameter(torch.ones(5))             # a parameter that gets no gradient on rank 0
+    params = list(net.parameters()) + [unused]
+    red = cdist.GradAllReducer(params, bucket_bytes=bucket_bytes)
+    worst = 0.0
+    for step in range(2):
+        xs = [torch.randn(4, 16, generator=torch.Generator().manual_seed(100 * step + r)) for r in range(world)]
+        # reference: every rank's gradient computed locally (reducer switched off), averaged
+        red.enabled = False
+        ref = [torch.zeros_like(p) for p in params]
+        for r in range(world):
+            for p in params:
+                p.grad = None
+            (net(xs[r]).square().mean() + (unused.sum() if r == 1 else 0.0)).backward()
+            for a, p in zip(ref, params):
+                if p.grad is not None:
+                    a += p.grad / world
+        red.enabled = True
+        for p in params:
+            p.grad = None
+        loss = net(xs[rank]).square().mean() + (unused.sum() if rank == 1 else 0.0)
+        loss.backward()
+        red.finish()
+        got = [p.grad.clone() for p in params]
+        worst = max(worst, max(float((a - b).abs().max()) for a, b in zip(got, ref)))
+    ret[rank] = (worst, len(red.buckets))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,bucket_bytes", [(2, 32 << 20), (2, 4096), (4, 1024)])
+def test_grad_all_reducer_matches_averaged_gradients(world, bucket_bytes):
+    """train_camera.py:105-110 (DistributedDataParallel) equivalent: one bucket, several buckets, a parameter without a gradient
+    on some ranks, two consecutive steps"""
+    ret = _spawn(_grad_worker, world, bucket_bytes)
+    for r in range(world):
+        assert ret[r][0] <= 1e-6, ret
+    assert ret[0][1] == 1 if bucket_bytes > (1 << 20) else ret[0][1] > 1

@@ -1,0 +1,274 @@
+"""Gradient parity of the training slice (-m gpu): train()-mode HIP forward + backward kernels against torch autograd through the
+CPU oracle (oracle/ restates the reference modules functionally, so autograd through it is the reference's own training
+graph, train_camera.py:143-179) on the gv2 / gv5 / gv9 golden cases.  fp32, tolerance 1e-3 of each tensor's scale."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from cobevt_amd import autograd as ag
+from cobevt_amd import host, ops, synth
+from cobevt_amd.lib import CobevtHipError
+from cobevt_amd.synth import fill_module_
+import oracle.fax as o_fax
+import oracle.swap_fusion as o_swap
+from util import assert_close, golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _train_module(m, cuda):
+    return fill_module_(m, cases.SEED).train().to(cuda)
+
+
+def _oracle_sd(m):
+    """CPU leaf copies of the module's parameters (requires_grad) + its buffers, keyed like the state_dict"""
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    for k, p in m.named_parameters():
+        sd[k] = p.detach().cpu().clone().requires_grad_(True)
+    return sd
+
+
+def _compare(m, sd, out, out_ref, inputs, inputs_ref, what):
+    """backward of sum(out * w) on both sides, then outputs, input gradients and every parameter gradient"""
+    w = synth.procedural_input("train.w." + what, tuple(out_ref.shape), cases.SEED)
+    (out_ref * w).sum().backward()
+    (out * w.to(out.device)).sum().backward()
+    assert_close(out, out_ref, TOL, what + " forward")
+    for i, (a, b) in enumerate(zip(inputs, inputs_ref)):
+        if b is not None and b.grad is not None:
+            assert_close(a.grad, b.grad, TOL, "%s d input %d" % (what, i))
+    n = 0
+    # a gradient that is analytically zero (e.g. the key LayerNorm's bias: softmax ignores a constant added to every key) is
+    # rounding noise on both sides: each tensor is compared on its own scale, floored at 1e-3 of the largest gradient
+    floor = 1e-3 * max(float(t.grad.abs().max()) for t in sd.values() if t.grad is not None)
+    for k, p in m.named_parameters():
+        ref = sd[k].grad
+        if ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, "no gradient for " + k
+        assert torch.isfinite(p.grad).all(), k
+        err = float((p.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), floor)
+        assert err <= TOL, "%s d %s: rel err %.3e > %.1e" % (what, k, err, TOL)
+        n += 1
+    assert n > 0
+
+
+def _leaf(t, cuda=None):
+    if t is None:
+        return None
+    t = t.detach().clone()
+    if cuda is not None:
+        t = t.to(cuda)
+    return t.requires_grad_(True)
+
+
+@pytest.mark.parametrize("name", sorted(cases.CROSS_WIN))
+def test_cross_win_attention_gradients(cuda, name):
+    c = cases.CROSS_WIN[name]
+    m = _train_module(host.CrossWinAttention(c["dim"], c["heads"], c["dim_head"], c["qkv_bias"]), cuda)
+    sd = _oracle_sd(m)
+    ins = cases.cross_win_inputs(name)
+    with torch.enable_grad():
+        ref_in = [_leaf(t) for t in ins]
+        out_ref = o_fax.cross_win_attention(sd, "", *ref_in, c["heads"], c["dim_head"])
+        dev_in = [_leaf(t, cuda) for t in ins]
+        out = m(*dev_in)
+        # the train() forward is the same function as the eval() one (and the golden vector)
+        assert_close(out, golden("gv2_cross_win_attention")[name], TOL, "train-mode forward vs golden")
+        _compare(m, sd, out, out_ref, dev_in, ref_in, "CrossWinAttention." + name)
+
+
+def test_global_attention_gradients(cuda):
+    c = cases.GLOBAL_ATTN
+    m = _train_module(host.FaxAttention(c["dim"], c["dim_head"], 0.0, c["window_size"]), cuda)
+    sd = _oracle_sd(m)
+    x = synth.procedural_input("gv9.x", (c["b"], c["dim"], c["window_size"], c["window_size"]), cases.SEED)
+    with torch.enable_grad():
+        xr, xd = _leaf(x), _leaf(x, cuda)
+        out_ref = o_fax.global_attention(sd, "", xr, c["dim_head"], c["window_size"])
+        out = m(xd)
+        assert_close(out, golden("gv9_global_attention")["out"], TOL, "train-mode forward vs golden")
+        _compare(m, sd, out, out_ref, [xd], [xr], "FAX global attention")
+
+
+@pytest.mark.parametrize("use_mask", [True, False])
+def test_swap_fusion_encoder_gradients(cuda, use_mask):
+    c = cases.SWAP
+    x, mask = cases.swap_inputs()
+    args = dict(input_dim=c["dim"], mlp_dim=c["mlp_dim"], agent_size=c["agent_size"], window_size=c["window_size"],
+                dim_head=c["dim_head"], drop_out=0.0, depth=c["depth"], mask=use_mask)
+    m = _train_module(host.SwapFusionEncoder(dict(args)), cuda)
+    sd = _oracle_sd(m)
+    with torch.enable_grad():
+        xr, xd = _leaf(x), _leaf(x, cuda)
+        out_ref = o_swap.swap_fusion_encoder(sd, "", args, xr, mask if use_mask else None)
+        out = m(xd, mask.to(cuda) if use_mask else None)
+        assert_close(out, golden("gv5_swap_fusion")["encoder_mask" if use_mask else "encoder_nomask"], TOL,
+                     "train-mode forward vs golden")
+        _compare(m, sd, out, out_ref, [xd], [xr], "SwapFusionEncoder mask=%s" % use_mask)
+
+
+def test_swap_block_and_attention_gradients(cuda):
+    c = cases.SWAP
+    x, mask = cases.swap_inputs()
+    w, b, L, d, hw = c["window_size"], c["b"], c["agent_size"], c["dim"], c["hw"]
+    blk = _train_module(host.SwapFusionBlockMask(d, c["mlp_dim"], c["dim_head"], w, L, 0.0), cuda)
+    sd = _oracle_sd(blk)
+    with torch.enable_grad():
+        xr, xd = _leaf(x), _leaf(x, cuda)
+        names = o_swap.block_names("", 0, True)
+        names = {k: v.replace("layers.0.", "") for k, v in names.items()} if isinstance(names, dict) else \
+            [n.replace("layers.0.", "") for n in names]
+        out_ref = o_swap.swap_fusion_block(sd, names, xr, mask, c["dim_head"], L, w)
+        out = blk(xd, mask.to(cuda))
+        _compare(blk, sd, out, out_ref, [xd], [xr], "SwapFusionBlockMask")
+    att = _train_module(host.SwapAttention(d, c["dim_head"], 0.0, L, w), cuda)
+    sd = _oracle_sd(att)
+    xw = x.permute(0, 1, 3, 4, 2).reshape(b, L, hw // w, w, hw // w, w, d).permute(0, 1, 2, 4, 3, 5, 6).contiguous()
+    mw = mask.reshape(b, hw // w, w, hw // w, w, 1, L).permute(0, 1, 3, 2, 4, 5, 6).contiguous()
+    with torch.enable_grad():
+        xr, xd = _leaf(xw), _leaf(xw, cuda)
+        out_ref = o_swap.swap_attention(sd, "", xr, mw, c["dim_head"], L, w)
+        out = att(xd, mask=mw.to(cuda))
+        _compare(att, sd, out, out_ref, [xd], [xr], "swap Attention (stored partition, mask)")
+
+
+def _dense_attention(q, k, v, qrows, krows, bias, mask_keys, heads, scale):
+    """torch reference of the gathered attention: rows (B, L, N) index maps, bias (Nq, Nk, heads) | None,
+    mask_keys (B, L, Nk) bool | None -> per-window outputs (B, L, Nq, d)"""
+    B, L, Nq = qrows.shape
+    Nk = krows.shape[2]
+    d = q.shape[1]
+    qg = q[qrows.reshape(-1)].reshape(B, L, Nq, heads, 32).permute(0, 1, 3, 2, 4)
+    kg = k[krows.reshape(-1)].reshape(B, L, Nk, heads, 32).permute(0, 1, 3, 2, 4)
+    vg = v[krows.reshape(-1)].reshape(B, L, Nk, heads, 32).permute(0, 1, 3, 2, 4)
+    s = scale * qg @ kg.transpose(-1, -2)
+    if bias is not None:
+        s = s + bias.permute(2, 0, 1)
+    if mask_keys is not None:
+        s = s.masked_fill(~mask_keys[:, :, None, None, :], -float("inf"))
+    o = s.softmax(-1) @ vg
+    return o.permute(0, 1, 3, 2, 4).reshape(B, L, Nq, d)
+
+
+@pytest.mark.parametrize("mode,ncam,H,W,w1,w2,heads,use_bias,use_mask", [
+    (0, 3, 12, 20, 6, 5, 2, True, True),      # Nq = Nk = 90: ragged 32-tiles, 3-D bias, key mask
+    (1, 2, 8, 8, 4, 4, 4, True, False),       # dilated grid
+    (0, 1, 10, 10, 5, 5, 1, False, False),    # Nq = 25 < one tile
+    (1, 5, 14, 14, 7, 7, 2, True, True),      # 245 tokens: eight 32-key tiles, two query rounds per wave
+])
+def test_window_attention_backward_vs_dense_torch(cuda, mode, ncam, H, W, w1, w2, heads, use_bias, use_mask):
+    """the kernel pair alone, on shapes the module cases do not reach; the reference is dense torch attention over the index
+    maps the forward kernels are tested against bit-exactly (cobevt_attention_index_map)"""
+    B, d = 2, heads * 32
+    tm = ops.tokmap(mode, ncam, H, W, w1, w2)
+    rows_n = B * ncam * H * W
+    g = torch.Generator().manual_seed(5)
+    q0, k0, v0 = (torch.randn(rows_n, d, generator=g) for _ in range(3))
+    table0 = torch.randn((2 * ncam - 1) * (2 * w1 - 1) * (2 * w2 - 1), heads, generator=g) if use_bias else None
+    mask = None
+    if use_mask:
+        mask = (torch.rand(B, H, W, ncam, generator=g) > 0.3).float()
+        mask[..., 0] = 1.0                                        # the ego agent is always visible
+        mask = mask.to(cuda)
+    rows = ops.attention_index_map(tm, B, cuda).long()
+    bidx = ops.attention_bias_index(tm, tm, ncam, cuda).long() if use_bias else None
+    wgt = torch.randn(rows_n, d, generator=g).to(cuda)
+    with torch.enable_grad():
+        q, k, v = (_leaf(t, cuda) for t in (q0, k0, v0))
+        table = _leaf(table0, cuda)
+        out = ag.window_attention(q, k, v, tm, tm, tm, B, heads, 0.37, rows_n, bias_table=table, bias_L=ncam, mask=mask)
+        (out * wgt).sum().backward()
+        qr, kr, vr = (_leaf(t, cuda) for t in (q0, k0, v0))
+        tr = _leaf(table0, cuda)
+        mk = None
+        if use_mask:
+            # mask (B, H, W, ncam) -> per token of the (B * ncam, H, W) matrix -> gathered per window
+            tok = mask.permute(0, 3, 1, 2).reshape(-1)
+            mk = tok[rows.reshape(-1)].reshape(rows.shape) != 0
+        o = _dense_attention(qr, kr, vr, rows, rows, tr[bidx] if use_bias else None, mk, heads, 0.37)
+        ref = torch.zeros(rows_n, d, device=cuda).index_copy(0, rows.reshape(-1), o.reshape(-1, d))
+        (ref * wgt).sum().backward()
+    assert_close(out, ref, 1e-4, "forward")
+    assert_close(q.grad, qr.grad, TOL, "dq")
+    assert_close(k.grad, kr.grad, TOL, "dk")
+    assert_close(v.grad, vr.grad, TOL, "dv")
+    if use_bias:
+        assert_close(table.grad, tr.grad, TOL, "dbias")
+
+
+def test_layernorm_and_gelu_backward(cuda):
+    g = torch.Generator().manual_seed(3)
+    for rows, C in ((1000, 128), (37, 64), (5000, 256), (16, 512)):
+        x0 = torch.randn(rows, C, generator=g) * 2 + 0.5
+        ln = torch.nn.LayerNorm(C).to(cuda)
+        with torch.no_grad():
+            ln.weight.copy_(torch.randn(C, generator=g))
+            ln.bias.copy_(torch.randn(C, generator=g))
+        w = torch.randn(rows, C, generator=g).to(cuda)
+        with torch.enable_grad():
+            x = _leaf(x0, cuda)
+            (ag.layernorm(x, ln) * w).sum().backward()
+            got = (x.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone())
+            ln.zero_grad()
+            xr = _leaf(x0, cuda)
+            (ln(xr) * w).sum().backward()
+        for a, b, what in zip(got, (xr.grad, ln.weight.grad, ln.bias.grad), ("dx", "dgamma", "dbeta")):
+            assert_close(a, b, 1e-4, "LayerNorm %s (%d x %d)" % (what, rows, C))
+        with torch.enable_grad():
+            x = _leaf(x0, cuda)
+            y = ag.gelu(x)
+            (y * w).sum().backward()
+            xr = _leaf(x0, cuda)
+            yr = torch.nn.functional.gelu(xr)
+            (yr * w).sum().backward()
+        assert_close(y, yr, 1e-5, "GELU")
+        assert_close(x.grad, xr.grad, 1e-5, "GELU backward")
+
+
+def test_training_slice_fails_loudly(cuda):
+    m = _train_module(host.SwapAttention(64, 32, 0.0, 3, 4), cuda)
+    x = torch.zeros(1, 3, 2, 2, 4, 4, 64)
+    with pytest.raises(CobevtHipError):
+        m(x)                                                       # CPU tensor
+    with pytest.raises(CobevtHipError):
+        m(x.to(cuda).to(torch.bfloat16))                           # bf16 is the inference layout
+    # modules without backward kernels keep refusing train() mode
+    conv = host.Bottleneck(128, 32).train().to(cuda)
+    with pytest.raises(CobevtHipError):
+        conv(torch.zeros(1, 128, 8, 8, device=cuda))
+
+
+def test_one_optimizer_step_reduces_the_loss(cuda):
+    """train_camera.py:143-179 in miniature: forward, loss, backward, Adam step on the masked swap-fusion encoder"""
+    c = cases.SWAP
+    x, mask = cases.swap_inputs()
+    args = dict(input_dim=c["dim"], mlp_dim=c["mlp_dim"], agent_size=c["agent_size"], window_size=c["window_size"],
+                dim_head=c["dim_head"], drop_out=0.1, depth=c["depth"], mask=True)
+    m = _train_module(host.SwapFusionEncoder(args), cuda)
+    target = synth.procedural_input("train.target", (c["b"], c["dim"], c["hw"], c["hw"]), cases.SEED).to(cuda)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    losses = []
+    torch.manual_seed(0)
+    with torch.enable_grad():
+        for _ in range(8):
+            opt.zero_grad()
+            loss = torch.nn.functional.mse_loss(m(x.to(cuda), mask.to(cuda)), target)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    # eval() after training: the inference plans follow the updated parameters
+    m.eval()
+    with torch.no_grad(), host.compute_dtype(torch.float32):
+        y_eval = m(x.to(cuda), mask.to(cuda))
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    with torch.no_grad():
+        y_train = m(x.to(cuda), mask.to(cuda))
+    assert_close(y_eval, y_train, TOL, "eval() forward after optimizer steps vs train-mode graph")
