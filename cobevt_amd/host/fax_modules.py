@@ -362,6 +362,8 @@ class CrossViewSwapAttention(HipModule):
 
     def forward(self, index, x, bev, feature, I_inv, E_inv):
         """x (b,d,H,W); feature (b,n,C,h,w); I_inv (b,n,3,3); E_inv (b,n,4,4) -> (b,d,H,W)"""
+        if self.training:
+            return training.cross_view_swap_attention(self, index, x, bev, feature, I_inv, E_inv)
         self._require_inference(x, feature, I_inv, E_inv)
         b, n = feature.shape[:2]
         f = rt.to_nhwc(feature.reshape(b * n, *feature.shape[2:]))

@@ -8,9 +8,9 @@ own nn.Parameter containers, so optimizers, state_dicts and the gradient all-red
 reference's names.
 
 Covered: swap Attention / PreNormResidual / FeedForward / SwapFusionBlock(Mask) / SwapFusionEncoder
-(swap_fusion_modules.py:13-286, base_transformer.py:102-124), FAX CrossWinAttention and the global Attention
-(fax_modules.py:93-248).  The convolutional parts (encoders, decoder, Bottlenecks) have no backward kernels yet: their
-modules keep raising in train() mode.
+(swap_fusion_modules.py:13-286, base_transformer.py:102-124), FAX CrossWinAttention, CrossViewSwapAttention and the global
+Attention (fax_modules.py:93-441).  The 3x3-convolutional parts (encoders, decoder, Bottlenecks, down-sampling blocks) have no
+backward kernels yet: their modules keep raising in train() mode.
 """
 import torch
 
@@ -98,6 +98,24 @@ def swap_fusion_encoder(enc, x, mask):
     return y.permute(0, 3, 1, 2)
 
 
+def _project(seq, t):
+    """nn.Sequential(LayerNorm, Linear) of a cross attention on (..., d) -> (rows, inner)"""
+    t = t.contiguous()
+    return ag.linear(ag.layernorm(t, seq[0]).reshape(-1, t.shape[-1]), seq[1])
+
+
+def cross_win_attend(m, q_src, k_src, v_src, qmap, kmap, batch, skip):
+    """CrossWinAttention (fax_modules.py:198-248) on token-major sources whose rows the maps address: q_src (b, n, .., d) with
+    n = qmap[1] cameras, k_src / v_src (b, nk, .., d); skip (b, .., d) | None in the layout of ONE camera of q_src.  Every
+    camera's queries see all cameras' keys; the camera mean (:243) is taken after the projection (:240), outside the kernel, so
+    that autograd sees it.  Returns (b, .., dim) in q_src's single-camera layout."""
+    n = qmap[1]
+    qt, kt, vt = _project(m.to_q, q_src), _project(m.to_k, k_src), _project(m.to_v, v_src)
+    a = ag.window_attention(qt, kt, vt, qmap, kmap, qmap, batch, m.heads, m.scale, qt.shape[0])
+    z = ag.linear(a, m.proj).reshape((batch, n) + tuple(q_src.shape[2:-1]) + (-1,)).mean(dim=1)
+    return z + skip if skip is not None else z
+
+
 def cross_win_attention(m, q, k, v, skip):
     """CrossWinAttention.forward (fax_modules.py:194-248): q (b n X Y W1 W2 d), k, v (b n x y w1 w2 d), skip (b X Y W1 W2 d)."""
     _check(q, k, v, skip)
@@ -105,20 +123,76 @@ def cross_win_attention(m, q, k, v, skip):
     b, n, X, Y, W1, W2, d = q.shape
     _, nk, kx, ky, w1, w2, _ = k.shape
     assert X * Y == kx * ky
-    inner = m.heads * m.dim_head
     qmap = (2, n, X * W1, Y * W2, W1, W2, X, Y)
     kmap = (2, nk, kx * w1, ky * w2, w1, w2, kx, ky)
+    return cross_win_attend(m, q, k, v, qmap, kmap, b, skip)
 
-    def project(seq, t):
-        t = t.contiguous()
-        return ag.linear(ag.layernorm(t, seq[0]).reshape(-1, t.shape[-1]), seq[1])
 
-    qt, kt, vt = project(m.to_q, q), project(m.to_k, k), project(m.to_v, v)
-    # every camera's queries against all cameras' keys; the camera mean (:243) is taken after the projection (:240), outside
-    # the kernel, so that autograd sees it
-    a = ag.window_attention(qt, kt, vt, qmap, kmap, qmap, b, m.heads, m.scale, qt.shape[0])
-    z = ag.linear(a, m.proj).reshape(b, n, X, Y, W1, W2, -1).mean(dim=1)
-    return z + skip if skip is not None else z
+def _mlp(x, prenorm, mlp):
+    """x + Linear(GELU(Linear(LayerNorm(x))))  (fax_modules.py:411,435)"""
+    return x + ag.linear(ag.gelu(ag.linear(ag.layernorm(x.contiguous(), prenorm), mlp[0])), mlp[2])
+
+
+def _pre_act_conv1x1(seq, x):
+    """nn.Sequential(BatchNorm2d, ReLU, Conv2d 1x1) (fax_modules.py:281-292).  The BatchNorm follows ITS OWN .training flag
+    (batch statistics + running-stat update, or the frozen running statistics), as torch would; both and the 1x1 convolution
+    are library calls - there is no hot kernel here."""
+    F = torch.nn.functional
+    bn = seq[0]
+    y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
+    return F.conv2d(F.relu(y), seq[2].weight, seq[2].bias)
+
+
+def cross_view_swap_attention(m, index, x, bev, feature, I_inv, E_inv):
+    """CrossViewSwapAttention.forward (fax_modules.py:323-441) as a differentiable graph: x (b d H W), feature (b n C h w),
+    I_inv (b n 3 3), E_inv (b n 4 4) -> (b d H W).  The camera-geometry embeddings and the BN -> ReLU -> 1x1 projections are
+    small library ops; both cross attentions (gathered window / grid attention), the LayerNorms and the GELUs are the HIP
+    kernels with their HIP backward."""
+    _check(x, feature, I_inv, E_inv)
+    F = torch.nn.functional
+    b, n, _, h, w = feature.shape
+    _, d, H, W = x.shape
+    W1, W2 = m.q_win_size
+    w1, w2 = m.feat_win_size
+    pixel = m.image_plane.reshape(1, 1, 3, h * w)
+    c = E_inv[..., -1:]
+    c_embed = F.conv2d(c.reshape(b * n, 4, 1, 1), m.cam_embed.weight)                   # (bn) d 1 1
+    cam = F.pad(I_inv @ pixel, (0, 0, 0, 1), value=1)                                   # b n 4 hw
+    dd = (E_inv @ cam).reshape(b * n, 4, h, w)
+    img_embed = F.conv2d(dd, m.img_embed.weight) - c_embed
+    img_embed = img_embed / (img_embed.norm(dim=1, keepdim=True) + 1e-7)
+    if m.bev_embed_flag:
+        grid = getattr(bev, "grid%d" % index)
+        bev_embed = F.conv2d(grid[:2][None], m.bev_embed.weight, m.bev_embed.bias) - c_embed
+        bev_embed = bev_embed / (bev_embed.norm(dim=1, keepdim=True) + 1e-7)
+        query = bev_embed.reshape(b, n, d, H, W) + x[:, None]
+    else:
+        query = x[:, None]
+    feat = feature.reshape(b * n, -1, h, w)
+    key = img_embed if m.feature_proj is None else img_embed + _pre_act_conv1x1(m.feature_proj, feat)
+    val = _pre_act_conv1x1(m.feature_linear, feat)
+    hp, wp = m._padded_hw(h, w)
+    if (hp, wp) != (h, w):
+        key, val = F.pad(key, (0, wp - w, 0, hp - h)), F.pad(val, (0, wp - w, 0, hp - h))
+    # channels-last token matrices; the window / grid partitions are index arithmetic inside the attention kernels
+    key_l = key.reshape(b, n, d, hp, wp).permute(0, 1, 3, 4, 2).contiguous()
+    val_l = val.reshape(b, n, d, hp, wp).permute(0, 1, 3, 4, 2).contiguous()
+    query_l = query.permute(0, 1, 3, 4, 2).contiguous()
+    x_l = x.permute(0, 2, 3, 1).contiguous()
+    nq = query_l.shape[1]
+    qmap = ops.tokmap(0, nq, H, W, W1, W2)
+    kwin, kgrid = ops.tokmap(0, n, hp, wp, w1, w2), ops.tokmap(1, n, hp, wp, w1, w2)
+    if qmap[6] * qmap[7] != kwin[6] * kwin[7]:
+        raise CobevtHipError("query windows %dx%d != key windows %dx%d" % (qmap[6], qmap[7], kwin[6], kwin[7]))
+    out = cross_win_attend(m.cross_win_attend_1, query_l, key_l, val_l, qmap, kwin, b, x_l if m.skip else None)
+    out = _mlp(out, m.prenorm_1, m.mlp_1)
+    # local-to-global: the reference repeats the query over the n cameras (:417); the copies are identical, one is enough
+    q2 = out[:, None]
+    out = cross_win_attend(m.cross_win_attend_2, q2, key_l, val_l, ops.tokmap(0, 1, H, W, W1, W2), kgrid, b,
+                           out if m.skip else None)
+    out = _mlp(out, m.prenorm_2, m.mlp_2)
+    out = ag.layernorm(out.contiguous(), m.postnorm)
+    return out.permute(0, 3, 1, 2)
 
 
 def global_attention(m, x):

@@ -81,6 +81,38 @@ def test_cross_win_attention_gradients(cuda, name):
         _compare(m, sd, out, out_ref, dev_in, ref_in, "CrossWinAttention." + name)
 
 
+@pytest.mark.parametrize("name", sorted(cases.CVSA))
+def test_cross_view_swap_attention_gradients(cuda, name):
+    """gv3: both cross attentions (window x window, window x dilated grid), the padded key / value maps, the camera mean, MLPs and
+    norms under autograd.  BatchNorms frozen (.eval(), the fine-tuning recipe) so that the oracle's running-statistics
+    BatchNorm is the same function; in full train() mode they take batch statistics like torch's."""
+    c = cases.CVSA[name]
+    fd, fh, fw = c["feat"]
+    m = _train_module(host.CrossViewSwapAttention(fh, fw, fd, c["dim"], c["index"], c["image"][0], c["image"][1], **c["kwargs"]), cuda)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.eval()
+    bev = host.BEVEmbedding(c["dim"], **c["bev_embedding"]).to(cuda)
+    sd = _oracle_sd(m)
+    x, feat, I_inv, E = cases.cvsa_inputs(name)
+    grid = getattr(bev, "grid%d" % c["index"]).detach().cpu()
+    with torch.enable_grad():
+        xr, fr = _leaf(x), _leaf(feat)
+        out_ref = o_fax.cross_view_swap_attention(sd, "", dict(c["kwargs"], image_height=c["image"][0], image_width=c["image"][1]),
+                                                  c["index"], xr, grid, fr, I_inv, E)
+        xd, fdv = _leaf(x, cuda), _leaf(feat, cuda)
+        out = m(c["index"], xd, bev, fdv, I_inv.to(cuda), E.to(cuda))
+        assert_close(out, golden("gv3_cross_view_swap_attention")[name], TOL, "train-mode forward vs golden")
+        _compare(m, sd, out, out_ref, [xd, fdv], [xr, fr], "CrossViewSwapAttention." + name)
+    # full train() mode: batch statistics, running statistics updated
+    m.train()
+    before = m.feature_linear[0].running_mean.clone()
+    with torch.enable_grad():
+        out2 = m(c["index"], x.to(cuda), bev, feat.to(cuda), I_inv.to(cuda), E.to(cuda))
+        out2.square().mean().backward()
+    assert torch.isfinite(out2).all() and not torch.equal(before, m.feature_linear[0].running_mean)
+
+
 def test_global_attention_gradients(cuda):
     c = cases.GLOBAL_ATTN
     m = _train_module(host.FaxAttention(c["dim"], c["dim_head"], 0.0, c["window_size"]), cuda)
@@ -259,7 +291,7 @@ def test_one_optimizer_step_reduces_the_loss(cuda):
             loss = torch.nn.functional.mse_loss(m(x.to(cuda), mask.to(cuda)), target)
             loss.backward()
             opt.step()
-            losses.append(float(loss))
+            losses.append(float(loss.detach()))
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
     # eval() after training: the inference plans follow the updated parameters
     m.eval()
