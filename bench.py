@@ -177,6 +177,13 @@ def roofline_leg(runner, dtype_name):
     fams.sort(key=lambda f: -best[f]["ms"])
     dom = entry(fams[0], best[fams[0]], fam_pmc.get(fams[0], {}))
     dom["pmc_source"] = pmc_file
+    # the family's launches by shape (largest first): the family figure above averages 64-channel, 512-channel and tiny
+    # decoder launches; a rocprofv3 --kernel-trace row is one tile variant, i.e. close to one of these lines
+    shp = sorted(((k, v) for k, v in best_shapes.items() if k.startswith(fams[0] + "|")), key=lambda kv: -kv[1]["ms"])
+    dom["by_launch_shape"] = [
+        {"shape": k.split("|", 1)[1], "launches_per_frame": v["calls"], "avg_launch_us": round(v["ms"] * 1e3 / v["calls"], 2),
+         "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak, 4)}
+        for k, v in shp[:6]]
     others = [entry(f, best[f], fam_pmc.get(f, {})) for f in fams[1:]]
     # the largest attention launch = level-0 cross attention #1 (64 windows x 4 cameras x 256 queries x 256 keys per agent)
     attn = {k: v for k, v in best_shapes.items() if k.startswith("attention|")}

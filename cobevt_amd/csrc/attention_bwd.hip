@@ -5,18 +5,22 @@
 // einsum of fax_modules.py:219-237 and swap_fusion_modules.py:100-121 under train_camera.py:143-179).  For one (window, head):
 //     P = softmax(scale * Q K^T + bias (+ mask)),  O = P V
 //     dV = P^T dO,   dP = dO V^T,   dZ = P o (dP - rowsum(dO o O)),   dQ = scale * dZ K,   dK = scale * dZ^T Q,   dbias = dZ
-// Work decomposition: one workgroup = (batch, window, head, 32-key tile); its four waves walk the window's 32-query tiles.  With
-// D = A.B on v_mfma_f32_32x32x2_f32 a lane owns one COLUMN of the 32 x 32 result, so
-//   * S = Q K^T and dP = dO V^T are computed with lane = key: the key's K / V rows are the B operands and stay in registers for
-//     the whole kernel; P, dP, dZ live as [query row registers][key lane];
-//   * dV^T += dO^T P and dK^T += Q^T dZ contract over the query rows: the A operands are read (transposed, for free: a lane reads
-//     one element) from the wave's LDS copies of the dO / Q tiles, the B operand is the P / dZ register itself - the two half-waves
-//     supply rows (j & 3) + 8 (j >> 2) + 4 half in step j, on both operands;
-//   * dQ += dZ K contracts over the keys, i.e. over the lanes: dZ makes one round trip through a wave-private LDS tile to become an
-//     A operand; the result is added to dq with fp32 atomics (the other key tiles of the window add to the same rows);
-//   * dK / dV rows belong to this workgroup alone (a key token is in exactly one window): the four waves' partial sums are reduced
-//     through LDS and stored plainly.
-// The partitions / reverses are the forward's index arithmetic (attn_common.hpp); dq must be zero-initialised by the caller.
+// Two kernels, neither of which adds into global memory per element (the first version did dQ with 16 fp32 atomics per lane
+// and (query, key) tile - 5 x 10^8 of them on the LiDAR shape - and flushed the bias gradient once per workgroup: 9.1 ms there):
+//
+// attn_bwd_kv_kernel  (dK, dV, dbias): a workgroup owns one 32-key tile position of one head and walks a share of the WINDOWS;
+//   per window its four waves walk the 32-query tiles.  With D = A.B on v_mfma_f32_32x32x2_f32 a lane owns one COLUMN of the
+//   result: S = Q K^T and dP = dO V^T are computed with lane = key (the key's K / V rows are the B operands, in registers for the
+//   whole window), P / dP / dZ live as [query row registers][key lane], and dV^T += dO^T P, dK^T += Q^T dZ contract over the query
+//   rows with the P / dZ registers as B operands directly (step j pairs rows (j & 3) + 8 (j >> 2) + 4 half, on both operands).
+//   dK / dV rows belong to this workgroup alone; the bias gradient is accumulated in an LDS copy of the table over ALL the
+//   windows of the workgroup and flushed once.
+// attn_bwd_q_kernel  (dQ): a workgroup owns one 32-query tile of one (window, head); its waves take the key tiles round robin.
+//   Here lane = QUERY: S^T = K Q^T and dP^T = V dO^T take the query's Q / dO rows as register B operands, lse and
+//   D = rowsum(dO o O) are per-lane scalars, and dQ^T += K^T dZ^T contracts over the keys = the register index, so dQ stays in
+//   registers over the whole key loop and is stored once (the waves' partial sums meet in LDS).
+// The softmax is recomputed in both (3 extra products over the minimal 5): 7 x 10^4 fp32 MFMAs are cheaper than the atomics.
+// The partitions / reverses are the forward's index arithmetic (attn_common.hpp).
 #include "attn_common.hpp"
 
 namespace cobevt {
@@ -28,194 +32,168 @@ struct AttnBwdParams {
     float* dk;
     float* dv;
     float* dbias;             // [bias_rows][heads], zero-initialised by the caller (nullable without bias)
+    int nsplit;               // attn_bwd_kv_kernel: workgroups that share the windows of one (head, key tile position)
 };
 
 namespace {
 
 constexpr int kPad = 33;      // floats per row of the 32 x 32 LDS tiles
 constexpr float kLog2eB = 1.4426950408889634f;
+constexpr int kMaskedKey = (int)0x80000000;   // per-key info of a masked / out-of-range key
+
+__device__ __forceinline__ bool key_visible(const AttnParams& p, int b, int l, const TokCoord& kc) {
+    if (p.kmap.mode == 2)
+        return p.mask[((((size_t)b * p.L + l) * p.kmap.w1 + kc.i) * p.kmap.w2 + kc.j) * p.kmap.ncam + kc.cam] != 0.f;
+    int ph, pw;
+    tok_pixel(p.kmap, l, kc, ph, pw);
+    return p.mask[(((size_t)b * p.kmap.HH + ph) * p.kmap.WW + pw) * p.kmap.ncam + kc.cam] != 0.f;
+}
 
 template <bool BIAS, bool MASK>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdParams bp) {
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnBwdParams bp) {
     const AttnParams& p = bp.a;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = (float*)smem_raw;
-    float* Ks = smem;                                   // [32][33] this tile's K rows (head slice)
-    float* wbase = smem + 32 * kPad;                    // per wave: Qs, dOs, dSs [32][33] + lse, D, qrow, obias [32] each
-    constexpr int kWaveFloats = 3 * 32 * kPad + 4 * 32;
-    float* red = wbase + 4 * kWaveFloats;               // [3][16][64] cross-wave reduction of dK^T / dV^T
+    constexpr int kWaveFloats = 2 * 32 * kPad + 3 * 32;
+    float* red = smem + 4 * kWaveFloats;                // [3][16][64] cross-wave reduction of dK^T / dV^T
     float* bias_col = red + 3 * 16 * 64;                // [bias_rows] forward bias (x log2e)   (BIAS)
     float* dtab = bias_col + (BIAS ? p.bias_rows : 0);  // [bias_rows] gradient accumulator      (BIAS)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, ql = lane & 31;
     const int b = blockIdx.z, kt = blockIdx.y;
-    const int l = blockIdx.x / p.heads, head = blockIdx.x - l * p.heads;
-    float* Qs = wbase + wave * kWaveFloats;
+    const int head = blockIdx.x % p.heads, split = blockIdx.x / p.heads;
+    float* Qs = smem + wave * kWaveFloats;              // per wave: Q and dO tiles [32][33], lse, D, bias query term [32]
     float* dOs = Qs + 32 * kPad;
-    float* dSs = dOs + 32 * kPad;
-    float* lse_s = dSs + 32 * kPad;
+    float* lse_s = dOs + 32 * kPad;
     float* D_s = lse_s + 32;
-    int* qrow_s = (int*)(D_s + 32);
-    int* qb_s = qrow_s + 32;
+    int* qb_s = (int*)(D_s + 32);
 
-    // ---- this lane's key: K / V rows as B operands (element 2 i + half of step i), mask, bias key term
-    const int tk = kt * 32 + ql;
-    const bool k_in = tk < p.Nk;
-    const TokCoord kc = tok_coord(p.kmap, k_in ? tk : 0);
-    const size_t krow = tok_row(p.kmap, b, l, kc);
-    bool k_ok = k_in;
-    if (MASK && k_in) {
-        if (p.kmap.mode == 2) {
-            k_ok = p.mask[((((size_t)b * p.L + l) * p.kmap.w1 + kc.i) * p.kmap.w2 + kc.j) * p.kmap.ncam + kc.cam] != 0.f;
-        } else {
-            int ph, pw;
-            tok_pixel(p.kmap, l, kc, ph, pw);
-            k_ok = p.mask[(((size_t)b * p.kmap.HH + ph) * p.kmap.WW + pw) * p.kmap.ncam + kc.cam] != 0.f;
-        }
-    }
-    const int kterm = BIAS ? rel_bias_key_term(p.kmap, kc) : 0;
-    float kreg[16], vreg[16];
-    {
-        const float* kr = (const float*)p.k + krow * p.ldk + p.koff + head * 32 + h;
-        const float* vr = (const float*)p.v + krow * p.ldv + p.voff + head * 32 + h;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            kreg[i] = k_in ? kr[2 * i] : 0.f;
-            vreg[i] = k_in ? vr[2 * i] : 0.f;
-        }
-    }
-    if (wave == 0) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) Ks[ql * kPad + 2 * i + h] = kreg[i];
-    }
     if (BIAS) {
         for (int i = tid; i < p.bias_rows; i += 256) {
             bias_col[i] = p.bias_table[(size_t)i * p.heads + head] * kLog2eB;
             dtab[i] = 0.f;
         }
     }
-    __syncthreads();
-
-    f32x16 dKT, dVT;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dKT[r] = 0.f; dVT[r] = 0.f; }
+    const int tk = kt * 32 + ql;
+    const bool k_in = tk < p.Nk;
     const float sl2 = p.scale * kLog2eB;
     const int nqt = (p.Nq + 31) / 32;
     const int nit = (nqt + 3) / 4;                      // uniform trip count: the loop contains workgroup barriers
-    for (int it = 0; it < nit; ++it) {
-        const int qt = it * 4 + wave;
-        const bool t_ok = qt < nqt;
-        // ---- stage the Q and dO tiles (two lanes per query row, 16 floats each), D = rowsum(dO o O), lse, row indices
-        {
-            const int r = lane >> 1, half = lane & 1;
-            const int tq = qt * 32 + r;
-            const bool ok = t_ok && tq < p.Nq;
-            const TokCoord qc = tok_coord(p.qmap, ok ? tq : 0);
-            const size_t qrow = tok_row(p.qmap, b, l, qc);
-            const size_t orow = tok_row(p.omap, b, l, qc);
-            const float* qp = (const float*)p.q + qrow * p.ldq + p.qoff + head * 32 + half * 16;
-            const float* op = (const float*)p.out + orow * p.ldo + p.ooff + head * 32 + half * 16;
-            const float* dp = bp.dout + orow * p.ldo + p.ooff + head * 32 + half * 16;
-            float dsum = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float4 qv = ok ? *(const float4*)(qp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 dv = ok ? *(const float4*)(dp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 ov = ok ? *(const float4*)(op + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                float* qd = Qs + r * kPad + half * 16 + 4 * c;
-                float* dd = dOs + r * kPad + half * 16 + 4 * c;
-                qd[0] = qv.x; qd[1] = qv.y; qd[2] = qv.z; qd[3] = qv.w;
-                dd[0] = dv.x; dd[1] = dv.y; dd[2] = dv.z; dd[3] = dv.w;
-                dsum += dv.x * ov.x + dv.y * ov.y + dv.z * ov.z + dv.w * ov.w;
-            }
-            dsum += __shfl_xor(dsum, 1, 64);
-            if (half == 0) {
-                D_s[r] = dsum;
-                // invalid rows: lse = +inf -> P = exp2(-inf) = 0
-                lse_s[r] = ok ? p.lse[(((size_t)b * p.L + l) * p.heads + head) * p.Nq + tq] : INFINITY;
-                qrow_s[r] = ok ? (int)qrow : -1;
-                qb_s[r] = BIAS ? rel_bias_query_term(p.kmap, p.bias_L, qc) : 0;
-            }
-        }
-        __syncthreads();
-        // ---- S = Q K^T and dP = dO V^T  (lane = key column, register r <-> query row (r & 3) + 8 (r >> 2) + 4 h)
-        f32x16 S, dP;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            S = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[ql * kPad + 2 * i + h], kreg[i], S, 0, 0, 0);
-            dP = __builtin_amdgcn_mfma_f32_32x32x2f32(dOs[ql * kPad + 2 * i + h], vreg[i], dP, 0, 0, 0);
-        }
-        // ---- P = exp2(z log2e - lse2),  dZ = P (dP - D)
-        f32x16 P, dZ;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = acc_row(r, lane);
-            float z = S[r] * sl2;
-            int bidx = 0;
-            if (BIAS) { bidx = qb_s[row] - kterm; z += bias_col[k_ok ? bidx : 0]; }
-            const float pr = k_ok ? __builtin_amdgcn_exp2f(z - lse_s[row]) : 0.f;
-            P[r] = pr;
-            dZ[r] = pr * (dP[r] - D_s[row]);
-            if (BIAS && k_ok && dZ[r] != 0.f) atomicAdd(&dtab[bidx], dZ[r]);
-        }
-        // ---- dV^T += dO^T P,  dK^T += Q^T dZ  (contraction over the query rows; step j pairs rows qj(0) and qj(1))
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int qj = (j & 3) + 8 * (j >> 2) + 4 * h;
-            dVT = __builtin_amdgcn_mfma_f32_32x32x2f32(dOs[qj * kPad + ql], P[j], dVT, 0, 0, 0);
-            dKT = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[qj * kPad + ql], dZ[j], dKT, 0, 0, 0);
-        }
-        // ---- dQ += dZ K : dZ through LDS to become the A operand (rows = queries, contraction over the keys = lanes)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dSs[acc_row(r, lane) * kPad + ql] = dZ[r];
-        __syncthreads();
-        f32x16 dQ;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dQ[r] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            dQ = __builtin_amdgcn_mfma_f32_32x32x2f32(dSs[ql * kPad + 2 * j + h], Ks[(2 * j + h) * kPad + ql], dQ, 0, 0, 0);
-        // dQ: lane = dh column, register r <-> query row
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qr = qrow_s[acc_row(r, lane)];
-            if (qr >= 0) atomicAdd(bp.dq + (size_t)qr * p.ldq + p.qoff + head * 32 + ql, dQ[r] * p.scale);
-        }
-        __syncthreads();                                // the next iteration overwrites the wave tiles
-    }
 
-    // ---- reduce dK^T / dV^T over the four waves, store (lane = key column, register r <-> dh row)
+    for (int l = split; l < p.L; l += bp.nsplit) {
+        // ---- this lane's key: K / V rows as B operands (element 2 i + half of step i), mask, bias key term
+        const TokCoord kc = tok_coord(p.kmap, k_in ? tk : 0);
+        const size_t krow = tok_row(p.kmap, b, l, kc);
+        bool k_ok = k_in;
+        if (MASK && k_in) k_ok = key_visible(p, b, l, kc);
+        const int kterm = BIAS ? rel_bias_key_term(p.kmap, kc) : 0;
+        float kreg[16], vreg[16];
+        {
+            const float* kr = (const float*)p.k + krow * p.ldk + p.koff + head * 32 + h;
+            const float* vr = (const float*)p.v + krow * p.ldv + p.voff + head * 32 + h;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        if (wave > 0) {
-            red[((wave - 1) * 16 + r) * 64 + lane] = dKT[r];
+            for (int i = 0; i < 16; ++i) {
+                kreg[i] = k_in ? kr[2 * i] : 0.f;
+                vreg[i] = k_in ? vr[2 * i] : 0.f;
+            }
         }
-    }
-    __syncthreads();
-    if (wave == 0) {
+        f32x16 dKT, dVT;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dKT[r] += red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane];
-    }
-    __syncthreads();
+        for (int r = 0; r < 16; ++r) { dKT[r] = 0.f; dVT[r] = 0.f; }
+        for (int it = 0; it < nit; ++it) {
+            const int qt = it * 4 + wave;
+            const bool t_ok = qt < nqt;
+            __syncthreads();                            // the previous iteration's tile reads are done (and the tables are ready)
+            // ---- stage the Q and dO tiles (two lanes per query row, 16 floats each), D = rowsum(dO o O), lse, bias query term
+            {
+                const int r = lane >> 1, half = lane & 1;
+                const int tq = qt * 32 + r;
+                const bool ok = t_ok && tq < p.Nq;
+                const TokCoord qc = tok_coord(p.qmap, ok ? tq : 0);
+                const size_t qrow = tok_row(p.qmap, b, l, qc);
+                const size_t orow = tok_row(p.omap, b, l, qc);
+                const float* qp = (const float*)p.q + qrow * p.ldq + p.qoff + head * 32 + half * 16;
+                const float* op = (const float*)p.out + orow * p.ldo + p.ooff + head * 32 + half * 16;
+                const float* dp = bp.dout + orow * p.ldo + p.ooff + head * 32 + half * 16;
+                float dsum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        if (wave > 0) red[((wave - 1) * 16 + r) * 64 + lane] = dVT[r];
-    }
-    __syncthreads();
-    if (wave == 0) {
+                for (int c = 0; c < 4; ++c) {
+                    const float4 qv = ok ? *(const float4*)(qp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 dv = ok ? *(const float4*)(dp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 ov = ok ? *(const float4*)(op + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float* qd = Qs + r * kPad + half * 16 + 4 * c;
+                    float* dd = dOs + r * kPad + half * 16 + 4 * c;
+                    qd[0] = qv.x; qd[1] = qv.y; qd[2] = qv.z; qd[3] = qv.w;
+                    dd[0] = dv.x; dd[1] = dv.y; dd[2] = dv.z; dd[3] = dv.w;
+                    dsum += dv.x * ov.x + dv.y * ov.y + dv.z * ov.z + dv.w * ov.w;
+                }
+                dsum += __shfl_xor(dsum, 1, 64);
+                if (half == 0) {
+                    D_s[r] = dsum;
+                    // invalid rows: lse = +inf -> P = exp2(-inf) = 0
+                    lse_s[r] = ok ? p.lse[(((size_t)b * p.L + l) * p.heads + head) * p.Nq + tq] : INFINITY;
+                    qb_s[r] = BIAS ? rel_bias_query_term(p.kmap, p.bias_L, qc) : 0;
+                }
+            }
+            __syncthreads();
+            // ---- S = Q K^T and dP = dO V^T  (lane = key column, register r <-> query row (r & 3) + 8 (r >> 2) + 4 h)
+            f32x16 S, dP;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dVT[r] += red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane];
-        if (k_in) {
-            float* dkr = bp.dk + krow * p.ldk + p.koff + head * 32 + 4 * h;
-            float* dvr = bp.dv + krow * p.ldv + p.voff + head * 32 + 4 * h;
+            for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {               // dh rows 8 g + 4 h .. + 3
-                *(float4*)(dkr + 8 * g) = make_float4(dKT[4 * g] * p.scale, dKT[4 * g + 1] * p.scale, dKT[4 * g + 2] * p.scale,
-                                                      dKT[4 * g + 3] * p.scale);
-                *(float4*)(dvr + 8 * g) = make_float4(dVT[4 * g], dVT[4 * g + 1], dVT[4 * g + 2], dVT[4 * g + 3]);
+            for (int i = 0; i < 16; ++i) {
+                S = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[ql * kPad + 2 * i + h], kreg[i], S, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_32x32x2f32(dOs[ql * kPad + 2 * i + h], vreg[i], dP, 0, 0, 0);
+            }
+            // ---- P = exp2(z log2e - lse2),  dZ = P (dP - D)
+            f32x16 P, dZ;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = acc_row(r, lane);
+                float z = S[r] * sl2;
+                int bidx = 0;
+                if (BIAS) { bidx = qb_s[row] - kterm; z += bias_col[k_ok ? bidx : 0]; }
+                const float pr = k_ok ? __builtin_amdgcn_exp2f(z - lse_s[row]) : 0.f;
+                P[r] = pr;
+                dZ[r] = pr * (dP[r] - D_s[row]);
+                if (BIAS && k_ok && dZ[r] != 0.f) atomicAdd(&dtab[bidx], dZ[r]);
+            }
+            // ---- dV^T += dO^T P,  dK^T += Q^T dZ  (contraction over the query rows; step j pairs rows qj(0) and qj(1))
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int qj = (j & 3) + 8 * (j >> 2) + 4 * h;
+                dVT = __builtin_amdgcn_mfma_f32_32x32x2f32(dOs[qj * kPad + ql], P[j], dVT, 0, 0, 0);
+                dKT = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[qj * kPad + ql], dZ[j], dKT, 0, 0, 0);
+            }
+        }
+        // ---- reduce dK^T / dV^T over the four waves, store (lane = key column, register r <-> dh row)
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (wave > 0) red[((wave - 1) * 16 + r) * 64 + lane] = dKT[r];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dKT[r] += red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (wave > 0) red[((wave - 1) * 16 + r) * 64 + lane] = dVT[r];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dVT[r] += red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane];
+            if (k_in) {
+                float* dkr = bp.dk + krow * p.ldk + p.koff + head * 32 + 4 * h;
+                float* dvr = bp.dv + krow * p.ldv + p.voff + head * 32 + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {               // dh rows 8 g + 4 h .. + 3
+                    *(float4*)(dkr + 8 * g) = make_float4(dKT[4 * g] * p.scale, dKT[4 * g + 1] * p.scale, dKT[4 * g + 2] * p.scale,
+                                                          dKT[4 * g + 3] * p.scale);
+                    *(float4*)(dvr + 8 * g) = make_float4(dVT[4 * g], dVT[4 * g + 1], dVT[4 * g + 2], dVT[4 * g + 3]);
+                }
             }
         }
     }
@@ -226,6 +204,131 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdParams bp) {
             if (g != 0.f) atomicAdd(bp.dbias + (size_t)i * p.heads + head, g);
         }
     }
+}
+
+template <bool BIAS, bool MASK>
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnBwdParams bp) {
+    const AttnParams& p = bp.a;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = (float*)smem_raw;
+    constexpr int kWaveFloats = 2 * 32 * kPad + 32;
+    float* red = smem + 4 * kWaveFloats;                // [3][16][64] cross-wave reduction of dQ^T
+    float* bias_col = red + 3 * 16 * 64;                // [bias_rows] forward bias (x log2e)   (BIAS)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, ql = lane & 31;
+    const int b = blockIdx.z, qt = blockIdx.y;
+    const int l = blockIdx.x / p.heads, head = blockIdx.x - l * p.heads;
+    float* Kt = smem + wave * kWaveFloats;              // per wave: K and V tiles [32][33], per-key info [32]
+    float* Vt = Kt + 32 * kPad;
+    int* kinfo_s = (int*)(Vt + 32 * kPad);              // bias key term, or kMaskedKey for a masked / out-of-range key
+
+    if (BIAS) {
+        for (int i = tid; i < p.bias_rows; i += 256) bias_col[i] = p.bias_table[(size_t)i * p.heads + head] * kLog2eB;
+    }
+    // ---- this lane's query: Q / dO rows as B operands, lse, D = rowsum(dO o O), bias query term
+    const int tq = qt * 32 + ql;
+    const bool q_ok = tq < p.Nq;
+    const TokCoord qc = tok_coord(p.qmap, q_ok ? tq : 0);
+    const size_t qrow = tok_row(p.qmap, b, l, qc);
+    const size_t orow = tok_row(p.omap, b, l, qc);
+    float qreg[16], doreg[16];
+    float Dq = 0.f;
+    {
+        const float* qp = (const float*)p.q + qrow * p.ldq + p.qoff + head * 32 + h;
+        const float* op = (const float*)p.out + orow * p.ldo + p.ooff + head * 32 + h;
+        const float* dp = bp.dout + orow * p.ldo + p.ooff + head * 32 + h;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            qreg[i] = q_ok ? qp[2 * i] : 0.f;
+            doreg[i] = q_ok ? dp[2 * i] : 0.f;
+            Dq += q_ok ? doreg[i] * op[2 * i] : 0.f;
+        }
+        Dq += __shfl_xor(Dq, 32, 64);
+    }
+    const float lse_q = q_ok ? p.lse[(((size_t)b * p.L + l) * p.heads + head) * p.Nq + tq] : INFINITY;
+    const int qterm = BIAS ? rel_bias_query_term(p.kmap, p.bias_L, qc) : 0;
+    const float sl2 = p.scale * kLog2eB;
+
+    f32x16 dQT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dQT[r] = 0.f;
+    const int nkt = (p.Nk + 31) / 32;
+    const int nit = (nkt + 3) / 4;
+    for (int it = 0; it < nit; ++it) {
+        const int kt = it * 4 + wave;
+        const bool t_ok = kt < nkt;
+        __syncthreads();
+        {   // stage this wave's key tile: two lanes per key row, 16 floats each
+            const int r = lane >> 1, half = lane & 1;
+            const int tk = kt * 32 + r;
+            const bool ok = t_ok && tk < p.Nk;
+            const TokCoord kc = tok_coord(p.kmap, ok ? tk : 0);
+            const size_t krow = tok_row(p.kmap, b, l, kc);
+            const float* kp = (const float*)p.k + krow * p.ldk + p.koff + head * 32 + half * 16;
+            const float* vp = (const float*)p.v + krow * p.ldv + p.voff + head * 32 + half * 16;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 kv = ok ? *(const float4*)(kp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 vv = ok ? *(const float4*)(vp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float* kd = Kt + r * kPad + half * 16 + 4 * c;
+                float* vd = Vt + r * kPad + half * 16 + 4 * c;
+                kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+                vd[0] = vv.x; vd[1] = vv.y; vd[2] = vv.z; vd[3] = vv.w;
+            }
+            if (half == 0) {
+                bool vis = ok;
+                if (MASK && ok) vis = key_visible(p, b, l, kc);
+                kinfo_s[r] = vis ? (BIAS ? rel_bias_key_term(p.kmap, kc) : 0) : kMaskedKey;
+            }
+        }
+        __syncthreads();
+        // ---- S^T = K Q^T and dP^T = V dO^T  (lane = query column, register r <-> key row (r & 3) + 8 (r >> 2) + 4 h)
+        f32x16 S, dP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            S = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[ql * kPad + 2 * i + h], qreg[i], S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt[ql * kPad + 2 * i + h], doreg[i], dP, 0, 0, 0);
+        }
+        f32x16 dZ;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kinfo = kinfo_s[acc_row(r, lane)];
+            const bool vis = kinfo != kMaskedKey;
+            float z = S[r] * sl2;
+            if (BIAS) z += bias_col[vis ? qterm - kinfo : 0];
+            const float pr = vis ? __builtin_amdgcn_exp2f(z - lse_q) : 0.f;
+            dZ[r] = pr * (dP[r] - Dq);
+        }
+        // ---- dQ^T += K^T dZ^T  (contraction over the keys = the register index; step j pairs key rows kj(0) and kj(1))
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int kj = (j & 3) + 8 * (j >> 2) + 4 * h;
+            dQT = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[kj * kPad + ql], dZ[j], dQT, 0, 0, 0);
+        }
+    }
+    // ---- the waves' partial sums meet in LDS; lane = query column, register r <-> dh row
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (wave > 0) red[((wave - 1) * 16 + r) * 64 + lane] = dQT[r];
+    __syncthreads();
+    if (wave == 0 && q_ok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dQT[r] += red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane];
+        float* dqr = bp.dq + qrow * p.ldq + p.qoff + head * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *(float4*)(dqr + 8 * g) = make_float4(dQT[4 * g] * p.scale, dQT[4 * g + 1] * p.scale, dQT[4 * g + 2] * p.scale,
+                                                  dQT[4 * g + 3] * p.scale);
+    }
+}
+
+template <typename K>
+static void set_max_lds(K kernel) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 }  // namespace
@@ -259,17 +362,24 @@ extern "C" int cobevt_window_attention_bwd(const void* q, const void* k, const v
     if ((p.ldq | p.ldk | p.ldv | p.ldo | p.qoff | p.koff | p.voff | p.ooff) % 4) return COBEVT_ERR_SHAPE;
     p.Nq = p.qmap.ncam * p.qmap.w1 * p.qmap.w2;
     p.Nk = p.kmap.ncam * p.kmap.w1 * p.kmap.w2;
-    const dim3 grid(p.L * p.heads, (p.Nk + 31) / 32, p.B), block(256);
-    if (grid.y > 65535 || grid.z > 65535) return COBEVT_ERR_SHAPE;
-    size_t lds = (size_t)(32 * kPad + 4 * (3 * 32 * kPad + 4 * 32) + 3 * 16 * 64) * 4;
-    if (p.bias_mode) lds += (size_t)p.bias_rows * 8;
-    if (lds > 160 * 1024) return COBEVT_ERR_UNSUPPORTED;
+    const int nkt = (p.Nk + 31) / 32, nqt = (p.Nq + 31) / 32;
+    if (nkt > 65535 || nqt > 65535 || p.B > 65535) return COBEVT_ERR_SHAPE;
+    // dK / dV / dbias: about 2048 workgroups in all; the windows of one (head, key tile position) are shared by nsplit of them
+    long per_window = (long)p.heads * nkt * p.B;
+    int nsplit = (int)((2048 + per_window - 1) / per_window);
+    nsplit = nsplit < 1 ? 1 : (nsplit > p.L ? p.L : nsplit);
+    bp.nsplit = nsplit;
+    const size_t lds_kv = (size_t)(4 * (2 * 32 * kPad + 3 * 32) + 3 * 16 * 64) * 4 + (p.bias_mode ? (size_t)p.bias_rows * 8 : 0);
+    const size_t lds_q = (size_t)(4 * (2 * 32 * kPad + 32) + 3 * 16 * 64) * 4 + (p.bias_mode ? (size_t)p.bias_rows * 4 : 0);
+    if (lds_kv > 160 * 1024) return COBEVT_ERR_UNSUPPORTED;
+    const dim3 grid_kv(p.heads * nsplit, nkt, p.B), grid_q(p.L * p.heads, nqt, p.B), block(256);
     const bool hb = p.bias_mode != 0, hm = mask != nullptr;
-#define COBEVT_BWD_LAUNCH(B_, M_)                                                                                              \
-    do {                                                                                                                       \
-        static bool attr = false;                                                                                              \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<B_, M_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
-        hipLaunchKernelGGL((attn_bwd_kernel<B_, M_>), grid, block, lds, stream, bp);                                          \
+#define COBEVT_BWD_LAUNCH(B_, M_)                                                                     \
+    do {                                                                                              \
+        static bool attr = false;                                                                     \
+        if (!attr) { set_max_lds(attn_bwd_kv_kernel<B_, M_>); set_max_lds(attn_bwd_q_kernel<B_, M_>); attr = true; } \
+        hipLaunchKernelGGL((attn_bwd_kv_kernel<B_, M_>), grid_kv, block, lds_kv, stream, bp);         \
+        hipLaunchKernelGGL((attn_bwd_q_kernel<B_, M_>), grid_q, block, lds_q, stream, bp);            \
     } while (0)
     if (hb && hm) COBEVT_BWD_LAUNCH(true, true);
     else if (hb) COBEVT_BWD_LAUNCH(true, false);

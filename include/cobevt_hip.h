@@ -174,8 +174,8 @@ int cobevt_window_attention(const void* q, const void* k, const void* v, void* o
 
 /* Training slice (fp32 storage, dims[0] dtype = 1).  cobevt_window_attention_lse: the forward above that also stores the base-2
  * log-sum-exp of every query's logits, lse[B][L][heads][Nq] (mean_q must be 0).  cobevt_window_attention_bwd: given the forward
- * tensors, `out`, lse and dout (layout of out), writes dk, dv (layouts of k, v), ADDS dq into a zero-initialised buffer
- * (layout of q) and ADDS the bias-table gradient into dbias[bias_rows][heads] (zero-initialised; nullable without bias).
+ * tensors, `out`, lse and dout (layout of out), writes dq, dk, dv (layouts of q, k, v; rows no window covers are left
+ * untouched) and ADDS the bias-table gradient into dbias[bias_rows][heads] (zero-initialised; nullable without bias).
  * Replaces torch autograd through the einsum / softmax / einsum of fax_modules.py:219-237, swap_fusion_modules.py:100-121
  * (train_camera.py:143-179 loss.backward()). */
 int cobevt_window_attention_lse(const void* q, const void* k, const void* v, void* out, float* lse, const float* bias_table,
