@@ -4,7 +4,7 @@ from .fax_modules import (Attention as FaxAttention, BEVEmbedding, Bottleneck, C
                           CrossWinAttention, FAXModule, generate_grid, get_view_matrix)
 from .swap_fusion_modules import (Attention as SwapAttention, SwapFusionBlock, SwapFusionBlockMask,  # noqa: F401
                                   SwapFusionEncoder)
-from .base_transformer import FeedForward, PreNormResidual  # noqa: F401
+from .base_transformer import BaseEncoder, BaseTransformer, CavAttention, FeedForward, PreNorm, PreNormResidual  # noqa: F401
 from .resnet_ms import ResnetEncoder  # noqa: F401
 from .naive_decoder import NaiveDecoder  # noqa: F401
 from .naive_compress import NaiveCompressor  # noqa: F401
@@ -16,6 +16,7 @@ from .cvt_modules import CrossAttention, CrossViewAttention, CrossViewModule  # 
 from .cross_view_transformer import CrossViewTransformer  # noqa: F401
 from .cross_view_transformer_swap_fuse import CrossViewTransformerSwapFuse  # noqa: F401
 from .cross_view_transformer_fcooper import CrossViewTransformerFcooper  # noqa: F401
+from .cross_view_transformer_att_fuse import CrossViewTransformerAttFuse  # noqa: F401
 from .pipeline import CapturedCall, CapturedCorpBEVT, PipelinedCorpBEVT  # noqa: F401
 # the data formats either side of the path
 from .camera_bev_postprocessor import CameraBevPostprocessor  # noqa: F401

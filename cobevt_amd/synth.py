@@ -265,7 +265,7 @@ def nuscenes_inputs(key="gv11", seed=0):
 # ----------------------------------------------------------------------------------------------
 def cvt_small_config(kind="single"):
     """Reduced opv2v/opencood/hypes_yaml/opcamera/cvt*.yaml: resnet18, 128^2 images, 2 cams, id_pick [1, 3], dim 32, 1 head, BEV
-    64 with three decoder blocks -> 8x8 BEV queries.  kind: 'single' (cross_view_transformer), 'swap_fuse', 'fcooper'."""
+    64 with three decoder blocks -> 8x8 BEV queries.  kind: 'single' (cross_view_transformer), 'swap_fuse', 'fcooper', 'att_fuse'."""
     cfg = {
         "target": "dynamic",
         "encoder": {"num_layers": 18, "pretrained": False, "image_width": 128, "image_height": 128, "id_pick": [1, 3]},
@@ -286,6 +286,8 @@ def cvt_small_config(kind="single"):
     if kind == "swap_fuse":
         cfg["swap_fusion"] = {"input_dim": 32, "mlp_dim": 64, "agent_size": 3, "window_size": 4, "dim_head": 32, "drop_out": 0.1,
                               "depth": 2, "mask": True}
+    if kind == "att_fuse":
+        cfg["base_transformer"] = {"dim": 32, "depth": 2, "heads": 2, "dim_head": 32, "mlp_dim": 64, "dropout": 0.1, "max_cav": 3}
     return cfg
 
 
@@ -311,4 +313,7 @@ def cvt_config(kind="single", max_cav=5, image=512):
     if kind == "swap_fuse":
         cfg["swap_fusion"] = {"input_dim": 128, "mlp_dim": 256, "agent_size": max_cav, "window_size": 8, "dim_head": 32,
                               "drop_out": 0.1, "depth": 3, "mask": True}
+    if kind == "att_fuse":          # cvt_att_fuse.yaml:68-74
+        cfg["base_transformer"] = {"dim": 128, "depth": 2, "heads": 8, "dim_head": 32, "mlp_dim": 256, "dropout": 0.1,
+                                   "max_cav": max_cav}
     return cfg

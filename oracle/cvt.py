@@ -3,7 +3,9 @@
 Follows opv2v/opencood/models/sub_modules/cvt_modules.py (BEVEmbedding :41-90, CrossAttention :93-170, CrossViewAttention
 :173-283, CrossViewModule :286-327) and the model files cross_view_transformer.py:14-51 (single agent),
 cross_view_transformer_swap_fuse.py:63-131 (CVT + swap fusion), cross_view_transformer_fcooper.py:62-129 (CVT + F-Cooper
-max-out, fusion_modules/f_cooper_fuse.py:30-36).  Plain torch, functional over a flat state_dict.
+max-out, fusion_modules/f_cooper_fuse.py:30-36), cross_view_transformer_att_fuse.py:62-131 (CVT + per-pixel agent attention:
+base_transformer.py CavAttention :127-172, BaseEncoder :321-339, BaseTransformer :342-362).  Plain torch, functional over a flat
+state_dict.
 """
 import torch
 import torch.nn.functional as F
@@ -143,3 +145,41 @@ def cross_view_transformer_fcooper_forward(sd, config, batch):
     w, _ = _warp(sd, config, batch)
     fused = w.max(dim=1)[0].permute(0, 3, 1, 2)
     return _decode(sd, config, fused)
+
+
+def cav_attention(sd, pfx, x, mask, heads):
+    """CavAttention.forward, base_transformer.py:143-172: at every pixel, attention over the agents.  x (b l h w c) already
+    LayerNorm'ed; mask (b h w 1 l) (0 = agent not visible at that pixel, as a KEY) -> (b l h w c)."""
+    b, l, h, w, c = x.shape
+    t = x.permute(0, 2, 3, 1, 4)                                                    # b h w l c
+    q, k, v = F.linear(t, sd[pfx + "to_qkv.weight"]).chunk(3, dim=-1)
+    inner = q.shape[-1]
+    dh = inner // heads
+    scale = dh ** -0.5
+    split = lambda z: z.reshape(b, h, w, l, heads, dh).permute(0, 4, 1, 2, 3, 5)    # b m h w l c
+    q, k, v = split(q), split(k), split(v)
+    att = torch.matmul(q, k.transpose(-1, -2)) * scale                              # b m h w i j
+    att = att.masked_fill(mask.unsqueeze(1) == 0, -float("inf"))                    # (b 1 h w 1 l)
+    att = att.softmax(dim=-1)
+    out = torch.matmul(att, v)                                                      # b m h w l c
+    out = out.permute(0, 2, 3, 4, 1, 5).reshape(b, h, w, l, inner)
+    out = F.linear(out, sd[pfx + "to_out.0.weight"], sd[pfx + "to_out.0.bias"])
+    return out.permute(0, 3, 1, 2, 4)
+
+
+def base_transformer(sd, pfx, args, x, mask):
+    """BaseTransformer.forward (:357-362) over BaseEncoder (:335-339): depth x [PreNorm(CavAttention) + x, PreNorm(FeedForward) + x],
+    then the ego agent's map.  x (b l h w c), mask (b h w 1 l) -> (b h w c)."""
+    for i in range(args["depth"]):
+        a, f = "%sencoder.layers.%d.0." % (pfx, i), "%sencoder.layers.%d.1." % (pfx, i)
+        x = cav_attention(sd, a + "fn.", _ln(x, sd, a + "norm"), mask, args["heads"]) + x
+        y = _ln(x, sd, f + "norm")
+        x = _lin(F.gelu(_lin(y, sd, f + "fn.net.0")), sd, f + "fn.net.3") + x
+    return x[:, 0]
+
+
+def cross_view_transformer_att_fuse_forward(sd, config, batch):
+    """CrossViewTransformerAttFuse.forward, cross_view_transformer_att_fuse.py:96-131."""
+    w, com_mask = _warp(sd, config, batch)
+    fused = base_transformer(sd, "fusion_net.", config["base_transformer"], w, com_mask)      # b h w c
+    return _decode(sd, config, fused.permute(0, 3, 1, 2))

@@ -481,13 +481,15 @@ def gv17():
     from opencood.models.cross_view_transformer import CrossViewTransformer as R_Cvt
     from opencood.models.cross_view_transformer_swap_fuse import CrossViewTransformerSwapFuse as R_CvtSwap
     from opencood.models.cross_view_transformer_fcooper import CrossViewTransformerFcooper as R_CvtFcooper
+    from opencood.models.cross_view_transformer_att_fuse import CrossViewTransformerAttFuse as R_CvtAtt
     out = {}
     single = synth.opv2v_batch(agents=1, cams=2, image=128, max_cav=3, seed=cases.SEED)
     single_b = {k: single[k] for k in ("inputs", "intrinsic", "extrinsic")}
     multi = synth.opv2v_batch(agents=2, cams=2, image=128, max_cav=3, seed=cases.SEED)
     for kind, cls, fwd, batch in (("single", R_Cvt, o_cvt.cross_view_transformer_forward, single_b),
                                   ("swap_fuse", R_CvtSwap, o_cvt.cross_view_transformer_swap_fuse_forward, multi),
-                                  ("fcooper", R_CvtFcooper, o_cvt.cross_view_transformer_fcooper_forward, multi)):
+                                  ("fcooper", R_CvtFcooper, o_cvt.cross_view_transformer_fcooper_forward, multi),
+                                  ("att_fuse", R_CvtAtt, o_cvt.cross_view_transformer_att_fuse_forward, multi)):
         cfg = synth.cvt_small_config(kind)
         m = fill_module_(cls(copy.deepcopy(cfg)).eval(), cases.SEED)
         ref = m(dict(batch))

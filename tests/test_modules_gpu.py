@@ -342,7 +342,8 @@ def test_lidar_fusebevt_full_size(cuda):
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
 @pytest.mark.parametrize("kind,core", [("single", "cross_view_transformer"), ("swap_fuse", "cross_view_transformer_swap_fuse"),
-                                       ("fcooper", "cross_view_transformer_fcooper")])
+                                       ("fcooper", "cross_view_transformer_fcooper"),
+                                       ("att_fuse", "cross_view_transformer_att_fuse")])
 def test_cvt_baseline_models(cuda, dtype, tol, kind, core):
     """the CVT baselines behind the reference's registry names, against the reference's own logits (gv17):
     CVT per-agent encoder (camera-paired global cross attention), + swap fusion, + F-Cooper max-out."""
@@ -382,3 +383,28 @@ def test_cvt_full_config_vs_oracle(cuda):
     e32, e16 = rel_err(y32, ref), rel_err(y16, ref)
     print("CVT swap-fuse full config: fp32 rel %.2e | bf16 rel %.2e" % (e32, e16))
     assert e32 <= 1e-3 and e16 <= 5e-2
+
+
+def test_cav_attention_and_base_transformer_full_width(cuda):
+    """cvt_att_fuse.yaml's fusion at its real width (dim 128, 8 heads of 32, depth 2, 5 agent slots on a 32 x 32 map) against
+    the oracle: per-pixel attention over the agents with the ROI / padded-agent key mask."""
+    import oracle.cvt as o_cvt
+    args = synth.cvt_config("att_fuse")["base_transformer"]
+    m = fill_module_(host.BaseTransformer(dict(args)), cases.SEED).eval()
+    x = synth.procedural_input("att.x", (2, 5, 32, 32, 128), cases.SEED)
+    mask = torch.ones(2, 32, 32, 1, 5)
+    mask[1, :, :, :, 3:] = 0                           # two padded agents in sample 1
+    mask[0, :10, :, :, 1] = 0                          # a partially visible agent
+    mask[0, :, 20:, :, 4] = 0
+    ref = o_cvt.base_transformer(m.state_dict(), "", args, x, mask)
+    m = m.to(cuda)
+    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, 3e-2)):
+        with host.compute_dtype(dtype):
+            y = m(x.to(cuda), mask.to(cuda))
+        assert_close(y, ref, tol, "BaseTransformer %s" % dtype)
+    att = m.encoder.layers[0][0].fn
+    xa = x.to(cuda)
+    with host.compute_dtype(torch.float32):
+        ya = att(xa, mask.to(cuda))
+    assert_close(ya, o_cvt.cav_attention({k: v.cpu() for k, v in att.state_dict().items()}, "", x, mask, args["heads"]), 1e-3,
+                 "CavAttention")

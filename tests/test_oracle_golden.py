@@ -219,7 +219,8 @@ def test_gv13_naive_compressor():
 
 
 @pytest.mark.parametrize("kind,core", [("single", "cross_view_transformer"), ("swap_fuse", "cross_view_transformer_swap_fuse"),
-                                       ("fcooper", "cross_view_transformer_fcooper")])
+                                       ("fcooper", "cross_view_transformer_fcooper"),
+                                       ("att_fuse", "cross_view_transformer_att_fuse")])
 def test_gv17_cvt_baselines(kind, core):
     """CVT baseline models: the host mirrors' state_dict schema equals the reference's key for key, the
     registry resolves the reference's core_method names, and the oracle reproduces the reference's logits."""
@@ -234,7 +235,8 @@ def test_gv17_cvt_baselines(kind, core):
     agents = 1 if kind == "single" else 2
     batch = synth.opv2v_batch(agents=agents, cams=2, image=128, max_cav=3, seed=cases.SEED)
     fwd = {"single": o_cvt.cross_view_transformer_forward, "swap_fuse": o_cvt.cross_view_transformer_swap_fuse_forward,
-           "fcooper": o_cvt.cross_view_transformer_fcooper_forward}[kind]
+           "fcooper": o_cvt.cross_view_transformer_fcooper_forward,
+           "att_fuse": o_cvt.cross_view_transformer_att_fuse_forward}[kind]
     assert_close(fwd(sd, cfg, dict(batch))["dynamic_seg"], g[kind + "_dynamic_seg"], TOL, "CVT " + kind)
     if kind == "single":
         assert_close(o_cvt.encode_agents(sd, cfg, dict(batch)), g["single_cvm"], TOL, "CrossViewModule")
