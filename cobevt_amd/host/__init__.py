@@ -17,6 +17,9 @@ from .cross_view_transformer import CrossViewTransformer  # noqa: F401
 from .cross_view_transformer_swap_fuse import CrossViewTransformerSwapFuse  # noqa: F401
 from .cross_view_transformer_fcooper import CrossViewTransformerFcooper  # noqa: F401
 from .cross_view_transformer_att_fuse import CrossViewTransformerAttFuse  # noqa: F401
+from .v2v_fuse import ConvGRU, DiscoNetFusion, PixelWeightedFusionSoftmax, V2VNetFusion  # noqa: F401
+from .cross_view_transformer_v2vnet import CrossViewTransformerV2VNet  # noqa: F401
+from .cross_view_transformer_disconet import CrossViewTransformerDiscoNet  # noqa: F401
 from .pipeline import CapturedCall, CapturedCorpBEVT, PipelinedCorpBEVT  # noqa: F401
 # the data formats either side of the path
 from .camera_bev_postprocessor import CameraBevPostprocessor  # noqa: F401

@@ -1,0 +1,10 @@
+"""CrossViewTransformerDiscoNet (CVT per agent + DiscoNet pixel-weighted fusion) — mirror of
+opv2v/opencood/models/cross_view_transformer_disconet.py:14-68 (cvt_disconet.yaml)."""
+from .cross_view_transformer_v2vnet import _CvtPairwiseBase
+from .v2v_fuse import DiscoNetFusion
+
+
+class CrossViewTransformerDiscoNet(_CvtPairwiseBase):
+    def __init__(self, config):
+        super().__init__(config)
+        self.fusion_net = DiscoNetFusion(config["disconet_fusion"])

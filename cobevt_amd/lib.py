@@ -32,6 +32,10 @@ SIGNATURES = {
     "cobevt_linear_rows_wfrag": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_long_p, ctypes.c_float, _vp]),
     "cobevt_linear_rows": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_long_p, ctypes.c_float, _vp]),
     "cobevt_attn_mlp_chain": (ctypes.c_int, [_vp] * 14 + [_c_int_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
+    "cobevt_pairwise_warp": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_float, _vp]),
+    "cobevt_agent_message_reduce": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int] * 6 + [_vp]),
+    "cobevt_gru_zero_state": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_int, _vp]),
+    "cobevt_agent_softmax_sum": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp] + [ctypes.c_int] * 6 + [_vp]),
     "cobevt_window_attention": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int_p, ctypes.c_float, _vp]),
     "cobevt_window_attention_lse": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int_p, ctypes.c_float, _vp]),
     "cobevt_layernorm_bwd": (ctypes.c_int, [_vp] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp]),

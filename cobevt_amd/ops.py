@@ -812,6 +812,57 @@ def sttf_warp(x, tmat, cav_mask, discrete_ratio, downsample_rate, want_mask=True
     return (out, com, cav) if record_len is not None else (out, com)
 
 
+def pairwise_warp(x, pairwise, record_len, max_cav, discrete_ratio, downsample_rate):
+    """x (sum(record_len), H, W, C) un-grouped agent maps; pairwise (B, L, L, 4, 4) fp32; record_len device int32 (B,) ->
+    nb (B, L, L, H, W, C): nb[b, i, j] = agent j in agent i's frame; roi (B, L, L, H, W) fp32 (v2v_fuse.py:59-103)."""
+    _need_cuda(x, pairwise, record_len)
+    if record_len.dtype != torch.int32 or x.dim() != 4 or pairwise.dtype != torch.float32:
+        raise CobevtHipError("pairwise_warp: record_len int32 on the device, x (N, H, W, C), pairwise fp32")
+    b, l = record_len.shape[0], int(max_cav)
+    _, h, w, c = x.shape
+    if tuple(pairwise.shape) != (b, l, l, 4, 4):
+        raise CobevtHipError("pairwise_warp: pairwise must be (B, max_cav, max_cav, 4, 4)")
+    nb = torch.empty((b, l, l, h, w, c), device=x.device, dtype=x.dtype)
+    roi = torch.empty((b, l, l, h, w), device=x.device, dtype=torch.float32)
+    rc = _L.load().cobevt_pairwise_warp(_p(x), _p(pairwise.contiguous()), _p(record_len), _p(nb), _p(roi), dcode(x.dtype), b, l, h, w, c,
+                                        ctypes.c_float(discrete_ratio), ctypes.c_float(downsample_rate), _stream())
+    _L.check(rc, "cobevt_pairwise_warp")
+    return nb, roi
+
+
+def agent_message_reduce(msg, ego, roi, record_len, mode):
+    """msg (B, L, L, H, W, C), ego (N, H, W, C), roi (B, L, L, H, W) -> (N, H, W, C): mean ('avg') | max over the valid source agents of
+    (msg + ego) * roi  (v2v_fuse.py:108-119)"""
+    _need_cuda(msg, ego, roi, record_len)
+    b, l, _, h, w, c = msg.shape
+    out = torch.zeros_like(ego)
+    rc = _L.load().cobevt_agent_message_reduce(_p(msg), _p(ego), _p(roi), _p(record_len), _p(out), dcode(msg.dtype), b, l, h * w, c,
+                                               {"avg": 0, "max": 1}[mode], _stream())
+    _L.check(rc, "cobevt_agent_message_reduce")
+    return out
+
+
+def gru_zero_state(x):
+    """(..., 2C) [update | candidate] pre-activations -> (..., C): sigmoid(update) * tanh(candidate)"""
+    _need_cuda(x)
+    c = x.shape[-1] // 2
+    out = torch.empty(x.shape[:-1] + (c,), device=x.device, dtype=x.dtype)
+    rc = _L.load().cobevt_gru_zero_state(_p(x), _p(out), dcode(x.dtype), x.numel() // (2 * c), c, _stream())
+    _L.check(rc, "cobevt_gru_zero_state")
+    return out
+
+
+def agent_softmax_sum(score, nb, roi, record_len, n_agents, use_mask=True):
+    """score (B*L*L*H*W, lds) (column 0), nb (B, L, L, H, W, C), roi -> (n_agents, H, W, C)  (disconet_fuse.py:141-150)"""
+    _need_cuda(score, nb, roi, record_len)
+    b, l, _, h, w, c = nb.shape
+    out = torch.zeros((n_agents, h, w, c), device=nb.device, dtype=nb.dtype)
+    rc = _L.load().cobevt_agent_softmax_sum(_p(score), score.shape[-1], _p(nb), _p(roi), _p(record_len), _p(out), dcode(nb.dtype),
+                                            b, l, h * w, c, int(bool(use_mask)), _stream())
+    _L.check(rc, "cobevt_agent_softmax_sum")
+    return out
+
+
 def invert_small(m):
     """Batched inverse of (..., 3, 3) or (..., 4, 4) fp32 matrices on the device."""
     _need_cuda(m)

@@ -137,11 +137,19 @@ def opv2v_batch(agents, cams=4, image=512, max_cav=5, seed=0, batch=1):
     for b in range(batch):
         for a in range(min(agents, max_cav)):
             tm[b, a] = _rz(10.0 * a) @ _trans(6.0 * a, -4.0 * a, 0.0)
+    # intermediate_fusion_dataset.py:110-150: pairwise[i, j] = inv(T_j) T_i for the valid agents, identity elsewhere
+    pw = np.tile(np.eye(4, dtype=np.float64), (batch, max_cav, max_cav, 1, 1))
+    for b in range(batch):
+        for i in range(min(agents, max_cav)):
+            for j in range(min(agents, max_cav)):
+                if i != j:
+                    pw[b, i, j] = np.linalg.inv(tm[b, j]) @ tm[b, i]
     return {
         "inputs": inputs,
         "intrinsic": intrinsic,
         "extrinsic": extrinsic,
         "transformation_matrix": torch.from_numpy(tm.astype(np.float32)),
+        "pairwise_t_matrix": torch.from_numpy(pw.astype(np.float32)),
         "record_len": torch.full((batch,), agents, dtype=torch.int64),
     }
 
@@ -265,7 +273,7 @@ def nuscenes_inputs(key="gv11", seed=0):
 # ----------------------------------------------------------------------------------------------
 def cvt_small_config(kind="single"):
     """Reduced opv2v/opencood/hypes_yaml/opcamera/cvt*.yaml: resnet18, 128^2 images, 2 cams, id_pick [1, 3], dim 32, 1 head, BEV
-    64 with three decoder blocks -> 8x8 BEV queries.  kind: 'single' (cross_view_transformer), 'swap_fuse', 'fcooper', 'att_fuse'."""
+    64 with three decoder blocks -> 8x8 BEV queries.  kind: 'single' (cross_view_transformer), 'swap_fuse', 'fcooper', 'att_fuse', 'v2vnet', 'disconet'."""
     cfg = {
         "target": "dynamic",
         "encoder": {"num_layers": 18, "pretrained": False, "image_width": 128, "image_height": 128, "id_pick": [1, 3]},
@@ -288,6 +296,13 @@ def cvt_small_config(kind="single"):
                               "depth": 2, "mask": True}
     if kind == "att_fuse":
         cfg["base_transformer"] = {"dim": 32, "depth": 2, "heads": 2, "dim_head": 32, "mlp_dim": 64, "dropout": 0.1, "max_cav": 3}
+    gru = {"H": 8, "W": 8, "num_layers": 1, "kernel_size": [[3, 3]]}
+    if kind == "v2vnet":
+        cfg["v2vnet_fusion"] = {"resolution": 1.5625, "downsample_rate": 8, "num_iteration": 2, "in_channels": 32, "gru_flag": True,
+                                "agg_operator": "avg", "conv_gru": gru}
+    if kind == "disconet":
+        cfg["disconet_fusion"] = {"use_temporal_encoding": True, "resolution": 1.5625, "downsample_rate": 8, "num_iteration": 2,
+                                  "in_channels": 32, "gru_flag": True, "use_mask": True, "agg_operator": "avg", "conv_gru": gru}
     return cfg
 
 
@@ -316,4 +331,11 @@ def cvt_config(kind="single", max_cav=5, image=512):
     if kind == "att_fuse":          # cvt_att_fuse.yaml:68-74
         cfg["base_transformer"] = {"dim": 128, "depth": 2, "heads": 8, "dim_head": 32, "mlp_dim": 256, "dropout": 0.1,
                                    "max_cav": max_cav}
+    gru = {"H": 32, "W": 32, "num_layers": 1, "kernel_size": [[3, 3]]}
+    if kind == "v2vnet":            # cvt_v2vnet.yaml:68-79
+        cfg["v2vnet_fusion"] = {"resolution": 0.390625, "downsample_rate": 8, "num_iteration": 3, "in_channels": 128, "gru_flag": True,
+                                "agg_operator": "avg", "conv_gru": gru}
+    if kind == "disconet":          # cvt_disconet.yaml:68-81
+        cfg["disconet_fusion"] = {"use_temporal_encoding": True, "resolution": 0.390625, "downsample_rate": 8, "num_iteration": 3,
+                                  "in_channels": 128, "gru_flag": True, "use_mask": True, "agg_operator": "avg", "conv_gru": gru}
     return cfg

@@ -251,6 +251,27 @@ int cobevt_to_nhwc(const void* in, int in_dtype, void* out, int out_dtype, int N
 int cobevt_from_nhwc(const void* in, int in_dtype, void* out, int out_dtype, int N, int C, int H, int W,
                      const long* strides, hipStream_t stream);
 
+/* Pairwise-warp fusion baselines (V2VNet fusion_modules/v2v_fuse.py:72-144, DiscoNet fusion_modules/disconet_fuse.py:106-168) on the
+ * un-grouped channels-last agent batch x (sum(record_len), H, W, C), H == W; record_len device int32[B]; pairwise (B, L, L, 4, 4)
+ * fp32 = batch['pairwise_t_matrix'] (intermediate_fusion_dataset.py:110-150).  All maps stay in their original orientation (the
+ * reference's transpose + flip is folded into the kernels' indexing).
+ * cobevt_pairwise_warp: nb[b][i][j] (B, L, L, H, W, C) = agent j's map warped into agent i's frame (zeros unless i, j <
+ *   record_len[b]); roi (B, L, L, H, W) fp32 = get_rotated_roi's mask (torch_transformation_utils.py:77-105) at the position the
+ *   reference multiplies that output pixel with.
+ * cobevt_agent_message_reduce: out[off_b + i] = mean (mode 0) | max (mode 1) over j < record_len[b] of
+ *   (msg[b][i][j] + ego[off_b + i]) * roi[b][i][j]   (v2v_fuse.py:108-119; ego = the ego half of msg_cnn + its bias).
+ * cobevt_gru_zero_state: out[row] = sigmoid(in[row][0:C]) * tanh(in[row][C:2C]): the ConvGRU cell with the zero hidden state
+ *   the fusions always pass (convgru.py:57-78, v2v_fuse.py:125-130).
+ * cobevt_agent_softmax_sum: out[off_b + i] = sum_j softmax_j(score or -inf where roi == 0) * nb[b][i][j] * roi[b][i][j]
+ *   (disconet_fuse.py:35-42,141-150); score = column 0 of a (B*L*L*H*W, lds) matrix. */
+int cobevt_pairwise_warp(const void* x, const float* pairwise, const int* record_len, void* nb, float* roi, int dtype, int B, int L,
+                         int H, int W, int C, float discrete_ratio, float downsample_rate, hipStream_t stream);
+int cobevt_agent_message_reduce(const void* msg, const void* ego, const float* roi, const int* record_len, void* out, int dtype,
+                                int B, int L, int HW, int C, int mode, hipStream_t stream);
+int cobevt_gru_zero_state(const void* in, void* out, int dtype, long rows, int C, hipStream_t stream);
+int cobevt_agent_softmax_sum(const void* score, int lds, const void* nb, const float* roi, const int* record_len, void* out, int dtype,
+                             int B, int L, int HW, int C, int use_mask, hipStream_t stream);
+
 /* regroup: split by record_len (device int32[B]), zero pad to max_cav, agent mask (B,max_cav) fp32.
  * Replaces fuse_utils.py:8-61 without its host synchronisation (:26). */
 int cobevt_regroup(const void* in, const int* record_len, void* out, float* mask, int dtype, int B, int max_cav,

@@ -482,6 +482,9 @@ def gv17():
     from opencood.models.cross_view_transformer_swap_fuse import CrossViewTransformerSwapFuse as R_CvtSwap
     from opencood.models.cross_view_transformer_fcooper import CrossViewTransformerFcooper as R_CvtFcooper
     from opencood.models.cross_view_transformer_att_fuse import CrossViewTransformerAttFuse as R_CvtAtt
+    from opencood.models.cross_view_transformer_v2vnet import CrossViewTransformerV2VNet as R_CvtV2V
+    from opencood.models.cross_view_transformer_disconet import CrossViewTransformerDiscoNet as R_CvtDisco
+    import oracle.v2v as o_v2v
     out = {}
     single = synth.opv2v_batch(agents=1, cams=2, image=128, max_cav=3, seed=cases.SEED)
     single_b = {k: single[k] for k in ("inputs", "intrinsic", "extrinsic")}
@@ -489,7 +492,9 @@ def gv17():
     for kind, cls, fwd, batch in (("single", R_Cvt, o_cvt.cross_view_transformer_forward, single_b),
                                   ("swap_fuse", R_CvtSwap, o_cvt.cross_view_transformer_swap_fuse_forward, multi),
                                   ("fcooper", R_CvtFcooper, o_cvt.cross_view_transformer_fcooper_forward, multi),
-                                  ("att_fuse", R_CvtAtt, o_cvt.cross_view_transformer_att_fuse_forward, multi)):
+                                  ("att_fuse", R_CvtAtt, o_cvt.cross_view_transformer_att_fuse_forward, multi),
+                                  ("v2vnet", R_CvtV2V, o_v2v.cross_view_transformer_v2vnet_forward, multi),
+                                  ("disconet", R_CvtDisco, o_v2v.cross_view_transformer_disconet_forward, multi)):
         cfg = synth.cvt_small_config(kind)
         m = fill_module_(cls(copy.deepcopy(cfg)).eval(), cases.SEED)
         ref = m(dict(batch))

@@ -343,7 +343,8 @@ def test_lidar_fusebevt_full_size(cuda):
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
 @pytest.mark.parametrize("kind,core", [("single", "cross_view_transformer"), ("swap_fuse", "cross_view_transformer_swap_fuse"),
                                        ("fcooper", "cross_view_transformer_fcooper"),
-                                       ("att_fuse", "cross_view_transformer_att_fuse")])
+                                       ("att_fuse", "cross_view_transformer_att_fuse"),
+                                       ("v2vnet", "cross_view_transformer_v2vnet"), ("disconet", "cross_view_transformer_disconet")])
 def test_cvt_baseline_models(cuda, dtype, tol, kind, core):
     """the CVT baselines behind the reference's registry names, against the reference's own logits (gv17):
     CVT per-agent encoder (camera-paired global cross attention), + swap fusion, + F-Cooper max-out."""
@@ -408,3 +409,47 @@ def test_cav_attention_and_base_transformer_full_width(cuda):
         ya = att(xa, mask.to(cuda))
     assert_close(ya, o_cvt.cav_attention({k: v.cpu() for k, v in att.state_dict().items()}, "", x, mask, args["heads"]), 1e-3,
                  "CavAttention")
+
+
+def _pairwise_case(batch, agents, max_cav, c, hw, seed):
+    b = synth.opv2v_batch(agents=agents, cams=1, image=32, max_cav=max_cav, seed=seed, batch=batch)
+    x = synth.procedural_input("pairwise.x", (batch * agents, c, hw, hw), seed)
+    return x, b["record_len"], b["pairwise_t_matrix"]
+
+
+@pytest.mark.parametrize("kind", ["v2vnet", "disconet"])
+def test_pairwise_fusion_full_width_vs_oracle(cuda, kind):
+    """cvt_v2vnet.yaml / cvt_disconet.yaml fusion at its real size (128 channels, 32 x 32 maps, 5 agent slots, 3 iterations; two
+    samples of three agents: 2 x 3 x 3 pairwise warps per iteration) against the oracle"""
+    import oracle.v2v as o_v2v
+    key = {"v2vnet": "v2vnet_fusion", "disconet": "disconet_fusion"}[kind]
+    args = synth.cvt_config(kind)[key]
+    cls = {"v2vnet": host.V2VNetFusion, "disconet": host.DiscoNetFusion}[kind]
+    fwd = {"v2vnet": o_v2v.v2vnet_fusion, "disconet": o_v2v.disconet_fusion}[kind]
+    m = fill_module_(cls(copy.deepcopy(args)), cases.SEED).eval()
+    x, rl, pw = _pairwise_case(2, 3, 5, 128, 32, cases.SEED)
+    ref = fwd(m.state_dict(), "", args, x, rl, pw)
+    m = m.to(cuda)
+    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, 5e-2)):
+        with host.compute_dtype(dtype):
+            y = m(x.to(cuda), rl.to(cuda), pw.to(cuda))
+        assert_close(y, ref, tol, "%s fusion %s" % (kind, dtype))
+
+
+def test_v2vnet_fusion_variants_and_ragged_batch(cuda):
+    """max aggregation, the gru_flag = False branch (v2v_fuse.py:112-133), samples with different agent counts"""
+    import oracle.v2v as o_v2v
+    base = synth.cvt_small_config("v2vnet")["v2vnet_fusion"]
+    b1 = synth.opv2v_batch(agents=3, cams=1, image=32, max_cav=3, seed=1)
+    b2 = synth.opv2v_batch(agents=1, cams=1, image=32, max_cav=3, seed=2)
+    pw = torch.cat([b1["pairwise_t_matrix"], b2["pairwise_t_matrix"]])
+    rl = torch.tensor([3, 1])
+    x = synth.procedural_input("pairwise.ragged", (4, 32, 8, 8), cases.SEED)
+    for agg, gru in (("max", True), ("avg", False)):
+        args = dict(base, agg_operator=agg, gru_flag=gru)
+        m = fill_module_(host.V2VNetFusion(copy.deepcopy(args)), cases.SEED).eval()
+        ref = o_v2v.v2vnet_fusion(m.state_dict(), "", args, x, rl, pw)
+        m = m.to(cuda)
+        with host.compute_dtype(torch.float32):
+            y = m(x.to(cuda), rl.to(cuda), pw.to(cuda))
+        assert_close(y, ref, 1e-3, "V2VNetFusion agg=%s gru=%s" % (agg, gru))
