@@ -414,8 +414,15 @@ __device__ unsigned long long cobevt_conv3_rt[3 * 2048];    // per workgroup: s_
 // output pixels needs 5 x 33 input pixels; they are stored de-interleaved by column parity ([row][parity][17 pixels]) so
 // that a tap's A fragments are again 16 consecutive pixels at the 144-byte stride (conflict-free ds_read_b128), and the
 // patch is single-buffered (25.6 KB per strip; these layers have 1-4 channel chunks, the refill is exposed 0-3 times).
-template <typename T, int MT, int WN, int KS, int S = 1> struct Conv3SCfg {
-    static constexpr int NT = 512, KG = 4, KGW = KG / KS;
+// NW = waves per workgroup.  8: one workgroup per CU, patch double-buffered across channel chunks.  4 (stride 1, one 32-cout tile x
+// four k-splits): for layers with <= 32 output channels (FAX down-sampling 128 -> 32, decoder tails), where a 64-cout tile wastes
+// half its MFMAs - the patch is single-buffered (46 KB), two workgroups share a CU and fill each other's barrier / refill gaps.
+// In-graph: 128 -> 32 on 5 x 128 x 128 22.1 -> 12.9 us, on 5 x 64 x 64 13.3 -> 7.1 us (tools/conv_graph_probe.py).  The same
+// half-size form with 64-cout tiles measured SLOWER than the eight-wave kernel on the 256- / 512-channel layers (29.2 vs 27.3 us:
+// twice the patch fills, exposed patch stores) and is not built.
+template <typename T, int MT, int WN, int KS, int S = 1, int NW = 8> struct Conv3SCfg {
+    static constexpr int NT = 64 * NW, KG = 4, KGW = KG / KS;
+    static constexpr bool HALF = NW == 4;
     static constexpr int BN = WN * 32;
     static constexpr int PW = S == 1 ? 18 : 33;               // input pixels per patch row
     static constexpr int SROWS = S == 1 ? 4 : 5;              // input rows per strip
@@ -426,14 +433,15 @@ template <typename T, int MT, int WN, int KS, int S = 1> struct Conv3SCfg {
     static constexpr int PATCH_BYTES = MT * STRIP_BYTES;
     static constexpr int SSTR = BN * 4 + 16;
     static constexpr int STAGE_BYTES = MT * 32 * SSTR;
-    static constexpr int MAIN_BYTES = (S == 1 ? 2 : 1) * PATCH_BYTES;
+    static constexpr int MAIN_BYTES = (S == 1 && !HALF ? 2 : 1) * PATCH_BYTES;
     static constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
-    static_assert(WN * KS == 8, "eight waves");
+    static_assert(WN * KS == NW && (NW == 8 || (NW == 4 && S == 1)), "eight waves, or four (stride 1)");
 };
 
-template <typename T, int MT, int WN, int KS, int S>
-__global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
-    using C = Conv3SCfg<T, MT, WN, KS, S>;
+template <typename T, int MT, int WN, int KS, int S, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kernel(Conv3Params p) {
+    using C = Conv3SCfg<T, MT, WN, KS, S, NW>;
+    constexpr bool HALF = C::HALF;
     constexpr int NT = C::NT, KG = C::KG, KGW = C::KGW, BN = C::BN, PW = C::PW;
     constexpr int CH = Elem<T>::kChunk;
     constexpr int CC = KG * 32 / Elem<T>::kBytes;
@@ -574,8 +582,8 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
     COBEVT_TRACE_MARK(1);
     auto run_chunk = [&](int chunk) {
         const bool more = chunk + 1 < nchunk;
-        unsigned char* pbuf = patch + (S == 1 ? (chunk & 1) * C::PATCH_BYTES : 0);
-        unsigned char* pother = patch + (S == 1 ? ((chunk & 1) ^ 1) * C::PATCH_BYTES : 0);
+        unsigned char* pbuf = patch + (S == 1 && !HALF ? (chunk & 1) * C::PATCH_BYTES : 0);
+        unsigned char* pother = patch + (S == 1 && !HALF ? ((chunk & 1) ^ 1) * C::PATCH_BYTES : 0);
         if (S == 1 && !(COBEVT_CONV3_KNOCK & 8)) load_patch(more ? chunk + 1 : chunk);   // unconditional (clamped): counted vmcnt
         // A fragments run two k-groups ahead of the MFMAs in a three-slot register ring (9 * KGW groups per chunk, a
         // multiple of 3, so slots are static); sched_group_barrier pins the issue order "one ds_read, one MFMA", i.e. a
@@ -627,7 +635,7 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             // the other buffer has been free since the last barrier: write the next chunk's patch under taps 7-8
-            if (S == 1 && tap == 6 && more && !(COBEVT_CONV3_KNOCK & 8)) {
+            if (S == 1 && !HALF && tap == 6 && more && !(COBEVT_CONV3_KNOCK & 8)) {
                 store_patch(pother);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -642,6 +650,10 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
         }
 #endif
         __syncthreads();
+        if (HALF && more) {                          // single patch buffer: every wave is done reading it, write the next chunk
+            store_patch(pbuf);
+            __syncthreads();
+        }
         if (chunk < 4) COBEVT_TRACE_MARK(42 + 2 * chunk);
     };
     auto coord = [&](int px, int& im, int& oy, int& ox) {
@@ -747,9 +759,9 @@ __global__ __launch_bounds__(512) void conv3x3_strips_kernel(Conv3Params p) {
     COBEVT_TRACE_RT(1);
 }
 
-template <typename T, int MT, int WN, int KS, int S>
+template <typename T, int MT, int WN, int KS, int S, int NW = 8>
 static int launch_conv3s(Conv3Params p, int coutp, hipStream_t stream) {
-    using C = Conv3SCfg<T, MT, WN, KS, S>;
+    using C = Conv3SCfg<T, MT, WN, KS, S, NW>;
     if ((long)p.N * p.H * p.W * p.Cin >= 0x7fffffffL) return COBEVT_ERR_UNSUPPORTED;   // 32-bit patch offsets
     p.tiles_y = (p.Ho + 1) / 2;
     p.tiles_x = (p.Wo + 15) / 16;
@@ -761,15 +773,20 @@ static int launch_conv3s(Conv3Params p, int coutp, hipStream_t stream) {
     constexpr size_t lds = C::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_strips_kernel<T, MT, WN, KS, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv3x3_strips_kernel<T, MT, WN, KS, S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_strips_kernel<T, MT, WN, KS, S>), dim3((unsigned)blocks), dim3(C::NT), lds, stream, p);
+    hipLaunchKernelGGL((conv3x3_strips_kernel<T, MT, WN, KS, S, NW>), dim3((unsigned)blocks), dim3(C::NT), lds, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
 template <typename T, int MT>
 static int launch_conv3s_bn(const Conv3Params& p, int coutp, int bn64, int stride, hipStream_t stream) {
+    // code 3: 32-cout tiles in four-wave workgroups, two per CU; bf16, stride 1
+    if constexpr (Elem<T>::kIsBf16 && MT <= 5) {
+        if (bn64 == 3 && stride == 1) return launch_conv3s<T, MT, 1, 4, 1, 4>(p, coutp, stream);
+    }
+    if (bn64 > 1) return COBEVT_ERR_UNSUPPORTED;
     if (stride == 2) return bn64 ? launch_conv3s<T, MT, 2, 4, 2>(p, coutp, stream) : launch_conv3s<T, MT, 4, 2, 2>(p, coutp, stream);
     return bn64 ? launch_conv3s<T, MT, 2, 4, 1>(p, coutp, stream) : launch_conv3s<T, MT, 4, 2, 1>(p, coutp, stream);
 }
@@ -777,10 +794,11 @@ static int launch_conv3s_bn(const Conv3Params& p, int coutp, int bn64, int strid
 template <typename T>
 static int dispatch_conv3f(const Conv3Params& p, int kg, int coutp, int variant, int stride, hipStream_t stream) {
     if (kg != 4) return COBEVT_ERR_UNSUPPORTED;
-    // variant = 100 + 10*MT + (1 if 64-cout tiles else 0); 0 = a safe default
+    // variant = 100 + 10*MT + code; code 0 = 128-cout tiles, 1 = 64-cout tiles (8 waves), 3 = 32-cout tiles in four-wave workgroups
+    // (bf16, stride 1, MT <= 5); 0 = a safe default
     if (variant == 0) variant = p.Cout <= 64 ? 151 : 150;
     const int mt = (variant - 100) / 10, bn64 = (variant - 100) % 10;
-    if (variant < 100 || bn64 > 1) return COBEVT_ERR_ARG;
+    if (variant < 100 || bn64 > 3) return COBEVT_ERR_ARG;
     switch (mt) {
         case 3: return launch_conv3s_bn<T, 3>(p, coutp, bn64, stride, stream);
         case 4: return launch_conv3s_bn<T, 4>(p, coutp, bn64, stride, stream);

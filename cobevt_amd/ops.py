@@ -301,13 +301,24 @@ def ln_fusable(plan):
     return USE_GEMM_ROWS and plan.wgt_rows is not None and plan.K <= (128 if plan.code == BF16 else 64)
 
 
-def conv3_tiling(n, ho, wo, cin, cout, cc, cus=256, stride=1):
+def conv3_tiling(n, ho, wo, cin, cout, cc, cus=256, stride=1, bf16=True):
     """Pick the 3x3 kernel / tile shape for one launch: 0 = the LDS-staged kernel (cobevt_conv3x3_nhwc), else the
     `variant` of cobevt_conv3x3_wfrag_nhwc (100 + 10*MT + bn64: MT strips of 2x16 pixels x 128|64 couts per workgroup).
     The LDS-staged kernel runs two workgroups per CU and wins once its grid is >= 2 per CU; below that the kernel time
     is whole workgroup lifetimes, so the strip count MT is chosen to make the grid a whole number of waves of `cus`
     workgroups (cycle model: 12k fixed + 40 cycles per MFMA-tile-step, both from the s_memtime traces)."""
     if stride == 1:
+        if cout <= 32 and bf16 and cc == 64:
+            # 32-cout tiles in four-wave workgroups, two per CU (a 64-cout tile would waste half its MFMAs): one round of
+            # 2 * cus workgroups if the strips allow it, else the fewest strips per workgroup (tools/conv_graph_probe.py)
+            nstrips = n * (-(-ho // 2)) * (-(-wo // 16))
+            best = None
+            for mt in (3, 4, 5):
+                blocks = -(-nstrips // mt) * -(-cout // 32)
+                cost = -(-blocks // (2 * cus)) * (6000 + 9 * (cin // cc) * mt * 80)
+                if best is None or cost < best[0]:
+                    best = (cost, 100 + 10 * mt + 3)
+            return best[1]
         if cout < 64:
             return 0
         th, bn = (16, 64) if cout <= 64 else (8, 128)
@@ -411,7 +422,7 @@ def conv2d(x, plan, residual=None, out=None):
     variant = 0
     if plan.wfrag is not None and (out_h, out_w) == (ho, wo) and USE_CONV3X3 and USE_CONV3_WFRAG \
             and (plan.stride == 1 or USE_CONV3_S2):
-        variant = CONV3_VARIANT or conv3_tiling(n, ho, wo, cin, plan.cout, plan.cc3, stride=plan.stride)
+        variant = CONV3_VARIANT or conv3_tiling(n, ho, wo, cin, plan.cout, plan.cc3, stride=plan.stride, bf16=plan.code == BF16)
         if variant == 0 and plan.stride == 2:
             variant = 151 if plan.cout <= 64 else 150
     if variant > 0:

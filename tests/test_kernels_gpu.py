@@ -248,6 +248,30 @@ def test_conv3x3_wfrag_tile_variants(cuda, dtype, variant):
         ops.CONV3_VARIANT = 0
 
 
+@pytest.mark.parametrize("variant", [133, 143, 153])
+def test_conv3x3_wfrag_four_wave_32_cout_tiles(cuda, variant):
+    """the four-wave / 32-cout-tile form (bf16, stride 1; what layers with <= 32 output channels are routed to): ragged strips, a
+    cout tail over several tiles, 1-3 channel chunks (single-buffered patch refill), residual / up-sampled / PixelUnshuffle epilogues"""
+    ops.CONV3_VARIANT = variant
+    try:
+        for i, (nch, h, w, cout, kw) in enumerate([(1, 19, 37, 32, dict(bn=True, act=1, residual=True)),
+                                                   (3, 16, 16, 24, dict(act=2)),
+                                                   (2, 9, 12, 72, dict(bias=False, upsample=True, act=1)),
+                                                   (2, 12, 20, 32, dict(bias=False, store_mode=1))]):
+            _conv_case(cuda, torch.bfloat16, "wf4_%d_%d" % (variant, i), 2, 64 * nch, h, w, cout, 3, 1, 1, **kw)
+    finally:
+        ops.CONV3_VARIANT = 0
+    # the automatic choice takes this form for cout <= 32 and only then
+    assert ops.conv3_tiling(5, 128, 128, 128, 32, 64) % 10 == 3 and ops.conv3_tiling(5, 64, 64, 128, 32, 64) == 133
+    assert ops.conv3_tiling(5, 128, 128, 128, 32, 32, bf16=False) == 0 and ops.conv3_tiling(5, 64, 64, 128, 64, 64) % 10 != 3
+    with pytest.raises(ops.CobevtHipError):                       # not built for fp32
+        ops.CONV3_VARIANT = 153
+        try:
+            _conv_case(cuda, torch.float32, "wf4_fp32", 1, 32, 8, 16, 32, 3, 1, 1)
+        finally:
+            ops.CONV3_VARIANT = 0
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv3x3_wfrag_matches_lds_staged(cuda, dtype):
     """the two 3x3 kernels on one plan (the LDS-staged one stays the path for 64-byte channel chunks)"""

@@ -43,8 +43,8 @@ def test_captured_runner_equals_model_call(cuda):
             for k in ref[i]:
                 assert torch.equal(out[k], ref[i][k]), "frame %d %s" % (i, k)
         # writing into the static buffers directly (what a data loader would do) is the same thing
-        for k, v in frames[1].items():
-            run.static_batch[k].copy_(v if k != "record_len" else v.to(torch.int32))
+        for k, dst in run.static_batch.items():              # (the keys CorpBEVT consumes; a batch may carry more)
+            dst.copy_(frames[1][k] if k != "record_len" else frames[1][k].to(torch.int32))
         out = run.step()
         assert torch.equal(out["dynamic_seg"], ref[1]["dynamic_seg"])
 

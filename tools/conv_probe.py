@@ -14,6 +14,8 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 SHAPES = [(20, 128, 128, 64, 64), (20, 64, 64, 128, 128), (20, 32, 32, 256, 256), (20, 16, 16, 512, 512),
           (5, 128, 128, 128, 32), (1, 32, 32, 128, 128)]
+if os.environ.get("SHAPES"):
+    SHAPES = [tuple(int(v) for v in t.split("x")) for t in os.environ["SHAPES"].split(",")]
 ITERS = 30
 
 
@@ -42,7 +44,7 @@ for (n, h, w, cin, cout) in SHAPES:
     us = bench(lambda: ops.conv2d(x, plan, residual=res))
     print("%3dx%3dx%3d %3d->%3d  lds-staged     %7.1f us %7.1f TF/s" % (n, h, w, cin, cout, us, flops / us / 1e6))
     ops.USE_CONV3_WFRAG = True
-    for variant in (130, 131, 140, 141, 150, 151, 160, 161):
+    for variant in [int(v) for v in os.environ.get('VARIANTS', '130,131,140,141,150,151,160,161').split(',')]:
         ops.CONV3_VARIANT = variant
         try:
             y = ops.conv2d(x, plan, residual=res).float()
