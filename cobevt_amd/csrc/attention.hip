@@ -23,9 +23,11 @@
 
 namespace cobevt {
 
-constexpr int kKeysPerTile = 64;
-
-template <typename T> struct AttnLds {
+// KT = keys per staged tile: 64, or 128 (bf16, key counts >= 256).  The tile loop is one global round trip per iteration (the
+// next tile is requested when the current one's MFMAs start), so on the small grids that take this kernel - the level-2 / global
+// attentions with 1024 keys, the fusion windows with 320 - the iteration count, not the arithmetic, sets the time.
+template <typename T, int KT> struct AttnLds {
+    static constexpr int kKeysPerTile = KT;
     static constexpr int kKRow = 32 * Elem<T>::kBytes + 16;              // K tile row: 32 dh + pad
     static constexpr int kVRow = kKeysPerTile * Elem<T>::kBytes + (Elem<T>::kIsBf16 ? 8 : 16);  // V^T row: 64 keys + pad
     static constexpr int kKBytes = kKeysPerTile * kKRow;
@@ -36,9 +38,11 @@ template <typename T> struct AttnLds {
 };
 
 // BIAS / MASK are compile-time so the plain cross-attention path carries no per-element metadata work.
-template <typename T, bool BIAS, bool MASK>
+template <typename T, bool BIAS, bool MASK, int KT>
 __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
-    using L = AttnLds<T>;
+    using L = AttnLds<T, KT>;
+    constexpr int kKeysPerTile = KT;
+    constexpr int NS = KT / 32;                    // 32-key sub-tiles per tile
     constexpr int CH = Elem<T>::kChunk;
     constexpr int NG = 32 * Elem<T>::kBytes / 32;  // 32-byte k-groups along dh (2 bf16, 4 fp32)
     constexpr int CPR = 32 / CH;                   // 16-byte chunks per K token row (head slice)
@@ -252,9 +256,9 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
         const int* kinfo = (const int*)(Vts + L::kVBytes);
 
         // ---- S^T = K . Q^T for the two 32-key sub-tiles
-        f32x16 st[2];
+        f32x16 st[NS];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NS; ++s) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[s][r] = 0.f;
 #pragma unroll
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
         const int nvalid = tile_valid(kt);               // >= 64 except in the last tile (of a camera, in pair mode)
         if (INFO) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < NS; ++s) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int info = kinfo[s * 32 + acc_row(r, lane)];
@@ -287,13 +291,13 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
         } else {
             if (nvalid < kKeysPerTile) {                 // ragged last tile (wave-uniform branch)
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
+                for (int s = 0; s < NS; ++s)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         if (s * 32 + acc_row(r, lane) >= nvalid) st[s][r] = -INFINITY;
             }
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < NS; ++s)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[s][r]);
             mloc *= sl2;                                 // scale > 0: max commutes with the scaling
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float e = INFO ? __builtin_amdgcn_exp2f(st[s][r] - m_safe)
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
 
         // ---- O^T += V^T . P^T
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NS; ++s) {
             if constexpr (Elem<T>::kIsBf16) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -447,7 +451,7 @@ static int window_attention_impl(const void* q, const void* k, const void* v, vo
     // keys of a single window that covers the whole map are rows b * Nk + tk: no table (CVT attends to 4 x 64 x 64 keys)
     p.klinear = (p.kmap.mode != 2 && p.kmap.X == 1 && p.kmap.Y == 1 && !p.bias_mode && !mask) ? 1 : 0;
     if (lse && p.mean_q) return COBEVT_ERR_UNSUPPORTED;     // (the training path averages cameras outside the kernel)
-    if (dtype == 0 && variant != 1 && p.mean_q != 2 && !lse) {
+    if (dtype == 0 && variant == 0 && p.mean_q != 2 && !lse) {
         const int rc = launch_attn_resident(p, qsplit_hint, stream);
         if (rc >= 0) return rc;
     }
@@ -456,7 +460,9 @@ static int window_attention_impl(const void* q, const void* k, const void* v, vo
     if (p.mean_q == 1) { block = dim3(64 * (p.qmap.ncam < 4 ? 4 : p.qmap.ncam)); grid = dim3(p.L * p.heads, (P + 31) / 32, p.B); }
     else { block = dim3(256); grid = dim3(p.L * p.heads, ((p.mean_q == 2 ? P : p.Nq) + 127) / 128, p.B); }
     if (grid.y > 65535 || grid.z > 65535) return COBEVT_ERR_SHAPE;
-    size_t lds = dtype == 0 ? AttnLds<bf16_t>::kFixed : AttnLds<float>::kFixed;
+    // 128-key tiles: bf16, enough keys, not the camera-paired mode (its tiles never mix cameras)
+    const bool wide = dtype == 0 && p.mean_q != 2 && p.Nk >= 256 && variant != 2;     // variant 2: streaming kernel, 64-key tiles (A/B)
+    size_t lds = dtype == 0 ? (wide ? AttnLds<bf16_t, 128>::kFixed : AttnLds<bf16_t, 64>::kFixed) : AttnLds<float, 64>::kFixed;
     if (p.bias_mode) lds += ((size_t)p.bias_rows * 4 + 15) & ~(size_t)15;
     if (!p.klinear) lds += (size_t)p.Nk * 8;        // per-key row / coordinate table
     if ((long)p.B * p.kmap.ncam * (p.kmap.mode == 2 ? (long)p.L * p.kmap.w1 * p.kmap.w2 : (long)p.kmap.HH * p.kmap.WW) >= 0x7fffffffL)
@@ -464,15 +470,16 @@ static int window_attention_impl(const void* q, const void* k, const void* v, vo
     if (p.mean_q == 1) { const size_t need = (size_t)p.qmap.ncam * 16 * 64 * 4; if (need > lds) lds = need; }
     if (lds > 64 * 1024) return COBEVT_ERR_UNSUPPORTED;
     const bool hb = p.bias_mode != 0, hm = p.mask != nullptr;
-#define COBEVT_ATTN_LAUNCH(TT)                                                                                   \
-    do {                                                                                                          \
-        if (hb && hm) hipLaunchKernelGGL((attn_gather_kernel<TT, true, true>), grid, block, lds, stream, p);      \
-        else if (hb) hipLaunchKernelGGL((attn_gather_kernel<TT, true, false>), grid, block, lds, stream, p);      \
-        else if (hm) hipLaunchKernelGGL((attn_gather_kernel<TT, false, true>), grid, block, lds, stream, p);      \
-        else hipLaunchKernelGGL((attn_gather_kernel<TT, false, false>), grid, block, lds, stream, p);             \
+#define COBEVT_ATTN_LAUNCH(TT, KT_)                                                                                  \
+    do {                                                                                                              \
+        if (hb && hm) hipLaunchKernelGGL((attn_gather_kernel<TT, true, true, KT_>), grid, block, lds, stream, p);     \
+        else if (hb) hipLaunchKernelGGL((attn_gather_kernel<TT, true, false, KT_>), grid, block, lds, stream, p);     \
+        else if (hm) hipLaunchKernelGGL((attn_gather_kernel<TT, false, true, KT_>), grid, block, lds, stream, p);     \
+        else hipLaunchKernelGGL((attn_gather_kernel<TT, false, false, KT_>), grid, block, lds, stream, p);            \
     } while (0)
-    if (dtype == 0) COBEVT_ATTN_LAUNCH(bf16_t);
-    else COBEVT_ATTN_LAUNCH(float);
+    if (dtype == 0 && wide) COBEVT_ATTN_LAUNCH(bf16_t, 128);
+    else if (dtype == 0) COBEVT_ATTN_LAUNCH(bf16_t, 64);
+    else COBEVT_ATTN_LAUNCH(float, 64);
 #undef COBEVT_ATTN_LAUNCH
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

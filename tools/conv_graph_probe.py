@@ -41,6 +41,8 @@ def graph_time(fn):
     return t0.elapsed_time(t1) / (10 * REP) * 1e3
 
 
+if __name__ != "__main__":
+    SHAPES = []
 for (n, h, w, cin, cout) in SHAPES:
     wt = torch.randn(cout, cin, 3, 3) / (3.0 * cin ** 0.5)
     plan = ops.ConvPlan(wt, torch.randn(cout) * 0.1, stride=1, pad=1, act=1, dtype=dtype, device=dev)
