@@ -19,7 +19,9 @@ if __name__ == "__main__":
             ("global + 2-D bias B5 L1 Nq1024 Nk1024", 0, 1, 32, 32, 32, 32, 4, 5, True, False),
             ("fusion window     B1 L16 Nq320 Nk320", 0, 5, 32, 32, 8, 8, 4, 1, True, True),
             ("fusion grid       B1 L16 Nq320 Nk320", 1, 5, 32, 32, 8, 8, 4, 1, True, True),
-            ("level-1 #2        B5 L16 Nq256 Nk256", 0, 1, 64, 64, 16, 16, 4, 5, False, False)]:
+            ("level-1 #2        B5 L16 Nq256 Nk256", 0, 1, 64, 64, 16, 16, 4, 5, False, False),
+            ("LiDAR window      B1 L1024 Nq512 Nk512", 0, 8, 256, 256, 8, 8, 2, 1, True, True),
+            ("LiDAR grid        B1 L1024 Nq512 Nk512", 1, 8, 256, 256, 8, 8, 2, 1, True, True)]:
         d = heads * 32
         tm = ops.tokmap(mode, ncam, H, W, w1, w2)
         rows = B * ncam * H * W
