@@ -22,6 +22,8 @@ if __name__ == "__main__":
             ("level-1 #2        B5 L16 Nq256 Nk256", 0, 1, 64, 64, 16, 16, 4, 5, False, False),
             ("LiDAR window      B1 L1024 Nq512 Nk512", 0, 8, 256, 256, 8, 8, 2, 1, True, True),
             ("LiDAR grid        B1 L1024 Nq512 Nk512", 1, 8, 256, 256, 8, 8, 2, 1, True, True)]:
+        if os.environ.get("ONLY") and os.environ["ONLY"] not in name:
+            continue
         d = heads * 32
         tm = ops.tokmap(mode, ncam, H, W, w1, w2)
         rows = B * ncam * H * W
@@ -31,7 +33,7 @@ if __name__ == "__main__":
         mk = torch.ones(B, H, W, ncam, device=dev) if mask else None
         line = name + " |"
         ref = None
-        for variant in (0, 1, 2):
+        for variant in [int(v) for v in os.environ.get('ATTN_VARIANTS', '0,1,2').split(',')]:
             fn = lambda: ops.window_attention(qkv, qkv, qkv, out, tm, tm, tm, B, heads, 0.17, 3 * d, 3 * d, 3 * d, d, koff=d, voff=2 * d,
                                               bias_table=table, bias_L=ncam, mask=mk, variant=variant)
             us = graph_time(fn)
