@@ -161,3 +161,20 @@ def test_bottleneck_fragment_tables():
             contrib = torch.einsum("lj,plj->lp", f2[tap, u], win[:, ch])
             acc.reshape(32, -1).index_add_(0, row, contrib)
     assert torch.allclose(acc, ref2, atol=1e-4)
+
+
+def test_flipped_domain_taps_identity():
+    """host/v2v_fuse.py runs the 3x3 convolutions that the reference applies to the TRANSPOSED + FLIPPED maps
+    (v2v_fuse.py:89-93, 'b c h w -> b c w h' + flip) on the original orientation with re-indexed taps: the identity
+    conv(flipT(x), W) == flipT(conv(x, W~)), W~[u][v] = W[v][2 - u], checked with torch on the CPU."""
+    import torch.nn.functional as F
+    from cobevt_amd.host.v2v_fuse import _flipped_domain_taps
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 5, 7, 7, generator=g)
+    w = torch.randn(4, 5, 3, 3, generator=g)
+    flip_t = lambda t: t.permute(0, 1, 3, 2).flip(3)
+    ref = F.conv2d(flip_t(x), w, padding=1)
+    got = flip_t(F.conv2d(x, _flipped_domain_taps(w), padding=1))
+    assert torch.allclose(got, ref, atol=1e-5)
+    # and back: un-flipping the reference's result gives the plain-orientation convolution
+    assert torch.allclose(ref.flip(3).permute(0, 1, 3, 2), F.conv2d(x, _flipped_domain_taps(w), padding=1), atol=1e-5)
