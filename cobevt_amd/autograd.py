@@ -43,11 +43,12 @@ def _rows_view(t, what):
 class WindowAttentionFn(torch.autograd.Function):
     """out = softmax(scale q k^T + bias[rel(q, k)] + mask) v over the gathered windows (cobevt_window_attention_lse /
     cobevt_window_attention_bwd).  q (Rq, d), k, v (Rk, d) token matrices (views with a row stride are accepted), bias_table
-    (rows, heads) | None, mask fp32 | None (no gradient).  cfg = (qmap, kmap, omap, batch, heads, scale, bias_L, out_rows)."""
+    (rows, heads) | None, mask fp32 | None (no gradient).  cfg = (qmap, kmap, omap, batch, heads, scale, bias_L, out_rows,
+    drop_p, drop_seed): drop_p > 0 = dropout on the probabilities with the keep mask hashed from drop_seed."""
 
     @staticmethod
     def forward(ctx, q, k, v, bias_table, mask, cfg):
-        qmap, kmap, omap, batch, heads, scale, bias_L, out_rows = cfg
+        qmap, kmap, omap, batch, heads, scale, bias_L, out_rows, drop_p, drop_seed = cfg
         _need_cuda(q, k, v, bias_table, mask)
         ldq, ldk, ldv = _rows_view(q, "q"), _rows_view(k, "k"), _rows_view(v, "v")
         d = heads * 32
@@ -61,7 +62,7 @@ class WindowAttentionFn(torch.autograd.Function):
         lse = torch.empty((batch, L, heads, nq), device=q.device, dtype=torch.float32)
         dims = _attn_dims(batch, heads, ldq, ldk, ldv, d, table, bias_L, qmap, kmap, omap)
         rc = _L.load().cobevt_window_attention_lse(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(table), _p(mk), dims,
-                                                   ctypes.c_float(scale), _stream())
+                                                   ctypes.c_float(scale), ctypes.c_float(drop_p), ctypes.c_uint(drop_seed), _stream())
         _L.check(rc, "cobevt_window_attention_lse")
         ctx.save_for_backward(q, k, v, out, lse, table, mk)
         ctx.cfg = cfg
@@ -70,7 +71,7 @@ class WindowAttentionFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         q, k, v, out, lse, table, mk = ctx.saved_tensors
-        qmap, kmap, omap, batch, heads, scale, bias_L, _ = ctx.cfg
+        qmap, kmap, omap, batch, heads, scale, bias_L, _, drop_p, drop_seed = ctx.cfg
         d = heads * 32
         dout = _f32c(dout, "dout")
         # dq is accumulated with atomics by the key tiles of a window; dk / dv rows are written once each
@@ -85,14 +86,31 @@ class WindowAttentionFn(torch.autograd.Function):
             q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
             dims = _attn_dims(batch, heads, d, d, d, d, table, bias_L, qmap, kmap, omap)
         rc = _L.load().cobevt_window_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), _p(dq), _p(dk), _p(dv),
-                                                   _p(dbias), _p(table), _p(mk), dims, ctypes.c_float(scale), _stream())
+                                                   _p(dbias), _p(table), _p(mk), dims, ctypes.c_float(scale), ctypes.c_float(drop_p),
+                                                   ctypes.c_uint(drop_seed), _stream())
         _L.check(rc, "cobevt_window_attention_bwd")
         return dq, dk, dv, dbias, None, None
 
 
-def window_attention(q, k, v, qmap, kmap, omap, batch, heads, scale, out_rows, bias_table=None, bias_L=1, mask=None):
-    cfg = (tuple(qmap), tuple(kmap), tuple(omap), int(batch), int(heads), float(scale), int(bias_L), int(out_rows))
+def window_attention(q, k, v, qmap, kmap, omap, batch, heads, scale, out_rows, bias_table=None, bias_L=1, mask=None, drop_p=0.0,
+                     drop_seed=None):
+    """drop_p > 0: dropout on the attention probabilities; drop_seed None draws one from torch's CPU generator (so
+    torch.manual_seed makes a run repeatable, and no device round trip is needed)"""
+    if drop_p > 0 and drop_seed is None:
+        drop_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    cfg = (tuple(qmap), tuple(kmap), tuple(omap), int(batch), int(heads), float(scale), int(bias_L), int(out_rows),
+           float(drop_p), int(drop_seed or 0))
     return WindowAttentionFn.apply(q, k, v, bias_table, mask, cfg)
+
+
+def attention_dropout_mask(batch, windows, heads, nq, nk, drop_p, drop_seed, device):
+    """bool (batch, windows, heads, nq, nk): the keep mask the training kernels use for (drop_p, drop_seed) (test hook)"""
+    keep = torch.empty((batch, windows, heads, nq, nk), device=device, dtype=torch.uint8)
+    _need_cuda(keep)
+    rc = _L.load().cobevt_attention_dropout_mask(batch, windows, heads, nq, nk, ctypes.c_float(drop_p), ctypes.c_uint(drop_seed),
+                                                 _p(keep), _stream())
+    _L.check(rc, "cobevt_attention_dropout_mask")
+    return keep.bool()
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -163,3 +181,136 @@ def linear(x, lin):
 def dropout(x, p):
     """nn.Dropout in train mode (elementwise mask; torch's generator so seeds behave like the reference's)."""
     return torch.nn.functional.dropout(x, p, True) if p > 0 else x
+
+
+# ----------------------------------------------------------------------------------------------
+# convolutions (the convolutional half of the training path)
+# ----------------------------------------------------------------------------------------------
+_KLUT = {}
+
+
+def _weight_rows(weight):
+    """(Cout, Cin, kh, kw) -> ([Cout][Kpad] fp32 rows with k = (kh * Kw + kw) * Cin + c, K, Kpad): the implicit-GEMM kernel's weight
+    layout, produced ON THE DEVICE (a permute + pad) so that it follows the parameter through optimizer steps."""
+    cout, cin, kh, kw = weight.shape
+    K = kh * kw * cin
+    kpad = (K + 15) // 16 * 16
+    w2 = weight.permute(0, 2, 3, 1).reshape(cout, K)
+    if kpad != K:
+        w2 = torch.nn.functional.pad(w2, (0, kpad - K))
+    return w2.contiguous(), K, kpad
+
+
+def _klut(kh, kw, cin, kpad, device):
+    key = (kh, kw, cin, kpad, device)
+    if key not in _KLUT:
+        k = torch.arange(kpad)
+        tap, c = k // cin, k % cin
+        code = ((tap // kw) << 20) | ((tap % kw) << 10) | c
+        code[k >= kh * kw * cin] = -1
+        _KLUT[key] = code.to(torch.int32).to(device).contiguous()
+    return _KLUT[key]
+
+
+def _igemm_conv(x, weight, bias, stride, pad, ho, wo):
+    """x (N, H, W, Cin) fp32 channels-last, weight (Cout, Cin, kh, kw) -> (N, ho, wo, Cout): cobevt_conv2d_nhwc (csrc/igemm.hip),
+    top / left padding `pad`; taps past the bottom / right edge read zeros (the kernel bounds-checks every tap)."""
+    n, h, w, cin = x.shape
+    cout, _, kh, kw = weight.shape
+    w2, K, kpad = _weight_rows(weight)
+    smallc = int(cin % 4 != 0)
+    klut = _klut(kh, kw, cin, kpad, x.device) if smallc else None
+    out = torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.float32)
+    dims = _ints([ops.FP32, n, h, w, cin, ho, wo, cout, kh, kw, stride, pad, K, kpad, 0, 0, 0, 0, ho, wo, smallc])
+    b = None if bias is None else _f32c(bias, "bias")
+    rc = _L.load().cobevt_conv2d_nhwc(_p(x), _p(w2), _p(b), None, None, None, _p(klut), _p(out), dims, _stream())
+    _L.check(rc, "cobevt_conv2d_nhwc")
+    return out
+
+
+class Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d (square kernel, symmetric padding, groups 1) on (N, C, H, W)-shaped tensors (channels-last memory is used as it
+    is).  Forward and the input gradient run on the fp32 implicit-GEMM kernel (the input gradient is the same convolution with
+    the taps flipped and the channel roles swapped, on the zero-stuffed output gradient when stride > 1); the weight gradient is
+    kh * kw plain GEMMs dY^T . X_tap, i.e. library calls."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad):
+        _need_cuda(x, weight, bias)
+        if x.dtype != torch.float32 or weight.dtype != torch.float32:
+            raise CobevtHipError("the training slice is fp32")
+        xl = x.permute(0, 2, 3, 1).contiguous()
+        n, h, w, _ = xl.shape
+        kh, kw = weight.shape[2:]
+        ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+        out = _igemm_conv(xl, weight, bias, stride, pad, ho, wo)
+        ctx.save_for_backward(xl, weight)
+        ctx.cfg = (stride, pad, bias is not None)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xl, weight = ctx.saved_tensors
+        stride, pad, has_bias = ctx.cfg
+        cout, cin, kh, kw = weight.shape
+        n, h, w, _ = xl.shape
+        dyl = dy.permute(0, 2, 3, 1).contiguous()
+        ho, wo = dyl.shape[1:3]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            g = dyl
+            if stride > 1:                       # zero-stuffed gradient map: dgrad of a strided conv = stride-1 conv on it
+                g = torch.zeros((n, (ho - 1) * stride + 1, (wo - 1) * stride + 1, cout), device=dyl.device, dtype=torch.float32)
+                g[:, ::stride, ::stride] = dyl
+            wt = weight.flip(2, 3).transpose(0, 1)                 # (Cin, Cout, kh, kw)
+            dx = _igemm_conv(g, wt, None, 1, kh - 1 - pad, h, w).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            F = torch.nn.functional
+            # rows / columns the strided windows can reach past the padded map are zeros too
+            need_h, need_w = (ho - 1) * stride + kh, (wo - 1) * stride + kw
+            xp = F.pad(xl, (0, 0, pad, max(need_w - w - pad, 0), pad, max(need_h - h - pad, 0)))
+            dy2 = dyl.reshape(-1, cout).t()
+            taps = []
+            for a in range(kh):
+                for b in range(kw):
+                    xt = xp[:, a:a + stride * (ho - 1) + 1:stride, b:b + stride * (wo - 1) + 1:stride, :].reshape(-1, cin)
+                    taps.append(dy2 @ xt)                          # (Cout, Cin)
+            dw = torch.stack(taps, dim=2).reshape(cout, cin, kh, kw)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dyl.sum(dim=(0, 1, 2))
+        return dx, dw, db, None, None
+
+
+def conv2d(x, conv):
+    """x through the nn.Conv2d container `conv` (square kernel / stride / padding, groups 1, dilation 1)"""
+    if conv.groups != 1 or conv.dilation != (1, 1) or conv.kernel_size[0] != conv.kernel_size[1] or conv.stride[0] != conv.stride[1] \
+            or conv.padding[0] != conv.padding[1]:
+        raise CobevtHipError("training conv2d: square kernel / stride / padding, groups 1, dilation 1 only")
+    return Conv2dFn.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
+
+
+class WeightedCrossEntropyFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss(weight=w)(logits (N, C, H, W) fp32, target (N, H, W)) with the HIP forward (cobevt_weighted_cross_entropy)
+    and backward (cobevt_weighted_cross_entropy_bwd): vanilla_seg_loss.py:18-23,58-70 under train_camera.py:166-173."""
+
+    @staticmethod
+    def forward(ctx, logits, target, weight):
+        if logits.dtype != torch.float32:
+            raise CobevtHipError("the training slice is fp32")
+        loss, stats, x, y, wt = ops.weighted_cross_entropy(logits, target, weight, want_stats=True)
+        ctx.save_for_backward(x, y, wt, stats)
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        x, y, wt, stats = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dx = torch.empty_like(x)
+        up = dloss.reshape(1).to(torch.float32).contiguous()
+        rc = _L.load().cobevt_weighted_cross_entropy_bwd(_p(x), _p(y), _p(wt), _p(stats), _p(up), _p(dx), n, c, h * w, _stream())
+        _L.check(rc, "cobevt_weighted_cross_entropy_bwd")
+        return dx, None, None
+
+
+def weighted_cross_entropy(logits, target, weight):
+    return WeightedCrossEntropyFn.apply(logits, target, weight)

@@ -38,7 +38,9 @@ template <typename T, int KT> struct AttnLds {
 };
 
 // BIAS / MASK are compile-time so the plain cross-attention path carries no per-element metadata work.
-template <typename T, bool BIAS, bool MASK, int KT>
+// DROP (fp32 training forward only): dropout on the probabilities - the softmax denominator sums every exponential, the PV
+// product takes the kept ones scaled by 1 / (1 - p).
+template <typename T, bool BIAS, bool MASK, int KT, bool DROP = false>
 __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
     using L = AttnLds<T, KT>;
     constexpr int kKeysPerTile = KT;
@@ -314,8 +316,13 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
             for (int r = 0; r < 16; ++r) {
                 const float e = INFO ? __builtin_amdgcn_exp2f(st[s][r] - m_safe)
                                      : __builtin_amdgcn_exp2f(fmaf(st[s][r], sl2, -m_safe));
-                st[s][r] = e;
                 psum += e;
+                if (DROP) {
+                    const int tk = tile_base(kt) + s * 32 + acc_row(r, lane);
+                    st[s][r] = attn_keep(p, b, l, head, tq, tk) ? e * (1.f / (1.f - p.drop_p)) : 0.f;
+                } else {
+                    st[s][r] = e;
+                }
             }
         l_run = l_run * alpha + psum;
 #pragma unroll
@@ -418,7 +425,7 @@ using namespace cobevt;
 // C-ABI entry point, see include/cobevt_hip.h
 static int window_attention_impl(const void* q, const void* k, const void* v, void* out, float* lse,
                                  const float* bias_table, const float* mask, const int* dims, float scale,
-                                 hipStream_t stream) {
+                                 float drop_p, unsigned drop_seed, hipStream_t stream) {
     // dims: [dtype, B, L, heads, ldq, ldk, ldv, ldo, qoff, koff, voff, ooff, bias_mode, bias_rows, bias_L,
     //        mean_q, qmap[8], kmap[8], omap[8]]
     if (!q || !k || !v || !out || !dims) return COBEVT_ERR_ARG;
@@ -434,6 +441,8 @@ static int window_attention_impl(const void* q, const void* k, const void* v, vo
     p.mean_q = dims[15];
     p.qmap = read_map(dims + 16); p.kmap = read_map(dims + 24); p.omap = read_map(dims + 32);
     p.bias_table = bias_table; p.mask = mask; p.scale = scale; p.lse = lse;
+    p.drop_p = drop_p; p.drop_seed = drop_seed;
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (!lse || dtype != 1))) return COBEVT_ERR_ARG;   // dropout: training forward only
     if (dtype != 0 && dtype != 1) return COBEVT_ERR_ARG;
     if (!map_ok(p.qmap) || !map_ok(p.kmap) || !map_ok(p.omap)) return COBEVT_ERR_SHAPE;
     if (p.B < 1 || p.heads < 1 || p.L != p.qmap.X * p.qmap.Y || p.L != p.kmap.X * p.kmap.Y) return COBEVT_ERR_SHAPE;
@@ -480,7 +489,12 @@ static int window_attention_impl(const void* q, const void* k, const void* v, vo
         else if (hm) hipLaunchKernelGGL((attn_gather_kernel<TT, false, true, KT_>), grid, block, lds, stream, p);     \
         else hipLaunchKernelGGL((attn_gather_kernel<TT, false, false, KT_>), grid, block, lds, stream, p);            \
     } while (0)
-    if (dtype == 0 && wide) COBEVT_ATTN_LAUNCH(bf16_t, 128);
+    if (p.drop_p > 0.f) {                          // training forward (fp32, lse): checked by the caller
+        if (hb && hm) hipLaunchKernelGGL((attn_gather_kernel<float, true, true, 64, true>), grid, block, lds, stream, p);
+        else if (hb) hipLaunchKernelGGL((attn_gather_kernel<float, true, false, 64, true>), grid, block, lds, stream, p);
+        else if (hm) hipLaunchKernelGGL((attn_gather_kernel<float, false, true, 64, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((attn_gather_kernel<float, false, false, 64, true>), grid, block, lds, stream, p);
+    } else if (dtype == 0 && wide) COBEVT_ATTN_LAUNCH(bf16_t, 128);
     else if (dtype == 0) COBEVT_ATTN_LAUNCH(bf16_t, 64);
     else COBEVT_ATTN_LAUNCH(float, 64);
 #undef COBEVT_ATTN_LAUNCH
@@ -491,14 +505,36 @@ static int window_attention_impl(const void* q, const void* k, const void* v, vo
 extern "C" int cobevt_window_attention(const void* q, const void* k, const void* v, void* out,
                                        const float* bias_table, const float* mask, const int* dims, float scale,
                                        hipStream_t stream) {
-    return window_attention_impl(q, k, v, out, nullptr, bias_table, mask, dims, scale, stream);
+    return window_attention_impl(q, k, v, out, nullptr, bias_table, mask, dims, scale, 0.f, 0u, stream);
 }
 
 extern "C" int cobevt_window_attention_lse(const void* q, const void* k, const void* v, void* out, float* lse,
                                            const float* bias_table, const float* mask, const int* dims, float scale,
-                                           hipStream_t stream) {
+                                           float drop_p, unsigned drop_seed, hipStream_t stream) {
     if (!lse) return COBEVT_ERR_ARG;
-    return window_attention_impl(q, k, v, out, lse, bias_table, mask, dims, scale, stream);
+    return window_attention_impl(q, k, v, out, lse, bias_table, mask, dims, scale, drop_p, drop_seed, stream);
+}
+
+// Test hook: the keep mask of the probability dropout exactly as the training kernels regenerate it
+__global__ void attn_dropout_mask_kernel(AttnParams p, unsigned char* keep) {
+    const long total = (long)p.B * p.L * p.heads * p.Nq * p.Nk;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int tk = (int)(i % p.Nk);
+        long r = i / p.Nk;
+        const int tq = (int)(r % p.Nq); r /= p.Nq;
+        const int head = (int)(r % p.heads); r /= p.heads;
+        const int l = (int)(r % p.L), b = (int)(r / p.L);
+        keep[i] = cobevt::attn_keep(p, b, l, head, tq, tk) ? 1 : 0;
+    }
+}
+
+extern "C" int cobevt_attention_dropout_mask(int B, int L, int heads, int Nq, int Nk, float drop_p, unsigned drop_seed,
+                                             unsigned char* keep, hipStream_t stream) {
+    if (!keep || B < 1 || L < 1 || heads < 1 || Nq < 1 || Nk < 1) return COBEVT_ERR_ARG;
+    AttnParams p = {};
+    p.B = B; p.L = L; p.heads = heads; p.Nq = Nq; p.Nk = Nk; p.drop_p = drop_p; p.drop_seed = drop_seed;
+    hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3(2048), dim3(256), 0, stream, p, keep);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
 // Test hooks (tests/test_kernels_gpu.py: bit-exact against tests/golden/gv1_index_maps.npz), see include/cobevt_hip.h

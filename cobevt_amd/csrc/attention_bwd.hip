@@ -155,8 +155,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnBwdParams bp) {
                 int bidx = 0;
                 if (BIAS) { bidx = qb_s[row] - kterm; z += bias_col[k_ok ? bidx : 0]; }
                 const float pr = k_ok ? __builtin_amdgcn_exp2f(z - lse_s[row]) : 0.f;
-                P[r] = pr;
-                dZ[r] = pr * (dP[r] - D_s[row]);
+                // dropout on the probabilities: O = (P o M') V, M' = keep / (1 - p)  ->  dV takes P o M', dZ = P o (M' o dP - D)
+                float keep = 1.f;
+                if (p.drop_p > 0.f) keep = attn_keep(p, b, l, head, (it * 4 + wave) * 32 + row, tk) ? 1.f / (1.f - p.drop_p) : 0.f;
+                P[r] = pr * keep;
+                dZ[r] = pr * (keep * dP[r] - D_s[row]);
                 if (BIAS && k_ok && dZ[r] != 0.f) atomicAdd(&dtab[bidx], dZ[r]);
             }
             // ---- dV^T += dO^T P,  dK^T += Q^T dZ  (contraction over the query rows; step j pairs rows qj(0) and qj(1))
@@ -300,7 +303,9 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnBwdParams bp) {
             float z = S[r] * sl2;
             if (BIAS) z += bias_col[vis ? qterm - kinfo : 0];
             const float pr = vis ? __builtin_amdgcn_exp2f(z - lse_q) : 0.f;
-            dZ[r] = pr * (dP[r] - Dq);
+            float keep = 1.f;
+            if (p.drop_p > 0.f) keep = attn_keep(p, b, l, head, tq, kt * 32 + acc_row(r, lane)) ? 1.f / (1.f - p.drop_p) : 0.f;
+            dZ[r] = pr * (keep * dP[r] - Dq);
         }
         // ---- dQ^T += K^T dZ^T  (contraction over the keys = the register index; step j pairs key rows kj(0) and kj(1))
 #pragma unroll
@@ -340,8 +345,9 @@ using namespace cobevt;
 extern "C" int cobevt_window_attention_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
                                            const void* dout, void* dq, void* dk, void* dv, float* dbias,
                                            const float* bias_table, const float* mask, const int* dims, float scale,
-                                           hipStream_t stream) {
+                                           float drop_p, unsigned drop_seed, hipStream_t stream) {
     if (!q || !k || !v || !out || !lse || !dout || !dq || !dk || !dv || !dims) return COBEVT_ERR_ARG;
+    if (drop_p < 0.f || drop_p >= 1.f) return COBEVT_ERR_ARG;
     AttnBwdParams bp;
     AttnParams& p = bp.a;
     const int dtype = dims[0] & 0xff;
@@ -354,6 +360,7 @@ extern "C" int cobevt_window_attention_bwd(const void* q, const void* k, const v
     p.mean_q = dims[15];
     p.qmap = read_map(dims + 16); p.kmap = read_map(dims + 24); p.omap = read_map(dims + 32);
     p.bias_table = bias_table; p.mask = mask; p.scale = scale; p.lse = const_cast<float*>(lse); p.klinear = 0;
+    p.drop_p = drop_p; p.drop_seed = drop_seed;
     bp.dout = (const float*)dout; bp.dq = (float*)dq; bp.dk = (float*)dk; bp.dv = (float*)dv; bp.dbias = dbias;
     if (!map_ok(p.qmap) || !map_ok(p.kmap) || !map_ok(p.omap)) return COBEVT_ERR_SHAPE;
     if (p.B < 1 || p.heads < 1 || p.L != p.qmap.X * p.qmap.Y || p.L != p.kmap.X * p.kmap.Y) return COBEVT_ERR_SHAPE;

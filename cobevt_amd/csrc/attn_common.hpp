@@ -71,7 +71,24 @@ struct AttnParams {
                               // ONE softmax over all cameras' keys (CVT CrossAttention, cvt_modules.py:142-153)
     float* lse;               // training forward: base-2 log-sum-exp of every query's logits, [B][L][heads][Nq] (nullable)
     int klinear;              // streaming kernel: key token tk of the (single) window is row b * Nk + tk - no key table in LDS
+    // training only: nn.Dropout on the attention probabilities (FAX global attention, fax_modules.py:114,161): element (query,
+    // key) of a (batch, window, head) is kept with probability 1 - drop_p and scaled by 1 / (1 - drop_p); the keep decision is a
+    // counter-based hash of (drop_seed, element index), so the backward kernels regenerate the forward's mask
+    float drop_p;
+    unsigned drop_seed;
 };
+
+__host__ __device__ __forceinline__ unsigned attn_mix32(unsigned x) {       // murmur3 finaliser
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+    return x;
+}
+// keep decision of probability element (tq, tk) of (b, l, head): uniform 32-bit hash >= p * 2^32
+__device__ __forceinline__ bool attn_keep(const AttnParams& p, int b, int l, int head, int tq, int tk) {
+    const unsigned long long row = ((unsigned long long)((b * p.L + l) * p.heads + head)) * (unsigned)p.Nq + (unsigned)tq;
+    const unsigned hrow = attn_mix32((unsigned)row ^ attn_mix32((unsigned)(row >> 32) ^ p.drop_seed));
+    const unsigned u = attn_mix32(hrow ^ ((unsigned)tk * 0x9e3779b1u));
+    return (float)u * 2.3283064365386963e-10f >= p.drop_p;
+}
 
 static inline bool map_ok(const TokMap& m) {
     if (m.mode < 0 || m.mode > 2 || m.ncam < 1 || m.w1 < 1 || m.w2 < 1 || m.X < 1 || m.Y < 1) return false;

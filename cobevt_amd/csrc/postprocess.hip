@@ -178,6 +178,31 @@ __global__ __launch_bounds__(256) void wce_partial_kernel(const T* logits, const
     }
 }
 
+// d loss / d logits of the class-weighted mean cross entropy: w[y] (softmax_c - [c == y]) / sum w[y], times the upstream
+// gradient (a device scalar); pixels with the ignore label -100 get zeros.  stats = the forward's out[] (stats[2] = sum w[y]).
+template <int C>
+__global__ __launch_bounds__(256) void wce_backward_kernel(const float* logits, const long long* target, const float* weight,
+                                                           const float* stats, const float* upstream, float* dlogits, int hw) {
+    const int n = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= hw) return;
+    float x[C];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { x[c] = logits[((size_t)n * C + c) * hw + pix]; m = fmaxf(m, x[c]); }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { x[c] = expf(x[c] - m); s += x[c]; }
+    const long long y = target[(size_t)n * hw + pix];
+    float wy = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+        if (y == c) wy = weight[c];
+    const float g = upstream[0] * wy / stats[2] / s;
+#pragma unroll
+    for (int c = 0; c < C; ++c) dlogits[((size_t)n * C + c) * hw + pix] = g * x[c] - (y == c ? upstream[0] * wy / stats[2] : 0.f);
+}
+
 // `stride` floats per partial record: 3 = {numerator, denominator, bad-label count} (cross entropy), 2 = {numerator, denominator}
 __global__ __launch_bounds__(256) void wce_final_kernel(const float* partial, float* out, int nparts, int stride) {
     __shared__ float sn[256], sd[256], sb[256];
@@ -229,6 +254,21 @@ extern "C" int cobevt_weighted_cross_entropy(const void* logits, const long long
     else return COBEVT_ERR_ARG;
     if (rc != COBEVT_OK) return rc;
     hipLaunchKernelGGL(wce_final_kernel, dim3(1), dim3(256), 0, stream, scratch, out, nparts, 3);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// Backward of cobevt_weighted_cross_entropy (fp32 logits (N, C, hw)): see wce_backward_kernel.  stats = the forward's out[4].
+extern "C" int cobevt_weighted_cross_entropy_bwd(const float* logits, const long long* target, const float* weight, const float* stats,
+                                                 const float* upstream, float* dlogits, int N, int C, int hw, hipStream_t stream) {
+    if (!logits || !target || !weight || !stats || !upstream || !dlogits) return COBEVT_ERR_ARG;
+    if (N < 1 || N > 65535 || hw < 1 || C < 2 || C > kPostMaxClasses) return COBEVT_ERR_SHAPE;
+    const dim3 grid((hw + 255) / 256, N), block(256);
+    switch (C) {
+#define COBEVT_WCEB_CASE(c) case c: hipLaunchKernelGGL((wce_backward_kernel<c>), grid, block, 0, stream, logits, target, weight, stats, upstream, dlogits, hw); break;
+        COBEVT_WCEB_CASE(2) COBEVT_WCEB_CASE(3) COBEVT_WCEB_CASE(4) COBEVT_WCEB_CASE(5) COBEVT_WCEB_CASE(6) COBEVT_WCEB_CASE(7) COBEVT_WCEB_CASE(8)
+#undef COBEVT_WCEB_CASE
+        default: return COBEVT_ERR_SHAPE;
+    }
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 

@@ -6,6 +6,7 @@ import torch.nn as nn
 
 from .. import ops
 from . import runtime as rt
+from . import training
 from .runtime import HipModule
 
 
@@ -34,6 +35,8 @@ class BevSegHead(HipModule):
 
     def forward(self, x, b, l):
         """x: ((b l), C, H, W) -> {'static_seg', 'dynamic_seg'} each (b, l, classes, H, W) fp32"""
+        if self.training:
+            return training.bev_seg_head(self, x, b, l)
         self._require_inference(x)
         xn = rt.to_nhwc(x)
         if self.target == "dynamic":

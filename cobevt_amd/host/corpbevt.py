@@ -8,6 +8,7 @@ import torch
 from .. import ops
 from ..lib import CobevtHipError
 from . import runtime as rt
+from . import training
 from .bev_seg_head import BevSegHead
 from .fax_modules import FAXModule
 from .naive_compress import NaiveCompressor
@@ -33,6 +34,8 @@ class STTF(HipModule):
 
     def forward(self, x, spatial_correction_matrix):
         """x: (B, L, C, H, W) -> (B, L, H, W, C)"""
+        if self.training:
+            return training.sttf_warp(x, spatial_correction_matrix.to(x.device), self.discrete_ratio, self.downsample_rate)
         self._require_inference(x)
         b, l, c, h, w = x.shape
         xl = rt.to_nhwc(x.reshape(b * l, c, h, w)).reshape(b, l, h, w, c)
@@ -159,5 +162,7 @@ class CorpBEVT(HipModule):
         return self.fax_query(self.encode_trunk(batch_dict))
 
     def forward(self, batch_dict):
+        if self.training:               # the differentiable fp32 graph (host/training.py): train_camera.py:143-179
+            return training.corpbevt(self, batch_dict)
         feats = self.encode_agents(batch_dict)
         return self.fuse_and_decode(feats, batch_dict["transformation_matrix"], batch_dict["record_len"])

@@ -73,6 +73,8 @@ class Bottleneck(HipModule):
         return ops.conv2d(y, rt.conv_plan(self, "c3", self.conv3, self.bn3, act=1), residual=x)
 
     def forward(self, x):
+        if self.training:
+            return training.bottleneck(self, x)
         self._require_inference(x)
         return rt.like_input(rt.nchw_view(self.forward_nhwc(rt.to_nhwc(x))), x)
 
@@ -460,6 +462,8 @@ class FAXModule(HipModule):
         return x
 
     def forward(self, batch):
+        if self.training:
+            return training.fax_module(self, batch)
         b, l, n = batch["inputs"].shape[:3]
         intrinsic, extrinsic = batch["intrinsic"], batch["extrinsic"]
         self._require_inference(intrinsic, extrinsic, *batch["features"])

@@ -7,6 +7,7 @@ import torch.nn as nn
 
 from .. import ops
 from . import runtime as rt
+from . import training
 from .runtime import HipModule
 
 
@@ -38,6 +39,10 @@ class NaiveDecoder(HipModule):
 
     def forward(self, x):
         """(B, L, C1, H, W) -> (B, L, C2, 8H, 8W)"""
+        if self.training:
+            b, l = x.shape[:2]
+            y = training.naive_decoder(self, x.reshape(b * l, *x.shape[2:]))
+            return y.reshape(b, l, *y.shape[1:])
         self._require_inference(x)
         b, l, c, h, w = x.shape
         y = rt.nchw_view(self.forward_nhwc(rt.to_nhwc(x.reshape(b * l, c, h, w))))

@@ -11,6 +11,7 @@ import torch.nn as nn
 from .. import ops
 from ..lib import CobevtHipError
 from . import runtime as rt
+from . import training
 from .runtime import HipModule
 
 _BLOCKS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}
@@ -114,6 +115,8 @@ class ResnetEncoder(HipModule):
 
     def forward(self, input_images):
         """(B, L, M, H, W, 3) channels-last fp32 -> list of (B, L, M, C, h, w) (channels-last views)."""
+        if self.training:
+            return training.resnet_encoder(self, input_images)
         self._require_inference(input_images)
         b, l, m, h, w, c = input_images.shape
         x = input_images.reshape(b * l * m, h, w, c)

@@ -205,10 +205,185 @@ def global_attention(m, x):
     rows = b * h * w
     qkv = ag.linear(t.reshape(rows, d), m.to_qkv)
     tm = ops.tokmap(0, 1, h, w, h, w)
+    # nn.Dropout on the probabilities (attend[1], fax_modules.py:114,161) happens inside the attention kernels
     a = ag.window_attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], tm, tm, tm, b, m.heads, m.scale, rows,
-                            bias_table=m.rel_pos_bias.weight, bias_L=1)
-    # nn.Dropout on the probabilities (attend[1]) has no fused counterpart: only p = 0 is supported in train mode
-    if m.attend[1].p > 0:
-        raise CobevtHipError("FAX global attention: dropout on the attention probabilities is not built (set dropout = 0)")
+                            bias_table=m.rel_pos_bias.weight, bias_L=1, drop_p=m.attend[1].p if m.attend[1].training else 0.0)
     y = ag.dropout(ag.linear(a, m.to_out[0]), m.to_out[1].p)
     return y.reshape(b, h, w, d).permute(0, 3, 1, 2)
+
+
+# ----------------------------------------------------------------------------------------------
+# the convolutional half: encoder, Bottlenecks, down-sampling, decoder, heads, STTF - and the whole model
+# ----------------------------------------------------------------------------------------------
+# Convolutions: fp32 implicit-GEMM kernel forward and for the input gradient, library GEMMs for the weight gradient
+# (cobevt_amd.autograd.Conv2dFn).  BatchNorm follows each container's own .training flag (batch statistics and running-stat
+# updates, or the frozen statistics), max-pooling / nearest up-sampling / PixelUnshuffle / the affine warp are torch's
+# differentiable ops: plumbing between the kernels.  Tensors are (N, C, H, W)-shaped in channels-last memory.
+_F = torch.nn.functional
+
+
+def _bn(x, bn):
+    return _F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
+
+
+def _conv_bn(x, conv, bn=None, relu=False):
+    y = ag.conv2d(x, conv)
+    if bn is not None:
+        y = _bn(y, bn)
+    return _F.relu(y) if relu else y
+
+
+def basic_block(blk, x):
+    """torchvision BasicBlock.forward as reached from resnet_ms.py:67-74"""
+    identity = x if blk.downsample is None else _conv_bn(x, blk.downsample[0], blk.downsample[1])
+    y = _conv_bn(x, blk.conv1, blk.bn1, relu=True)
+    return _F.relu(_conv_bn(y, blk.conv2, blk.bn2) + identity)
+
+
+def resnet_encoder(enc, input_images):
+    """ResnetEncoder.forward (resnet_ms.py:46-89): (B, L, M, H, W, 3) -> list of (B, L, M, C, h, w)"""
+    _check(input_images)
+    b, l, m, h, w, c = input_images.shape
+    net = enc.encoder
+    x = input_images.reshape(b * l * m, h, w, c).permute(0, 3, 1, 2)          # channels-last memory, no copy
+    x = _conv_bn(x, net.conv1, net.bn1, relu=True)
+    x = _F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    results = []
+    for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
+        for blk in layer:
+            x = basic_block(blk, x)
+        results.append(x.reshape(b, l, m, *x.shape[1:]))
+    return [results[i] for i in enc.idx_pick] if isinstance(enc.idx_pick, list) else results[enc.idx_pick]
+
+
+def bottleneck(blk, x):
+    """torchvision Bottleneck(c, c // 4) (fax_modules.py:10,472)"""
+    y = _conv_bn(x, blk.conv1, blk.bn1, relu=True)
+    y = _conv_bn(y, blk.conv2, blk.bn2, relu=True)
+    return _F.relu(_conv_bn(y, blk.conv3, blk.bn3) + x)
+
+
+def downsample(ds, x):
+    """fax_modules.py:476-489: conv3x3 -> PixelUnshuffle(2) -> conv3x3 -> BN -> ReLU -> conv1x1 -> BN"""
+    y = _F.pixel_unshuffle(ag.conv2d(x, ds[0]), 2)
+    y = _conv_bn(y, ds[2], ds[3], relu=True)
+    return _conv_bn(y, ds[5], ds[6])
+
+
+def fax_module(m, batch):
+    """FAXModule.forward (fax_modules.py:497-521): batch['features'] list of (b, l, n, C, h, w) -> (b, l, d, H, W)"""
+    feats = batch["features"]
+    b, l, n = feats[0].shape[:3]
+    I_inv = torch.linalg.inv(batch["intrinsic"].reshape(b * l, n, 3, 3).to(torch.float32))
+    E_inv = m._extrinsic(batch["extrinsic"].reshape(b * l, n, 4, 4).to(torch.float32))
+    prior = m.bev_embedding.get_prior()
+    x = prior[None].expand(b * l, *prior.shape)
+    for i, (cross_view, feature, layer) in enumerate(zip(m.cross_views, feats, m.layers)):
+        feature = feature.reshape(b * l, n, *feature.shape[3:])
+        x = cross_view_swap_attention(cross_view, i, x.contiguous(), m.bev_embedding, feature.contiguous(), I_inv, E_inv)
+        for blk in layer:
+            x = bottleneck(blk, x)
+        if i < len(m.cross_views) - 1:
+            x = downsample(m.downsample_layers[i][0], x)
+    if m.self_attn is not None:
+        x = global_attention(m.self_attn, x.contiguous())
+    return x.reshape(b, l, *x.shape[1:])
+
+
+def naive_decoder(dec, x):
+    """NaiveDecoder.forward (naive_decoder.py:62-91) on (N, C, H, W)"""
+    for i in range(dec.num_layer - 1, -1, -1):
+        x = _conv_bn(x, dec.convs[("upconv", i, 0)], dec.convs[("norm", i, 0)], relu=True)
+        x = _F.interpolate(x, scale_factor=2, mode="nearest")
+        x = _conv_bn(x, dec.convs[("upconv", i, 1)], dec.convs[("norm", i, 1)], relu=True)
+    return x
+
+
+def bev_seg_head(head, x, b, l):
+    """BevSegHead.forward (bev_seg_head.py:35-61): x ((b l), C, H, W) -> both maps (b, l, classes, H, W)"""
+    def run(conv):
+        y = ag.conv2d(x, conv)
+        return y.reshape(b, l, *y.shape[1:])
+    if head.target == "dynamic":
+        dyn = run(head.dynamic_head)
+        return {"static_seg": torch.zeros_like(dyn), "dynamic_seg": dyn}
+    if head.target == "static":
+        sta = run(head.static_head)
+        return {"static_seg": sta, "dynamic_seg": torch.zeros_like(sta)}
+    return {"static_seg": run(head.static_head), "dynamic_seg": run(head.dynamic_head)}
+
+
+def _regroup(x, record_len, max_cav):
+    """fuse_utils.py:8-61: (sum(record_len), C, H, W) -> (B, max_cav, C, H, W) zero padded (record_len read on the host, as there)"""
+    lens = [int(v) for v in record_len]
+    out, off = [], 0
+    for n in lens:
+        f = x[off:off + n]
+        off += n
+        out.append(torch.cat([f, f.new_zeros((max_cav - n,) + tuple(f.shape[1:]))], 0)[None])
+    return torch.cat(out, 0)
+
+
+def _warp_affine(src, M, dsize):
+    """warp_affine (torch_transformation_utils.py:317-355) with its normalisation helpers (:160-191): bilinear, zeros,
+    align_corners=True; src (N, C, H, W), M (N, 2, 3) destination-from-source in pixels"""
+    N, C, H, W = src.shape
+
+    def norm_px(h, w):
+        t = torch.tensor([[1.0, 0.0, -1.0], [0.0, 1.0, -1.0], [0.0, 0.0, 1.0]], dtype=M.dtype, device=M.device)
+        t[0, 0] = t[0, 0] * 2.0 / (1e-14 if w == 1 else w - 1.0)
+        t[1, 1] = t[1, 1] * 2.0 / (1e-14 if h == 1 else h - 1.0)
+        return t[None]
+    M3 = _F.pad(M, [0, 0, 0, 1], "constant", value=0.0)
+    M3[..., -1, -1] += 1.0
+    theta = torch.linalg.inv(norm_px(dsize[0], dsize[1]) @ (M3 @ torch.linalg.inv(norm_px(H, W))))[:, :2, :]
+    grid = _F.affine_grid(theta, [N, C, dsize[0], dsize[1]], align_corners=True)
+    return _F.grid_sample(src, grid, align_corners=True, mode="bilinear", padding_mode="zeros")
+
+
+def sttf_warp(x, tm, discrete_ratio, downsample_rate):
+    """STTF.forward (corpbevt.py:28-64): x (B, L, C, H, W) -> (B, L, H, W, C) in the ego frame, differentiable in x"""
+    m = tm[:, :, [0, 1], :][:, :, :, [0, 1, 3]].to(torch.float32).clone()          # :108-134
+    m[..., -1] = m[..., -1] / (discrete_ratio * downsample_rate)
+    x = x.permute(0, 1, 2, 4, 3).flip(4)
+    B, L, C, H, W = x.shape
+    M = m.reshape(-1, 2, 3)
+    eye = torch.eye(3, dtype=M.dtype, device=M.device)[None].repeat(M.shape[0], 1, 1)      # :254-297
+    shift, shift_inv, rot = eye.clone(), eye.clone(), eye.clone()
+    center = torch.tensor([W / 2, H / 2], dtype=M.dtype, device=M.device)
+    shift[:, :2, 2] = center
+    shift_inv[:, :2, 2] = -center
+    rot[:, :2, :2] = M[:, :2, :2]
+    T = (shift @ rot @ shift_inv)[:, :2, :].clone()
+    T[..., 2] += M[..., 2]
+    y = _warp_affine(x.reshape(-1, C, H, W), T, (H, W)).reshape(B, L, C, H, W)
+    return y.flip(4).permute(0, 1, 4, 3, 2)
+
+
+def fuse_and_decode(model, f, transformation_matrix, record_len):
+    """the cross-agent part of CorpBEVT.forward (corpbevt.py:119-145): f (N, C, H, W) per-agent BEV features"""
+    if model.compression:
+        raise CobevtHipError("CorpBEVT train(): the NaiveCompressor branch has no training forward")
+    dev = f.device
+    tm = transformation_matrix.to(device=dev, dtype=torch.float32)
+    w = sttf_warp(_regroup(f, record_len, model.max_cav), tm, model.discrete_ratio, model.downsample_rate)   # b l h w c
+    # the ROI / agent mask carries no gradient: the inference kernel computes it
+    rl = torch.as_tensor(record_len).to(device=dev, dtype=torch.int32)
+    with torch.no_grad():
+        _, com_mask, cav_mask = ops.sttf_warp(f.detach().permute(0, 2, 3, 1).contiguous(), tm.contiguous(), None, model.discrete_ratio,
+                                              model.downsample_rate, want_mask=model.use_roi_mask, record_len=rl,
+                                              max_cav=model.max_cav)
+        if not model.use_roi_mask:
+            b, l, h, ww, _ = w.shape
+            com_mask = cav_mask[:, None, None, None, :].expand(b, h, ww, 1, l).contiguous()
+    fused = swap_fusion_encoder(model.fusion_net, w.permute(0, 1, 4, 2, 3).contiguous(), com_mask)           # b c h w
+    y = naive_decoder(model.decoder, fused)
+    return bev_seg_head(model.seg_head, y, y.shape[0], 1)
+
+
+def corpbevt(model, batch_dict):
+    """CorpBEVT.forward (corpbevt.py:104-145) as a differentiable graph"""
+    feats = resnet_encoder(model.encoder, batch_dict["inputs"])
+    batch_dict.update({"features": feats})
+    f = fax_module(model.fax, batch_dict).squeeze(1)
+    return fuse_and_decode(model, f, batch_dict["transformation_matrix"], batch_dict["record_len"])

@@ -2,9 +2,11 @@
 the reference reports as validation loss (train_camera.py:182-196 under no_grad) and optimises in training.  Same
 constructor arguments (`d_weights`, `s_weights`, optional `l_weights` (default 50), `d_coe`, `s_coe`, `target`), same
 `forward(output_dict, gt_dict)` -> total loss and `loss_dict` entries; the cross entropies run on the logits where they are
-(cobevt_weighted_cross_entropy).  Back-propagation is out of scope: the result carries no graph."""
+(cobevt_weighted_cross_entropy).  When a prediction requires grad (training, train_camera.py:166-173) the same kernel runs behind
+an autograd Function whose backward is cobevt_weighted_cross_entropy_bwd; otherwise the result carries no graph."""
 import torch
 
+from .. import autograd as ag
 from .. import ops
 
 
@@ -29,12 +31,14 @@ class VanillaSegLoss(object):
         static_loss = torch.tensor(0, device=static_pred.device)
         dynamic_loss = torch.tensor(0, device=dynamic_pred.device)
         flat = lambda t: t.reshape(t.shape[0] * t.shape[1], *t.shape[2:])
+
+        def ce(pred, gt, weight):
+            fn = ag.weighted_cross_entropy if (pred.requires_grad and torch.is_grad_enabled()) else ops.weighted_cross_entropy
+            return fn(flat(pred), flat(gt).to(pred.device), weight)
         if self.target != "static":
-            dynamic_loss = ops.weighted_cross_entropy(flat(dynamic_pred), flat(gt_dict["gt_dynamic"]).to(dynamic_pred.device),
-                                                      self.dynamic_weight)
+            dynamic_loss = ce(dynamic_pred, gt_dict["gt_dynamic"], self.dynamic_weight)
         if self.target != "dynamic":
-            static_loss = ops.weighted_cross_entropy(flat(static_pred), flat(gt_dict["gt_static"]).to(static_pred.device),
-                                                     self.static_weight)
+            static_loss = ce(static_pred, gt_dict["gt_static"], self.static_weight)
         total_loss = self.s_coe * static_loss + self.d_coe * dynamic_loss
         self.loss_dict.update({"total_loss": total_loss, "static_loss": static_loss, "dynamic_loss": dynamic_loss})
         return total_loss

@@ -1087,7 +1087,7 @@ def channel_gate(x, gate):
     return out
 
 
-def weighted_cross_entropy(logits, target, weight):
+def weighted_cross_entropy(logits, target, weight, want_stats=False):
     """nn.CrossEntropyLoss(weight=weight)(logits (N, C, H, W), target (N, H, W) int64) -> 0-d fp32 tensor on the device
     (vanilla_seg_loss.py:18-23,58-70); forward only."""
     _need_cuda(logits, target)
@@ -1105,7 +1105,7 @@ def weighted_cross_entropy(logits, target, weight):
     bad = int(out[3].item())          # nn.CrossEntropyLoss raises for targets outside [0, C) other than ignore_index = -100
     if bad:
         raise CobevtHipError("weighted_cross_entropy: %d target labels outside [0, %d) (only -100 is ignored)" % (bad, c))
-    return out[0]
+    return (out[0], out, x, y, wt) if want_stats else out[0]
 
 
 def iou_counts(pred, label, visibility, label_indices, thresholds, min_visibility):

@@ -179,10 +179,18 @@ int cobevt_window_attention(const void* q, const void* k, const void* v, void* o
  * Replaces torch autograd through the einsum / softmax / einsum of fax_modules.py:219-237, swap_fusion_modules.py:100-121
  * (train_camera.py:143-179 loss.backward()). */
 int cobevt_window_attention_lse(const void* q, const void* k, const void* v, void* out, float* lse, const float* bias_table,
-                                const float* mask, const int* dims, float scale, hipStream_t stream);
+                                const float* mask, const int* dims, float scale, float drop_p, unsigned drop_seed,
+                                hipStream_t stream);
 int cobevt_window_attention_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
                                 const void* dout, void* dq, void* dk, void* dv, float* dbias, const float* bias_table,
-                                const float* mask, const int* dims, float scale, hipStream_t stream);
+                                const float* mask, const int* dims, float scale, float drop_p, unsigned drop_seed,
+                                hipStream_t stream);
+/* drop_p > 0: nn.Dropout on the attention probabilities (FAX global attention in train mode, fax_modules.py:114,161): element
+ * (query, key) is kept with probability 1 - drop_p and scaled by 1 / (1 - drop_p); the decision is a counter-based hash of
+ * (drop_seed, batch, window, head, query, key), regenerated by the backward kernels.  cobevt_attention_dropout_mask dumps it
+ * (test hook): keep uint8 [B][L][heads][Nq][Nk]. */
+int cobevt_attention_dropout_mask(int B, int L, int heads, int Nq, int Nk, float drop_p, unsigned drop_seed, unsigned char* keep,
+                                  hipStream_t stream);
 
 /* Row-local backward kernels of the training slice (fp32).  cobevt_layernorm_bwd: x, dy (rows, C) -> dx; ADDS dy * xhat / dy
  * column sums into zero-initialised dgamma[C] / dbeta[C] (both nullable together); gamma nullable (= 1).  C % 4 == 0, C <= 1024.
@@ -322,6 +330,10 @@ int cobevt_seg_class_counts(const long long* pred, const long long* gt, unsigned
  * weight [C] fp32, out >= 4 floats, scratch >= 3 * N * ceil(hw / 4096) floats, fixed summation order. */
 int cobevt_weighted_cross_entropy(const void* logits, const long long* target, const float* weight, float* scratch, float* out,
                                   int dtype, int N, int C, int hw, hipStream_t stream);
+/* Backward of the loss above for fp32 logits: dlogits (N, C, hw) = upstream[0] * w[y] (softmax_c - [c == y]) / sum w[y]; stats = the
+ * forward's out[4]; upstream = the incoming gradient of the scalar loss (device fp32[1]).  train_camera.py:166-173 loss.backward(). */
+int cobevt_weighted_cross_entropy_bwd(const float* logits, const long long* target, const float* weight, const float* stats,
+                                      const float* upstream, float* dlogits, int N, int C, int hw, hipStream_t stream);
 
 /* The same GEMM as cobevt_linear_rows for K <= 512 in bf16 (the to_q / to_k / to_v / to_qkv projections behind a LayerNorm,
  * feature_proj / feature_linear behind BN + ReLU, the Bottleneck 1x1 convs), on the row chain's structure: 32-row workgroups,

@@ -268,10 +268,10 @@ def test_training_slice_fails_loudly(cuda):
         m(x)                                                       # CPU tensor
     with pytest.raises(CobevtHipError):
         m(x.to(cuda).to(torch.bfloat16))                           # bf16 is the inference layout
-    # modules without backward kernels keep refusing train() mode
-    conv = host.Bottleneck(128, 32).train().to(cuda)
+    # modules without a training forward keep refusing train() mode
+    comp = host.NaiveCompressor(128, 2).train().to(cuda)
     with pytest.raises(CobevtHipError):
-        conv(torch.zeros(1, 128, 8, 8, device=cuda))
+        comp(torch.zeros(1, 128, 8, 8, device=cuda))
 
 
 def test_one_optimizer_step_reduces_the_loss(cuda):
@@ -304,3 +304,147 @@ def test_one_optimizer_step_reduces_the_loss(cuda):
     with torch.no_grad():
         y_train = m(x.to(cuda), mask.to(cuda))
     assert_close(y_eval, y_train, TOL, "eval() forward after optimizer steps vs train-mode graph")
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,h,w,bias", [
+    (64, 64, 3, 1, 1, 12, 20, False), (64, 128, 3, 2, 1, 16, 16, False), (64, 128, 1, 2, 0, 16, 16, False), (3, 64, 7, 2, 3, 32, 32, False),
+    (32, 2, 3, 1, 1, 9, 11, True), (128, 32, 1, 1, 0, 8, 8, True), (16, 24, 3, 2, 1, 15, 13, True)])
+def test_conv2d_forward_backward_vs_torch(cuda, cin, cout, k, stride, pad, h, w, bias):
+    """the training conv (fp32 implicit-GEMM forward and input gradient, library-GEMM weight gradient) against torch's conv2d
+    autograd: the ResNet / decoder / head shapes incl. strided, odd sizes, 3 input and 2 output channels"""
+    g = torch.Generator().manual_seed(7)
+    conv = torch.nn.Conv2d(cin, cout, k, stride, pad, bias=bias).to(cuda)
+    x0 = torch.randn(2, cin, h, w, generator=g)
+    with torch.enable_grad():
+        x = _leaf(x0, cuda)
+        y = ag.conv2d(x, conv)
+        wgt = torch.randn(y.shape, generator=g).to(cuda)
+        (y * wgt).sum().backward()
+        got = (y.detach().clone(), x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone() if bias else None)
+        conv.zero_grad()
+        xr = _leaf(x0, cuda)
+        yr = conv(xr)
+        (yr * wgt).sum().backward()
+    assert_close(got[0], yr, 1e-4, "conv forward")
+    assert_close(got[1], xr.grad, 1e-4, "conv dX")
+    assert_close(got[2], conv.weight.grad, 1e-4, "conv dW")
+    if bias:
+        assert_close(got[3], conv.bias.grad, 1e-4, "conv db")
+
+
+def _freeze_bn(m):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.eval()
+    return m
+
+
+def test_corpbevt_trains_end_to_end_gradients_vs_oracle(cuda):
+    """The whole reduced CorpBEVT (gv8 config: ResNet encoder, FAX pyramid, STTF, swap fusion, decoder, head) in train() mode
+    against torch autograd through the oracle: logits and the gradient of every parameter (BatchNorms frozen so that the
+    oracle's running-statistics BatchNorm is the same function)."""
+    import copy
+    import oracle.corpbevt as o_model
+    cfg = synth.corpbevt_small_config()
+    cfg["fax"]["self_attn"]["dropout"] = 0.0          # dropout off everywhere: the oracle is the eval-mode function
+    cfg["fax_fusion"]["drop_out"] = 0.0
+    m = _freeze_bn(_train_module(host.CorpBEVT(copy.deepcopy(cfg)), cuda))
+    sd = _oracle_sd(m)
+    batch = synth.opv2v_batch(agents=2, cams=2, image=128, max_cav=3, seed=cases.SEED)
+    with torch.enable_grad():
+        out_ref = o_model.corpbevt_forward(sd, cfg, dict(batch))["dynamic_seg"]
+        out = m({k: v.to(cuda) for k, v in batch.items()})["dynamic_seg"]
+        assert_close(out, golden("gv8_corpbevt_small")["dynamic_seg"], TOL, "train-mode forward vs golden")
+        _compare(m, sd, out, out_ref, [], [], "CorpBEVT (reduced)")
+
+
+def test_corpbevt_optimizer_steps(cuda):
+    """train_camera.py:143-179 in miniature on the whole model: full train() mode (BatchNorm batch statistics), cross-entropy on the
+    dynamic head, Adam; the loss goes down and the bf16 inference path follows the updated parameters"""
+    import copy
+    cfg = synth.corpbevt_small_config()
+    m = _train_module(host.CorpBEVT(copy.deepcopy(cfg)), cuda)
+    batch = {k: v.to(cuda) for k, v in synth.opv2v_batch(agents=2, cams=2, image=128, max_cav=3, seed=3).items()}
+    gt = None
+    opt = torch.optim.Adam(m.parameters(), lr=2e-4)
+    losses = []
+    with torch.enable_grad():
+        for _ in range(6):
+            opt.zero_grad()
+            logits = m(dict(batch))["dynamic_seg"][:, 0]
+            if gt is None:
+                gt = (synth.procedural_input("train.gt", (logits.shape[0],) + tuple(logits.shape[2:]), cases.SEED) > 0.3).long().to(cuda)
+            loss = torch.nn.functional.cross_entropy(logits, gt)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    m.eval()
+    with torch.no_grad():
+        y = m(dict(batch))["dynamic_seg"]
+    assert torch.isfinite(y).all()
+
+
+def test_attention_probability_dropout(cuda):
+    """nn.Dropout on the attention probabilities (FAX global attention in train mode, fax_modules.py:114,161) inside the kernels: the
+    keep mask is a counter-based hash, dumped by the test hook; forward and all gradients must equal dense torch attention with
+    that same mask; the mask has the right density and changes with the seed"""
+    B, heads, hw, d = 2, 2, 8, 64
+    tm = ops.tokmap(0, 1, hw, hw, hw, hw)
+    n = hw * hw
+    g = torch.Generator().manual_seed(9)
+    q0, k0, v0 = (torch.randn(B * n, d, generator=g) for _ in range(3))
+    table0 = torch.randn((2 * hw - 1) ** 2, heads, generator=g)
+    wgt = torch.randn(B * n, d, generator=g).to(cuda)
+    p_drop, seed = 0.3, 12345
+    keep = ag.attention_dropout_mask(B, 1, heads, n, n, p_drop, seed, cuda)               # (B, 1, heads, n, n)
+    frac = float(keep.float().mean())
+    assert abs(frac - (1 - p_drop)) < 0.01, frac
+    assert not torch.equal(keep, ag.attention_dropout_mask(B, 1, heads, n, n, p_drop, seed + 1, cuda))
+    rows = ops.attention_index_map(tm, B, cuda).long()
+    bidx = ops.attention_bias_index(tm, tm, 1, cuda).long()
+    with torch.enable_grad():
+        q, k, v, table = (_leaf(t, cuda) for t in (q0, k0, v0, table0))
+        out = ag.window_attention(q, k, v, tm, tm, tm, B, heads, 0.21, B * n, bias_table=table, bias_L=1, drop_p=p_drop,
+                                  drop_seed=seed)
+        (out * wgt).sum().backward()
+        qr, kr, vr, tr = (_leaf(t, cuda) for t in (q0, k0, v0, table0))
+        qg = qr[rows.reshape(-1)].reshape(B, 1, n, heads, 32).permute(0, 1, 3, 2, 4)
+        kg = kr[rows.reshape(-1)].reshape(B, 1, n, heads, 32).permute(0, 1, 3, 2, 4)
+        vg = vr[rows.reshape(-1)].reshape(B, 1, n, heads, 32).permute(0, 1, 3, 2, 4)
+        s = 0.21 * qg @ kg.transpose(-1, -2) + tr[bidx].permute(2, 0, 1)
+        pm = s.softmax(-1) * keep.float() / (1 - p_drop)
+        o = (pm @ vg).permute(0, 1, 3, 2, 4).reshape(B, 1, n, d)
+        ref = torch.zeros(B * n, d, device=cuda).index_copy(0, rows.reshape(-1), o.reshape(-1, d))
+        (ref * wgt).sum().backward()
+    assert_close(out, ref, 1e-4, "dropout forward")
+    for a, b_, what in ((q.grad, qr.grad, "dq"), (k.grad, kr.grad, "dk"), (v.grad, vr.grad, "dv"), (table.grad, tr.grad, "dbias")):
+        assert_close(a, b_, TOL, "dropout " + what)
+    # p = 0 in eval-like use and the module route: train() with the shipped dropout runs and differs between calls
+    m = _train_module(host.FaxAttention(64, 32, 0.1, 8), cuda)
+    x = torch.randn(2, 64, 8, 8, generator=g).to(cuda)
+    with torch.no_grad():
+        y1, y2 = m(x), m(x)
+    assert torch.isfinite(y1).all() and not torch.equal(y1, y2)
+
+
+def test_vanilla_seg_loss_backward(cuda):
+    """VanillaSegLoss (vanilla_seg_loss.py:7-76) with predictions that require grad: value and d loss / d logits against torch's
+    nn.CrossEntropyLoss(weight), both heads, ignore label -100 included"""
+    g = torch.Generator().manual_seed(2)
+    crit = host.VanillaSegLoss({"d_weights": 75.0, "s_weights": 15.0, "l_weights": 50, "d_coe": 2.0, "s_coe": 0.5, "target": "both"})
+    dyn0, sta0 = torch.randn(2, 1, 2, 24, 20, generator=g), torch.randn(2, 1, 3, 24, 20, generator=g)
+    gd, gs = torch.randint(0, 2, (2, 1, 24, 20), generator=g), torch.randint(0, 3, (2, 1, 24, 20), generator=g)
+    gd[0, 0, :3] = -100
+    with torch.enable_grad():
+        dyn, sta = _leaf(dyn0, cuda), _leaf(sta0, cuda)
+        loss = crit({"dynamic_seg": dyn, "static_seg": sta}, {"gt_dynamic": gd.to(cuda), "gt_static": gs.to(cuda)})
+        loss.backward()
+        dr, sr = _leaf(dyn0, cuda), _leaf(sta0, cuda)
+        ce = torch.nn.functional.cross_entropy
+        ref = 2.0 * ce(dr.flatten(0, 1), gd.flatten(0, 1).to(cuda), torch.tensor([1.0, 75.0], device=cuda)) + \
+            0.5 * ce(sr.flatten(0, 1), gs.flatten(0, 1).to(cuda), torch.tensor([1.0, 15.0, 50.0], device=cuda))
+        ref.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    assert_close(dyn.grad, dr.grad, 1e-4, "d loss / d dynamic logits")
+    assert_close(sta.grad, sr.grad, 1e-4, "d loss / d static logits")

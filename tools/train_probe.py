@@ -78,8 +78,39 @@ def encoder_step(name, args, shape, use_mask):
     return {"case": name, "train_step_ms": round(t, 3), "fp32_inference_forward_ms": round(t_inf32, 3)}
 
 
+def corpbevt_step(agents):
+    """train_camera.py:143-179 on the full corpbevt.yaml model: forward, VanillaSegLoss, backward, Adam - fp32"""
+    import copy
+    cfg = synth.corpbevt_config()
+    model = synth.fill_module_(host.CorpBEVT(copy.deepcopy(cfg)), 0).train().cuda()
+    batch = {k: v.cuda() for k, v in synth.opv2v_batch(agents=agents).items()}
+    crit = host.VanillaSegLoss({"d_weights": 75.0, "s_weights": 15.0, "l_weights": 50, "d_coe": 2.0, "s_coe": 0.0, "target": "dynamic"})
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-4)
+    gt = None
+
+    def step():
+        nonlocal gt
+        opt.zero_grad(set_to_none=True)
+        out = model(dict(batch))
+        if gt is None:
+            gt = {"gt_dynamic": (torch.rand(out["dynamic_seg"].shape[:2] + out["dynamic_seg"].shape[3:], device="cuda") > 0.9).long(),
+                  "gt_static": torch.zeros(out["dynamic_seg"].shape[:2] + out["dynamic_seg"].shape[3:], device="cuda", dtype=torch.long)}
+        loss = crit(out, gt)
+        loss.backward()
+        opt.step()
+        return float(loss.detach())
+
+    torch.cuda.reset_peak_memory_stats()
+    l0 = step()
+    t = _time(step, iters=5, warm=1)
+    l1 = step()
+    return {"case": "CorpBEVT corpbevt.yaml, %d agents x 4 cams x 512x512, fp32 train step (forward + VanillaSegLoss + backward + AdamW)" % agents,
+            "train_step_ms": round(t, 2), "loss_first": round(l0, 4), "loss_after_8_steps": round(l1, 4),
+            "peak_memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+
+
 def main():
-    out = {"attention": [], "encoder": []}
+    out = {"attention": [], "encoder": [], "model": []}
     out["attention"].append(attention_pair("fusion window 5 agents 32x32 w8", 0, 5, 32, 32, 8, 4, 1, True, True))
     out["attention"].append(attention_pair("fusion grid 5 agents 32x32 w8", 1, 5, 32, 32, 8, 4, 1, True, True))
     out["attention"].append(attention_pair("LiDAR window 8 agents 256x256 w8", 0, 8, 256, 256, 8, 2, 1, True, True))
@@ -91,6 +122,8 @@ def main():
     lidar = dict(input_dim=64, mlp_dim=128, agent_size=8, window_size=8, dim_head=32, drop_out=0.0, depth=3, mask=True)
     out["encoder"].append(encoder_step("LiDAR FuseBEVT (8 x 64 x 256 x 256, depth 3, BASELINE configs[4])", lidar,
                                        (1, 8, 64, 256, 256), True))
+    for agents in (2, 5):
+        out["model"].append(corpbevt_step(agents))
     print(json.dumps(out, indent=1))
 
 
