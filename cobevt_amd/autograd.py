@@ -232,7 +232,7 @@ class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d (square kernel, symmetric padding, groups 1) on (N, C, H, W)-shaped tensors (channels-last memory is used as it
     is).  Forward and the input gradient run on the fp32 implicit-GEMM kernel (the input gradient is the same convolution with
     the taps flipped and the channel roles swapped, on the zero-stuffed output gradient when stride > 1); the weight gradient is
-    kh * kw plain GEMMs dY^T . X_tap, i.e. library calls."""
+    cobevt_conv_wgrad (csrc/train_rows.hip: a GEMM over the pixels on the fp32 matrix path, operands straight from global memory)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad):
@@ -265,17 +265,10 @@ class Conv2dFn(torch.autograd.Function):
             wt = weight.flip(2, 3).transpose(0, 1)                 # (Cin, Cout, kh, kw)
             dx = _igemm_conv(g, wt, None, 1, kh - 1 - pad, h, w).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            F = torch.nn.functional
-            # rows / columns the strided windows can reach past the padded map are zeros too
-            need_h, need_w = (ho - 1) * stride + kh, (wo - 1) * stride + kw
-            xp = F.pad(xl, (0, 0, pad, max(need_w - w - pad, 0), pad, max(need_h - h - pad, 0)))
-            dy2 = dyl.reshape(-1, cout).t()
-            taps = []
-            for a in range(kh):
-                for b in range(kw):
-                    xt = xp[:, a:a + stride * (ho - 1) + 1:stride, b:b + stride * (wo - 1) + 1:stride, :].reshape(-1, cin)
-                    taps.append(dy2 @ xt)                          # (Cout, Cin)
-            dw = torch.stack(taps, dim=2).reshape(cout, cin, kh, kw)
+            dw = torch.zeros((cout, cin, kh, kw), device=dyl.device, dtype=torch.float32)
+            dims = _ints([n, h, w, cin, ho, wo, cout, kh, stride, pad])
+            rc = _L.load().cobevt_conv_wgrad(_p(xl), _p(dyl), _p(dw), dims, _stream())
+            _L.check(rc, "cobevt_conv_wgrad")
         if has_bias and ctx.needs_input_grad[2]:
             db = dyl.sum(dim=(0, 1, 2))
         return dx, dw, db, None, None

@@ -119,6 +119,72 @@ __global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ x, 
     ((float4*)out)[i] = o;
 }
 
+// Weight gradient of a k x k convolution (fp32, channels-last): dW[o][c][a][b] = sum over output pixels m of
+// dY[m][o] * X[pixel of m shifted by tap (a, b)][c]  - a GEMM whose contraction runs over the PIXELS.  One workgroup = (32-cout
+// tile, 32-cin tile, tap, share of the output rows); v_mfma_f32_32x32x2_f32 consumes two pixels per instruction and both operands
+// are one coalesced 128-byte row piece per half-wave straight from global memory (A[cout][pixel] = dY, B[pixel][cin] = X), so there
+// is no LDS staging; the four waves split the rows, meet in LDS and add the tile into dW with fp32 atomics (dW zero-initialised).
+// The reference gets this from cuDNN under autograd (every nn.Conv2d of resnet_ms.py / fax_modules.py / naive_decoder.py).
+struct WgradParams {
+    const float* x;      // (N, H, W, Cin)
+    const float* dy;     // (N, Ho, Wo, Cout)
+    float* dw;           // (Cout, Cin, k, k)
+    int N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, nchunks;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+    __shared__ float red[3 * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, ql = lane & 31;
+    const int co0 = blockIdx.x * 32;
+    const int ntap = p.k * p.k;
+    const int ci0 = (blockIdx.y / ntap) * 32, tap = blockIdx.y % ntap;
+    const int ta = tap / p.k, tb = tap - ta * p.k;
+    const int rows = p.N * p.Ho;                                   // output rows (image, oy)
+    const int per = (rows + p.nchunks - 1) / p.nchunks;
+    const int r0 = blockIdx.z * per, r1 = min(rows, r0 + per);
+    const bool co_ok = co0 + ql < p.Cout, ci_ok = ci0 + ql < p.Cin;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int row = r0 + wave; row < r1; row += 4) {
+        const int n = row / p.Ho, oy = row - n * p.Ho;
+        const int iy = oy * p.stride - p.pad + ta;
+        const bool y_ok = iy >= 0 && iy < p.H;
+        // unconditional loads from clamped addresses + select: a load under a branch makes the compiler drain vmcnt right after it
+        const float* dyr = p.dy + (size_t)row * p.Wo * p.Cout + min(co0 + ql, p.Cout - 1);
+        const float* xr = p.x + ((size_t)n * p.H + (y_ok ? iy : 0)) * p.W * p.Cin + min(ci0 + ql, p.Cin - 1);
+        for (int ox0 = 0; ox0 < p.Wo; ox0 += 8) {                  // four MFMAs (eight pixels) with their loads in flight together
+            float a[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ox = ox0 + 2 * u + h;
+                const int ix = ox * p.stride - p.pad + tb;
+                const bool o_ok = ox < p.Wo;
+                const bool i_ok = o_ok && y_ok && ix >= 0 && ix < p.W;
+                const float av = dyr[(size_t)min(ox, p.Wo - 1) * p.Cout];
+                const float xv = xr[(size_t)min(max(ix, 0), p.W - 1) * p.Cin];
+                a[u] = (o_ok && co_ok) ? av : 0.f;
+                bv[u] = (i_ok && ci_ok) ? xv : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv[u], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (wave > 0) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[r] + red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane];
+            const int co = co0 + acc_row(r, lane), ci = ci0 + ql;   // D[cout rows][cin cols]
+            if (co < p.Cout && ci < p.Cin && v != 0.f) atomicAdd(p.dw + ((size_t)co * p.Cin + ci) * ntap + tap, v);
+        }
+    }
+}
+
 }  // namespace
 }  // namespace cobevt
 
@@ -142,5 +208,26 @@ extern "C" int cobevt_gelu(const float* x, const float* dy, float* out, long n, 
     if (n < 4 || n % 4) return COBEVT_ERR_SHAPE;
     const long n4 = n / 4;
     hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, dy, out, n4);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+extern "C" int cobevt_conv_wgrad(const float* x, const float* dy, float* dw, const int* dims, hipStream_t stream) {
+    // dims: [N, H, W, Cin, Ho, Wo, Cout, k, stride, pad]
+    if (!x || !dy || !dw || !dims) return COBEVT_ERR_ARG;
+    WgradParams p;
+    p.x = x; p.dy = dy; p.dw = dw;
+    p.N = dims[0]; p.H = dims[1]; p.W = dims[2]; p.Cin = dims[3]; p.Ho = dims[4]; p.Wo = dims[5]; p.Cout = dims[6];
+    p.k = dims[7]; p.stride = dims[8]; p.pad = dims[9];
+    if (p.N < 1 || p.H < 1 || p.W < 1 || p.Cin < 1 || p.Ho < 1 || p.Wo < 1 || p.Cout < 1 || p.k < 1 || p.k > 7 || p.stride < 1 || p.pad < 0)
+        return COBEVT_ERR_SHAPE;
+    const int tiles_o = (p.Cout + 31) / 32, tiles_i = (p.Cin + 31) / 32, ntap = p.k * p.k;
+    const long per = (long)tiles_o * tiles_i * ntap;
+    const int rows = p.N * p.Ho;
+    long chunks = (2048 + per - 1) / per;                          // about 2048 workgroups, at least four rows each
+    if (chunks > rows / 4) chunks = rows / 4;
+    if (chunks < 1) chunks = 1;
+    p.nchunks = (int)chunks;
+    if (tiles_i * ntap > 65535 || chunks > 65535) return COBEVT_ERR_SHAPE;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles_o, tiles_i * ntap, (unsigned)chunks), dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

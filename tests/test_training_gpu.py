@@ -445,6 +445,6 @@ def test_vanilla_seg_loss_backward(cuda):
         ref = 2.0 * ce(dr.flatten(0, 1), gd.flatten(0, 1).to(cuda), torch.tensor([1.0, 75.0], device=cuda)) + \
             0.5 * ce(sr.flatten(0, 1), gs.flatten(0, 1).to(cuda), torch.tensor([1.0, 15.0, 50.0], device=cuda))
         ref.backward()
-    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach()))
     assert_close(dyn.grad, dr.grad, 1e-4, "d loss / d dynamic logits")
     assert_close(sta.grad, sr.grad, 1e-4, "d loss / d static logits")
