@@ -135,12 +135,12 @@ def _mlp(x, prenorm, mlp):
 
 def _pre_act_conv1x1(seq, x):
     """nn.Sequential(BatchNorm2d, ReLU, Conv2d 1x1) (fax_modules.py:281-292).  The BatchNorm follows ITS OWN .training flag
-    (batch statistics + running-stat update, or the frozen running statistics), as torch would; both and the 1x1 convolution
-    are library calls - there is no hot kernel here."""
+    (batch statistics + running-stat update, or the frozen running statistics), as torch would; the 1x1 convolution is the
+    training conv (implicit-GEMM forward / input gradient, cobevt_conv_wgrad)."""
     F = torch.nn.functional
     bn = seq[0]
     y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
-    return F.conv2d(F.relu(y), seq[2].weight, seq[2].bias)
+    return ag.conv2d(F.relu(y), seq[2])
 
 
 def cross_view_swap_attention(m, index, x, bev, feature, I_inv, E_inv):
@@ -156,14 +156,18 @@ def cross_view_swap_attention(m, index, x, bev, feature, I_inv, E_inv):
     w1, w2 = m.feat_win_size
     pixel = m.image_plane.reshape(1, 1, 3, h * w)
     c = E_inv[..., -1:]
-    c_embed = F.conv2d(c.reshape(b * n, 4, 1, 1), m.cam_embed.weight)                   # (bn) d 1 1
+    # the 2- / 4-channel geometry embeddings are 1x1 convolutions = tiny matrix products over the channel axis (library GEMMs)
+    def pointwise(t, conv):
+        y = torch.einsum("nchw,oc->nohw", t, conv.weight.reshape(conv.weight.shape[0], -1))
+        return y if conv.bias is None else y + conv.bias[None, :, None, None]
+    c_embed = pointwise(c.reshape(b * n, 4, 1, 1), m.cam_embed)                         # (bn) d 1 1
     cam = F.pad(I_inv @ pixel, (0, 0, 0, 1), value=1)                                   # b n 4 hw
     dd = (E_inv @ cam).reshape(b * n, 4, h, w)
-    img_embed = F.conv2d(dd, m.img_embed.weight) - c_embed
+    img_embed = pointwise(dd, m.img_embed) - c_embed
     img_embed = img_embed / (img_embed.norm(dim=1, keepdim=True) + 1e-7)
     if m.bev_embed_flag:
         grid = getattr(bev, "grid%d" % index)
-        bev_embed = F.conv2d(grid[:2][None], m.bev_embed.weight, m.bev_embed.bias) - c_embed
+        bev_embed = pointwise(grid[:2][None], m.bev_embed) - c_embed
         bev_embed = bev_embed / (bev_embed.norm(dim=1, keepdim=True) + 1e-7)
         query = bev_embed.reshape(b, n, d, H, W) + x[:, None]
     else:
