@@ -462,7 +462,7 @@ def main():
                 from cobevt_amd.host import nuscenes as nu
                 c = synth.nuscenes_config()
                 feats, image, intr, ext = synth.nuscenes_inputs("bench.nuscenes", 0)
-                encn = nu.PyramidAxialEncoder(nu.FeatureMapBackbone(feats), **copy.deepcopy(c["encoder"]))
+                encn = nu.PyramidAxialEncoder(synth.FeatureMapBackbone(feats), **copy.deepcopy(c["encoder"]))
                 sin = synth.fill_module_(nu.CrossViewTransformer(encn, nu.Decoder(**c["decoder"]), c["dim_last"], c["outputs"]), 0)
                 sin = sin.eval().to(dev)
                 r4 = pipeline.CapturedCall(lambda im, ii, ee: sin({"image": im, "intrinsics": ii, "extrinsics": ee}),

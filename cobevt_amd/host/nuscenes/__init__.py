@@ -3,7 +3,6 @@
 from .encoder_pyramid_axial import Normalize, PyramidAxialEncoder  # noqa: F401
 from .decoder import Decoder, DecoderBlock  # noqa: F401
 from .cvt import CrossViewTransformer  # noqa: F401
-from .backbones import FeatureMapBackbone  # noqa: F401
 from .efficientnet import EfficientNetExtractor  # noqa: F401
 from .metrics import BaseIoUMetric, IoUMetric  # noqa: F401
 from .losses import BinarySegmentationLoss, CenterLoss, MultipleLoss, SigmoidFocalLoss  # noqa: F401

@@ -339,3 +339,27 @@ def cvt_config(kind="single", max_cav=5, image=512):
         cfg["disconet_fusion"] = {"use_temporal_encoding": True, "resolution": 0.390625, "downsample_rate": 8, "num_iteration": 3,
                                   "in_channels": 128, "gru_flag": True, "use_mask": True, "agg_operator": "avg", "conv_gru": gru}
     return cfg
+
+
+# ----------------------------------------------------------------------------------------------
+# nuScenes: a stand-in for the image backbone (synthetic feature maps of the shipped config's shapes)
+# ----------------------------------------------------------------------------------------------
+NUSCENES_B4_SHAPES = [(1, 32, 56, 120), (1, 56, 28, 60), (1, 112, 14, 30)]
+
+
+class FeatureMapBackbone(torch.nn.Module):
+    """Backbone contract of PyramidAxialEncoder (any module with `.output_shapes` whose forward maps normalised images to that list
+    of feature maps, efficientnet.py:24-110) that returns FIXED maps of the shapes EfficientNet-B4 produces at 224 x 480
+    ((32,56,120), (56,28,60), (112,14,30)).  A test / bench harness, not a component: the reference-generated fixture gv11 was made
+    with it (the reference itself could only be run with stand-in features here).  The real backbone is
+    cobevt_amd.host.nuscenes.EfficientNetExtractor."""
+
+    def __init__(self, features):
+        """features: list of (b*n, C, h, w) tensors returned verbatim by forward."""
+        super().__init__()
+        self.output_shapes = [torch.Size((1,) + tuple(f.shape[1:])) for f in features]
+        for i, f in enumerate(features):
+            self.register_buffer("feature%d" % i, f, persistent=False)
+
+    def forward(self, x):
+        return [getattr(self, "feature%d" % i) for i in range(len(self.output_shapes))]

@@ -281,7 +281,7 @@ def gv11():
     from cross_view_transformer.model.encoder_pyramid_axial import PyramidAxialEncoder as R_Enc
     from cross_view_transformer.model.decoder import Decoder as R_Dec
     from cross_view_transformer.model.cvt import CrossViewTransformer as R_CVT
-    from cobevt_amd.host.nuscenes.backbones import FeatureMapBackbone
+    from cobevt_amd.synth import FeatureMapBackbone
     import copy
     import oracle.nuscenes as o_nu
     c = cases.NUSCENES

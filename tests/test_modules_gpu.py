@@ -264,7 +264,7 @@ def test_nuscenes_sinbevt(cuda, dtype, tol):
     g = golden("gv11_nuscenes_sinbevt")
     c = cases.NUSCENES
     feats, image, intr, ext = cases.nuscenes_inputs()
-    enc = nu.PyramidAxialEncoder(nu.FeatureMapBackbone(feats), **copy.deepcopy(c["encoder"]))
+    enc = nu.PyramidAxialEncoder(synth.FeatureMapBackbone(feats), **copy.deepcopy(c["encoder"]))
     model = dev(nu.CrossViewTransformer(enc, nu.Decoder(**c["decoder"]), c["dim_last"], c["outputs"]), cuda)
     batch = {"image": image.to(cuda), "intrinsics": intr.to(cuda), "extrinsics": ext.to(cuda)}
     with host.compute_dtype(dtype):

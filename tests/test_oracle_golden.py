@@ -179,7 +179,7 @@ def _nuscenes_model():
     from cobevt_amd.host import nuscenes as nu
     c = cases.NUSCENES
     feats, image, intr, ext = cases.nuscenes_inputs()
-    enc = nu.PyramidAxialEncoder(nu.FeatureMapBackbone(feats), **copy.deepcopy(c["encoder"]))
+    enc = nu.PyramidAxialEncoder(synth.FeatureMapBackbone(feats), **copy.deepcopy(c["encoder"]))
     model = nu.CrossViewTransformer(enc, nu.Decoder(**c["decoder"]), c["dim_last"], c["outputs"])
     return fill_module_(model, cases.SEED), feats, image, intr, ext
 
