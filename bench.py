@@ -121,8 +121,8 @@ def quick(step, warmup=3, steps=20):
 # ----------------------------------------------------------------------------------------------
 # roofline leg
 # ----------------------------------------------------------------------------------------------
-MFMA_FAMILIES = ("conv3x3", "basicblock", "bottleneck", "gemm_rows", "row_chain", "igemm", "attention", "stem7x7")
-HBM_BOUND_FAMILIES = ("gemm_rows", "row_chain", "stem7x7")
+MFMA_FAMILIES = ("conv3x3", "basicblock", "bottleneck", "gemm_rows", "row_chain", "igemm", "attention", "stem7x7", "head3x3")
+HBM_BOUND_FAMILIES = ("gemm_rows", "row_chain", "stem7x7", "head3x3")
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s peak (about 6.3 TB/s achievable)
 
 

@@ -412,3 +412,81 @@ extern "C" int cobevt_sigmoid_focal_loss(const float* pred, const float* label, 
     hipLaunchKernelGGL(wce_final_kernel, dim3(1), dim3(256), 0, stream, scratch, out, gx * N, 2);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with a handful of output channels, channels-last input -> fp32 NCHW logits: BevSegHead's
+// dynamic / static heads (bev_seg_head.py:20-33,44-58: Conv2d(32, 2 | 3, 3, padding=1)) on the 256 x 256 BEV map.  75 MFLOP and
+// 4.7 MB: on the implicit-GEMM kernel the 2 output channels occupy one lane column of a 32-wide MFMA tile (21 us); here a thread
+// owns one pixel and all its output channels, the 18 x 18 x Cin input patch of a 16 x 16 pixel tile sits in LDS (16-byte reads),
+// the weights are wave-uniform scalar loads.
+namespace cobevt {
+
+template <typename T, int COUT>
+__global__ __launch_bounds__(256) void conv3x3_head_kernel(const T* in, const float* wgt, const float* bias, float* out, int N, int H,
+                                                           int W, int Cin) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int CH = Elem<T>::kChunk;
+    const int pstr = Cin * (int)sizeof(T) + 16;                 // patch pixel stride in bytes (odd multiple of 16: conflict-free)
+    const int tid = threadIdx.x;
+    const int tx = blockIdx.x * 16, ty = blockIdx.y * 16, n = blockIdx.z;
+    const int cpp = Cin / CH;                                   // 16-byte pieces per pixel
+    for (int item = tid; item < 18 * 18 * cpp; item += 256) {
+        const int pix = item / cpp, j = item - pix * cpp;
+        const int py = pix / 18, px = pix - py * 18;
+        const int y = ty - 1 + py, x = tx - 1 + px;
+        const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+        const uint4 v = *(const uint4*)(in + (((size_t)n * H + (ok ? y : 0)) * W + (ok ? x : 0)) * Cin + j * CH);
+        *(uint4*)(smem + pix * pstr + j * 16) = ok ? v : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    const int ly = tid >> 4, lx = tid & 15;
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = bias ? bias[o] : 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const unsigned char* pp = smem + ((ly + tap / 3) * 18 + lx + tap % 3) * pstr;
+        for (int j = 0; j < cpp; ++j) {
+            float v[8];
+            chunk_to_f32<T>(*(const uint4*)(pp + j * 16), v);
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                const float* wp = wgt + ((size_t)o * 9 + tap) * Cin + j * CH;      // wave-uniform: scalar loads
+#pragma unroll
+                for (int e = 0; e < CH; ++e) acc[o] = fmaf(v[e], wp[e], acc[o]);
+            }
+        }
+    }
+    const int y = ty + ly, x = tx + lx;
+    if (y < H && x < W) {
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) out[(((size_t)n * COUT + o) * H + y) * W + x] = acc[o];
+    }
+}
+
+template <typename T>
+static int launch_head(const void* in, const float* wgt, const float* bias, float* out, int N, int H, int W, int Cin, int Cout,
+                       hipStream_t stream) {
+    const dim3 grid((W + 15) / 16, (H + 15) / 16, N), block(256);
+    const size_t lds = (size_t)18 * 18 * (Cin * sizeof(T) + 16);
+    if (lds > 96 * 1024) return COBEVT_ERR_UNSUPPORTED;            // a pixel row of at most 256 bytes
+    switch (Cout) {
+#define COBEVT_HEAD_CASE(c) case c: (void)hipFuncSetAttribute((const void*)conv3x3_head_kernel<T, c>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); hipLaunchKernelGGL((conv3x3_head_kernel<T, c>), grid, block, lds, stream, (const T*)in, wgt, bias, out, N, H, W, Cin); break;
+        COBEVT_HEAD_CASE(1) COBEVT_HEAD_CASE(2) COBEVT_HEAD_CASE(3) COBEVT_HEAD_CASE(4)
+#undef COBEVT_HEAD_CASE
+        default: return COBEVT_ERR_SHAPE;
+    }
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+}  // namespace cobevt
+
+// wgt fp32 [Cout][9 taps][Cin]; out fp32 (N, Cout, H, W); Cout 1..4, Cin a multiple of the 16-byte chunk, a pixel row <= 256 bytes
+extern "C" int cobevt_conv3x3_head_nchw(const void* in, const float* wgt, const float* bias, float* out, int dtype, int N, int H, int W,
+                                        int Cin, int Cout, hipStream_t stream) {
+    if (!in || !wgt || !out) return COBEVT_ERR_ARG;
+    const int ch = dtype == 0 ? 8 : 4;
+    if (N < 1 || N > 65535 || H < 1 || W < 1 || Cin < ch || Cin % ch || Cin > 128 || Cout < 1 || Cout > 4) return COBEVT_ERR_SHAPE;
+    if (dtype == 0) return launch_head<bf16_t>(in, wgt, bias, out, N, H, W, Cin, Cout, stream);
+    if (dtype == 1) return launch_head<float>(in, wgt, bias, out, N, H, W, Cin, Cout, stream);
+    return COBEVT_ERR_ARG;
+}

@@ -39,6 +39,7 @@ USE_EMBED_GEMM3 = False   # the BEV query produced inside the 32-row GEMM that p
 # measured SLOWER on MI355X (119 vs 92 us on the level-0 shape, 361 vs 364 frames/s): the producer's 64 LDS
 # coefficient reads + ~400 VALU per thread cost more than the 170 MB of HBM traffic they save; kept for parity tests
 USE_CHAIN_NEXT = True  # ... and let the row-local GEMM that consumes its output next ride in the same launch
+USE_HEAD_CONV = True    # 3x3 convs with <= 4 output channels to NCHW fp32 logits (BevSegHead) on the direct kernel
 USE_BOTTLENECK = True   # FAX ResNetBottleNeck (128 -> 32 -> 32 -> 128) as one launch (bottleneck.hip) instead of three
 ATTN_VARIANT = 0    # 0 = automatic (K/V-resident attention kernel where it applies), 1 = always the streaming kernel, 2 = ... with 64-key tiles (A/B runs)
 ATTN_QSPLIT = 0     # 0 = automatic query split of the resident attention kernel; > 0 pins it (tools/attn_probe.py)
@@ -284,6 +285,11 @@ class ConvPlan(object):
             wp_[:cout] = wr
             wf = wp_.reshape(npad // 32, 32, kp // (2 * eg), 2, eg).permute(0, 2, 3, 1, 4)
             self.wfrag_rows = wf.to(torch.float32).to(dtype).to(device).contiguous()
+        # BevSegHead-style 3x3 convs with 1..4 output channels to fp32 NCHW logits: a direct kernel (postprocess.hip)
+        self.wgt_head = None
+        if kh == 3 and kw == 3 and int(stride) == 1 and int(pad) == 1 and not asym and not smallc and int(store_mode) == 2 and int(act) == 0 \
+                and not upsample and pre_bn is None and cout <= 4 and cin * (2 if self.code == BF16 else 4) <= 256 and cin % ch == 0:
+            self.wgt_head = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).to(torch.float32).to(device).contiguous()
         self.cin, self.cout, self.kh, self.kw = cin, cout, kh, kw
         self.K, self.kpad = K, kpad
         self.stride, self.pad, self.act = int(stride), int(pad), int(act)
@@ -382,6 +388,12 @@ def conv2d(x, plan, residual=None, out=None):
             nbytes += residual.numel() * esz
         return 2.0 * m * plan.cout * plan.K, float(nbytes)
 
+    if plan.wgt_head is not None and USE_HEAD_CONV and residual is None and (out_h, out_w) == (ho, wo):
+        with _timed("head3x3|%d->%d %dx%dx%d" % (cin, plan.cout, n, ho, wo), cost):
+            rc = _L.load().cobevt_conv3x3_head_nchw(_p(x), _p(plan.wgt_head), _p(plan.bias), _p(out), plan.code, n, h, w, cin, plan.cout,
+                                                    _stream())
+        _L.check(rc, "cobevt_conv3x3_head_nchw")
+        return out
     if plan.wgt_stem is not None and USE_STEM and h % 2 == 0 and w % 2 == 0 and residual is None and (out_h, out_w) == (ho, wo):
         sdims = _ints([plan.code, n, h, w, plan.cout, plan.act])
         with _timed("stem7x7|%dx%dx%d" % (n, h, w), cost):

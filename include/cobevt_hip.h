@@ -339,6 +339,12 @@ int cobevt_weighted_cross_entropy(const void* logits, const long long* target, c
 int cobevt_weighted_cross_entropy_bwd(const float* logits, const long long* target, const float* weight, const float* stats,
                                       const float* upstream, float* dlogits, int N, int C, int hw, hipStream_t stream);
 
+/* 3x3 / stride 1 / pad 1 convolution with 1..4 output channels on a channels-last map -> fp32 NCHW logits: the BevSegHead heads
+ * (bev_seg_head.py:20-33,44-58).  wgt fp32 [Cout][9 taps][Cin] (tap = kh * 3 + kw), bias fp32[Cout] nullable, Cin a multiple of
+ * the 16-byte chunk with at most 256 bytes per pixel. */
+int cobevt_conv3x3_head_nchw(const void* in, const float* wgt, const float* bias, float* out, int dtype, int N, int H, int W, int Cin,
+                             int Cout, hipStream_t stream);
+
 /* The same GEMM as cobevt_linear_rows for K <= 512 in bf16 (the to_q / to_k / to_v / to_qkv projections behind a LayerNorm,
  * feature_proj / feature_linear behind BN + ReLU, the Bottleneck 1x1 convs), on the row chain's structure: 32-row workgroups,
  * weights as MFMA fragments straight from L2.  wfrag: [N_p/32][8][64 lanes][16 bytes] as for cobevt_attn_mlp_chain (rows

@@ -1074,3 +1074,26 @@ def test_small_block_gemm_row_tiles_agree(cuda):
         finally:
             ops.USE_GEMM_ROWS3 = True
         assert (y32.float() - y1.float()).abs().max().item() <= 2e-2 * y1.float().abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cout,cin,h,w", [(2, 32, 256, 256), (3, 32, 37, 21), (1, 64, 16, 16), (4, 128, 20, 33)])
+def test_head_conv_direct_kernel(cuda, dtype, cout, cin, h, w):
+    """BevSegHead's 3x3 convs (2 / 3 classes) on the direct small-Cout kernel: against torch and against the implicit-GEMM path"""
+    g = torch.Generator().manual_seed(4)
+    wt, b = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5), torch.randn(cout, generator=g)
+    x = torch.randn(2, h, w, cin, generator=g)
+    plan = ops.ConvPlan(wt, b, stride=1, pad=1, store_mode=2, dtype=dtype, device=cuda)
+    assert (plan.wgt_head is not None) == (cin * (4 if dtype == torch.float32 else 2) <= 256)      # one pixel row <= 256 bytes
+    xd = x.to(cuda).to(dtype)
+    y = ops.conv2d(xd, plan)
+    ops.USE_HEAD_CONV = False
+    try:
+        y_igemm = ops.conv2d(xd, plan)
+    finally:
+        ops.USE_HEAD_CONV = True
+    ref = torch.nn.functional.conv2d(xd.float().permute(0, 3, 1, 2), wt.to(cuda).to(dtype).float(), b.to(cuda), padding=1)
+    assert y.dtype == torch.float32 and tuple(y.shape) == (2, cout, h, w)
+    from util import assert_close
+    assert_close(y, ref, 1e-4 if dtype == torch.float32 else 2e-3, "head conv vs torch")
+    assert_close(y, y_igemm, 1e-4 if dtype == torch.float32 else 2e-3, "head conv vs implicit GEMM")

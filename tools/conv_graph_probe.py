@@ -60,3 +60,11 @@ for (n, h, w, cin, cout) in SHAPES:
             line += " %d err" % v
     ops.USE_CONV3_WFRAG, ops.CONV3_VARIANT = True, 0
     print(line, flush=True)
+if __name__ == "__main__" and os.environ.get("HEAD"):
+    wt = torch.randn(2, 32, 3, 3) / 17.0
+    plan = ops.ConvPlan(wt, torch.randn(2), stride=1, pad=1, store_mode=2, dtype=dtype, device=dev)
+    x = torch.randn(1, 256, 256, 32, device=dev).to(dtype)
+    out = torch.empty(1, 2, 256, 256, device=dev, dtype=torch.float32)
+    for flag in (True, False):
+        ops.USE_HEAD_CONV = flag
+        print("head 32->2 256x256 direct=%s %.1f us" % (flag, graph_time(lambda: ops.conv2d(x, plan))), flush=True)
