@@ -35,7 +35,7 @@ if __name__ == "__main__":
         ref = None
         for variant in [int(v) for v in os.environ.get('ATTN_VARIANTS', '0,1,2').split(',')]:
             fn = lambda: ops.window_attention(qkv, qkv, qkv, out, tm, tm, tm, B, heads, 0.17, 3 * d, 3 * d, 3 * d, d, koff=d, voff=2 * d,
-                                              bias_table=table, bias_L=ncam, mask=mk, variant=variant)
+                                              bias_table=table, bias_L=ncam, mask=mk, variant=variant, qsplit=int(os.environ.get('QSPLIT', '0')))
             us = graph_time(fn)
             fn()
             torch.cuda.synchronize()
