@@ -448,3 +448,55 @@ def test_vanilla_seg_loss_backward(cuda):
     assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach()))
     assert_close(dyn.grad, dr.grad, 1e-4, "d loss / d dynamic logits")
     assert_close(sta.grad, sr.grad, 1e-4, "d loss / d static logits")
+
+
+def _dp_worker(rank, world, port, ret):
+    import os
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port)})
+    import torch.distributed as dist
+    from cobevt_amd import dist as cdist
+    dist.init_process_group("gloo", rank=rank, world_size=world)          # gloo moves CUDA tensors through the host: one GPU is enough
+    dev = torch.device("cuda:0")
+    c = cases.SWAP
+    args = dict(input_dim=c["dim"], mlp_dim=c["mlp_dim"], agent_size=c["agent_size"], window_size=c["window_size"],
+                dim_head=c["dim_head"], drop_out=0.0, depth=c["depth"], mask=True)
+    m = fill_module_(host.SwapFusionEncoder(args), cases.SEED).train().to(dev)          # identical initial weights on every rank
+    red = cdist.GradAllReducer(m.parameters(), bucket_bytes=64 << 10)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    x, mask = cases.swap_inputs()
+    x = (x + 0.1 * rank).to(dev)                                                       # a different batch per rank
+    target = synth.procedural_input("dp.target.%d" % rank, (c["b"], c["dim"], c["hw"], c["hw"]), cases.SEED).to(dev)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.mse_loss(m(x, mask.to(dev)), target)
+        loss.backward()
+        red.finish()
+        opt.step()
+        losses.append(float(loss.detach()))
+    flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    both = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    ret[rank] = (float((both[0] - both[1]).abs().max()), losses, len(red.buckets))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_training_two_ranks_one_gpu(cuda):
+    """train_camera.py:105-110 (DistributedDataParallel) with the package's pieces: two processes (gloo, sharing the one GPU),
+    identical initial weights, different batches, GradAllReducer between backward and the optimizer step: the replicas'
+    parameters stay bit-identical and the losses go down"""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_dp_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert sorted(ret.keys()) == [0, 1]
+    for r in (0, 1):
+        diff, losses, nb = ret[r]
+        assert diff == 0.0, "replicas diverged by %g" % diff
+        assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+        assert nb > 1
