@@ -5,18 +5,20 @@
 //     S[Y][X][dy][dx][c] = in[2Y+dy][2X+dx][c]                      (12 channels, padded to 16)
 //     out[oy][ox][n] = sum_{a,b in 0..3} sum_{dy,dx,c} S[oy+a-2][ox+b-2][dy][dx][c] * W'[n][a][b][dy][dx][c]
 //     W'[n][a][b][dy][dx][c] = w[n][c][2a+dy-1][2b+dx-1]   (0 where an index is -1)
-// so every tap is exactly one 32-byte k-group (bf16) whose A fragment is read straight out of an LDS patch at the
-// tap's pixel offset, as in conv3x3.hip — no im2col, no per-element tap decoding (the generic igemm "small Cin" path
-// spent 269 us here).  A workgroup (4 waves, 8x16 output pixels x 64 channels) is persistent: the [64][16][16]
-// weight tile stays in LDS, the next tile's patch is prefetched into registers (fp32 image read once, converted on
-// the fly), and the epilogue is staged through LDS for 16-byte coalesced stores.
+// The A fragments are read straight out of an LDS patch of S, as in conv3x3.hip — no im2col, no per-element tap decoding
+// (the generic igemm "small Cin" path spent 269 us here).  In LDS a patch pixel holds its 12 real channels only, so a tap
+// row a is 48 CONTIGUOUS values of the patch row (b, dy, dx, c) = three 16-value k-groups: K = 4 x 48 = 192, 12 MFMA steps.
+// (The weight image in global memory keeps one 16-channel group per tap, [Cout][16 taps][16 ch] with 4 zero channels; the
+// kernels drop them while staging the weights into LDS.)  A workgroup (4 waves, 8x16 output pixels x 64 channels) is
+// persistent: the weight tile stays in LDS, the next tile's patch is prefetched into registers (fp32 image read once,
+// converted on the fly), and the epilogue is staged through LDS for 16-byte coalesced stores.
 #include "common.hpp"
 
 namespace cobevt {
 
 struct StemParams {
     const float* in;     // (N, H, W, 3) fp32
-    const void* wgt;     // [Cout][16 taps][16 ch]
+    const void* wgt;     // [Cout][16 taps][16 ch] (12 real channels per tap)
     const float* bias;   // folded BN shift
     void* out;           // (N, Ho, Wo, Cout)
     int N, H, W, Ho, Wo, Cout;
@@ -25,12 +27,14 @@ struct StemParams {
 };
 
 template <typename T> struct StemCfg {
-    static constexpr int KG = 16 * Elem<T>::kBytes / 32;      // k-groups per tap (1 bf16, 2 fp32)
-    static constexpr int PIX = 16 * Elem<T>::kBytes + 16;     // patch pixel stride (odd multiple of 16 bytes)
+    static constexpr int KB = Elem<T>::kBytes;
+    static constexpr int STEPS_ROW = 48 * KB / 32;            // 32-byte operand steps per tap row (bf16 3, fp32 6)
+    static constexpr int PIX = 12 * KB;                       // patch pixel pitch: 6 / 12 banks (bf16: 8-byte aligned only)
     static constexpr int PH = 11, PW = 19;                    // (8 + 3) x (16 + 3) space-to-depth pixels
-    static constexpr int PROW = (PW * PIX + 255) / 256 * 256;
-    static constexpr int PATCH = PH * PROW;
-    static constexpr int WROW = 16 * 16 * Elem<T>::kBytes + 16;
+    // a lane half = pixels (y, 0..15), (y + 1, 0..15): pitch == 16 PIX (mod 256 B) continues the bank sequence into the next row
+    static constexpr int PROW = (PW * PIX - 16 * PIX % 256 + 255) / 256 * 256 + 16 * PIX % 256;
+    static constexpr int PATCH = (PH * PROW + 255) / 256 * 256;
+    static constexpr int WROW = 192 * KB + 16;
     static constexpr int WBYTES = 64 * WROW;
     static constexpr int SROW = 64 * 4 + 16;                  // fp32 staging row (64 channels)
     static constexpr int STAGE = 128 * SROW;
@@ -40,7 +44,7 @@ template <typename T> struct StemCfg {
 template <typename T>
 __global__ __launch_bounds__(256) void stem7x7_kernel(StemParams p) {
     using C = StemCfg<T>;
-    constexpr int KG = C::KG;
+    constexpr int KB = C::KB;
     constexpr int NPIECE = C::PH * C::PW * 2 * 3;             // (pixel, dy, 2-float piece): 8-byte global loads
     constexpr int P_IT = (NPIECE + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -51,7 +55,6 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(StemParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, ql = lane & 31;
 
-    // zero the patch once: channels 12..15 of every pixel (and the pad bytes) stay zero for the whole kernel
     for (int i = tid; i < C::PATCH / 16; i += 256) ((uint4*)patch)[i] = make_uint4(0, 0, 0, 0);
 
     float2 preg[P_IT];
@@ -90,14 +93,14 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(StemParams p) {
                 const int pc = item % 3, rest = item / 3;
                 const int dy = rest & 1, pix = rest >> 1;
                 const int py = pix / C::PW, px = pix - py * C::PW;
-                unsigned char* dst = patch + py * C::PROW + px * C::PIX + (dy * 6 + pc * 2) * Elem<T>::kBytes;
+                unsigned char* dst = patch + py * C::PROW + px * C::PIX + (dy * 6 + pc * 2) * KB;
                 if constexpr (Elem<T>::kIsBf16) *(uint32_t*)dst = pack_bf2(preg[it].x, preg[it].y);
                 else *(float2*)dst = preg[it];
             }
         }
     };
 
-    // ---- weights resident in LDS: [64][16 taps][16 ch]
+    // ---- weights resident in LDS: [64][4 tap rows][48] (the global image's 4 zero channels per tap dropped)
     int img, oy0, ox0, n0;
     int tile = blockIdx.x;
     if (tile >= p.ntiles) return;
@@ -105,11 +108,19 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(StemParams p) {
     int n0_loaded = -1;
     auto load_weights = [&](int nb) {
         constexpr int PIECES = 16 * 16 * Elem<T>::kBytes / 16;        // 16-byte pieces per weight row
+        constexpr int PPT = PIECES / 16;                              // pieces per tap: bf16 2 (8 channels), fp32 4 (4 channels)
         for (int i = tid; i < 64 * PIECES; i += 256) {
             const int row = i / PIECES, j = i - row * PIECES;
+            const int tap = j / PPT, part = j - tap * PPT;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (nb + row < p.Cout) v = *(const uint4*)((const unsigned char*)p.wgt + ((size_t)(nb + row) * PIECES + j) * 16);
-            *(uint4*)(wl + row * C::WROW + j * 16) = v;
+            unsigned char* d = wl + row * C::WROW + ((tap >> 2) * 48 + (tap & 3) * 12) * KB + part * 16;
+            if constexpr (Elem<T>::kIsBf16) {                         // channels 0..7 (two 8-byte halves), then 8..11
+                *(uint2*)d = make_uint2(v.x, v.y);
+                if (part == 0) *(uint2*)(d + 8) = make_uint2(v.z, v.w);
+            } else if (part < 3) {
+                *(uint4*)d = v;
+            }
         }
         n0_loaded = nb;
     };
@@ -136,17 +147,20 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(StemParams p) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                const unsigned char* pa = patch + abase + a * C::PROW + bb * C::PIX;
-                const unsigned char* pw = wl + bbase + (a * 4 + bb) * 16 * Elem<T>::kBytes;
-#pragma unroll
-                for (int g = 0; g < KG; ++g) {
-                    const uint4 af = *(const uint4*)(pa + g * 32);
-                    const uint4 b0 = *(const uint4*)(pw + g * 32);
-                    const uint4 b1 = *(const uint4*)(pw + 32 * C::WROW + g * 32);
-                    mfma_kgroup<T>(af, b0, acc[0]);
-                    mfma_kgroup<T>(af, b1, acc[1]);
+            for (int sub = 0; sub < C::STEPS_ROW; ++sub) {
+                const unsigned char* pa = patch + abase + a * C::PROW + sub * 32;
+                const unsigned char* pw = wl + bbase + a * 48 * KB + sub * 32;
+                uint4 af;
+                if constexpr (Elem<T>::kIsBf16) {             // 8-byte aligned: two halves (one ds_read2_b64)
+                    const uint2 lo = *(const uint2*)pa, hi = *(const uint2*)(pa + 8);
+                    af = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                } else {
+                    af = *(const uint4*)pa;
                 }
+                const uint4 b0 = *(const uint4*)pw;
+                const uint4 b1 = *(const uint4*)(pw + 32 * C::WROW);
+                mfma_kgroup<T>(af, b0, acc[0]);
+                mfma_kgroup<T>(af, b1, acc[1]);
             }
         }
         // ---- epilogue: bias + activation staged as fp32, then coalesced 16-byte stores
@@ -187,43 +201,82 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(StemParams p) {
 // ---------------------------------------------------------------------------------------------------------------------
 // Stem + MaxPool2d(3, 2, 1) in one kernel (cobevt_stem_conv7x7s2_pool): torchvision resnet conv1/bn1/relu/maxpool,
 // resnet_ms.py:67-71.  Separately the stem writes its 168 MB map (20 images) and the pool reads it back: 123 us for
-// 63 MB of input and 42 MB of pooled output.  Here a workgroup owns a 4 x 8 tile of POOLED pixels: it evaluates the
-// conv on the 9 x 17 region those windows cover (origin (2 py0 - 1, 2 px0 - 1); its 153 pixels linearised into five
+// 63 MB of input and 42 MB of pooled output.  Here a workgroup owns a ROWS x 8 tile of POOLED pixels: it evaluates the
+// conv on the (2 ROWS + 1) x 17 region those windows cover (origin (2 py0 - 1, 2 px0 - 1); its pixels linearised into
 // 32-row MFMA tiles), stages bias + ReLU as the storage type (rounding commutes with max) with zeros for conv pixels
 // outside the map (post-ReLU values are >= 0 and every window holds a valid pixel, so 0 is the max-pool identity),
-// and writes the 3 x 3 / stride 2 maxima.  20 % of the conv is recomputed on tile borders; the kernel stays HBM-bound.
+// and writes the 3 x 3 / stride 2 maxima.  17 - 24 % of the conv is recomputed on tile borders.
+// One wave per (pixel tile, 32-cout half) unit: bf16 = 5 rows = 187 region pixels = 6 pixel tiles (97 % of the MFMA rows
+// used) = 12 waves, two workgroups per CU; fp32 = 3 rows = 119 pixels = 4 tiles = 8 waves, one workgroup per CU.
+// What the knock-out builds (COBEVT_STEM_KNOCK, tools/stem_probe.py) showed: the kernel is bound by LDS throughput - taking
+// out the operand reads, the pool reads, the staging or the image loads each shortens it, deeper operand rings lengthen it.
+// So the work went into LDS bytes and bank conflicts: the K order without the zero channels (12 steps, not 16), the pooled
+// pixel order of the window reads, the patch row pitch; and into waits that were on the critical path for no reason (the
+// store of a tile's result, nine window reads one at a time).  87 -> 70 us bf16, 535 -> 350 us fp32 (same job).
+// (Earlier: eight waves for ten units had two waves carry two units - 32 dependent MFMA steps where the others had 16 - and,
+// `wave` being a VGPR value, the other six issued the second unit's MFMAs under an empty exec mask, which costs the same
+// pipeline time: 2.6 M MFMAs per launch in the PMC pass against 1.6 M of work.)
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef COBEVT_STEM_POOL_ROWS_BF16        // tools/stem_probe.py builds other geometries side by side
+#define COBEVT_STEM_POOL_ROWS_BF16 5
+#endif
+#ifndef COBEVT_STEM_POOL_ROWS_F32
+#define COBEVT_STEM_POOL_ROWS_F32 3
+#endif
+#ifndef COBEVT_STEM_KNOCK                 // probe builds only: 1 no operand reads, 2 no MFMAs, 4 no pool reads, 8 no image loads, 16 no staging
+#define COBEVT_STEM_KNOCK 0
+#endif
+
+typedef short short2_t __attribute__((ext_vector_type(2)));
+// maximum of non-negative storage-type values on their bit patterns (see the pool phase): one fp32, or two packed bf16
+template <typename T> __device__ __forceinline__ uint32_t word_max(uint32_t a, uint32_t b) {
+    if constexpr (Elem<T>::kIsBf16) {
+        const short2_t r = __builtin_elementwise_max(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b));
+        return __builtin_bit_cast(uint32_t, r);
+    } else {
+        return (uint32_t)max((int)a, (int)b);
+    }
+}
+
 template <typename T> struct StemPoolCfg {
-    static constexpr int KG = 16 * Elem<T>::kBytes / 32;
-    static constexpr int PIX = 16 * Elem<T>::kBytes + 16;
-    static constexpr int RH = 9, RW = 17, RPIX = RH * RW;     // conv region
-    static constexpr int NPT = (RPIX + 31) / 32;              // 5 MFMA pixel tiles
-    static constexpr int PH = RH + 3, PW = RW + 3;            // 12 x 20 space-to-depth pixels
-    static constexpr int PROW = (PW * PIX + 255) / 256 * 256;
-    static constexpr int PATCH = PH * PROW;
-    static constexpr int WROW = 16 * 16 * Elem<T>::kBytes + 16;
+    // K order of the pool kernel: (tap row a, tap column b, the 12 real channels of a space-to-depth pixel) - the four zero
+    // channels that pad a tap to one k-group in the weight image are dropped in LDS, so a tap row is 48 contiguous values of
+    // the patch row (4 pixels x 12) = three 16-value k-groups instead of four: 12 MFMA steps and operand reads, not 16
+    static constexpr int KB = Elem<T>::kBytes;
+    static constexpr int STEPS_ROW = 48 * KB / 32;            // 32-byte operand steps per tap row (bf16 3, fp32 6)
+    static constexpr int NS = 4 * STEPS_ROW;
+    static constexpr int PIX = 12 * KB;                       // patch pixel pitch (bf16: 8-byte aligned only)
+    static constexpr int ROWS = Elem<T>::kIsBf16 ? COBEVT_STEM_POOL_ROWS_BF16 : COBEVT_STEM_POOL_ROWS_F32;   // pooled rows of a tile
+    static constexpr int RH = 2 * ROWS + 1, RW = 17, RPIX = RH * RW;     // conv region
+    static constexpr int NPT = (RPIX + 31) / 32;              // MFMA pixel tiles
+    static constexpr int NT = 64 * NPT * 2;                   // one wave per (pixel tile, cout half)
+    static constexpr int PH = RH + 3, PW = RW + 3;            // space-to-depth pixels under the region's 4 x 4 taps
+    // patch row pitch == RW * PIX (mod 256 B): the 32 pixels of an MFMA tile are consecutive in the LINEARISED region, and
+    // with this pitch a tile that wraps to the next region row keeps the bank sequence of 32 consecutive pixels (6 or 12
+    // banks apart: conflict-free for the 8-byte halves of bf16 and the 16-byte reads of fp32)
+    static constexpr int PROW = (PW * PIX - RW * PIX % 256 + 255) / 256 * 256 + RW * PIX % 256;
+    static constexpr int PATCH = (PH * PROW + 255) / 256 * 256;
+    static constexpr int WROW = 192 * KB + 16;                // 100 / 196 banks: rows 36 / 4 banks apart
     static constexpr int WBYTES = 64 * WROW;
     static constexpr int SROW = 64 * Elem<T>::kBytes + 16;    // staging row: 64 channels in the storage type
     static constexpr int STAGE = (RPIX * SROW + 255) / 256 * 256;
     static constexpr int LDS = PATCH + WBYTES + STAGE + 256;      // + the 64 bias values
+    static_assert(NT <= 1024, "stem_pool_kernel: region too large for one workgroup");
 };
 
-#ifdef COBEVT_STEM_TRACE      // tools/stem_trace.py builds a copy with s_memtime marks (never the product .so)
+#ifdef COBEVT_STEM_TRACE      // tools/stem_probe.py builds copies with s_memtime marks (never the product .so)
 __device__ unsigned long long cobevt_stem_trace[16];
 #define COBEVT_ST_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && tile == (int)blockIdx.x + 2 * (int)gridDim.x) cobevt_stem_trace[(i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define COBEVT_ST_MARK(i) do {} while (0)
 #endif
 
-constexpr int kStemPoolThreads = 512;   // 8 waves share the ten (pixel tile, cout half) units of a region: 2,2,1,1,1,1,1,1
-
 template <typename T>
-__global__ __launch_bounds__(kStemPoolThreads, 4) void stem_pool_kernel(StemParams p) {
+__global__ __launch_bounds__(StemPoolCfg<T>::NT) void stem_pool_kernel(StemParams p) {
     using C = StemPoolCfg<T>;
-    constexpr int KG = C::KG, RW = C::RW, RPIX = C::RPIX, NT = kStemPoolThreads;
+    constexpr int RW = C::RW, RPIX = C::RPIX, NT = C::NT, KB = C::KB;
     constexpr int NPIECE = C::PH * C::PW * 2 * 3;
     constexpr int P_IT = (NPIECE + NT - 1) / NT;
-    constexpr int NUNIT = C::NPT * 2;                         // (pixel tile, 32-cout half)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* patch = smem;
     unsigned char* wl = smem + C::PATCH;
@@ -245,32 +298,37 @@ __global__ __launch_bounds__(kStemPoolThreads, 4) void stem_pool_kernel(StemPara
             const int pc = item % 3, rest = item / 3;
             const int dy = rest & 1, pix = rest >> 1;
             const int py = pix / C::PW, px = pix - py * C::PW;
-            pdst[it] = py * C::PROW + px * C::PIX + (dy * 6 + pc * 2) * Elem<T>::kBytes;
+            pdst[it] = py * C::PROW + px * C::PIX + (dy * 6 + pc * 2) * KB;
             prow[it] = 2 * (py - 2) + dy;                     // image row = 2*oy0 + prow
             pxo[it] = 2 * (px - 2);                           // first image column of the pixel pair = 2*ox0 + pxo
             pcol[it] = pxo[it] * 3 + pc * 2;                  // float offset inside the image row = 6*ox0 + pcol
         }
     }
+    // element offset of the piece relative to in[img][2 oy0][2 ox0][0] (fits 32 bits: |prow| <= 2 PH, the row pitch < 2^24)
+    int poff[P_IT];
+#pragma unroll
+    for (int it = 0; it < P_IT; ++it) poff[it] = prow[it] * p.W * 3 + pcol[it];
     float2 preg[P_IT];
     auto decode = [&](int tile, int& img, int& py0, int& px0) {
         const int tx = tile % p.tiles_x;
         const int rest = tile / p.tiles_x;
         const int ty = rest % p.tiles_y;
         img = rest / p.tiles_y;
-        py0 = ty * 4; px0 = tx * 8;
+        py0 = ty * C::ROWS; px0 = tx * 8;
     };
     auto load_patch = [&](int tile) {
         int img, py0, px0;
         decode(tile, img, py0, px0);
         const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;       // conv region origin
-        const float* base = p.in + (size_t)img * p.H * p.W * 3;
+        // uniform part of the address in scalar registers; per piece one 32-bit offset and four compares against scalars
+        const float* base = p.in + ((size_t)img * p.H + 2 * oy0) * (size_t)p.W * 3 + 6 * ox0;
+        const int ylo = -2 * oy0, yhi = p.H - 2 * oy0, xlo = -2 * ox0, xhi = p.W - 1 - 2 * ox0;
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
             float2 v = make_float2(0.f, 0.f);
-            const int iy = 2 * oy0 + prow[it], ix = 2 * ox0 + pxo[it];
             // the 6 floats in[iy][ix..ix+1][0..2] are contiguous; columns are valid in pairs (W is even)
-            if (pdst[it] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix + 1 < p.W)
-                v = *(const float2*)(base + (size_t)iy * p.W * 3 + 6 * ox0 + pcol[it]);
+            const bool ok = (pdst[it] >= 0) & (prow[it] >= ylo) & (prow[it] < yhi) & (pxo[it] >= xlo) & (pxo[it] < xhi);
+            if (!(COBEVT_STEM_KNOCK & 8) && ok) v = *(const float2*)(base + poff[it]);
             preg[it] = v;
         }
     };
@@ -291,42 +349,54 @@ __global__ __launch_bounds__(kStemPoolThreads, 4) void stem_pool_kernel(StemPara
         // once (unconditional, row clamped): the rolled, branch-guarded loop paid one L2 round trip per iteration before the
         // patch load could even be issued
         load_patch(tile);
-        constexpr int PIECES = 16 * 16 * Elem<T>::kBytes / 16;
+        // weight image in global memory: [64][16 taps][16 channels] (shared with stem7x7_kernel); compacted to [64][4][48] here
+        constexpr int PIECES = 16 * 16 * KB / 16;             // 16-byte pieces of a cout row
+        constexpr int PPT = PIECES / 16;                      // pieces per tap: bf16 2 (8 channels), fp32 4 (4 channels)
         constexpr int W_IT = (64 * PIECES + NT - 1) / NT;
         uint4 wv[W_IT];
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int i = tid + it * NT;
             const int row = i / PIECES, j = i - row * PIECES;
-            wv[it] = *(const uint4*)((const unsigned char*)p.wgt + ((size_t)(row < p.Cout ? row : 0) * PIECES + j) * 16);
+            wv[it] = *(const uint4*)((const unsigned char*)p.wgt + ((size_t)(row < p.Cout ? row : 0) * PIECES + (i < 64 * PIECES ? j : 0)) * 16);
         }
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int i = tid + it * NT;
             const int row = i / PIECES, j = i - row * PIECES;
-            if (i < 64 * PIECES) *(uint4*)(wl + row * C::WROW + j * 16) = row < p.Cout ? wv[it] : make_uint4(0, 0, 0, 0);
+            const int tap = j / PPT, part = j - tap * PPT;
+            if (i < 64 * PIECES) {
+                const uint4 v = row < p.Cout ? wv[it] : make_uint4(0, 0, 0, 0);
+                unsigned char* d = wl + row * C::WROW + ((tap >> 2) * 48 + (tap & 3) * 12) * KB + part * 16;
+                if constexpr (Elem<T>::kIsBf16) {             // channels 0..7 (two 8-byte halves), then 8..11
+                    *(uint2*)d = make_uint2(v.x, v.y);
+                    if (part == 0) *(uint2*)(d + 8) = make_uint2(v.z, v.w);
+                } else if (part < 3) {
+                    *(uint4*)d = v;
+                }
+            }
         }
     }
-    __syncthreads();
 
-    // this wave's units: u = wave and u = wave + 8 (waves 0, 1): pixel tile u >> 1, cout half u & 1
-    int abase[2], bbase[2], rpix[2], chalf[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int u = wave + 8 * t;
-        const int pt = (u < NUNIT ? u : 0) >> 1;
-        chalf[t] = u & 1;
-        int pr = pt * 32 + ql;
-        rpix[t] = pr;
-        if (pr >= RPIX) pr = RPIX - 1;
-        const int ry = pr / RW, rx = pr - ry * RW;
-        abase[t] = ry * C::PROW + rx * C::PIX + h * 16;
-        bbase[t] = (chalf[t] * 32 + ql) * C::WROW + h * 16;
-    }
-    const bool two = wave + 8 < NUNIT;                        // wave-uniform
+    // this wave's unit: pixel tile wave >> 1, cout half wave & 1
+    const int chalf = wave & 1;
+    const int rpix = (wave >> 1) * 32 + ql;                   // region pixel of this lane's accumulator column
+    const int rpc = rpix < RPIX ? rpix : RPIX - 1;
+    const int ry = rpc / RW, rx = rpc - ry * RW;
+    const int abase = ry * C::PROW + rx * C::PIX + h * 16;
+    const int bbase = (chalf * 32 + ql) * C::WROW + h * 16;
     float* bias_l = (float*)(smem + C::PATCH + C::WBYTES + C::STAGE);     // bias in LDS: 32 VGPRs less than keeping it
     if (tid < 64) bias_l[tid] = p.bias ? p.bias[tid] : 0.f;
     __syncthreads();
+
+    // the pooled chunk of a thread is stored one tile late, after the next patch has left its registers: vmcnt counts the
+    // store behind the prefetch loads, so a store issued at the end of a tile made the patch wait at the top of the next one
+    // wait for the write to complete
+    constexpr int CH = Elem<T>::kChunk;
+    constexpr int CPP = 64 / CH;
+    static_assert(C::ROWS * 8 * CPP <= NT, "stem_pool_kernel: one pooled chunk per thread");
+    uint4 pend = make_uint4(0, 0, 0, 0);
+    T* pend_dst = nullptr;
 
     for (; tile < p.ntiles; tile += gridDim.x) {
         int img, py0, px0;
@@ -334,60 +404,61 @@ __global__ __launch_bounds__(kStemPoolThreads, 4) void stem_pool_kernel(StemPara
         const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;
         COBEVT_ST_MARK(0);
         store_patch();
+        if (pend_dst) *(uint4*)pend_dst = pend;
         __syncthreads();
         COBEVT_ST_MARK(1);
         const int next = tile + gridDim.x;
         if (next < p.ntiles) load_patch(next);
         COBEVT_ST_MARK(2);
 
-        f32x16 acc[2];
+        f32x16 acc;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        // 16 taps x KG k-groups, operands one step ahead of the MFMAs in a two-slot register ring with the issue order
-        // pinned (each MFMA had its two ds_read_b128 right in front of it: 3.3k cycles for 32 MFMAs in the s_memtime trace)
-        constexpr int NS = 16 * KG;
-        constexpr int RS = 2;                                 // ring slots (one step ahead keeps the kernel at 128 VGPRs = 2 workgroups / CU)
-        uint4 ra[RS][2], rb[RS][2];
-        auto fetch = [&](int slot, int i) {                  // i = tap * KG + g (compile-time after unrolling)
-            const int tap = i / KG, g = i - tap * KG;
-            const int toff = (tap >> 2) * C::PROW + (tap & 3) * C::PIX + g * 32;
-            const int woff = tap * 16 * Elem<T>::kBytes + g * 32;
-            rb[slot][0] = *(const uint4*)(wl + bbase[0] + woff);
-            ra[slot][0] = *(const uint4*)(patch + abase[0] + toff);
-            if (two) {
-                rb[slot][1] = *(const uint4*)(wl + bbase[1] + woff);
-                ra[slot][1] = *(const uint4*)(patch + abase[1] + toff);
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // 4 tap rows x STEPS_ROW 32-byte steps, operands one step ahead of the MFMAs in a register ring with the issue order
+        // pinned (each MFMA had its two LDS reads right in front of it: 3.3k cycles for 32 MFMAs in the s_memtime trace; deeper
+        // rings measured slower - the loop is bound by LDS throughput, not latency)
+        constexpr int NS = C::NS;
+        constexpr int RS = 2;
+        uint4 ra[RS], rb[RS];
+        auto fetch = [&](int slot, int i) {                  // compile-time i after unrolling
+            const int a = i / C::STEPS_ROW, sub = i - a * C::STEPS_ROW;
+            rb[slot] = *(const uint4*)(wl + bbase + a * 48 * KB + sub * 32);
+            const unsigned char* pa = patch + abase + a * C::PROW + sub * 32;
+            if constexpr (Elem<T>::kIsBf16) {                 // 8-byte aligned: two halves (one ds_read2_b64)
+                const uint2 lo = *(const uint2*)pa, hi = *(const uint2*)(pa + 8);
+                ra[slot] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            } else {
+                ra[slot] = *(const uint4*)pa;
             }
         };
-        fetch(0, 0);
+#pragma unroll
+        for (int i = 0; i < RS - 1; ++i) fetch(i, i);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            if (i + 1 < NS) fetch((i + 1) % RS, i + 1);
-            mfma_kgroup<T>(rb[i % RS][0], ra[i % RS][0], acc[0]);      // D = W . X^T: lane <-> pixel, registers <-> couts
-            if (two) mfma_kgroup<T>(rb[i % RS][1], ra[i % RS][1], acc[1]);
+            if (i + RS - 1 < NS && !(COBEVT_STEM_KNOCK & 1)) fetch((i + RS - 1) % RS, i + RS - 1);
+            if constexpr (COBEVT_STEM_KNOCK & 2) asm volatile("" :: "v"(rb[i % RS].x), "v"(rb[i % RS].y), "v"(rb[i % RS].z), "v"(rb[i % RS].w), "v"(ra[i % RS].x), "v"(ra[i % RS].y), "v"(ra[i % RS].z), "v"(ra[i % RS].w));
+            else
+            mfma_kgroup<T>(rb[i % RS], ra[i % RS], acc);      // D = W . X^T: lane <-> pixel, registers <-> couts
             __builtin_amdgcn_sched_barrier(0);
         }
         COBEVT_ST_MARK(3);
         // ---- bias + ReLU, rounded to T, staged [region pixel][64]; conv pixels outside the map -> 0
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (t == 1 && !two) break;
-            const int pr = rpix[t];
-            if (pr >= RPIX) continue;
-            const int ry = pr / RW, rx = pr - ry * RW;
+        if (rpix < RPIX && !(COBEVT_STEM_KNOCK & 16)) {
             const int oy = oy0 + ry, ox = ox0 + rx;
             const bool inside = oy >= 0 && oy < p.Ho && ox >= 0 && ox < p.Wo;
+            float4 bq[4];                                     // the four reads in flight together (one LDS round trip, not four)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bq[k] = *(const float4*)(bias_l + chalf * 32 + 8 * k + 4 * h);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int c0 = chalf[t] * 32 + 8 * k + 4 * h;
-                const float4 b = *(const float4*)(bias_l + c0);
-                float v[4] = {acc[t][4 * k] + b.x, acc[t][4 * k + 1] + b.y, acc[t][4 * k + 2] + b.z, acc[t][4 * k + 3] + b.w};
+                const int c0 = chalf * 32 + 8 * k + 4 * h;
+                const float4 b = bq[k];
+                float v[4] = {acc[4 * k] + b.x, acc[4 * k + 1] + b.y, acc[4 * k + 2] + b.z, acc[4 * k + 3] + b.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = inside ? fmaxf(v[e], 0.f) : 0.f;
-                unsigned char* d = stage + pr * C::SROW + c0 * Elem<T>::kBytes;
+                unsigned char* d = stage + rpix * C::SROW + c0 * Elem<T>::kBytes;
                 if constexpr (Elem<T>::kIsBf16) *(uint2*)d = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                 else *(float4*)d = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -395,33 +466,41 @@ __global__ __launch_bounds__(kStemPoolThreads, 4) void stem_pool_kernel(StemPara
         COBEVT_ST_MARK(4);
         __syncthreads();      // staging complete; every wave is done with the patch
         COBEVT_ST_MARK(5);
-        // ---- 3 x 3 / stride 2 maxima: pooled pixel (qy, qx) of the 4 x 8 tile covers region rows 2qy..2qy+2, cols 2qx..2qx+2
-        constexpr int CH = Elem<T>::kChunk;
-        constexpr int CPP = 64 / CH;
-        T* out = (T*)p.out;
-        for (int item = tid; item < 32 * CPP; item += NT) {
-            const int q = item / CPP, cj = item - q * CPP;
-            const int qy = q >> 3, qx = q & 7;
+        // ---- 3 x 3 / stride 2 maxima: pooled pixel (qy, qx) of the ROWS x 8 tile covers region rows 2qy..2qy+2, cols 2qx..2qx+2
+        pend_dst = nullptr;
+        if (tid < C::ROWS * 8 * CPP) {
+            const int q = tid / CPP, cj = tid - q * CPP;
+            // 16 lanes (one ds_read_b128 pass) = two pooled pixels: columns qx and qx + 4 are 8 * 144 B = 32 banks apart in the
+            // staging rows (bf16), neighbours only 8 banks - a 2-way conflict on every read of the phase
+            const int qy = q >> 3, qx = ((q & 7) >> 1) | ((q & 1) << 2);
             const int py = py0 + qy, px = px0 + qx;
-            if (py >= Hp || px >= Wp) continue;
-            float m[8];
-#pragma unroll
-            for (int e = 0; e < CH; ++e) m[e] = 0.f;
+            // the nine window reads are issued together (one LDS round trip; value by value the compiler waited after each)
+            uint4 wv[9];
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    float v[8];
-                    chunk_to_f32<T>(*(const uint4*)(stage + ((2 * qy + dy) * RW + 2 * qx + dx) * C::SROW + cj * 16), v);
-#pragma unroll
-                    for (int e = 0; e < CH; ++e) m[e] = fmaxf(m[e], v[e]);
+                    wv[dy * 3 + dx] = *(const uint4*)(stage + ((2 * qy + dy) * RW + 2 * qx + dx) * C::SROW + cj * 16);
+                    if constexpr (COBEVT_STEM_KNOCK & 4) wv[dy * 3 + dx] = make_uint4(dy, dx, dy, dx);
                 }
-            *(uint4*)(out + (((size_t)img * Hp + py) * Wp + px) * 64 + cj * CH) = f32_to_chunk<T>(m);
+            __builtin_amdgcn_sched_barrier(0);
+            // staged values are >= +0 after the ReLU (or the -0 a ReLU of -0 may leave): as SIGNED integers their bit patterns
+            // order like the values and -0 sorts below +0, so the maximum runs on the raw words - packed 16-bit for bf16 -
+            // starting from +0 exactly like the float maximum it replaces
+            uint4 m = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                m.x = word_max<T>(m.x, wv[i].x); m.y = word_max<T>(m.y, wv[i].y);
+                m.z = word_max<T>(m.z, wv[i].z); m.w = word_max<T>(m.w, wv[i].w);
+            }
+            pend = m;
+            if (py < Hp && px < Wp) pend_dst = (T*)p.out + (((size_t)img * Hp + py) * Wp + px) * 64 + cj * CH;
         }
         COBEVT_ST_MARK(6);
         __syncthreads();
         COBEVT_ST_MARK(7);
     }
+    if (pend_dst) *(uint4*)pend_dst = pend;
 }
 
 }  // namespace cobevt
@@ -471,7 +550,8 @@ extern "C" int cobevt_stem_conv7x7s2_pool(const float* in, const void* wgt, cons
     if (dtype != 0 && dtype != 1) return COBEVT_ERR_ARG;
     if (p.N < 1 || p.H < 4 || p.W < 4 || (p.H & 3) || (p.W & 3)) return COBEVT_ERR_SHAPE;
     p.Ho = p.H / 2; p.Wo = p.W / 2;
-    p.tiles_y = (p.Ho / 2 + 3) / 4; p.tiles_x = (p.Wo / 2 + 7) / 8; p.tiles_n = 1;
+    const int rows = dtype == 0 ? StemPoolCfg<bf16_t>::ROWS : StemPoolCfg<float>::ROWS;
+    p.tiles_y = (p.Ho / 2 + rows - 1) / rows; p.tiles_x = (p.Wo / 2 + 7) / 8; p.tiles_n = 1;
     const long nt = (long)p.N * p.tiles_y * p.tiles_x;
     if (nt > 0x7fffffffL) return COBEVT_ERR_SHAPE;
     p.ntiles = (int)nt;
@@ -484,8 +564,8 @@ extern "C" int cobevt_stem_conv7x7s2_pool(const float* in, const void* wgt, cons
     }
     const int per_cu = dtype == 0 ? 2 : 1;
     const unsigned blocks = (unsigned)(nt < 256L * per_cu ? nt : 256L * per_cu);
-    if (dtype == 0) hipLaunchKernelGGL(stem_pool_kernel<bf16_t>, dim3(blocks), dim3(kStemPoolThreads), lds, stream, p);
-    else hipLaunchKernelGGL(stem_pool_kernel<float>, dim3(blocks), dim3(kStemPoolThreads), lds, stream, p);
+    if (dtype == 0) hipLaunchKernelGGL(stem_pool_kernel<bf16_t>, dim3(blocks), dim3(StemPoolCfg<bf16_t>::NT), lds, stream, p);
+    else hipLaunchKernelGGL(stem_pool_kernel<float>, dim3(blocks), dim3(StemPoolCfg<float>::NT), lds, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
