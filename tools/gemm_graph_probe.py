@@ -20,10 +20,11 @@ class LN(object):
 
 
 if __name__ == "__main__":
-    for (m, k, n, ln, res) in [(5120, 128, 128, True, False), (5120, 128, 384, True, False), (5120, 128, 256, True, False),
+    shapes = os.environ.get("GEMM_SHAPES")    # "m,k,n,ln;..."
+    for (m, k, n, ln, res) in ([tuple(int(v) for v in t.split(",")) + (False,) for t in shapes.split(";")] if shapes else [(5120, 128, 128, True, False), (5120, 128, 384, True, False), (5120, 128, 256, True, False),
                                (5120, 512, 128, False, False), (20480, 128, 128, True, False), (20480, 256, 128, False, False),
                                (81920, 128, 128, False, False), (81920, 128, 256, True, False), (327680, 128, 128, True, False),
-                               (1024, 128, 128, False, False)]:
+                               (1024, 128, 128, False, False)]):
         plan = ops.ConvPlan(torch.randn(n, k) / k ** 0.5, torch.zeros(n), dtype=dtype, device=dev, ln=LN(k) if ln else None)
         x = torch.randn(m, k, device=dev).to(dtype)
         out = torch.empty(m, n, device=dev, dtype=dtype)
