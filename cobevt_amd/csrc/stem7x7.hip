@@ -581,7 +581,11 @@ extern "C" int cobevt_stem_conv7x7s2_pool(const float* in, const void* wgt, cons
         (void)hipFuncSetAttribute((const void*)stem_pool_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StemPoolCfg<float>::LDS);
         attr_set = true;
     }
-    const int per_cu = dtype == 0 ? 2 : 1;
+    // persistent grid: as many workgroups per CU as LDS and the 32-wave limit admit (bf16 2, fp32 1)
+    const int nthreads = dtype == 0 ? StemPoolCfg<bf16_t>::NT : StemPoolCfg<float>::NT;
+    int per_cu = (int)(163840 / lds);
+    if (per_cu > 2048 / nthreads) per_cu = 2048 / nthreads;
+    if (per_cu < 1) per_cu = 1;
     const unsigned blocks = (unsigned)(nt < 256L * per_cu ? nt : 256L * per_cu);
     if (dtype == 0) hipLaunchKernelGGL(stem_pool_kernel<bf16_t>, dim3(blocks), dim3(StemPoolCfg<bf16_t>::NT), lds, stream, p);
     else hipLaunchKernelGGL(stem_pool_kernel<float>, dim3(blocks), dim3(StemPoolCfg<float>::NT), lds, stream, p);
