@@ -4,8 +4,9 @@ The reference trains through torch autograd (opv2v/opencood/tools/train_camera.p
 optimizer.step()).  Here the attention core (gathered window / dilated-grid partition, relative-position bias, key mask,
 softmax, PV, partition reverse), LayerNorm and GELU run as HIP kernels in both directions (fp32 storage, exact-fp32 MFMA:
 csrc/attention.hip + attention_bwd.hip, csrc/elementwise.hip + train_rows.hip); the dense projections are plain GEMMs and go
-to the library (rocBLAS through torch.matmul) in both directions.  fp32 only: the bf16 inference layouts (fragment-ordered
-weights, folded norms) are not differentiable containers.
+to the library (rocBLAS through torch.matmul) in both directions.  The kernels of this slice compute in fp32 (the bf16 inference
+layouts - fragment-ordered weights, folded norms - are not differentiable containers); under torch autocast their inputs are cast
+to fp32 at the Function boundary (see _amp_fwd).
 
 No CPU path: every Function raises on CPU tensors (lib.CobevtHipError) like the inference ops do.
 """
@@ -18,6 +19,13 @@ from . import ops
 from .lib import CobevtHipError
 
 _p, _stream, _ints, _need_cuda = ops._p, ops._stream, ops._ints, ops._need_cuda
+
+# Mixed precision (train_camera.py:123-124,157-160,174-177: `--half` = torch.cuda.amp.autocast + GradScaler): inside an autocast
+# region every Function below receives its floating-point inputs cast to fp32 and runs with autocast off - the HIP kernels of
+# the training slice compute in fp32, i.e. at or above the precision autocast would have picked - while the torch ops between
+# them (the projections, batch norm, the warps) follow the autocast dtype; GradScaler sees ordinary fp32 parameter gradients.
+_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
 
 
 def _f32c(t, what):
@@ -47,6 +55,7 @@ class WindowAttentionFn(torch.autograd.Function):
     drop_p, drop_seed): drop_p > 0 = dropout on the probabilities with the keep mask hashed from drop_seed."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, q, k, v, bias_table, mask, cfg):
         qmap, kmap, omap, batch, heads, scale, bias_L, out_rows, drop_p, drop_seed = cfg
         _need_cuda(q, k, v, bias_table, mask)
@@ -69,6 +78,7 @@ class WindowAttentionFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, dout):
         q, k, v, out, lse, table, mk = ctx.saved_tensors
         qmap, kmap, omap, batch, heads, scale, bias_L, _, drop_p, drop_seed = ctx.cfg
@@ -117,6 +127,7 @@ class LayerNormFn(torch.autograd.Function):
     """nn.LayerNorm over the last dimension: cobevt_layernorm forward, cobevt_layernorm_bwd backward."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, gamma, beta, eps):
         x = _f32c(x, "layernorm input")
         g, b = _f32c(gamma, "gamma"), _f32c(beta, "beta")
@@ -126,6 +137,7 @@ class LayerNormFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, dy):
         x, g = ctx.saved_tensors
         dy = _f32c(dy, "dy")
@@ -149,6 +161,7 @@ class GeluFn(torch.autograd.Function):
     """nn.GELU() (exact erf form): cobevt_gelu in both directions."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x):
         x = _f32c(x, "gelu input")
         _need_cuda(x)
@@ -159,6 +172,7 @@ class GeluFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         dy = _f32c(dy, "dy")
@@ -235,6 +249,7 @@ class Conv2dFn(torch.autograd.Function):
     cobevt_conv_wgrad (csrc/train_rows.hip: a GEMM over the pixels on the fp32 matrix path, operands straight from global memory)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, weight, bias, stride, pad):
         _need_cuda(x, weight, bias)
         if x.dtype != torch.float32 or weight.dtype != torch.float32:
@@ -249,6 +264,7 @@ class Conv2dFn(torch.autograd.Function):
         return out.permute(0, 3, 1, 2)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, dy):
         xl, weight = ctx.saved_tensors
         stride, pad, has_bias = ctx.cfg
@@ -287,6 +303,7 @@ class WeightedCrossEntropyFn(torch.autograd.Function):
     and backward (cobevt_weighted_cross_entropy_bwd): vanilla_seg_loss.py:18-23,58-70 under train_camera.py:166-173."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, logits, target, weight):
         if logits.dtype != torch.float32:
             raise CobevtHipError("the training slice is fp32")
@@ -295,6 +312,7 @@ class WeightedCrossEntropyFn(torch.autograd.Function):
         return loss.clone()
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, dloss):
         x, y, wt, stats = ctx.saved_tensors
         n, c, h, w = x.shape

@@ -25,7 +25,8 @@ def _check(*tensors):
             continue
         if not t.is_cuda:
             raise CobevtHipError("training forward needs ROCm device tensors; the HIP path has no CPU fallback")
-        if t.dtype != torch.float32:
+        # inside an autocast region the torch ops between the HIP Functions produce half tensors; the Functions cast them back
+        if t.dtype != torch.float32 and not (torch.is_autocast_enabled() and t.dtype in (torch.float16, torch.bfloat16)):
             raise CobevtHipError("the training slice is fp32 (got %s)" % t.dtype)
 
 
@@ -346,7 +347,14 @@ def _warp_affine(src, M, dsize):
 
 
 def sttf_warp(x, tm, discrete_ratio, downsample_rate):
-    """STTF.forward (corpbevt.py:28-64): x (B, L, C, H, W) -> (B, L, H, W, C) in the ego frame, differentiable in x"""
+    """STTF.forward (corpbevt.py:28-64): x (B, L, C, H, W) -> (B, L, H, W, C) in the ego frame, differentiable in x.
+    The pose algebra (3x3 products and inverses) and the sampling stay in fp32 inside an autocast region: the reference needs an
+    fp16-safe inverse and a `.half()` hack here (torch_transformation_utils.py:137-157,354); fp32 is the simpler equivalent"""
+    with torch.autocast("cuda", enabled=False):
+        return _sttf_warp_f32(x.float(), tm, discrete_ratio, downsample_rate)
+
+
+def _sttf_warp_f32(x, tm, discrete_ratio, downsample_rate):
     m = tm[:, :, [0, 1], :][:, :, :, [0, 1, 3]].to(torch.float32).clone()          # :108-134
     m[..., -1] = m[..., -1] / (discrete_ratio * downsample_rate)
     x = x.permute(0, 1, 2, 4, 3).flip(4)
@@ -374,7 +382,7 @@ def fuse_and_decode(model, f, transformation_matrix, record_len):
     # the ROI / agent mask carries no gradient: the inference kernel computes it
     rl = torch.as_tensor(record_len).to(device=dev, dtype=torch.int32)
     with torch.no_grad():
-        _, com_mask, cav_mask = ops.sttf_warp(f.detach().permute(0, 2, 3, 1).contiguous(), tm.contiguous(), None, model.discrete_ratio,
+        _, com_mask, cav_mask = ops.sttf_warp(f.detach().float().permute(0, 2, 3, 1).contiguous(), tm.contiguous(), None, model.discrete_ratio,
                                               model.downsample_rate, want_mask=model.use_roi_mask, record_len=rl,
                                               max_cav=model.max_cav)
         if not model.use_roi_mask:

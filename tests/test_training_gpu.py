@@ -385,6 +385,62 @@ def test_corpbevt_optimizer_steps(cuda):
     assert torch.isfinite(y).all()
 
 
+def test_corpbevt_mixed_precision_step_with_grad_scaler(cuda):
+    """train_camera.py:123-124,157-160,174-177 (`--half`): forward under torch autocast, GradScaler around backward / step.  The HIP
+    Functions take their inputs as fp32 inside the region (autograd._amp_fwd), the torch ops in between run in half: the loss and
+    every parameter gradient stay close to the fp32 run, the scaler unscales to fp32 gradients, steps, and skips a step whose
+    gradients overflow"""
+    import copy
+    cfg = synth.corpbevt_small_config()
+    cfg["fax"]["self_attn"]["dropout"] = 0.0
+    cfg["fax_fusion"]["drop_out"] = 0.0
+    m = _freeze_bn(_train_module(host.CorpBEVT(copy.deepcopy(cfg)), cuda))
+    batch = {k: v.to(cuda) for k, v in synth.opv2v_batch(agents=2, cams=2, image=128, max_cav=3, seed=5).items()}
+    gt = None
+
+    def loss_of(amp_dtype):
+        nonlocal gt
+        with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
+            logits = m(dict(batch))["dynamic_seg"][:, 0]
+            if gt is None:
+                gt = (synth.procedural_input("amp.gt", (logits.shape[0],) + tuple(logits.shape[2:]), cases.SEED) > 0.3).long().to(cuda)
+            return torch.nn.functional.cross_entropy(logits.float(), gt)
+
+    with torch.enable_grad():
+        m.zero_grad()
+        ref_loss = loss_of(None)
+        ref_loss.backward()
+        ref = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        for amp_dtype in (torch.float16, torch.bfloat16):
+            m.zero_grad()
+            scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+            loss = loss_of(amp_dtype)
+            scaler.scale(loss).backward()
+            assert abs(float(loss.detach()) - float(ref_loss.detach())) < 2e-2 * abs(float(ref_loss.detach())), (float(loss.detach()), float(ref_loss.detach()))
+            opt = torch.optim.SGD(m.parameters(), lr=0.0)
+            scaler.unscale_(opt)
+            worst = 0.0
+            for n, p in m.named_parameters():
+                if n in ref:
+                    assert p.grad is not None and p.grad.dtype == torch.float32, n
+                    scale = float(ref[n].abs().max())
+                    if scale > 1e-3 * max(float(r.abs().max()) for r in ref.values()):
+                        worst = max(worst, float((p.grad - ref[n]).abs().max()) / scale)
+            # worst parameter, max-norm relative: the half-precision projections in between carry 11 (fp16) / 8 (bf16) mantissa bits
+            assert worst < (8e-2 if amp_dtype == torch.float16 else 2.5e-1), "%s autocast gradients differ from the fp32 run: %.3g" % (amp_dtype, worst)
+        # an overflowing gradient: the step is skipped and the scale backs off
+        before = [p.detach().clone() for p in m.parameters()]
+        opt = torch.optim.SGD(m.parameters(), lr=1.0)
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+        m.zero_grad()
+        scaler.scale(loss_of(torch.float16)).backward()
+        next(iter(m.parameters())).grad.view(-1)[0] = float("inf")
+        scaler.step(opt)
+        scaler.update()
+        assert scaler.get_scale() == 512.0
+        assert all(torch.equal(a, b) for a, b in zip(before, m.parameters()))
+
+
 def test_attention_probability_dropout(cuda):
     """nn.Dropout on the attention probabilities (FAX global attention in train mode, fax_modules.py:114,161) inside the kernels: the
     keep mask is a counter-based hash, dumped by the test hook; forward and all gradients must equal dense torch attention with
