@@ -52,12 +52,13 @@ class WindowAttentionFn(torch.autograd.Function):
     """out = softmax(scale q k^T + bias[rel(q, k)] + mask) v over the gathered windows (cobevt_window_attention_lse /
     cobevt_window_attention_bwd).  q (Rq, d), k, v (Rk, d) token matrices (views with a row stride are accepted), bias_table
     (rows, heads) | None, mask fp32 | None (no gradient).  cfg = (qmap, kmap, omap, batch, heads, scale, bias_L, out_rows,
-    drop_p, drop_seed): drop_p > 0 = dropout on the probabilities with the keep mask hashed from drop_seed."""
+    drop_p, drop_seed, seed_dev): drop_p > 0 = dropout on the probabilities with the keep mask hashed from drop_seed (+ the device
+    word seed_dev, see dropout_step)."""
 
     @staticmethod
     @_amp_fwd
     def forward(ctx, q, k, v, bias_table, mask, cfg):
-        qmap, kmap, omap, batch, heads, scale, bias_L, out_rows, drop_p, drop_seed = cfg
+        qmap, kmap, omap, batch, heads, scale, bias_L, out_rows, drop_p, drop_seed, seed_dev = cfg
         _need_cuda(q, k, v, bias_table, mask)
         ldq, ldk, ldv = _rows_view(q, "q"), _rows_view(k, "k"), _rows_view(v, "v")
         d = heads * 32
@@ -71,7 +72,8 @@ class WindowAttentionFn(torch.autograd.Function):
         lse = torch.empty((batch, L, heads, nq), device=q.device, dtype=torch.float32)
         dims = _attn_dims(batch, heads, ldq, ldk, ldv, d, table, bias_L, qmap, kmap, omap)
         rc = _L.load().cobevt_window_attention_lse(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(table), _p(mk), dims,
-                                                   ctypes.c_float(scale), ctypes.c_float(drop_p), ctypes.c_uint(drop_seed), _stream())
+                                                   ctypes.c_float(scale), ctypes.c_float(drop_p), ctypes.c_uint(drop_seed), _p(seed_dev),
+                                                   _stream())
         _L.check(rc, "cobevt_window_attention_lse")
         ctx.save_for_backward(q, k, v, out, lse, table, mk)
         ctx.cfg = cfg
@@ -81,7 +83,7 @@ class WindowAttentionFn(torch.autograd.Function):
     @_amp_bwd
     def backward(ctx, dout):
         q, k, v, out, lse, table, mk = ctx.saved_tensors
-        qmap, kmap, omap, batch, heads, scale, bias_L, _, drop_p, drop_seed = ctx.cfg
+        qmap, kmap, omap, batch, heads, scale, bias_L, _, drop_p, drop_seed, seed_dev = ctx.cfg
         d = heads * 32
         dout = _f32c(dout, "dout")
         # dq is accumulated with atomics by the key tiles of a window; dk / dv rows are written once each
@@ -97,19 +99,35 @@ class WindowAttentionFn(torch.autograd.Function):
             dims = _attn_dims(batch, heads, d, d, d, d, table, bias_L, qmap, kmap, omap)
         rc = _L.load().cobevt_window_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), _p(dq), _p(dk), _p(dv),
                                                    _p(dbias), _p(table), _p(mk), dims, ctypes.c_float(scale), ctypes.c_float(drop_p),
-                                                   ctypes.c_uint(drop_seed), _stream())
+                                                   ctypes.c_uint(drop_seed), _p(seed_dev), _stream())
         _L.check(rc, "cobevt_window_attention_bwd")
         return dq, dk, dv, dbias, None, None
 
 
+_DROPOUT_STEP = {}
+
+
+def dropout_step(device):
+    """The per-device int32 word the attention-probability dropout adds to its seed.  Eager training does not need it (a fresh host
+    seed is drawn per call); a training step replayed from a captured HIP graph does `dropout_step(dev).add_(1)` INSIDE the graph,
+    because the host seeds are frozen into the graph's kernel nodes at capture (tools/train_graph_probe.py)."""
+    key = str(torch.device(device))
+    if key not in _DROPOUT_STEP:
+        _DROPOUT_STEP[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _DROPOUT_STEP[key]
+
+
 def window_attention(q, k, v, qmap, kmap, omap, batch, heads, scale, out_rows, bias_table=None, bias_L=1, mask=None, drop_p=0.0,
                      drop_seed=None):
-    """drop_p > 0: dropout on the attention probabilities; drop_seed None draws one from torch's CPU generator (so
-    torch.manual_seed makes a run repeatable, and no device round trip is needed)"""
+    """drop_p > 0: dropout on the attention probabilities.  drop_seed None draws a host seed from torch's CPU generator (so
+    torch.manual_seed makes a run repeatable, and no device round trip is needed) and adds the device word dropout_step();
+    an explicit drop_seed is used as it is (tests: attention_dropout_mask reproduces the mask)"""
+    seed_dev = None
     if drop_p > 0 and drop_seed is None:
         drop_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        seed_dev = dropout_step(q.device)
     cfg = (tuple(qmap), tuple(kmap), tuple(omap), int(batch), int(heads), float(scale), int(bias_L), int(out_rows),
-           float(drop_p), int(drop_seed or 0))
+           float(drop_p), int(drop_seed or 0), seed_dev)
     return WindowAttentionFn.apply(q, k, v, bias_table, mask, cfg)
 
 

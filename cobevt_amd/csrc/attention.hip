@@ -425,7 +425,7 @@ using namespace cobevt;
 // C-ABI entry point, see include/cobevt_hip.h
 static int window_attention_impl(const void* q, const void* k, const void* v, void* out, float* lse,
                                  const float* bias_table, const float* mask, const int* dims, float scale,
-                                 float drop_p, unsigned drop_seed, hipStream_t stream) {
+                                 float drop_p, unsigned drop_seed, const unsigned* drop_seed_dev, hipStream_t stream) {
     // dims: [dtype, B, L, heads, ldq, ldk, ldv, ldo, qoff, koff, voff, ooff, bias_mode, bias_rows, bias_L,
     //        mean_q, qmap[8], kmap[8], omap[8]]
     if (!q || !k || !v || !out || !dims) return COBEVT_ERR_ARG;
@@ -441,7 +441,7 @@ static int window_attention_impl(const void* q, const void* k, const void* v, vo
     p.mean_q = dims[15];
     p.qmap = read_map(dims + 16); p.kmap = read_map(dims + 24); p.omap = read_map(dims + 32);
     p.bias_table = bias_table; p.mask = mask; p.scale = scale; p.lse = lse;
-    p.drop_p = drop_p; p.drop_seed = drop_seed;
+    p.drop_p = drop_p; p.drop_seed = drop_seed; p.drop_seed_dev = drop_seed_dev;
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (!lse || dtype != 1))) return COBEVT_ERR_ARG;   // dropout: training forward only
     if (dtype != 0 && dtype != 1) return COBEVT_ERR_ARG;
     if (!map_ok(p.qmap) || !map_ok(p.kmap) || !map_ok(p.omap)) return COBEVT_ERR_SHAPE;
@@ -505,14 +505,14 @@ static int window_attention_impl(const void* q, const void* k, const void* v, vo
 extern "C" int cobevt_window_attention(const void* q, const void* k, const void* v, void* out,
                                        const float* bias_table, const float* mask, const int* dims, float scale,
                                        hipStream_t stream) {
-    return window_attention_impl(q, k, v, out, nullptr, bias_table, mask, dims, scale, 0.f, 0u, stream);
+    return window_attention_impl(q, k, v, out, nullptr, bias_table, mask, dims, scale, 0.f, 0u, nullptr, stream);
 }
 
 extern "C" int cobevt_window_attention_lse(const void* q, const void* k, const void* v, void* out, float* lse,
                                            const float* bias_table, const float* mask, const int* dims, float scale,
-                                           float drop_p, unsigned drop_seed, hipStream_t stream) {
+                                           float drop_p, unsigned drop_seed, const unsigned* drop_seed_dev, hipStream_t stream) {
     if (!lse) return COBEVT_ERR_ARG;
-    return window_attention_impl(q, k, v, out, lse, bias_table, mask, dims, scale, drop_p, drop_seed, stream);
+    return window_attention_impl(q, k, v, out, lse, bias_table, mask, dims, scale, drop_p, drop_seed, drop_seed_dev, stream);
 }
 
 // Test hook: the keep mask of the probability dropout exactly as the training kernels regenerate it

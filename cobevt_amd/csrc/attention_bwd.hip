@@ -345,7 +345,7 @@ using namespace cobevt;
 extern "C" int cobevt_window_attention_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
                                            const void* dout, void* dq, void* dk, void* dv, float* dbias,
                                            const float* bias_table, const float* mask, const int* dims, float scale,
-                                           float drop_p, unsigned drop_seed, hipStream_t stream) {
+                                           float drop_p, unsigned drop_seed, const unsigned* drop_seed_dev, hipStream_t stream) {
     if (!q || !k || !v || !out || !lse || !dout || !dq || !dk || !dv || !dims) return COBEVT_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f) return COBEVT_ERR_ARG;
     AttnBwdParams bp;
@@ -360,7 +360,7 @@ extern "C" int cobevt_window_attention_bwd(const void* q, const void* k, const v
     p.mean_q = dims[15];
     p.qmap = read_map(dims + 16); p.kmap = read_map(dims + 24); p.omap = read_map(dims + 32);
     p.bias_table = bias_table; p.mask = mask; p.scale = scale; p.lse = const_cast<float*>(lse); p.klinear = 0;
-    p.drop_p = drop_p; p.drop_seed = drop_seed;
+    p.drop_p = drop_p; p.drop_seed = drop_seed; p.drop_seed_dev = drop_seed_dev;
     bp.dout = (const float*)dout; bp.dq = (float*)dq; bp.dk = (float*)dk; bp.dv = (float*)dv; bp.dbias = dbias;
     if (!map_ok(p.qmap) || !map_ok(p.kmap) || !map_ok(p.omap)) return COBEVT_ERR_SHAPE;
     if (p.B < 1 || p.heads < 1 || p.L != p.qmap.X * p.qmap.Y || p.L != p.kmap.X * p.kmap.Y) return COBEVT_ERR_SHAPE;

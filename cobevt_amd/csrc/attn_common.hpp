@@ -76,6 +76,9 @@ struct AttnParams {
     // counter-based hash of (drop_seed, element index), so the backward kernels regenerate the forward's mask
     float drop_p;
     unsigned drop_seed;
+    // nullable device word ADDED to drop_seed: a captured training step (tools/train_graph_probe.py) bumps it inside the graph, so every
+    // replay draws a new mask although the kernel arguments are frozen in the graph's nodes
+    const unsigned* drop_seed_dev;
 };
 
 __host__ __device__ __forceinline__ unsigned attn_mix32(unsigned x) {       // murmur3 finaliser
@@ -85,7 +88,8 @@ __host__ __device__ __forceinline__ unsigned attn_mix32(unsigned x) {       // m
 // keep decision of probability element (tq, tk) of (b, l, head): uniform 32-bit hash >= p * 2^32
 __device__ __forceinline__ bool attn_keep(const AttnParams& p, int b, int l, int head, int tq, int tk) {
     const unsigned long long row = ((unsigned long long)((b * p.L + l) * p.heads + head)) * (unsigned)p.Nq + (unsigned)tq;
-    const unsigned hrow = attn_mix32((unsigned)row ^ attn_mix32((unsigned)(row >> 32) ^ p.drop_seed));
+    const unsigned seed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);       // uniform scalar load
+    const unsigned hrow = attn_mix32((unsigned)row ^ attn_mix32((unsigned)(row >> 32) ^ seed));
     const unsigned u = attn_mix32(hrow ^ ((unsigned)tk * 0x9e3779b1u));
     return (float)u * 2.3283064365386963e-10f >= p.drop_p;
 }

@@ -279,7 +279,8 @@ def fax_module(m, batch):
     """FAXModule.forward (fax_modules.py:497-521): batch['features'] list of (b, l, n, C, h, w) -> (b, l, d, H, W)"""
     feats = batch["features"]
     b, l, n = feats[0].shape[:3]
-    I_inv = torch.linalg.inv(batch["intrinsic"].reshape(b * l, n, 3, 3).to(torch.float32))
+    # (no gradient flows into the camera matrices; the device kernel has no host round trip, unlike torch.linalg.inv's error check)
+    I_inv = ops.invert_small(batch["intrinsic"].reshape(b * l * n, 3, 3).to(torch.float32)).reshape(b * l, n, 3, 3)
     E_inv = m._extrinsic(batch["extrinsic"].reshape(b * l, n, 4, 4).to(torch.float32))
     prior = m.bev_embedding.get_prior()
     x = prior[None].expand(b * l, *prior.shape)
@@ -334,14 +335,20 @@ def _warp_affine(src, M, dsize):
     align_corners=True; src (N, C, H, W), M (N, 2, 3) destination-from-source in pixels"""
     N, C, H, W = src.shape
 
+    # small constant matrices are built with fills on the device and inverted by the device kernel: no host -> device copies and no
+    # host-side error check, so the whole warp can sit inside a captured training step (tools/train_graph_probe.py)
     def norm_px(h, w):
-        t = torch.tensor([[1.0, 0.0, -1.0], [0.0, 1.0, -1.0], [0.0, 0.0, 1.0]], dtype=M.dtype, device=M.device)
-        t[0, 0] = t[0, 0] * 2.0 / (1e-14 if w == 1 else w - 1.0)
-        t[1, 1] = t[1, 1] * 2.0 / (1e-14 if h == 1 else h - 1.0)
+        t = torch.eye(3, dtype=M.dtype, device=M.device)          # (`t[i, j] = python_float` would be a host -> device copy)
+        t[0, 0].fill_(2.0 / (1e-14 if w == 1 else w - 1.0))
+        t[1, 1].fill_(2.0 / (1e-14 if h == 1 else h - 1.0))
+        t[0, 2].fill_(-1.0)
+        t[1, 2].fill_(-1.0)
         return t[None]
     M3 = _F.pad(M, [0, 0, 0, 1], "constant", value=0.0)
     M3[..., -1, -1] += 1.0
-    theta = torch.linalg.inv(norm_px(dsize[0], dsize[1]) @ (M3 @ torch.linalg.inv(norm_px(H, W))))[:, :2, :]
+    with torch.no_grad():
+        prod = norm_px(dsize[0], dsize[1]) @ (M3 @ ops.invert_small(norm_px(H, W)))
+        theta = ops.invert_small(prod.contiguous())[:, :2, :]
     grid = _F.affine_grid(theta, [N, C, dsize[0], dsize[1]], align_corners=True)
     return _F.grid_sample(src, grid, align_corners=True, mode="bilinear", padding_mode="zeros")
 
@@ -355,16 +362,17 @@ def sttf_warp(x, tm, discrete_ratio, downsample_rate):
 
 
 def _sttf_warp_f32(x, tm, discrete_ratio, downsample_rate):
-    m = tm[:, :, [0, 1], :][:, :, :, [0, 1, 3]].to(torch.float32).clone()          # :108-134
+    m = torch.cat([tm[:, :, 0:2, 0:2], tm[:, :, 0:2, 3:4]], -1).to(torch.float32)     # rows 0-1, columns 0, 1, 3 (:108-134); slices, not index lists: no host -> device copy
     m[..., -1] = m[..., -1] / (discrete_ratio * downsample_rate)
     x = x.permute(0, 1, 2, 4, 3).flip(4)
     B, L, C, H, W = x.shape
     M = m.reshape(-1, 2, 3)
     eye = torch.eye(3, dtype=M.dtype, device=M.device)[None].repeat(M.shape[0], 1, 1)      # :254-297
     shift, shift_inv, rot = eye.clone(), eye.clone(), eye.clone()
-    center = torch.tensor([W / 2, H / 2], dtype=M.dtype, device=M.device)
-    shift[:, :2, 2] = center
-    shift_inv[:, :2, 2] = -center
+    shift[:, 0, 2].fill_(W / 2)
+    shift[:, 1, 2].fill_(H / 2)
+    shift_inv[:, 0, 2].fill_(-(W / 2))
+    shift_inv[:, 1, 2].fill_(-(H / 2))
     rot[:, :2, :2] = M[:, :2, :2]
     T = (shift @ rot @ shift_inv)[:, :2, :].clone()
     T[..., 2] += M[..., 2]
@@ -372,13 +380,15 @@ def _sttf_warp_f32(x, tm, discrete_ratio, downsample_rate):
     return y.flip(4).permute(0, 1, 4, 3, 2)
 
 
-def fuse_and_decode(model, f, transformation_matrix, record_len):
-    """the cross-agent part of CorpBEVT.forward (corpbevt.py:119-145): f (N, C, H, W) per-agent BEV features"""
+def fuse_and_decode(model, f, transformation_matrix, record_len, record_len_host=None):
+    """the cross-agent part of CorpBEVT.forward (corpbevt.py:119-145): f (N, C, H, W) per-agent BEV features.  record_len_host:
+    the agent counts as Python ints when record_len lives on the device (a captured training step cannot read it back)"""
     if model.compression:
         raise CobevtHipError("CorpBEVT train(): the NaiveCompressor branch has no training forward")
     dev = f.device
     tm = transformation_matrix.to(device=dev, dtype=torch.float32)
-    w = sttf_warp(_regroup(f, record_len, model.max_cav), tm, model.discrete_ratio, model.downsample_rate)   # b l h w c
+    lens = record_len if record_len_host is None else record_len_host
+    w = sttf_warp(_regroup(f, lens, model.max_cav), tm, model.discrete_ratio, model.downsample_rate)   # b l h w c
     # the ROI / agent mask carries no gradient: the inference kernel computes it
     rl = torch.as_tensor(record_len).to(device=dev, dtype=torch.int32)
     with torch.no_grad():
@@ -398,4 +408,4 @@ def corpbevt(model, batch_dict):
     feats = resnet_encoder(model.encoder, batch_dict["inputs"])
     batch_dict.update({"features": feats})
     f = fax_module(model.fax, batch_dict).squeeze(1)
-    return fuse_and_decode(model, f, batch_dict["transformation_matrix"], batch_dict["record_len"])
+    return fuse_and_decode(model, f, batch_dict["transformation_matrix"], batch_dict["record_len"], batch_dict.get("record_len_host"))

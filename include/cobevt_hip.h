@@ -180,15 +180,17 @@ int cobevt_window_attention(const void* q, const void* k, const void* v, void* o
  * (train_camera.py:143-179 loss.backward()). */
 int cobevt_window_attention_lse(const void* q, const void* k, const void* v, void* out, float* lse, const float* bias_table,
                                 const float* mask, const int* dims, float scale, float drop_p, unsigned drop_seed,
-                                hipStream_t stream);
+                                const unsigned* drop_seed_dev, hipStream_t stream);
 int cobevt_window_attention_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
                                 const void* dout, void* dq, void* dk, void* dv, float* dbias, const float* bias_table,
                                 const float* mask, const int* dims, float scale, float drop_p, unsigned drop_seed,
-                                hipStream_t stream);
+                                const unsigned* drop_seed_dev, hipStream_t stream);
 /* drop_p > 0: nn.Dropout on the attention probabilities (FAX global attention in train mode, fax_modules.py:114,161): element
  * (query, key) is kept with probability 1 - drop_p and scaled by 1 / (1 - drop_p); the decision is a counter-based hash of
- * (drop_seed, batch, window, head, query, key), regenerated by the backward kernels.  cobevt_attention_dropout_mask dumps it
- * (test hook): keep uint8 [B][L][heads][Nq][Nk]. */
+ * (seed, batch, window, head, query, key), regenerated by the backward kernels, seed = drop_seed + *drop_seed_dev (drop_seed_dev: a
+ * nullable DEVICE word - a training step replayed from a captured HIP graph bumps it inside the graph, the scalar arguments being
+ * frozen in the graph's nodes; forward and backward of one step must see the same value).  cobevt_attention_dropout_mask dumps
+ * the mask of an effective seed (test hook): keep uint8 [B][L][heads][Nq][Nk]. */
 int cobevt_attention_dropout_mask(int B, int L, int heads, int Nq, int Nk, float drop_p, unsigned drop_seed, unsigned char* keep,
                                   hipStream_t stream);
 

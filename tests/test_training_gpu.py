@@ -441,6 +441,44 @@ def test_corpbevt_mixed_precision_step_with_grad_scaler(cuda):
         assert all(torch.equal(a, b) for a, b in zip(before, m.parameters()))
 
 
+def test_attention_dropout_device_seed_word(cuda):
+    """the dropout mask of the attention probabilities = hash(host seed + the device word autograd.dropout_step): bumping the word
+    changes the mask while the host seed (what a captured HIP graph would freeze) stays the same; forward and backward agree on it"""
+    B, heads, hw, d = 1, 2, 8, 64
+    tm = ops.tokmap(0, 1, hw, hw, hw, hw)
+    n = hw * hw
+    g = torch.Generator().manual_seed(3)
+    q0, k0, v0 = (torch.randn(B * n, d, generator=g) for _ in range(3))
+
+    def run():
+        torch.manual_seed(1234)                        # the same host seed every time
+        with torch.enable_grad():
+            q, k, v = _leaf(q0, cuda), _leaf(k0, cuda), _leaf(v0, cuda)
+            o = ag.window_attention(q, k, v, tm, tm, tm, B, heads, 0.2, B * n, drop_p=0.4)
+            o.sum().backward()
+        return o.detach().clone(), v.grad.clone()
+    word = ag.dropout_step(cuda)
+    start = int(word.item())
+    o1, g1 = run()
+    o2, g2 = run()
+    assert torch.equal(o1, o2) and torch.equal(g1, g2)
+    word.add_(1)
+    o3, g3 = run()
+    assert not torch.equal(o1, o3)
+    # forward and backward regenerate the same mask: with v = 1 and dout = 1, sum(out) and sum(dv) are both 32 x the sum of the
+    # kept, rescaled probabilities of every head
+    with torch.enable_grad():
+        torch.manual_seed(1234)
+        q, k, v = _leaf(q0, cuda), _leaf(k0, cuda), _leaf(torch.ones_like(v0), cuda)
+        o = ag.window_attention(q, k, v, tm, tm, tm, B, heads, 0.2, B * n, drop_p=0.4)
+        o.sum().backward()
+    assert abs(float(o.detach().sum()) - float(v.grad.sum())) < 1e-4 * abs(float(o.detach().sum()))
+    assert abs(float(o.detach().sum()) / (B * n * d) - 1.0) < 0.1           # E[kept / (1 - p)] = 1
+    word.fill_(start)
+    o4, _ = run()
+    assert torch.equal(o1, o4)
+
+
 def test_attention_probability_dropout(cuda):
     """nn.Dropout on the attention probabilities (FAX global attention in train mode, fax_modules.py:114,161) inside the kernels: the
     keep mask is a counter-based hash, dumped by the test hook; forward and all gradients must equal dense torch attention with

@@ -104,9 +104,10 @@ def corpbevt_step(agents):
     l0 = step()
     t = _time(step, iters=5, warm=1)
     l1 = step()
-    return {"case": "CorpBEVT corpbevt.yaml, %d agents x 4 cams x 512x512, fp32 train step (forward + VanillaSegLoss + backward + AdamW)" % agents,
-            "train_step_ms": round(t, 2), "loss_first": round(l0, 4), "loss_after_8_steps": round(l1, 4),
-            "peak_memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    res = {"case": "CorpBEVT corpbevt.yaml, %d agents x 4 cams x 512x512, fp32 train step (forward + VanillaSegLoss + backward + AdamW)" % agents,
+           "train_step_ms": round(t, 2), "loss_first": round(l0, 4), "loss_after_8_steps": round(l1, 4),
+           "peak_memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    return res
 
 
 def main():
