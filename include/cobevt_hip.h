@@ -100,7 +100,8 @@ int cobevt_stem_conv7x7s2(const float* in, const void* wgt, const float* bias, v
 
 /*
  * The stem followed by MaxPool2d(3, 2, 1) in one launch (torchvision resnet conv1/bn1/relu/maxpool, resnet_ms.py:67-71):
- * a workgroup computes the conv on the 9 x 17 region a 4 x 8 tile of pooled pixels covers and writes the maxima, so the
+ * a workgroup computes the conv on the (2 R + 1) x 17 region an R x 8 tile of pooled pixels covers (R = 5 bf16, 3 fp32) and writes
+ * the maxima, so the
  * (N, H/2, W/2, 64) stem map never reaches HBM.  Cout = 64, ReLU.  out (N, H/4, W/4, 64).
  * dims (int32[4]): dtype, N, H, W (multiples of 4).
  */
