@@ -222,11 +222,12 @@ _KLUT = {}
 
 
 def _weight_rows(weight):
-    """(Cout, Cin, kh, kw) -> ([Cout][Kpad] fp32 rows with k = (kh * Kw + kw) * Cin + c, K, Kpad): the implicit-GEMM kernel's weight
-    layout, produced ON THE DEVICE (a permute + pad) so that it follows the parameter through optimizer steps."""
+    """(Cout, Cin, kh, kw) -> ([Cout][Kpad] rows with k = (kh * Kw + kw) * Cin + c, K, Kpad) in the weight's dtype: the implicit-GEMM
+    kernel's weight layout, produced ON THE DEVICE (a permute + pad) so that it follows the parameter through optimizer steps."""
     cout, cin, kh, kw = weight.shape
     K = kh * kw * cin
-    kpad = (K + 15) // 16 * 16
+    tile = 32 if weight.dtype == torch.bfloat16 else 16
+    kpad = (K + tile - 1) // tile * tile
     w2 = weight.permute(0, 2, 3, 1).reshape(cout, K)
     if kpad != K:
         w2 = torch.nn.functional.pad(w2, (0, kpad - K))
@@ -245,16 +246,21 @@ def _klut(kh, kw, cin, kpad, device):
 
 
 def _igemm_conv(x, weight, bias, stride, pad, ho, wo):
-    """x (N, H, W, Cin) fp32 channels-last, weight (Cout, Cin, kh, kw) -> (N, ho, wo, Cout): cobevt_conv2d_nhwc (csrc/igemm.hip),
-    top / left padding `pad`; taps past the bottom / right edge read zeros (the kernel bounds-checks every tap)."""
+    """x (N, H, W, Cin) channels-last, weight (Cout, Cin, kh, kw), both fp32 or both bf16 -> (N, ho, wo, Cout) in that dtype:
+    cobevt_conv2d_nhwc (csrc/igemm.hip), top / left padding `pad`; taps past the bottom / right edge read zeros (the kernel
+    bounds-checks every tap).  Channel counts that are not a multiple of a 16-byte chunk take the kernel's gather path, which
+    reads its input as fp32."""
     n, h, w, cin = x.shape
     cout, _, kh, kw = weight.shape
+    bf16 = x.dtype == torch.bfloat16
     w2, K, kpad = _weight_rows(weight)
-    smallc = int(cin % 4 != 0)
+    smallc = int(cin % (8 if bf16 else 4) != 0)
     klut = _klut(kh, kw, cin, kpad, x.device) if smallc else None
-    out = torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.float32)
-    dims = _ints([ops.FP32, n, h, w, cin, ho, wo, cout, kh, kw, stride, pad, K, kpad, 0, 0, 0, 0, ho, wo, smallc])
-    b = None if bias is None else _f32c(bias, "bias")
+    if smallc and bf16:
+        x = x.float()
+    out = torch.empty((n, ho, wo, cout), device=x.device, dtype=weight.dtype)
+    dims = _ints([ops.BF16 if bf16 else ops.FP32, n, h, w, cin, ho, wo, cout, kh, kw, stride, pad, K, kpad, 0, 0, 0, 0, ho, wo, smallc])
+    b = None if bias is None else _f32c(bias.float(), "bias")
     rc = _L.load().cobevt_conv2d_nhwc(_p(x), _p(w2), _p(b), None, None, None, _p(klut), _p(out), dims, _stream())
     _L.check(rc, "cobevt_conv2d_nhwc")
     return out
@@ -262,16 +268,18 @@ def _igemm_conv(x, weight, bias, stride, pad, ho, wo):
 
 class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d (square kernel, symmetric padding, groups 1) on (N, C, H, W)-shaped tensors (channels-last memory is used as it
-    is).  Forward and the input gradient run on the fp32 implicit-GEMM kernel (the input gradient is the same convolution with
-    the taps flipped and the channel roles swapped, on the zero-stuffed output gradient when stride > 1); the weight gradient is
-    cobevt_conv_wgrad (csrc/train_rows.hip: a GEMM over the pixels on the fp32 matrix path, operands straight from global memory)."""
+    is).  Forward and the input gradient run on the implicit-GEMM kernel (the input gradient is the same convolution with the
+    taps flipped and the channel roles swapped, on the zero-stuffed output gradient when stride > 1); the weight gradient is
+    cobevt_conv_wgrad (csrc/train_rows.hip: a GEMM over the pixels on the fp32 matrix path, operands straight from global memory).
+    fp32, or - x and weight both bf16, which is what conv2d() hands over inside a bf16 autocast region - bf16 storage with the
+    bf16 matrix instructions in forward / input gradient and fp32 accumulation of the weight gradient."""
 
     @staticmethod
     @_amp_fwd
     def forward(ctx, x, weight, bias, stride, pad):
         _need_cuda(x, weight, bias)
-        if x.dtype != torch.float32 or weight.dtype != torch.float32:
-            raise CobevtHipError("the training slice is fp32")
+        if x.dtype != weight.dtype or x.dtype not in (torch.float32, torch.bfloat16):
+            raise CobevtHipError("training conv2d: x and weight both fp32 or both bf16 (got %s, %s)" % (x.dtype, weight.dtype))
         xl = x.permute(0, 2, 3, 1).contiguous()
         n, h, w, _ = xl.shape
         kh, kw = weight.shape[2:]
@@ -279,6 +287,7 @@ class Conv2dFn(torch.autograd.Function):
         out = _igemm_conv(xl, weight, bias, stride, pad, ho, wo)
         ctx.save_for_backward(xl, weight)
         ctx.cfg = (stride, pad, bias is not None)
+        ctx.bias_dtype = None if bias is None else bias.dtype
         return out.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -288,23 +297,24 @@ class Conv2dFn(torch.autograd.Function):
         stride, pad, has_bias = ctx.cfg
         cout, cin, kh, kw = weight.shape
         n, h, w, _ = xl.shape
-        dyl = dy.permute(0, 2, 3, 1).contiguous()
+        dyl = dy.to(xl.dtype).permute(0, 2, 3, 1).contiguous()
         ho, wo = dyl.shape[1:3]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             g = dyl
             if stride > 1:                       # zero-stuffed gradient map: dgrad of a strided conv = stride-1 conv on it
-                g = torch.zeros((n, (ho - 1) * stride + 1, (wo - 1) * stride + 1, cout), device=dyl.device, dtype=torch.float32)
+                g = torch.zeros((n, (ho - 1) * stride + 1, (wo - 1) * stride + 1, cout), device=dyl.device, dtype=dyl.dtype)
                 g[:, ::stride, ::stride] = dyl
             wt = weight.flip(2, 3).transpose(0, 1)                 # (Cin, Cout, kh, kw)
             dx = _igemm_conv(g, wt, None, 1, kh - 1 - pad, h, w).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             dw = torch.zeros((cout, cin, kh, kw), device=dyl.device, dtype=torch.float32)
-            dims = _ints([n, h, w, cin, ho, wo, cout, kh, stride, pad])
+            dims = _ints([n, h, w, cin, ho, wo, cout, kh, stride, pad, ops.BF16 if xl.dtype == torch.bfloat16 else ops.FP32])
             rc = _L.load().cobevt_conv_wgrad(_p(xl), _p(dyl), _p(dw), dims, _stream())
             _L.check(rc, "cobevt_conv_wgrad")
+            dw = dw.to(weight.dtype)
         if has_bias and ctx.needs_input_grad[2]:
-            db = dyl.sum(dim=(0, 1, 2))
+            db = dyl.float().sum(dim=(0, 1, 2)).to(ctx.bias_dtype)
         return dx, dw, db, None, None
 
 
@@ -313,6 +323,12 @@ def conv2d(x, conv):
     if conv.groups != 1 or conv.dilation != (1, 1) or conv.kernel_size[0] != conv.kernel_size[1] or conv.stride[0] != conv.stride[1] \
             or conv.padding[0] != conv.padding[1]:
         raise CobevtHipError("training conv2d: square kernel / stride / padding, groups 1, dilation 1 only")
+    if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        # a bf16 autocast region: the convolution computes in bf16 like torch's own conv would (fp32 master weights: the casts are
+        # differentiable, the parameter receives an fp32 gradient); fp16 regions stay on the fp32 kernels (_amp_fwd)
+        with torch.autocast("cuda", enabled=False):
+            b = None if conv.bias is None else conv.bias.to(torch.bfloat16)
+            return Conv2dFn.apply(x.to(torch.bfloat16), conv.weight.to(torch.bfloat16), b, conv.stride[0], conv.padding[0])
     return Conv2dFn.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
 
 

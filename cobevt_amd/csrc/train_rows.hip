@@ -125,14 +125,21 @@ __global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ x, 
 // are one coalesced 128-byte row piece per half-wave straight from global memory (A[cout][pixel] = dY, B[pixel][cin] = X), so there
 // is no LDS staging; the four waves split the rows, meet in LDS and add the tile into dW with fp32 atomics (dW zero-initialised).
 // The reference gets this from cuDNN under autograd (every nn.Conv2d of resnet_ms.py / fax_modules.py / naive_decoder.py).
+// T = storage type of X and dY (bf16 under autocast: half the operand bytes); the products and dW are fp32 either way (a bf16
+// matrix instruction would want the contraction - the PIXELS - contiguous per lane, i.e. both operands transposed).
 struct WgradParams {
-    const float* x;      // (N, H, W, Cin)
-    const float* dy;     // (N, Ho, Wo, Cout)
-    float* dw;           // (Cout, Cin, k, k)
+    const void* x;       // (N, H, W, Cin)
+    const void* dy;      // (N, Ho, Wo, Cout)
+    float* dw;           // (Cout, Cin, k, k) fp32
     int N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, nchunks;
 };
 
+// (Tried: one workgroup per tap ROW / per all k x k taps with one accumulator per tap, so that dY is loaded once for several
+// matrix instructions: 82 -> 96 / 111 ms per CorpBEVT step (5 agents, fp32).  The kernel lives on having eight waves per SIMD hide its scalar
+// loads; more accumulators per wave means fewer waves.  The structural fix is a bf16 matrix path over pixel-contiguous operands.)
+template <typename T>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+    constexpr int PU = 4;              // pixel pairs per batch of loads (8: 82 -> 89 ms per step, a wave less per SIMD and idle lanes on narrow maps)
     __shared__ float red[3 * 16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, ql = lane & 31;
@@ -152,23 +159,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
         const int iy = oy * p.stride - p.pad + ta;
         const bool y_ok = iy >= 0 && iy < p.H;
         // unconditional loads from clamped addresses + select: a load under a branch makes the compiler drain vmcnt right after it
-        const float* dyr = p.dy + (size_t)row * p.Wo * p.Cout + min(co0 + ql, p.Cout - 1);
-        const float* xr = p.x + ((size_t)n * p.H + (y_ok ? iy : 0)) * p.W * p.Cin + min(ci0 + ql, p.Cin - 1);
-        for (int ox0 = 0; ox0 < p.Wo; ox0 += 8) {                  // four MFMAs (eight pixels) with their loads in flight together
-            float a[4], bv[4];
+        const T* dyr = (const T*)p.dy + (size_t)row * p.Wo * p.Cout + min(co0 + ql, p.Cout - 1);
+        const T* xr = (const T*)p.x + ((size_t)n * p.H + (y_ok ? iy : 0)) * p.W * p.Cin + min(ci0 + ql, p.Cin - 1);
+        for (int ox0 = 0; ox0 < p.Wo; ox0 += 2 * PU) {             // PU MFMAs (2 PU pixels) with their loads in flight together
+            float a[PU], bv[PU];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < PU; ++u) {
                 const int ox = ox0 + 2 * u + h;
                 const int ix = ox * p.stride - p.pad + tb;
                 const bool o_ok = ox < p.Wo;
                 const bool i_ok = o_ok && y_ok && ix >= 0 && ix < p.W;
-                const float av = dyr[(size_t)min(ox, p.Wo - 1) * p.Cout];
-                const float xv = xr[(size_t)min(max(ix, 0), p.W - 1) * p.Cin];
+                const float av = load_elem<T>(dyr, (size_t)min(ox, p.Wo - 1) * p.Cout);
+                const float xv = load_elem<T>(xr, (size_t)min(max(ix, 0), p.W - 1) * p.Cin);
                 a[u] = (o_ok && co_ok) ? av : 0.f;
                 bv[u] = (i_ok && ci_ok) ? xv : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv[u], acc, 0, 0, 0);
+            for (int u = 0; u < PU; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv[u], acc, 0, 0, 0);
         }
     }
 #pragma unroll
@@ -211,9 +218,10 @@ extern "C" int cobevt_gelu(const float* x, const float* dy, float* out, long n, 
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
-extern "C" int cobevt_conv_wgrad(const float* x, const float* dy, float* dw, const int* dims, hipStream_t stream) {
-    // dims: [N, H, W, Cin, Ho, Wo, Cout, k, stride, pad]
+extern "C" int cobevt_conv_wgrad(const void* x, const void* dy, float* dw, const int* dims, hipStream_t stream) {
+    // dims: [N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, dtype of x / dy (0 bf16, 1 fp32)]
     if (!x || !dy || !dw || !dims) return COBEVT_ERR_ARG;
+    if (dims[10] != 0 && dims[10] != 1) return COBEVT_ERR_ARG;
     WgradParams p;
     p.x = x; p.dy = dy; p.dw = dw;
     p.N = dims[0]; p.H = dims[1]; p.W = dims[2]; p.Cin = dims[3]; p.Ho = dims[4]; p.Wo = dims[5]; p.Cout = dims[6];
@@ -228,6 +236,8 @@ extern "C" int cobevt_conv_wgrad(const float* x, const float* dy, float* dw, con
     if (chunks < 1) chunks = 1;
     p.nchunks = (int)chunks;
     if (tiles_i * ntap > 65535 || chunks > 65535) return COBEVT_ERR_SHAPE;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles_o, tiles_i * ntap, (unsigned)chunks), dim3(256), 0, stream, p);
+    const dim3 grid(tiles_o, tiles_i * ntap, (unsigned)chunks);
+    if (dims[10] == 0) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

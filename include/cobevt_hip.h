@@ -202,10 +202,11 @@ int cobevt_attention_dropout_mask(int B, int L, int heads, int Nq, int Nk, float
 int cobevt_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, int rows,
                          int C, float eps, hipStream_t stream);
 int cobevt_gelu(const float* x, const float* dy, float* out, long n, hipStream_t stream);
-/* Weight gradient of a k x k convolution, fp32 channels-last: dw (Cout, Cin, k, k) += sum over output pixels of dy (N, Ho, Wo, Cout)
- * x the tap-shifted x (N, H, W, Cin); dw must be zero-initialised (fp32 atomics).  dims (int32[10]): N, H, W, Cin, Ho, Wo, Cout, k,
- * stride, pad.  (cuDNN under autograd in the reference: every nn.Conv2d on the path, train_camera.py:166-173.) */
-int cobevt_conv_wgrad(const float* x, const float* dy, float* dw, const int* dims, hipStream_t stream);
+/* Weight gradient of a k x k convolution, channels-last: dw fp32 (Cout, Cin, k, k) += sum over output pixels of dy (N, Ho, Wo, Cout)
+ * x the tap-shifted x (N, H, W, Cin); dw must be zero-initialised (fp32 atomics).  dims (int32[11]): N, H, W, Cin, Ho, Wo, Cout, k,
+ * stride, pad, storage type of x and dy (0 bf16 - the autocast path -, 1 fp32).  (cuDNN under autograd in the reference: every
+ * nn.Conv2d on the path, train_camera.py:166-173.) */
+int cobevt_conv_wgrad(const void* x, const void* dy, float* dw, const int* dims, hipStream_t stream);
 
 /* out[b][i] = max over l of in[b][l][i] (F-Cooper max-out fusion over the max_cav agent slots, SpatialFusionMask,
  * opv2v/opencood/models/fusion_modules/f_cooper_fuse.py:30-36).  in (B, L, per) contiguous, dtype 0 bf16 / 1 fp32, per % 8 == 0. */

@@ -332,6 +332,38 @@ def test_conv2d_forward_backward_vs_torch(cuda, cin, cout, k, stride, pad, h, w,
         assert_close(got[3], conv.bias.grad, 1e-4, "conv db")
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,pad,h,w,bias", [
+    (64, 64, 3, 1, 1, 12, 20, False), (64, 128, 3, 2, 1, 16, 16, False), (64, 128, 1, 2, 0, 16, 16, False), (3, 64, 7, 2, 3, 32, 32, False),
+    (32, 2, 3, 1, 1, 9, 11, True), (128, 32, 1, 1, 0, 8, 8, True), (24, 40, 3, 2, 1, 15, 13, True)])
+def test_conv2d_bf16_autocast_forward_backward_vs_torch(cuda, cin, cout, k, stride, pad, h, w, bias):
+    """inside a bf16 autocast region the training conv runs on the bf16 implicit-GEMM kernel in forward and input gradient (the
+    gather path for channel counts off the 16-byte chunk, incl. the 2-channel head whose input gradient has 2 'input' channels) and
+    accumulates the weight gradient in fp32 from bf16 operands; fp32 master weights receive fp32 gradients.  Against torch's fp32
+    conv2d autograd on the bf16-rounded operands, 2e-2 of each tensor's scale"""
+    g = torch.Generator().manual_seed(11)
+    conv = torch.nn.Conv2d(cin, cout, k, stride, pad, bias=bias).to(cuda)
+    x0 = torch.randn(2, cin, h, w, generator=g)
+    with torch.enable_grad():
+        x = _leaf(x0, cuda)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = ag.conv2d(x, conv)
+        assert y.dtype == torch.bfloat16
+        wgt = torch.randn(y.shape, generator=g).to(cuda)
+        (y.float() * wgt).sum().backward()
+        assert x.grad.dtype == torch.float32 and conv.weight.grad.dtype == torch.float32
+        got = (y.detach().float(), x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone() if bias else None)
+        conv.zero_grad()
+        rnd = lambda t: t.to(torch.bfloat16).float()      # noqa: E731
+        xr = _leaf(rnd(x0), cuda)
+        yr = torch.nn.functional.conv2d(xr, rnd(conv.weight), conv.bias, stride, pad)
+        (yr * wgt).sum().backward(inputs=[xr, conv.weight] + ([conv.bias] if bias else []))
+    assert_close(got[0], yr, 2e-2, "bf16 conv forward")
+    assert_close(got[1], xr.grad, 2e-2, "bf16 conv dX")
+    assert_close(got[2], conv.weight.grad, 2e-2, "bf16 conv dW")
+    if bias:
+        assert_close(got[3], conv.bias.grad, 2e-2, "bf16 conv db")
+
+
 def _freeze_bn(m):
     for mod in m.modules():
         if isinstance(mod, torch.nn.BatchNorm2d):
@@ -427,7 +459,7 @@ def test_corpbevt_mixed_precision_step_with_grad_scaler(cuda):
                     if scale > 1e-3 * max(float(r.abs().max()) for r in ref.values()):
                         worst = max(worst, float((p.grad - ref[n]).abs().max()) / scale)
             # worst parameter, max-norm relative: the half-precision projections in between carry 11 (fp16) / 8 (bf16) mantissa bits
-            assert worst < (8e-2 if amp_dtype == torch.float16 else 2.5e-1), "%s autocast gradients differ from the fp32 run: %.3g" % (amp_dtype, worst)
+            assert worst < (8e-2 if amp_dtype == torch.float16 else 3e-1), "%s autocast gradients differ from the fp32 run: %.3g" % (amp_dtype, worst)
         # an overflowing gradient: the step is skipped and the scale backs off
         before = [p.detach().clone() for p in m.parameters()]
         opt = torch.optim.SGD(m.parameters(), lr=1.0)

@@ -107,6 +107,18 @@ def corpbevt_step(agents):
     res = {"case": "CorpBEVT corpbevt.yaml, %d agents x 4 cams x 512x512, fp32 train step (forward + VanillaSegLoss + backward + AdamW)" % agents,
            "train_step_ms": round(t, 2), "loss_first": round(l0, 4), "loss_after_8_steps": round(l1, 4),
            "peak_memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    # the same step inside a bf16 autocast region (train_camera.py --half with bf16): convolutions on the bf16 kernels, library
+    # GEMMs in bf16, the attention / LayerNorm / GELU / loss kernels in fp32 behind casts
+    def step_amp():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = crit(model(dict(batch)), gt)
+        loss.backward()
+        opt.step()
+        return float(loss.detach())
+    la = step_amp()
+    ta = _time(step_amp, iters=5, warm=1)
+    res.update({"bf16_autocast_train_step_ms": round(ta, 2), "bf16_autocast_loss_first": round(la, 4), "bf16_autocast_loss_after_7_steps": round(step_amp(), 4)})
     return res
 
 
