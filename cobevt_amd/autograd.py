@@ -266,6 +266,25 @@ def _igemm_conv(x, weight, bias, stride, pad, ho, wo):
     return out
 
 
+USE_WGRAD_BLOCKED = True      # bf16, stride 1, k in (1, 3): weight gradient on the bf16 matrix path (cobevt_conv_wgrad_blocked)
+
+
+def _blocked_operands(xl, dyl, k, pad):
+    """The operands of cobevt_conv_wgrad_blocked from channels-last bf16 x (N, H, W, Cin) and dy (N, Ho, Wo, Cout): 8 pixels of one
+    channel per 16-byte piece, [n][row][block][channel][8]; x zero-padded by `pad` on every side, both rows padded with zero blocks
+    (dy to an even number of blocks, x to one block more).  One pad + one permuting copy per operand."""
+    n, h, w, cin = xl.shape
+    _, ho, wo, cout = dyl.shape
+    ndb = (wo + 15) // 16 * 2
+    nxb = ndb + 1
+    hp = max(h + 2 * pad, ho + k - 1)
+    xp = torch.nn.functional.pad(xl, (0, 0, pad, nxb * 8 - w - pad, pad, hp - h - pad))
+    dp = torch.nn.functional.pad(dyl, (0, 0, 0, ndb * 8 - wo))
+    xb = xp.view(n, hp, nxb, 8, cin).permute(0, 1, 2, 4, 3).contiguous()
+    db = dp.view(n, ho, ndb, 8, cout).permute(0, 1, 2, 4, 3).contiguous()
+    return xb, db, hp, nxb, ndb
+
+
 class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d (square kernel, symmetric padding, groups 1) on (N, C, H, W)-shaped tensors (channels-last memory is used as it
     is).  Forward and the input gradient run on the implicit-GEMM kernel (the input gradient is the same convolution with the
@@ -309,9 +328,15 @@ class Conv2dFn(torch.autograd.Function):
             dx = _igemm_conv(g, wt, None, 1, kh - 1 - pad, h, w).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             dw = torch.zeros((cout, cin, kh, kw), device=dyl.device, dtype=torch.float32)
-            dims = _ints([n, h, w, cin, ho, wo, cout, kh, stride, pad, ops.BF16 if xl.dtype == torch.bfloat16 else ops.FP32])
-            rc = _L.load().cobevt_conv_wgrad(_p(xl), _p(dyl), _p(dw), dims, _stream())
-            _L.check(rc, "cobevt_conv_wgrad")
+            if USE_WGRAD_BLOCKED and xl.dtype == torch.bfloat16 and stride == 1 and kh in (1, 3):
+                x_blk, dy_blk, hp, nxb, ndb = _blocked_operands(xl, dyl, kh, pad)
+                dims = _ints([n, hp, nxb, cin, ho, ndb, cout, kh])
+                rc = _L.load().cobevt_conv_wgrad_blocked(_p(x_blk), _p(dy_blk), _p(dw), dims, _stream())
+                _L.check(rc, "cobevt_conv_wgrad_blocked")
+            else:
+                dims = _ints([n, h, w, cin, ho, wo, cout, kh, stride, pad, ops.BF16 if xl.dtype == torch.bfloat16 else ops.FP32])
+                rc = _L.load().cobevt_conv_wgrad(_p(xl), _p(dyl), _p(dw), dims, _stream())
+                _L.check(rc, "cobevt_conv_wgrad")
             dw = dw.to(weight.dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = dyl.float().sum(dim=(0, 1, 2)).to(ctx.bias_dtype)

@@ -192,6 +192,98 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     }
 }
 
+// Weight gradient on the bf16 matrix path (stride 1, k = 1 or 3): v_mfma_f32_32x32x16_bf16 contracts 16 PIXELS per instruction
+// and wants each lane's 8 pixels of its channel in one register quad, while consecutive lanes (channels) should read consecutive
+// addresses.  Both hold for a BLOCKED copy of the operands, made by the caller with one permute:
+//     Xb[n][iy + pad][blk][c][8]   X zero-padded by `pad` on every side (and on the right up to the block count), 8 pixels per block
+//     Db[n][oy][blk][o][8]         dY, the row zero-padded to a multiple of 16 pixels
+// A lane's operand is one 16-byte load and a half-wave reads 512 contiguous bytes; no bounds tests in the loop (the zero padding
+// does it).  The k taps of a tap ROW differ only by a shift of 0 .. k-1 pixels inside the same two blocks: they share their loads
+// and are separated by a funnel shift in registers (one accumulator per tap); tap rows, channel tiles and shares of the output
+// rows are separate workgroups as in conv_wgrad_kernel.
+struct Wgrad16Params {
+    const uint4* xb;     // [N][Hp][XB][Cin] blocks of 8 bf16
+    const uint4* db;     // [N][Ho][DB][Cout] blocks of 8 bf16
+    float* dw;           // (Cout, Cin, k, k) fp32, zero-initialised
+    int N, Hp, XB, Cin, Ho, DB, Cout, k, nchunks;
+};
+
+template <int KW>
+__global__ __launch_bounds__(256) void conv_wgrad16_kernel(Wgrad16Params p) {
+    __shared__ float red[3 * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, ql = lane & 31;
+    const int co0 = blockIdx.x * 32;
+    const int ci0 = (blockIdx.y / p.k) * 32, ta = blockIdx.y % p.k;          // one tap row per workgroup
+    const int rows = p.N * p.Ho;
+    const int per = (rows + p.nchunks - 1) / p.nchunks;
+    const int r0 = blockIdx.z * per, r1 = min(rows, r0 + per);
+    const bool co_ok = co0 + ql < p.Cout, ci_ok = ci0 + ql < p.Cin;
+    const int co = min(co0 + ql, p.Cout - 1), ci = min(ci0 + ql, p.Cin - 1);
+    f32x16 acc[KW];
+#pragma unroll
+    for (int t = 0; t < KW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    // this wave's work = (row, 16-pixel step) pairs, rows r0 + wave, + 4, ...; U of them per batch so that 3 U loads are in flight
+    // before the first matrix instruction (one step per batch left the wave waiting out a global round trip per 3 MFMAs)
+    constexpr int U = 4;
+    const int nsteps = p.DB >> 1;
+    const int nrows_w = r1 > r0 + wave ? (r1 - r0 - wave + 3) >> 2 : 0;
+    const int total = nrows_w * nsteps;
+    for (int base = 0; base < total; base += U) {
+        uint4 a[U], w0[U];
+        uint32_t w4[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = min(base + u, total - 1);              // the tail repeats the last step; its products are dropped below
+            const int ri = idx / nsteps, b0 = (idx - ri * nsteps) * 2;
+            const int row = r0 + wave + 4 * ri;
+            const int n = row / p.Ho, oy = row - n * p.Ho;
+            const uint4* dr = p.db + ((size_t)row * p.DB + b0 + h) * p.Cout + co;                          // block b0 + h of dY's row
+            const uint4* xr = p.xb + (((size_t)n * p.Hp + oy + ta) * p.XB + b0 + h) * p.Cin + ci;         // padded row oy + ta
+            a[u] = dr[0];
+            w0[u] = xr[0];
+            w4[u] = 0;
+            if constexpr (KW > 1) w4[u] = ((const uint32_t*)(xr + p.Cin))[0];                              // pixels 8, 9 of the window
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = base + u < total;
+            uint4 av = (co_ok && live) ? a[u] : zero;
+            uint4 wv = ci_ok ? w0[u] : zero;
+            const uint32_t w4v = ci_ok ? w4[u] : 0u;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, wv), acc[0], 0, 0, 0);
+            if constexpr (KW > 1) {
+                // tap 1: pixels 1..8, tap 2: pixels 2..9 of the ten loaded
+                const uint4 s1 = make_uint4(__builtin_amdgcn_alignbit(wv.y, wv.x, 16), __builtin_amdgcn_alignbit(wv.z, wv.y, 16),
+                                            __builtin_amdgcn_alignbit(wv.w, wv.z, 16), __builtin_amdgcn_alignbit(w4v, wv.w, 16));
+                const uint4 s2 = make_uint4(wv.y, wv.z, wv.w, w4v);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, s1), acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, s2), acc[2], 0, 0, 0);
+            }
+        }
+    }
+    const int ntap = p.k * p.k;
+#pragma unroll
+    for (int t = 0; t < KW; ++t) {
+        if (t) __syncthreads();                                    // red is reused per tap
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (wave > 0) red[((wave - 1) * 16 + r) * 64 + lane] = acc[t][r];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[t][r] + red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane];
+                const int o = co0 + acc_row(r, lane), c = ci0 + ql;     // D[cout rows][cin cols]
+                if (o < p.Cout && c < p.Cin && v != 0.f) atomicAdd(p.dw + ((size_t)o * p.Cin + c) * ntap + ta * p.k + t, v);
+            }
+        }
+    }
+}
+
 }  // namespace
 }  // namespace cobevt
 
@@ -239,5 +331,28 @@ extern "C" int cobevt_conv_wgrad(const void* x, const void* dy, float* dw, const
     const dim3 grid(tiles_o, tiles_i * ntap, (unsigned)chunks);
     if (dims[10] == 0) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+extern "C" int cobevt_conv_wgrad_blocked(const void* xb, const void* db, float* dw, const int* dims, hipStream_t stream) {
+    // dims: [N, Hp, XB, Cin, Ho, DB, Cout, k]
+    if (!xb || !db || !dw || !dims) return COBEVT_ERR_ARG;
+    Wgrad16Params p;
+    p.xb = (const uint4*)xb; p.db = (const uint4*)db; p.dw = dw;
+    p.N = dims[0]; p.Hp = dims[1]; p.XB = dims[2]; p.Cin = dims[3]; p.Ho = dims[4]; p.DB = dims[5]; p.Cout = dims[6]; p.k = dims[7];
+    if (p.N < 1 || p.Cin < 1 || p.Ho < 1 || p.Cout < 1 || (p.k != 1 && p.k != 3)) return COBEVT_ERR_SHAPE;
+    // the blocked rows must hold what the loop reads: rows oy + ta <= Ho + k - 2, blocks b0 + h (+ 1 for k = 3) with b0 + 1 < DB + 1
+    if (p.DB < 2 || (p.DB & 1) || p.Hp < p.Ho + p.k - 1 || p.XB < p.DB + (p.k > 1 ? 1 : 0)) return COBEVT_ERR_SHAPE;
+    const int tiles_o = (p.Cout + 31) / 32, tiles_i = (p.Cin + 31) / 32;
+    const long per = (long)tiles_o * tiles_i * p.k;
+    const int rows = p.N * p.Ho;
+    long chunks = (2048 + per - 1) / per;                          // about 2048 workgroups, at least four rows each
+    if (chunks > rows / 4) chunks = rows / 4;
+    if (chunks < 1) chunks = 1;
+    p.nchunks = (int)chunks;
+    if (tiles_i * p.k > 65535 || chunks > 65535) return COBEVT_ERR_SHAPE;
+    const dim3 grid(tiles_o, tiles_i * p.k, (unsigned)chunks);
+    if (p.k == 3) hipLaunchKernelGGL(conv_wgrad16_kernel<3>, grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(conv_wgrad16_kernel<1>, grid, dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

@@ -207,6 +207,12 @@ int cobevt_gelu(const float* x, const float* dy, float* out, long n, hipStream_t
  * stride, pad, storage type of x and dy (0 bf16 - the autocast path -, 1 fp32).  (cuDNN under autograd in the reference: every
  * nn.Conv2d on the path, train_camera.py:166-173.) */
 int cobevt_conv_wgrad(const void* x, const void* dy, float* dw, const int* dims, hipStream_t stream);
+/* The same weight gradient on the bf16 matrix path, for stride 1 and k = 1 or 3, from BLOCKED bf16 copies of the operands (8
+ * pixels of one channel = one 16-byte piece, so a lane's matrix operand is one coalesced load and zero padding replaces every
+ * bounds test): xb [N][Hp][XB][Cin][8] = x zero-padded by `pad` rows / columns (Hp >= Ho + k - 1 rows, XB >= DB + (k > 1) blocks
+ * per row), db [N][Ho][DB][Cout][8] = dy with rows zero-padded to an even number DB of blocks; dw fp32 (Cout, Cin, k, k),
+ * zero-initialised.  dims (int32[8]): N, Hp, XB, Cin, Ho, DB, Cout, k. */
+int cobevt_conv_wgrad_blocked(const void* xb, const void* db, float* dw, const int* dims, hipStream_t stream);
 
 /* out[b][i] = max over l of in[b][l][i] (F-Cooper max-out fusion over the max_cav agent slots, SpatialFusionMask,
  * opv2v/opencood/models/fusion_modules/f_cooper_fuse.py:30-36).  in (B, L, per) contiguous, dtype 0 bf16 / 1 fp32, per % 8 == 0. */
