@@ -178,3 +178,35 @@ def test_flipped_domain_taps_identity():
     assert torch.allclose(got, ref, atol=1e-5)
     # and back: un-flipping the reference's result gives the plain-orientation convolution
     assert torch.allclose(ref.flip(3).permute(0, 1, 3, 2), F.conv2d(x, _flipped_domain_taps(w), padding=1), atol=1e-5)
+
+
+def test_blocked_weight_gradient_operands():
+    """autograd._blocked_operands: the operand layout cobevt_conv_wgrad_blocked reads ([n][row][block of 8 pixels][channel][8], x
+    zero-padded by `pad`, dy rows padded to an even block count) - checked on the CPU by evaluating the weight gradient from the
+    blocked tensors exactly as the kernel indexes them (tap (a, b): x pixel ox + b of padded row oy + a) against torch's conv2d
+    autograd, for 3x3 / pad 1 and 1x1 / pad 0 and a width that is not a multiple of 8"""
+    import torch.nn.functional as F
+    from cobevt_amd import autograd as ag
+    g = torch.Generator().manual_seed(5)
+    for k, pad, (n, cin, cout, h, w) in ((3, 1, (2, 5, 4, 6, 11)), (1, 0, (1, 3, 6, 4, 16))):
+        x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+        wt = torch.randn(cout, cin, k, k, generator=g, requires_grad=True)
+        y = F.conv2d(x, wt, padding=pad)
+        dy = torch.randn(y.shape, generator=g)
+        (y * dy).sum().backward()
+        xl, dyl = x.detach().permute(0, 2, 3, 1).contiguous(), dy.permute(0, 2, 3, 1).contiguous()
+        xb, db, hp, nxb, ndb = ag._blocked_operands(xl, dyl, k, pad)
+        ho, wo = dyl.shape[1:3]
+        assert xb.shape == (n, hp, nxb, cin, 8) and db.shape == (n, ho, ndb, cout, 8)
+        assert ndb % 2 == 0 and nxb >= ndb + (k > 1) and hp >= ho + k - 1
+        # un-block: pixel p of a row lives in block p // 8, slot p % 8
+        xrow = xb.permute(0, 1, 3, 2, 4).reshape(n, hp, cin, nxb * 8)          # [n][padded row][c][padded pixel]
+        drow = db.permute(0, 1, 3, 2, 4).reshape(n, ho, cout, ndb * 8)         # [n][oy][o][pixel]
+        assert torch.equal(drow[..., :wo], dyl.permute(0, 1, 3, 2)) and not drow[..., wo:].any()
+        dw = torch.zeros(cout, cin, k, k)
+        npx = ndb * 8                                                         # the kernel walks every pixel of the padded dy rows
+        for a in range(k):
+            for b in range(k):
+                win = xrow[:, a:a + ho, :, b:b + npx]                           # x pixel ox + b of padded row oy + a
+                dw[:, :, a, b] = torch.einsum("nyop,nycp->oc", drow, win)
+        assert torch.allclose(dw, wt.grad, atol=1e-4), (k, (dw - wt.grad).abs().max())
