@@ -346,7 +346,11 @@ extern "C" int cobevt_conv_wgrad_blocked(const void* xb, const void* db, float* 
     const int tiles_o = (p.Cout + 31) / 32, tiles_i = (p.Cin + 31) / 32;
     const long per = (long)tiles_o * tiles_i * p.k;
     const int rows = p.N * p.Ho;
-    long chunks = (2048 + per - 1) / per;                          // about 2048 workgroups, at least four rows each
+    // about COBEVT_WGRAD16_WGS workgroups, at least four rows each: every workgroup ends in 1024 x k fp32 atomics
+#ifndef COBEVT_WGRAD16_WGS
+#define COBEVT_WGRAD16_WGS 512
+#endif
+    long chunks = (COBEVT_WGRAD16_WGS + per - 1) / per;
     if (chunks > rows / 4) chunks = rows / 4;
     if (chunks < 1) chunks = 1;
     p.nchunks = (int)chunks;
