@@ -191,9 +191,10 @@ def test_blocked_weight_gradient_operands():
     for k, pad, (n, cin, cout, h, w) in ((3, 1, (2, 5, 4, 6, 11)), (1, 0, (1, 3, 6, 4, 16))):
         x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
         wt = torch.randn(cout, cin, k, k, generator=g, requires_grad=True)
-        y = F.conv2d(x, wt, padding=pad)
-        dy = torch.randn(y.shape, generator=g)
-        (y * dy).sum().backward()
+        with torch.enable_grad():                       # (other modules of the suite switch gradients off globally)
+            y = F.conv2d(x, wt, padding=pad)
+            dy = torch.randn(y.shape, generator=g)
+            (y * dy).sum().backward()
         xl, dyl = x.detach().permute(0, 2, 3, 1).contiguous(), dy.permute(0, 2, 3, 1).contiguous()
         xb, db, hp, nxb, ndb = ag._blocked_operands(xl, dyl, k, pad)
         ho, wo = dyl.shape[1:3]
