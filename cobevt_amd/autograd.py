@@ -383,4 +383,6 @@ class WeightedCrossEntropyFn(torch.autograd.Function):
 
 
 def weighted_cross_entropy(logits, target, weight):
-    return WeightedCrossEntropyFn.apply(logits, target, weight)
+    # explicit (differentiable) cast: the criterion is commonly called OUTSIDE the autocast region, where custom_fwd's
+    # cast_inputs no longer applies and a bf16 / fp16 head output would reach the fp32 kernel as it is
+    return WeightedCrossEntropyFn.apply(logits.float(), target, weight)

@@ -383,8 +383,8 @@ extern "C" int cobevt_window_attention_bwd(const void* q, const void* k, const v
     const bool hb = p.bias_mode != 0, hm = mask != nullptr;
 #define COBEVT_BWD_LAUNCH(B_, M_)                                                                     \
     do {                                                                                              \
-        static bool attr = false;                                                                     \
-        if (!attr) { set_max_lds(attn_bwd_kv_kernel<B_, M_>); set_max_lds(attn_bwd_q_kernel<B_, M_>); attr = true; } \
+        static cobevt::PerDeviceOnce attr;                                                                   \
+        if (attr.first()) { set_max_lds(attn_bwd_kv_kernel<B_, M_>); set_max_lds(attn_bwd_q_kernel<B_, M_>); } \
         hipLaunchKernelGGL((attn_bwd_kv_kernel<B_, M_>), grid_kv, block, lds_kv, stream, bp);         \
         hipLaunchKernelGGL((attn_bwd_q_kernel<B_, M_>), grid_q, block, lds_q, stream, bp);            \
     } while (0)

@@ -346,10 +346,9 @@ static int launch_basicblock(BasicBlockParams p, hipStream_t stream) {
     p.tiles_x = (p.W + G::TW - 1) / G::TW;
     const long blocks = (long)p.N * p.tiles_y * p.tiles_x;
     if (blocks <= 0 || blocks > 0x7fffffffL) return COBEVT_ERR_SHAPE;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static cobevt::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)basicblock_kernel<T, C, TH_>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-        attr_set = true;
     }
     hipLaunchKernelGGL((basicblock_kernel<T, C, TH_>), dim3((unsigned)blocks), dim3(G::NT), G::LDS, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;

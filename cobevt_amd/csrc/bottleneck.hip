@@ -232,10 +232,9 @@ int launch_bn(BottleneckParams p, hipStream_t stream) {
     p.tiles_x = (p.W + 15) / 16;
     const long blocks = (long)p.N * p.tiles_y * p.tiles_x;
     if (blocks <= 0 || blocks > 0x7fffffffL) return COBEVT_ERR_SHAPE;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static cobevt::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)bottleneck_kernel<TH>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-        attr_set = true;
     }
     hipLaunchKernelGGL((bottleneck_kernel<TH>), dim3((unsigned)blocks), dim3(G::NTHR), G::LDS, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;

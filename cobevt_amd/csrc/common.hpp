@@ -127,6 +127,20 @@ __device__ __forceinline__ float wave_sum_xor(float v, int width) {
     return v;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE attribute: a launch site keeps one of these (static) and
+// raises the limit once per device the process launches on, not once per process.
+struct PerDeviceOnce {
+    unsigned long long done = 0;
+    bool first() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) return true;
+        const unsigned long long bit = 1ull << d;
+        if (done & bit) return false;
+        done |= bit;
+        return true;
+    }
+};
+
 }  // namespace cobevt
 
 // error codes shared with include/cobevt_hip.h

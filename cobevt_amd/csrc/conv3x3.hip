@@ -363,10 +363,9 @@ static int launch_conv3(Conv3Params p, hipStream_t stream) {
     const long blocks = (long)p.N * p.tiles_y * p.tiles_x * p.tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffffL) return COBEVT_ERR_SHAPE;
     constexpr size_t lds = C::LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static cobevt::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)conv3x3_kernel<T, BN, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL((conv3x3_kernel<T, BN, KG>), dim3((unsigned)blocks), dim3(kConv3Threads), lds, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
@@ -771,10 +770,9 @@ static int launch_conv3s(Conv3Params p, int coutp, hipStream_t stream) {
     const long blocks = (nstrips + MT - 1) / MT * p.tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffffL) return COBEVT_ERR_SHAPE;
     constexpr size_t lds = C::LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static cobevt::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)conv3x3_strips_kernel<T, MT, WN, KS, S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL((conv3x3_strips_kernel<T, MT, WN, KS, S, NW>), dim3((unsigned)blocks), dim3(C::NT), lds, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;

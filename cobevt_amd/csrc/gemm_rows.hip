@@ -647,11 +647,10 @@ extern "C" int cobevt_linear_rows(const void* in, const void* wgt, const float* 
     if (blocks > 0x7fffffffL) return COBEVT_ERR_SHAPE;
     constexpr size_t lds = kGrLds;                 // A + W tiles (the fp32 staging (128 x 528) fits inside) + coefficients
     static_assert(128 * kGrStageRow <= 2 * kGrTile * kGrRow, "staging must fit");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static cobevt::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<bf16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     if (dtype == 0) hipLaunchKernelGGL((gemm_rows_kernel<bf16_t, false>), dim3((unsigned)blocks), dim3(kGrThreads), lds, stream, p);
     else hipLaunchKernelGGL((gemm_rows_kernel<float, false>), dim3((unsigned)blocks), dim3(kGrThreads), lds, stream, p);
@@ -683,11 +682,10 @@ extern "C" int cobevt_bev_embed_linear_rows(const float* E_inv, const float* wor
     p.emb_n = (int)n; p.emb_hw = (int)hw;
     const long blocks = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (blocks > 0x7fffffffL) return COBEVT_ERR_SHAPE;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static cobevt::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrLds);
         (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGrLds);
-        attr_set = true;
     }
     if (dtype == 0) hipLaunchKernelGGL((gemm_rows_kernel<bf16_t, true>), dim3((unsigned)blocks), dim3(kGrThreads), kGrLds, stream, p);
     else hipLaunchKernelGGL((gemm_rows_kernel<float, true>), dim3((unsigned)blocks), dim3(kGrThreads), kGrLds, stream, p);
@@ -730,11 +728,10 @@ extern "C" int cobevt_linear_rows_wfrag(const void* in, const void* wfrag, const
     const long blocks = ntn * per_col;
     if (blocks > 0x7fffffffL) return COBEVT_ERR_SHAPE;
     const size_t lds = (size_t)kGrTile * kGrRow + (size_t)128 * (128 * (dtype == 0 ? 2 : 4) + 16);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static cobevt::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)gemm_rows2_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 34816 + 34816);
         (void)hipFuncSetAttribute((const void*)gemm_rows2_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 34816 + 67584);
-        attr_set = true;
     }
     if (dtype == 0) hipLaunchKernelGGL(gemm_rows2_kernel<bf16_t>, dim3((unsigned)blocks), dim3(kGrThreads), lds, stream, p);
     else hipLaunchKernelGGL(gemm_rows2_kernel<float>, dim3((unsigned)blocks), dim3(kGrThreads), lds, stream, p);

@@ -257,10 +257,9 @@ extern "C" int cobevt_linear_rows_small_k(const void* in, const void* wfrag, con
     p.emb_E = p.emb_world = p.emb_wbev = p.emb_bbev = p.emb_wcam = nullptr;
     p.emb_n = p.emb_hw = 1; p.emb_xbcast = 0;
     if (rows == 64) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static cobevt::PerDeviceOnce attr_once;
+        if (attr_once.first()) {
             (void)hipFuncSetAttribute((const void*)gemm_rows3_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1040 + 64 * kG3Row + 4096 * 4);
-            attr_set = true;
         }
         hipLaunchKernelGGL((gemm_rows3_kernel<false, 64>), dim3(blocks), dim3(512), lds, stream, p);
     } else {

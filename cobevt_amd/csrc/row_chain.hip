@@ -327,10 +327,9 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
 
 template <int NPASS, int ROWS, bool FULL>
 static void launch_chain(const RowChainParams& p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static cobevt::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)row_chain_kernel<NPASS, ROWS, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<ROWS>::BYTES);
-        attr_set = true;
     }
     const unsigned blocks = (unsigned)((p.M + ROWS - 1) / ROWS);
     hipLaunchKernelGGL((row_chain_kernel<NPASS, ROWS, FULL>), dim3(blocks), dim3(ROWS * 8), RcLds<ROWS>::BYTES, stream, p);

@@ -544,11 +544,10 @@ extern "C" int cobevt_stem_conv7x7s2(const float* in, const void* wgt, const flo
     if (nt > 0x7fffffffL) return COBEVT_ERR_SHAPE;
     p.ntiles = (int)nt;
     const size_t lds = dtype == 0 ? StemCfg<bf16_t>::LDS : StemCfg<float>::LDS;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static cobevt::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)stem7x7_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StemCfg<bf16_t>::LDS);
         (void)hipFuncSetAttribute((const void*)stem7x7_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StemCfg<float>::LDS);
-        attr_set = true;
     }
     const int per_cu = dtype == 0 ? 2 : 1;
     const unsigned blocks = (unsigned)(nt < 256L * per_cu ? nt : 256L * per_cu);
@@ -575,11 +574,10 @@ extern "C" int cobevt_stem_conv7x7s2_pool(const float* in, const void* wgt, cons
     if (nt > 0x7fffffffL) return COBEVT_ERR_SHAPE;
     p.ntiles = (int)nt;
     const size_t lds = dtype == 0 ? StemPoolCfg<bf16_t>::LDS : StemPoolCfg<float>::LDS;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static cobevt::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)stem_pool_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StemPoolCfg<bf16_t>::LDS);
         (void)hipFuncSetAttribute((const void*)stem_pool_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StemPoolCfg<float>::LDS);
-        attr_set = true;
     }
     // persistent grid: as many workgroups per CU as LDS and the 32-wave limit admit (bf16 2, fp32 1)
     const int nthreads = dtype == 0 ? StemPoolCfg<bf16_t>::NT : StemPoolCfg<float>::NT;

@@ -164,6 +164,126 @@ def exchange_features_strong(local_feats, n_local, rank, world, agents, group=No
     return gathered.index_select(0, idx)
 
 
+# ----------------------------------------------------------------------------------------------
+# One-shot direct exchange over xGMI: 256-KiB agent blocks are latency-bound in a ring, so every rank
+# stores its blocks straight into the peers' windows (csrc/peer_gather.hip, include/cobevt_hip.h cobevt_peer_*).
+# ----------------------------------------------------------------------------------------------
+class _DeviceBytes(object):
+    """raw device memory as a __cuda_array_interface__ provider (torch.as_tensor wraps it without a copy)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+class DirectExchange(object):
+    """Window-based replacement of the agent all-gather for DEVICE tensors.
+
+    `block_shape` / `dtype`: one agent's feature block; `blocks`: block slots of the window (the frame's agents in agent
+    order).  Set-up (collective over `group`, any backend): allocate the window, all-gather the hipIpc handles, map the
+    peers.  `plan(dest_rank, dest_block)`: where this rank's local blocks go (dest_rank < 0: every rank).  `__call__(local)`
+    enqueues one exchange on the current stream and returns the window as an (blocks, *block_shape) tensor - valid for the
+    kernels that follow in stream order, until the next exchange is enqueued.  Capturable in a HIP graph."""
+
+    def __init__(self, block_shape, dtype, blocks, rank, world, group=None, device=None, spin_limit=0):
+        import ctypes
+        from . import lib as _L
+        self._L, self._ct = _L, ctypes
+        self.rank, self.world, self.blocks = int(rank), int(world), int(blocks)
+        self.block_shape, self.dtype = tuple(block_shape), dtype
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        n = 1
+        for d in self.block_shape:
+            n *= int(d)
+        self.block_bytes = n * torch.empty((), dtype=dtype).element_size()
+        if self.block_bytes % 16:
+            raise ValueError("DirectExchange: a block must be a multiple of 16 bytes")
+        self.window_bytes = self.block_bytes * self.blocks
+        self.spin_limit = int(spin_limit)
+        lib = _L.load()
+        ptr, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
+        with torch.cuda.device(self.device):
+            _L.check(lib.cobevt_peer_window_alloc(self.window_bytes, ctypes.byref(ptr), handle), "cobevt_peer_window_alloc")
+        self._own = ptr.value
+        handles = [None] * self.world
+        if self.world > 1:
+            dist.all_gather_object(handles, (os.getpid(), handle.raw), group=group)
+        else:
+            handles[0] = (os.getpid(), handle.raw)
+        self._mapped = []
+        ptrs = (ctypes.c_void_p * self.world)()
+        for r, (pid, raw) in enumerate(handles):
+            if r == self.rank:
+                ptrs[r] = self._own
+                continue
+            q = ctypes.c_void_p()
+            with torch.cuda.device(self.device):
+                _L.check(lib.cobevt_peer_window_open(ctypes.create_string_buffer(raw, 64), ctypes.byref(q)),
+                         "cobevt_peer_window_open (rank %d's window)" % r)
+            ptrs[r] = q.value
+            self._mapped.append(q.value)
+        self._ptrs = ptrs
+        raw_t = torch.as_tensor(_DeviceBytes(self._own, self.window_bytes), device=self.device)
+        self.window = raw_t.view(dtype).reshape((self.blocks,) + self.block_shape)
+        self._dest_rank = self._dest_block = None
+        self._n_local = 0
+        if self.world > 1:
+            dist.barrier(group=group)            # every peer has mapped every window before the first store
+
+    def plan(self, dest_rank, dest_block):
+        if len(dest_rank) != len(dest_block) or len(dest_rank) > 16:
+            raise ValueError("DirectExchange.plan: at most 16 local blocks")
+        self._n_local = len(dest_rank)
+        self._dest_rank = (self._ct.c_int * max(1, self._n_local))(*[int(v) for v in dest_rank])
+        self._dest_block = (self._ct.c_int * max(1, self._n_local))(*[int(v) for v in dest_block])
+        return self
+
+    def __call__(self, local):
+        """local: (>= n_local, *block_shape) contiguous device tensor (ignored when this rank sends nothing)"""
+        n = self._n_local
+        if n:
+            if not local.is_cuda or not local.is_contiguous() or local.dtype != self.dtype or local.shape[0] < n:
+                raise ValueError("DirectExchange: local blocks must be a contiguous device tensor of the window's dtype")
+        lib = self._L.load()
+        stream = self._ct.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self._L.check(lib.cobevt_peer_exchange(self._ct.c_void_p(local.data_ptr()) if n else None, self._ptrs, self.world,
+                                               self.rank, n, self.block_bytes, self._dest_rank, self._dest_block,
+                                               self.window_bytes, self.spin_limit, stream), "cobevt_peer_exchange")
+        return self.window
+
+    def status(self):
+        """(status, completed exchanges) after synchronising the current stream; status != 0: a bounded wait gave up"""
+        st, ep = self._ct.c_int(), self._ct.c_int()
+        stream = self._ct.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self._L.check(self._L.load().cobevt_peer_window_status(self._ct.c_void_p(self._own), self.window_bytes,
+                                                               self._ct.byref(st), self._ct.byref(ep), stream),
+                      "cobevt_peer_window_status")
+        return st.value, ep.value
+
+    def close(self):
+        lib = self._L.load()
+        torch.cuda.synchronize(self.device)
+        for q in self._mapped:
+            lib.cobevt_peer_window_close(self._ct.c_void_p(q))
+        self._mapped = []
+        if self._own:
+            self.window = None
+            lib.cobevt_peer_window_free(self._ct.c_void_p(self._own))
+            self._own = None
+
+
+def direct_plan_strong(rank, world, agents):
+    """latency mode: this rank's agents r, r + G, .. go to every rank, block slot = agent id"""
+    mine = agents_of_rank(rank, world, agents)
+    return [-1] * len(mine), list(mine)
+
+
+def direct_plan_weak(rank, world, agents):
+    """throughput mode: local slot j holds task t = j * world + rank = (frame t // agents, agent t % agents) and goes to the
+    frame's owner only (an all-to-all, not an all-gather: each block crosses one link once)"""
+    tasks = tasks_of_rank(rank, world, agents)
+    return [f for f, _ in tasks], [a for _, a in tasks]
+
+
 class FrameShardedCoBEVT(object):
     """One frame across the ranks (strong scaling): rank r encodes agents r, r+G, ..; all-gather; fusion replicated."""
 
@@ -314,9 +434,15 @@ class GradAllReducer(object):
     Parameters are packed in REVERSE registration order (backward reaches the last layers first) into flat fp32 buckets.  A
     post-accumulate hook marks a parameter ready; when a bucket is complete its gradients are copied into the flat buffer and
     ONE asynchronous all-reduce is issued for it, so the collective of the late layers runs under the backward of the early
-    ones.  `finish()` (call after loss.backward(), before optimizer.step()) issues buckets that stayed incomplete (parameters
-    without a gradient this step contribute zeros, every rank issues every bucket in the same order), waits, divides by the
-    world size and scatters the result back into p.grad.
+    ones.  `finish()` (call after loss.backward(), before optimizer.step()) issues buckets that stayed incomplete, waits,
+    divides by the world size and scatters the result back into p.grad.
+
+    Parameters that receive no gradient (DDP's find_unused_parameters=True case: BevSegHead registers `static_head` although
+    `target: dynamic` never runs it, bev_seg_head.py:17-33; DiscoNet's unused containers) must not stall the queue: every
+    bucket carries one "used" word per parameter behind its gradients, so after the reduction all ranks know which
+    parameters had a gradient on ANY rank.  Those that had none keep `p.grad = None` (the optimizer skips them, as under DDP)
+    and a rank leaves the parameters it had no LOCAL gradient for out of its readiness count of the next step.  Should such a
+    parameter receive a gradient after its bucket has gone out, one scalar all-reduce in `finish()` makes every rank re-reduce this step's buckets synchronously.
 
     Bucket size: xGMI is point-to-point, so a ring all-reduce moves 2 (N-1)/N of the bucket over each ~153 GB/s link in N-1 +
     N-1 steps of bucket / N bytes; at 8 GPUs a 32-MB bucket gives 4-MB chunks per step (bandwidth-bound, ~0.4 ms per bucket)
@@ -328,7 +454,7 @@ class GradAllReducer(object):
         self.group = group
         self.world = torch.distributed.get_world_size(group) if torch.distributed.is_initialized() else 1
         params = [p for p in params if p.requires_grad]
-        self.buckets = []            # [dict(params, flat, offsets, pending, work)]
+        self.buckets = []            # [dict(params, flat, offsets, n, pending, work, ready)]
         cur, cur_bytes = [], 0
         for p in reversed(params):
             nbytes = p.numel() * 4
@@ -346,6 +472,9 @@ class GradAllReducer(object):
                 self._bucket_of[p] = bi
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.launched = []           # bucket indices in issue order (this step)
+        self.launched_in_backward = 0    # buckets that went out before finish() in the last step (the overlap actually achieved)
+        self.skip = set()            # id(p) of the parameters THIS rank had no gradient for in the previous step
+        self._late = False
         self.enabled = True          # False: backward passes are local (gradient accumulation steps, like DDP.no_sync())
 
     def _close(self, plist):
@@ -353,58 +482,92 @@ class GradAllReducer(object):
         for p in plist:
             offs.append(n)
             n += p.numel()
-        flat = torch.zeros(n, device=plist[0].device, dtype=torch.float32)
-        self.buckets.append(dict(params=list(plist), flat=flat, offsets=offs, pending=len(plist), work=None, ready=set()))
+        flat = torch.zeros(n + len(plist), device=plist[0].device, dtype=torch.float32)     # gradients | one "used" word each
+        self.buckets.append(dict(params=list(plist), flat=flat, offsets=offs, n=n, pending=len(plist), work=None, ready=set()))
 
     def _on_grad(self, p):
         if not self.enabled:
             return
-        b = self.buckets[self._bucket_of[p]]
+        bi = self._bucket_of[p]
+        b = self.buckets[bi]
         if id(p) in b["ready"]:
             return
         b["ready"].add(id(p))
-        b["pending"] -= 1
+        if bi in self.launched:       # only a parameter that was expected to stay unused can arrive after its bucket went out
+            self._late = True
+            return
+        if id(p) not in self.skip:
+            b["pending"] -= 1
         # buckets are issued strictly in order so that every rank posts the same sequence of collectives
         self._issue_ready()
 
     def _issue_ready(self, force=False):
         nxt = len(self.launched)
-        while nxt < len(self.buckets) and (force or self.buckets[nxt]["pending"] == 0):
+        while nxt < len(self.buckets) and (force or self.buckets[nxt]["pending"] <= 0):
             self._issue(nxt)
             nxt += 1
 
-    def _issue(self, bi):
-        b = self.buckets[bi]
+    def _pack(self, b):
         flat = b["flat"]
+        used = []
         for p, o in zip(b["params"], b["offsets"]):
             view = flat[o:o + p.numel()]
             if p.grad is None:
                 view.zero_()
+                used.append(0.0)
             else:
                 view.copy_(p.grad.reshape(-1))
+                used.append(1.0)
+        flat[b["n"]:].copy_(torch.tensor(used, dtype=torch.float32), non_blocking=True)
+
+    def _issue(self, bi):
+        b = self.buckets[bi]
+        self._pack(b)
         if self.world > 1:
-            b["work"] = torch.distributed.all_reduce(flat, group=self.group, async_op=True)
+            b["work"] = torch.distributed.all_reduce(b["flat"], group=self.group, async_op=True)
         self.launched.append(bi)
 
     def finish(self):
         """after backward: issue what is left, wait, average, write back into p.grad"""
+        self.launched_in_backward = len(self.launched)
         self._issue_ready(force=True)
+        if self.world > 1:
+            late = torch.tensor([1.0 if self._late else 0.0], device=self.buckets[0]["flat"].device)
+            torch.distributed.all_reduce(late, group=self.group)
+            if float(late.item()) > 0:            # some rank packed a bucket before one of its gradients existed: redo, in order
+                for bi in self.launched:
+                    b = self.buckets[bi]
+                    if b["work"] is not None:
+                        b["work"].wait()
+                    self._pack(b)
+                    b["work"] = torch.distributed.all_reduce(b["flat"], group=self.group, async_op=True)
+        skip = set()
         for bi in self.launched:
             b = self.buckets[bi]
             if b["work"] is not None:
                 b["work"].wait()
                 b["work"] = None
+            used = b["flat"][b["n"]:].tolist()
             if self.world > 1:
-                b["flat"].mul_(1.0 / self.world)
-            for p, o in zip(b["params"], b["offsets"]):
+                b["flat"][:b["n"]].mul_(1.0 / self.world)
+            pending = 0
+            for p, o, u in zip(b["params"], b["offsets"], used):
+                if p.grad is None:                # not expected locally next step either (readiness is a per-rank matter;
+                    skip.add(id(p))               # the ORDER of the collectives is the same on every rank regardless)
+                else:
+                    pending += 1
+                if u <= 0:                        # no gradient on any rank: leave p.grad as it is (None), as DDP does
+                    continue
                 g = b["flat"][o:o + p.numel()].view_as(p)
                 if p.grad is None:
                     p.grad = g.clone()
                 else:
                     p.grad.copy_(g)
-            b["pending"] = len(b["params"])
+            b["pending"] = pending
             b["ready"] = set()
+        self.skip = skip
         self.launched = []
+        self._late = False
 
     def remove(self):
         for h in self._hooks:

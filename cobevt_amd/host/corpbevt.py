@@ -82,10 +82,13 @@ class CorpBEVT(HipModule):
             b, l, h, w, _ = x.shape
             com_mask = cav_mask[:, None, None, None, :].expand(b, h, w, 1, l).contiguous()
         fused = self.fusion_net.forward_blhwc(x, com_mask)                      # (B, H, W, C)
+        if self.taps is not None:
+            self.taps.update({"feats": feats, "sttf": x, "com_mask": com_mask, "fused": fused})
         y = self.decoder.forward_nhwc(fused)                                    # (B, 8H, 8W, C')
         b = y.shape[0]
         return self.seg_head(rt.nchw_view(y), b, 1)
 
+    taps = None              # set to a dict to receive intermediate tensors (tests compare them against the oracle's)
     overlap_streams = True   # run each level's key/value path on a side HIP stream under the remaining encoder stages
     overlap_kv = os.environ.get("COBEVT_OVERLAP_KV", "1") != "0"
 

@@ -424,6 +424,8 @@ class FAXModule(HipModule):
         self.downsample_layers = nn.ModuleList(downsample_layers)
         self.self_attn = Attention(dim[-1], **config["self_attn"])
 
+    taps = None      # set to a dict to receive intermediate tensors (tests compare them against the oracle's)
+
     def forward_features(self, features, I_inv, E_inv, batch, kv=None, levels=None, x=None, out=None):
         """features: list of (batch*n, h, w, C) channels-last; returns (batch, H, W, d) channels-last.
         kv: optional list of callables returning each level's prepare_kv() result (computed ahead on side streams).
@@ -451,6 +453,8 @@ class FAXModule(HipModule):
                 x = cross_view.forward_query(i, x, self.bev_embedding, E_inv, kvi)
             for j, blk in enumerate(blocks):
                 x = blk.forward_nhwc(x, y1=y1 if j == 0 else None)
+            if self.taps is not None:                   # tests: the level's BEV query (batch, H_i, W_i, d) channels-last
+                self.taps["level%d" % i] = x
             if i < len(self.cross_views) - 1:
                 final = out is not None and i == last - 1 and not (self.self_attn is not None and last == nlev)
                 x = self.downsample_layers[i][0].forward_nhwc(x, out=out if final else None)

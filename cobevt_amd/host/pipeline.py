@@ -305,28 +305,51 @@ class CapturedCall(object):
 
 
 class FrameShardedCorpBEVT(object):
-    """Strong scaling ("latency mode"): ONE frame over `world` GPUs.  Rank r encodes the agents r, r + world, ..
-    of the frame (its sub-batch is `static_sub`), one all-gather hands every rank all agents' (H, W, C) features, and the
-    18-GF STTF + fusion + decoder tail runs replicated on every rank (cheaper than a second exchange).  The two halves are
-    captured HIP graphs with the RCCL all-gather eager between them."""
+    """Strong scaling ("latency mode"; BASELINE.json north_star: one agent per GPU, ONE all-gather before
+    FuseBEVT): ONE frame over `world` GPUs.  Rank r encodes the agents r, r + world, .. of the frame (its sub-batch is
+    `static_sub`), one exchange hands every rank all agents' (H, W, C) features, and the 18-GF STTF + fusion + decoder tail
+    runs replicated on every rank (cheaper than a second exchange).
 
-    latency_steps = 1
+    gather = "rccl":   torch.distributed.all_gather_into_tensor (RCCL over xGMI), eager between two captured graphs;
+    gather = "direct": the one-shot peer-window exchange (cobevt_amd.dist.DirectExchange, csrc/peer_gather.hip) - two more
+                       kernels INSIDE the captured graph, so a step is a single graph replay.
+    depth = 1: encode -> exchange -> fuse, the latency of a frame is one step.
+    depth = 2: step i runs encode + exchange of frame i and, on a second stream of the same graph, fusion + decoder of frame
+               i - 1 (two alternating windows / buffers); one frame in, one frame out per step, latency two steps."""
 
-    def __init__(self, model, sub_batch, frame_batch, rank, world, agents, use_graph=True):
+    def __init__(self, model, sub_batch, frame_batch, rank, world, agents, use_graph=True, gather="rccl", depth=1, group=None):
         if model.training:
             raise CobevtHipError("graph runners implement inference: call model.eval() first")
+        if gather not in ("rccl", "direct") or depth not in (1, 2):
+            raise CobevtHipError("FrameShardedCorpBEVT: gather must be 'rccl' or 'direct', depth 1 or 2")
         dev = next(model.parameters()).device
         self.model, self.rank, self.world, self.agents = model, rank, world, int(agents)
+        self.gather, self.depth, self.group = gather, depth, group
+        self.latency_steps = depth
         self.mine = cdist.agents_of_rank(rank, world, self.agents)
         self.static_sub = {k: sub_batch[k].to(dev).clone() for k in _IMAGE_KEYS}
-        self.pose = frame_batch["transformation_matrix"].to(device=dev, dtype=torch.float32).clone()
-        self.rlen = torch.as_tensor(frame_batch["record_len"]).to(device=dev, dtype=torch.int32).clone()
-        self.graphs, self.out = None, None
+        pose = frame_batch["transformation_matrix"].to(device=dev, dtype=torch.float32)
+        rlen = torch.as_tensor(frame_batch["record_len"]).to(device=dev, dtype=torch.int32)
+        self.pose = [pose.clone() for _ in range(depth)]            # slot q % depth holds the pose of the frame submitted at step q
+        self.rlen = [rlen.clone() for _ in range(depth)]
+        self.graphs, self.out, self.outs = None, None, [None] * depth
         feats = self._encode()                  # also for a surplus rank (one agent): fixes the block shape, builds the plans
+        block = tuple(feats.shape[1:])
         self.slots = cdist.slots_per_rank(world, self.agents)
-        self.staging = torch.zeros((self.slots,) + tuple(feats.shape[1:]), device=dev, dtype=feats.dtype)
-        self.full = torch.empty((self.agents,) + tuple(feats.shape[1:]), device=dev, dtype=feats.dtype)
-        self.eager_step()
+        if gather == "direct":
+            self.windows = [cdist.DirectExchange(block, feats.dtype, self.agents, rank, world, group=group, device=dev)
+                            .plan(*cdist.direct_plan_strong(rank, world, self.agents)) for _ in range(depth)]
+            self.full = [w.window for w in self.windows]
+            self.staging = None
+        else:
+            self.windows = None
+            self.staging = torch.zeros((self.slots,) + block, device=dev, dtype=feats.dtype)
+            self.full = [torch.zeros((self.agents,) + block, device=dev, dtype=feats.dtype) for _ in range(depth)]
+        self.empty = feats[:0]
+        self.i = self.filled = 0
+        self.side = torch.cuda.Stream(device=dev) if depth == 2 else None
+        for q in range(2 * depth):
+            self._step_body(q % depth, eager=True)
         torch.cuda.synchronize()
         if use_graph:
             self.capture()
@@ -334,44 +357,98 @@ class FrameShardedCorpBEVT(object):
     def _encode(self):
         return self.model.encode_agents(dict(self.static_sub))
 
-    def _exchange(self, feats):
-        n = len(self.mine)
-        return cdist.exchange_features_strong(feats, n, self.rank, self.world, self.agents, out=self.full,
-                                              staging=self.staging)
+    def _exchange(self, feats, slot):
+        if self.gather == "direct":
+            self.windows[slot](feats)
+        else:
+            cdist.exchange_features_strong(feats, len(self.mine), self.rank, self.world, self.agents, group=self.group,
+                                           out=self.full[slot], staging=self.staging)
 
-    def _fuse(self):
-        return self.model.fuse_and_decode(self.full, self.pose, self.rlen)
+    def _fuse(self, slot):
+        return self.model.fuse_and_decode(self.full[slot], self.pose[slot], self.rlen[slot])
+
+    def _step_body(self, q, eager=False, stage=None):
+        """slot q = step index mod depth.  stage None: the whole step; "a": everything in front of an eager (RCCL) exchange;
+        "b": everything behind it (depth 1 only: the fusion of the same frame)."""
+        main = torch.cuda.current_stream()
+        if self.depth == 1:
+            if stage in (None, "a"):
+                self.feats = self._encode() if self.mine else self.empty
+            if stage is None:
+                self._exchange(self.feats, 0)
+            if stage in (None, "b"):
+                self.outs[0] = self._fuse(0)
+            return
+        # depth 2: fusion of the previous frame (slot q - 1) on the side stream, under this frame's encoder
+        prev = (q - 1) % 2
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            self.outs[prev] = self._fuse(prev)
+        self.feats = self._encode() if self.mine else self.empty
+        if stage is None:
+            self._exchange(self.feats, q)
+        main.wait_stream(self.side)
 
     def eager_step(self):
-        feats = self._encode() if self.mine else self.staging[:0]
-        self._exchange(feats)
-        self.out = self._fuse()
-        return self.out
+        q = self.i % self.depth
+        self._step_body(q, eager=True)
+        return self._finish(q)
 
     def capture(self):
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            self.eager_step()
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        g1 = None
-        if self.mine:
-            g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                self.feats = self._encode()
-        g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2):
-            self.out = self._fuse()
-        self.graphs = (g1, g2)
+        in_graph = self.gather == "direct"            # the peer-window kernels are captured; an RCCL call stays eager
+        self.graphs = []
+        pool = None
+        for q in range(self.depth):
+            stages = [None] if in_graph else (["a", "b"] if self.depth == 1 else ["a"])
+            gs = []
+            for st in stages:
+                if st == "a" and self.depth == 1 and not self.mine:
+                    gs.append(None)                  # a surplus rank has nothing in front of the exchange
+                    continue
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    self._step_body(q, stage=st)
+                pool = g.pool()
+                gs.append(g)
+            self.graphs.append(gs)
+
+    def _finish(self, q):
+        self.i += 1
+        self.filled += 1
+        self.out = self.outs[(q - (self.depth - 1)) % self.depth]
+        return self.out if self.filled >= self.latency_steps else None
+
+    def load(self, batch, q):
+        """copy the caller's frame (this rank's agents' images, the frame's poses) into the static buffers of slot q"""
+        if batch is None:
+            return
+        for k in _IMAGE_KEYS:
+            if batch[k].data_ptr() != self.static_sub[k].data_ptr():
+                self.static_sub[k].copy_(batch[k], non_blocking=True)
+        self.pose[q].copy_(batch["transformation_matrix"], non_blocking=True)
+        self.rlen[q].copy_(torch.as_tensor(batch["record_len"]), non_blocking=True)
 
     def step(self, batch=None):
+        q = self.i % self.depth
+        self.load(batch, q)
         if self.graphs is None:
-            return self.eager_step()
-        if self.graphs[0] is not None:
-            self.graphs[0].replay()
-            self._exchange(self.feats)
+            self._step_body(q, eager=True)
+            return self._finish(q)
+        gs = self.graphs[q]
+        if self.gather == "direct":
+            gs[0].replay()
         else:
-            self._exchange(self.staging[:0])
-        self.graphs[1].replay()
-        return self.out
+            if gs[0] is not None:
+                gs[0].replay()
+            self._exchange(self.feats, q)
+            if self.depth == 1:
+                gs[1].replay()
+        return self._finish(q)
+
+    def status(self):
+        """direct gather only: raise if a bounded flag wait gave up (a peer never arrived)"""
+        if self.windows:
+            for w in self.windows:
+                st, _ = w.status()
+                if st:
+                    raise CobevtHipError("peer-window exchange timed out (status %d): a rank is missing or stalled" % st)

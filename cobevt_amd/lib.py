@@ -81,6 +81,13 @@ SIGNATURES = {
     "cobevt_depthwise_conv_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_spatial_mean_nhwc": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "cobevt_se_gate": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    "cobevt_peer_window_alloc": (ctypes.c_int, [ctypes.c_long, ctypes.POINTER(_vp), _vp]),
+    "cobevt_peer_window_open": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
+    "cobevt_peer_window_close": (ctypes.c_int, [_vp]),
+    "cobevt_peer_window_free": (ctypes.c_int, [_vp]),
+    "cobevt_peer_window_status": (ctypes.c_int, [_vp, ctypes.c_long, _c_int_p, _c_int_p, _vp]),
+    "cobevt_peer_exchange": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long,
+                                            _c_int_p, _c_int_p, ctypes.c_long, ctypes.c_long, _vp]),
     "cobevt_channel_gate_nhwc": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
 }
 

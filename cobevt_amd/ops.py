@@ -1099,6 +1099,24 @@ def channel_gate(x, gate):
     return out
 
 
+_DEFERRED_LABELS = []
+
+
+def _check_deferred_labels():
+    for word, c in _DEFERRED_LABELS:
+        bad = int(word[0])
+        if bad:
+            word[0] = 0.0
+            raise CobevtHipError("weighted_cross_entropy: %d target labels outside [0, %d) in an earlier call (only -100 is ignored)"
+                                 % (bad, c))
+
+
+def check_deferred_label_errors():
+    """synchronise and raise if any weighted_cross_entropy call so far saw labels outside [0, C) (other than -100)"""
+    torch.cuda.synchronize()
+    _check_deferred_labels()
+
+
 def weighted_cross_entropy(logits, target, weight, want_stats=False):
     """nn.CrossEntropyLoss(weight=weight)(logits (N, C, H, W), target (N, H, W) int64) -> 0-d fp32 tensor on the device
     (vanilla_seg_loss.py:18-23,58-70); forward only."""
@@ -1114,13 +1132,15 @@ def weighted_cross_entropy(logits, target, weight, want_stats=False):
     out = torch.empty(4, device=x.device, dtype=torch.float32)
     rc = _L.load().cobevt_weighted_cross_entropy(_p(x), _p(y), _p(wt), _p(scratch), _p(out), dcode(x.dtype), n, c, h * w, _stream())
     _L.check(rc, "cobevt_weighted_cross_entropy")
-    # nn.CrossEntropyLoss raises for targets outside [0, C) other than ignore_index = -100.  The count is read back (one device ->
-    # host word) except while the stream is being captured into a HIP graph (tools/train_graph_probe.py): a captured step cannot sync,
-    # and out-of-range labels then contribute nothing, as ignore_index does
-    if not torch.cuda.is_current_stream_capturing():
-        bad = int(out[3].item())
-        if bad:
-            raise CobevtHipError("weighted_cross_entropy: %d target labels outside [0, %d) (only -100 is ignored)" % (bad, c))
+    # nn.CrossEntropyLoss raises for targets outside [0, C) other than ignore_index = -100.  Here the count of such labels leaves the
+    # device WITHOUT a host sync (a blocking read would drain the launch queue twice per training step): it is copied into a pinned
+    # host word behind the kernel and inspected by the following calls (and by check_deferred_label_errors()), so a bad label
+    # raises one call late - identically in eager steps and in steps replayed from a captured HIP graph (the copy is a graph node)
+    _check_deferred_labels()
+    host_word = torch.zeros(1, dtype=torch.float32).pin_memory()
+    host_word.copy_(out[3:4], non_blocking=True)
+    _DEFERRED_LABELS.append((host_word, c))
+    del _DEFERRED_LABELS[:-8]
     return (out[0], out, x, y, wt) if want_stats else out[0]
 
 

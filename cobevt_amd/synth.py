@@ -78,6 +78,23 @@ def fill_module_(module, seed=0):
     return module
 
 
+# Procedural weights make the dynamic head's two logits differ by a nearly constant amount (class 0 wins 16 of 65 536 pixels on the
+# bench frame), so an arg-max / mIoU comparison has no support on one class.  The bias below moves class 0's logit by the MEDIAN
+# of (logit_1 - logit_0) of the fp32 CPU restatement on opv2v_batch(agents, seed 0) with fill_module_(seed 0): both classes then
+# cover half of the BEV map and every pixel near the median is a near-tie - the hardest case for a reduced-precision path.
+BENCH_HEAD_BALANCE = {5: 0.4542081, 2: 0.4087829}
+
+
+def balance_seg_head_(model, agents):
+    """class-balance the procedural dynamic head of a CorpBEVT built with fill_module_(seed 0) for the `agents`-agent bench
+    frame (no-op for agent counts without a table entry).  Returns the shift applied."""
+    shift = BENCH_HEAD_BALANCE.get(int(agents), 0.0)
+    if shift:
+        with torch.no_grad():
+            model.seg_head.dynamic_head.bias[0] += shift
+    return shift
+
+
 def fill_state_dict(shapes, seed=0):
     """shapes: {key: shape} -> {key: tensor} (float entries only)."""
     out = {}

@@ -412,6 +412,33 @@ int cobevt_se_gate(const float* mean, const float* w_reduce, const float* b_redu
 int cobevt_channel_gate_nhwc(const void* in, const float* gate, void* out, int dtype, int N, int hw, int C,
                              hipStream_t stream);
 
+/* ---- multi-GPU: the V2V feature-sharing step in front of FuseBEVT.  The reference keeps all agents in one
+ * process (opv2v/opencood/models/corpbevt.py:112-124, sub_modules/fuse_utils.py:8-61: agents are a batch dimension up to
+ * `regroup`); its only collective call sites are the DDP set-up in opv2v/opencood/tools/multi_gpu_utils.py:32-37 and
+ * train_camera.py:105-110.  With one agent per GPU the (32, 32, 128) per-agent blocks (256 KiB bf16) are exchanged once per
+ * frame: either by RCCL (torch.distributed.all_gather_into_tensor, cobevt_amd/dist.py) or by the one-shot direct exchange
+ * below - every rank owns a WINDOW of uncached device memory mapped by all peers through hipIpc, and one launch pair per
+ * frame stores the local blocks straight into the destination windows over xGMI (csrc/peer_gather.hip). ------------------ */
+
+/* Allocate this rank's window: `bytes` of block storage (multiple of 16) followed by the flag words, zero-filled; writes the
+ * device pointer and the 64-byte hipIpc handle peers open with cobevt_peer_window_open.  Synchronous (set-up time only). */
+int cobevt_peer_window_alloc(long bytes, void** dptr, void* handle64);
+/* Map a peer's window into this process (hipIpcOpenMemHandle with lazy peer access). */
+int cobevt_peer_window_open(const void* handle64, void** dptr);
+int cobevt_peer_window_close(void* dptr);
+int cobevt_peer_window_free(void* dptr);
+/* Synchronise `stream`, then read the local window's status (0 = every bounded wait so far completed, 1 = a peer's
+ * "window free" acknowledgement timed out, 2 = a peer's data-ready flag timed out) and the count of completed exchanges. */
+int cobevt_peer_window_status(const void* window, long bytes, int* status, int* epoch, hipStream_t stream);
+/* One exchange, two launches on `stream` (capturable in a HIP graph: the epoch lives in the window).  windows: HOST array
+ * of `world` (<= 8) device pointers = this process's mappings of every rank's window, the own window at [rank].  local:
+ * n_local (<= 16) contiguous blocks of block_bytes; block j is stored at block slot dest_block[j] of rank dest_rank[j]'s
+ * window, or of every rank's window when dest_rank[j] < 0 (all-gather).  When the second launch retires, every block
+ * addressed to this rank has landed in its window.  spin_limit: bound on the flag polls (<= 0: default, ~seconds). */
+int cobevt_peer_exchange(const void* local, void* const* windows, int world, int rank, int n_local, long block_bytes,
+                         const int* dest_rank, const int* dest_block, long window_bytes, long spin_limit,
+                         hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

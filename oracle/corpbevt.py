@@ -52,10 +52,11 @@ def naive_compressor(sd, prefix, x):
     return x
 
 
-def encode_agents(sd, config, batch):
-    """Per-agent part of CorpBEVT.forward (corpbevt.py:112-117): encoder + FAX -> (N, C, H, W)."""
+def encode_agents(sd, config, batch, taps=None):
+    """Per-agent part of CorpBEVT.forward (corpbevt.py:112-117): encoder + FAX -> (N, C, H, W).  taps: optional dict that
+    receives the per-level FAX outputs (tests compare intermediate tensors, not only the logits)."""
     feats = resnet_encoder(sd, "encoder.encoder.", config["encoder"], batch["inputs"])
-    f = fax_module(sd, "fax.", config["fax"], feats, batch["intrinsic"], batch["extrinsic"])
+    f = fax_module(sd, "fax.", config["fax"], feats, batch["intrinsic"], batch["extrinsic"], taps=taps)
     return f.squeeze(1)
 
 
@@ -82,8 +83,12 @@ def fuse_and_decode(sd, config, f, tm, record_len, return_intermediates=False):
 
 def corpbevt_forward(sd, config, batch, return_intermediates=False):
     """CorpBEVT.forward, corpbevt.py:104-145."""
-    f = encode_agents(sd, config, batch)
-    return fuse_and_decode(sd, config, f, batch["transformation_matrix"], batch["record_len"], return_intermediates)
+    taps = {} if return_intermediates else None
+    f = encode_agents(sd, config, batch, taps=taps)
+    out = fuse_and_decode(sd, config, f, batch["transformation_matrix"], batch["record_len"], return_intermediates)
+    if return_intermediates:
+        out.update({"fax_" + k: v for k, v in taps.items()})
+    return out
 
 
 def fax_fused_transformer_forward(sd, config, batch):

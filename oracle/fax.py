@@ -243,7 +243,7 @@ def _downsample(sd, pfx, x):
     return bn_eval(y, sd, pfx + "0.6")
 
 
-def fax_module(sd, pfx, cfg, features, intrinsic, extrinsic, invert_extrinsic=False, final_self_attn=True):
+def fax_module(sd, pfx, cfg, features, intrinsic, extrinsic, invert_extrinsic=False, final_self_attn=True, taps=None):
     """FAXModule.forward, fax_modules.py:497-521.  features: list of (b l n C h w); intrinsic (b l n 3 3);
     extrinsic (b l n 4 4).  Returns (b l d H W).  nuScenes flavour (encoder_pyramid_axial.py:534-558):
     invert_extrinsic=True, final_self_attn=False."""
@@ -262,6 +262,8 @@ def fax_module(sd, pfx, cfg, features, intrinsic, extrinsic, invert_extrinsic=Fa
         x = cross_view_swap_attention(sd, pfx + "cross_views.%d." % i, cva_cfg, i, x, grids[i], feature, I_inv, E_inv)
         for j in range(cfg["middle"][i]):
             x = bottleneck_forward(sd, pfx + "layers.%d.%d." % (i, j), x)
+        if taps is not None:                      # per-level BEV query (b*l, d, H_i, W_i) in front of the down-sampling layer
+            taps["level%d" % i] = x
         if i < len(features) - 1:
             x = _downsample(sd, pfx + "downsample_layers.%d." % i, x)
     if final_self_attn:

@@ -3,8 +3,10 @@
 
 Follows, function by function:
   standardize_rgb      opv2v/opencood/data_utils/pre_processor/rgb_preprocessor.py:16-33,35-44 (channel swap, /255.,
-                       (x - mean) / std in float64; the resize step :46-55 is cv2.resize and is NOT restated — cv2 is
-                       absent from the build image, "parity unpinned" for it)
+                       (x - mean) / std in float64)
+  resize_linear_float  the resize step :46-55 = cv2.resize(INTER_LINEAR): the published sampling rule (pixel centres aligned,
+                       fx = (d + 0.5) * scale - 0.5, border taps clamped) evaluated in float64 - cv2 is absent from the build
+                       image, so this is "parity unpinned"; it checks the product's fixed-point restatement to 1 LSB
   bgr_to_gray_u8       cv2.cvtColor(BGR2GRAY) on uint8 as camera_bev_postprocessor.py:33 uses it: OpenCV's published
                        fixed-point formula (B*1868 + G*9617 + R*4899 + 8192) >> 14.  Third-party (opencv-python, not
                        pinned by the reference's requirements): parity unpinned.
@@ -34,6 +36,34 @@ def standardize_rgb(image_u8, mean, std, bgr2rgb):
     img = image_u8[..., ::-1] if bgr2rgb else image_u8
     x = np.asarray(img, dtype=np.float64) / 255.0
     return (x - np.asarray(mean, dtype=np.float64)) / np.asarray(std, dtype=np.float64)
+
+
+def resize_linear_float(image, width, height):
+    img = np.asarray(image, dtype=np.float64)
+    h, w = img.shape[:2]
+    out = np.zeros((height, width) + img.shape[2:], dtype=np.float64)
+    for dy in range(height):
+        fy = (dy + 0.5) * h / height - 0.5
+        y0 = int(np.floor(fy))
+        wy = fy - y0
+        if y0 < 0:
+            y0, wy = 0, 0.0
+        if y0 >= h - 1:
+            y0, wy = h - 1, 0.0
+        y1 = min(y0 + 1, h - 1)
+        for dx in range(width):
+            fx = (dx + 0.5) * w / width - 0.5
+            x0 = int(np.floor(fx))
+            wx = fx - x0
+            if x0 < 0:
+                x0, wx = 0, 0.0
+            if x0 >= w - 1:
+                x0, wx = w - 1, 0.0
+            x1 = min(x0 + 1, w - 1)
+            top = img[y0, x0] * (1 - wx) + img[y0, x1] * wx
+            bot = img[y1, x0] * (1 - wx) + img[y1, x1] * wx
+            out[dy, dx] = top * (1 - wy) + bot * wy
+    return out
 
 
 def bgr_to_gray_u8(bgr):

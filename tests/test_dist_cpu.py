@@ -196,10 +196,11 @@ def _grad_worker(rank, world, port, bucket_bytes, ret):
     net = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.GELU(), torch.nn.Linear(64, 64), torch.nn.LayerNorm(64),
                               torch.nn.Linear(64, 8))
     unused = torch.nn.Parameter(torch.ones(5))             # a parameter that gets no gradient on rank 0
-    params = list(net.parameters()) + [unused]
+    never = torch.nn.Parameter(torch.ones(3))              # ... and one no rank ever uses, registered last (BevSegHead.static_head
+    params = list(net.parameters()) + [unused, never]      #     under `target: dynamic`): it sits in bucket 0 of the reversed order
     red = cdist.GradAllReducer(params, bucket_bytes=bucket_bytes)
-    worst = 0.0
-    for step in range(2):
+    worst, early = 0.0, []
+    for step in range(3):
         xs = [torch.randn(4, 16, generator=torch.Generator().manual_seed(100 * step + r)) for r in range(world)]
         # reference: every rank's gradient computed locally (reducer switched off), averaged
         red.enabled = False
@@ -217,9 +218,11 @@ def _grad_worker(rank, world, port, bucket_bytes, ret):
         loss = net(xs[rank]).square().mean() + (unused.sum() if rank == 1 else 0.0)
         loss.backward()
         red.finish()
-        got = [p.grad.clone() for p in params]
-        worst = max(worst, max(float((a - b).abs().max()) for a, b in zip(got, ref)))
-    ret[rank] = (worst, len(red.buckets))
+        assert never.grad is None                          # DDP (find_unused_parameters) leaves it None: the optimizer skips it
+        got = [p.grad.clone() for p in params if p is not never]
+        worst = max(worst, max(float((a - b).abs().max()) for a, b in zip(got, [r_ for r_, p in zip(ref, params) if p is not never])))
+        early.append(red.launched_in_backward)
+    ret[rank] = (worst, len(red.buckets), early)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -232,3 +235,7 @@ def test_grad_all_reducer_matches_averaged_gradients(world, bucket_bytes):
     for r in range(world):
         assert ret[r][0] <= 1e-6, ret
     assert ret[0][1] == 1 if bucket_bytes > (1 << 20) else ret[0][1] > 1
+    if ret[0][1] > 1:
+        # from the second step on the never-used parameter no longer holds bucket 0 back: buckets go out DURING backward
+        for r in range(world):
+            assert ret[r][2][0] == 0 and ret[r][2][1] > 0 and ret[r][2][2] > 0, ret

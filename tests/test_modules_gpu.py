@@ -15,12 +15,13 @@ from cobevt_amd import host, synth
 from cobevt_amd.synth import fill_module_
 import oracle.corpbevt as o_model
 import oracle.fax as o_fax
-from util import assert_close, golden, rel_err
+from util import assert_close, class_margin_stats, golden, rel_err, rms_rel_err
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
 MODES = [(torch.float32, 1e-3), (torch.bfloat16, 3e-2)]
+BF16_E2E_TOL, BF16_E2E_RMS = 2e-2, 8e-3        # full-size end-to-end bf16 gates (measured 1.5e-2 max-rel on the bench frame)
 
 
 def dev(m, cuda):
@@ -242,18 +243,40 @@ def test_corpbevt_full_config_vs_oracle(cuda, agents):
     cfg = synth.corpbevt_config()
     m = fill_module_(host.CorpBEVT(copy.deepcopy(cfg)), cases.SEED).eval()
     batch = synth.opv2v_batch(agents=agents, seed=cases.SEED)
-    ref = o_model.corpbevt_forward(m.state_dict(), cfg, batch)["dynamic_seg"]
+    ref_all = o_model.corpbevt_forward(m.state_dict(), cfg, batch, return_intermediates=True)
+    ref = ref_all["dynamic_seg"]
     m = m.to(cuda)
     b = {k: v.to(cuda) for k, v in batch.items()}
-    with host.compute_dtype(torch.float32):
-        y32 = m(dict(b))["dynamic_seg"]
-    with host.compute_dtype(torch.bfloat16):
-        y16 = m(dict(b))["dynamic_seg"]
+    got = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        m.taps, m.fax.taps = {}, {}
+        with host.compute_dtype(dtype):
+            y = m(dict(b))["dynamic_seg"]
+        got[dtype] = dict(m.taps, logits=y, **{"fax_" + k: v for k, v in m.fax.taps.items()})
+    m.taps = m.fax.taps = None
+    y32, y16 = got[torch.float32]["logits"], got[torch.bfloat16]["logits"]
     e32, e16 = rel_err(y32, ref), rel_err(y16, ref)
-    a32, a16 = _argmax_agreement(y32.cpu(), ref), _argmax_agreement(y16.cpu(), ref)
-    print("full CorpBEVT %d agents: fp32 rel %.2e argmax %.5f | bf16 rel %.2e argmax %.5f" % (agents, e32, a32, e16, a16))
-    assert e32 <= 1e-3 and a32 >= 0.999
-    assert e16 <= 5e-2 and a16 >= 0.98
+    r32, r16 = rms_rel_err(y32, ref), rms_rel_err(y16, ref)
+    s32, s16 = class_margin_stats(y32, ref, 2), class_margin_stats(y16, ref, 2)
+    print("full CorpBEVT %d agents: fp32 max-rel %.2e rms-rel %.2e argmax %.5f | bf16 max-rel %.2e rms-rel %.2e argmax %.5f decisive %.5f "
+          "worst flipped margin %.4f" % (agents, e32, r32, s32["agreement"], e16, r16, s16["agreement"], s16["decisive_agreement"],
+                                         s16["worst_flipped_margin"]))
+    assert e32 <= 1e-3 and r32 <= 1e-4 and s32["agreement"] >= 0.999
+    # bf16 gates sit at <= 1.5x the values measured on MI355X (max-rel 1.5e-2 / rms-rel 4e-3 on this frame)
+    assert e16 <= BF16_E2E_TOL and r16 <= BF16_E2E_RMS and s16["agreement"] >= 0.98
+    assert s16["decisive_agreement"] >= 0.9999 and s16["worst_flipped_margin"] <= 0.03
+    # intermediate tensors, not only the logits: every pyramid level's BEV query, the per-agent features V2V sharing transmits,
+    # the warped maps and the fused BEV map (oracle tensors are channels-first)
+    for dtype, tol, rms in ((torch.float32, 1e-3, 1e-4), (torch.bfloat16, BF16_E2E_TOL, BF16_E2E_RMS)):
+        g = got[dtype]
+        pairs = [("fax_level%d" % i, g["fax_level%d" % i].permute(0, 3, 1, 2), ref_all["fax_level%d" % i]) for i in range(3)]
+        pairs.append(("agent features", g["feats"].permute(0, 3, 1, 2), ref_all["fax"]))
+        pairs.append(("sttf", g["sttf"], ref_all["sttf"]))
+        pairs.append(("fused", g["fused"].permute(0, 3, 1, 2), ref_all["fused"]))
+        for name, a, r in pairs:
+            e, q = rel_err(a, r), rms_rel_err(a, r)
+            print("   %-16s %s max-rel %.2e rms-rel %.2e" % (name, str(dtype).split(".")[-1], e, q))
+            assert e <= tol and q <= rms, "%s (%s): max-rel %.3e rms-rel %.3e" % (name, dtype, e, q)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])

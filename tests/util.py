@@ -21,9 +21,46 @@ def rel_err(got, ref):
     return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
 
 
+def rms_rel_err(got, ref):
+    """||got - ref||_2 / ||ref||_2: the AVERAGE error on the output's own scale.  The max-norm above cannot see an error that sits
+    on low-magnitude entries (small logits); this one cannot see a single bad entry - the gates use both."""
+    got = torch.as_tensor(got).detach().double().cpu()
+    ref = torch.as_tensor(ref).detach().double().cpu()
+    return ((got - ref).square().sum().sqrt() / ref.square().sum().sqrt().clamp_min(1e-30)).item()
+
+
+def class_margin_stats(got, ref, class_dim):
+    """logit tensors (classes along `class_dim`): arg-max agreement over all positions, over the positions whose REFERENCE
+    top-1 / top-2 margin exceeds 2 % of the logit scale ("decisive" positions: a flip there is an error, not a tie), and the
+    largest reference margin at which the arg-max flipped (0.0 if none did), as a fraction of the logit scale."""
+    got = torch.as_tensor(got).detach().float().cpu().movedim(class_dim, -1)
+    ref = torch.as_tensor(ref).detach().float().cpu().movedim(class_dim, -1)
+    scale = ref.abs().max().clamp_min(1e-12)
+    top2 = ref.topk(2, dim=-1).values
+    margin = (top2[..., 0] - top2[..., 1]) / scale
+    same = got.argmax(-1) == ref.argmax(-1)
+    decisive = margin > 0.02
+    flipped = margin[~same]
+    return {"agreement": same.float().mean().item(),
+            "decisive_agreement": same[decisive].float().mean().item() if decisive.any() else 1.0,
+            "decisive_fraction": decisive.float().mean().item(),
+            "worst_flipped_margin": flipped.max().item() if flipped.numel() else 0.0}
+
+
+# bf16 gates: the max-norm tolerance a test passes is the CAP; the average error must be far below it.  fp32: rms <= tol too.
+RMS_FRACTION = {True: 0.4, False: 1.0}           # keyed by "tol is a bf16 gate" (tol > 2e-3)
+_REPORT = os.environ.get("COBEVT_PARITY_REPORT")
+
+
 def assert_close(got, ref, tol, what):
     e = rel_err(got, ref)
+    r = rms_rel_err(got, ref)
+    if _REPORT:                      # measured values next to their gates: how the gates in the tests were set
+        with open(_REPORT, "a") as f:
+            f.write("%s\t%s\tmax_rel=%.3e\trms_rel=%.3e\tgate=%.1e\n" % (os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], what, e, r, tol))
     assert e <= tol, "%s: rel err %.3e > %.1e" % (what, e, tol)
+    rms_gate = tol * RMS_FRACTION[tol > 2e-3]
+    assert r <= rms_gate, "%s: rms rel err %.3e > %.1e" % (what, r, rms_gate)
     return e
 
 

@@ -28,6 +28,15 @@ def main():
         a[0] += 1
         a[1] += (e - s) / 1e3
     tot = sum(a[1] for a in agg.values())
+    # the per-frame normaliser: a CoBEVT frame launches the stem (+ pool) kernel exactly once, so its dispatch count IS the
+    # number of traced frames; --frames only overrides that when the trace has no such kernel (operator-level workloads).  A
+    # disagreement between the two is reported instead of silently dividing by the wrong number
+    once = [a[0] for k, a in agg.items() if k.startswith("stem_pool_kernel") or k.startswith("stem7x7_kernel")]
+    if once:
+        counted = sum(once)
+        if "--frames" in sys.argv and frames != counted:
+            print("note: --frames %d ignored, the trace holds %d frames (stem launches)" % (frames, counted))
+        frames = counted
     print("%d dispatches, %.1f us of kernel time (%.1f us per frame over %d frames)" % (len(rows), tot, tot / frames, frames))
     print("%10s %6s %6s %9s  %4s %4s %6s %5s  %s" % ("total_us", "calls", "%", "avg_us", "vgpr", "agpr", "lds", "scr", "kernel"))
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
