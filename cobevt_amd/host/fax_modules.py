@@ -282,19 +282,25 @@ class CrossViewSwapAttention(HipModule):
         w_cam = rt.f32_param(self, "w_cam", self.cam_embed.weight, (d, 4))
         img = ops.ray_embed(I_inv, E_inv, plane, w_img, w_cam, h * w, d, dt).reshape(bn, h, w, d)
 
-        def kv_buffer():
-            return torch.zeros((bn, hp, wp, d), device=feature.device, dtype=dt) if padded else None
+        def kv_buffer(tag):
+            """zero-padded (bn, hp, wp, d) map whose interior the convolution's epilogue writes.  The pad rows / columns are
+            zeroed ONCE: the buffer is a per-module scratch map (only read by the two GEMMs below, in this call), so a
+            replayed HIP graph holds no fill kernel for it"""
+            if not padded:
+                return None
+            return self._plan("kvpad.%s.%dx%dx%d" % (tag, bn, hp, wp), [self.img_embed.weight],
+                              lambda dt_, dev: torch.zeros((bn, hp, wp, d), device=feature.device, dtype=dt))
 
         if self.feature_proj is not None:
             key = ops.conv2d(feature, rt.conv_plan(self, "fproj", self.feature_proj[2], pre_bn=self.feature_proj[0]),
-                             residual=img, out=kv_buffer())
+                             residual=img, out=kv_buffer("key"))
         elif padded:
-            key = kv_buffer()
+            key = kv_buffer("key")
             key[:, :h, :w] = img
         else:
             key = img
         val = ops.conv2d(feature, rt.conv_plan(self, "flin", self.feature_linear[2], pre_bn=self.feature_linear[0]),
-                         out=kv_buffer())
+                         out=kv_buffer("val"))
         o = out if out is not None else {}      # optional preallocated {"kk", "vv"} buffers
         # to_k of both attentions read the same `key` rows (to_v: `val`): one GEMM each with the two weight matrices
         # stacked (each LayerNorm's affine folded into its half; the normalisation itself is shared) -> (.., 2*inner);

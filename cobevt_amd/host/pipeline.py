@@ -116,6 +116,43 @@ class CapturedCorpBEVT(_RunnerBase):
         return self.out
 
 
+class AgentCountPlans(object):
+    """One captured plan per frame shape behind ONE `step(batch)`.  Real OPV2V frames carry 1..max_cav agents
+    (intermediate_fusion_dataset.py:261-295 concatenates the agents present, `record_len` says how many; regroup pads to
+    max_cav, fuse_utils.py:8-61), while a captured HIP graph fixes (agents, cameras, image size).  A serving loop therefore
+    keeps one `CapturedCorpBEVT` per shape it has seen - captured on first use from that frame, replayed afterwards - and
+    dispatches on the incoming batch.  `step(batch)` equals `model(batch)` bit for bit for every agent count.
+
+    max_plans bounds the cache (least recently used plan dropped; its graphs and static buffers are freed)."""
+
+    def __init__(self, model, use_graph=True, max_plans=8, prewarm=None):
+        self.model, self.use_graph, self.max_plans = model, use_graph, int(max_plans)
+        self.plans = {}            # key -> CapturedCorpBEVT, insertion order = recency
+        self.captures = 0
+        for b in (prewarm or []):  # capture ahead of time (e.g. one synthetic frame per agent count) instead of on first sight
+            self._runner(b)
+
+    @staticmethod
+    def key(batch):
+        rl = batch["record_len"]
+        n_scen = int(rl.numel()) if torch.is_tensor(rl) else len(rl)
+        return (tuple(batch["inputs"].shape), n_scen, tuple(batch["transformation_matrix"].shape))
+
+    def _runner(self, batch):
+        k = self.key(batch)
+        r = self.plans.pop(k, None)
+        if r is None:
+            r = CapturedCorpBEVT(self.model, batch, use_graph=self.use_graph)
+            self.captures += 1
+            while len(self.plans) >= self.max_plans:
+                self.plans.pop(next(iter(self.plans)))
+        self.plans[k] = r
+        return r
+
+    def step(self, batch):
+        return self._runner(batch).step(batch)
+
+
 class PipelinedCorpBEVT(_RunnerBase):
     """Several frames in flight on ONE GPU.  A CoBEVT frame is ~1.2 ms of camera encoder that fills the chip followed by
     ~1 ms of FAX query path, swap fusion and decoder whose ~100 dependent launches are latency-bound and leave most CUs idle.
@@ -134,12 +171,20 @@ class PipelinedCorpBEVT(_RunnerBase):
         if depth not in (3, 4):
             raise CobevtHipError("PipelinedCorpBEVT: depth must be 3 or 4")
         self.depth = D = depth
-        st = model.encode_trunk(dict(self._images))
+        # The small per-frame inputs (camera matrices, poses, record_len) are consumed up to `depth` steps after the images, so
+        # they live in RINGS of `depth` slots that `load()` fills from the host side: graph q reads slot q for its encoder
+        # stage and the slots of the earlier frames for its later stages - no copy of them inside the replayed graph.
+        # `static_batch` (the public "write your next frame here" dict) always points at the slot of the NEXT step.
+        sb = self.static_batch
+        self.slots = [sb] + [{k: v.clone() for k, v in sb.items() if k != "inputs"} for _ in range(D - 1)]
+        for sl in self.slots[1:]:
+            sl["inputs"] = sb["inputs"]                       # the images are consumed within the step: one buffer
+        st = model.encode_trunk(self._images_of(0))
         torch.cuda.synchronize()
         self.meta = [{k: v for k, v in lvl.items() if not torch.is_tensor(v)} for lvl in st["kv"]]
         self.batch = st["batch"]
         self.kv = [[{k: torch.empty_like(v) for k, v in lvl.items() if torch.is_tensor(v)} for lvl in st["kv"]] for _ in range(D)]
-        self.einv = [torch.empty_like(st["E_inv"]) for _ in range(D)]
+        self.einv = [None] * D                                # E_inv of slot q as encode_trunk derives it (a view of the ring slot)
         x0 = model.fax_query(st, levels=(0, 1))
         self.x = [torch.empty_like(x0) for _ in range(D)] if depth == 4 else None
         feats = model.fax_query(st, levels=(1, len(st["kv"])), x=x0)
@@ -150,40 +195,54 @@ class PipelinedCorpBEVT(_RunnerBase):
         self.g = self.f if world == 1 else [torch.empty_like(feats) for _ in range(D)]
         self.lag = 1 if world == 1 else 2                     # fusion of step q reads the features of slot q - lag
         self.latency_steps = D if world == 1 else D + 1
-        # pose / record_len of a frame are consumed latency_steps - 1 steps after its images: S1 parks them in ring `pose`;
-        # with the gather's extra step the consumer's slot is the one S1 rewrites in the same step -> staged copy `pose_s3`
-        self.pose = [self.static_batch["transformation_matrix"].clone() for _ in range(D)]
-        self.rlen = [self.static_batch["record_len"].clone() for _ in range(D)]
-        self.pose_s3 = [t.clone() for t in self.pose] if world > 1 else None
-        self.rlen_s3 = [t.clone() for t in self.rlen] if world > 1 else None
+        # with the gather's extra step the pose slot fusion needs is the one `load()` rewrites for the same step -> the graph
+        # parks it in a staged copy first (multi-GPU only)
+        self.pose_s3 = [sl["transformation_matrix"].clone() for sl in self.slots] if world > 1 else None
+        self.rlen_s3 = [sl["record_len"].clone() for sl in self.slots] if world > 1 else None
         self.comm = torch.cuda.Stream() if world > 1 else None
         self.gathered = [None] * D
         self.out, self.graphs = None, None
         self.i = self.filled = 0
         self.capture()
 
+    def _images_of(self, slot):
+        return {k: self.slots[slot][k] for k in _IMAGE_KEYS}
+
+    @property
+    def _next_slot(self):
+        return self.i % self.depth
+
+    def load(self, batch):
+        """copy the caller's frame into the input buffers of the next step's slot (no-op for tensors that already are them)"""
+        self.static_batch = self.slots[self._next_slot]
+        super().load(batch)
+
     def _state(self, slot):
         return {"kv": [dict(self.meta[i], **self.kv[slot][i]) for i in range(len(self.meta))],
                 "E_inv": self.einv[slot], "batch": self.batch}
 
     def _s1(self, slot):
-        st = self.model.encode_trunk(dict(self._images), kv_out=self.kv[slot])      # K/V land in the slot directly
+        st = self.model.encode_trunk(self._images_of(slot), kv_out=self.kv[slot])      # K/V land in the slot directly
         main = torch.cuda.current_stream()
         for level, lvl in enumerate(st["kv"]):
             main.wait_stream(st["side"][level])
             for k, v in lvl.items():
                 if torch.is_tensor(v) and v.data_ptr() != self.kv[slot][level][k].data_ptr():
                     self.kv[slot][level][k].copy_(v)
-        self.einv[slot].copy_(st["E_inv"])       # E_inv may alias the static input buffer the next frame overwrites
-        self.pose[slot].copy_(self.static_batch["transformation_matrix"])
-        self.rlen[slot].copy_(self.static_batch["record_len"])
+        e = st["E_inv"]
+        if e.data_ptr() != self.slots[slot]["extrinsic"].data_ptr():     # encode_trunk had to convert it: keep the result per slot
+            if self.einv[slot] is None or self.einv[slot].data_ptr() == self.slots[slot]["extrinsic"].data_ptr():
+                self.einv[slot] = torch.empty_like(e)
+            self.einv[slot].copy_(e)
+        else:
+            self.einv[slot] = e                                           # a view of the ring slot: nothing to copy
 
     def _s3(self, q):
         """fusion + decoder of the frame whose images were submitted latency_steps - 1 steps before step q"""
         feats = self.g[(q - self.lag) % self.depth]
         if self.world == 1:
-            src = (q - (self.latency_steps - 1)) % self.depth          # written by S1 one graph replay (or more) ago
-            return self.model.fuse_and_decode(feats, self.pose[src], self.rlen[src])
+            src = self.slots[(q - (self.latency_steps - 1)) % self.depth]       # filled by load() latency_steps - 1 steps ago
+            return self.model.fuse_and_decode(feats, src["transformation_matrix"], src["record_len"])
         return self.model.fuse_and_decode(feats, self.pose_s3[q], self.rlen_s3[q])
 
     def _exchange(self, q):
@@ -208,9 +267,10 @@ class PipelinedCorpBEVT(_RunnerBase):
         """slot q = step index mod depth: S1 writes kv[q]; the later stages read the slots written 1, 2, .. steps ago"""
         D = self.depth
         main = torch.cuda.current_stream()
-        if self.world > 1:        # pose slot q still holds the frame of `depth` steps ago until S1 (below) rewrites it
-            self.pose_s3[q].copy_(self.pose[q])
-            self.rlen_s3[q].copy_(self.rlen[q])
+        if self.world > 1:        # (see __init__) the frame fused in step q + 1 was loaded into slot q + 1 `depth` steps ago
+            nxt = (q + 1) % D
+            self.pose_s3[nxt].copy_(self.slots[nxt]["transformation_matrix"])
+            self.rlen_s3[nxt].copy_(self.slots[nxt]["record_len"])
         for s in self.streams:
             s.wait_stream(main)
         nlev = len(self.meta)
