@@ -184,7 +184,9 @@ class PipelinedCorpBEVT(_RunnerBase):
         self.meta = [{k: v for k, v in lvl.items() if not torch.is_tensor(v)} for lvl in st["kv"]]
         self.batch = st["batch"]
         self.kv = [[{k: torch.empty_like(v) for k, v in lvl.items() if torch.is_tensor(v)} for lvl in st["kv"]] for _ in range(D)]
-        self.einv = [None] * D                                # E_inv of slot q as encode_trunk derives it (a view of the ring slot)
+        # E_inv of slot q as encode_trunk derives it: a view of the ring slot when the extrinsics are fp32 (OPV2V passes them
+        # un-inverted, fax_modules.py:502-503), so the later stages of later steps read the slot itself
+        self.einv = [model.fax._extrinsic(sl["extrinsic"].reshape(-1, 4, 4).to(torch.float32)).contiguous() for sl in self.slots]
         x0 = model.fax_query(st, levels=(0, 1))
         self.x = [torch.empty_like(x0) for _ in range(D)] if depth == 4 else None
         feats = model.fax_query(st, levels=(1, len(st["kv"])), x=x0)
@@ -406,6 +408,7 @@ class FrameShardedCorpBEVT(object):
             self.staging = torch.zeros((self.slots,) + block, device=dev, dtype=feats.dtype)
             self.full = [torch.zeros((self.agents,) + block, device=dev, dtype=feats.dtype) for _ in range(depth)]
         self.empty = feats[:0]
+        self.feats = [self.empty] * depth        # slot q: the features the encoder of step q produced (graph q's own buffer)
         self.i = self.filled = 0
         self.side = torch.cuda.Stream(device=dev) if depth == 2 else None
         for q in range(2 * depth):
@@ -433,9 +436,9 @@ class FrameShardedCorpBEVT(object):
         main = torch.cuda.current_stream()
         if self.depth == 1:
             if stage in (None, "a"):
-                self.feats = self._encode() if self.mine else self.empty
+                self.feats[q] = self._encode() if self.mine else self.empty
             if stage is None:
-                self._exchange(self.feats, 0)
+                self._exchange(self.feats[0], 0)
             if stage in (None, "b"):
                 self.outs[0] = self._fuse(0)
             return
@@ -444,9 +447,9 @@ class FrameShardedCorpBEVT(object):
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
             self.outs[prev] = self._fuse(prev)
-        self.feats = self._encode() if self.mine else self.empty
+        self.feats[q] = self._encode() if self.mine else self.empty
         if stage is None:
-            self._exchange(self.feats, q)
+            self._exchange(self.feats[q], q)
         main.wait_stream(self.side)
 
     def eager_step(self):
@@ -500,7 +503,7 @@ class FrameShardedCorpBEVT(object):
         else:
             if gs[0] is not None:
                 gs[0].replay()
-            self._exchange(self.feats, q)
+            self._exchange(self.feats[q], q)
             if self.depth == 1:
                 gs[1].replay()
         return self._finish(q)

@@ -96,11 +96,29 @@ def _attn_ffd(attn_res, ffd_res, x, mask, mode, qkv=None, next_attn=None):
     qkv: this attention's to_qkv(norm(x)) if the previous stage already produced it; next_attn: the PreNormResidual
     (Attention) that consumes the result - its norm + to_qkv then ride in this stage's launch and (x, qkv) is returned."""
     attn, ffd = attn_res.fn, ffd_res.fn
-    a = attn.forward_fused(x, mask=mask, mode=mode, ln=attn_res.norm, core_only=True, qkv=qkv)
     nxt = next_attn.fn.qkv_plan(next_attn.norm) if next_attn is not None else None
-    return ops.attn_mlp_chain(a, x, rt.linear_plan(attn, "out", attn.to_out[0]),
-                              rt.linear_plan(ffd, "fc1", ffd.net[0], act=2, ln=ffd_res.norm),
-                              rt.linear_plan(ffd, "fc2", ffd.net[3]), next_plan=nxt)
+    plan_p = rt.linear_plan(attn, "out", attn.to_out[0])
+    plan_1 = rt.linear_plan(ffd, "fc1", ffd.net[0], act=2, ln=ffd_res.norm)
+    plan_2 = rt.linear_plan(ffd, "fc2", ffd.net[3])
+    if x.dim() == 5 and mode in (0, 1):
+        b, l, H, W, d = x.shape
+        L, w = attn.window_size[0], attn.window_size[1]
+        if l == L and H % w == 0 and W % w == 0:
+            tmap = ops.tokmap(mode, l, H, W, w, w)
+            mk = None
+            if mask is not None:
+                mk = mask.to(torch.float32)
+                mk = mk if mk.is_contiguous() else mk.contiguous()
+            if qkv is None and x.dtype == torch.bfloat16:
+                qkv = ops.linear(x, attn.qkv_plan(attn_res.norm))
+            if qkv is not None and ops.swap_stage_fusable(qkv, x, tmap, attn.heads, plan_p, plan_1, plan_2, nxt, mk):
+                # the whole half in ONE launch: attention core, to_out + residual, pre-norm FeedForward + residual, and the
+                # next half's LayerNorm + to_qkv (csrc/swap_stage.hip)
+                table = rt.f32_param(attn, "table", attn.relative_position_bias_table.weight)
+                out, qn = ops.swap_stage(qkv, x, tmap, b, attn.heads, attn.scale, table, L, mk, plan_p, plan_1, plan_2, nxt)
+                return (out, qn) if nxt is not None else out
+    a = attn.forward_fused(x, mask=mask, mode=mode, ln=attn_res.norm, core_only=True, qkv=qkv)
+    return ops.attn_mlp_chain(a, x, plan_p, plan_1, plan_2, next_plan=nxt)
 
 
 def _run_stages(stages, x, mask_of):

@@ -81,6 +81,8 @@ SIGNATURES = {
     "cobevt_depthwise_conv_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_spatial_mean_nhwc": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "cobevt_se_gate": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    "cobevt_swap_fusion_stage": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int_p,
+                                                ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
     "cobevt_peer_window_alloc": (ctypes.c_int, [ctypes.c_long, ctypes.POINTER(_vp), _vp]),
     "cobevt_peer_window_open": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "cobevt_peer_window_close": (ctypes.c_int, [_vp]),

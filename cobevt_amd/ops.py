@@ -40,6 +40,7 @@ USE_EMBED_GEMM3 = False   # the BEV query produced inside the 32-row GEMM that p
 # coefficient reads + ~400 VALU per thread cost more than the 170 MB of HBM traffic they save; kept for parity tests
 USE_CHAIN_NEXT = True  # ... and let the row-local GEMM that consumes its output next ride in the same launch
 USE_HEAD_CONV = True    # 3x3 convs with <= 4 output channels to NCHW fp32 logits (BevSegHead) on the direct kernel
+USE_SWAP_STAGE = True   # a SwapFusionBlock half (attention + row chain + next to_qkv) as one launch (swap_stage.hip)
 USE_BOTTLENECK = True   # FAX ResNetBottleNeck (128 -> 32 -> 32 -> 128) as one launch (bottleneck.hip) instead of three
 ATTN_VARIANT = 0    # 0 = automatic (K/V-resident attention kernel where it applies), 1 = always the streaming kernel, 2 = ... with 64-key tiles (A/B runs)
 ATTN_QSPLIT = 0     # 0 = automatic query split of the resident attention kernel; > 0 pins it (tools/attn_probe.py)
@@ -974,6 +975,49 @@ def attn_mlp_chain(a, skip, plan_p, plan_1, plan_2, post_ln=None, next_plan=None
     if next_plan is None:
         return out
     return out, (out_next if fuse_next else linear(out, next_plan))
+
+
+def swap_stage_fusable(qkv, x, tmap, heads, plan_p, plan_1, plan_2, next_plan, mask):
+    """does one SwapFusionBlock half fit the single-launch kernel (cobevt_swap_fusion_stage)?"""
+    c = x.shape[-1]
+    nk = tmap[1] * tmap[4] * tmap[5]
+    return (USE_SWAP_STAGE and x.dtype == torch.bfloat16 and qkv.dtype == torch.bfloat16 and c == 128 and heads == 4
+            and tmap[0] in (0, 1) and nk <= 384 and x.is_contiguous() and qkv.is_contiguous() and qkv.shape[-1] == 3 * c
+            and plan_p.wfrag_rows is not None and plan_1.wfrag_rows is not None and plan_2.wfrag_rows is not None
+            and plan_p.kp_rows == 128 and plan_1.kp_rows == 128 and plan_2.kp_rows in (128, 256) and plan_1.has_ln
+            and plan_1.act == 2 and plan_p.act == 0 and plan_2.act == 0 and not plan_p.has_ln and not plan_2.has_ln
+            and plan_p.K == c and plan_1.K == c and plan_2.K == plan_1.cout and plan_2.cout == c and plan_1.cout % 8 == 0
+            and plan_1.cout <= 256 and plan_p.cout == c
+            and (next_plan is None or (chain_next_fusable(next_plan, c) and next_plan.cout <= 384 and next_plan.has_ln
+                                       and next_plan.act == 0))
+            and (mask is None or (mask.dtype == torch.float32 and mask.is_contiguous())))
+
+
+def swap_stage(qkv, x, tmap, batch, heads, scale, bias_table, bias_L, mask, plan_p, plan_1, plan_2, next_plan=None):
+    """One SwapFusionBlock half: x (b, l, h, w, 128) + its qkv = to_qkv(LN(x)) (b, l, h, w, 384) -> x_out (and the next
+    half's to_qkv(LN(x_out)) when next_plan is given).  Caller checks swap_stage_fusable() first."""
+    _need_cuda(qkv, x, bias_table, mask)
+    c, hd = 128, plan_1.cout
+    out = torch.empty_like(x)
+    nn_ = next_plan.cout if next_plan is not None else 0
+    qkv_next = torch.empty(x.shape[:-1] + (nn_,), device=x.device, dtype=x.dtype) if next_plan is not None else None
+    dims = _ints([0, batch, c, heads, hd, plan_2.kp_rows, nn_, bias_table.shape[0], bias_L])
+    m = x.numel() // c
+    nk = tmap[1] * tmap[4] * tmap[5]
+
+    def cost():
+        flops = 4.0 * m * nk * c + 2.0 * m * (c * c + 2 * c * hd + c * nn_)
+        return flops, float(m * (3 * c + 2 * c + nn_) * 2 + (c * c + 2 * c * hd + c * nn_) * 2)
+
+    with _timed("swap_stage|mode%d M=%d Nk%d H%d%s" % (tmap[0], m, nk, hd, " +next%d" % nn_ if nn_ else ""), cost):
+        rc = _L.load().cobevt_swap_fusion_stage(
+            _p(qkv), _p(x), _p(out), _p(qkv_next), _ints(tmap), _p(bias_table), _p(mask), _p(plan_p.wfrag_rows), _p(plan_p.bias),
+            _p(plan_1.wfrag_rows), _p(plan_1.bias), _p(plan_2.wfrag_rows), _p(plan_2.bias),
+            _p(next_plan.wfrag_rows) if next_plan is not None else None, _p(next_plan.bias) if next_plan is not None else None,
+            dims, ctypes.c_float(scale), ctypes.c_float(plan_1.ln_eps), ctypes.c_float(next_plan.ln_eps if next_plan is not None else 0.0),
+            _stream())
+    _L.check(rc, "cobevt_swap_fusion_stage")
+    return out, qkv_next
 
 
 # ----------------------------------------------------------------------------------------------

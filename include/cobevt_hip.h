@@ -412,6 +412,25 @@ int cobevt_se_gate(const float* mean, const float* w_reduce, const float* b_redu
 int cobevt_channel_gate_nhwc(const void* in, const float* gate, void* out, int dtype, int N, int hw, int C,
                              hipStream_t stream);
 
+/*
+ * One half of a SwapFusionBlock in ONE launch (bf16 mode, 128 channels = 4 heads of 32): PreNormResidual(Attention) +
+ * PreNormResidual(FeedForward) over the window (map mode 0) or dilated-grid (mode 1) partition of (B, L, H, W, 128) agent maps
+ * = opv2v/opencood/models/fusion_modules/swap_fusion_modules.py:87-128 (attention with the 3-D relative position bias and the
+ * key mask), :126,172-190 (to_out, residuals, rearranges) and base_transformer.py:102-124 (PreNormResidual / FeedForward), plus
+ * the LayerNorm + to_qkv (:93) of the NEXT half while the rows are in LDS.  A workgroup carries 32 query tokens of one
+ * window / grid group through attention (one wave per head, K rows straight from L2, V^T in LDS) and the row chain; the
+ * attention output never reaches memory (csrc/swap_stage.hip).
+ * qkv [rows][384] = to_qkv(LayerNorm(x)) (q | k | v), x / out [rows][128], qkv_next [rows][Nn] (nullable with wn / bn);
+ * rows = (b, l, h, w).  map (int32[8]): mode, L, H, W, w1, w2, X, Y as for cobevt_window_attention.  bias_table
+ * [(2L-1)(2w1-1)(2w2-1)][4] fp32; mask (B, H, W, L) fp32 (0 = key masked out) or null.  Weights in MFMA fragment order as for
+ * cobevt_attn_mlp_chain (wp: to_out, w1 / b1: fc1 with the LayerNorm affine folded in, w2 / b2: fc2, wn / bn: next to_qkv
+ * with its LayerNorm folded in).  dims (int32[9]): dtype (0), B, C (128), heads (4), Hd, Hdp, Nn, bias_rows, bias_L.
+ */
+int cobevt_swap_fusion_stage(const void* qkv, const void* x, void* out, void* qkv_next, const int* map,
+                             const float* bias_table, const float* mask, const void* wp, const float* bp, const void* w1,
+                             const float* b1, const void* w2, const float* b2, const void* wn, const float* bn,
+                             const int* dims, float scale, float eps1, float eps_next, hipStream_t stream);
+
 /* ---- multi-GPU: the V2V feature-sharing step in front of FuseBEVT.  The reference keeps all agents in one
  * process (opv2v/opencood/models/corpbevt.py:112-124, sub_modules/fuse_utils.py:8-61: agents are a batch dimension up to
  * `regroup`); its only collective call sites are the DDP set-up in opv2v/opencood/tools/multi_gpu_utils.py:32-37 and

@@ -1,7 +1,7 @@
 """GPU parity of the HIP-backed host modules against the oracle and the reference's golden vectors.
 
-Gates (north-star): fp32 mode <= 1e-3 rel of the output scale; bf16 mode <= 3e-2 rel on single operators,
-and for end-to-end logits <= 5e-2 rel + >= 99% arg-max agreement (a bf16 pipeline cannot meet
+Gates (north-star): fp32 mode <= 1e-3 rel of the output scale; bf16 mode at <= 1.5x the measured errors (tests/util.py:
+1.5e-2 rel on single operators, 2e-2 on full-size and 4.5e-2 on reduced-size end-to-end logits; max-norm AND rms-norm) + >= 99% arg-max agreement (a bf16 pipeline cannot meet
 1e-3 against an fp32 reference; the 1e-3 gate is the fp32-I/O mode).
 """
 import copy
@@ -15,12 +15,12 @@ from cobevt_amd import host, synth
 from cobevt_amd.synth import fill_module_
 import oracle.corpbevt as o_model
 import oracle.fax as o_fax
-from util import assert_close, class_margin_stats, golden, rel_err, rms_rel_err
+from util import BF16_NUSC_E2E, BF16_OP, BF16_SMALL_E2E, assert_close, class_margin_stats, golden, rel_err, rms_rel_err
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
-MODES = [(torch.float32, 1e-3), (torch.bfloat16, 3e-2)]
+MODES = [(torch.float32, 1e-3), (torch.bfloat16, BF16_OP)]
 BF16_E2E_TOL, BF16_E2E_RMS = 2e-2, 8e-3        # full-size end-to-end bf16 gates (measured 1.5e-2 max-rel on the bench frame)
 
 
@@ -160,7 +160,7 @@ def _argmax_agreement(a, b, margin=0.0):
     return float(same.float().mean().item())
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16_SMALL_E2E)])
 def test_corpbevt_small_end_to_end(cuda, dtype, tol):
     """GV8: the reference's own output for the reduced CorpBEVT, through the registry, both models."""
     from cobevt_amd.registry import create_model
@@ -188,7 +188,7 @@ def test_corpbevt_small_end_to_end(cuda, dtype, tol):
     assert_close(out2["dynamic_seg"], golden("gv8_fax_fused_small")["dynamic_seg"], tol, "FaxFusedTransformer.small")
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16_SMALL_E2E)])
 def test_corpbevt_ragged_scenarios_vs_oracle(cuda, dtype, tol):
     """a training-style batch of several scenarios with different agent counts (collate_batch concatenates the agents of
     all scenarios, record_len says how many belong to each, intermediate_fusion_dataset.py:261-295): regroup pads every
@@ -217,7 +217,7 @@ def test_corpbevt_ragged_scenarios_vs_oracle(cuda, dtype, tol):
     assert_close(alone[0], out[1].cpu().numpy(), tol, "scenario independent of its batch neighbours")
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16_SMALL_E2E)])
 def test_naive_compressor_and_compressed_corpbevt(cuda, dtype, tol):
     """GV13: the reference's NaiveCompressor output and its reduced CorpBEVT with compression = 2"""
     g = golden("gv13_naive_compressor")
@@ -226,7 +226,7 @@ def test_naive_compressor_and_compressed_corpbevt(cuda, dtype, tol):
     with host.compute_dtype(dtype):
         y = comp(x.to(cuda))
     assert y.dtype == torch.float32
-    assert_close(y, g["compressor"], 3e-2 if dtype == torch.bfloat16 else tol, "NaiveCompressor")
+    assert_close(y, g["compressor"], BF16_OP if dtype == torch.bfloat16 else tol, "NaiveCompressor")
     cfg = synth.corpbevt_small_compressed_config(2)
     m = dev(fill_module_(host.CorpBEVT(copy.deepcopy(cfg)), cases.SEED), cuda)
     batch = synth.opv2v_batch(agents=2, cams=2, image=128, max_cav=3, seed=cases.SEED)
@@ -279,7 +279,7 @@ def test_corpbevt_full_config_vs_oracle(cuda, agents):
             assert e <= tol and q <= rms, "%s (%s): max-rel %.3e rms-rel %.3e" % (name, dtype, e, q)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16_NUSC_E2E)])
 def test_nuscenes_sinbevt(cuda, dtype, tol):
     """BASELINE config[1]: nuScenes SinBEVT, 1 ego x 6 cams (EfficientNet-B4-shaped features of 224x480 images),
     200x200 BEV, non-square 6x12 / 14x30 key windows on zero-padded maps, heads 1/2/4 — vs the reference's outputs."""
@@ -301,7 +301,7 @@ def test_nuscenes_sinbevt(cuda, dtype, tol):
     assert np.allclose(nrm[:, :, ::37, ::41].cpu().numpy(), g["normalized_image_sample"], atol=1e-5)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16_OP)])
 def test_lidar_shaped_fusebevt(cuda, dtype, tol):
     """BASELINE config[4] operator config (SwapFusionEncoder input_dim 64, 8 agents, window 8, depth 3, mask: 512 tokens
     per window, 2 heads, 3375-row 3-D bias table) on a reduced 32x32 map, against the oracle."""
@@ -341,7 +341,7 @@ def test_lidar_fusebevt_full_size(cuda):
     ref = o_swap.swap_fusion_encoder(enc.state_dict(), "", args, x, mask)
     enc = enc.to(cuda)
     xd, md = x.to(cuda), mask.to(cuda)
-    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, 3e-2)):
+    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, BF16_OP)):
         with host.compute_dtype(dtype):
             y = enc(xd, md)
         assert tuple(y.shape) == (1, 64, 256, 256)
@@ -363,7 +363,7 @@ def test_lidar_fusebevt_full_size(cuda):
     assert not torch.equal(outs[0][:, 6:], outs[1][:, 6:])
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16_SMALL_E2E)])
 @pytest.mark.parametrize("kind,core", [("single", "cross_view_transformer"), ("swap_fuse", "cross_view_transformer_swap_fuse"),
                                        ("fcooper", "cross_view_transformer_fcooper"),
                                        ("att_fuse", "cross_view_transformer_att_fuse"),
@@ -383,7 +383,7 @@ def test_cvt_baseline_models(cuda, dtype, tol, kind, core):
         if kind == "single":
             feats = m.encoder(b["inputs"])
             cvm = m.cvm({"inputs": b["inputs"], "intrinsic": b["intrinsic"], "extrinsic": b["extrinsic"], "features": feats})
-            assert_close(cvm, g["single_cvm"], 3e-2 if dtype == torch.bfloat16 else tol, "CrossViewModule")
+            assert_close(cvm, g["single_cvm"], BF16_OP if dtype == torch.bfloat16 else tol, "CrossViewModule")
     assert out["dynamic_seg"].dtype == torch.float32
     assert_close(out["dynamic_seg"], g[kind + "_dynamic_seg"], tol, "CVT %s logits" % kind)
 
@@ -422,7 +422,7 @@ def test_cav_attention_and_base_transformer_full_width(cuda):
     mask[0, :, 20:, :, 4] = 0
     ref = o_cvt.base_transformer(m.state_dict(), "", args, x, mask)
     m = m.to(cuda)
-    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, 3e-2)):
+    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, BF16_OP)):
         with host.compute_dtype(dtype):
             y = m(x.to(cuda), mask.to(cuda))
         assert_close(y, ref, tol, "BaseTransformer %s" % dtype)
@@ -453,7 +453,7 @@ def test_pairwise_fusion_full_width_vs_oracle(cuda, kind):
     x, rl, pw = _pairwise_case(2, 3, 5, 128, 32, cases.SEED)
     ref = fwd(m.state_dict(), "", args, x, rl, pw)
     m = m.to(cuda)
-    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, 5e-2)):
+    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, BF16_OP)):
         with host.compute_dtype(dtype):
             y = m(x.to(cuda), rl.to(cuda), pw.to(cuda))
         assert_close(y, ref, tol, "%s fusion %s" % (kind, dtype))

@@ -96,8 +96,9 @@ def test_agent_count_plans_serve_ragged_frames(cuda):
             out = srv.step(frames[a][i])
             torch.cuda.synchronize()
             assert torch.equal(out["dynamic_seg"], ref[(a, i)]), "agents %d frame %d" % (a, i)
-    # 3 shapes through a 2-plan cache in this order: 2, 1 captured; 3 evicts 2; 1 hit; 3 hit; 2 captured again (evicts 1)
-    assert srv.captures == 4 and len(srv.plans) == 2
+    # 3 shapes through a 2-plan LRU cache in this order: 2, 1 captured; 2 hit; 3 captured (evicts 1); 1 captured again (evicts 2);
+    # 3 hit; 2 captured again (evicts 1)
+    assert srv.captures == 5 and len(srv.plans) == 2
 
 
 def test_pipelined_graph_holds_no_torch_copies(cuda):

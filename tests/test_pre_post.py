@@ -277,7 +277,8 @@ def test_vanilla_seg_loss_forward(cuda, dtype):
     ref = torch.nn.functional.cross_entropy(x, y, weight=wt)
     assert abs(float(a) - float(ref)) <= 1e-5 * float(ref)
     # ignore_index -100 drops the pixel from numerator and denominator like nn.CrossEntropyLoss; any other label outside
-    # [0, C) raises as the reference does (it used to be dropped silently)
+    # [0, C) raises as the reference does - one call late or at check_deferred_label_errors(): the count leaves the device without a
+    # host sync (a blocking read drained the launch queue twice per training step)
     y2 = y.clone()
     y2[0, :7, :9] = -100
     a2 = ops.weighted_cross_entropy(x.to(cuda), y2.to(cuda), wt)
@@ -285,8 +286,11 @@ def test_vanilla_seg_loss_forward(cuda, dtype):
     assert abs(float(a2) - float(ref2)) <= 1e-5 * float(ref2)
     y3 = y.clone()
     y3[1, 200, 100] = 255
+    ops.check_deferred_label_errors()                       # nothing pending from the calls above
+    ops.weighted_cross_entropy(x.to(cuda), y3.to(cuda), wt)  # does not sync, does not raise yet
     with pytest.raises(Exception, match="outside"):
-        ops.weighted_cross_entropy(x.to(cuda), y3.to(cuda), wt)
+        ops.check_deferred_label_errors()
+    ops.check_deferred_label_errors()                       # reported once
 
 
 @pytest.mark.gpu
