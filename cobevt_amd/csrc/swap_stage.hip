@@ -97,7 +97,8 @@ struct StageLds {
     }
 };
 
-template <int NPASS>
+// NPASS: 128-column passes over the hidden layer.  NT: 32-key tiles (keys padded to NT * 32 = p.NKP).
+template <int NPASS, int NT>
 __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const StageLds L(p.NKP, p.bias_rows);
@@ -181,6 +182,22 @@ __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams
 
     // ================================ attention: wave = head ================================
     const int head = wave;
+    // Q and every K fragment of this wave's (head, 32 queries): requested now, in flight while V^T is transposed into LDS
+    uint4 qf0, qf1, ka[NT][2];
+    {
+        const int qr = qrow[ql];
+        const bf16_t* qp = p.qkv + (size_t)(qr < 0 ? 0 : qr) * ld + head * 32 + h * 8;
+        qf0 = *(const uint4*)(qp);
+        qf1 = *(const uint4*)(qp + 16);
+        const bf16_t* kbase = p.qkv + C + head * 32 + h * 8;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int kr = ktab[t * 32 + ql];
+            const bf16_t* kp = kbase + (size_t)(kr < 0 ? 0 : kr) * ld;
+            ka[t][0] = *(const uint4*)(kp);
+            ka[t][1] = *(const uint4*)(kp + 16);
+        }
+    }
     {
         unsigned char* vth = Vt + head * 32 * L.vstr;
         // ---- V^T of this head -> LDS: item = (key pair, dh quad); 16-key blocks in the score registers' key order (perm16)
@@ -219,73 +236,61 @@ __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams
     {
         unsigned char* vth = Vt + head * 32 * L.vstr;
 
-        const int qr = qrow[ql];
-        const bf16_t* qp = p.qkv + (size_t)(qr < 0 ? 0 : qr) * ld + head * 32 + h * 8;
-        const uint4 qf0 = *(const uint4*)(qp), qf1 = *(const uint4*)(qp + 16);
         const unsigned char* bias_qp = (const unsigned char*)(biasl + head * L.brows) + qterm[ql];
-        const bf16_t* kbase = p.qkv + C + head * 32 + h * 8;
         const float sl2 = p.scale * kLog2e;
         const unsigned char* vrow = vth + ql * L.vstr + h * 16;
 
-        float m_run = -INFINITY, l_run = 0.f;
-        f32x16 ot;
+        // Two-pass softmax over the WHOLE key set (NT * 32 <= 384 keys = NT * 16 score registers per lane; a workgroup owns its CU,
+        // so a lane may use ~450 VGPRs): every K fragment load, every score MFMA and every bias gather is independent of the
+        // others - the first version walked the key tiles with an online softmax, i.e. NT dependent
+        // load -> MFMA -> gather -> max -> exp -> MFMA chains of ~2k cycles each (26 us per launch, no faster than the two
+        // launches it replaced).
+        f32x16 s[NT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ot[r] = 0.f;
-        const int ntile = p.NKP >> 5;
-        uint4 ka0, ka1;
-        {
-            const int kr = ktab[ql];
-            const bf16_t* kp = kbase + (size_t)(kr < 0 ? 0 : kr) * ld;
-            ka0 = *(const uint4*)(kp); ka1 = *(const uint4*)(kp + 16);
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+            mfma_kgroup<bf16_t>(ka[t][0], qf0, s[t]);       // S^T tile: rows = keys t*32 + acc_row(r), column = this lane's query
+            mfma_kgroup<bf16_t>(ka[t][1], qf1, s[t]);
         }
-#pragma unroll 1
-        for (int st = 0; st < ntile; ++st) {
-            uint4 kn0, kn1;                                  // next tile's K fragments (clamped, unconditional) under this tile's math
-            {
-                const int nt = st + 1 < ntile ? st + 1 : st;
-                const int kr = ktab[nt * 32 + ql];
-                const bf16_t* kp = kbase + (size_t)(kr < 0 ? 0 : kr) * ld;
-                kn0 = *(const uint4*)(kp); kn1 = *(const uint4*)(kp + 16);
-            }
-            f32x16 s;
+        float mloc = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-            mfma_kgroup<bf16_t>(ka0, qf0, s);               // S^T tile: rows = keys st*32 + acc_row(r), column = this lane's query
-            mfma_kgroup<bf16_t>(ka1, qf1, s);
-            float mloc = -INFINITY;
+        for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {                    // registers 4g..4g+3 <-> keys kb..kb+3
-                const int kb = st * 32 + 8 * g + 4 * h;
+                const int kb = t * 32 + 8 * g + 4 * h;
                 const f32x4 add = *(const f32x4*)(kmadd + kb);
                 const uint4 ki = *(const uint4*)(kterm + kb);
                 const float b0 = *(const float*)(bias_qp - ki.x), b1 = *(const float*)(bias_qp - ki.y);
                 const float b2 = *(const float*)(bias_qp - ki.z), b3 = *(const float*)(bias_qp - ki.w);
-                s[4 * g] = fmaf(s[4 * g], sl2, b0 + add.x);
-                s[4 * g + 1] = fmaf(s[4 * g + 1], sl2, b1 + add.y);
-                s[4 * g + 2] = fmaf(s[4 * g + 2], sl2, b2 + add.z);
-                s[4 * g + 3] = fmaf(s[4 * g + 3], sl2, b3 + add.w);
-                mloc = fmaxf(fmaxf(mloc, fmaxf(s[4 * g], s[4 * g + 1])), fmaxf(s[4 * g + 2], s[4 * g + 3]));
+                s[t][4 * g] = fmaf(s[t][4 * g], sl2, b0 + add.x);
+                s[t][4 * g + 1] = fmaf(s[t][4 * g + 1], sl2, b1 + add.y);
+                s[t][4 * g + 2] = fmaf(s[t][4 * g + 2], sl2, b2 + add.z);
+                s[t][4 * g + 3] = fmaf(s[t][4 * g + 3], sl2, b3 + add.w);
+                mloc = fmaxf(fmaxf(mloc, fmaxf(s[t][4 * g], s[t][4 * g + 1])), fmaxf(s[t][4 * g + 2], s[t][4 * g + 3]));
             }
-            const float m_new = fmaxf(m_run, xor32_max(mloc));
-            const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);        // first tile: exp2(-inf) = 0
-            m_run = m_new;
-            float e[16], psum = 0.f;
+        }
+        const float m_all = xor32_max(mloc);
+        const float m_safe = (m_all == -INFINITY) ? 0.f : m_all;
+        float l_run = 0.f;
+        f32x16 ot;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { e[r] = __builtin_amdgcn_exp2f(s[r] - m_safe); psum += e[r]; }
-            l_run = fmaf(l_run, alpha, psum);
-            ot *= alpha;
+        for (int r = 0; r < 16; ++r) ot[r] = 0.f;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {                    // k-block u = keys st*32 + 16u .. +15 (registers 8u .. 8u+7 of both halves)
+        for (int t = 0; t < NT; ++t) {
+            float e[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { e[r] = __builtin_amdgcn_exp2f(s[t][r] - m_safe); l_run += e[r]; }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {                    // k-block u = keys t*32 + 16u .. +15 (registers 8u .. 8u+7 of both halves)
                 uint4 pb;
                 pb.x = pack_bf2(e[8 * u + 0], e[8 * u + 1]);
                 pb.y = pack_bf2(e[8 * u + 2], e[8 * u + 3]);
                 pb.z = pack_bf2(e[8 * u + 4], e[8 * u + 5]);
                 pb.w = pack_bf2(e[8 * u + 6], e[8 * u + 7]);
-                const uint4 va = *(const uint4*)(vrow + (st * 2 + u) * 32);
+                const uint4 va = *(const uint4*)(vrow + (t * 2 + u) * 32);
                 mfma_kgroup<bf16_t>(va, pb, ot);             // O^T += V^T . P^T : rows = dh, column = query
             }
-            ka0 = kn0; ka1 = kn1;
         }
         const float inv = 1.0f / xor32_sum(l_run);           // an all-masked row yields NaN like the reference softmax
 #pragma unroll
@@ -504,7 +509,10 @@ extern "C" int cobevt_swap_fusion_stage(const void* qkv, const void* x, void* ou
     if (p.B < 1 || p.B > 65535 || p.Hd < 8 || p.Hd > 256 || p.Hd % 8 || p.Hdp % 128 || p.Hdp < p.Hd || p.Hdp > 256) return COBEVT_ERR_SHAPE;
     if (wn && (p.Nn < 8 || p.Nn % 8 || p.Nn > 384)) return COBEVT_ERR_SHAPE;
     p.NK = p.map.ncam * p.map.w1 * p.map.w2;
-    p.NKP = (p.NK + 31) & ~31;
+    const int nt_need = (p.NK + 31) / 32;
+    const int nt = nt_need <= 4 ? 4 : nt_need <= 6 ? 6 : nt_need <= 8 ? 8 : nt_need <= 10 ? 10 : 12;     // built tile counts
+    if (nt_need > 12) return COBEVT_ERR_UNSUPPORTED;
+    p.NKP = nt * 32;
     const int want_rows = (2 * p.bias_L - 1) * (2 * p.map.w1 - 1) * (2 * p.map.w2 - 1);
     if (p.bias_L != p.map.ncam || p.bias_rows != want_rows) return COBEVT_ERR_SHAPE;
     if ((long)p.B * p.map.ncam * p.map.HH * p.map.WW >= 0x7fffffffL / 384) return COBEVT_ERR_SHAPE;
@@ -512,14 +520,23 @@ extern "C" int cobevt_swap_fusion_stage(const void* qkv, const void* x, void* ou
     if (L.total > 160 * 1024) return COBEVT_ERR_UNSUPPORTED;
     p.nsplit = (p.NK + kRows - 1) / kRows;
     const dim3 grid((unsigned)(p.map.X * p.map.Y * p.nsplit), (unsigned)p.B);
-    if (p.Hd > 128) {
-        static cobevt::PerDeviceOnce once;
-        if (once.first()) (void)hipFuncSetAttribute((const void*)swap_stage_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((swap_stage_kernel<2>), grid, dim3(kThreads), (size_t)L.total, stream, p);
-    } else {
-        static cobevt::PerDeviceOnce once;
-        if (once.first()) (void)hipFuncSetAttribute((const void*)swap_stage_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((swap_stage_kernel<1>), grid, dim3(kThreads), (size_t)L.total, stream, p);
+#define COBEVT_STAGE_LAUNCH(NP_, NT_)                                                                                               \
+    do {                                                                                                                             \
+        static cobevt::PerDeviceOnce once;                                                                                           \
+        if (once.first())                                                                                                            \
+            (void)hipFuncSetAttribute((const void*)swap_stage_kernel<NP_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((swap_stage_kernel<NP_, NT_>), grid, dim3(kThreads), (size_t)L.total, stream, p);                        \
+    } while (0)
+#define COBEVT_STAGE_NT(NP_)                                                                                                         \
+    switch (nt) {                                                                                                                    \
+        case 4: COBEVT_STAGE_LAUNCH(NP_, 4); break;                                                                                  \
+        case 6: COBEVT_STAGE_LAUNCH(NP_, 6); break;                                                                                  \
+        case 8: COBEVT_STAGE_LAUNCH(NP_, 8); break;                                                                                  \
+        case 10: COBEVT_STAGE_LAUNCH(NP_, 10); break;                                                                                \
+        default: COBEVT_STAGE_LAUNCH(NP_, 12); break;                                                                                \
     }
+    if (p.Hd > 128) { COBEVT_STAGE_NT(2) } else { COBEVT_STAGE_NT(1) }
+#undef COBEVT_STAGE_NT
+#undef COBEVT_STAGE_LAUNCH
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

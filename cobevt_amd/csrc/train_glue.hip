@@ -1,0 +1,466 @@
+// Training glue between the convolution / attention kernels, both directions, channels-last (N, H, W, C) maps (gfx950):
+// what torch autograd + cuDNN do for the reference under opv2v/opencood/tools/train_camera.py:143-179 -
+//   BatchNorm2d with batch statistics (+ running-stat update) or frozen statistics, fused with the residual add and the ReLU that
+//     follow it in torchvision's BasicBlock / Bottleneck (resnet_ms.py:67-74, fax_modules.py:10,472-489), NaiveDecoder
+//     (naive_decoder.py:78-87) and the pre-activation BN -> ReLU of fax_modules.py:281-292;
+//   MaxPool2d(3, 2, 1) of the ResNet stem (resnet_ms.py:70) backward; nn.PixelUnshuffle(2) (fax_modules.py:479) and nearest x2
+//     up-sampling (naive_decoder.py:84) in both directions; the STTF bilinear warp's input gradient (corpbevt.py:28-64,
+//     torch_transformation_utils.py:317-355); bias gradients (column sums).
+// All of it is HBM-bound streaming work: one 16-byte piece (8 channels) per lane, per-channel reductions in fp64 partial sums
+// per workgroup + one fp64 atomic per (workgroup, channel) (E[x^2] - E[x]^2 in fp32 loses the variance of activations whose
+// mean dominates; torch's batch_norm uses Welford), scatter-type gradients as fp32 atomics on the input-gradient map.
+#include "warp_common.hpp"
+
+namespace cobevt {
+namespace {
+
+constexpr int kThreads = 256;
+
+// ---- per-channel sums over rows: sum[c] += x, sumsq[c] += x^2 (BatchNorm statistics; column sum for bias gradients) ----
+// grid.x = row blocks; a thread owns one 8-channel group (gl) and walks rows gid, gid + stride, ...
+template <typename T, bool SQ>
+__global__ __launch_bounds__(kThreads) void channel_sums_kernel(const T* __restrict__ x, double* __restrict__ sum,
+                                                                double* __restrict__ sumsq, long rows, int C, int rows_per_block) {
+    const int G = C >> 3;
+    const int gl = threadIdx.x % G, r0 = threadIdx.x / G, rstep = kThreads / G;
+    const long row_lo = (long)blockIdx.x * rows_per_block;
+    const long row_hi = row_lo + rows_per_block < rows ? row_lo + rows_per_block : rows;
+    double s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.0; q[e] = 0.0; }
+    if (r0 < rstep) {
+        for (long r = row_lo + r0; r < row_hi; r += rstep) {
+            float v[8];
+            load8<T>(x + r * C + gl * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] += (double)v[e]; if (SQ) q[e] += (double)v[e] * (double)v[e]; }
+        }
+        // threads with the same gl differ by G in threadIdx: reduce through atomics on LDS-free path = one global atomic per thread
+        // group would be rstep x too many; fold the rstep partial sums of a channel group in LDS first
+    }
+    __shared__ double red[kThreads][9];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < G) {
+        double t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = 0.0;
+        for (int k = 0; k < rstep; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] += red[k * G + threadIdx.x][e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(sum + threadIdx.x * 8 + e, t[e]);
+    }
+    if (SQ) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = q[e];
+        __syncthreads();
+        if (threadIdx.x < G) {
+            double t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = 0.0;
+            for (int k = 0; k < rstep; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] += red[k * G + threadIdx.x][e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(sumsq + threadIdx.x * 8 + e, t[e]);
+        }
+    }
+}
+
+// ---- BatchNorm finalize: stats (training: from the sums; eval: the running statistics) -> per-channel scale / shift, mean / rstd
+// saved for backward, running statistics updated in place (momentum, unbiased variance) as nn.BatchNorm2d does
+__global__ void bn_finalize_kernel(const double* sum, const double* sumsq, const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out, int C,
+                                   double rows, float eps, float momentum, int training) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double mean, var;
+    if (training) {
+        mean = sum[c] / rows;
+        var = sumsq[c] / rows - mean * mean;
+        if (var < 0.0) var = 0.0;
+        if (running_mean) {
+            const double unbiased = rows > 1.0 ? var * rows / (rows - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+        }
+    } else {
+        mean = (double)running_mean[c];
+        var = (double)running_var[c];
+    }
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    scale[c] = g * rstd;
+    shift[c] = b - (float)mean * g * rstd;
+    mean_out[c] = (float)mean;
+    rstd_out[c] = rstd;
+}
+
+// ---- y = act(x * scale[c] + shift[c] (+ residual)) ; act: 0 none, 1 ReLU
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, T* __restrict__ y, long items, int C, int act) {
+    const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+    if (gid >= items) return;
+    const int G = C >> 3;
+    const int gl = (int)(gid % G);
+    float v[8], r[8];
+    load8<T>(x + gid * 8, v);
+    if (res) load8<T>(res + gid * 8, r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float t = fmaf(v[e], scale[gl * 8 + e], shift[gl * 8 + e]);
+        if (res) t += r[e];
+        v[e] = act == 1 ? fmaxf(t, 0.f) : t;
+    }
+    store8<T>(y + gid * 8, v);
+}
+
+// ---- backward, pass 1: g = dy * [y > 0] ; dbeta[c] += g ; dgamma[c] += g * xhat, xhat = (x - mean) * rstd
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 double* __restrict__ dgamma, double* __restrict__ dbeta, long rows, int C,
+                                                                 int act, int rows_per_block) {
+    const int G = C >> 3;
+    const int gl = threadIdx.x % G, r0 = threadIdx.x / G, rstep = kThreads / G;
+    const long row_lo = (long)blockIdx.x * rows_per_block;
+    const long row_hi = row_lo + rows_per_block < rows ? row_lo + rows_per_block : rows;
+    double sg[8], sb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sg[e] = 0.0; sb[e] = 0.0; }
+    if (r0 < rstep) {
+        float mu[8], rs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mu[e] = mean[gl * 8 + e]; rs[e] = rstd[gl * 8 + e]; }
+        for (long r = row_lo + r0; r < row_hi; r += rstep) {
+            float xv[8], gv[8], yv[8];
+            load8<T>(x + r * C + gl * 8, xv);
+            load8<T>(dy + r * C + gl * 8, gv);
+            if (act == 1) load8<T>(y + r * C + gl * 8, yv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float g = (act == 1 && !(yv[e] > 0.f)) ? 0.f : gv[e];
+                sb[e] += (double)g;
+                sg[e] += (double)(g * ((xv[e] - mu[e]) * rs[e]));
+            }
+        }
+    }
+    __shared__ double red[kThreads][9];
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = pass ? sb[e] : sg[e];
+        __syncthreads();
+        if (threadIdx.x < G) {
+            double t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = 0.0;
+            for (int k = 0; k < rstep; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] += red[k * G + threadIdx.x][e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd((pass ? dbeta : dgamma) + threadIdx.x * 8 + e, t[e]);
+        }
+    }
+}
+
+// ---- backward, pass 2: dx = gamma rstd (g - (dbeta + xhat dgamma) / rows)   (training)   |   dx = gamma rstd g   (frozen statistics)
+//      dres = g (the gradient of the residual branch), when wanted
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, const double* __restrict__ dgamma,
+                                                                const double* __restrict__ dbeta, T* __restrict__ dx, T* __restrict__ dres,
+                                                                long items, int C, float inv_rows, int act, int training) {
+    const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+    if (gid >= items) return;
+    const int G = C >> 3;
+    const int gl = (int)(gid % G);
+    float xv[8], gv[8], yv[8], o[8];
+    load8<T>(x + gid * 8, xv);
+    load8<T>(dy + gid * 8, gv);
+    if (act == 1) load8<T>(y + gid * 8, yv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = gl * 8 + e;
+        const float g = (act == 1 && !(yv[e] > 0.f)) ? 0.f : gv[e];
+        gv[e] = g;
+        const float k = (gamma ? gamma[c] : 1.f) * rstd[c];
+        if (training) {
+            const float xhat = (xv[e] - mean[c]) * rstd[c];
+            o[e] = k * (g - ((float)dbeta[c] + xhat * (float)dgamma[c]) * inv_rows);
+        } else {
+            o[e] = k * g;
+        }
+    }
+    store8<T>(dx + gid * 8, o);
+    if (dres) store8<T>(dres + gid * 8, gv);
+}
+
+// ---- MaxPool2d(3, stride 2, padding 1) backward: every output pixel finds its window's first maximum (row-major scan, ties ->
+// the first, as torch) and adds its gradient there
+template <typename T>
+__global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dx,
+                                                               int N, int H, int W, int C, int Ho, int Wo) {
+    const int G = C >> 3;
+    const long gid = ((long)blockIdx.x * kThreads + threadIdx.x) / G;
+    const int gl = threadIdx.x % G;
+    if (gid >= (long)N * Ho * Wo) return;
+    const int ow = (int)(gid % Wo), oh = (int)((gid / Wo) % Ho), n = (int)(gid / ((long)Wo * Ho));
+    float best[8];
+    int arg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; arg[e] = -1; }
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh * 2 - 1 + kh;
+        if (ih < 0 || ih >= H) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            const int iw = ow * 2 - 1 + kw;
+            if (iw < 0 || iw >= W) continue;
+            float v[8];
+            load8<T>(x + (((size_t)n * H + ih) * W + iw) * C + gl * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (v[e] > best[e] || arg[e] < 0) { best[e] = v[e]; arg[e] = ih * W + iw; }
+        }
+    }
+    float g[8];
+    load8<T>(dy + gid * C + gl * 8, g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (arg[e] >= 0) atomicAdd(dx + ((size_t)n * H * W + arg[e]) * C + gl * 8 + e, g[e]);
+}
+
+// ---- nn.PixelUnshuffle(2) on channels-last maps: out[n][h][w][c*4 + 2i + j] = in[n][2h + i][2w + j][c]; inverse = 1: the other way
+template <typename T>
+__global__ __launch_bounds__(kThreads) void pixel_unshuffle_kernel(const T* __restrict__ in, T* __restrict__ out, long total, int Ho, int Wo,
+                                                                   int C, int inverse) {
+    const long i = (long)blockIdx.x * kThreads + threadIdx.x;       // index into the UNSHUFFLED tensor (N, Ho, Wo, 4C)
+    if (i >= total) return;
+    const int c4 = (int)(i % (4 * C));
+    const long pix = i / (4 * C);
+    const int w = (int)(pix % Wo), h = (int)((pix / Wo) % Ho);
+    const long n = pix / ((long)Wo * Ho);
+    const int c = c4 >> 2, di = (c4 >> 1) & 1, dj = c4 & 1;
+    const long j = (((n * (2 * Ho) + 2 * h + di) * (2 * Wo)) + 2 * w + dj) * C + c;     // index into the (N, 2Ho, 2Wo, C) tensor
+    if (inverse) out[j] = in[i];
+    else out[i] = in[j];
+}
+
+// ---- nearest x2 up-sampling: forward out[n][h][w] = in[n][h/2][w/2]; backward dx[n][h][w] = sum of the 2 x 2 block of dy
+template <typename T>
+__global__ __launch_bounds__(kThreads) void upsample2_kernel(const T* __restrict__ in, T* __restrict__ out, long items, int H, int W, int C,
+                                                             int backward) {
+    // items = 8-channel groups of the SMALL map (N, H, W, C) for backward, of the LARGE map (N, 2H, 2W, C) for forward
+    const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+    if (gid >= items) return;
+    const int G = C >> 3;
+    const int gl = (int)(gid % G);
+    const long pix = gid / G;
+    if (!backward) {
+        const int w = (int)(pix % (2 * W)), h = (int)((pix / (2 * W)) % (2 * H));
+        const long n = pix / ((long)4 * W * H);
+        float v[8];
+        load8<T>(in + (((n * H + (h >> 1)) * W) + (w >> 1)) * C + gl * 8, v);
+        store8<T>(out + gid * 8, v);
+    } else {
+        const int w = (int)(pix % W), h = (int)((pix / W) % H);
+        const long n = pix / ((long)W * H);
+        float s[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = 0.f;
+        for (int di = 0; di < 2; ++di)
+            for (int dj = 0; dj < 2; ++dj) {
+                float v[8];
+                load8<T>(in + (((n * (2 * H) + 2 * h + di) * (2 * W)) + 2 * w + dj) * C + gl * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += v[e];
+            }
+        store8<T>(out + gid * 8, s);
+    }
+}
+
+// ---- STTF warp, gradient with respect to the feature maps: the adjoint of sttf_warp_kernel's bilinear gather (same sample
+// positions, computed by the same device functions) as fp32 atomic adds.  dout (B, L, H, W, C) fp32; dx (agents, H, W, C) fp32, zeroed
+__global__ __launch_bounds__(kThreads) void sttf_warp_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ tmat,
+                                                                 const int* __restrict__ record_len, float* __restrict__ dx, int B, int Lc,
+                                                                 int H, int W, int C, float discrete_ratio, float downsample_rate) {
+    const int G = C >> 3;
+    const int bl = blockIdx.y;
+    const int b = bl / Lc, l = bl - b * Lc;
+    __shared__ Affine th_feat;
+    __shared__ int src_agent;
+    if (threadIdx.x == 0) {
+        th_feat = sttf_theta(tmat + (size_t)bl * 16, discrete_ratio, downsample_rate, /*Hd=*/W, /*Wd=*/H);
+        int src = bl;
+        if (record_len) {
+            int off = 0;
+            for (int bb = 0; bb < b; ++bb) off += record_len[bb];
+            src = l < record_len[b] ? off + l : -1;
+        }
+        src_agent = src;
+    }
+    __syncthreads();
+    const int srcb = src_agent;
+    if (srcb < 0) return;
+    const int gid = (blockIdx.x * kThreads + threadIdx.x) / G;
+    const int gl = threadIdx.x % G;
+    if (gid >= H * W) return;
+    const int h = gid / W, w = gid - h * W;
+    float ix, iy;
+    affine_sample_xy(th_feat, w, H - 1 - h, W, H, ix, iy);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    float g[8];
+    load8<float>(dout + ((size_t)bl * H * W + gid) * C + gl * 8, g);
+    float* dst = dx + (size_t)srcb * H * W * C + gl * 8;
+    auto tap = [&](int xx, int yy, float wgt) {
+        if (xx < 0 || xx >= H || yy < 0 || yy >= W) return;
+        float* p = dst + ((size_t)(H - 1 - xx) * W + yy) * C;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(p + e, g[e] * wgt);
+    };
+    tap(x0, y0, wx0 * wy0);
+    tap(x1, y0, wx1 * wy0);
+    tap(x0, y1, wx0 * wy1);
+    tap(x1, y1, wx1 * wy1);
+}
+
+__global__ void f64_to_f32_kernel(const double* in, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+
+inline bool groups_ok(int C) { return C >= 8 && (C % 8) == 0 && (C >> 3) <= kThreads && kThreads % (C >> 3) == 0; }
+
+inline int row_blocks(long rows, int C, int* rows_per_block) {
+    const int rstep = kThreads / (C >> 3);
+    long want = (rows + (long)rstep * 16 - 1) / ((long)rstep * 16);          // >= 16 rows per thread
+    if (want > 1024) want = 1024;
+    if (want < 1) want = 1;
+    *rows_per_block = (int)((rows + want - 1) / want);
+    return (int)((rows + *rows_per_block - 1) / *rows_per_block);
+}
+
+}  // namespace
+}  // namespace cobevt
+
+using namespace cobevt;
+
+// sums (C) and, when sumsq != null, sums of squares of the rows of x (rows, C); fp64 accumulators, ADDED to (zero them first)
+extern "C" int cobevt_channel_sums(const void* x, double* sum, double* sumsq, int dtype, long rows, int C, hipStream_t stream) {
+    if (!x || !sum) return COBEVT_ERR_ARG;
+    if (!groups_ok(C) || rows < 1) return COBEVT_ERR_SHAPE;
+    int rpb;
+    const int blocks = row_blocks(rows, C, &rpb);
+    if (dtype == 0) {
+        if (sumsq) hipLaunchKernelGGL((channel_sums_kernel<bf16_t, true>), dim3(blocks), dim3(kThreads), 0, stream, (const bf16_t*)x, sum, sumsq, rows, C, rpb);
+        else hipLaunchKernelGGL((channel_sums_kernel<bf16_t, false>), dim3(blocks), dim3(kThreads), 0, stream, (const bf16_t*)x, sum, sumsq, rows, C, rpb);
+    } else if (dtype == 1) {
+        if (sumsq) hipLaunchKernelGGL((channel_sums_kernel<float, true>), dim3(blocks), dim3(kThreads), 0, stream, (const float*)x, sum, sumsq, rows, C, rpb);
+        else hipLaunchKernelGGL((channel_sums_kernel<float, false>), dim3(blocks), dim3(kThreads), 0, stream, (const float*)x, sum, sumsq, rows, C, rpb);
+    } else return COBEVT_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+extern "C" int cobevt_f64_to_f32(const double* in, float* out, int n, hipStream_t stream) {
+    if (!in || !out || n < 1) return COBEVT_ERR_ARG;
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, in, out, n);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+extern "C" int cobevt_bn_finalize(const double* sum, const double* sumsq, const float* gamma, const float* beta, float* running_mean,
+                                  float* running_var, float* scale, float* shift, float* mean, float* rstd, int C, long rows,
+                                  float eps, float momentum, int training, hipStream_t stream) {
+    if (!scale || !shift || !mean || !rstd || C < 1 || rows < 1) return COBEVT_ERR_ARG;
+    if (training ? (!sum || !sumsq) : (!running_mean || !running_var)) return COBEVT_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sum, sumsq, gamma, beta, running_mean, running_var,
+                       scale, shift, mean, rstd, C, (double)rows, eps, momentum, training);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+extern "C" int cobevt_bn_apply(const void* x, const void* residual, const float* scale, const float* shift, void* y, int dtype,
+                               long rows, int C, int act, hipStream_t stream) {
+    if (!x || !scale || !shift || !y) return COBEVT_ERR_ARG;
+    if (C < 8 || C % 8 || rows < 1 || act < 0 || act > 1) return COBEVT_ERR_SHAPE;
+    const long items = rows * (C >> 3);
+    const dim3 grid((unsigned)((items + kThreads - 1) / kThreads));
+    if (dtype == 0) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(kThreads), 0, stream, (const bf16_t*)x, (const bf16_t*)residual, scale, shift, (bf16_t*)y, items, C, act);
+    else if (dtype == 1) hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(kThreads), 0, stream, (const float*)x, (const float*)residual, scale, shift, (float*)y, items, C, act);
+    else return COBEVT_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// dgamma / dbeta: fp64 [C], zeroed by the caller; dres nullable
+extern "C" int cobevt_bn_backward(const void* x, const void* y, const void* dy, const float* mean, const float* rstd, const float* gamma,
+                                  double* dgamma, double* dbeta, void* dx, void* dres, int dtype, long rows, int C, int act,
+                                  int training, hipStream_t stream) {
+    if (!x || !dy || !mean || !rstd || !dgamma || !dbeta || !dx || (act == 1 && !y)) return COBEVT_ERR_ARG;
+    if (!groups_ok(C) || rows < 1 || act < 0 || act > 1) return COBEVT_ERR_SHAPE;
+    int rpb;
+    const int blocks = row_blocks(rows, C, &rpb);
+    const long items = rows * (C >> 3);
+    const dim3 grid((unsigned)((items + kThreads - 1) / kThreads));
+    const float inv_rows = 1.0f / (float)rows;
+    if (dtype == 0) {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(kThreads), 0, stream, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, mean, rstd, dgamma, dbeta, rows, C, act, rpb);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(kThreads), 0, stream, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, mean, rstd, gamma, dgamma, dbeta, (bf16_t*)dx, (bf16_t*)dres, items, C, inv_rows, act, training);
+    } else if (dtype == 1) {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(kThreads), 0, stream, (const float*)x, (const float*)y, (const float*)dy, mean, rstd, dgamma, dbeta, rows, C, act, rpb);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(kThreads), 0, stream, (const float*)x, (const float*)y, (const float*)dy, mean, rstd, gamma, dgamma, dbeta, (float*)dx, (float*)dres, items, C, inv_rows, act, training);
+    } else return COBEVT_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// dx fp32 (N, H, W, C), zeroed by the caller
+extern "C" int cobevt_maxpool3x3s2_bwd(const void* x, const void* dy, float* dx, int dtype, int N, int H, int W, int C, hipStream_t stream) {
+    if (!x || !dy || !dx) return COBEVT_ERR_ARG;
+    if (!groups_ok(C) || N < 1 || H < 1 || W < 1) return COBEVT_ERR_SHAPE;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long items = (long)N * Ho * Wo * (C >> 3);
+    const dim3 grid((unsigned)((items + kThreads - 1) / kThreads));
+    if (dtype == 0) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, grid, dim3(kThreads), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, dx, N, H, W, C, Ho, Wo);
+    else if (dtype == 1) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(kThreads), 0, stream, (const float*)x, (const float*)dy, dx, N, H, W, C, Ho, Wo);
+    else return COBEVT_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// inverse = 0: in (N, 2Ho, 2Wo, C) -> out (N, Ho, Wo, 4C) [nn.PixelUnshuffle(2)] ; inverse = 1: in (N, Ho, Wo, 4C) -> out (N, 2Ho, 2Wo, C)
+extern "C" int cobevt_pixel_unshuffle2_nhwc(const void* in, void* out, int dtype, int N, int Ho, int Wo, int C, int inverse, hipStream_t stream) {
+    if (!in || !out) return COBEVT_ERR_ARG;
+    if (N < 1 || Ho < 1 || Wo < 1 || C < 1) return COBEVT_ERR_SHAPE;
+    const long total = (long)N * Ho * Wo * 4 * C;
+    const dim3 grid((unsigned)((total + kThreads - 1) / kThreads));
+    if (dtype == 0) hipLaunchKernelGGL(pixel_unshuffle_kernel<uint16_t>, grid, dim3(kThreads), 0, stream, (const uint16_t*)in, (uint16_t*)out, total, Ho, Wo, C, inverse);
+    else if (dtype == 1) hipLaunchKernelGGL(pixel_unshuffle_kernel<float>, grid, dim3(kThreads), 0, stream, (const float*)in, (float*)out, total, Ho, Wo, C, inverse);
+    else return COBEVT_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// backward = 0: in (N, H, W, C) -> out (N, 2H, 2W, C) nearest ; backward = 1: in = dy (N, 2H, 2W, C) -> out = dx (N, H, W, C)
+extern "C" int cobevt_upsample_nearest2_nhwc(const void* in, void* out, int dtype, int N, int H, int W, int C, int backward, hipStream_t stream) {
+    if (!in || !out) return COBEVT_ERR_ARG;
+    if (C < 8 || C % 8 || N < 1 || H < 1 || W < 1) return COBEVT_ERR_SHAPE;
+    const long items = (long)N * H * W * (C >> 3) * (backward ? 1 : 4);
+    const dim3 grid((unsigned)((items + kThreads - 1) / kThreads));
+    if (dtype == 0) hipLaunchKernelGGL(upsample2_kernel<bf16_t>, grid, dim3(kThreads), 0, stream, (const bf16_t*)in, (bf16_t*)out, items, H, W, C, backward);
+    else if (dtype == 1) hipLaunchKernelGGL(upsample2_kernel<float>, grid, dim3(kThreads), 0, stream, (const float*)in, (float*)out, items, H, W, C, backward);
+    else return COBEVT_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// dout (B, L, H, W, C) fp32 -> dx (agents, H, W, C) fp32 (zeroed by the caller); record_len as for cobevt_sttf_warp (nullable: agent = b * L + l)
+extern "C" int cobevt_sttf_warp_bwd(const float* dout, const float* tmat, const int* record_len, float* dx, int B, int L, int H, int W, int C,
+                                    float discrete_ratio, float downsample_rate, hipStream_t stream) {
+    if (!dout || !tmat || !dx) return COBEVT_ERR_ARG;
+    if (!groups_ok(C) || B < 1 || L < 1 || H < 1 || W < 1 || B * L > 65535) return COBEVT_ERR_SHAPE;
+    const long items = (long)H * W * (C >> 3);
+    const dim3 grid((unsigned)((items + kThreads - 1) / kThreads), (unsigned)(B * L));
+    hipLaunchKernelGGL(sttf_warp_bwd_kernel, grid, dim3(kThreads), 0, stream, dout, tmat, record_len, dx, B, L, H, W, C, discrete_ratio, downsample_rate);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}

@@ -137,11 +137,8 @@ def _mlp(x, prenorm, mlp):
 def _pre_act_conv1x1(seq, x):
     """nn.Sequential(BatchNorm2d, ReLU, Conv2d 1x1) (fax_modules.py:281-292).  The BatchNorm follows ITS OWN .training flag
     (batch statistics + running-stat update, or the frozen running statistics), as torch would; the 1x1 convolution is the
-    training conv (implicit-GEMM forward / input gradient, cobevt_conv_wgrad)."""
-    F = torch.nn.functional
-    bn = seq[0]
-    y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
-    return ag.conv2d(F.relu(y), seq[2])
+    training conv (implicit-GEMM forward / input gradient, cobevt_conv_wgrad); BN + ReLU is one HIP Function (csrc/train_glue.hip)."""
+    return ag.conv2d(ag.batch_norm_act(x, seq[0], relu=True), seq[2])
 
 
 def cross_view_swap_attention(m, index, x, bev, feature, I_inv, E_inv):
@@ -220,21 +217,22 @@ def global_attention(m, x):
 # ----------------------------------------------------------------------------------------------
 # the convolutional half: encoder, Bottlenecks, down-sampling, decoder, heads, STTF - and the whole model
 # ----------------------------------------------------------------------------------------------
-# Convolutions: fp32 implicit-GEMM kernel forward and for the input gradient, library GEMMs for the weight gradient
-# (cobevt_amd.autograd.Conv2dFn).  BatchNorm follows each container's own .training flag (batch statistics and running-stat
-# updates, or the frozen statistics), max-pooling / nearest up-sampling / PixelUnshuffle / the affine warp are torch's
-# differentiable ops: plumbing between the kernels.  Tensors are (N, C, H, W)-shaped in channels-last memory.
+# Convolutions AND dense projections: the implicit-GEMM kernel forward and for the input gradient, cobevt_conv_wgrad(_blocked) for
+# the weight gradient (cobevt_amd.autograd.Conv2dFn / linear).  BatchNorm (each container's own .training flag: batch statistics and
+# running-stat updates, or the frozen statistics) fused with the residual add and the ReLU behind it, max-pooling, nearest
+# up-sampling, PixelUnshuffle and the STTF warp are HIP kernels in both directions too (csrc/train_glue.hip).  What is left to
+# torch: elementwise residual adds / means, layout permutes, dropout masks, the tiny camera-geometry embeddings and the optimiser.
+# Tensors are (N, C, H, W)-shaped in channels-last memory.
 _F = torch.nn.functional
 
 
-def _bn(x, bn):
-    return _F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
-
-
-def _conv_bn(x, conv, bn=None, relu=False):
+def _conv_bn(x, conv, bn=None, relu=False, residual=None):
+    """conv -> BatchNorm (its own .training flag) [-> + residual] [-> ReLU]; the BN / add / ReLU tail is ONE HIP Function"""
     y = ag.conv2d(x, conv)
     if bn is not None:
-        y = _bn(y, bn)
+        return ag.batch_norm_act(y, bn, residual=residual, relu=relu)
+    if residual is not None:
+        y = y + residual
     return _F.relu(y) if relu else y
 
 
@@ -242,7 +240,7 @@ def basic_block(blk, x):
     """torchvision BasicBlock.forward as reached from resnet_ms.py:67-74"""
     identity = x if blk.downsample is None else _conv_bn(x, blk.downsample[0], blk.downsample[1])
     y = _conv_bn(x, blk.conv1, blk.bn1, relu=True)
-    return _F.relu(_conv_bn(y, blk.conv2, blk.bn2) + identity)
+    return _conv_bn(y, blk.conv2, blk.bn2, relu=True, residual=identity)
 
 
 def resnet_encoder(enc, input_images):
@@ -252,7 +250,7 @@ def resnet_encoder(enc, input_images):
     net = enc.encoder
     x = input_images.reshape(b * l * m, h, w, c).permute(0, 3, 1, 2)          # channels-last memory, no copy
     x = _conv_bn(x, net.conv1, net.bn1, relu=True)
-    x = _F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    x = ag.max_pool3x3s2(x)
     results = []
     for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
         for blk in layer:
@@ -265,12 +263,12 @@ def bottleneck(blk, x):
     """torchvision Bottleneck(c, c // 4) (fax_modules.py:10,472)"""
     y = _conv_bn(x, blk.conv1, blk.bn1, relu=True)
     y = _conv_bn(y, blk.conv2, blk.bn2, relu=True)
-    return _F.relu(_conv_bn(y, blk.conv3, blk.bn3) + x)
+    return _conv_bn(y, blk.conv3, blk.bn3, relu=True, residual=x)
 
 
 def downsample(ds, x):
     """fax_modules.py:476-489: conv3x3 -> PixelUnshuffle(2) -> conv3x3 -> BN -> ReLU -> conv1x1 -> BN"""
-    y = _F.pixel_unshuffle(ag.conv2d(x, ds[0]), 2)
+    y = ag.pixel_unshuffle2(ag.conv2d(x, ds[0]))
     y = _conv_bn(y, ds[2], ds[3], relu=True)
     return _conv_bn(y, ds[5], ds[6])
 
@@ -300,7 +298,7 @@ def naive_decoder(dec, x):
     """NaiveDecoder.forward (naive_decoder.py:62-91) on (N, C, H, W)"""
     for i in range(dec.num_layer - 1, -1, -1):
         x = _conv_bn(x, dec.convs[("upconv", i, 0)], dec.convs[("norm", i, 0)], relu=True)
-        x = _F.interpolate(x, scale_factor=2, mode="nearest")
+        x = ag.upsample_nearest2(x)
         x = _conv_bn(x, dec.convs[("upconv", i, 1)], dec.convs[("norm", i, 1)], relu=True)
     return x
 
@@ -319,78 +317,37 @@ def bev_seg_head(head, x, b, l):
     return {"static_seg": run(head.static_head), "dynamic_seg": run(head.dynamic_head)}
 
 
-def _regroup(x, record_len, max_cav):
-    """fuse_utils.py:8-61: (sum(record_len), C, H, W) -> (B, max_cav, C, H, W) zero padded (record_len read on the host, as there)"""
-    lens = [int(v) for v in record_len]
-    out, off = [], 0
-    for n in lens:
-        f = x[off:off + n]
-        off += n
-        out.append(torch.cat([f, f.new_zeros((max_cav - n,) + tuple(f.shape[1:]))], 0)[None])
-    return torch.cat(out, 0)
-
-
-def _warp_affine(src, M, dsize):
-    """warp_affine (torch_transformation_utils.py:317-355) with its normalisation helpers (:160-191): bilinear, zeros,
-    align_corners=True; src (N, C, H, W), M (N, 2, 3) destination-from-source in pixels"""
-    N, C, H, W = src.shape
-
-    # small constant matrices are built with fills on the device and inverted by the device kernel: no host -> device copies and no
-    # host-side error check, so the whole warp can sit inside a captured training step (tools/train_graph_probe.py)
-    def norm_px(h, w):
-        t = torch.eye(3, dtype=M.dtype, device=M.device)          # (`t[i, j] = python_float` would be a host -> device copy)
-        t[0, 0].fill_(2.0 / (1e-14 if w == 1 else w - 1.0))
-        t[1, 1].fill_(2.0 / (1e-14 if h == 1 else h - 1.0))
-        t[0, 2].fill_(-1.0)
-        t[1, 2].fill_(-1.0)
-        return t[None]
-    M3 = _F.pad(M, [0, 0, 0, 1], "constant", value=0.0)
-    M3[..., -1, -1] += 1.0
-    with torch.no_grad():
-        prod = norm_px(dsize[0], dsize[1]) @ (M3 @ ops.invert_small(norm_px(H, W)))
-        theta = ops.invert_small(prod.contiguous())[:, :2, :]
-    grid = _F.affine_grid(theta, [N, C, dsize[0], dsize[1]], align_corners=True)
-    return _F.grid_sample(src, grid, align_corners=True, mode="bilinear", padding_mode="zeros")
+def naive_compressor(comp, x):
+    """NaiveCompressor.forward (naive_compress.py:22-31) on (N, C, H, W): three conv3x3 + BatchNorm + ReLU stages"""
+    _check(x)
+    x = _conv_bn(x, comp.encoder[0], comp.encoder[1], relu=True)
+    x = _conv_bn(x, comp.decoder[0], comp.decoder[1], relu=True)
+    return _conv_bn(x, comp.decoder[3], comp.decoder[4], relu=True)
 
 
 def sttf_warp(x, tm, discrete_ratio, downsample_rate):
-    """STTF.forward (corpbevt.py:28-64): x (B, L, C, H, W) -> (B, L, H, W, C) in the ego frame, differentiable in x.
-    The pose algebra (3x3 products and inverses) and the sampling stay in fp32 inside an autocast region: the reference needs an
-    fp16-safe inverse and a `.half()` hack here (torch_transformation_utils.py:137-157,354); fp32 is the simpler equivalent"""
+    """STTF.forward (corpbevt.py:28-64): x (B, L, C, H, W) -> (B, L, H, W, C) in the ego frame, differentiable in x: the inference
+    warp kernel forward, its adjoint backward (cobevt_amd.autograd.SttfWarpFn).  The pose algebra and the sampling stay in fp32
+    inside an autocast region (the reference needs an fp16-safe inverse and a `.half()` hack there,
+    torch_transformation_utils.py:137-157,354)."""
     with torch.autocast("cuda", enabled=False):
-        return _sttf_warp_f32(x.float(), tm, discrete_ratio, downsample_rate)
-
-
-def _sttf_warp_f32(x, tm, discrete_ratio, downsample_rate):
-    m = torch.cat([tm[:, :, 0:2, 0:2], tm[:, :, 0:2, 3:4]], -1).to(torch.float32)     # rows 0-1, columns 0, 1, 3 (:108-134); slices, not index lists: no host -> device copy
-    m[..., -1] = m[..., -1] / (discrete_ratio * downsample_rate)
-    x = x.permute(0, 1, 2, 4, 3).flip(4)
-    B, L, C, H, W = x.shape
-    M = m.reshape(-1, 2, 3)
-    eye = torch.eye(3, dtype=M.dtype, device=M.device)[None].repeat(M.shape[0], 1, 1)      # :254-297
-    shift, shift_inv, rot = eye.clone(), eye.clone(), eye.clone()
-    shift[:, 0, 2].fill_(W / 2)
-    shift[:, 1, 2].fill_(H / 2)
-    shift_inv[:, 0, 2].fill_(-(W / 2))
-    shift_inv[:, 1, 2].fill_(-(H / 2))
-    rot[:, :2, :2] = M[:, :2, :2]
-    T = (shift @ rot @ shift_inv)[:, :2, :].clone()
-    T[..., 2] += M[..., 2]
-    y = _warp_affine(x.reshape(-1, C, H, W), T, (H, W)).reshape(B, L, C, H, W)
-    return y.flip(4).permute(0, 1, 4, 3, 2)
+        xl = x.float().permute(0, 1, 3, 4, 2).contiguous()
+        return ag.sttf_warp(xl, tm.to(device=x.device, dtype=torch.float32).contiguous(), None, x.shape[1], discrete_ratio, downsample_rate)
 
 
 def fuse_and_decode(model, f, transformation_matrix, record_len, record_len_host=None):
     """the cross-agent part of CorpBEVT.forward (corpbevt.py:119-145): f (N, C, H, W) per-agent BEV features.  record_len_host:
     the agent counts as Python ints when record_len lives on the device (a captured training step cannot read it back)"""
-    if model.compression:
-        raise CobevtHipError("CorpBEVT train(): the NaiveCompressor branch has no training forward")
+    if model.compression:                               # corpbevt.py:119-121
+        f = naive_compressor(model.naive_compressor, f)
     dev = f.device
     tm = transformation_matrix.to(device=dev, dtype=torch.float32)
-    lens = record_len if record_len_host is None else record_len_host
-    w = sttf_warp(_regroup(f, lens, model.max_cav), tm, model.discrete_ratio, model.downsample_rate)   # b l h w c
-    # the ROI / agent mask carries no gradient: the inference kernel computes it
     rl = torch.as_tensor(record_len).to(device=dev, dtype=torch.int32)
+    # regroup (fuse_utils.py:8-61) + warp in one HIP Function: no host read of record_len, adjoint kernel in backward
+    with torch.autocast("cuda", enabled=False):
+        w = ag.sttf_warp(f.float().permute(0, 2, 3, 1).contiguous(), tm.contiguous(), rl, model.max_cav, model.discrete_ratio,
+                         model.downsample_rate)                                                   # b l h w c
+    # the ROI / agent mask carries no gradient: the inference kernel computes it
     with torch.no_grad():
         _, com_mask, cav_mask = ops.sttf_warp(f.detach().float().permute(0, 2, 3, 1).contiguous(), tm.contiguous(), None, model.discrete_ratio,
                                               model.downsample_rate, want_mask=model.use_roi_mask, record_len=rl,

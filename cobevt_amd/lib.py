@@ -83,6 +83,15 @@ SIGNATURES = {
     "cobevt_se_gate": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "cobevt_swap_fusion_stage": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int_p,
                                                 ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
+    "cobevt_channel_sums": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_int, _vp]),
+    "cobevt_f64_to_f32": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp]),
+    "cobevt_bn_finalize": (ctypes.c_int, [_vp] * 10 + [ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_float, ctypes.c_int, _vp]),
+    "cobevt_bn_apply": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, _vp]),
+    "cobevt_bn_backward": (ctypes.c_int, [_vp] * 10 + [ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    "cobevt_maxpool3x3s2_bwd": (ctypes.c_int, [_vp, _vp, _vp] + [ctypes.c_int] * 5 + [_vp]),
+    "cobevt_pixel_unshuffle2_nhwc": (ctypes.c_int, [_vp, _vp] + [ctypes.c_int] * 6 + [_vp]),
+    "cobevt_upsample_nearest2_nhwc": (ctypes.c_int, [_vp, _vp] + [ctypes.c_int] * 6 + [_vp]),
+    "cobevt_sttf_warp_bwd": (ctypes.c_int, [_vp, _vp, _vp, _vp] + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_float, _vp]),
     "cobevt_peer_window_alloc": (ctypes.c_int, [ctypes.c_long, ctypes.POINTER(_vp), _vp]),
     "cobevt_peer_window_open": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "cobevt_peer_window_close": (ctypes.c_int, [_vp]),

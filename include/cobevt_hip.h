@@ -431,6 +431,43 @@ int cobevt_swap_fusion_stage(const void* qkv, const void* x, void* out, void* qk
                              const float* b1, const void* w2, const float* b2, const void* wn, const float* bn,
                              const int* dims, float scale, float eps1, float eps_next, hipStream_t stream);
 
+/* ---- training glue, both directions (csrc/train_glue.hip): what torch autograd + cuDNN run between the convolutions under
+ * opv2v/opencood/tools/train_camera.py:143-179.  Channels-last maps flattened to (rows, C) / (N, H, W, C); dtype 0 bf16, 1 fp32;
+ * C a multiple of 8 that divides 2048 into whole lanes (8, 16, 32, 64, 128, 256, 512, 1024, 2048). ---------------------------- */
+
+/* sum[c] += sum over rows of x, and (sumsq nullable) sumsq[c] += sum of squares; fp64 accumulators (zero them first): BatchNorm
+ * batch statistics (torchvision BasicBlock / Bottleneck bn1-3 reached from resnet_ms.py:67-74, fax_modules.py:10,472-489,
+ * naive_decoder.py:78-87) and bias gradients. */
+int cobevt_channel_sums(const void* x, double* sum, double* sumsq, int dtype, long rows, int C, hipStream_t stream);
+int cobevt_f64_to_f32(const double* in, float* out, int n, hipStream_t stream);
+/* nn.BatchNorm2d statistics -> per-channel scale / shift (scale = gamma rstd, shift = beta - mean scale), mean / rstd for backward.
+ * training != 0: batch statistics from the sums, running_mean / running_var (nullable) updated in place with `momentum` and the
+ * unbiased variance; training == 0: the frozen running statistics. */
+int cobevt_bn_finalize(const double* sum, const double* sumsq, const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, float* scale, float* shift, float* mean, float* rstd, int C, long rows, float eps,
+                       float momentum, int training, hipStream_t stream);
+/* y = act(x * scale[c] + shift[c] (+ residual)), act 0 none / 1 ReLU. */
+int cobevt_bn_apply(const void* x, const void* residual, const float* scale, const float* shift, void* y, int dtype, long rows,
+                    int C, int act, hipStream_t stream);
+/* Backward of cobevt_bn_apply behind the statistics: g = dy [y > 0 when act == 1]; dbeta[c] += sum g, dgamma[c] += sum g xhat (fp64,
+ * zero them first); dx = gamma rstd (g - (dbeta + xhat dgamma) / rows) with batch statistics, gamma rstd g with frozen ones; dres
+ * (nullable) = g. */
+int cobevt_bn_backward(const void* x, const void* y, const void* dy, const float* mean, const float* rstd, const float* gamma,
+                       double* dgamma, double* dbeta, void* dx, void* dres, int dtype, long rows, int C, int act, int training,
+                       hipStream_t stream);
+/* nn.MaxPool2d(3, 2, 1) backward (resnet_ms.py:70): dx fp32 (N, H, W, C), zeroed by the caller; first maximum of a window wins. */
+int cobevt_maxpool3x3s2_bwd(const void* x, const void* dy, float* dx, int dtype, int N, int H, int W, int C, hipStream_t stream);
+/* nn.PixelUnshuffle(2) (fax_modules.py:479) on channels-last maps: inverse 0: (N, 2Ho, 2Wo, C) -> (N, Ho, Wo, 4C); 1: back. */
+int cobevt_pixel_unshuffle2_nhwc(const void* in, void* out, int dtype, int N, int Ho, int Wo, int C, int inverse,
+                                 hipStream_t stream);
+/* nearest x2 up-sampling (naive_decoder.py:84): backward 0: (N, H, W, C) -> (N, 2H, 2W, C); 1: dy (N, 2H, 2W, C) -> dx (N, H, W, C). */
+int cobevt_upsample_nearest2_nhwc(const void* in, void* out, int dtype, int N, int H, int W, int C, int backward,
+                                  hipStream_t stream);
+/* Input gradient of cobevt_sttf_warp (corpbevt.py:28-64, torch_transformation_utils.py:317-355): dout (B, L, H, W, C) fp32 ->
+ * dx (agents, H, W, C) fp32 (zeroed by the caller), scattered through the same sample positions; record_len as there. */
+int cobevt_sttf_warp_bwd(const float* dout, const float* tmat, const int* record_len, float* dx, int B, int L, int H, int W, int C,
+                         float discrete_ratio, float downsample_rate, hipStream_t stream);
+
 /* ---- multi-GPU: the V2V feature-sharing step in front of FuseBEVT.  The reference keeps all agents in one
  * process (opv2v/opencood/models/corpbevt.py:112-124, sub_modules/fuse_utils.py:8-61: agents are a batch dimension up to
  * `regroup`); its only collective call sites are the DDP set-up in opv2v/opencood/tools/multi_gpu_utils.py:32-37 and

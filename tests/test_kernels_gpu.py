@@ -1097,3 +1097,44 @@ def test_head_conv_direct_kernel(cuda, dtype, cout, cin, h, w):
     from util import assert_close
     assert_close(y, ref, 1e-4 if dtype == torch.float32 else 2e-3, "head conv vs torch")
     assert_close(y, y_igemm, 1e-4 if dtype == torch.float32 else 2e-3, "head conv vs implicit GEMM")
+
+
+@pytest.mark.parametrize("agents,window,hw,mlp,use_mask", [(5, 8, 32, 256, True), (5, 8, 32, 256, False), (3, 8, 16, 128, True),
+                                                           (5, 4, 16, 256, True), (2, 8, 24, 256, True)])
+def test_swap_fusion_stage_single_launch(cuda, agents, window, hw, mlp, use_mask):
+    """cobevt_swap_fusion_stage (one launch per SwapFusionBlock half: attention + row chain + next to_qkv) against the oracle
+    (swap_fusion_modules.py:87-128,165-192, base_transformer.py:102-124) and against the two-launch path it replaces - the
+    camera config's shape (5 agents x 8x8 windows = 320 keys, 32x32 map), key counts that need padding to the 32-key tile
+    (3 x 64 = 192, 5 x 16 = 80, 2 x 64 = 128), hidden widths of one and two 128-column passes, with and without the key mask
+    (incl. a fully masked agent and a half-masked one)."""
+    import cases
+    from cobevt_amd import host, synth
+    from cobevt_amd.synth import fill_module_
+    from util import rel_err
+    args = dict(input_dim=128, mlp_dim=mlp, agent_size=agents, window_size=window, dim_head=32, drop_out=0.1, depth=2, mask=use_mask)
+    enc = fill_module_(host.SwapFusionEncoder(args), cases.SEED).eval()
+    x = synth.procedural_input("stage.x", (2, agents, 128, hw, hw), cases.SEED, -2.0, 2.0)
+    mask = None
+    if use_mask:
+        mask = torch.ones(2, hw, hw, 1, agents)
+        mask[0, :, :, :, agents - 1] = 0                         # an absent agent
+        ii, jj = torch.meshgrid(torch.arange(hw), torch.arange(hw), indexing="ij")
+        mask[1, :, :, 0, 1] = (jj > ii // 2).float()             # an agent whose warped map covers part of the ego's
+    ref = o_swap.swap_fusion_encoder(enc.state_dict(), "", args, x, mask)
+    enc = enc.to(cuda)
+    xm = (x.to(cuda), mask.to(cuda) if use_mask else None)
+    with host.compute_dtype(torch.bfloat16):
+        launches = []
+        with ops.LaunchProfile() as prof:
+            y = enc(*xm)
+        launches = sorted(prof.summary())
+        assert "swap_stage" in launches and "attention" not in launches and "row_chain" not in launches, launches
+        old = ops.USE_SWAP_STAGE
+        ops.USE_SWAP_STAGE = False
+        try:
+            y2 = enc(*xm)
+        finally:
+            ops.USE_SWAP_STAGE = old
+    e, e2, d = rel_err(y, ref), rel_err(y2, ref), rel_err(y, y2)
+    print("swap stage %s: fused vs oracle %.2e, two-launch vs oracle %.2e, fused vs two-launch %.2e" % ((agents, window, hw, mlp, use_mask), e, e2, d))
+    assert e <= 1.5e-2 and e <= 1.5 * e2 + 2e-3, (e, e2)

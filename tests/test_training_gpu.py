@@ -626,3 +626,137 @@ def test_data_parallel_training_two_ranks_one_gpu(cuda):
         assert diff == 0.0, "replicas diverged by %g" % diff
         assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
         assert nb > 1
+
+
+# ----------------------------------------------------------------------------------------------
+# training glue kernels (csrc/train_glue.hip) against torch's own differentiable ops
+# ----------------------------------------------------------------------------------------------
+def _grads(fn, leaves, wgt=None):
+    with torch.enable_grad():
+        y = fn()
+        w = wgt if wgt is not None else torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(y.device)
+        (y.float() * w).sum().backward()
+    return y.detach().clone(), [None if t.grad is None else t.grad.detach().clone() for t in leaves], w
+
+
+@pytest.mark.parametrize("c,h,w,training,relu,res", [(64, 12, 20, True, True, True), (64, 12, 20, False, True, True),
+                                                     (128, 9, 7, True, False, False), (32, 16, 16, True, True, False),
+                                                     (512, 4, 4, False, False, True), (8, 5, 3, True, True, True)])
+def test_batch_norm_act_vs_torch(cuda, c, h, w, training, relu, res):
+    """relu(bn(x) + residual) with batch statistics (+ running-stat update) and with frozen statistics: forward, dx, d residual,
+    dgamma, dbeta and the updated running statistics against F.batch_norm + add + relu (what BasicBlock / Bottleneck / NaiveDecoder
+    run under train_camera.py:143-179)"""
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(3, c, h, w, generator=g) * 2.0 + 0.7
+    r0 = torch.randn(3, c, h, w, generator=g) if res else None
+    bns = []
+    for _ in range(2):
+        bn = torch.nn.BatchNorm2d(c, eps=1e-3, momentum=0.07).to(cuda)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(c, generator=g) * 0.3)
+            bn.running_mean.copy_(torch.randn(c, generator=g) * 0.2)
+            bn.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+        bn.train(training)
+        g = torch.Generator().manual_seed(11)
+        torch.randn(3, c, h, w, generator=g); (torch.randn(3, c, h, w, generator=g) if res else None)
+        bns.append(bn)
+    bns[1].load_state_dict(bns[0].state_dict())
+    x, r = _leaf(x0, cuda), _leaf(r0, cuda)
+    got, gg, wgt = _grads(lambda: ag.batch_norm_act(x, bns[0], residual=r, relu=relu), [x, r, bns[0].weight, bns[0].bias])
+    xr, rr = _leaf(x0, cuda), _leaf(r0, cuda)
+
+    def ref_fn():
+        y = bns[1](xr)
+        if rr is not None:
+            y = y + rr
+        return torch.relu(y) if relu else y
+    ref, rg, _ = _grads(ref_fn, [xr, rr, bns[1].weight, bns[1].bias], wgt)
+    assert_close(got, ref, 1e-5, "bn forward")
+    for name, a, b in zip(("dx", "dres", "dgamma", "dbeta"), gg, rg):
+        if b is not None:
+            assert_close(a, b, 1e-4, "bn " + name)
+    assert_close(bns[0].running_mean, bns[1].running_mean, 1e-5, "running_mean")
+    assert_close(bns[0].running_var, bns[1].running_var, 1e-5, "running_var")
+    assert int(bns[0].num_batches_tracked) == int(bns[1].num_batches_tracked)
+
+
+def test_pool_shuffle_upsample_linear_vs_torch(cuda):
+    """MaxPool2d(3, 2, 1) (with ties), PixelUnshuffle(2), nearest x2 up-sampling and nn.Linear through the implicit-GEMM kernels:
+    forward and every gradient against torch's ops"""
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randint(-3, 4, (2, 16, 13, 10), generator=g).float()                  # integer values: ties inside the windows
+    x = _leaf(x0, cuda)
+    xr = _leaf(x0, cuda)
+    got, gg, wgt = _grads(lambda: ag.max_pool3x3s2(x), [x])
+    ref, rg, _ = _grads(lambda: F.max_pool2d(xr, 3, 2, 1), [xr], wgt)
+    assert torch.equal(got, ref) and torch.equal(gg[0], rg[0]), "max-pool forward / backward (first maximum wins)"
+    x0 = torch.randn(2, 24, 12, 8, generator=g)
+    for ours, theirs, what in ((ag.pixel_unshuffle2, lambda t: F.pixel_unshuffle(t, 2), "pixel_unshuffle"),
+                               (ag.upsample_nearest2, lambda t: F.interpolate(t, scale_factor=2, mode="nearest"), "upsample")):
+        x, xr = _leaf(x0, cuda), _leaf(x0, cuda)
+        got, gg, wgt = _grads(lambda: ours(x), [x])
+        ref, rg, _ = _grads(lambda: theirs(xr), [xr], wgt)
+        assert torch.equal(got, ref), what
+        assert_close(gg[0], rg[0], 1e-6, what + " backward")
+    for k, n, bias in ((128, 384, False), (128, 256, True), (64, 8, True)):
+        lin = torch.nn.Linear(k, n, bias=bias).to(cuda)
+        x0 = torch.randn(3, 37, k, generator=g)
+        x = _leaf(x0, cuda)
+        got, gg, wgt = _grads(lambda: ag.linear(x, lin), [x, lin.weight] + ([lin.bias] if bias else []))
+        lin.zero_grad()
+        xr = _leaf(x0, cuda)
+        ref, rg, _ = _grads(lambda: F.linear(xr, lin.weight, lin.bias), [xr, lin.weight] + ([lin.bias] if bias else []), wgt)
+        assert_close(got, ref, 1e-4, "linear forward")
+        for name, a, b in zip(("dx", "dW", "db"), gg, rg):
+            assert_close(a, b, 1e-4, "linear " + name)
+
+
+def test_sttf_warp_backward_is_the_adjoint(cuda):
+    """<warp(x), g> == <x, warp^T(g)> for the regrouping STTF warp (a linear map of x), and the forward equals the inference kernel:
+    cobevt_sttf_warp_bwd scatters through the same sample positions cobevt_sttf_warp gathers from"""
+    g = torch.Generator().manual_seed(9)
+    batch = synth.opv2v_batch(agents=3, cams=1, image=64, max_cav=4, seed=cases.SEED, batch=2)
+    tm = batch["transformation_matrix"].to(cuda).float().contiguous()
+    rl = torch.tensor([3, 3], dtype=torch.int32, device=cuda)
+    x0 = torch.randn(6, 12, 16, 32, generator=g)
+    x = _leaf(x0, cuda)
+    with torch.enable_grad():
+        y = ag.sttf_warp(x, tm, rl, 4, 0.390625, 8)
+        gy = torch.randn(y.shape, generator=g).to(cuda)
+        (y * gy).sum().backward()
+    ref, _, _ = ops.sttf_warp(x0.to(cuda).contiguous(), tm, None, 0.390625, 8, want_mask=False, record_len=rl, max_cav=4)
+    assert torch.equal(y.detach(), ref)
+    # adjoint identity with a second, independent x
+    x2 = torch.randn(6, 12, 16, 32, generator=g).to(cuda)
+    y2, _, _ = ops.sttf_warp(x2.contiguous(), tm, None, 0.390625, 8, want_mask=False, record_len=rl, max_cav=4)
+    lhs, rhs = float((y2.double() * gy.double()).sum()), float((x2.double() * x.grad.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (lhs, rhs)
+    assert float(x.grad.abs().max()) > 0
+
+
+def test_naive_compressor_trains(cuda):
+    """NaiveCompressor (naive_compress.py:5-31) in train() mode: forward / gradients against the torch module built from the same
+    containers (batch statistics)"""
+    comp = _train_module(host.NaiveCompressor(32, 4), cuda)
+    g = torch.Generator().manual_seed(2)
+    x0 = torch.randn(3, 32, 12, 16, generator=g)
+    x = _leaf(x0, cuda)
+    params = list(comp.parameters())
+    got, gg, wgt = _grads(lambda: comp(x), [x] + params)
+    state = {k: v.clone() for k, v in comp.state_dict().items()}
+    comp.zero_grad()
+    ref_mod = torch.nn.Sequential(*comp.encoder, *comp.decoder)          # plain torch forward over the same parameter containers
+    fresh = _train_module(host.NaiveCompressor(32, 4), cuda)            # running stats as they were before the first forward
+    for (k, v), (_, v0) in zip(comp.state_dict().items(), fresh.state_dict().items()):
+        if "running" in k or "num_batches" in k:
+            v.copy_(v0)
+    xr = _leaf(x0, cuda)
+    ref, rg, _ = _grads(lambda: ref_mod(xr), [xr] + params, wgt)
+    assert_close(got, ref, 1e-4, "compressor forward")
+    for i, (a, b) in enumerate(zip(gg, rg)):
+        assert_close(a, b, 2e-4, "compressor grad %d" % i)
+    for k, v in comp.state_dict().items():
+        if "running" in k:
+            assert_close(v, state[k], 1e-5, k)
