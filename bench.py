@@ -568,8 +568,17 @@ def main():
                                                "without the cross-frame pipeline = the latency of a frame"))
         if not args.no_extra:
             safe(result, "eager_model_call", lambda: dict(
-                quick(lambda: model(dict(batch)), 3, 20), note="plain `model(batch_dict)` as INTEGRATION.md §1 documents it: ~100 "
+                quick(lambda: model(dict(batch)), 3, 20), note="plain `model(batch_dict)` as INTEGRATION.md §1 documents it: ~90 "
                                                                 "ctypes launches per frame from Python, no HIP graph"))
+
+            def graph_call():
+                model.enable_graphs()
+                try:
+                    return dict(quick(lambda: model(batch), 3, 30), note="the same drop-in call after `model.enable_graphs()`: eval-mode "
+                                "forward served from a captured plan per frame shape (host.pipeline.AgentCountPlans)")
+                finally:
+                    model.enable_graphs(False)
+            safe(result, "model_call_with_graphs", graph_call)
         if not args.no_roofline:
             def roof():
                 dom, others, fax0, timed_ms = roofline_leg(runner, args.dtype)

@@ -46,6 +46,12 @@ struct RowChainParams {
     int M, C, Hd, Hdp;
     int Nn, next_ln, next_act, skip_rows;
     float eps1, eps_post, eps_next;
+    // MLP = false ("projection chain"): a <- ReLU?(a * pre_scale[c] + pre_shift[c]) while it is staged (pre-activation
+    // BatchNorm -> ReLU -> 1x1 conv, fax_modules.py:281-292), y = a . Wp^T + bp + skip, `out` is not stored unless non-null, and the
+    // next projection (LayerNorm + Linear: to_k / to_v of both cross attentions, fax_modules.py:201-205) reads y from LDS
+    const float* pre_scale;
+    const float* pre_shift;
+    int pre_relu;
 };
 
 constexpr int kRcRow = 256 + 16;            // 128 bf16 + pad
@@ -84,7 +90,7 @@ __device__ __forceinline__ void rc_normalise(float (&v)[16], int sub, int C, flo
 // NPASS: 128-column passes over the hidden layer (Hd <= 128 -> 1, else 2).  ROWS: rows per workgroup (8 threads per row).
 // FULL: C == 128, i.e. every operand row holds all eight 32-byte k-groups - the per-k-group `g < n` tests fold away and the
 // fragment loads / MFMAs become straight-line code (with runtime n each group sat behind its own uniform branch).
-template <int NPASS, int ROWS, bool FULL>
+template <int NPASS, int ROWS, bool FULL, bool MLP = true>
 __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem + RcLds<ROWS>::A;
@@ -160,6 +166,19 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
             const int k = (sub * 2 + j) * 8;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (ok && k < p.C) v = *(const uint4*)(p.a + (size_t)(m0 + r) * p.C + k);
+            if (!MLP && p.pre_scale) {
+                float f[8];
+                chunk_to_f32<bf16_t>(v, f);
+                const float4 s0 = *(const float4*)(p.pre_scale + k), s1 = *(const float4*)(p.pre_scale + k + 4);
+                const float4 t0 = *(const float4*)(p.pre_shift + k), t1 = *(const float4*)(p.pre_shift + k + 4);
+                const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    f[e] = fmaf(f[e], sc[e], sh[e]);
+                    if (p.pre_relu) f[e] = fmaxf(f[e], 0.f);
+                }
+                v = ok ? f32_to_chunk<bf16_t>(f) : make_uint4(0, 0, 0, 0);
+            }
             *(uint4*)(As + r * kRcRow + (sub * 2 + j) * 16) = v;
         }
     }
@@ -175,7 +194,8 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
 
     // ---- phase A: y = a . Wp^T + bp + skip -> Ys (bf16, exactly what the unfused path would have stored)
     mma(As, abase, fa, ngc, true);
-    load_frags(fb, p.w1, wn, 8, 0, ngc);             // fc1 columns [32 wn, +32) ; needed after phase B
+    if (MLP) load_frags(fb, p.w1, wn, 8, 0, ngc);    // fc1 columns [32 wn, +32) ; needed after phase B
+    else load_frags(fb, p.wn, wn, 8, 0, ngc);        // projection chain: the next projection's first pass
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int col0 = cbase + 8 * k;
@@ -186,6 +206,9 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
         *(uint2*)(Ys + row * kRcRow + col0 * 2) = pack4(v0, v1, v2, v3);
     }
     __syncthreads();                                  // Ys complete; As free
+    float* stage = (float*)Hs;
+    constexpr int SROW = kRcHRow / 4;
+    if constexpr (MLP) {
 
     // ---- phase B: x_hat = normalise(y) -> As ; 8 threads per row, 32 bytes (16 channels) each
     if (NPASS == 2) load_frags(fa, p.w1, 4 + wn, 8, 0, ngc);   // fc1 columns [128 + 32 wn, +32)
@@ -234,8 +257,6 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
         mma(Hs, hbase, fa, (p.Hd * 2 + 31) / 32, true);
     }
     __syncthreads();                                  // Hs no longer read: reuse it as the fp32 staging of z
-    float* stage = (float*)Hs;
-    constexpr int SROW = kRcHRow / 4;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int col0 = cbase + 8 * k;
@@ -246,6 +267,15 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
             z = make_float4(acc[4 * k] + b.x + bf2f(y.x & 0xffff), acc[4 * k + 1] + b.y + bf2f(y.x >> 16),
                             acc[4 * k + 2] + b.z + bf2f(y.y & 0xffff), acc[4 * k + 3] + b.w + bf2f(y.y >> 16));
         *(float4*)(stage + row * SROW + col0) = z;
+    }
+    } else {
+        // projection chain: "z" = y exactly as the unfused path would have stored it (bf16), widened into the staging tile
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int col0 = cbase + 8 * k;
+            const uint2 y = *(const uint2*)(Ys + row * kRcRow + col0 * 2);
+            *(float4*)(stage + row * SROW + col0) = make_float4(bf2f(y.x & 0xffff), bf2f(y.x >> 16), bf2f(y.y & 0xffff), bf2f(y.y >> 16));
+        }
     }
     const int npn = p.wn ? (p.Nn + 127) / 128 : 0;    // 128-column passes of the next projection
     __syncthreads();
@@ -272,7 +302,7 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
         uint4 o[2];
         o[0] = f32_to_chunk<bf16_t>(v);
         o[1] = f32_to_chunk<bf16_t>(v + 8);
-        if (live) {
+        if (live && (MLP || p.out)) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int c0 = sub * 16 + j * 8;
@@ -325,14 +355,14 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
     }
 }
 
-template <int NPASS, int ROWS, bool FULL>
+template <int NPASS, int ROWS, bool FULL, bool MLP = true>
 static void launch_chain(const RowChainParams& p, hipStream_t stream) {
     static cobevt::PerDeviceOnce attr_once;
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)row_chain_kernel<NPASS, ROWS, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<ROWS>::BYTES);
+        (void)hipFuncSetAttribute((const void*)row_chain_kernel<NPASS, ROWS, FULL, MLP>, hipFuncAttributeMaxDynamicSharedMemorySize, RcLds<ROWS>::BYTES);
     }
     const unsigned blocks = (unsigned)((p.M + ROWS - 1) / ROWS);
-    hipLaunchKernelGGL((row_chain_kernel<NPASS, ROWS, FULL>), dim3(blocks), dim3(ROWS * 8), RcLds<ROWS>::BYTES, stream, p);
+    hipLaunchKernelGGL((row_chain_kernel<NPASS, ROWS, FULL, MLP>), dim3(blocks), dim3(ROWS * 8), RcLds<ROWS>::BYTES, stream, p);
 }
 
 }  // namespace cobevt
@@ -357,6 +387,7 @@ extern "C" int cobevt_attn_mlp_chain(const void* a, const void* skip, void* out,
     p.Nn = dims[5]; p.next_ln = dims[6]; p.next_act = dims[7];
     p.skip_rows = dims[9] > 0 ? dims[9] : p.M;                 // dims[9]: rows of `skip` (0 = M), M % skip_rows == 0
     p.eps1 = eps1; p.eps_post = eps_post; p.eps_next = eps_next;
+    p.pre_scale = p.pre_shift = nullptr; p.pre_relu = 0;
     if (p.M < 1 || p.C < 8 || p.C > 128 || p.C % 8 || p.Hd < 8 || p.Hd > 256 || p.Hd % 8) return COBEVT_ERR_SHAPE;
     if (p.Hdp % 128 || p.Hdp < p.Hd || p.Hdp > 256) return COBEVT_ERR_SHAPE;
     if (p.skip_rows > p.M || p.M % p.skip_rows) return COBEVT_ERR_SHAPE;
@@ -372,5 +403,31 @@ extern "C" int cobevt_attn_mlp_chain(const void* a, const void* skip, void* out,
         if (two) { if (full) launch_chain<2, 32, true>(p, stream); else launch_chain<2, 32, false>(p, stream); }
         else { if (full) launch_chain<1, 32, true>(p, stream); else launch_chain<1, 32, false>(p, stream); }
     }
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// Projection chain, see include/cobevt_hip.h: y = ReLU?(a * pre_scale + pre_shift) . Wp^T + bp + skip ; next = act(LN?(y) . Wn'^T + bn')
+extern "C" int cobevt_proj_chain(const void* a, const float* pre_scale, const float* pre_shift, const void* skip, const void* wp,
+                                 const float* bp, void* out, const void* wnext, const float* bnext, void* out_next, const int* dims,
+                                 float eps_next, hipStream_t stream) {
+    // dims: [dtype, M, C (= 128), Nn, next_ln, next_act, skip_rows, pre_relu]
+    if (!a || !wp || !wnext || !bnext || !out_next || !dims) return COBEVT_ERR_ARG;
+    if ((pre_scale == nullptr) != (pre_shift == nullptr)) return COBEVT_ERR_ARG;
+    if (dims[0] != 0) return COBEVT_ERR_UNSUPPORTED;
+    RowChainParams p;
+    p.a = (const bf16_t*)a; p.skip = (const bf16_t*)skip; p.out = (bf16_t*)out;
+    p.wp = (const uint4*)wp; p.bp = bp;
+    p.w1 = (const uint4*)wnext; p.b1 = bnext; p.w2 = (const uint4*)wnext; p.b2 = bnext;      // unused by the projection chain (valid stand-ins)
+    p.post_g = p.post_b = nullptr;
+    p.wn = (const uint4*)wnext; p.bn = bnext; p.out_next = (bf16_t*)out_next;
+    p.M = dims[1]; p.C = dims[2]; p.Hd = 8; p.Hdp = 128;
+    p.Nn = dims[3]; p.next_ln = dims[4]; p.next_act = dims[5];
+    p.skip_rows = dims[6] > 0 ? dims[6] : p.M;
+    p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.pre_relu = dims[7];
+    p.eps1 = 0.f; p.eps_post = 0.f; p.eps_next = eps_next;
+    if (p.M < 1 || p.C != 128) return COBEVT_ERR_SHAPE;             // K = C = 128 (the level-0 feature / embedding width)
+    if (p.Nn < 8 || p.Nn % 8 || p.Nn > kRcBnMax || p.next_act < 0 || p.next_act > 2) return COBEVT_ERR_SHAPE;
+    if (p.skip_rows > p.M || p.M % p.skip_rows) return COBEVT_ERR_SHAPE;
+    launch_chain<1, 32, true, false>(p, stream);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

@@ -50,6 +50,18 @@ struct SwapStageParams {
     float eps1, eps_next;
 };
 
+#ifdef COBEVT_STAGE_TRACE
+// probe builds only (tools/stage_trace.py): s_memtime marks of wave 0 of every workgroup at the phase boundaries
+__device__ unsigned long long g_stage_trace[8 * 4096];
+#define STAGE_MARK(i)                                                                                       \
+    do {                                                                                                     \
+        const unsigned wgid = blockIdx.x + gridDim.x * blockIdx.y;                                           \
+        if (threadIdx.x == 0 && wgid < 4096) g_stage_trace[8 * wgid + (i)] = __builtin_amdgcn_s_memtime();   \
+    } while (0)
+#else
+#define STAGE_MARK(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ int perm16(int k) { return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1); }
 
 __device__ __forceinline__ float xor32_max(float v) {
@@ -123,6 +135,7 @@ __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams
     constexpr int C = 128;
     const int ld = 3 * C;
 
+    STAGE_MARK(0);
     // ---- chain bias vectors: fetched now (registers), written to LDS when region R changes hands
     float cb[kBiasFloats / kThreads];
 #pragma unroll
@@ -179,6 +192,7 @@ __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams
         }
     }
     __syncthreads();
+    STAGE_MARK(1);
 
     // ================================ attention: wave = head ================================
     const int head = wave;
@@ -233,6 +247,7 @@ __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams
         }
     }
     __syncthreads();          // (a wave only reads its own head's V^T; the barrier just keeps the hand-over free of ordering assumptions)
+    STAGE_MARK(2);
     {
         unsigned char* vth = Vt + head * 32 * L.vstr;
 
@@ -302,6 +317,7 @@ __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams
         }
     }
 
+    STAGE_MARK(3);
     // ================================ row chain on the 32 x 128 tile in As ================================
     unsigned char* Ys = R;
     unsigned char* Hs = R + kRows * kRow;
@@ -360,6 +376,7 @@ __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams
         *(uint2*)(Ys + row * kRow + col0 * 2) = pack4(v0, v1, v2, v3);
     }
     __syncthreads();                                  // Ys complete; As free
+    STAGE_MARK(4);
 
     // ---- phase B: x_hat = normalise(y) -> As ; 8 threads per row, 16 channels each
     if (NPASS == 2) load_frags(fa, p.w1, 4 + wn, 8, 0);
@@ -421,6 +438,7 @@ __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams
     }
     const int npn = p.wn ? (p.Nn + 127) / 128 : 0;
     __syncthreads();
+    STAGE_MARK(5);
 
     // ---- phase E: coalesced 16-byte stores of the rows (scattered through the token -> row table)
     {
@@ -439,7 +457,7 @@ __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams
             *(uint4*)(p.out + (size_t)gr * C + sub * 16) = o[0];
             *(uint4*)(p.out + (size_t)gr * C + sub * 16 + 8) = o[1];
         }
-        if (!npn) return;
+        if (!npn) { STAGE_MARK(6); STAGE_MARK(7); return; }
         // ---- phase F: A operand of the next to_qkv = LayerNorm(out rows as stored) -> As
         chunk_to_f32<bf16_t>(o[0], v);
         chunk_to_f32<bf16_t>(o[1], v + 8);
@@ -448,6 +466,7 @@ __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams
         *(uint4*)(As + r * kRow + sub * 32 + 16) = f32_to_chunk<bf16_t>(v + 8);
     }
     __syncthreads();
+    STAGE_MARK(6);
     auto next_pass = [&](int pass, const uint4 (&cur)[8], uint4 (&nxt)[8]) {
         if (pass + 1 < npn) load_frags(nxt, p.wn, (pass + 1) * 4 + wn, 8, 0);
         mma(As, abase, cur, true);
@@ -476,10 +495,17 @@ __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams
         next_pass(pass, fb, fa);
         if (pass + 1 < npn) next_pass(pass + 1, fa, fb);
     }
+    STAGE_MARK(7);
 }
 
 }  // namespace
 }  // namespace cobevt
+
+#ifdef COBEVT_STAGE_TRACE
+extern "C" int cobevt_stage_trace_read(unsigned long long* dst, int n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(cobevt::g_stage_trace), sizeof(unsigned long long) * (size_t)n, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
 
 using namespace cobevt;
 

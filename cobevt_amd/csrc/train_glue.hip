@@ -22,7 +22,7 @@ template <typename T, bool SQ>
 __global__ __launch_bounds__(kThreads) void channel_sums_kernel(const T* __restrict__ x, double* __restrict__ sum,
                                                                 double* __restrict__ sumsq, long rows, int C, int rows_per_block) {
     const int G = C >> 3;
-    const int gl = threadIdx.x % G, r0 = threadIdx.x / G, rstep = kThreads / G;
+    const int gl = threadIdx.x % G, r0 = threadIdx.x / G, rstep = kThreads / G;      // threads with r0 >= rstep idle (256 % G != 0)
     const long row_lo = (long)blockIdx.x * rows_per_block;
     const long row_hi = row_lo + rows_per_block < rows ? row_lo + rows_per_block : rows;
     double s[8], q[8];
@@ -35,8 +35,7 @@ __global__ __launch_bounds__(kThreads) void channel_sums_kernel(const T* __restr
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s[e] += (double)v[e]; if (SQ) q[e] += (double)v[e] * (double)v[e]; }
         }
-        // threads with the same gl differ by G in threadIdx: reduce through atomics on LDS-free path = one global atomic per thread
-        // group would be rstep x too many; fold the rstep partial sums of a channel group in LDS first
+        // (the rstep partial sums of a channel group are folded in LDS below: one global atomic per (workgroup, channel))
     }
     __shared__ double red[kThreads][9];
 #pragma unroll
@@ -207,8 +206,9 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dx,
                                                                int N, int H, int W, int C, int Ho, int Wo) {
     const int G = C >> 3;
-    const long gid = ((long)blockIdx.x * kThreads + threadIdx.x) / G;
-    const int gl = threadIdx.x % G;
+    const long item = (long)blockIdx.x * kThreads + threadIdx.x;
+    const long gid = item / G;
+    const int gl = (int)(item % G);
     if (gid >= (long)N * Ho * Wo) return;
     const int ow = (int)(gid % Wo), oh = (int)((gid / Wo) % Ho), n = (int)(gid / ((long)Wo * Ho));
     float best[8];
@@ -307,8 +307,9 @@ __global__ __launch_bounds__(kThreads) void sttf_warp_bwd_kernel(const float* __
     __syncthreads();
     const int srcb = src_agent;
     if (srcb < 0) return;
-    const int gid = (blockIdx.x * kThreads + threadIdx.x) / G;
-    const int gl = threadIdx.x % G;
+    const int item = blockIdx.x * kThreads + threadIdx.x;
+    const int gid = item / G;
+    const int gl = item % G;
     if (gid >= H * W) return;
     const int h = gid / W, w = gid - h * W;
     float ix, iy;
@@ -336,7 +337,25 @@ __global__ void f64_to_f32_kernel(const double* in, float* out, int n) {
     if (i < n) out[i] = (float)in[i];
 }
 
-inline bool groups_ok(int C) { return C >= 8 && (C % 8) == 0 && (C >> 3) <= kThreads && kThreads % (C >> 3) == 0; }
+inline bool groups_ok(int C) { return C >= 8 && (C % 8) == 0 && (C >> 3) <= kThreads; }
+
+// any channel count (bias gradients of 2- / 3-class heads, odd test shapes): one lane per channel, rows strided over blockIdx.y
+template <typename T>
+__global__ __launch_bounds__(kThreads) void channel_sums_generic_kernel(const T* __restrict__ x, double* __restrict__ sum,
+                                                                        double* __restrict__ sumsq, long rows, int C, int rows_per_block) {
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= C) return;
+    const long row_lo = (long)blockIdx.y * rows_per_block;
+    const long row_hi = row_lo + rows_per_block < rows ? row_lo + rows_per_block : rows;
+    double s = 0.0, q = 0.0;
+    for (long r = row_lo; r < row_hi; ++r) {
+        const double v = (double)load_elem<T>(x, (size_t)(r * C + c));
+        s += v;
+        q += v * v;
+    }
+    atomicAdd(sum + c, s);
+    if (sumsq) atomicAdd(sumsq + c, q);
+}
 
 inline int row_blocks(long rows, int C, int* rows_per_block) {
     const int rstep = kThreads / (C >> 3);
@@ -355,7 +374,16 @@ using namespace cobevt;
 // sums (C) and, when sumsq != null, sums of squares of the rows of x (rows, C); fp64 accumulators, ADDED to (zero them first)
 extern "C" int cobevt_channel_sums(const void* x, double* sum, double* sumsq, int dtype, long rows, int C, hipStream_t stream) {
     if (!x || !sum) return COBEVT_ERR_ARG;
-    if (!groups_ok(C) || rows < 1) return COBEVT_ERR_SHAPE;
+    if (C < 1 || rows < 1 || (dtype != 0 && dtype != 1)) return COBEVT_ERR_SHAPE;
+    if (!groups_ok(C)) {
+        long nb = (rows + 255) / 256;
+        if (nb > 512) nb = 512;
+        const int rpb = (int)((rows + nb - 1) / nb);
+        const dim3 grid((unsigned)((C + kThreads - 1) / kThreads), (unsigned)((rows + rpb - 1) / rpb));
+        if (dtype == 0) hipLaunchKernelGGL(channel_sums_generic_kernel<bf16_t>, grid, dim3(kThreads), 0, stream, (const bf16_t*)x, sum, sumsq, rows, C, rpb);
+        else hipLaunchKernelGGL(channel_sums_generic_kernel<float>, grid, dim3(kThreads), 0, stream, (const float*)x, sum, sumsq, rows, C, rpb);
+        return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+    }
     int rpb;
     const int blocks = row_blocks(rows, C, &rpb);
     if (dtype == 0) {

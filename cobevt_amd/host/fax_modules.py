@@ -291,22 +291,30 @@ class CrossViewSwapAttention(HipModule):
             return self._plan("kvpad.%s.%dx%dx%d" % (tag, bn, hp, wp), [self.img_embed.weight],
                               lambda dt_, dev: torch.zeros((bn, hp, wp, d), device=feature.device, dtype=dt))
 
+        o = out if out is not None else {}      # optional preallocated {"kk", "vv"} buffers
+        # to_k of both attentions read the same `key` rows (to_v: `val`): one GEMM each with the two weight matrices
+        # stacked (each LayerNorm's affine folded into its half; the normalisation itself is shared) -> (.., 2*inner);
+        # attention #1 reads columns [0, inner), attention #2 columns [inner, 2*inner) through its row stride
+        pk, pv = self._pair_plan("k"), self._pair_plan("v")
+        plan_key = rt.conv_plan(self, "fproj", self.feature_proj[2], pre_bn=self.feature_proj[0]) if self.feature_proj is not None else None
+        plan_val = rt.conv_plan(self, "flin", self.feature_linear[2], pre_bn=self.feature_linear[0])
+        if (not padded and plan_key is not None and ops.proj_chain_fusable(feature, plan_key, pk, img)
+                and ops.proj_chain_fusable(feature, plan_val, pv, None)):
+            # 128-channel features (pyramid level 0: 3/4 of the key / value rows of a frame): projection + ray embedding ->
+            # LayerNorm -> stacked to_k (to_v) in one launch per operand; `key` / `val` stay in LDS (csrc/row_chain.hip)
+            kk = ops.proj_chain(feature, plan_key, pk, residual=img, out_next=o.get("kk"))
+            vv = ops.proj_chain(feature, plan_val, pv, out_next=o.get("vv"))
+            return {"n": n, "hp": hp, "wp": wp, "kk": kk, "vv": vv}
         if self.feature_proj is not None:
-            key = ops.conv2d(feature, rt.conv_plan(self, "fproj", self.feature_proj[2], pre_bn=self.feature_proj[0]),
-                             residual=img, out=kv_buffer("key"))
+            key = ops.conv2d(feature, plan_key, residual=img, out=kv_buffer("key"))
         elif padded:
             key = kv_buffer("key")
             key[:, :h, :w] = img
         else:
             key = img
-        val = ops.conv2d(feature, rt.conv_plan(self, "flin", self.feature_linear[2], pre_bn=self.feature_linear[0]),
-                         out=kv_buffer("val"))
-        o = out if out is not None else {}      # optional preallocated {"kk", "vv"} buffers
-        # to_k of both attentions read the same `key` rows (to_v: `val`): one GEMM each with the two weight matrices
-        # stacked (each LayerNorm's affine folded into its half; the normalisation itself is shared) -> (.., 2*inner);
-        # attention #1 reads columns [0, inner), attention #2 columns [inner, 2*inner) through its row stride
-        kk = ops.linear(key, self._pair_plan("k"), out=o.get("kk"))
-        vv = ops.linear(val, self._pair_plan("v"), out=o.get("vv"))
+        val = ops.conv2d(feature, plan_val, out=kv_buffer("val"))
+        kk = ops.linear(key, pk, out=o.get("kk"))
+        vv = ops.linear(val, pv, out=o.get("vv"))
         return {"n": n, "hp": hp, "wp": wp, "kk": kk, "vv": vv}
 
     def _pair_plan(self, which):

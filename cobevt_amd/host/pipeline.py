@@ -129,6 +129,7 @@ class AgentCountPlans(object):
         self.model, self.use_graph, self.max_plans = model, use_graph, int(max_plans)
         self.plans = {}            # key -> CapturedCorpBEVT, insertion order = recency
         self.captures = 0
+        self.busy = False          # True while a plan is being built (the model's own forward runs eagerly inside)
         for b in (prewarm or []):  # capture ahead of time (e.g. one synthetic frame per agent count) instead of on first sight
             self._runner(b)
 
@@ -136,13 +137,18 @@ class AgentCountPlans(object):
     def key(batch):
         rl = batch["record_len"]
         n_scen = int(rl.numel()) if torch.is_tensor(rl) else len(rl)
-        return (tuple(batch["inputs"].shape), n_scen, tuple(batch["transformation_matrix"].shape))
+        from . import runtime as rt
+        return (tuple(batch["inputs"].shape), n_scen, tuple(batch["transformation_matrix"].shape), str(rt.get_compute_dtype()))
 
     def _runner(self, batch):
         k = self.key(batch)
         r = self.plans.pop(k, None)
         if r is None:
-            r = CapturedCorpBEVT(self.model, batch, use_graph=self.use_graph)
+            self.busy = True
+            try:
+                r = CapturedCorpBEVT(self.model, batch, use_graph=self.use_graph)
+            finally:
+                self.busy = False
             self.captures += 1
             while len(self.plans) >= self.max_plans:
                 self.plans.pop(next(iter(self.plans)))

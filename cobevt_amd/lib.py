@@ -81,6 +81,7 @@ SIGNATURES = {
     "cobevt_depthwise_conv_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_spatial_mean_nhwc": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "cobevt_se_gate": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    "cobevt_proj_chain": (ctypes.c_int, [_vp] * 10 + [_c_int_p, ctypes.c_float, _vp]),
     "cobevt_swap_fusion_stage": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int_p,
                                                 ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
     "cobevt_channel_sums": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_int, _vp]),

@@ -40,6 +40,8 @@ USE_EMBED_GEMM3 = False   # the BEV query produced inside the 32-row GEMM that p
 # coefficient reads + ~400 VALU per thread cost more than the 170 MB of HBM traffic they save; kept for parity tests
 USE_CHAIN_NEXT = True  # ... and let the row-local GEMM that consumes its output next ride in the same launch
 USE_HEAD_CONV = True    # 3x3 convs with <= 4 output channels to NCHW fp32 logits (BevSegHead) on the direct kernel
+USE_PROJ_CHAIN = True   # FAX key / value side at 128 feature channels: BN -> ReLU -> 1x1 conv (+ ray embedding) -> LayerNorm -> to_k | to_v
+                        # of both attentions in ONE launch per operand, the key / value map itself never reaches HBM (row_chain.hip)
 USE_SWAP_STAGE = True   # a SwapFusionBlock half (attention + row chain + next to_qkv) as one launch (swap_stage.hip)
 USE_BOTTLENECK = True   # FAX ResNetBottleNeck (128 -> 32 -> 32 -> 128) as one launch (bottleneck.hip) instead of three
 ATTN_VARIANT = 0    # 0 = automatic (K/V-resident attention kernel where it applies), 1 = always the streaming kernel, 2 = ... with 64-key tiles (A/B runs)
@@ -975,6 +977,37 @@ def attn_mlp_chain(a, skip, plan_p, plan_1, plan_2, post_ln=None, next_plan=None
     if next_plan is None:
         return out
     return out, (out_next if fuse_next else linear(out, next_plan))
+
+
+def proj_chain_fusable(x, plan_p, next_plan, residual):
+    c = x.shape[-1]
+    return (USE_PROJ_CHAIN and x.dtype == torch.bfloat16 and c == 128 and x.is_contiguous() and plan_p.wfrag_rows is not None
+            and plan_p.kp_rows == 128 and plan_p.K == c and plan_p.cout == c and plan_p.act == 0 and not plan_p.has_ln
+            and plan_p.stride == 1 and chain_next_fusable(next_plan, c)
+            and (residual is None or (residual.is_contiguous() and residual.shape == x.shape and residual.dtype == x.dtype)))
+
+
+def proj_chain(x, plan_p, next_plan, residual=None, out_next=None):
+    """next_plan(plan_p(x) + residual) on (..., 128) rows in one launch (cobevt_proj_chain); plan_p may carry the pre-activation
+    BatchNorm -> ReLU of its input, next_plan a folded LayerNorm.  The intermediate map is not materialised."""
+    _need_cuda(x, residual)
+    c, nn_ = 128, next_plan.cout
+    m = x.numel() // c
+    if out_next is None:
+        out_next = torch.empty(x.shape[:-1] + (nn_,), device=x.device, dtype=x.dtype)
+    elif out_next.numel() != m * nn_ or not out_next.is_contiguous() or out_next.dtype != x.dtype:
+        raise CobevtHipError("proj_chain: `out_next` must be a contiguous (.., %d) buffer of dtype %s" % (nn_, x.dtype))
+    dims = _ints([0, m, c, nn_, int(next_plan.has_ln), next_plan.act, 0, plan_p.pre_relu])
+
+    def cost():
+        return 2.0 * m * (c * c + c * nn_), float(m * (c * (2 if residual is not None else 1) + nn_) * 2 + (c * c + c * nn_) * 2)
+
+    with _timed("row_chain|proj C%d M=%d +next%d" % (c, m, nn_), cost):
+        rc = _L.load().cobevt_proj_chain(_p(x), _p(plan_p.pre_scale), _p(plan_p.pre_shift), _p(residual), _p(plan_p.wfrag_rows),
+                                         _p(plan_p.bias), None, _p(next_plan.wfrag_rows), _p(next_plan.bias), _p(out_next), dims,
+                                         ctypes.c_float(next_plan.ln_eps), _stream())
+    _L.check(rc, "cobevt_proj_chain")
+    return out_next
 
 
 def swap_stage_fusable(qkv, x, tmap, heads, plan_p, plan_1, plan_2, next_plan, mask):

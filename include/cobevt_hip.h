@@ -413,6 +413,19 @@ int cobevt_channel_gate_nhwc(const void* in, const float* gate, void* out, int d
                              hipStream_t stream);
 
 /*
+ * Projection chain (bf16, 128 channels): the key / value side of a FAX cross-view level in one launch per operand -
+ *   y = ReLU?(a * pre_scale[c] + pre_shift[c]) . Wp^T + bp + skip     pre-activation BatchNorm -> ReLU -> 1x1 conv (feature_proj /
+ *                                                                     feature_linear, fax_modules.py:281-292,377-396) + the ray embedding
+ *   next = act(LayerNorm?(y) . Wn'^T + bn')                           to_k / to_v of BOTH cross attentions stacked (fax_modules.py:201-205)
+ * with y (the "key" / "val" map of the reference) kept in LDS: it is written to `out` only when out != null.  The row_chain
+ * kernel without its MLP phases (csrc/row_chain.hip).  Weights in MFMA fragment order as for cobevt_attn_mlp_chain.
+ * dims (int32[8]): dtype (0), M, C (128), Nn (<= 768), next_ln, next_act, skip_rows (0 = M), pre_relu.
+ */
+int cobevt_proj_chain(const void* a, const float* pre_scale, const float* pre_shift, const void* skip, const void* wp,
+                      const float* bp, void* out, const void* wnext, const float* bnext, void* out_next, const int* dims,
+                      float eps_next, hipStream_t stream);
+
+/*
  * One half of a SwapFusionBlock in ONE launch (bf16 mode, 128 channels = 4 heads of 32): PreNormResidual(Attention) +
  * PreNormResidual(FeedForward) over the window (map mode 0) or dilated-grid (mode 1) partition of (B, L, H, W, 128) agent maps
  * = opv2v/opencood/models/fusion_modules/swap_fusion_modules.py:87-128 (attention with the 3-D relative position bias and the
@@ -433,11 +446,11 @@ int cobevt_swap_fusion_stage(const void* qkv, const void* x, void* out, void* qk
 
 /* ---- training glue, both directions (csrc/train_glue.hip): what torch autograd + cuDNN run between the convolutions under
  * opv2v/opencood/tools/train_camera.py:143-179.  Channels-last maps flattened to (rows, C) / (N, H, W, C); dtype 0 bf16, 1 fp32;
- * C a multiple of 8 that divides 2048 into whole lanes (8, 16, 32, 64, 128, 256, 512, 1024, 2048). ---------------------------- */
+ * C a multiple of 8 (<= 2048) except where noted. --------------------------------------------------------------------------- */
 
 /* sum[c] += sum over rows of x, and (sumsq nullable) sumsq[c] += sum of squares; fp64 accumulators (zero them first): BatchNorm
  * batch statistics (torchvision BasicBlock / Bottleneck bn1-3 reached from resnet_ms.py:67-74, fax_modules.py:10,472-489,
- * naive_decoder.py:78-87) and bias gradients. */
+ * naive_decoder.py:78-87) and bias gradients (any C). */
 int cobevt_channel_sums(const void* x, double* sum, double* sumsq, int dtype, long rows, int C, hipStream_t stream);
 int cobevt_f64_to_f32(const double* in, float* out, int n, hipStream_t stream);
 /* nn.BatchNorm2d statistics -> per-channel scale / shift (scale = gamma rstd, shift = beta - mean scale), mean / rstd for backward.

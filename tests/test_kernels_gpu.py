@@ -1138,3 +1138,42 @@ def test_swap_fusion_stage_single_launch(cuda, agents, window, hw, mlp, use_mask
     e, e2, d = rel_err(y, ref), rel_err(y2, ref), rel_err(y, y2)
     print("swap stage %s: fused vs oracle %.2e, two-launch vs oracle %.2e, fused vs two-launch %.2e" % ((agents, window, hw, mlp, use_mask), e, e2, d))
     assert e <= 1.5e-2 and e <= 1.5 * e2 + 2e-3, (e, e2)
+
+
+@pytest.mark.parametrize("rows,with_res", [(4096, True), (4096, False), (1000, True)])
+def test_projection_chain_single_launch(cuda, rows, with_res):
+    """cobevt_proj_chain (BN -> ReLU -> 1x1 conv (+ ray embedding) -> LayerNorm -> stacked to_k / to_v without materialising the key
+    / value map; fax_modules.py:281-292,377-396,201-205) against the two launches it replaces and against fp32 torch"""
+    import torch.nn as nn
+    from cobevt_amd import host
+    from cobevt_amd.host import runtime as rt
+    g = torch.Generator().manual_seed(4)
+    bn, conv = nn.BatchNorm2d(128), nn.Conv2d(128, 128, 1, bias=False)
+    ln, lin = nn.LayerNorm(128), nn.Linear(128, 256, bias=True)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(128, generator=g) + 0.5); bn.bias.copy_(torch.randn(128, generator=g) * 0.2)
+        bn.running_mean.copy_(torch.randn(128, generator=g) * 0.3); bn.running_var.copy_(torch.rand(128, generator=g) + 0.5)
+        ln.weight.copy_(torch.rand(128, generator=g) + 0.5); ln.bias.copy_(torch.randn(128, generator=g) * 0.2)
+    x = torch.randn(rows, 128, generator=g)
+    res = torch.randn(rows, 128, generator=g) if with_res else None
+    xb = x.to(torch.bfloat16).to(cuda)
+    rb = res.to(torch.bfloat16).to(cuda) if with_res else None
+    owner = host.runtime.HipModule()
+    owner.bn, owner.conv, owner.ln, owner.lin = bn.eval(), conv, ln, lin
+    owner = owner.to(cuda)
+    with host.compute_dtype(torch.bfloat16):
+        pp = rt.conv_plan(owner, "p", owner.conv, pre_bn=owner.bn)
+        pn = rt.linear_plan(owner, "n", owner.lin, ln=owner.ln)
+        assert ops.proj_chain_fusable(xb, pp, pn, rb)
+        fused = ops.proj_chain(xb, pp, pn, residual=rb)
+        key = ops.conv2d(xb.reshape(1, 1, rows, 128), pp, residual=None if rb is None else rb.reshape(1, 1, rows, 128)).reshape(rows, 128)
+        two = ops.linear(key, pn)
+    with torch.no_grad():
+        xr = xb.float().cpu()
+        y = torch.relu(bn(xr.t().reshape(1, 128, rows, 1))).reshape(128, rows).t() @ conv.weight.reshape(128, 128).t().cpu()
+        if with_res:
+            y = y + rb.float().cpu()
+        ref = lin.cpu()(ln.cpu()(y.to(torch.bfloat16).float()))
+    s = float(ref.abs().max())
+    assert (fused.float().cpu() - ref).abs().max().item() <= 1.5e-2 * s
+    assert (fused.float() - two.float()).abs().max().item() <= 1.5e-2 * s

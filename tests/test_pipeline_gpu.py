@@ -121,3 +121,20 @@ def test_pipelined_graph_holds_no_torch_copies(cuda):
     assert kernels, "profiler saw no device activity"
     bad = [n for n in names if "Memcpy" in n or "Memset" in n or "copyBuffer" in n or "at::native" in n or "fillBuffer" in n]
     assert not bad, "torch / runtime copies inside the replayed graph: %s" % bad
+
+
+def test_model_call_served_from_graphs(cuda):
+    """`model.enable_graphs()`: the plain eval-mode model(batch) call is served from a captured plan per frame shape and stays
+    bit-identical to the eager forward; train() mode and a disabled switch go back to the eager paths"""
+    model = _model(cuda)
+    frames = {a: _frames(2, cuda, agents=a) for a in (1, 2)}
+    with host.compute_dtype(torch.bfloat16):
+        ref = {(a, i): model(dict(f))["dynamic_seg"].clone() for a, fs in frames.items() for i, f in enumerate(fs)}
+        model.enable_graphs()
+        for a, i in ((2, 0), (1, 1), (2, 1), (1, 0)):
+            out = model(frames[a][i])
+            torch.cuda.synchronize()
+            assert torch.equal(out["dynamic_seg"], ref[(a, i)])
+        assert model.graph_plans.captures == 2
+        model.enable_graphs(False)
+        assert torch.equal(model(dict(frames[2][0]))["dynamic_seg"], ref[(2, 0)])

@@ -268,10 +268,11 @@ def test_training_slice_fails_loudly(cuda):
         m(x)                                                       # CPU tensor
     with pytest.raises(CobevtHipError):
         m(x.to(cuda).to(torch.bfloat16))                           # bf16 is the inference layout
-    # modules without a training forward keep refusing train() mode
-    comp = host.NaiveCompressor(128, 2).train().to(cuda)
+    # modules without a training forward keep refusing train() mode (the nuScenes decoder)
+    from cobevt_amd.host import nuscenes as nu
+    dec = nu.Decoder(128, [128, 64]).train().to(cuda)
     with pytest.raises(CobevtHipError):
-        comp(torch.zeros(1, 128, 8, 8, device=cuda))
+        dec(torch.zeros(1, 128, 8, 8, device=cuda))
 
 
 def test_one_optimizer_step_reduces_the_loss(cuda):
@@ -636,7 +637,7 @@ def _grads(fn, leaves, wgt=None):
         y = fn()
         w = wgt if wgt is not None else torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(y.device)
         (y.float() * w).sum().backward()
-    return y.detach().clone(), [None if t.grad is None else t.grad.detach().clone() for t in leaves], w
+    return y.detach().clone(), [None if (t is None or t.grad is None) else t.grad.detach().clone() for t in leaves], w
 
 
 @pytest.mark.parametrize("c,h,w,training,relu,res", [(64, 12, 20, True, True, True), (64, 12, 20, False, True, True),
@@ -658,8 +659,6 @@ def test_batch_norm_act_vs_torch(cuda, c, h, w, training, relu, res):
             bn.running_mean.copy_(torch.randn(c, generator=g) * 0.2)
             bn.running_var.copy_(torch.rand(c, generator=g) + 0.5)
         bn.train(training)
-        g = torch.Generator().manual_seed(11)
-        torch.randn(3, c, h, w, generator=g); (torch.randn(3, c, h, w, generator=g) if res else None)
         bns.append(bn)
     bns[1].load_state_dict(bns[0].state_dict())
     x, r = _leaf(x0, cuda), _leaf(r0, cuda)
@@ -691,7 +690,9 @@ def test_pool_shuffle_upsample_linear_vs_torch(cuda):
     xr = _leaf(x0, cuda)
     got, gg, wgt = _grads(lambda: ag.max_pool3x3s2(x), [x])
     ref, rg, _ = _grads(lambda: F.max_pool2d(xr, 3, 2, 1), [xr], wgt)
-    assert torch.equal(got, ref) and torch.equal(gg[0], rg[0]), "max-pool forward / backward (first maximum wins)"
+    assert torch.equal(got, ref), "max-pool forward"
+    # same arg-max (first maximum of a window wins); overlapping windows add into one pixel in a different order (atomics)
+    assert torch.equal(gg[0] != 0, rg[0] != 0) and float((gg[0] - rg[0]).abs().max()) <= 1e-5, "max-pool backward"
     x0 = torch.randn(2, 24, 12, 8, generator=g)
     for ours, theirs, what in ((ag.pixel_unshuffle2, lambda t: F.pixel_unshuffle(t, 2), "pixel_unshuffle"),
                                (ag.upsample_nearest2, lambda t: F.interpolate(t, scale_factor=2, mode="nearest"), "upsample")):
@@ -755,8 +756,11 @@ def test_naive_compressor_trains(cuda):
     xr = _leaf(x0, cuda)
     ref, rg, _ = _grads(lambda: ref_mod(xr), [xr] + params, wgt)
     assert_close(got, ref, 1e-4, "compressor forward")
+    # (a conv bias in front of a batch-statistics BatchNorm has an analytically zero gradient: compared on the scale of the largest one)
+    floor = 1e-3 * max(float(b.abs().max()) for b in rg)
     for i, (a, b) in enumerate(zip(gg, rg)):
-        assert_close(a, b, 2e-4, "compressor grad %d" % i)
+        err = float((a - b).abs().max()) / max(float(b.abs().max()), floor)
+        assert err <= 2e-4, "compressor grad %d: %.3e" % (i, err)
     for k, v in comp.state_dict().items():
         if "running" in k:
             assert_close(v, state[k], 1e-5, k)
