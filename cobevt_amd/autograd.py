@@ -391,6 +391,9 @@ def conv2d(x, conv):
 # glue between the convolutions: BatchNorm (+ residual + ReLU), max-pool, PixelUnshuffle, nearest up-sampling, the STTF warp
 # (csrc/train_glue.hip).  Tensors are (N, C, H, W)-shaped in channels-last memory, fp32 or bf16 (bf16 autocast regions).
 # ----------------------------------------------------------------------------------------------
+USE_TORCH_GLUE = False       # True: BatchNorm / max-pool / PixelUnshuffle / up-sampling through torch's ops (A/B and diagnostics only)
+
+
 def _nhwc(x):
     """(N, C, H, W)-shaped -> contiguous (N, H, W, C) (no copy for channels-last memory); fp16 is widened to fp32"""
     if x.dtype == torch.float16:
@@ -461,7 +464,7 @@ class BatchNormActFn(torch.autograd.Function):
 
 def batch_norm_act(x, bn, residual=None, relu=False):
     """relu?(bn(x) [+ residual]) through the nn.BatchNorm2d container `bn` (its own .training flag decides the statistics)"""
-    if x.shape[1] % 8:                  # channel counts off the 16-byte piece (none in the shipped configs): torch's ops
+    if x.shape[1] % 8 or USE_TORCH_GLUE:    # channel counts off the 16-byte piece (none in the shipped configs): torch's ops
         F = torch.nn.functional
         y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
         y = y + residual if residual is not None else y
@@ -490,6 +493,8 @@ class MaxPool3x3s2Fn(torch.autograd.Function):
 
 
 def max_pool3x3s2(x):
+    if USE_TORCH_GLUE:
+        return torch.nn.functional.max_pool2d(x, 3, 2, 1)
     return MaxPool3x3s2Fn.apply(x)
 
 
@@ -522,6 +527,8 @@ class PixelUnshuffle2Fn(torch.autograd.Function):
 
 
 def pixel_unshuffle2(x):
+    if USE_TORCH_GLUE:
+        return torch.nn.functional.pixel_unshuffle(x, 2)
     return PixelUnshuffle2Fn.apply(x)
 
 
@@ -550,6 +557,8 @@ class UpsampleNearest2Fn(torch.autograd.Function):
 
 
 def upsample_nearest2(x):
+    if USE_TORCH_GLUE:
+        return torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")
     return UpsampleNearest2Fn.apply(x)
 
 

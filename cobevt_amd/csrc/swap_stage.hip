@@ -30,6 +30,8 @@ constexpr int kHRow = 512 + 16;             // 256 bf16 + pad ; also the fp32 st
 constexpr int kRows = 32, kThreads = 256;
 // bias table of the chain (floats): [0,128) bp, [128,384) b1, [384,512) b2, [512,896) bnext (<= 384 columns)
 constexpr int kBp = 0, kB1 = 128, kB2 = 384, kBn = 512, kBiasFloats = 1024;
+// relative-position table image handed over by the host: [4 heads][brows] fp32 (x log2 e) zero-padded to this many bytes
+constexpr int kBiasCopyIters = 10, kBiasCopyBytes = kBiasCopyIters * kThreads * 16;
 
 struct SwapStageParams {
     const bf16_t* qkv;      // [rows][3C]  q | k | v = to_qkv(LayerNorm(x)) of this half
@@ -39,7 +41,7 @@ struct SwapStageParams {
     TokMap map;             // window (0) / grid (1) partition: ncam = agents, HH x WW map, w1 x w2 windows, X x Y groups
     int B, NK, NKP, nsplit;
     float scale;
-    const float* bias_table;    // [bias_rows][heads] fp32
+    const float* bias_table;    // [4 heads][brows] fp32 (brows = bias_rows rounded up to 4) x log2(e), zero-padded to 10240 floats (host)
     int bias_rows, bias_L;
     const float* mask;      // (B, HH, WW, ncam) fp32, 0 = key masked out; nullable
     const uint4* wp; const float* bp;       // to_out            fragment-ordered [4 tiles][8]
@@ -99,7 +101,7 @@ struct StageLds {
         brows = (bias_rows + 3) & ~3;
         vt = 0;
         bias = vt + 4 * 32 * vstr;
-        ktab = bias + 4 * brows * 4;
+        ktab = bias + kBiasCopyBytes;                   // the bias image is copied whole (unconditional 16-byte pieces)
         kmadd = ktab + nkp * 4;
         kterm = kmadd + nkp * 4;
         qterm = kterm + nkp * 4;
@@ -149,47 +151,51 @@ __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams
         cb[it] = keep ? v : 0.f;
     }
 
-    // ---- tables: key token -> row / additive mask / bias key term; query token -> row / bias query term; bias columns
-    for (int tk = tid; tk < p.NKP; tk += kThreads) {
-        int row = -1, info = 0;
-        bool valid = false;
-        if (tk < p.NK) {
-            const TokCoord kc = tok_coord(p.map, tk);
-            row = (int)tok_row(p.map, b, grp, kc);
-            valid = true;
-            if (p.mask) {
-                int ph, pw;
-                tok_pixel(p.map, grp, kc, ph, pw);
-                valid = p.mask[(((size_t)b * p.map.HH + ph) * p.map.WW + pw) * p.map.ncam + kc.cam] != 0.f;
-            }
-            info = 4 * rel_bias_key_term(p.map, kc);
-        }
-        ktab[tk] = row;
-        kmadd[tk] = valid ? 0.f : -INFINITY;
-        kterm[tk] = info;
-    }
-    if (tid < kRows) {
-        const int t = q0 + tid;
-        const bool ok = t < p.NK;
-        const TokCoord qc = tok_coord(p.map, ok ? t : 0);
-        qrow[tid] = ok ? (int)tok_row(p.map, b, grp, qc) : -1;
-        qterm[tid] = 4 * rel_bias_query_term(p.map, p.bias_L, qc);
-    }
+    // ---- tables: key token -> row / additive mask / bias key term; query token -> row / bias query term; bias columns.
+    // Everything is straight-line code with a compile-time trip count: a rolled loop with a global load inside makes the compiler
+    // drain ALL outstanding loads at every iteration (vmcnt(0) at the back edge), which is what the first version's s_memtime
+    // trace showed - tables 9.6k + V^T staging 15.3k of a workgroup's 47k cycles, spent in a dozen serialised round trips.
     {
-        const int n = p.bias_rows * 4;
-        for (int base = 0; base < n; base += kThreads * 8) {
-            float tv[8];
+        constexpr int KIT = (NT * 32 + kThreads - 1) / kThreads;
+        int row[KIT], info[KIT];
+        float mval[KIT];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + u * kThreads + tid;
-                tv[u] = p.bias_table[i < n ? i : n - 1];
-            }
+        for (int it = 0; it < KIT; ++it) {
+            const int tk = tid + it * kThreads;
+            const TokCoord kc = tok_coord(p.map, tk < p.NK ? tk : 0);
+            row[it] = tk < p.NK ? (int)tok_row(p.map, b, grp, kc) : -1;
+            info[it] = tk < p.NK ? 4 * rel_bias_key_term(p.map, kc) : 0;
+            int ph, pw;
+            tok_pixel(p.map, grp, kc, ph, pw);
+            // unconditional load from a valid address (the key mask, or - without one - the bias table as a stand-in)
+            const float* mp = p.mask ? p.mask + (((size_t)b * p.map.HH + ph) * p.map.WW + pw) * p.map.ncam + kc.cam : p.bias_table;
+            mval[it] = *mp;
+        }
+        // the head columns of the bias table, [4][brows] fp32 already scaled by log2(e) and zero-padded to 40 KB on the host
+        // (>= 4 heads x 2475 rows: 6 agents, 8 x 8 windows): unconditional 16-byte copies, one batch - with a bounds test the
+        // compiler fuses load and store into one branch per piece and waits for each load on its own
+        constexpr int BIT = kBiasCopyIters;
+        uint4 bv[BIT];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + u * kThreads + tid;
-                if (i < n) biasl[(i & 3) * L.brows + (i >> 2)] = tv[u] * kLog2e;
+        for (int u = 0; u < BIT; ++u) bv[u] = ((const uint4*)p.bias_table)[u * kThreads + tid];
+        if (tid < kRows) {
+            const int t = q0 + tid;
+            const bool ok = t < p.NK;
+            const TokCoord qc = tok_coord(p.map, ok ? t : 0);
+            qrow[tid] = ok ? (int)tok_row(p.map, b, grp, qc) : -1;
+            qterm[tid] = 4 * rel_bias_query_term(p.map, p.bias_L, qc);
+        }
+#pragma unroll
+        for (int it = 0; it < KIT; ++it) {
+            const int tk = tid + it * kThreads;
+            if (tk < NT * 32) {
+                ktab[tk] = row[it];
+                kmadd[tk] = (row[it] >= 0 && (!p.mask || mval[it] != 0.f)) ? 0.f : -INFINITY;
+                kterm[tk] = info[it];
             }
         }
+#pragma unroll
+        for (int u = 0; u < BIT; ++u) ((uint4*)biasl)[u * kThreads + tid] = bv[u];
     }
     __syncthreads();
     STAGE_MARK(1);
@@ -216,33 +222,31 @@ __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams
         unsigned char* vth = Vt + head * 32 * L.vstr;
         // ---- V^T of this head -> LDS: item = (key pair, dh quad); 16-key blocks in the score registers' key order (perm16)
         const bf16_t* vbase = p.qkv + 2 * C + head * 32;
-        const int nitem = p.NKP * 4;
-        for (int base = 0; base < nitem; base += 64 * 5) {
-            uint2 v0[5], v1[5];
+        constexpr int VIT = NT * 2;                         // NT * 32 keys x 4 dh quads / 2 keys per item / 64 lanes
+        // Rows of padded keys are read from row 0 and NOT zeroed: their probabilities are exactly 0 (additive -inf) and row 0 holds
+        // finite values, so they add nothing - while a `row >= 0 ? load : 0` select makes hipcc put the load under a branch
+        // (s_cbranch_execz + a full lgkmcnt / vmcnt drain per item: 15k of the first version's 47k cycles)
+        int2 rr[VIT];
 #pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                const int item = base + u * 64 + lane;
-                const int it = item < nitem ? item : 0;
-                const int kp = it >> 3, dq = it & 7;
-                const int r0 = ktab[2 * kp], r1 = ktab[2 * kp + 1];
-                const uint2 a0 = *(const uint2*)(vbase + (size_t)(r0 < 0 ? 0 : r0) * ld + dq * 4);
-                const uint2 a1 = *(const uint2*)(vbase + (size_t)(r1 < 0 ? 0 : r1) * ld + dq * 4);
-                v0[u] = r0 >= 0 ? a0 : make_uint2(0, 0);
-                v1[u] = r1 >= 0 ? a1 : make_uint2(0, 0);
-            }
+        for (int u = 0; u < VIT; ++u) rr[u] = *(const int2*)(ktab + 2 * ((u * 64 + lane) >> 3));
+        uint2 v0[VIT], v1[VIT];
 #pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                const int item = base + u * 64 + lane;
-                if (item >= nitem) continue;
-                const int kp = item >> 3, dq = item & 7;
-                const int pos = ((2 * kp) & ~15) | perm16((2 * kp) & 15);        // even key of the pair; its partner sits at pos + 1
-                const uint32_t a[2] = {v0[u].x, v0[u].y}, c[2] = {v1[u].x, v1[u].y};
+        for (int u = 0; u < VIT; ++u) {
+            const int dq = lane & 7;
+            v0[u] = *(const uint2*)(vbase + (size_t)max(rr[u].x, 0) * ld + dq * 4);
+            v1[u] = *(const uint2*)(vbase + (size_t)max(rr[u].y, 0) * ld + dq * 4);
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int dh = dq * 4 + e;
-                    const uint32_t lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xffffu, hi = (c[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
-                    *(uint32_t*)(vth + dh * L.vstr + pos * 2) = lo | (hi << 16);
-                }
+        for (int u = 0; u < VIT; ++u) {
+            const int item = u * 64 + lane;
+            const int kp = item >> 3, dq = item & 7;
+            const int pos = ((2 * kp) & ~15) | perm16((2 * kp) & 15);        // even key of the pair; its partner sits at pos + 1
+            const uint32_t a[2] = {v0[u].x, v0[u].y}, c[2] = {v1[u].x, v1[u].y};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int dh = dq * 4 + e;
+                const uint32_t lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xffffu, hi = (c[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+                *(uint32_t*)(vth + dh * L.vstr + pos * 2) = lo | (hi << 16);
             }
         }
     }
@@ -268,22 +272,55 @@ __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams
             mfma_kgroup<bf16_t>(ka[t][0], qf0, s[t]);       // S^T tile: rows = keys t*32 + acc_row(r), column = this lane's query
             mfma_kgroup<bf16_t>(ka[t][1], qf1, s[t]);
         }
+        // bias + mask: per tile 4 x (kmadd, kterm) 16-byte reads, then 16 dependent 4-byte gathers.  Software-pipelined by hand -
+        // tile t's math runs under tile t+1's gathers and tile t+2's table reads (as written first, every tile paid two exposed
+        // LDS round trips: "read, wait, gather, wait, add")
         float mloc = -INFINITY;
+        f32x4 madd[2][4];
+        uint4 kt[2][4];
+        float bg[2][16];
+        auto read_tables = [&](int t, int slot) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int kb = t * 32 + 8 * g + 4 * h;
+                madd[slot][g] = *(const f32x4*)(kmadd + kb);
+                kt[slot][g] = *(const uint4*)(kterm + kb);
+            }
+        };
+        auto gather = [&](int slot) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bg[slot][4 * g] = *(const float*)(bias_qp - kt[slot][g].x);
+                bg[slot][4 * g + 1] = *(const float*)(bias_qp - kt[slot][g].y);
+                bg[slot][4 * g + 2] = *(const float*)(bias_qp - kt[slot][g].z);
+                bg[slot][4 * g + 3] = *(const float*)(bias_qp - kt[slot][g].w);
+            }
+        };
+        read_tables(0, 0);
+        if (NT > 1) read_tables(1, 1);
+        gather(0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            const int cur = t & 1, nxt = cur ^ 1;
+            float b_[16];
+            f32x4 m_[4];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) b_[r] = bg[cur][r];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) m_[g] = madd[cur][g];
+            if (t + 1 < NT) gather(nxt);                     // kt[nxt] was requested one step ago
+            if (t + 2 < NT) read_tables(t + 2, cur);         // (kt[cur] / madd[cur] are consumed above)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {                    // registers 4g..4g+3 <-> keys kb..kb+3
-                const int kb = t * 32 + 8 * g + 4 * h;
-                const f32x4 add = *(const f32x4*)(kmadd + kb);
-                const uint4 ki = *(const uint4*)(kterm + kb);
-                const float b0 = *(const float*)(bias_qp - ki.x), b1 = *(const float*)(bias_qp - ki.y);
-                const float b2 = *(const float*)(bias_qp - ki.z), b3 = *(const float*)(bias_qp - ki.w);
-                s[t][4 * g] = fmaf(s[t][4 * g], sl2, b0 + add.x);
-                s[t][4 * g + 1] = fmaf(s[t][4 * g + 1], sl2, b1 + add.y);
-                s[t][4 * g + 2] = fmaf(s[t][4 * g + 2], sl2, b2 + add.z);
-                s[t][4 * g + 3] = fmaf(s[t][4 * g + 3], sl2, b3 + add.w);
+                s[t][4 * g] = fmaf(s[t][4 * g], sl2, b_[4 * g] + m_[g].x);
+                s[t][4 * g + 1] = fmaf(s[t][4 * g + 1], sl2, b_[4 * g + 1] + m_[g].y);
+                s[t][4 * g + 2] = fmaf(s[t][4 * g + 2], sl2, b_[4 * g + 2] + m_[g].z);
+                s[t][4 * g + 3] = fmaf(s[t][4 * g + 3], sl2, b_[4 * g + 3] + m_[g].w);
                 mloc = fmaxf(fmaxf(mloc, fmaxf(s[t][4 * g], s[t][4 * g + 1])), fmaxf(s[t][4 * g + 2], s[t][4 * g + 3]));
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         const float m_all = xor32_max(mloc);
         const float m_safe = (m_all == -INFINITY) ? 0.f : m_all;
@@ -541,6 +578,7 @@ extern "C" int cobevt_swap_fusion_stage(const void* qkv, const void* x, void* ou
     p.NKP = nt * 32;
     const int want_rows = (2 * p.bias_L - 1) * (2 * p.map.w1 - 1) * (2 * p.map.w2 - 1);
     if (p.bias_L != p.map.ncam || p.bias_rows != want_rows) return COBEVT_ERR_SHAPE;
+    if (4 * ((p.bias_rows + 3) & ~3) * 4 > kBiasCopyBytes) return COBEVT_ERR_UNSUPPORTED;
     if ((long)p.B * p.map.ncam * p.map.HH * p.map.WW >= 0x7fffffffL / 384) return COBEVT_ERR_SHAPE;
     const StageLds L(p.NKP, p.bias_rows);
     if (L.total > 160 * 1024) return COBEVT_ERR_UNSUPPORTED;

@@ -40,6 +40,22 @@ class Attention(HipModule):
                  + (ca[:, None] - ca[None, :] + w - 1) * (2 * w - 1) + (cb[:, None] - cb[None, :] + w - 1))
         self.register_buffer("relative_position_index", index)
 
+    def stage_bias_table(self):
+        """the relative-position table as the single-launch stage kernel reads it: one column per head, [heads][rows padded to 4],
+        in the base-2 domain (x log2 e), as a flat zero-padded image of ops.SWAP_STAGE_BIAS_FLOATS floats - the kernel copies the
+        whole image into LDS with unconditional 16-byte loads and gathers (query term - key term) from it"""
+        def build(dt, dev):
+            t = self.relative_position_bias_table.weight.detach().to(device=dev, dtype=torch.float32).t().contiguous()
+            rows = t.shape[1]
+            pad = (-rows) % 4
+            if pad:
+                t = torch.nn.functional.pad(t, (0, pad))
+            flat = (t * 1.4426950408889634).reshape(-1)
+            if flat.numel() > ops.SWAP_STAGE_BIAS_FLOATS:
+                return None
+            return torch.nn.functional.pad(flat, (0, ops.SWAP_STAGE_BIAS_FLOATS - flat.numel())).contiguous()
+        return self._plan("stage_table", [self.relative_position_bias_table.weight], build)
+
     def qkv_plan(self, ln=None):
         """to_qkv (with the PreNormResidual LayerNorm `ln` folded in) as a plan the producer of the rows may run."""
         return rt.linear_plan(self, "qkv", self.to_qkv, ln=ln)
@@ -111,10 +127,10 @@ def _attn_ffd(attn_res, ffd_res, x, mask, mode, qkv=None, next_attn=None):
                 mk = mk if mk.is_contiguous() else mk.contiguous()
             if qkv is None and x.dtype == torch.bfloat16:
                 qkv = ops.linear(x, attn.qkv_plan(attn_res.norm))
-            if qkv is not None and ops.swap_stage_fusable(qkv, x, tmap, attn.heads, plan_p, plan_1, plan_2, nxt, mk):
+            table = attn.stage_bias_table() if attn.heads == 4 else None
+            if qkv is not None and table is not None and ops.swap_stage_fusable(qkv, x, tmap, attn.heads, plan_p, plan_1, plan_2, nxt, mk):
                 # the whole half in ONE launch: attention core, to_out + residual, pre-norm FeedForward + residual, and the
                 # next half's LayerNorm + to_qkv (csrc/swap_stage.hip)
-                table = rt.f32_param(attn, "table", attn.relative_position_bias_table.weight)
                 out, qn = ops.swap_stage(qkv, x, tmap, b, attn.heads, attn.scale, table, L, mk, plan_p, plan_1, plan_2, nxt)
                 return (out, qn) if nxt is not None else out
     a = attn.forward_fused(x, mask=mask, mode=mode, ln=attn_res.norm, core_only=True, qkv=qkv)

@@ -1026,15 +1026,22 @@ def swap_stage_fusable(qkv, x, tmap, heads, plan_p, plan_1, plan_2, next_plan, m
             and (mask is None or (mask.dtype == torch.float32 and mask.is_contiguous())))
 
 
+SWAP_STAGE_BIAS_FLOATS = 10240     # the kernel copies the relative-position table as a fixed 40-KB image (csrc/swap_stage.hip)
+
+
 def swap_stage(qkv, x, tmap, batch, heads, scale, bias_table, bias_L, mask, plan_p, plan_1, plan_2, next_plan=None):
     """One SwapFusionBlock half: x (b, l, h, w, 128) + its qkv = to_qkv(LN(x)) (b, l, h, w, 384) -> x_out (and the next
-    half's to_qkv(LN(x_out)) when next_plan is given).  Caller checks swap_stage_fusable() first."""
+    half's to_qkv(LN(x_out)) when next_plan is given).  bias_table: the flat SWAP_STAGE_BIAS_FLOATS image of
+    swap_fusion_modules.Attention.stage_bias_table().  Caller checks swap_stage_fusable() first."""
     _need_cuda(qkv, x, bias_table, mask)
     c, hd = 128, plan_1.cout
     out = torch.empty_like(x)
     nn_ = next_plan.cout if next_plan is not None else 0
     qkv_next = torch.empty(x.shape[:-1] + (nn_,), device=x.device, dtype=x.dtype) if next_plan is not None else None
-    dims = _ints([0, batch, c, heads, hd, plan_2.kp_rows, nn_, bias_table.shape[0], bias_L])
+    bias_rows = (2 * bias_L - 1) * (2 * tmap[4] - 1) * (2 * tmap[5] - 1)
+    if bias_table.numel() != SWAP_STAGE_BIAS_FLOATS or bias_table.dtype != torch.float32 or not bias_table.is_contiguous():
+        raise CobevtHipError("swap_stage: bias table must be the flat fp32 image of stage_bias_table()")
+    dims = _ints([0, batch, c, heads, hd, plan_2.kp_rows, nn_, bias_rows, bias_L])
     m = x.numel() // c
     nk = tmap[1] * tmap[4] * tmap[5]
 

@@ -434,8 +434,9 @@ int cobevt_proj_chain(const void* a, const float* pre_scale, const float* pre_sh
  * window / grid group through attention (one wave per head, K rows straight from L2, V^T in LDS) and the row chain; the
  * attention output never reaches memory (csrc/swap_stage.hip).
  * qkv [rows][384] = to_qkv(LayerNorm(x)) (q | k | v), x / out [rows][128], qkv_next [rows][Nn] (nullable with wn / bn);
- * rows = (b, l, h, w).  map (int32[8]): mode, L, H, W, w1, w2, X, Y as for cobevt_window_attention.  bias_table
- * [(2L-1)(2w1-1)(2w2-1)][4] fp32; mask (B, H, W, L) fp32 (0 = key masked out) or null.  Weights in MFMA fragment order as for
+ * rows = (b, l, h, w).  map (int32[8]): mode, L, H, W, w1, w2, X, Y as for cobevt_window_attention.  bias_table: the
+ * relative-position table one column per head, [4][bias_rows rounded up to a multiple of 4] fp32, multiplied by log2(e) (the
+ * kernel's softmax runs in the base-2 domain) and zero-padded to 10240 floats (copied whole), bias_rows = (2L-1)(2w1-1)(2w2-1); mask (B, H, W, L) fp32 (0 = key masked out) or null.  Weights in MFMA fragment order as for
  * cobevt_attn_mlp_chain (wp: to_out, w1 / b1: fc1 with the LayerNorm affine folded in, w2 / b2: fc2, wn / bn: next to_qkv
  * with its LayerNorm folded in).  dims (int32[9]): dtype (0), B, C (128), heads (4), Hd, Hdp, Nn, bias_rows, bias_L.
  */

@@ -1168,12 +1168,11 @@ def test_projection_chain_single_launch(cuda, rows, with_res):
         fused = ops.proj_chain(xb, pp, pn, residual=rb)
         key = ops.conv2d(xb.reshape(1, 1, rows, 128), pp, residual=None if rb is None else rb.reshape(1, 1, rows, 128)).reshape(rows, 128)
         two = ops.linear(key, pn)
-    with torch.no_grad():
-        xr = xb.float().cpu()
-        y = torch.relu(bn(xr.t().reshape(1, 128, rows, 1))).reshape(128, rows).t() @ conv.weight.reshape(128, 128).t().cpu()
+    with torch.no_grad():                                  # fp32 torch on the device over the same bf16-rounded inputs
+        y = torch.relu(owner.bn(xb.float().t().reshape(1, 128, rows, 1))).reshape(128, rows).t() @ owner.conv.weight.reshape(128, 128).t()
         if with_res:
-            y = y + rb.float().cpu()
-        ref = lin.cpu()(ln.cpu()(y.to(torch.bfloat16).float()))
+            y = y + rb.float()
+        ref = owner.lin(owner.ln(y.to(torch.bfloat16).float())).cpu()
     s = float(ref.abs().max())
     assert (fused.float().cpu() - ref).abs().max().item() <= 1.5e-2 * s
     assert (fused.float() - two.float()).abs().max().item() <= 1.5e-2 * s
