@@ -392,6 +392,8 @@ def conv2d(x, conv):
 # (csrc/train_glue.hip).  Tensors are (N, C, H, W)-shaped in channels-last memory, fp32 or bf16 (bf16 autocast regions).
 # ----------------------------------------------------------------------------------------------
 USE_TORCH_GLUE = False       # True: BatchNorm / max-pool / PixelUnshuffle / up-sampling through torch's ops (A/B and diagnostics only)
+TORCH_GLUE_BN_IDS = set()    # ... or for the BatchNorm containers with these id()s (tools/train_grad_diag.py bisects by module name)
+TORCH_GLUE_OPS = set()       # ... or only some of them: {"bn", "bn_res", "bn_plain", "pool", "shuffle", "up", "sttf"} (tools/train_grad_diag.py)
 
 
 def _nhwc(x):
@@ -464,7 +466,9 @@ class BatchNormActFn(torch.autograd.Function):
 
 def batch_norm_act(x, bn, residual=None, relu=False):
     """relu?(bn(x) [+ residual]) through the nn.BatchNorm2d container `bn` (its own .training flag decides the statistics)"""
-    if x.shape[1] % 8 or USE_TORCH_GLUE:    # channel counts off the 16-byte piece (none in the shipped configs): torch's ops
+    if (x.shape[1] % 8 or USE_TORCH_GLUE or id(bn) in TORCH_GLUE_BN_IDS or "bn" in TORCH_GLUE_OPS or ("bn_res" in TORCH_GLUE_OPS and residual is not None)
+            or ("bn_plain" in TORCH_GLUE_OPS and residual is None)):
+        # channel counts off the 16-byte piece (none in the shipped configs), or a diagnostic switch: torch's ops
         F = torch.nn.functional
         y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
         y = y + residual if residual is not None else y
@@ -493,7 +497,7 @@ class MaxPool3x3s2Fn(torch.autograd.Function):
 
 
 def max_pool3x3s2(x):
-    if USE_TORCH_GLUE:
+    if USE_TORCH_GLUE or "pool" in TORCH_GLUE_OPS:
         return torch.nn.functional.max_pool2d(x, 3, 2, 1)
     return MaxPool3x3s2Fn.apply(x)
 
@@ -527,7 +531,7 @@ class PixelUnshuffle2Fn(torch.autograd.Function):
 
 
 def pixel_unshuffle2(x):
-    if USE_TORCH_GLUE:
+    if USE_TORCH_GLUE or "shuffle" in TORCH_GLUE_OPS:
         return torch.nn.functional.pixel_unshuffle(x, 2)
     return PixelUnshuffle2Fn.apply(x)
 
@@ -557,7 +561,7 @@ class UpsampleNearest2Fn(torch.autograd.Function):
 
 
 def upsample_nearest2(x):
-    if USE_TORCH_GLUE:
+    if USE_TORCH_GLUE or "up" in TORCH_GLUE_OPS:
         return torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")
     return UpsampleNearest2Fn.apply(x)
 

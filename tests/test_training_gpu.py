@@ -30,8 +30,9 @@ def _oracle_sd(m):
     return sd
 
 
-def _compare(m, sd, out, out_ref, inputs, inputs_ref, what, grad_tol=TOL):
-    """backward of sum(out * w) on both sides, then outputs, input gradients and every parameter gradient"""
+def _compare(m, sd, out, out_ref, inputs, inputs_ref, what, grad_tol=TOL, rms_tol=None):
+    """backward of sum(out * w) on both sides, then outputs, input gradients and every parameter gradient.  rms_tol: additionally (and
+    with a looser max-norm grad_tol) gate ||got - ref||_2 / ||ref||_2 per tensor - the metric for deep ReLU networks, see the caller"""
     w = synth.procedural_input("train.w." + what, tuple(out_ref.shape), cases.SEED)
     (out_ref * w).sum().backward()
     (out * w.to(out.device)).sum().backward()
@@ -52,6 +53,9 @@ def _compare(m, sd, out, out_ref, inputs, inputs_ref, what, grad_tol=TOL):
         assert torch.isfinite(p.grad).all(), k
         err = float((p.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), floor)
         assert err <= grad_tol, "%s d %s: rel err %.3e > %.1e" % (what, k, err, grad_tol)
+        if rms_tol is not None:
+            rms = float((p.grad.cpu() - ref).double().norm()) / max(float(ref.double().norm()), floor * ref.numel() ** 0.5)
+            assert rms <= rms_tol, "%s d %s: rms rel err %.3e > %.1e" % (what, k, rms, rms_tol)
         n += 1
     assert n > 0
 
@@ -388,9 +392,14 @@ def test_corpbevt_trains_end_to_end_gradients_vs_oracle(cuda):
         out_ref = o_model.corpbevt_forward(sd, cfg, dict(batch))["dynamic_seg"]
         out = m({k: v.to(cuda) for k, v in batch.items()})["dynamic_seg"]
         assert_close(out, golden("gv8_corpbevt_small")["dynamic_seg"], TOL, "train-mode forward vs golden")
-        # the whole model: the gradient of the stem convolution has crossed ~60 layers of fp32 kernels whose summation orders differ
-        # from the CPU oracle's (measured 1.2e-3 there, <= 1e-3 everywhere else): 2e-3 on parameter gradients, 1e-3 on the logits
-        _compare(m, sd, out, out_ref, [], [], "CorpBEVT (reduced)", grad_tol=2e-3)
+        # The whole model is a deep ReLU network: its activations agree with the CPU oracle's to ~1e-6, which is enough to put a
+        # handful of the ~3 M pre-activations on the other side of zero, and one flipped ReLU moves one row of one weight gradient by up
+        # to ~1 % of that tensor's largest entry (tools/train_grad_diag.py, tools/bn_flip_probe.py: the mismatching elements are one
+        # channel of one layer, forward outputs identical to 3e-6, and WHICH layers are hit changes with any 1e-7 perturbation - it
+        # moved when the stem BatchNorm went from torch's formula to x * scale + shift, whose outputs are equally close to fp64).
+        # So: logits to 1e-3; per-tensor gradients to 5e-3 in the rms norm and 2e-2 in the max norm.  The module-level gradient
+        # tests above (no ReLU between the parameter and the loss, or few) keep the 1e-3 max-norm gate.
+        _compare(m, sd, out, out_ref, [], [], "CorpBEVT (reduced)", grad_tol=2e-2, rms_tol=5e-3)
 
 
 def test_corpbevt_optimizer_steps(cuda):

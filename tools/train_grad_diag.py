@@ -56,14 +56,37 @@ def run(label):
     print("%-28s forward %.2e | worst: %s" % (label, fwd, ", ".join("%s %.2e" % (k.replace("encoder.encoder.", "enc."), e) for e, k in errs[:4])))
 
 
-for rep in range(2):
-    ag.USE_LIBRARY_GEMM, ag.USE_TORCH_GLUE = False, False
-    run("package kernels #%d" % rep)
-for rep in range(2):
-    ag.USE_LIBRARY_GEMM, ag.USE_TORCH_GLUE = True, False
-    run("library GEMM linears #%d" % rep)
-for rep in range(2):
-    ag.USE_LIBRARY_GEMM, ag.USE_TORCH_GLUE = False, True
-    run("torch glue #%d" % rep)
-ag.USE_LIBRARY_GEMM, ag.USE_TORCH_GLUE = True, True
-run("library GEMM + torch glue")
+ag.USE_LIBRARY_GEMM, ag.USE_TORCH_GLUE = False, False
+run("package kernels")
+bns = [(k, mod) for k, mod in m.named_modules() if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm)]
+stem = {id(mod) for k, mod in bns if k == "encoder.encoder.bn1"}
+others = {id(mod) for k, mod in bns if k != "encoder.encoder.bn1"}
+
+
+def grads(label):
+    m.zero_grad(set_to_none=True)
+    with torch.enable_grad():
+        out = m({k: v.to(dev) for k, v in batch.items()})["dynamic_seg"]
+        (out * w.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+
+ag.TORCH_GLUE_BN_IDS = stem | others
+ga = grads("all torch BN")
+ag.TORCH_GLUE_BN_IDS = others
+gb = grads("HIP stem BN only")
+gb2 = grads("HIP stem BN only (again)")
+print("params whose gradient differs between `all torch BN` and `HIP stem BN only` (rel to the tensor's max):")
+for k in ga:
+    d = float((ga[k] - gb[k]).abs().max()) / max(float(ga[k].abs().max()), 1e-30)
+    d2 = float((gb2[k] - gb[k]).abs().max()) / max(float(gb[k].abs().max()), 1e-30)
+    if d > 1e-5 or d2 > 1e-5:
+        bad = (ga[k] - gb[k]).abs() > 1e-4 * ga[k].abs().max()
+        print("  %-50s diff %.2e (run-to-run %.2e) shape %s ptr %x mismatching elements %d of %d" % (k, d, d2, tuple(ga[k].shape), gb[k].data_ptr(), int(bad.sum()), bad.numel()))
+ag.TORCH_GLUE_BN_IDS = set()
+run("all HIP BN, torch pool")
+ag.TORCH_GLUE_OPS = set()
+ag.TORCH_GLUE_BN_IDS = stem
+run("torch stem BN")
+ag.TORCH_GLUE_BN_IDS = set()
