@@ -204,16 +204,29 @@ def gelu(x):
     return GeluFn.apply(x)
 
 
+_SCRATCH_BLOCKS = 512         # per-workgroup partial sums of the channel reductions (fp64 [blocks][2][C]); see csrc/train_glue.hip
+
+
+def _scratch(c, device):
+    return torch.empty(_SCRATCH_BLOCKS * 2 * c, device=device, dtype=torch.float64)
+
+
 def column_sum(rows2d):
     """fp32 (C,) = sum over the rows of a contiguous (rows, C) fp32 / bf16 matrix (bias gradients): cobevt_channel_sums, fp64
     partial sums per workgroup"""
     _need_cuda(rows2d)
     m, c = rows2d.shape
-    acc = torch.zeros(c, device=rows2d.device, dtype=torch.float64)
-    out = torch.empty(c, device=rows2d.device, dtype=torch.float32)
+    acc = torch.empty(c, device=rows2d.device, dtype=torch.float64)
     lib = _L.load()
-    _L.check(lib.cobevt_channel_sums(_p(rows2d), _p(acc), None, ops.dcode(rows2d.dtype), m, c, _stream()), "cobevt_channel_sums")
-    _L.check(lib.cobevt_f64_to_f32(_p(acc), _p(out), c, _stream()), "cobevt_f64_to_f32")
+    if c % 8:
+        out = torch.empty(c, device=rows2d.device, dtype=torch.float32)
+        _L.check(lib.cobevt_channel_sums(_p(rows2d), None, _p(acc), None, None, None, 0, ops.dcode(rows2d.dtype), m, c, _stream()),
+                 "cobevt_channel_sums")
+        _L.check(lib.cobevt_f64_to_f32(_p(acc), _p(out), c, _stream()), "cobevt_f64_to_f32")
+        return out
+    out = torch.empty(c, device=rows2d.device, dtype=torch.float32)
+    _L.check(lib.cobevt_channel_sums(_p(rows2d), None, _p(acc), None, _p(out), _p(_scratch(c, rows2d.device)), _SCRATCH_BLOCKS,
+                                     ops.dcode(rows2d.dtype), m, c, _stream()), "cobevt_channel_sums")
     return out
 
 
@@ -229,7 +242,15 @@ def linear(x, lin):
         return torch.nn.functional.linear(x, lin.weight, lin.bias)
     k = x.shape[-1]
     rows = x.numel() // k
-    x4 = x.reshape(1, rows, 1, k).permute(0, 3, 1, 2)                  # (1, K, rows, 1)-shaped view of channels-last memory
+    # any (H, W) factorisation of the rows is the same 1 x 1 convolution; the blocked weight-gradient kernel walks 16-pixel blocks of
+    # map rows and shares rows out over workgroups, so the rows are presented as an H x W map with a wide W (as (rows, 1) every
+    # "map row" was one pixel padded to 16: 20 ms of padding copies per 5-agent step)
+    mh, mw = rows, 1
+    for cand in (256, 128, 64, 32, 16):
+        if rows % cand == 0 and rows // cand >= 4:
+            mh, mw = rows // cand, cand
+            break
+    x4 = x.reshape(1, mh, mw, k).permute(0, 3, 1, 2)                   # (1, K, H, W)-shaped view of channels-last memory
     w4 = lin.weight[:, :, None, None]
     if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
         with torch.autocast("cuda", enabled=False):
@@ -424,15 +445,17 @@ class BatchNormActFn(torch.autograd.Function):
         g = None if gamma is None else _f32c(gamma.float(), "gamma")
         b = None if beta is None else _f32c(beta.float(), "beta")
         sums = None
-        if training:
-            sums = torch.zeros((2, c), device=dev, dtype=torch.float64)
-            _L.check(lib.cobevt_channel_sums(_p(xl), _p(sums[0]), _p(sums[1]), dt, rows, c, _stream()), "cobevt_channel_sums")
         track = bn.track_running_stats and bn.running_mean is not None
+        if training:        # sums of x - running_mean (when there is one): no cancellation in the variance, fp32 partial sums suffice
+            sums = torch.empty((2, c), device=dev, dtype=torch.float64)
+            _L.check(lib.cobevt_channel_sums(_p(xl), _p(bn.running_mean) if track else None, _p(sums[0]), _p(sums[1]), None,
+                                             _p(_scratch(c, dev)), _SCRATCH_BLOCKS, dt, rows, c, _stream()), "cobevt_channel_sums")
         momentum = 0.1 if bn.momentum is None else bn.momentum
         _L.check(lib.cobevt_bn_finalize(_p(sums[0]) if training else None, _p(sums[1]) if training else None, _p(g), _p(b),
                                         _p(bn.running_mean) if track else None, _p(bn.running_var) if track else None,
                                         _p(scale), _p(shift), _p(mean), _p(rstd), c, rows, ctypes.c_float(bn.eps),
-                                        ctypes.c_float(momentum), int(training), _stream()), "cobevt_bn_finalize")
+                                        ctypes.c_float(momentum), int(training), int(bool(training and track)), _stream()),
+                 "cobevt_bn_finalize")
         if training and track and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
         y = torch.empty_like(xl)
@@ -449,18 +472,16 @@ class BatchNormActFn(torch.autograd.Function):
         n, h, w, c = xl.shape
         rows = n * h * w
         dyl = _nhwc(dy.to(xl.dtype))
-        acc = torch.zeros((2, c), device=xl.device, dtype=torch.float64)
+        acc = torch.empty((2, c), device=xl.device, dtype=torch.float64)
+        f = torch.empty((2, c), device=xl.device, dtype=torch.float32) if (has_g or has_b) else None
         dx = torch.empty_like(xl)
         dres = torch.empty_like(xl) if has_res else None
         lib = _L.load()
-        _L.check(lib.cobevt_bn_backward(_p(xl), _p(y), _p(dyl), _p(mean), _p(rstd), _p(g), _p(acc[0]), _p(acc[1]), _p(dx), _p(dres),
-                                        ops.dcode(xl.dtype), rows, c, act, training, _stream()), "cobevt_bn_backward")
-        dg = db = None
-        if has_g or has_b:
-            f = torch.empty((2, c), device=xl.device, dtype=torch.float32)
-            _L.check(lib.cobevt_f64_to_f32(_p(acc), _p(f), 2 * c, _stream()), "cobevt_f64_to_f32")
-            dg = f[0].to(pdt) if has_g else None
-            db = f[1].to(pdt) if has_b else None
+        _L.check(lib.cobevt_bn_backward(_p(xl), _p(y), _p(dyl), _p(mean), _p(rstd), _p(g), _p(acc), _p(f), _p(_scratch(c, xl.device)),
+                                        _SCRATCH_BLOCKS, _p(dx), _p(dres), ops.dcode(xl.dtype), rows, c, act, training, _stream()),
+                 "cobevt_bn_backward")
+        dg = f[0].to(pdt) if has_g else None
+        db = f[1].to(pdt) if has_b else None
         return (dx.permute(0, 3, 1, 2), None if dres is None else dres.permute(0, 3, 1, 2), dg, db, None, None, None)
 
 
@@ -490,7 +511,7 @@ class MaxPool3x3s2Fn(torch.autograd.Function):
         (xl,) = ctx.saved_tensors
         n, h, w, c = xl.shape
         dyl = _nhwc(dy.to(xl.dtype))
-        dx = torch.zeros((n, h, w, c), device=xl.device, dtype=torch.float32)
+        dx = torch.empty((n, h, w, c), device=xl.device, dtype=torch.float32)
         _L.check(_L.load().cobevt_maxpool3x3s2_bwd(_p(xl), _p(dyl), _p(dx), ops.dcode(xl.dtype), n, h, w, c, _stream()),
                  "cobevt_maxpool3x3s2_bwd")
         return dx.to(xl.dtype).permute(0, 3, 1, 2)

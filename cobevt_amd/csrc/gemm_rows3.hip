@@ -34,6 +34,10 @@ struct Gr3Params {
     // (fax_modules.py:370-375,387-388) of row m = ((b * n + cam) * hw + pix), produced while staging; `in` is x (B | 1, hw, K)
     const float* emb_E; const float* emb_world; const float* emb_wbev; const float* emb_bbev; const float* emb_wcam;
     int emb_n, emb_hw, emb_xbcast;
+    // navg > 1: A row m = (b, r) is the MEAN of the navg rows in[b * avg_batch_stride + j * avg_stride + r * lda], j < navg
+    // (SwapFusionEncoder.mlp_head: Reduce('b m d h w -> b d h w', 'mean') -> LayerNorm -> Linear, swap_fusion_modules.py:275-281)
+    int navg, avg_rows_per_batch;
+    long avg_stride, avg_batch_stride;
 };
 
 constexpr int kG3Row = 256 + 16;            // staged output row: 128 bf16 + pad
@@ -110,6 +114,10 @@ __global__ __launch_bounds__(ROWS * 8, 4) void gemm_rows3_kernel(Gr3Params p) {
             arow_idx = (size_t)(p.emb_xbcast ? 0 : bn / p.emb_n) * p.emb_hw + pix;
         }
         const bf16_t* src = p.in + arow_idx * p.lda;
+        if (p.navg > 1) {
+            const long bb = (long)arow_idx / p.avg_rows_per_batch, rr = (long)arow_idx - bb * p.avg_rows_per_batch;
+            src = p.in + bb * p.avg_batch_stride + rr * p.lda;
+        }
         for (int kt = 0; kt < nkt; ++kt) {
             const int kb = kt * 128 + sub * 16;
             uint4 raw[2];
@@ -118,6 +126,19 @@ __global__ __launch_bounds__(ROWS * 8, 4) void gemm_rows3_kernel(Gr3Params p) {
             float v[16];
             chunk_to_f32<bf16_t>(raw[0], v);
             chunk_to_f32<bf16_t>(raw[1], v + 8);
+            if (p.navg > 1) {
+                for (int a = 1; a < p.navg; ++a) {
+                    float u[16];
+                    const bf16_t* sa = src + a * p.avg_stride;
+                    chunk_to_f32<bf16_t>(*(const uint4*)(sa + (kb < p.K ? kb : 0)), u);
+                    chunk_to_f32<bf16_t>(*(const uint4*)(sa + (kb + 8 < p.K ? kb + 8 : 0)), u + 8);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] += u[e];
+                }
+                const float inv = 1.0f / (float)p.navg;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] *= inv;
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 if (!ok || kb + e >= p.K) v[e] = 0.f;
@@ -256,6 +277,7 @@ extern "C" int cobevt_linear_rows_small_k(const void* in, const void* wfrag, con
     const unsigned blocks = (unsigned)((p.M + rows - 1) / rows);
     p.emb_E = p.emb_world = p.emb_wbev = p.emb_bbev = p.emb_wcam = nullptr;
     p.emb_n = p.emb_hw = 1; p.emb_xbcast = 0;
+    p.navg = 1; p.avg_rows_per_batch = 1; p.avg_stride = p.avg_batch_stride = 0;
     if (rows == 64) {
         static cobevt::PerDeviceOnce attr_once;
         if (attr_once.first()) {
@@ -287,8 +309,34 @@ extern "C" int cobevt_bev_embed_linear_rows_small_k(const float* E_inv, const fl
     p.M = (int)(B * n * hw);
     p.emb_E = E_inv; p.emb_world = world; p.emb_wbev = w_bev; p.emb_bbev = b_bev; p.emb_wcam = w_cam;
     p.emb_n = (int)n; p.emb_hw = (int)hw; p.emb_xbcast = (int)dims[7];
+    p.navg = 1; p.avg_rows_per_batch = 1; p.avg_stride = p.avg_batch_stride = 0;
     const size_t lds = (size_t)kG3Rows * (p.Kp * 2 + 16) + (size_t)kG3Rows * kG3Row + (size_t)((p.N + 127) / 128) * 128 * 4 + 128 * 16;
     const unsigned blocks = (unsigned)((p.M + kG3Rows - 1) / kG3Rows);
     hipLaunchKernelGGL((gemm_rows3_kernel<true, 32>), dim3(blocks), dim3(256), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// C-ABI entry point, see include/cobevt_hip.h: out (B * R, N) = act(LayerNorm?(mean_j in[b][j][r][:]) . W^T + bias), in (B, L, R, K)
+extern "C" int cobevt_mean_linear_rows_small_k(const void* in, const void* wfrag, const float* bias, void* out, const long* dims,
+                                               float ln_eps, hipStream_t stream) {
+    // dims: [dtype(0), B, L, R, K, N, ln, act]
+    if (!in || !wfrag || !out || !dims) return COBEVT_ERR_ARG;
+    if (dims[0] != 0) return COBEVT_ERR_UNSUPPORTED;
+    const long B = dims[1], Lr = dims[2], R = dims[3];
+    Gr3Params p;
+    p.in = (const bf16_t*)in; p.wfrag = (const uint4*)wfrag; p.bias = bias; p.residual = nullptr;
+    p.pre_scale = p.pre_shift = nullptr; p.out = (bf16_t*)out;
+    p.K = (int)dims[4]; p.N = (int)dims[5]; p.ln = (int)dims[6]; p.act = (int)dims[7]; p.ln_eps = ln_eps;
+    p.Kp = 128; p.lda = p.K; p.pre_relu = 0;
+    p.in_stride = 1; p.src_H = p.src_W = p.in_H = p.in_W = 1;
+    if (B < 1 || Lr < 1 || Lr > 64 || R < 1 || B * R > 0x7fffffffL) return COBEVT_ERR_SHAPE;
+    if (p.N < 8 || p.N % 8 || p.N > 4096 || p.K < 8 || p.K > 128 || p.K % 8 || p.act < 0 || p.act > 4) return COBEVT_ERR_SHAPE;
+    p.M = (int)(B * R);
+    p.emb_E = p.emb_world = p.emb_wbev = p.emb_bbev = p.emb_wcam = nullptr;
+    p.emb_n = p.emb_hw = 1; p.emb_xbcast = 0;
+    p.navg = (int)Lr; p.avg_rows_per_batch = (int)R; p.avg_stride = R * p.K; p.avg_batch_stride = Lr * R * p.K;
+    const size_t lds = (size_t)kG3Rows * (p.Kp * 2 + 16) + (size_t)kG3Rows * kG3Row + (size_t)((p.N + 127) / 128) * 128 * 4;
+    const unsigned blocks = (unsigned)((p.M + kG3Rows - 1) / kG3Rows);
+    hipLaunchKernelGGL((gemm_rows3_kernel<false, 32>), dim3(blocks), dim3(256), lds, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

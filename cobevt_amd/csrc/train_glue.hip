@@ -19,42 +19,45 @@ constexpr int kThreads = 256;
 // ---- per-channel sums over rows: sum[c] += x, sumsq[c] += x^2 (BatchNorm statistics; column sum for bias gradients) ----
 // grid.x = row blocks; a thread owns one 8-channel group (gl) and walks rows gid, gid + stride, ...
 template <typename T, bool SQ>
-__global__ __launch_bounds__(kThreads) void channel_sums_kernel(const T* __restrict__ x, double* __restrict__ sum,
-                                                                double* __restrict__ sumsq, long rows, int C, int rows_per_block) {
+__global__ __launch_bounds__(kThreads) void channel_sums_kernel(const T* __restrict__ x, const float* __restrict__ shift,
+                                                                double* __restrict__ partial, long rows, int C, int rows_per_block) {
+    // partial: [gridDim.x][2][C] fp64 - this workgroup's sums; combined by reduce_partials_kernel.  (Atomics on the C result
+    // words serialise: with 1024 workgroups a launch took ~50 us whatever the map size.)
+    // sums of (x - shift[c]) and (x - shift[c])^2 (shift nullable = 0): with the shift near the mean (BatchNorm passes its running
+    // mean) the variance no longer comes out of a cancellation, so a thread accumulates its <= ~64 rows in fp32 (v_pk_add rate
+    // instead of fp64 conversions per element); threads and workgroups are combined in fp64
     const int G = C >> 3;
     const int gl = threadIdx.x % G, r0 = threadIdx.x / G, rstep = kThreads / G;      // threads with r0 >= rstep idle (256 % G != 0)
     const long row_lo = (long)blockIdx.x * rows_per_block;
     const long row_hi = row_lo + rows_per_block < rows ? row_lo + rows_per_block : rows;
-    double s[8], q[8];
+    float s[8], q[8], sh[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s[e] = 0.0; q[e] = 0.0; }
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; sh[e] = shift ? shift[gl * 8 + e] : 0.f; }
     if (r0 < rstep) {
-        for (long r = row_lo + r0; r < row_hi; r += rstep) {
+        long r = row_lo + r0;
+        for (; r + rstep < row_hi; r += 2 * rstep) {          // two rows in flight
+            float v[8], u[8];
+            load8<T>(x + r * C + gl * 8, v);
+            load8<T>(x + (r + rstep) * C + gl * 8, u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = v[e] - sh[e], b = u[e] - sh[e];
+                s[e] += a + b;
+                if (SQ) q[e] += a * a + b * b;
+            }
+        }
+        if (r < row_hi) {
             float v[8];
             load8<T>(x + r * C + gl * 8, v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s[e] += (double)v[e]; if (SQ) q[e] += (double)v[e] * (double)v[e]; }
+            for (int e = 0; e < 8; ++e) { const float a = v[e] - sh[e]; s[e] += a; if (SQ) q[e] += a * a; }
         }
-        // (the rstep partial sums of a channel group are folded in LDS below: one global atomic per (workgroup, channel))
     }
-    __shared__ double red[kThreads][9];
+    __shared__ float red[kThreads][9];
+    for (int pass = 0; pass < (SQ ? 2 : 1); ++pass) {
+        if (pass) __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = s[e];
-    __syncthreads();
-    if (threadIdx.x < G) {
-        double t[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) t[e] = 0.0;
-        for (int k = 0; k < rstep; ++k)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] += red[k * G + threadIdx.x][e];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(sum + threadIdx.x * 8 + e, t[e]);
-    }
-    if (SQ) {
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = q[e];
+        for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = pass ? q[e] : s[e];
         __syncthreads();
         if (threadIdx.x < G) {
             double t[8];
@@ -62,24 +65,47 @@ __global__ __launch_bounds__(kThreads) void channel_sums_kernel(const T* __restr
             for (int e = 0; e < 8; ++e) t[e] = 0.0;
             for (int k = 0; k < rstep; ++k)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) t[e] += red[k * G + threadIdx.x][e];
+                for (int e = 0; e < 8; ++e) t[e] += (double)red[k * G + threadIdx.x][e];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(sumsq + threadIdx.x * 8 + e, t[e]);
+            for (int e = 0; e < 8; ++e) partial[((size_t)blockIdx.x * 2 + pass) * C + threadIdx.x * 8 + e] = t[e];
         }
     }
+}
+
+__global__ void reduce_partials_strided_kernel(const double* __restrict__ partial, int nblk, int n, int stride, double* __restrict__ out_d,
+                                               float* __restrict__ out_f) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double t = 0.0;
+    for (int b = 0; b < nblk; ++b) t += partial[(size_t)b * stride + j];
+    if (out_d) out_d[j] = t;
+    if (out_f) out_f[j] = (float)t;
+}
+
+// out[j] = sum over the nblk workgroups of partial[b][j], j < n (n = 2 C: the two vectors of a reduction pair back to back)
+__global__ void reduce_partials_kernel(const double* __restrict__ partial, int nblk, int n, double* __restrict__ out_d,
+                                       float* __restrict__ out_f) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double t = 0.0;
+    for (int b = 0; b < nblk; ++b) t += partial[(size_t)b * n + j];
+    if (out_d) out_d[j] = t;
+    if (out_f) out_f[j] = (float)t;
 }
 
 // ---- BatchNorm finalize: stats (training: from the sums; eval: the running statistics) -> per-channel scale / shift, mean / rstd
 // saved for backward, running statistics updated in place (momentum, unbiased variance) as nn.BatchNorm2d does
 __global__ void bn_finalize_kernel(const double* sum, const double* sumsq, const float* gamma, const float* beta, float* running_mean,
                                    float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out, int C,
-                                   double rows, float eps, float momentum, int training) {
+                                   double rows, float eps, float momentum, int training, int shifted) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double mean, var;
     if (training) {
-        mean = sum[c] / rows;
-        var = sumsq[c] / rows - mean * mean;
+        // the sums were taken of x - running_mean (shifted != 0: channel_sums with shift = running_mean, read BEFORE its update below)
+        const double d = sum[c] / rows;
+        var = sumsq[c] / rows - d * d;
+        mean = d + (shifted ? (double)running_mean[c] : 0.0);
         if (var < 0.0) var = 0.0;
         if (running_mean) {
             const double unbiased = rows > 1.0 ? var * rows / (rows - 1.0) : var;
@@ -122,15 +148,14 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const T* __restrict_
 template <typename T>
 __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                 double* __restrict__ dgamma, double* __restrict__ dbeta, long rows, int C,
-                                                                 int act, int rows_per_block) {
+                                                                 double* __restrict__ partial, long rows, int C, int act, int rows_per_block) {
     const int G = C >> 3;
     const int gl = threadIdx.x % G, r0 = threadIdx.x / G, rstep = kThreads / G;
     const long row_lo = (long)blockIdx.x * rows_per_block;
     const long row_hi = row_lo + rows_per_block < rows ? row_lo + rows_per_block : rows;
-    double sg[8], sb[8];
+    float sg[8], sb[8];                              // per-thread partials in fp32 (<= ~64 rows), combined in fp64
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sg[e] = 0.0; sb[e] = 0.0; }
+    for (int e = 0; e < 8; ++e) { sg[e] = 0.f; sb[e] = 0.f; }
     if (r0 < rstep) {
         float mu[8], rs[8];
 #pragma unroll
@@ -143,12 +168,12 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const T* __rest
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float g = (act == 1 && !(yv[e] > 0.f)) ? 0.f : gv[e];
-                sb[e] += (double)g;
-                sg[e] += (double)(g * ((xv[e] - mu[e]) * rs[e]));
+                sb[e] += g;
+                sg[e] += g * ((xv[e] - mu[e]) * rs[e]);
             }
         }
     }
-    __shared__ double red[kThreads][9];
+    __shared__ float red[kThreads][9];
     for (int pass = 0; pass < 2; ++pass) {
         if (pass) __syncthreads();
 #pragma unroll
@@ -160,9 +185,9 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const T* __rest
             for (int e = 0; e < 8; ++e) t[e] = 0.0;
             for (int k = 0; k < rstep; ++k)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) t[e] += red[k * G + threadIdx.x][e];
+                for (int e = 0; e < 8; ++e) t[e] += (double)red[k * G + threadIdx.x][e];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd((pass ? dbeta : dgamma) + threadIdx.x * 8 + e, t[e]);
+            for (int e = 0; e < 8; ++e) partial[((size_t)blockIdx.x * 2 + pass) * C + threadIdx.x * 8 + e] = t[e];
         }
     }
 }
@@ -200,8 +225,10 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const T* __restr
     if (dres) store8<T>(dres + gid * 8, gv);
 }
 
-// ---- MaxPool2d(3, stride 2, padding 1) backward: every output pixel finds its window's first maximum (row-major scan, ties ->
-// the first, as torch) and adds its gradient there
+// ---- MaxPool2d(3, stride 2, padding 1) backward as a GATHER: an input pixel lies in at most 2 x 2 pooling windows; for each of
+// them the window's first maximum (row-major scan, ties -> the first, as torch) is recomputed and the pixel takes that window's
+// gradient if it IS that maximum.  No atomics (the scatter form spent 965 us on the 5-agent stem map, 4 x torch's kernel), the
+// summation order per pixel is fixed, dx is written once (no zero fill).
 template <typename T>
 __global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dx,
                                                                int N, int H, int W, int C, int Ho, int Wo) {
@@ -209,30 +236,45 @@ __global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const T* __restri
     const long item = (long)blockIdx.x * kThreads + threadIdx.x;
     const long gid = item / G;
     const int gl = (int)(item % G);
-    if (gid >= (long)N * Ho * Wo) return;
-    const int ow = (int)(gid % Wo), oh = (int)((gid / Wo) % Ho), n = (int)(gid / ((long)Wo * Ho));
-    float best[8];
-    int arg[8];
+    if (gid >= (long)N * H * W) return;
+    const int iw = (int)(gid % W), ih = (int)((gid / W) % H), n = (int)(gid / ((long)W * H));
+    float mine[8], acc[8];
+    load8<T>(x + gid * C + gl * 8, mine);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; arg[e] = -1; }
-    for (int kh = 0; kh < 3; ++kh) {
-        const int ih = oh * 2 - 1 + kh;
-        if (ih < 0 || ih >= H) continue;
-        for (int kw = 0; kw < 3; ++kw) {
-            const int iw = ow * 2 - 1 + kw;
-            if (iw < 0 || iw >= W) continue;
-            float v[8];
-            load8<T>(x + (((size_t)n * H + ih) * W + iw) * C + gl * 8, v);
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    // windows (oh, ow) containing (ih, iw): oh * 2 - 1 <= ih <= oh * 2 + 1
+    const int oh_lo = ih >> 1, oh_hi = (ih + 1) >> 1, ow_lo = iw >> 1, ow_hi = (iw + 1) >> 1;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+        if (oh >= Ho) continue;
+        for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+            if (ow >= Wo) continue;
+            float best[8];
+            int arg[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; arg[e] = -1; }
+            for (int kh = 0; kh < 3; ++kh) {
+                const int yy = oh * 2 - 1 + kh;
+                if (yy < 0 || yy >= H) continue;
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int xx = ow * 2 - 1 + kw;
+                    if (xx < 0 || xx >= W) continue;
+                    float v[8];
+                    load8<T>(x + (((size_t)n * H + yy) * W + xx) * C + gl * 8, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (v[e] > best[e] || arg[e] < 0) { best[e] = v[e]; arg[e] = yy * W + xx; }
+                }
+            }
+            float g[8];
+            load8<T>(dy + (((size_t)n * Ho + oh) * Wo + ow) * C + gl * 8, g);
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                if (v[e] > best[e] || arg[e] < 0) { best[e] = v[e]; arg[e] = ih * W + iw; }
+                if (arg[e] == ih * W + iw) acc[e] += g[e];
         }
     }
-    float g[8];
-    load8<T>(dy + gid * C + gl * 8, g);
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-        if (arg[e] >= 0) atomicAdd(dx + ((size_t)n * H * W + arg[e]) * C + gl * 8 + e, g[e]);
+    float* o = dx + gid * C + gl * 8;
+    *(float4*)o = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *(float4*)(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
 }
 
 // ---- nn.PixelUnshuffle(2) on channels-last maps: out[n][h][w][c*4 + 2i + j] = in[n][2h + i][2w + j][c]; inverse = 1: the other way
@@ -357,10 +399,10 @@ __global__ __launch_bounds__(kThreads) void channel_sums_generic_kernel(const T*
     if (sumsq) atomicAdd(sumsq + c, q);
 }
 
-inline int row_blocks(long rows, int C, int* rows_per_block) {
+inline int row_blocks(long rows, int C, int* rows_per_block, int cap = 1024) {
     const int rstep = kThreads / (C >> 3);
-    long want = (rows + (long)rstep * 16 - 1) / ((long)rstep * 16);          // >= 16 rows per thread
-    if (want > 1024) want = 1024;
+    long want = (rows + (long)rstep * 8 - 1) / ((long)rstep * 8);            // >= 8 rows per thread
+    if (want > cap) want = cap;
     if (want < 1) want = 1;
     *rows_per_block = (int)((rows + want - 1) / want);
     return (int)((rows + *rows_per_block - 1) / *rows_per_block);
@@ -371,11 +413,16 @@ inline int row_blocks(long rows, int C, int* rows_per_block) {
 
 using namespace cobevt;
 
-// sums (C) and, when sumsq != null, sums of squares of the rows of x (rows, C); fp64 accumulators, ADDED to (zero them first)
-extern "C" int cobevt_channel_sums(const void* x, double* sum, double* sumsq, int dtype, long rows, int C, hipStream_t stream) {
+// sum[c] = sum over the rows of (x - shift[c]) and, when sumsq != null, sumsq[c] = sum of its squares, as fp64 (out_f nullable:
+// the same 2 C values as fp32, sums then sums of squares).  scratch: fp64 [scratch_blocks][2][C] for the per-workgroup partials.
+extern "C" int cobevt_channel_sums(const void* x, const float* shift, double* sum, double* sumsq, float* out_f, double* scratch,
+                                   int scratch_blocks, int dtype, long rows, int C, hipStream_t stream) {
     if (!x || !sum) return COBEVT_ERR_ARG;
     if (C < 1 || rows < 1 || (dtype != 0 && dtype != 1)) return COBEVT_ERR_SHAPE;
     if (!groups_ok(C)) {
+        if (shift || out_f) return COBEVT_ERR_UNSUPPORTED;
+        if (hipMemsetAsync(sum, 0, sizeof(double) * C, stream) != hipSuccess) return COBEVT_ERR_LAUNCH;
+        if (sumsq && hipMemsetAsync(sumsq, 0, sizeof(double) * C, stream) != hipSuccess) return COBEVT_ERR_LAUNCH;
         long nb = (rows + 255) / 256;
         if (nb > 512) nb = 512;
         const int rpb = (int)((rows + nb - 1) / nb);
@@ -384,15 +431,24 @@ extern "C" int cobevt_channel_sums(const void* x, double* sum, double* sumsq, in
         else hipLaunchKernelGGL(channel_sums_generic_kernel<float>, grid, dim3(kThreads), 0, stream, (const float*)x, sum, sumsq, rows, C, rpb);
         return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
     }
+    if (!scratch || scratch_blocks < 1) return COBEVT_ERR_ARG;
+    if (sumsq && sumsq != sum + C) return COBEVT_ERR_ARG;                  // the pair is reduced as one 2 C vector
     int rpb;
-    const int blocks = row_blocks(rows, C, &rpb);
+    const int blocks = row_blocks(rows, C, &rpb, scratch_blocks);
     if (dtype == 0) {
-        if (sumsq) hipLaunchKernelGGL((channel_sums_kernel<bf16_t, true>), dim3(blocks), dim3(kThreads), 0, stream, (const bf16_t*)x, sum, sumsq, rows, C, rpb);
-        else hipLaunchKernelGGL((channel_sums_kernel<bf16_t, false>), dim3(blocks), dim3(kThreads), 0, stream, (const bf16_t*)x, sum, sumsq, rows, C, rpb);
-    } else if (dtype == 1) {
-        if (sumsq) hipLaunchKernelGGL((channel_sums_kernel<float, true>), dim3(blocks), dim3(kThreads), 0, stream, (const float*)x, sum, sumsq, rows, C, rpb);
-        else hipLaunchKernelGGL((channel_sums_kernel<float, false>), dim3(blocks), dim3(kThreads), 0, stream, (const float*)x, sum, sumsq, rows, C, rpb);
-    } else return COBEVT_ERR_ARG;
+        if (sumsq) hipLaunchKernelGGL((channel_sums_kernel<bf16_t, true>), dim3(blocks), dim3(kThreads), 0, stream, (const bf16_t*)x, shift, scratch, rows, C, rpb);
+        else hipLaunchKernelGGL((channel_sums_kernel<bf16_t, false>), dim3(blocks), dim3(kThreads), 0, stream, (const bf16_t*)x, shift, scratch, rows, C, rpb);
+    } else {
+        if (sumsq) hipLaunchKernelGGL((channel_sums_kernel<float, true>), dim3(blocks), dim3(kThreads), 0, stream, (const float*)x, shift, scratch, rows, C, rpb);
+        else hipLaunchKernelGGL((channel_sums_kernel<float, false>), dim3(blocks), dim3(kThreads), 0, stream, (const float*)x, shift, scratch, rows, C, rpb);
+    }
+    // without sumsq only the first C words of every partial pair were written: reduce them with stride 2 C
+    const int n = sumsq ? 2 * C : C;
+    if (sumsq) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, scratch, blocks, n, sum, out_f);
+    } else {
+        hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, scratch, blocks, n, 2 * C, sum, out_f);
+    }
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
@@ -404,11 +460,12 @@ extern "C" int cobevt_f64_to_f32(const double* in, float* out, int n, hipStream_
 
 extern "C" int cobevt_bn_finalize(const double* sum, const double* sumsq, const float* gamma, const float* beta, float* running_mean,
                                   float* running_var, float* scale, float* shift, float* mean, float* rstd, int C, long rows,
-                                  float eps, float momentum, int training, hipStream_t stream) {
+                                  float eps, float momentum, int training, int shifted, hipStream_t stream) {
     if (!scale || !shift || !mean || !rstd || C < 1 || rows < 1) return COBEVT_ERR_ARG;
     if (training ? (!sum || !sumsq) : (!running_mean || !running_var)) return COBEVT_ERR_ARG;
+    if (shifted && !running_mean) return COBEVT_ERR_ARG;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sum, sumsq, gamma, beta, running_mean, running_var,
-                       scale, shift, mean, rstd, C, (double)rows, eps, momentum, training);
+                       scale, shift, mean, rstd, C, (double)rows, eps, momentum, training, shifted);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
@@ -424,33 +481,38 @@ extern "C" int cobevt_bn_apply(const void* x, const void* residual, const float*
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
-// dgamma / dbeta: fp64 [C], zeroed by the caller; dres nullable
+// dgamma / dbeta: fp64 [2][C] back to back (dgamma, then dbeta), written; grads_f (nullable): the same 2 C values as fp32; scratch: fp64
+// [scratch_blocks][2][C]; dres nullable
 extern "C" int cobevt_bn_backward(const void* x, const void* y, const void* dy, const float* mean, const float* rstd, const float* gamma,
-                                  double* dgamma, double* dbeta, void* dx, void* dres, int dtype, long rows, int C, int act,
-                                  int training, hipStream_t stream) {
-    if (!x || !dy || !mean || !rstd || !dgamma || !dbeta || !dx || (act == 1 && !y)) return COBEVT_ERR_ARG;
-    if (!groups_ok(C) || rows < 1 || act < 0 || act > 1) return COBEVT_ERR_SHAPE;
+                                  double* dgamma_dbeta, float* grads_f, double* scratch, int scratch_blocks, void* dx, void* dres,
+                                  int dtype, long rows, int C, int act, int training, hipStream_t stream) {
+    if (!x || !dy || !mean || !rstd || !dgamma_dbeta || !scratch || !dx || (act == 1 && !y)) return COBEVT_ERR_ARG;
+    if (!groups_ok(C) || rows < 1 || act < 0 || act > 1 || scratch_blocks < 1) return COBEVT_ERR_SHAPE;
     int rpb;
-    const int blocks = row_blocks(rows, C, &rpb);
+    const int blocks = row_blocks(rows, C, &rpb, scratch_blocks);
     const long items = rows * (C >> 3);
     const dim3 grid((unsigned)((items + kThreads - 1) / kThreads));
     const float inv_rows = 1.0f / (float)rows;
+    double* dgamma = dgamma_dbeta;
+    double* dbeta = dgamma_dbeta + C;
     if (dtype == 0) {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(kThreads), 0, stream, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, mean, rstd, dgamma, dbeta, rows, C, act, rpb);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(kThreads), 0, stream, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, mean, rstd, scratch, rows, C, act, rpb);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, scratch, blocks, 2 * C, dgamma_dbeta, grads_f);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(kThreads), 0, stream, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, mean, rstd, gamma, dgamma, dbeta, (bf16_t*)dx, (bf16_t*)dres, items, C, inv_rows, act, training);
     } else if (dtype == 1) {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(kThreads), 0, stream, (const float*)x, (const float*)y, (const float*)dy, mean, rstd, dgamma, dbeta, rows, C, act, rpb);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(kThreads), 0, stream, (const float*)x, (const float*)y, (const float*)dy, mean, rstd, scratch, rows, C, act, rpb);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, scratch, blocks, 2 * C, dgamma_dbeta, grads_f);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(kThreads), 0, stream, (const float*)x, (const float*)y, (const float*)dy, mean, rstd, gamma, dgamma, dbeta, (float*)dx, (float*)dres, items, C, inv_rows, act, training);
     } else return COBEVT_ERR_ARG;
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
-// dx fp32 (N, H, W, C), zeroed by the caller
+// dx fp32 (N, H, W, C), every element written
 extern "C" int cobevt_maxpool3x3s2_bwd(const void* x, const void* dy, float* dx, int dtype, int N, int H, int W, int C, hipStream_t stream) {
     if (!x || !dy || !dx) return COBEVT_ERR_ARG;
     if (!groups_ok(C) || N < 1 || H < 1 || W < 1) return COBEVT_ERR_SHAPE;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    const long items = (long)N * Ho * Wo * (C >> 3);
+    const long items = (long)N * H * W * (C >> 3);
     const dim3 grid((unsigned)((items + kThreads - 1) / kThreads));
     if (dtype == 0) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, grid, dim3(kThreads), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, dx, N, H, W, C, Ho, Wo);
     else if (dtype == 1) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(kThreads), 0, stream, (const float*)x, (const float*)dy, dx, N, H, W, C, Ho, Wo);

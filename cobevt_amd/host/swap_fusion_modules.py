@@ -232,10 +232,13 @@ class SwapFusionEncoder(HipModule):
         x = _run_stages(stages, x, lambda i: masks[i])
         b, l, h, w, d = x.shape
         ln = self.mlp_head[2]
-        y = ops.mean_layernorm(x.reshape(b, l, h * w, d), rt.f32_param(self, "head.ln.w", ln.weight),
-                               rt.f32_param(self, "head.ln.b", ln.bias), ln.eps)
-        y = ops.linear(y, rt.linear_plan(self, "head.fc", self.mlp_head[3]))
-        return y.reshape(b, h, w, d)
+        # mean over the agents -> LayerNorm -> Linear: one launch (the mean and the normalisation happen while the GEMM stages its rows)
+        y = ops.mean_ln_linear(x.reshape(b, l, h * w, d), rt.linear_plan(self, "head.fc_ln", self.mlp_head[3], ln=ln))
+        if y is None:
+            y = ops.mean_layernorm(x.reshape(b, l, h * w, d), rt.f32_param(self, "head.ln.w", ln.weight),
+                                   rt.f32_param(self, "head.ln.b", ln.bias), ln.eps)
+            y = ops.linear(y, rt.linear_plan(self, "head.fc", self.mlp_head[3]))
+        return y.reshape(b, h, w, -1)
 
     def forward(self, x, mask=None):
         """x: (b, m, d, h, w); mask: (b, h, w, 1, m) -> (b, d, h, w).  In train() mode: the differentiable fp32 graph of

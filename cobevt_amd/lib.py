@@ -81,14 +81,16 @@ SIGNATURES = {
     "cobevt_depthwise_conv_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_spatial_mean_nhwc": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "cobevt_se_gate": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    "cobevt_mean_linear_rows_small_k": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_long_p, ctypes.c_float, _vp]),
     "cobevt_proj_chain": (ctypes.c_int, [_vp] * 10 + [_c_int_p, ctypes.c_float, _vp]),
     "cobevt_swap_fusion_stage": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int_p,
                                                 ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
-    "cobevt_channel_sums": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_int, _vp]),
+    "cobevt_channel_sums": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_int, _vp]),
     "cobevt_f64_to_f32": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp]),
-    "cobevt_bn_finalize": (ctypes.c_int, [_vp] * 10 + [ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_float, ctypes.c_int, _vp]),
+    "cobevt_bn_finalize": (ctypes.c_int, [_vp] * 10 + [ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp]),
     "cobevt_bn_apply": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, _vp]),
-    "cobevt_bn_backward": (ctypes.c_int, [_vp] * 10 + [ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    "cobevt_bn_backward": (ctypes.c_int, [_vp] * 9 + [ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, _vp]),
     "cobevt_maxpool3x3s2_bwd": (ctypes.c_int, [_vp, _vp, _vp] + [ctypes.c_int] * 5 + [_vp]),
     "cobevt_pixel_unshuffle2_nhwc": (ctypes.c_int, [_vp, _vp] + [ctypes.c_int] * 6 + [_vp]),
     "cobevt_upsample_nearest2_nhwc": (ctypes.c_int, [_vp, _vp] + [ctypes.c_int] * 6 + [_vp]),

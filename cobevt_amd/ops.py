@@ -597,6 +597,28 @@ def mean_layernorm(x, gamma, beta, eps=1e-5):
     return out
 
 
+def mean_ln_linear(x, plan):
+    """x (B, L, R, C) contiguous bf16 -> plan(mean over L) with plan's folded LayerNorm: (B, R, Cout), one launch
+    (SwapFusionEncoder.mlp_head, swap_fusion_modules.py:275-281); None when the shape does not fit the kernel."""
+    _need_cuda(x)
+    b, l, r, c = x.shape
+    if not (USE_GEMM_ROWS3 and x.dtype == torch.bfloat16 and x.is_contiguous() and plan.wfrag_rows is not None and plan.kp_rows == 128
+            and plan.K == c and c % 8 == 0 and plan.cout % 8 == 0 and plan.cout <= 4096 and l <= 64 and plan.pre_scale is None
+            and plan.stride == 1):
+        return None
+    out = torch.empty((b, r, plan.cout), device=x.device, dtype=x.dtype)
+    dims = (ctypes.c_long * 8)(0, b, l, r, c, plan.cout, int(plan.has_ln), plan.act)
+
+    def cost():
+        return 2.0 * b * r * c * plan.cout, float((b * l * r * c + b * r * plan.cout + c * plan.cout) * 2)
+
+    with _timed("gemm_rows|mean%d %d->%d M=%d ln" % (l, c, plan.cout, b * r), cost):
+        rc = _L.load().cobevt_mean_linear_rows_small_k(_p(x), _p(plan.wfrag_rows), _p(plan.bias), _p(out), dims,
+                                                       ctypes.c_float(plan.ln_eps), _stream())
+    _L.check(rc, "cobevt_mean_linear_rows_small_k")
+    return out
+
+
 def tokmap(mode, ncam, hh, ww, w1, w2):
     """Token map tuple for cobevt_window_attention: mode 0 window / 1 grid / 2 stored-partitioned."""
     if hh % w1 or ww % w2:

@@ -412,6 +412,13 @@ int cobevt_se_gate(const float* mean, const float* w_reduce, const float* b_redu
 int cobevt_channel_gate_nhwc(const void* in, const float* gate, void* out, int dtype, int N, int hw, int C,
                              hipStream_t stream);
 
+/* SwapFusionEncoder.mlp_head in one launch (swap_fusion_modules.py:275-281: mean over the agents, LayerNorm, Linear): out (B * R, N) =
+ * act(LayerNorm?(mean over j < L of in[b][j][r][:]) . W^T + bias), in (B, L, R, K) bf16, K <= 128; the dense-row kernel of
+ * cobevt_linear_rows_small_k with the agent mean taken while the A rows are staged.  Weights in MFMA fragment order, the LayerNorm
+ * affine folded in.  dims (int64[8]): dtype (0), B, L, R, K, N, ln, act. */
+int cobevt_mean_linear_rows_small_k(const void* in, const void* wfrag, const float* bias, void* out, const long* dims,
+                                    float ln_eps, hipStream_t stream);
+
 /*
  * Projection chain (bf16, 128 channels): the key / value side of a FAX cross-view level in one launch per operand -
  *   y = ReLU?(a * pre_scale[c] + pre_shift[c]) . Wp^T + bp + skip     pre-activation BatchNorm -> ReLU -> 1x1 conv (feature_proj /
@@ -449,27 +456,31 @@ int cobevt_swap_fusion_stage(const void* qkv, const void* x, void* out, void* qk
  * opv2v/opencood/tools/train_camera.py:143-179.  Channels-last maps flattened to (rows, C) / (N, H, W, C); dtype 0 bf16, 1 fp32;
  * C a multiple of 8 (<= 2048) except where noted. --------------------------------------------------------------------------- */
 
-/* sum[c] += sum over rows of x, and (sumsq nullable) sumsq[c] += sum of squares; fp64 accumulators (zero them first): BatchNorm
- * batch statistics (torchvision BasicBlock / Bottleneck bn1-3 reached from resnet_ms.py:67-74, fax_modules.py:10,472-489,
- * naive_decoder.py:78-87) and bias gradients (any C). */
-int cobevt_channel_sums(const void* x, double* sum, double* sumsq, int dtype, long rows, int C, hipStream_t stream);
+/* sum[c] = sum over rows of (x - shift[c]) and (sumsq nullable; must be sum + C) sumsq[c] = sum of its squares, fp64 (shift nullable
+ * = 0; BatchNorm passes its running mean so that the variance is not a cancellation); out_f (nullable): the same values as fp32.
+ * scratch: fp64 [scratch_blocks][2][C] for per-workgroup partial sums (no atomics: they serialise on the C result words).
+ * BatchNorm batch statistics (torchvision BasicBlock / Bottleneck bn1-3 reached from resnet_ms.py:67-74, fax_modules.py:10,472-489,
+ * naive_decoder.py:78-87) and bias gradients (any C: channel counts off the 8-channel piece take a scalar kernel, without shift /
+ * out_f). */
+int cobevt_channel_sums(const void* x, const float* shift, double* sum, double* sumsq, float* out_f, double* scratch,
+                        int scratch_blocks, int dtype, long rows, int C, hipStream_t stream);
 int cobevt_f64_to_f32(const double* in, float* out, int n, hipStream_t stream);
 /* nn.BatchNorm2d statistics -> per-channel scale / shift (scale = gamma rstd, shift = beta - mean scale), mean / rstd for backward.
- * training != 0: batch statistics from the sums, running_mean / running_var (nullable) updated in place with `momentum` and the
- * unbiased variance; training == 0: the frozen running statistics. */
+ * training != 0: batch statistics from the sums (shifted != 0: they were taken of x - running_mean), running_mean / running_var
+ * (nullable) updated in place with `momentum` and the unbiased variance; training == 0: the frozen running statistics. */
 int cobevt_bn_finalize(const double* sum, const double* sumsq, const float* gamma, const float* beta, float* running_mean,
                        float* running_var, float* scale, float* shift, float* mean, float* rstd, int C, long rows, float eps,
-                       float momentum, int training, hipStream_t stream);
+                       float momentum, int training, int shifted, hipStream_t stream);
 /* y = act(x * scale[c] + shift[c] (+ residual)), act 0 none / 1 ReLU. */
 int cobevt_bn_apply(const void* x, const void* residual, const float* scale, const float* shift, void* y, int dtype, long rows,
                     int C, int act, hipStream_t stream);
-/* Backward of cobevt_bn_apply behind the statistics: g = dy [y > 0 when act == 1]; dbeta[c] += sum g, dgamma[c] += sum g xhat (fp64,
- * zero them first); dx = gamma rstd (g - (dbeta + xhat dgamma) / rows) with batch statistics, gamma rstd g with frozen ones; dres
- * (nullable) = g. */
+/* Backward of cobevt_bn_apply behind the statistics: g = dy [y > 0 when act == 1]; dgamma_dbeta (fp64 [2][C], written) = sum g xhat,
+ * sum g; grads_f (nullable) the same as fp32; dx = gamma rstd (g - (dbeta + xhat dgamma) / rows) with batch statistics, gamma rstd g
+ * with frozen ones; dres (nullable) = g.  scratch: fp64 [scratch_blocks][2][C]. */
 int cobevt_bn_backward(const void* x, const void* y, const void* dy, const float* mean, const float* rstd, const float* gamma,
-                       double* dgamma, double* dbeta, void* dx, void* dres, int dtype, long rows, int C, int act, int training,
-                       hipStream_t stream);
-/* nn.MaxPool2d(3, 2, 1) backward (resnet_ms.py:70): dx fp32 (N, H, W, C), zeroed by the caller; first maximum of a window wins. */
+                       double* dgamma_dbeta, float* grads_f, double* scratch, int scratch_blocks, void* dx, void* dres, int dtype,
+                       long rows, int C, int act, int training, hipStream_t stream);
+/* nn.MaxPool2d(3, 2, 1) backward (resnet_ms.py:70): dx fp32 (N, H, W, C), every element written; first maximum of a window wins. */
 int cobevt_maxpool3x3s2_bwd(const void* x, const void* dy, float* dx, int dtype, int N, int H, int W, int C, hipStream_t stream);
 /* nn.PixelUnshuffle(2) (fax_modules.py:479) on channels-last maps: inverse 0: (N, 2Ho, 2Wo, C) -> (N, Ho, Wo, 4C); 1: back. */
 int cobevt_pixel_unshuffle2_nhwc(const void* in, void* out, int dtype, int N, int Ho, int Wo, int C, int inverse,

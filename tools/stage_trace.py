@@ -43,9 +43,10 @@ with host.compute_dtype(torch.bfloat16):
         enc(x, mask)
     torch.cuda.synchronize()
 n = 160
-buf = (ctypes.c_ulonglong * (8 * n))()
-assert lib.cobevt_stage_trace_read(buf, 8 * n) == 0
-t = torch.tensor(list(buf), dtype=torch.float64).reshape(n, 8)
+buf = (ctypes.c_ulonglong * (16 * n))()
+assert lib.cobevt_stage_trace_read(buf, 16 * n) == 0
+full = torch.tensor(list(buf), dtype=torch.float64).reshape(n, 16)
+t = full[:, :8]
 names = ["tables", "V^T staging", "attention", "chain A (proj)", "chain B-D (MLP)", "store + LN", "next qkv"]
 ph = t[:, 1:] - t[:, :-1]
 print("last launch of the encoder (160 workgroups), phase medians in s_memtime ticks (10 ns each):")
@@ -53,3 +54,8 @@ for i, nm in enumerate(names):
     print("  %-18s median %7.0f   p90 %7.0f" % (nm, ph[:, i].median(), ph[:, i].quantile(0.9)))
 print("  workgroup total   median %7.0f ; first start -> last end %7.0f ; start spread %7.0f" %
       ((t[:, 7] - t[:, 0]).median(), t[:, 7].max() - t[:, 0].min(), t[:, 0].max() - t[:, 0].min()))
+fine = [("tables barrier -> key-row reads done", 1, 8), ("-> V loads issued", 8, 9), ("-> last K / V load returned", 9, 10),
+        ("-> V^T written (+ score MFMAs)", 10, 11), ("-> barrier", 11, 2), ("barrier -> scores + bias + max", 2, 12), ("-> exp, PV, output tile", 12, 3)]
+for nm, a, b in fine:
+    d = full[:, b] - full[:, a]
+    print("  %-42s median %7.0f   p90 %7.0f" % (nm, d.median(), d.quantile(0.9)))
