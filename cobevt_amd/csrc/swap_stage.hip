@@ -222,41 +222,40 @@ __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams
         unsigned char* vth = Vt + head * 32 * L.vstr;
         // ---- V^T of this head -> LDS: item = (key pair, dh quad); 16-key blocks in the score registers' key order (perm16)
         const bf16_t* vbase = p.qkv + 2 * C + head * 32;
-        constexpr int VIT = NT * 2;                         // NT * 32 keys x 4 sixteen-byte pieces / 64 lanes
+        constexpr int VIT = NT * 2;                         // NT * 32 keys x 4 dh quads / 2 keys per item / 64 lanes
         // Rows of padded keys are read from row 0 and NOT zeroed: their probabilities are exactly 0 (additive -inf) and row 0 holds
         // finite values, so they add nothing - while a `row >= 0 ? load : 0` select makes hipcc put the load under a branch
-        // (s_cbranch_execz + a full lgkmcnt / vmcnt drain per item: 15k of the first version's 47k cycles).
-        // item = (key, 16-byte piece of its 64-byte V_h row): lanes 2j / 2j+1 hold the two keys of a pair, lane bits 1-2 the piece.
-        // One 16-byte gather per item (the gathers' issue rate, ~40-100 cycles per wave-instruction, bounds this phase: the
-        // 8-byte form needed twice as many); the pair then swaps halves (one DPP exchange of 8 bytes) so that each lane writes
-        // 4 dh x (key, key + 1) as four 4-byte LDS stores.
-        int kr[VIT];
+        // (s_cbranch_execz + a full lgkmcnt / vmcnt drain per item: 15k of the first version's 47k cycles).  Two 8-byte gathers per
+        // (key pair, dh quad) item; one 16-byte gather per key + a DPP exchange of halves between the pair's lanes was measured too:
+        // the issue time of the gathers did not change (4.2k cycles either way: it goes by lanes, not by instructions) and the
+        // exchange made the write phase 1.7k cycles longer
+        int2 rr[VIT];
 #pragma unroll
-        for (int u = 0; u < VIT; ++u) kr[u] = ktab[2 * ((u * 64 + lane) >> 3) + (lane & 1)];
+        for (int u = 0; u < VIT; ++u) rr[u] = *(const int2*)(ktab + 2 * ((u * 64 + lane) >> 3));
         STAGE_MARK(8);
-        uint4 vv[VIT];
+        uint2 v0[VIT], v1[VIT];
 #pragma unroll
-        for (int u = 0; u < VIT; ++u) vv[u] = *(const uint4*)(vbase + (size_t)max(kr[u], 0) * ld + ((lane >> 1) & 3) * 8);
+        for (int u = 0; u < VIT; ++u) {
+            const int dq = lane & 7;
+            v0[u] = *(const uint2*)(vbase + (size_t)max(rr[u].x, 0) * ld + dq * 4);
+            v1[u] = *(const uint2*)(vbase + (size_t)max(rr[u].y, 0) * ld + dq * 4);
+        }
         STAGE_MARK(9);
 #ifdef COBEVT_STAGE_TRACE
         __builtin_amdgcn_s_waitcnt(0x0f70);      // probe builds: vmcnt(0) - when did the last K / V load return?
         STAGE_MARK(10);
 #endif
-        const int odd = lane & 1;
 #pragma unroll
         for (int u = 0; u < VIT; ++u) {
-            const int kp = (u * 64 + lane) >> 3;
+            const int item = u * 64 + lane;
+            const int kp = item >> 3, dq = item & 7;
             const int pos = ((2 * kp) & ~15) | perm16((2 * kp) & 15);        // even key of the pair; its partner sits at pos + 1
-            // what the partner needs: the even lane keeps dh 0..3 of both keys (sends its dh 4..7), the odd lane the other way round
-            const uint32_t s0 = odd ? vv[u].x : vv[u].z, s1 = odd ? vv[u].y : vv[u].w;
-            const uint32_t r0 = (uint32_t)__shfl_xor((int)s0, 1, 64), r1 = (uint32_t)__shfl_xor((int)s1, 1, 64);
-            const uint32_t a[2] = {odd ? r0 : vv[u].x, odd ? r1 : vv[u].y};          // key 2 kp     : dh 4 odd + 0..3 of this piece
-            const uint32_t c[2] = {odd ? vv[u].z : r0, odd ? vv[u].w : r1};          // key 2 kp + 1
-            const int dh0 = ((lane >> 1) & 3) * 8 + odd * 4;
+            const uint32_t a[2] = {v0[u].x, v0[u].y}, c[2] = {v1[u].x, v1[u].y};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                const int dh = dq * 4 + e;
                 const uint32_t lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xffffu, hi = (c[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
-                *(uint32_t*)(vth + (dh0 + e) * L.vstr + pos * 2) = lo | (hi << 16);
+                *(uint32_t*)(vth + dh * L.vstr + pos * 2) = lo | (hi << 16);
             }
         }
     }

@@ -72,25 +72,20 @@ __global__ __launch_bounds__(kThreads) void channel_sums_kernel(const T* __restr
     }
 }
 
-__global__ void reduce_partials_strided_kernel(const double* __restrict__ partial, int nblk, int n, int stride, double* __restrict__ out_d,
-                                               float* __restrict__ out_f) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+// out[j] = sum over the nblk workgroups of partial[b * stride + j], j < n: one wave per output word (64 lanes share out the
+// workgroups, then a shuffle reduction) - a thread per word walking 512 partials serially cost 45-60 us per launch
+__global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const double* __restrict__ partial, int nblk, int n, int stride,
+                                                                      double* __restrict__ out_d, float* __restrict__ out_f) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (j >= n) return;
     double t = 0.0;
-    for (int b = 0; b < nblk; ++b) t += partial[(size_t)b * stride + j];
-    if (out_d) out_d[j] = t;
-    if (out_f) out_f[j] = (float)t;
-}
-
-// out[j] = sum over the nblk workgroups of partial[b][j], j < n (n = 2 C: the two vectors of a reduction pair back to back)
-__global__ void reduce_partials_kernel(const double* __restrict__ partial, int nblk, int n, double* __restrict__ out_d,
-                                       float* __restrict__ out_f) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    double t = 0.0;
-    for (int b = 0; b < nblk; ++b) t += partial[(size_t)b * n + j];
-    if (out_d) out_d[j] = t;
-    if (out_f) out_f[j] = (float)t;
+    for (int b = lane; b < nblk; b += 64) t += partial[(size_t)b * stride + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if (lane == 0) {
+        if (out_d) out_d[j] = t;
+        if (out_f) out_f[j] = (float)t;
+    }
 }
 
 // ---- BatchNorm finalize: stats (training: from the sums; eval: the running statistics) -> per-channel scale / shift, mean / rstd
@@ -445,9 +440,9 @@ extern "C" int cobevt_channel_sums(const void* x, const float* shift, double* su
     // without sumsq only the first C words of every partial pair were written: reduce them with stride 2 C
     const int n = sumsq ? 2 * C : C;
     if (sumsq) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, scratch, blocks, n, sum, out_f);
+        hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, scratch, blocks, n, n, sum, out_f);
     } else {
-        hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, scratch, blocks, n, 2 * C, sum, out_f);
+        hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, scratch, blocks, n, 2 * C, sum, out_f);
     }
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
@@ -497,11 +492,11 @@ extern "C" int cobevt_bn_backward(const void* x, const void* y, const void* dy, 
     double* dbeta = dgamma_dbeta + C;
     if (dtype == 0) {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(kThreads), 0, stream, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, mean, rstd, scratch, rows, C, act, rpb);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, scratch, blocks, 2 * C, dgamma_dbeta, grads_f);
+        hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, stream, scratch, blocks, 2 * C, 2 * C, dgamma_dbeta, grads_f);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(kThreads), 0, stream, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, mean, rstd, gamma, dgamma, dbeta, (bf16_t*)dx, (bf16_t*)dres, items, C, inv_rows, act, training);
     } else if (dtype == 1) {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(kThreads), 0, stream, (const float*)x, (const float*)y, (const float*)dy, mean, rstd, scratch, rows, C, act, rpb);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, scratch, blocks, 2 * C, dgamma_dbeta, grads_f);
+        hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, stream, scratch, blocks, 2 * C, 2 * C, dgamma_dbeta, grads_f);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(kThreads), 0, stream, (const float*)x, (const float*)y, (const float*)dy, mean, rstd, gamma, dgamma, dbeta, (float*)dx, (float*)dres, items, C, inv_rows, act, training);
     } else return COBEVT_ERR_ARG;
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
