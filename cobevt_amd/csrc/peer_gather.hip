@@ -177,7 +177,7 @@ extern "C" int cobevt_peer_exchange(const void* local, void* const* windows, int
         plan.dest_rank[j] = dest_rank[j];
         plan.dest_block[j] = dest_block[j];
     }
-    if (spin_limit < 1) spin_limit = 4000000;
+    if (spin_limit < 1) spin_limit = 30000000;      // ~30 s of polls: ranks may be seconds apart while one of them builds plans / captures
     const long units = block_bytes / 16;
     hipLaunchKernelGGL(peer_ack_kernel, dim3(1), dim3(64), 0, stream, wins, world, rank, window_bytes, spin_limit);
     const long total = (long)n_local * units;

@@ -413,6 +413,8 @@ class FrameShardedCorpBEVT(object):
             self.windows = None
             self.staging = torch.zeros((self.slots,) + block, device=dev, dtype=feats.dtype)
             self.full = [torch.zeros((self.agents,) + block, device=dev, dtype=feats.dtype) for _ in range(depth)]
+        if world > 1 and torch.distributed.is_initialized():
+            torch.distributed.barrier(group=group)      # plans are built: ranks enter the first exchange together
         self.empty = feats[:0]
         self.feats = [self.empty] * depth        # slot q: the features the encoder of step q produced (graph q's own buffer)
         self.i = self.filled = 0

@@ -515,7 +515,7 @@ int cobevt_peer_window_status(const void* window, long bytes, int* status, int* 
  * of `world` (<= 8) device pointers = this process's mappings of every rank's window, the own window at [rank].  local:
  * n_local (<= 16) contiguous blocks of block_bytes; block j is stored at block slot dest_block[j] of rank dest_rank[j]'s
  * window, or of every rank's window when dest_rank[j] < 0 (all-gather).  When the second launch retires, every block
- * addressed to this rank has landed in its window.  spin_limit: bound on the flag polls (<= 0: default, ~seconds). */
+ * addressed to this rank has landed in its window.  spin_limit: bound on the flag polls (<= 0: default, ~30 s). */
 int cobevt_peer_exchange(const void* local, void* const* windows, int world, int rank, int n_local, long block_bytes,
                          const int* dest_rank, const int* dest_block, long window_bytes, long spin_limit,
                          hipStream_t stream);

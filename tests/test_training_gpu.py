@@ -586,6 +586,14 @@ def test_vanilla_seg_loss_backward(cuda):
     assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach()))
     assert_close(dyn.grad, dr.grad, 1e-4, "d loss / d dynamic logits")
     assert_close(sta.grad, sr.grad, 1e-4, "d loss / d static logits")
+    # the common AMP pattern: forward inside the autocast region, criterion OUTSIDE it - the head then hands over bf16 logits and no
+    # ambient autocast state casts them (this used to raise "the training slice is fp32")
+    with torch.enable_grad():
+        d16, s16 = _leaf(dyn0.to(torch.bfloat16), cuda), _leaf(sta0.to(torch.bfloat16), cuda)
+        loss16 = crit({"dynamic_seg": d16, "static_seg": s16}, {"gt_dynamic": gd.to(cuda), "gt_static": gs.to(cuda)})
+        loss16.backward()
+    assert d16.grad is not None and d16.grad.dtype == torch.bfloat16 and torch.isfinite(d16.grad.float()).all()
+    assert abs(float(loss16.detach()) - float(ref.detach())) <= 2e-2 * abs(float(ref.detach()))
 
 
 def _dp_worker(rank, world, port, ret):

@@ -22,6 +22,16 @@ def main():
     cur = sqlite3.connect(path).cursor()
     rows = list(cur.execute("select name, start, end, grid_x, grid_y, grid_z, workgroup_x, lds_size, vgpr_count, "
                             "accum_vgpr_count, scratch_size from kernels order by start"))
+    if "--steady" in sys.argv:
+        # only the steady state: everything from the start of the N-th last frame on (a frame starts with its stem launch).  A
+        # whole-trace table also counts model set-up (one small copy per uploaded weight plan, eager warm-up frames), which
+        # reads like "copies per frame" when divided by the frame count
+        nlast = int(sys.argv[sys.argv.index("--steady") + 1])
+        stems = [r[1] for r in rows if short(r[0]).startswith("stem_pool_kernel") or short(r[0]).startswith("stem7x7_kernel")]
+        if len(stems) > nlast:
+            t0 = stems[-nlast]
+            rows = [r for r in rows if r[1] >= t0]
+            print("steady state only: the last %d frames of the trace" % nlast)
     agg = collections.OrderedDict()
     for n, s, e, gx, gy, gz, wx, lds, vg, ag, sc in rows:
         a = agg.setdefault(short(n), [0, 0.0, vg, ag, lds, sc])
