@@ -27,11 +27,15 @@ def main():
         # whole-trace table also counts model set-up (one small copy per uploaded weight plan, eager warm-up frames), which
         # reads like "copies per frame" when divided by the frame count
         nlast = int(sys.argv[sys.argv.index("--steady") + 1])
+        # --skip-last M: leave out the M frames at the end of the trace (bench.py appends the one-frame-at-a-time leg, 55 frames,
+        # behind the pipelined timed loop)
+        skip = int(sys.argv[sys.argv.index("--skip-last") + 1]) if "--skip-last" in sys.argv else 0
         stems = [r[1] for r in rows if short(r[0]).startswith("stem_pool_kernel") or short(r[0]).startswith("stem7x7_kernel")]
-        if len(stems) > nlast:
-            t0 = stems[-nlast]
-            rows = [r for r in rows if r[1] >= t0]
-            print("steady state only: the last %d frames of the trace" % nlast)
+        if len(stems) > nlast + skip:
+            t0 = stems[-(nlast + skip)]
+            t1 = stems[-skip] if skip else None
+            rows = [r for r in rows if r[1] >= t0 and (t1 is None or r[1] < t1)]
+            print("steady state only: %d frames of the trace%s" % (nlast, ", ending %d frames before its end" % skip if skip else ""))
     agg = collections.OrderedDict()
     for n, s, e, gx, gy, gz, wx, lds, vg, ag, sc in rows:
         a = agg.setdefault(short(n), [0, 0.0, vg, ag, lds, sc])
