@@ -70,7 +70,8 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
     // shared K/V instead of 8 XCDs each fetching it from HBM (rocprofv3 FETCH_SIZE was 3x the algorithmic bytes).
     const int b = blockIdx.z;
     const int l = blockIdx.x / p.heads, head = blockIdx.x - l * p.heads;
-    const int qtile = blockIdx.y;
+    const int nqt = gridDim.y / p.ksplit;                 // (ksplit = 1: every launch but the key-split one)
+    const int split = blockIdx.y / nqt, qtile = blockIdx.y - split * nqt;
 
     // ---- this lane's query token (mean mode: wave = camera; waves beyond ncam only help staging)
     const int P = p.qmap.w1 * p.qmap.w2;
@@ -243,16 +244,18 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
     // ((dl + L-1)(2 w1 - 1) + (di + w1-1))(2 w2 - 1) + (dj + w2-1) with d = query - key coordinate
     const int bias_q = BIAS ? rel_bias_query_term(p.kmap, p.bias_L, qc) : 0;
 
-    load_tile(0);
+    // key split: this workgroup walks tiles [kt0, kt1) of the window
+    const int kt0 = (int)((long)split * nkt / p.ksplit), kt1 = (int)((long)(split + 1) * nkt / p.ksplit);
+    load_tile(kt0);
     store_tile(0);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
         if (pair) {                                   // (keys per camera is a multiple of the tile: one camera per tile)
             const int cam = kt / tiles_per_cam;
             if (cam != q_cam) { q_cam = cam; load_q(cam); }
         }
-        if (kt + 1 < nkt) load_tile(kt + 1);
+        if (kt + 1 < kt1) load_tile(kt + 1);
         const unsigned char* Ks = smem + buf * L::kBuf;
         const unsigned char* Vts = Ks + L::kKBytes;
         const int* kinfo = (const int*)(Vts + L::kVBytes);
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
                 }
             }
         }
-        if (kt + 1 < nkt) store_tile(buf ^ 1);
+        if (kt + 1 < kt1) store_tile(buf ^ 1);
         __syncthreads();
     }
 
@@ -365,6 +368,26 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) ot[r] *= inv;
 
+    if (p.ksplit > 1) {           // partial result of this key range: normalised rows + their log-sum-exp, merged afterwards
+        if (!q_ok) return;
+        const size_t orow_i = tok_row(p.omap, b, l, qc);
+        const int d = p.heads * 32;
+        if (h == 0) p.part_lse[((size_t)split * p.part_rows + orow_i) * p.heads + head] = m_run + __builtin_amdgcn_logf(l_tot);
+        T* orow = (T*)p.part_out + ((size_t)split * p.part_rows + orow_i) * d + head * 32;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d0 = 8 * g4 + 4 * h;
+            if constexpr (Elem<T>::kIsBf16) {
+                uint2 w;
+                w.x = pack_bf2(ot[4 * g4 + 0], ot[4 * g4 + 1]);
+                w.y = pack_bf2(ot[4 * g4 + 2], ot[4 * g4 + 3]);
+                *(uint2*)(orow + d0) = w;
+            } else {
+                *(float4*)(orow + d0) = make_float4(ot[4 * g4 + 0], ot[4 * g4 + 1], ot[4 * g4 + 2], ot[4 * g4 + 3]);
+            }
+        }
+        return;
+    }
     if (p.mean_q == 1) {
         const int nw = p.qmap.ncam;
         if (wave < nw) {
@@ -399,6 +422,51 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
     }
 }
 
+// out[row][head*32 + c] = sum_s w_s part_out[s][row][..] / sum_s w_s,  w_s = 2^(lse_s - max_s lse_s); a split whose keys were all
+// masked (lse = -inf, rows NaN) carries weight 0 and is skipped.  One thread per (row, head, 8 channels).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_ksplit_merge_kernel(AttnParams p) {
+    const int d = p.heads * 32;
+    const long item = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = p.part_rows * p.heads * 4;
+    if (item >= total) return;
+    const int c8 = (int)(item & 3), head = (int)((item >> 2) % p.heads);
+    const long row = (item >> 2) / p.heads;
+    float lse[8], mx = -INFINITY;
+    for (int s = 0; s < p.ksplit; ++s) {
+        lse[s] = p.part_lse[((size_t)s * p.part_rows + row) * p.heads + head];
+        if (lse[s] > mx) mx = lse[s];
+    }
+    float acc[8], wsum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int s = 0; s < p.ksplit; ++s) {
+        if (!(lse[s] > -INFINITY)) continue;
+        const float w = __builtin_amdgcn_exp2f(lse[s] - mx);
+        wsum += w;
+        const T* src = (const T*)p.part_out + ((size_t)s * p.part_rows + row) * d + head * 32 + c8 * 8;
+        float v[8];
+        if constexpr (Elem<T>::kIsBf16) {
+            chunk_to_f32<T>(*(const uint4*)src, v);
+        } else {
+            chunk_to_f32<T>(*(const uint4*)src, v);
+            chunk_to_f32<T>(*(const uint4*)(src + 4), v + 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += w * v[e];
+    }
+    const float inv = 1.0f / wsum;                    // every split masked: NaN, like the reference softmax
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= inv;
+    T* dst = (T*)p.out + (size_t)row * p.ldo + p.ooff + head * 32 + c8 * 8;
+    if constexpr (Elem<T>::kIsBf16) {
+        *(uint4*)dst = f32_to_chunk<T>(acc);
+    } else {
+        *(uint4*)dst = f32_to_chunk<T>(acc);
+        *(uint4*)(dst + 4) = f32_to_chunk<T>(acc + 4);
+    }
+}
+
 // Debug / test entry points: the token -> row map and the relative-position index exactly as the attention kernels compute them
 __global__ void attn_index_dump_kernel(TokMap m, int B, int L, int ntok, int* rows) {
     const long total = (long)B * L * ntok;
@@ -425,7 +493,8 @@ using namespace cobevt;
 // C-ABI entry point, see include/cobevt_hip.h
 static int window_attention_impl(const void* q, const void* k, const void* v, void* out, float* lse,
                                  const float* bias_table, const float* mask, const int* dims, float scale,
-                                 float drop_p, unsigned drop_seed, const unsigned* drop_seed_dev, hipStream_t stream) {
+                                 float drop_p, unsigned drop_seed, const unsigned* drop_seed_dev, hipStream_t stream,
+                                 int ksplit = 1, void* part_out = nullptr, float* part_lse = nullptr, long part_rows = 0) {
     // dims: [dtype, B, L, heads, ldq, ldk, ldv, ldo, qoff, koff, voff, ooff, bias_mode, bias_rows, bias_L,
     //        mean_q, qmap[8], kmap[8], omap[8]]
     if (!q || !k || !v || !out || !dims) return COBEVT_ERR_ARG;
@@ -442,6 +511,7 @@ static int window_attention_impl(const void* q, const void* k, const void* v, vo
     p.qmap = read_map(dims + 16); p.kmap = read_map(dims + 24); p.omap = read_map(dims + 32);
     p.bias_table = bias_table; p.mask = mask; p.scale = scale; p.lse = lse;
     p.drop_p = drop_p; p.drop_seed = drop_seed; p.drop_seed_dev = drop_seed_dev;
+    p.ksplit = 1; p.part_out = nullptr; p.part_lse = nullptr; p.part_rows = 0;
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (!lse || dtype != 1))) return COBEVT_ERR_ARG;   // dropout: training forward only
     if (dtype != 0 && dtype != 1) return COBEVT_ERR_ARG;
     if (!map_ok(p.qmap) || !map_ok(p.kmap) || !map_ok(p.omap)) return COBEVT_ERR_SHAPE;
@@ -460,20 +530,26 @@ static int window_attention_impl(const void* q, const void* k, const void* v, vo
     // keys of a single window that covers the whole map are rows b * Nk + tk: no table (CVT attends to 4 x 64 x 64 keys)
     p.klinear = (p.kmap.mode != 2 && p.kmap.X == 1 && p.kmap.Y == 1 && !p.bias_mode && !mask) ? 1 : 0;
     if (lse && p.mean_q) return COBEVT_ERR_UNSUPPORTED;     // (the training path averages cameras outside the kernel)
-    if (dtype == 0 && variant == 0 && p.mean_q != 2 && !lse) {
+    if (ksplit > 1) {       // key split: streaming kernel only, plain inference attention, every query of a window on its own
+        if (ksplit > 8 || !part_out || !part_lse || part_rows < 1 || lse || p.mean_q || drop_p > 0.f) return COBEVT_ERR_ARG;
+        if (p.omap.ncam != p.qmap.ncam) return COBEVT_ERR_UNSUPPORTED;
+        p.ksplit = ksplit; p.part_out = part_out; p.part_lse = part_lse; p.part_rows = part_rows;
+    }
+    if (dtype == 0 && variant == 0 && p.mean_q != 2 && !lse && ksplit == 1) {
         const int rc = launch_attn_resident(p, qsplit_hint, stream);
         if (rc >= 0) return rc;
     }
     const int P = p.qmap.w1 * p.qmap.w2;
     dim3 grid, block;
     if (p.mean_q == 1) { block = dim3(64 * (p.qmap.ncam < 4 ? 4 : p.qmap.ncam)); grid = dim3(p.L * p.heads, (P + 31) / 32, p.B); }
-    else { block = dim3(256); grid = dim3(p.L * p.heads, ((p.mean_q == 2 ? P : p.Nq) + 127) / 128, p.B); }
+    else { block = dim3(256); grid = dim3(p.L * p.heads, ((p.mean_q == 2 ? P : p.Nq) + 127) / 128 * p.ksplit, p.B); }
     if (grid.y > 65535 || grid.z > 65535) return COBEVT_ERR_SHAPE;
     // 128-key tiles: bf16, enough keys, not the camera-paired mode (its tiles never mix cameras)
     // ... and a grid that does not fill the chip anyway (there the iteration count sets the time; on a full grid the wider tile's
     // registers cost occupancy: 512-token LiDAR windows, bias + mask, 8192 workgroups: 357 us against 266 us with 64-key tiles)
     const bool wide = dtype == 0 && p.mean_q != 2 && p.Nk >= 256 && variant != 2 &&      // variant 2: 64-key tiles (A/B)
                       (long)grid.x * grid.y * grid.z <= 1024;
+    if (p.ksplit > 1 && (p.Nk + (wide ? 127 : 63)) / (wide ? 128 : 64) < p.ksplit) return COBEVT_ERR_SHAPE;   // >= 1 tile per split
     size_t lds = dtype == 0 ? (wide ? AttnLds<bf16_t, 128>::kFixed : AttnLds<bf16_t, 64>::kFixed) : AttnLds<float, 64>::kFixed;
     if (p.bias_mode) lds += ((size_t)p.bias_rows * 4 + 15) & ~(size_t)15;
     if (!p.klinear) lds += (size_t)p.Nk * 8;        // per-key row / coordinate table
@@ -498,7 +574,22 @@ static int window_attention_impl(const void* q, const void* k, const void* v, vo
     else if (dtype == 0) COBEVT_ATTN_LAUNCH(bf16_t, 64);
     else COBEVT_ATTN_LAUNCH(float, 64);
 #undef COBEVT_ATTN_LAUNCH
+    if (p.ksplit > 1) {
+        const long items = p.part_rows * p.heads * 4;
+        const dim3 mg((unsigned)((items + 255) / 256));
+        if (dtype == 0) hipLaunchKernelGGL(attn_ksplit_merge_kernel<bf16_t>, mg, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(attn_ksplit_merge_kernel<float>, mg, dim3(256), 0, stream, p);
+    }
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// Key-split form of cobevt_window_attention, see include/cobevt_hip.h
+extern "C" int cobevt_window_attention_ksplit(const void* q, const void* k, const void* v, void* out, const float* bias_table,
+                                              const float* mask, void* part_out, float* part_lse, const int* dims, float scale,
+                                              int ksplit, long out_rows, hipStream_t stream) {
+    if (ksplit < 2) return COBEVT_ERR_ARG;
+    return window_attention_impl(q, k, v, out, nullptr, bias_table, mask, dims, scale, 0.f, 0u, nullptr, stream, ksplit, part_out,
+                                 part_lse, out_rows);
 }
 
 // C-ABI entry points, see include/cobevt_hip.h

@@ -79,6 +79,15 @@ struct AttnParams {
     // nullable device word ADDED to drop_seed: a captured training step (tools/train_graph_probe.py) bumps it inside the graph, so every
     // replay draws a new mask although the kernel arguments are frozen in the graph's nodes
     const unsigned* drop_seed_dev;
+    // key split (streaming kernel, inference): the keys of a window are shared out over `ksplit` workgroups per query tile; each
+    // writes its normalised partial output rows to part_out[split] (same row indexing as `out`, row stride heads * 32) and the
+    // base-2 log-sum-exp of its keys to part_lse[split][row][head]; attn_ksplit_merge_kernel combines them into `out`.
+    // For the launches whose grid leaves the chip idle AND whose per-query key walk is long (level-2 / global FAX attention:
+    // 1024 keys, 160 workgroups) - the tile loop is one dependent round trip per iteration.
+    int ksplit;
+    void* part_out;
+    float* part_lse;
+    long part_rows;           // rows of `out` (stride between the splits' partial buffers)
 };
 
 __host__ __device__ __forceinline__ unsigned attn_mix32(unsigned x) {       // murmur3 finaliser

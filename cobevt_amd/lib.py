@@ -37,6 +37,7 @@ SIGNATURES = {
     "cobevt_gru_zero_state": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_int, _vp]),
     "cobevt_agent_softmax_sum": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp] + [ctypes.c_int] * 6 + [_vp]),
     "cobevt_window_attention": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int_p, ctypes.c_float, _vp]),
+    "cobevt_window_attention_ksplit": (ctypes.c_int, [_vp] * 8 + [_c_int_p, ctypes.c_float, ctypes.c_int, ctypes.c_long, _vp]),
     "cobevt_window_attention_lse": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int_p, ctypes.c_float, ctypes.c_float,
                                                    ctypes.c_uint, _vp, _vp]),
     "cobevt_conv3x3_head_nchw": (ctypes.c_int, [_vp, _vp, _vp, _vp] + [ctypes.c_int] * 6 + [_vp]),

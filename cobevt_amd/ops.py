@@ -45,6 +45,10 @@ USE_PROJ_CHAIN = True   # FAX key / value side at 128 feature channels: BN -> Re
 USE_SWAP_STAGE = True   # a SwapFusionBlock half (attention + row chain + next to_qkv) as one launch (swap_stage.hip)
 USE_BOTTLENECK = True   # FAX ResNetBottleNeck (128 -> 32 -> 32 -> 128) as one launch (bottleneck.hip) instead of three
 ATTN_VARIANT = 0    # 0 = automatic (K/V-resident attention kernel where it applies), 1 = always the streaming kernel, 2 = ... with 64-key tiles (A/B runs)
+ATTN_KSPLIT = 0     # streaming attention on a small grid with >= 1024 keys (FAX level 2 / global attention): share the keys of a window out
+                    # over this many workgroups per query tile + a merge pass (0 / 1 = off).  Off: same-job A/B 0 / 2 / 4 = 2.081 / 2.078 /
+                    # 2.083 ms per frame, 582 / 578 / 569 frames/s (profiles/r03_ab_key_split.txt) - the merge launch costs what the shorter
+                    # tile loop saves; parity-tested (tests/test_kernels_gpu.py::test_attention_key_split_matches_single_pass)
 ATTN_QSPLIT = 0     # 0 = automatic query split of the resident attention kernel; > 0 pins it (tools/attn_probe.py)
 
 
@@ -62,7 +66,7 @@ def _apply_env_flags():
         if "=" in item:
             k, v = item.split("=", 1)
             k = k.strip()
-            if k not in globals() or not (k.startswith("USE_") or k in ("CONV3_VARIANT", "BASICBLOCK_TILE_ROWS", "ROW_CHAIN_ROWS", "GEMM_ROWS3_MIN_M", "GEMM_ROWS3_MAX_K", "GEMM_ROWS3_STRIDED", "GEMM_ROWS3_ROWS64_MIN_M", "ATTN_VARIANT", "ATTN_QSPLIT")):
+            if k not in globals() or not (k.startswith("USE_") or k in ("CONV3_VARIANT", "BASICBLOCK_TILE_ROWS", "ROW_CHAIN_ROWS", "GEMM_ROWS3_MIN_M", "GEMM_ROWS3_MAX_K", "GEMM_ROWS3_STRIDED", "GEMM_ROWS3_ROWS64_MIN_M", "ATTN_VARIANT", "ATTN_QSPLIT", "ATTN_KSPLIT")):
                 raise CobevtHipError("COBEVT_FLAGS: unknown switch %r" % k)
             globals()[k] = int(v) if not k.startswith("USE_") else bool(int(v))
 
@@ -627,7 +631,7 @@ def tokmap(mode, ncam, hh, ww, w1, w2):
 
 
 def window_attention(q, k, v, out, qmap, kmap, omap, batch, heads, scale, ldq, ldk, ldv, ldo, qoff=0, koff=0, voff=0,
-                     ooff=0, bias_table=None, bias_L=1, mask=None, mean_q=False, variant=None, qsplit=None):
+                     ooff=0, bias_table=None, bias_L=1, mask=None, mean_q=False, variant=None, qsplit=None, ksplit=None):
     _need_cuda(q, k, v, out, bias_table, mask)
     code = dcode(q.dtype) | ((ATTN_VARIANT if variant is None else int(variant)) << 8) | \
         ((ATTN_QSPLIT if qsplit is None else int(qsplit)) << 16)
@@ -646,9 +650,20 @@ def window_attention(q, k, v, out, qmap, kmap, omap, batch, heads, scale, ldq, l
         pairs = nq * nk // (qmap[1] if int(mean_q) == 2 else 1)      # camera-paired: a query copy scores its own camera's keys
         return 4.0 * batch * L * heads * pairs * 32, float(nbytes)
 
-    with _timed("attention|B%d L%d h%d Nq%d Nk%d" % (batch, L, heads, qmap[1] * qmap[4] * qmap[5], kmap[1] * kmap[4] * kmap[5]), cost):
-        rc = _L.load().cobevt_window_attention(_p(q), _p(k), _p(v), _p(out), _p(bias_table), _p(mask), dims,
-                                               ctypes.c_float(scale), _stream())
+    nq_, nk_ = qmap[1] * qmap[4] * qmap[5], kmap[1] * kmap[4] * kmap[5]
+    ks = ATTN_KSPLIT if ksplit is None else int(ksplit)
+    use_ks = (ks > 1 and not mean_q and nk_ >= 1024 and batch * L * heads * ((nq_ + 127) // 128) * ks <= 1024
+              and out.is_contiguous() and ldo == out.shape[-1] and ooff == 0 and omap[1] == qmap[1])
+    with _timed("attention|B%d L%d h%d Nq%d Nk%d%s" % (batch, L, heads, nq_, nk_, " ks%d" % ks if use_ks else ""), cost):
+        if use_ks:
+            rows = out.numel() // out.shape[-1]
+            part_out = torch.empty((ks, rows, heads * 32), device=out.device, dtype=out.dtype)
+            part_lse = torch.empty((ks, rows, heads), device=out.device, dtype=torch.float32)
+            rc = _L.load().cobevt_window_attention_ksplit(_p(q), _p(k), _p(v), _p(out), _p(bias_table), _p(mask), _p(part_out),
+                                                          _p(part_lse), dims, ctypes.c_float(scale), ks, rows, _stream())
+        else:
+            rc = _L.load().cobevt_window_attention(_p(q), _p(k), _p(v), _p(out), _p(bias_table), _p(mask), dims,
+                                                   ctypes.c_float(scale), _stream())
     _L.check(rc, "cobevt_window_attention")
     return out
 

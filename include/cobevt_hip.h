@@ -419,6 +419,15 @@ int cobevt_channel_gate_nhwc(const void* in, const float* gate, void* out, int d
 int cobevt_mean_linear_rows_small_k(const void* in, const void* wfrag, const float* bias, void* out, const long* dims,
                                     float ln_eps, hipStream_t stream);
 
+/* cobevt_window_attention with the KEYS of every window shared out over `ksplit` (2..8) workgroups per query tile and a merge
+ * pass (same reference code: fax_modules.py:211-237, 137-171): for launches whose grid leaves the chip idle while every query
+ * walks a long key list (FAX level 2 / global attention: 1024 keys, 160 workgroups).  Plain inference attention only (no camera
+ * mean / pairing, no lse, no dropout); bias table and mask as there.  part_out: [ksplit][out_rows][heads * 32] in the storage
+ * dtype, part_lse: fp32 [ksplit][out_rows][heads] - scratch; out_rows = rows of `out` (ld = dims' ldo). */
+int cobevt_window_attention_ksplit(const void* q, const void* k, const void* v, void* out, const float* bias_table,
+                                   const float* mask, void* part_out, float* part_lse, const int* dims, float scale,
+                                   int ksplit, long out_rows, hipStream_t stream);
+
 /*
  * Projection chain (bf16, 128 channels): the key / value side of a FAX cross-view level in one launch per operand -
  *   y = ReLU?(a * pre_scale[c] + pre_shift[c]) . Wp^T + bp + skip     pre-activation BatchNorm -> ReLU -> 1x1 conv (feature_proj /

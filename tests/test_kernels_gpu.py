@@ -1176,3 +1176,45 @@ def test_projection_chain_single_launch(cuda, rows, with_res):
     s = float(ref.abs().max())
     assert (fused.float().cpu() - ref).abs().max().item() <= 1.5e-2 * s
     assert (fused.float() - two.float()).abs().max().item() <= 1.5e-2 * s
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("use_bias,ncam", [(True, 1), (False, 4)])
+def test_attention_key_split_matches_single_pass(cuda, dtype, use_bias, ncam):
+    """cobevt_window_attention_ksplit (keys of a window shared out over 2 / 4 workgroups per query tile + log-sum-exp merge) against the
+    single-pass streaming kernel and a dense fp32 softmax: the FAX global attention shape (one 32 x 32 window = 1024 keys, 2-D
+    relative position bias, fax_modules.py:137-171) and the level-2 cross attention shape (1024 queries x 4 cameras x 16 x 16 keys,
+    fax_modules.py:211-237)"""
+    g = torch.Generator().manual_seed(6)
+    B, heads, d = 2, 4, 128
+    if ncam == 1:
+        qmap = kmap = ops.tokmap(0, 1, 32, 32, 32, 32)
+        nq = nk = 1024
+        rows_q = rows_k = B * 1024
+    else:
+        qmap, kmap = ops.tokmap(0, 1, 32, 32, 32, 32), ops.tokmap(0, ncam, 16, 16, 16, 16)
+        nq, nk = 1024, ncam * 256
+        rows_q, rows_k = B * 1024, B * ncam * 256
+    q = (torch.randn(rows_q, d, generator=g) * 1.5).to(dtype).to(cuda)
+    k = (torch.randn(rows_k, d, generator=g) * 1.5).to(dtype).to(cuda)
+    v = torch.randn(rows_k, d, generator=g).to(dtype).to(cuda)
+    table = (torch.randn(63 * 63, heads, generator=g) * 0.5).to(cuda) if use_bias else None
+    outs = {}
+    for ks in (0, 2, 4):
+        out = torch.empty(rows_q, d, device=cuda, dtype=dtype)
+        with ops.LaunchProfile() as prof:
+            ops.window_attention(q, k, v, out, qmap, kmap, qmap, B, heads, 32 ** -0.5, d, d, d, d, bias_table=table, bias_L=1, ksplit=ks)
+        name = list(prof.summary(by_shape=True))[0]
+        assert ("ks%d" % ks in name) == (ks > 1), name
+        outs[ks] = out.float().cpu()
+    # dense reference: per (batch, head) softmax(q k^T / sqrt(32) + bias) v over the window's keys in kernel token order
+    qf, kf, vf = q.float().cpu().reshape(B, nq, heads, 32), k.float().cpu().reshape(B, nk, heads, 32), v.float().cpu().reshape(B, nk, heads, 32)
+    s = torch.einsum("bqhd,bkhd->bhqk", qf, kf) * 32 ** -0.5
+    if use_bias:
+        idx = ops.attention_bias_index(qmap, kmap, 1, cuda).cpu().long()
+        s = s + table.cpu()[idx].permute(2, 0, 1)[None]
+    ref = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), vf).reshape(B * nq, d)
+    tol_ = 1.5e-2 if dtype == torch.bfloat16 else 1e-4
+    scale = float(ref.abs().max())
+    for ks, o in outs.items():
+        assert float((o - ref).abs().max()) <= tol_ * scale, (ks, float((o - ref).abs().max()) / scale)
