@@ -251,14 +251,19 @@ def linear(x, lin):
             mh, mw = rows // cand, cand
             break
     x4 = x.reshape(1, mh, mw, k).permute(0, 3, 1, 2)                   # (1, K, H, W)-shaped view of channels-last memory
-    w4 = lin.weight[:, :, None, None]
+    w4 = _master(lin.weight)[:, :, None, None]
     if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
         with torch.autocast("cuda", enabled=False):
-            b = None if lin.bias is None else lin.bias.to(torch.bfloat16)
-            y = Conv2dFn.apply(x4.to(torch.bfloat16), w4.to(torch.bfloat16), b, 1, 0)
+            y = Conv2dFn.apply(x4.to(torch.bfloat16), w4, lin.bias, 1, 0)
     else:
         y = Conv2dFn.apply(x4, w4, lin.bias, 1, 0)
     return y.permute(0, 2, 3, 1).reshape(x.shape[:-1] + (lin.weight.shape[0],))
+
+
+def _master(weight):
+    """The fp32 master copy the training convolutions take (a module kept in fp32 - the reference's --half loop keeps fp32 parameters
+    under autocast - hands its parameter over as it is; anything else goes through a differentiable cast)"""
+    return weight if weight.dtype == torch.float32 else weight.float()
 
 
 def dropout(x, p):
@@ -296,28 +301,53 @@ def _klut(kh, kw, cin, kpad, device):
     return _KLUT[key]
 
 
-def _igemm_conv(x, weight, bias, stride, pad, ho, wo):
-    """x (N, H, W, Cin) channels-last, weight (Cout, Cin, kh, kw), both fp32 or both bf16 -> (N, ho, wo, Cout) in that dtype:
-    cobevt_conv2d_nhwc (csrc/igemm.hip), top / left padding `pad`; taps past the bottom / right edge read zeros (the kernel
-    bounds-checks every tap).  Channel counts that are not a multiple of a 16-byte chunk take the kernel's gather path, which
-    reads its input as fp32."""
-    n, h, w, cin = x.shape
-    cout, _, kh, kw = weight.shape
+def _kpad(K, dtype):
+    tile = 32 if dtype == torch.bfloat16 else 16
+    return (K + tile - 1) // tile * tile
+
+
+USE_TORCH_OPERAND_PREP = False      # True: weight rows / blocked operands through the torch-op specifications (A/B and diagnostics only)
+
+
+def conv_weight_rows(weight, dtype, fwd=True, dgrad=False):
+    """fp32 master weight (Cout, Cin, kh, kw) -> (rows_fwd [Cout][Kpad] | None, rows_dgrad [Cin][Kpad'] | None) in `dtype`: ONE launch of
+    cobevt_conv_weight_rows (csrc/train_prep.hip) instead of cast + permute + pad (+ flip + transpose + permute + pad) per convolution and
+    step.  Specification: _weight_rows(weight.to(dtype)) and _weight_rows(weight.to(dtype).flip(2, 3).transpose(0, 1))."""
+    cout, cin, kh, kw = weight.shape
+    if USE_TORCH_OPERAND_PREP:
+        wd = weight.detach().to(dtype)
+        return (_weight_rows(wd)[0] if fwd else None), (_weight_rows(wd.flip(2, 3).transpose(0, 1))[0] if dgrad else None)
+    w = _f32c(weight.detach(), "weight")
+    kpf, kpd = _kpad(kh * kw * cin, dtype), _kpad(kh * kw * cout, dtype)
+    rf = torch.empty((cout, kpf), device=w.device, dtype=dtype) if fwd else None
+    rd = torch.empty((cin, kpd), device=w.device, dtype=dtype) if dgrad else None
+    dims = _ints([ops.dcode(dtype), cout, cin, kh, kw, kpf, kpd])
+    _L.check(_L.load().cobevt_conv_weight_rows(_p(w), _p(rf), _p(rd), dims, _stream()), "cobevt_conv_weight_rows")
+    return rf, rd
+
+
+def _igemm_rows(x, w2, cout, cin, kh, kw, bias, stride, pad, ho, wo):
+    """x (N, H, W, Cin) channels-last, w2 = [Cout][Kpad] weight rows (k = (r * kw + s) * Cin + c) of the same dtype (fp32 / bf16) ->
+    (N, ho, wo, Cout) in that dtype: cobevt_conv2d_nhwc (csrc/igemm.hip), top / left padding `pad`; taps past the bottom / right edge
+    read zeros (the kernel bounds-checks every tap).  Channel counts that are not a multiple of a 16-byte chunk take the kernel's
+    gather path, which reads its input as fp32.  bias: fp32 (Cout,) | None."""
+    n, h, w, _ = x.shape
     bf16 = x.dtype == torch.bfloat16
-    w2, K, kpad = _weight_rows(weight)
+    K, kpad = kh * kw * cin, w2.shape[1]
     smallc = int(cin % (8 if bf16 else 4) != 0)
     klut = _klut(kh, kw, cin, kpad, x.device) if smallc else None
     if smallc and bf16:
         x = x.float()
-    out = torch.empty((n, ho, wo, cout), device=x.device, dtype=weight.dtype)
+    out = torch.empty((n, ho, wo, cout), device=x.device, dtype=w2.dtype)
     dims = _ints([ops.BF16 if bf16 else ops.FP32, n, h, w, cin, ho, wo, cout, kh, kw, stride, pad, K, kpad, 0, 0, 0, 0, ho, wo, smallc])
-    b = None if bias is None else _f32c(bias.float(), "bias")
+    b = None if bias is None else _f32c(bias.detach().float(), "bias")
     rc = _L.load().cobevt_conv2d_nhwc(_p(x), _p(w2), _p(b), None, None, None, _p(klut), _p(out), dims, _stream())
     _L.check(rc, "cobevt_conv2d_nhwc")
     return out
 
 
-USE_WGRAD_BLOCKED = True      # bf16, stride 1, k in (1, 3): weight gradient on the bf16 matrix path (cobevt_conv_wgrad_blocked)
+USE_WGRAD_BLOCKED = True      # bf16: weight gradient on the bf16 matrix path (cobevt_conv_wgrad_blocked) where wgrad_blocked_mode() has a form for it
+USE_WGRAD_BLOCKED_STRIDED = True   # ... incl. the stride-2 and stem forms (modes 1 / 2); False: those stay on cobevt_conv_wgrad (A/B runs)
 
 
 def _blocked_operands(xl, dyl, k, pad):
@@ -336,36 +366,93 @@ def _blocked_operands(xl, dyl, k, pad):
     return xb, db, hp, nxb, ndb
 
 
+def wgrad_blocked_mode(k, stride, pad, cin):
+    """Which form of cobevt_conv_wgrad_blocked serves a bf16 convolution: 0 stride 1 (k = 1 / 3), 1 stride 2 with the columns
+    de-interleaved into planes (3x3 / pad 1 and the 1x1 / pad 0 shortcut of a down-sampling BasicBlock), 2 the k tap columns as
+    pseudo-channels (the 7x7 / stride 2 stem on 3 channels); None = the generic fp32-matrix kernel (cobevt_conv_wgrad)"""
+    if stride == 1 and k in (1, 3):
+        return 0
+    if stride == 2 and ((k == 3 and pad == 1) or (k == 1 and pad == 0)):
+        return 1
+    if k in (1, 3, 5, 7) and k * cin <= 32:
+        return 2
+    return None
+
+
+def _blocked_geometry(h, w, ho, wo, k, pad, stride, mode):
+    ndb = (wo + 15) // 16 * 2
+    if mode == 0:
+        return ndb, ndb + 1, max(h + 2 * pad, ho + k - 1), 1, 1
+    if mode == 1:
+        return ndb, ndb + (1 if k == 3 else 0), max(h + 2 * pad, (ho - 1) * 2 + k), (2 if k == 3 else 1), 2
+    return ndb, ndb, max(h + 2 * pad, (ho - 1) * stride + k), k, stride
+
+
+def _blocked_x_general(xl, hp, nxb, pad, planes, sx):
+    """torch-op specification of cobevt_wgrad_block_operand for any (planes, sx): [n][row][block][plane][c][8], slot j of plane q of
+    block b = zero-padded input pixel sx (8 b + j) + q - pad of input row (row - pad)"""
+    n, h, w, c = xl.shape
+    width = (nxb * 8 - 1) * sx + planes                                  # padded columns the planes read
+    xp = torch.nn.functional.pad(xl, (0, 0, pad, max(0, width - w - pad), pad, hp - h - pad))
+    cols = (torch.arange(nxb * 8, device=xl.device) * sx)[:, None] + torch.arange(planes, device=xl.device)[None]     # [pixel slot][plane]
+    g = xp[:, :, cols.reshape(-1)]                                         # (n, hp, nxb * 8 * planes, c)
+    return g.view(n, hp, nxb, 8, planes, c).permute(0, 1, 2, 4, 5, 3).contiguous()
+
+
+def blocked_operands(xl, dyl, k, pad, stride=1, mode=0):
+    """The operands of cobevt_conv_wgrad_blocked (mode: wgrad_blocked_mode) as two launches of cobevt_wgrad_block_operand - instead of
+    two pads + two permuting copies (6-8 launches; _blocked_operands, the mode-0 specification).  Returns (xb, db, hp, nxb, ndb)."""
+    n, h, w, cin = xl.shape
+    _, ho, wo, cout = dyl.shape
+    if USE_TORCH_OPERAND_PREP and mode == 0:
+        return _blocked_operands(xl, dyl, k, pad)
+    ndb, nxb, hp, planes, sx = _blocked_geometry(h, w, ho, wo, k, pad, stride, mode)
+    if USE_TORCH_OPERAND_PREP:
+        xb = _blocked_x_general(xl, hp, nxb, pad, planes, sx)
+        db = _blocked_x_general(dyl, ho, ndb, 0, 1, 1)
+        return xb, db, hp, nxb, ndb
+    xb = torch.empty((n, hp, nxb, planes, cin, 8), device=xl.device, dtype=xl.dtype)
+    db = torch.empty((n, ho, ndb, 1, cout, 8), device=xl.device, dtype=xl.dtype)
+    lib = _L.load()
+    _L.check(lib.cobevt_wgrad_block_operand(_p(xl), _p(xb), _ints([n, h, w, cin, hp, nxb, pad, pad, planes, sx]), _stream()),
+             "cobevt_wgrad_block_operand")
+    _L.check(lib.cobevt_wgrad_block_operand(_p(dyl), _p(db), _ints([n, ho, wo, cout, ho, ndb, 0, 0, 1, 1]), _stream()),
+             "cobevt_wgrad_block_operand")
+    return xb, db, hp, nxb, ndb
+
+
 class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d (square kernel, symmetric padding, groups 1) on (N, C, H, W)-shaped tensors (channels-last memory is used as it
     is).  Forward and the input gradient run on the implicit-GEMM kernel (the input gradient is the same convolution with the
     taps flipped and the channel roles swapped, on the zero-stuffed output gradient when stride > 1); the weight gradient is
-    cobevt_conv_wgrad (csrc/train_rows.hip: a GEMM over the pixels on the fp32 matrix path, operands straight from global memory).
-    fp32, or - x and weight both bf16, which is what conv2d() hands over inside a bf16 autocast region - bf16 storage with the
-    bf16 matrix instructions in forward / input gradient and fp32 accumulation of the weight gradient."""
+    cobevt_conv_wgrad (csrc/train_rows.hip: a GEMM over the pixels on the fp32 matrix path, operands straight from global memory)
+    or cobevt_conv_wgrad_blocked (bf16 matrix path).  weight / bias are the fp32 MASTER parameters; x is fp32, or bf16 - which is
+    what conv2d() hands over inside a bf16 autocast region: bf16 storage, the bf16 matrix instructions in forward / input gradient,
+    fp32 accumulation of the weight gradient.  The weight rows of both directions are made from the master weight by one launch
+    (conv_weight_rows), the gradients of weight and bias are returned in fp32: no cast nodes in the autograd graph."""
 
     @staticmethod
     @_amp_fwd
     def forward(ctx, x, weight, bias, stride, pad):
         _need_cuda(x, weight, bias)
-        if x.dtype != weight.dtype or x.dtype not in (torch.float32, torch.bfloat16):
-            raise CobevtHipError("training conv2d: x and weight both fp32 or both bf16 (got %s, %s)" % (x.dtype, weight.dtype))
+        if weight.dtype != torch.float32 or x.dtype not in (torch.float32, torch.bfloat16):
+            raise CobevtHipError("training conv2d: fp32 master weight, x fp32 or bf16 (got %s, %s)" % (weight.dtype, x.dtype))
         xl = x.permute(0, 2, 3, 1).contiguous()
         n, h, w, _ = xl.shape
-        kh, kw = weight.shape[2:]
+        cout, cin, kh, kw = weight.shape
         ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
-        out = _igemm_conv(xl, weight, bias, stride, pad, ho, wo)
-        ctx.save_for_backward(xl, weight)
-        ctx.cfg = (stride, pad, bias is not None)
+        rows_f, rows_d = conv_weight_rows(weight, xl.dtype, True, ctx.needs_input_grad[0])
+        out = _igemm_rows(xl, rows_f, cout, cin, kh, kw, bias, stride, pad, ho, wo)
+        ctx.save_for_backward(xl, rows_d)
+        ctx.cfg = (stride, pad, bias is not None, tuple(weight.shape))
         ctx.bias_dtype = None if bias is None else bias.dtype
         return out.permute(0, 3, 1, 2)
 
     @staticmethod
     @_amp_bwd
     def backward(ctx, dy):
-        xl, weight = ctx.saved_tensors
-        stride, pad, has_bias = ctx.cfg
-        cout, cin, kh, kw = weight.shape
+        xl, rows_d = ctx.saved_tensors
+        stride, pad, has_bias, (cout, cin, kh, kw) = ctx.cfg
         n, h, w, _ = xl.shape
         dyl = dy.to(xl.dtype).permute(0, 2, 3, 1).contiguous()
         ho, wo = dyl.shape[1:3]
@@ -375,20 +462,21 @@ class Conv2dFn(torch.autograd.Function):
             if stride > 1:                       # zero-stuffed gradient map: dgrad of a strided conv = stride-1 conv on it
                 g = torch.zeros((n, (ho - 1) * stride + 1, (wo - 1) * stride + 1, cout), device=dyl.device, dtype=dyl.dtype)
                 g[:, ::stride, ::stride] = dyl
-            wt = weight.flip(2, 3).transpose(0, 1)                 # (Cin, Cout, kh, kw)
-            dx = _igemm_conv(g, wt, None, 1, kh - 1 - pad, h, w).permute(0, 3, 1, 2)
+            dx = _igemm_rows(g, rows_d, cin, cout, kh, kw, None, 1, kh - 1 - pad, h, w).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             dw = torch.zeros((cout, cin, kh, kw), device=dyl.device, dtype=torch.float32)
-            if USE_WGRAD_BLOCKED and xl.dtype == torch.bfloat16 and stride == 1 and kh in (1, 3):
-                x_blk, dy_blk, hp, nxb, ndb = _blocked_operands(xl, dyl, kh, pad)
-                dims = _ints([n, hp, nxb, cin, ho, ndb, cout, kh])
+            mode = wgrad_blocked_mode(kh, stride, pad, cin) if (USE_WGRAD_BLOCKED and xl.dtype == torch.bfloat16 and kh == kw) else None
+            if mode is not None and not USE_WGRAD_BLOCKED_STRIDED and mode != 0:
+                mode = None
+            if mode is not None:
+                x_blk, dy_blk, hp, nxb, ndb = blocked_operands(xl, dyl, kh, pad, stride, mode)
+                dims = _ints([n, hp, nxb, cin, ho, ndb, cout, kh, stride, mode])
                 rc = _L.load().cobevt_conv_wgrad_blocked(_p(x_blk), _p(dy_blk), _p(dw), dims, _stream())
                 _L.check(rc, "cobevt_conv_wgrad_blocked")
             else:
                 dims = _ints([n, h, w, cin, ho, wo, cout, kh, stride, pad, ops.BF16 if xl.dtype == torch.bfloat16 else ops.FP32])
                 rc = _L.load().cobevt_conv_wgrad(_p(xl), _p(dyl), _p(dw), dims, _stream())
                 _L.check(rc, "cobevt_conv_wgrad")
-            dw = dw.to(weight.dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = column_sum(dyl.reshape(-1, cout)).to(ctx.bias_dtype)
         return dx, dw, db, None, None
@@ -400,12 +488,11 @@ def conv2d(x, conv):
             or conv.padding[0] != conv.padding[1]:
         raise CobevtHipError("training conv2d: square kernel / stride / padding, groups 1, dilation 1 only")
     if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
-        # a bf16 autocast region: the convolution computes in bf16 like torch's own conv would (fp32 master weights: the casts are
-        # differentiable, the parameter receives an fp32 gradient); fp16 regions stay on the fp32 kernels (_amp_fwd)
+        # a bf16 autocast region: the convolution computes in bf16 like torch's own conv would, from the fp32 master weights (the
+        # parameter receives an fp32 gradient); fp16 regions stay on the fp32 kernels (_amp_fwd)
         with torch.autocast("cuda", enabled=False):
-            b = None if conv.bias is None else conv.bias.to(torch.bfloat16)
-            return Conv2dFn.apply(x.to(torch.bfloat16), conv.weight.to(torch.bfloat16), b, conv.stride[0], conv.padding[0])
-    return Conv2dFn.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
+            return Conv2dFn.apply(x.to(torch.bfloat16), _master(conv.weight), conv.bias, conv.stride[0], conv.padding[0])
+    return Conv2dFn.apply(x, _master(conv.weight), conv.bias, conv.stride[0], conv.padding[0])
 
 
 # ----------------------------------------------------------------------------------------------
@@ -653,3 +740,20 @@ def weighted_cross_entropy(logits, target, weight):
     # explicit (differentiable) cast: the criterion is commonly called OUTSIDE the autocast region, where custom_fwd's
     # cast_inputs no longer applies and a bf16 / fp16 head output would reach the fp32 kernel as it is
     return WeightedCrossEntropyFn.apply(logits.float(), target, weight)
+
+
+def _env_flags():
+    """COBEVT_TRAIN_FLAGS="USE_TORCH_OPERAND_PREP=1,USE_WGRAD_BLOCKED=0": the module's USE_* switches from the environment (same-job A/B
+    runs of tools/train_probe.py; never set in production)"""
+    import os
+    for item in os.environ.get("COBEVT_TRAIN_FLAGS", "").split(","):
+        if not item.strip():
+            continue
+        k, _, v = item.partition("=")
+        k = k.strip()
+        if not k.startswith("USE_") or k not in globals() or not isinstance(globals()[k], bool):
+            raise CobevtHipError("COBEVT_TRAIN_FLAGS: unknown switch %r" % k)
+        globals()[k] = bool(int(v))
+
+
+_env_flags()

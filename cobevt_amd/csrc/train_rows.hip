@@ -206,9 +206,15 @@ struct Wgrad16Params {
     const uint4* db;     // [N][Ho][DB][Cout] blocks of 8 bf16
     float* dw;           // (Cout, Cin, k, k) fp32, zero-initialised
     int N, Hp, XB, Cin, Ho, DB, Cout, k, nchunks;
+    int sy;              // padded X row of output row oy, tap row ta: oy * sy + ta (the convolution's stride)
+    int P;               // planes per block of X: [N][Hp][XB][P][Cin] (1 for stride 1)
 };
 
-template <int KW>
+// S2 (stride 2; the first convolution and the 1 x 1 shortcut of a down-sampling BasicBlock, resnet_ms.py:67-74): the caller de-interleaves
+// the columns - plane q of block b holds the (zero-padded) input pixels 2 (8 b + j) + q, j = 0..7 (cobevt_wgrad_block_operand with
+// sx = 2) - so tap 0 / 1 / 2 of output pixel ox are pixel ox of plane 0, pixel ox of plane 1 and pixel ox + 1 of plane 0: again
+// 16-byte loads and one funnel shift, no bounds tests.  k = 1: one plane (the even pixels).
+template <int KW, bool S2>
 __global__ __launch_bounds__(256) void conv_wgrad16_kernel(Wgrad16Params p) {
     __shared__ float red[3 * 16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(Wgrad16Params p) {
     const int nrows_w = r1 > r0 + wave ? (r1 - r0 - wave + 3) >> 2 : 0;
     const int total = nrows_w * nsteps;
     for (int base = 0; base < total; base += U) {
-        uint4 a[U], w0[U];
+        uint4 a[U], w0[U], w1[U];
         uint32_t w4[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -242,11 +248,12 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(Wgrad16Params p) {
             const int row = r0 + wave + 4 * ri;
             const int n = row / p.Ho, oy = row - n * p.Ho;
             const uint4* dr = p.db + ((size_t)row * p.DB + b0 + h) * p.Cout + co;                          // block b0 + h of dY's row
-            const uint4* xr = p.xb + (((size_t)n * p.Hp + oy + ta) * p.XB + b0 + h) * p.Cin + ci;         // padded row oy + ta
+            const uint4* xr = p.xb + ((((size_t)n * p.Hp + oy * p.sy + ta) * p.XB + b0 + h) * p.P) * p.Cin + ci;   // padded row oy * sy + ta
             a[u] = dr[0];
             w0[u] = xr[0];
             w4[u] = 0;
-            if constexpr (KW > 1) w4[u] = ((const uint32_t*)(xr + p.Cin))[0];                              // pixels 8, 9 of the window
+            if constexpr (KW > 1) w4[u] = ((const uint32_t*)(xr + p.P * p.Cin))[0];                        // pixels 8, 9 of the window
+            if constexpr (KW > 1 && S2) w1[u] = xr[p.Cin];                                                  // plane 1: the odd columns
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -260,8 +267,14 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(Wgrad16Params p) {
                 const uint4 s1 = make_uint4(__builtin_amdgcn_alignbit(wv.y, wv.x, 16), __builtin_amdgcn_alignbit(wv.z, wv.y, 16),
                                             __builtin_amdgcn_alignbit(wv.w, wv.z, 16), __builtin_amdgcn_alignbit(w4v, wv.w, 16));
                 const uint4 s2 = make_uint4(wv.y, wv.z, wv.w, w4v);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, s1), acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, s2), acc[2], 0, 0, 0);
+                if constexpr (S2) {                   // tap 1: plane 1 as loaded; tap 2: pixels 1..8 of plane 0
+                    const uint4 odd = ci_ok ? w1[u] : zero;
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, odd), acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, s1), acc[2], 0, 0, 0);
+                } else {
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, s1), acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, s2), acc[2], 0, 0, 0);
+                }
             }
         }
     }
@@ -279,6 +292,78 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(Wgrad16Params p) {
                 const float v = acc[t][r] + red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane];
                 const int o = co0 + acc_row(r, lane), c = ci0 + ql;     // D[cout rows][cin cols]
                 if (o < p.Cout && c < p.Cin && v != 0.f) atomicAdd(p.dw + ((size_t)o * p.Cin + c) * ntap + ta * p.k + t, v);
+            }
+        }
+    }
+}
+
+
+// "Columns as channels" (the 7 x 7 / stride 2 stem on 3 input channels, resnet_ms.py:67-69: a 32-channel tile per tap would be 90 % empty):
+// the caller lays the k taps of a tap row out as k planes per block - plane b of block q holds input pixels s (8 q + j) + b - pad -
+// so that (tap column b, channel c) = pseudo-channel b Cin + c <= 32 is ONE lane of the B operand and a tap ROW is one matrix
+// instruction per 16 pixels; a wave carries the KH tap rows as KH accumulators over one load of dY.  Workgroup = (32-cout tile, share of
+// the output rows).
+template <int KH>
+__global__ __launch_bounds__(256) void conv_wgrad16_cols_kernel(Wgrad16Params p) {
+    __shared__ float red[3 * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, ql = lane & 31;
+    const int co0 = blockIdx.x * 32;
+    const int CP = p.P * p.Cin;                                     // pseudo-channels (<= 32)
+    const int rows = p.N * p.Ho;
+    const int per = (rows + p.nchunks - 1) / p.nchunks;
+    const int r0 = blockIdx.z * per, r1 = min(rows, r0 + per);
+    const bool co_ok = co0 + ql < p.Cout, cp_ok = ql < CP;
+    const int co = min(co0 + ql, p.Cout - 1), cp = min(ql, CP - 1);
+    f32x16 acc[KH];
+#pragma unroll
+    for (int t = 0; t < KH; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    constexpr int U = 2;
+    const int nsteps = p.DB >> 1;
+    const int nrows_w = r1 > r0 + wave ? (r1 - r0 - wave + 3) >> 2 : 0;
+    const int total = nrows_w * nsteps;
+    for (int base = 0; base < total; base += U) {
+        uint4 a[U], w[U][KH];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = min(base + u, total - 1);
+            const int ri = idx / nsteps, b0 = (idx - ri * nsteps) * 2;
+            const int row = r0 + wave + 4 * ri;
+            const int n = row / p.Ho, oy = row - n * p.Ho;
+            a[u] = p.db[((size_t)row * p.DB + b0 + h) * p.Cout + co];
+            const uint4* xr = p.xb + (((size_t)n * p.Hp + oy * p.sy) * p.XB + b0 + h) * CP + cp;
+#pragma unroll
+            for (int t = 0; t < KH; ++t) w[u][t] = xr[(size_t)t * p.XB * CP];            // padded row oy * sy + t
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = base + u < total;
+            const uint4 av = (co_ok && live) ? a[u] : zero;
+#pragma unroll
+            for (int t = 0; t < KH; ++t) {
+                const uint4 wv = cp_ok ? w[u][t] : zero;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, wv), acc[t], 0, 0, 0);
+            }
+        }
+    }
+    const int ntap = p.k * p.k;
+#pragma unroll
+    for (int t = 0; t < KH; ++t) {
+        if (t) __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (wave > 0) red[((wave - 1) * 16 + r) * 64 + lane] = acc[t][r];
+        __syncthreads();
+        if (wave == 0) {
+            const int tb = ql / p.Cin, c = ql - tb * p.Cin;             // pseudo-channel -> (tap column, channel)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[t][r] + red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane];
+                const int o = co0 + acc_row(r, lane);
+                if (o < p.Cout && ql < CP && v != 0.f) atomicAdd(p.dw + ((size_t)o * p.Cin + c) * ntap + t * p.k + tb, v);
             }
         }
     }
@@ -335,16 +420,26 @@ extern "C" int cobevt_conv_wgrad(const void* x, const void* dy, float* dw, const
 }
 
 extern "C" int cobevt_conv_wgrad_blocked(const void* xb, const void* db, float* dw, const int* dims, hipStream_t stream) {
-    // dims: [N, Hp, XB, Cin, Ho, DB, Cout, k]
+    // dims: [N, Hp, XB, Cin, Ho, DB, Cout, k, sy, mode]; mode 0: stride 1 (k = 1 / 3), 1: stride 2 column planes (k = 1: one plane, k = 3: two),
+    // 2: the k tap columns as planes = pseudo-channels (k * Cin <= 32, k <= 7)
     if (!xb || !db || !dw || !dims) return COBEVT_ERR_ARG;
     Wgrad16Params p;
     p.xb = (const uint4*)xb; p.db = (const uint4*)db; p.dw = dw;
     p.N = dims[0]; p.Hp = dims[1]; p.XB = dims[2]; p.Cin = dims[3]; p.Ho = dims[4]; p.DB = dims[5]; p.Cout = dims[6]; p.k = dims[7];
-    if (p.N < 1 || p.Cin < 1 || p.Ho < 1 || p.Cout < 1 || (p.k != 1 && p.k != 3)) return COBEVT_ERR_SHAPE;
-    // the blocked rows must hold what the loop reads: rows oy + ta <= Ho + k - 2, blocks b0 + h (+ 1 for k = 3) with b0 + 1 < DB + 1
-    if (p.DB < 2 || (p.DB & 1) || p.Hp < p.Ho + p.k - 1 || p.XB < p.DB + (p.k > 1 ? 1 : 0)) return COBEVT_ERR_SHAPE;
-    const int tiles_o = (p.Cout + 31) / 32, tiles_i = (p.Cin + 31) / 32;
-    const long per = (long)tiles_o * tiles_i * p.k;
+    p.sy = dims[8];
+    const int mode = dims[9];
+    if (mode < 0 || mode > 2) return COBEVT_ERR_ARG;
+    if (p.N < 1 || p.Cin < 1 || p.Ho < 1 || p.Cout < 1 || p.sy < 1 || p.k < 1) return COBEVT_ERR_SHAPE;
+    if (mode < 2 && p.k != 1 && p.k != 3) return COBEVT_ERR_SHAPE;
+    if (mode == 0 && p.sy != 1) return COBEVT_ERR_SHAPE;
+    if (mode == 2 && (p.k > 7 || p.k * p.Cin > 32)) return COBEVT_ERR_SHAPE;
+    p.P = mode == 0 ? 1 : (mode == 1 ? (p.k == 3 ? 2 : 1) : p.k);
+    // the blocked rows must hold what the loop reads: rows (Ho - 1) sy + k - 1, blocks b0 + h (+ 1 where a tap is a pixel shift) with b0 + 1 < DB + 1
+    const int shift_blk = (mode < 2 && p.k > 1) ? 1 : 0;
+    if (p.DB < 2 || (p.DB & 1) || p.Hp < (p.Ho - 1) * p.sy + p.k || p.XB < p.DB + shift_blk) return COBEVT_ERR_SHAPE;
+    const int tiles_o = (p.Cout + 31) / 32, tiles_i = mode == 2 ? 1 : (p.Cin + 31) / 32;
+    const int ky = mode == 2 ? 1 : p.k;                             // tap rows as separate workgroups (mode 2: as accumulators)
+    const long per = (long)tiles_o * tiles_i * ky;
     const int rows = p.N * p.Ho;
     // about COBEVT_WGRAD16_WGS workgroups, at least four rows each: every workgroup ends in 1024 x k fp32 atomics
 #ifndef COBEVT_WGRAD16_WGS
@@ -354,9 +449,22 @@ extern "C" int cobevt_conv_wgrad_blocked(const void* xb, const void* db, float* 
     if (chunks > rows / 4) chunks = rows / 4;
     if (chunks < 1) chunks = 1;
     p.nchunks = (int)chunks;
-    if (tiles_i * p.k > 65535 || chunks > 65535) return COBEVT_ERR_SHAPE;
-    const dim3 grid(tiles_o, tiles_i * p.k, (unsigned)chunks);
-    if (p.k == 3) hipLaunchKernelGGL(conv_wgrad16_kernel<3>, grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(conv_wgrad16_kernel<1>, grid, dim3(256), 0, stream, p);
+    if (tiles_i * ky > 65535 || chunks > 65535) return COBEVT_ERR_SHAPE;
+    const dim3 grid(tiles_o, tiles_i * ky, (unsigned)chunks);
+    if (mode == 2) {
+        switch (p.k) {
+            case 1: hipLaunchKernelGGL(conv_wgrad16_cols_kernel<1>, grid, dim3(256), 0, stream, p); break;
+            case 3: hipLaunchKernelGGL(conv_wgrad16_cols_kernel<3>, grid, dim3(256), 0, stream, p); break;
+            case 5: hipLaunchKernelGGL(conv_wgrad16_cols_kernel<5>, grid, dim3(256), 0, stream, p); break;
+            case 7: hipLaunchKernelGGL(conv_wgrad16_cols_kernel<7>, grid, dim3(256), 0, stream, p); break;
+            default: return COBEVT_ERR_UNSUPPORTED;
+        }
+    } else if (mode == 1) {
+        if (p.k == 3) hipLaunchKernelGGL((conv_wgrad16_kernel<3, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_wgrad16_kernel<1, true>), grid, dim3(256), 0, stream, p);
+    } else {
+        if (p.k == 3) hipLaunchKernelGGL((conv_wgrad16_kernel<3, false>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_wgrad16_kernel<1, false>), grid, dim3(256), 0, stream, p);
+    }
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

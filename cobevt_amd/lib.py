@@ -96,6 +96,8 @@ SIGNATURES = {
     "cobevt_pixel_unshuffle2_nhwc": (ctypes.c_int, [_vp, _vp] + [ctypes.c_int] * 6 + [_vp]),
     "cobevt_upsample_nearest2_nhwc": (ctypes.c_int, [_vp, _vp] + [ctypes.c_int] * 6 + [_vp]),
     "cobevt_sttf_warp_bwd": (ctypes.c_int, [_vp, _vp, _vp, _vp] + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_float, _vp]),
+    "cobevt_conv_weight_rows": (ctypes.c_int, [_vp, _vp, _vp, _c_int_p, _vp]),
+    "cobevt_wgrad_block_operand": (ctypes.c_int, [_vp, _vp, _c_int_p, _vp]),
     "cobevt_peer_window_alloc": (ctypes.c_int, [ctypes.c_long, ctypes.POINTER(_vp), _vp]),
     "cobevt_peer_window_open": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "cobevt_peer_window_close": (ctypes.c_int, [_vp]),

@@ -207,11 +207,14 @@ int cobevt_gelu(const float* x, const float* dy, float* out, long n, hipStream_t
  * stride, pad, storage type of x and dy (0 bf16 - the autocast path -, 1 fp32).  (cuDNN under autograd in the reference: every
  * nn.Conv2d on the path, train_camera.py:166-173.) */
 int cobevt_conv_wgrad(const void* x, const void* dy, float* dw, const int* dims, hipStream_t stream);
-/* The same weight gradient on the bf16 matrix path, for stride 1 and k = 1 or 3, from BLOCKED bf16 copies of the operands (8
- * pixels of one channel = one 16-byte piece, so a lane's matrix operand is one coalesced load and zero padding replaces every
- * bounds test): xb [N][Hp][XB][Cin][8] = x zero-padded by `pad` rows / columns (Hp >= Ho + k - 1 rows, XB >= DB + (k > 1) blocks
- * per row), db [N][Ho][DB][Cout][8] = dy with rows zero-padded to an even number DB of blocks; dw fp32 (Cout, Cin, k, k),
- * zero-initialised.  dims (int32[8]): N, Hp, XB, Cin, Ho, DB, Cout, k. */
+/* The same weight gradient on the bf16 matrix path from BLOCKED bf16 copies of the operands (8 pixels of one channel = one 16-byte
+ * piece, so a lane's matrix operand is one coalesced load and zero padding replaces every bounds test; cobevt_wgrad_block_operand
+ * makes them): xb [N][Hp][XB][P][Cin][8] = x zero-padded by `pad` rows / columns, db [N][Ho][DB][Cout][8] = dy with rows zero-padded
+ * to an even number DB of blocks; dw fp32 (Cout, Cin, k, k), zero-initialised.  Output row oy, tap row a reads padded row oy * sy + a
+ * (Hp >= (Ho - 1) sy + k).  mode 0: stride 1, k = 1 / 3, P = 1, the taps of a row are pixel shifts (XB >= DB + (k > 1));
+ * mode 1: stride 2 (sy = 2), k = 3 / pad 1 with P = 2 planes = even / odd padded columns (XB >= DB + 1), or k = 1 / pad 0 with the even
+ * columns only (P = 1); mode 2: the k tap columns as P = k planes, k * Cin <= 32, k odd <= 7 (the 7x7 / stride 2 stem on 3 channels:
+ * a tap row is one matrix instruction).  dims (int32[10]): N, Hp, XB, Cin, Ho, DB, Cout, k, sy, mode. */
 int cobevt_conv_wgrad_blocked(const void* xb, const void* db, float* dw, const int* dims, hipStream_t stream);
 
 /* out[b][i] = max over l of in[b][l][i] (F-Cooper max-out fusion over the max_cav agent slots, SpatialFusionMask,
@@ -501,6 +504,20 @@ int cobevt_upsample_nearest2_nhwc(const void* in, void* out, int dtype, int N, i
  * dx (agents, H, W, C) fp32 (zeroed by the caller), scattered through the same sample positions; record_len as there. */
 int cobevt_sttf_warp_bwd(const float* dout, const float* tmat, const int* record_len, float* dx, int B, int L, int H, int W, int C,
                          float discrete_ratio, float downsample_rate, hipStream_t stream);
+
+/* Operand preparation of the training convolutions (what cuDNN does internally for the reference's nn.Conv2d / nn.Linear under
+ * train_camera.py:143-179; csrc/train_prep.hip).  cobevt_conv_weight_rows: fp32 master weight (Cout, Cin, kh, kw) -> the weight rows
+ * cobevt_conv2d_nhwc reads, in the compute type dims[0] (0 bf16, 1 fp32): rows_fwd [Cout][Kpad_fwd] with k = (r * kw + s) * Cin + c,
+ * rows_dgrad [Cin][Kpad_dgrad] with k = (r * kw + s) * Cout + o of w[o][c][kh-1-r][kw-1-s] (the input gradient = the same
+ * convolution, taps flipped, channel roles swapped); columns past K are zero; either output may be null.
+ * dims: [dtype, Cout, Cin, kh, kw, Kpad_fwd, Kpad_dgrad]. */
+int cobevt_conv_weight_rows(const float* w, void* rows_fwd, void* rows_dgrad, const int* dims, hipStream_t stream);
+/* bf16 channels-last map (N, H, W, C) -> the blocked operand of cobevt_conv_wgrad_blocked, dst [N][Hp][NB][C][8]: pixel x of input
+ * row y sits in block (x + pad_left) / 8 of row y + pad_top; everything else is zero.  In general dst is [N][Hp][NB][P][C][8] and slot j
+ * of plane q of block b holds input pixel sx (8 b + j) + q - pad_left (P = 1, sx = 1 above; P = 2, sx = 2: even / odd columns of a
+ * stride-2 convolution; P = k, sx = stride: the k tap columns of a tap row as planes).
+ * dims: [N, H, W, C, Hp, NB, pad_top, pad_left, P, sx]. */
+int cobevt_wgrad_block_operand(const void* src, void* dst, const int* dims, hipStream_t stream);
 
 /* ---- multi-GPU: the V2V feature-sharing step in front of FuseBEVT.  The reference keeps all agents in one
  * process (opv2v/opencood/models/corpbevt.py:112-124, sub_modules/fuse_utils.py:8-61: agents are a batch dimension up to

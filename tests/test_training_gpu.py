@@ -783,3 +783,36 @@ def test_naive_compressor_trains(cuda):
     for k, v in comp.state_dict().items():
         if "running" in k:
             assert_close(v, state[k], 1e-5, k)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cout,cin,k", [(128, 64, 3), (64, 3, 7), (2, 130, 1), (24, 40, 3), (32, 128, 1)])
+def test_conv_weight_rows_kernel_matches_torch_specification(cuda, dtype, cout, cin, k):
+    """cobevt_conv_weight_rows (one launch per convolution and step: fp32 master weight -> forward rows AND flipped / transposed
+    input-gradient rows in the compute type) is bit-identical to the torch-op construction it replaces (cast, permute, pad, flip,
+    transpose, contiguous: autograd._weight_rows), incl. K not a multiple of the k-tile (zero columns) and the 3- / 2-channel ends"""
+    g = torch.Generator().manual_seed(cout * 131 + cin)
+    w = torch.randn(cout, cin, k, k, generator=g).to(cuda)
+    rf, rd = ag.conv_weight_rows(w, dtype, True, True)
+    wd = w.to(dtype)
+    sf, sd = ag._weight_rows(wd)[0], ag._weight_rows(wd.flip(2, 3).transpose(0, 1))[0]
+    assert rf.shape == sf.shape and rd.shape == sd.shape and rf.dtype == dtype
+    assert torch.equal(rf, sf) and torch.equal(rd, sd)
+    only_f = ag.conv_weight_rows(w, dtype, True, False)
+    assert only_f[1] is None and torch.equal(only_f[0], sf)
+
+
+@pytest.mark.parametrize("k,pad,n,cin,cout,h,w", [(3, 1, 2, 64, 128, 6, 11), (1, 0, 1, 8, 16, 4, 16), (3, 1, 2, 5, 2, 7, 21), (1, 0, 3, 12, 24, 5, 9),
+                                                  (3, 1, 1, 128, 32, 32, 32)])
+def test_wgrad_block_operand_kernel_matches_torch_specification(cuda, k, pad, n, cin, cout, h, w):
+    """cobevt_wgrad_block_operand (pad + 8 x 8 transpose in one launch per operand) is bit-identical to autograd._blocked_operands, the
+    torch construction tests/test_weight_layouts.py pins against conv2d autograd: widths off the 8-pixel block, channel counts on
+    (16-byte path) and off (per-channel path) the 8-channel group, 3x3 / pad 1 and 1x1 / pad 0"""
+    g = torch.Generator().manual_seed(k * 17 + w)
+    xl = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16).to(cuda)
+    dyl = torch.randn(n, h + 2 * pad - k + 1, w + 2 * pad - k + 1, cout, generator=g).to(torch.bfloat16).to(cuda)
+    got = ag.blocked_operands(xl, dyl, k, pad)
+    ref = ag._blocked_operands(xl, dyl, k, pad)
+    assert got[2:] == ref[2:]
+    assert got[0].shape == ref[0].shape and got[1].shape == ref[1].shape
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])

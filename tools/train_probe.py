@@ -124,6 +124,11 @@ def corpbevt_step(agents):
 
 def main():
     out = {"attention": [], "encoder": [], "model": []}
+    if os.environ.get("PROBE_ONLY") == "model":            # same-job A/B runs: only the whole-model steps
+        for agents in (2, 5):
+            out["model"].append(corpbevt_step(agents))
+        print(json.dumps(out, indent=1))
+        return
     out["attention"].append(attention_pair("fusion window 5 agents 32x32 w8", 0, 5, 32, 32, 8, 4, 1, True, True))
     out["attention"].append(attention_pair("fusion grid 5 agents 32x32 w8", 1, 5, 32, 32, 8, 4, 1, True, True))
     out["attention"].append(attention_pair("LiDAR window 8 agents 256x256 w8", 0, 8, 256, 256, 8, 2, 1, True, True))
