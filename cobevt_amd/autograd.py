@@ -237,9 +237,14 @@ def linear(x, lin):
     """nn.Linear container on (..., K) rows.  A dense projection is a 1 x 1 convolution over a (1, rows, 1, K) channels-last map:
     forward and input gradient on the implicit-GEMM kernel (csrc/igemm.hip), weight gradient on cobevt_conv_wgrad (a GEMM over the
     rows), bias gradient a column sum - no vendor GEMM (VERDICT r02 #6; train_camera.py:143-179 runs these through cuBLAS)."""
+    return linear_weight(x, lin.weight, lin.bias)
+
+
+def linear_weight(x, weight, bias=None):
+    """linear() on a (out, K) weight tensor (a parameter, or a differentiable function of one - a reshaped / zero-padded 1 x 1 conv weight)"""
     _need_cuda(x)
-    if USE_LIBRARY_GEMM or x.shape[-1] % 4 or lin.weight.shape[0] % 4:
-        return torch.nn.functional.linear(x, lin.weight, lin.bias)
+    if USE_LIBRARY_GEMM or x.shape[-1] % 4 or weight.shape[0] % 4:
+        return torch.nn.functional.linear(x, weight, bias)
     k = x.shape[-1]
     rows = x.numel() // k
     # any (H, W) factorisation of the rows is the same 1 x 1 convolution; the blocked weight-gradient kernel walks 16-pixel blocks of
@@ -251,13 +256,13 @@ def linear(x, lin):
             mh, mw = rows // cand, cand
             break
     x4 = x.reshape(1, mh, mw, k).permute(0, 3, 1, 2)                   # (1, K, H, W)-shaped view of channels-last memory
-    w4 = _master(lin.weight)[:, :, None, None]
+    w4 = _master(weight)[:, :, None, None]
     if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
         with torch.autocast("cuda", enabled=False):
-            y = Conv2dFn.apply(x4.to(torch.bfloat16), w4, lin.bias, 1, 0)
+            y = Conv2dFn.apply(x4.to(torch.bfloat16), w4, bias, 1, 0)
     else:
-        y = Conv2dFn.apply(x4, w4, lin.bias, 1, 0)
-    return y.permute(0, 2, 3, 1).reshape(x.shape[:-1] + (lin.weight.shape[0],))
+        y = Conv2dFn.apply(x4, w4, bias, 1, 0)
+    return y.permute(0, 2, 3, 1).reshape(x.shape[:-1] + (weight.shape[0],))
 
 
 def _master(weight):
@@ -541,10 +546,10 @@ class BatchNormActFn(torch.autograd.Function):
         _L.check(lib.cobevt_bn_finalize(_p(sums[0]) if training else None, _p(sums[1]) if training else None, _p(g), _p(b),
                                         _p(bn.running_mean) if track else None, _p(bn.running_var) if track else None,
                                         _p(scale), _p(shift), _p(mean), _p(rstd), c, rows, ctypes.c_float(bn.eps),
-                                        ctypes.c_float(momentum), int(training), int(bool(training and track)), _stream()),
+                                        ctypes.c_float(momentum), int(training), int(bool(training and track)),
+                                        _p(bn.num_batches_tracked) if (training and track and bn.num_batches_tracked is not None) else None,
+                                        _stream()),
                  "cobevt_bn_finalize")
-        if training and track and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
         y = torch.empty_like(xl)
         _L.check(lib.cobevt_bn_apply(_p(xl), _p(rl), _p(scale), _p(shift), _p(y), dt, rows, c, int(act), _stream()), "cobevt_bn_apply")
         ctx.save_for_backward(xl, y if act else None, mean, rstd, g)

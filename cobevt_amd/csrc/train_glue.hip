@@ -92,9 +92,10 @@ __global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const doub
 // saved for backward, running statistics updated in place (momentum, unbiased variance) as nn.BatchNorm2d does
 __global__ void bn_finalize_kernel(const double* sum, const double* sumsq, const float* gamma, const float* beta, float* running_mean,
                                    float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out, int C,
-                                   double rows, float eps, float momentum, int training, int shifted) {
+                                   double rows, float eps, float momentum, int training, int shifted, long long* batches_tracked) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (c == 0 && batches_tracked) *batches_tracked += 1;          // nn.BatchNorm2d.num_batches_tracked (one launch less per BatchNorm)
     double mean, var;
     if (training) {
         // the sums were taken of x - running_mean (shifted != 0: channel_sums with shift = running_mean, read BEFORE its update below)
@@ -455,12 +456,13 @@ extern "C" int cobevt_f64_to_f32(const double* in, float* out, int n, hipStream_
 
 extern "C" int cobevt_bn_finalize(const double* sum, const double* sumsq, const float* gamma, const float* beta, float* running_mean,
                                   float* running_var, float* scale, float* shift, float* mean, float* rstd, int C, long rows,
-                                  float eps, float momentum, int training, int shifted, hipStream_t stream) {
+                                  float eps, float momentum, int training, int shifted, long long* batches_tracked,
+                                  hipStream_t stream) {
     if (!scale || !shift || !mean || !rstd || C < 1 || rows < 1) return COBEVT_ERR_ARG;
     if (training ? (!sum || !sumsq) : (!running_mean || !running_var)) return COBEVT_ERR_ARG;
     if (shifted && !running_mean) return COBEVT_ERR_ARG;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sum, sumsq, gamma, beta, running_mean, running_var,
-                       scale, shift, mean, rstd, C, (double)rows, eps, momentum, training, shifted);
+                       scale, shift, mean, rstd, C, (double)rows, eps, momentum, training, shifted, batches_tracked);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 

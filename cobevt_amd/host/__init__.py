@@ -28,3 +28,4 @@ from .intermediate_fusion_dataset import collate_batch  # noqa: F401
 from .train_utils import load_saved_model  # noqa: F401
 from .seg_utils import cal_iou_training, mean_IU, mean_precision  # noqa: F401
 from .vanilla_seg_loss import VanillaSegLoss  # noqa: F401
+from .train_graph import CapturedTrainStep  # noqa: F401

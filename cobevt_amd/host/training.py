@@ -143,9 +143,10 @@ def _pre_act_conv1x1(seq, x):
 
 def cross_view_swap_attention(m, index, x, bev, feature, I_inv, E_inv):
     """CrossViewSwapAttention.forward (fax_modules.py:323-441) as a differentiable graph: x (b d H W), feature (b n C h w),
-    I_inv (b n 3 3), E_inv (b n 4 4) -> (b d H W).  The camera-geometry embeddings and the BN -> ReLU -> 1x1 projections are
-    small library ops; both cross attentions (gathered window / grid attention), the LayerNorms and the GELUs are the HIP
-    kernels with their HIP backward."""
+    I_inv (b n 3 3), E_inv (b n 4 4) -> (b d H W).  The camera-geometry embeddings (1 x 1 convolutions of 2 / 4 channels) and the
+    BN -> ReLU -> 1x1 projections run the training convolution kernels; both cross attentions (gathered window / grid attention), the
+    LayerNorms and the GELUs are the HIP kernels with their HIP backward; what is left to torch is elementwise (the L2 normalisation,
+    the 3x3 / 4x4 camera-matrix products as broadcast multiply-adds, residual adds)."""
     _check(x, feature, I_inv, E_inv)
     F = torch.nn.functional
     b, n, _, h, w = feature.shape
@@ -154,13 +155,22 @@ def cross_view_swap_attention(m, index, x, bev, feature, I_inv, E_inv):
     w1, w2 = m.feat_win_size
     pixel = m.image_plane.reshape(1, 1, 3, h * w)
     c = E_inv[..., -1:]
-    # the 2- / 4-channel geometry embeddings are 1x1 convolutions = tiny matrix products over the channel axis (library GEMMs)
+    # the 2- / 4-channel geometry embeddings are 1x1 convolutions over the channel axis: the package's own implicit-GEMM kernel (forward, input
+    # gradient) and weight-gradient kernel through ag.linear - K = 4 is one 16-byte fp32 chunk, the 2-channel BEV grid is zero-padded to 4.
+    # The 3x3 / 4x4 camera-matrix products in front of them are broadcast multiply-adds (no trainable operand, no library GEMM).
     def pointwise(t, conv):
-        y = torch.einsum("nchw,oc->nohw", t, conv.weight.reshape(conv.weight.shape[0], -1))
-        return y if conv.bias is None else y + conv.bias[None, :, None, None]
+        k = t.shape[1]
+        rows = t.permute(0, 2, 3, 1).float()                                            # (N, h, w, k) channels-last rows
+        w2 = conv.weight.reshape(conv.weight.shape[0], k)
+        if k % 4:
+            rows, w2 = F.pad(rows, (0, 4 - k % 4)), F.pad(w2, (0, 4 - k % 4))
+        y = ag.linear_weight(rows, w2, conv.bias)
+        return y.permute(0, 3, 1, 2)
+    def matmul_small(a, bmat):                                                          # (..., r, k) @ (..., k, m) with k <= 4
+        return (a[..., :, :, None] * bmat[..., None, :, :]).sum(-2)
     c_embed = pointwise(c.reshape(b * n, 4, 1, 1), m.cam_embed)                         # (bn) d 1 1
-    cam = F.pad(I_inv @ pixel, (0, 0, 0, 1), value=1)                                   # b n 4 hw
-    dd = (E_inv @ cam).reshape(b * n, 4, h, w)
+    cam = F.pad(matmul_small(I_inv, pixel), (0, 0, 0, 1), value=1)                      # b n 4 hw
+    dd = matmul_small(E_inv, cam).reshape(b * n, 4, h, w)
     img_embed = pointwise(dd, m.img_embed) - c_embed
     img_embed = img_embed / (img_embed.norm(dim=1, keepdim=True) + 1e-7)
     if m.bev_embed_flag:

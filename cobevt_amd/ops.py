@@ -1223,6 +1223,30 @@ def channel_gate(x, gate):
 _DEFERRED_LABELS = []
 
 
+_LABEL_RING = 32
+
+
+def _label_word(c):
+    """The next pinned host word of a ring of _LABEL_RING (entries of _DEFERRED_LABELS are reused round-robin; _check_deferred_labels has
+    just read them all).  Pinned memory cannot be allocated while the stream is being captured into a HIP graph: the ring is filled by
+    the eager calls before a capture (CapturedTrainStep's warm-up steps); a capture that finds it short skips the copy (None)."""
+    global _LABEL_NEXT
+    if len(_DEFERRED_LABELS) < _LABEL_RING:
+        if torch.cuda.is_current_stream_capturing():
+            if not _DEFERRED_LABELS:
+                return None
+        else:
+            _DEFERRED_LABELS.append([torch.zeros(1, dtype=torch.float32).pin_memory(), c])
+            return _DEFERRED_LABELS[-1][0]
+    _LABEL_NEXT = (_LABEL_NEXT + 1) % len(_DEFERRED_LABELS)
+    ent = _DEFERRED_LABELS[_LABEL_NEXT]
+    ent[1] = c
+    return ent[0]
+
+
+_LABEL_NEXT = -1
+
+
 def _check_deferred_labels():
     for word, c in _DEFERRED_LABELS:
         bad = int(word[0])
@@ -1258,10 +1282,9 @@ def weighted_cross_entropy(logits, target, weight, want_stats=False):
     # host word behind the kernel and inspected by the following calls (and by check_deferred_label_errors()), so a bad label
     # raises one call late - identically in eager steps and in steps replayed from a captured HIP graph (the copy is a graph node)
     _check_deferred_labels()
-    host_word = torch.zeros(1, dtype=torch.float32).pin_memory()
-    host_word.copy_(out[3:4], non_blocking=True)
-    _DEFERRED_LABELS.append((host_word, c))
-    del _DEFERRED_LABELS[:-8]
+    host_word = _label_word(c)
+    if host_word is not None:
+        host_word.copy_(out[3:4], non_blocking=True)
     return (out[0], out, x, y, wt) if want_stats else out[0]
 
 

@@ -479,10 +479,11 @@ int cobevt_channel_sums(const void* x, const float* shift, double* sum, double* 
 int cobevt_f64_to_f32(const double* in, float* out, int n, hipStream_t stream);
 /* nn.BatchNorm2d statistics -> per-channel scale / shift (scale = gamma rstd, shift = beta - mean scale), mean / rstd for backward.
  * training != 0: batch statistics from the sums (shifted != 0: they were taken of x - running_mean), running_mean / running_var
- * (nullable) updated in place with `momentum` and the unbiased variance; training == 0: the frozen running statistics. */
+ * (nullable) updated in place with `momentum` and the unbiased variance; training == 0: the frozen running statistics.
+ * batches_tracked (nullable): the module's int64 num_batches_tracked word, incremented by one. */
 int cobevt_bn_finalize(const double* sum, const double* sumsq, const float* gamma, const float* beta, float* running_mean,
                        float* running_var, float* scale, float* shift, float* mean, float* rstd, int C, long rows, float eps,
-                       float momentum, int training, int shifted, hipStream_t stream);
+                       float momentum, int training, int shifted, long long* batches_tracked, hipStream_t stream);
 /* y = act(x * scale[c] + shift[c] (+ residual)), act 0 none / 1 ReLU. */
 int cobevt_bn_apply(const void* x, const void* residual, const float* scale, const float* shift, void* y, int dtype, long rows,
                     int C, int act, hipStream_t stream);

@@ -814,5 +814,80 @@ def test_wgrad_block_operand_kernel_matches_torch_specification(cuda, k, pad, n,
     got = ag.blocked_operands(xl, dyl, k, pad)
     ref = ag._blocked_operands(xl, dyl, k, pad)
     assert got[2:] == ref[2:]
-    assert got[0].shape == ref[0].shape and got[1].shape == ref[1].shape
-    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    # the kernel's layout carries a plane axis ([n][row][block][plane][c][8]); one plane for a stride-1 convolution
+    assert got[0].shape[3] == 1 and got[1].shape[3] == 1
+    assert torch.equal(got[0].squeeze(3), ref[0]) and torch.equal(got[1].squeeze(3), ref[1])
+
+
+@pytest.mark.parametrize("k,stride,pad,n,cin,h,w", [(3, 2, 1, 2, 64, 9, 13), (1, 2, 0, 1, 16, 8, 15), (7, 2, 3, 2, 3, 12, 18), (3, 2, 1, 1, 24, 16, 32),
+                                                    (3, 2, 1, 2, 128, 64, 64)])
+def test_strided_wgrad_block_operand_kernel_matches_specification(cuda, k, stride, pad, n, cin, h, w):
+    """cobevt_wgrad_block_operand with planes / a pixel stride (the stride-2 and stem forms of cobevt_conv_wgrad_blocked) is bit-identical to
+    autograd._blocked_x_general, which tests/test_weight_layouts.py::test_strided_blocked_weight_gradient_operands pins against conv2d autograd"""
+    g = torch.Generator().manual_seed(k * 31 + w)
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    xl = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16).to(cuda)
+    dyl = torch.randn(n, ho, wo, 8, generator=g).to(torch.bfloat16).to(cuda)
+    mode = ag.wgrad_blocked_mode(k, stride, pad, cin)
+    xb, db, hp, nxb, ndb = ag.blocked_operands(xl, dyl, k, pad, stride, mode)
+    _, _, _, planes, sx = ag._blocked_geometry(h, w, ho, wo, k, pad, stride, mode)
+    assert torch.equal(xb, ag._blocked_x_general(xl, hp, nxb, pad, planes, sx))
+    assert torch.equal(db, ag._blocked_x_general(dyl, ho, ndb, 0, 1, 1))
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_captured_train_step_follows_eager(cuda, amp):
+    """host.CapturedTrainStep (train_camera.py:143-179 - zero_grad, forward, criterion, backward, optimizer.step - as ONE replayed HIP graph)
+    against the same steps run eagerly from the same initial state, on two alternating batches: per-step losses, the accumulated parameter
+    update, BatchNorm running statistics and num_batches_tracked.  Same kernels on the same data; what differs is the order of the fp32
+    atomics in the weight gradients and the occasional ReLU flip that follows from it, so the update is compared in the rms
+    norm (2e-2 of the update's rms; measured ~1e-3) and the losses to 2e-3."""
+    import copy
+    cfg = synth.corpbevt_small_config()
+    cfg["fax"]["self_attn"]["dropout"] = 0.0          # the eager step draws its masks from host seeds, the replay from the device word
+    cfg["fax_fusion"]["drop_out"] = 0.0
+    batches = [{k: v.to(cuda) for k, v in synth.opv2v_batch(agents=2, cams=2, image=128, max_cav=3, seed=s).items()} for s in (3, 4)]
+    crit = host.VanillaSegLoss({"d_weights": 75.0, "s_weights": 15.0, "l_weights": 50, "d_coe": 2.0, "s_coe": 0.0, "target": "dynamic"})
+    models = [_train_module(host.CorpBEVT(copy.deepcopy(cfg)), cuda) for _ in range(2)]
+    with torch.no_grad():
+        shp = models[0].eval()(dict(batches[0]))["dynamic_seg"].shape
+    models[0].train()
+    for i, b in enumerate(batches):
+        g = torch.Generator().manual_seed(50 + i)
+        b["gt_dynamic"] = (torch.rand(shp[:2] + shp[3:], generator=g) > 0.8).long().to(cuda)
+        b["gt_static"] = torch.zeros(shp[:2] + shp[3:], dtype=torch.long, device=cuda)
+    init = {k: v.detach().clone() for k, v in models[0].state_dict().items()}
+    opts = [torch.optim.SGD(m.parameters(), lr=1e-2, momentum=0.9) for m in models]
+    dt = torch.bfloat16 if amp else None
+    steps = 4
+    eager_losses = []
+    for i in range(steps):
+        opts[0].zero_grad(set_to_none=True)
+        with torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            loss = crit(models[0](dict(batches[i % 2])), batches[i % 2])
+        loss.backward()
+        opts[0].step()
+        eager_losses.append(float(loss.detach()))
+    cap = host.CapturedTrainStep(models[1], lambda o, b: crit(o, b), opts[1], batches[0], autocast_dtype=dt)
+    # the warm-up steps inside the constructor must not leave a trace in the model
+    for k, v in models[1].state_dict().items():
+        assert torch.equal(v, init[k]), "state %s changed by the capture" % k
+    cap_losses = [float(cap.step(batches[i % 2])) for i in range(steps)]
+    for a, b in zip(eager_losses, cap_losses):
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (eager_losses, cap_losses)
+    assert cap_losses[-1] < cap_losses[0]
+    se, sc = models[0].state_dict(), models[1].state_dict()
+    num = den = 0.0
+    for k in se:
+        if k.endswith("num_batches_tracked"):
+            assert int(se[k]) == int(sc[k]) == int(init[k]) + steps, k
+            continue
+        de, dc = (se[k] - init[k]).double(), (sc[k] - init[k]).double()
+        num += float(((de - dc) ** 2).sum())
+        den += float((de ** 2).sum())
+    assert den > 0 and (num / den) ** 0.5 <= 2e-2, (num / den) ** 0.5
+    # a batch of another shape is refused, not silently mis-replayed
+    bad = dict(batches[0])
+    bad["inputs"] = bad["inputs"][:1]
+    with pytest.raises(CobevtHipError):
+        cap.step(bad)

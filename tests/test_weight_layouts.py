@@ -211,3 +211,49 @@ def test_blocked_weight_gradient_operands():
                 win = xrow[:, a:a + ho, :, b:b + npx]                           # x pixel ox + b of padded row oy + a
                 dw[:, :, a, b] = torch.einsum("nyop,nycp->oc", drow, win)
         assert torch.allclose(dw, wt.grad, atol=1e-4), (k, (dw - wt.grad).abs().max())
+
+
+def test_strided_blocked_weight_gradient_operands():
+    """The stride-2 and stem forms of cobevt_conv_wgrad_blocked (modes 1 / 2): the operand layout autograd._blocked_x_general specifies
+    ([n][row][block][plane][channel][8]; slot j of plane q of block b = padded input pixel sx (8 b + j) + q - pad), evaluated on the CPU
+    exactly as the kernels index it, against torch's conv2d autograd:
+      mode 1, 3x3 / stride 2 / pad 1: tap column 0 = plane 0 pixel ox, 1 = plane 1 pixel ox, 2 = plane 0 pixel ox + 1; tap row a = padded row 2 oy + a
+      mode 1, 1x1 / stride 2 / pad 0: one plane (the even columns), row 2 oy
+      mode 2, 7x7 / stride 2 / pad 3 on 3 channels: tap column b = plane b, pixel ox; tap row a = padded row 2 oy + a"""
+    import torch.nn.functional as F
+    from cobevt_amd import autograd as ag
+    g = torch.Generator().manual_seed(9)
+    for k, stride, pad, (n, cin, cout, h, w) in ((3, 2, 1, (2, 5, 4, 9, 13)), (1, 2, 0, (1, 6, 3, 8, 15)), (7, 2, 3, (2, 3, 5, 12, 18)),
+                                                 (3, 2, 1, (1, 8, 8, 16, 32))):
+        mode = ag.wgrad_blocked_mode(k, stride, pad, cin)
+        assert mode == (2 if k == 7 else 1)
+        x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+        wt = torch.randn(cout, cin, k, k, generator=g, requires_grad=True)
+        with torch.enable_grad():
+            y = F.conv2d(x, wt, stride=stride, padding=pad)
+            dy = torch.randn(y.shape, generator=g)
+            (y * dy).sum().backward()
+        xl, dyl = x.detach().permute(0, 2, 3, 1).contiguous(), dy.permute(0, 2, 3, 1).contiguous()
+        ho, wo = dyl.shape[1:3]
+        ndb, nxb, hp, planes, sx = ag._blocked_geometry(h, w, ho, wo, k, pad, stride, mode)
+        assert ndb % 2 == 0 and hp >= (ho - 1) * stride + k and nxb >= ndb + (1 if (mode == 1 and k == 3) else 0)
+        xb = ag._blocked_x_general(xl, hp, nxb, pad, planes, sx)             # [n][hp][nxb][planes][cin][8]
+        db = ag._blocked_x_general(dyl, ho, ndb, 0, 1, 1)                    # [n][ho][ndb][1][cout][8]
+        assert xb.shape == (n, hp, nxb, planes, cin, 8) and db.shape == (n, ho, ndb, 1, cout, 8)
+        xrow = xb.permute(0, 1, 3, 4, 2, 5).reshape(n, hp, planes, cin, nxb * 8)      # [n][padded row][plane][c][pixel slot]
+        drow = db[:, :, :, 0].permute(0, 1, 3, 2, 4).reshape(n, ho, cout, ndb * 8)     # [n][oy][o][pixel]
+        assert not drow[..., wo:].any()
+        npx = ndb * 8
+        rows = torch.arange(ho) * stride
+        dw = torch.zeros(cout, cin, k, k)
+        for a in range(k):
+            xr = xrow[:, rows + a]                                                      # padded row oy * stride + a
+            for b in range(k):
+                if mode == 2:
+                    win = xr[:, :, b, :, :npx]
+                elif k == 1:
+                    win = xr[:, :, 0, :, :npx]
+                else:
+                    win = xr[:, :, b & 1, :, (b >> 1):(b >> 1) + npx]
+                dw[:, :, a, b] = torch.einsum("nyop,nycp->oc", drow, win)
+        assert torch.allclose(dw, wt.grad, atol=2e-4), (k, stride, (dw - wt.grad).abs().max())
