@@ -48,22 +48,28 @@ def _rows_view(t, what):
     return t.stride(0)
 
 
+_LN2 = 0.6931471805599453
+
+
 class WindowAttentionFn(torch.autograd.Function):
     """out = softmax(scale q k^T + bias[rel(q, k)] + mask) v over the gathered windows (cobevt_window_attention_lse /
     cobevt_window_attention_bwd).  q (Rq, d), k, v (Rk, d) token matrices (views with a row stride are accepted), bias_table
     (rows, heads) | None, mask fp32 | None (no gradient).  cfg = (qmap, kmap, omap, batch, heads, scale, bias_L, out_rows,
-    drop_p, drop_seed, seed_dev): drop_p > 0 = dropout on the probabilities with the keep mask hashed from drop_seed (+ the device
-    word seed_dev, see dropout_step)."""
+    drop_p, drop_seed, seed_dev, want_lse): drop_p > 0 = dropout on the probabilities with the keep mask hashed from drop_seed (+ the
+    device word seed_dev, see dropout_step); want_lse: also return the natural log-sum-exp of every query's logits, (batch, windows,
+    heads, Nq), as a DIFFERENTIABLE output (its gradient enters the backward kernels as D - dlse)."""
 
     @staticmethod
     @_amp_fwd
     def forward(ctx, q, k, v, bias_table, mask, cfg):
-        qmap, kmap, omap, batch, heads, scale, bias_L, out_rows, drop_p, drop_seed, seed_dev = cfg
+        qmap, kmap, omap, batch, heads, scale, bias_L, out_rows, drop_p, drop_seed, seed_dev, want_lse = cfg
         _need_cuda(q, k, v, bias_table, mask)
         ldq, ldk, ldv = _rows_view(q, "q"), _rows_view(k, "k"), _rows_view(v, "v")
         d = heads * 32
         if q.shape[1] != d or k.shape[1] != d or v.shape[1] != d:
             raise CobevtHipError("window attention: token width must be heads * 32")
+        if want_lse and drop_p > 0:
+            raise CobevtHipError("window attention: the log-sum-exp output is not available with probability dropout")
         table = None if bias_table is None else _f32c(bias_table, "bias_table")
         mk = None if mask is None else _f32c(mask, "mask")
         L = qmap[6] * qmap[7]
@@ -77,15 +83,16 @@ class WindowAttentionFn(torch.autograd.Function):
         _L.check(rc, "cobevt_window_attention_lse")
         ctx.save_for_backward(q, k, v, out, lse, table, mk)
         ctx.cfg = cfg
-        return out
+        return (out, lse * _LN2) if want_lse else out
 
     @staticmethod
     @_amp_bwd
-    def backward(ctx, dout):
+    def backward(ctx, dout, dlse=None):
         q, k, v, out, lse, table, mk = ctx.saved_tensors
-        qmap, kmap, omap, batch, heads, scale, bias_L, _, drop_p, drop_seed, seed_dev = ctx.cfg
+        qmap, kmap, omap, batch, heads, scale, bias_L, _, drop_p, drop_seed, seed_dev, want_lse = ctx.cfg
         d = heads * 32
         dout = _f32c(dout, "dout")
+        dl = _f32c(dlse, "dlse") if (want_lse and dlse is not None) else None
         # dq is accumulated with atomics by the key tiles of a window; dk / dv rows are written once each
         dq = torch.zeros((q.shape[0], d), device=q.device, dtype=torch.float32)
         dk = torch.zeros((k.shape[0], d), device=q.device, dtype=torch.float32)
@@ -97,7 +104,7 @@ class WindowAttentionFn(torch.autograd.Function):
         if q.stride(0) != d or k.stride(0) != d or v.stride(0) != d:
             q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
             dims = _attn_dims(batch, heads, d, d, d, d, table, bias_L, qmap, kmap, omap)
-        rc = _L.load().cobevt_window_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), _p(dq), _p(dk), _p(dv),
+        rc = _L.load().cobevt_window_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), _p(dl), _p(dq), _p(dk), _p(dv),
                                                    _p(dbias), _p(table), _p(mk), dims, ctypes.c_float(scale), ctypes.c_float(drop_p),
                                                    ctypes.c_uint(drop_seed), _p(seed_dev), _stream())
         _L.check(rc, "cobevt_window_attention_bwd")
@@ -118,7 +125,7 @@ def dropout_step(device):
 
 
 def window_attention(q, k, v, qmap, kmap, omap, batch, heads, scale, out_rows, bias_table=None, bias_L=1, mask=None, drop_p=0.0,
-                     drop_seed=None):
+                     drop_seed=None, return_lse=False):
     """drop_p > 0: dropout on the attention probabilities.  drop_seed None draws a host seed from torch's CPU generator (so
     torch.manual_seed makes a run repeatable, and no device round trip is needed) and adds the device word dropout_step();
     an explicit drop_seed is used as it is (tests: attention_dropout_mask reproduces the mask)"""
@@ -127,7 +134,7 @@ def window_attention(q, k, v, qmap, kmap, omap, batch, heads, scale, out_rows, b
         drop_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
         seed_dev = dropout_step(q.device)
     cfg = (tuple(qmap), tuple(kmap), tuple(omap), int(batch), int(heads), float(scale), int(bias_L), int(out_rows),
-           float(drop_p), int(drop_seed or 0), seed_dev)
+           float(drop_p), int(drop_seed or 0), seed_dev, bool(return_lse))
     return WindowAttentionFn.apply(q, k, v, bias_table, mask, cfg)
 
 

@@ -32,6 +32,9 @@ struct AttnBwdParams {
     float* dk;
     float* dv;
     float* dbias;             // [bias_rows][heads], zero-initialised by the caller (nullable without bias)
+    const float* dlse;        // nullable: gradient w.r.t. the NATURAL log-sum-exp of every query's logits, [B][L][heads][Nq] (an output of
+                              // the forward that a caller combines further - the per-camera attentions of CVT's CrossAttention are merged
+                              // by a softmax over their lse, cvt_modules.py:142-153).  d lse / d logit = P, so it enters as D - dlse.
     int nsplit;               // attn_bwd_kv_kernel: workgroups that share the windows of one (head, key tile position)
 };
 
@@ -130,9 +133,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnBwdParams bp) {
                 }
                 dsum += __shfl_xor(dsum, 1, 64);
                 if (half == 0) {
-                    D_s[r] = dsum;
+                    const size_t li = (((size_t)b * p.L + l) * p.heads + head) * p.Nq + (ok ? tq : 0);
+                    D_s[r] = dsum - ((bp.dlse && ok) ? bp.dlse[li] : 0.f);
                     // invalid rows: lse = +inf -> P = exp2(-inf) = 0
-                    lse_s[r] = ok ? p.lse[(((size_t)b * p.L + l) * p.heads + head) * p.Nq + tq] : INFINITY;
+                    lse_s[r] = ok ? p.lse[li] : INFINITY;
                     qb_s[r] = BIAS ? rel_bias_query_term(p.kmap, p.bias_L, qc) : 0;
                 }
             }
@@ -249,7 +253,9 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnBwdParams bp) {
         }
         Dq += __shfl_xor(Dq, 32, 64);
     }
-    const float lse_q = q_ok ? p.lse[(((size_t)b * p.L + l) * p.heads + head) * p.Nq + tq] : INFINITY;
+    const size_t lse_i = (((size_t)b * p.L + l) * p.heads + head) * p.Nq + (q_ok ? tq : 0);
+    if (bp.dlse && q_ok) Dq -= bp.dlse[lse_i];
+    const float lse_q = q_ok ? p.lse[lse_i] : INFINITY;
     const int qterm = BIAS ? rel_bias_query_term(p.kmap, p.bias_L, qc) : 0;
     const float sl2 = p.scale * kLog2eB;
 
@@ -343,12 +349,14 @@ using namespace cobevt;
 
 // C-ABI entry point, see include/cobevt_hip.h
 extern "C" int cobevt_window_attention_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
-                                           const void* dout, void* dq, void* dk, void* dv, float* dbias,
+                                           const void* dout, const float* dlse, void* dq, void* dk, void* dv, float* dbias,
                                            const float* bias_table, const float* mask, const int* dims, float scale,
                                            float drop_p, unsigned drop_seed, const unsigned* drop_seed_dev, hipStream_t stream) {
     if (!q || !k || !v || !out || !lse || !dout || !dq || !dk || !dv || !dims) return COBEVT_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f) return COBEVT_ERR_ARG;
+    if (dlse && drop_p > 0.f) return COBEVT_ERR_UNSUPPORTED;
     AttnBwdParams bp;
+    bp.dlse = dlse;
     AttnParams& p = bp.a;
     const int dtype = dims[0] & 0xff;
     if (dtype != 1) return COBEVT_ERR_UNSUPPORTED;          // fp32 storage (the parity / training mode)

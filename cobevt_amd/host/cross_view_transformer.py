@@ -1,6 +1,7 @@
 """CrossViewTransformer (single-agent / late-fusion CVT baseline) — mirror of
 opv2v/opencood/models/cross_view_transformer.py:14-51 (hypes_yaml/opcamera/cvt.yaml: core_method cross_view_transformer)."""
 from . import runtime as rt
+from . import training
 from .bev_seg_head import BevSegHead
 from .cvt_modules import CrossViewModule
 from .naive_decoder import NaiveDecoder
@@ -27,6 +28,8 @@ class CrossViewTransformer(HipModule):
         return rt.to_nhwc(f.reshape(-1, *f.shape[2:]))
 
     def forward(self, batch_dict):
+        if self.training:                       # train_camera.py:143-179: the differentiable graph of host/training.py
+            return training.cross_view_transformer(self, batch_dict)
         b, l = batch_dict["inputs"].shape[:2]
         y = self.decoder.forward_nhwc(self.encode_agents(batch_dict))
         return self.seg_head(rt.nchw_view(y), b, l)

@@ -21,3 +21,7 @@ class CrossViewTransformerFcooper(_CvtFusionBase):
 
     def _fuse(self, x, com_mask):
         return self.fusion_net(x)
+
+    def _fuse_train(self, x, com_mask):
+        # the reference's own op (f_cooper_fuse.py:30-36: torch.max over the agent slots, its gradient goes to the arg-max agent)
+        return x.max(dim=1)[0].permute(0, 3, 1, 2)

@@ -5,6 +5,7 @@ import torch
 
 from .. import ops
 from . import runtime as rt
+from . import training
 from .bev_seg_head import BevSegHead
 from .corpbevt import STTF
 from .cross_view_transformer import CrossViewTransformer
@@ -37,12 +38,19 @@ class _CvtFusionBase(CrossViewTransformer):
     def _fuse(self, x, com_mask):
         raise NotImplementedError
 
+    def _fuse_train(self, x, com_mask):
+        """train() mode: x (B, L, H, W, C) fp32 autograd tensor, com_mask (B, H, W, 1, L) -> fused (B, C, H, W)"""
+        raise NotImplementedError
+
     def fuse_and_decode(self, feats, transformation_matrix, record_len):
         x, com_mask = self._warp(feats, transformation_matrix, record_len)
         y = self.decoder.forward_nhwc(self._fuse(x, com_mask))       # (B, 8H, 8W, C')
         return self.seg_head(rt.nchw_view(y), y.shape[0], 1)
 
     def forward(self, batch_dict):
+        if self.training:                       # train_camera.py:143-179: the differentiable graph of host/training.py
+            f = training.cvt_encode_agents(self, batch_dict).squeeze(1)
+            return training.cvt_fuse_and_decode(self, f, batch_dict["transformation_matrix"], batch_dict["record_len"])
         feats = self.encode_agents(batch_dict)
         return self.fuse_and_decode(feats, batch_dict["transformation_matrix"], batch_dict["record_len"])
 
@@ -54,3 +62,6 @@ class CrossViewTransformerSwapFuse(_CvtFusionBase):
 
     def _fuse(self, x, com_mask):
         return self.fusion_net.forward_blhwc(x, com_mask)
+
+    def _fuse_train(self, x, com_mask):
+        return training.swap_fusion_encoder(self.fusion_net, x.permute(0, 1, 4, 2, 3).contiguous(), com_mask)

@@ -1,5 +1,6 @@
 """CrossViewTransformerV2VNet (CVT per agent + V2VNet message passing) — mirror of
 opv2v/opencood/models/cross_view_transformer_v2vnet.py:13-68 (cvt_v2vnet.yaml)."""
+from ..lib import CobevtHipError
 from . import runtime as rt
 from .cross_view_transformer import CrossViewTransformer
 from .v2v_fuse import V2VNetFusion
@@ -15,6 +16,10 @@ class _CvtPairwiseBase(CrossViewTransformer):
         self.use_roi_mask = config["sttf"]["use_roi_mask"]
 
     def forward(self, batch_dict):
+        if self.training:
+            raise CobevtHipError("%s: the pairwise-warp fusions (V2VNet's ConvGRU message passing, DiscoNet's pixel-weighted fusion) have "
+                                 "forward kernels only - call .eval(); CrossViewTransformer and its swap-fuse / F-Cooper / att-fuse "
+                                 "variants train (INTEGRATION.md 1b)" % type(self).__name__)
         feats = self.encode_agents(batch_dict)                                   # (N, H, W, C)
         fused = self.fusion_net.forward_nhwc(feats, batch_dict["record_len"], batch_dict["pairwise_t_matrix"])
         y = self.decoder.forward_nhwc(fused)

@@ -18,6 +18,8 @@ from .. import autograd as ag
 from .. import ops
 from ..lib import CobevtHipError
 
+_F = torch.nn.functional
+
 
 def _check(*tensors):
     for t in tensors:
@@ -141,6 +143,23 @@ def _pre_act_conv1x1(seq, x):
     return ag.conv2d(ag.batch_norm_act(x, seq[0], relu=True), seq[2])
 
 
+# the 2- / 4-channel geometry embeddings are 1x1 convolutions over the channel axis: the package's own implicit-GEMM kernel (forward, input
+# gradient) and weight-gradient kernel through ag.linear - K = 4 is one 16-byte fp32 chunk, the 2-channel BEV grid is zero-padded to 4.
+# The 3x3 / 4x4 camera-matrix products in front of them are broadcast multiply-adds (no trainable operand, no library GEMM).
+def _pointwise(t, conv):
+    k = t.shape[1]
+    rows = t.permute(0, 2, 3, 1).float()                                            # (N, h, w, k) channels-last rows
+    w2 = conv.weight.reshape(conv.weight.shape[0], k)
+    if k % 4:
+        rows, w2 = _F.pad(rows, (0, 4 - k % 4)), _F.pad(w2, (0, 4 - k % 4))
+    y = ag.linear_weight(rows, w2, conv.bias)
+    return y.permute(0, 3, 1, 2)
+
+
+def _matmul_small(a, bmat):                                                          # (..., r, k) @ (..., k, m) with k <= 4
+    return (a[..., :, :, None] * bmat[..., None, :, :]).sum(-2)
+
+
 def cross_view_swap_attention(m, index, x, bev, feature, I_inv, E_inv):
     """CrossViewSwapAttention.forward (fax_modules.py:323-441) as a differentiable graph: x (b d H W), feature (b n C h w),
     I_inv (b n 3 3), E_inv (b n 4 4) -> (b d H W).  The camera-geometry embeddings (1 x 1 convolutions of 2 / 4 channels) and the
@@ -155,27 +174,14 @@ def cross_view_swap_attention(m, index, x, bev, feature, I_inv, E_inv):
     w1, w2 = m.feat_win_size
     pixel = m.image_plane.reshape(1, 1, 3, h * w)
     c = E_inv[..., -1:]
-    # the 2- / 4-channel geometry embeddings are 1x1 convolutions over the channel axis: the package's own implicit-GEMM kernel (forward, input
-    # gradient) and weight-gradient kernel through ag.linear - K = 4 is one 16-byte fp32 chunk, the 2-channel BEV grid is zero-padded to 4.
-    # The 3x3 / 4x4 camera-matrix products in front of them are broadcast multiply-adds (no trainable operand, no library GEMM).
-    def pointwise(t, conv):
-        k = t.shape[1]
-        rows = t.permute(0, 2, 3, 1).float()                                            # (N, h, w, k) channels-last rows
-        w2 = conv.weight.reshape(conv.weight.shape[0], k)
-        if k % 4:
-            rows, w2 = F.pad(rows, (0, 4 - k % 4)), F.pad(w2, (0, 4 - k % 4))
-        y = ag.linear_weight(rows, w2, conv.bias)
-        return y.permute(0, 3, 1, 2)
-    def matmul_small(a, bmat):                                                          # (..., r, k) @ (..., k, m) with k <= 4
-        return (a[..., :, :, None] * bmat[..., None, :, :]).sum(-2)
-    c_embed = pointwise(c.reshape(b * n, 4, 1, 1), m.cam_embed)                         # (bn) d 1 1
-    cam = F.pad(matmul_small(I_inv, pixel), (0, 0, 0, 1), value=1)                      # b n 4 hw
-    dd = matmul_small(E_inv, cam).reshape(b * n, 4, h, w)
-    img_embed = pointwise(dd, m.img_embed) - c_embed
+    c_embed = _pointwise(c.reshape(b * n, 4, 1, 1), m.cam_embed)                         # (bn) d 1 1
+    cam = F.pad(_matmul_small(I_inv, pixel), (0, 0, 0, 1), value=1)                      # b n 4 hw
+    dd = _matmul_small(E_inv, cam).reshape(b * n, 4, h, w)
+    img_embed = _pointwise(dd, m.img_embed) - c_embed
     img_embed = img_embed / (img_embed.norm(dim=1, keepdim=True) + 1e-7)
     if m.bev_embed_flag:
         grid = getattr(bev, "grid%d" % index)
-        bev_embed = pointwise(grid[:2][None], m.bev_embed) - c_embed
+        bev_embed = _pointwise(grid[:2][None], m.bev_embed) - c_embed
         bev_embed = bev_embed / (bev_embed.norm(dim=1, keepdim=True) + 1e-7)
         query = bev_embed.reshape(b, n, d, H, W) + x[:, None]
     else:
@@ -233,7 +239,6 @@ def global_attention(m, x):
 # up-sampling, PixelUnshuffle and the STTF warp are HIP kernels in both directions too (csrc/train_glue.hip).  What is left to
 # torch: elementwise residual adds / means, layout permutes, dropout masks, the tiny camera-geometry embeddings and the optimiser.
 # Tensors are (N, C, H, W)-shaped in channels-last memory.
-_F = torch.nn.functional
 
 
 def _conv_bn(x, conv, bn=None, relu=False, residual=None):
@@ -376,3 +381,138 @@ def corpbevt(model, batch_dict):
     batch_dict.update({"features": feats})
     f = fax_module(model.fax, batch_dict).squeeze(1)
     return fuse_and_decode(model, f, batch_dict["transformation_matrix"], batch_dict["record_len"], batch_dict.get("record_len_host"))
+
+
+# ----------------------------------------------------------------------------------------------
+# the CVT baselines: cvt_modules.py CrossAttention / CrossViewAttention / CrossViewModule, the per-pixel agent
+# attention of base_transformer.py, and the models cross_view_transformer{,_swap_fuse,_fcooper,_att_fuse}.py in train() mode
+# ----------------------------------------------------------------------------------------------
+def cvt_cross_attention(m, q, k, v, skip):
+    """cvt_modules.CrossAttention.forward (:116-170) on token-major sources: q (b, n, Q, d), k / v (b, n, K, d), skip (b, Q, d) | None
+    -> (b, Q, d).  Camera c's query copy scores camera c's keys and ONE softmax runs over the keys of all cameras (:142-153).
+    With s_c the scores of camera c,   softmax over (c, K)  =  softmax_K(s_c) * softmax_c(lse_c),   lse_c = log sum_K exp(s_c):
+    the attention kernels run once with the cameras as the windows of a stored-partitioned map (the per-camera outputs and their
+    log-sum-exp), a softmax over the n log-sum-exps merges them - both differentiable (WindowAttentionFn takes the lse gradient)."""
+    _check(q, k, v, skip)
+    b, n, Q, d = q.shape
+    K = k.shape[2]
+    heads = m.heads
+    qt, kt, vt = _project(m.to_q, q), _project(m.to_k, k), _project(m.to_v, v)
+    # mode-2 maps with ncam = 1, X * Y = n windows, w1 * w2 tokens: row = (b * n + camera) * tokens + token
+    qmap, kmap = (2, 1, n * Q, 1, Q, 1, n, 1), (2, 1, n * K, 1, K, 1, n, 1)
+    if Q >= 256 or K >= 256:                 # a window side is < 256 in the token-coordinate packing: factor the token count
+        def sides(t):
+            for a in (128, 64, 32, 16, 8, 4, 2):
+                if t % a == 0 and t // a < 256:
+                    return t // a, a
+            raise CobevtHipError("CVT cross attention: cannot factor %d tokens into a window below 256 x 256" % t)
+        (q1, q2), (k1, k2) = sides(Q), sides(K)
+        qmap, kmap = (2, 1, n * q1, q2, q1, q2, n, 1), (2, 1, n * k1, k2, k1, k2, n, 1)
+    a, lse = ag.window_attention(qt, kt, vt, qmap, kmap, qmap, b, heads, m.scale, qt.shape[0], return_lse=True)   # (b n Q, inner), (b, n, heads, Q)
+    wts = torch.softmax(lse, dim=1).permute(0, 1, 3, 2)                                     # (b, n, Q, heads)
+    a = (a.reshape(b, n, Q, heads, 32) * wts[..., None]).sum(dim=1).reshape(b * Q, heads * 32)
+    z = ag.linear(a, m.proj).reshape(b, Q, d)
+    if skip is not None:
+        z = z + skip
+    z = ag.layernorm(z.contiguous(), m.prenorm)
+    z = z + ag.linear(ag.gelu(ag.linear(z, m.mlp[0])), m.mlp[2])
+    return ag.layernorm(z.contiguous(), m.postnorm)
+
+
+def cvt_cross_view_attention(m, x, bev, feature, I_inv, E_inv):
+    """cvt_modules.CrossViewAttention.forward (:217-283): x (b d H W), feature (b n C h w), I_inv (b n 3 3), E_inv (b n 4 4) -> (b d H W)"""
+    _check(x, feature, I_inv, E_inv)
+    b, n, _, h, w = feature.shape
+    _, d, H, W = x.shape
+    pixel = m.image_plane.reshape(1, 1, 3, h * w)
+    c = E_inv[..., -1:]
+    c_embed = _pointwise(c.reshape(b * n, 4, 1, 1), m.cam_embed)                            # (bn) d 1 1
+    cam = _F.pad(_matmul_small(I_inv, pixel), (0, 0, 0, 1), value=1)                        # b n 4 hw
+    dd = _matmul_small(E_inv, cam).reshape(b * n, 4, h, w)
+    img_embed = _pointwise(dd, m.img_embed) - c_embed
+    img_embed = img_embed / (img_embed.norm(dim=1, keepdim=True) + 1e-7)
+    bev_embed = _pointwise(bev.grid[:2][None], m.bev_embed) - c_embed
+    bev_embed = bev_embed / (bev_embed.norm(dim=1, keepdim=True) + 1e-7)
+    query = bev_embed.reshape(b, n, d, H, W) + x[:, None]
+    feat = feature.reshape(b * n, -1, h, w)
+    key = img_embed if m.feature_proj is None else img_embed + _pre_act_conv1x1(m.feature_proj, feat)
+    val = _pre_act_conv1x1(m.feature_linear, feat)
+    tok = lambda t, hh, ww: t.reshape(b, n, d, hh * ww).permute(0, 1, 3, 2).contiguous()       # (b, n, tokens, d)
+    skip = x.reshape(b, d, H * W).permute(0, 2, 1) if m.skip else None
+    z = cvt_cross_attention(m.cross_attend, tok(query, H, W), tok(key, h, w), tok(val, h, w), skip)
+    return z.reshape(b, H, W, d).permute(0, 3, 1, 2)
+
+
+def cvt_cross_view_module(m, batch):
+    """cvt_modules.CrossViewModule.forward (:311-327): batch['features'] list of (b, l, n, C, h, w) -> (b, l, d, H, W)"""
+    feats = batch["features"]
+    b, l, n = feats[0].shape[:3]
+    I_inv = ops.invert_small(batch["intrinsic"].reshape(b * l * n, 3, 3).to(torch.float32)).reshape(b * l, n, 3, 3)
+    E_inv = batch["extrinsic"].reshape(b * l, n, 4, 4).to(torch.float32)                  # used un-inverted (:316-317)
+    prior = m.bev_embedding.get_prior()
+    x = prior[None].expand(b * l, *prior.shape)
+    for cross_view, feature, layer in zip(m.cross_views, feats, m.layers):
+        feature = feature.reshape(b * l, n, *feature.shape[3:])
+        x = cvt_cross_view_attention(cross_view, x.contiguous(), m.bev_embedding, feature.contiguous(), I_inv, E_inv)
+        for blk in layer:
+            x = bottleneck(blk, x)
+    return x.reshape(b, l, *x.shape[1:])
+
+
+def cvt_encode_agents(model, batch_dict):
+    """images -> (b, l, d, H, W) per-agent BEV features (cross_view_transformer.py:36-45)"""
+    feats = resnet_encoder(model.encoder, batch_dict["inputs"])
+    batch_dict.update({"features": feats})
+    return cvt_cross_view_module(model.cvm, batch_dict)
+
+
+def cross_view_transformer(model, batch_dict):
+    """CrossViewTransformer.forward (cross_view_transformer.py:36-51) as a differentiable graph"""
+    b, l = batch_dict["inputs"].shape[:2]
+    f = cvt_encode_agents(model, batch_dict)
+    y = naive_decoder(model.decoder, f.reshape(b * l, *f.shape[2:]))
+    return bev_seg_head(model.seg_head, y, b, l)
+
+
+def cav_attention(attn, x, mask, norm):
+    """base_transformer.CavAttention (:127-172) behind its PreNorm, residual added: x (b, l, h, w, c), mask (b, h, w, 1, l) | None.  The
+    gathered window attention with 1 x 1 windows: the tokens of a window are the l agents' features at that pixel."""
+    _check(x)
+    b, l, h, w, c = x.shape
+    x = x.contiguous()
+    rows = x.numel() // c
+    inner = attn.heads * 32
+    qkv = ag.linear(ag.layernorm(x, norm).reshape(rows, c), attn.to_qkv)
+    m = ops.tokmap(0, l, h, w, 1, 1)
+    mk = None if mask is None else mask.to(torch.float32).expand(b, h, w, 1, l).reshape(b, h, w, l).contiguous()
+    a = ag.window_attention(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], m, m, m, b, attn.heads, attn.scale, rows, mask=mk)
+    y = ag.dropout(ag.linear(a, attn.to_out[0]), attn.to_out[1].p).reshape(x.shape)
+    return y + x
+
+
+def base_transformer(bt, x, mask):
+    """BaseTransformer.forward (base_transformer.py:342-362): x (b, l, h, w, c), mask (b, h, w, 1, l) -> the ego agent's map (b, h, w, c)"""
+    for attn, ff in bt.encoder.layers:
+        x = cav_attention(attn.fn, x, mask, attn.norm)
+        x = feed_forward(ff.fn, x, norm=ff.norm)
+    return x[:, 0]
+
+
+def cvt_fuse_and_decode(model, f, transformation_matrix, record_len):
+    """the V2V tail of the CVT fusion baselines (cross_view_transformer_{swap_fuse,fcooper,att_fuse}.py): regroup + STTF warp (+ ROI
+    mask), the model's fusion, NaiveDecoder, BevSegHead.  f (N, C, H, W) per-agent BEV features."""
+    dev = f.device
+    tm = transformation_matrix.to(device=dev, dtype=torch.float32)
+    rl = torch.as_tensor(record_len).to(device=dev, dtype=torch.int32)
+    with torch.autocast("cuda", enabled=False):
+        fl = f.float().permute(0, 2, 3, 1).contiguous()
+        w = ag.sttf_warp(fl, tm.contiguous(), rl, model.max_cav, model.discrete_ratio, model.downsample_rate)     # b l h w c
+    with torch.no_grad():
+        _, com_mask, cav_mask = ops.sttf_warp(fl.detach(), tm.contiguous(), None, model.discrete_ratio, model.downsample_rate,
+                                              want_mask=model.use_roi_mask, record_len=rl, max_cav=model.max_cav)
+        if not model.use_roi_mask:
+            b, l, h, ww, _ = w.shape
+            com_mask = cav_mask[:, None, None, None, :].expand(b, h, ww, 1, l).contiguous()
+    fused = model._fuse_train(w, com_mask)                                                       # (b, c, h, w)
+    y = naive_decoder(model.decoder, fused)
+    return bev_seg_head(model.seg_head, y, y.shape[0], 1)

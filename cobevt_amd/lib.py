@@ -47,7 +47,7 @@ SIGNATURES = {
     "cobevt_conv_wgrad": (ctypes.c_int, [_vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_conv_wgrad_blocked": (ctypes.c_int, [_vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_gelu": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_long, _vp]),
-    "cobevt_window_attention_bwd": (ctypes.c_int, [_vp] * 12 + [_c_int_p, ctypes.c_float, ctypes.c_float, ctypes.c_uint, _vp, _vp]),
+    "cobevt_window_attention_bwd": (ctypes.c_int, [_vp] * 13 + [_c_int_p, ctypes.c_float, ctypes.c_float, ctypes.c_uint, _vp, _vp]),
     "cobevt_layernorm": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                         ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_int, _vp]),
     "cobevt_fax_ray_embed": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -176,14 +176,16 @@ int cobevt_window_attention(const void* q, const void* k, const void* v, void* o
 /* Training slice (fp32 storage, dims[0] dtype = 1).  cobevt_window_attention_lse: the forward above that also stores the base-2
  * log-sum-exp of every query's logits, lse[B][L][heads][Nq] (mean_q must be 0).  cobevt_window_attention_bwd: given the forward
  * tensors, `out`, lse and dout (layout of out), writes dq, dk, dv (layouts of q, k, v; rows no window covers are left
- * untouched) and ADDS the bias-table gradient into dbias[bias_rows][heads] (zero-initialised; nullable without bias).
+ * untouched) and ADDS the bias-table gradient into dbias[bias_rows][heads] (zero-initialised; nullable without bias).  dlse (nullable,
+ * layout of lse, drop_p must be 0): gradient w.r.t. the NATURAL log-sum-exp ln(2) * lse when the caller combines the lse further - CVT's
+ * CrossAttention (cvt_modules.py:142-153: one softmax over all cameras' keys) trains as per-camera attentions merged by softmax(lse).
  * Replaces torch autograd through the einsum / softmax / einsum of fax_modules.py:219-237, swap_fusion_modules.py:100-121
  * (train_camera.py:143-179 loss.backward()). */
 int cobevt_window_attention_lse(const void* q, const void* k, const void* v, void* out, float* lse, const float* bias_table,
                                 const float* mask, const int* dims, float scale, float drop_p, unsigned drop_seed,
                                 const unsigned* drop_seed_dev, hipStream_t stream);
 int cobevt_window_attention_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
-                                const void* dout, void* dq, void* dk, void* dv, float* dbias, const float* bias_table,
+                                const void* dout, const float* dlse, void* dq, void* dk, void* dv, float* dbias, const float* bias_table,
                                 const float* mask, const int* dims, float scale, float drop_p, unsigned drop_seed,
                                 const unsigned* drop_seed_dev, hipStream_t stream);
 /* drop_p > 0: nn.Dropout on the attention probabilities (FAX global attention in train mode, fax_modules.py:114,161): element

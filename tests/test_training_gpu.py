@@ -891,3 +891,65 @@ def test_captured_train_step_follows_eager(cuda, amp):
     bad["inputs"] = bad["inputs"][:1]
     with pytest.raises(CobevtHipError):
         cap.step(bad)
+
+
+def test_cvt_cross_attention_gradients(cuda):
+    """cvt_modules.CrossAttention in train() mode (per-camera attentions merged by a softmax over their log-sum-exp, the lse gradient
+    entering the attention backward kernels) against torch autograd through the oracle's single softmax over all cameras' keys
+    (oracle.cvt.cross_attention, cvt_modules.py:116-170): output, input gradients and every parameter gradient"""
+    import oracle.cvt as o_cvt
+    from cobevt_amd.host import training
+    g = torch.Generator().manual_seed(21)
+    b, n, d, H, W, h, w, heads = 2, 3, 64, 8, 12, 6, 10, 2
+    m = _train_module(host.CrossAttention(d, heads, 32, True), cuda)
+    sd = _oracle_sd(m)
+    q0, k0, v0 = torch.randn(b, n, d, H, W, generator=g), torch.randn(b, n, d, h, w, generator=g), torch.randn(b, n, d, h, w, generator=g)
+    s0 = torch.randn(b, d, H, W, generator=g)
+    with torch.enable_grad():
+        ins_ref = [_leaf(t) for t in (q0, k0, v0, s0)]
+        out_ref = o_cvt.cross_attention(sd, "", *ins_ref, heads, 32)
+        ins = [_leaf(t, cuda) for t in (q0, k0, v0, s0)]
+        tok = lambda t: t.reshape(t.shape[0], t.shape[1], d, -1).permute(0, 1, 3, 2)
+        z = training.cvt_cross_attention(m, tok(ins[0]).contiguous(), tok(ins[1]).contiguous(), tok(ins[2]).contiguous(),
+                                         ins[3].reshape(b, d, H * W).permute(0, 2, 1))
+        out = z.reshape(b, H, W, d).permute(0, 3, 1, 2)
+        _compare(m, sd, out, out_ref, ins, ins_ref, "CVT CrossAttention")
+
+
+@pytest.mark.parametrize("kind,core,fwd", [("single", "cross_view_transformer", "cross_view_transformer_forward"),
+                                           ("swap_fuse", "cross_view_transformer_swap_fuse", "cross_view_transformer_swap_fuse_forward"),
+                                           ("fcooper", "cross_view_transformer_fcooper", "cross_view_transformer_fcooper_forward"),
+                                           ("att_fuse", "cross_view_transformer_att_fuse", "cross_view_transformer_att_fuse_forward")])
+def test_cvt_baselines_train_gradients_vs_oracle(cuda, kind, core, fwd):
+    """The CVT baselines in train() mode - ResNet encoder, CrossViewModule (camera-paired cross attention),
+    STTF warp, the model's fusion (swap fusion / F-Cooper max / per-pixel agent attention), decoder, head - against torch autograd
+    through the oracle: logits and every parameter gradient (BatchNorms frozen, dropout off: the oracle is the eval-mode function).
+    Same gates as the whole-model CorpBEVT test: a deep ReLU network, gradients to 5e-3 rms / 2e-2 max."""
+    import copy
+    import oracle.cvt as o_cvt
+    from cobevt_amd.registry import create_model
+    cfg = synth.cvt_small_config(kind)
+    for key in ("swap_fusion", "base_transformer"):
+        if key in cfg:
+            for dk in ("drop_out", "dropout"):
+                if dk in cfg[key]:
+                    cfg[key][dk] = 0.0
+    m = _freeze_bn(_train_module(create_model({"model": {"core_method": core, "args": copy.deepcopy(cfg)}}), cuda))
+    sd = _oracle_sd(m)
+    batch = synth.opv2v_batch(agents=1 if kind == "single" else 2, cams=2, image=128, max_cav=3, seed=cases.SEED)
+    with torch.enable_grad():
+        out_ref = getattr(o_cvt, fwd)(sd, cfg, dict(batch))["dynamic_seg"]
+        out = m({k: v.to(cuda) for k, v in batch.items()})["dynamic_seg"]
+        assert_close(out, golden("gv17_cvt_baselines")[kind + "_dynamic_seg"], TOL, "train-mode forward vs the reference's logits")
+        _compare(m, sd, out, out_ref, [], [], "CVT " + kind, grad_tol=2e-2, rms_tol=5e-3)
+
+
+def test_cvt_pairwise_baselines_still_refuse_to_train(cuda):
+    """V2VNet / DiscoNet fusion (pairwise warps + ConvGRU / distillation weights) have forward kernels only: train() raises, loudly"""
+    import copy
+    from cobevt_amd.registry import create_model
+    cfg = synth.cvt_small_config("v2vnet")
+    m = _train_module(create_model({"model": {"core_method": "cross_view_transformer_v2vnet", "args": copy.deepcopy(cfg)}}), cuda)
+    batch = {k: v.to(cuda) for k, v in synth.opv2v_batch(agents=2, cams=2, image=128, max_cav=3, seed=cases.SEED).items()}
+    with pytest.raises(CobevtHipError):
+        m(batch)
