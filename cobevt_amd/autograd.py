@@ -754,6 +754,167 @@ def weighted_cross_entropy(logits, target, weight):
     return WeightedCrossEntropyFn.apply(logits.float(), target, weight)
 
 
+# ----------------------------------------------------------------------------------------------
+# nuScenes SinBEVT pieces (csrc/train_nusc.hip): swish, depthwise convolution, align_corners bilinear resize, sigmoid focal loss
+# ----------------------------------------------------------------------------------------------
+class SwishFn(torch.autograd.Function):
+    """x sigmoid(x) (efficientnet-pytorch's swish) on any contiguous tensor whose element count is a multiple of 8: cobevt_swish both ways"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        xc = x if x.dtype in (torch.float32, torch.bfloat16) else x.float()
+        # elementwise over memory: any dense layout will do (row-major, or the (N, C, H, W)-shaped channels-last views of this path)
+        if not (xc.is_contiguous() or (xc.dim() == 4 and xc.is_contiguous(memory_format=torch.channels_last))):
+            xc = xc.contiguous()
+        out = torch.empty_like(xc)                          # same strides
+        _L.check(_L.load().cobevt_swish(_p(xc), None, _p(out), ops.dcode(xc.dtype), xc.numel(), _stream()), "cobevt_swish")
+        ctx.save_for_backward(xc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xc,) = ctx.saved_tensors
+        g = dy.to(xc.dtype)
+        if g.stride() != xc.stride():                       # bring the gradient into x's memory order
+            g = torch.empty_like(xc).copy_(g)
+        dx = torch.empty_like(xc)
+        _L.check(_L.load().cobevt_swish(_p(xc), _p(g), _p(dx), ops.dcode(xc.dtype), xc.numel(), _stream()), "cobevt_swish")
+        return dx
+
+
+def swish(x):
+    if x.numel() % 8:
+        return x * torch.sigmoid(x)
+    return SwishFn.apply(x)
+
+
+class DepthwiseConvFn(torch.autograd.Function):
+    """k x k depthwise convolution (groups == channels, TensorFlow-"same" static padding: `pad` = (before, after) zero rows / columns on
+    each axis) on (N, C, H, W)-shaped tensors in channels-last memory, fp32 or bf16: cobevt_depthwise_conv_nhwc forward; the input
+    gradient is the same kernel on the flipped taps (on the zero-stuffed gradient when strided), the weight gradient cobevt_depthwise_wgrad.
+    weight: the fp32 (C, 1, k, k) parameter."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, x, weight, stride, pad):
+        _need_cuda(x, weight)
+        xl = _nhwc(x)
+        n, h, w, c = xl.shape
+        k = weight.shape[-1]
+        if c % 8 or weight.shape[0] != c or weight.shape[1] != 1 or weight.shape[2] != k or k not in (3, 5):
+            raise CobevtHipError("training depthwise conv: (C, 1, k, k) weight with k = 3 / 5 and a multiple of 8 channels")
+        ho, wo = (h + pad[0] + pad[1] - k) // stride + 1, (w + pad[0] + pad[1] - k) // stride + 1
+        taps = weight.detach().float()[:, 0].permute(1, 2, 0).reshape(k * k, c).contiguous()          # [tap][C]
+        zero = torch.zeros(c, device=xl.device, dtype=torch.float32)
+        out = torch.empty((n, ho, wo, c), device=xl.device, dtype=xl.dtype)
+        dims = _ints([ops.dcode(xl.dtype), n, h, w, c, k, stride, pad[0], pad[0], ho, wo, 0])
+        _L.check(_L.load().cobevt_depthwise_conv_nhwc(_p(xl), _p(taps), _p(zero), _p(out), dims, _stream()), "cobevt_depthwise_conv_nhwc")
+        ctx.save_for_backward(xl, taps, zero)
+        ctx.cfg = (int(stride), (int(pad[0]), int(pad[1])), k, weight.dtype)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, dy):
+        xl, taps, zero = ctx.saved_tensors
+        stride, pad, k, wdt = ctx.cfg
+        n, h, w, c = xl.shape
+        dyl = _nhwc(dy.to(xl.dtype))
+        ho, wo = dyl.shape[1:3]
+        lib = _L.load()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            g = dyl
+            gh, gw = h + pad[0] + pad[1] - k + 1, w + pad[0] + pad[1] - k + 1          # the stride-1 output extent of the forward
+            if stride > 1 or (gh, gw) != (ho, wo):           # zero-stuffed gradient map on that extent
+                g = torch.zeros((n, gh, gw, c), device=dyl.device, dtype=dyl.dtype)
+                g[:, :(ho - 1) * stride + 1:stride, :(wo - 1) * stride + 1:stride] = dyl
+            flipped = taps.reshape(k, k, c).flip(0, 1).reshape(k * k, c).contiguous()
+            dx = torch.empty_like(xl)
+            # dx[i] = sum_a dy_stuffed[i + pad0 - a] w[a]  =  correlation of the stuffed gradient with the flipped taps, top / left pad k - 1 - pad0
+            dims = _ints([ops.dcode(xl.dtype), n, g.shape[1], g.shape[2], c, k, 1, k - 1 - pad[0], k - 1 - pad[0], h, w, 0])
+            _L.check(lib.cobevt_depthwise_conv_nhwc(_p(g), _p(flipped), _p(zero), _p(dx), dims, _stream()), "cobevt_depthwise_conv_nhwc")
+            dx = dx.permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            dwt = torch.zeros((k * k, c), device=xl.device, dtype=torch.float32)
+            dims = _ints([ops.dcode(xl.dtype), n, h, w, c, k, stride, pad[0], pad[0], ho, wo])
+            _L.check(lib.cobevt_depthwise_wgrad(_p(xl), _p(dyl), _p(dwt), dims, _stream()), "cobevt_depthwise_wgrad")
+            dw = dwt.reshape(k, k, c).permute(2, 0, 1)[:, None].contiguous().to(wdt)
+        return dx, dw, None, None
+
+
+def depthwise_conv2d(x, conv, pad):
+    """x through the depthwise nn.Conv2d container `conv` (groups == channels, no bias) with static "same" padding pad = (before, after)"""
+    if conv.groups != conv.in_channels or conv.bias is not None or conv.kernel_size[0] != conv.kernel_size[1] or conv.stride[0] != conv.stride[1]:
+        raise CobevtHipError("training depthwise conv: groups == channels, square kernel / stride, no bias")
+    if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        with torch.autocast("cuda", enabled=False):
+            return DepthwiseConvFn.apply(x.to(torch.bfloat16), _master(conv.weight), conv.stride[0], tuple(pad))
+    return DepthwiseConvFn.apply(x, _master(conv.weight), conv.stride[0], tuple(pad))
+
+
+class ResizeBilinearFn(torch.autograd.Function):
+    """align_corners bilinear resize of an (N, C, H, W)-shaped tensor (nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True),
+    nuscenes decoder.py:12): cobevt_resize_nhwc forward, its adjoint cobevt_resize_bilinear_bwd backward"""
+
+    @staticmethod
+    def forward(ctx, x, ho, wo):
+        xl = _nhwc(x)
+        ctx.shape = tuple(xl.shape)
+        ctx.dt = xl.dtype
+        return ops.resize_nhwc(xl, ho, wo, "bilinear").permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, h, w, c = ctx.shape
+        dyl = _nhwc(dy.to(ctx.dt))
+        dx = torch.zeros((n, h, w, c), device=dyl.device, dtype=torch.float32)
+        _L.check(_L.load().cobevt_resize_bilinear_bwd(_p(dyl), _p(dx), ops.dcode(dyl.dtype), n, h, w, c, dyl.shape[1], dyl.shape[2], _stream()),
+                 "cobevt_resize_bilinear_bwd")
+        return dx.to(ctx.dt).permute(0, 3, 1, 2), None, None
+
+
+def resize_bilinear(x, ho, wo):
+    c = x.shape[1]
+    g = c >> 3
+    if c % 8 or g > 64 or (g & (g - 1)):
+        return torch.nn.functional.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=True)
+    return ResizeBilinearFn.apply(x, int(ho), int(wo))
+
+
+class SigmoidFocalLossFn(torch.autograd.Function):
+    """mean sigmoid focal loss over the visible pixels (nuscenes losses.py:27-84): cobevt_sigmoid_focal_loss / _bwd; pred (N, C, hw) fp32"""
+
+    @staticmethod
+    def forward(ctx, pred, label, vis, masks, cfg):
+        min_visibility, alpha, gamma, soft = cfg
+        _need_cuda(pred, label)
+        n, c, hw = pred.shape
+        p32 = _f32c(pred, "pred")
+        nl = label.shape[1]
+        scratch = torch.empty(2 * n * ((hw + 2047) // 2048), device=pred.device, dtype=torch.float32)
+        out = torch.empty(3, device=pred.device, dtype=torch.float32)
+        rc = _L.load().cobevt_sigmoid_focal_loss(_p(p32), _p(label), _p(vis), _p(masks), _p(scratch), _p(out), n, c, nl, hw, min_visibility,
+                                                 ctypes.c_float(alpha), ctypes.c_float(gamma), int(soft), _stream())
+        _L.check(rc, "cobevt_sigmoid_focal_loss")
+        ctx.save_for_backward(p32, label, vis, masks, out)
+        ctx.cfg = cfg
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        p32, label, vis, masks, out = ctx.saved_tensors
+        min_visibility, alpha, gamma, soft = ctx.cfg
+        n, c, hw = p32.shape
+        dp = torch.empty_like(p32)
+        gs = g.reshape(1).float().contiguous()
+        rc = _L.load().cobevt_sigmoid_focal_loss_bwd(_p(p32), _p(label), _p(vis), _p(masks), _p(out), _p(gs), _p(dp), n, c, label.shape[1], hw,
+                                                     min_visibility, ctypes.c_float(alpha), ctypes.c_float(gamma), int(soft), _stream())
+        _L.check(rc, "cobevt_sigmoid_focal_loss_bwd")
+        return dp, None, None, None, None
+
+
 def _env_flags():
     """COBEVT_TRAIN_FLAGS="USE_TORCH_OPERAND_PREP=1,USE_WGRAD_BLOCKED=0": the module's USE_* switches from the environment (same-job A/B
     runs of tools/train_probe.py; never set in production)"""

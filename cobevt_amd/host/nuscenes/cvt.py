@@ -6,6 +6,7 @@ import torch.nn as nn
 
 from ... import ops
 from .. import runtime as rt
+from .. import training
 from ..runtime import HipModule
 
 
@@ -29,6 +30,8 @@ class CrossViewTransformer(HipModule):
 
     def forward(self, batch):
         """batch: image / intrinsics / extrinsics -> {name: (b, stop - start, H, W) fp32 logits}"""
+        if self.training:                   # model_module.py:35-60 training_step: the differentiable graph of host/training.py
+            return training.nusc_cross_view_transformer(self, batch)
         bev = self.decoder.forward_nhwc(rt.to_nhwc(self.encoder(batch)))
         hidden = ops.conv2d(bev, rt.conv_plan(self, "l0", self.to_logits[0], self.to_logits[1], act=1))
         logits = ops.conv2d(hidden, rt.conv_plan(self, "l3", self.to_logits[3], store_mode=2))       # (b, width, H, W) fp32

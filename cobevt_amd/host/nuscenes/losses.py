@@ -2,10 +2,30 @@
 (`SigmoidFocalLoss`, `BinarySegmentationLoss`, `CenterLoss`, `MultipleLoss`): same constructor arguments and call
 signatures, the value computed where the logits are (cobevt_sigmoid_focal_loss: label grouping, visibility mask and the mean
 in one pass).  fvcore's `sigmoid_focal_loss` (third-party, absent here) is restated from its published definition.
-Back-propagation is out of scope: the results carry no graph."""
+When the prediction requires grad the value comes from cobevt_amd.autograd.SigmoidFocalLossFn (same forward kernel; its gradient w.r.t. the
+logits is cobevt_sigmoid_focal_loss_bwd), so `loss.backward()` of the reference's training_step (model_module.py:35-60) works."""
 import logging
 
+import torch
+
+from ... import autograd as ag
 from ... import ops
+
+
+def _focal_mean(pred, label, vis, label_indices, min_visibility, alpha, gamma):
+    """pred (b, c, hw) logits; the differentiable path when pred carries a graph, the plain forward kernel otherwise"""
+    if not (torch.is_grad_enabled() and pred.requires_grad):
+        return ops.sigmoid_focal_loss_mean(pred.detach(), label.detach(), vis, label_indices, min_visibility, alpha, gamma)
+    dev = pred.device
+    lab = label.detach().to(device=dev, dtype=torch.float32).contiguous()
+    soft = label_indices is None
+    masks = None
+    if not soft:
+        masks = torch.tensor([sum(1 << int(l) for l in g) for g in label_indices], dtype=torch.int64).to(torch.int32).to(dev)
+    v, mv = None, -1
+    if min_visibility is not None:
+        v, mv = vis.to(device=dev, dtype=torch.uint8).contiguous(), int(min_visibility)
+    return ag.SigmoidFocalLossFn.apply(pred.float(), lab, v, masks, (mv, float(alpha), float(gamma), bool(soft)))
 
 logger = logging.getLogger(__name__)
 
@@ -23,8 +43,7 @@ class SigmoidFocalLoss(object):
     def forward(self, pred, label):
         """pred, label: same shape (b, c, h, w)"""
         b, c, h, w = pred.shape
-        return ops.sigmoid_focal_loss_mean(pred.detach().reshape(b, c, h * w), label.detach().reshape(b, c, h * w), None, None, None,
-                                           self.alpha, self.gamma)
+        return _focal_mean(pred.reshape(b, c, h * w), label.reshape(b, c, h * w), None, None, None, self.alpha, self.gamma)
 
 
 class BinarySegmentationLoss(SigmoidFocalLoss):
@@ -39,8 +58,8 @@ class BinarySegmentationLoss(SigmoidFocalLoss):
         b, c, h, w = pred.shape
         label = batch["bev"]
         vis = batch["visibility"].reshape(b, h * w) if self.min_visibility is not None else None
-        return ops.sigmoid_focal_loss_mean(pred.detach().reshape(b, c, h * w), label.detach().reshape(b, label.shape[1], h * w), vis,
-                                           self.label_indices, self.min_visibility, self.alpha, self.gamma)
+        return _focal_mean(pred.reshape(b, c, h * w), label.reshape(b, label.shape[1], h * w), vis, self.label_indices, self.min_visibility,
+                           self.alpha, self.gamma)
 
 
 class CenterLoss(SigmoidFocalLoss):
@@ -52,8 +71,7 @@ class CenterLoss(SigmoidFocalLoss):
         pred, label = pred["center"], batch["center"]
         b, c, h, w = pred.shape
         vis = batch["visibility"].reshape(b, h * w) if self.min_visibility is not None else None
-        return ops.sigmoid_focal_loss_mean(pred.detach().reshape(b, c, h * w), label.detach().reshape(b, c, h * w), vis, None,
-                                           self.min_visibility, self.alpha, self.gamma)
+        return _focal_mean(pred.reshape(b, c, h * w), label.reshape(b, c, h * w), vis, None, self.min_visibility, self.alpha, self.gamma)
 
 
 class MultipleLoss(dict):

@@ -516,3 +516,108 @@ def cvt_fuse_and_decode(model, f, transformation_matrix, record_len):
     fused = model._fuse_train(w, com_mask)                                                       # (b, c, h, w)
     y = naive_decoder(model.decoder, fused)
     return bev_seg_head(model.seg_head, y, y.shape[0], 1)
+
+
+# ----------------------------------------------------------------------------------------------
+# the nuScenes SinBEVT model (nuscenes/cross_view_transformer/model/{cvt,encoder_pyramid_axial,decoder}.py and
+# backbones/efficientnet.py over efficientnet-pytorch's MBConvBlock) in train() mode
+# ----------------------------------------------------------------------------------------------
+def _drop_connect(x, p, training):
+    """efficientnet_pytorch.utils.drop_connect: per-sample stochastic depth on the block's output before the identity skip"""
+    if not training or not p:
+        return x
+    keep = 1.0 - p
+    mask = torch.floor(keep + torch.rand((x.shape[0], 1, 1, 1), dtype=x.dtype, device=x.device))
+    return x / keep * mask
+
+
+def mbconv(blk, x, drop_rate):
+    """efficientnet-pytorch MBConvBlock.forward (restated in oracle/efficientnet.py:mbconv; host mirror nuscenes/efficientnet.py): 1x1 expand
+    + BN + swish, depthwise k x k ("same" static padding) + BN + swish, squeeze-and-excitation, 1x1 project + BN, drop-connect + identity
+    skip.  Convolutions, BatchNorm, swish and the depthwise convolution are HIP kernels in both directions; the squeeze-and-excitation
+    vector algebra ((N, C) tensors) and the gate multiply are elementwise torch ops."""
+    inp = x
+    if blk.expand != 1:
+        x = ag.swish(ag.batch_norm_act(ag.conv2d(x, blk._expand_conv), blk._bn0))
+    x = ag.depthwise_conv2d(x, blk._depthwise_conv, blk.pad)
+    x = ag.swish(ag.batch_norm_act(x, blk._bn1))
+    mid, sq = blk._se_reduce.in_channels, blk._se_reduce.out_channels
+    s = x.float().mean(dim=(2, 3))                                                      # (N, mid)
+    s = (s[:, None, :] * blk._se_reduce.weight.reshape(1, sq, mid)).sum(-1) + blk._se_reduce.bias
+    s = s * torch.sigmoid(s)
+    s = (s[:, None, :] * blk._se_expand.weight.reshape(1, mid, sq)).sum(-1) + blk._se_expand.bias
+    x = x * torch.sigmoid(s).to(x.dtype)[:, :, None, None]
+    x = ag.batch_norm_act(ag.conv2d(x, blk._project_conv), blk._bn2)
+    if blk.stride == 1 and blk.cin == blk.cout:
+        x = _drop_connect(x, drop_rate, blk.training) + inp
+    return x
+
+
+def efficientnet_extractor(m, x):
+    """EfficientNetExtractor.forward (backbones/efficientnet.py:85-96): x (N, 3, H, W) normalised images -> the picked feature maps.  (The
+    reference wraps every layer in torch.utils.checkpoint in training mode - a memory / recompute trade that does not change the function.)"""
+    _check(x)
+    stem = m.layers[0]
+    p0, p1 = m._stem_pad
+    y = ag.conv2d(_F.pad(x, (p0, p1, p0, p1)), stem[0])
+    y = ag.swish(ag.batch_norm_act(y, stem[1]))
+    result = [y]
+    for group in list(m.layers)[1:]:
+        for blk, a in zip(group, group.args):
+            y = mbconv(blk, y, a[0] if a else 0.0)
+        result.append(y)
+    return [result[i] for i in m.idx_pick]
+
+
+def pyramid_axial_encoder(m, batch):
+    """PyramidAxialEncoder.forward (encoder_pyramid_axial.py:534-558): image (b, n, 3, h, w), intrinsics, extrinsics -> (b, d, H, W)"""
+    image = batch["image"]
+    _check(image, batch["intrinsics"], batch["extrinsics"])
+    b, n = image.shape[:2]
+    I_inv = ops.invert_small(batch["intrinsics"].reshape(b * n, 3, 3).to(torch.float32)).reshape(b, n, 3, 3)
+    E_inv = ops.invert_small(batch["extrinsics"].reshape(b * n, 4, 4).to(torch.float32)).reshape(b, n, 4, 4)     # inverted in the model (:538-539)
+    feats = efficientnet_extractor(m.backbone, (image.flatten(0, 1) - m.norm.mean) / m.norm.std)
+    prior = m.bev_embedding.get_prior()
+    x = prior[None].expand(b, *prior.shape)
+    for i, (cross_view, feature, layer) in enumerate(zip(m.cross_views, feats, m.layers)):
+        feature = feature.reshape(b, n, *feature.shape[1:])
+        x = cross_view_swap_attention(cross_view, i, x.contiguous(), m.bev_embedding, feature.contiguous(), I_inv, E_inv)
+        for blk in layer:
+            x = bottleneck(blk, x)
+        if i < len(m.cross_views) - 1:
+            x = downsample(m.downsample_layers[i][0], x)
+    return x
+
+
+def nusc_decoder_block(blk, x, skip):
+    """DecoderBlock.forward (decoder.py:27-36): bilinear x2 (align_corners) -> conv3x3 + BN + ReLU -> conv1x1 + BN, + the 1x1 projection of the
+    decoder's INPUT map resized (nearest) to the new size, ReLU"""
+    h, w = x.shape[2:]
+    big = ag.resize_bilinear(x, 2 * h, 2 * w)
+    hidden = _conv_bn(big, blk.conv[1], blk.conv[2], relu=True)
+    branch = None
+    if blk.up is not None:
+        branch = ag.conv2d(skip, blk.up)
+        f = (2 * h) // branch.shape[2]
+        if branch.shape[2] * f == 2 * h and branch.shape[3] * f == 2 * w and f & (f - 1) == 0:
+            while branch.shape[2] < 2 * h:               # nearest by an integer power of two = nearest x2, repeated
+                branch = ag.upsample_nearest2(branch)
+        else:
+            branch = _F.interpolate(branch, (2 * h, 2 * w))
+    return _conv_bn(hidden, blk.conv[4], blk.conv[5], relu=True, residual=branch)
+
+
+def nusc_decoder(dec, x):
+    y = x
+    for blk in dec.layers:                               # every block's skip branch reads the decoder INPUT (decoder.py:55-61)
+        y = nusc_decoder_block(blk, y, x)
+    return y
+
+
+def nusc_cross_view_transformer(model, batch):
+    """nuScenes CrossViewTransformer.forward (cvt.py:35-40) as a differentiable graph"""
+    bev = pyramid_axial_encoder(model.encoder, batch)
+    y = nusc_decoder(model.decoder, bev)
+    hidden = _conv_bn(y, model.to_logits[0], model.to_logits[1], relu=True)
+    logits = ag.conv2d(hidden, model.to_logits[3])
+    return {name: logits[:, lo:hi] for name, (lo, hi) in model.outputs.items()}

@@ -98,6 +98,10 @@ SIGNATURES = {
     "cobevt_sttf_warp_bwd": (ctypes.c_int, [_vp, _vp, _vp, _vp] + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_float, _vp]),
     "cobevt_conv_weight_rows": (ctypes.c_int, [_vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_wgrad_block_operand": (ctypes.c_int, [_vp, _vp, _c_int_p, _vp]),
+    "cobevt_swish": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_long, _vp]),
+    "cobevt_depthwise_wgrad": (ctypes.c_int, [_vp, _vp, _vp, _c_int_p, _vp]),
+    "cobevt_resize_bilinear_bwd": (ctypes.c_int, [_vp, _vp] + [ctypes.c_int] * 7 + [_vp]),
+    "cobevt_sigmoid_focal_loss_bwd": (ctypes.c_int, [_vp] * 7 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_float, ctypes.c_int, _vp]),
     "cobevt_peer_window_alloc": (ctypes.c_int, [ctypes.c_long, ctypes.POINTER(_vp), _vp]),
     "cobevt_peer_window_open": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "cobevt_peer_window_close": (ctypes.c_int, [_vp]),

@@ -522,6 +522,24 @@ int cobevt_conv_weight_rows(const float* w, void* rows_fwd, void* rows_dgrad, co
  * dims: [N, H, W, C, Hp, NB, pad_top, pad_left, P, sx]. */
 int cobevt_wgrad_block_operand(const void* src, void* dst, const int* dims, hipStream_t stream);
 
+/* Backward pieces of the nuScenes SinBEVT training path (csrc/train_nusc.hip; torch autograd + cuDNN in the reference:
+ * nuscenes/cross_view_transformer/model/model_module.py:35-60 over backbones/efficientnet.py:85-96, decoder.py:27-36, losses.py:27-84).
+ * cobevt_swish: dy == NULL: out = x sigmoid(x) (efficientnet-pytorch's MemoryEfficientSwish); else out = dy d/dx; n elements (multiple of 8),
+ * dtype 0 bf16 / 1 fp32. */
+int cobevt_swish(const void* x, const void* dy, void* out, int dtype, long n, hipStream_t stream);
+/* Weight gradient of the depthwise k x k convolution (k = 3 / 5): dw fp32 [k * k][C] += sum over output pixels of dy (N, Ho, Wo, C) x the
+ * tap-shifted x (N, H, W, C); dw zero-initialised.  dims (int32[11]): dtype, N, H, W, C, k, stride, pad_top, pad_left, Ho, Wo.  (The input
+ * gradient is cobevt_depthwise_conv_nhwc on the flipped taps, on the zero-stuffed gradient when strided.) */
+int cobevt_depthwise_wgrad(const void* x, const void* dy, float* dw, const int* dims, hipStream_t stream);
+/* Adjoint of cobevt_resize_nhwc mode 1 (align_corners bilinear; nn.Upsample of decoder.py:12): dy (N, Ho, Wo, C) -> dx fp32 (N, H, W, C),
+ * zero-initialised. */
+int cobevt_resize_bilinear_bwd(const void* dy, float* dx, int dtype, int N, int H, int W, int C, int Ho, int Wo, hipStream_t stream);
+/* Gradient of cobevt_sigmoid_focal_loss's mean w.r.t. the logits: dpred (N, C, hw) fp32 = gscale[0] / count x d loss / d logit on the kept
+ * elements, 0 elsewhere.  stats = the forward's out[3] (mean, sum, count) and gscale (the upstream gradient) are DEVICE words: no host sync. */
+int cobevt_sigmoid_focal_loss_bwd(const float* pred, const float* label, const unsigned char* visibility, const unsigned int* label_mask,
+                                  const float* stats, const float* gscale, float* dpred, int N, int C, int NL, int hw, int min_visibility,
+                                  float alpha, float gamma, int soft_label, hipStream_t stream);
+
 /* ---- multi-GPU: the V2V feature-sharing step in front of FuseBEVT.  The reference keeps all agents in one
  * process (opv2v/opencood/models/corpbevt.py:112-124, sub_modules/fuse_utils.py:8-61: agents are a batch dimension up to
  * `regroup`); its only collective call sites are the DDP set-up in opv2v/opencood/tools/multi_gpu_utils.py:32-37 and
