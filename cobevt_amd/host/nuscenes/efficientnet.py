@@ -32,6 +32,7 @@ _PARAMS = {"efficientnet-b0": (1.0, 1.0, 224), "efficientnet-b4": (1.4, 1.8, 380
 _B0_STAGES = [(1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80), (3, 5, 1, 6, 80, 112),
               (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320)]                               # repeats, k, stride, expand, in, out
 _BN_EPS = 1e-3
+_BN_MOM = 0.01            # 1 - batch_norm_momentum (0.99) of efficientnet-pytorch's global params: only the running-stat update of train() sees it
 _SWISH = 3
 
 
@@ -58,14 +59,14 @@ class MBConvBlock(HipModule):
         self.pad = _same_pad(image, kernel, stride)
         if expand != 1:
             self._expand_conv = nn.Conv2d(cin, mid, 1, bias=False)
-            self._bn0 = nn.BatchNorm2d(mid, eps=_BN_EPS)
+            self._bn0 = nn.BatchNorm2d(mid, eps=_BN_EPS, momentum=_BN_MOM)
         self._depthwise_conv = nn.Conv2d(mid, mid, kernel, stride=stride, groups=mid, bias=False)
-        self._bn1 = nn.BatchNorm2d(mid, eps=_BN_EPS)
+        self._bn1 = nn.BatchNorm2d(mid, eps=_BN_EPS, momentum=_BN_MOM)
         squeezed = max(1, int(cin * 0.25))
         self._se_reduce = nn.Conv2d(mid, squeezed, 1)
         self._se_expand = nn.Conv2d(squeezed, mid, 1)
         self._project_conv = nn.Conv2d(mid, cout, 1, bias=False)
-        self._bn2 = nn.BatchNorm2d(cout, eps=_BN_EPS)
+        self._bn2 = nn.BatchNorm2d(cout, eps=_BN_EPS, momentum=_BN_MOM)
 
     def forward_nhwc(self, x):
         inp = x
@@ -111,7 +112,7 @@ class _Stem(nn.Sequential):
     """Sequential(conv_stem, bn0, swish) of the reference (:60) - keys layers.0.0.weight, layers.0.1.*"""
 
     def __init__(self, cout):
-        super().__init__(nn.Conv2d(3, cout, 3, stride=2, bias=False), nn.BatchNorm2d(cout, eps=_BN_EPS), nn.Identity())
+        super().__init__(nn.Conv2d(3, cout, 3, stride=2, bias=False), nn.BatchNorm2d(cout, eps=_BN_EPS, momentum=_BN_MOM), nn.Identity())
 
 
 class EfficientNetExtractor(HipModule):

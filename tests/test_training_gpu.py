@@ -953,3 +953,153 @@ def test_cvt_pairwise_baselines_still_refuse_to_train(cuda):
     batch = {k: v.to(cuda) for k, v in synth.opv2v_batch(agents=2, cams=2, image=128, max_cav=3, seed=cases.SEED).items()}
     with pytest.raises(CobevtHipError):
         m(batch)
+
+
+def _fwd_bwd(fn, x0, w):
+    x = x0.clone().requires_grad_(True)
+    y = fn(x)
+    (y.float() * w).sum().backward()
+    return y.detach(), x.grad.detach().clone()
+
+
+def test_swish_depthwise_resize_vs_torch(cuda):
+    """the nuScenes-path Functions of csrc/train_nusc.hip against torch's own differentiable ops on the device: swish (fp32 / bf16),
+    the depthwise convolution with TensorFlow-"same" static padding (3x3 / 5x5, stride 1 / 2, odd sizes, a pad that leaves input rows
+    unused), the align_corners bilinear resize (its backward is the adjoint kernel)"""
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(31)
+    with torch.enable_grad():
+        # swish
+        for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
+            x0 = (torch.randn(2, 24, 7, 9, generator=g) * 3).to(cuda).to(dt).contiguous(memory_format=torch.channels_last)
+            w = torch.randn(x0.shape, generator=g).to(cuda)
+            got = _fwd_bwd(lambda t: ag.swish(t).float(), x0, w)
+            ref = _fwd_bwd(lambda t: (t.float() * torch.sigmoid(t.float())), x0, w)
+            assert_close(got[0], ref[0], tol, "swish forward %s" % dt)
+            assert_close(got[1].float(), ref[1].float(), tol, "swish backward %s" % dt)
+        # depthwise
+        for c, k, stride, pad, h, w_ in ((16, 3, 1, (1, 1), 9, 11), (24, 5, 2, (1, 2), 12, 15), (8, 3, 2, (0, 1), 10, 13), (32, 5, 1, (2, 2), 7, 8),
+                                         (8, 3, 2, (0, 0), 10, 10)):
+            conv = torch.nn.Conv2d(c, c, k, stride=stride, groups=c, bias=False).to(cuda)
+            x0 = torch.randn(2, c, h, w_, generator=g).to(cuda)
+            def run(fn):
+                conv.zero_grad()
+                x = x0.clone().requires_grad_(True)
+                y = fn(x)
+                wgt = synth.procedural_input("dw.w%d%d" % (c, k), tuple(y.shape), 3).to(cuda)
+                (y * wgt).sum().backward()
+                return y.detach(), x.grad.clone(), conv.weight.grad.clone()
+            got = run(lambda x: ag.depthwise_conv2d(x, conv, pad))
+            ref = run(lambda x: F.conv2d(F.pad(x, (pad[0], pad[1], pad[0], pad[1])), conv.weight, None, stride=stride, groups=c))
+            for a, b, what in zip(got, ref, ("forward", "dX", "dW")):
+                assert_close(a, b, 1e-4, "depthwise %dx%d s%d pad %s %s" % (k, k, stride, pad, what))
+        # bilinear resize
+        x0 = torch.randn(2, 16, 5, 7, generator=g).to(cuda)
+        w = torch.randn(2, 16, 10, 14, generator=g).to(cuda)
+        got = _fwd_bwd(lambda t: ag.resize_bilinear(t, 10, 14), x0, w)
+        ref = _fwd_bwd(lambda t: F.interpolate(t, size=(10, 14), mode="bilinear", align_corners=True), x0, w)
+        assert_close(got[0], ref[0], 1e-5, "bilinear resize forward")
+        assert_close(got[1], ref[1], 1e-5, "bilinear resize backward (adjoint)")
+
+
+def _focal_reference(pred, label, vis, label_indices, min_visibility, alpha, gamma):
+    """torch restatement of BinarySegmentationLoss / CenterLoss (nuscenes losses.py:27-84) over fvcore's published sigmoid_focal_loss"""
+    F = torch.nn.functional
+    if label_indices is not None:
+        label = torch.stack([label[:, idx].max(1)[0] for idx in label_indices], 1)
+    p = torch.sigmoid(pred)
+    ce = F.binary_cross_entropy_with_logits(pred, label, reduction="none")
+    pt = p * label + (1 - p) * (1 - label)
+    loss = ce * (1 - pt) ** gamma
+    if alpha >= 0:
+        loss = (alpha * label + (1 - alpha) * (1 - label)) * loss
+    if min_visibility is not None:
+        mask = (vis >= min_visibility)[:, None].expand_as(loss)
+        loss = loss[mask]
+    return loss.mean()
+
+
+def test_sigmoid_focal_losses_backward(cuda):
+    """BinarySegmentationLoss (grouped labels, visibility mask, alpha) and CenterLoss (soft labels) of the nuScenes experiments: value and
+    gradient w.r.t. the logits against the torch restatement; MultipleLoss sums them and back-propagates"""
+    from cobevt_amd.host import nuscenes as nu
+    g = torch.Generator().manual_seed(8)
+    b, h, w = 2, 20, 24
+    pred_bev, pred_ctr = torch.randn(b, 1, h, w, generator=g) * 2, torch.randn(b, 1, h, w, generator=g) * 2
+    label = (torch.rand(b, 12, h, w, generator=g) > 0.7).float()
+    center = torch.rand(b, 1, h, w, generator=g)
+    vis = torch.randint(0, 5, (b, h, w), generator=g).to(torch.uint8)
+    batch = {"bev": label.to(cuda), "center": center.to(cuda), "visibility": vis.to(cuda)}
+    losses = nu.MultipleLoss({"bev": nu.BinarySegmentationLoss(label_indices=[[4, 5, 6, 7, 8, 10, 11]], min_visibility=2, alpha=0.25, gamma=2.0),
+                              "bev_weight": 1.0, "center": nu.CenterLoss(min_visibility=2, alpha=-1.0, gamma=2.0), "center_weight": 0.1})
+    with torch.enable_grad():
+        pb, pc = _leaf(pred_bev, cuda), _leaf(pred_ctr, cuda)
+        total, parts = losses({"bev": pb, "center": pc}, batch)
+        total.backward()
+        rb, rc = _leaf(pred_bev), _leaf(pred_ctr)
+        ref_b = _focal_reference(rb, label, vis, [[4, 5, 6, 7, 8, 10, 11]], 2, 0.25, 2.0)
+        ref_c = _focal_reference(rc, center, vis, None, 2, -1.0, 2.0)
+        (ref_b + 0.1 * ref_c).backward()
+    assert abs(float(parts["bev"]) - float(ref_b)) <= 1e-5 * max(1.0, abs(float(ref_b)))
+    assert abs(float(parts["center"]) - float(ref_c)) <= 1e-5 * max(1.0, abs(float(ref_c)))
+    assert_close(pb.grad, rb.grad, 1e-4, "d BinarySegmentationLoss / d logits")
+    assert_close(pc.grad, rc.grad, 1e-4, "d CenterLoss / d logits")
+
+
+def _nuscenes_model(cuda):
+    import copy
+    from cobevt_amd.host import nuscenes as nu
+    c = cases.NUSCENES
+    backbone = nu.EfficientNetExtractor(["reduction_2", "reduction_3", "reduction_4"], *c["image"])
+    enc = nu.PyramidAxialEncoder(backbone, **copy.deepcopy(c["encoder"]))
+    return _train_module(nu.CrossViewTransformer(enc, nu.Decoder(**c["decoder"]), c["dim_last"], c["outputs"]), cuda)
+
+
+def test_nuscenes_sinbevt_trains_gradients_vs_oracle(cuda):
+    """The nuScenes SinBEVT model (BASELINE configs[1]: 6 cameras 224 x 480, EfficientNet-B4 extractor, PyramidAxialEncoder, Decoder, two
+    heads) in train() mode against torch autograd through the oracles (oracle/efficientnet.py + oracle/nuscenes.py): logits and every
+    parameter gradient.  BatchNorms frozen and drop-connect off (the oracles are the eval-mode function); gates as for CorpBEVT."""
+    import oracle.efficientnet as o_eff
+    import oracle.nuscenes as o_nu
+    c = cases.NUSCENES
+    m = _freeze_bn(_nuscenes_model(cuda))
+    for group in list(m.encoder.backbone.layers)[1:]:
+        group.args = [[0.0] for _ in group.args]
+    sd = _oracle_sd(m)
+    _, image, intr, ext = cases.nuscenes_inputs()
+    with torch.enable_grad():
+        feats = o_eff.efficientnet_extractor(sd, "encoder.backbone.", ["reduction_2", "reduction_3", "reduction_4"], o_nu.normalize(image.flatten(0, 1)))
+        ref = o_nu.cross_view_transformer(sd, c["encoder"], len(c["decoder"]["blocks"]), c["outputs"], feats, intr, ext)
+        out = m({"image": image.to(cuda), "intrinsics": intr.to(cuda), "extrinsics": ext.to(cuda)})
+        out_ref = torch.cat([ref["bev"], ref["center"]], 1)
+        _compare(m, sd, torch.cat([out["bev"], out["center"]], 1), out_ref, [], [], "nuScenes SinBEVT", grad_tol=2e-2, rms_tol=5e-3)
+
+
+def test_nuscenes_training_steps(cuda):
+    """model_module.py:35-60 in miniature: full train() mode (BatchNorm batch statistics, drop-connect, attention dropout), MultipleLoss of
+    BinarySegmentationLoss + CenterLoss, backward, AdamW; the loss goes down and the bf16 inference path follows the updated parameters"""
+    from cobevt_amd.host import nuscenes as nu
+    m = _nuscenes_model(cuda)
+    _, image, intr, ext = cases.nuscenes_inputs()
+    batch = {"image": image.to(cuda), "intrinsics": intr.to(cuda), "extrinsics": ext.to(cuda)}
+    g = torch.Generator().manual_seed(4)
+    batch["bev"] = (torch.rand(1, 12, 200, 200, generator=g) > 0.8).float().to(cuda)
+    batch["center"] = torch.rand(1, 1, 200, 200, generator=g).to(cuda)
+    batch["visibility"] = torch.randint(0, 5, (1, 200, 200), generator=g).to(torch.uint8).to(cuda)
+    losses = nu.MultipleLoss({"bev": nu.BinarySegmentationLoss(label_indices=[[4, 5, 6, 7, 8, 10, 11]], min_visibility=2, alpha=-1.0, gamma=2.0),
+                              "bev_weight": 1.0, "center": nu.CenterLoss(min_visibility=2, alpha=-1.0, gamma=2.0), "center_weight": 0.1})
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    seen = []
+    with torch.enable_grad():
+        for _ in range(5):
+            opt.zero_grad(set_to_none=True)
+            total, _ = losses(m(batch), batch)
+            total.backward()
+            opt.step()
+            seen.append(float(total.detach()))
+    assert np.isfinite(seen).all() and seen[-1] < seen[0], seen
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters() if p.requires_grad)
+    m.eval()
+    with torch.no_grad():
+        y = m(batch)
+    assert torch.isfinite(y["bev"]).all() and tuple(y["bev"].shape) == (1, 1, 200, 200)
