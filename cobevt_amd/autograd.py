@@ -915,6 +915,38 @@ class SigmoidFocalLossFn(torch.autograd.Function):
         return dp, None, None, None, None
 
 
+class PairwiseWarpFn(torch.autograd.Function):
+    """ops.pairwise_warp (every agent's map in every other agent's frame, v2v_fuse.py:59-103) with its adjoint as backward: x (N, H, W, C)
+    channels-last fp32 -> nb (B, L, L, H, W, C); the ROI mask carries no gradient (ops.pairwise_warp returns it)"""
+
+    @staticmethod
+    def forward(ctx, x, pairwise, record_len, max_cav, discrete_ratio, downsample_rate):
+        nb, _ = ops.pairwise_warp(x, pairwise, record_len, max_cav, discrete_ratio, downsample_rate)
+        ctx.save_for_backward(pairwise, record_len)
+        ctx.cfg = (tuple(x.shape), int(max_cav), float(discrete_ratio), float(downsample_rate))
+        return nb
+
+    @staticmethod
+    def backward(ctx, dnb):
+        pairwise, record_len = ctx.saved_tensors
+        (n, h, w, c), l, dr, ds = ctx.cfg
+        dnb = dnb.contiguous()
+        dx = torch.zeros((n, h, w, c), device=dnb.device, dtype=torch.float32)
+        rc = _L.load().cobevt_pairwise_warp_bwd(_p(dnb), _p(pairwise), _p(record_len), _p(dx), ops.dcode(dnb.dtype), record_len.shape[0], l,
+                                                h, w, c, ctypes.c_float(dr), ctypes.c_float(ds), _stream())
+        _L.check(rc, "cobevt_pairwise_warp_bwd")
+        return dx.to(dnb.dtype), None, None, None, None, None
+
+
+def conv2d_weight(x, weight, bias, stride=1, pad=0):
+    """the training convolution on a weight TENSOR (a differentiable function of parameters: sliced / re-indexed taps) instead of an
+    nn.Conv2d container"""
+    if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        with torch.autocast("cuda", enabled=False):
+            return Conv2dFn.apply(x.to(torch.bfloat16), _master(weight).contiguous(), bias, stride, pad)
+    return Conv2dFn.apply(x, _master(weight).contiguous(), bias, stride, pad)
+
+
 def _env_flags():
     """COBEVT_TRAIN_FLAGS="USE_TORCH_OPERAND_PREP=1,USE_WGRAD_BLOCKED=0": the module's USE_* switches from the environment (same-job A/B
     runs of tools/train_probe.py; never set in production)"""

@@ -77,6 +77,51 @@ __global__ __launch_bounds__(256) void pairwise_warp_kernel(const T* x, const fl
     }
 }
 
+// Adjoint of pairwise_warp_kernel w.r.t. x (training: torch autograd through F.affine_grid + F.grid_sample in the reference's
+// warp_affine, v2v_fuse.py:95-103): dx[agent j] += the bilinear weights x dnb[b][i][j]; dx fp32 (N, H, W, C), zero-initialised.
+template <typename T>
+__global__ __launch_bounds__(256) void pairwise_warp_bwd_kernel(const T* dnb, const float* pairwise, const int* record_len, float* dx,
+                                                                int B, int L, int H, int W, int C, float discrete_ratio,
+                                                                float downsample_rate) {
+    const int G = C >> 3;
+    const int v = blockIdx.y;
+    const int j = v % L, i = (v / L) % L, b = v / (L * L);
+    __shared__ Affine th_feat;
+    __shared__ int src_agent;
+    if (threadIdx.x == 0) {
+        const float* m = pairwise + (((size_t)b * L + j) * L + i) * 16;
+        th_feat = sttf_theta(m, discrete_ratio, downsample_rate, /*Hd=*/W, /*Wd=*/H);
+        int off, n;
+        sample_rows(record_len, b, off, n);
+        src_agent = (i < n && j < n) ? off + j : -1;
+    }
+    __syncthreads();
+    const int srcb = src_agent;
+    if (srcb < 0) return;
+    const int gid = (blockIdx.x * 256 + threadIdx.x) / G;
+    const int gl = threadIdx.x & (G - 1);
+    if (gid >= H * W) return;
+    const int h = gid / W, w = gid - h * W;
+    float ix, iy;
+    affine_sample_xy(th_feat, w, H - 1 - h, W, H, ix, iy);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    float g[8];
+    load8<T>(dnb + ((size_t)v * H * W + gid) * C + gl * 8, g);
+    float* dst = dx + (size_t)srcb * H * W * C + gl * 8;
+    auto tap = [&](int xx, int yy, float wgt) {
+        if (xx < 0 || xx >= H || yy < 0 || yy >= W || wgt == 0.f) return;
+        float* q = dst + ((size_t)(H - 1 - xx) * W + yy) * C;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(q + e, g[e] * wgt);
+    };
+    tap(x0, y0, wx0 * wy0);
+    tap(x1, y0, wx1 * wy0);
+    tap(x0, y1, wx0 * wy1);
+    tap(x1, y1, wx1 * wy1);
+}
+
 // V2VNet message aggregation (v2v_fuse.py:108-119): out[(b, i)] = reduce over j < N_b of (msg[b][i][j] + ego[(b, i)]) * roi[b][i][j]
 // with reduce = mean (mode 0) or max (mode 1); written at agent row off_b + i of the un-grouped layout.
 template <typename T>
@@ -196,6 +241,18 @@ extern "C" int cobevt_pairwise_warp(const void* x, const float* pairwise, const 
     const dim3 grid((unsigned)((items + 255) / 256), (unsigned)(B * L * L));
     if (dtype == 0) hipLaunchKernelGGL(pairwise_warp_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, pairwise, record_len, (bf16_t*)nb, roi, B, L, H, W, C, discrete_ratio, downsample_rate);
     else if (dtype == 1) hipLaunchKernelGGL(pairwise_warp_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, pairwise, record_len, (float*)nb, roi, B, L, H, W, C, discrete_ratio, downsample_rate);
+    else return COBEVT_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+extern "C" int cobevt_pairwise_warp_bwd(const void* dnb, const float* pairwise, const int* record_len, float* dx, int dtype, int B, int L,
+                                        int H, int W, int C, float discrete_ratio, float downsample_rate, hipStream_t stream) {
+    if (!dnb || !pairwise || !record_len || !dx) return COBEVT_ERR_ARG;
+    if (!group_ok(C) || B < 1 || L < 1 || H < 1 || W < 1 || H != W || (long)B * L * L > 65535) return COBEVT_ERR_SHAPE;
+    const long items = (long)H * W * (C >> 3);
+    const dim3 grid((unsigned)((items + 255) / 256), (unsigned)(B * L * L));
+    if (dtype == 0) hipLaunchKernelGGL(pairwise_warp_bwd_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)dnb, pairwise, record_len, dx, B, L, H, W, C, discrete_ratio, downsample_rate);
+    else if (dtype == 1) hipLaunchKernelGGL(pairwise_warp_bwd_kernel<float>, grid, dim3(256), 0, stream, (const float*)dnb, pairwise, record_len, dx, B, L, H, W, C, discrete_ratio, downsample_rate);
     else return COBEVT_ERR_ARG;
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

@@ -621,3 +621,115 @@ def nusc_cross_view_transformer(model, batch):
     hidden = _conv_bn(y, model.to_logits[0], model.to_logits[1], relu=True)
     logits = ag.conv2d(hidden, model.to_logits[3])
     return {name: logits[:, lo:hi] for name, (lo, hi) in model.outputs.items()}
+
+
+# ----------------------------------------------------------------------------------------------
+# the pairwise-warp fusions of the V2VNet / DiscoNet baselines (fusion_modules/v2v_fuse.py:47-144, disconet_fuse.py:82-168) in train()
+# mode.  As in the inference path the maps stay in their original orientation: the warp undoes the reference's transposition + flip,
+# the 3x3 convolutions run with re-indexed taps W~[u][v] = W[v][2 - u] (a differentiable view of the parameter).
+# ----------------------------------------------------------------------------------------------
+def _flipped_taps(w):
+    return w.transpose(2, 3).flip(2)
+
+
+def _agent_index(rl, n):
+    """sample b and slot i of each of the n un-grouped agent rows, on the device (no host round trip)"""
+    rl64 = rl.to(torch.int64)
+    ends = torch.cumsum(rl64, 0)
+    a = torch.arange(n, device=rl.device)
+    b_of = torch.searchsorted(ends, a, right=True)
+    return b_of, a - (ends - rl64)[b_of]
+
+
+def _pairwise_inputs(m, x, record_len, pairwise_t_matrix):
+    rl = torch.as_tensor(record_len).to(device=x.device, dtype=torch.int32)
+    pw = pairwise_t_matrix.to(device=x.device, dtype=torch.float32).contiguous()
+    return rl, pw
+
+
+def _warp_pairs(m, feats, pw, rl, l):
+    """feats (N, C, H, W) -> nb (B, L, L, H, W, C) differentiable in feats, roi (B, L, L, H, W) (no gradient)"""
+    with torch.autocast("cuda", enabled=False):
+        fl = feats.float().permute(0, 2, 3, 1).contiguous()
+        nb = ag.PairwiseWarpFn.apply(fl, pw, rl, l, m.discrete_ratio, m.downsample_rate)
+        with torch.no_grad():
+            _, roi = ops.pairwise_warp(fl.detach(), pw, rl, l, m.discrete_ratio, m.downsample_rate)
+    return nb, roi
+
+
+def v2vnet_fusion(m, x, record_len, pairwise_t_matrix):
+    """V2VNetFusion.forward (v2v_fuse.py:47-144): x (sum(record_len), C, H, W) -> (B, H, W, C)"""
+    _check(x)
+    rl, pw = _pairwise_inputs(m, x, record_len, pairwise_t_matrix)
+    b, l = pw.shape[:2]
+    n, c, h, w = x.shape
+    b_of, i_of = _agent_index(rl, n)
+    valid = (torch.arange(l, device=x.device)[None, :] < rl[:, None])[b_of]                       # (n, l): slot j holds an agent
+    count = rl[b_of].to(torch.float32)[:, None, None, None]
+    wt = _flipped_taps(m.msg_cnn.weight)
+    cell = m.conv_gru.cell_list[0]
+    feats = x
+    for _ in range(m.num_iteration):
+        nb, roi = _warp_pairs(m, feats, pw, rl, l)
+        # message = msg_cnn(cat[neighbour, ego]): the ego half (and the bias) is the same for every neighbour
+        msg = ag.conv2d_weight(nb.reshape(b * l * l, h, w, c).permute(0, 3, 1, 2), wt[:, :c], None, 1, 1)
+        ego = ag.conv2d_weight(feats, wt[:, c:], m.msg_cnn.bias, 1, 1)
+        msg_a = msg.reshape(b, l, l, c, h, w)[b_of, i_of]                                            # (n, l, c, h, w)
+        val = (msg_a + ego[:, None]) * roi[b_of, i_of][:, :, None]
+        if m.agg_operator == "avg":
+            agg = (val * valid[:, :, None, None, None]).sum(1) / count
+        else:
+            agg = val.masked_fill(~valid[:, :, None, None, None], float("-inf")).max(1)[0]
+        if m.gru_flag:
+            # one ConvGRU step from h = 0 (convgru.py:57-78): h' = sigmoid(update) * tanh(candidate), both from the 2C input channels only
+            wg, wc = _flipped_taps(cell.conv_gates.weight), _flipped_taps(cell.conv_can.weight)
+            gw = torch.cat([wg[c:2 * c, :2 * c], wc[:, :2 * c]], dim=0)
+            gb = torch.cat([cell.conv_gates.bias[c:2 * c], cell.conv_can.bias], dim=0)
+            g = ag.conv2d_weight(torch.cat([feats.float(), agg.float()], dim=1), gw, gb, 1, 1)
+            feats = torch.sigmoid(g[:, :c]) * torch.tanh(g[:, c:])
+        else:
+            feats = feats + agg
+    rl64 = rl.to(torch.int64)
+    out = feats.index_select(0, torch.cumsum(rl64, 0) - rl64)
+    return ag.linear(out.permute(0, 2, 3, 1), m.mlp)
+
+
+def disconet_fusion(m, x, record_len, pairwise_t_matrix, record_len_host=None):
+    """DiscoNetFusion.forward (disconet_fuse.py:82-168): x (sum(record_len), C, H, W) -> (B, H, W, C).  PixelWeightedFusionSoftmax runs once per
+    target agent on its N_b neighbours, as in the reference - its BatchNorms then see the same batches (statistics over N_b x H x W, running
+    statistics updated call by call) - which needs the agent counts on the host (the reference reads them there too, :98-104)."""
+    _check(x)
+    rl, pw = _pairwise_inputs(m, x, record_len, pairwise_t_matrix)
+    lens = [int(v) for v in (record_len_host if record_len_host is not None else record_len)]
+    b, l = pw.shape[:2]
+    n, c, h, w = x.shape
+    f = m.pixel_weighted_fusion
+    feats = x
+    for _ in range(m.num_iteration):
+        nb, roi = _warp_pairs(m, feats, pw, rl, l)
+        rows, a = [], 0
+        for bi, nb_count in enumerate(lens):
+            for i in range(nb_count):
+                neigh = nb[bi, i, :nb_count].permute(0, 3, 1, 2)                                     # (N_b, c, h, w)
+                mask = roi[bi, i, :nb_count][:, None]                                                 # (N_b, 1, h, w)
+                y = torch.cat([neigh, feats[a][None].float().expand(nb_count, c, h, w)], dim=1)
+                y = _conv_bn(y, f.conv1_1, f.bn1_1, relu=True)
+                y = _conv_bn(y, f.conv1_2, f.bn1_2, relu=True)
+                y = _conv_bn(y, f.conv1_3, f.bn1_3, relu=True)
+                s = _F.relu(ag.conv2d(y, f.conv1_4)).float()
+                if m.use_mask:
+                    s = s.masked_fill(mask == 0, float("-inf"))
+                rows.append((torch.softmax(s, dim=0) * neigh * mask).sum(0))
+                a += 1
+        feats = torch.stack(rows, 0)
+    rl64 = rl.to(torch.int64)
+    out = feats.index_select(0, torch.cumsum(rl64, 0) - rl64)
+    return ag.linear(out.permute(0, 2, 3, 1), m.mlp)
+
+
+def cvt_pairwise_model(model, batch_dict):
+    """CrossViewTransformerV2VNet / DiscoNet .forward (cross_view_transformer_{v2vnet,disconet}.py:41-68) as a differentiable graph"""
+    f = cvt_encode_agents(model, batch_dict).squeeze(1)
+    fused = model._fuse_train(f, batch_dict["record_len"], batch_dict["pairwise_t_matrix"], batch_dict.get("record_len_host"))   # (B, H, W, C)
+    y = naive_decoder(model.decoder, fused.permute(0, 3, 1, 2))
+    return bev_seg_head(model.seg_head, y, y.shape[0], 1)

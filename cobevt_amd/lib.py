@@ -33,6 +33,7 @@ SIGNATURES = {
     "cobevt_linear_rows": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_long_p, ctypes.c_float, _vp]),
     "cobevt_attn_mlp_chain": (ctypes.c_int, [_vp] * 14 + [_c_int_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
     "cobevt_pairwise_warp": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_float, _vp]),
+    "cobevt_pairwise_warp_bwd": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_float, _vp]),
     "cobevt_agent_message_reduce": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int] * 6 + [_vp]),
     "cobevt_gru_zero_state": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_int, _vp]),
     "cobevt_agent_softmax_sum": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp] + [ctypes.c_int] * 6 + [_vp]),

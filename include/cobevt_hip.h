@@ -293,6 +293,10 @@ int cobevt_from_nhwc(const void* in, int in_dtype, void* out, int out_dtype, int
  *   (disconet_fuse.py:35-42,141-150); score = column 0 of a (B*L*L*H*W, lds) matrix. */
 int cobevt_pairwise_warp(const void* x, const float* pairwise, const int* record_len, void* nb, float* roi, int dtype, int B, int L,
                          int H, int W, int C, float discrete_ratio, float downsample_rate, hipStream_t stream);
+/* Adjoint of cobevt_pairwise_warp w.r.t. x (training; torch autograd through warp_affine in the reference): dnb (B, L, L, H, W, C) ->
+ * dx fp32 (N, H, W, C), zero-initialised; the same bilinear sample positions, scattered with fp32 atomics. */
+int cobevt_pairwise_warp_bwd(const void* dnb, const float* pairwise, const int* record_len, float* dx, int dtype, int B, int L, int H,
+                             int W, int C, float discrete_ratio, float downsample_rate, hipStream_t stream);
 int cobevt_agent_message_reduce(const void* msg, const void* ego, const float* roi, const int* record_len, void* out, int dtype,
                                 int B, int L, int HW, int C, int mode, hipStream_t stream);
 int cobevt_gru_zero_state(const void* in, void* out, int dtype, long rows, int C, hipStream_t stream);

@@ -944,15 +944,24 @@ def test_cvt_baselines_train_gradients_vs_oracle(cuda, kind, core, fwd):
         _compare(m, sd, out, out_ref, [], [], "CVT " + kind, grad_tol=2e-2, rms_tol=5e-3)
 
 
-def test_cvt_pairwise_baselines_still_refuse_to_train(cuda):
-    """V2VNet / DiscoNet fusion (pairwise warps + ConvGRU / distillation weights) have forward kernels only: train() raises, loudly"""
+@pytest.mark.parametrize("kind,core,fwd", [("v2vnet", "cross_view_transformer_v2vnet", "cross_view_transformer_v2vnet_forward"),
+                                           ("disconet", "cross_view_transformer_disconet", "cross_view_transformer_disconet_forward")])
+def test_cvt_pairwise_baselines_train_gradients_vs_oracle(cuda, kind, core, fwd):
+    """V2VNet (ConvGRU message passing) and DiscoNet (pixel-weighted softmax fusion) on the CVT encoder in train() mode: the pairwise warp
+    with its adjoint kernel, the flipped-domain 3x3 convolutions as re-indexed views of the parameters, against torch autograd through
+    oracle/v2v.py (the reference's transposed + flipped formulation): logits and every parameter gradient, BatchNorms frozen"""
     import copy
+    import oracle.v2v as o_v2v
     from cobevt_amd.registry import create_model
-    cfg = synth.cvt_small_config("v2vnet")
-    m = _train_module(create_model({"model": {"core_method": "cross_view_transformer_v2vnet", "args": copy.deepcopy(cfg)}}), cuda)
-    batch = {k: v.to(cuda) for k, v in synth.opv2v_batch(agents=2, cams=2, image=128, max_cav=3, seed=cases.SEED).items()}
-    with pytest.raises(CobevtHipError):
-        m(batch)
+    cfg = synth.cvt_small_config(kind)
+    m = _freeze_bn(_train_module(create_model({"model": {"core_method": core, "args": copy.deepcopy(cfg)}}), cuda))
+    sd = _oracle_sd(m)
+    batch = synth.opv2v_batch(agents=2, cams=2, image=128, max_cav=3, seed=cases.SEED)
+    with torch.enable_grad():
+        out_ref = getattr(o_v2v, fwd)(sd, cfg, dict(batch))["dynamic_seg"]
+        out = m({k: v.to(cuda) for k, v in batch.items()})["dynamic_seg"]
+        assert_close(out, golden("gv17_cvt_baselines")[kind + "_dynamic_seg"], TOL, "train-mode forward vs the reference's logits")
+        _compare(m, sd, out, out_ref, [], [], "CVT " + kind, grad_tol=2e-2, rms_tol=5e-3)
 
 
 def _fwd_bwd(fn, x0, w):
