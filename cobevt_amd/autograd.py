@@ -1,12 +1,13 @@
-"""Training slice: torch.autograd.Functions over the HIP forward / backward kernels.
+"""Training path: torch.autograd.Functions over the HIP forward / backward kernels.
 
 The reference trains through torch autograd (opv2v/opencood/tools/train_camera.py:143-179: model.train(), loss.backward(),
-optimizer.step()).  Here the attention core (gathered window / dilated-grid partition, relative-position bias, key mask,
-softmax, PV, partition reverse), LayerNorm and GELU run as HIP kernels in both directions (fp32 storage, exact-fp32 MFMA:
-csrc/attention.hip + attention_bwd.hip, csrc/elementwise.hip + train_rows.hip); the dense projections are plain GEMMs and go
-to the library (rocBLAS through torch.matmul) in both directions.  The kernels of this slice compute in fp32 (the bf16 inference
-layouts - fragment-ordered weights, folded norms - are not differentiable containers); under torch autocast their inputs are cast
-to fp32 at the Function boundary (see _amp_fwd).
+optimizer.step(); nuscenes/cross_view_transformer/model/model_module.py:35-60).  Here the attention core (gathered window / dilated-grid
+partition, relative-position bias, key mask, softmax, PV, partition reverse; optionally with its log-sum-exp as a differentiable output),
+LayerNorm, GELU, swish, every convolution and dense projection (implicit-GEMM forward / input gradient, cobevt_conv_wgrad[_blocked] weight
+gradient, operands prepared by csrc/train_prep.hip), the depthwise convolution, BatchNorm (+ residual + ReLU), max-pool, PixelUnshuffle,
+nearest / bilinear resizes, the STTF and pairwise warps and the losses run as HIP kernels in both directions - no vendor GEMM, no MIOpen.
+The attention / LayerNorm / GELU kernels compute in fp32 (their inputs are cast at the Function boundary under autocast, see _amp_fwd);
+the convolution family follows a bf16 autocast region (bf16 storage, fp32 master weights and gradients).
 
 No CPU path: every Function raises on CPU tensors (lib.CobevtHipError) like the inference ops do.
 """

@@ -67,8 +67,9 @@ class HipModule(nn.Module):
 
     def _require_inference(self, *tensors):
         if self.training:
-            raise CobevtHipError("%s implements the inference hot path only: call .eval() first (training is out "
-                                 "of scope, SURVEY.md §8f)" % type(self).__name__)
+            raise CobevtHipError("%s.forward is the fused inference path: call .eval() first.  In train() mode this module runs "
+                                 "inside its model's differentiable graph (cobevt_amd/host/training.py; every registry model trains), "
+                                 "not through this stand-alone forward" % type(self).__name__)
         for t in tensors:
             if t is not None and not t.is_cuda:
                 raise CobevtHipError("%s.forward needs ROCm device tensors; the HIP path has no CPU fallback"
