@@ -164,3 +164,19 @@ def test_invalidate_plans_sees_dot_data_writes():
     assert len(built) == 3
     m.load_state_dict(m.state_dict())
     assert not m._plan_cache
+
+
+def test_driver_entry_points_compile_and_exist():
+    """__graft_entry__.build / smoke and bench.py are what the driver runs unattended: they must at least compile and import on a
+    machine without a GPU (a stray syntax error there fails the whole round silently for every other test)"""
+    import importlib
+    import os
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ("__graft_entry__.py", "bench.py"):
+        py_compile.compile(os.path.join(root, name), doraise=True)
+    for name in sorted(os.listdir(os.path.join(root, "tools"))):
+        if name.endswith(".py"):
+            py_compile.compile(os.path.join(root, "tools", name), doraise=True)
+    mod = importlib.import_module("__graft_entry__")
+    assert callable(mod.build) and callable(mod.smoke)
