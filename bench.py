@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the eager / fp32 / other-config legs")
+    ap.add_argument("--direct-probe", action="store_true", help=argparse.SUPPRESS)   # the isolated child job of direct_probe_child()
     return ap.parse_args()
 
 
@@ -360,16 +361,15 @@ def rank_table(rank, world, dev):
             "distinct_gpus": len({(r["device_index"], r["uuid"], r["pci_bus_id"]) for r in rows})}
 
 
-def gather_latency_leg(model, batch, rank, world, A, dev):
-    """the exchange on its own, both ways: microseconds per agent all-gather of the (A, 32, 32, 128) blocks (HIP events over
-    200 back-to-back exchanges, max over ranks)"""
+def gather_latency_leg(model, batch, rank, world, A, dev, which=("rccl", "direct")):
+    """the exchange on its own: microseconds per agent all-gather of the (A, 32, 32, 128) blocks (HIP events over 200 back-to-back
+    exchanges, max over ranks) through RCCL and / or the direct peer-window path"""
     feats = model.encode_agents(cdist.take_agents(batch, [0]))
     block, dt = tuple(feats.shape[1:]), feats.dtype
     mine = cdist.agents_of_rank(rank, world, A)
     local = torch.zeros((max(1, len(mine)),) + block, device=dev, dtype=dt)
     staging = torch.zeros((cdist.slots_per_rank(world, A),) + block, device=dev, dtype=dt)
     full = torch.empty((A,) + block, device=dev, dtype=dt)
-    ex = cdist.DirectExchange(block, dt, A, rank, world, device=dev).plan(*cdist.direct_plan_strong(rank, world, A))
 
     def timed(fn, n=200):
         for _ in range(20):
@@ -386,15 +386,49 @@ def gather_latency_leg(model, batch, rank, world, A, dev):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         return round(t.item(), 2)
 
-    out = {"bytes_per_agent_block": int(local[0].numel() * local.element_size()),
-           "rccl_all_gather_into_tensor": timed(lambda: cdist.exchange_features_strong(local, len(mine), rank, world, A, out=full,
-                                                                                       staging=staging)),
-           "direct_peer_write": timed(lambda: ex(local))}
-    st, _ = ex.status()
-    if st:
-        out["direct_peer_write_status"] = st
-    ex.close()
+    out = {"bytes_per_agent_block": int(local[0].numel() * local.element_size())}
+    if "rccl" in which:
+        out["rccl_all_gather_into_tensor"] = timed(lambda: cdist.exchange_features_strong(local, len(mine), rank, world, A, out=full,
+                                                                                          staging=staging))
+    if "direct" in which:
+        ex = cdist.DirectExchange(block, dt, A, rank, world, device=dev).plan(*cdist.direct_plan_strong(rank, world, A))
+        out["direct_peer_write"] = timed(lambda: ex(local))
+        st, _ = ex.status()
+        if st:
+            out["direct_peer_write_status"] = st
+        ex.close()
     return out
+
+
+def direct_probe_child(args, world):
+    """The direct peer-window legs (latency mode over the hipIpc windows, the exchange microbenchmark) as a job of their own: rank 0 of
+    the finished main job starts a second `torch.distributed.run` with --direct-probe and merges its JSON line.  The path maps other GPUs'
+    memory into every rank and polls flags in it; it has run between processes on ONE GPU and in the gloo dry run only, so on the first
+    real multi-GPU node a fault in it (a GPU page fault aborts the process, nothing to catch) must not take the RCCL headline down with
+    it.  Returns the child's dict, or {"error": ...}."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME",
+            "MASTER_ADDR", "MASTER_PORT")
+    env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith("TORCHELASTIC_")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.steps), "--warmup",
+           str(args.warmup), "--dtype", args.dtype, "--agents", str(args.agents), "--direct-probe"] + (["--no-graph"] if args.no_graph else [])
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    except subprocess.TimeoutExpired:
+        return {"error": "direct-exchange probe job timed out after 900 s"}
+    for line in reversed(p.stdout.splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                break
+    return {"error": "direct-exchange probe job failed (exit code %d): %s" % (p.returncode, p.stderr.strip()[-400:])}
 
 
 def camera_leg(args, mode, model, cfg, rank, world, dev, gather="rccl", depth=None):
@@ -541,6 +575,23 @@ def main():
     # latency over RCCL and over the direct peer-window path.
     mode = args.mode or ("throughput" if world == 1 else "both")
     ranks = rank_table(rank, world, dev)
+    if args.direct_probe:                   # the child job of direct_probe_child(): only the direct peer-window legs
+        if world < 2:
+            raise SystemExit("--direct-probe is the multi-rank child job of bench.py")
+        probe = {}
+        try:
+            r = camera_leg(args, "latency", model, cfg, rank, world, dev, gather="direct")
+            probe["latency_mode_direct_gather"] = {k: r[0][k] for k in ("value", "unit", "ms_per_step", "ms_per_step_median", "scaling", "mode", "config")}
+            safe(probe, "all_gather_us", lambda: gather_latency_leg(model, r[3], rank, world, A, dev, which=("direct",)))
+        except Exception as e:  # noqa: BLE001
+            torch.cuda.synchronize()
+            probe["latency_mode_direct_gather"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        probe["rccl_ranks"] = ranks
+        if rank == 0:
+            print(json.dumps(probe), flush=True)
+        torch.distributed.destroy_process_group()
+        return
+    isolate_direct = False
     if world > 1 and mode in ("both", "latency"):
         result, runner, timed, batch, full, in_flight = camera_leg(args, "latency", model, cfg, rank, world, dev, gather=args.gather)
         other_gather = "direct" if args.gather == "rccl" else "rccl"
@@ -554,9 +605,15 @@ def main():
                 return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if mode == "both":
             result["latency_mode_unpipelined"] = side("depth1", gather=args.gather, depth=1)
-            result["latency_mode_%s_gather" % other_gather] = side("other", gather=other_gather)
             result["throughput_mode"] = side("throughput", mode="throughput")
-            safe(result, "all_gather_us", lambda: gather_latency_leg(model, batch, rank, world, A, dev))
+            # the direct peer-window legs run in a job of their own after this one (direct_probe_child) unless the direct exchange
+            # IS the requested headline (--gather direct): a fault there must not cost the RCCL numbers
+            isolate_direct = args.gather == "rccl"
+            if isolate_direct:
+                safe(result, "all_gather_us", lambda: gather_latency_leg(model, batch, rank, world, A, dev, which=("rccl",)))
+            else:
+                result["latency_mode_%s_gather" % other_gather] = side("other", gather=other_gather)
+                safe(result, "all_gather_us", lambda: gather_latency_leg(model, batch, rank, world, A, dev))
     else:
         result, runner, timed, batch, full, in_flight = camera_leg(args, "throughput", model, cfg, rank, world, dev)
     result["rccl_ranks"] = ranks
@@ -631,10 +688,23 @@ def main():
             for k, v in parity.items():
                 if k != args.dtype:
                     result["parity_" + k] = v
+    if world > 1:
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+        torch.distributed.destroy_process_group()
+    if rank == 0 and isolate_direct:
+        # ranks 1.. have left; their GPUs are free for the probe job's ranks
+        probe = direct_probe_child(args, world)
+        if "error" in probe and "latency_mode_direct_gather" not in probe:
+            result["latency_mode_direct_gather"] = probe
+        else:
+            result["latency_mode_direct_gather"] = probe.get("latency_mode_direct_gather")
+            if isinstance(probe.get("all_gather_us"), dict) and isinstance(result.get("all_gather_us"), dict):
+                result["all_gather_us"].update({k: v for k, v in probe["all_gather_us"].items() if k.startswith("direct")})
+        result["direct_exchange_note"] = ("measured by a second torch.distributed.run job started by rank 0 after the main job "
+                                          "(bench.py --direct-probe): isolated from the RCCL legs")
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -95,4 +95,6 @@ def test_bench_spawns_its_own_ranks(cuda):
     assert res["rccl_ranks"]["backend"] == ("nccl" if two else "gloo")
     assert res["mode"] == "latency" and res["scaling"] == "strong" and "throughput_mode" in res
     assert res["throughput_mode"]["value"] > 0 and res["value"] > 0
-    assert "direct_peer_write" in res["all_gather_us"]
+    # the direct peer-window legs come from the isolated second job (bench.py --direct-probe) and are merged into the one line
+    assert "direct_peer_write" in res["all_gather_us"] and "rccl_all_gather_into_tensor" in res["all_gather_us"]
+    assert res["latency_mode_direct_gather"].get("value", 0) > 0, res["latency_mode_direct_gather"]

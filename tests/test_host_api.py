@@ -180,3 +180,22 @@ def test_driver_entry_points_compile_and_exist():
             py_compile.compile(os.path.join(root, "tools", name), doraise=True)
     mod = importlib.import_module("__graft_entry__")
     assert callable(mod.build) and callable(mod.smoke)
+
+
+def test_training_host_index_helpers():
+    """host/training.py: the (sample, slot) of every un-grouped agent row from record_len without a host round trip, and the choice of the
+    blocked weight-gradient form per convolution shape"""
+    import torch
+    from cobevt_amd import autograd as ag
+    from cobevt_amd.host import training
+    rl = torch.tensor([2, 1, 3], dtype=torch.int32)
+    b_of, i_of = training._agent_index(rl, 6)
+    assert b_of.tolist() == [0, 0, 1, 2, 2, 2] and i_of.tolist() == [0, 1, 0, 0, 1, 2]
+    assert ag.wgrad_blocked_mode(3, 1, 1, 64) == 0 and ag.wgrad_blocked_mode(1, 1, 0, 128) == 0
+    assert ag.wgrad_blocked_mode(3, 2, 1, 64) == 1 and ag.wgrad_blocked_mode(1, 2, 0, 64) == 1
+    assert ag.wgrad_blocked_mode(7, 2, 3, 3) == 2                       # the stem: 7 tap columns x 3 channels = 21 pseudo-channels
+    assert ag.wgrad_blocked_mode(7, 2, 3, 8) is None                     # 56 pseudo-channels do not fit one 32-lane operand
+    assert ag.wgrad_blocked_mode(3, 2, 0, 64) is None and ag.wgrad_blocked_mode(5, 1, 2, 64) is None
+    w = torch.arange(2 * 3 * 3 * 3, dtype=torch.float32).reshape(2, 3, 3, 3)
+    wt = training._flipped_taps(w)
+    assert all(float(wt[o, c, u, v]) == float(w[o, c, v, 2 - u]) for o in range(2) for c in range(3) for u in range(3) for v in range(3))
