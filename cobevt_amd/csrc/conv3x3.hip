@@ -13,6 +13,8 @@
 //       the tap's pixel offset.
 // Weights are laid out [Cout][chunk][tap][chunk channels] on the host so a tap's slice is contiguous.
 // Epilogue as in igemm.hip: folded-BN bias, residual add, ReLU, NHWC store or PixelUnshuffle(2) store.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace cobevt {
@@ -383,6 +385,28 @@ static int launch_conv3(Conv3Params p, hipStream_t stream) {
 // buffered across channel chunks -> one barrier per nine taps) and the fragments of the tap two steps ahead are
 // prefetched into a register ring while the current tap runs.
 // ---------------------------------------------------------------------------------------------------------------------
+// Where the global loads of the NEXT chunk's patch (and of the store pass's residual) are issued inside a chunk, and how their LDS
+// stores go out.  s_waitcnt vmcnt is in-order: every weight-fragment wait behind such a load is also a wait for it, and these come
+// from HBM / Infinity Cache (1.5-2k cycles under load) while the fragments are L2 hits - issued in front of tap 0 (the round-2 code)
+// the first fragment wait that covers them is tap 2's, ~1.1k cycles later; issued at tap T, right behind tap T + 2's fragment request,
+// it is tap T + 3's.  And the six ds_write_b128 per thread of that patch used to go out as ONE burst in tap 6, where both waves of
+// every SIMD sat in the LDS store path together: spread in equal shares over taps FIRST .. 8 they hide between the MFMAs.  Same-job A/B
+// (bit-identical outputs): 20 back-to-back launches of ONE layer in a replayed graph, i.e. input and weights hot in L2 / Infinity Cache
+// (tools/conv_sched_probe.py, profiles/r03_conv_sched_probe.txt): 256 -> 256 on 20 x 32 x 32 27.3 -> 25.4 us, 512 -> 512 on 20 x 16 x 16
+// 31.9 -> 25.9 us, 128 -> 128 on 20 x 64 x 64 34-37 -> 32 us (the spread stores are most of it; any load tap in 0..5 with any first store
+// tap in 3..7 within 1 %).  INSIDE THE FRAME, where every launch reads what the previous kernel just wrote (L2 is written back and
+// invalidated at kernel boundaries, so the patch and the residual come from the Infinity Cache and the same kernels take 29.8 us
+// instead of 25.4), the gain is 1-1.5 % per launch (30.22 -> 29.77 us, 28.82 -> 28.57 us, kernel trace of both builds in one job) and
+// the frame time does not move (5 alternating bench runs): the hot-cache microbenchmark overstated it.
+#ifndef COBEVT_CONV3_PLOAD_TAP
+#define COBEVT_CONV3_PLOAD_TAP 3
+#endif
+#ifndef COBEVT_CONV3_PSTORE_SPREAD
+#define COBEVT_CONV3_PSTORE_SPREAD 1
+#endif
+#ifndef COBEVT_CONV3_PSTORE_FIRST
+#define COBEVT_CONV3_PSTORE_FIRST 6      // spread form: the stores go out in equal shares over taps FIRST .. 8
+#endif
 #ifndef COBEVT_CONV3_KNOCK
 #define COBEVT_CONV3_KNOCK 0          // tools/conv_probe.py builds knock-out copies of this file (never the product .so)
 #endif
@@ -527,6 +551,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
             if (plds[it] >= 0)
                 *(uint4*)(dst + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : preg[it];
     };
+    constexpr int PSN = 9 - COBEVT_CONV3_PSTORE_FIRST;               // taps that carry stores
+    auto store_patch_part = [&](unsigned char* dst, int part) {      // one share of the pieces (part = 0 .. PSN - 1, compile-time after unrolling)
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it)
+            if (it % PSN == part && plds[it] >= 0)
+                *(uint4*)(dst + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : preg[it];
+    };
     auto load_b = [&](uint4 (&b)[KGW], int step) {
 #pragma unroll
         for (int g = 0; g < KGW; ++g) b[g] = wq[(size_t)step * (KG * 64) + g * 64];
@@ -579,11 +610,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
     else fill_patch_s2(0);
     __syncthreads();
     COBEVT_TRACE_MARK(1);
-    auto run_chunk = [&](int chunk) {
+    constexpr bool EARLY_RES = S == 1 && Elem<T>::kIsBf16 && MT <= 5;
+    Conv3Store<T, NT, MT * 32, BN> st;
+    auto coord = [&](int px, int& im, int& oy, int& ox) {
+        const int4 sc = *(const int4*)&stab[(px >> 5) * 4];      // branch-free: one 16-byte LDS read, no dependent waits
+        im = sc.x;
+        oy = sc.y * 2 + ((px >> 4) & 1); ox = sc.z * 16 + (px & 15);
+        return (sc.w != 0) & (oy < p.Ho) & (ox < p.Wo);
+    };
+    constexpr int PLT = (S == 1 && !HALF) ? COBEVT_CONV3_PLOAD_TAP : 0;
+    auto run_chunk = [&](int chunk, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;          // the peeled last chunk: its residual loads ride at tap PLT too
         const bool more = chunk + 1 < nchunk;
         unsigned char* pbuf = patch + (S == 1 && !HALF ? (chunk & 1) * C::PATCH_BYTES : 0);
         unsigned char* pother = patch + (S == 1 && !HALF ? ((chunk & 1) ^ 1) * C::PATCH_BYTES : 0);
-        if (S == 1 && !(COBEVT_CONV3_KNOCK & 8)) load_patch(more ? chunk + 1 : chunk);   // unconditional (clamped): counted vmcnt
+        if (S == 1 && PLT == 0 && !(COBEVT_CONV3_KNOCK & 8)) load_patch(more ? chunk + 1 : chunk);   // unconditional (clamped): counted vmcnt
         // A fragments run two k-groups ahead of the MFMAs in a three-slot register ring (9 * KGW groups per chunk, a
         // multiple of 3, so slots are static); sched_group_barrier pins the issue order "one ds_read, one MFMA", i.e. a
         // fragment is requested 2 * MT MFMAs (>= 320 cycles) before its first use.  A wave alone on its SIMD then
@@ -614,6 +655,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
 #endif
             if (!(COBEVT_CONV3_KNOCK & 1) || chunk == 0)
                 load_b(bq[(tap + PF) % R], step + PF < nsteps ? step + PF : nsteps - 1);
+            if (S == 1 && PLT > 0 && tap == PLT) {
+                if (LAST) { if (EARLY_RES && p.store_mode == 0) st.prepare(p, tid, n0, coord); }
+                else if (!(COBEVT_CONV3_KNOCK & 8)) load_patch(more ? chunk + 1 : chunk);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < KGW; ++g) {
@@ -634,9 +679,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
                 __builtin_amdgcn_sched_barrier(0);
             }
             // the other buffer has been free since the last barrier: write the next chunk's patch under taps 7-8
-            if (S == 1 && !HALF && tap == 6 && more && !(COBEVT_CONV3_KNOCK & 8)) {
-                store_patch(pother);
-                __builtin_amdgcn_sched_barrier(0);
+            if (S == 1 && !HALF && more && !LAST && !(COBEVT_CONV3_KNOCK & 8)) {
+                if (COBEVT_CONV3_PSTORE_SPREAD) {
+                    if (tap >= COBEVT_CONV3_PSTORE_FIRST) { store_patch_part(pother, tap - COBEVT_CONV3_PSTORE_FIRST); __builtin_amdgcn_sched_barrier(0); }
+                } else if (tap == 6) {
+                    store_patch(pother);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         if (chunk < 4) COBEVT_TRACE_MARK(41 + 2 * chunk);
@@ -655,21 +704,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
         }
         if (chunk < 4) COBEVT_TRACE_MARK(42 + 2 * chunk);
     };
-    auto coord = [&](int px, int& im, int& oy, int& ox) {
-        const int4 sc = *(const int4*)&stab[(px >> 5) * 4];      // branch-free: one 16-byte LDS read, no dependent waits
-        im = sc.x;
-        oy = sc.y * 2 + ((px >> 4) & 1); ox = sc.z * 16 + (px & 15);
-        return (sc.w != 0) & (oy < p.Ho) & (ox < p.Wo);
-    };
     // the last chunk is peeled so the residual loads of the store pass can be issued (unconditionally, keeping the
     // vmcnt waits counted) one chunk of MFMAs before they are needed
-    constexpr bool EARLY_RES = S == 1 && Elem<T>::kIsBf16 && MT <= 5;
-    Conv3Store<T, NT, MT * 32, BN> st;
     if (S == 1) {
-        for (int chunk = 0; chunk + 1 < nchunk; ++chunk) run_chunk(chunk);
-        if (EARLY_RES && p.store_mode == 0) st.prepare(p, tid, n0, coord);
+        for (int chunk = 0; chunk + 1 < nchunk; ++chunk) run_chunk(chunk, std::false_type{});
+        if (PLT == 0 && EARLY_RES && p.store_mode == 0) st.prepare(p, tid, n0, coord);
         __builtin_amdgcn_sched_barrier(0);           // keep the residual loads up here
-        run_chunk(nchunk - 1);
+        run_chunk(nchunk - 1, std::true_type{});
     } else {
         // single patch buffer: refill between two barriers (run_chunk ends with one); ONE call site keeps the fully
         // unrolled body within the unroller's budget (with two, LLVM left the tap loop rolled and the fragment rings
@@ -680,7 +721,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
                 fill_patch_s2(chunk);
                 __syncthreads();
             }
-            run_chunk(chunk);
+            run_chunk(chunk, std::false_type{});
         }
     }
     COBEVT_TRACE_MARK(38);

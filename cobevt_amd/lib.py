@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcobevt_hip.so")
 # A/B measurements inside one GPU job (box-to-box variance is larger than most kernel changes): COBEVT_HIP_LIB points at
 # another build of the same ABI, e.g. the previous commit's library kept under tools/_probe/
-LIB_PATH = os.environ.get("COBEVT_HIP_LIB", LIB_PATH)
+LIB_PATH = os.environ.get("COBEVT_HIP_LIB") or LIB_PATH
 
 _c_int_p = ctypes.POINTER(ctypes.c_int)
 _c_long_p = ctypes.POINTER(ctypes.c_long)
