@@ -29,7 +29,17 @@ struct BasicBlockParams {
     void* out;
     int N, H, W;
     int tiles_y, tiles_x;
+    int ntiles;             // N * tiles_y * tiles_x; the grid may be smaller (persistent workgroups walk tiles logical, logical + grid, ...)
 };
+
+// Persistent workgroups: one per CU slot, walking the tiles logical, logical + grid, ...  A tile used to be a workgroup: load the input
+// patch (a cold fetch - the previous kernel wrote it, and L2 is invalidated at kernel boundaries: 3.5-3.9k cycles of the 23k / 37k of a
+// tile in the s_memtime trace, tools/bb_trace.py), conv1, conv2, store, exit, and the NEXT workgroup of the CU (LDS admits one) started
+// with the same cold fetch.  Now the next tile's patch is requested right behind conv2's last weight fragments and lands under the
+// epilogue (stage write, barrier, store pass: ~4k cycles); only the LDS stores of it remain in front of the next conv1.
+#ifndef COBEVT_BB_PERSIST
+#define COBEVT_BB_PERSIST 1
+#endif
 
 template <typename T, int C, int TH_> struct BBCfg {
     static constexpr int NT = 512;
@@ -63,6 +73,11 @@ template <typename T, int C, int TH_> struct BBCfg {
     static constexpr int MAIN = PATCH1 + PATCH2;
     static constexpr int LDS = MAIN > STAGE ? MAIN : STAGE;
     static_assert(NCT >= 2 && NCT <= 8 && 8 % NCT == 0 && N2 % NPG == 0, "wave layout");
+    // persistent workgroups (see above): the bf16 64-channel 16-row shape only.  Same-job kernel traces of both builds inside the frame
+    // (gpurun_out/r03ad): 64 channels 69.47 -> 67.93 us per launch, 128 channels 69.22 -> 70.87 us (slower: its second chunk's refill and
+    // the longer conv2 leave less to hide, and 231 registers instead of 195), whole frame 557.7 / 558.1 -> 559.3 / 559.1 frames/s, i.e.
+    // nothing; the fp32 parity mode and the two-per-CU 8-row tile spill registers in the tile loop.
+    static constexpr bool PERSIST = COBEVT_BB_PERSIST && Elem<T>::kIsBf16 && C == 64 && TH_ == 16;
 };
 
 // One 128-byte channel chunk of a 3x3 convolution out of an LDS patch: 9 taps x 4 k-groups, NTW pixel tiles per wave.
@@ -141,33 +156,40 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
         const int q = nblk >> 3, r = nblk & 7;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    const int tx = logical % p.tiles_x;
-    const int ty = (logical / p.tiles_x) % p.tiles_y;
-    const int img = logical / (p.tiles_x * p.tiles_y);
-    const int oy0 = ty * TH, ox0 = tx * TW;
+    int tile = logical, img, oy0, ox0;
+    auto set_tile = [&](int t) {
+        const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y;
+        img = t / (p.tiles_x * p.tiles_y);
+        oy0 = ty * TH;
+        ox0 = tx * TW;
+    };
+    set_tile(tile);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, ql = lane & 31;
     const int ct = wave % NCT, pg = wave / NCT;                 // cout tile, pixel-tile group
     const T* in = (const T*)p.in;
 
-    // ---- input patch addressing (12 x 20 pixels, origin (oy0 - 2, ox0 - 2)), computed once
+    // ---- input patch addressing (12 x 20 pixels, origin (oy0 - 2, ox0 - 2)), once per tile
     int pgoff[P_IT], plds[P_IT];
+    auto patch_addr = [&]() {
 #pragma unroll
-    for (int it = 0; it < P_IT; ++it) {
-        const int item = tid + it * NT;
-        pgoff[it] = 0;
-        plds[it] = -1;
-        if (item < P1_ITEMS) {
-            const int pix = item / PIECES, j = item - pix * PIECES;
-            const int py = pix / P1W, px = pix - py * P1W;
-            const int lds = py * G::PITCH1 + px * PSTR1 + j * 16;
-            const int iy = oy0 - 2 + py, ix = ox0 - 2 + px;
-            const bool inside = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            if (inside) pgoff[it] = ((img * p.H + iy) * p.W + ix) * C + j * CH;
-            plds[it] = inside ? lds : (lds | (1 << 30));
+        for (int it = 0; it < P_IT; ++it) {
+            const int item = tid + it * NT;
+            pgoff[it] = 0;
+            plds[it] = -1;
+            if (item < P1_ITEMS) {
+                const int pix = item / PIECES, j = item - pix * PIECES;
+                const int py = pix / P1W, px = pix - py * P1W;
+                const int lds = py * G::PITCH1 + px * PSTR1 + j * 16;
+                const int iy = oy0 - 2 + py, ix = ox0 - 2 + px;
+                const bool inside = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                if (inside) pgoff[it] = ((img * p.H + iy) * p.W + ix) * C + j * CH;
+                plds[it] = inside ? lds : (lds | (1 << 30));
+            }
         }
-    }
+    };
+    patch_addr();
     uint4 preg[P_IT];
     auto load_patch = [&](int chunk) {
 #pragma unroll
@@ -182,8 +204,8 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
     };
     // weight fragments of this wave's cout tile: step s = chunk * 9 + tap -> 4 k-groups x 64 lanes
     uint4 bq[R][4];
-    auto load_b = [&](uint4 (&b)[4], const uint4* w, int step) {
-        const uint4* src = w + ((size_t)ct * NSTEP + (step < NSTEP ? step : NSTEP - 1)) * 256 + lane;
+    auto load_b = [&](uint4 (&b)[4], const uint4* wsrc, int step) {        // wsrc = this wave's cout tile, this lane
+        const uint4* src = wsrc + (size_t)(step < NSTEP ? step : NSTEP - 1) * 256;
 #pragma unroll
         for (int g = 0; g < 4; ++g) b[g] = src[g * 64];
         __builtin_amdgcn_sched_barrier(0);
@@ -202,17 +224,15 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
         a1[t] = ry * G::PITCH1 + rx * PSTR1 + h * 16;
     }
     f32x16 acc1[T1W];
-#pragma unroll
-    for (int t = 0; t < T1W; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
 
-    const uint4* w1src = p.w1 + (size_t)ct * NSTEP * 256 + lane;
-    const uint4* w2src = p.w2 + (size_t)ct * NSTEP * 256 + lane;
+    const uint4* w1base = p.w1 + (size_t)ct * NSTEP * 256 + lane;
+    const uint4* w2base = p.w2 + (size_t)ct * NSTEP * 256 + lane;
+    const uint4* w1src = w1base;
+    const uint4* w2src = w2base;
     COBEVT_BB_MARK(0);
     load_patch(0);
-    load_b(bq[0], p.w1, 0);
-    load_b(bq[1], p.w1, 1);
+    load_b(bq[0], w1src, 0);
+    load_b(bq[1], w1src, 1);
     // both folded-BN biases into LDS now (visible after the chunk loop's barriers): neither epilogue starts with a global
     // round trip
     __shared__ __attribute__((aligned(16))) float sbias[2 * C];
@@ -220,6 +240,26 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
         const float* b = tid < C ? p.b1 : p.b2;
         sbias[tid] = b ? b[tid < C ? tid : tid - C] : 0.f;
     }
+    // conv2's pixel tiles: 2 rows x 16 columns each (tile independent)
+    int a2[T2W];
+    bool t2_ok[T2W];
+#pragma unroll
+    for (int t = 0; t < T2W; ++t) {
+        const int tl = pg + t * NPG;
+        a2[t] = (tl * 2 + (ql >> 4)) * G::PITCH2 + (ql & 15) * PSTR2 + h * 16;
+        t2_ok[t] = true;
+    }
+#pragma unroll 1
+  for (;;) {                                                    // ---- one tile per iteration
+    // the weight pointers through an opaque copy per iteration: as loop invariants LLVM hoists all 2 x 36 per-step fragment addresses
+    // out of the tile loop (144 VGPRs of 64-bit pointers -> 256 VGPRs + scratch spills instead of 153)
+    w1src = w1base;
+    w2src = w2base;
+    asm volatile("" : "+v"(w1src), "+v"(w2src));
+#pragma unroll
+    for (int t = 0; t < T1W; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
 #pragma unroll 1
     for (int chunk = 0; chunk < NCH; ++chunk) {
         if (chunk > 0) __syncthreads();                         // every wave finished reading the previous chunk
@@ -231,8 +271,8 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
         COBEVT_BB_MARK(2 + 2 * chunk);
     }
     // conv2's first fragments while the intermediate is written (the ring slots 0 / 1 are free: NSTEP % 3 == 0)
-    load_b(bq[0], p.w2, 0);
-    load_b(bq[1], p.w2, 1);
+    load_b(bq[0], w2src, 0);
+    load_b(bq[1], w2src, 1);
     // ---- intermediate: ReLU(conv1 + b1) rounded to T -> patch2 [region pixel][C] ; zeros outside the image
     {
         const int c0 = ct * 32 + 4 * h;
@@ -279,22 +319,25 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
     __syncthreads();                                            // patch2 complete
     COBEVT_BB_MARK(9);
 
-    // ---- conv2 on the 8 x 16 tile: output pixel tiles pg, pg + NPG, ... (2 rows x 16 columns each)
-    int a2[T2W];
-    bool t2_ok[T2W];
+    // ---- conv2 on the 8 x 16 tile: output pixel tiles pg, pg + NPG, ...
     f32x16 acc[T2W];
 #pragma unroll
-    for (int t = 0; t < T2W; ++t) {
-        const int tile = pg + t * NPG;
-        a2[t] = (tile * 2 + (ql >> 4)) * G::PITCH2 + (ql & 15) * PSTR2 + h * 16;
-        t2_ok[t] = true;
+    for (int t = 0; t < T2W; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    }
 #pragma unroll 1
     for (int chunk = 0; chunk < NCH; ++chunk)
         bb_conv_chunk<T, T2W>(patch2 + chunk * 128, a2, t2_ok, G::PITCH2, PSTR2, w2src, chunk * 9, NSTEP, bq, acc);
     COBEVT_BB_MARK(10);
+    // the next tile's patch: requested now (every weight fragment of this tile has been requested, so nothing queues behind these
+    // cold loads in the in-order vmcnt), it lands under the epilogue
+    const int next = tile + (int)gridDim.x;
+    const bool has_next = G::PERSIST && next < p.ntiles;
+    if (has_next) {
+        set_tile(next);
+        patch_addr();
+        load_patch(0);
+    }
     __syncthreads();                                            // patch2 no longer read: stage over the patches
     COBEVT_BB_MARK(11);
 
@@ -325,6 +368,7 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
 #pragma unroll
         for (int e = 0; e < CH; ++e) sv[i][e] = stage[px * SROW + cj * CH + e];
     }
+    if (has_next) __syncthreads();                              // the staging tile has been read: the next patch may overwrite it
 #pragma unroll
     for (int i = 0; i < S_IT; ++i) {
         if (soff[i] < 0) continue;
@@ -337,6 +381,11 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
         *(uint4*)(out + soff[i]) = f32_to_chunk<T>(v);
     }
     COBEVT_BB_MARK(13);
+    if (!has_next) break;
+    tile = next;
+    load_b(bq[0], w1src, 0);
+    load_b(bq[1], w1src, 1);
+  }
 }
 
 template <typename T, int C, int TH_>
@@ -344,12 +393,21 @@ static int launch_basicblock(BasicBlockParams p, hipStream_t stream) {
     using G = BBCfg<T, C, TH_>;
     p.tiles_y = (p.H + G::TH - 1) / G::TH;
     p.tiles_x = (p.W + G::TW - 1) / G::TW;
-    const long blocks = (long)p.N * p.tiles_y * p.tiles_x;
+    long blocks = (long)p.N * p.tiles_y * p.tiles_x;
     if (blocks <= 0 || blocks > 0x7fffffffL) return COBEVT_ERR_SHAPE;
+    p.ntiles = (int)blocks;
     static cobevt::PerDeviceOnce attr_once;
+    static int cu_slots[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)basicblock_kernel<T, C, TH_>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        const int per_cu = (160 * 1024) / (G::LDS + 2048) < 1 ? 1 : (160 * 1024) / (G::LDS + 2048);     // workgroups of this kernel a CU holds
+        cu_slots[dev & 15] = cus * (per_cu > 2 ? 2 : per_cu);
     }
+    if (G::PERSIST && cu_slots[dev & 15] > 0 && blocks > cu_slots[dev & 15]) blocks = cu_slots[dev & 15];
     hipLaunchKernelGGL((basicblock_kernel<T, C, TH_>), dim3((unsigned)blocks), dim3(G::NT), G::LDS, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
