@@ -587,9 +587,11 @@ class BatchNormActFn(torch.autograd.Function):
 
 def batch_norm_act(x, bn, residual=None, relu=False):
     """relu?(bn(x) [+ residual]) through the nn.BatchNorm2d container `bn` (its own .training flag decides the statistics)"""
-    if (x.shape[1] % 8 or USE_TORCH_GLUE or id(bn) in TORCH_GLUE_BN_IDS or "bn" in TORCH_GLUE_OPS or ("bn_res" in TORCH_GLUE_OPS and residual is not None)
+    cumulative = bn.momentum is None and bn.training and bn.track_running_stats   # running stats as a cumulative average (1 / n)
+    if (x.shape[1] % 8 or cumulative or USE_TORCH_GLUE or id(bn) in TORCH_GLUE_BN_IDS or "bn" in TORCH_GLUE_OPS or ("bn_res" in TORCH_GLUE_OPS and residual is not None)
             or ("bn_plain" in TORCH_GLUE_OPS and residual is None)):
-        # channel counts off the 16-byte piece (none in the shipped configs), or a diagnostic switch: torch's ops
+        # channel counts off the 16-byte piece, momentum=None (neither occurs in the shipped configs), or a diagnostic switch:
+        # torch's ops
         F = torch.nn.functional
         y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
         y = y + residual if residual is not None else y

@@ -123,11 +123,17 @@ class AgentCountPlans(object):
     keeps one `CapturedCorpBEVT` per shape it has seen - captured on first use from that frame, replayed afterwards - and
     dispatches on the incoming batch.  `step(batch)` equals `model(batch)` bit for bit for every agent count.
 
-    max_plans bounds the cache (least recently used plan dropped; its graphs and static buffers are freed)."""
+    max_plans bounds the cache (least recently used plan dropped; its graphs and static buffers are freed).
+
+    A captured graph holds the raw addresses of the lowered weight buffers (`HipModule._plan`), and those buffers are rebuilt
+    when a parameter changes.  Every plan therefore remembers the (version counter, address) of every parameter and
+    floating-point buffer of the model at capture time; `step` compares them and re-captures the plan after an optimizer
+    step, `load_state_dict` or any other in-place update (train_camera.py's train -> eval validation loop).  Writes through
+    `.data` bypass the version counter: call `model.invalidate_plans()` after those, which also empties this cache."""
 
     def __init__(self, model, use_graph=True, max_plans=8, prewarm=None):
         self.model, self.use_graph, self.max_plans = model, use_graph, int(max_plans)
-        self.plans = {}            # key -> CapturedCorpBEVT, insertion order = recency
+        self.plans = {}            # key -> (weight fingerprint, CapturedCorpBEVT), insertion order = recency
         self.captures = 0
         self.busy = False          # True while a plan is being built (the model's own forward runs eagerly inside)
         for b in (prewarm or []):  # capture ahead of time (e.g. one synthetic frame per agent count) instead of on first sight
@@ -140,10 +146,21 @@ class AgentCountPlans(object):
         from . import runtime as rt
         return (tuple(batch["inputs"].shape), n_scen, tuple(batch["transformation_matrix"].shape), str(rt.get_compute_dtype()))
 
+    def weights_fingerprint(self):
+        """(version counter, address) of every parameter / floating-point buffer the captured kernels may read"""
+        from . import runtime as rt
+        return tuple((t._version, t.data_ptr()) for t in rt.module_tensors(self.model))
+
+    def clear(self):
+        self.plans.clear()
+
     def _runner(self, batch):
         k = self.key(batch)
-        r = self.plans.pop(k, None)
-        if r is None:
+        fp = self.weights_fingerprint()
+        ent = self.plans.pop(k, None)
+        if ent is not None and ent[0] != fp:       # weights moved on since the capture: the graph reads dead buffers
+            ent = None
+        if ent is None:
             self.busy = True
             try:
                 r = CapturedCorpBEVT(self.model, batch, use_graph=self.use_graph)
@@ -152,8 +169,9 @@ class AgentCountPlans(object):
             self.captures += 1
             while len(self.plans) >= self.max_plans:
                 self.plans.pop(next(iter(self.plans)))
-        self.plans[k] = r
-        return r
+            ent = (fp, r)
+        self.plans[k] = ent
+        return ent[1]
 
     def step(self, batch):
         return self._runner(batch).step(batch)
@@ -323,6 +341,7 @@ class PipelinedCorpBEVT(_RunnerBase):
             pool = g.pool()
             self.graphs.append(g)
         self.i = self.filled = 0
+        self.static_batch = self.slots[0]
 
     def step(self, batch=None):
         """submit one frame, complete one frame.  Returns the output dict of the frame submitted latency_steps - 1 calls ago
@@ -335,6 +354,7 @@ class PipelinedCorpBEVT(_RunnerBase):
         self.out = self.outs[q]
         self.i += 1
         self.filled += 1
+        self.static_batch = self.slots[self._next_slot]      # the public dict names the NEXT step's slot between steps
         return self.out if self.filled >= self.latency_steps else None
 
 
@@ -384,6 +404,11 @@ class FrameShardedCorpBEVT(object):
     depth = 1: encode -> exchange -> fuse, the latency of a frame is one step.
     depth = 2: step i runs encode + exchange of frame i and, on a second stream of the same graph, fusion + decoder of frame
                i - 1 (two alternating windows / buffers); one frame in, one frame out per step, latency two steps."""
+
+    #: direct gather: `step()` reads the windows' status words after the first step and then every `status_every` steps
+    #: (one stream synchronise each time) and raises when a bounded flag wait gave up - a stalled or missing rank must not
+    #: turn into a normal-looking output fused from a partially filled window.  0 switches the periodic check off.
+    status_every = 64
 
     def __init__(self, model, sub_batch, frame_batch, rank, world, agents, use_graph=True, gather="rccl", depth=1, group=None):
         if model.training:
@@ -486,6 +511,8 @@ class FrameShardedCorpBEVT(object):
     def _finish(self, q):
         self.i += 1
         self.filled += 1
+        if self.windows and self.status_every and (self.i == 1 or self.i % self.status_every == 0):
+            self.status()
         self.out = self.outs[(q - (self.depth - 1)) % self.depth]
         return self.out if self.filled >= self.latency_steps else None
 
@@ -517,7 +544,8 @@ class FrameShardedCorpBEVT(object):
         return self._finish(q)
 
     def status(self):
-        """direct gather only: raise if a bounded flag wait gave up (a peer never arrived)"""
+        """direct gather only: raise if a bounded flag wait gave up (a peer never arrived).  After a timeout the ranks' epochs
+        are out of step: the runner must be rebuilt (collectively) before it is used again."""
         if self.windows:
             for w in self.windows:
                 st, _ = w.status()

@@ -25,13 +25,19 @@ class RgbPreProcessor(object):
         return np.ascontiguousarray(rgb_image[..., ::-1]) if self.params["args"]["bgr2rgb"] else rgb_image
 
     def resize_image(self, rgb_image):
-        """cv2.resize(image, (resize_x, resize_y)) with its default INTER_LINEAR (:46-55).  OpenCV is third-party and not in
-        this image, so the resize is restated from OpenCV's published algorithm (`resize_linear`, below) - PARITY UNPINNED:
-        there is no cv2 here to replay it against; frames already at the target resolution pass through."""
+        """cv2.resize(image, (resize_x, resize_y)) with its default INTER_LINEAR (:46-55).  Where OpenCV is installed this IS
+        that call (data-loader code, host side, exactly what the reference does).  OpenCV is third-party and not in the build
+        image, so without it the resize is restated from OpenCV's published algorithm (`resize_linear`, below) - PARITY
+        UNPINNED: there is no cv2 here to replay it against; frames already at the target resolution pass
+        through."""
         args = self.params["args"]
         if rgb_image.shape[1] == args["resize_x"] and rgb_image.shape[0] == args["resize_y"]:
             return rgb_image
-        return resize_linear(rgb_image, args["resize_x"], args["resize_y"])
+        try:
+            import cv2
+        except ImportError:
+            return resize_linear(rgb_image, args["resize_x"], args["resize_y"])
+        return cv2.resize(rgb_image, (args["resize_x"], args["resize_y"]))
 
 
 def _linear_taps(n_src, n_dst):

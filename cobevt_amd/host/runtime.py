@@ -59,6 +59,9 @@ class HipModule(nn.Module):
         for m in self.modules():
             if isinstance(m, HipModule):
                 m._plan_cache.clear()
+            gp = getattr(m, "graph_plans", None)      # captured graphs hold the addresses of the dropped buffers
+            if gp is not None:
+                gp.clear()
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)

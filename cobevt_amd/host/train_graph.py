@@ -78,6 +78,9 @@ class CapturedTrainStep(object):
 
     def _warm_up(self, n):
         saved = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        # optimizer state that already exists (resumed momentum / Adam moments and step, eager steps taken before the capture)
+        # is put back afterwards; state the warm-up creates is zeroed = the freshly built state
+        saved_opt = {id(t): t.detach().clone() for t in _state_tensors(self.optimizer)}
         # warm-up and capture share ONE side stream: a parameter's gradient accumulator is bound to the stream it was created on,
         # and a capture that has to reach an accumulator living on the default stream dies inside hipGraphInstantiate.  That happens
         # when the autograd graph of an EARLIER eager step is still referenced (a kept loss tensor pins the accumulators it was
@@ -95,8 +98,12 @@ class CapturedTrainStep(object):
             cur = self.model.state_dict()
             for k, v in saved.items():
                 cur[k].copy_(v)
-            for t in _state_tensors(self.optimizer):       # zero = the freshly built state of SGD(momentum) / Adam / AdamW
-                t.zero_()
+            for t in _state_tensors(self.optimizer):
+                old = saved_opt.get(id(t))
+                if old is not None:
+                    t.copy_(old)
+                else:                                      # zero = the freshly built state of SGD(momentum) / Adam / AdamW
+                    t.zero_()
         self.optimizer.zero_grad(set_to_none=True)
         for w in caught:
             if "AccumulateGrad node's stream does not match" in str(w.message):

@@ -69,6 +69,62 @@ def test_pipelined_runner_equals_model_call(cuda, depth):
         assert torch.equal(got[i + depth - 1], ref[i]), "frame %d came out wrong (depth %d)" % (i, depth)
 
 
+def test_pipelined_runner_direct_writes_go_to_the_next_slot(cuda):
+    """the documented loader pattern - write the next frame into `runner.static_batch[...]`, then `step()` - on the
+    PIPELINED runner, whose camera matrices / poses / record_len live in a ring of slots: between steps `static_batch` must name
+    the slot of the NEXT step, or the geometry of every frame lands one slot late"""
+    model = _model(cuda)
+    frames = _frames(7, cuda)
+    depth = 3
+    with host.compute_dtype(torch.bfloat16):
+        ref = [model(dict(f))["dynamic_seg"].clone() for f in frames]
+        run = pipeline.PipelinedCorpBEVT(model, frames[0], depth=depth)
+        got = []
+        for f in frames + [frames[-1]] * (depth - 1):
+            for k, dst in run.static_batch.items():
+                dst.copy_(f[k] if k != "record_len" else f[k].to(torch.int32))
+            out = run.step()
+            got.append(None if out is None else out["dynamic_seg"].clone())
+        torch.cuda.synchronize()
+    for i in range(len(frames)):
+        assert torch.equal(got[i + depth - 1], ref[i]), "frame %d came out wrong" % i
+
+
+def test_graph_plans_follow_weight_updates(cuda):
+    """plans captured by `enable_graphs()` hold the addresses of the lowered weights; after an in-place parameter
+    update (optimizer step / load_state_dict between validation passes) the plan is re-captured instead of replaying stale
+    weights"""
+    model = _model(cuda)
+    f = _frames(1, cuda)[0]
+    with host.compute_dtype(torch.bfloat16):
+        model.enable_graphs()
+        a = model(dict(f))["dynamic_seg"].clone()
+        assert model.graph_plans.captures == 1
+        model(dict(f))
+        assert model.graph_plans.captures == 1
+        with torch.no_grad():
+            for p in model.seg_head.parameters():
+                p.mul_(1.5)
+        model.enable_graphs(False)
+        want = model(dict(f))["dynamic_seg"].clone()
+        model.enable_graphs()
+        b = model(dict(f))["dynamic_seg"].clone()
+        assert torch.equal(b, want) and not torch.equal(a, b)
+        with torch.no_grad():
+            for p in model.seg_head.parameters():
+                p.mul_(1 / 1.5)
+        assert model.graph_plans.captures == 1
+        c = model(dict(f))["dynamic_seg"].clone()       # same plan cache, weights changed underneath it -> re-captured
+        assert model.graph_plans.captures == 2
+        model.enable_graphs(False)
+        assert torch.equal(c, model(dict(f))["dynamic_seg"])
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        model.enable_graphs()
+        model(dict(f))
+        model.load_state_dict(sd)                        # invalidate_plans() empties the graph cache too
+        assert len(model.graph_plans.plans) == 0
+
+
 def test_captured_call_operator_level(cuda):
     """CapturedCall around SwapFusionEncoder.forward (the LiDAR bench workload's runner) == the eager call"""
     args = dict(input_dim=64, mlp_dim=128, agent_size=8, window_size=8, dim_head=32, drop_out=0.1, depth=2, mask=True)

@@ -893,6 +893,36 @@ def test_captured_train_step_follows_eager(cuda, amp):
         cap.step(bad)
 
 
+def test_captured_train_step_keeps_existing_optimizer_state(cuda):
+    """an optimizer that already carries state (an eager step taken before the capture, resumed momentum) keeps it
+    through CapturedTrainStep's warm-up steps; only state the warm-up itself creates is reset"""
+    import copy
+    cfg = synth.corpbevt_small_config()
+    cfg["fax"]["self_attn"]["dropout"] = 0.0
+    cfg["fax_fusion"]["drop_out"] = 0.0
+    batch = {k: v.to(cuda) for k, v in synth.opv2v_batch(agents=2, cams=2, image=128, max_cav=3, seed=3).items()}
+    crit = host.VanillaSegLoss({"d_weights": 75.0, "s_weights": 15.0, "l_weights": 50, "d_coe": 2.0, "s_coe": 0.0, "target": "dynamic"})
+    model = _train_module(host.CorpBEVT(copy.deepcopy(cfg)), cuda)
+    with torch.no_grad():
+        shp = model.eval()(dict(batch))["dynamic_seg"].shape
+    model.train()
+    batch["gt_dynamic"] = (torch.rand(shp[:2] + shp[3:], generator=torch.Generator().manual_seed(5)) > 0.8).long().to(cuda)
+    batch["gt_static"] = torch.zeros(shp[:2] + shp[3:], dtype=torch.long, device=cuda)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9)
+    with torch.enable_grad():
+        loss = crit(model(dict(batch)), batch)
+    loss.backward()
+    opt.step()
+    del loss
+    opt.zero_grad(set_to_none=True)
+    mom = {id(p): st["momentum_buffer"].clone() for p, st in opt.state.items() if st.get("momentum_buffer") is not None}
+    assert mom and any(float(v.abs().max()) > 0 for v in mom.values())
+    host.CapturedTrainStep(model, lambda o, b: crit(o, b), opt, batch)
+    for p, st in opt.state.items():
+        if id(p) in mom:
+            assert torch.equal(st["momentum_buffer"], mom[id(p)])
+
+
 def test_cvt_cross_attention_gradients(cuda):
     """cvt_modules.CrossAttention in train() mode (per-camera attentions merged by a softmax over their log-sum-exp, the lse gradient
     entering the attention backward kernels) against torch autograd through the oracle's single softmax over all cameras' keys
