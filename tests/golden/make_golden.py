@@ -510,9 +510,265 @@ def gv17():
             out["single_cvm"] = _np(cvm)
     save("gv17_cvt_baselines", **out)
 
+GV18_SEEDS = (0, 1, 2, 3)
+
+
+def _dev_stats(run, class_dim):
+    """run(): reference forward returning a tensor, a list or {key: tensor}.  Evaluated in fp32 and again inside
+    torch.autocast("cpu", dtype=torch.bfloat16) - the reference's own mixed-precision mode (train_camera.py:157-160 and
+    nuscenes/scripts/benchmark.py:45 wrap the same forward in torch.cuda.amp.autocast).
+    -> {output key: (max|d| / max|ref|, ||d||_2 / ||ref||_2, arg-max agreement along class_dim or 1.0)}"""
+    ref = run()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        amp = run()
+    if torch.is_tensor(ref):
+        ref, amp = {"": ref}, {"": amp}
+    if isinstance(ref, (list, tuple)):
+        ref, amp = {"[%d]" % i: v for i, v in enumerate(ref)}, {"[%d]" % i: v for i, v in enumerate(amp)}
+    res = {}
+    for k, r in ref.items():
+        a, r = amp[k].float(), r.float()
+        d = (a - r).double()
+        mx = float(d.abs().max() / r.abs().max().clamp_min(1e-12))
+        rms = float(d.square().sum().sqrt() / r.double().square().sum().sqrt().clamp_min(1e-30))
+        agree = float((a.argmax(class_dim) == r.argmax(class_dim)).float().mean()) if class_dim is not None else 1.0
+        res[k] = (mx, rms, agree)
+    return res
+
+
+def _dev(out, name, build, class_dim=None, seeds=GV18_SEEDS):
+    """build(seed) -> run(): the reference module / model with the procedural weight set `seed` (fill_module_), on the inputs
+    the tests use.  The bf16 deviation of a deep network is one realisation of accumulated rounding noise and moves by
+    +-40 % between weight sets, so what is stored is the ENVELOPE over the weight sets 0..3 -
+    [largest max-rel, largest rms-rel, smallest arg-max agreement] - plus the per-seed values under '<key>#seeds'."""
+    per = [_dev_stats(build(sd), class_dim) for sd in seeds]
+    for k in per[0]:
+        key = name + (("." + k) if k and not k.startswith("[") else k)
+        v = np.array([p[k] for p in per], dtype=np.float64)            # (seeds, 3)
+        out[key] = np.array([v[:, 0].max(), v[:, 1].max(), v[:, 2].min()])
+        out[key + "#seeds"] = v
+        print("  reference bf16-autocast vs fp32 %-44s max-rel %.3e (%s)  rms-rel %.3e (%s)  arg-max agreement >= %.4f"
+              % (key, out[key][0], " ".join("%.2e" % x for x in v[:, 0]), out[key][1], " ".join("%.2e" % x for x in v[:, 1]), out[key][2]))
+
+
+def gv18(full=None):
+    """The REFERENCE's own bf16 mixed-precision deviation: every module / model of GV2-GV11, GV13, GV17 and
+    the full-size corpbevt.yaml frame run by the reference in fp32 and under torch.autocast(bfloat16) on the tests' procedural
+    inputs, for the procedural weight sets 0..3.  These numbers - not anything measured on the HIP path - are what the bf16
+    gates in tests/util.py are derived from: a bf16 result may deviate from the fp32 reference by as much as the reference's own
+    bf16 run does, or 1e-2, whichever is larger."""
+    import copy
+    full = ("--no-full" not in sys.argv) if full is None else full
+    out = {}
+    for name, c in cases.CROSS_WIN.items():
+        q, k, v, skip = cases.cross_win_inputs(name)
+
+        def build(sd, c=c):
+            m = fill_module_(R_fax.CrossWinAttention(c["dim"], c["heads"], c["dim_head"], c["qkv_bias"]).eval(), sd)
+            return lambda: m(q, k, v, skip)
+        _dev(out, "CrossWinAttention." + name, build)
+    for name, c in cases.CVSA.items():
+        fd, fh, fw = c["feat"]
+        bev = R_fax.BEVEmbedding(c["dim"], **c["bev_embedding"])
+        x, feat, I_inv, E = cases.cvsa_inputs(name)
+
+        def build(sd, c=c):
+            m = R_fax.CrossViewSwapAttention(fh, fw, fd, c["dim"], c["index"], c["image"][0], c["image"][1], **c["kwargs"]).eval()
+            fill_module_(m, sd)
+            return lambda: m(c["index"], x, bev, feat, I_inv, E)
+        _dev(out, "CrossViewSwapAttention." + name, build)
+    c = cases.FAX_SMALL
+    batch = cases.fax_small_inputs()
+
+    def build(sd):
+        cfg = {k: (dict(v) if isinstance(v, dict) else list(v)) for k, v in c["config"].items()}
+        m = fill_module_(R_fax.FAXModule(cfg).eval(), sd)
+        return lambda: m(dict(batch))
+    _dev(out, "FAXModule", build)
+    c = cases.SWAP
+    x, mask = cases.swap_inputs()
+    w = c["window_size"]
+    xw = rearrange(x, "b m d (x w1) (y w2) -> b m x y w1 w2 d", w1=w, w2=w)
+    mw = rearrange(mask, "b (x w1) (y w2) e l -> b x y w1 w2 e l", w1=w, w2=w)
+    for nm, mk in (("swap Attention + mask", mw), ("swap Attention", None)):
+        def build(sd, mk=mk):
+            att = fill_module_(R_swap.Attention(c["dim"], c["dim_head"], 0.1, c["agent_size"], w).eval(), sd)
+            return lambda: att(xw, mask=mk)
+        _dev(out, nm, build)
+
+    def build(sd):
+        blk = fill_module_(R_swap.SwapFusionBlockMask(c["dim"], c["mlp_dim"], c["dim_head"], w, c["agent_size"], 0.1).eval(), sd)
+        return lambda: blk(x, mask)
+    _dev(out, "SwapFusionBlockMask", build)
+    for use_mask in (True, False):
+        def build(sd, use_mask=use_mask):
+            args = dict(input_dim=c["dim"], mlp_dim=c["mlp_dim"], agent_size=c["agent_size"], window_size=w,
+                        dim_head=c["dim_head"], drop_out=0.1, depth=c["depth"], mask=use_mask)
+            enc = fill_module_(R_swap.SwapFusionEncoder(args).eval(), sd)
+            return lambda: enc(x, mask if use_mask else None)
+        _dev(out, "SwapFusionEncoder mask=%s" % use_mask, build)
+    # LiDAR-shaped FuseBEVT operator config (64 ch, 8 agents, window 8) on a 32 x 32 map
+    xl = synth.procedural_input("gv18.lidar.x", (1, 8, 64, 32, 32), cases.SEED)
+    ml = torch.ones(1, 32, 32, 1, 8)
+    ml[0, :, :, :, 5:] = 0
+
+    def build(sd):
+        args = dict(input_dim=64, mlp_dim=128, agent_size=8, window_size=8, dim_head=32, drop_out=0.1, depth=3, mask=True)
+        enc = fill_module_(R_swap.SwapFusionEncoder(args).eval(), sd)
+        return lambda: enc(xl, ml)
+    _dev(out, "SwapFusionEncoder lidar-shaped", build)
+    d = cases.DECODER
+    xd = synth.procedural_input("gv7.x", (1, 2, d["input_dim"], 8, 8), cases.SEED)
+
+    def build(sd):
+        dec = fill_module_(R_NaiveDecoder(dict(d)).eval(), sd)
+        return lambda: dec(xd)
+    _dev(out, "NaiveDecoder", build)
+    dec0 = fill_module_(R_NaiveDecoder(dict(d)).eval(), cases.SEED)
+    y = dec0(xd)
+    y = y.reshape(-1, *y.shape[2:])
+    for target, classes in (("dynamic", 2), ("static", 3), ("both", 2)):
+        def build(sd, target=target, classes=classes):
+            head = fill_module_(R_BevSegHead(target, d["num_ch_dec"][0], classes).eval(), sd)
+            return lambda: {k: v for k, v in head(y, 1, 2).items() if v.is_floating_point() and v.numel() > 1 and float(v.abs().max()) > 0}
+        _dev(out, "BevSegHead." + target, build, class_dim=2)
+    c = cases.GLOBAL_ATTN
+    xg = synth.procedural_input("gv9.x", (c["b"], c["dim"], c["window_size"], c["window_size"]), cases.SEED)
+
+    def build(sd):
+        m = fill_module_(R_fax.Attention(c["dim"], c["dim_head"], 0.1, c["window_size"]).eval(), sd)
+        return lambda: m(xg)
+    _dev(out, "FAX global attention", build)
+    xr = synth.procedural_input("gv10.x", (1, 1, 2, 64, 64, 3), cases.SEED)
+    for depth, cfg in cases.RESNET.items():
+        def build(sd, cfg=cfg):
+            m = fill_module_(R_ResnetEncoder(dict(cfg)).eval(), sd)
+            return lambda: list(m(xr))
+        _dev(out, "resnet%d" % depth, build)
+    from opencood.models.sub_modules.naive_compress import NaiveCompressor as R_Comp
+    xc = synth.procedural_input("gv13.x", (3, 32, 12, 16), cases.SEED, -2.0, 2.0)
+
+    def build(sd):
+        comp = fill_module_(R_Comp(32, 4).eval(), sd)
+        return lambda: comp(xc)
+    _dev(out, "NaiveCompressor", build)
+
+    # reduced end-to-end models (GV8, GV13, GV17) on the tests' batches
+    cfg = synth.corpbevt_small_config()
+    batch = synth.opv2v_batch(agents=2, cams=2, image=128, max_cav=3, seed=cases.SEED)
+
+    def build(sd):
+        m = fill_module_(R_corpbevt.CorpBEVT(copy.deepcopy(cfg)).eval(), sd)
+        inter = {}
+        m.fax.register_forward_hook(lambda mod, i, o: inter.__setitem__("fax", o))
+        m.fusion_net.register_forward_hook(lambda mod, i, o: inter.__setitem__("fused", o))
+
+        def run():
+            r = m({k: v.clone() for k, v in batch.items()})
+            return {"dynamic_seg": r["dynamic_seg"], "fax": inter["fax"], "fused": inter["fused"]}
+        return run
+    _dev(out, "CorpBEVT.small", build, class_dim=2)
+    # the ragged training-style batch of tests/test_modules_gpu.py::test_corpbevt_ragged_scenarios_vs_oracle
+    record_len = [2, 1, 3]
+    fullb = synth.opv2v_batch(agents=3, cams=2, image=128, max_cav=3, seed=cases.SEED + 1, batch=len(record_len))
+    keep = [s_ * 3 + a for s_, n in enumerate(record_len) for a in range(n)]
+    rb = {k: fullb[k][keep] for k in ("inputs", "intrinsic", "extrinsic")}
+    rb["transformation_matrix"] = fullb["transformation_matrix"]
+    rb["record_len"] = torch.tensor(record_len, dtype=torch.int64)
+
+    def build(sd):
+        m = fill_module_(R_corpbevt.CorpBEVT(copy.deepcopy(cfg)).eval(), sd)
+        return lambda: m({k: v.clone() for k, v in rb.items()})["dynamic_seg"]
+    _dev(out, "CorpBEVT ragged scenarios", build, class_dim=2)
+    cfg2 = {k: copy.deepcopy(v) for k, v in cfg.items() if k in ("target", "encoder", "decoder", "fax", "seg_head_dim", "output_class")}
+    b2 = {k: batch[k].reshape(1, 2, *batch[k].shape[2:]) for k in ("inputs", "intrinsic", "extrinsic")}
+
+    def build(sd):
+        m2 = fill_module_(R_FaxFused(copy.deepcopy(cfg2)).eval(), sd)
+        return lambda: m2({k: v.clone() for k, v in b2.items()})["dynamic_seg"]
+    _dev(out, "FaxFusedTransformer.small", build, class_dim=2)
+    cfgc = synth.corpbevt_small_compressed_config(2)
+
+    def build(sd):
+        mc = fill_module_(R_corpbevt.CorpBEVT(copy.deepcopy(cfgc)).eval(), sd)
+        return lambda: mc({k: v.clone() for k, v in batch.items()})["dynamic_seg"]
+    _dev(out, "CorpBEVT.small compression=2", build, class_dim=2)
+
+    from opencood.models.cross_view_transformer import CrossViewTransformer as R_Cvt
+    from opencood.models.cross_view_transformer_swap_fuse import CrossViewTransformerSwapFuse as R_CvtSwap
+    from opencood.models.cross_view_transformer_fcooper import CrossViewTransformerFcooper as R_CvtFcooper
+    from opencood.models.cross_view_transformer_att_fuse import CrossViewTransformerAttFuse as R_CvtAtt
+    from opencood.models.cross_view_transformer_v2vnet import CrossViewTransformerV2VNet as R_CvtV2V
+    from opencood.models.cross_view_transformer_disconet import CrossViewTransformerDiscoNet as R_CvtDisco
+    single = synth.opv2v_batch(agents=1, cams=2, image=128, max_cav=3, seed=cases.SEED)
+    single_b = {k: single[k] for k in ("inputs", "intrinsic", "extrinsic")}
+    for kind, cls, bt in (("single", R_Cvt, single_b), ("swap_fuse", R_CvtSwap, batch), ("fcooper", R_CvtFcooper, batch),
+                          ("att_fuse", R_CvtAtt, batch), ("v2vnet", R_CvtV2V, batch), ("disconet", R_CvtDisco, batch)):
+        def build(sd, kind=kind, cls=cls, bt=bt):
+            mk = fill_module_(cls(copy.deepcopy(synth.cvt_small_config(kind))).eval(), sd)
+            return lambda: mk(dict(bt))["dynamic_seg"]
+        _dev(out, "CVT " + kind, build, class_dim=2)
+        if kind == "single":
+            def build(sd, cls=cls, bt=bt):
+                mk = fill_module_(cls(copy.deepcopy(synth.cvt_small_config("single"))).eval(), sd)
+                return lambda: mk.cvm({"inputs": bt["inputs"], "intrinsic": bt["intrinsic"], "extrinsic": bt["extrinsic"],
+                                       "features": mk.encoder(bt["inputs"])})
+            _dev(out, "CrossViewModule", build)
+
+    # nuScenes SinBEVT at the real config shapes (GV11)
+    sys.path.insert(0, "/root/reference/nuscenes")
+    from cross_view_transformer.model.encoder_pyramid_axial import PyramidAxialEncoder as R_Enc
+    from cross_view_transformer.model.decoder import Decoder as R_Dec
+    from cross_view_transformer.model.cvt import CrossViewTransformer as R_CVT
+    from cobevt_amd.synth import FeatureMapBackbone
+    c = cases.NUSCENES
+    feats, image, intr, ext = cases.nuscenes_inputs()
+
+    def build(sd):
+        enc = R_Enc(FeatureMapBackbone(feats), **copy.deepcopy(c["encoder"]))
+        model = fill_module_(R_CVT(enc, R_Dec(**c["decoder"]), c["dim_last"], c["outputs"]).eval(), sd)
+        inter_n = {}
+        model.encoder.register_forward_hook(lambda mod, i, o: inter_n.__setitem__("enc", o))
+
+        def run():
+            r = dict(model({"image": image, "intrinsics": intr, "extrinsics": ext}))
+            r["encoder"] = inter_n["enc"]
+            return r
+        return run
+    _dev(out, "nuScenes SinBEVT", build)
+
+    if full:
+        # the full-size corpbevt.yaml frame (BASELINE configs[2] / [3] and the bench headline), inputs as in bench.py / the tests
+        cfgf = synth.corpbevt_config()
+        for agents in (2, 5):
+            bf = synth.opv2v_batch(agents=agents, cams=4, image=512, max_cav=5, seed=0)
+
+            def build(sd, bf=bf):
+                mf = fill_module_(R_corpbevt.CorpBEVT(copy.deepcopy(cfgf)).eval(), sd)
+                interf = {}
+                mf.fax.register_forward_hook(lambda mod, i, o: interf.__setitem__("fax", o))
+                mf.fusion_net.register_forward_hook(lambda mod, i, o: interf.__setitem__("fused", o))
+                mf.encoder.register_forward_hook(lambda mod, i, o: interf.__setitem__("enc", o))
+
+                def run():
+                    r = mf({k: v.clone() for k, v in bf.items()})
+                    o = {"dynamic_seg": r["dynamic_seg"], "fax": interf["fax"], "fused": interf["fused"]}
+                    for i, e in enumerate(interf["enc"]):
+                        o["resnet34_f%d" % i] = e
+                    return o
+                return run
+            _dev(out, "CorpBEVT.full %d agents" % agents, build, class_dim=2, seeds=GV18_SEEDS[:2])
+
+            def build(sd, bf=bf, agents=agents):             # the bench frame: the class-balanced head of seed 0 (synth.balance_seg_head_)
+                mf = fill_module_(R_corpbevt.CorpBEVT(copy.deepcopy(cfgf)).eval(), sd)
+                synth.balance_seg_head_(mf, agents)
+                return lambda: mf({k: v.clone() for k, v in bf.items()})["dynamic_seg"]
+            _dev(out, "CorpBEVT.full %d agents balanced head" % agents, build, class_dim=2, seeds=(0,))
+    save("gv18_reference_bf16_autocast", **out)
+
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gv0", "gv1", "gv2", "gv3", "gv4", "gv5", "gv6", "gv7", "gv8", "gv9", "gv10", "gv11", "gv12", "gv13", "gv14", "gv15", "gv16", "gv17"]
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["gv0", "gv1", "gv2", "gv3", "gv4", "gv5", "gv6", "gv7", "gv8", "gv9", "gv10", "gv11", "gv12", "gv13", "gv14", "gv15", "gv16", "gv17", "gv18"]
     for name in which:
         print("== " + name)
         globals()[name]()

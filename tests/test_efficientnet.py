@@ -5,7 +5,7 @@ the reference tree and from this image -> restated from its published definition
 unpinned" for the third-party arithmetic.  What IS pinned by the reference: the layer selection quirk and the resulting
 feature shapes (probed on the reference: (32,56,120), (56,28,60), (112,14,30) for 224x480 images).
 CPU: structure / state_dict keys / oracle vs a plain-torch forward over the host module's own nn containers.
-GPU (-m gpu): the MBConv kernels vs torch, the extractor vs the oracle (fp32 1e-3 rel, bf16 5e-2 rel), and the whole
+GPU (-m gpu): the MBConv kernels vs torch, the extractor vs the oracle (fp32 1e-3 rel, bf16 1e-2 rel), and the whole
 nuScenes SinBEVT with the real backbone in front."""
 import copy
 
@@ -19,7 +19,7 @@ from cobevt_amd import host, ops
 from cobevt_amd.host.nuscenes.efficientnet import EfficientNetExtractor, MBConvBlock
 from cobevt_amd.synth import fill_module_, procedural_input
 import oracle.efficientnet as o_eff
-from util import assert_close, rel_err
+from util import BF16, BF16_FLOOR, assert_close, rel_err
 
 torch.set_grad_enabled(False)
 LAYERS = ["reduction_2", "reduction_3", "reduction_4"]          # config/model/cvt_pyramid_axial.yaml:19
@@ -160,7 +160,7 @@ def test_swish_epilogue_of_the_gemm_paths(cuda, dtype, tol):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16_FLOOR)])   # restated third-party backbone: no reference fixture, BASELINE.md's 1e-2
 def test_mbconv_block_and_extractor_vs_oracle(cuda, dtype, tol):
     blk = fill_module_(MBConvBlock(32, 32, 3, 1, 6, 95), cases.SEED).eval()
     x = procedural_input("mb.x", (2, 32, 17, 23), cases.SEED, -2, 2)
@@ -184,7 +184,7 @@ def test_mbconv_block_and_extractor_vs_oracle(cuda, dtype, tol):
 @pytest.mark.gpu
 def test_nuscenes_sinbevt_with_the_real_backbone(cuda):
     """images -> Normalize -> EfficientNetExtractor -> PyramidAxialEncoder -> Decoder -> heads, all on the device, vs the same
-    pipeline assembled from the oracles (fp32 parity mode 1e-3 rel; bf16 5e-2 rel)"""
+    pipeline assembled from the oracles (fp32 parity mode 1e-3 rel; bf16: util.bf16_gate)"""
     from cobevt_amd.host import nuscenes as nu
     import oracle.nuscenes as o_nu
     c = cases.NUSCENES
@@ -197,9 +197,10 @@ def test_nuscenes_sinbevt_with_the_real_backbone(cuda):
     ref = o_nu.cross_view_transformer(sd, c["encoder"], len(c["decoder"]["blocks"]), c["outputs"], feats, intr, ext)
     model = model.to(cuda)
     batch = {"image": image.to(cuda), "intrinsics": intr.to(cuda), "extrinsics": ext.to(cuda)}
-    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, 5e-2)):
+    # bf16: gated like the reference's own bf16-autocast deviation of the same model behind its backbone (gv18 "nuScenes SinBEVT")
+    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, BF16)):
         with host.compute_dtype(dtype):
             out = model(batch)
         assert tuple(out["bev"].shape) == (1, 1, 200, 200)
         for k in ref:
-            assert_close(out[k], ref[k].numpy(), tol, "nuScenes SinBEVT with EfficientNet-B4 [%s] %s" % (k, dtype))
+            assert_close(out[k], ref[k].numpy(), tol, "nuScenes SinBEVT with EfficientNet-B4 [%s] %s" % (k, dtype), case="nuScenes SinBEVT." + k)

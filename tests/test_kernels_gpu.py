@@ -1,7 +1,8 @@
 """Kernel-level parity: every C-ABI entry point against a plain PyTorch fp32 CPU computation of the same op.
 
 Tolerances: fp32 mode 2e-4 of the output scale (exact-fp32 MFMA, different summation order);
-bf16 mode 2e-2 of the output scale, measured against the fp32 result on bf16-rounded operands.
+bf16 mode 1e-2 of the output scale (BASELINE.md section 2's bf16 gate; a single kernel's output rounding is 2^-9), against the
+fp32 result on bf16-rounded operands.
 """
 import math
 
@@ -22,7 +23,7 @@ DTYPES = [torch.float32, torch.bfloat16]
 
 
 def tol(dtype):
-    return 2e-4 if dtype == torch.float32 else 2e-2
+    return 2e-4 if dtype == torch.float32 else 1e-2
 
 
 def rnd(t, dtype):
@@ -338,7 +339,7 @@ def test_bottleneck_fused(cuda, n, h, w, tile_rows):
     p3 = ops.ConvPlan(m.conv3.weight, None, bn=m.bn3, act=1, dtype=dtype, device=cuda)
     z = ops.conv2d(ops.conv2d(ops.conv2d(xd, p1), p2), p3, residual=xd)
     torch.cuda.synchronize()
-    assert (y.float() - z.float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    assert (y.float() - z.float()).abs().max().item() <= 1e-2 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -362,7 +363,7 @@ def test_basicblock_fused(cuda, dtype, c, n, h, w):
     ref = F.relu(F.conv2d(mid, wr2, p2.bias.cpu(), padding=1) + rnd(x, dtype))
     check(y.permute(0, 3, 1, 2), ref, dtype, "fused basicblock vs torch")
     s = ref.abs().max().item()
-    assert (y.float() - y2.float()).abs().max().item() <= (2e-2 if dtype == torch.bfloat16 else 1e-5) * s
+    assert (y.float() - y2.float()).abs().max().item() <= (1e-2 if dtype == torch.bfloat16 else 1e-5) * s
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -571,7 +572,7 @@ def test_attn_mlp_chain_next_projection(cuda, c, rows, nn_, next_ln, next_act, p
     ref = F.relu(ref) if next_act == 1 else (F.gelu(ref) if next_act == 2 else ref)
     s = ref.abs().max().item()
     assert (nx.float().cpu() - ref).abs().max().item() <= 3e-2 * s
-    assert (nx.float() - nx_b.float()).abs().max().item() <= 2e-2 * s
+    assert (nx.float() - nx_b.float()).abs().max().item() <= 1e-2 * s
 
 
 # ---------------------------------------------------------------------------------------------
@@ -793,7 +794,7 @@ def test_resident_attention_bias_mask(cuda, L, w, H, use_mask, mode, qsplit):
     ref = o.permute(0, 1, 2, 4, 3, 5, 6).reshape(B, L, H, W, d) if mode == 0 else o.permute(0, 1, 4, 2, 5, 3, 6).reshape(B, L, H, W, d)
     check(outs[0], ref, dtype, "resident swap attention L=%d mode=%d qsplit=%d" % (L, mode, qsplit))
     check(outs[1], ref, dtype, "streaming swap attention L=%d mode=%d" % (L, mode))
-    assert (outs[0].float() - outs[1].float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    assert (outs[0].float() - outs[1].float()).abs().max().item() <= 1e-2 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("nq_cams,mean", [(4, True), (1, False)])
@@ -963,7 +964,7 @@ def test_bev_embed_fused_into_q_projection(cuda, dtype):
         ops.USE_EMBED_GEMM, ops.USE_EMBED_GEMM3 = keep
     assert y.shape == (b, n, H * W, 96)
     s = y2.float().abs().max().item()
-    assert (y.float() - y2.float()).abs().max().item() <= (2e-2 if dtype == torch.bfloat16 else 1e-5) * s
+    assert (y.float() - y2.float()).abs().max().item() <= (1e-2 if dtype == torch.bfloat16 else 1e-5) * s
     if dtype == torch.bfloat16:
         # produced inside the 32-row GEMM, also with the batch-broadcast prior of pyramid level 0
         prior = x[0]
@@ -977,9 +978,9 @@ def test_bev_embed_fused_into_q_projection(cuda, dtype):
         finally:
             ops.USE_EMBED_GEMM3 = keep[1]
         assert y3.shape == (b, n, H * W, 96)
-        assert (y3.float() - y2.float()).abs().max().item() <= 2e-2 * s
+        assert (y3.float() - y2.float()).abs().max().item() <= 1e-2 * s
         assert torch.equal(yb, yc)
-        assert (yb.float() - yr.float()).abs().max().item() <= 2e-2 * yr.float().abs().max().item()
+        assert (yb.float() - yr.float()).abs().max().item() <= 1e-2 * yr.float().abs().max().item()
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -1073,7 +1074,7 @@ def test_small_block_gemm_row_tiles_agree(cuda):
             y1 = ops.linear(x, plan)                        # the 128 x 128-tile kernel
         finally:
             ops.USE_GEMM_ROWS3 = True
-        assert (y32.float() - y1.float()).abs().max().item() <= 2e-2 * y1.float().abs().max().item()
+        assert (y32.float() - y1.float()).abs().max().item() <= 1e-2 * y1.float().abs().max().item()
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -1137,7 +1138,7 @@ def test_swap_fusion_stage_single_launch(cuda, agents, window, hw, mlp, use_mask
             ops.USE_SWAP_STAGE = old
     e, e2, d = rel_err(y, ref), rel_err(y2, ref), rel_err(y, y2)
     print("swap stage %s: fused vs oracle %.2e, two-launch vs oracle %.2e, fused vs two-launch %.2e" % ((agents, window, hw, mlp, use_mask), e, e2, d))
-    assert e <= 1.5e-2 and e <= 1.5 * e2 + 2e-3, (e, e2)
+    assert e <= 1e-2 and e <= 1.5 * e2 + 2e-3, (e, e2)
 
 
 @pytest.mark.parametrize("rows,with_res", [(4096, True), (4096, False), (1000, True)])
@@ -1174,8 +1175,8 @@ def test_projection_chain_single_launch(cuda, rows, with_res):
             y = y + rb.float()
         ref = owner.lin(owner.ln(y.to(torch.bfloat16).float())).cpu()
     s = float(ref.abs().max())
-    assert (fused.float().cpu() - ref).abs().max().item() <= 1.5e-2 * s
-    assert (fused.float() - two.float()).abs().max().item() <= 1.5e-2 * s
+    assert (fused.float().cpu() - ref).abs().max().item() <= 1e-2 * s
+    assert (fused.float() - two.float()).abs().max().item() <= 1e-2 * s
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
@@ -1214,7 +1215,7 @@ def test_attention_key_split_matches_single_pass(cuda, dtype, use_bias, ncam):
         idx = ops.attention_bias_index(qmap, kmap, 1, cuda).cpu().long()
         s = s + table.cpu()[idx].permute(2, 0, 1)[None]
     ref = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), vf).reshape(B * nq, d)
-    tol_ = 1.5e-2 if dtype == torch.bfloat16 else 1e-4
+    tol_ = 1e-2 if dtype == torch.bfloat16 else 1e-4
     scale = float(ref.abs().max())
     for ks, o in outs.items():
         assert float((o - ref).abs().max()) <= tol_ * scale, (ks, float((o - ref).abs().max()) / scale)

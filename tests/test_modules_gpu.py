@@ -1,7 +1,7 @@
 """GPU parity of the HIP-backed host modules against the oracle and the reference's golden vectors.
 
-Gates (north-star): fp32 mode <= 1e-3 rel of the output scale; bf16 mode at <= 1.5x the measured errors (tests/util.py:
-1.5e-2 rel on single operators, 2e-2 on full-size and 4.5e-2 on reduced-size end-to-end logits; max-norm AND rms-norm) + >= 99% arg-max agreement (a bf16 pipeline cannot meet
+Gates (north-star): fp32 mode <= 1e-3 rel of the output scale; bf16 mode at
+max(1e-2, the reference's own bf16-autocast deviation on the same case) - tests/util.py, fixture gv18; max-norm AND rms-norm - + >= 99% arg-max agreement (a bf16 pipeline cannot meet
 1e-3 against an fp32 reference; the 1e-3 gate is the fp32-I/O mode).
 """
 import copy
@@ -15,13 +15,12 @@ from cobevt_amd import host, synth
 from cobevt_amd.synth import fill_module_
 import oracle.corpbevt as o_model
 import oracle.fax as o_fax
-from util import BF16_NUSC_E2E, BF16_OP, BF16_SMALL_E2E, assert_close, class_margin_stats, golden, rel_err, rms_rel_err
+from util import BF16, BF16_FLOOR, bf16_gate, assert_close, class_margin_stats, golden, rel_err, rms_rel_err
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
-MODES = [(torch.float32, 1e-3), (torch.bfloat16, BF16_OP)]
-BF16_E2E_TOL, BF16_E2E_RMS = 2e-2, 8e-3        # full-size end-to-end bf16 gates (measured 1.5e-2 max-rel on the bench frame)
+MODES = [(torch.float32, 1e-3), (torch.bfloat16, BF16)]      # BF16: gate = max(1e-2, the reference's own bf16-autocast deviation), util.py
 
 
 def dev(m, cuda):
@@ -86,7 +85,7 @@ def test_swap_fusion(cuda, dtype, tol):
             assert_close(y, g["encoder_mask" if use_mask else "encoder_nomask"], tol, "SwapFusionEncoder mask=%s" % use_mask)
 
 
-@pytest.mark.parametrize("dtype,tol", MODES)
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16_FLOOR)])   # a warp / a copy: storage rounding only
 def test_sttf_and_regroup_modules(cuda, dtype, tol):
     g = golden("gv6_sttf_regroup")
     s = cases.STTF
@@ -160,7 +159,7 @@ def _argmax_agreement(a, b, margin=0.0):
     return float(same.float().mean().item())
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16_SMALL_E2E)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16)])
 def test_corpbevt_small_end_to_end(cuda, dtype, tol):
     """GV8: the reference's own output for the reduced CorpBEVT, through the registry, both models."""
     from cobevt_amd.registry import create_model
@@ -174,10 +173,10 @@ def test_corpbevt_small_end_to_end(cuda, dtype, tol):
     assert "features" in b                                            # the reference's side effect (corpbevt.py:113)
     assert out["dynamic_seg"].dtype == torch.float32 and tuple(out["dynamic_seg"].shape) == g["dynamic_seg"].shape
     assert out["static_seg"].abs().max().item() == 0
-    assert_close(out["dynamic_seg"], g["dynamic_seg"], tol, "CorpBEVT.small logits")
+    assert_close(out["dynamic_seg"], g["dynamic_seg"], tol, "CorpBEVT.small logits", case="CorpBEVT.small.dynamic_seg")
     ref = torch.from_numpy(g["dynamic_seg"])
     agree = _argmax_agreement(out["dynamic_seg"].cpu(), ref)
-    decisive = _argmax_agreement(out["dynamic_seg"].cpu(), ref, margin=2 * tol)
+    decisive = _argmax_agreement(out["dynamic_seg"].cpu(), ref, margin=2 * (bf16_gate("CorpBEVT.small.dynamic_seg")[0] if tol is BF16 else tol))
     assert decisive >= 0.999, "arg-max agreement on decisive pixels %.4f" % decisive
     assert agree >= (0.999 if dtype == torch.float32 else 0.97), "arg-max agreement %.4f" % agree
     cfg2 = {k: copy.deepcopy(v) for k, v in cfg.items() if k in ("target", "encoder", "decoder", "fax", "seg_head_dim", "output_class")}
@@ -188,7 +187,7 @@ def test_corpbevt_small_end_to_end(cuda, dtype, tol):
     assert_close(out2["dynamic_seg"], golden("gv8_fax_fused_small")["dynamic_seg"], tol, "FaxFusedTransformer.small")
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16_SMALL_E2E)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16)])
 def test_corpbevt_ragged_scenarios_vs_oracle(cuda, dtype, tol):
     """a training-style batch of several scenarios with different agent counts (collate_batch concatenates the agents of
     all scenarios, record_len says how many belong to each, intermediate_fusion_dataset.py:261-295): regroup pads every
@@ -214,10 +213,10 @@ def test_corpbevt_ragged_scenarios_vs_oracle(cuda, dtype, tol):
     solo["record_len"] = torch.tensor([1], dtype=torch.int64)
     with host.compute_dtype(dtype):
         alone = m({k: v.to(cuda) for k, v in solo.items()})["dynamic_seg"]
-    assert_close(alone[0], out[1].cpu().numpy(), tol, "scenario independent of its batch neighbours")
+    assert_close(alone[0], out[1].cpu().numpy(), tol, "scenario independent of its batch neighbours", case="CorpBEVT ragged scenarios")
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16_SMALL_E2E)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16)])
 def test_naive_compressor_and_compressed_corpbevt(cuda, dtype, tol):
     """GV13: the reference's NaiveCompressor output and its reduced CorpBEVT with compression = 2"""
     g = golden("gv13_naive_compressor")
@@ -226,7 +225,7 @@ def test_naive_compressor_and_compressed_corpbevt(cuda, dtype, tol):
     with host.compute_dtype(dtype):
         y = comp(x.to(cuda))
     assert y.dtype == torch.float32
-    assert_close(y, g["compressor"], BF16_OP if dtype == torch.bfloat16 else tol, "NaiveCompressor")
+    assert_close(y, g["compressor"], tol, "NaiveCompressor")
     cfg = synth.corpbevt_small_compressed_config(2)
     m = dev(fill_module_(host.CorpBEVT(copy.deepcopy(cfg)), cases.SEED), cuda)
     batch = synth.opv2v_batch(agents=2, cams=2, image=128, max_cav=3, seed=cases.SEED)
@@ -262,24 +261,29 @@ def test_corpbevt_full_config_vs_oracle(cuda, agents):
           "worst flipped margin %.4f" % (agents, e32, r32, s32["agreement"], e16, r16, s16["agreement"], s16["decisive_agreement"],
                                          s16["worst_flipped_margin"]))
     assert e32 <= 1e-3 and r32 <= 1e-4 and s32["agreement"] >= 0.999
-    # bf16 gates sit at <= 1.5x the values measured on MI355X (max-rel 1.5e-2 / rms-rel 4e-3 on this frame)
-    assert e16 <= BF16_E2E_TOL and r16 <= BF16_E2E_RMS and s16["agreement"] >= 0.98
+    # bf16: max(1e-2, the reference's own bf16-autocast deviation on this frame) in both norms (util.bf16_gate, gv18 fixture)
+    full = "CorpBEVT.full %d agents." % agents
+    g_max, g_rms = bf16_gate(full + "dynamic_seg")
+    assert e16 <= g_max and r16 <= g_rms and s16["agreement"] >= 0.98, (e16, r16, g_max, g_rms)
     assert s16["decisive_agreement"] >= 0.9999 and s16["worst_flipped_margin"] <= 0.03
     # intermediate tensors, not only the logits: every pyramid level's BEV query, the per-agent features V2V sharing transmits,
     # the warped maps and the fused BEV map (oracle tensors are channels-first)
-    for dtype, tol, rms in ((torch.float32, 1e-3, 1e-4), (torch.bfloat16, BF16_E2E_TOL, BF16_E2E_RMS)):
+    # (the reference fixture holds the pyramid's output and the fused map; the per-level queries and the warped maps are gated
+    #  like the pyramid output they lead to / are interpolated from)
+    for dtype in (torch.float32, torch.bfloat16):
         g = got[dtype]
-        pairs = [("fax_level%d" % i, g["fax_level%d" % i].permute(0, 3, 1, 2), ref_all["fax_level%d" % i]) for i in range(3)]
-        pairs.append(("agent features", g["feats"].permute(0, 3, 1, 2), ref_all["fax"]))
-        pairs.append(("sttf", g["sttf"], ref_all["sttf"]))
-        pairs.append(("fused", g["fused"].permute(0, 3, 1, 2), ref_all["fused"]))
-        for name, a, r in pairs:
+        pairs = [("fax_level%d" % i, g["fax_level%d" % i].permute(0, 3, 1, 2), ref_all["fax_level%d" % i], "fax") for i in range(3)]
+        pairs.append(("agent features", g["feats"].permute(0, 3, 1, 2), ref_all["fax"], "fax"))
+        pairs.append(("sttf", g["sttf"], ref_all["sttf"], "fax"))
+        pairs.append(("fused", g["fused"].permute(0, 3, 1, 2), ref_all["fused"], "fused"))
+        for name, a, r, case in pairs:
+            tol, rms = (1e-3, 1e-4) if dtype == torch.float32 else bf16_gate(full + case)
             e, q = rel_err(a, r), rms_rel_err(a, r)
-            print("   %-16s %s max-rel %.2e rms-rel %.2e" % (name, str(dtype).split(".")[-1], e, q))
+            print("   %-16s %s max-rel %.2e rms-rel %.2e (gates %.2e / %.2e)" % (name, str(dtype).split(".")[-1], e, q, tol, rms))
             assert e <= tol and q <= rms, "%s (%s): max-rel %.3e rms-rel %.3e" % (name, dtype, e, q)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16_NUSC_E2E)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16)])
 def test_nuscenes_sinbevt(cuda, dtype, tol):
     """BASELINE config[1]: nuScenes SinBEVT, 1 ego x 6 cams (EfficientNet-B4-shaped features of 224x480 images),
     200x200 BEV, non-square 6x12 / 14x30 key windows on zero-padded maps, heads 1/2/4 — vs the reference's outputs."""
@@ -294,14 +298,14 @@ def test_nuscenes_sinbevt(cuda, dtype, tol):
         e = model.encoder(batch)
         out = model(batch)
         nrm = model.encoder.norm(batch["image"].flatten(0, 1))
-    assert_close(e, g["encoder"], tol, "PyramidAxialEncoder")
+    assert_close(e, g["encoder"], tol, "PyramidAxialEncoder", case="nuScenes SinBEVT.encoder")
     assert out["bev"].dtype == torch.float32 and tuple(out["bev"].shape) == (1, 1, 200, 200)
-    assert_close(out["bev"], g["bev"], tol, "bev logits")
-    assert_close(out["center"], g["center"], tol, "center logits")
+    assert_close(out["bev"], g["bev"], tol, "bev logits", case="nuScenes SinBEVT.bev")
+    assert_close(out["center"], g["center"], tol, "center logits", case="nuScenes SinBEVT.center")
     assert np.allclose(nrm[:, :, ::37, ::41].cpu().numpy(), g["normalized_image_sample"], atol=1e-5)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16_OP)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16)])
 def test_lidar_shaped_fusebevt(cuda, dtype, tol):
     """BASELINE config[4] operator config (SwapFusionEncoder input_dim 64, 8 agents, window 8, depth 3, mask: 512 tokens
     per window, 2 heads, 3375-row 3-D bias table) on a reduced 32x32 map, against the oracle."""
@@ -316,7 +320,7 @@ def test_lidar_shaped_fusebevt(cuda, dtype, tol):
     enc = enc.to(cuda)
     with host.compute_dtype(dtype):
         y = enc(x.to(cuda), mask.to(cuda))
-    assert_close(y, ref, tol, "LiDAR-shaped SwapFusionEncoder")
+    assert_close(y, ref, tol, "LiDAR-shaped SwapFusionEncoder", case="SwapFusionEncoder lidar-shaped")
 
 
 def _lidar_encoder_and_inputs():
@@ -341,11 +345,11 @@ def test_lidar_fusebevt_full_size(cuda):
     ref = o_swap.swap_fusion_encoder(enc.state_dict(), "", args, x, mask)
     enc = enc.to(cuda)
     xd, md = x.to(cuda), mask.to(cuda)
-    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, BF16_OP)):
+    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, BF16)):
         with host.compute_dtype(dtype):
             y = enc(xd, md)
         assert tuple(y.shape) == (1, 64, 256, 256)
-        e = assert_close(y, ref, tol, "LiDAR FuseBEVT 8x64x256x256 %s" % dtype)
+        e = assert_close(y, ref, tol, "LiDAR FuseBEVT 8x64x256x256 %s" % dtype, case="SwapFusionEncoder lidar-shaped")
         print("LiDAR FuseBEVT full size %s: rel err %.2e" % (dtype, e))
     # masked agents are never read as keys: the block stack's output rows of the real agents do not depend on them
     from cobevt_amd.host import swap_fusion_modules as sfm
@@ -363,7 +367,7 @@ def test_lidar_fusebevt_full_size(cuda):
     assert not torch.equal(outs[0][:, 6:], outs[1][:, 6:])
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16_SMALL_E2E)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16)])
 @pytest.mark.parametrize("kind,core", [("single", "cross_view_transformer"), ("swap_fuse", "cross_view_transformer_swap_fuse"),
                                        ("fcooper", "cross_view_transformer_fcooper"),
                                        ("att_fuse", "cross_view_transformer_att_fuse"),
@@ -383,9 +387,9 @@ def test_cvt_baseline_models(cuda, dtype, tol, kind, core):
         if kind == "single":
             feats = m.encoder(b["inputs"])
             cvm = m.cvm({"inputs": b["inputs"], "intrinsic": b["intrinsic"], "extrinsic": b["extrinsic"], "features": feats})
-            assert_close(cvm, g["single_cvm"], BF16_OP if dtype == torch.bfloat16 else tol, "CrossViewModule")
+            assert_close(cvm, g["single_cvm"], tol, "CrossViewModule")
     assert out["dynamic_seg"].dtype == torch.float32
-    assert_close(out["dynamic_seg"], g[kind + "_dynamic_seg"], tol, "CVT %s logits" % kind)
+    assert_close(out["dynamic_seg"], g[kind + "_dynamic_seg"], tol, "CVT %s logits" % kind, case="CVT " + kind)
 
 
 def test_cvt_full_config_vs_oracle(cuda):
@@ -406,7 +410,8 @@ def test_cvt_full_config_vs_oracle(cuda):
         y16 = m(dict(b))["dynamic_seg"]
     e32, e16 = rel_err(y32, ref), rel_err(y16, ref)
     print("CVT swap-fuse full config: fp32 rel %.2e | bf16 rel %.2e" % (e32, e16))
-    assert e32 <= 1e-3 and e16 <= 5e-2
+    # full-size: gated like the reduced swap-fuse model's own reference deviation (gv18 "CVT swap_fuse")
+    assert e32 <= 1e-3 and e16 <= bf16_gate("CVT swap_fuse")[0]
 
 
 def test_cav_attention_and_base_transformer_full_width(cuda):
@@ -422,7 +427,7 @@ def test_cav_attention_and_base_transformer_full_width(cuda):
     mask[0, :, 20:, :, 4] = 0
     ref = o_cvt.base_transformer(m.state_dict(), "", args, x, mask)
     m = m.to(cuda)
-    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, BF16_OP)):
+    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, BF16_FLOOR)):       # no reference fixture for the operator alone: 1e-2
         with host.compute_dtype(dtype):
             y = m(x.to(cuda), mask.to(cuda))
         assert_close(y, ref, tol, "BaseTransformer %s" % dtype)
@@ -453,7 +458,7 @@ def test_pairwise_fusion_full_width_vs_oracle(cuda, kind):
     x, rl, pw = _pairwise_case(2, 3, 5, 128, 32, cases.SEED)
     ref = fwd(m.state_dict(), "", args, x, rl, pw)
     m = m.to(cuda)
-    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, BF16_OP)):
+    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, BF16_FLOOR)):       # no reference fixture for the operator alone: 1e-2
         with host.compute_dtype(dtype):
             y = m(x.to(cuda), rl.to(cuda), pw.to(cuda))
         assert_close(y, ref, tol, "%s fusion %s" % (kind, dtype))

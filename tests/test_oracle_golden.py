@@ -5,6 +5,7 @@ procedurally, inputs are procedural — so these tests also pin the host modules
 Tolerance 1e-5 rel: same fp32 math on a possibly different CPU / thread count.
 """
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -244,3 +245,40 @@ def test_gv17_cvt_baselines(kind, core):
     assert_close(fwd(sd, cfg, dict(batch))["dynamic_seg"], g[kind + "_dynamic_seg"], TOL, "CVT " + kind)
     if kind == "single":
         assert_close(o_cvt.encode_agents(sd, cfg, dict(batch)), g["single_cvm"], TOL, "CrossViewModule")
+
+
+def test_gv18_reference_bf16_fixture_backs_every_bf16_gate():
+    """gv18 (the reference's own bf16-autocast deviation, tests/golden/make_golden.py gv18) holds every case the GPU tests look
+    up, its envelopes are the maxima of the per-weight-set values it also stores, and the gate rule of tests/util.py is
+    max(1e-2, that deviation) - fixed numbers, nothing measured on the HIP path"""
+    import re
+    import util
+    g = golden("gv18_reference_bf16_autocast")
+    for k in g.files:
+        if k.endswith("#seeds"):
+            continue
+        per = g[k + "#seeds"]
+        assert per.ndim == 2 and per.shape[1] == 3 and per.shape[0] >= 1
+        assert np.allclose(g[k], [per[:, 0].max(), per[:, 1].max(), per[:, 2].min()])
+        assert 1e-3 < g[k][0] < 0.1 and 1e-3 < g[k][1] < 0.1, (k, g[k])        # a bf16 run: between 2^-10 and 10 %
+        gm, gr = util.bf16_gate(k)
+        assert gm == max(1e-2, g[k][0]) and abs(gr - max(0.9e-2, g[k][1])) < 1e-12
+    assert util.bf16_gate()[0] == 1e-2 and abs(util.bf16_gate()[1] - 0.9e-2) < 1e-12
+    # every case name the GPU tests pass resolves
+    here = os.path.dirname(os.path.abspath(__file__))
+    names = set()
+    for f in ("test_modules_gpu.py", "test_efficientnet.py"):
+        src = open(os.path.join(here, f)).read()
+        names.update(re.findall(r'case="([^"%]+)"\)', src))          # literal case names (the concatenated ones are listed below)
+    names.update(["CrossWinAttention." + n for n in cases.CROSS_WIN] + ["CrossViewSwapAttention." + n for n in cases.CVSA])
+    names.update(["FAXModule", "swap Attention + mask", "swap Attention", "SwapFusionBlockMask", "SwapFusionEncoder mask=True",
+                  "SwapFusionEncoder mask=False", "NaiveDecoder", "FAX global attention", "NaiveCompressor", "CrossViewModule",
+                  "CorpBEVT.small compression=2", "FaxFusedTransformer.small", "CorpBEVT ragged scenarios", "regroup"])
+    names.update("resnet%d[%d]" % (d, i) for d in (18, 34) for i in range(3))
+    names.update("CVT " + k for k in ("single", "swap_fuse", "fcooper", "att_fuse", "v2vnet", "disconet"))
+    names.update("CorpBEVT.full %d agents.%s" % (a, k) for a in (2, 5) for k in ("dynamic_seg", "fax", "fused"))
+    names.update("nuScenes SinBEVT." + k for k in ("bev", "center", "encoder"))
+    names.update("BevSegHead.%s.%s" % (t, k) for t, k in (("dynamic", "dynamic_seg"), ("static", "static_seg"),
+                                                         ("both", "static_seg"), ("both", "dynamic_seg")))
+    missing = sorted(n for n in names if n not in g.files and n != "regroup")
+    assert not missing, missing

@@ -47,25 +47,58 @@ def class_margin_stats(got, ref, class_dim):
             "worst_flipped_margin": flipped.max().item() if flipped.numel() else 0.0}
 
 
-# Gates sit at <= 1.5x the values measured on MI355X (gpurun_out/r03a/parity_report.tsv, written by assert_close below with
-# COBEVT_PARITY_REPORT set): bf16 per operator max-rel <= 9.0e-3 / rms-rel <= 8.4e-3 -> BF16_OP; reduced-size end-to-end
-# models (CorpBEVT.small, the CVT baselines: tiny logit scales) <= 3.0e-2 / 2.6e-2 -> BF16_SMALL_E2E; nuScenes SinBEVT at
-# its real shapes <= 1.4e-2 / 8.1e-3 -> BF16_NUSC_E2E; the full-size OPV2V frame 1.5e-2 -> test_modules_gpu.BF16_E2E_TOL.
-# The rms-rel error must stay below 0.9x the max-rel gate (fp32: below the gate itself).
-BF16_OP, BF16_SMALL_E2E, BF16_NUSC_E2E = 1.5e-2, 4.5e-2, 2e-2
+# bf16 gates (VERDICT r03 item 1).  Fixed numbers that do not come from anything measured on the HIP path:
+#   * BF16_FLOOR = 1e-2: the bf16 gate BASELINE.md section 2 states ("bf16 perf mode is gated at 1e-2 + argmax/mIoU agreement");
+#   * tests/golden/gv18_reference_bf16_autocast.npz: how far the REFERENCE's own bf16 run - the same module / model inside
+#     torch.autocast(bfloat16), its mixed-precision mode (opv2v/opencood/tools/train_camera.py:157-160,
+#     nuscenes/scripts/benchmark.py:45) - moves away from its fp32 forward, on the tests' inputs, as the envelope over the
+#     procedural weight sets 0..3 (tests/golden/make_golden.py gv18; the reference's deviation moves by +-40 % between weight
+#     sets: it is one realisation of accumulated rounding noise).
+# A bf16 result of the HIP path may deviate from the fp32 reference / oracle by max(BF16_FLOOR, the reference's own deviation)
+# in the max norm and by max(0.9 * BF16_FLOOR, the reference's own rms deviation) in the rms norm - never by more.
+# `BF16` as a tolerance means "look the gate up under the comparison's case name"; comparisons whose module the reference
+# fixture does not hold (restated third-party EfficientNet, fusion operators in isolation) name the fixture case of the
+# model they belong to or run at the floor.
+BF16_FLOOR = 1e-2
+BF16 = "bf16: reference-derived gate"
 RMS_FRACTION = {True: 0.9, False: 1.0}           # keyed by "tol is a bf16 gate" (tol > 2e-3)
+_REF_BF16 = None
 _REPORT = os.environ.get("COBEVT_PARITY_REPORT")
 
 
-def assert_close(got, ref, tol, what):
+def reference_bf16_deviation(case):
+    """[max-rel, rms-rel, arg-max agreement] of the reference's bf16-autocast run for `case` (gv18 fixture)"""
+    global _REF_BF16
+    if _REF_BF16 is None:
+        _REF_BF16 = golden("gv18_reference_bf16_autocast")
+    if case not in _REF_BF16:
+        raise KeyError("no reference bf16-autocast deviation recorded for %r (tests/golden/make_golden.py gv18)" % case)
+    return [float(v) for v in _REF_BF16[case]]
+
+
+def bf16_gate(case=None):
+    """(max-rel gate, rms-rel gate) for a bf16 comparison; case=None: no reference counterpart -> the floor"""
+    if case is None:
+        return BF16_FLOOR, RMS_FRACTION[True] * BF16_FLOOR
+    r = reference_bf16_deviation(case)
+    return max(BF16_FLOOR, r[0]), max(RMS_FRACTION[True] * BF16_FLOOR, r[1])
+
+
+def assert_close(got, ref, tol, what, case=None):
+    """tol: a number (max-rel gate; the rms-rel gate is tol itself, 0.9 * tol for a bf16-sized gate) or BF16 (gates looked up
+    in the reference's bf16-autocast fixture under `case`, default: `what`)"""
+    if tol is BF16 or tol == BF16:
+        tol, rms_gate = bf16_gate(what if case is None else case)
+    else:
+        rms_gate = tol * RMS_FRACTION[tol > 2e-3]
     e = rel_err(got, ref)
     r = rms_rel_err(got, ref)
-    if _REPORT:                      # measured values next to their gates: how the gates in the tests were set
+    if _REPORT:                      # measured values next to their gates
         with open(_REPORT, "a") as f:
-            f.write("%s\t%s\tmax_rel=%.3e\trms_rel=%.3e\tgate=%.1e\n" % (os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], what, e, r, tol))
-    assert e <= tol, "%s: rel err %.3e > %.1e" % (what, e, tol)
-    rms_gate = tol * RMS_FRACTION[tol > 2e-3]
-    assert r <= rms_gate, "%s: rms rel err %.3e > %.1e" % (what, r, rms_gate)
+            f.write("%s\t%s\tmax_rel=%.3e\trms_rel=%.3e\tgate=%.2e\trms_gate=%.2e\n"
+                    % (os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], what, e, r, tol, rms_gate))
+    assert e <= tol, "%s: rel err %.3e > %.2e" % (what, e, tol)
+    assert r <= rms_gate, "%s: rms rel err %.3e > %.2e" % (what, r, rms_gate)
     return e
 
 
