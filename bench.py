@@ -8,10 +8,11 @@
 `--workload camera` (default; the configuration BASELINE.json's metric is quoted on): one "step" = one full CorpBEVT forward
 per GPU: `agents` x 4 cameras x 512x512 fp32 images (resident in HBM) -> ResNet-34 -> FAX pyramid -> [all-gather of agent
 features] -> STTF -> swap fusion -> decoder -> 256x256 logits, through cobevt_amd.host.pipeline (HIP graphs, three frames
-in flight).  N > 1, `--mode throughput` (default, "weak" scaling): N frames per step, the N*agents agent tasks dealt
-round-robin over the ranks and exchanged by ONE RCCL all-gather before fusion; value = N frames / step time.
-`--mode latency` ("strong" scaling): ONE frame per step, rank r encodes agents r, r+N, .., one all-gather, fusion replicated;
-value = 1 frame / step time.
+in flight).  N > 1: the headline is the same quantity ("throughput" mode, "weak" scaling): N frames per step, the N*agents
+agent tasks dealt round-robin over the ranks and exchanged ONCE before fusion; value = N frames / step time, so
+value_N / (N x value_1) is the agent-shard scaling efficiency.  The same line carries `latency_mode` ("strong" scaling, the
+north-star's partition): ONE frame per step, rank r encodes agents r, r+N, .., one all-gather, fusion replicated, with its
+`frame_latency_ms`; `--mode latency` makes that the headline.
 `--workload lidar` (BASELINE configs[4]): one step = SwapFusionEncoder(64 ch, 8 agents, window 8, depth 3, mask) on
 x (1, 8, 64, 256, 256); N > 1 throughput = one frame per rank (replicas), latency = the map row-sharded over the ranks with
 an all-to-all between the window and grid halves of every block (cobevt_amd/dist.py).
@@ -58,9 +59,10 @@ def parse():
     ap.add_argument("--agents", type=int, default=5)
     ap.add_argument("--workload", default="camera", choices=["camera", "lidar"])
     ap.add_argument("--mode", default=None, choices=["throughput", "latency", "both"],
-                    help="N > 1: latency = ONE frame over N GPUs, one agent per GPU + one all-gather (strong scaling; BASELINE.json's "
-                         "partitioning, the headline), throughput = N frames in flight (weak scaling), both (default at N > 1) = "
-                         "latency as the headline `value` with the throughput mode in the same JSON line.  N = 1: throughput")
+                    help="N > 1: throughput = N frames in flight, their agents dealt over the GPUs + one exchange (weak scaling; the "
+                         "same quantity as the N = 1 headline), latency = ONE frame over N GPUs, one agent per GPU + one all-gather "
+                         "(strong scaling; BASELINE.json's partitioning), both (default at N > 1) = throughput as the headline `value` "
+                         "with `latency_mode` (frame_latency_ms) in the same JSON line.  N = 1: throughput")
     ap.add_argument("--gather", default="rccl", choices=["rccl", "direct"],
                     help="latency mode: the agent all-gather through RCCL (torch.distributed, default) or the one-shot direct "
                          "peer-window exchange over xGMI (csrc/peer_gather.hip); the other one is reported next to it")
@@ -125,6 +127,55 @@ def quick(step, warmup=3, steps=20):
 
 
 # ----------------------------------------------------------------------------------------------
+# box calibration
+# ----------------------------------------------------------------------------------------------
+def box_calibration(dev):
+    """What THIS box delivers, measured in-process in ~100 ms (csrc/calibrate.hip): the dense issue rate of
+    v_mfma_f32_32x32x16_bf16 (four waves per SIMD, no operand traffic), the shader clock under that load, and an HBM stream copy.
+    Boxes of the pool differ by +-6..10 %: with these three numbers in the line a roofline fraction can be normalised by the
+    box it was measured on, and a few-% frames/s difference between two runs can be attributed."""
+    import ctypes
+    from cobevt_amd import lib as L
+    lib = L.load()
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    blocks, iters = 1024, 16000
+    out = torch.empty(blocks * 256, device=dev, dtype=torch.float32)
+    clk = torch.zeros(2, device=dev, dtype=torch.int64)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = None
+    for _ in range(3):
+        e0.record()
+        L.check(lib.cobevt_calibrate_mfma(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(clk.data_ptr()), blocks, iters, stream),
+                "cobevt_calibrate_mfma")
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        if best is None or ms < best[0]:
+            best = (ms, [int(v) for v in clk.tolist()])
+    flops = blocks * 4 * iters * 4 * 2.0 * 32 * 32 * 16
+    wall, smax = ctypes.c_int(), ctypes.c_int()
+    L.check(lib.cobevt_calibrate_clock_khz(ctypes.byref(wall), ctypes.byref(smax)), "cobevt_calibrate_clock_khz")
+    sclk = best[1][0] / max(1, best[1][1]) * wall.value / 1e3
+    n = 1 << 30
+    src = torch.empty(n, device=dev, dtype=torch.uint8).fill_(1)
+    dst = torch.empty(n, device=dev, dtype=torch.uint8)
+    cms = None
+    for _ in range(5):
+        e0.record()
+        L.check(lib.cobevt_calibrate_copy(ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), n, stream), "cobevt_calibrate_copy")
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1)
+        cms = t if cms is None or t < cms else cms
+    del src, dst
+    return {"mfma_bf16_tflops": round(flops / (best[0] * 1e-3) / 1e12, 1), "sclk_mhz_under_mfma_load": round(sclk, 0),
+            "sclk_max_mhz": round(smax.value / 1e3, 0), "hbm_copy_gbs": round(2.0 * n / (cms * 1e-3) / 1e9, 1),
+            "note": "csrc/calibrate.hip, best of 3 / 5 launches: 1024 workgroups x 4 waves x %d x 4 independent bf16 32x32x16 MFMAs; "
+                    "shader clock = s_memtime / wall-clock ticks of workgroup 0 inside that loop; 1 GiB streaming copy "
+                    "(read + write bytes)" % iters}
+
+
+# ----------------------------------------------------------------------------------------------
 # roofline leg
 # ----------------------------------------------------------------------------------------------
 MFMA_FAMILIES = ("conv3x3", "basicblock", "bottleneck", "gemm_rows", "row_chain", "igemm", "attention", "stem7x7", "head3x3", "swap_stage")
@@ -167,7 +218,11 @@ def roofline_leg(runner, dtype_name):
         gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
         e = {"kernel": name, "traffic": pmc.get("hbm_bytes"), "mfma_util_pmc": pmc.get("mfma_util"),
              "launches_per_frame": d["calls"],
-             "avg_launch_us": round(d["ms"] * 1e3 / d["calls"], 2), "total_ms_per_frame": round(d["ms"], 3),
+             "avg_launch_us": round(d["ms"] * 1e3 / d["calls"], 2),
+             # `traffic` / `mfma_util_pmc` come from the committed rocprofv3 PMC run (another box): its own average launch
+             # duration beside this run's HIP-event figure, so a reader sees how far the two runs are apart
+             "avg_duration_us_profiled": pmc.get("avg_duration_us_profiled"),
+             "total_ms_per_frame": round(d["ms"], 3),
              "algorithmic_gflop_per_launch": round(d["flops"] / 1e9 / d["calls"], 2),
              "algorithmic_mbyte_per_launch": round(d["bytes"] / 1e6 / d["calls"], 2),
              "algorithmic_tflop_s": round(tf, 2), "algorithmic_gbyte_s": round(gbs, 1)}
@@ -201,6 +256,16 @@ def roofline_leg(runner, dtype_name):
         if big:                   # the PMC record with the most MFMA work per launch is the same launch
             pm = max(big, key=lambda v: v["counters_per_launch"].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0))
         fax0 = entry("fax_attention_level0 (%s)" % k0.split("|", 1)[1], attn[k0], pm, bound="mfma")
+        # two different numbers: `useful_mfma_frac` = algorithmic FLOP/s / dense peak (= `frac`);
+        # `mfma_util_pmc` = matrix-pipe BUSY share, which also counts the row-sum MFMAs (ones x P^T, 4 of every 12
+        # matrix instructions of a 64-key tile: csrc/attention_resident.hip) - VALU work moved onto the idle matrix pipe, not
+        # useful FLOPs.  SQ_INSTS_MFMA per launch vs the count the algorithmic FLOPs need states the overhead.
+        fax0["useful_mfma_frac"] = fax0["frac"]
+        need = attn[k0]["flops"] / attn[k0]["calls"] / (2.0 * 32 * 32 * 16)
+        have = (pm.get("counters_per_launch") or {}).get("SQ_INSTS_MFMA")
+        fax0["mfma_insts_needed_per_launch"] = round(need)
+        fax0["mfma_insts_issued_per_launch_pmc"] = None if have is None else round(have)
+        fax0["mfma_inst_overhead"] = None if not have else round(have / need, 3)
     return dom, others, fax0, round(best_tot, 3)
 
 
@@ -246,7 +311,19 @@ def cpu_baseline_leg(model, cfg, batch_cpu, gpu_out):
                           "over the decisive ones (oracle top-2 margin > 2 % of the logit scale); per-class IoU of the arg-max maps "
                           "(seg_utils.py:25-51).  The procedural head is class-balanced (cobevt_amd.synth.balance_seg_head_): half "
                           "of the map sits within a few % of a tie, so agreement here is a worst case"}
-    return base, {k: parity(v) for k, v in gpu_out.items()}
+    par = {k: parity(v) for k, v in gpu_out.items()}
+    # what the REFERENCE's own bf16 run (torch.autocast) does on this very frame (fixture made by running the reference,
+    # tests/golden/make_golden.py gv18): the yardstick of the bf16 figures above
+    try:
+        g = np.load(os.path.join(ROOT, "tests", "golden", "gv18_reference_bf16_autocast.npz"))
+        key = "CorpBEVT.full %d agents balanced head" % batch_cpu["inputs"].shape[0]
+        if "bf16" in par and key in g.files:
+            par["bf16"]["reference_bf16_autocast_on_this_frame"] = {
+                "logits_rel_err_vs_fp32": float("%.3e" % g[key][0]), "logits_rms_rel_err_vs_fp32": float("%.3e" % g[key][1]),
+                "argmax_agreement": round(float(g[key][2]), 5), "source": "tests/golden/gv18_reference_bf16_autocast.npz[%r]" % key}
+    except Exception:  # noqa: BLE001
+        pass
+    return base, par
 
 
 # ----------------------------------------------------------------------------------------------
@@ -306,22 +383,28 @@ def run_lidar(args, rank, world, dev):
                       "weights": "procedural (cobevt_amd.synth)"},
            "achieved_tflops_end_to_end": round(LIDAR_GF * frames_per_step / (ms * 1e-3) / 1e3, 2)}
     if rank == 0 and world == 1 and not args.no_roofline:
-        with ops.LaunchProfile() as prof:
-            enc(x, mask)
-        summ = prof.summary()
-        peak = PEAK_TFLOPS[args.dtype]
-        fams = sorted(summ, key=lambda f: -summ[f]["ms"])
-        ent = []
-        for f in fams:
-            d = summ[f]
-            tf, gbs = d["flops"] / (d["ms"] * 1e-3) / 1e12, d["bytes"] / (d["ms"] * 1e-3) / 1e9
-            hbm = f in HBM_BOUND_FAMILIES
-            ent.append({"kernel": f, "traffic": None, "launches_per_frame": d["calls"], "avg_launch_us": round(d["ms"] * 1e3 / d["calls"], 2),
-                        "bound": "hbm" if hbm else "mfma", "achieved": round(gbs if hbm else tf, 2),
-                        "peak": PEAK_HBM_GBS if hbm else peak, "unit": "GB/s" if hbm else "TFLOP/s",
-                        "frac": round((gbs / PEAK_HBM_GBS) if hbm else (tf / peak), 4)})
+        ent = lidar_roofline(enc, x, mask, args.dtype)
         res["roofline"], res["roofline_other_kernels"] = ent[0], ent[1:]
     return res
+
+
+def lidar_roofline(enc, x, mask, dtype_name):
+    """HIP events around every launch of one eager SwapFusionEncoder forward -> one roofline entry per kernel family, largest first"""
+    with ops.LaunchProfile() as prof:
+        enc(x, mask)
+    summ = prof.summary()
+    peak = PEAK_TFLOPS[dtype_name]
+    fams = sorted(summ, key=lambda f: -summ[f]["ms"])
+    ent = []
+    for f in fams:
+        d = summ[f]
+        tf, gbs = d["flops"] / (d["ms"] * 1e-3) / 1e12, d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        hbm = f in HBM_BOUND_FAMILIES
+        ent.append({"kernel": f, "traffic": None, "launches_per_frame": d["calls"], "avg_launch_us": round(d["ms"] * 1e3 / d["calls"], 2),
+                    "bound": "hbm" if hbm else "mfma", "achieved": round(gbs if hbm else tf, 2),
+                    "peak": PEAK_HBM_GBS if hbm else peak, "unit": "GB/s" if hbm else "TFLOP/s",
+                    "frac": round((gbs / PEAK_HBM_GBS) if hbm else (tf / peak), 4)})
+    return ent
 
 
 def maybe_spawn(args):
@@ -418,10 +501,23 @@ def direct_probe_child(args, world):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.steps), "--warmup",
            str(args.warmup), "--dtype", args.dtype, "--agents", str(args.agents), "--direct-probe"] + (["--no-graph"] if args.no_graph else [])
+    # its own session / process group, so that a hung rank (a peer that never arrives leaves the others in bounded GPU polls, then in
+    # a host-side barrier) can be killed as a whole; the limit is generous for a healthy job (~60-120 s) and short enough not to
+    # eat the driver's window around the bench
+    limit = int(os.environ.get("COBEVT_DIRECT_PROBE_TIMEOUT", "360"))
+    import signal
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
     try:
-        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        out, err = proc.communicate(timeout=limit)
     except subprocess.TimeoutExpired:
-        return {"error": "direct-exchange probe job timed out after 900 s"}
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        proc.communicate()
+        return {"error": "direct-exchange probe job killed after %d s (COBEVT_DIRECT_PROBE_TIMEOUT): a rank of the peer-window "
+                         "exchange stalled; the RCCL figures of this line are unaffected" % limit}
+    p = subprocess.CompletedProcess(cmd, proc.returncode, out, err)
     for line in reversed(p.stdout.splitlines()):
         if line.startswith("{"):
             try:
@@ -592,32 +688,73 @@ def main():
         torch.distributed.destroy_process_group()
         return
     isolate_direct = False
-    if world > 1 and mode in ("both", "latency"):
-        result, runner, timed, batch, full, in_flight = camera_leg(args, "latency", model, cfg, rank, world, dev, gather=args.gather)
-        other_gather = "direct" if args.gather == "rccl" else "rccl"
-
-        def side(label, **kw):
+    if world > 1 and ranks.get("backend") == "nccl" and ranks.get("distinct_gpus") != world:
+        raise SystemExit("bench.py: RCCL process group of %d ranks sits on %s distinct GPU(s) - one GPU per rank is required "
+                         "(rank table: %s)" % (world, ranks.get("distinct_gpus"), ranks["ranks"]))
+    if world > 1:
+        # Headline at N > 1: the SAME quantity as at N = 1 - whole-job frames/s with frames in flight ("throughput"
+        # mode, weak scaling: N frames per step, their N x A agent tasks dealt round-robin over the GPUs, ONE exchange of the agent
+        # blocks in front of FuseBEVT) - so the driver's value_N / (N x value_1) IS the agent-shard scaling efficiency.  The
+        # north-star's one-frame partition (one agent per GPU, "latency" mode, strong scaling) rides in the same line as
+        # `latency_mode` with its `frame_latency_ms`: with 5 agents it cannot use more than 5 GPUs, so its frames/s per GPU falls
+        # as 1/N by construction and is not the scaling figure.  `--mode latency` makes it the headline explicitly.
+        def side(**kw):
             try:
-                r = camera_leg(args, kw.pop("mode", "latency"), model, cfg, rank, world, dev, **kw)[0]
-                return {k: r[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_median", "scaling", "mode", "config")}
+                r, _, t, _, _, _ = camera_leg(args, kw.pop("mode", "latency"), model, cfg, rank, world, dev, **kw)
+                out = {k: r[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_median", "scaling", "mode", "config")}
+                if r["mode"] == "latency":
+                    out["frame_latency_ms"] = round(r["ms_per_step"] * r["config"]["frame_latency_steps"], 4)
+                return out
             except Exception as e:  # noqa: BLE001
                 torch.cuda.synchronize()
                 return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        head_mode = "latency" if mode == "latency" else "throughput"
+        result, runner, timed, batch, full, in_flight = camera_leg(args, head_mode, model, cfg, rank, world, dev,
+                                                                   **({"gather": args.gather} if head_mode == "latency" else {}))
+        if head_mode == "latency":
+            result["frame_latency_ms"] = round(result["ms_per_step"] * result["config"]["frame_latency_steps"], 4)
+        other_gather = "direct" if args.gather == "rccl" else "rccl"
         if mode == "both":
-            result["latency_mode_unpipelined"] = side("depth1", gather=args.gather, depth=1)
-            result["throughput_mode"] = side("throughput", mode="throughput")
+            result["latency_mode"] = side(gather=args.gather)                      # depth 2: the tail of frame i-1 under frame i
+            result["latency_mode_unpipelined"] = side(gather=args.gather, depth=1)
             # the direct peer-window legs run in a job of their own after this one (direct_probe_child) unless the direct exchange
-            # IS the requested headline (--gather direct): a fault there must not cost the RCCL numbers
+            # IS the requested gather (--gather direct): a fault there must not cost the RCCL numbers
             isolate_direct = args.gather == "rccl"
             if isolate_direct:
                 safe(result, "all_gather_us", lambda: gather_latency_leg(model, batch, rank, world, A, dev, which=("rccl",)))
             else:
-                result["latency_mode_%s_gather" % other_gather] = side("other", gather=other_gather)
+                result["latency_mode_%s_gather" % other_gather] = side(gather=other_gather)
                 safe(result, "all_gather_us", lambda: gather_latency_leg(model, batch, rank, world, A, dev))
+        # the N = 1 figures of the same box, measured by rank 0 alone while the other ranks wait at the barrier below: what the
+        # per-GPU numbers above are to be compared with
+        torch.distributed.barrier()
+        if rank == 0:
+            def single():
+                r1, run1, _, _, _, _ = camera_leg(args, "throughput", model, cfg, 0, 1, dev)
+                lat = quick(run1.step, 3, 20)
+                return {"frames_per_sec": r1["value"], "ms_per_step": r1["ms_per_step"], "one_frame_at_a_time_ms": lat["ms_median"]}
+            safe(result, "single_gpu_reference", single)
+            ref1 = result["single_gpu_reference"]
+            if "error" not in ref1:
+                tp = result if head_mode == "throughput" else result.get("throughput_mode", {})
+                sc = {}
+                if "value" in tp:
+                    sc["throughput_frames_per_sec_per_gpu"] = round(tp["value"] / world, 3)
+                    sc["throughput_scaling_efficiency_vs_n1"] = round(tp["value"] / world / ref1["frames_per_sec"], 4)
+                lm = result if head_mode == "latency" else result.get("latency_mode", {})
+                if "frame_latency_ms" in lm:
+                    sc["frame_latency_ms"] = lm["frame_latency_ms"]
+                    sc["frame_latency_speedup_vs_n1"] = round(ref1["one_frame_at_a_time_ms"] / lm["frame_latency_ms"], 4)
+                sc["note"] = ("SCALE reads `value` (throughput mode at every N): efficiency = value_N / (N x value_1); the latency "
+                              "mode's figure of merit is frame_latency_ms, not frames/s per GPU")
+                result["scaling_summary"] = sc
+        torch.distributed.barrier()
     else:
         result, runner, timed, batch, full, in_flight = camera_leg(args, "throughput", model, cfg, rank, world, dev)
     result["rccl_ranks"] = ranks
 
+    if rank == 0:
+        safe(result, "box_calibration", lambda: box_calibration(dev))
     if rank == 0 and world == 1:
         if in_flight > 1:
             safe(result, "one_frame_at_a_time", lambda: dict(
@@ -665,21 +802,47 @@ def main():
                 return dict(quick(r3.step, 3, 30), config="OPV2V-camera CoBEVT: 2 agents x 4 cams 512x512, 256x256 BEV, one frame at "
                                                            "a time", algorithmic_gflop=round(GF_PER_AGENT * 2 + GF_PER_FRAME, 1))
 
-            def nuscenes():
+            def nuscenes(from_images):
+                """BASELINE configs[1]: 1 ego x 6 cams 224x480 -> 200x200 BEV.  from_images: the whole model - Normalize ->
+                EfficientNet-B4 extractor mirror (host/nuscenes/efficientnet.py) -> PyramidAxialEncoder -> Decoder -> heads - as the
+                reference's benchmark times it (nuscenes/scripts/benchmark.py:42-55: batch 1, forward only); otherwise the FAX encoder
+                + decoder on synthetic backbone features (SURVEY.md 8d's original leg, kept for continuity)"""
                 from cobevt_amd.host import nuscenes as nu
                 c = synth.nuscenes_config()
                 feats, image, intr, ext = synth.nuscenes_inputs("bench.nuscenes", 0)
-                encn = nu.PyramidAxialEncoder(synth.FeatureMapBackbone(feats), **copy.deepcopy(c["encoder"]))
+                if from_images:
+                    from cobevt_amd.host.nuscenes.efficientnet import EfficientNetExtractor
+                    backbone = EfficientNetExtractor(["reduction_2", "reduction_3", "reduction_4"], *c["image"])   # cvt_pyramid_axial.yaml:19
+                else:
+                    backbone = synth.FeatureMapBackbone(feats)
+                encn = nu.PyramidAxialEncoder(backbone, **copy.deepcopy(c["encoder"]))
                 sin = synth.fill_module_(nu.CrossViewTransformer(encn, nu.Decoder(**c["decoder"]), c["dim_last"], c["outputs"]), 0)
                 sin = sin.eval().to(dev)
                 r4 = pipeline.CapturedCall(lambda im, ii, ee: sin({"image": im, "intrinsics": ii, "extrinsics": ee}),
                                            image.to(dev), intr.to(dev), ext.to(dev), use_graph=not args.no_graph)
-                return dict(quick(r4.step, 3, 30), config="nuScenes SinBEVT: 1 ego x 6 cams 224x480, 200x200 BEV, FAX encoder + decoder "
-                                                           "on synthetic EfficientNet-B4-shaped backbone features (SURVEY.md §8d)",
-                            algorithmic_gflop=26.2)
+                if from_images:
+                    return dict(quick(r4.step, 3, 30), config="nuScenes SinBEVT (BASELINE configs[1]): 1 ego x 6 cams 224x480 images -> "
+                                "EfficientNet-B4 extractor -> FAX pyramid -> decoder -> 200x200 BEV, whole model from images, one "
+                                "frame at a time from a captured graph (EfficientNet arithmetic restated: parity unpinned, DESIGN.md 4)")
+                return dict(quick(r4.step, 3, 30), config="nuScenes SinBEVT: FAX encoder + decoder only, on synthetic "
+                            "EfficientNet-B4-shaped backbone features (SURVEY.md 8d)", algorithmic_gflop=26.2)
+
+            def lidar():
+                """BASELINE configs[4] on one GPU: SwapFusionEncoder (64 ch, 8 agents, window 8, depth 3, mask) on the
+                (1, 8, 64, 256, 256) voxel-BEV map, with the roofline of its kernels (`bench.py --workload lidar` is this leg alone)"""
+                enc = synth.fill_module_(host.SwapFusionEncoder(dict(LIDAR_ARGS)), 0).eval().to(dev)
+                x, mask = lidar_inputs(dev, seed=0)
+                run = pipeline.CapturedCall(lambda a, m: enc(a, m), x, mask, use_graph=not args.no_graph)
+                out = dict(quick(run.step, 3, 20), config="OPV2V-LiDAR FuseBEVT (BASELINE configs[4], one GPU): SwapFusionEncoder(64 ch, "
+                           "8 agents, window 8, depth 3, mask) on (1, 8, 64, 256, 256)", algorithmic_gflop=LIDAR_GF)
+                out["achieved_tflops_end_to_end"] = round(LIDAR_GF / out["ms_median"], 2)
+                out["roofline"] = lidar_roofline(enc, x, mask, args.dtype)
+                return out
             oc = {}
             safe(oc, "opv2v_2_agents", two_agents)
-            safe(oc, "nuscenes_sinbevt", nuscenes)
+            safe(oc, "nuscenes_sinbevt_from_images", lambda: nuscenes(True))
+            safe(oc, "nuscenes_sinbevt", lambda: nuscenes(False))
+            safe(oc, "lidar_fusebevt", lidar)
             result["other_configs"] = oc
         if not args.no_cpu_baseline:
             base, parity = cpu_baseline_leg(model, cfg, dict(full), outs)

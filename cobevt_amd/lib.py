@@ -108,6 +108,9 @@ SIGNATURES = {
     "cobevt_peer_window_close": (ctypes.c_int, [_vp]),
     "cobevt_peer_window_free": (ctypes.c_int, [_vp]),
     "cobevt_peer_window_status": (ctypes.c_int, [_vp, ctypes.c_long, _c_int_p, _c_int_p, _vp]),
+    "cobevt_calibrate_mfma": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
+    "cobevt_calibrate_copy": (ctypes.c_int, [_vp, _vp, ctypes.c_long, _vp]),
+    "cobevt_calibrate_clock_khz": (ctypes.c_int, [_c_int_p, _c_int_p]),
     "cobevt_peer_exchange": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long,
                                             _c_int_p, _c_int_p, ctypes.c_long, ctypes.c_long, _vp]),
     "cobevt_channel_gate_nhwc": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),

@@ -571,6 +571,18 @@ int cobevt_peer_exchange(const void* local, void* const* windows, int world, int
                          const int* dest_rank, const int* dest_block, long window_bytes, long spin_limit,
                          hipStream_t stream);
 
+/*
+ * Box calibration (bench.py `box_calibration`; no reference counterpart - the reference's benchmark protocol,
+ * nuscenes/scripts/benchmark.py:42-55, reports wall time only).  cobevt_calibrate_mfma: `blocks` workgroups of 4 waves issue
+ * 4 * iters independent v_mfma_f32_32x32x16_bf16 each (no operand traffic): 2 * 32*32*16 * 16 * iters flops per workgroup;
+ * clk[0] / clk[1] (device int64[2]) = shader-clock / 100-MHz wall-clock ticks workgroup 0 spent in the loop.  out: fp32
+ * [blocks * 256].  cobevt_calibrate_copy: streaming copy of `bytes` (multiple of 16) src -> dst.
+ */
+int cobevt_calibrate_mfma(float* out, long long* clk, int blocks, int iters, hipStream_t stream);
+int cobevt_calibrate_copy(const void* src, void* dst, long bytes, hipStream_t stream);
+/* rate of the wall clock behind clk[1] and the device's maximum shader clock (kHz), of the current device */
+int cobevt_calibrate_clock_khz(int* wall_khz, int* sclk_max_khz);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,13 +88,37 @@ def _bench(extra, env=None, timeout=900):
 
 def test_bench_spawns_its_own_ranks(cuda):
     """`python bench.py --gpus 2` with no launcher starts 2 ranks itself; every rank checks its sharded frame against the
-    single-process forward before timing (bench.py raises otherwise).  RCCL with >= 2 GPUs, gloo dry-run on one."""
+    single-process forward before timing (bench.py raises otherwise).  RCCL with >= 2 GPUs, gloo dry-run on one.  Layout of the
+    line at N > 1: headline = throughput mode (the N = 1 quantity), `latency_mode` with frame_latency_ms beside it,
+    the N = 1 reference of the same box and the efficiencies derived from it"""
     two = torch.cuda.device_count() >= 2
     res = _bench(["--gpus", "2"], env=None if two else {"COBEVT_DIST_BACKEND": "gloo"})
     assert res["n_gpus"] == 2 and res["rccl_ranks"]["world_size"] == 2
     assert res["rccl_ranks"]["backend"] == ("nccl" if two else "gloo")
-    assert res["mode"] == "latency" and res["scaling"] == "strong" and "throughput_mode" in res
-    assert res["throughput_mode"]["value"] > 0 and res["value"] > 0
+    if two:
+        assert res["rccl_ranks"]["distinct_gpus"] == 2
+    assert res["mode"] == "throughput" and res["scaling"] == "weak" and res["value"] > 0
+    lm = res["latency_mode"]
+    assert lm["mode"] == "latency" and lm["scaling"] == "strong" and lm["value"] > 0 and lm["frame_latency_ms"] > 0, lm
+    assert res["latency_mode_unpipelined"]["frame_latency_ms"] > 0
+    assert res["single_gpu_reference"]["frames_per_sec"] > 0, res["single_gpu_reference"]
+    sc = res["scaling_summary"]
+    assert sc["throughput_scaling_efficiency_vs_n1"] > 0 and sc["frame_latency_speedup_vs_n1"] > 0
+    assert res["box_calibration"]["mfma_bf16_tflops"] > 0
     # the direct peer-window legs come from the isolated second job (bench.py --direct-probe) and are merged into the one line
     assert "direct_peer_write" in res["all_gather_us"] and "rccl_all_gather_into_tensor" in res["all_gather_us"]
     assert res["latency_mode_direct_gather"].get("value", 0) > 0, res["latency_mode_direct_gather"]
+
+
+@pytest.mark.parametrize("world", [5, 8])
+def test_bench_agent_per_gpu_partitions(cuda, world):
+    """BASELINE configs[3] (5 agents on 5 GPUs, one each) and the 8-GPU node with 5 agents (three surplus ranks that encode nothing
+    and still take part in the exchange and the replicated fusion): bench.py's latency mode starting its own ranks - every rank
+    checks its output against the single-process forward of the whole frame before timing.  RCCL when the box has the GPUs,
+    otherwise gloo ranks sharing GPU 0 (the HIP kernels and the partition logic are the same; only the collective differs)"""
+    real = torch.cuda.device_count() >= world
+    res = _bench(["--gpus", str(world), "--mode", "latency"], env=None if real else {"COBEVT_DIST_BACKEND": "gloo"}, timeout=1200)
+    assert res["n_gpus"] == world and res["rccl_ranks"]["world_size"] == world
+    assert res["mode"] == "latency" and res["scaling"] == "strong" and res["value"] > 0 and res["frame_latency_ms"] > 0
+    assert "agent a on GPU a mod %d" % world in res["config"]["parallelism"]
+    assert res["single_gpu_reference"]["frames_per_sec"] > 0
