@@ -749,10 +749,14 @@ def gv18(full=None):
                 mf.fax.register_forward_hook(lambda mod, i, o: interf.__setitem__("fax", o))
                 mf.fusion_net.register_forward_hook(lambda mod, i, o: interf.__setitem__("fused", o))
                 mf.encoder.register_forward_hook(lambda mod, i, o: interf.__setitem__("enc", o))
+                mf.sttf.register_forward_hook(lambda mod, i, o: interf.__setitem__("sttf", o))
+                for lv, layer in enumerate(mf.fax.layers):          # the level's BEV query in front of its down-sampling layer
+                    layer.register_forward_hook(lambda mod, i, o, lv=lv: interf.__setitem__("fax_level%d" % lv, o))
 
                 def run():
                     r = mf({k: v.clone() for k, v in bf.items()})
-                    o = {"dynamic_seg": r["dynamic_seg"], "fax": interf["fax"], "fused": interf["fused"]}
+                    o = {"dynamic_seg": r["dynamic_seg"], "fax": interf["fax"], "fused": interf["fused"], "sttf": interf["sttf"]}
+                    o.update({k: v for k, v in interf.items() if k.startswith("fax_level")})
                     for i, e in enumerate(interf["enc"]):
                         o["resnet34_f%d" % i] = e
                     return o
