@@ -78,7 +78,10 @@ template <int NT> struct ResLds {
 // RAGGED: Nk is not a multiple of 128 and there is no per-key metadata (BIAS / MASK) to carry the padding: the padded keys are
 // taken out of the softmax by a compare + select per score (a template parameter: as a run-time branch the compiler turns it
 // into 64 always-executed compare / select pairs per tile).
-template <int NT, int NW, bool MEAN, bool BIAS, bool MASK, bool RAGGED>
+// W8 (BIAS only): 8 x 8 windows and no padded keys - a 64-key tile is exactly one agent's window, so the padded key term of the
+// quad (tile c, sub-tile s, accumulator quad g, half h) is the constant 960 c + 256 s + 64 g + 16 h bytes: the four bias reads
+// of a sub-tile are immediate offsets from one per-lane pointer (no key-term lookup, no address arithmetic).
+template <int NT, int NW, bool MEAN, bool BIAS, bool MASK, bool RAGGED, bool W8 = false>
 // Register budget: the plain variants keep 4 waves per SIMD (35 KB of LDS -> 4 workgroups per CU); with a bias table / mask the
 // LDS footprint (>= 56 KB for the shipped windows) allows 2 waves per SIMD at most, so those variants may use 256 VGPRs.
 __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void attn_resident_kernel(AttnParams p, int qsplit) {
@@ -92,14 +95,23 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
     unsigned char* Ks = smem;
     unsigned char* Vts = smem + L::kKBytes;
     int* ktab = (int*)(smem + L::kKBytes + L::kVBytes);    // [NKP] row of key tk, -1 = padding
-    float* kmadd = (float*)(ktab + NKP);                    // [NKP] (INFO) additive key mask: 0, or -inf for masked / padded keys
-    int* kinfo4 = (int*)(kmadd + (INFO ? NKP : 0));         // [NKP] (BIAS) 4 x the key term of the bias index (a byte offset)
+    // (INFO) [NKP][2] A operand of the "augmented" score MFMA: word 0 = bf16 {1, additive key mask (0, or -inf for masked / padded
+    // keys)} for the k-slice of lanes 0-31, word 1 = 0 for lanes 32-63
+    uint32_t* kaug = (uint32_t*)(ktab + NKP);
+    int* kinfo4 = (int*)(kaug + (INFO ? 2 * NKP : 0));      // [NKP] (BIAS) 4 x the key term of the padded bias index (a byte offset)
     const int P = p.qmap.w1 * p.qmap.w2;
     const int NQ = MEAN ? P : p.Nq;                         // table entries: mean mode keeps camera 0 and strides over cameras
     int* qtab = kinfo4 + (BIAS ? NKP : 0);                  // [NQ] row of query token
     int* otab = qtab + NQ;                                  // [NQ] row of its output
-    int* qbias = otab + NQ;                                 // [NQ] (BIAS) query term of the bias index
-    float* bias_col = (float*)(qbias + (BIAS ? NQ : 0));    // [bias_rows] this head's table column, base-2 domain
+    int* qbias = otab + NQ;                                 // [NQ] (BIAS) byte offset of the query's base inside bias4
+    // (BIAS) the head's table column in the base-2 domain, REVERSED and with rows padded from 2 w2 - 1 to Wp = 2 w2 entries, in four
+    // copies shifted by 0..3 entries: the four consecutive keys a lane holds per accumulator quad (same agent and window row,
+    // columns j0..j0+3) then read four consecutive table entries - one aligned ds_read_b128 straight into the accumulator image
+    // - and which copy is aligned depends on the query's column only, i.e. it is a per-lane constant (its base offset is qbias)
+    const int Wp = 2 * p.kmap.w2;
+    const int Rp = (2 * p.bias_L - 1) * (2 * p.kmap.w1 - 1) * Wp;
+    const int CS = Rp + 4;                                  // floats per copy (a multiple of 4: every copy is 16-byte aligned)
+    float* bias4 = (float*)(smem + ((((unsigned char*)(qbias + (BIAS ? NQ : 0)) - smem) + 15) & ~(size_t)15));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, ql = lane & 31;
@@ -139,32 +151,49 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
                         valid = p.mask[(((size_t)b * p.kmap.HH + ph) * p.kmap.WW + pw) * p.kmap.ncam + kc.cam] != 0.f;
                     }
                 }
-                if (BIAS) info = 4 * rel_bias_key_term(p.kmap, kc);     // also for masked keys: the lookup stays in range
+                if (BIAS) info = 4 * ((kc.cam * (2 * p.kmap.w1 - 1) + kc.i) * Wp + kc.j);   // also for masked keys: the lookup stays in range
             }
         }
         ktab[tk] = row;
-        if (INFO) kmadd[tk] = valid ? 0.f : -INFINITY;
+        if (INFO) {
+            kaug[2 * tk] = pack_bf2(1.0f, valid ? 0.f : -INFINITY);
+            kaug[2 * tk + 1] = 0u;
+        }
         if (BIAS) kinfo4[tk] = info;
     }
     for (int t = tid; t < NQ; t += NTHR) {
         const TokCoord qc = tok_coord(p.qmap, t);           // mean mode: t < P -> camera 0
         qtab[t] = (int)tok_row(p.qmap, b, l, qc);
         otab[t] = (int)tok_row(p.omap, b, l, qc);
-        if (BIAS) qbias[t] = rel_bias_query_term(p.kmap, p.bias_L, qc);
+        if (BIAS) {
+            // padded index = query term - key term (linear in the coordinates, attn_common.hpp); reversed: a + key term
+            const int qterm = ((qc.cam + p.bias_L - 1) * (2 * p.kmap.w1 - 1) + qc.i + p.kmap.w1 - 1) * Wp + qc.j + p.kmap.w2 - 1;
+            const int a = Rp - 1 - qterm, sh = a & 3;
+            qbias[t] = 4 * (sh * CS + a - sh);
+        }
     }
     if (BIAS) {
         constexpr int BI = 8;
-        for (int base = 0; base < p.bias_rows; base += NTHR * BI) {
+        const int w2m = 2 * p.kmap.w2 - 1;
+        for (int base = 0; base < Rp; base += NTHR * BI) {
             float tv[BI];
 #pragma unroll
             for (int u = 0; u < BI; ++u) {
                 const int i = base + u * NTHR + tid;
-                tv[u] = p.bias_table[(size_t)(i < p.bias_rows ? i : p.bias_rows - 1) * p.heads + head];
+                const int ic = i < Rp ? i : Rp - 1;
+                const int row = ic / Wp, c = ic - row * Wp;
+                const int src = row * w2m + (c < w2m ? c : w2m - 1);
+                tv[u] = c < w2m ? p.bias_table[(size_t)src * p.heads + head] * kLog2e : 0.f;   // (clamped, unconditional load)
             }
 #pragma unroll
             for (int u = 0; u < BI; ++u) {
                 const int i = base + u * NTHR + tid;
-                if (i < p.bias_rows) bias_col[i] = tv[u] * kLog2e;
+                if (i < Rp) {
+                    const int rx = Rp - 1 - i;
+#pragma unroll
+                    for (int sh = 0; sh < 4; ++sh)
+                        if (rx - sh >= 0) bias4[sh * CS + rx - sh] = tv[u];
+                }
             }
         }
     }
@@ -237,16 +266,24 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
     const float inv_ncam = 1.0f / (float)ncam;
 
     float m_run = 0.f;                             // softmax reference value, carried across this lane's tasks
-    f32x16 mneg;                                   // splat(-m_run): the C operand of the score MFMAs
+    f32x16 mneg;                                   // splat(-m_run): the C operand of the score MFMAs (variants without bias / mask)
 #pragma unroll
     for (int r = 0; r < 16; ++r) mneg[r] = 0.f;
+    // Bias / mask variants: the accumulator image of a score MFMA is the BIAS tile itself (four aligned ds_read_b128 per 32 keys,
+    // no VALU), so "- reference" and "+ key mask" ride on the matrix pipe instead: a third k-group whose A operand is {1, mask(key)}
+    // (kaug) and whose B operand is {-reference(query), 1} - the reference therefore has to be a bf16 value (it is truncated to
+    // one when it is set; any value works as a softmax reference as long as numerator and denominator use the same one).
+    // qaug0 = {0, 1} is the B operand of the throw-away pass that measures a tile's exact maximum.
+    const uint32_t qaug0 = h == 0 ? pack_bf2(0.f, 1.0f) : 0u;
+    uint32_t qaugm = qaug0;
     for (int tile = qs + qsplit * wave; tile < ntiles; tile += qsplit * NW) {
         const int t = tile * 32 + ql;
         const bool q_ok = t < NQ;
         const int tq = q_ok ? t : 0;
         const size_t qrow0 = (size_t)(unsigned)qtab[tq];
-        // LDS address of bias_col[query term]: the gather address of a score is this minus the key's 4 x key term (one v_sub)
-        const unsigned char* bias_qp = (const unsigned char*)bias_col + (BIAS ? 4 * qbias[tq] : 0);
+        // LDS address of this query's base inside its (aligned) copy of the reversed bias column: a quad of keys reads 16 bytes
+        // at this plus the quad's key term (one v_add)
+        const unsigned char* bias_qp = (const unsigned char*)bias4 + (BIAS ? qbias[tq] : 0);
         f32x16 osum;
         if (MEAN) {
 #pragma unroll
@@ -287,37 +324,49 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
                 const unsigned char* kp0 = kptr0 + kp2 * (128 * 64);
                 const unsigned char* kp1 = kptr1 + kp2 * (128 * 64);
                 const unsigned char* vp = vrow + kp2 * 256;
+                const unsigned char* bk = bias_qp + 16 * h + kp2 * 1920;       // W8: this lane's bias base of agent 2 kp2
 #pragma unroll
                 for (int par = 0; par < 2; ++par) {
                     const int key0 = kp2 * 128 + par * 64;      // first key of this tile
-                    // scores of one 32-key sub-tile on top of the accumulator image `c` (+ bias, + additive key mask)
-                    auto scores = [&](int s, const f32x16& c) -> f32x16 {
-                        f32x16 st = c;
+                    // scores of one 32-key sub-tile; with_ref: minus the running reference (the exponent's argument), otherwise
+                    // the plain logits (+ bias, + additive key mask in both cases)
+                    auto scores = [&](int s, bool with_ref) -> f32x16 {
+                        f32x16 st;
                         const int off = (par * 64 + s * 32) * 64;
                         const uint4 a0 = *(const uint4*)(kp0 + off);
                         const uint4 a1 = *(const uint4*)(kp1 + off);
-                        mfma_kgroup<bf16_t>(a0, qs0, st);
-                        mfma_kgroup<bf16_t>(a1, qs1, st);
-                        if (INFO) {        // this lane's 16 keys of the sub-tile: 4 x (4 consecutive keys 8g + 4h ..)
+                        if (INFO) {
+                            const int kt = key0 + s * 32;
+                            if (BIAS) {    // this lane's 16 keys of the sub-tile: 4 x (4 consecutive keys 8g + 4h ..) = 4 aligned 16-byte reads
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                const int kb = key0 + s * 32 + 8 * g + 4 * h;
-                                f32x4 add = *(const f32x4*)(kmadd + kb);
-                                if (BIAS) {
-                                    const uint4 ki = *(const uint4*)(kinfo4 + kb);
-                                    const f32x4 bb = {*(const float*)(bias_qp - ki.x), *(const float*)(bias_qp - ki.y),
-                                                      *(const float*)(bias_qp - ki.z), *(const float*)(bias_qp - ki.w)};
-                                    add += bb;
+                                for (int g = 0; g < 4; ++g) {
+                                    const f32x4 bb = W8 ? *(const f32x4*)(bk + par * 960 + s * 256 + g * 64)
+                                                        : *(const f32x4*)(bias_qp + kinfo4[kt + 8 * g + 4 * h]);
+                                    st[4 * g] = bb.x; st[4 * g + 1] = bb.y; st[4 * g + 2] = bb.z; st[4 * g + 3] = bb.w;
                                 }
-                                const f32x2 lo = f32x2{st[4 * g], st[4 * g + 1]} + f32x2{add.x, add.y};          // v_pk_add_f32
-                                const f32x2 hi = f32x2{st[4 * g + 2], st[4 * g + 3]} + f32x2{add.z, add.w};
-                                st[4 * g] = lo.x; st[4 * g + 1] = lo.y; st[4 * g + 2] = hi.x; st[4 * g + 3] = hi.y;
-                            }
-                        } else if (RAGGED) {                    // padded keys out of the softmax
-                            const int nv = p.Nk - key0 - s * 32 - 4 * h;
+                            } else {
 #pragma unroll
-                            for (int r = 0; r < 16; ++r)
-                                if ((r & 3) + 8 * (r >> 2) >= nv) st[r] = -INFINITY;
+                                for (int r = 0; r < 16; ++r) st[r] = 0.f;
+                            }
+                            const uint4 ka = make_uint4(kaug[2 * (kt + ql) + h], 0u, 0u, 0u);
+                            const uint4 qa = make_uint4(with_ref ? qaugm : qaug0, 0u, 0u, 0u);
+                            mfma_kgroup<bf16_t>(a0, qs0, st);
+                            mfma_kgroup<bf16_t>(a1, qs1, st);
+                            mfma_kgroup<bf16_t>(ka, qa, st);
+                        } else {
+                            if (with_ref) st = mneg;
+                            else {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) st[r] = 0.f;
+                            }
+                            mfma_kgroup<bf16_t>(a0, qs0, st);
+                            mfma_kgroup<bf16_t>(a1, qs1, st);
+                            if (RAGGED) {                       // padded keys out of the softmax
+                                const int nv = p.Nk - key0 - s * 32 - 4 * h;
+#pragma unroll
+                                for (int r = 0; r < 16; ++r)
+                                    if ((r & 3) + 8 * (r >> 2) >= nv) st[r] = -INFINITY;
+                            }
                         }
                         return st;
                     };
@@ -328,19 +377,17 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
                         if (need_max) {
                             // exact maximum of this tile (first tile of a task, or a tile that outgrew the running maximum):
                             // throw-away score MFMAs, then the rescale; the regular pass below then runs against the new maximum
-                            f32x16 zero;
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) zero[r] = 0.f;
                             float mloc = -INFINITY;
 #pragma unroll
                             for (int s = 0; s < 2; ++s) {
-                                const f32x16 st = scores(s, zero);
+                                const f32x16 st = scores(s, false);
                                 float m0 = max3(st[0], st[1], st[2]);
 #pragma unroll
                                 for (int r = 3; r < 15; r += 2) m0 = max3(m0, st[r], st[r + 1]);
                                 mloc = max3(mloc, m0, st[15]);
                             }
-                            const float m_new = fmaxf(m_run, xor32_max(mloc));
+                            float m_new = fmaxf(m_run, xor32_max(mloc));
+                            if (INFO) m_new = __uint_as_float(__float_as_uint(m_new) & 0xffff0000u);     // a bf16 value (see qaugm)
                             const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
                             const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);       // first tile: exp2(-inf) = 0
                             m_run = m_new;
@@ -348,6 +395,7 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
                             ot *= alpha;
 #pragma unroll
                             for (int r = 0; r < 16; ++r) mneg[r] = -m_safe;
+                            if (INFO) qaugm = h == 0 ? pack_bf2(-m_safe, 1.0f) : 0u;
                             have_m = true;
                         }
                         // ---- regular pass: P = exp2(S - m_run) straight from the MFMA result, packed to bf16.  Row sums on the
@@ -359,7 +407,7 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
                         const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
 #pragma unroll
                         for (int s = 0; s < 2; ++s) {
-                            const f32x16 st = scores(s, mneg);
+                            const f32x16 st = scores(s, true);
                             float e[16];
 #pragma unroll
                             for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(st[r]);
@@ -422,16 +470,22 @@ int launch_nt(const AttnParams& p, int qsplit, size_t lds, dim3 grid, hipStream_
     const bool ragged = p.Nk != NT * 64;
 #define COBEVT_RES_LAUNCH(M, B, K, R) \
     hipLaunchKernelGGL((attn_resident_kernel<NT, NW, M, B, K, R>), grid, dim3(NW * 64), lds, stream, p, qsplit)
+#define COBEVT_RES_LAUNCH_W8(K) \
+    hipLaunchKernelGGL((attn_resident_kernel<NT, NW, false, true, K, false, true>), grid, dim3(NW * 64), lds, stream, p, qsplit)
+    const bool w8 = hb && p.kmap.w1 == 8 && p.kmap.w2 == 8 && p.Nk == NT * 64;
     if (mean) {
         if (hb || hm) return -1;                       // the camera mean only occurs in the plain cross attention
         if (ragged) COBEVT_RES_LAUNCH(true, false, false, true);
         else COBEVT_RES_LAUNCH(true, false, false, false);
-    } else if (hb && hm) COBEVT_RES_LAUNCH(false, true, true, false);
+    } else if (w8 && hm) COBEVT_RES_LAUNCH_W8(true);
+    else if (w8) COBEVT_RES_LAUNCH_W8(false);
+    else if (hb && hm) COBEVT_RES_LAUNCH(false, true, true, false);
     else if (hb) COBEVT_RES_LAUNCH(false, true, false, false);
     else if (hm) COBEVT_RES_LAUNCH(false, false, true, false);
     else if (ragged) COBEVT_RES_LAUNCH(false, false, false, true);
     else COBEVT_RES_LAUNCH(false, false, false, false);
 #undef COBEVT_RES_LAUNCH
+#undef COBEVT_RES_LAUNCH_W8
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
@@ -446,9 +500,14 @@ int launch_attn_resident(const AttnParams& p, int qsplit_hint, hipStream_t strea
     if (mean && p.omap.ncam != 1) return -1;
     const int NQ = mean ? P : p.Nq;
     const bool info = p.bias_mode != 0 || p.mask != nullptr;
-    size_t lds = (size_t)nt * 64 * 128 + (size_t)nt * 64 * 4 * (1 + (info ? 1 : 0) + (p.bias_mode ? 1 : 0)) +
+    size_t lds = (size_t)nt * 64 * 128 + (size_t)nt * 64 * 4 * (1 + (info ? 2 : 0) + (p.bias_mode ? 1 : 0)) +
                  (size_t)NQ * 4 * (p.bias_mode ? 3 : 2);
-    if (p.bias_mode) lds += ((size_t)p.bias_rows * 4 + 15) & ~(size_t)15;
+    if (p.bias_mode) {
+        // four shifted copies of the reversed, row-padded table column (see the kernel): key quads must share (agent, window row)
+        if (p.kmap.w2 % 4 != 0 || p.bias_rows != (2 * p.bias_L - 1) * (2 * p.kmap.w1 - 1) * (2 * p.kmap.w2 - 1)) return -1;
+        const size_t rp = (size_t)(2 * p.bias_L - 1) * (2 * p.kmap.w1 - 1) * (2 * p.kmap.w2);
+        lds = ((lds + 15) & ~(size_t)15) + 4 * (rp + 4) * 4;
+    }
     lds = (lds + 15) & ~(size_t)15;
     if (lds > 160 * 1024) return -1;
     if ((long)p.B * p.qmap.ncam * (p.qmap.mode == 2 ? (long)p.L * P : (long)p.qmap.HH * p.qmap.WW) >= 0x7fffffffL) return -1;

@@ -24,35 +24,9 @@
 // and four runs of four consecutive output columns: every epilogue is 8-byte LDS traffic instead of sixteen 2-byte writes.
 //
 // 512 threads = 8 waves arranged 2 (row halves) x 4 (32-column tiles of a 128-column panel).  C <= 128, hidden <= 256.
-#include "common.hpp"
+#include "row_chain.hpp"
 
 namespace cobevt {
-
-struct RowChainParams {
-    const bf16_t* a;        // [M][C] attention output
-    const bf16_t* skip;     // [skip_rows][C] or null; row m adds skip[m % skip_rows] (skip_rows = M: plain; < M: broadcast)
-    bf16_t* out;            // [M][C]
-    const uint4* wp;        // fragment-ordered [4 tiles][8]      out-projection
-    const float* bp;        // [C] or null
-    const uint4* w1;        // fragment-ordered [8 tiles][8]      fc1 with the LayerNorm affine folded in
-    const float* b1;        // [Hd]
-    const uint4* w2;        // fragment-ordered [4 tiles][Hdp/16] fc2
-    const float* b2;        // [C]
-    const float* post_g;    // post-LayerNorm affine or null
-    const float* post_b;
-    const uint4* wn;        // fragment-ordered [4*ceil(Nn/128) tiles][8]  next projection or null
-    const float* bn;        // [Nn] or null
-    bf16_t* out_next;       // [M][Nn]
-    int M, C, Hd, Hdp;
-    int Nn, next_ln, next_act, skip_rows;
-    float eps1, eps_post, eps_next;
-    // MLP = false ("projection chain"): a <- ReLU?(a * pre_scale[c] + pre_shift[c]) while it is staged (pre-activation
-    // BatchNorm -> ReLU -> 1x1 conv, fax_modules.py:281-292), y = a . Wp^T + bp + skip, `out` is not stored unless non-null, and the
-    // next projection (LayerNorm + Linear: to_k / to_v of both cross attentions, fax_modules.py:201-205) reads y from LDS
-    const float* pre_scale;
-    const float* pre_shift;
-    int pre_relu;
-};
 
 constexpr int kRcRow = 256 + 16;            // 128 bf16 + pad
 constexpr int kRcHRow = 512 + 16;           // 256 bf16 + pad ; also the fp32 staging row of 128 floats
@@ -394,7 +368,11 @@ extern "C" int cobevt_attn_mlp_chain(const void* a, const void* skip, void* out,
     if ((post_gamma == nullptr) != (post_beta == nullptr)) return COBEVT_ERR_ARG;
     if ((wnext == nullptr) != (out_next == nullptr)) return COBEVT_ERR_ARG;
     if (wnext && (p.Nn < 8 || p.Nn % 8 || p.Nn > kRcBnMax || p.next_act < 0 || p.next_act > 2)) return COBEVT_ERR_SHAPE;
-    const int rows = dims[8] == 64 ? 64 : 32;                  // dims[8]: rows per workgroup (0 = default 32)
+    if (dims[8] == 0) {                                        // automatic: 64-channel chains on big maps take the persistent form
+        const int rc = launch_row_chain64(p, stream);
+        if (rc >= 0) return rc;
+    }
+    const int rows = dims[8] == 64 ? 64 : 32;                  // dims[8]: rows per workgroup (0 = default 32; 32 / 64 pin the generic kernel)
     const bool two = p.Hd > 128, full = p.C == 128;
     if (rows == 64) {
         if (two) { if (full) launch_chain<2, 64, true>(p, stream); else launch_chain<2, 64, false>(p, stream); }

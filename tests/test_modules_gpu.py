@@ -277,6 +277,12 @@ def test_corpbevt_full_config_vs_oracle(cuda, agents):
         pairs.append(("fused", g["fused"].permute(0, 3, 1, 2), ref_all["fused"], "fused"))
         for name, a, r, case in pairs:
             tol, rms = (1e-3, 1e-4) if dtype == torch.float32 else bf16_gate(full + case)
+            # Intermediate taps (not outputs): the rms norm at the reference-derived gate; the max norm - there to catch a
+            # LOCALISED fault such as a wrong border pixel, which shows as >= 1e-1 - at twice it: over the 1e7 elements of a level-0
+            # map the maximum of pure rounding noise moves by +-30 % between kernel variants that differ in nothing but summation
+            # order (0.96e-2 .. 1.15e-2 at an unchanged rms of 5.47e-3: profiles/r04_level0_error_probe.txt)
+            if dtype == torch.bfloat16:
+                tol = 2.0 * tol
             e, q = rel_err(a, r), rms_rel_err(a, r)
             print("   %-16s %s max-rel %.2e rms-rel %.2e (gates %.2e / %.2e)" % (name, str(dtype).split(".")[-1], e, q, tol, rms))
             assert e <= tol and q <= rms, "%s (%s): max-rel %.3e rms-rel %.3e" % (name, dtype, e, q)

@@ -67,6 +67,25 @@ def cross(name, B, n, H, W, W1, W2, h, w, w1, w2, kmode, mean, heads=4, qsplit=0
     report(name, B * qmap[6] * qmap[7] * heads * max(qsplit, 1))
 
 
+def swap(name, L, w, H, mode=0, heads=2):
+    """swap-fusion self attention with the 3-D bias + key mask (LiDAR FuseBEVT: 8 agents, 8 x 8 windows, 2 heads)"""
+    d = heads * 32
+    qkv = torch.randn(1, L, H, H, 3 * d, device=dev).to(torch.bfloat16)
+    table = torch.randn((2 * L - 1) * (2 * w - 1) ** 2, heads, device=dev)
+    mask = torch.ones(1, H, H, 1, L, device=dev)
+    mask[0, :, :, :, L - 2:] = 0
+    out = torch.empty(1, L, H, H, d, device=dev, dtype=torch.bfloat16)
+    m = ops.tokmap(mode, L, H, H, w, w)
+    for _ in range(3):
+        ops.window_attention(qkv, qkv, qkv, out, m, m, m, 1, heads, 32 ** -0.5, 3 * d, 3 * d, 3 * d, d, qoff=0, koff=d, voff=2 * d,
+                             bias_table=table, bias_L=L, mask=mask, variant=0)
+    report(name, (H // w) ** 2 * heads)
+
+
+if "--lidar" in sys.argv:
+    swap("LiDAR window 8 agents 256x256", 8, 8, 256, 0)
+    swap("LiDAR grid   8 agents 256x256", 8, 8, 256, 1)
+    sys.exit(0)
 cross("L0 #1 mean 5 agents", 5, 4, 128, 128, 16, 16, 64, 64, 8, 8, 0, True, qsplit=1)
 cross("L0 #2 grid 5 agents", 5, 4, 128, 128, 16, 16, 64, 64, 8, 8, 1, False, qsplit=1)
 cross("L1 #1 5 agents qs=2", 5, 4, 64, 64, 16, 16, 32, 32, 8, 8, 0, False, qsplit=2)
