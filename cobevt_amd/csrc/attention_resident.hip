@@ -133,34 +133,90 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
     }
 
     RES_MARK(0);
-    // ---- tables (one token -> row computation per thread instead of one per staging item / per task)
-    for (int tk = tid; tk < NKP; tk += NTHR) {
-        int row = -1, info = 0;
-        bool valid = false;
-        if (tk < p.Nk) {
-            const TokCoord kc = tok_coord(p.kmap, tk);
-            row = (int)tok_row(p.kmap, b, l, kc);
-            valid = true;
-            if (INFO) {
-                if (MASK) {
-                    if (p.kmap.mode == 2) {
-                        valid = p.mask[((((size_t)b * p.L + l) * p.kmap.w1 + kc.i) * p.kmap.w2 + kc.j) * p.kmap.ncam + kc.cam] != 0.f;
-                    } else {
-                        int ph, pw;
-                        tok_pixel(p.kmap, l, kc, ph, pw);
-                        valid = p.mask[(((size_t)b * p.kmap.HH + ph) * p.kmap.WW + pw) * p.kmap.ncam + kc.cam] != 0.f;
-                    }
-                }
-                if (BIAS) info = 4 * ((kc.cam * (2 * p.kmap.w1 - 1) + kc.i) * Wp + kc.j);   // also for masked keys: the lookup stays in range
+    // ---- prologue, ONE global round trip: with one workgroup per CU (the 512-key windows) nothing else runs on the CU while a
+    // workgroup builds its tables and stages K / V - 19k of a LiDAR workgroup's 43k cycles in the s_memtime trace when the key
+    // mask, the bias column and the K / V rows were three dependent batches of loads (tables -> barrier -> staging).  Every
+    // staging item therefore derives its key's row itself (shifts for power-of-two windows) and all loads - the thread's mask
+    // word first, it is needed first - are in flight together; the table arithmetic runs under them.
+    const float sl2 = p.scale * kLog2e;
+    const int kws = p.kmap.w1 * p.kmap.w2;
+    const bool kpow2 = ((kws & (kws - 1)) | (p.kmap.w2 & (p.kmap.w2 - 1))) == 0;
+    const int ksh_ws = 31 - __builtin_clz(kws), ksh_w2 = 31 - __builtin_clz(p.kmap.w2);
+    auto key_coord = [&](int tk) {
+        if (!kpow2) return tok_coord(p.kmap, tk);
+        TokCoord c;
+        c.cam = tk >> ksh_ws;
+        const int rem = tk & (kws - 1);
+        c.i = rem >> ksh_w2;
+        c.j = rem & (p.kmap.w2 - 1);
+        return c;
+    };
+    auto key_row = [&](int tk) { return tk < p.Nk ? (int)tok_row(p.kmap, b, l, key_coord(tk)) : -1; };
+
+    // (a) this thread's keys of the tables: coordinates, row, mask word
+    constexpr int NKT = (NKP + NTHR - 1) / NTHR;
+    TokCoord tkc[NKT];
+    int trow[NKT];
+    float tmask[NKT];
+#pragma unroll
+    for (int u = 0; u < NKT; ++u) {
+        const int tk = tid + u * NTHR;
+        const bool in = tk < p.Nk;
+        tkc[u] = key_coord(in ? tk : 0);
+        trow[u] = in ? (int)tok_row(p.kmap, b, l, tkc[u]) : -1;
+        tmask[u] = 1.f;
+        if (MASK) {                                   // unconditional load (address of token 0 for the padded keys)
+            size_t mi;
+            if (p.kmap.mode == 2) {
+                mi = ((((size_t)b * p.L + l) * p.kmap.w1 + tkc[u].i) * p.kmap.w2 + tkc[u].j) * p.kmap.ncam + tkc[u].cam;
+            } else {
+                int ph, pw;
+                tok_pixel(p.kmap, l, tkc[u], ph, pw);
+                mi = (((size_t)b * p.kmap.HH + ph) * p.kmap.WW + pw) * p.kmap.ncam + tkc[u].cam;
             }
+            tmask[u] = p.mask[mi];
         }
-        ktab[tk] = row;
-        if (INFO) {
-            kaug[2 * tk] = pack_bf2(1.0f, valid ? 0.f : -INFINITY);
-            kaug[2 * tk + 1] = 0u;
-        }
-        if (BIAS) kinfo4[tk] = info;
     }
+    // (b) K / V staging loads (rows, 16-byte chunks; key pairs x dh quads), rows derived per item
+    const bf16_t* kbase = (const bf16_t*)p.k + p.koff + head * 32;
+    const bf16_t* vbase = (const bf16_t*)p.v + p.voff + head * 32;
+    uint4 kreg[NITEM];
+    uint2 v0[NITEM], v1[NITEM];
+    int krow[NITEM], vr0[NITEM], vr1[NITEM];
+#pragma unroll
+    for (int it = 0; it < NITEM; ++it) {
+        const int item = tid + it * NTHR;
+        const int kk = item >> 2, cj = item & 3;
+        krow[it] = key_row(kk);
+        // unconditional loads from a clamped row, zeroed afterwards: a load under a branch makes hipcc wait for it inside the
+        // branch (vmcnt(0) per load = one serialised HBM round trip per staging item)
+        kreg[it] = *(const uint4*)(kbase + (size_t)(krow[it] < 0 ? 0 : krow[it]) * p.ldk + cj * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NITEM; ++it) {
+        const int item = tid + it * NTHR;
+        const int kp = item >> 3, dq = item & 7;
+        vr0[it] = key_row(2 * kp);
+        vr1[it] = key_row(2 * kp + 1);
+        v0[it] = *(const uint2*)(vbase + (size_t)(vr0[it] < 0 ? 0 : vr0[it]) * p.ldv + dq * 4);
+        v1[it] = *(const uint2*)(vbase + (size_t)(vr1[it] < 0 ? 0 : vr1[it]) * p.ldv + dq * 4);
+    }
+    // (c) the head's bias column (first batch of the padded index space; one batch covers the shipped windows)
+    constexpr int BI = 8;
+    const int w2m = 2 * p.kmap.w2 - 1;
+    float tv[BI];
+    if (BIAS) {
+#pragma unroll
+        for (int u = 0; u < BI; ++u) {
+            const int i = u * NTHR + tid;
+            const int ic = i < Rp ? i : Rp - 1;
+            const int row = ic / Wp, c = ic - row * Wp;
+            const int src = row * w2m + (c < w2m ? c : w2m - 1);
+            tv[u] = p.bias_table[(size_t)src * p.heads + head];          // (clamped, unconditional load)
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // (d) table arithmetic under the loads: query rows / output rows / bias bases, key terms
     for (int t = tid; t < NQ; t += NTHR) {
         const TokCoord qc = tok_coord(p.qmap, t);           // mean mode: t < P -> camera 0
         qtab[t] = (int)tok_row(p.qmap, b, l, qc);
@@ -172,75 +228,65 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
             qbias[t] = 4 * (sh * CS + a - sh);
         }
     }
-    if (BIAS) {
-        constexpr int BI = 8;
-        const int w2m = 2 * p.kmap.w2 - 1;
-        for (int base = 0; base < Rp; base += NTHR * BI) {
-            float tv[BI];
 #pragma unroll
-            for (int u = 0; u < BI; ++u) {
-                const int i = base + u * NTHR + tid;
-                const int ic = i < Rp ? i : Rp - 1;
-                const int row = ic / Wp, c = ic - row * Wp;
-                const int src = row * w2m + (c < w2m ? c : w2m - 1);
-                tv[u] = c < w2m ? p.bias_table[(size_t)src * p.heads + head] * kLog2e : 0.f;   // (clamped, unconditional load)
+    for (int u = 0; u < NKT; ++u) {
+        const int tk = tid + u * NTHR;
+        if (tk < NKP) {
+            ktab[tk] = trow[u];
+            if (BIAS) kinfo4[tk] = trow[u] >= 0 ? 4 * ((tkc[u].cam * (2 * p.kmap.w1 - 1) + tkc[u].i) * Wp + tkc[u].j) : 0;
+            if (INFO) {
+                const bool valid = trow[u] >= 0 && tmask[u] != 0.f;
+                kaug[2 * tk] = pack_bf2(1.0f, valid ? 0.f : -INFINITY);
+                kaug[2 * tk + 1] = 0u;
+            }
+        }
+    }
+    RES_MARK(1);
+    // (e) the loads land: bias copies, then K (rows, 16-byte chunks XOR-swizzled by (key >> 2) & 3) and V^T (dh rows, 16-byte
+    // chunks XOR-swizzled by dh & 15)
+    if (BIAS) {
+        for (int base = 0; base < Rp; base += NTHR * BI) {
+            if (base > 0) {                            // tables wider than one batch (none of the shipped windows)
+#pragma unroll
+                for (int u = 0; u < BI; ++u) {
+                    const int i = base + u * NTHR + tid;
+                    const int ic = i < Rp ? i : Rp - 1;
+                    const int row = ic / Wp, c = ic - row * Wp;
+                    const int src = row * w2m + (c < w2m ? c : w2m - 1);
+                    tv[u] = p.bias_table[(size_t)src * p.heads + head];
+                }
             }
 #pragma unroll
             for (int u = 0; u < BI; ++u) {
                 const int i = base + u * NTHR + tid;
                 if (i < Rp) {
+                    const int row = i / Wp, c = i - row * Wp;
+                    const float val = c < w2m ? tv[u] * kLog2e : 0.f;
                     const int rx = Rp - 1 - i;
 #pragma unroll
                     for (int sh = 0; sh < 4; ++sh)
-                        if (rx - sh >= 0) bias4[sh * CS + rx - sh] = tv[u];
+                        if (rx - sh >= 0) bias4[sh * CS + rx - sh] = val;
                 }
             }
         }
     }
-    __syncthreads();
-    RES_MARK(1);
-    const float sl2 = p.scale * kLog2e;
-
-    // ---- stage K (rows, 16-byte chunks XOR-swizzled by (key >> 2) & 3) and V^T (dh rows, 16-byte chunks XOR-swizzled by dh & 15)
     {
-        const bf16_t* kbase = (const bf16_t*)p.k + p.koff + head * 32;
-        const bf16_t* vbase = (const bf16_t*)p.v + p.voff + head * 32;
-        uint4 kreg[NITEM];
-        uint2 v0[NITEM], v1[NITEM];
 #pragma unroll
         for (int it = 0; it < NITEM; ++it) {
             const int item = tid + it * NTHR;
             const int kk = item >> 2, cj = item & 3;
-            // unconditional loads from a clamped row, zeroed afterwards: a load under a branch makes hipcc wait for it inside the
-            // branch (vmcnt(0) per load = one serialised HBM round trip per staging item)
-            const int row = ktab[kk];
-            const uint4 kv = *(const uint4*)(kbase + (size_t)(row < 0 ? 0 : row) * p.ldk + cj * 8);
             // K pre-scaled by scale * log2(e) (one extra bf16 rounding, once per workgroup): the score MFMA then delivers base-2
             // logits and, with C = -reference maximum, the exponent's argument itself - no per-score VALU before v_exp_f32
-            kreg[it] = row >= 0 ? scale_bf16x8(kv, sl2) : make_uint4(0, 0, 0, 0);
+            const uint4 kv = krow[it] >= 0 ? scale_bf16x8(kreg[it], sl2) : make_uint4(0, 0, 0, 0);
+            *(uint4*)(Ks + kk * 64 + ((cj ^ ((kk >> 2) & 3)) << 4)) = kv;
         }
 #pragma unroll
         for (int it = 0; it < NITEM; ++it) {
             const int item = tid + it * NTHR;
             const int kp = item >> 3, dq = item & 7;
-            const int r0 = ktab[2 * kp], r1 = ktab[2 * kp + 1];
-            const uint2 a0 = *(const uint2*)(vbase + (size_t)(r0 < 0 ? 0 : r0) * p.ldv + dq * 4);
-            const uint2 a1 = *(const uint2*)(vbase + (size_t)(r1 < 0 ? 0 : r1) * p.ldv + dq * 4);
-            v0[it] = r0 >= 0 ? a0 : make_uint2(0, 0);
-            v1[it] = r1 >= 0 ? a1 : make_uint2(0, 0);
-        }
-#pragma unroll
-        for (int it = 0; it < NITEM; ++it) {
-            const int item = tid + it * NTHR;
-            const int kk = item >> 2, cj = item & 3;
-            *(uint4*)(Ks + kk * 64 + ((cj ^ ((kk >> 2) & 3)) << 4)) = kreg[it];
-        }
-#pragma unroll
-        for (int it = 0; it < NITEM; ++it) {
-            const int item = tid + it * NTHR;
-            const int kp = item >> 3, dq = item & 7;
+            const uint2 w0 = vr0[it] >= 0 ? v0[it] : make_uint2(0, 0), w1 = vr1[it] >= 0 ? v1[it] : make_uint2(0, 0);
             const int pos = ((2 * kp) & ~15) | perm16((2 * kp) & 15);     // even key of the pair; its partner sits at pos + 1
-            const uint32_t a[2] = {v0[it].x, v0[it].y}, c[2] = {v1[it].x, v1[it].y};
+            const uint32_t a[2] = {w0.x, w0.y}, c[2] = {w1.x, w1.y};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int dh = dq * 4 + e;
