@@ -139,19 +139,21 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
     // staging item therefore derives its key's row itself (shifts for power-of-two windows) and all loads - the thread's mask
     // word first, it is needed first - are in flight together; the table arithmetic runs under them.
     const float sl2 = p.scale * kLog2e;
-    const int kws = p.kmap.w1 * p.kmap.w2;
-    const bool kpow2 = ((kws & (kws - 1)) | (p.kmap.w2 & (p.kmap.w2 - 1))) == 0;
-    const int ksh_ws = 31 - __builtin_clz(kws), ksh_w2 = 31 - __builtin_clz(p.kmap.w2);
-    auto key_coord = [&](int tk) {
-        if (!kpow2) return tok_coord(p.kmap, tk);
+    // token -> (camera, i, j): shifts for power-of-two windows (every OPV2V shape; a runtime integer division is ~45 VALU
+    // instructions, and the prologue evaluates a dozen of them per thread)
+    auto fast_coord = [&](const TokMap& m, int t) {
+        const int ws = m.w1 * m.w2;
+        if (((ws & (ws - 1)) | (m.w2 & (m.w2 - 1))) != 0) return tok_coord(m, t);      // (uniform)
         TokCoord c;
-        c.cam = tk >> ksh_ws;
-        const int rem = tk & (kws - 1);
-        c.i = rem >> ksh_w2;
-        c.j = rem & (p.kmap.w2 - 1);
+        c.cam = t >> (31 - __builtin_clz(ws));
+        const int rem = t & (ws - 1);
+        c.i = rem >> (31 - __builtin_clz(m.w2));
+        c.j = rem & (m.w2 - 1);
         return c;
     };
-    auto key_row = [&](int tk) { return tk < p.Nk ? (int)tok_row(p.kmap, b, l, key_coord(tk)) : -1; };
+    auto key_coord = [&](int tk) { return fast_coord(p.kmap, tk); };
+    const RowAffine kaff = row_affine(p.kmap, b, l), qaff = row_affine(p.qmap, b, l), oaff = row_affine(p.omap, b, l);
+    auto key_row = [&](int tk) { return tk < p.Nk ? row_of(kaff, key_coord(tk)) : -1; };
 
     // (a) this thread's keys of the tables: coordinates, row, mask word
     constexpr int NKT = (NKP + NTHR - 1) / NTHR;
@@ -163,15 +165,14 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
         const int tk = tid + u * NTHR;
         const bool in = tk < p.Nk;
         tkc[u] = key_coord(in ? tk : 0);
-        trow[u] = in ? (int)tok_row(p.kmap, b, l, tkc[u]) : -1;
+        trow[u] = in ? row_of(kaff, tkc[u]) : -1;
         tmask[u] = 1.f;
         if (MASK) {                                   // unconditional load (address of token 0 for the padded keys)
             size_t mi;
             if (p.kmap.mode == 2) {
                 mi = ((((size_t)b * p.L + l) * p.kmap.w1 + tkc[u].i) * p.kmap.w2 + tkc[u].j) * p.kmap.ncam + tkc[u].cam;
             } else {
-                int ph, pw;
-                tok_pixel(p.kmap, l, tkc[u], ph, pw);
+                const int ph = kaff.ph0 + tkc[u].i * kaff.pi, pw = kaff.pw0 + tkc[u].j * kaff.pj;
                 mi = (((size_t)b * p.kmap.HH + ph) * p.kmap.WW + pw) * p.kmap.ncam + tkc[u].cam;
             }
             tmask[u] = p.mask[mi];
@@ -201,26 +202,53 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
         v0[it] = *(const uint2*)(vbase + (size_t)(vr0[it] < 0 ? 0 : vr0[it]) * p.ldv + dq * 4);
         v1[it] = *(const uint2*)(vbase + (size_t)(vr1[it] < 0 ? 0 : vr1[it]) * p.ldv + dq * 4);
     }
-    // (c) the head's bias column (first batch of the padded index space; one batch covers the shipped windows)
-    constexpr int BI = 8;
+    // (c) the head's bias column.  A thread fills aligned 16-byte groups of the four shifted copies: group m of copy sh holds
+    // rev[4 m + sh .. + 3], so the seven values rev[4 m .. 4 m + 6] make the group in all four copies (8 ds_write_b128 per thread
+    // instead of 32 scattered ds_write_b32).  rev[x] = padded table entry Rp - 1 - x (0 in the padding column and past the end).
+    constexpr int BG = 2;
+    const int NG = Rp >> 2;
     const int w2m = 2 * p.kmap.w2 - 1;
-    float tv[BI];
-    if (BIAS) {
+    const bool wp_pow2 = (Wp & (Wp - 1)) == 0;
+    const int wp_sh = 31 - __builtin_clz(Wp);
+    float tv[BG][7];
+    unsigned tvok[BG];
+    auto bias_fetch = [&](int base) {
 #pragma unroll
-        for (int u = 0; u < BI; ++u) {
-            const int i = u * NTHR + tid;
-            const int ic = i < Rp ? i : Rp - 1;
-            const int row = ic / Wp, c = ic - row * Wp;
-            const int src = row * w2m + (c < w2m ? c : w2m - 1);
-            tv[u] = p.bias_table[(size_t)src * p.heads + head];          // (clamped, unconditional load)
+        for (int u = 0; u < BG; ++u) {
+            const int m = base + u * NTHR + tid;
+            tvok[u] = 0u;
+#pragma unroll
+            for (int e = 0; e < 7; ++e) {
+                const int i = Rp - 1 - (4 * m + e);
+                const int ic = i < 0 ? 0 : (i >= Rp ? Rp - 1 : i);
+                const int row = wp_pow2 ? (ic >> wp_sh) : ic / Wp, c = ic - row * Wp;
+                const int src = row * w2m + (c < w2m ? c : w2m - 1);
+                tv[u][e] = p.bias_table[(size_t)src * p.heads + head];          // (clamped, unconditional load)
+                if (i >= 0 && i < Rp && c < w2m) tvok[u] |= 1u << e;
+            }
         }
-    }
+    };
+    auto bias_store = [&](int base) {
+#pragma unroll
+        for (int u = 0; u < BG; ++u) {
+            const int m = base + u * NTHR + tid;
+            if (m < NG) {
+                float val[7];
+#pragma unroll
+                for (int e = 0; e < 7; ++e) val[e] = ((tvok[u] >> e) & 1u) ? tv[u][e] * kLog2e : 0.f;
+#pragma unroll
+                for (int sh = 0; sh < 4; ++sh)
+                    *(f32x4*)(bias4 + sh * CS + 4 * m) = f32x4{val[sh], val[sh + 1], val[sh + 2], val[sh + 3]};
+            }
+        }
+    };
+    if (BIAS) bias_fetch(0);
     __builtin_amdgcn_sched_barrier(0);
     // (d) table arithmetic under the loads: query rows / output rows / bias bases, key terms
     for (int t = tid; t < NQ; t += NTHR) {
-        const TokCoord qc = tok_coord(p.qmap, t);           // mean mode: t < P -> camera 0
-        qtab[t] = (int)tok_row(p.qmap, b, l, qc);
-        otab[t] = (int)tok_row(p.omap, b, l, qc);
+        const TokCoord qc = fast_coord(p.qmap, t);          // mean mode: t < P -> camera 0
+        qtab[t] = row_of(qaff, qc);
+        otab[t] = row_of(oaff, qc);
         if (BIAS) {
             // padded index = query term - key term (linear in the coordinates, attn_common.hpp); reversed: a + key term
             const int qterm = ((qc.cam + p.bias_L - 1) * (2 * p.kmap.w1 - 1) + qc.i + p.kmap.w1 - 1) * Wp + qc.j + p.kmap.w2 - 1;
@@ -245,29 +273,9 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
     // (e) the loads land: bias copies, then K (rows, 16-byte chunks XOR-swizzled by (key >> 2) & 3) and V^T (dh rows, 16-byte
     // chunks XOR-swizzled by dh & 15)
     if (BIAS) {
-        for (int base = 0; base < Rp; base += NTHR * BI) {
-            if (base > 0) {                            // tables wider than one batch (none of the shipped windows)
-#pragma unroll
-                for (int u = 0; u < BI; ++u) {
-                    const int i = base + u * NTHR + tid;
-                    const int ic = i < Rp ? i : Rp - 1;
-                    const int row = ic / Wp, c = ic - row * Wp;
-                    const int src = row * w2m + (c < w2m ? c : w2m - 1);
-                    tv[u] = p.bias_table[(size_t)src * p.heads + head];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < BI; ++u) {
-                const int i = base + u * NTHR + tid;
-                if (i < Rp) {
-                    const int row = i / Wp, c = i - row * Wp;
-                    const float val = c < w2m ? tv[u] * kLog2e : 0.f;
-                    const int rx = Rp - 1 - i;
-#pragma unroll
-                    for (int sh = 0; sh < 4; ++sh)
-                        if (rx - sh >= 0) bias4[sh * CS + rx - sh] = val;
-                }
-            }
+        for (int base = 0; base < NG; base += NTHR * BG) {
+            if (base > 0) bias_fetch(base);            // tables wider than one batch
+            bias_store(base);
         }
     }
     {

@@ -43,6 +43,27 @@ __device__ __forceinline__ size_t tok_row(const TokMap& m, int b, int l, const T
     return ((size_t)(b * m.ncam + c.cam) * m.HH + ph) * m.WW + pw;
 }
 
+// tok_row as an affine function of (camera, i, j) for one (batch b, window l): row = cam * cs + i * si + j * sj + base, all int32
+// (the launchers reject maps with 2^31 or more rows).  The window's origin - one integer division of l by m.Y - is paid once per
+// workgroup instead of once per token; the resident kernel's prologue evaluates a dozen token rows per thread.
+struct RowAffine { int cs, si, sj, base; int ph0, pw0, pi, pj; };   // (ph, pw) = (ph0 + i * pi, pw0 + j * pj): the token's pixel (modes 0 / 1)
+__device__ __forceinline__ RowAffine row_affine(const TokMap& m, int b, int l) {
+    RowAffine a;
+    if (m.mode == 2) {
+        const int ws = m.w1 * m.w2;
+        a.cs = m.X * m.Y * ws; a.si = m.w2; a.sj = 1;
+        a.base = (b * m.ncam * (m.X * m.Y) + l) * ws;
+        a.ph0 = a.pw0 = 0; a.pi = a.pj = 1;
+        return a;
+    }
+    const int x = l / m.Y, y = l - x * m.Y;
+    a.cs = m.HH * m.WW;
+    if (m.mode == 1) { a.si = m.X * m.WW; a.sj = m.Y; a.base = (b * m.ncam * m.HH + x) * m.WW + y; a.ph0 = x; a.pw0 = y; a.pi = m.X; a.pj = m.Y; }
+    else { a.si = m.WW; a.sj = 1; a.base = (b * m.ncam * m.HH + x * m.w1) * m.WW + y * m.w2; a.ph0 = x * m.w1; a.pw0 = y * m.w2; a.pi = a.pj = 1; }
+    return a;
+}
+__device__ __forceinline__ int row_of(const RowAffine& a, const TokCoord& c) { return c.cam * a.cs + c.i * a.si + c.j * a.sj + a.base; }
+
 // Relative-position bias index split into a query term and a key term (the table index is linear in the coordinates):
 //   index = ((dl + L-1)(2 w1 - 1) + (di + w1-1))(2 w2 - 1) + (dj + w2-1),  d = query - key coordinate
 // swap_fusion_modules.py:55-85 (3-D, agent extent L) and fax_modules.py:121-130 (2-D: L = 1, cam = 0).  Integer arithmetic that
