@@ -13,6 +13,7 @@
 // sets), D = W.X^T so a lane owns one row and runs of four consecutive columns (bias / residual / activation in registers),
 // results leave through a bf16 LDS tile as 16-byte coalesced stores.
 #include "common.hpp"
+#include "bev_query.hpp"
 
 namespace cobevt {
 
@@ -298,6 +299,15 @@ extern "C" int cobevt_bev_embed_linear_rows_small_k(const float* E_inv, const fl
     if (!E_inv || !world || !w_bev || !b_bev || !w_cam || !x || !wfrag || !out || !dims) return COBEVT_ERR_ARG;
     if (dims[0] != 0) return COBEVT_ERR_UNSUPPORTED;
     const long B = dims[1], n = dims[2], hw = dims[3];
+    if (dims[4] == 128 && dims[5] == 128 && dims[6] && hw % 32 == 0 && B >= 1 && n >= 1 && B * n * hw <= 0x7fffffffL) {
+        // the FAX level-0 shape: the wave-level kernel (bev_query.hip) - rows never leave the registers, weights in LDS
+        BevQueryParams q;
+        q.E_inv = E_inv; q.world = world; q.w_bev = w_bev; q.b_bev = b_bev; q.w_cam = w_cam; q.x = (const bf16_t*)x;
+        q.wfrag = (const uint4*)wfrag; q.bias = bias; q.out = (bf16_t*)out;
+        q.B = (int)B; q.n = (int)n; q.hw = (int)hw; q.x_bcast = (int)dims[7]; q.ln_eps = ln_eps;
+        const int rc = launch_bev_query(q, stream);
+        if (rc >= 0) return rc;
+    }
     Gr3Params p;
     p.in = (const bf16_t*)x; p.wfrag = (const uint4*)wfrag; p.bias = bias; p.residual = nullptr;
     p.pre_scale = p.pre_shift = nullptr; p.out = (bf16_t*)out;

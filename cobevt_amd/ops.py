@@ -34,8 +34,9 @@ USE_ROW_CHAIN = True  # fuse out-proj + skip + pre-norm MLP (+ post-norm) after 
 BASICBLOCK_TILE_ROWS = 0   # 0 = kernel default; 8 | 16 pins the output tile height (tools/bb_probe.py)
 USE_BASICBLOCK = True  # stride-1 BasicBlocks on 64 / 128 channels as one launch (intermediate map stays in LDS)
 USE_EMBED_GEMM = False  # compute the BEV query embedding inside the to_q GEMM instead of materialising the query:
-USE_EMBED_GEMM3 = False   # the BEV query produced inside the 32-row GEMM that projects it (gemm_rows3.hip): measured 3 % slower
-                          # end to end than the embedding kernel + GEMM (the staging threads become VALU-bound), kept off
+USE_EMBED_GEMM3 = True    # the BEV query produced inside the launch that projects it.  128 -> 128 with LayerNorm (every OPV2V level): the
+                          # wave-level kernel of bev_query.hip (rows in registers, weights in LDS); other widths keep the embedding
+                          # kernel + GEMM - inside the 32-row GEMM of gemm_rows3.hip the staging threads become VALU-bound (3 % slower)
 # measured SLOWER on MI355X (119 vs 92 us on the level-0 shape, 361 vs 364 frames/s): the producer's 64 LDS
 # coefficient reads + ~400 VALU per thread cost more than the 170 MB of HBM traffic they save; kept for parity tests
 USE_CHAIN_NEXT = True  # ... and let the row-local GEMM that consumes its output next ride in the same launch
@@ -736,7 +737,9 @@ def bev_embed_linear(e_inv, world, w_bev, b_bev, w_cam, x, n, plan):
     launches."""
     b, hw, d = x.shape
     bcast = batch_broadcast(x)
-    fused3 = (USE_EMBED_GEMM3 and USE_GEMM_ROWS3 and plan.code == BF16 and plan.has_ln and plan.K == d and d <= 128 and d % 8 == 0
+    wave_level = d == 128 and plan.cout == 128 and b * n <= 32           # bev_query.hip's shape (else the call lands in gemm_rows3.hip)
+    fused3 = ((USE_EMBED_GEMM3 == 2 or (USE_EMBED_GEMM3 and wave_level)) and USE_GEMM_ROWS3 and plan.code == BF16 and plan.has_ln
+              and plan.K == d and d <= 128 and d % 8 == 0
               and plan.kp_rows == 128 and plan.wfrag_rows is not None and hw % 32 == 0 and plan.stride == 1
               and plan.pre_scale is None and plan.act == 0 and plan.cout % 8 == 0 and (bcast or x.is_contiguous()))
     if fused3:

@@ -934,6 +934,52 @@ def test_sttf_warp_and_mask(cuda, dtype, hw):
         assert np.array_equal(com.cpu().numpy(), g["mask_%dx%d" % (h, w)])
 
 
+@pytest.mark.parametrize("b,n,H,W,bcast", [(2, 3, 16, 24, False), (5, 4, 32, 32, True), (1, 1, 8, 4, False)])
+def test_bev_query_wave_level_kernel(cuda, b, n, H, W, bcast):
+    """bev_query.hip (the 128 -> 128 query side of FAX cross attention #1 in one launch: embedding, + x, bf16 rounding, LayerNorm,
+    to_q; fax_modules.py:370-375,387-388,201) against the embedding kernel + GEMM (same roundings: equal to bf16 rounding of the
+    result) and against an fp32 torch evaluation of the reference formulas"""
+    import cases
+    d, dtype = 128, torch.bfloat16
+    _, E = cases.camera_geometry(b * n, n, 112, 120)
+    Ec = E.reshape(b * n, 4, 4).contiguous()
+    world = procedural_input("bq.world", (2, H * W), 0, -40, 40)
+    w_bev, b_bev, w_cam = procedural_input("bq.wb", (d, 2), 0), procedural_input("bq.bb", (d,), 0), procedural_input("bq.wc", (d, 4), 0)
+    x = procedural_input("bq.x", (1 if bcast else b, H * W, d), 0)
+    wq = procedural_input("bq.wq", (d, d), 0) * math.sqrt(3.0 / d)
+    bq = procedural_input("bq.bq", (d,), 0, -0.2, 0.2)
+
+    class LN(object):
+        weight, bias, eps = 0.8 + 0.4 * procedural_input("bq.g", (d,), 0, 0, 1), procedural_input("bq.be", (d,), 0, -0.2, 0.2), 1e-5
+    plan = ops.ConvPlan(wq, bq, dtype=dtype, device=cuda, ln=LN)
+    xd = x.to(cuda).to(dtype)
+    xin = xd.expand(b, H * W, d) if bcast else xd
+    args = (Ec.to(cuda), world.to(cuda), w_bev.to(cuda), b_bev.to(cuda), w_cam.to(cuda))
+    keep = (ops.USE_EMBED_GEMM, ops.USE_EMBED_GEMM3)
+    try:
+        ops.USE_EMBED_GEMM, ops.USE_EMBED_GEMM3 = False, False
+        two = ops.bev_embed_linear(*args, xin, n, plan)
+        ops.USE_EMBED_GEMM3 = True
+        with ops.LaunchProfile() as prof:
+            one = ops.bev_embed_linear(*args, xin, n, plan)
+        assert len(prof.records) == 1, "the fused query must be ONE launch"
+    finally:
+        ops.USE_EMBED_GEMM, ops.USE_EMBED_GEMM3 = keep
+    assert one.shape == (b, n, H * W, d) and one.dtype == dtype
+    # fp32 reference on the bf16-rounded x / weights: query = normalise(w_bev . world + b_bev - w_cam . c) + x ; LN ; Linear
+    c = Ec[:, :, 3]                                                        # (b n, 4): camera position column
+    emb = (w_bev @ world)[None] + b_bev[None, :, None] - (c @ w_cam.t())[:, :, None]        # (bn, d, hw)
+    emb = emb / (emb.norm(dim=1, keepdim=True) + 1e-7)
+    xr = rnd(x, dtype)
+    q = emb.permute(0, 2, 1).reshape(b, n, H * W, d) + (xr[0][None, None] if bcast else xr[:, None])
+    q = rnd(q, dtype)                                                      # the query as the unfused path stores it
+    qn = F.layer_norm(q, (d,), LN.weight, LN.bias, LN.eps)
+    ref = qn @ wq.t() + bq
+    s = ref.abs().max().item()
+    assert (one.float().cpu() - ref).abs().max().item() <= 1e-2 * s
+    assert (one.float() - two.float()).abs().max().item() <= 1e-2 * s
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_bev_embed_fused_into_q_projection(cuda, dtype):
     """to_q(LayerNorm(x + bev embedding)) with the embedding produced inside the GEMM == bev_embed kernel + GEMM"""
@@ -970,7 +1016,7 @@ def test_bev_embed_fused_into_q_projection(cuda, dtype):
         prior = x[0]
         view = prior[None].expand(b, H * W, d)
         yr = ops.bev_embed_linear(E, world, w_bev, b_bev, w_cam, view, n, plan)       # two launches
-        ops.USE_EMBED_GEMM3 = True
+        ops.USE_EMBED_GEMM3 = 2                   # (2 = also for widths the wave-level kernel does not take)
         try:
             y3 = ops.bev_embed_linear(E, world, w_bev, b_bev, w_cam, x, n, plan)
             yb = ops.bev_embed_linear(E, world, w_bev, b_bev, w_cam, view, n, plan)
