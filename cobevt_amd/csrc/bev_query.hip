@@ -43,18 +43,41 @@ __global__ __launch_bounds__(NW * 64, 3) void bev_query_kernel(BevQueryParams p,
     const int h = lane >> 5, ql = lane & 31;
 
     {
+        // (every thread's loads first, then its LDS stores: rolled load -> store loops cost one exposed round trip per iteration)
         uint4* dst = (uint4*)smem;
-        for (int i = tid; i < 32 * 64; i += NW * 64) dst[i] = p.wfrag[i];
-        for (int i = tid; i < 128; i += NW * 64) {
-            cxy[i] = make_float2(p.w_bev[2 * i], p.w_bev[2 * i + 1]);
-            sbias[i] = p.bias ? p.bias[i] : 0.f;
-        }
+        constexpr int PER = 32 * 64 / (NW * 64);
+        uint4 tmp[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) tmp[u] = p.wfrag[tid + u * NW * 64];
         const int ncam = p.B * p.n;
-        for (int i = tid; i < ncam * 128; i += NW * 64) {
-            const int bn = i >> 7, ch = i & 127;
+        constexpr int CPER = (kMaxCams * 128 + NW * 64 - 1) / (NW * 64);
+        float4 wc[CPER];
+        float e3[CPER], e7[CPER], e11[CPER], e15[CPER], bb[CPER];
+#pragma unroll
+        for (int u = 0; u < CPER; ++u) {
+            const int i = tid + u * NW * 64, ic = i < ncam * 128 ? i : 0;
+            const int bn = ic >> 7, ch = ic & 127;
             const float* E = p.E_inv + (size_t)bn * 16;
-            const float4 wc = *(const float4*)(p.w_cam + ch * 4);
-            cz[i] = p.b_bev[ch] - (wc.x * E[3] + wc.y * E[7] + wc.z * E[11] + wc.w * E[15]);
+            wc[u] = *(const float4*)(p.w_cam + ch * 4);
+            e3[u] = E[3]; e7[u] = E[7]; e11[u] = E[11]; e15[u] = E[15];
+            bb[u] = p.b_bev[ch];
+        }
+        float2 cc = make_float2(0.f, 0.f);
+        float bq = 0.f;
+        if (tid < 128) {
+            cc = make_float2(p.w_bev[2 * tid], p.w_bev[2 * tid + 1]);
+            bq = p.bias ? p.bias[tid] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) dst[tid + u * NW * 64] = tmp[u];
+#pragma unroll
+        for (int u = 0; u < CPER; ++u) {
+            const int i = tid + u * NW * 64;
+            if (i < ncam * 128) cz[i] = bb[u] - (wc[u].x * e3[u] + wc[u].y * e7[u] + wc[u].z * e11[u] + wc[u].w * e15[u]);
+        }
+        if (tid < 128) {
+            cxy[tid] = cc;
+            sbias[tid] = bq;
         }
     }
     __syncthreads();

@@ -388,7 +388,7 @@ extern "C" int cobevt_attn_mlp_chain(const void* a, const void* skip, void* out,
 extern "C" int cobevt_proj_chain(const void* a, const float* pre_scale, const float* pre_shift, const void* skip, const void* wp,
                                  const float* bp, void* out, const void* wnext, const float* bnext, void* out_next, const int* dims,
                                  float eps_next, hipStream_t stream) {
-    // dims: [dtype, M, C (= 128), Nn, next_ln, next_act, skip_rows, pre_relu]
+    // dims: [dtype, M, C (= 128), Nn, next_ln, next_act, skip_rows, pre_relu, variant (0 = automatic, 1 = the barrier-phased kernel)]
     if (!a || !wp || !wnext || !bnext || !out_next || !dims) return COBEVT_ERR_ARG;
     if ((pre_scale == nullptr) != (pre_shift == nullptr)) return COBEVT_ERR_ARG;
     if (dims[0] != 0) return COBEVT_ERR_UNSUPPORTED;
@@ -406,6 +406,10 @@ extern "C" int cobevt_proj_chain(const void* a, const float* pre_scale, const fl
     if (p.M < 1 || p.C != 128) return COBEVT_ERR_SHAPE;             // K = C = 128 (the level-0 feature / embedding width)
     if (p.Nn < 8 || p.Nn % 8 || p.Nn > kRcBnMax || p.next_act < 0 || p.next_act > 2) return COBEVT_ERR_SHAPE;
     if (p.skip_rows > p.M || p.M % p.skip_rows) return COBEVT_ERR_SHAPE;
+    if (dims[8] == 0) {
+        const int rc = launch_proj_chain128(p, stream);         // big maps: rows in registers, weights in LDS (proj_chain128.hip)
+        if (rc >= 0) return rc;
+    }
     launch_chain<1, 32, true, false>(p, stream);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

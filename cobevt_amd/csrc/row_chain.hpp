@@ -34,5 +34,7 @@ struct RowChainParams {
 // workgroups with every weight fragment resident in registers; returns COBEVT_OK, an error code, or -1 when the shape does not
 // qualify (the caller then launches the generic kernel)
 int launch_row_chain64(const RowChainParams& p, hipStream_t stream);
+// proj_chain128.hip: the projection chain (MLP = false form: pre-activation -> Wp + skip -> LN -> Wn) on big 128-channel maps, same idea
+int launch_proj_chain128(const RowChainParams& p, hipStream_t stream);
 
 }  // namespace cobevt

@@ -83,25 +83,31 @@ __global__ __launch_bounds__(NW * 64, 2) void row_chain64_kernel(RowChainParams 
     // ---- weights -> LDS.  Natural fragments are [tile][k-group][half][32 lanes][16 B]; accumulator k order: lane (h, q) of
     // k-group G takes bytes [8 h, +8) of the half-0 piece and bytes [8 h, +8) of the half-1 piece of lane q
     {
+        // (all of a thread's loads first, then its LDS stores: a rolled load -> store loop is one exposed L2 round trip per iteration)
         uint4* dst = (uint4*)smem;
-        for (int i = tid; i < kFrags * 64; i += NW * 64) {
-            const int f = i >> 6, ln = i & 63, hh = ln >> 5, q = ln & 31;
+        constexpr int TOTAL = (kFn + 4 * NNT2) * 64, PER = (TOTAL + NW * 64 - 1) / (NW * 64);
+        uint4 tmp[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = tid + u * NW * 64, ic = i < TOTAL ? i : TOTAL - 1;
+            const int f = ic >> 6, ln = ic & 63, hh = ln >> 5, q = ln & 31;
             const uint4* src;
             int sf;                                   // source fragment index (tile * k-groups-per-tile + k-group)
-            bool acc_order = true;
-            if (f < kF1) { src = p.wp; sf = (f >> 2) * 8 + (f & 3); acc_order = false; }
+            if (f < kF1) { src = p.wp; sf = (f >> 2) * 8 + (f & 3); }
             else if (f < kF2) { src = p.w1; sf = ((f - kF1) >> 2) * 8 + ((f - kF1) & 3); }
             else if (f < kFn) { src = p.w2; sf = f - kF2; }                       // [2 tiles][8 k-groups] = Hdp / 16 per tile
             else { src = p.wn ? p.wn : p.w1; sf = ((f - kFn) >> 2) * 8 + ((f - kFn) & 3); }
-            if (f >= kFn + 4 * NNT2) continue;
-            uint4 v;
-            if (!acc_order) v = src[(size_t)sf * 64 + ln];
-            else {
-                const uint2 lo = *(const uint2*)((const unsigned char*)(src + (size_t)sf * 64 + q) + 8 * hh);
-                const uint2 hi = *(const uint2*)((const unsigned char*)(src + (size_t)sf * 64 + 32 + q) + 8 * hh);
-                v = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            }
-            dst[i] = v;
+            const bool nat = f < kF1;                 // Wp keeps the natural k order
+            const uint4* base = src + (size_t)sf * 64;
+            const unsigned char* a0 = (const unsigned char*)(base + (nat ? ln : q)) + (nat ? 0 : 8 * hh);
+            const unsigned char* a1 = nat ? a0 + 8 : (const unsigned char*)(base + 32 + q) + 8 * hh;
+            const uint2 lo = *(const uint2*)a0, hi = *(const uint2*)a1;
+            tmp[u] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = tid + u * NW * 64;
+            if (i < TOTAL) dst[i] = tmp[u];
         }
         for (int i = tid; i < kBiasFloats; i += NW * 64) {
             const float* src = i < kB1 ? p.bp : i < kB2 ? p.b1 : i < kPg ? p.b2 : i < kPb ? p.post_g : i < kBn ? p.post_b : p.bn;

@@ -43,6 +43,7 @@ USE_CHAIN_NEXT = True  # ... and let the row-local GEMM that consumes its output
 USE_HEAD_CONV = True    # 3x3 convs with <= 4 output channels to NCHW fp32 logits (BevSegHead) on the direct kernel
 USE_PROJ_CHAIN = True   # FAX key / value side at 128 feature channels: BN -> ReLU -> 1x1 conv (+ ray embedding) -> LayerNorm -> to_k | to_v
                         # of both attentions in ONE launch per operand, the key / value map itself never reaches HBM (row_chain.hip)
+USE_PROJ_CHAIN_WAVE = True   # ... on maps of >= 32768 rows as independent waves with the rows in registers and the weights in LDS (proj_chain128.hip)
 USE_SWAP_STAGE = True   # a SwapFusionBlock half (attention + row chain + next to_qkv) as one launch (swap_stage.hip)
 USE_BOTTLENECK = True   # FAX ResNetBottleNeck (128 -> 32 -> 32 -> 128) as one launch (bottleneck.hip) instead of three
 ATTN_VARIANT = 0    # 0 = automatic (K/V-resident attention kernel where it applies), 1 = always the streaming kernel, 2 = ... with 64-key tiles (A/B runs)
@@ -1037,7 +1038,7 @@ def proj_chain(x, plan_p, next_plan, residual=None, out_next=None):
         out_next = torch.empty(x.shape[:-1] + (nn_,), device=x.device, dtype=x.dtype)
     elif out_next.numel() != m * nn_ or not out_next.is_contiguous() or out_next.dtype != x.dtype:
         raise CobevtHipError("proj_chain: `out_next` must be a contiguous (.., %d) buffer of dtype %s" % (nn_, x.dtype))
-    dims = _ints([0, m, c, nn_, int(next_plan.has_ln), next_plan.act, 0, plan_p.pre_relu])
+    dims = _ints([0, m, c, nn_, int(next_plan.has_ln), next_plan.act, 0, plan_p.pre_relu, 0 if USE_PROJ_CHAIN_WAVE else 1])
 
     def cost():
         return 2.0 * m * (c * c + c * nn_), float(m * (c * (2 if residual is not None else 1) + nn_) * 2 + (c * c + c * nn_) * 2)

@@ -444,7 +444,9 @@ int cobevt_window_attention_ksplit(const void* q, const void* k, const void* v, 
  *   next = act(LayerNorm?(y) . Wn'^T + bn')                           to_k / to_v of BOTH cross attentions stacked (fax_modules.py:201-205)
  * with y (the "key" / "val" map of the reference) kept in LDS: it is written to `out` only when out != null.  The row_chain
  * kernel without its MLP phases (csrc/row_chain.hip).  Weights in MFMA fragment order as for cobevt_attn_mlp_chain.
- * dims (int32[8]): dtype (0), M, C (128), Nn (<= 768), next_ln, next_act, skip_rows (0 = M), pre_relu.
+ * dims (int32[9]): dtype (0), M, C (128), Nn (<= 768), next_ln, next_act, skip_rows (0 = M), pre_relu, variant (0 = automatic:
+ * maps of >= 32768 rows run as independent waves with the rows in registers and the weights in LDS, csrc/proj_chain128.hip;
+ * 1 = always the barrier-phased kernel).
  */
 int cobevt_proj_chain(const void* a, const float* pre_scale, const float* pre_shift, const void* skip, const void* wp,
                       const float* bp, void* out, const void* wnext, const float* bnext, void* out_next, const int* dims,

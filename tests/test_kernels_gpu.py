@@ -1187,8 +1187,8 @@ def test_swap_fusion_stage_single_launch(cuda, agents, window, hw, mlp, use_mask
     assert e <= 1e-2 and e <= 1.5 * e2 + 2e-3, (e, e2)
 
 
-@pytest.mark.parametrize("rows,with_res", [(4096, True), (4096, False), (1000, True)])
-def test_projection_chain_single_launch(cuda, rows, with_res):
+@pytest.mark.parametrize("rows,with_res", [(4096, True), (4096, False), (1000, True), (40960, True), (32768 + 77, False)])
+def test_projection_chain_single_launch(cuda, rows, with_res):      # (>= 32768 rows: the wave-level kernel, proj_chain128.hip)
     """cobevt_proj_chain (BN -> ReLU -> 1x1 conv (+ ray embedding) -> LayerNorm -> stacked to_k / to_v without materialising the key
     / value map; fax_modules.py:281-292,377-396,201-205) against the two launches it replaces and against fp32 torch"""
     import torch.nn as nn
