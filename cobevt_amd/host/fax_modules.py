@@ -308,8 +308,7 @@ class CrossViewSwapAttention(HipModule):
         if self.feature_proj is not None:
             key = ops.conv2d(feature, plan_key, residual=img, out=kv_buffer("key"))
         elif padded:
-            key = kv_buffer("key")
-            key[:, :h, :w] = img
+            key = ops.copy_into_interior(img, kv_buffer("key"))
         else:
             key = img
         val = ops.conv2d(feature, plan_val, out=kv_buffer("val"))

@@ -837,6 +837,22 @@ def from_nhwc(x, dtype):
     return out
 
 
+def copy_into_interior(x, dst):
+    """dst[:, :h, :w, :] = x for contiguous (N, h, w, C) `x` and a contiguous, larger (N, H, W, C) `dst` of the same dtype - the
+    zero-padded key map of a FAX level without image features (fax_modules.py:392-396).  cobevt_from_nhwc with the interior's
+    strides: no torch arithmetic on the inference path."""
+    _need_cuda(x, dst)
+    n, h, w, c = x.shape
+    if dst.dtype != x.dtype or not x.is_contiguous() or not dst.is_contiguous() or dst.shape[0] != n or dst.shape[3] != c \
+            or dst.shape[1] < h or dst.shape[2] < w:
+        raise CobevtHipError("copy_into_interior: dst must be a contiguous (N, >= h, >= w, C) map of x's dtype")
+    sN, sH, sW, sC = dst.stride()
+    strides = (ctypes.c_long * 4)(sN, sC, sH, sW)                     # (N, C, H, W) order of the C entry point
+    rc = _L.load().cobevt_from_nhwc(_p(x), dcode(x.dtype), _p(dst), dcode(dst.dtype), n, c, h, w, strides, _stream())
+    _L.check(rc, "cobevt_from_nhwc")
+    return dst
+
+
 def regroup(x, record_len, max_cav):
     """x: (N, ...) contiguous, record_len int32 device (B,) -> (B, max_cav, ...), mask (B, max_cav) fp32."""
     _need_cuda(x, record_len)

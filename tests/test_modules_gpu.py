@@ -52,6 +52,25 @@ def test_cross_view_swap_attention(cuda, dtype, tol, name):
     assert_close(y, golden("gv3_cross_view_swap_attention")[name], tol, "CrossViewSwapAttention." + name)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, BF16)])
+def test_cross_view_swap_attention_without_image_features(cuda, dtype, tol):
+    """`no_image_features: True` (fax_modules.py:392-396: the key is the ray embedding alone) on the zero-padded key map of the
+    "padded" case - the branch whose interior copy used to be a torch slice assignment, now
+    ops.copy_into_interior - against the oracle (no reference fixture for this flag: the operator is gated like its padded twin)"""
+    c = copy.deepcopy(cases.CVSA["padded"])
+    c["kwargs"]["no_image_features"] = True
+    fd, fh, fw = c["feat"]
+    m = dev(host.CrossViewSwapAttention(fh, fw, fd, c["dim"], c["index"], c["image"][0], c["image"][1], **c["kwargs"]), cuda)
+    bev = host.BEVEmbedding(c["dim"], **c["bev_embedding"])
+    x, feat, I_inv, E = cases.cvsa_inputs("padded")
+    cfg = dict(c["kwargs"], image_height=c["image"][0], image_width=c["image"][1])
+    grid = o_fax.bev_grids(**c["bev_embedding"])[c["index"]]
+    ref = o_fax.cross_view_swap_attention({k: v.cpu() for k, v in m.state_dict().items()}, "", cfg, c["index"], x, grid, feat, I_inv, E)
+    with host.compute_dtype(dtype):
+        y = m(c["index"], x.to(cuda), bev.to(cuda), feat.to(cuda), I_inv.to(cuda), E.to(cuda))
+    assert_close(y, ref, tol, "CrossViewSwapAttention.padded without image features", case="CrossViewSwapAttention.padded")
+
+
 @pytest.mark.parametrize("dtype,tol", MODES)
 def test_fax_module(cuda, dtype, tol):
     c = cases.FAX_SMALL
