@@ -455,9 +455,9 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
                         // ---- regular pass: P = exp2(S - m_run) straight from the MFMA result, packed to bf16.  Row sums on the
                         // matrix pipe too (it has the slack, the VALU does not): ones(32 x 16) . P^T sums the 16 keys of a k-block
                         // for every query into all 16 accumulator rows - 4 MFMAs replace 32 v_add_f32 and the half-wave exchange
+                        // (the first one takes a literal zero accumulator - an inline constant of the instruction - instead of sixteen
+                        //  v_mov per tile to clear `lt`: 16 of the ~70 VALU instructions of a tile in the ISA)
                         f32x16 lt;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) lt[r] = 0.f;
                         const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
 #pragma unroll
                         for (int s = 0; s < 2; ++s) {
@@ -471,7 +471,13 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
                                 pb[s * 2 + u].y = pack_bf2(e[8 * u + 2], e[8 * u + 3]);
                                 pb[s * 2 + u].z = pack_bf2(e[8 * u + 4], e[8 * u + 5]);
                                 pb[s * 2 + u].w = pack_bf2(e[8 * u + 6], e[8 * u + 7]);
-                                mfma_kgroup<bf16_t>(ones, pb[s * 2 + u], lt);
+                                if (s == 0 && u == 0) {
+                                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                    lt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pb[0]),
+                                                                                 zero, 0, 0, 0);
+                                } else {
+                                    mfma_kgroup<bf16_t>(ones, pb[s * 2 + u], lt);
+                                }
                             }
                         }
                         psum = lt[0];                       // the whole tile's row sum of this lane's query (both key halves)
