@@ -575,6 +575,65 @@ def test_attn_mlp_chain_next_projection(cuda, c, rows, nn_, next_ln, next_act, p
     assert (nx.float() - nx_b.float()).abs().max().item() <= 1e-2 * s
 
 
+@pytest.mark.parametrize("rows,nn_,next_ln,next_act,post", [(16384 + 40, 192, True, 0, False), (20000, 0, False, 0, True),
+                                                            (16384, 64, False, 1, True), (33000, 128, True, 2, False)])
+def test_row_chain64_wave_level_kernel(cuda, rows, nn_, next_ln, next_act, post):
+    """row_chain64.hip (64-channel rows, hidden 128: the LiDAR FuseBEVT chain as independent waves, activations in registers in
+    accumulator k order, weights in LDS) against the barrier-phased generic kernel (ROW_CHAIN_ROWS = 32 pins it) and fp32 torch, on
+    ragged row counts, with / without the next projection, its LayerNorm / activation and the post-LayerNorm"""
+    dtype, c, hd = torch.bfloat16, 64, 128
+    a = procedural_input("c64.a", (rows, c), 0, -2, 2)
+    sk = procedural_input("c64.s", (rows, c), 0, -1, 1)
+    mk = lambda key, shape, fan: procedural_input(key, shape, 0) * math.sqrt(3.0 / fan)
+    wp, w1, w2 = mk("c64.wp", (c, c), c), mk("c64.w1", (hd, c), c), mk("c64.w2", (c, hd), hd)
+    bp, b1, b2 = [procedural_input("c64.b%d" % i, (n,), 0, -0.2, 0.2) for i, n in enumerate((c, hd, c))]
+
+    class LN1(object):
+        weight, bias, eps = 0.8 + 0.4 * procedural_input("c64.g1", (c,), 0, 0, 1), procedural_input("c64.be1", (c,), 0, -0.2, 0.2), 1e-5
+
+    class LNn(object):
+        weight, bias, eps = 0.8 + 0.4 * procedural_input("c64.gn", (c,), 0, 0, 1), procedural_input("c64.ben", (c,), 0, -0.2, 0.2), 1e-5
+    g2, be2 = 0.8 + 0.4 * procedural_input("c64.g2", (c,), 0, 0, 1), procedural_input("c64.be2", (c,), 0, -0.2, 0.2)
+    pp = ops.ConvPlan(wp, bp, dtype=dtype, device=cuda)
+    p1 = ops.ConvPlan(w1, b1, act=2, dtype=dtype, device=cuda, ln=LN1)
+    p2 = ops.ConvPlan(w2, b2, dtype=dtype, device=cuda)
+    pn = None
+    if nn_:
+        wn, bn_ = mk("c64.wn", (nn_, c), c), procedural_input("c64.bn", (nn_,), 0, -0.2, 0.2)
+        pn = ops.ConvPlan(wn, bn_, act=next_act, dtype=dtype, device=cuda, ln=LNn if next_ln else None)
+    post_ln = (g2.to(cuda), be2.to(cuda), 1e-5) if post else None
+    ad, sd = a.to(cuda).to(dtype), sk.to(cuda).to(dtype)
+    with ops.LaunchProfile() as prof:
+        res = ops.attn_mlp_chain(ad, sd, pp, p1, p2, post_ln, next_plan=pn)
+    assert len(prof.records) == 1
+    keep = ops.ROW_CHAIN_ROWS
+    ops.ROW_CHAIN_ROWS = 32
+    try:
+        gen = ops.attn_mlp_chain(ad, sd, pp, p1, p2, post_ln, next_plan=pn)
+    finally:
+        ops.ROW_CHAIN_ROWS = keep
+    y, nx = res if nn_ else (res, None)
+    yg, nxg = gen if nn_ else (gen, None)
+    # fp32 torch over the bf16-rounded operands, with the same roundings of y / LN(y) / hidden the kernels store
+    yr = rnd(F.linear(rnd(a, dtype), rnd(wp, dtype), bp) + rnd(sk, dtype), dtype)
+    hid = rnd(F.gelu(F.linear(rnd(F.layer_norm(yr, (c,), None, None, 1e-5), dtype), p1.wgt_rows.float().cpu()[:, :c], p1.bias.cpu())), dtype)
+    z = F.linear(hid, rnd(w2, dtype), b2) + yr
+    ref = F.layer_norm(z, (c,), g2, be2, 1e-5) if post else z
+    s = ref.abs().max().item()
+    assert (y.float().cpu() - ref).abs().max().item() <= 1e-2 * s
+    assert (y.float() - yg.float()).abs().max().item() <= 1e-2 * s
+    if nn_:
+        xin = y.float().cpu()
+        if next_ln:
+            xin = F.layer_norm(xin, (c,), LNn.weight, LNn.bias, 1e-5)
+        rn = F.linear(xin, rnd(wn, dtype), bn_)
+        rn = F.relu(rn) if next_act == 1 else (F.gelu(rn) if next_act == 2 else rn)
+        sn = rn.abs().max().item()
+        assert nx.shape == (rows, nn_)
+        assert (nx.float().cpu() - rn).abs().max().item() <= 1e-2 * sn
+        assert (nx.float() - nxg.float()).abs().max().item() <= 1e-2 * sn
+
+
 # ---------------------------------------------------------------------------------------------
 def _attn_ref(q, k, v, scale, bias=None, key_mask=None):
     """q (G, Nq, dh), k/v (G, Nk, dh) fp32 -> (G, Nq, dh)"""
