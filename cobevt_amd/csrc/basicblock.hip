@@ -87,11 +87,15 @@ template <typename T, int C, int TH_> struct BBCfg {
 template <typename T, int NTW>
 __device__ __forceinline__ void bb_conv_chunk(const unsigned char* patch, const int (&aoff)[NTW], const bool (&ok)[NTW],
                                               int row_pitch, int pstr, const uint4* wsrc, int step0, int nstep,
-                                              uint4 (&bq)[3][4], f32x16 (&acc)[NTW]) {
+                                              uint4 (&bq)[3][4], f32x16 (&acc)[NTW], int odd_off = -1) {
     uint4 af[3][NTW];
     auto read_a = [&](uint4 (&dst)[NTW], int n) {               // n = tap * 4 + k-group (compile-time after unrolling)
         const int tap = n >> 2, g = n & 3;
-        const int off = (tap / 3) * row_pitch + (tap % 3) * pstr + g * 32;      // row_pitch in bytes
+        // odd_off >= 0: a stride-2 convolution out of a patch whose rows are de-interleaved by column parity ([even columns][odd
+        // columns]; the lane base steps two patch rows / one plane pixel per output pixel): tap column 0 / 1 / 2 = even plane,
+        // odd plane, even plane + 1 pixel
+        const int kw = tap % 3;
+        const int off = (tap / 3) * row_pitch + (odd_off < 0 ? kw * pstr : (kw == 1 ? odd_off : (kw == 2 ? pstr : 0))) + g * 32;      // row_pitch in bytes
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
             if (ok[t]) dst[t] = *(const uint4*)(patch + aoff[t] + off);
@@ -412,6 +416,239 @@ static int launch_basicblock(BasicBlockParams p, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The first BasicBlock of ResNet layer2 (stride 2, 64 -> 128 channels, projection shortcut; torchvision BasicBlock + downsample as
+// reached from resnet_ms.py:67-74) in one launch (bf16):
+//
+//     out = ReLU( conv3x3_2( ReLU( conv3x3_1/s2(x) + b1 ) ) + b2 + conv1x1/s2(x) + b_ds )
+//
+// As three launches it cost 35 + 40 + 17 us per 5-agent frame (the stride-2 conv with a single 64-channel chunk is all prologue and
+// epilogue: 0.13 of the matrix peak; the shortcut map is written and read back).  Same scheme as basicblock_kernel with a 4 x 16
+// output tile: the (2 * 6 + 1) x 37 input patch in LDS with its rows de-interleaved by column parity, so a tap's A fragments are 32
+// consecutive region pixels at the 144-byte pitch again; conv1 on the 6 x 18 region conv2 needs -> + b1, ReLU, bf16 -> second patch;
+// conv2 out of that patch; the shortcut is four more k-groups into conv2's accumulators, read at the centre taps of the first patch
+// (x[2 oy][2 ox]) - it is never rounded to bf16 on its own; epilogue straight from the registers (D = W X^T: a lane owns one pixel
+// and runs of couts; one v_permlane32_swap per register pairs them into 16-byte stores).  1280 workgroups on the 20 x 64 x 64 maps =
+// five per CU.
+struct DsBlockParams {
+    const void* in;
+    const uint4* w1;        // fragment-ordered [4][1][9][4][64]   conv1: 64 -> 128, stride 2
+    const float* b1;
+    const uint4* w2;        // fragment-ordered [4][2][9][4][64]   conv2: 128 -> 128
+    const float* b2;
+    const uint4* wds;       // dense-row fragments [4 tiles][8 k-groups][64] of the 1x1 / stride-2 shortcut (K = 64 padded to 128)
+    const float* bds;
+    void* out;
+    int N, H, W;            // input map (even sides)
+    int Ho, Wo;
+    int tiles_y, tiles_x;
+};
+
+struct DsCfg {
+    static constexpr int TH = 4, TW = 16, R1H = TH + 2, R1W = TW + 2, R1 = R1H * R1W;      // conv1 region 6 x 18 = 108 pixels
+    static constexpr int N1 = (R1 + 31) / 32, NPG = 2, T1W = N1 / NPG;                      // 4 pixel tiles, 2 per wave
+    static constexpr int P1H = 2 * R1H + 1, P1W = 2 * R1W + 1;                              // 13 x 37 input pixels
+    static constexpr int PSTR1 = 128 + 16;
+    static constexpr int ODD = ((P1W + 1) / 2) * PSTR1;                                     // odd-column plane behind the 19 even columns
+    // pitch: >= 37 * 144 and == 16 * (8 k + 1), so that two patch rows (one region row) advance the 16-byte slot by 2 = 18 * 9 mod 16:
+    // the slot of region pixel p is 9 p + const across the row wrap -> conflict-free ds_read_b128 for any 32 consecutive pixels
+    static constexpr int PITCH1 = 337 * 16;
+    static constexpr int PATCH1 = P1H * PITCH1;                                             // 70,096 B
+    static constexpr int PSTR2 = 256 + 16;
+    static constexpr int PITCH2 = (R1W * PSTR2 + 255) / 256 * 256;
+    static constexpr int PATCH2 = R1H * PITCH2;                                             // 30,720 B, over the first patch once conv1 is done
+    static constexpr int XCH = PATCH2;                                                      // partial-sum exchange behind it: 8 waves x 4 KB
+    static constexpr int SC = PATCH1;                                                       // the shortcut's pixels x[2 oy][2 ox]: [64][144 B]
+    static constexpr int LDS = PATCH1 + TH * TW * PSTR1;                                    // 79,312 B (+ 1 KB of biases): two workgroups per CU
+    static_assert(PITCH1 >= P1W * PSTR1 && N1 % NPG == 0 && XCH + 8 * 4096 <= PATCH1, "geometry");
+};
+
+__global__ __launch_bounds__(512, 2) void dsblock_kernel(DsBlockParams p) {
+    using G = DsCfg;
+    using T = bf16_t;
+    constexpr int NT = 512, PIECES = 8;
+    constexpr int P1_ITEMS = G::P1H * G::P1W * PIECES;          // 3848
+    constexpr int P_IT = (P1_ITEMS + NT - 1) / NT;              // 8
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* patch1 = smem;
+    unsigned char* patch2 = smem;
+
+    int logical;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+        const int q = nblk >> 3, r = nblk & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int tx_ = logical % p.tiles_x, ty_ = (logical / p.tiles_x) % p.tiles_y, img = logical / (p.tiles_x * p.tiles_y);
+    const int oy0 = ty_ * G::TH, ox0 = tx_ * G::TW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, ql = lane & 31;
+    const int ct = wave & 3, pg = wave >> 2;                    // cout tile; conv1: pixel-tile group, conv2: half of the reduction
+    const T* in = (const T*)p.in;
+
+    // ---- input patch: rows 2 oy0 - 3 .., columns 2 ox0 - 3 .. (all loads of a thread in flight together, zeros outside the image)
+    {
+        uint4 preg[P_IT];
+        int plds[P_IT];
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const int item = tid + it * NT;
+            plds[it] = -1;
+            int goff = 0;
+            if (item < P1_ITEMS) {
+                const int pix = item / PIECES, j = item - pix * PIECES;
+                const int py = pix / G::P1W, pc = pix - py * G::P1W;
+                const int iy = 2 * oy0 - 3 + py, ix = 2 * ox0 - 3 + pc;
+                const bool inside = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                const int lds = py * G::PITCH1 + (pc & 1) * G::ODD + (pc >> 1) * G::PSTR1 + j * 16;
+                if (inside) goff = ((img * p.H + iy) * p.W + ix) * 64 + j * 8;
+                plds[it] = inside ? lds : (lds | (1 << 30));
+            }
+            preg[it] = *(const uint4*)(in + goff);              // unconditional (element 0 for the padding items)
+        }
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it)
+            if (plds[it] >= 0) {
+                const int lds = plds[it] & 0x3fffffff;
+                const uint4 v = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : preg[it];
+                *(uint4*)(patch1 + lds) = v;
+                // the centre taps x[2 oy][2 ox] once more, compactly, for the shortcut after the patch has been overwritten
+                const int py = lds / G::PITCH1, rem = lds - py * G::PITCH1;
+                if ((py & 1) && py >= 3 && py <= 2 * G::TH + 1 && rem >= G::ODD + G::PSTR1 && rem < G::ODD + (G::TW + 1) * G::PSTR1) {
+                    const int tx = (rem - G::ODD) / G::PSTR1 - 1, jj = (rem - G::ODD) % G::PSTR1;
+                    *(uint4*)(smem + G::SC + (((py - 3) >> 1) * G::TW + tx) * G::PSTR1 + jj) = v;
+                }
+            }
+    }
+    uint4 bq[3][4];
+    auto load_b = [&](uint4 (&b)[4], const uint4* wsrc, int step, int nstep) {
+        const uint4* src = wsrc + (size_t)(step < nstep ? step : nstep - 1) * 256;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b[g] = src[g * 64];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const uint4* w1src = p.w1 + (size_t)ct * 9 * 256 + lane;
+    const uint4* w2src = p.w2 + (size_t)ct * 18 * 256 + lane;
+    load_b(bq[0], w1src, 0, 9);
+    load_b(bq[1], w1src, 1, 9);
+    __shared__ __attribute__((aligned(16))) float sbias[256];   // b1 | b2 + b_ds
+    if (tid < 256) sbias[tid] = tid < 128 ? (p.b1 ? p.b1[tid] : 0.f) : ((p.b2 ? p.b2[tid - 128] : 0.f) + (p.bds ? p.bds[tid - 128] : 0.f));
+    __syncthreads();
+
+    // ---- conv1 (stride 2) on the 6 x 18 region: region pixel 32 * tile + ql, tiles pg, pg + 2
+    f32x16 acc1[G::T1W];
+    {
+        int a1[G::T1W];
+        bool ok1[G::T1W];
+#pragma unroll
+        for (int t = 0; t < G::T1W; ++t) {
+            int pr = (pg + t * G::NPG) * 32 + ql;
+            ok1[t] = true;
+            if (pr >= G::R1) pr = G::R1 - 1;                    // padding lanes of the last tile compute a duplicate
+            const int ry = pr / G::R1W, rx = pr - ry * G::R1W;
+            a1[t] = 2 * ry * G::PITCH1 + rx * G::PSTR1 + h * 16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
+        }
+        bb_conv_chunk<T, G::T1W>(patch1, a1, ok1, G::PITCH1, G::PSTR1, w1src, 0, 9, bq, acc1, G::ODD);
+    }
+    // conv2's first fragments (this wave's half of the reduction: channels 64 pg ..) and the shortcut's while the intermediate is written
+    load_b(bq[0], w2src, pg * 9, 18);
+    load_b(bq[1], w2src, pg * 9 + 1, 18);
+    uint4 wd[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) wd[g] = p.wds[(size_t)(ct * 8 + 2 * pg + g) * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                            // every wave is done reading the input patch
+    // ---- intermediate: ReLU(conv1 + b1) rounded to bf16 -> patch2 [region pixel][128] ; zeros outside the map (conv2's padding)
+    {
+        const int c0 = ct * 32 + 4 * h;
+        float4 bias[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bias[k] = *(const float4*)&sbias[c0 + 8 * k];
+#pragma unroll
+        for (int t = 0; t < G::T1W; ++t) {
+            const int pr = (pg + t * G::NPG) * 32 + ql;
+            if (pr >= G::R1) continue;
+            const int ry = pr / G::R1W, rx = pr - ry * G::R1W;
+            const int my = oy0 - 1 + ry, mx = ox0 - 1 + rx;
+            const bool inside = my >= 0 && my < p.Ho && mx >= 0 && mx < p.Wo;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v[4] = {acc1[t][4 * k] + bias[k].x, acc1[t][4 * k + 1] + bias[k].y, acc1[t][4 * k + 2] + bias[k].z,
+                              acc1[t][4 * k + 3] + bias[k].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = inside ? fmaxf(v[e], 0.f) : 0.f;
+                *(uint2*)(patch2 + ry * G::PITCH2 + rx * G::PSTR2 + (c0 + 8 * k) * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            }
+        }
+    }
+    __syncthreads();                                            // patch2 complete
+
+    // ---- conv2 on the 4 x 16 tile: both output pixel tiles (rows 2 t, 2 t + 1), input channels 64 pg .. 64 pg + 63 (one B fragment
+    //      feeds two MFMAs); the two halves of the reduction meet through LDS below
+    f32x16 acc[2];
+    const int tx = ql & 15;
+    {
+        int a2[2];
+        bool ok2[2] = {true, true};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            a2[t] = (2 * t + (ql >> 4)) * G::PITCH2 + tx * G::PSTR2 + h * 16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        }
+        bb_conv_chunk<T, 2>(patch2 + pg * 128, a2, ok2, G::PITCH2, G::PSTR2, w2src, pg * 9, 18, bq, acc);
+    }
+    // ---- projection shortcut: k-groups 2 pg, 2 pg + 1 of x[2 oy][2 ox] into the same accumulators (never rounded on its own)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const unsigned char* ap = smem + G::SC + (32 * t + ql) * G::PSTR1 + h * 16 + 2 * pg * 32;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) mfma_kgroup<T>(wd[g], *(const uint4*)(ap + g * 32), acc[t]);
+    }
+    // ---- wave (ct, pg) finishes pixel tile pg: hand the other tile's partial sums to wave (ct, 1 - pg)
+    {
+        float4* xw = (float4*)(smem + G::XCH + (ct * 2 + pg) * 4096) + lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            xw[k * 64] = pg ? make_float4(acc[0][4 * k], acc[0][4 * k + 1], acc[0][4 * k + 2], acc[0][4 * k + 3])
+                            : make_float4(acc[1][4 * k], acc[1][4 * k + 1], acc[1][4 * k + 2], acc[1][4 * k + 3]);
+    }
+    __syncthreads();
+    float fin[16];
+    {
+        const float4* xr = (const float4*)(smem + G::XCH + (ct * 2 + (1 - pg)) * 4096) + lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 o = xr[k * 64];
+            fin[4 * k] = (pg ? acc[1][4 * k] : acc[0][4 * k]) + o.x;
+            fin[4 * k + 1] = (pg ? acc[1][4 * k + 1] : acc[0][4 * k + 1]) + o.y;
+            fin[4 * k + 2] = (pg ? acc[1][4 * k + 2] : acc[0][4 * k + 2]) + o.z;
+            fin[4 * k + 3] = (pg ? acc[1][4 * k + 3] : acc[0][4 * k + 3]) + o.w;
+        }
+    }
+    // ---- epilogue from the registers: + (b2 + b_ds), ReLU, pair the 8-byte cout runs of the two half-waves into 16-byte stores
+    {
+        const int oy = oy0 + 2 * pg + (ql >> 4), ox = ox0 + tx;
+        const bool live = oy < p.Ho && ox < p.Wo;
+        T* orow = (T*)p.out + ((size_t)(img * p.Ho + oy) * p.Wo + ox) * 128 + ct * 32;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const float4 b0 = *(const float4*)&sbias[128 + ct * 32 + 16 * m + 4 * h];
+            const float4 b1v = *(const float4*)&sbias[128 + ct * 32 + 16 * m + 8 + 4 * h];
+            uint32_t r0x = pack_bf2(fmaxf(fin[8 * m] + b0.x, 0.f), fmaxf(fin[8 * m + 1] + b0.y, 0.f));
+            uint32_t r0y = pack_bf2(fmaxf(fin[8 * m + 2] + b0.z, 0.f), fmaxf(fin[8 * m + 3] + b0.w, 0.f));
+            uint32_t r1x = pack_bf2(fmaxf(fin[8 * m + 4] + b1v.x, 0.f), fmaxf(fin[8 * m + 5] + b1v.y, 0.f));
+            uint32_t r1y = pack_bf2(fmaxf(fin[8 * m + 6] + b1v.z, 0.f), fmaxf(fin[8 * m + 7] + b1v.w, 0.f));
+            auto sx = __builtin_amdgcn_permlane32_swap(r0x, r1x, false, false);
+            auto sy = __builtin_amdgcn_permlane32_swap(r0y, r1y, false, false);
+            if (live) *(uint4*)(orow + 16 * m + 8 * h) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+    }
+}
+
 }  // namespace cobevt
 
 using namespace cobevt;
@@ -437,6 +674,31 @@ extern "C" int cobevt_basicblock_nhwc(const void* in, const void* wfrag1, const 
     if (c == 64) return dtype == 0 ? launch_basicblock<bf16_t, 64, 16>(p, stream) : launch_basicblock<float, 64, 16>(p, stream);
     if (c == 128) return dtype == 0 ? launch_basicblock<bf16_t, 128, 8>(p, stream) : launch_basicblock<float, 128, 8>(p, stream);
     return COBEVT_ERR_UNSUPPORTED;
+}
+
+// C-ABI entry point, see include/cobevt_hip.h
+extern "C" int cobevt_dsblock_nhwc(const void* in, const void* wfrag1, const float* bias1, const void* wfrag2, const float* bias2,
+                                   const void* wfrag_ds, const float* bias_ds, void* out, const int* dims, hipStream_t stream) {
+    // dims: [dtype (0), N, H, W, Cin (64), Cout (128)]
+    if (!in || !wfrag1 || !wfrag2 || !wfrag_ds || !out || !dims) return COBEVT_ERR_ARG;
+    if (dims[0] != 0 || dims[4] != 64 || dims[5] != 128) return COBEVT_ERR_UNSUPPORTED;
+    DsBlockParams p;
+    p.in = in; p.w1 = (const uint4*)wfrag1; p.b1 = bias1; p.w2 = (const uint4*)wfrag2; p.b2 = bias2;
+    p.wds = (const uint4*)wfrag_ds; p.bds = bias_ds; p.out = out;
+    p.N = dims[1]; p.H = dims[2]; p.W = dims[3];
+    if (p.N < 1 || p.H < 2 || p.W < 2 || (p.H & 1) || (p.W & 1)) return COBEVT_ERR_SHAPE;
+    if ((long)p.N * p.H * p.W * 64 >= 0x7fffffffL) return COBEVT_ERR_UNSUPPORTED;          // 32-bit element offsets
+    p.Ho = p.H / 2; p.Wo = p.W / 2;
+    p.tiles_y = (p.Ho + DsCfg::TH - 1) / DsCfg::TH;
+    p.tiles_x = (p.Wo + DsCfg::TW - 1) / DsCfg::TW;
+    const long blocks = (long)p.N * p.tiles_y * p.tiles_x;
+    if (blocks <= 0 || blocks > 0x7fffffffL) return COBEVT_ERR_SHAPE;
+    static cobevt::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
+        (void)hipFuncSetAttribute((const void*)dsblock_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DsCfg::LDS);
+    }
+    hipLaunchKernelGGL(dsblock_kernel, dim3((unsigned)blocks), dim3(512), DsCfg::LDS, stream, p);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
 #ifdef COBEVT_BB_TRACE

@@ -32,10 +32,13 @@ class BasicBlock(HipModule):
 
     def forward_nhwc(self, x):
         identity = x
-        if self.downsample is not None:
-            identity = ops.conv2d(x, rt.conv_plan(self, "ds", self.downsample[0], self.downsample[1]))
         p1 = rt.conv_plan(self, "c1", self.conv1, self.bn1, act=1)
         p2 = rt.conv_plan(self, "c2", self.conv2, self.bn2, act=1)
+        if self.downsample is not None:
+            pd = rt.conv_plan(self, "ds", self.downsample[0], self.downsample[1])
+            if ops.dsblock_fusable(x, p1, p2, pd):
+                return ops.dsblock(x, p1, p2, pd)
+            identity = ops.conv2d(x, pd)
         if self.downsample is None and self.stride == 1 and ops.basicblock_fusable(x, p1, p2):
             return ops.basicblock(x, p1, p2)
         y = ops.conv2d(x, p1)

@@ -33,6 +33,7 @@ ROW_CHAIN_ROWS = 0     # rows per workgroup of the fused row chain: 0 = default 
 USE_ROW_CHAIN = True  # fuse out-proj + skip + pre-norm MLP (+ post-norm) after attention into one launch (bf16)
 BASICBLOCK_TILE_ROWS = 0   # 0 = kernel default; 8 | 16 pins the output tile height (tools/bb_probe.py)
 USE_BASICBLOCK = True  # stride-1 BasicBlocks on 64 / 128 channels as one launch (intermediate map stays in LDS)
+USE_DSBLOCK = True  # layer2's stride-2 BasicBlock with its projection shortcut as one launch (bf16)
 USE_EMBED_GEMM = False  # compute the BEV query embedding inside the to_q GEMM instead of materialising the query:
 USE_EMBED_GEMM3 = True    # the BEV query produced inside the launch that projects it.  128 -> 128 with LayerNorm (every OPV2V level): the
                           # wave-level kernel of bev_query.hip (rows in registers, weights in LDS); other widths keep the embedding
@@ -491,6 +492,35 @@ def basicblock(x, plan1, plan2):
         rc = _L.load().cobevt_basicblock_nhwc(_p(x), _p(plan1.wfrag), _p(plan1.bias), _p(plan2.wfrag), _p(plan2.bias),
                                               _p(out), dims, _stream())
     _L.check(rc, "cobevt_basicblock_nhwc")
+    return out
+
+
+def dsblock_fusable(x, plan1, plan2, plan_ds):
+    """layer2's first BasicBlock (64 -> 128, stride 2, 1x1 / stride-2 projection shortcut), bf16: one launch (basicblock.hip)"""
+    return (USE_DSBLOCK and x.dtype == torch.bfloat16 and plan1.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous()
+            and plan1.wfrag is not None and plan2.wfrag is not None and plan_ds.wfrag_rows is not None
+            and (plan1.cin, plan1.cout, plan1.stride) == (64, 128, 2) and (plan2.cin, plan2.cout, plan2.stride) == (128, 128, 1)
+            and (plan_ds.cin, plan_ds.cout, plan_ds.stride, plan_ds.kp_rows) == (64, 128, 2, 128)
+            and plan1.act == 1 and plan2.act == 1 and plan_ds.act == 0 and plan_ds.pre_scale is None and not plan_ds.has_ln
+            and not plan1.upsample and not plan2.upsample and plan1.store_mode == 0 and plan2.store_mode == 0
+            and x.shape[3] == 64 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and x.numel() < 2 ** 31)
+
+
+def dsblock(x, plan1, plan2, plan_ds):
+    """relu(conv2(relu(conv1/s2(x))) + ds(x)) for BN-folded plans; x (N,H,W,64) channels-last bf16 -> (N,H/2,W/2,128)."""
+    _need_cuda(x)
+    n, h, w, c = x.shape
+    out = torch.empty((n, h // 2, w // 2, 128), dtype=x.dtype, device=x.device)
+    dims = _ints([plan1.code, n, h, w, c, 128])
+
+    def cost():
+        px = n * (h // 2) * (w // 2)
+        return 2.0 * px * 128 * (9 * 64 + 9 * 128 + 64), float(2 * (x.numel() + out.numel()) + 2 * 128 * (9 * 64 + 9 * 128 + 64))
+
+    with _timed("dsblock|%d->128 %dx%dx%d" % (c, n, h // 2, w // 2), cost):
+        rc = _L.load().cobevt_dsblock_nhwc(_p(x), _p(plan1.wfrag), _p(plan1.bias), _p(plan2.wfrag), _p(plan2.bias),
+                                           _p(plan_ds.wfrag_rows), _p(plan_ds.bias), _p(out), dims, _stream())
+    _L.check(rc, "cobevt_dsblock_nhwc")
     return out
 
 

@@ -91,6 +91,18 @@ int cobevt_basicblock_nhwc(const void* in, const void* wfrag1, const float* bias
                            void* out, const int* dims, hipStream_t stream);
 
 /*
+ * Fused down-sampling BasicBlock (ResNet layer2's first block: 64 -> 128 channels, stride 2, projection shortcut), bf16:
+ * out = ReLU(conv2(ReLU(conv1/s2(x) + b1)) + b2 + conv1x1/s2(x) + b_ds) with the eval BatchNorms folded - torchvision
+ * resnet.BasicBlock.forward with its `downsample` branch, as reached from resnet_ms.py:67-74.  One launch instead of three;
+ * the intermediate map stays in LDS and is rounded to bf16 as the unfused path stores it, the shortcut is accumulated in
+ * fp32 with conv2 (the unfused path rounds it to bf16 first).  wfrag1 / wfrag2: the fragment-ordered tables of
+ * cobevt_conv3x3_wfrag_nhwc; wfrag_ds: the dense-row fragment table of cobevt_linear_rows_wfrag (K padded to 128).
+ * dims (int32[6]): dtype (0 = bf16), N, H, W (even), Cin (64), Cout (128).  out: (N, H/2, W/2, 128).
+ */
+int cobevt_dsblock_nhwc(const void* in, const void* wfrag1, const float* bias1, const void* wfrag2, const float* bias2,
+                        const void* wfrag_ds, const float* bias_ds, void* out, const int* dims, hipStream_t stream);
+
+/*
  * ResNet stem: 7x7 / stride 2 / pad 3 conv on the fp32 3-channel channels-last image (+ folded BN, ReLU), computed as a
  * 4x4 stride-1 conv over the 2x2 space-to-depth image; torchvision resnet conv1/bn1/relu via resnet_ms.py:67-69.
  * wgt [Cout][16 taps][16] (12 real (dy,dx,c) channels + 4 zeros).  dims (int32[6]): dtype, N, H, W (even), Cout, act.

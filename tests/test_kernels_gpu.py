@@ -366,6 +366,40 @@ def test_basicblock_fused(cuda, dtype, c, n, h, w):
     assert (y.float() - y2.float()).abs().max().item() <= (1e-2 if dtype == torch.bfloat16 else 1e-5) * s
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 128, 128), (1, 26, 44), (3, 8, 32), (1, 2, 2)])
+def test_dsblock_fused(cuda, n, h, w):
+    """layer2's first BasicBlock (64 -> 128, stride 2, projection shortcut) in ONE launch vs the three launches vs torch;
+    ragged tiles exercise the zero padding of the input patch and of the intermediate at the image border"""
+    dtype = torch.bfloat16
+    x = procedural_input("ds.x", (n, 64, h, w), 0)
+    w1 = procedural_input("ds.w1", (128, 64, 3, 3), 0) * math.sqrt(3.0 / (64 * 9))
+    w2 = procedural_input("ds.w2", (128, 128, 3, 3), 0) * math.sqrt(3.0 / (128 * 9))
+    wd = procedural_input("ds.wd", (128, 64, 1, 1), 0) * math.sqrt(3.0 / 64)
+    p1 = ops.ConvPlan(w1, None, bn=FakeBN(128, "ds.bn1"), stride=2, pad=1, act=1, dtype=dtype, device=cuda)
+    p2 = ops.ConvPlan(w2, None, bn=FakeBN(128, "ds.bn2"), stride=1, pad=1, act=1, dtype=dtype, device=cuda)
+    pd = ops.ConvPlan(wd, None, bn=FakeBN(128, "ds.bnd"), stride=2, pad=0, act=0, dtype=dtype, device=cuda)
+    xd = nhwc(x).to(cuda).to(dtype)
+    assert ops.dsblock_fusable(xd, p1, p2, pd)
+    y = ops.dsblock(xd, p1, p2, pd)
+    assert y.shape == (n, h // 2, w // 2, 128)
+    y2 = ops.conv2d(ops.conv2d(xd, p1), p2, residual=ops.conv2d(xd, pd))
+    wr1 = p1.wgt.float().cpu()[:, :p1.K].reshape(128, 3, 3, 64).permute(0, 3, 1, 2)
+    wr2 = p2.wgt.float().cpu()[:, :p2.K].reshape(128, 3, 3, 128).permute(0, 3, 1, 2)
+    wrd = pd.wgt_rows.float().cpu()[:, :64].reshape(128, 64, 1, 1)
+    xr = rnd(x, dtype)
+    mid = rnd(F.relu(F.conv2d(xr, wr1, p1.bias.cpu(), stride=2, padding=1)), dtype)
+    ref = F.relu(F.conv2d(mid, wr2, p2.bias.cpu(), padding=1) + F.conv2d(xr, wrd, pd.bias.cpu(), stride=2))
+    check(y.permute(0, 3, 1, 2), ref, dtype, "fused down-sampling basicblock vs torch")
+    s = ref.abs().max().item()
+    assert (y.float() - y2.float()).abs().max().item() <= 1e-2 * s
+    # the host block takes the fused path for exactly this shape
+    ops.USE_DSBLOCK = False
+    try:
+        assert not ops.dsblock_fusable(xd, p1, p2, pd)
+    finally:
+        ops.USE_DSBLOCK = True
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv3x3_matches_generic_igemm(cuda, dtype):
     """same plan through both kernels (the generic implicit GEMM is the fallback for padded outputs / stride 2)"""
