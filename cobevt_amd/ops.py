@@ -517,7 +517,7 @@ def dsblock(x, plan1, plan2, plan_ds):
         px = n * (h // 2) * (w // 2)
         return 2.0 * px * 128 * (9 * 64 + 9 * 128 + 64), float(2 * (x.numel() + out.numel()) + 2 * 128 * (9 * 64 + 9 * 128 + 64))
 
-    with _timed("dsblock|%d->128 %dx%dx%d" % (c, n, h // 2, w // 2), cost):
+    with _timed("basicblock|%d->128/s2 %dx%dx%d" % (c, n, h // 2, w // 2), cost):
         rc = _L.load().cobevt_dsblock_nhwc(_p(x), _p(plan1.wfrag), _p(plan1.bias), _p(plan2.wfrag), _p(plan2.bias),
                                            _p(plan_ds.wfrag_rows), _p(plan_ds.bias), _p(out), dims, _stream())
     _L.check(rc, "cobevt_dsblock_nhwc")

@@ -12,7 +12,7 @@ import re
 import sqlite3
 import sys
 
-FAMILIES = [("conv3x3_strips_kernel", "conv3x3"), ("conv3x3_kernel", "conv3x3"), ("basicblock_kernel", "basicblock"),
+FAMILIES = [("conv3x3_strips_kernel", "conv3x3"), ("conv3x3_kernel", "conv3x3"), ("basicblock_kernel", "basicblock"), ("dsblock_kernel", "basicblock"),
             ("bottleneck_kernel", "bottleneck"), ("gemm_rows3_kernel", "gemm_rows"), ("gemm_rows_kernel", "gemm_rows"),
             ("gemm_rows2_kernel", "gemm_rows"), ("bev_query_kernel", "gemm_rows"), ("row_chain64_kernel", "row_chain"),
             ("proj_chain128_kernel", "row_chain"), ("row_chain_kernel", "row_chain"), ("swap_stage_kernel", "swap_stage"), ("attn_resident_kernel", "attention"),

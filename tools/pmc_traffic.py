@@ -8,7 +8,7 @@ import json
 import sqlite3
 import sys
 
-FAMILIES = [("conv3x3_strips_kernel", "conv3x3"), ("conv3x3_kernel", "conv3x3"), ("basicblock_kernel", "basicblock"),
+FAMILIES = [("conv3x3_strips_kernel", "conv3x3"), ("conv3x3_kernel", "conv3x3"), ("basicblock_kernel", "basicblock"), ("dsblock_kernel", "basicblock"),
             ("gemm_rows_kernel", "gemm_rows"), ("row_chain_kernel", "row_chain"), ("attn_gather_kernel", "attention"),
             ("igemm_kernel", "igemm"), ("stem7x7_kernel", "stem7x7"), ("stem_pool_kernel", "stem7x7")]
 
