@@ -52,6 +52,51 @@ def _rows_view(t, what):
 _LN2 = 0.6931471805599453
 
 
+# ----------------------------------------------------------------------------------------------
+# zero-initialised gradient buffers (atomically accumulated weight / bias / bias-table gradients): slices of one zero-filled chunk
+# instead of a fill launch each - a 5-agent step made ~490 such tensors, most of them a few KB (profiles/r03_train_amp_kernel_trace.txt).
+# A slice is handed out once; a chunk is freed when the tensors cut from it are.  Inside a HIP-graph capture only between
+# begin_capture_zero_pool() / end_capture_zero_pool() (host/train_graph.py), so that the chunk's fill is a node of THAT graph.
+# ----------------------------------------------------------------------------------------------
+USE_ZERO_POOL = True
+_ZERO_CHUNK_BYTES = 16 << 20
+_ZERO_POOL_MAX_BYTES = 1 << 20        # larger buffers keep their own fill
+_ZERO_POOL = {"eager": {}, "capture": None}
+
+
+def begin_capture_zero_pool():
+    _ZERO_POOL["capture"] = {}
+
+
+def end_capture_zero_pool():
+    _ZERO_POOL["capture"] = None
+
+
+def _zeros(shape, device, dtype):
+    shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)))
+    n = 1
+    for v in shape:
+        n *= v
+    nbytes = n * torch.empty((), dtype=dtype).element_size()
+    device = torch.device(device)
+    if not USE_ZERO_POOL or device.type != "cuda" or nbytes == 0 or nbytes > _ZERO_POOL_MAX_BYTES:
+        return torch.zeros(shape, device=device, dtype=dtype)
+    if torch.cuda.is_current_stream_capturing():
+        pool = _ZERO_POOL["capture"]
+        if pool is None:
+            return torch.zeros(shape, device=device, dtype=dtype)
+    else:
+        pool = _ZERO_POOL["eager"]
+    st = pool.get(device)
+    need = (nbytes + 255) // 256 * 256
+    if st is None or st[1] + need > st[0].numel():
+        st = [torch.zeros(_ZERO_CHUNK_BYTES, device=device, dtype=torch.uint8), 0]
+        pool[device] = st
+    out = st[0][st[1]:st[1] + nbytes].view(dtype).view(shape)
+    st[1] += need
+    return out
+
+
 class WindowAttentionFn(torch.autograd.Function):
     """out = softmax(scale q k^T + bias[rel(q, k)] + mask) v over the gathered windows (cobevt_window_attention_lse /
     cobevt_window_attention_bwd).  q (Rq, d), k, v (Rk, d) token matrices (views with a row stride are accepted), bias_table
@@ -95,10 +140,10 @@ class WindowAttentionFn(torch.autograd.Function):
         dout = _f32c(dout, "dout")
         dl = _f32c(dlse, "dlse") if (want_lse and dlse is not None) else None
         # dq is accumulated with atomics by the key tiles of a window; dk / dv rows are written once each
-        dq = torch.zeros((q.shape[0], d), device=q.device, dtype=torch.float32)
-        dk = torch.zeros((k.shape[0], d), device=q.device, dtype=torch.float32)
-        dv = torch.zeros((v.shape[0], d), device=q.device, dtype=torch.float32)
-        dbias = None if table is None else torch.zeros_like(table)
+        dq = _zeros((q.shape[0], d), q.device, torch.float32)
+        dk = _zeros((k.shape[0], d), q.device, torch.float32)
+        dv = _zeros((v.shape[0], d), q.device, torch.float32)
+        dbias = None if table is None else _zeros(table.shape, table.device, table.dtype)
         dims = _attn_dims(batch, heads, q.stride(0), k.stride(0), v.stride(0), d, table, bias_L, qmap, kmap, omap)
         # the gradient buffers are dense (ld = d) while q / k / v may be strided views: the kernel shares one ld per
         # operand between the tensor and its gradient, so strided operands are compacted first
@@ -170,8 +215,8 @@ class LayerNormFn(torch.autograd.Function):
         C = x.shape[-1]
         rows = x.numel() // C
         dx = torch.empty_like(x)
-        dg = torch.zeros(C, device=x.device, dtype=torch.float32)
-        db = torch.zeros(C, device=x.device, dtype=torch.float32)
+        dg = _zeros(C, x.device, torch.float32)
+        db = _zeros(C, x.device, torch.float32)
         rc = _L.load().cobevt_layernorm_bwd(_p(x), _p(dy), _p(g), _p(dx), _p(dg), _p(db), rows, C, ctypes.c_float(ctx.eps),
                                             _stream())
         _L.check(rc, "cobevt_layernorm_bwd")
@@ -359,6 +404,51 @@ def _igemm_rows(x, w2, cout, cin, kh, kw, bias, stride, pad, ho, wo):
     return out
 
 
+USE_TRAIN_STRIPS = True       # bf16 3x3 / pad-1 convolutions with 64 | Cin: forward and (stride 1) input gradient on the inference kernels
+
+
+def conv3_strips_plan(n, ho, wo, cin, cout, stride):
+    """tile choice of ops.conv2d for one bf16 3x3 launch: 0 = the LDS-staged kernel (reads `rows3`), else a strip variant (`frag`)"""
+    variant = ops.CONV3_VARIANT or ops.conv3_tiling(n, ho, wo, cin, cout, 64, stride=stride, bf16=True)
+    if variant == 0 and stride == 2:
+        variant = 151 if cout <= 64 else 150
+    return variant
+
+
+def conv3_weight_operand(weight, variant, dgrad):
+    """fp32 master weight (Cout, Cin, 3, 3) -> the bf16 operand that `variant` reads (csrc/train_prep.hip), for the forward convolution or
+    (dgrad) for its input gradient = the convolution with the channel roles swapped and the taps flipped.  Specification:
+    ops.ConvPlan(weight or weight.flip(2, 3).transpose(0, 1), ...).wfrag / .wgt3."""
+    cout, cin = weight.shape[:2]
+    o, i = (cin, cout) if dgrad else (cout, cin)
+    w = _f32c(weight.detach(), "weight")
+    if variant:
+        op = torch.empty(((o + 127) // 128 * 4, i // 64, 9, 4, 64, 8), device=w.device, dtype=torch.bfloat16)
+    else:
+        op = torch.empty((o, i // 64, 9, 64), device=w.device, dtype=torch.bfloat16)
+    _L.check(_L.load().cobevt_conv3_weight_operands(_p(w), _p(op) if variant else None, None if variant else _p(op),
+                                                    _ints([cout, cin, int(dgrad)]), _stream()), "cobevt_conv3_weight_operands")
+    return op
+
+
+def _conv3_strips(x, operand, variant, cout, bias, stride):
+    """x (N, H, W, Cin) bf16 channels-last -> (N, Ho, Wo, Cout) bf16: cobevt_conv3x3_wfrag_nhwc / cobevt_conv3x3_nhwc (csrc/conv3x3.hip) with
+    the operand conv3_weight_operand made for `variant`; bias fp32 (Cout,) | None"""
+    n, h, w, cin = x.shape
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    out = torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.bfloat16)
+    b = None if bias is None else _f32c(bias.detach().float(), "bias")
+    if variant:
+        dims = _ints([ops.BF16, n, h, w, cin, cout, 0, 0, 0, 64, (cout + 127) // 128 * 128, variant, stride])
+        rc = _L.load().cobevt_conv3x3_wfrag_nhwc(_p(x), _p(operand), _p(b), None, _p(out), dims, _stream())
+        _L.check(rc, "cobevt_conv3x3_wfrag_nhwc")
+    else:
+        dims = _ints([ops.BF16, n, h, w, cin, cout, 0, 0, 0, 64])
+        rc = _L.load().cobevt_conv3x3_nhwc(_p(x), _p(operand), _p(b), None, _p(out), dims, _stream())
+        _L.check(rc, "cobevt_conv3x3_nhwc")
+    return out
+
+
 USE_WGRAD_BLOCKED = True      # bf16: weight gradient on the bf16 matrix path (cobevt_conv_wgrad_blocked) where wgrad_blocked_mode() has a form for it
 USE_WGRAD_BLOCKED_STRIDED = True   # ... incl. the stride-2 and stem forms (modes 1 / 2); False: those stay on cobevt_conv_wgrad (A/B runs)
 
@@ -454,10 +544,26 @@ class Conv2dFn(torch.autograd.Function):
         n, h, w, _ = xl.shape
         cout, cin, kh, kw = weight.shape
         ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
-        rows_f, rows_d = conv_weight_rows(weight, xl.dtype, True, ctx.needs_input_grad[0])
-        out = _igemm_rows(xl, rows_f, cout, cin, kh, kw, bias, stride, pad, ho, wo)
+        strips = (USE_TRAIN_STRIPS and xl.dtype == torch.bfloat16 and kh == 3 and kw == 3 and pad == 1 and stride in (1, 2) and cin % 64 == 0
+                  and cout % 8 == 0 and xl.numel() < 2 ** 31)
+        # the input gradient of a stride-1 convolution is a 3x3 / pad-1 convolution again (Cout -> Cin channels)
+        strips_d = USE_TRAIN_STRIPS and xl.dtype == torch.bfloat16 and kh == 3 and kw == 3 and pad == 1 and stride == 1 and cout % 64 == 0 \
+            and cin % 8 == 0 and n * h * w * cout < 2 ** 31
+        need_d = ctx.needs_input_grad[0]
+        var_d = conv3_strips_plan(n, h, w, cout, cin, 1) if (strips_d and need_d) else -1
+        if strips:
+            var_f = conv3_strips_plan(n, ho, wo, cin, cout, stride)
+            out = _conv3_strips(xl, conv3_weight_operand(weight, var_f, False), var_f, cout, bias, stride)
+            rows_d = conv3_weight_operand(weight, var_d, True) if var_d >= 0 else \
+                conv_weight_rows(weight, xl.dtype, False, need_d)[1]
+        else:
+            rows_f, rows_d = conv_weight_rows(weight, xl.dtype, True, need_d and var_d < 0)
+            out = _igemm_rows(xl, rows_f, cout, cin, kh, kw, bias, stride, pad, ho, wo)
+            if var_d >= 0:
+                rows_d = conv3_weight_operand(weight, var_d, True)
         ctx.save_for_backward(xl, rows_d)
         ctx.cfg = (stride, pad, bias is not None, tuple(weight.shape))
+        ctx.var_d = var_d
         ctx.bias_dtype = None if bias is None else bias.dtype
         return out.permute(0, 3, 1, 2)
 
@@ -475,9 +581,12 @@ class Conv2dFn(torch.autograd.Function):
             if stride > 1:                       # zero-stuffed gradient map: dgrad of a strided conv = stride-1 conv on it
                 g = torch.zeros((n, (ho - 1) * stride + 1, (wo - 1) * stride + 1, cout), device=dyl.device, dtype=dyl.dtype)
                 g[:, ::stride, ::stride] = dyl
-            dx = _igemm_rows(g, rows_d, cin, cout, kh, kw, None, 1, kh - 1 - pad, h, w).permute(0, 3, 1, 2)
+            if ctx.var_d >= 0:
+                dx = _conv3_strips(g, rows_d, ctx.var_d, cin, None, 1).permute(0, 3, 1, 2)
+            else:
+                dx = _igemm_rows(g, rows_d, cin, cout, kh, kw, None, 1, kh - 1 - pad, h, w).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros((cout, cin, kh, kw), device=dyl.device, dtype=torch.float32)
+            dw = _zeros((cout, cin, kh, kw), dyl.device, torch.float32)
             mode = wgrad_blocked_mode(kh, stride, pad, cin) if (USE_WGRAD_BLOCKED and xl.dtype == torch.bfloat16 and kh == kw) else None
             if mode is not None and not USE_WGRAD_BLOCKED_STRIDED and mode != 0:
                 mode = None
@@ -809,7 +918,7 @@ class DepthwiseConvFn(torch.autograd.Function):
             raise CobevtHipError("training depthwise conv: (C, 1, k, k) weight with k = 3 / 5 and a multiple of 8 channels")
         ho, wo = (h + pad[0] + pad[1] - k) // stride + 1, (w + pad[0] + pad[1] - k) // stride + 1
         taps = weight.detach().float()[:, 0].permute(1, 2, 0).reshape(k * k, c).contiguous()          # [tap][C]
-        zero = torch.zeros(c, device=xl.device, dtype=torch.float32)
+        zero = _zeros(c, xl.device, torch.float32)
         out = torch.empty((n, ho, wo, c), device=xl.device, dtype=xl.dtype)
         dims = _ints([ops.dcode(xl.dtype), n, h, w, c, k, stride, pad[0], pad[0], ho, wo, 0])
         _L.check(_L.load().cobevt_depthwise_conv_nhwc(_p(xl), _p(taps), _p(zero), _p(out), dims, _stream()), "cobevt_depthwise_conv_nhwc")
@@ -840,7 +949,7 @@ class DepthwiseConvFn(torch.autograd.Function):
             _L.check(lib.cobevt_depthwise_conv_nhwc(_p(g), _p(flipped), _p(zero), _p(dx), dims, _stream()), "cobevt_depthwise_conv_nhwc")
             dx = dx.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            dwt = torch.zeros((k * k, c), device=xl.device, dtype=torch.float32)
+            dwt = _zeros((k * k, c), xl.device, torch.float32)
             dims = _ints([ops.dcode(xl.dtype), n, h, w, c, k, stride, pad[0], pad[0], ho, wo])
             _L.check(lib.cobevt_depthwise_wgrad(_p(xl), _p(dyl), _p(dwt), dims, _stream()), "cobevt_depthwise_wgrad")
             dw = dwt.reshape(k, k, c).permute(2, 0, 1)[:, None].contiguous().to(wdt)

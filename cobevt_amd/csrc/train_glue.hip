@@ -140,6 +140,48 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const T* __restrict_
     store8<T>(y + gid * 8, v);
 }
 
+// The same with the workgroup count fixed and every thread walking pieces gid, gid + T, ... (T = all threads, a multiple of the channel
+// groups G, so a thread stays on ONE 8-channel group and holds its 16 coefficients in registers).  The piece-per-thread form above
+// issues 16 four-byte coefficient loads beside its two or three 16-byte data loads: the texture-address path, not HBM, set its time
+// (5 x the streaming bound on the 5-agent encoder maps).  Four pieces in flight per thread.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_apply_walk_kernel(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, T* __restrict__ y, long items, int C, int act) {
+    const int G = C >> 3;
+    const long step = (long)gridDim.x * kThreads;
+    long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+    const int gl = (int)(gid % G);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = scale[gl * 8 + e]; sh[e] = shift[gl * 8 + e]; }
+    auto finish = [&](float* v, const float* r) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = fmaf(v[e], sc[e], sh[e]);
+            if (res) t += r[e];
+            v[e] = act == 1 ? fmaxf(t, 0.f) : t;
+        }
+    };
+    for (; gid + 3 * step < items; gid += 4 * step) {
+        float v[4][8], r[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load8<T>(x + (gid + u * step) * 8, v[u]);
+        if (res) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load8<T>(res + (gid + u * step) * 8, r[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { finish(v[u], r[u]); store8<T>(y + (gid + u * step) * 8, v[u]); }
+    }
+    for (; gid < items; gid += step) {
+        float v[8], r[8];
+        load8<T>(x + gid * 8, v);
+        if (res) load8<T>(res + gid * 8, r);
+        finish(v, r);
+        store8<T>(y + gid * 8, v);
+    }
+}
+
 // ---- backward, pass 1: g = dy * [y > 0] ; dbeta[c] += g ; dgamma[c] += g * xhat, xhat = (x - mean) * rstd
 template <typename T>
 __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
@@ -219,6 +261,67 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const T* __restr
     }
     store8<T>(dx + gid * 8, o);
     if (dres) store8<T>(dres + gid * 8, gv);
+}
+
+// bn_bwd_apply_kernel as a walk (see bn_apply_walk_kernel): the 8 channels' k = gamma rstd, mean, rstd, dbeta, dgamma in registers; the
+// arithmetic per element is unchanged.  Two pieces in flight (three or four 16-byte streams each).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_walk_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
+                                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                     const float* __restrict__ gamma, const double* __restrict__ dgamma,
+                                                                     const double* __restrict__ dbeta, T* __restrict__ dx, T* __restrict__ dres,
+                                                                     long items, int C, float inv_rows, int act, int training) {
+    const int G = C >> 3;
+    const long step = (long)gridDim.x * kThreads;
+    long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+    const int gl = (int)(gid % G);
+    float k[8], mu[8], rs[8], db[8], dg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = gl * 8 + e;
+        rs[e] = rstd[c];
+        mu[e] = mean[c];
+        k[e] = (gamma ? gamma[c] : 1.f) * rs[e];
+        db[e] = training ? (float)dbeta[c] : 0.f;
+        dg[e] = training ? (float)dgamma[c] : 0.f;
+    }
+    auto finish = [&](const float* xv, float* gv, const float* yv, float* o) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float g = (act == 1 && !(yv[e] > 0.f)) ? 0.f : gv[e];
+            gv[e] = g;
+            if (training) {
+                const float xhat = (xv[e] - mu[e]) * rs[e];
+                o[e] = k[e] * (g - (db[e] + xhat * dg[e]) * inv_rows);
+            } else {
+                o[e] = k[e] * g;
+            }
+        }
+    };
+    for (; gid + step < items; gid += 2 * step) {
+        float xv[2][8], gv[2][8], yv[2][8], o[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            load8<T>(x + (gid + u * step) * 8, xv[u]);
+            load8<T>(dy + (gid + u * step) * 8, gv[u]);
+            if (act == 1) load8<T>(y + (gid + u * step) * 8, yv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            finish(xv[u], gv[u], yv[u], o[u]);
+            store8<T>(dx + (gid + u * step) * 8, o[u]);
+            if (dres) store8<T>(dres + (gid + u * step) * 8, gv[u]);
+        }
+    }
+    for (; gid < items; gid += step) {
+        float xv[8], gv[8], yv[8], o[8];
+        load8<T>(x + gid * 8, xv);
+        load8<T>(dy + gid * 8, gv);
+        if (act == 1) load8<T>(y + gid * 8, yv);
+        finish(xv, gv, yv, o);
+        store8<T>(dx + gid * 8, o);
+        if (dres) store8<T>(dres + gid * 8, gv);
+    }
 }
 
 // ---- MaxPool2d(3, stride 2, padding 1) backward as a GATHER: an input pixel lies in at most 2 x 2 pooling windows; for each of
@@ -404,6 +507,12 @@ inline int row_blocks(long rows, int C, int* rows_per_block, int cap = 1024) {
     return (int)((rows + *rows_per_block - 1) / *rows_per_block);
 }
 
+// workgroups of a walking kernel: about `per_thread` pieces per thread per round, at most 8 workgroups of 256 per CU
+inline unsigned walk_blocks(long items, int per_thread) {
+    long b = (items + (long)kThreads * per_thread - 1) / ((long)kThreads * per_thread);
+    return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
 }  // namespace
 }  // namespace cobevt
 
@@ -471,6 +580,13 @@ extern "C" int cobevt_bn_apply(const void* x, const void* residual, const float*
     if (!x || !scale || !shift || !y) return COBEVT_ERR_ARG;
     if (C < 8 || C % 8 || rows < 1 || act < 0 || act > 1) return COBEVT_ERR_SHAPE;
     const long items = rows * (C >> 3);
+    if (kThreads % (C >> 3) == 0 && items >= 4L * kThreads) {          // a thread keeps one channel group: coefficients in registers
+        const dim3 wgrid(walk_blocks(items, 4));
+        if (dtype == 0) hipLaunchKernelGGL(bn_apply_walk_kernel<bf16_t>, wgrid, dim3(kThreads), 0, stream, (const bf16_t*)x, (const bf16_t*)residual, scale, shift, (bf16_t*)y, items, C, act);
+        else if (dtype == 1) hipLaunchKernelGGL(bn_apply_walk_kernel<float>, wgrid, dim3(kThreads), 0, stream, (const float*)x, (const float*)residual, scale, shift, (float*)y, items, C, act);
+        else return COBEVT_ERR_ARG;
+        return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+    }
     const dim3 grid((unsigned)((items + kThreads - 1) / kThreads));
     if (dtype == 0) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(kThreads), 0, stream, (const bf16_t*)x, (const bf16_t*)residual, scale, shift, (bf16_t*)y, items, C, act);
     else if (dtype == 1) hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(kThreads), 0, stream, (const float*)x, (const float*)residual, scale, shift, (float*)y, items, C, act);
@@ -492,6 +608,20 @@ extern "C" int cobevt_bn_backward(const void* x, const void* y, const void* dy, 
     const float inv_rows = 1.0f / (float)rows;
     double* dgamma = dgamma_dbeta;
     double* dbeta = dgamma_dbeta + C;
+    const bool walk = kThreads % (C >> 3) == 0 && items >= 4L * kThreads;
+    const dim3 wgrid(walk_blocks(items, 2));
+    if (walk && (dtype == 0 || dtype == 1)) {
+        if (dtype == 0) {
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(kThreads), 0, stream, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, mean, rstd, scratch, rows, C, act, rpb);
+            hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, stream, scratch, blocks, 2 * C, 2 * C, dgamma_dbeta, grads_f);
+            hipLaunchKernelGGL(bn_bwd_apply_walk_kernel<bf16_t>, wgrid, dim3(kThreads), 0, stream, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, mean, rstd, gamma, dgamma, dbeta, (bf16_t*)dx, (bf16_t*)dres, items, C, inv_rows, act, training);
+        } else {
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(kThreads), 0, stream, (const float*)x, (const float*)y, (const float*)dy, mean, rstd, scratch, rows, C, act, rpb);
+            hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, stream, scratch, blocks, 2 * C, 2 * C, dgamma_dbeta, grads_f);
+            hipLaunchKernelGGL(bn_bwd_apply_walk_kernel<float>, wgrid, dim3(kThreads), 0, stream, (const float*)x, (const float*)y, (const float*)dy, mean, rstd, gamma, dgamma, dbeta, (float*)dx, (float*)dres, items, C, inv_rows, act, training);
+        }
+        return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+    }
     if (dtype == 0) {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(kThreads), 0, stream, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, mean, rstd, scratch, rows, C, act, rpb);
         hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, stream, scratch, blocks, 2 * C, 2 * C, dgamma_dbeta, grads_f);

@@ -43,6 +43,51 @@ __global__ __launch_bounds__(kThreads) void conv_weight_rows_kernel(const float*
     }
 }
 
+// ---- 3x3 convolutions on the inference kernels (conv3x3.hip): the master weight -> the two bf16 layouts those kernels read, for the
+// forward pass (O = Cout, I = Cin, value w[O][I][tap]) or for the input gradient (the same convolution with the channel roles swapped and
+// the taps flipped: O = Cin, I = Cout, value w[I][O][8 - tap]).
+//   frag:  [Op/32][I/64][9 taps][4 k-groups][2 halves][32][8]  (ops.ConvPlan.wfrag: MFMA B fragments, Op = O rounded up to 128, zero rows)
+//   rows3: [O][I/64][9 taps][64]                               (ops.ConvPlan.wgt3: the LDS-staged kernel's rows)
+// One thread per 16-byte piece; pieces [0, nfrag) then [nfrag, nfrag + nrows).
+__global__ __launch_bounds__(kThreads) void conv3_weight_operands_kernel(const float* __restrict__ w, uint4* __restrict__ frag, uint4* __restrict__ rows3,
+                                                                         int O, int I, int Cin_w, int dgrad, long nfrag, long nrows) {
+    long i = (long)blockIdx.x * kThreads + threadIdx.x;
+    int o, i0, tap;
+    uint4* dst;
+    if (i < nfrag) {
+        dst = frag + i;
+        const int n = (int)(i & 31), half = (int)((i >> 5) & 1), kg = (int)((i >> 6) & 3);
+        long t = i >> 8;
+        tap = (int)(t % 9);
+        t /= 9;
+        const int chunks = I >> 6;
+        const int chunk = (int)(t % chunks), ct = (int)(t / chunks);
+        o = ct * 32 + n;
+        i0 = chunk * 64 + kg * 16 + half * 8;
+    } else if (i - nfrag < nrows) {
+        i -= nfrag;
+        dst = rows3 + i;
+        const int j = (int)(i & 7);
+        long t = i >> 3;
+        tap = (int)(t % 9);
+        t /= 9;
+        const int chunks = I >> 6;
+        const int chunk = (int)(t % chunks);
+        o = (int)(t / chunks);
+        i0 = chunk * 64 + j * 8;
+    } else {
+        return;
+    }
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        // w is (Cout, Cin_w, 3, 3): forward w[o][i0 + e][tap], input gradient w[i0 + e][o][8 - tap]
+        const long idx = dgrad ? (((long)(i0 + e) * Cin_w + o) * 9 + (8 - tap)) : (((long)o * Cin_w + (i0 + e)) * 9 + tap);
+        v[e] = o < O ? w[idx] : 0.f;
+    }
+    *dst = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+}
+
 // one thread = (n, padded row, block, 8-channel group): 8 pixels x 8 channels in, 8 channels x 8 pixels out
 __global__ __launch_bounds__(kThreads) void wgrad_block8_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, long items,
                                                                 int H, int W, int C, int Hp, int NB, int pt, int pl, int P, int sx) {
@@ -129,6 +174,22 @@ extern "C" int cobevt_conv_weight_rows(const float* w, void* rows_fwd, void* row
     if (dtype == 0) hipLaunchKernelGGL(conv_weight_rows_kernel<bf16_t>, grid, dim3(kThreads), 0, stream, w, (bf16_t*)rows_fwd, (bf16_t*)rows_dgrad, Cout, Cin, kh, kw, kpf, kpd);
     else if (dtype == 1) hipLaunchKernelGGL(conv_weight_rows_kernel<float>, grid, dim3(kThreads), 0, stream, w, (float*)rows_fwd, (float*)rows_dgrad, Cout, Cin, kh, kw, kpf, kpd);
     else return COBEVT_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+extern "C" int cobevt_conv3_weight_operands(const float* w, void* frag, void* rows3, const int* dims, hipStream_t stream) {
+    // dims: [Cout, Cin, dgrad]; bf16 outputs (either nullable).  Forward: O = Cout, I = Cin; input gradient: O = Cin, I = Cout.
+    if (!w || !dims || (!frag && !rows3)) return COBEVT_ERR_ARG;
+    const int Cout = dims[0], Cin = dims[1], dgrad = dims[2];
+    if (Cout < 1 || Cin < 1 || (dgrad != 0 && dgrad != 1)) return COBEVT_ERR_SHAPE;
+    const int O = dgrad ? Cin : Cout, I = dgrad ? Cout : Cin;
+    if (I % 64 != 0) return COBEVT_ERR_SHAPE;
+    const int Op = (O + 127) / 128 * 128;
+    const long nfrag = frag ? (long)Op * I * 9 / 8 : 0, nrows = rows3 ? (long)O * I * 9 / 8 : 0;
+    const long total = nfrag + nrows;
+    if (total > 0x7fffffffL * (long)kThreads) return COBEVT_ERR_SHAPE;
+    hipLaunchKernelGGL(conv3_weight_operands_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, w,
+                       (uint4*)frag, (uint4*)rows3, O, I, Cin, dgrad, nfrag, nrows);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 

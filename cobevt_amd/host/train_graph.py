@@ -114,6 +114,13 @@ class CapturedTrainStep(object):
     def _capture(self):
         dev = self.device
         step_word = ag.dropout_step(dev)
+        ag.begin_capture_zero_pool()          # zero-initialised gradient buffers: slices of chunks whose fills are nodes of these graphs
+        try:
+            self._capture_graphs(step_word)
+        finally:
+            ag.end_capture_zero_pool()
+
+    def _capture_graphs(self, step_word):
         if self.reducer is None:
             g = torch.cuda.CUDAGraph()
             with torch.enable_grad(), torch.cuda.graph(g, stream=self._stream):

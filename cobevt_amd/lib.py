@@ -99,6 +99,7 @@ SIGNATURES = {
     "cobevt_upsample_nearest2_nhwc": (ctypes.c_int, [_vp, _vp] + [ctypes.c_int] * 6 + [_vp]),
     "cobevt_sttf_warp_bwd": (ctypes.c_int, [_vp, _vp, _vp, _vp] + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_float, _vp]),
     "cobevt_conv_weight_rows": (ctypes.c_int, [_vp, _vp, _vp, _c_int_p, _vp]),
+    "cobevt_conv3_weight_operands": (ctypes.c_int, [_vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_wgrad_block_operand": (ctypes.c_int, [_vp, _vp, _c_int_p, _vp]),
     "cobevt_swish": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_long, _vp]),
     "cobevt_depthwise_wgrad": (ctypes.c_int, [_vp, _vp, _vp, _c_int_p, _vp]),

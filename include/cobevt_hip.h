@@ -533,6 +533,14 @@ int cobevt_sttf_warp_bwd(const float* dout, const float* tmat, const int* record
  * convolution, taps flipped, channel roles swapped); columns past K are zero; either output may be null.
  * dims: [dtype, Cout, Cin, kh, kw, Kpad_fwd, Kpad_dgrad]. */
 int cobevt_conv_weight_rows(const float* w, void* rows_fwd, void* rows_dgrad, const int* dims, hipStream_t stream);
+/*
+ * The same for a 3x3 / pad-1 convolution with 64 | channel counts that runs on the inference kernels in training (bf16): the fp32
+ * master weight (Cout, Cin, 3, 3) -> `frag` (cobevt_conv3x3_wfrag_nhwc's fragment table, [Op/32][I/64][9][4][64 lanes][8], Op = O
+ * rounded up to 128) and / or `rows3` (cobevt_conv3x3_nhwc's [O][I/64][9][64]); either nullable.  dims (int32[3]): Cout, Cin, dgrad.
+ * dgrad = 0: the forward convolution (O = Cout, I = Cin); dgrad = 1: its input gradient, i.e. the convolution with the channel
+ * roles swapped and the taps flipped (O = Cin, I = Cout) - what cuDNN's backward-data does under train_camera.py:143-179.
+ */
+int cobevt_conv3_weight_operands(const float* w, void* frag, void* rows3, const int* dims, hipStream_t stream);
 /* bf16 channels-last map (N, H, W, C) -> the blocked operand of cobevt_conv_wgrad_blocked, dst [N][Hp][NB][C][8]: pixel x of input
  * row y sits in block (x + pad_left) / 8 of row y + pad_top; everything else is zero.  In general dst is [N][Hp][NB][P][C][8] and slot j
  * of plane q of block b holds input pixel sx (8 b + j) + q - pad_left (P = 1, sx = 1 above; P = 2, sx = 2: even / odd columns of a

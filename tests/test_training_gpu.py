@@ -339,7 +339,12 @@ def test_conv2d_forward_backward_vs_torch(cuda, cin, cout, k, stride, pad, h, w,
 
 @pytest.mark.parametrize("cin,cout,k,stride,pad,h,w,bias", [
     (64, 64, 3, 1, 1, 12, 20, False), (64, 128, 3, 2, 1, 16, 16, False), (64, 128, 1, 2, 0, 16, 16, False), (3, 64, 7, 2, 3, 32, 32, False),
-    (32, 2, 3, 1, 1, 9, 11, True), (128, 32, 1, 1, 0, 8, 8, True), (24, 40, 3, 2, 1, 15, 13, True)])
+    (32, 2, 3, 1, 1, 9, 11, True), (128, 32, 1, 1, 0, 8, 8, True), (24, 40, 3, 2, 1, 15, 13, True),
+    # 3x3 / pad 1 with 64 | Cin: forward (and, stride 1 with 64 | Cout, the input gradient) on the inference strip kernels - a biased
+    # 128 -> 64, the 32-cout four-wave tiles, 256 / 512 channels, a stride-2 whose input gradient stays on the implicit GEMM, a
+    # 64 -> 72 whose input gradient does (Cout off 64), and a map large enough for the LDS-staged kernel (variant 0) both ways
+    (128, 64, 3, 1, 1, 20, 36, True), (64, 32, 3, 1, 1, 16, 48, False), (256, 256, 3, 1, 1, 8, 8, False), (512, 512, 3, 1, 1, 6, 10, False),
+    (128, 256, 3, 2, 1, 18, 30, True), (64, 72, 3, 1, 1, 10, 16, False), (64, 64, 3, 1, 1, 256, 256, False)])
 def test_conv2d_bf16_autocast_forward_backward_vs_torch(cuda, cin, cout, k, stride, pad, h, w, bias):
     """inside a bf16 autocast region the training conv runs on the bf16 implicit-GEMM kernel in forward and input gradient (the
     gather path for channel counts off the 16-byte chunk, incl. the 2-channel head whose input gradient has 2 'input' channels) and
@@ -800,6 +805,46 @@ def test_conv_weight_rows_kernel_matches_torch_specification(cuda, dtype, cout, 
     assert torch.equal(rf, sf) and torch.equal(rd, sd)
     only_f = ag.conv_weight_rows(w, dtype, True, False)
     assert only_f[1] is None and torch.equal(only_f[0], sf)
+
+
+@pytest.mark.parametrize("cout,cin", [(128, 64), (64, 128), (72, 64), (32, 192), (512, 256)])
+def test_conv3_weight_operand_kernel_matches_plan_layouts(cuda, cout, cin):
+    """cobevt_conv3_weight_operands (fp32 master weight -> the bf16 fragment table / LDS-staged rows the inference 3x3 kernels read, for the
+    forward convolution and for its input gradient = flipped taps, swapped channel roles) is bit-identical to ops.ConvPlan's tables"""
+    from cobevt_amd import ops
+    g = torch.Generator().manual_seed(cout * 7 + cin)
+    w = torch.randn(cout, cin, 3, 3, generator=g)
+    wd = w.to(cuda)
+    plan = ops.ConvPlan(w, None, stride=1, pad=1, act=0, dtype=torch.bfloat16, device=cuda)
+    assert torch.equal(ag.conv3_weight_operand(wd, 150, False).reshape(-1), plan.wfrag.reshape(-1))
+    assert torch.equal(ag.conv3_weight_operand(wd, 0, False).reshape(-1), plan.wgt3.reshape(-1))
+    if cout % 64 == 0:
+        pland = ops.ConvPlan(w.flip(2, 3).transpose(0, 1).contiguous(), None, stride=1, pad=1, act=0, dtype=torch.bfloat16, device=cuda)
+        assert torch.equal(ag.conv3_weight_operand(wd, 143, True).reshape(-1), pland.wfrag.reshape(-1))
+        assert torch.equal(ag.conv3_weight_operand(wd, 0, True).reshape(-1), pland.wgt3.reshape(-1))
+
+
+def test_zero_pool_hands_out_disjoint_zeroed_slices(cuda):
+    """autograd._zeros: small gradient buffers are slices of one zero-filled chunk (one fill launch per 16 MiB instead of one per tensor):
+    zero, disjoint, handed out once, 256-byte aligned; large ones and captures outside begin/end_capture_zero_pool() keep their own fill"""
+    a = ag._zeros((3, 5), cuda, torch.float32)
+    b = ag._zeros(7, cuda, torch.float32)
+    c = ag._zeros((2, 4), cuda, torch.bfloat16)
+    assert a.shape == (3, 5) and b.shape == (7,) and c.dtype == torch.bfloat16
+    assert not a.any() and not b.any() and not c.any()
+    ptrs = sorted([(t.data_ptr(), t.numel() * t.element_size()) for t in (a, b, c)])
+    assert all(p0 + n0 <= p1 for (p0, n0), (p1, _) in zip(ptrs, ptrs[1:])) and all(p % 256 == 0 for p, _ in ptrs)
+    assert a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() == c.untyped_storage().data_ptr()
+    a.add_(1.0)
+    assert not ag._zeros((3, 5), cuda, torch.float32).any()
+    big = ag._zeros((1 << 20) + 1, cuda, torch.float32)
+    assert big.untyped_storage().data_ptr() != a.untyped_storage().data_ptr() and not big.any()
+    ag.USE_ZERO_POOL = False
+    try:
+        d = ag._zeros(5, cuda, torch.float32)
+        assert d.untyped_storage().nbytes() < 4096
+    finally:
+        ag.USE_ZERO_POOL = True
 
 
 @pytest.mark.parametrize("k,pad,n,cin,cout,h,w", [(3, 1, 2, 64, 128, 6, 11), (1, 0, 1, 8, 16, 4, 16), (3, 1, 2, 5, 2, 7, 21), (1, 0, 3, 12, 24, 5, 9),
