@@ -404,6 +404,7 @@ def _igemm_rows(x, w2, cout, cin, kh, kw, bias, stride, pad, ho, wo):
     return out
 
 
+USE_WGRAD3 = True             # bf16 3x3 / stride-1 weight gradients straight from the channels-last maps (csrc/wgrad3.hip)
 USE_TRAIN_STRIPS = True       # bf16 3x3 / pad-1 convolutions with 64 | Cin: forward and (stride 1) input gradient on the inference kernels
 
 
@@ -585,7 +586,16 @@ class Conv2dFn(torch.autograd.Function):
                 dx = _conv3_strips(g, rows_d, ctx.var_d, cin, None, 1).permute(0, 3, 1, 2)
             else:
                 dx = _igemm_rows(g, rows_d, cin, cout, kh, kw, None, 1, kh - 1 - pad, h, w).permute(0, 3, 1, 2)
-        if ctx.needs_input_grad[1]:
+        chunks3 = -1
+        if ctx.needs_input_grad[1] and USE_WGRAD3 and xl.dtype == torch.bfloat16 and kh == 3 and kw == 3 and stride == 1 and pad == 1:
+            chunks3 = _L.load().cobevt_conv_wgrad3_chunks(_ints([n, h, w, cin, cout]))
+        if chunks3 > 0:
+            # straight from the channels-last maps (csrc/wgrad3.hip): dw is written, partial sums in a scratch buffer
+            dw = torch.empty((cout, cin, kh, kw), device=dyl.device, dtype=torch.float32)
+            scratch = torch.empty((chunks3, cout * cin * 9), device=dyl.device, dtype=torch.float32)
+            rc = _L.load().cobevt_conv_wgrad3(_p(xl), _p(dyl), _p(dw), _p(scratch), _ints([n, h, w, cin, cout, chunks3]), _stream())
+            _L.check(rc, "cobevt_conv_wgrad3")
+        elif ctx.needs_input_grad[1]:
             dw = _zeros((cout, cin, kh, kw), dyl.device, torch.float32)
             mode = wgrad_blocked_mode(kh, stride, pad, cin) if (USE_WGRAD_BLOCKED and xl.dtype == torch.bfloat16 and kh == kw) else None
             if mode is not None and not USE_WGRAD_BLOCKED_STRIDED and mode != 0:

@@ -541,6 +541,17 @@ int cobevt_conv_weight_rows(const float* w, void* rows_fwd, void* rows_dgrad, co
  * roles swapped and the taps flipped (O = Cin, I = Cout) - what cuDNN's backward-data does under train_camera.py:143-179.
  */
 int cobevt_conv3_weight_operands(const float* w, void* frag, void* rows3, const int* dims, hipStream_t stream);
+/*
+ * Weight gradient of a 3x3 / stride-1 / pad-1 convolution from the channels-last bf16 maps themselves (csrc/wgrad3.hip: the
+ * pixel-major operands of the matrix instruction come out of LDS through ds_read_b64_tr_b16, no blocked copies, no atomics):
+ * dw (Cout, Cin, 3, 3) fp32 is WRITTEN (not accumulated).  x (N, H, W, Cin), dy (N, H, W, Cout) bf16, 32 | Cin, 32 | Cout, 16 | W.
+ * cobevt_conv_wgrad3_chunks(dims[5]: N, H, W, Cin, Cout) returns the number of partial copies of dw the launch writes (scratch must hold
+ * that many x Cout * Cin * 9 floats), or minus an error code when the shape is not served (the caller then takes
+ * cobevt_conv_wgrad_blocked); cobevt_conv_wgrad3 takes dims (int32[6]): N, H, W, Cin, Cout, that chunk count.
+ * cuDNN's backward-filter under train_camera.py:143-179.
+ */
+int cobevt_conv_wgrad3_chunks(const int* dims);
+int cobevt_conv_wgrad3(const void* x, const void* dy, float* dw, float* scratch, const int* dims, hipStream_t stream);
 /* bf16 channels-last map (N, H, W, C) -> the blocked operand of cobevt_conv_wgrad_blocked, dst [N][Hp][NB][C][8]: pixel x of input
  * row y sits in block (x + pad_left) / 8 of row y + pad_top; everything else is zero.  In general dst is [N][Hp][NB][P][C][8] and slot j
  * of plane q of block b holds input pixel sx (8 b + j) + q - pad_left (P = 1, sx = 1 above; P = 2, sx = 2: even / odd columns of a

@@ -344,7 +344,11 @@ def test_conv2d_forward_backward_vs_torch(cuda, cin, cout, k, stride, pad, h, w,
     # 128 -> 64, the 32-cout four-wave tiles, 256 / 512 channels, a stride-2 whose input gradient stays on the implicit GEMM, a
     # 64 -> 72 whose input gradient does (Cout off 64), and a map large enough for the LDS-staged kernel (variant 0) both ways
     (128, 64, 3, 1, 1, 20, 36, True), (64, 32, 3, 1, 1, 16, 48, False), (256, 256, 3, 1, 1, 8, 8, False), (512, 512, 3, 1, 1, 6, 10, False),
-    (128, 256, 3, 2, 1, 18, 30, True), (64, 72, 3, 1, 1, 10, 16, False), (64, 64, 3, 1, 1, 256, 256, False)])
+    (128, 256, 3, 2, 1, 18, 30, True), (64, 72, 3, 1, 1, 10, 16, False), (64, 64, 3, 1, 1, 256, 256, False),
+    # 16 | W with 32 | channel counts: the weight gradient straight from the channels-last maps (csrc/wgrad3.hip) - 16- and 32-pixel
+    # segments, several segments per row, odd heights, fewer rows than waves
+    (128, 128, 3, 1, 1, 32, 32, False), (256, 64, 3, 1, 1, 16, 16, True), (64, 128, 3, 1, 1, 9, 64, False), (32, 32, 3, 1, 1, 5, 16, False),
+    (32, 96, 3, 1, 1, 1, 48, False), (512, 512, 3, 1, 1, 16, 16, False)])
 def test_conv2d_bf16_autocast_forward_backward_vs_torch(cuda, cin, cout, k, stride, pad, h, w, bias):
     """inside a bf16 autocast region the training conv runs on the bf16 implicit-GEMM kernel in forward and input gradient (the
     gather path for channel counts off the 16-byte chunk, incl. the 2-channel head whose input gradient has 2 'input' channels) and
@@ -824,6 +828,31 @@ def test_conv3_weight_operand_kernel_matches_plan_layouts(cuda, cout, cin):
         assert torch.equal(ag.conv3_weight_operand(wd, 0, True).reshape(-1), pland.wgt3.reshape(-1))
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout", [(3, 7, 32, 64, 32), (1, 4, 16, 32, 64), (2, 33, 128, 64, 64), (20, 16, 16, 128, 96)])
+def test_conv_wgrad3_matches_blocked_weight_gradient(cuda, n, h, w, cin, cout):
+    """cobevt_conv_wgrad3 (operands transposed by the LDS read, partial tiles summed by a second launch: deterministic) against fp64 torch on
+    the same bf16 operands at fp32 rounding level, and bit-identical between two runs"""
+    g = torch.Generator().manual_seed(n * 1000 + w)
+    x = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16).to(cuda)
+    dy = torch.randn(n, h, w, cout, generator=g).to(torch.bfloat16).to(cuda)
+    lib = ag._L.load()
+    chunks = lib.cobevt_conv_wgrad3_chunks(ag._ints([n, h, w, cin, cout]))
+    assert chunks >= 1
+    outs = []
+    for _ in range(2):
+        dw = torch.full((cout, cin, 3, 3), float("nan"), device=cuda)
+        scratch = torch.empty((chunks, cout * cin * 9), device=cuda)
+        ag._L.check(lib.cobevt_conv_wgrad3(ag._p(x), ag._p(dy), ag._p(dw), ag._p(scratch), ag._ints([n, h, w, cin, cout, chunks]), ag._stream()),
+                    "cobevt_conv_wgrad3")
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.nn.grad.conv2d_weight(x.double().permute(0, 3, 1, 2), (cout, cin, 3, 3), dy.double().permute(0, 3, 1, 2), padding=1)
+    assert_close(outs[0], ref.float(), 2e-5, "wgrad3 vs fp64 torch")
+    # shapes it does not serve are refused, not mangled
+    assert lib.cobevt_conv_wgrad3_chunks(ag._ints([n, h, w + 8, cin, cout])) < 0
+    assert lib.cobevt_conv_wgrad3_chunks(ag._ints([n, h, w, cin + 8, cout])) < 0
+
+
 def test_zero_pool_hands_out_disjoint_zeroed_slices(cuda):
     """autograd._zeros: small gradient buffers are slices of one zero-filled chunk (one fill launch per 16 MiB instead of one per tensor):
     zero, disjoint, handed out once, 256-byte aligned; large ones and captures outside begin/end_capture_zero_pool() keep their own fill"""
@@ -886,7 +915,8 @@ def test_captured_train_step_follows_eager(cuda, amp):
     against the same steps run eagerly from the same initial state, on two alternating batches: per-step losses, the accumulated parameter
     update, BatchNorm running statistics and num_batches_tracked.  Same kernels on the same data; what differs is the order of the fp32
     atomics in the weight gradients and the occasional ReLU flip that follows from it, so the update is compared in the rms
-    norm (2e-2 of the update's rms; measured ~1e-3) and the losses to 2e-3."""
+    norm (2e-2 of the update's rms; measured ~1e-3) and the losses to 5e-3: two EAGER runs from the same state differ by up to 2.3e-3 at
+    step 4 of the bf16 run (profiles/r04_train_eager_repro.txt; steps 1-3 agree to the last digit)."""
     import copy
     cfg = synth.corpbevt_small_config()
     cfg["fax"]["self_attn"]["dropout"] = 0.0          # the eager step draws its masks from host seeds, the replay from the device word
@@ -919,7 +949,7 @@ def test_captured_train_step_follows_eager(cuda, amp):
         assert torch.equal(v, init[k]), "state %s changed by the capture" % k
     cap_losses = [float(cap.step(batches[i % 2])) for i in range(steps)]
     for a, b in zip(eager_losses, cap_losses):
-        assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (eager_losses, cap_losses)
+        assert abs(a - b) <= 5e-3 * max(1.0, abs(a)), (eager_losses, cap_losses)
     assert cap_losses[-1] < cap_losses[0]
     se, sc = models[0].state_dict(), models[1].state_dict()
     num = den = 0.0
