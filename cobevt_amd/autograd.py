@@ -589,7 +589,16 @@ class Conv2dFn(torch.autograd.Function):
         chunks3 = -1
         if ctx.needs_input_grad[1] and USE_WGRAD3 and xl.dtype == torch.bfloat16 and kh == 3 and kw == 3 and stride == 1 and pad == 1:
             chunks3 = _L.load().cobevt_conv_wgrad3_chunks(_ints([n, h, w, cin, cout]))
-        if chunks3 > 0:
+        chunks1 = -1
+        if ctx.needs_input_grad[1] and USE_WGRAD3 and xl.dtype == torch.bfloat16 and kh == 1 and kw == 1 and stride == 1 and pad == 0:
+            chunks1 = _L.load().cobevt_linear_wgrad_chunks((ctypes.c_long * 3)(n * h * w, cin, cout))
+        if chunks1 > 0:
+            # a dense projection: dy^T x over the rows (csrc/wgrad3.hip), dw written, partial sums in a scratch buffer
+            dw = torch.empty((cout, cin, 1, 1), device=dyl.device, dtype=torch.float32)
+            scratch = torch.empty((chunks1, cout * cin), device=dyl.device, dtype=torch.float32)
+            rc = _L.load().cobevt_linear_wgrad(_p(xl), _p(dyl), _p(dw), _p(scratch), (ctypes.c_long * 4)(n * h * w, cin, cout, chunks1), _stream())
+            _L.check(rc, "cobevt_linear_wgrad")
+        elif chunks3 > 0:
             # straight from the channels-last maps (csrc/wgrad3.hip): dw is written, partial sums in a scratch buffer
             dw = torch.empty((cout, cin, kh, kw), device=dyl.device, dtype=torch.float32)
             scratch = torch.empty((chunks3, cout * cin * 9), device=dyl.device, dtype=torch.float32)

@@ -168,20 +168,161 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_tr_kernel(Wgrad3Params p) 
     }
 }
 
-// dw[(o * Cin + c) * 9 + t] = sum over the chunks of part[chunk][o / 32][c / 32][t][r][lane], (o % 32, c % 32) = (acc_row(r, lane), lane % 32)
+// dw[(o * Cin + c) * 9 + t] = sum over the chunks of part[chunk][o / 32][c / 32][t][r][lane], (o % 32, c % 32) = (acc_row(r, lane), lane % 32).
+// A workgroup sums 64 consecutive partial words: its four waves take every fourth chunk (four loads in flight each - up to 128 chunks
+// for the 64-channel layers; one thread walking them serially cost 18 us per launch) and meet through LDS.
 __global__ __launch_bounds__(256) void conv_wgrad3_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nchunks, long tile_elems,
                                                                  int TC, int Cin) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= tile_elems) return;
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += part[(size_t)c * tile_elems + e];
-    const int lane = (int)(e & 63), r = (int)((e >> 6) & 15);
+    __shared__ float red[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + lane;               // tile_elems is a multiple of 1024
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = wave;
+    for (; c + 12 < nchunks; c += 16) {
+        s0 += part[(size_t)c * tile_elems + e];
+        s1 += part[(size_t)(c + 4) * tile_elems + e];
+        s2 += part[(size_t)(c + 8) * tile_elems + e];
+        s3 += part[(size_t)(c + 12) * tile_elems + e];
+    }
+    for (; c < nchunks; c += 4) s0 += part[(size_t)c * tile_elems + e];
+    float s = (s0 + s1) + (s2 + s3);
+    if (wave > 0) red[wave - 1][lane] = s;
+    __syncthreads();
+    if (wave > 0) return;
+    s += red[0][lane] + red[1][lane] + red[2][lane];
+    const int r = (int)((e >> 6) & 15);
     long t = e >> 10;
     const int tap = (int)(t % 9);
     t /= 9;
     const int tc = (int)(t % TC), to = (int)(t / TC);
     const int o = to * 32 + acc_row(r, lane), ci = tc * 32 + (lane & 31);
     dw[((size_t)o * Cin + ci) * 9 + tap] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a dense projection / 1x1 convolution, dW[o][c] = sum over the rows of dY[row][o] X[row][c] (bf16 rows, 128 | Cin,
+// 128 | Cout): nn.Linear's and the 1x1 convolutions' backward-filter under train_camera.py:143-179 (the FAX / fusion projections and
+// MLPs, base_transformer.py:102-124, fax_modules.py:189-237).  A handful of FLOPs per byte: the kernel is a stream over X and dY, so a
+// workgroup owns a whole 128 x 128 output tile and every row slice is read once per tile.  16 waves = 4 row groups x (2 x 2) waves of
+// 64 x 64: a row group copies its 16 rows of both slices into LDS as they lie in memory ([row][128 channels], the 32-byte blocks of a row
+// XOR-ed with 2 (row % 4) so that the four rows of a transposing read cover the 64 banks) and ds_read_b64_tr_b16 hands out the pixel-major
+// operands; 8 reads and 4 MFMAs per wave and step, the next step's rows in flight meanwhile (two LDS buffers, one barrier per 64 rows).
+// The four row groups meet through LDS, the workgroup's tile goes to the partial buffer and the reduce launch above's sibling sums it.
+struct Wgrad1Params {
+    const bf16_t* x;     // (R, Cin)
+    const bf16_t* dy;    // (R, Cout)
+    float* part;         // [nchunks][tiles][4 waves][4 accumulators][16][64]
+    long R;
+    int Cin, Cout, TCn;  // TCn = Cin / 128
+    int nchunks;
+};
+
+__global__ __launch_bounds__(1024, 1) void linear_wgrad_tr_kernel(Wgrad1Params p) {
+    constexpr int GRP = 2 * 16 * 256;                   // one row group's buffer: 16 rows of dY's slice, 16 of X's
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 4 * GRP];          // 64 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kg = wave >> 2, wo = (wave >> 1) & 1, wc = wave & 1;
+    const int gt = tid & 255;                           // thread within the row group
+    const int tile = blockIdx.x, chunk = blockIdx.y;
+    const int o_base = (tile / p.TCn) * 128, c_base = (tile % p.TCn) * 128;
+    const long steps = (p.R + 63) / 64;
+    const long s0 = steps * chunk / p.nchunks, s1 = steps * (chunk + 1) / p.nchunks;
+    // staging: thread gt copies piece (gt & 15) of row (gt >> 4) of each slice
+    const int srow = gt >> 4, sj = gt & 15;
+    const int st_off = srow * 256 + ((((sj >> 1) ^ (2 * (srow & 3))) << 5) | ((sj & 1) << 4));
+    // operands: lane = 16 g + i -> row 8 (g >> 1) + i / 4 (+ 4 for the second read), 16-channel block cblk ^ 2 (i / 4), channels 4 (i % 4) ..
+    const int g = lane >> 4, i = lane & 15;
+    const int rowoff = (8 * (g >> 1) + (i >> 2)) * 256 + 8 * (i & 3);
+    int aoff[2], boff[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        aoff[t] = rowoff + (((4 * wo + 2 * t + (g & 1)) ^ (2 * (i >> 2))) << 5);
+        boff[t] = 16 * 256 + rowoff + (((4 * wc + 2 * t + (g & 1)) ^ (2 * (i >> 2))) << 5);
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    uint4 nd = make_uint4(0, 0, 0, 0), nx = nd;
+    bool nok = false;
+    auto fetch = [&](long step) __attribute__((always_inline)) {
+        const long row = step * 64 + kg * 16 + srow;
+        nok = row < p.R;
+        const long rr = nok ? row : 0;
+        nd = *(const uint4*)(p.dy + rr * p.Cout + o_base + sj * 8);
+        nx = *(const uint4*)(p.x + rr * p.Cin + c_base + sj * 8);
+    };
+    if (s0 < s1) fetch(s0);
+    for (long s = s0; s < s1; ++s) {
+        unsigned char* buf = smem + ((int)((s - s0) & 1) * 4 + kg) * GRP;
+        *(uint4*)(buf + st_off) = make_uint4(nok ? nd.x : 0u, nok ? nd.y : 0u, nok ? nd.z : 0u, nok ? nd.w : 0u);
+        *(uint4*)(buf + 16 * 256 + st_off) = make_uint4(nok ? nx.x : 0u, nok ? nx.y : 0u, nok ? nx.z : 0u, nok ? nx.w : 0u);
+        __syncthreads();                                // this step's rows are in LDS; the other buffer is free again
+        if (s + 1 < s1) fetch(s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 af[2], bfr[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint2 a0 = tr_read(buf + aoff[t]), a1 = tr_read(buf + aoff[t] + 4 * 256);
+            const uint2 b0 = tr_read(buf + boff[t]), b1 = tr_read(buf + boff[t] + 4 * 256);
+            af[t] = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+            bfr[t] = __builtin_bit_cast(bf16x8, make_uint4(b0.x, b0.y, b1.x, b1.y));
+        }
+#pragma unroll
+        for (int to = 0; to < 2; ++to)
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc)
+                acc[to * 2 + tc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[to], bfr[tc], acc[to * 2 + tc], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the four row groups -> one tile: per accumulator, groups 1..3 park theirs in LDS (3 x 4 waves x 4 KiB), group 0 adds and stores
+    float* red = (float*)smem;
+    float* dst = p.part + (((size_t)chunk * gridDim.x + tile) * 4 + (wave & 3)) * (4 * 16 * 64);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        __syncthreads();
+        if (kg > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(((kg - 1) * 4 + (wave & 3)) * 16 + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = ((wave & 3) * 16 + r) * 64 + lane;
+                dst[(t * 16 + r) * 64 + lane] = acc[t][r] + red[k] + red[4 * 16 * 64 + k] + red[2 * 4 * 16 * 64 + k];
+            }
+        }
+    }
+}
+
+// dw[o * Cin + c] = sum over the chunks of part[chunk][tile][wave][acc][r][lane]
+__global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nchunks, long elems,
+                                                                  int TCn, int Cin) {
+    __shared__ float red[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = wave;
+    for (; c + 12 < nchunks; c += 16) {
+        s0 += part[(size_t)c * elems + e];
+        s1 += part[(size_t)(c + 4) * elems + e];
+        s2 += part[(size_t)(c + 8) * elems + e];
+        s3 += part[(size_t)(c + 12) * elems + e];
+    }
+    for (; c < nchunks; c += 4) s0 += part[(size_t)c * elems + e];
+    float s = (s0 + s1) + (s2 + s3);
+    if (wave > 0) red[wave - 1][lane] = s;
+    __syncthreads();
+    if (wave > 0) return;
+    s += red[0][lane] + red[1][lane] + red[2][lane];
+    const int r = (int)((e >> 6) & 15), a = (int)((e >> 10) & 3), w = (int)((e >> 12) & 3);
+    const int tile = (int)(e >> 14);
+    const int o = (tile / TCn) * 128 + ((w >> 1) & 1) * 64 + (a >> 1) * 32 + acc_row(r, lane);
+    const int ci = (tile % TCn) * 128 + (w & 1) * 64 + (a & 1) * 32 + (lane & 31);
+    dw[(size_t)o * Cin + ci] = s;
 }
 
 }  // namespace
@@ -224,7 +365,38 @@ extern "C" int cobevt_conv_wgrad3(const void* x, const void* dy, float* dw, floa
     if (WS == 32) hipLaunchKernelGGL(conv_wgrad3_tr_kernel<32>, grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(conv_wgrad3_tr_kernel<16>, grid, dim3(256), 0, stream, p);
     const long tile_elems = (long)p.Cout * p.Cin * 9;
-    hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3((unsigned)((tile_elems + 255) / 256)), dim3(256), 0, stream, scratch, dw, chunks, tile_elems,
+    hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3((unsigned)(tile_elems / 64)), dim3(256), 0, stream, scratch, dw, chunks, tile_elems,
                        p.Cin / 32, p.Cin);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+extern "C" int cobevt_linear_wgrad_chunks(const long* dims) {
+    // dims: [R, Cin, Cout]: partial copies of dw (Cout x Cin fp32) cobevt_linear_wgrad writes, or minus an error code (shape not served)
+    if (!dims) return -COBEVT_ERR_ARG;
+    const long R = dims[0], Cin = dims[1], Cout = dims[2];
+    if (R < 1 || Cin < 128 || Cin % 128 || Cout < 128 || Cout % 128 || Cin > 65536 || Cout > 65536) return -COBEVT_ERR_UNSUPPORTED;
+    if (R * (Cin > Cout ? Cin : Cout) >= (1L << 40)) return -COBEVT_ERR_UNSUPPORTED;
+    const long tiles = (Cout / 128) * (Cin / 128), steps = (R + 63) / 64;
+    long chunks = (256 + tiles - 1) / tiles;                 // one 16-wave workgroup per CU
+    if (chunks > steps / 4) chunks = steps / 4;              // at least four steps each
+    if (chunks < 1) chunks = 1;
+    if (chunks > 65535 || tiles > 0x7fffffffL) return -COBEVT_ERR_UNSUPPORTED;
+    return (int)chunks;
+}
+
+extern "C" int cobevt_linear_wgrad(const void* x, const void* dy, float* dw, float* scratch, const long* dims, hipStream_t stream) {
+    // dims: [R, Cin, Cout, nchunks]
+    if (!x || !dy || !dw || !scratch || !dims) return COBEVT_ERR_ARG;
+    const int chunks = cobevt_linear_wgrad_chunks(dims);
+    if (chunks < 0) return -chunks;
+    if (dims[3] != chunks) return COBEVT_ERR_ARG;
+    Wgrad1Params p;
+    p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.part = scratch;
+    p.R = dims[0]; p.Cin = (int)dims[1]; p.Cout = (int)dims[2]; p.TCn = p.Cin / 128;
+    p.nchunks = chunks;
+    const int tiles = (p.Cout / 128) * p.TCn;
+    hipLaunchKernelGGL(linear_wgrad_tr_kernel, dim3(tiles, chunks), dim3(1024), 0, stream, p);
+    const long elems = (long)p.Cout * p.Cin;
+    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)(elems / 64)), dim3(256), 0, stream, scratch, dw, chunks, elems, p.TCn, p.Cin);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

@@ -102,6 +102,8 @@ SIGNATURES = {
     "cobevt_conv3_weight_operands": (ctypes.c_int, [_vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_conv_wgrad3_chunks": (ctypes.c_int, [_c_int_p]),
     "cobevt_conv_wgrad3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp]),
+    "cobevt_linear_wgrad_chunks": (ctypes.c_int, [_c_long_p]),
+    "cobevt_linear_wgrad": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_long_p, _vp]),
     "cobevt_wgrad_block_operand": (ctypes.c_int, [_vp, _vp, _c_int_p, _vp]),
     "cobevt_swish": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_long, _vp]),
     "cobevt_depthwise_wgrad": (ctypes.c_int, [_vp, _vp, _vp, _c_int_p, _vp]),

@@ -552,6 +552,14 @@ int cobevt_conv3_weight_operands(const float* w, void* frag, void* rows3, const 
  */
 int cobevt_conv_wgrad3_chunks(const int* dims);
 int cobevt_conv_wgrad3(const void* x, const void* dy, float* dw, float* scratch, const int* dims, hipStream_t stream);
+/*
+ * The same for a dense projection / 1x1 stride-1 convolution: dw (Cout, Cin) fp32 = dy^T x over R bf16 rows (x (R, Cin), dy (R, Cout),
+ * 128 | Cin, 128 | Cout), written, not accumulated - nn.Linear's backward-filter under train_camera.py:143-179.
+ * cobevt_linear_wgrad_chunks(dims[3]: R, Cin, Cout) -> partial copies of dw in `scratch` (or minus an error code);
+ * cobevt_linear_wgrad dims (int64[4]): R, Cin, Cout, that chunk count.
+ */
+int cobevt_linear_wgrad_chunks(const long* dims);
+int cobevt_linear_wgrad(const void* x, const void* dy, float* dw, float* scratch, const long* dims, hipStream_t stream);
 /* bf16 channels-last map (N, H, W, C) -> the blocked operand of cobevt_conv_wgrad_blocked, dst [N][Hp][NB][C][8]: pixel x of input
  * row y sits in block (x + pad_left) / 8 of row y + pad_top; everything else is zero.  In general dst is [N][Hp][NB][P][C][8] and slot j
  * of plane q of block b holds input pixel sx (8 b + j) + q - pad_left (P = 1, sx = 1 above; P = 2, sx = 2: even / odd columns of a

@@ -853,6 +853,37 @@ def test_conv_wgrad3_matches_blocked_weight_gradient(cuda, n, h, w, cin, cout):
     assert lib.cobevt_conv_wgrad3_chunks(ag._ints([n, h, w, cin + 8, cout])) < 0
 
 
+@pytest.mark.parametrize("rows,cin,cout", [(5120, 128, 128), (1000, 128, 384), (81920, 128, 256), (777, 512, 128), (64, 256, 256), (3, 128, 128)])
+def test_linear_wgrad_matches_fp64(cuda, rows, cin, cout):
+    """cobevt_linear_wgrad (dy^T x over bf16 rows with the operands transposed by the LDS read; row counts off the 64-row step, fewer
+    rows than one step, several output tiles) against fp64 torch, bit-identical between two runs, and through autograd.linear"""
+    g = torch.Generator().manual_seed(rows + cin)
+    x = torch.randn(rows, cin, generator=g).to(torch.bfloat16).to(cuda)
+    dy = torch.randn(rows, cout, generator=g).to(torch.bfloat16).to(cuda)
+    lib = ag._L.load()
+    import ctypes
+    chunks = lib.cobevt_linear_wgrad_chunks((ctypes.c_long * 3)(rows, cin, cout))
+    assert chunks >= 1
+    outs = []
+    for _ in range(2):
+        dw = torch.full((cout, cin), float("nan"), device=cuda)
+        scratch = torch.empty((chunks, cout * cin), device=cuda)
+        ag._L.check(lib.cobevt_linear_wgrad(ag._p(x), ag._p(dy), ag._p(dw), ag._p(scratch), (ctypes.c_long * 4)(rows, cin, cout, chunks),
+                                            ag._stream()), "cobevt_linear_wgrad")
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])
+    ref = dy.double().t() @ x.double()
+    assert_close(outs[0], ref.float(), 2e-5, "linear wgrad vs fp64 torch")
+    assert lib.cobevt_linear_wgrad_chunks((ctypes.c_long * 3)(rows, cin + 64, cout)) < 0
+    # the autograd path takes it inside a bf16 autocast region
+    lin = torch.nn.Linear(cin, cout).to(cuda)
+    xin = x.float().requires_grad_(True)
+    with torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y = ag.linear(xin, lin)
+    y.backward(dy.to(y.dtype))
+    assert_close(lin.weight.grad, ref.float(), 1e-2, "autograd.linear dW (bf16 autocast)")
+
+
 def test_zero_pool_hands_out_disjoint_zeroed_slices(cuda):
     """autograd._zeros: small gradient buffers are slices of one zero-filled chunk (one fill launch per 16 MiB instead of one per tensor):
     zero, disjoint, handed out once, 256-byte aligned; large ones and captures outside begin/end_capture_zero_pool() keep their own fill"""
