@@ -728,7 +728,7 @@ def batch_norm_act(x, bn, residual=None, relu=False):
 
 
 class MaxPool3x3s2Fn(torch.autograd.Function):
-    """nn.MaxPool2d(3, 2, 1) (the ResNet stem, resnet_ms.py:70): cobevt_maxpool3x3s2 / cobevt_maxpool3x3s2_bwd"""
+    """nn.MaxPool2d(3, 2, 1) (the ResNet stem, resnet_ms.py:70): cobevt_maxpool3x3s2 / cobevt_maxpool3x3s2_bwd_t"""
 
     @staticmethod
     def forward(ctx, x):
@@ -741,10 +741,10 @@ class MaxPool3x3s2Fn(torch.autograd.Function):
         (xl,) = ctx.saved_tensors
         n, h, w, c = xl.shape
         dyl = _nhwc(dy.to(xl.dtype))
-        dx = torch.empty((n, h, w, c), device=xl.device, dtype=torch.float32)
-        _L.check(_L.load().cobevt_maxpool3x3s2_bwd(_p(xl), _p(dyl), _p(dx), ops.dcode(xl.dtype), n, h, w, c, _stream()),
-                 "cobevt_maxpool3x3s2_bwd")
-        return dx.to(xl.dtype).permute(0, 3, 1, 2)
+        dx = torch.empty_like(xl)
+        _L.check(_L.load().cobevt_maxpool3x3s2_bwd_t(_p(xl), _p(dyl), _p(dx), ops.dcode(xl.dtype), n, h, w, c, _stream()),
+                 "cobevt_maxpool3x3s2_bwd_t")
+        return dx.permute(0, 3, 1, 2)
 
 
 def max_pool3x3s2(x):

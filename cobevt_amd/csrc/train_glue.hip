@@ -148,8 +148,12 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void bn_apply_walk_kernel(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, T* __restrict__ y, long items, int C, int act) {
     const int G = C >> 3;
-    const long step = (long)gridDim.x * kThreads;
-    long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+    // a workgroup walks ONE contiguous span of pieces (a multiple of 256, hence of G): neighbouring waves stay in the same DRAM pages /
+    // TLB entries (a grid-wide stride put every wave of the chip on its own 2 MiB page each round)
+    constexpr long step = kThreads;
+    const long span = ((items + gridDim.x - 1) / gridDim.x + kThreads - 1) / kThreads * kThreads;
+    long gid = (long)blockIdx.x * span + threadIdx.x;
+    items = items < (long)(blockIdx.x + 1) * span ? items : (long)(blockIdx.x + 1) * span;
     const int gl = (int)(gid % G);
     float sc[8], sh[8];
 #pragma unroll
@@ -272,8 +276,10 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_walk_kernel(const T* __
                                                                      const double* __restrict__ dbeta, T* __restrict__ dx, T* __restrict__ dres,
                                                                      long items, int C, float inv_rows, int act, int training) {
     const int G = C >> 3;
-    const long step = (long)gridDim.x * kThreads;
-    long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+    constexpr long step = kThreads;                  // one contiguous span per workgroup, see bn_apply_walk_kernel
+    const long span = ((items + gridDim.x - 1) / gridDim.x + kThreads - 1) / kThreads * kThreads;
+    long gid = (long)blockIdx.x * span + threadIdx.x;
+    items = items < (long)(blockIdx.x + 1) * span ? items : (long)(blockIdx.x + 1) * span;
     const int gl = (int)(gid % G);
     float k[8], mu[8], rs[8], db[8], dg[8];
 #pragma unroll
@@ -374,6 +380,65 @@ __global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const T* __restri
     float* o = dx + gid * C + gl * 8;
     *(float4*)o = make_float4(acc[0], acc[1], acc[2], acc[3]);
     *(float4*)(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
+// The same per 2 x 2 block of input pixels, dx in the map's own type: the block (2a.., 2b..) lies in the four windows {a, a + 1} x {b, b + 1},
+// whose maxima are found once (36 loads for four pixels; the pixel-per-thread form above re-derives every window for each of its up to nine
+// pixels: 21 loads per pixel) and a pixel takes the gradients of the windows whose first maximum it is.  The fp32 sum of its <= 4 gradients is
+// rounded once - what the fp32 map + cast of the old entry point produced, without the 336 MB fp32 map on the 5-agent stem.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void maxpool_bwd_block_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                                                     int N, int H, int W, int C, int Ho, int Wo) {
+    const int G = C >> 3;
+    const int Hb = (H + 1) >> 1, Wb = (W + 1) >> 1;
+    const long item = (long)blockIdx.x * kThreads + threadIdx.x;
+    const long bid = item / G;
+    const int gl = (int)(item % G);
+    if (bid >= (long)N * Hb * Wb) return;
+    const int b = (int)(bid % Wb), a = (int)((bid / Wb) % Hb), n = (int)(bid / ((long)Wb * Hb));
+    float acc[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
+#pragma unroll
+    for (int wq = 0; wq < 4; ++wq) {
+        const int oh = a + (wq >> 1), ow = b + (wq & 1);
+        if (oh >= Ho || ow >= Wo) continue;
+        float best[8];
+        int arg[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; arg[e] = -1; }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int yy = oh * 2 - 1 + kh;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int xx = ow * 2 - 1 + kw;
+                if (xx < 0 || xx >= W) continue;
+                float v[8];
+                load8<T>(x + (((size_t)n * H + yy) * W + xx) * C + gl * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (v[e] > best[e] || arg[e] < 0) { best[e] = v[e]; arg[e] = yy * W + xx; }
+            }
+        }
+        float g[8];
+        load8<T>(dy + (((size_t)n * Ho + oh) * Wo + ow) * C + gl * 8, g);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pid = (2 * a + (q >> 1)) * W + 2 * b + (q & 1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (arg[e] == pid) acc[q][e] += g[e];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ih = 2 * a + (q >> 1), iw = 2 * b + (q & 1);
+        if (ih < H && iw < W) store8<T>(dx + (((size_t)n * H + ih) * W + iw) * C + gl * 8, acc[q]);
+    }
 }
 
 // ---- nn.PixelUnshuffle(2) on channels-last maps: out[n][h][w][c*4 + 2i + j] = in[n][2h + i][2w + j][c]; inverse = 1: the other way
@@ -643,6 +708,19 @@ extern "C" int cobevt_maxpool3x3s2_bwd(const void* x, const void* dy, float* dx,
     const dim3 grid((unsigned)((items + kThreads - 1) / kThreads));
     if (dtype == 0) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, grid, dim3(kThreads), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, dx, N, H, W, C, Ho, Wo);
     else if (dtype == 1) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(kThreads), 0, stream, (const float*)x, (const float*)dy, dx, N, H, W, C, Ho, Wo);
+    else return COBEVT_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// dx (N, H, W, C) in the map's type, every element written
+extern "C" int cobevt_maxpool3x3s2_bwd_t(const void* x, const void* dy, void* dx, int dtype, int N, int H, int W, int C, hipStream_t stream) {
+    if (!x || !dy || !dx) return COBEVT_ERR_ARG;
+    if (!groups_ok(C) || N < 1 || H < 1 || W < 1) return COBEVT_ERR_SHAPE;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long items = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C >> 3);
+    const dim3 grid((unsigned)((items + kThreads - 1) / kThreads));
+    if (dtype == 0) hipLaunchKernelGGL(maxpool_bwd_block_kernel<bf16_t>, grid, dim3(kThreads), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo);
+    else if (dtype == 1) hipLaunchKernelGGL(maxpool_bwd_block_kernel<float>, grid, dim3(kThreads), 0, stream, (const float*)x, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo);
     else return COBEVT_ERR_ARG;
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

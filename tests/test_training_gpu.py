@@ -742,6 +742,24 @@ def test_pool_shuffle_upsample_linear_vs_torch(cuda):
             assert_close(a, b, 1e-4, "linear " + name)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,h,w,c", [(2, 9, 15, 16), (1, 1, 1, 8), (3, 16, 12, 64), (1, 7, 2, 24)])
+def test_maxpool_backward_block_kernel_matches_pixel_kernel(cuda, dtype, n, h, w, c):
+    """cobevt_maxpool3x3s2_bwd_t (a thread per 2 x 2 input block, dx in the map's type) against cobevt_maxpool3x3s2_bwd (a thread per pixel,
+    fp32 dx): the same first-maximum rule with ties, odd sizes, one-pixel maps; bit-identical after the cast"""
+    g = torch.Generator().manual_seed(h * 31 + w)
+    x = torch.randint(-2, 3, (n, h, w, c), generator=g).float().to(dtype).to(cuda)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    dy = torch.randn(n, ho, wo, c, generator=g).to(dtype).to(cuda)
+    lib = ag._L.load()
+    old = torch.empty((n, h, w, c), device=cuda, dtype=torch.float32)
+    new = torch.full((n, h, w, c), float("nan"), device=cuda, dtype=dtype)
+    code = ops.dcode(dtype)
+    ag._L.check(lib.cobevt_maxpool3x3s2_bwd(ag._p(x), ag._p(dy), ag._p(old), code, n, h, w, c, ag._stream()), "cobevt_maxpool3x3s2_bwd")
+    ag._L.check(lib.cobevt_maxpool3x3s2_bwd_t(ag._p(x), ag._p(dy), ag._p(new), code, n, h, w, c, ag._stream()), "cobevt_maxpool3x3s2_bwd_t")
+    assert torch.equal(new, old.to(dtype))
+
+
 def test_sttf_warp_backward_is_the_adjoint(cuda):
     """<warp(x), g> == <x, warp^T(g)> for the regrouping STTF warp (a linear map of x), and the forward equals the inference kernel:
     cobevt_sttf_warp_bwd scatters through the same sample positions cobevt_sttf_warp gathers from"""
