@@ -194,67 +194,114 @@ def attention_dropout_mask(batch, windows, heads, nq, nk, drop_p, drop_seed, dev
     return keep.bool()
 
 
+def _autocast_mode():
+    """None outside autocast regions, "bf16" inside a bfloat16 one, "other" (fp16: the kernels' fp32 forms) otherwise"""
+    if not torch.is_autocast_enabled():
+        return None
+    return "bf16" if torch.get_autocast_dtype("cuda") == torch.bfloat16 else "other"
+
+
 class LayerNormFn(torch.autograd.Function):
-    """nn.LayerNorm over the last dimension: cobevt_layernorm forward, cobevt_layernorm_bwd backward."""
+    """nn.LayerNorm over the last dimension.  fp32 in / out: cobevt_layernorm / cobevt_layernorm_bwd.  Inside a bf16 autocast region
+    (layernorm() below) x may be bf16 (a projection's output) and the result is written as bf16 when its consumer is a projection
+    (`out_bf16`): torch's autocast computes layer_norm in fp32 and casts its result for the linear that follows (train_camera.py:157-160) -
+    cobevt_layernorm_fwd_t does that rounding in the same pass, and cobevt_layernorm_bwd_t reads the bf16 gradient the projection's input
+    gradient produced; statistics, arithmetic and the parameter gradients are fp32 in every case."""
 
     @staticmethod
-    @_amp_fwd
-    def forward(ctx, x, gamma, beta, eps):
-        x = _f32c(x, "layernorm input")
+    def forward(ctx, x, gamma, beta, eps, out_bf16):
+        _need_cuda(x, gamma, beta)
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            raise CobevtHipError("layernorm: fp32 or bf16 input (got %s)" % x.dtype)
+        x = x if x.is_contiguous() else x.contiguous()
         g, b = _f32c(gamma, "gamma"), _f32c(beta, "beta")
-        y = ops.layernorm(x, g, b, eps)
+        if x.dtype == torch.float32 and not out_bf16:
+            y = ops.layernorm(x, g, b, eps)
+        else:
+            C = x.shape[-1]
+            y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+            rc = _L.load().cobevt_layernorm_fwd_t(_p(x), _p(g), _p(b), _p(y), x.numel() // C, C, ctypes.c_float(eps),
+                                                  _ints([ops.dcode(x.dtype), ops.dcode(y.dtype)]), _stream())
+            _L.check(rc, "cobevt_layernorm_fwd_t")
         ctx.save_for_backward(x, g)
         ctx.eps = eps
         return y
 
     @staticmethod
-    @_amp_bwd
     def backward(ctx, dy):
         x, g = ctx.saved_tensors
-        dy = _f32c(dy, "dy")
+        if dy.dtype not in (torch.float32, torch.bfloat16):
+            dy = dy.float()
+        dy = dy if dy.is_contiguous() else dy.contiguous()
         C = x.shape[-1]
         rows = x.numel() // C
         dx = torch.empty_like(x)
         dg = _zeros(C, x.device, torch.float32)
         db = _zeros(C, x.device, torch.float32)
-        rc = _L.load().cobevt_layernorm_bwd(_p(x), _p(dy), _p(g), _p(dx), _p(dg), _p(db), rows, C, ctypes.c_float(ctx.eps),
-                                            _stream())
-        _L.check(rc, "cobevt_layernorm_bwd")
-        return dx, dg, db, None
+        if x.dtype == torch.float32 and dy.dtype == torch.float32:
+            rc = _L.load().cobevt_layernorm_bwd(_p(x), _p(dy), _p(g), _p(dx), _p(dg), _p(db), rows, C, ctypes.c_float(ctx.eps), _stream())
+            _L.check(rc, "cobevt_layernorm_bwd")
+        else:
+            rc = _L.load().cobevt_layernorm_bwd_t(_p(x), _p(dy), _p(g), _p(dx), _p(dg), _p(db), rows, C, ctypes.c_float(ctx.eps),
+                                                  _ints([ops.dcode(x.dtype), ops.dcode(dy.dtype), ops.dcode(dx.dtype)]), _stream())
+            _L.check(rc, "cobevt_layernorm_bwd_t")
+        return dx, dg, db, None, None
 
 
-def layernorm(x, ln):
-    """x through the nn.LayerNorm container `ln`"""
-    return LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps)
+def layernorm(x, ln, for_projection=False):
+    """x through the nn.LayerNorm container `ln`.  for_projection: the only consumer is linear() / linear_weight() - inside a bf16 autocast
+    region the result is then written in bf16, the operand type of that projection (what torch's autocast cast produces, minus the cast)."""
+    mode = _autocast_mode()
+    if mode is None:
+        return LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps, False)
+    with torch.autocast("cuda", enabled=False):
+        if mode != "bf16" or x.dtype not in (torch.float32, torch.bfloat16):
+            return LayerNormFn.apply(x.float(), ln.weight.float(), ln.bias.float(), ln.eps, False)
+        return LayerNormFn.apply(x, ln.weight.float(), ln.bias.float(), ln.eps, bool(for_projection))
 
 
 class GeluFn(torch.autograd.Function):
-    """nn.GELU() (exact erf form): cobevt_gelu in both directions."""
+    """nn.GELU() (exact erf form): cobevt_gelu in both directions; bf16 tensors (a projection's output inside a bf16 autocast region - torch
+    runs gelu in its input's type) on cobevt_gelu_bf16: bf16 storage, fp32 arithmetic."""
 
     @staticmethod
-    @_amp_fwd
     def forward(ctx, x):
-        x = _f32c(x, "gelu input")
         _need_cuda(x)
+        x = x if x.is_contiguous() else x.contiguous()
         y = torch.empty_like(x)
-        rc = _L.load().cobevt_gelu(_p(x), None, _p(y), x.numel(), _stream())
-        _L.check(rc, "cobevt_gelu")
+        if x.dtype == torch.bfloat16:
+            rc = _L.load().cobevt_gelu_bf16(_p(x), None, _p(y), x.numel(), _stream())
+            _L.check(rc, "cobevt_gelu_bf16")
+        else:
+            x = _f32c(x, "gelu input")
+            rc = _L.load().cobevt_gelu(_p(x), None, _p(y), x.numel(), _stream())
+            _L.check(rc, "cobevt_gelu")
         ctx.save_for_backward(x)
         return y
 
     @staticmethod
-    @_amp_bwd
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        dy = _f32c(dy, "dy")
+        dy = dy.to(x.dtype)
+        dy = dy if dy.is_contiguous() else dy.contiguous()
         dx = torch.empty_like(x)
-        rc = _L.load().cobevt_gelu(_p(x), _p(dy), _p(dx), x.numel(), _stream())
-        _L.check(rc, "cobevt_gelu")
+        if x.dtype == torch.bfloat16:
+            rc = _L.load().cobevt_gelu_bf16(_p(x), _p(dy), _p(dx), x.numel(), _stream())
+            _L.check(rc, "cobevt_gelu_bf16")
+        else:
+            rc = _L.load().cobevt_gelu(_p(x), _p(dy), _p(dx), x.numel(), _stream())
+            _L.check(rc, "cobevt_gelu")
         return dx
 
 
 def gelu(x):
-    return GeluFn.apply(x)
+    mode = _autocast_mode()
+    if mode is None:
+        return GeluFn.apply(x)
+    with torch.autocast("cuda", enabled=False):
+        if mode == "bf16" and x.dtype == torch.bfloat16 and x.numel() % 8 == 0:
+            return GeluFn.apply(x)
+        return GeluFn.apply(x.float())
 
 
 _SCRATCH_BLOCKS = 512         # per-workgroup partial sums of the channel reductions (fp64 [blocks][2][C]); see csrc/train_glue.hip

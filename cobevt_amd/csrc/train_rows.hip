@@ -17,10 +17,24 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // y = LN(x) gamma + beta.  dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma; dgamma += dy xhat; dbeta += dy.
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                            const float* __restrict__ gamma, float* __restrict__ dx,
+// x / dy / dx are fp32 or bf16 each (xb / db / ob: 1 = bf16) - inside a bf16 autocast region the residual stream is fp32 while the
+// gradient arriving from a projection's input gradient is bf16 (train_camera.py:157-160); the arithmetic is fp32 either way.
+__device__ __forceinline__ float4 ld4(const void* p, int bf, size_t i) {
+    if (bf) {
+        const uint2 u = *(const uint2*)((const uint16_t*)p + i);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    }
+    return *(const float4*)((const float*)p + i);
+}
+__device__ __forceinline__ void st4(void* p, int bf, size_t i, const float4& v) {
+    if (bf) *(uint2*)((uint16_t*)p + i) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+    else *(float4*)((float*)p + i) = v;
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dy,
+                                                            const float* __restrict__ gamma, void* __restrict__ dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C,
-                                                            float eps, int rows_per_block) {
+                                                            float eps, int rows_per_block, int xb, int db_, int ob) {
     __shared__ float red[2][4][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int groups = C >> 2;                           // float4 groups per row
@@ -42,8 +56,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         for (int i = 0; i < kLnMaxPerLane; ++i) {
             const int g = lane + 64 * i;
             const bool ok = g < groups;
-            xv[i] = ok ? *(const float4*)(x + (size_t)row * C + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-            dv[i] = ok ? *(const float4*)(dy + (size_t)row * C + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[i] = ok ? ld4(x, xb, (size_t)row * C + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            dv[i] = ok ? ld4(dy, db_, (size_t)row * C + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
             s += xv[i].x + xv[i].y + xv[i].z + xv[i].w;
         }
         const float mean = wave_sum(s) * invC;
@@ -78,7 +92,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                 float4 o;
                 o.x = rstd * (dv[i].x - mg - xv[i].x * mgx); o.y = rstd * (dv[i].y - mg - xv[i].y * mgx);
                 o.z = rstd * (dv[i].z - mg - xv[i].z * mgx); o.w = rstd * (dv[i].w - mg - xv[i].w * mgx);
-                *(float4*)(dx + (size_t)row * C + 4 * g) = o;
+                st4(dx, ob, (size_t)row * C + 4 * g, o);
             }
         }
     }
@@ -117,6 +131,67 @@ __global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ x, 
         o = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
     }
     ((float4*)out)[i] = o;
+}
+
+// bf16 storage (a bf16 autocast region: nn.GELU runs in the dtype of its input, the projection's bf16 output): 8 values per lane,
+// fp32 arithmetic, one rounding of the result
+__global__ __launch_bounds__(256) void gelu_bf16_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy, uint4* __restrict__ out, long n8) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    float v[8], d[8], o[8];
+    chunk_to_f32<bf16_t>(x[i], v);
+    if (dy) {
+        chunk_to_f32<bf16_t>(dy[i], d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = d[e] * gelu_grad(v[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = gelu_f(v[e]);
+    }
+    out[i] = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+}
+
+// y = LN(x) gamma + beta with x fp32 | bf16 and y fp32 | bf16 (one wave per row, the statistics in fp32 from the row in registers):
+// the training forward whose consumer is a bf16 projection writes the projection's operand directly - torch's autocast runs
+// layer_norm in fp32 and casts its result for the linear that follows (train_camera.py:157-160), the same rounding in one pass
+__global__ __launch_bounds__(256) void layernorm_fwd_mixed_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, void* __restrict__ y, int rows, int C, float eps,
+                                                                  int xb, int yb) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int groups = C >> 2;
+    float4 xv[kLnMaxPerLane];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnMaxPerLane; ++i) {
+        const int g = lane + 64 * i;
+        xv[i] = g < groups ? ld4(x, xb, (size_t)row * C + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += xv[i].x + xv[i].y + xv[i].z + xv[i].w;
+    }
+    const float invC = 1.f / (float)C;
+    const float mean = wave_sum(s) * invC;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnMaxPerLane; ++i) {
+        if (lane + 64 * i < groups) {
+            const float a = xv[i].x - mean, b = xv[i].y - mean, c = xv[i].z - mean, d = xv[i].w - mean;
+            v += a * a + b * b + c * c + d * d;
+        }
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(v) * invC + eps);
+#pragma unroll
+    for (int i = 0; i < kLnMaxPerLane; ++i) {
+        const int g = lane + 64 * i;
+        if (g < groups) {
+            const float4 ga = gamma ? *(const float4*)(gamma + 4 * g) : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 be = beta ? *(const float4*)(beta + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 o;
+            o.x = (xv[i].x - mean) * rstd * ga.x + be.x; o.y = (xv[i].y - mean) * rstd * ga.y + be.y;
+            o.z = (xv[i].z - mean) * rstd * ga.z + be.z; o.w = (xv[i].w - mean) * rstd * ga.w + be.w;
+            st4(y, yb, (size_t)row * C + 4 * g, o);
+        }
+    }
 }
 
 // Weight gradient of a k x k convolution (fp32, channels-last): dW[o][c][a][b] = sum over output pixels m of
@@ -383,7 +458,42 @@ extern "C" int cobevt_layernorm_bwd(const float* x, const float* dy, const float
     int rpb = (rows + 1023) / 1024;
     rpb = ((rpb + 3) / 4) * 4;
     const int blocks = (rows + rpb - 1) / rpb;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, stream, x, dy, gamma, dx, dgamma, dbeta, rows, C, eps, rpb);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, stream, (const void*)x, (const void*)dy, gamma, (void*)dx, dgamma, dbeta, rows, C,
+                       eps, rpb, 0, 0, 0);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// dtypes: [x, dy, dx], 0 = bf16, 1 = fp32 each
+extern "C" int cobevt_layernorm_bwd_t(const void* x, const void* dy, const float* gamma, void* dx, float* dgamma, float* dbeta,
+                                      int rows, int C, float eps, const int* dtypes, hipStream_t stream) {
+    if (!x || !dy || !dx || !dtypes || ((dgamma == nullptr) != (dbeta == nullptr))) return COBEVT_ERR_ARG;
+    for (int i = 0; i < 3; ++i) if (dtypes[i] != 0 && dtypes[i] != 1) return COBEVT_ERR_ARG;
+    if (rows < 1 || C < 4 || C % 4 || C > 1024) return COBEVT_ERR_SHAPE;
+    int rpb = (rows + 1023) / 1024;
+    rpb = ((rpb + 3) / 4) * 4;
+    const int blocks = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, stream, x, dy, gamma, dx, dgamma, dbeta, rows, C, eps, rpb,
+                       dtypes[0] == 0, dtypes[1] == 0, dtypes[2] == 0);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// dtypes: [x, y], 0 = bf16, 1 = fp32 each
+extern "C" int cobevt_layernorm_fwd_t(const void* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps,
+                                      const int* dtypes, hipStream_t stream) {
+    if (!x || !y || !dtypes || ((gamma == nullptr) != (beta == nullptr))) return COBEVT_ERR_ARG;
+    for (int i = 0; i < 2; ++i) if (dtypes[i] != 0 && dtypes[i] != 1) return COBEVT_ERR_ARG;
+    if (rows < 1 || C < 4 || C % 4 || C > 1024) return COBEVT_ERR_SHAPE;
+    hipLaunchKernelGGL(layernorm_fwd_mixed_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, rows, C, eps, dtypes[0] == 0,
+                       dtypes[1] == 0);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// bf16 x / dy / out: out = GELU(x) (dy null) or dy * GELU'(x); n % 8 == 0
+extern "C" int cobevt_gelu_bf16(const void* x, const void* dy, void* out, long n, hipStream_t stream) {
+    if (!x || !out) return COBEVT_ERR_ARG;
+    if (n < 8 || n % 8) return COBEVT_ERR_SHAPE;
+    const long n8 = n / 8;
+    hipLaunchKernelGGL(gelu_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, (const uint4*)x, (const uint4*)dy, (uint4*)out, n8);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 

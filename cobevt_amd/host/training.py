@@ -55,7 +55,7 @@ def swap_attention(attn, x, mask, mode, norm=None):
         raise CobevtHipError("swap attention built for %d agents x %dx%d windows, got %d x %dx%d" % (L, w, w, l, w1, w2))
     x = x.contiguous()
     rows = x.numel() // d
-    xn = ag.layernorm(x, norm) if norm is not None else x
+    xn = ag.layernorm(x, norm, for_projection=True) if norm is not None else x
     qkv = ag.linear(xn.reshape(rows, d), attn.to_qkv)
     a = ag.window_attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], m, m, m, b, attn.heads, attn.scale, rows,
                             bias_table=attn.relative_position_bias_table.weight, bias_L=L, mask=_mask_f32(mask))
@@ -66,7 +66,7 @@ def swap_attention(attn, x, mask, mode, norm=None):
 def feed_forward(ffd, x, norm=None):
     """base_transformer.FeedForward (:112-124) on (..., d), with the PreNormResidual wrapper when `norm` is given."""
     _check(x)
-    xn = ag.layernorm(x.contiguous(), norm) if norm is not None else x
+    xn = ag.layernorm(x.contiguous(), norm, for_projection=True) if norm is not None else x
     h = ag.dropout(ag.gelu(ag.linear(xn, ffd.net[0])), ffd.net[2].p)
     y = ag.dropout(ag.linear(h, ffd.net[3]), ffd.net[4].p)
     return y + x if norm is not None else y
@@ -97,14 +97,14 @@ def swap_fusion_encoder(enc, x, mask):
     for layer in enc.layers:
         y = run_stages(layer.stages(), y, lambda i: mask if layer.uses_mask else None)
     y = y.mean(dim=1)                                                        # Reduce('b m d h w -> b d h w', 'mean')
-    y = ag.linear(ag.layernorm(y.contiguous(), enc.mlp_head[2]), enc.mlp_head[3])
+    y = ag.linear(ag.layernorm(y.contiguous(), enc.mlp_head[2], for_projection=True), enc.mlp_head[3])
     return y.permute(0, 3, 1, 2)
 
 
 def _project(seq, t):
     """nn.Sequential(LayerNorm, Linear) of a cross attention on (..., d) -> (rows, inner)"""
     t = t.contiguous()
-    return ag.linear(ag.layernorm(t, seq[0]).reshape(-1, t.shape[-1]), seq[1])
+    return ag.linear(ag.layernorm(t, seq[0], for_projection=True).reshape(-1, t.shape[-1]), seq[1])
 
 
 def cross_win_attend(m, q_src, k_src, v_src, qmap, kmap, batch, skip):
@@ -133,7 +133,7 @@ def cross_win_attention(m, q, k, v, skip):
 
 def _mlp(x, prenorm, mlp):
     """x + Linear(GELU(Linear(LayerNorm(x))))  (fax_modules.py:411,435)"""
-    return x + ag.linear(ag.gelu(ag.linear(ag.layernorm(x.contiguous(), prenorm), mlp[0])), mlp[2])
+    return x + ag.linear(ag.gelu(ag.linear(ag.layernorm(x.contiguous(), prenorm, for_projection=True), mlp[0])), mlp[2])
 
 
 def _pre_act_conv1x1(seq, x):
@@ -482,7 +482,7 @@ def cav_attention(attn, x, mask, norm):
     x = x.contiguous()
     rows = x.numel() // c
     inner = attn.heads * 32
-    qkv = ag.linear(ag.layernorm(x, norm).reshape(rows, c), attn.to_qkv)
+    qkv = ag.linear(ag.layernorm(x, norm, for_projection=True).reshape(rows, c), attn.to_qkv)
     m = ops.tokmap(0, l, h, w, 1, 1)
     mk = None if mask is None else mask.to(torch.float32).expand(b, h, w, 1, l).reshape(b, h, w, l).contiguous()
     a = ag.window_attention(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], m, m, m, b, attn.heads, attn.scale, rows, mask=mk)

@@ -49,6 +49,9 @@ SIGNATURES = {
     "cobevt_conv_wgrad": (ctypes.c_int, [_vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_conv_wgrad_blocked": (ctypes.c_int, [_vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_gelu": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_long, _vp]),
+    "cobevt_layernorm_fwd_t": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _c_int_p, _vp]),
+    "cobevt_layernorm_bwd_t": (ctypes.c_int, [_vp] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, _c_int_p, _vp]),
+    "cobevt_gelu_bf16": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_long, _vp]),
     "cobevt_window_attention_bwd": (ctypes.c_int, [_vp] * 13 + [_c_int_p, ctypes.c_float, ctypes.c_float, ctypes.c_uint, _vp, _vp]),
     "cobevt_layernorm": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                         ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_int, _vp]),

@@ -216,6 +216,16 @@ int cobevt_attention_dropout_mask(int B, int L, int heads, int Nq, int Nk, float
 int cobevt_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, int rows,
                          int C, float eps, hipStream_t stream);
 int cobevt_gelu(const float* x, const float* dy, float* out, long n, hipStream_t stream);
+/*
+ * The same inside a bf16 autocast region (train_camera.py:157-160: torch's autocast runs layer_norm in fp32 and hands its result to the
+ * bf16 projection that follows; nn.GELU runs in its input's bf16): every tensor fp32 or bf16 (dtype codes 0 = bf16, 1 = fp32), fp32
+ * arithmetic.  cobevt_layernorm_fwd_t dtypes = [x, y]; cobevt_layernorm_bwd_t dtypes = [x, dy, dx]; cobevt_gelu_bf16: all bf16, n % 8 == 0.
+ */
+int cobevt_layernorm_fwd_t(const void* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps, const int* dtypes,
+                           hipStream_t stream);
+int cobevt_layernorm_bwd_t(const void* x, const void* dy, const float* gamma, void* dx, float* dgamma, float* dbeta, int rows, int C,
+                           float eps, const int* dtypes, hipStream_t stream);
+int cobevt_gelu_bf16(const void* x, const void* dy, void* out, long n, hipStream_t stream);
 /* Weight gradient of a k x k convolution, channels-last: dw fp32 (Cout, Cin, k, k) += sum over output pixels of dy (N, Ho, Wo, Cout)
  * x the tap-shifted x (N, H, W, Cin); dw must be zero-initialised (fp32 atomics).  dims (int32[11]): N, H, W, Cin, Ho, Wo, Cout, k,
  * stride, pad, storage type of x and dy (0 bf16 - the autocast path -, 1 fp32).  (cuDNN under autograd in the reference: every

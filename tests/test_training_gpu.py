@@ -265,6 +265,47 @@ def test_layernorm_and_gelu_backward(cuda):
         assert_close(x.grad, xr.grad, 1e-5, "GELU backward")
 
 
+def test_layernorm_and_gelu_inside_bf16_autocast(cuda):
+    """inside a bf16 autocast region: LayerNorm -> projection writes the projection's bf16 operand directly (for_projection) and reads the
+    bf16 gradient coming back, GELU runs on the projection's bf16 output; both against torch's own autocast graph of the same modules
+    (layer_norm in fp32 + cast, gelu in bf16) - forward to one bf16 step on <= 0.1 % of the elements, gradients to bf16 rounding"""
+    g = torch.Generator().manual_seed(9)
+    for rows, C in ((1000, 128), (40, 256)):
+        x0 = torch.randn(rows, C, generator=g) * 2 + 0.5
+        ln = torch.nn.LayerNorm(C).to(cuda)
+        lin = torch.nn.Linear(C, 2 * C).to(cuda)
+        with torch.no_grad():
+            ln.weight.copy_(torch.randn(C, generator=g))
+            ln.bias.copy_(torch.randn(C, generator=g))
+        w = torch.randn(rows, 2 * C, generator=g).to(cuda)
+        with torch.enable_grad():
+            x = _leaf(x0, cuda)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                xn = ag.layernorm(x, ln, for_projection=True)
+                assert xn.dtype == torch.bfloat16
+                h = ag.gelu(ag.linear(xn, lin))
+                assert h.dtype == torch.bfloat16
+                keep = ag.layernorm(x, ln)
+                assert keep.dtype == torch.float32                  # not for a projection: fp32 like torch's autocast
+            (h.float() * w).sum().backward()
+            got = (x.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone(), lin.weight.grad.clone())
+            ln.zero_grad()
+            lin.zero_grad()
+            xr = _leaf(x0, cuda)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                xnr = ln(xr)
+                hr = torch.nn.functional.gelu(torch.nn.functional.linear(xnr, lin.weight, lin.bias))
+            (hr.float() * w).sum().backward()
+        # = torch's fp32 layer_norm + cast up to fp32 rounding of the statistics: the odd element lands on the neighbouring bf16 value
+        assert float((xn != xnr.to(torch.bfloat16)).float().mean()) <= 1e-3, "LayerNorm written as bf16"
+        assert_close(xn.float(), xnr, 1e-2, "LayerNorm written as bf16")
+        assert_close(keep, xnr, 1e-5, "LayerNorm fp32 result inside the region")
+        assert_close(h.float(), hr.float(), 1e-2, "projection + GELU (bf16)")
+        for a, b, what in zip(got, (xr.grad, ln.weight.grad, ln.bias.grad, lin.weight.grad), ("dx", "dgamma", "dbeta", "dW")):
+            assert a.dtype == torch.float32
+            assert_close(a, b, 1e-2, "bf16 autocast LayerNorm/GELU chain %s (%d x %d)" % (what, rows, C))
+
+
 def test_training_slice_fails_loudly(cuda):
     m = _train_module(host.SwapAttention(64, 32, 0.0, 3, 4), cuda)
     x = torch.zeros(1, 3, 2, 2, 4, 4, 64)
