@@ -97,18 +97,21 @@ def _zeros(shape, device, dtype):
     return out
 
 
+USE_ATTN_BWD_BF16 = True      # bf16 autocast regions: the attention backward's products on the bf16 matrix path
+
+
 class WindowAttentionFn(torch.autograd.Function):
     """out = softmax(scale q k^T + bias[rel(q, k)] + mask) v over the gathered windows (cobevt_window_attention_lse /
     cobevt_window_attention_bwd).  q (Rq, d), k, v (Rk, d) token matrices (views with a row stride are accepted), bias_table
     (rows, heads) | None, mask fp32 | None (no gradient).  cfg = (qmap, kmap, omap, batch, heads, scale, bias_L, out_rows,
-    drop_p, drop_seed, seed_dev, want_lse): drop_p > 0 = dropout on the probabilities with the keep mask hashed from drop_seed (+ the
+    drop_p, drop_seed, seed_dev, want_lse, bf16_mm): drop_p > 0 = dropout on the probabilities with the keep mask hashed from drop_seed (+ the
     device word seed_dev, see dropout_step); want_lse: also return the natural log-sum-exp of every query's logits, (batch, windows,
     heads, Nq), as a DIFFERENTIABLE output (its gradient enters the backward kernels as D - dlse)."""
 
     @staticmethod
     @_amp_fwd
     def forward(ctx, q, k, v, bias_table, mask, cfg):
-        qmap, kmap, omap, batch, heads, scale, bias_L, out_rows, drop_p, drop_seed, seed_dev, want_lse = cfg
+        qmap, kmap, omap, batch, heads, scale, bias_L, out_rows, drop_p, drop_seed, seed_dev, want_lse, _ = cfg
         _need_cuda(q, k, v, bias_table, mask)
         ldq, ldk, ldv = _rows_view(q, "q"), _rows_view(k, "k"), _rows_view(v, "v")
         d = heads * 32
@@ -135,7 +138,7 @@ class WindowAttentionFn(torch.autograd.Function):
     @_amp_bwd
     def backward(ctx, dout, dlse=None):
         q, k, v, out, lse, table, mk = ctx.saved_tensors
-        qmap, kmap, omap, batch, heads, scale, bias_L, _, drop_p, drop_seed, seed_dev, want_lse = ctx.cfg
+        qmap, kmap, omap, batch, heads, scale, bias_L, _, drop_p, drop_seed, seed_dev, want_lse, bf16_mm = ctx.cfg
         d = heads * 32
         dout = _f32c(dout, "dout")
         dl = _f32c(dlse, "dlse") if (want_lse and dlse is not None) else None
@@ -150,6 +153,8 @@ class WindowAttentionFn(torch.autograd.Function):
         if q.stride(0) != d or k.stride(0) != d or v.stride(0) != d:
             q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
             dims = _attn_dims(batch, heads, d, d, d, d, table, bias_L, qmap, kmap, omap)
+        if bf16_mm:
+            dims[0] |= 0x100          # the five products on the bf16 matrix path (operands rounded as they are staged; softmax, sums fp32)
         rc = _L.load().cobevt_window_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), _p(dl), _p(dq), _p(dk), _p(dv),
                                                    _p(dbias), _p(table), _p(mk), dims, ctypes.c_float(scale), ctypes.c_float(drop_p),
                                                    ctypes.c_uint(drop_seed), _p(seed_dev), _stream())
@@ -179,8 +184,12 @@ def window_attention(q, k, v, qmap, kmap, omap, batch, heads, scale, out_rows, b
     if drop_p > 0 and drop_seed is None:
         drop_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
         seed_dev = dropout_step(q.device)
+    # inside a bf16 autocast region torch runs the two einsums of the attention (and their gradients) in bf16 and the softmax in fp32
+    # (train_camera.py:157-160).  q / k / v arrive as bf16 projections, so the fp32 forward kernel already sees bf16-representable operands;
+    # the backward kernels take the bf16 matrix path (16 x fewer matrix cycles) with dO, P and dZ rounded like autocast's backward does
+    bf16_mm = USE_ATTN_BWD_BF16 and _autocast_mode() == "bf16"
     cfg = (tuple(qmap), tuple(kmap), tuple(omap), int(batch), int(heads), float(scale), int(bias_L), int(out_rows),
-           float(drop_p), int(drop_seed or 0), seed_dev, bool(return_lse))
+           float(drop_p), int(drop_seed or 0), seed_dev, bool(return_lse), bool(bf16_mm))
     return WindowAttentionFn.apply(q, k, v, bias_table, mask, cfg)
 
 

@@ -44,6 +44,34 @@ constexpr int kPad = 33;      // floats per row of the 32 x 32 LDS tiles
 constexpr float kLog2eB = 1.4426950408889634f;
 constexpr int kMaskedKey = (int)0x80000000;   // per-key info of a masked / out-of-range key
 
+// ---- BF (bf16 matrix path, a bf16 autocast region: torch runs the two einsums and their gradients in bf16, the softmax in fp32 -
+// train_camera.py:157-160): the tensors stay fp32 in memory, the tiles are rounded to bf16 as they are staged ([32 rows][32 d] with 80-byte
+// rows) and every 32 x 32 x 32 product is two v_mfma_f32_32x32x16_bf16 instead of sixteen v_mfma_f32_32x32x2_f32.  Products whose
+// contraction runs over the tile's ROWS take their A operand through ds_read_b64_tr_b16 (4 consecutive rows of a lane's column per read);
+// the k-slots (half h, element e) of instruction m then stand for row 16 m + 8 (e / 4) + 4 h + e % 4 = acc_row(8 m + e, lane), i.e. the B
+// operand is the lane's accumulator registers 8 m .. 8 m + 7 packed to bf16, unchanged.
+constexpr int kRowB = 80;     // bytes per row of a bf16 tile
+typedef short v4s_b __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 tr_read_b(const unsigned char* lds) {
+    const v4s_b r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_b __attribute__((address_space(3)))*)lds);
+    return __builtin_bit_cast(uint2, r);
+}
+// accumulator registers 8 M .. 8 M + 7 as one bf16 operand (constant indices: an indexed copy of the vector went through scratch)
+template <int M> __device__ __forceinline__ bf16x8 pack_acc8(const f32x16& v) {
+    return __builtin_bit_cast(bf16x8, make_uint4(pack_bf2(v[8 * M], v[8 * M + 1]), pack_bf2(v[8 * M + 2], v[8 * M + 3]),
+                                                  pack_bf2(v[8 * M + 4], v[8 * M + 5]), pack_bf2(v[8 * M + 6], v[8 * M + 7])));
+}
+__device__ __forceinline__ uint4 pack8f4(const float4& a, const float4& b) {
+    return make_uint4(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(b.x, b.y), pack_bf2(b.z, b.w));
+}
+// A operand of a product contracting over the rows of `tile` (bf16 [32][kRowB]): this lane's column = lane % 32, rows of instruction m
+__device__ __forceinline__ bf16x8 tr_operand(const unsigned char* tile, int lane, int m) {
+    const int g = lane >> 4, i = lane & 15;
+    const unsigned char* a = tile + (16 * m + 4 * (g >> 1) + (i >> 2)) * kRowB + (16 * (g & 1) + 4 * (i & 3)) * 2;
+    const uint2 lo = tr_read_b(a), hi = tr_read_b(a + 8 * kRowB);
+    return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
+
 __device__ __forceinline__ bool key_visible(const AttnParams& p, int b, int l, const TokCoord& kc) {
     if (p.kmap.mode == 2)
         return p.mask[((((size_t)b * p.L + l) * p.kmap.w1 + kc.i) * p.kmap.w2 + kc.j) * p.kmap.ncam + kc.cam] != 0.f;
@@ -52,7 +80,7 @@ __device__ __forceinline__ bool key_visible(const AttnParams& p, int b, int l, c
     return p.mask[(((size_t)b * p.kmap.HH + ph) * p.kmap.WW + pw) * p.kmap.ncam + kc.cam] != 0.f;
 }
 
-template <bool BIAS, bool MASK>
+template <bool BIAS, bool MASK, bool BF>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnBwdParams bp) {
     const AttnParams& p = bp.a;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -92,7 +120,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnBwdParams bp) {
         if (MASK && k_in) k_ok = key_visible(p, b, l, kc);
         const int kterm = BIAS ? rel_bias_key_term(p.kmap, kc) : 0;
         float kreg[16], vreg[16];
-        {
+        uint4 kbf0 = make_uint4(0, 0, 0, 0), kbf1 = kbf0, vbf0 = kbf0, vbf1 = kbf0;   // BF: d = 16 m + 8 h .. + 7 of this key's K / V rows
+        if constexpr (BF) {
+            const float* kr = (const float*)p.k + krow * p.ldk + p.koff + head * 32 + 8 * h;
+            const float* vr = (const float*)p.v + krow * p.ldv + p.voff + head * 32 + 8 * h;
+            if (k_in) {
+                kbf0 = pack8f4(*(const float4*)kr, *(const float4*)(kr + 4));
+                kbf1 = pack8f4(*(const float4*)(kr + 16), *(const float4*)(kr + 20));
+                vbf0 = pack8f4(*(const float4*)vr, *(const float4*)(vr + 4));
+                vbf1 = pack8f4(*(const float4*)(vr + 16), *(const float4*)(vr + 20));
+            }
+        } else {
             const float* kr = (const float*)p.k + krow * p.ldk + p.koff + head * 32 + h;
             const float* vr = (const float*)p.v + krow * p.ldv + p.voff + head * 32 + h;
 #pragma unroll
@@ -125,10 +163,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnBwdParams bp) {
                     const float4 qv = ok ? *(const float4*)(qp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
                     const float4 dv = ok ? *(const float4*)(dp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
                     const float4 ov = ok ? *(const float4*)(op + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    float* qd = Qs + r * kPad + half * 16 + 4 * c;
-                    float* dd = dOs + r * kPad + half * 16 + 4 * c;
-                    qd[0] = qv.x; qd[1] = qv.y; qd[2] = qv.z; qd[3] = qv.w;
-                    dd[0] = dv.x; dd[1] = dv.y; dd[2] = dv.z; dd[3] = dv.w;
+                    if constexpr (BF) {
+                        *(uint2*)((unsigned char*)Qs + r * kRowB + (half * 16 + 4 * c) * 2) = make_uint2(pack_bf2(qv.x, qv.y), pack_bf2(qv.z, qv.w));
+                        *(uint2*)((unsigned char*)dOs + r * kRowB + (half * 16 + 4 * c) * 2) = make_uint2(pack_bf2(dv.x, dv.y), pack_bf2(dv.z, dv.w));
+                    } else {
+                        float* qd = Qs + r * kPad + half * 16 + 4 * c;
+                        float* dd = dOs + r * kPad + half * 16 + 4 * c;
+                        qd[0] = qv.x; qd[1] = qv.y; qd[2] = qv.z; qd[3] = qv.w;
+                        dd[0] = dv.x; dd[1] = dv.y; dd[2] = dv.z; dd[3] = dv.w;
+                    }
                     dsum += dv.x * ov.x + dv.y * ov.y + dv.z * ov.z + dv.w * ov.w;
                 }
                 dsum += __shfl_xor(dsum, 1, 64);
@@ -145,10 +188,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnBwdParams bp) {
             f32x16 S, dP;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+            if constexpr (BF) {
+                const unsigned char* qa = (const unsigned char*)Qs + ql * kRowB + 16 * h;
+                const unsigned char* da = (const unsigned char*)dOs + ql * kRowB + 16 * h;
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)qa), __builtin_bit_cast(bf16x8, kbf0), S, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)da), __builtin_bit_cast(bf16x8, vbf0), dP, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)(qa + 32)), __builtin_bit_cast(bf16x8, kbf1), S, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)(da + 32)), __builtin_bit_cast(bf16x8, vbf1), dP, 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                S = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[ql * kPad + 2 * i + h], kreg[i], S, 0, 0, 0);
-                dP = __builtin_amdgcn_mfma_f32_32x32x2f32(dOs[ql * kPad + 2 * i + h], vreg[i], dP, 0, 0, 0);
+                for (int i = 0; i < 16; ++i) {
+                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[ql * kPad + 2 * i + h], kreg[i], S, 0, 0, 0);
+                    dP = __builtin_amdgcn_mfma_f32_32x32x2f32(dOs[ql * kPad + 2 * i + h], vreg[i], dP, 0, 0, 0);
+                }
             }
             // ---- P = exp2(z log2e - lse2),  dZ = P (dP - D)
             f32x16 P, dZ;
@@ -167,11 +219,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnBwdParams bp) {
                 if (BIAS && k_ok && dZ[r] != 0.f) atomicAdd(&dtab[bidx], dZ[r]);
             }
             // ---- dV^T += dO^T P,  dK^T += Q^T dZ  (contraction over the query rows; step j pairs rows qj(0) and qj(1))
+            if constexpr (BF) {
+                dVT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand((const unsigned char*)dOs, lane, 0), pack_acc8<0>(P), dVT, 0, 0, 0);
+                dKT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand((const unsigned char*)Qs, lane, 0), pack_acc8<0>(dZ), dKT, 0, 0, 0);
+                dVT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand((const unsigned char*)dOs, lane, 1), pack_acc8<1>(P), dVT, 0, 0, 0);
+                dKT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand((const unsigned char*)Qs, lane, 1), pack_acc8<1>(dZ), dKT, 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int qj = (j & 3) + 8 * (j >> 2) + 4 * h;
-                dVT = __builtin_amdgcn_mfma_f32_32x32x2f32(dOs[qj * kPad + ql], P[j], dVT, 0, 0, 0);
-                dKT = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[qj * kPad + ql], dZ[j], dKT, 0, 0, 0);
+                for (int j = 0; j < 16; ++j) {
+                    const int qj = (j & 3) + 8 * (j >> 2) + 4 * h;
+                    dVT = __builtin_amdgcn_mfma_f32_32x32x2f32(dOs[qj * kPad + ql], P[j], dVT, 0, 0, 0);
+                    dKT = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[qj * kPad + ql], dZ[j], dKT, 0, 0, 0);
+                }
             }
         }
         // ---- reduce dK^T / dV^T over the four waves, store (lane = key column, register r <-> dh row)
@@ -213,7 +272,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnBwdParams bp) {
     }
 }
 
-template <bool BIAS, bool MASK>
+template <bool BIAS, bool MASK, bool BF>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnBwdParams bp) {
     const AttnParams& p = bp.a;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -240,8 +299,24 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnBwdParams bp) {
     const size_t qrow = tok_row(p.qmap, b, l, qc);
     const size_t orow = tok_row(p.omap, b, l, qc);
     float qreg[16], doreg[16];
+    uint4 qbf0 = make_uint4(0, 0, 0, 0), qbf1 = qbf0, dobf0 = qbf0, dobf1 = qbf0;   // BF: d = 16 m + 8 h .. + 7 of this query's Q / dO rows
     float Dq = 0.f;
-    {
+    if constexpr (BF) {
+        const float* qp = (const float*)p.q + qrow * p.ldq + p.qoff + head * 32 + 8 * h;
+        const float* op = (const float*)p.out + orow * p.ldo + p.ooff + head * 32 + 8 * h;
+        const float* dp = bp.dout + orow * p.ldo + p.ooff + head * 32 + 8 * h;
+        if (q_ok) {
+            const float4 d0 = *(const float4*)dp, d1 = *(const float4*)(dp + 4), d2 = *(const float4*)(dp + 16), d3 = *(const float4*)(dp + 20);
+            const float4 o0 = *(const float4*)op, o1 = *(const float4*)(op + 4), o2 = *(const float4*)(op + 16), o3 = *(const float4*)(op + 20);
+            qbf0 = pack8f4(*(const float4*)qp, *(const float4*)(qp + 4));
+            qbf1 = pack8f4(*(const float4*)(qp + 16), *(const float4*)(qp + 20));
+            dobf0 = pack8f4(d0, d1);
+            dobf1 = pack8f4(d2, d3);
+            Dq = d0.x * o0.x + d0.y * o0.y + d0.z * o0.z + d0.w * o0.w + d1.x * o1.x + d1.y * o1.y + d1.z * o1.z + d1.w * o1.w
+               + d2.x * o2.x + d2.y * o2.y + d2.z * o2.z + d2.w * o2.w + d3.x * o3.x + d3.y * o3.y + d3.z * o3.z + d3.w * o3.w;
+        }
+        Dq += __shfl_xor(Dq, 32, 64);
+    } else {
         const float* qp = (const float*)p.q + qrow * p.ldq + p.qoff + head * 32 + h;
         const float* op = (const float*)p.out + orow * p.ldo + p.ooff + head * 32 + h;
         const float* dp = bp.dout + orow * p.ldo + p.ooff + head * 32 + h;
@@ -280,10 +355,15 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnBwdParams bp) {
             for (int c = 0; c < 4; ++c) {
                 const float4 kv = ok ? *(const float4*)(kp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float4 vv = ok ? *(const float4*)(vp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                float* kd = Kt + r * kPad + half * 16 + 4 * c;
-                float* vd = Vt + r * kPad + half * 16 + 4 * c;
-                kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
-                vd[0] = vv.x; vd[1] = vv.y; vd[2] = vv.z; vd[3] = vv.w;
+                if constexpr (BF) {
+                    *(uint2*)((unsigned char*)Kt + r * kRowB + (half * 16 + 4 * c) * 2) = make_uint2(pack_bf2(kv.x, kv.y), pack_bf2(kv.z, kv.w));
+                    *(uint2*)((unsigned char*)Vt + r * kRowB + (half * 16 + 4 * c) * 2) = make_uint2(pack_bf2(vv.x, vv.y), pack_bf2(vv.z, vv.w));
+                } else {
+                    float* kd = Kt + r * kPad + half * 16 + 4 * c;
+                    float* vd = Vt + r * kPad + half * 16 + 4 * c;
+                    kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+                    vd[0] = vv.x; vd[1] = vv.y; vd[2] = vv.z; vd[3] = vv.w;
+                }
             }
             if (half == 0) {
                 bool vis = ok;
@@ -296,10 +376,19 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnBwdParams bp) {
         f32x16 S, dP;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+        if constexpr (BF) {
+            const unsigned char* ka = (const unsigned char*)Kt + ql * kRowB + 16 * h;
+            const unsigned char* va = (const unsigned char*)Vt + ql * kRowB + 16 * h;
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)ka), __builtin_bit_cast(bf16x8, qbf0), S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)va), __builtin_bit_cast(bf16x8, dobf0), dP, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)(ka + 32)), __builtin_bit_cast(bf16x8, qbf1), S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)(va + 32)), __builtin_bit_cast(bf16x8, dobf1), dP, 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            S = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[ql * kPad + 2 * i + h], qreg[i], S, 0, 0, 0);
-            dP = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt[ql * kPad + 2 * i + h], doreg[i], dP, 0, 0, 0);
+            for (int i = 0; i < 16; ++i) {
+                S = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[ql * kPad + 2 * i + h], qreg[i], S, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt[ql * kPad + 2 * i + h], doreg[i], dP, 0, 0, 0);
+            }
         }
         f32x16 dZ;
 #pragma unroll
@@ -314,10 +403,15 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnBwdParams bp) {
             dZ[r] = pr * (keep * dP[r] - Dq);
         }
         // ---- dQ^T += K^T dZ^T  (contraction over the keys = the register index; step j pairs key rows kj(0) and kj(1))
+        if constexpr (BF) {
+            dQT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand((const unsigned char*)Kt, lane, 0), pack_acc8<0>(dZ), dQT, 0, 0, 0);
+            dQT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand((const unsigned char*)Kt, lane, 1), pack_acc8<1>(dZ), dQT, 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int kj = (j & 3) + 8 * (j >> 2) + 4 * h;
-            dQT = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[kj * kPad + ql], dZ[j], dQT, 0, 0, 0);
+            for (int j = 0; j < 16; ++j) {
+                const int kj = (j & 3) + 8 * (j >> 2) + 4 * h;
+                dQT = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[kj * kPad + ql], dZ[j], dQT, 0, 0, 0);
+            }
         }
     }
     // ---- the waves' partial sums meet in LDS; lane = query column, register r <-> dh row
@@ -360,6 +454,7 @@ extern "C" int cobevt_window_attention_bwd(const void* q, const void* k, const v
     AttnParams& p = bp.a;
     const int dtype = dims[0] & 0xff;
     if (dtype != 1) return COBEVT_ERR_UNSUPPORTED;          // fp32 storage (the parity / training mode)
+    const bool bfmm = (dims[0] & 0x100) != 0;               // + 0x100: the products on the bf16 matrix path (bf16 autocast regions)
     p.q = q; p.k = k; p.v = v; p.out = const_cast<void*>(out);
     p.B = dims[1]; p.L = dims[2]; p.heads = dims[3];
     p.ldq = dims[4]; p.ldk = dims[5]; p.ldv = dims[6]; p.ldo = dims[7];
@@ -389,17 +484,19 @@ extern "C" int cobevt_window_attention_bwd(const void* q, const void* k, const v
     if (lds_kv > 160 * 1024) return COBEVT_ERR_UNSUPPORTED;
     const dim3 grid_kv(p.heads * nsplit, nkt, p.B), grid_q(p.L * p.heads, nqt, p.B), block(256);
     const bool hb = p.bias_mode != 0, hm = mask != nullptr;
-#define COBEVT_BWD_LAUNCH(B_, M_)                                                                     \
+#define COBEVT_BWD_LAUNCH2(B_, M_, F_)                                                                \
     do {                                                                                              \
         static cobevt::PerDeviceOnce attr;                                                                   \
-        if (attr.first()) { set_max_lds(attn_bwd_kv_kernel<B_, M_>); set_max_lds(attn_bwd_q_kernel<B_, M_>); } \
-        hipLaunchKernelGGL((attn_bwd_kv_kernel<B_, M_>), grid_kv, block, lds_kv, stream, bp);         \
-        hipLaunchKernelGGL((attn_bwd_q_kernel<B_, M_>), grid_q, block, lds_q, stream, bp);            \
+        if (attr.first()) { set_max_lds(attn_bwd_kv_kernel<B_, M_, F_>); set_max_lds(attn_bwd_q_kernel<B_, M_, F_>); } \
+        hipLaunchKernelGGL((attn_bwd_kv_kernel<B_, M_, F_>), grid_kv, block, lds_kv, stream, bp);     \
+        hipLaunchKernelGGL((attn_bwd_q_kernel<B_, M_, F_>), grid_q, block, lds_q, stream, bp);        \
     } while (0)
+#define COBEVT_BWD_LAUNCH(B_, M_) do { if (bfmm) COBEVT_BWD_LAUNCH2(B_, M_, true); else COBEVT_BWD_LAUNCH2(B_, M_, false); } while (0)
     if (hb && hm) COBEVT_BWD_LAUNCH(true, true);
     else if (hb) COBEVT_BWD_LAUNCH(true, false);
     else if (hm) COBEVT_BWD_LAUNCH(false, true);
     else COBEVT_BWD_LAUNCH(false, false);
 #undef COBEVT_BWD_LAUNCH
+#undef COBEVT_BWD_LAUNCH2
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
