@@ -162,6 +162,72 @@ class WindowAttentionFn(torch.autograd.Function):
         return dq, dk, dv, dbias, None, None
 
 
+class WindowSelfAttentionFn(torch.autograd.Function):
+    """WindowAttentionFn on a fused projection: qkv (rows, 3 d) fp32 holds q | k | v side by side (the to_qkv projection of the swap / global
+    self-attentions, base_transformer.py:200-237, swap_fusion_modules.py:87-128).  The kernels read the three column blocks in place (row
+    stride 3 d) and the backward writes dq | dk | dv into ONE (rows, 3 d) gradient - torch's autograd of three slices is three zero fills,
+    three copies and two adds of the full tensor per attention, plus a cast per slice inside autocast regions."""
+
+    @staticmethod
+    def forward(ctx, qkv, bias_table, mask, cfg):
+        qmap, kmap, omap, batch, heads, scale, bias_L, out_rows, drop_p, drop_seed, seed_dev, want_lse, _ = cfg
+        qkv = _f32c(qkv, "qkv")
+        _need_cuda(qkv, bias_table, mask)
+        d = heads * 32
+        if qkv.dim() != 2 or qkv.shape[1] != 3 * d or want_lse:
+            raise CobevtHipError("window self-attention: qkv must be (rows, 3 * heads * 32)")
+        table = None if bias_table is None else _f32c(bias_table.float(), "bias_table")
+        mk = None if mask is None else _f32c(mask, "mask")
+        L = qmap[6] * qmap[7]
+        nq = qmap[1] * qmap[4] * qmap[5]
+        out = torch.empty((out_rows, d), device=qkv.device, dtype=torch.float32)
+        lse = torch.empty((batch, L, heads, nq), device=qkv.device, dtype=torch.float32)
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        dims = _attn_dims(batch, heads, 3 * d, 3 * d, 3 * d, d, table, bias_L, qmap, kmap, omap)
+        rc = _L.load().cobevt_window_attention_lse(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(table), _p(mk), dims,
+                                                   ctypes.c_float(scale), ctypes.c_float(drop_p), ctypes.c_uint(drop_seed), _p(seed_dev),
+                                                   _stream())
+        _L.check(rc, "cobevt_window_attention_lse")
+        ctx.save_for_backward(qkv, out, lse, table, mk)
+        ctx.cfg = cfg
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse, table, mk = ctx.saved_tensors
+        qmap, kmap, omap, batch, heads, scale, bias_L, _, drop_p, drop_seed, seed_dev, _, bf16_mm = ctx.cfg
+        d = heads * 32
+        dout = _f32c(dout.float(), "dout")
+        dqkv = _zeros(qkv.shape, qkv.device, torch.float32)
+        dbias = None if table is None else _zeros(table.shape, table.device, table.dtype)
+        dims = _attn_dims(batch, heads, 3 * d, 3 * d, 3 * d, d, table, bias_L, qmap, kmap, omap)
+        if bf16_mm:
+            dims[0] |= 0x100
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        dq, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
+        rc = _L.load().cobevt_window_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), None, _p(dq), _p(dk), _p(dv),
+                                                   _p(dbias), _p(table), _p(mk), dims, ctypes.c_float(scale), ctypes.c_float(drop_p),
+                                                   ctypes.c_uint(drop_seed), _p(seed_dev), _stream())
+        _L.check(rc, "cobevt_window_attention_bwd")
+        return dqkv, dbias, None, None
+
+
+def window_self_attention(qkv, tokmap, batch, heads, scale, out_rows, bias_table=None, bias_L=1, mask=None, drop_p=0.0, drop_seed=None):
+    """window_attention(qkv[:, :d], qkv[:, d:2d], qkv[:, 2d:], tokmap, tokmap, tokmap, ...) on the fused (rows, 3 d) projection, one
+    gradient tensor back (WindowSelfAttentionFn)"""
+    seed_dev = None
+    if drop_p > 0 and drop_seed is None:
+        drop_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        seed_dev = dropout_step(qkv.device)
+    mode = _autocast_mode()
+    cfg = (tuple(tokmap), tuple(tokmap), tuple(tokmap), int(batch), int(heads), float(scale), int(bias_L), int(out_rows),
+           float(drop_p), int(drop_seed or 0), seed_dev, False, bool(USE_ATTN_BWD_BF16 and mode == "bf16"))
+    if mode is None:
+        return WindowSelfAttentionFn.apply(qkv, bias_table, mask, cfg)
+    with torch.autocast("cuda", enabled=False):
+        return WindowSelfAttentionFn.apply(qkv.float(), bias_table, None if mask is None else mask.float(), cfg)
+
+
 _DROPOUT_STEP = {}
 
 
@@ -781,6 +847,40 @@ def batch_norm_act(x, bn, residual=None, relu=False):
         y = y + residual if residual is not None else y
         return F.relu(y) if relu else y
     return BatchNormActFn.apply(x, residual, bn.weight, bn.bias, bn, bool(bn.training or not bn.track_running_stats), 1 if relu else 0)
+
+
+class GroupMeanFn(torch.autograd.Function):
+    """mean over dim 1 of a contiguous (B, n, ...) tensor (fp32 or bf16, fp32 arithmetic): the camera mean of CrossWinAttention
+    (fax_modules.py:243) - cobevt_group_mean in both directions (torch: a reduce kernel, and div + expand + copy backward)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = x if x.is_contiguous() else x.contiguous()
+        b, n = x.shape[:2]
+        inner = x.numel() // (b * n)
+        out = torch.empty((b,) + tuple(x.shape[2:]), device=x.device, dtype=x.dtype)
+        _L.check(_L.load().cobevt_group_mean(_p(x), _p(out), ops.dcode(x.dtype), b, n, inner, 0, _stream()), "cobevt_group_mean")
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, n = ctx.shape[:2]
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=dy.dtype)
+        _L.check(_L.load().cobevt_group_mean(_p(dy), _p(dx), ops.dcode(dy.dtype), b, n, dy.numel() // b, 1, _stream()), "cobevt_group_mean")
+        return dx
+
+
+def group_mean(x):
+    """x.mean(dim=1) for (B, n, ...) tensors with 8 | the inner size, fp32 / bf16 (anything else: torch)"""
+    if x.dim() >= 2 and x.shape[1] == 1:
+        return x.squeeze(1)                             # one slab: a view in both directions
+    if x.dim() < 3 or x.dtype not in (torch.float32, torch.bfloat16) or (x.numel() // (x.shape[0] * x.shape[1])) % 8:
+        return x.mean(dim=1)
+    with torch.autocast("cuda", enabled=False):
+        return GroupMeanFn.apply(x)
 
 
 class MaxPool3x3s2Fn(torch.autograd.Function):

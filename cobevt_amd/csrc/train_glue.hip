@@ -441,6 +441,37 @@ __global__ __launch_bounds__(kThreads) void maxpool_bwd_block_kernel(const T* __
     }
 }
 
+// ---- mean over the n slabs of a (B, n, inner) tensor (the camera mean of CrossWinAttention, fax_modules.py:243) and its backward
+// (every slab gets dout / n): one 16-byte piece per thread, fp32 arithmetic.  backward = 0: in (B, n, inner) -> out (B, inner);
+// backward = 1: in (B, inner) -> out (B, n, inner).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void group_mean_kernel(const T* __restrict__ in, T* __restrict__ out, long pieces, long inner8, int n, int backward) {
+    const long gid = (long)blockIdx.x * kThreads + threadIdx.x;          // piece of the (B, inner) side
+    if (gid >= pieces) return;
+    constexpr int E = 16 / sizeof(T);
+    const long b = gid / inner8, r = gid - b * inner8;
+    const float inv = 1.f / (float)n;
+    float v[8], a[8];
+    if (backward) {
+        load8<T>(in + gid * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= inv;
+        for (int k = 0; k < n; ++k) store8<T>(out + ((b * n + k) * inner8 + r) * 8, v);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = 0.f;
+        for (int k = 0; k < n; ++k) {
+            load8<T>(in + ((b * n + k) * inner8 + r) * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] *= inv;
+        store8<T>(out + gid * 8, a);
+    }
+    (void)E;
+}
+
 // ---- nn.PixelUnshuffle(2) on channels-last maps: out[n][h][w][c*4 + 2i + j] = in[n][2h + i][2w + j][c]; inverse = 1: the other way
 template <typename T>
 __global__ __launch_bounds__(kThreads) void pixel_unshuffle_kernel(const T* __restrict__ in, T* __restrict__ out, long total, int Ho, int Wo,
@@ -721,6 +752,17 @@ extern "C" int cobevt_maxpool3x3s2_bwd_t(const void* x, const void* dy, void* dx
     const dim3 grid((unsigned)((items + kThreads - 1) / kThreads));
     if (dtype == 0) hipLaunchKernelGGL(maxpool_bwd_block_kernel<bf16_t>, grid, dim3(kThreads), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo);
     else if (dtype == 1) hipLaunchKernelGGL(maxpool_bwd_block_kernel<float>, grid, dim3(kThreads), 0, stream, (const float*)x, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo);
+    else return COBEVT_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+extern "C" int cobevt_group_mean(const void* in, void* out, int dtype, long B, int n, long inner, int backward, hipStream_t stream) {
+    if (!in || !out) return COBEVT_ERR_ARG;
+    if (B < 1 || n < 1 || inner < 8 || inner % 8 || (backward != 0 && backward != 1)) return COBEVT_ERR_SHAPE;
+    const long pieces = B * (inner / 8);
+    const dim3 grid((unsigned)((pieces + kThreads - 1) / kThreads));
+    if (dtype == 0) hipLaunchKernelGGL(group_mean_kernel<bf16_t>, grid, dim3(kThreads), 0, stream, (const bf16_t*)in, (bf16_t*)out, pieces, inner / 8, n, backward);
+    else if (dtype == 1) hipLaunchKernelGGL(group_mean_kernel<float>, grid, dim3(kThreads), 0, stream, (const float*)in, (float*)out, pieces, inner / 8, n, backward);
     else return COBEVT_ERR_ARG;
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

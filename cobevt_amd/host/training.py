@@ -57,8 +57,8 @@ def swap_attention(attn, x, mask, mode, norm=None):
     rows = x.numel() // d
     xn = ag.layernorm(x, norm, for_projection=True) if norm is not None else x
     qkv = ag.linear(xn.reshape(rows, d), attn.to_qkv)
-    a = ag.window_attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], m, m, m, b, attn.heads, attn.scale, rows,
-                            bias_table=attn.relative_position_bias_table.weight, bias_L=L, mask=_mask_f32(mask))
+    a = ag.window_self_attention(qkv, m, b, attn.heads, attn.scale, rows, bias_table=attn.relative_position_bias_table.weight, bias_L=L,
+                                 mask=_mask_f32(mask))
     y = ag.dropout(ag.linear(a, attn.to_out[0]), attn.to_out[1].p).reshape(x.shape)
     return y + x if norm is not None else y
 
@@ -115,7 +115,7 @@ def cross_win_attend(m, q_src, k_src, v_src, qmap, kmap, batch, skip):
     n = qmap[1]
     qt, kt, vt = _project(m.to_q, q_src), _project(m.to_k, k_src), _project(m.to_v, v_src)
     a = ag.window_attention(qt, kt, vt, qmap, kmap, qmap, batch, m.heads, m.scale, qt.shape[0])
-    z = ag.linear(a, m.proj).reshape((batch, n) + tuple(q_src.shape[2:-1]) + (-1,)).mean(dim=1)
+    z = ag.group_mean(ag.linear(a, m.proj).reshape((batch, n) + tuple(q_src.shape[2:-1]) + (-1,)))
     return z + skip if skip is not None else z
 
 
@@ -224,8 +224,8 @@ def global_attention(m, x):
     qkv = ag.linear(t.reshape(rows, d), m.to_qkv)
     tm = ops.tokmap(0, 1, h, w, h, w)
     # nn.Dropout on the probabilities (attend[1], fax_modules.py:114,161) happens inside the attention kernels
-    a = ag.window_attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], tm, tm, tm, b, m.heads, m.scale, rows,
-                            bias_table=m.rel_pos_bias.weight, bias_L=1, drop_p=m.attend[1].p if m.attend[1].training else 0.0)
+    a = ag.window_self_attention(qkv, tm, b, m.heads, m.scale, rows, bias_table=m.rel_pos_bias.weight, bias_L=1,
+                                 drop_p=m.attend[1].p if m.attend[1].training else 0.0)
     y = ag.dropout(ag.linear(a, m.to_out[0]), m.to_out[1].p)
     return y.reshape(b, h, w, d).permute(0, 3, 1, 2)
 
@@ -485,7 +485,7 @@ def cav_attention(attn, x, mask, norm):
     qkv = ag.linear(ag.layernorm(x, norm, for_projection=True).reshape(rows, c), attn.to_qkv)
     m = ops.tokmap(0, l, h, w, 1, 1)
     mk = None if mask is None else mask.to(torch.float32).expand(b, h, w, 1, l).reshape(b, h, w, l).contiguous()
-    a = ag.window_attention(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], m, m, m, b, attn.heads, attn.scale, rows, mask=mk)
+    a = ag.window_self_attention(qkv, m, b, attn.heads, attn.scale, rows, mask=mk)
     y = ag.dropout(ag.linear(a, attn.to_out[0]), attn.to_out[1].p).reshape(x.shape)
     return y + x
 

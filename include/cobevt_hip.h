@@ -526,6 +526,10 @@ int cobevt_bn_backward(const void* x, const void* y, const void* dy, const float
 /* nn.MaxPool2d(3, 2, 1) backward (resnet_ms.py:70): dx fp32 (N, H, W, C), every element written; first maximum of a window wins. */
 int cobevt_maxpool3x3s2_bwd(const void* x, const void* dy, float* dx, int dtype, int N, int H, int W, int C, hipStream_t stream);
 /* the same with dx in the maps' own type (dtype 0 bf16 | 1 fp32): one thread per 2 x 2 input block and 8 channels */
+/* mean over the n slabs of a contiguous (B, n, inner) tensor -> (B, inner) (backward = 0), or its backward: (B, inner) -> (B, n, inner),
+ * every slab = in / n (backward = 1); dtype 0 bf16 | 1 fp32, 8 | inner.  The camera mean of CrossWinAttention (fax_modules.py:243) under
+ * train_camera.py:143-179. */
+int cobevt_group_mean(const void* in, void* out, int dtype, long B, int n, long inner, int backward, hipStream_t stream);
 int cobevt_maxpool3x3s2_bwd_t(const void* x, const void* dy, void* dx, int dtype, int N, int H, int W, int C, hipStream_t stream);
 /* nn.PixelUnshuffle(2) (fax_modules.py:479) on channels-last maps: inverse 0: (N, 2Ho, 2Wo, C) -> (N, Ho, Wo, 4C); 1: back. */
 int cobevt_pixel_unshuffle2_nhwc(const void* in, void* out, int dtype, int N, int Ho, int Wo, int C, int inverse,

@@ -276,6 +276,44 @@ def test_window_attention_backward_bf16_matrix_path(cuda, mode, ncam, H, W, w1, 
             assert float((a - b).abs().max()) > 0, "the bf16 path did not run"
 
 
+@pytest.mark.parametrize("amp", [False, True])
+def test_window_self_attention_on_the_fused_projection(cuda, amp):
+    """ag.window_self_attention(qkv) = ag.window_attention on the three column blocks of the fused (rows, 3 d) projection: same kernels reading
+    / writing the blocks in place (row stride 3 d), one gradient tensor; bit-identical output, dqkv equal to the concatenated dq | dk | dv
+    (exactly in fp32; inside a bf16 autocast region up to the bf16 rounding of the returned gradient)"""
+    B, heads, ncam, H, W, w1, w2 = 2, 2, 3, 12, 20, 6, 5
+    d = heads * 32
+    tm = ops.tokmap(0, ncam, H, W, w1, w2)
+    rows_n = B * ncam * H * W
+    g = torch.Generator().manual_seed(8)
+    qkv0 = torch.randn(rows_n, 3 * d, generator=g).to(torch.bfloat16).float()
+    table0 = torch.randn((2 * ncam - 1) * (2 * w1 - 1) * (2 * w2 - 1), heads, generator=g)
+    mask = (torch.rand(B, H, W, ncam, generator=g) > 0.3).float()
+    mask[..., 0] = 1.0
+    mask = mask.to(cuda)
+    wgt = torch.randn(rows_n, d, generator=g).to(cuda)
+    res = []
+    for fused in (False, True):
+        with torch.enable_grad():
+            qkv = _leaf(qkv0, cuda)
+            table = _leaf(table0, cuda)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                src = qkv.to(torch.bfloat16) if amp else qkv            # what a projection hands over inside the region
+                if fused:
+                    out = ag.window_self_attention(src, tm, B, heads, 0.37, rows_n, bias_table=table, bias_L=ncam, mask=mask)
+                else:
+                    out = ag.window_attention(src[:, :d], src[:, d:2 * d], src[:, 2 * d:], tm, tm, tm, B, heads, 0.37, rows_n, bias_table=table,
+                                              bias_L=ncam, mask=mask)
+            (out.float() * wgt).sum().backward()
+        res.append((out.detach().float(), qkv.grad.clone(), table.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    if amp:
+        assert_close(res[1][1], res[0][1], 1e-2, "dqkv")
+    else:
+        assert torch.equal(res[1][1], res[0][1])
+    assert_close(res[1][2], res[0][2], 1e-2 if amp else 1e-5, "dbias")
+
+
 def test_layernorm_and_gelu_backward(cuda):
     g = torch.Generator().manual_seed(3)
     for rows, C in ((1000, 128), (37, 64), (5000, 256), (16, 512)):
@@ -839,6 +877,25 @@ def test_maxpool_backward_block_kernel_matches_pixel_kernel(cuda, dtype, n, h, w
     ag._L.check(lib.cobevt_maxpool3x3s2_bwd(ag._p(x), ag._p(dy), ag._p(old), code, n, h, w, c, ag._stream()), "cobevt_maxpool3x3s2_bwd")
     ag._L.check(lib.cobevt_maxpool3x3s2_bwd_t(ag._p(x), ag._p(dy), ag._p(new), code, n, h, w, c, ag._stream()), "cobevt_maxpool3x3s2_bwd_t")
     assert torch.equal(new, old.to(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_group_mean_vs_torch(cuda, dtype):
+    """ag.group_mean (the camera mean of CrossWinAttention) in both directions against torch's mean(dim=1)"""
+    g = torch.Generator().manual_seed(4)
+    for shape in ((2, 4, 33, 128), (1, 3, 5, 7, 8), (3, 1, 9, 16)):
+        x0 = torch.randn(*shape, generator=g).to(dtype)
+        w = torch.randn(shape[:1] + shape[2:], generator=g).to(cuda)
+        with torch.enable_grad():
+            x = x0.to(cuda).requires_grad_(True)
+            y = ag.group_mean(x)
+            (y.float() * w).sum().backward()
+            xr = x0.to(cuda).requires_grad_(True)
+            yr = xr.mean(dim=1)
+            (yr.float() * w).sum().backward()
+        assert y.dtype == dtype and x.grad.dtype == dtype
+        assert_close(y.float(), yr.float(), 1e-6 if dtype == torch.float32 else 4e-3, "group mean")
+        assert_close(x.grad.float(), xr.grad.float(), 1e-6 if dtype == torch.float32 else 4e-3, "group mean backward")
 
 
 def test_sttf_warp_backward_is_the_adjoint(cuda):
