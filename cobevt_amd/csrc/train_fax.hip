@@ -1,0 +1,171 @@
+// Training forms of the FAX query embedding (gfx950): CrossViewSwapAttention's BEV query
+//     v = bev_embed(grid) - cam_embed(camera centre),   query = v / (||v|| + 1e-7) + x        (fax_modules.py:344-372)
+// for every (batch, camera, BEV pixel), channels-last, forward and backward - what torch autograd runs as a K = 2 convolution, a broadcast
+// subtraction, a norm, a division, an addition and a permute + copy over a (B, n, d, H, W) tensor (42 M elements at level 0 of the 5-agent
+// frame: eight 76-us elementwise launches, two 100-us reductions and their copies per step, profiles/r04_train_amp_kernel_trace.txt) under
+// train_camera.py:143-179.  The inference path has this fused since round 1 (cobevt_fax_bev_embed); here the parameters need gradients:
+//     dv = dq / s - v (v . dq) / (r s^2),  r = ||v||, s = r + 1e-7;   dx = sum over cameras of dq;
+//     dW[:, 0] = sum dv gx, dW[:, 1] = sum dv gy, dbias = sum dv, dc[b, cam] = - sum over pixels of dv.
+// d = 128: a row is 32 lanes x 4 channels, one row per half-wave; a workgroup walks the pixels of one batch element, every camera of a pixel
+// in turn (dx is written once, no atomics), keeps the parameter-gradient partial sums in registers and adds them to the global fp32
+// accumulators once (LDS reduction over its 8 half-waves, then one atomic per word).
+// round_bf16 = 1 (inside a bf16 autocast region): the 1x1 convolution's operands and result and the difference are rounded to bf16 as
+// torch's autocast does (conv in bf16, the subtraction of two bf16 tensors in bf16; norm / division / addition in fp32).
+#include "common.hpp"
+
+namespace cobevt {
+namespace {
+
+constexpr int kD = 128;
+constexpr int kMaxCam = 8;
+
+struct BevQueryTrainParams {
+    const float* grid;   // (2, H, W)
+    const float* w;      // (d, 2)
+    const float* bias;   // (d) | null
+    const float* c;      // (B * n, d)
+    const float* x;      // (B, H, W, d)            forward
+    float* out;          // (B, n, H, W, d)         forward
+    const float* dq;     // (B, n, H, W, d)         backward
+    float* dx;           // (B, H, W, d)            backward
+    float* dw;           // (d, 2)  accumulated
+    float* dbias;        // (d)     accumulated | null
+    float* dc;           // (B * n, d) accumulated
+    int B, n, HW, W, round_bf16;
+};
+
+__device__ __forceinline__ float rbf(float v) { return bf2f(f2bf(v)); }
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// v of one row for this lane's 4 channels
+__device__ __forceinline__ float4 embed_v(const BevQueryTrainParams& p, const float4& w0, const float4& w1, const float4& bi, const float4& cc, float gx,
+                                          float gy) {
+    float4 v;
+    if (p.round_bf16) {
+        v.x = rbf(rbf(w0.x * gx + w1.x * gy + bi.x) - cc.x); v.y = rbf(rbf(w0.y * gx + w1.y * gy + bi.y) - cc.y);
+        v.z = rbf(rbf(w0.z * gx + w1.z * gy + bi.z) - cc.z); v.w = rbf(rbf(w0.w * gx + w1.w * gy + bi.w) - cc.w);
+    } else {
+        v.x = w0.x * gx + w1.x * gy + bi.x - cc.x; v.y = w0.y * gx + w1.y * gy + bi.y - cc.y;
+        v.z = w0.z * gx + w1.z * gy + bi.z - cc.z; v.w = w0.w * gx + w1.w * gy + bi.w - cc.w;
+    }
+    return v;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void bev_query_train_kernel(BevQueryTrainParams p) {
+    __shared__ float red[8][kD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane & 31, hw8 = wave * 2 + (lane >> 5);        // channel group, half-wave of the workgroup
+    const int b = blockIdx.y;
+    // this lane's weight columns (w is (d, 2): w[c][0], w[c][1])
+    float4 w0, w1, bi;
+    {
+        const float* wp = p.w + 8 * g;                             // channels 4 g .. 4 g + 3 -> 8 floats
+        const float4 a = *(const float4*)wp, c4 = *(const float4*)(wp + 4);
+        w0 = make_float4(a.x, a.z, c4.x, c4.z);
+        w1 = make_float4(a.y, a.w, c4.y, c4.w);
+        bi = p.bias ? *(const float4*)(p.bias + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.round_bf16) {
+            w0 = make_float4(rbf(w0.x), rbf(w0.y), rbf(w0.z), rbf(w0.w));
+            w1 = make_float4(rbf(w1.x), rbf(w1.y), rbf(w1.z), rbf(w1.w));
+        }
+    }
+    float4 aw0 = make_float4(0.f, 0.f, 0.f, 0.f), aw1 = aw0, ab = aw0;     // backward: parameter-gradient partial sums
+    float4 cc[kMaxCam], ac[kMaxCam];
+#pragma unroll
+    for (int cam = 0; cam < kMaxCam; ++cam) {
+        cc[cam] = cam < p.n ? *(const float4*)(p.c + ((size_t)b * p.n + cam) * kD + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ac[cam] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int pix = blockIdx.x * 8 + hw8; pix < p.HW; pix += gridDim.x * 8) {
+        float gx = p.grid[pix], gy = p.grid[p.HW + pix];
+        if (p.round_bf16) { gx = rbf(gx); gy = rbf(gy); }
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);               // forward: x of the pixel; backward: dx = sum over the cameras of dq
+        if constexpr (!BWD) xv = *(const float4*)(p.x + ((size_t)b * p.HW + pix) * kD + 4 * g);
+#pragma unroll
+        for (int cam = 0; cam < kMaxCam; ++cam) {
+            if (cam >= p.n) break;
+            const float4 v = embed_v(p, w0, w1, bi, cc[cam], gx, gy);
+            const float r = sqrtf(half_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w));
+            const float s = r + 1e-7f;
+            const size_t row = (((size_t)b * p.n + cam) * p.HW + pix) * kD + 4 * g;
+            if constexpr (!BWD) {
+                const float inv = 1.f / s;
+                *(float4*)(p.out + row) = make_float4(v.x * inv + xv.x, v.y * inv + xv.y, v.z * inv + xv.z, v.w * inv + xv.w);
+            } else {
+                const float4 dq = *(const float4*)(p.dq + row);
+                const float vd = half_sum(v.x * dq.x + v.y * dq.y + v.z * dq.z + v.w * dq.w);
+                const float a = 1.f / s, k = r > 0.f ? vd / (r * s * s) : 0.f;
+                const float4 dv = make_float4(dq.x * a - v.x * k, dq.y * a - v.y * k, dq.z * a - v.z * k, dq.w * a - v.w * k);
+                aw0.x += dv.x * gx; aw0.y += dv.y * gx; aw0.z += dv.z * gx; aw0.w += dv.w * gx;
+                aw1.x += dv.x * gy; aw1.y += dv.y * gy; aw1.z += dv.z * gy; aw1.w += dv.w * gy;
+                ab.x += dv.x; ab.y += dv.y; ab.z += dv.z; ab.w += dv.w;
+                ac[cam].x -= dv.x; ac[cam].y -= dv.y; ac[cam].z -= dv.z; ac[cam].w -= dv.w;
+                xv.x += dq.x; xv.y += dq.y; xv.z += dq.z; xv.w += dq.w;
+            }
+        }
+        if constexpr (BWD) *(float4*)(p.dx + ((size_t)b * p.HW + pix) * kD + 4 * g) = xv;
+    }
+    if constexpr (BWD) {
+        // the workgroup's partial sums: LDS reduction over its 8 half-waves, one atomic per word
+        auto flush = [&](const float4& v, float* dst, int stride) __attribute__((always_inline)) {
+            __syncthreads();
+            *(float4*)&red[hw8][4 * g] = v;
+            __syncthreads();
+            if (threadIdx.x < kD) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+                if (dst && t != 0.f) atomicAdd(dst + threadIdx.x * stride, t);
+            }
+        };
+#pragma unroll
+        for (int cam = 0; cam < kMaxCam; ++cam)
+            if (cam < p.n) flush(ac[cam], p.dc + ((size_t)b * p.n + cam) * kD, 1);
+        flush(aw0, p.dw, 2);
+        flush(aw1, p.dw + 1, 2);
+        flush(ab, p.dbias, 1);
+    }
+}
+
+inline int pixel_blocks(int HW, int B) {
+    int blocks = (HW + 7) / 8;                       // one row per half-wave and round
+    const int cap = (2048 + B - 1) / B;              // about 2048 workgroups in all (eight per CU)
+    return blocks > cap ? cap : (blocks < 1 ? 1 : blocks);
+}
+
+}  // namespace
+}  // namespace cobevt
+
+using namespace cobevt;
+
+// C-ABI entry points, see include/cobevt_hip.h
+extern "C" int cobevt_fax_bev_query_train(const float* grid, const float* w, const float* bias, const float* c, const float* x, float* out,
+                                          const int* dims, hipStream_t stream) {
+    // dims: [B, n, H, W, d, round_bf16]
+    if (!grid || !w || !c || !x || !out || !dims) return COBEVT_ERR_ARG;
+    if (dims[4] != kD) return COBEVT_ERR_UNSUPPORTED;
+    BevQueryTrainParams p = {};
+    p.grid = grid; p.w = w; p.bias = bias; p.c = c; p.x = x; p.out = out;
+    p.B = dims[0]; p.n = dims[1]; p.HW = dims[2] * dims[3]; p.W = dims[3]; p.round_bf16 = dims[5] != 0;
+    if (p.B < 1 || p.n < 1 || p.n > kMaxCam || dims[2] < 1 || dims[3] < 1 || p.B > 65535) return COBEVT_ERR_SHAPE;
+    hipLaunchKernelGGL(bev_query_train_kernel<false>, dim3(pixel_blocks(p.HW, p.B), p.B), dim3(256), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+extern "C" int cobevt_fax_bev_query_train_bwd(const float* grid, const float* w, const float* bias, const float* c, const float* dq, float* dx,
+                                              float* dw, float* dbias, float* dc, const int* dims, hipStream_t stream) {
+    // dims as above; dw (d, 2), dbias (d) | null, dc (B * n, d): zero-initialised by the caller, accumulated; dx written
+    if (!grid || !w || !c || !dq || !dx || !dw || !dc || !dims) return COBEVT_ERR_ARG;
+    if (dims[4] != kD) return COBEVT_ERR_UNSUPPORTED;
+    BevQueryTrainParams p = {};
+    p.grid = grid; p.w = w; p.bias = bias; p.c = c; p.dq = dq; p.dx = dx; p.dw = dw; p.dbias = dbias; p.dc = dc;
+    p.B = dims[0]; p.n = dims[1]; p.HW = dims[2] * dims[3]; p.W = dims[3]; p.round_bf16 = dims[5] != 0;
+    if (p.B < 1 || p.n < 1 || p.n > kMaxCam || dims[2] < 1 || dims[3] < 1 || p.B > 65535) return COBEVT_ERR_SHAPE;
+    hipLaunchKernelGGL(bev_query_train_kernel<true>, dim3(pixel_blocks(p.HW, p.B), p.B), dim3(256), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}

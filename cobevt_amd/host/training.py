@@ -179,11 +179,17 @@ def cross_view_swap_attention(m, index, x, bev, feature, I_inv, E_inv):
     dd = _matmul_small(E_inv, cam).reshape(b * n, 4, h, w)
     img_embed = _pointwise(dd, m.img_embed) - c_embed
     img_embed = img_embed / (img_embed.norm(dim=1, keepdim=True) + 1e-7)
+    x_l = x.permute(0, 2, 3, 1).contiguous()
+    query_l = None
     if m.bev_embed_flag:
         grid = getattr(bev, "grid%d" % index)
-        bev_embed = _pointwise(grid[:2][None], m.bev_embed) - c_embed
-        bev_embed = bev_embed / (bev_embed.norm(dim=1, keepdim=True) + 1e-7)
-        query = bev_embed.reshape(b, n, d, H, W) + x[:, None]
+        if ag.USE_FAX_BEV_QUERY and ag.fax_bev_query_fusable(x_l, m.bev_embed, n):
+            # embedding, normalisation, + x and the channels-last layout in one kernel per direction (csrc/train_fax.hip)
+            query_l = ag.fax_bev_query(x_l, grid[:2], m.bev_embed, c_embed.reshape(b * n, d), n)
+        else:
+            bev_embed = _pointwise(grid[:2][None], m.bev_embed) - c_embed
+            bev_embed = bev_embed / (bev_embed.norm(dim=1, keepdim=True) + 1e-7)
+            query = bev_embed.reshape(b, n, d, H, W) + x[:, None]
     else:
         query = x[:, None]
     feat = feature.reshape(b * n, -1, h, w)
@@ -195,8 +201,8 @@ def cross_view_swap_attention(m, index, x, bev, feature, I_inv, E_inv):
     # channels-last token matrices; the window / grid partitions are index arithmetic inside the attention kernels
     key_l = key.reshape(b, n, d, hp, wp).permute(0, 1, 3, 4, 2).contiguous()
     val_l = val.reshape(b, n, d, hp, wp).permute(0, 1, 3, 4, 2).contiguous()
-    query_l = query.permute(0, 1, 3, 4, 2).contiguous()
-    x_l = x.permute(0, 2, 3, 1).contiguous()
+    if query_l is None:
+        query_l = query.permute(0, 1, 3, 4, 2).contiguous()
     nq = query_l.shape[1]
     qmap = ops.tokmap(0, nq, H, W, W1, W2)
     kwin, kgrid = ops.tokmap(0, n, hp, wp, w1, w2), ops.tokmap(1, n, hp, wp, w1, w2)

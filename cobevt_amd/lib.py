@@ -99,6 +99,8 @@ SIGNATURES = {
                                           ctypes.c_int, _vp]),
     "cobevt_maxpool3x3s2_bwd": (ctypes.c_int, [_vp, _vp, _vp] + [ctypes.c_int] * 5 + [_vp]),
     "cobevt_maxpool3x3s2_bwd_t": (ctypes.c_int, [_vp, _vp, _vp] + [ctypes.c_int] * 5 + [_vp]),
+    "cobevt_fax_bev_query_train": (ctypes.c_int, [_vp] * 6 + [_c_int_p, _vp]),
+    "cobevt_fax_bev_query_train_bwd": (ctypes.c_int, [_vp] * 9 + [_c_int_p, _vp]),
     "cobevt_group_mean": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_long, ctypes.c_int, _vp]),
     "cobevt_pixel_unshuffle2_nhwc": (ctypes.c_int, [_vp, _vp] + [ctypes.c_int] * 6 + [_vp]),
     "cobevt_upsample_nearest2_nhwc": (ctypes.c_int, [_vp, _vp] + [ctypes.c_int] * 6 + [_vp]),

@@ -526,6 +526,19 @@ int cobevt_bn_backward(const void* x, const void* y, const void* dy, const float
 /* nn.MaxPool2d(3, 2, 1) backward (resnet_ms.py:70): dx fp32 (N, H, W, C), every element written; first maximum of a window wins. */
 int cobevt_maxpool3x3s2_bwd(const void* x, const void* dy, float* dx, int dtype, int N, int H, int W, int C, hipStream_t stream);
 /* the same with dx in the maps' own type (dtype 0 bf16 | 1 fp32): one thread per 2 x 2 input block and 8 channels */
+/*
+ * Training forms of the FAX BEV query (CrossViewSwapAttention, fax_modules.py:344-372), channels-last, d = 128:
+ *   v = W grid + bias - c[b, cam];  query[b, cam, pixel] = v / (||v|| + 1e-7) + x[b, pixel]
+ * grid (2, H, W), w (d, 2), bias (d) | null, c (B * n, d), x (B, H, W, d), out / dq (B, n, H, W, d), all fp32; n <= 8.
+ * dims (int32[6]): B, n, H, W, d, round_bf16 (1 inside a bf16 autocast region: W, grid, W grid + bias and v rounded to bf16 like torch's
+ * autocast conv / subtraction).  The backward WRITES dx (B, H, W, d) and ADDS into dw (d, 2), dbias (d) | null, dc (B * n, d).
+ * What torch autograd does with a K = 2 convolution, sub, norm, div, add and a permute over the (B, n, d, H, W) tensor
+ * (train_camera.py:143-179).
+ */
+int cobevt_fax_bev_query_train(const float* grid, const float* w, const float* bias, const float* c, const float* x, float* out,
+                               const int* dims, hipStream_t stream);
+int cobevt_fax_bev_query_train_bwd(const float* grid, const float* w, const float* bias, const float* c, const float* dq, float* dx,
+                                   float* dw, float* dbias, float* dc, const int* dims, hipStream_t stream);
 /* mean over the n slabs of a contiguous (B, n, inner) tensor -> (B, inner) (backward = 0), or its backward: (B, inner) -> (B, n, inner),
  * every slab = in / n (backward = 1); dtype 0 bf16 | 1 fp32, 8 | inner.  The camera mean of CrossWinAttention (fax_modules.py:243) under
  * train_camera.py:143-179. */

@@ -898,6 +898,40 @@ def test_group_mean_vs_torch(cuda, dtype):
         assert_close(x.grad.float(), xr.grad.float(), 1e-6 if dtype == torch.float32 else 4e-3, "group mean backward")
 
 
+@pytest.mark.parametrize("amp", [False, True])
+@pytest.mark.parametrize("B,n,H,W", [(2, 4, 16, 16), (1, 6, 5, 9), (3, 1, 8, 8)])
+def test_fax_bev_query_vs_torch(cuda, amp, B, n, H, W):
+    """ag.fax_bev_query (embedding, normalisation, + x, channels-last: one kernel per direction) against the torch graph it replaces
+    (fax_modules.py:344-372: 1x1 conv of the grid - camera embedding, / (norm + 1e-7), + x, permute): output and the gradients of x, the
+    convolution's weight / bias and the camera embedding; fp32 1e-5, inside a bf16 autocast region 1e-2 (the same roundings are applied)"""
+    d = 128
+    g = torch.Generator().manual_seed(B * 10 + n)
+    conv = torch.nn.Conv2d(2, d, 1).to(cuda)
+    x0 = torch.randn(B, d, H, W, generator=g)
+    c0 = torch.randn(B * n, d, 1, 1, generator=g)
+    grid = (torch.randn(3, H, W, generator=g) * 20).to(cuda)
+    wgt = torch.randn(B, n, H, W, d, generator=g).to(cuda)
+    res = []
+    for fused in (True, False):
+        conv.zero_grad()
+        with torch.enable_grad():
+            x, c = _leaf(x0, cuda), _leaf(c0, cuda)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                ce = c.to(torch.bfloat16) if amp else c                 # the camera embedding is a bf16 projection inside the region
+                if fused:
+                    q = ag.fax_bev_query(x.permute(0, 2, 3, 1).contiguous(), grid[:2], conv, ce.reshape(B * n, d), n)
+                else:
+                    e = torch.nn.functional.conv2d(grid[:2][None], conv.weight, conv.bias) - ce
+                    e = e / (e.norm(dim=1, keepdim=True) + 1e-7)
+                    q = (e.reshape(B, n, d, H, W) + x[:, None]).permute(0, 1, 3, 4, 2).contiguous()
+            assert q.shape == (B, n, H, W, d) and q.dtype == torch.float32
+            (q * wgt).sum().backward()
+        res.append((q.detach(), x.grad.clone(), c.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()))
+    tol = 1e-2 if amp else 1e-5
+    for a, b_, what in zip(res[0], res[1], ("query", "dx", "dc", "dW", "dbias")):
+        assert_close(a, b_, tol, "fax_bev_query " + what)
+
+
 def test_sttf_warp_backward_is_the_adjoint(cuda):
     """<warp(x), g> == <x, warp^T(g)> for the regrouping STTF warp (a linear map of x), and the forward equals the inference kernel:
     cobevt_sttf_warp_bwd scatters through the same sample positions cobevt_sttf_warp gathers from"""
