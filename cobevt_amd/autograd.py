@@ -98,6 +98,7 @@ def _zeros(shape, device, dtype):
 
 
 USE_ATTN_BWD_BF16 = True      # bf16 autocast regions: the attention backward's products on the bf16 matrix path
+USE_ATTN_KV2 = True           # ... with two key tiles per workgroup in the dK / dV kernel (False: one, A/B runs)
 
 
 class WindowAttentionFn(torch.autograd.Function):
@@ -154,7 +155,7 @@ class WindowAttentionFn(torch.autograd.Function):
             q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
             dims = _attn_dims(batch, heads, d, d, d, d, table, bias_L, qmap, kmap, omap)
         if bf16_mm:
-            dims[0] |= 0x100          # the five products on the bf16 matrix path (operands rounded as they are staged; softmax, sums fp32)
+            dims[0] |= 0x100 if USE_ATTN_KV2 else 0x300   # the five products on the bf16 matrix path (operands rounded as they are staged; softmax, sums fp32)
         rc = _L.load().cobevt_window_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), _p(dl), _p(dq), _p(dk), _p(dv),
                                                    _p(dbias), _p(table), _p(mk), dims, ctypes.c_float(scale), ctypes.c_float(drop_p),
                                                    ctypes.c_uint(drop_seed), _p(seed_dev), _stream())
@@ -202,7 +203,7 @@ class WindowSelfAttentionFn(torch.autograd.Function):
         dbias = None if table is None else _zeros(table.shape, table.device, table.dtype)
         dims = _attn_dims(batch, heads, 3 * d, 3 * d, 3 * d, d, table, bias_L, qmap, kmap, omap)
         if bf16_mm:
-            dims[0] |= 0x100
+            dims[0] |= 0x100 if USE_ATTN_KV2 else 0x300
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         dq, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
         rc = _L.load().cobevt_window_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), None, _p(dq), _p(dk), _p(dv),

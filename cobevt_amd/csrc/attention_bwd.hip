@@ -272,6 +272,188 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnBwdParams bp) {
     }
 }
 
+// attn_bwd_kv_kernel<.., BF = true> with TWO 32-key tiles per workgroup.  On the bf16 matrix path the kernel is bound by its staging traffic:
+// every key tile of a window reads all the window's Q / dO / O tiles (4 GB through L2 per level-0 launch, 350 us); with two key tiles
+// sharing each staged query tile (and its four row-contracting A operands) that traffic halves.  Same arithmetic, same results.
+struct KeyTileB {
+    uint4 kb0, kb1, vb0, vb1;      // d = 16 m + 8 h .. + 7 of this lane's key, bf16
+    size_t krow;
+    int tk, kterm;
+    bool k_in, k_ok;
+    f32x16 dKT, dVT;
+};
+
+template <bool BIAS, bool MASK>
+__global__ __launch_bounds__(256, 2) void attn_bwd_kv2_kernel(AttnBwdParams bp) {
+    const AttnParams& p = bp.a;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = (float*)smem_raw;
+    constexpr int kWaveFloats = 2 * 32 * kPad + 3 * 32;
+    float* red = smem + 4 * kWaveFloats;                // [3][16][64] cross-wave reduction of dK^T / dV^T
+    float* bias_col = red + 3 * 16 * 64;                // [bias_rows] forward bias (x log2e)   (BIAS)
+    float* dtab = bias_col + (BIAS ? p.bias_rows : 0);  // [bias_rows] gradient accumulator      (BIAS)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, ql = lane & 31;
+    const int b = blockIdx.z, kt2 = blockIdx.y;
+    const int head = blockIdx.x % p.heads, split = blockIdx.x / p.heads;
+    unsigned char* Qs = (unsigned char*)(smem + wave * kWaveFloats);        // per wave: Q and dO tiles bf16 [32][kRowB], lse, D, bias query term [32]
+    unsigned char* dOs = Qs + 32 * kPad * 4;
+    float* lse_s = (float*)(dOs + 32 * kPad * 4);
+    float* D_s = lse_s + 32;
+    int* qb_s = (int*)(D_s + 32);
+
+    if (BIAS) {
+        for (int i = tid; i < p.bias_rows; i += 256) {
+            bias_col[i] = p.bias_table[(size_t)i * p.heads + head] * kLog2eB;
+            dtab[i] = 0.f;
+        }
+    }
+    const float sl2 = p.scale * kLog2eB;
+    const int nqt = (p.Nq + 31) / 32;
+    const int nit = (nqt + 3) / 4;                      // uniform trip count: the loop contains workgroup barriers
+    KeyTileB A, Bt;
+    A.tk = (kt2 * 2) * 32 + ql;
+    Bt.tk = (kt2 * 2 + 1) * 32 + ql;
+    A.k_in = A.tk < p.Nk;
+    Bt.k_in = Bt.tk < p.Nk;
+
+    for (int l = split; l < p.L; l += bp.nsplit) {
+        auto load_key = [&](KeyTileB& T) __attribute__((always_inline)) {
+            const TokCoord kc = tok_coord(p.kmap, T.k_in ? T.tk : 0);
+            T.krow = tok_row(p.kmap, b, l, kc);
+            T.k_ok = T.k_in;
+            if (MASK && T.k_in) T.k_ok = key_visible(p, b, l, kc);
+            T.kterm = BIAS ? rel_bias_key_term(p.kmap, kc) : 0;
+            T.kb0 = T.kb1 = T.vb0 = T.vb1 = make_uint4(0, 0, 0, 0);
+            if (T.k_in) {
+                const float* kr = (const float*)p.k + T.krow * p.ldk + p.koff + head * 32 + 8 * h;
+                const float* vr = (const float*)p.v + T.krow * p.ldv + p.voff + head * 32 + 8 * h;
+                T.kb0 = pack8f4(*(const float4*)kr, *(const float4*)(kr + 4));
+                T.kb1 = pack8f4(*(const float4*)(kr + 16), *(const float4*)(kr + 20));
+                T.vb0 = pack8f4(*(const float4*)vr, *(const float4*)(vr + 4));
+                T.vb1 = pack8f4(*(const float4*)(vr + 16), *(const float4*)(vr + 20));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { T.dKT[r] = 0.f; T.dVT[r] = 0.f; }
+        };
+        load_key(A);
+        load_key(Bt);
+        for (int it = 0; it < nit; ++it) {
+            const int qt = it * 4 + wave;
+            const bool t_ok = qt < nqt;
+            __syncthreads();                            // the previous iteration's tile reads are done (and the tables are ready)
+            // ---- stage the Q and dO tiles (two lanes per query row, 16 floats each), D = rowsum(dO o O), lse, bias query term
+            {
+                const int r = lane >> 1, half = lane & 1;
+                const int tq = qt * 32 + r;
+                const bool ok = t_ok && tq < p.Nq;
+                const TokCoord qc = tok_coord(p.qmap, ok ? tq : 0);
+                const size_t qrow = tok_row(p.qmap, b, l, qc);
+                const size_t orow = tok_row(p.omap, b, l, qc);
+                const float* qp = (const float*)p.q + qrow * p.ldq + p.qoff + head * 32 + half * 16;
+                const float* op = (const float*)p.out + orow * p.ldo + p.ooff + head * 32 + half * 16;
+                const float* dp = bp.dout + orow * p.ldo + p.ooff + head * 32 + half * 16;
+                float dsum = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 qv = ok ? *(const float4*)(qp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 dv = ok ? *(const float4*)(dp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 ov = ok ? *(const float4*)(op + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    *(uint2*)(Qs + r * kRowB + (half * 16 + 4 * c) * 2) = make_uint2(pack_bf2(qv.x, qv.y), pack_bf2(qv.z, qv.w));
+                    *(uint2*)(dOs + r * kRowB + (half * 16 + 4 * c) * 2) = make_uint2(pack_bf2(dv.x, dv.y), pack_bf2(dv.z, dv.w));
+                    dsum += dv.x * ov.x + dv.y * ov.y + dv.z * ov.z + dv.w * ov.w;
+                }
+                dsum += __shfl_xor(dsum, 1, 64);
+                if (half == 0) {
+                    const size_t li = (((size_t)b * p.L + l) * p.heads + head) * p.Nq + (ok ? tq : 0);
+                    D_s[r] = dsum - ((bp.dlse && ok) ? bp.dlse[li] : 0.f);
+                    lse_s[r] = ok ? p.lse[li] : INFINITY;         // invalid rows: lse = +inf -> P = exp2(-inf) = 0
+                    qb_s[r] = BIAS ? rel_bias_query_term(p.kmap, p.bias_L, qc) : 0;
+                }
+            }
+            __syncthreads();
+            // (the staged tile's LDS operands are read again per key tile: holding them across both cost a wave per SIMD in registers)
+            auto tile_step = [&](KeyTileB& T) __attribute__((always_inline)) {
+                // ---- S = Q K^T and dP = dO V^T  (lane = key column, register r <-> query row (r & 3) + 8 (r >> 2) + 4 h)
+                f32x16 S, dP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+                const bf16x8 qa0 = __builtin_bit_cast(bf16x8, *(const uint4*)(Qs + ql * kRowB + 16 * h));
+                const bf16x8 qa1 = __builtin_bit_cast(bf16x8, *(const uint4*)(Qs + ql * kRowB + 16 * h + 32));
+                const bf16x8 da0 = __builtin_bit_cast(bf16x8, *(const uint4*)(dOs + ql * kRowB + 16 * h));
+                const bf16x8 da1 = __builtin_bit_cast(bf16x8, *(const uint4*)(dOs + ql * kRowB + 16 * h + 32));
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa0, __builtin_bit_cast(bf16x8, T.kb0), S, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, __builtin_bit_cast(bf16x8, T.vb0), dP, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa1, __builtin_bit_cast(bf16x8, T.kb1), S, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, __builtin_bit_cast(bf16x8, T.vb1), dP, 0, 0, 0);
+                // ---- P = exp2(z log2e - lse2),  dZ = P (dP - D)
+                f32x16 P, dZ;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = acc_row(r, lane);
+                    float z = S[r] * sl2;
+                    int bidx = 0;
+                    if (BIAS) { bidx = qb_s[row] - T.kterm; z += bias_col[T.k_ok ? bidx : 0]; }
+                    const float pr = T.k_ok ? __builtin_amdgcn_exp2f(z - lse_s[row]) : 0.f;
+                    float keep = 1.f;
+                    if (p.drop_p > 0.f) keep = attn_keep(p, b, l, head, (it * 4 + wave) * 32 + row, T.tk) ? 1.f / (1.f - p.drop_p) : 0.f;
+                    P[r] = pr * keep;
+                    dZ[r] = pr * (keep * dP[r] - D_s[row]);
+                    if (BIAS && T.k_ok && dZ[r] != 0.f) atomicAdd(&dtab[bidx], dZ[r]);
+                }
+                // ---- dV^T += dO^T P,  dK^T += Q^T dZ  (contraction over the query rows)
+                T.dVT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(dOs, lane, 0), pack_acc8<0>(P), T.dVT, 0, 0, 0);
+                T.dKT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(Qs, lane, 0), pack_acc8<0>(dZ), T.dKT, 0, 0, 0);
+                T.dVT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(dOs, lane, 1), pack_acc8<1>(P), T.dVT, 0, 0, 0);
+                T.dKT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(Qs, lane, 1), pack_acc8<1>(dZ), T.dKT, 0, 0, 0);
+            };
+            tile_step(A);
+            tile_step(Bt);
+        }
+        // ---- reduce dK^T / dV^T over the four waves, store (lane = key column, register r <-> dh row)
+        auto reduce_store = [&](KeyTileB& T) __attribute__((always_inline)) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (wave > 0) red[((wave - 1) * 16 + r) * 64 + lane] = T.dKT[r];
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) T.dKT[r] += red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (wave > 0) red[((wave - 1) * 16 + r) * 64 + lane] = T.dVT[r];
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) T.dVT[r] += red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane];
+                if (T.k_in) {
+                    float* dkr = bp.dk + T.krow * p.ldk + p.koff + head * 32 + 4 * h;
+                    float* dvr = bp.dv + T.krow * p.ldv + p.voff + head * 32 + 4 * h;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {           // dh rows 8 g + 4 h .. + 3
+                        *(float4*)(dkr + 8 * g) = make_float4(T.dKT[4 * g] * p.scale, T.dKT[4 * g + 1] * p.scale, T.dKT[4 * g + 2] * p.scale,
+                                                              T.dKT[4 * g + 3] * p.scale);
+                        *(float4*)(dvr + 8 * g) = make_float4(T.dVT[4 * g], T.dVT[4 * g + 1], T.dVT[4 * g + 2], T.dVT[4 * g + 3]);
+                    }
+                }
+            }
+        };
+        reduce_store(A);
+        reduce_store(Bt);
+    }
+    if (BIAS) {
+        __syncthreads();
+        for (int i = tid; i < p.bias_rows; i += 256) {
+            const float g = dtab[i];
+            if (g != 0.f) atomicAdd(bp.dbias + (size_t)i * p.heads + head, g);
+        }
+    }
+}
+
 template <bool BIAS, bool MASK, bool BF>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnBwdParams bp) {
     const AttnParams& p = bp.a;
@@ -483,12 +665,23 @@ extern "C" int cobevt_window_attention_bwd(const void* q, const void* k, const v
     const size_t lds_q = (size_t)(4 * (2 * 32 * kPad + 32) + 3 * 16 * 64) * 4 + (p.bias_mode ? (size_t)p.bias_rows * 4 : 0);
     if (lds_kv > 160 * 1024) return COBEVT_ERR_UNSUPPORTED;
     const dim3 grid_kv(p.heads * nsplit, nkt, p.B), grid_q(p.L * p.heads, nqt, p.B), block(256);
+    // bf16 matrix path: two key tiles per workgroup (halves the staging traffic that bounds it), window shares re-balanced to ~2048 workgroups
+    const bool kv2 = bfmm && nkt >= 2 && (dims[0] & 0x200) == 0;     // (+ 0x200: one key tile per workgroup, for A/B runs)
+    const int nkt2 = (nkt + 1) / 2;
+    AttnBwdParams bp2 = bp;
+    {
+        const long per2 = (long)p.heads * nkt2 * p.B;
+        int ns2 = (int)((2048 + per2 - 1) / per2);
+        bp2.nsplit = ns2 < 1 ? 1 : (ns2 > p.L ? p.L : ns2);
+    }
+    const dim3 grid_kv2(p.heads * bp2.nsplit, nkt2, p.B);
     const bool hb = p.bias_mode != 0, hm = mask != nullptr;
 #define COBEVT_BWD_LAUNCH2(B_, M_, F_)                                                                \
     do {                                                                                              \
         static cobevt::PerDeviceOnce attr;                                                                   \
-        if (attr.first()) { set_max_lds(attn_bwd_kv_kernel<B_, M_, F_>); set_max_lds(attn_bwd_q_kernel<B_, M_, F_>); } \
-        hipLaunchKernelGGL((attn_bwd_kv_kernel<B_, M_, F_>), grid_kv, block, lds_kv, stream, bp);     \
+        if (attr.first()) { set_max_lds(attn_bwd_kv_kernel<B_, M_, F_>); set_max_lds(attn_bwd_q_kernel<B_, M_, F_>); set_max_lds(attn_bwd_kv2_kernel<B_, M_>); } \
+        if (F_ && kv2) hipLaunchKernelGGL((attn_bwd_kv2_kernel<B_, M_>), grid_kv2, block, lds_kv, stream, bp2); \
+        else hipLaunchKernelGGL((attn_bwd_kv_kernel<B_, M_, F_>), grid_kv, block, lds_kv, stream, bp);     \
         hipLaunchKernelGGL((attn_bwd_q_kernel<B_, M_, F_>), grid_q, block, lds_q, stream, bp);        \
     } while (0)
 #define COBEVT_BWD_LAUNCH(B_, M_) do { if (bfmm) COBEVT_BWD_LAUNCH2(B_, M_, true); else COBEVT_BWD_LAUNCH2(B_, M_, false); } while (0)
