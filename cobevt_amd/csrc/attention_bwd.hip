@@ -613,6 +613,124 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnBwdParams bp) {
     }
 }
 
+// attn_bwd_q_kernel<.., BF = true> with FOUR query tiles per workgroup, one per wave, all on the same key tiles: the K / V tile is staged
+// once per workgroup (every thread copies one float4 of each, rounded to bf16; the next tile's loads are issued before this tile's products:
+// two LDS buffers, one barrier per key tile) instead of once per wave and query tile, and a wave keeps its dQ^T to itself - no cross-wave
+// reduction.  Level 0 of the 5-agent frame was 40,960 workgroups of 48 MFMAs each behind 64 KB of staging loads.
+template <bool BIAS, bool MASK>
+__global__ __launch_bounds__(256) void attn_bwd_q4_kernel(AttnBwdParams bp) {
+    const AttnParams& p = bp.a;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int kTile = 32 * kRowB;                   // one bf16 tile
+    unsigned char* tiles = smem_raw;                    // [2 buffers][K, V][kTile]
+    int* kinfo_s = (int*)(smem_raw + 4 * kTile);        // [2][32]: bias key term, or kMaskedKey
+    float* bias_col = (float*)(kinfo_s + 64);           // [bias_rows] forward bias (x log2e)   (BIAS)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, ql = lane & 31;
+    const int b = blockIdx.z, qt = blockIdx.y * 4 + wave;
+    const int l = blockIdx.x / p.heads, head = blockIdx.x - l * p.heads;
+    if (BIAS) {
+        for (int i = tid; i < p.bias_rows; i += 256) bias_col[i] = p.bias_table[(size_t)i * p.heads + head] * kLog2eB;
+    }
+    // ---- this lane's query: Q / dO rows as B operands, lse, D = rowsum(dO o O), bias query term
+    const int tq = qt * 32 + ql;
+    const bool q_ok = tq < p.Nq;
+    const TokCoord qc = tok_coord(p.qmap, q_ok ? tq : 0);
+    const size_t qrow = tok_row(p.qmap, b, l, qc);
+    const size_t orow = tok_row(p.omap, b, l, qc);
+    uint4 qbf0 = make_uint4(0, 0, 0, 0), qbf1 = qbf0, dobf0 = qbf0, dobf1 = qbf0;
+    float Dq = 0.f;
+    if (q_ok) {
+        const float* qp = (const float*)p.q + qrow * p.ldq + p.qoff + head * 32 + 8 * h;
+        const float* op = (const float*)p.out + orow * p.ldo + p.ooff + head * 32 + 8 * h;
+        const float* dp = bp.dout + orow * p.ldo + p.ooff + head * 32 + 8 * h;
+        const float4 d0 = *(const float4*)dp, d1 = *(const float4*)(dp + 4), d2 = *(const float4*)(dp + 16), d3 = *(const float4*)(dp + 20);
+        const float4 o0 = *(const float4*)op, o1 = *(const float4*)(op + 4), o2 = *(const float4*)(op + 16), o3 = *(const float4*)(op + 20);
+        qbf0 = pack8f4(*(const float4*)qp, *(const float4*)(qp + 4));
+        qbf1 = pack8f4(*(const float4*)(qp + 16), *(const float4*)(qp + 20));
+        dobf0 = pack8f4(d0, d1);
+        dobf1 = pack8f4(d2, d3);
+        Dq = d0.x * o0.x + d0.y * o0.y + d0.z * o0.z + d0.w * o0.w + d1.x * o1.x + d1.y * o1.y + d1.z * o1.z + d1.w * o1.w
+           + d2.x * o2.x + d2.y * o2.y + d2.z * o2.z + d2.w * o2.w + d3.x * o3.x + d3.y * o3.y + d3.z * o3.z + d3.w * o3.w;
+    }
+    Dq += __shfl_xor(Dq, 32, 64);
+    const size_t lse_i = (((size_t)b * p.L + l) * p.heads + head) * p.Nq + (q_ok ? tq : 0);
+    if (bp.dlse && q_ok) Dq -= bp.dlse[lse_i];
+    const float lse_q = q_ok ? p.lse[lse_i] : INFINITY;
+    const int qterm = BIAS ? rel_bias_query_term(p.kmap, p.bias_L, qc) : 0;
+    const float sl2 = p.scale * kLog2eB;
+
+    // staging: thread -> key row tid / 8, float4 (tid % 8) of its K and V rows; the row's visibility / bias term by the first of the 8
+    const int sr = tid >> 3, sc = tid & 7;
+    float4 nk = make_float4(0.f, 0.f, 0.f, 0.f), nv = nk;
+    int ninfo = kMaskedKey;
+    auto fetch = [&](int kt) __attribute__((always_inline)) {
+        const int tk = kt * 32 + sr;
+        const bool ok = tk < p.Nk;
+        const TokCoord kc = tok_coord(p.kmap, ok ? tk : 0);
+        const size_t krow = tok_row(p.kmap, b, l, kc);
+        const float4 kv = *(const float4*)((const float*)p.k + krow * p.ldk + p.koff + head * 32 + 4 * sc);
+        const float4 vv = *(const float4*)((const float*)p.v + krow * p.ldv + p.voff + head * 32 + 4 * sc);
+        nk = ok ? kv : make_float4(0.f, 0.f, 0.f, 0.f);
+        nv = ok ? vv : make_float4(0.f, 0.f, 0.f, 0.f);
+        bool vis = ok;
+        if (MASK && ok && sc == 0) vis = key_visible(p, b, l, kc);
+        ninfo = vis ? (BIAS ? rel_bias_key_term(p.kmap, kc) : 0) : kMaskedKey;
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        unsigned char* kt_ = tiles + buf * 2 * kTile;
+        *(uint2*)(kt_ + sr * kRowB + sc * 8) = make_uint2(pack_bf2(nk.x, nk.y), pack_bf2(nk.z, nk.w));
+        *(uint2*)(kt_ + kTile + sr * kRowB + sc * 8) = make_uint2(pack_bf2(nv.x, nv.y), pack_bf2(nv.z, nv.w));
+        if (sc == 0) kinfo_s[buf * 32 + sr] = ninfo;
+    };
+    f32x16 dQT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dQT[r] = 0.f;
+    const int nkt = (p.Nk + 31) / 32;
+    fetch(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        stage(buf);
+        __syncthreads();                                // tile kt (and the bias column) is in LDS; the other buffer is free
+        if (kt + 1 < nkt) fetch(kt + 1);
+        const unsigned char* Kt = tiles + buf * 2 * kTile;
+        const unsigned char* Vt = Kt + kTile;
+        // ---- S^T = K Q^T and dP^T = V dO^T  (lane = query column, register r <-> key row (r & 3) + 8 (r >> 2) + 4 h)
+        f32x16 S, dP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+        const unsigned char* ka = Kt + ql * kRowB + 16 * h;
+        const unsigned char* va = Vt + ql * kRowB + 16 * h;
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)ka), __builtin_bit_cast(bf16x8, qbf0), S, 0, 0, 0);
+        dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)va), __builtin_bit_cast(bf16x8, dobf0), dP, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)(ka + 32)), __builtin_bit_cast(bf16x8, qbf1), S, 0, 0, 0);
+        dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *(const uint4*)(va + 32)), __builtin_bit_cast(bf16x8, dobf1), dP, 0, 0, 0);
+        f32x16 dZ;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kinfo = kinfo_s[buf * 32 + acc_row(r, lane)];
+            const bool vis = kinfo != kMaskedKey;
+            float z = S[r] * sl2;
+            if (BIAS) z += bias_col[vis ? qterm - kinfo : 0];
+            const float pr = vis ? __builtin_amdgcn_exp2f(z - lse_q) : 0.f;
+            float keep = 1.f;
+            if (p.drop_p > 0.f) keep = attn_keep(p, b, l, head, tq, kt * 32 + acc_row(r, lane)) ? 1.f / (1.f - p.drop_p) : 0.f;
+            dZ[r] = pr * (keep * dP[r] - Dq);
+        }
+        // ---- dQ^T += K^T dZ^T  (contraction over the keys = the register index)
+        dQT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(Kt, lane, 0), pack_acc8<0>(dZ), dQT, 0, 0, 0);
+        dQT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(Kt, lane, 1), pack_acc8<1>(dZ), dQT, 0, 0, 0);
+    }
+    if (q_ok) {                                         // lane = query column, register r <-> dh row
+        float* dqr = bp.dq + qrow * p.ldq + p.qoff + head * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *(float4*)(dqr + 8 * g) = make_float4(dQT[4 * g] * p.scale, dQT[4 * g + 1] * p.scale, dQT[4 * g + 2] * p.scale,
+                                                  dQT[4 * g + 3] * p.scale);
+    }
+}
+
 template <typename K>
 static void set_max_lds(K kernel) {
     (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -675,14 +793,17 @@ extern "C" int cobevt_window_attention_bwd(const void* q, const void* k, const v
         bp2.nsplit = ns2 < 1 ? 1 : (ns2 > p.L ? p.L : ns2);
     }
     const dim3 grid_kv2(p.heads * bp2.nsplit, nkt2, p.B);
+    const dim3 grid_q4(p.L * p.heads, (nqt + 3) / 4, p.B);           // ... and four query tiles per workgroup in the dQ kernel
+    const size_t lds_q4 = (size_t)4 * 32 * kRowB + 64 * 4 + (p.bias_mode ? (size_t)p.bias_rows * 4 : 0);
     const bool hb = p.bias_mode != 0, hm = mask != nullptr;
 #define COBEVT_BWD_LAUNCH2(B_, M_, F_)                                                                \
     do {                                                                                              \
         static cobevt::PerDeviceOnce attr;                                                                   \
-        if (attr.first()) { set_max_lds(attn_bwd_kv_kernel<B_, M_, F_>); set_max_lds(attn_bwd_q_kernel<B_, M_, F_>); set_max_lds(attn_bwd_kv2_kernel<B_, M_>); } \
+        if (attr.first()) { set_max_lds(attn_bwd_kv_kernel<B_, M_, F_>); set_max_lds(attn_bwd_q_kernel<B_, M_, F_>); set_max_lds(attn_bwd_kv2_kernel<B_, M_>); set_max_lds(attn_bwd_q4_kernel<B_, M_>); } \
         if (F_ && kv2) hipLaunchKernelGGL((attn_bwd_kv2_kernel<B_, M_>), grid_kv2, block, lds_kv, stream, bp2); \
         else hipLaunchKernelGGL((attn_bwd_kv_kernel<B_, M_, F_>), grid_kv, block, lds_kv, stream, bp);     \
-        hipLaunchKernelGGL((attn_bwd_q_kernel<B_, M_, F_>), grid_q, block, lds_q, stream, bp);        \
+        if (F_ && kv2) hipLaunchKernelGGL((attn_bwd_q4_kernel<B_, M_>), grid_q4, block, lds_q4, stream, bp); \
+        else hipLaunchKernelGGL((attn_bwd_q_kernel<B_, M_, F_>), grid_q, block, lds_q, stream, bp);        \
     } while (0)
 #define COBEVT_BWD_LAUNCH(B_, M_) do { if (bfmm) COBEVT_BWD_LAUNCH2(B_, M_, true); else COBEVT_BWD_LAUNCH2(B_, M_, false); } while (0)
     if (hb && hm) COBEVT_BWD_LAUNCH(true, true);
