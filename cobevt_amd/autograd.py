@@ -87,11 +87,13 @@ def _zeros(shape, device, dtype):
             return torch.zeros(shape, device=device, dtype=dtype)
     else:
         pool = _ZERO_POOL["eager"]
-    st = pool.get(device)
+    # a chunk belongs to the stream it was filled on: a slice handed to work on another stream could be read before the fill ran
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    st = pool.get(key)
     need = (nbytes + 255) // 256 * 256
     if st is None or st[1] + need > st[0].numel():
         st = [torch.zeros(_ZERO_CHUNK_BYTES, device=device, dtype=torch.uint8), 0]
-        pool[device] = st
+        pool[key] = st
     out = st[0][st[1]:st[1] + nbytes].view(dtype).view(shape)
     st[1] += need
     return out
@@ -863,11 +865,13 @@ class GroupMeanFn(torch.autograd.Function):
         out = torch.empty((b,) + tuple(x.shape[2:]), device=x.device, dtype=x.dtype)
         _L.check(_L.load().cobevt_group_mean(_p(x), _p(out), ops.dcode(x.dtype), b, n, inner, 0, _stream()), "cobevt_group_mean")
         ctx.shape = tuple(x.shape)
+        ctx.dtype = x.dtype
         return out
 
     @staticmethod
     def backward(ctx, dy):
         b, n = ctx.shape[:2]
+        dy = dy.to(ctx.dtype)
         dy = dy if dy.is_contiguous() else dy.contiguous()
         dx = torch.empty(ctx.shape, device=dy.device, dtype=dy.dtype)
         _L.check(_L.load().cobevt_group_mean(_p(dy), _p(dx), ops.dcode(dy.dtype), b, n, dy.numel() // b, 1, _stream()), "cobevt_group_mean")
