@@ -892,41 +892,47 @@ USE_FAX_BEV_QUERY = True      # the BEV query of CrossViewSwapAttention as one k
 
 
 class FaxBevQueryFn(torch.autograd.Function):
-    """The BEV query of CrossViewSwapAttention (fax_modules.py:344-372) as one kernel per direction (csrc/train_fax.hip):
-    query[b, cam] = normalize(bev_embed(grid) - c[b, cam]) + x[b], channels-last.  x (B, H, W, 128) fp32, grid (2, H, W), weight (128, 2, 1, 1)
-    and bias (128,) of the 1x1 bev_embed convolution (fp32 masters), c (B * n, 128) the camera-centre embedding -> (B, n, H, W, 128) fp32.
-    round_bf16: inside a bf16 autocast region (the convolution and the subtraction round to bf16 there)."""
+    """The geometry embeddings of CrossViewSwapAttention (fax_modules.py:330-372) as one kernel per direction (csrc/train_fax.hip):
+    out[b, cam] = normalize(conv1x1(grid) - c[b, cam]) (+ x[b]), channels-last.  The BEV query: x (B, H, W, 128) fp32, grid (2, H, W) shared
+    by the batch; the image (key) embedding: x None, grid (B, 4, h, w) the homogeneous ray directions per camera, n = 1.  weight
+    (128, K, 1, 1) / bias (128,) | None the 1x1 convolution (fp32 masters), c (B * n, 128) the camera-centre embedding ->
+    (B, n, H, W, 128) fp32.  round_bf16: inside a bf16 autocast region (the convolution and the subtraction round to bf16 there)."""
 
     @staticmethod
     def forward(ctx, x, grid, weight, bias, c, n, round_bf16):
         _need_cuda(x, grid, weight, bias, c)
-        x, grid, c = _f32c(x, "x"), _f32c(grid, "grid"), _f32c(c, "c")
-        w = _f32c(weight.detach().reshape(weight.shape[0], 2), "bev_embed.weight")
-        bb = None if bias is None else _f32c(bias.detach(), "bev_embed.bias")
-        B, H, W, d = x.shape
-        out = torch.empty((B, n, H, W, d), device=x.device, dtype=torch.float32)
-        dims = _ints([B, n, H, W, d, int(round_bf16)])
+        grid, c = _f32c(grid, "grid"), _f32c(c, "c")
+        x = None if x is None else _f32c(x, "x")
+        kd = weight.shape[1]
+        w = _f32c(weight.detach().reshape(weight.shape[0], kd), "embedding weight")
+        bb = None if bias is None else _f32c(bias.detach(), "embedding bias")
+        per_batch = grid.dim() == 4
+        H, W = grid.shape[-2:]
+        B = grid.shape[0] if per_batch else x.shape[0]
+        d = w.shape[0]
+        out = torch.empty((B, n, H, W, d), device=grid.device, dtype=torch.float32)
+        dims = _ints([B, n, H, W, d, int(round_bf16), kd, int(per_batch)])
         _L.check(_L.load().cobevt_fax_bev_query_train(_p(grid), _p(w), _p(bb), _p(c), _p(x), _p(out), dims, _stream()), "cobevt_fax_bev_query_train")
         ctx.save_for_backward(grid, w, bb, c)
-        ctx.cfg = (B, n, H, W, d, int(round_bf16), tuple(weight.shape), bias is not None)
+        ctx.cfg = (B, n, H, W, d, int(round_bf16), kd, int(per_batch), tuple(weight.shape), bias is not None, x is not None)
         return out
 
     @staticmethod
     def backward(ctx, dq):
         grid, w, bb, c = ctx.saved_tensors
-        B, n, H, W, d, rb, wshape, has_bias = ctx.cfg
+        B, n, H, W, d, rb, kd, per_batch, wshape, has_bias, has_x = ctx.cfg
         dq = _f32c(dq.float(), "dq")
-        dx = torch.empty((B, H, W, d), device=dq.device, dtype=torch.float32)
-        dw = _zeros((d, 2), dq.device, torch.float32)
+        dx = torch.empty((B, H, W, d), device=dq.device, dtype=torch.float32) if has_x else None
+        dw = _zeros((d, kd), dq.device, torch.float32)
         db = _zeros(d, dq.device, torch.float32) if has_bias else None
         dc = _zeros((B * n, d), dq.device, torch.float32)
         _L.check(_L.load().cobevt_fax_bev_query_train_bwd(_p(grid), _p(w), _p(bb), _p(c), _p(dq), _p(dx), _p(dw), _p(db), _p(dc),
-                                                          _ints([B, n, H, W, d, rb]), _stream()), "cobevt_fax_bev_query_train_bwd")
+                                                          _ints([B, n, H, W, d, rb, kd, per_batch]), _stream()), "cobevt_fax_bev_query_train_bwd")
         return dx, None, dw.reshape(wshape), db, dc, None, None
 
 
 def fax_bev_query_fusable(x_l, conv, n):
-    return (x_l.dim() == 4 and x_l.shape[-1] == 128 and 1 <= n <= 8 and conv.weight.shape[1:] == (2, 1, 1) and conv.weight.shape[0] == 128
+    return (x_l.dim() == 4 and x_l.shape[-1] == 128 and 1 <= n <= 8 and tuple(conv.weight.shape[1:]) == (2, 1, 1) and conv.weight.shape[0] == 128
             and conv.weight.dtype == torch.float32)
 
 
@@ -936,6 +942,19 @@ def fax_bev_query(x_l, grid2, conv, c_embed, n):
     mode = _autocast_mode()
     with torch.autocast("cuda", enabled=False):
         return FaxBevQueryFn.apply(x_l.float(), grid2.float(), conv.weight, conv.bias, c_embed.float(), int(n), mode == "bf16")
+
+
+def fax_img_embed_fusable(dd, conv):
+    return (dd.dim() == 4 and dd.shape[1] == 4 and tuple(conv.weight.shape) == (128, 4, 1, 1) and conv.weight.dtype == torch.float32)
+
+
+def fax_img_embed(dd, conv, c_embed):
+    """dd (BN, 4, h, w) homogeneous ray directions (no gradient), conv = the nn.Conv2d(4, 128, 1, bias=False) img_embed container,
+    c_embed (BN, 128) -> normalize(conv(dd) - c_embed) as (BN, h, w, 128) fp32 channels-last (FaxBevQueryFn with one "camera" per batch element)"""
+    mode = _autocast_mode()
+    with torch.autocast("cuda", enabled=False):
+        out = FaxBevQueryFn.apply(None, dd.detach().float().contiguous(), conv.weight, conv.bias, c_embed.float(), 1, mode == "bf16")
+    return out.reshape(dd.shape[0], dd.shape[2], dd.shape[3], out.shape[-1])
 
 
 class MaxPool3x3s2Fn(torch.autograd.Function):

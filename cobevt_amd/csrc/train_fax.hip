@@ -20,17 +20,18 @@ constexpr int kD = 128;
 constexpr int kMaxCam = 8;
 
 struct BevQueryTrainParams {
-    const float* grid;   // (2, H, W)
-    const float* w;      // (d, 2)
+    const float* grid;   // (KD, H, W), or (B, KD, H, W) with grid_stride = KD * H * W (the per-camera ray directions of the image embedding)
+    const float* w;      // (d, KD)
     const float* bias;   // (d) | null
     const float* c;      // (B * n, d)
-    const float* x;      // (B, H, W, d)            forward
+    const float* x;      // (B, H, W, d) | null     forward
     float* out;          // (B, n, H, W, d)         forward
     const float* dq;     // (B, n, H, W, d)         backward
-    float* dx;           // (B, H, W, d)            backward
-    float* dw;           // (d, 2)  accumulated
+    float* dx;           // (B, H, W, d) | null     backward
+    float* dw;           // (d, KD) accumulated
     float* dbias;        // (d)     accumulated | null
     float* dc;           // (B * n, d) accumulated
+    long grid_stride;    // floats between the batch elements' grids (0: one grid for all)
     int B, n, HW, W, round_bf16;
 };
 
@@ -41,55 +42,54 @@ __device__ __forceinline__ float half_sum(float v) {
     return v;
 }
 
-// v of one row for this lane's 4 channels
-__device__ __forceinline__ float4 embed_v(const BevQueryTrainParams& p, const float4& w0, const float4& w1, const float4& bi, const float4& cc, float gx,
-                                          float gy) {
-    float4 v;
-    if (p.round_bf16) {
-        v.x = rbf(rbf(w0.x * gx + w1.x * gy + bi.x) - cc.x); v.y = rbf(rbf(w0.y * gx + w1.y * gy + bi.y) - cc.y);
-        v.z = rbf(rbf(w0.z * gx + w1.z * gy + bi.z) - cc.z); v.w = rbf(rbf(w0.w * gx + w1.w * gy + bi.w) - cc.w);
-    } else {
-        v.x = w0.x * gx + w1.x * gy + bi.x - cc.x; v.y = w0.y * gx + w1.y * gy + bi.y - cc.y;
-        v.z = w0.z * gx + w1.z * gy + bi.z - cc.z; v.w = w0.w * gx + w1.w * gy + bi.w - cc.w;
-    }
-    return v;
-}
-
-template <bool BWD>
+// KD = input channels of the 1x1 embedding convolution: 2 (the BEV grid) or 4 (homogeneous ray directions, fax_modules.py:330-343)
+template <bool BWD, int KD>
 __global__ __launch_bounds__(256) void bev_query_train_kernel(BevQueryTrainParams p) {
     __shared__ float red[8][kD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane & 31, hw8 = wave * 2 + (lane >> 5);        // channel group, half-wave of the workgroup
     const int b = blockIdx.y;
-    // this lane's weight columns (w is (d, 2): w[c][0], w[c][1])
-    float4 w0, w1, bi;
+    // this lane's weight columns: w is (d, KD), channels 4 g .. 4 g + 3 are 4 KD consecutive floats
+    float4 wk[KD], awk[KD];
     {
-        const float* wp = p.w + 8 * g;                             // channels 4 g .. 4 g + 3 -> 8 floats
-        const float4 a = *(const float4*)wp, c4 = *(const float4*)(wp + 4);
-        w0 = make_float4(a.x, a.z, c4.x, c4.z);
-        w1 = make_float4(a.y, a.w, c4.y, c4.w);
-        bi = p.bias ? *(const float4*)(p.bias + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.round_bf16) {
-            w0 = make_float4(rbf(w0.x), rbf(w0.y), rbf(w0.z), rbf(w0.w));
-            w1 = make_float4(rbf(w1.x), rbf(w1.y), rbf(w1.z), rbf(w1.w));
+        float wr[4 * KD];
+#pragma unroll
+        for (int i = 0; i < KD; ++i) *(float4*)&wr[4 * i] = *(const float4*)(p.w + 4 * KD * g + 4 * i);
+#pragma unroll
+        for (int k = 0; k < KD; ++k) {
+            wk[k] = make_float4(wr[k], wr[KD + k], wr[2 * KD + k], wr[3 * KD + k]);
+            if (p.round_bf16) wk[k] = make_float4(rbf(wk[k].x), rbf(wk[k].y), rbf(wk[k].z), rbf(wk[k].w));
+            awk[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    float4 aw0 = make_float4(0.f, 0.f, 0.f, 0.f), aw1 = aw0, ab = aw0;     // backward: parameter-gradient partial sums
+    const float4 bi = p.bias ? *(const float4*)(p.bias + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ab = make_float4(0.f, 0.f, 0.f, 0.f);                   // backward: bias-gradient partial sum
     float4 cc[kMaxCam], ac[kMaxCam];
 #pragma unroll
     for (int cam = 0; cam < kMaxCam; ++cam) {
         cc[cam] = cam < p.n ? *(const float4*)(p.c + ((size_t)b * p.n + cam) * kD + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
         ac[cam] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    const float* grid = p.grid + (size_t)b * p.grid_stride;
     for (int pix = blockIdx.x * 8 + hw8; pix < p.HW; pix += gridDim.x * 8) {
-        float gx = p.grid[pix], gy = p.grid[p.HW + pix];
-        if (p.round_bf16) { gx = rbf(gx); gy = rbf(gy); }
+        float gk[KD];
+#pragma unroll
+        for (int k = 0; k < KD; ++k) {
+            gk[k] = grid[(size_t)k * p.HW + pix];
+            if (p.round_bf16) gk[k] = rbf(gk[k]);
+        }
+        // the convolution's result for this pixel (shared by the cameras)
+        float4 e = bi;
+#pragma unroll
+        for (int k = 0; k < KD; ++k) { e.x += wk[k].x * gk[k]; e.y += wk[k].y * gk[k]; e.z += wk[k].z * gk[k]; e.w += wk[k].w * gk[k]; }
+        if (p.round_bf16) e = make_float4(rbf(e.x), rbf(e.y), rbf(e.z), rbf(e.w));
         float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);               // forward: x of the pixel; backward: dx = sum over the cameras of dq
-        if constexpr (!BWD) xv = *(const float4*)(p.x + ((size_t)b * p.HW + pix) * kD + 4 * g);
+        if constexpr (!BWD) { if (p.x) xv = *(const float4*)(p.x + ((size_t)b * p.HW + pix) * kD + 4 * g); }
 #pragma unroll
         for (int cam = 0; cam < kMaxCam; ++cam) {
             if (cam >= p.n) break;
-            const float4 v = embed_v(p, w0, w1, bi, cc[cam], gx, gy);
+            float4 v = make_float4(e.x - cc[cam].x, e.y - cc[cam].y, e.z - cc[cam].z, e.w - cc[cam].w);
+            if (p.round_bf16) v = make_float4(rbf(v.x), rbf(v.y), rbf(v.z), rbf(v.w));
             const float r = sqrtf(half_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w));
             const float s = r + 1e-7f;
             const size_t row = (((size_t)b * p.n + cam) * p.HW + pix) * kD + 4 * g;
@@ -99,16 +99,18 @@ __global__ __launch_bounds__(256) void bev_query_train_kernel(BevQueryTrainParam
             } else {
                 const float4 dq = *(const float4*)(p.dq + row);
                 const float vd = half_sum(v.x * dq.x + v.y * dq.y + v.z * dq.z + v.w * dq.w);
-                const float a = 1.f / s, k = r > 0.f ? vd / (r * s * s) : 0.f;
-                const float4 dv = make_float4(dq.x * a - v.x * k, dq.y * a - v.y * k, dq.z * a - v.z * k, dq.w * a - v.w * k);
-                aw0.x += dv.x * gx; aw0.y += dv.y * gx; aw0.z += dv.z * gx; aw0.w += dv.w * gx;
-                aw1.x += dv.x * gy; aw1.y += dv.y * gy; aw1.z += dv.z * gy; aw1.w += dv.w * gy;
+                const float a = 1.f / s, kk = r > 0.f ? vd / (r * s * s) : 0.f;
+                const float4 dv = make_float4(dq.x * a - v.x * kk, dq.y * a - v.y * kk, dq.z * a - v.z * kk, dq.w * a - v.w * kk);
+#pragma unroll
+                for (int k = 0; k < KD; ++k) {
+                    awk[k].x += dv.x * gk[k]; awk[k].y += dv.y * gk[k]; awk[k].z += dv.z * gk[k]; awk[k].w += dv.w * gk[k];
+                }
                 ab.x += dv.x; ab.y += dv.y; ab.z += dv.z; ab.w += dv.w;
                 ac[cam].x -= dv.x; ac[cam].y -= dv.y; ac[cam].z -= dv.z; ac[cam].w -= dv.w;
                 xv.x += dq.x; xv.y += dq.y; xv.z += dq.z; xv.w += dq.w;
             }
         }
-        if constexpr (BWD) *(float4*)(p.dx + ((size_t)b * p.HW + pix) * kD + 4 * g) = xv;
+        if constexpr (BWD) { if (p.dx) *(float4*)(p.dx + ((size_t)b * p.HW + pix) * kD + 4 * g) = xv; }
     }
     if constexpr (BWD) {
         // the workgroup's partial sums: LDS reduction over its 8 half-waves, one atomic per word
@@ -126,8 +128,8 @@ __global__ __launch_bounds__(256) void bev_query_train_kernel(BevQueryTrainParam
 #pragma unroll
         for (int cam = 0; cam < kMaxCam; ++cam)
             if (cam < p.n) flush(ac[cam], p.dc + ((size_t)b * p.n + cam) * kD, 1);
-        flush(aw0, p.dw, 2);
-        flush(aw1, p.dw + 1, 2);
+#pragma unroll
+        for (int k = 0; k < KD; ++k) flush(awk[k], p.dw + k, KD);
         flush(ab, p.dbias, 1);
     }
 }
@@ -146,26 +148,32 @@ using namespace cobevt;
 // C-ABI entry points, see include/cobevt_hip.h
 extern "C" int cobevt_fax_bev_query_train(const float* grid, const float* w, const float* bias, const float* c, const float* x, float* out,
                                           const int* dims, hipStream_t stream) {
-    // dims: [B, n, H, W, d, round_bf16]
-    if (!grid || !w || !c || !x || !out || !dims) return COBEVT_ERR_ARG;
-    if (dims[4] != kD) return COBEVT_ERR_UNSUPPORTED;
+    // dims: [B, n, H, W, d, round_bf16, KD (2 | 4), per_batch_grid (0 | 1)]; x nullable
+    if (!grid || !w || !c || !out || !dims) return COBEVT_ERR_ARG;
+    if (dims[4] != kD || (dims[6] != 2 && dims[6] != 4)) return COBEVT_ERR_UNSUPPORTED;
     BevQueryTrainParams p = {};
     p.grid = grid; p.w = w; p.bias = bias; p.c = c; p.x = x; p.out = out;
     p.B = dims[0]; p.n = dims[1]; p.HW = dims[2] * dims[3]; p.W = dims[3]; p.round_bf16 = dims[5] != 0;
+    p.grid_stride = dims[7] ? (long)dims[6] * p.HW : 0;
     if (p.B < 1 || p.n < 1 || p.n > kMaxCam || dims[2] < 1 || dims[3] < 1 || p.B > 65535) return COBEVT_ERR_SHAPE;
-    hipLaunchKernelGGL(bev_query_train_kernel<false>, dim3(pixel_blocks(p.HW, p.B), p.B), dim3(256), 0, stream, p);
+    const dim3 grid_dim(pixel_blocks(p.HW, p.B), p.B);
+    if (dims[6] == 2) hipLaunchKernelGGL((bev_query_train_kernel<false, 2>), grid_dim, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((bev_query_train_kernel<false, 4>), grid_dim, dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
 extern "C" int cobevt_fax_bev_query_train_bwd(const float* grid, const float* w, const float* bias, const float* c, const float* dq, float* dx,
                                               float* dw, float* dbias, float* dc, const int* dims, hipStream_t stream) {
-    // dims as above; dw (d, 2), dbias (d) | null, dc (B * n, d): zero-initialised by the caller, accumulated; dx written
-    if (!grid || !w || !c || !dq || !dx || !dw || !dc || !dims) return COBEVT_ERR_ARG;
-    if (dims[4] != kD) return COBEVT_ERR_UNSUPPORTED;
+    // dims as above; dw (d, KD), dbias (d) | null, dc (B * n, d): zero-initialised by the caller, accumulated; dx (nullable) written
+    if (!grid || !w || !c || !dq || !dw || !dc || !dims) return COBEVT_ERR_ARG;
+    if (dims[4] != kD || (dims[6] != 2 && dims[6] != 4)) return COBEVT_ERR_UNSUPPORTED;
     BevQueryTrainParams p = {};
     p.grid = grid; p.w = w; p.bias = bias; p.c = c; p.dq = dq; p.dx = dx; p.dw = dw; p.dbias = dbias; p.dc = dc;
     p.B = dims[0]; p.n = dims[1]; p.HW = dims[2] * dims[3]; p.W = dims[3]; p.round_bf16 = dims[5] != 0;
+    p.grid_stride = dims[7] ? (long)dims[6] * p.HW : 0;
     if (p.B < 1 || p.n < 1 || p.n > kMaxCam || dims[2] < 1 || dims[3] < 1 || p.B > 65535) return COBEVT_ERR_SHAPE;
-    hipLaunchKernelGGL(bev_query_train_kernel<true>, dim3(pixel_blocks(p.HW, p.B), p.B), dim3(256), 0, stream, p);
+    const dim3 grid_dim(pixel_blocks(p.HW, p.B), p.B);
+    if (dims[6] == 2) hipLaunchKernelGGL((bev_query_train_kernel<true, 2>), grid_dim, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((bev_query_train_kernel<true, 4>), grid_dim, dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }

@@ -177,8 +177,14 @@ def cross_view_swap_attention(m, index, x, bev, feature, I_inv, E_inv):
     c_embed = _pointwise(c.reshape(b * n, 4, 1, 1), m.cam_embed)                         # (bn) d 1 1
     cam = F.pad(_matmul_small(I_inv, pixel), (0, 0, 0, 1), value=1)                      # b n 4 hw
     dd = _matmul_small(E_inv, cam).reshape(b * n, 4, h, w)
-    img_embed = _pointwise(dd, m.img_embed) - c_embed
-    img_embed = img_embed / (img_embed.norm(dim=1, keepdim=True) + 1e-7)
+    img_l = None
+    if ag.USE_FAX_BEV_QUERY and ag.fax_img_embed_fusable(dd, m.img_embed) and d == 128:
+        # the image embedding, normalised, channels-last: one kernel per direction (csrc/train_fax.hip); as an NCHW-shaped view below
+        img_l = ag.fax_img_embed(dd, m.img_embed, c_embed.reshape(b * n, d))
+        img_embed = img_l.permute(0, 3, 1, 2)
+    else:
+        img_embed = _pointwise(dd, m.img_embed) - c_embed
+        img_embed = img_embed / (img_embed.norm(dim=1, keepdim=True) + 1e-7)
     x_l = x.permute(0, 2, 3, 1).contiguous()
     query_l = None
     if m.bev_embed_flag:

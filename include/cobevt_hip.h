@@ -529,9 +529,11 @@ int cobevt_maxpool3x3s2_bwd(const void* x, const void* dy, float* dx, int dtype,
 /*
  * Training forms of the FAX BEV query (CrossViewSwapAttention, fax_modules.py:344-372), channels-last, d = 128:
  *   v = W grid + bias - c[b, cam];  query[b, cam, pixel] = v / (||v|| + 1e-7) + x[b, pixel]
- * grid (2, H, W), w (d, 2), bias (d) | null, c (B * n, d), x (B, H, W, d), out / dq (B, n, H, W, d), all fp32; n <= 8.
- * dims (int32[6]): B, n, H, W, d, round_bf16 (1 inside a bf16 autocast region: W, grid, W grid + bias and v rounded to bf16 like torch's
- * autocast conv / subtraction).  The backward WRITES dx (B, H, W, d) and ADDS into dw (d, 2), dbias (d) | null, dc (B * n, d).
+ * grid (K, H, W) - or (B, K, H, W): the per-camera homogeneous ray directions of the key-side image embedding (fax_modules.py:330-343,
+ * K = 4, n = 1, x null) - w (d, K), bias (d) | null, c (B * n, d), x (B, H, W, d) | null, out / dq (B, n, H, W, d), all fp32; n <= 8.
+ * dims (int32[8]): B, n, H, W, d, round_bf16 (1 inside a bf16 autocast region: W, grid, W grid + bias and v rounded to bf16 like torch's
+ * autocast conv / subtraction), K (2 | 4), per_batch_grid (0 | 1).  The backward WRITES dx (B, H, W, d) (nullable) and ADDS into
+ * dw (d, K), dbias (d) | null, dc (B * n, d).
  * What torch autograd does with a K = 2 convolution, sub, norm, div, add and a permute over the (B, n, d, H, W) tensor
  * (train_camera.py:143-179).
  */

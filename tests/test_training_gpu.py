@@ -932,6 +932,38 @@ def test_fax_bev_query_vs_torch(cuda, amp, B, n, H, W):
         assert_close(a, b_, tol, "fax_bev_query " + what)
 
 
+@pytest.mark.parametrize("amp", [False, True])
+@pytest.mark.parametrize("BN,h,w", [(8, 16, 16), (3, 5, 9)])
+def test_fax_img_embed_vs_torch(cuda, amp, BN, h, w):
+    """ag.fax_img_embed (the key-side image embedding of CrossViewSwapAttention: 1x1 convolution of the per-camera ray directions - camera
+    embedding, normalised, channels-last) against the torch graph it replaces (fax_modules.py:330-343)"""
+    d = 128
+    g = torch.Generator().manual_seed(BN * 7 + h)
+    conv = torch.nn.Conv2d(4, d, 1, bias=False).to(cuda)
+    c0 = torch.randn(BN, d, 1, 1, generator=g)
+    dd = torch.randn(BN, 4, h, w, generator=g).to(cuda)
+    wgt = torch.randn(BN, h, w, d, generator=g).to(cuda)
+    res = []
+    for fused in (True, False):
+        conv.zero_grad()
+        with torch.enable_grad():
+            c = _leaf(c0, cuda)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                ce = c.to(torch.bfloat16) if amp else c
+                if fused:
+                    assert ag.fax_img_embed_fusable(dd, conv)
+                    q = ag.fax_img_embed(dd, conv, ce.reshape(BN, d))
+                else:
+                    e = torch.nn.functional.conv2d(dd, conv.weight) - ce
+                    q = (e / (e.norm(dim=1, keepdim=True) + 1e-7)).permute(0, 2, 3, 1).contiguous()
+            assert q.shape == (BN, h, w, d) and q.dtype == torch.float32
+            (q * wgt).sum().backward()
+        res.append((q.detach(), c.grad.clone(), conv.weight.grad.clone()))
+    tol = 1e-2 if amp else 1e-5
+    for a, b_, what in zip(res[0], res[1], ("embedding", "dc", "dW")):
+        assert_close(a, b_, tol, "fax_img_embed " + what)
+
+
 def test_sttf_warp_backward_is_the_adjoint(cuda):
     """<warp(x), g> == <x, warp^T(g)> for the regrouping STTF warp (a linear map of x), and the forward equals the inference kernel:
     cobevt_sttf_warp_bwd scatters through the same sample positions cobevt_sttf_warp gathers from"""
