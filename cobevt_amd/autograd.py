@@ -797,20 +797,20 @@ class BatchNormActFn(torch.autograd.Function):
         mean, rstd = torch.empty(c, device=dev), torch.empty(c, device=dev)
         g = None if gamma is None else _f32c(gamma.float(), "gamma")
         b = None if beta is None else _f32c(beta.float(), "beta")
-        sums = None
         track = bn.track_running_stats and bn.running_mean is not None
-        if training:        # sums of x - running_mean (when there is one): no cancellation in the variance, fp32 partial sums suffice
-            sums = torch.empty((2, c), device=dev, dtype=torch.float64)
-            _L.check(lib.cobevt_channel_sums(_p(xl), _p(bn.running_mean) if track else None, _p(sums[0]), _p(sums[1]), None,
-                                             _p(_scratch(c, dev)), _SCRATCH_BLOCKS, dt, rows, c, _stream()), "cobevt_channel_sums")
         momentum = 0.1 if bn.momentum is None else bn.momentum
-        _L.check(lib.cobevt_bn_finalize(_p(sums[0]) if training else None, _p(sums[1]) if training else None, _p(g), _p(b),
-                                        _p(bn.running_mean) if track else None, _p(bn.running_var) if track else None,
-                                        _p(scale), _p(shift), _p(mean), _p(rstd), c, rows, ctypes.c_float(bn.eps),
-                                        ctypes.c_float(momentum), int(training), int(bool(training and track)),
-                                        _p(bn.num_batches_tracked) if (training and track and bn.num_batches_tracked is not None) else None,
-                                        _stream()),
-                 "cobevt_bn_finalize")
+        if training:
+            # batch statistics: sums of x - running_mean (when there is one: no cancellation in the variance, fp32 partial sums suffice)
+            # per workgroup, then one launch that reduces them and finishes every channel incl. the running-stat update
+            _L.check(lib.cobevt_bn_batch_stats(_p(xl), _p(g), _p(b), _p(bn.running_mean) if track else None, _p(bn.running_var) if track else None,
+                                               _p(scale), _p(shift), _p(mean), _p(rstd), _p(_scratch(c, dev)), _SCRATCH_BLOCKS, dt, rows, c,
+                                               ctypes.c_float(bn.eps), ctypes.c_float(momentum),
+                                               _p(bn.num_batches_tracked) if (track and bn.num_batches_tracked is not None) else None, _stream()),
+                     "cobevt_bn_batch_stats")
+        else:
+            _L.check(lib.cobevt_bn_finalize(None, None, _p(g), _p(b), _p(bn.running_mean), _p(bn.running_var), _p(scale), _p(shift), _p(mean),
+                                            _p(rstd), c, rows, ctypes.c_float(bn.eps), ctypes.c_float(momentum), 0, 0, None, _stream()),
+                     "cobevt_bn_finalize")
         y = torch.empty_like(xl)
         _L.check(lib.cobevt_bn_apply(_p(xl), _p(rl), _p(scale), _p(shift), _p(y), dt, rows, c, int(act), _stream()), "cobevt_bn_apply")
         ctx.save_for_backward(xl, y if act else None, mean, rstd, g)

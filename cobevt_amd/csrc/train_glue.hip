@@ -90,6 +90,40 @@ __global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const doub
 
 // ---- BatchNorm finalize: stats (training: from the sums; eval: the running statistics) -> per-channel scale / shift, mean / rstd
 // saved for backward, running statistics updated in place (momentum, unbiased variance) as nn.BatchNorm2d does
+// reduce_partials_strided_kernel + bn_finalize_kernel in one launch (training statistics): a wave per channel sums the workgroups' partial
+// pairs [blk][2][C] and its first lane finishes the channel (statistics of x - running_mean when `shifted`, read before the update)
+__global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const double* __restrict__ partial, int nblk, const float* gamma, const float* beta,
+                                                                 float* running_mean, float* running_var, float* scale, float* shift, float* mean_out,
+                                                                 float* rstd_out, int C, double rows, float eps, float momentum, int shifted,
+                                                                 long long* batches_tracked) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = lane; b < nblk; b += 64) {
+        s += partial[((size_t)b * 2) * C + c];
+        q += partial[((size_t)b * 2 + 1) * C + c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (lane) return;
+    if (c == 0 && batches_tracked) *batches_tracked += 1;
+    const double d = s / rows;
+    double var = q / rows - d * d;
+    const double mean = d + (shifted ? (double)running_mean[c] : 0.0);
+    if (var < 0.0) var = 0.0;
+    if (running_mean) {
+        const double unbiased = rows > 1.0 ? var * rows / (rows - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
+    scale[c] = g * rstd;
+    shift[c] = bb - (float)mean * g * rstd;
+    mean_out[c] = (float)mean;
+    rstd_out[c] = rstd;
+}
+
 __global__ void bn_finalize_kernel(const double* sum, const double* sumsq, const float* gamma, const float* beta, float* running_mean,
                                    float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out, int C,
                                    double rows, float eps, float momentum, int training, int shifted, long long* batches_tracked) {
@@ -668,6 +702,23 @@ extern "C" int cobevt_bn_finalize(const double* sum, const double* sumsq, const 
     if (shifted && !running_mean) return COBEVT_ERR_ARG;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sum, sumsq, gamma, beta, running_mean, running_var,
                        scale, shift, mean, rstd, C, (double)rows, eps, momentum, training, shifted, batches_tracked);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// cobevt_channel_sums (with the square sums, shifted by running_mean when it is given) + cobevt_bn_finalize (training = 1) in two launches
+// instead of three; running_mean / running_var nullable together (no tracking: plain batch statistics); 8 | C
+extern "C" int cobevt_bn_batch_stats(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* scale,
+                                     float* shift, float* mean, float* rstd, double* scratch, int scratch_blocks, int dtype, long rows, int C,
+                                     float eps, float momentum, long long* batches_tracked, hipStream_t stream) {
+    if (!x || !scale || !shift || !mean || !rstd || !scratch || scratch_blocks < 1) return COBEVT_ERR_ARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return COBEVT_ERR_ARG;
+    if (!groups_ok(C) || rows < 1 || (dtype != 0 && dtype != 1)) return COBEVT_ERR_SHAPE;
+    int rpb;
+    const int blocks = row_blocks(rows, C, &rpb, scratch_blocks);
+    if (dtype == 0) hipLaunchKernelGGL((channel_sums_kernel<bf16_t, true>), dim3(blocks), dim3(kThreads), 0, stream, (const bf16_t*)x, running_mean, scratch, rows, C, rpb);
+    else hipLaunchKernelGGL((channel_sums_kernel<float, true>), dim3(blocks), dim3(kThreads), 0, stream, (const float*)x, running_mean, scratch, rows, C, rpb);
+    hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, scratch, blocks, gamma, beta, running_mean, running_var, scale,
+                       shift, mean, rstd, C, (double)rows, eps, momentum, running_mean != nullptr, batches_tracked);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 

@@ -93,6 +93,7 @@ SIGNATURES = {
                                                 ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
     "cobevt_channel_sums": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_int, _vp]),
     "cobevt_f64_to_f32": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp]),
+    "cobevt_bn_batch_stats": (ctypes.c_int, [_vp] * 10 + [ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp, _vp]),
     "cobevt_bn_finalize": (ctypes.c_int, [_vp] * 10 + [ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     "cobevt_bn_apply": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, _vp]),
     "cobevt_bn_backward": (ctypes.c_int, [_vp] * 9 + [ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int,

@@ -514,6 +514,11 @@ int cobevt_f64_to_f32(const double* in, float* out, int n, hipStream_t stream);
 int cobevt_bn_finalize(const double* sum, const double* sumsq, const float* gamma, const float* beta, float* running_mean,
                        float* running_var, float* scale, float* shift, float* mean, float* rstd, int C, long rows, float eps,
                        float momentum, int training, int shifted, long long* batches_tracked, hipStream_t stream);
+/* cobevt_channel_sums (x and x^2, shifted by running_mean when given) + cobevt_bn_finalize(training = 1) as two launches instead of three:
+ * the batch statistics of a training BatchNorm2d incl. the running-stat update; running_mean / running_var nullable together; 8 | C. */
+int cobevt_bn_batch_stats(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* scale,
+                          float* shift, float* mean, float* rstd, double* scratch, int scratch_blocks, int dtype, long rows, int C,
+                          float eps, float momentum, long long* batches_tracked, hipStream_t stream);
 /* y = act(x * scale[c] + shift[c] (+ residual)), act 0 none / 1 ReLU. */
 int cobevt_bn_apply(const void* x, const void* residual, const float* scale, const float* shift, void* y, int dtype, long rows,
                     int C, int act, hipStream_t stream);
