@@ -227,8 +227,89 @@ def window_self_attention(qkv, tokmap, batch, heads, scale, out_rows, bias_table
            float(drop_p), int(drop_seed or 0), seed_dev, False, bool(USE_ATTN_BWD_BF16 and mode == "bf16"))
     if mode is None:
         return WindowSelfAttentionFn.apply(qkv, bias_table, mask, cfg)
+    half = _half_attention_ok((qkv,), drop_p, False, heads) and qkv.shape[1] == 3 * heads * 32
     with torch.autocast("cuda", enabled=False):
+        if half:
+            return WindowAttentionHalfFn.apply(qkv, None, None, bias_table, mask, cfg, True)
         return WindowSelfAttentionFn.apply(qkv.float(), bias_table, None if mask is None else mask.float(), cfg)
+
+
+class WindowAttentionHalfFn(torch.autograd.Function):
+    """WindowAttentionFn inside a bf16 autocast region, on the projections' own bf16 tensors: no casts at the boundary.  Forward: the bf16
+    gather kernel with its log-sum-exp output (bf16 MFMAs, fp32 softmax - what torch's autocast does with the two einsums and the softmax,
+    train_camera.py:157-160), out in bf16; backward: the bf16-matrix-path kernels reading q / k / v / out / dout and writing dq / dk / dv
+    in bf16 (fp32 accumulation; the bias-table gradient stays fp32).  q, k, v: (rows, d) bf16 with unit column stride - column blocks of
+    one fused (rows, 3 d) projection when `fused` (then ONE (rows, 3 d) gradient is returned for it), else three tensors."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, bias_table, mask, cfg, fused):
+        qmap, kmap, omap, batch, heads, scale, bias_L, out_rows, drop_p, drop_seed, seed_dev, want_lse, _ = cfg
+        d = heads * 32
+        qkv = None
+        if fused:
+            qkv = q if q.is_contiguous() else q.contiguous()
+            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        _need_cuda(q, k, v, bias_table, mask)
+        for t in (q, k, v):
+            if t.dim() != 2 or t.dtype != torch.bfloat16 or t.shape[1] != d or t.stride(1) != 1 or t.stride(0) % 8 or t.data_ptr() % 16:
+                raise CobevtHipError("bf16 window attention: (rows, heads * 32) bf16 matrices with unit column stride, 16-byte aligned rows")
+        if want_lse or drop_p > 0:
+            raise CobevtHipError("bf16 window attention: no log-sum-exp output, no probability dropout")
+        table = None if bias_table is None else _f32c(bias_table.float(), "bias_table")
+        mk = None if mask is None else _f32c(mask.float(), "mask")
+        L = qmap[6] * qmap[7]
+        nq = qmap[1] * qmap[4] * qmap[5]
+        out = torch.empty((out_rows, d), device=q.device, dtype=torch.bfloat16)
+        lse = torch.empty((batch, L, heads, nq), device=q.device, dtype=torch.float32)
+        dims = _attn_dims(batch, heads, q.stride(0), k.stride(0), v.stride(0), d, table, bias_L, qmap, kmap, omap)
+        dims[0] = ops.BF16
+        rc = _L.load().cobevt_window_attention_lse(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(table), _p(mk), dims,
+                                                   ctypes.c_float(scale), ctypes.c_float(0.0), ctypes.c_uint(0), None, _stream())
+        _L.check(rc, "cobevt_window_attention_lse")
+        if fused:
+            ctx.save_for_backward(qkv, out, lse, table, mk)
+        else:
+            ctx.save_for_backward(q, k, v, out, lse, table, mk)
+        ctx.cfg = cfg
+        ctx.fused = bool(fused)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qmap, kmap, omap, batch, heads, scale, bias_L, _, _, _, _, _, _ = ctx.cfg
+        d = heads * 32
+        if ctx.fused:
+            qkv, out, lse, table, mk = ctx.saved_tensors
+            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+            dqkv = torch.zeros_like(qkv)
+            dq, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
+        else:
+            q, k, v, out, lse, table, mk = ctx.saved_tensors
+            # the kernels share one row stride per operand between a tensor and its gradient
+            dq, dk, dv = (torch.zeros((t.shape[0], t.stride(0)), device=t.device, dtype=torch.bfloat16)[:, :d] if t.stride(0) != d
+                          else torch.zeros_like(t) for t in (q, k, v))
+        dout = dout.to(torch.bfloat16)
+        dout = dout if dout.is_contiguous() else dout.contiguous()
+        dbias = None if table is None else _zeros(table.shape, table.device, table.dtype)
+        dims = _attn_dims(batch, heads, q.stride(0), k.stride(0), v.stride(0), d, table, bias_L, qmap, kmap, omap)
+        dims[0] = ops.BF16 | 0x100
+        rc = _L.load().cobevt_window_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), None, _p(dq), _p(dk), _p(dv),
+                                                   _p(dbias), _p(table), _p(mk), dims, ctypes.c_float(scale), ctypes.c_float(0.0),
+                                                   ctypes.c_uint(0), None, _stream())
+        _L.check(rc, "cobevt_window_attention_bwd")
+        if ctx.fused:
+            return dqkv, None, None, dbias, None, None, None
+        return dq, dk, dv, dbias, None, None, None
+
+
+USE_ATTN_HALF_IO = True       # bf16 autocast regions: bf16 q / k / v / out / gradients through the attention Functions (no boundary casts)
+
+
+def _half_attention_ok(tensors, drop_p, return_lse, heads):
+    d = heads * 32
+    return (USE_ATTN_HALF_IO and USE_ATTN_BWD_BF16 and USE_ATTN_KV2 and _autocast_mode() == "bf16" and drop_p == 0 and not return_lse
+            and all(t.dtype == torch.bfloat16 and t.dim() == 2 and t.shape[1] in (d, 3 * d) and t.stride(1) == 1 and t.stride(0) % 8 == 0
+                    and t.data_ptr() % 16 == 0 for t in tensors))
 
 
 _DROPOUT_STEP = {}
@@ -259,6 +340,9 @@ def window_attention(q, k, v, qmap, kmap, omap, batch, heads, scale, out_rows, b
     bf16_mm = USE_ATTN_BWD_BF16 and _autocast_mode() == "bf16"
     cfg = (tuple(qmap), tuple(kmap), tuple(omap), int(batch), int(heads), float(scale), int(bias_L), int(out_rows),
            float(drop_p), int(drop_seed or 0), seed_dev, bool(return_lse), bool(bf16_mm))
+    if _half_attention_ok((q, k, v), drop_p, return_lse, heads) and q.shape[1] == heads * 32:
+        with torch.autocast("cuda", enabled=False):
+            return WindowAttentionHalfFn.apply(q, k, v, bias_table, mask, cfg, False)
     return WindowAttentionFn.apply(q, k, v, bias_table, mask, cfg)
 
 

@@ -36,6 +36,7 @@ struct AttnBwdParams {
                               // the forward that a caller combines further - the per-camera attentions of CVT's CrossAttention are merged
                               // by a softmax over their lse, cvt_modules.py:142-153).  d lse / d logit = P, so it enters as D - dlse.
     int nsplit;               // attn_bwd_kv_kernel: workgroups that share the windows of one (head, key tile position)
+    int sb;                   // 1: q / k / v / out / dout / dq / dk / dv are bf16 in memory (attn_bwd_kv2_kernel / attn_bwd_q4_kernel only)
 };
 
 namespace {
@@ -51,6 +52,18 @@ constexpr int kMaskedKey = (int)0x80000000;   // per-key info of a masked / out-
 // the k-slots (half h, element e) of instruction m then stand for row 16 m + 8 (e / 4) + 4 h + e % 4 = acc_row(8 m + e, lane), i.e. the B
 // operand is the lane's accumulator registers 8 m .. 8 m + 7 packed to bf16, unchanged.
 constexpr int kRowB = 80;     // bytes per row of a bf16 tile
+// four consecutive elements at element offset `off` of an fp32 (sb = 0) or bf16 (sb = 1) tensor
+__device__ __forceinline__ float4 ld4q(const void* base, size_t off, int sb) {
+    if (sb) {
+        const uint2 u = *(const uint2*)((const uint16_t*)base + off);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    }
+    return *(const float4*)((const float*)base + off);
+}
+__device__ __forceinline__ void st4q(void* base, size_t off, int sb, const float4& v) {
+    if (sb) *(uint2*)((uint16_t*)base + off) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+    else *(float4*)((float*)base + off) = v;
+}
 typedef short v4s_b __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint2 tr_read_b(const unsigned char* lds) {
     const v4s_b r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_b __attribute__((address_space(3)))*)lds);
@@ -327,12 +340,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv2_kernel(AttnBwdParams bp) 
             T.kterm = BIAS ? rel_bias_key_term(p.kmap, kc) : 0;
             T.kb0 = T.kb1 = T.vb0 = T.vb1 = make_uint4(0, 0, 0, 0);
             if (T.k_in) {
-                const float* kr = (const float*)p.k + T.krow * p.ldk + p.koff + head * 32 + 8 * h;
-                const float* vr = (const float*)p.v + T.krow * p.ldv + p.voff + head * 32 + 8 * h;
-                T.kb0 = pack8f4(*(const float4*)kr, *(const float4*)(kr + 4));
-                T.kb1 = pack8f4(*(const float4*)(kr + 16), *(const float4*)(kr + 20));
-                T.vb0 = pack8f4(*(const float4*)vr, *(const float4*)(vr + 4));
-                T.vb1 = pack8f4(*(const float4*)(vr + 16), *(const float4*)(vr + 20));
+                const size_t ko = T.krow * p.ldk + p.koff + head * 32 + 8 * h, vo = T.krow * p.ldv + p.voff + head * 32 + 8 * h;
+                T.kb0 = pack8f4(ld4q(p.k, ko, bp.sb), ld4q(p.k, ko + 4, bp.sb));
+                T.kb1 = pack8f4(ld4q(p.k, ko + 16, bp.sb), ld4q(p.k, ko + 20, bp.sb));
+                T.vb0 = pack8f4(ld4q(p.v, vo, bp.sb), ld4q(p.v, vo + 4, bp.sb));
+                T.vb1 = pack8f4(ld4q(p.v, vo + 16, bp.sb), ld4q(p.v, vo + 20, bp.sb));
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) { T.dKT[r] = 0.f; T.dVT[r] = 0.f; }
@@ -351,15 +363,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv2_kernel(AttnBwdParams bp) 
                 const TokCoord qc = tok_coord(p.qmap, ok ? tq : 0);
                 const size_t qrow = tok_row(p.qmap, b, l, qc);
                 const size_t orow = tok_row(p.omap, b, l, qc);
-                const float* qp = (const float*)p.q + qrow * p.ldq + p.qoff + head * 32 + half * 16;
-                const float* op = (const float*)p.out + orow * p.ldo + p.ooff + head * 32 + half * 16;
-                const float* dp = bp.dout + orow * p.ldo + p.ooff + head * 32 + half * 16;
+                const size_t qo = qrow * p.ldq + p.qoff + head * 32 + half * 16, oo = orow * p.ldo + p.ooff + head * 32 + half * 16;
                 float dsum = 0.f;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float4 qv = ok ? *(const float4*)(qp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float4 dv = ok ? *(const float4*)(dp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float4 ov = ok ? *(const float4*)(op + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 qv = ok ? ld4q(p.q, qo + 4 * c, bp.sb) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 dv = ok ? ld4q(bp.dout, oo + 4 * c, bp.sb) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 ov = ok ? ld4q(p.out, oo + 4 * c, bp.sb) : make_float4(0.f, 0.f, 0.f, 0.f);
                     *(uint2*)(Qs + r * kRowB + (half * 16 + 4 * c) * 2) = make_uint2(pack_bf2(qv.x, qv.y), pack_bf2(qv.z, qv.w));
                     *(uint2*)(dOs + r * kRowB + (half * 16 + 4 * c) * 2) = make_uint2(pack_bf2(dv.x, dv.y), pack_bf2(dv.z, dv.w));
                     dsum += dv.x * ov.x + dv.y * ov.y + dv.z * ov.z + dv.w * ov.w;
@@ -431,13 +441,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv2_kernel(AttnBwdParams bp) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) T.dVT[r] += red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane];
                 if (T.k_in) {
-                    float* dkr = bp.dk + T.krow * p.ldk + p.koff + head * 32 + 4 * h;
-                    float* dvr = bp.dv + T.krow * p.ldv + p.voff + head * 32 + 4 * h;
+                    const size_t ko = T.krow * p.ldk + p.koff + head * 32 + 4 * h, vo = T.krow * p.ldv + p.voff + head * 32 + 4 * h;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {           // dh rows 8 g + 4 h .. + 3
-                        *(float4*)(dkr + 8 * g) = make_float4(T.dKT[4 * g] * p.scale, T.dKT[4 * g + 1] * p.scale, T.dKT[4 * g + 2] * p.scale,
-                                                              T.dKT[4 * g + 3] * p.scale);
-                        *(float4*)(dvr + 8 * g) = make_float4(T.dVT[4 * g], T.dVT[4 * g + 1], T.dVT[4 * g + 2], T.dVT[4 * g + 3]);
+                        st4q(bp.dk, ko + 8 * g, bp.sb, make_float4(T.dKT[4 * g] * p.scale, T.dKT[4 * g + 1] * p.scale, T.dKT[4 * g + 2] * p.scale,
+                                                                    T.dKT[4 * g + 3] * p.scale));
+                        st4q(bp.dv, vo + 8 * g, bp.sb, make_float4(T.dVT[4 * g], T.dVT[4 * g + 1], T.dVT[4 * g + 2], T.dVT[4 * g + 3]));
                     }
                 }
             }
@@ -642,13 +651,11 @@ __global__ __launch_bounds__(256) void attn_bwd_q4_kernel(AttnBwdParams bp) {
     uint4 qbf0 = make_uint4(0, 0, 0, 0), qbf1 = qbf0, dobf0 = qbf0, dobf1 = qbf0;
     float Dq = 0.f;
     if (q_ok) {
-        const float* qp = (const float*)p.q + qrow * p.ldq + p.qoff + head * 32 + 8 * h;
-        const float* op = (const float*)p.out + orow * p.ldo + p.ooff + head * 32 + 8 * h;
-        const float* dp = bp.dout + orow * p.ldo + p.ooff + head * 32 + 8 * h;
-        const float4 d0 = *(const float4*)dp, d1 = *(const float4*)(dp + 4), d2 = *(const float4*)(dp + 16), d3 = *(const float4*)(dp + 20);
-        const float4 o0 = *(const float4*)op, o1 = *(const float4*)(op + 4), o2 = *(const float4*)(op + 16), o3 = *(const float4*)(op + 20);
-        qbf0 = pack8f4(*(const float4*)qp, *(const float4*)(qp + 4));
-        qbf1 = pack8f4(*(const float4*)(qp + 16), *(const float4*)(qp + 20));
+        const size_t qo = qrow * p.ldq + p.qoff + head * 32 + 8 * h, oo = orow * p.ldo + p.ooff + head * 32 + 8 * h;
+        const float4 d0 = ld4q(bp.dout, oo, bp.sb), d1 = ld4q(bp.dout, oo + 4, bp.sb), d2 = ld4q(bp.dout, oo + 16, bp.sb), d3 = ld4q(bp.dout, oo + 20, bp.sb);
+        const float4 o0 = ld4q(p.out, oo, bp.sb), o1 = ld4q(p.out, oo + 4, bp.sb), o2 = ld4q(p.out, oo + 16, bp.sb), o3 = ld4q(p.out, oo + 20, bp.sb);
+        qbf0 = pack8f4(ld4q(p.q, qo, bp.sb), ld4q(p.q, qo + 4, bp.sb));
+        qbf1 = pack8f4(ld4q(p.q, qo + 16, bp.sb), ld4q(p.q, qo + 20, bp.sb));
         dobf0 = pack8f4(d0, d1);
         dobf1 = pack8f4(d2, d3);
         Dq = d0.x * o0.x + d0.y * o0.y + d0.z * o0.z + d0.w * o0.w + d1.x * o1.x + d1.y * o1.y + d1.z * o1.z + d1.w * o1.w
@@ -670,8 +677,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q4_kernel(AttnBwdParams bp) {
         const bool ok = tk < p.Nk;
         const TokCoord kc = tok_coord(p.kmap, ok ? tk : 0);
         const size_t krow = tok_row(p.kmap, b, l, kc);
-        const float4 kv = *(const float4*)((const float*)p.k + krow * p.ldk + p.koff + head * 32 + 4 * sc);
-        const float4 vv = *(const float4*)((const float*)p.v + krow * p.ldv + p.voff + head * 32 + 4 * sc);
+        const float4 kv = ld4q(p.k, krow * p.ldk + p.koff + head * 32 + 4 * sc, bp.sb);
+        const float4 vv = ld4q(p.v, krow * p.ldv + p.voff + head * 32 + 4 * sc, bp.sb);
         nk = ok ? kv : make_float4(0.f, 0.f, 0.f, 0.f);
         nv = ok ? vv : make_float4(0.f, 0.f, 0.f, 0.f);
         bool vis = ok;
@@ -723,11 +730,10 @@ __global__ __launch_bounds__(256) void attn_bwd_q4_kernel(AttnBwdParams bp) {
         dQT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(Kt, lane, 1), pack_acc8<1>(dZ), dQT, 0, 0, 0);
     }
     if (q_ok) {                                         // lane = query column, register r <-> dh row
-        float* dqr = bp.dq + qrow * p.ldq + p.qoff + head * 32 + 4 * h;
+        const size_t qo = qrow * p.ldq + p.qoff + head * 32 + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            *(float4*)(dqr + 8 * g) = make_float4(dQT[4 * g] * p.scale, dQT[4 * g + 1] * p.scale, dQT[4 * g + 2] * p.scale,
-                                                  dQT[4 * g + 3] * p.scale);
+            st4q(bp.dq, qo + 8 * g, bp.sb, make_float4(dQT[4 * g] * p.scale, dQT[4 * g + 1] * p.scale, dQT[4 * g + 2] * p.scale, dQT[4 * g + 3] * p.scale));
     }
 }
 
@@ -753,8 +759,10 @@ extern "C" int cobevt_window_attention_bwd(const void* q, const void* k, const v
     bp.dlse = dlse;
     AttnParams& p = bp.a;
     const int dtype = dims[0] & 0xff;
-    if (dtype != 1) return COBEVT_ERR_UNSUPPORTED;          // fp32 storage (the parity / training mode)
     const bool bfmm = (dims[0] & 0x100) != 0;               // + 0x100: the products on the bf16 matrix path (bf16 autocast regions)
+    // fp32 storage (the parity / training mode); bf16 storage of q / k / v / out / dout / dq / dk / dv only on the bf16 matrix path
+    if (dtype != 1 && !(dtype == 0 && bfmm && (dims[0] & 0x200) == 0)) return COBEVT_ERR_UNSUPPORTED;
+    bp.sb = dtype == 0;
     p.q = q; p.k = k; p.v = v; p.out = const_cast<void*>(out);
     p.B = dims[1]; p.L = dims[2]; p.heads = dims[3];
     p.ldq = dims[4]; p.ldk = dims[5]; p.ldv = dims[6]; p.ldo = dims[7];
@@ -770,6 +778,7 @@ extern "C" int cobevt_window_attention_bwd(const void* q, const void* k, const v
     if (p.mean_q || p.omap.ncam != p.qmap.ncam) return COBEVT_ERR_UNSUPPORTED;   // (camera mean: done outside the kernel when training)
     if (p.bias_mode && (!bias_table || !dbias || p.bias_rows < 1 || p.bias_L < 1)) return COBEVT_ERR_ARG;
     if ((p.ldq | p.ldk | p.ldv | p.ldo | p.qoff | p.koff | p.voff | p.ooff) % 4) return COBEVT_ERR_SHAPE;
+    if (bp.sb && p.drop_p > 0.f) return COBEVT_ERR_UNSUPPORTED;        // (the dropout forward is fp32 storage)
     p.Nq = p.qmap.ncam * p.qmap.w1 * p.qmap.w2;
     p.Nk = p.kmap.ncam * p.kmap.w1 * p.kmap.w2;
     const int nkt = (p.Nk + 31) / 32, nqt = (p.Nq + 31) / 32;
@@ -784,7 +793,7 @@ extern "C" int cobevt_window_attention_bwd(const void* q, const void* k, const v
     if (lds_kv > 160 * 1024) return COBEVT_ERR_UNSUPPORTED;
     const dim3 grid_kv(p.heads * nsplit, nkt, p.B), grid_q(p.L * p.heads, nqt, p.B), block(256);
     // bf16 matrix path: two key tiles per workgroup (halves the staging traffic that bounds it), window shares re-balanced to ~2048 workgroups
-    const bool kv2 = bfmm && nkt >= 2 && (dims[0] & 0x200) == 0;     // (+ 0x200: one key tile per workgroup, for A/B runs)
+    const bool kv2 = bfmm && (nkt >= 2 || bp.sb) && (dims[0] & 0x200) == 0;     // (+ 0x200: one key tile per workgroup, for A/B runs)
     const int nkt2 = (nkt + 1) / 2;
     AttnBwdParams bp2 = bp;
     {

@@ -312,6 +312,24 @@ def test_window_self_attention_on_the_fused_projection(cuda, amp):
     else:
         assert torch.equal(res[1][1], res[0][1])
     assert_close(res[1][2], res[0][2], 1e-2 if amp else 1e-5, "dbias")
+    if amp:
+        # both of the above ran with bf16 q / k / v / out / gradients end to end (WindowAttentionHalfFn: bf16 forward kernel, bf16 storage in the
+        # backward); against the fp32-storage Functions on the same bf16 operands
+        ag.USE_ATTN_HALF_IO = False
+        try:
+            with torch.enable_grad():
+                qkv = _leaf(qkv0, cuda)
+                table = _leaf(table0, cuda)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    out = ag.window_self_attention(qkv.to(torch.bfloat16), tm, B, heads, 0.37, rows_n, bias_table=table, bias_L=ncam, mask=mask)
+                assert out.dtype == torch.float32
+                (out.float() * wgt).sum().backward()
+        finally:
+            ag.USE_ATTN_HALF_IO = True
+        assert res[1][0].dtype == torch.float32          # (converted above; the Function's own output was bf16)
+        assert_close(res[1][0], out.detach(), 1e-2, "bf16-storage forward vs fp32-storage forward")
+        assert_close(res[1][1], qkv.grad, 1e-2, "bf16-storage dqkv vs fp32-storage dqkv")
+        assert_close(res[1][2], table.grad, 1e-2, "bf16-storage dbias vs fp32-storage dbias")
 
 
 def test_layernorm_and_gelu_backward(cuda):
