@@ -260,7 +260,8 @@ class WindowAttentionHalfFn(torch.autograd.Function):
         L = qmap[6] * qmap[7]
         nq = qmap[1] * qmap[4] * qmap[5]
         out = torch.empty((out_rows, d), device=q.device, dtype=torch.bfloat16)
-        lse = torch.empty((batch, L, heads, nq), device=q.device, dtype=torch.float32)
+        # [0]: the log-sum-exp; [1]: scratch of the backward (D = rowsum(dO o O): the dQ kernel writes it, the dK / dV kernel reads it)
+        lse = torch.empty((2, batch, L, heads, nq), device=q.device, dtype=torch.float32)
         dims = _attn_dims(batch, heads, q.stride(0), k.stride(0), v.stride(0), d, table, bias_L, qmap, kmap, omap)
         dims[0] = ops.BF16
         rc = _L.load().cobevt_window_attention_lse(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(table), _p(mk), dims,
@@ -292,7 +293,7 @@ class WindowAttentionHalfFn(torch.autograd.Function):
         dout = dout if dout.is_contiguous() else dout.contiguous()
         dbias = None if table is None else _zeros(table.shape, table.device, table.dtype)
         dims = _attn_dims(batch, heads, q.stride(0), k.stride(0), v.stride(0), d, table, bias_L, qmap, kmap, omap)
-        dims[0] = ops.BF16 | 0x100
+        dims[0] = ops.BF16 | 0x100 | (0x400 if USE_ATTN_D_SCRATCH else 0)
         rc = _L.load().cobevt_window_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), None, _p(dq), _p(dk), _p(dv),
                                                    _p(dbias), _p(table), _p(mk), dims, ctypes.c_float(scale), ctypes.c_float(0.0),
                                                    ctypes.c_uint(0), None, _stream())
@@ -302,6 +303,7 @@ class WindowAttentionHalfFn(torch.autograd.Function):
         return dq, dk, dv, dbias, None, None, None
 
 
+USE_ATTN_D_SCRATCH = True     # ... and D = rowsum(dO o O) handed from the dQ kernel to the dK / dV kernel through the lse tensor's second half
 USE_ATTN_HALF_IO = True       # bf16 autocast regions: bf16 q / k / v / out / gradients through the attention Functions (no boundary casts)
 
 

@@ -37,6 +37,8 @@ struct AttnBwdParams {
                               // by a softmax over their lse, cvt_modules.py:142-153).  d lse / d logit = P, so it enters as D - dlse.
     int nsplit;               // attn_bwd_kv_kernel: workgroups that share the windows of one (head, key tile position)
     int sb;                   // 1: q / k / v / out / dout / dq / dk / dv are bf16 in memory (attn_bwd_kv2_kernel / attn_bwd_q4_kernel only)
+    float* dscr;              // nullable: [B][L][heads][Nq] scratch for D = rowsum(dO o O) - dlse: attn_bwd_q4_kernel (launched first) writes it,
+                              // attn_bwd_kv2_kernel reads it instead of re-deriving it from the O tiles (a third of its staging loads)
 };
 
 namespace {
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv2_kernel(AttnBwdParams bp) 
                 for (int c = 0; c < 4; ++c) {
                     const float4 qv = ok ? ld4q(p.q, qo + 4 * c, bp.sb) : make_float4(0.f, 0.f, 0.f, 0.f);
                     const float4 dv = ok ? ld4q(bp.dout, oo + 4 * c, bp.sb) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float4 ov = ok ? ld4q(p.out, oo + 4 * c, bp.sb) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 ov = (ok && !bp.dscr) ? ld4q(p.out, oo + 4 * c, bp.sb) : make_float4(0.f, 0.f, 0.f, 0.f);
                     *(uint2*)(Qs + r * kRowB + (half * 16 + 4 * c) * 2) = make_uint2(pack_bf2(qv.x, qv.y), pack_bf2(qv.z, qv.w));
                     *(uint2*)(dOs + r * kRowB + (half * 16 + 4 * c) * 2) = make_uint2(pack_bf2(dv.x, dv.y), pack_bf2(dv.z, dv.w));
                     dsum += dv.x * ov.x + dv.y * ov.y + dv.z * ov.z + dv.w * ov.w;
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv2_kernel(AttnBwdParams bp) 
                 dsum += __shfl_xor(dsum, 1, 64);
                 if (half == 0) {
                     const size_t li = (((size_t)b * p.L + l) * p.heads + head) * p.Nq + (ok ? tq : 0);
-                    D_s[r] = dsum - ((bp.dlse && ok) ? bp.dlse[li] : 0.f);
+                    D_s[r] = bp.dscr ? (ok ? bp.dscr[li] : 0.f) : dsum - ((bp.dlse && ok) ? bp.dlse[li] : 0.f);
                     lse_s[r] = ok ? p.lse[li] : INFINITY;         // invalid rows: lse = +inf -> P = exp2(-inf) = 0
                     qb_s[r] = BIAS ? rel_bias_query_term(p.kmap, p.bias_L, qc) : 0;
                 }
@@ -664,6 +666,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q4_kernel(AttnBwdParams bp) {
     Dq += __shfl_xor(Dq, 32, 64);
     const size_t lse_i = (((size_t)b * p.L + l) * p.heads + head) * p.Nq + (q_ok ? tq : 0);
     if (bp.dlse && q_ok) Dq -= bp.dlse[lse_i];
+    if (bp.dscr && q_ok && h == 0) bp.dscr[lse_i] = Dq;            // for attn_bwd_kv2_kernel, launched behind this kernel
     const float lse_q = q_ok ? p.lse[lse_i] : INFINITY;
     const int qterm = BIAS ? rel_bias_query_term(p.kmap, p.bias_L, qc) : 0;
     const float sl2 = p.scale * kLog2eB;
@@ -763,6 +766,8 @@ extern "C" int cobevt_window_attention_bwd(const void* q, const void* k, const v
     // fp32 storage (the parity / training mode); bf16 storage of q / k / v / out / dout / dq / dk / dv only on the bf16 matrix path
     if (dtype != 1 && !(dtype == 0 && bfmm && (dims[0] & 0x200) == 0)) return COBEVT_ERR_UNSUPPORTED;
     bp.sb = dtype == 0;
+    // + 0x400: `lse` is [2][B][L][heads][Nq] - the second half is scratch for D (dQ kernel writes, dK / dV kernel reads; bf16 matrix path only)
+    bp.dscr = nullptr;
     p.q = q; p.k = k; p.v = v; p.out = const_cast<void*>(out);
     p.B = dims[1]; p.L = dims[2]; p.heads = dims[3];
     p.ldq = dims[4]; p.ldk = dims[5]; p.ldv = dims[6]; p.ldo = dims[7];
@@ -796,6 +801,7 @@ extern "C" int cobevt_window_attention_bwd(const void* q, const void* k, const v
     const bool kv2 = bfmm && (nkt >= 2 || bp.sb) && (dims[0] & 0x200) == 0;     // (+ 0x200: one key tile per workgroup, for A/B runs)
     const int nkt2 = (nkt + 1) / 2;
     AttnBwdParams bp2 = bp;
+    if (kv2 && (dims[0] & 0x400)) bp2.dscr = const_cast<float*>(lse) + (size_t)p.B * p.L * p.heads * p.Nq;
     {
         const long per2 = (long)p.heads * nkt2 * p.B;
         int ns2 = (int)((2048 + per2 - 1) / per2);
@@ -809,10 +815,13 @@ extern "C" int cobevt_window_attention_bwd(const void* q, const void* k, const v
     do {                                                                                              \
         static cobevt::PerDeviceOnce attr;                                                                   \
         if (attr.first()) { set_max_lds(attn_bwd_kv_kernel<B_, M_, F_>); set_max_lds(attn_bwd_q_kernel<B_, M_, F_>); set_max_lds(attn_bwd_kv2_kernel<B_, M_>); set_max_lds(attn_bwd_q4_kernel<B_, M_>); } \
-        if (F_ && kv2) hipLaunchKernelGGL((attn_bwd_kv2_kernel<B_, M_>), grid_kv2, block, lds_kv, stream, bp2); \
-        else hipLaunchKernelGGL((attn_bwd_kv_kernel<B_, M_, F_>), grid_kv, block, lds_kv, stream, bp);     \
-        if (F_ && kv2) hipLaunchKernelGGL((attn_bwd_q4_kernel<B_, M_>), grid_q4, block, lds_q4, stream, bp); \
-        else hipLaunchKernelGGL((attn_bwd_q_kernel<B_, M_, F_>), grid_q, block, lds_q, stream, bp);        \
+        if (F_ && kv2) {                                                                              \
+            hipLaunchKernelGGL((attn_bwd_q4_kernel<B_, M_>), grid_q4, block, lds_q4, stream, bp2);    \
+            hipLaunchKernelGGL((attn_bwd_kv2_kernel<B_, M_>), grid_kv2, block, lds_kv, stream, bp2);  \
+        } else {                                                                                      \
+            hipLaunchKernelGGL((attn_bwd_kv_kernel<B_, M_, F_>), grid_kv, block, lds_kv, stream, bp); \
+            hipLaunchKernelGGL((attn_bwd_q_kernel<B_, M_, F_>), grid_q, block, lds_q, stream, bp);    \
+        }                                                                                             \
     } while (0)
 #define COBEVT_BWD_LAUNCH(B_, M_) do { if (bfmm) COBEVT_BWD_LAUNCH2(B_, M_, true); else COBEVT_BWD_LAUNCH2(B_, M_, false); } while (0)
     if (hb && hm) COBEVT_BWD_LAUNCH(true, true);
