@@ -661,6 +661,31 @@ def _conv3_strips(x, operand, variant, cout, bias, stride):
     return out
 
 
+USE_TRAIN_ROWS_GEMM = True    # bf16 dense projections / 1x1 stride-1 convolutions with K, N <= 512: forward and input gradient on the inference row GEMM
+
+
+def linear_weight_frags(weight2d, transpose):
+    """fp32 master weight (N, K) -> the bf16 fragment table cobevt_linear_rows_small_k reads (csrc/train_prep.hip), for y = x W^T or
+    (transpose) for dx = dy W.  Specification: ops.ConvPlan(weight or weight.t(), ...).wfrag_rows."""
+    n, k = weight2d.shape
+    r, c = (k, n) if transpose else (n, k)
+    w = _f32c(weight2d.detach(), "weight")
+    op = torch.empty(((r + 127) // 128 * 4, (c + 127) // 128 * 8, 64, 8), device=w.device, dtype=torch.bfloat16)
+    _L.check(_L.load().cobevt_linear_weight_frags(_p(w), _p(op), _ints([n, k, int(transpose)]), _stream()), "cobevt_linear_weight_frags")
+    return op
+
+
+def _rows_gemm(x2d, frag, n_out, k_in, bias):
+    """x2d (M, k_in) bf16 rows -> (M, n_out) bf16 = x W^T (+ bias): cobevt_linear_rows_small_k with the table of linear_weight_frags"""
+    m = x2d.shape[0]
+    out = torch.empty((m, n_out), device=x2d.device, dtype=torch.bfloat16)
+    b = None if bias is None else _f32c(bias.detach().float(), "bias")
+    d3 = (ctypes.c_long * 14)(ops.BF16, m, n_out, k_in, k_in, 0, 0, 0, 1, m, 1, m, 1, 32)
+    rc = _L.load().cobevt_linear_rows_small_k(_p(x2d), _p(frag), _p(b), None, None, None, _p(out), d3, ctypes.c_float(0.0), _stream())
+    _L.check(rc, "cobevt_linear_rows_small_k")
+    return out
+
+
 USE_WGRAD_BLOCKED = True      # bf16: weight gradient on the bf16 matrix path (cobevt_conv_wgrad_blocked) where wgrad_blocked_mode() has a form for it
 USE_WGRAD_BLOCKED_STRIDED = True   # ... incl. the stride-2 and stem forms (modes 1 / 2); False: those stay on cobevt_conv_wgrad (A/B runs)
 
@@ -763,7 +788,14 @@ class Conv2dFn(torch.autograd.Function):
             and cin % 8 == 0 and n * h * w * cout < 2 ** 31
         need_d = ctx.needs_input_grad[0]
         var_d = conv3_strips_plan(n, h, w, cout, cin, 1) if (strips_d and need_d) else -1
-        if strips:
+        rows = (USE_TRAIN_ROWS_GEMM and xl.dtype == torch.bfloat16 and kh == 1 and kw == 1 and stride == 1 and pad == 0 and cin % 8 == 0
+                and cout % 8 == 0 and cin <= 512 and cout <= 512)
+        if rows:
+            # a dense projection: the inference row GEMM both ways (weights resident per workgroup, rows streamed once)
+            out = _rows_gemm(xl.reshape(-1, cin), linear_weight_frags(weight.reshape(cout, cin), False), cout, cin, bias).reshape(n, ho, wo, cout)
+            rows_d = linear_weight_frags(weight.reshape(cout, cin), True) if need_d else None
+            var_d = -2 if need_d else -1
+        elif strips:
             var_f = conv3_strips_plan(n, ho, wo, cin, cout, stride)
             out = _conv3_strips(xl, conv3_weight_operand(weight, var_f, False), var_f, cout, bias, stride)
             rows_d = conv3_weight_operand(weight, var_d, True) if var_d >= 0 else \
@@ -793,7 +825,9 @@ class Conv2dFn(torch.autograd.Function):
             if stride > 1:                       # zero-stuffed gradient map: dgrad of a strided conv = stride-1 conv on it
                 g = torch.zeros((n, (ho - 1) * stride + 1, (wo - 1) * stride + 1, cout), device=dyl.device, dtype=dyl.dtype)
                 g[:, ::stride, ::stride] = dyl
-            if ctx.var_d >= 0:
+            if ctx.var_d == -2:
+                dx = _rows_gemm(g.reshape(-1, cout), rows_d, cin, cout, None).reshape(n, h, w, cin).permute(0, 3, 1, 2)
+            elif ctx.var_d >= 0:
                 dx = _conv3_strips(g, rows_d, ctx.var_d, cin, None, 1).permute(0, 3, 1, 2)
             else:
                 dx = _igemm_rows(g, rows_d, cin, cout, kh, kw, None, 1, kh - 1 - pad, h, w).permute(0, 3, 1, 2)

@@ -88,6 +88,29 @@ __global__ __launch_bounds__(kThreads) void conv3_weight_operands_kernel(const f
     *dst = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
 }
 
+// ---- dense projections on the inference row-GEMM kernel (gemm_rows3.hip): the fp32 master weight (N, K) -> its fragment table
+// [Np/32][Kp/16][2 halves][32][8] bf16 (ops.ConvPlan.wfrag_rows: Kp = K rounded up to 128, Np = N rounded up to 128, zero padding), for the
+// projection itself (rows = output features) or, transposed, for its input gradient dx = dy W (rows = input features, contraction over N).
+__global__ __launch_bounds__(kThreads) void linear_weight_frags_kernel(const float* __restrict__ w, uint4* __restrict__ frag, int N, int K, int transpose,
+                                                                       int Rp, int Cp, long pieces) {
+    const long i = (long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= pieces) return;
+    // rows R (padded Rp) x contraction C (padded Cp) of the GEMM: forward R = N, C = K, value w[r][c]; transposed R = K, C = N, value w[c][r]
+    const int n = (int)(i & 31), half = (int)((i >> 5) & 1);
+    long t = i >> 6;
+    const int kgs = Cp >> 4;
+    const int kg = (int)(t % kgs), tile = (int)(t / kgs);
+    const int r = tile * 32 + n, c0 = kg * 16 + half * 8;
+    const int R = transpose ? K : N, C = transpose ? N : K;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e;
+        v[e] = (r < R && c < C) ? (transpose ? w[(long)c * K + r] : w[(long)r * K + c]) : 0.f;
+    }
+    frag[i] = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+}
+
 // one thread = (n, padded row, block, 8-channel group): 8 pixels x 8 channels in, 8 channels x 8 pixels out
 __global__ __launch_bounds__(kThreads) void wgrad_block8_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, long items,
                                                                 int H, int W, int C, int Hp, int NB, int pt, int pl, int P, int sx) {
@@ -190,6 +213,19 @@ extern "C" int cobevt_conv3_weight_operands(const float* w, void* frag, void* ro
     if (total > 0x7fffffffL * (long)kThreads) return COBEVT_ERR_SHAPE;
     hipLaunchKernelGGL(conv3_weight_operands_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, w,
                        (uint4*)frag, (uint4*)rows3, O, I, Cin, dgrad, nfrag, nrows);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+extern "C" int cobevt_linear_weight_frags(const float* w, void* frag, const int* dims, hipStream_t stream) {
+    // dims: [N, K, transpose]; frag: (Rp / 32) x (Cp / 16) x 64 x 16 bytes with (R, C) = (N, K) or, transposed, (K, N); Rp, Cp rounded up to 128
+    if (!w || !frag || !dims) return COBEVT_ERR_ARG;
+    const int N = dims[0], K = dims[1], tr = dims[2];
+    if (N < 1 || K < 1 || (tr != 0 && tr != 1)) return COBEVT_ERR_SHAPE;
+    const int R = tr ? K : N, C = tr ? N : K;
+    const int Rp = (R + 127) / 128 * 128, Cp = (C + 127) / 128 * 128;
+    const long pieces = (long)Rp * Cp / 8;
+    hipLaunchKernelGGL(linear_weight_frags_kernel, dim3((unsigned)((pieces + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, w, (uint4*)frag, N, K, tr,
+                       Rp, Cp, pieces);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 

@@ -1124,6 +1124,20 @@ def test_linear_wgrad_matches_fp64(cuda, rows, cin, cout):
     assert_close(lin.weight.grad, ref.float(), 1e-2, "autograd.linear dW (bf16 autocast)")
 
 
+@pytest.mark.parametrize("n,k", [(128, 128), (384, 128), (128, 512), (72, 40), (8, 8)])
+def test_linear_weight_frags_kernel_matches_plan_layout(cuda, n, k):
+    """cobevt_linear_weight_frags (fp32 master weight -> the bf16 fragment table of the inference row GEMM, for the projection and, transposed,
+    for its input gradient) is bit-identical to ops.ConvPlan's wfrag_rows"""
+    from cobevt_amd import ops
+    g = torch.Generator().manual_seed(n * 3 + k)
+    w = torch.randn(n, k, generator=g)
+    wd = w.to(cuda)
+    plan = ops.ConvPlan(w[:, :, None, None], None, stride=1, pad=0, act=0, dtype=torch.bfloat16, device=cuda)
+    assert torch.equal(ag.linear_weight_frags(wd, False).reshape(-1), plan.wfrag_rows.reshape(-1))
+    plant = ops.ConvPlan(w.t().contiguous()[:, :, None, None], None, stride=1, pad=0, act=0, dtype=torch.bfloat16, device=cuda)
+    assert torch.equal(ag.linear_weight_frags(wd, True).reshape(-1), plant.wfrag_rows.reshape(-1))
+
+
 def test_zero_pool_hands_out_disjoint_zeroed_slices(cuda):
     """autograd._zeros: small gradient buffers are slices of one zero-filled chunk (one fill launch per 16 MiB instead of one per tensor):
     zero, disjoint, handed out once, 256-byte aligned; large ones and captures outside begin/end_capture_zero_pool() keep their own fill"""
