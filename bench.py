@@ -20,7 +20,7 @@ Rank 0 prints ONE JSON line.  Timing: W warm-up steps, then K steps between barr
 median / p95 come from HIP events recorded after every step.
 
 Extra legs at N = 1 (rank 0): `one_frame_at_a_time`, `eager_model_call` (the plain `model(batch)` a drop-in user calls),
-`fp32_parity_mode` (same frame in the exact-fp32 mode), `other_configs` (2-agent OPV2V, nuScenes SinBEVT), `roofline` (+ the
+`fp32_parity_mode` (same frame in the exact-fp32 mode), `other_configs` (the captured bf16 training step of the same model and frame, 2-agent OPV2V, nuScenes SinBEVT, LiDAR FuseBEVT), `roofline` (+ the
 level-0 FAX attention launch on its own) from HIP-event timings of one eager frame and the committed rocprofv3 PMC summary
 (profiles/pmc_*.json), `cpu_baseline` (the oracle on the host cores, kind "port") and `parity` against it.
 """
@@ -838,7 +838,24 @@ def main():
                 out["achieved_tflops_end_to_end"] = round(LIDAR_GF / out["ms_median"], 2)
                 out["roofline"] = lidar_roofline(enc, x, mask, args.dtype)
                 return out
+            def train_step():
+                """one optimisation step of train_camera.py:143-179 (forward, VanillaSegLoss, backward, AdamW) of the
+                same corpbevt.yaml model on the same 5-agent frame, bf16 autocast, replayed from a captured HIP graph
+                (host.CapturedTrainStep; tools/train_graph_probe.py is this leg with its eager and fp32 counterparts)"""
+                from cobevt_amd.host.train_graph import CapturedTrainStep
+                tm = synth.fill_module_(host.CorpBEVT(copy.deepcopy(cfg)), 0).train().to(dev)
+                tb = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
+                shp = outs[args.dtype]["dynamic_seg"].shape
+                tb["gt_dynamic"] = (torch.rand(shp[:2] + shp[3:], device=dev) > 0.9).long()
+                tb["gt_static"] = torch.zeros(shp[:2] + shp[3:], device=dev, dtype=torch.long)
+                crit = host.VanillaSegLoss({"d_weights": 75.0, "s_weights": 15.0, "l_weights": 50, "d_coe": 2.0, "s_coe": 0.0, "target": "dynamic"})
+                opt = torch.optim.AdamW(tm.parameters(), lr=2e-4, capturable=True)
+                cap = CapturedTrainStep(tm, lambda o, b: crit(o, b), opt, tb, autocast_dtype=torch.bfloat16)
+                q = quick(lambda: cap.step(), 2, 10)
+                return dict(q, loss=round(float(cap.step()), 4), config="OPV2V-camera CoBEVT training step: 5 agents x 4 cams 512x512, forward + "
+                            "VanillaSegLoss + backward + AdamW under bf16 autocast, one captured HIP graph per step; steps_per_sec = frames_per_sec")
             oc = {}
+            safe(oc, "train_step_bf16_autocast", train_step)
             safe(oc, "opv2v_2_agents", two_agents)
             safe(oc, "nuscenes_sinbevt_from_images", lambda: nuscenes(True))
             safe(oc, "nuscenes_sinbevt", lambda: nuscenes(False))
