@@ -664,15 +664,16 @@ def _conv3_strips(x, operand, variant, cout, bias, stride):
 USE_TRAIN_ROWS_GEMM = True    # bf16 dense projections / 1x1 stride-1 convolutions with K, N <= 512: forward and input gradient on the inference row GEMM
 
 
-def linear_weight_frags(weight2d, transpose):
-    """fp32 master weight (N, K) -> the bf16 fragment table cobevt_linear_rows_small_k reads (csrc/train_prep.hip), for y = x W^T or
-    (transpose) for dx = dy W.  Specification: ops.ConvPlan(weight or weight.t(), ...).wfrag_rows."""
+def linear_weight_frags(weight2d, forward=True, transposed=False):
+    """fp32 master weight (N, K) -> (table for y = x W^T | None, table for dx = dy W | None): the bf16 fragment tables
+    cobevt_linear_rows_small_k reads, both from one launch (csrc/train_prep.hip).  Specification: ops.ConvPlan(weight or weight.t(), ...).wfrag_rows."""
     n, k = weight2d.shape
-    r, c = (k, n) if transpose else (n, k)
     w = _f32c(weight2d.detach(), "weight")
-    op = torch.empty(((r + 127) // 128 * 4, (c + 127) // 128 * 8, 64, 8), device=w.device, dtype=torch.bfloat16)
-    _L.check(_L.load().cobevt_linear_weight_frags(_p(w), _p(op), _ints([n, k, int(transpose)]), _stream()), "cobevt_linear_weight_frags")
-    return op
+    np_, kp = (n + 127) // 128 * 128, (k + 127) // 128 * 128
+    f = torch.empty((np_ // 32, kp // 16, 64, 8), device=w.device, dtype=torch.bfloat16) if forward else None
+    t = torch.empty((kp // 32, np_ // 16, 64, 8), device=w.device, dtype=torch.bfloat16) if transposed else None
+    _L.check(_L.load().cobevt_linear_weight_frags(_p(w), _p(f), _p(t), _ints([n, k]), _stream()), "cobevt_linear_weight_frags")
+    return f, t
 
 
 def _rows_gemm(x2d, frag, n_out, k_in, bias):
@@ -792,8 +793,8 @@ class Conv2dFn(torch.autograd.Function):
                 and cout % 8 == 0 and cin <= 512 and cout <= 512)
         if rows:
             # a dense projection: the inference row GEMM both ways (weights resident per workgroup, rows streamed once)
-            out = _rows_gemm(xl.reshape(-1, cin), linear_weight_frags(weight.reshape(cout, cin), False), cout, cin, bias).reshape(n, ho, wo, cout)
-            rows_d = linear_weight_frags(weight.reshape(cout, cin), True) if need_d else None
+            frag_f, rows_d = linear_weight_frags(weight.reshape(cout, cin), True, need_d)
+            out = _rows_gemm(xl.reshape(-1, cin), frag_f, cout, cin, bias).reshape(n, ho, wo, cout)
             var_d = -2 if need_d else -1
         elif strips:
             var_f = conv3_strips_plan(n, ho, wo, cin, cout, stride)

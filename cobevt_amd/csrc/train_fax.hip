@@ -134,9 +134,9 @@ __global__ __launch_bounds__(256) void bev_query_train_kernel(BevQueryTrainParam
     }
 }
 
-inline int pixel_blocks(int HW, int B) {
+inline int pixel_blocks(int HW, int B, int total = 2048) {
     int blocks = (HW + 7) / 8;                       // one row per half-wave and round
-    const int cap = (2048 + B - 1) / B;              // about 2048 workgroups in all (eight per CU)
+    const int cap = (total + B - 1) / B;             // about `total` workgroups in all (2048 = eight per CU)
     return blocks > cap ? cap : (blocks < 1 ? 1 : blocks);
 }
 
@@ -172,7 +172,9 @@ extern "C" int cobevt_fax_bev_query_train_bwd(const float* grid, const float* w,
     p.B = dims[0]; p.n = dims[1]; p.HW = dims[2] * dims[3]; p.W = dims[3]; p.round_bf16 = dims[5] != 0;
     p.grid_stride = dims[7] ? (long)dims[6] * p.HW : 0;
     if (p.B < 1 || p.n < 1 || p.n > kMaxCam || dims[2] < 1 || dims[3] < 1 || p.B > 65535) return COBEVT_ERR_SHAPE;
-    const dim3 grid_dim(pixel_blocks(p.HW, p.B), p.B);
+    // every workgroup ends in atomics on the SAME d x K (+ d) parameter-gradient words: 2,060 workgroups made the image embedding's
+    // backward 159 us for 84 MB (profiles/r04_train_amp_kernel_trace.txt); two per CU keep the stream fed and the contention low
+    const dim3 grid_dim(pixel_blocks(p.HW, p.B, 512), p.B);
     if (dims[6] == 2) hipLaunchKernelGGL((bev_query_train_kernel<true, 2>), grid_dim, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((bev_query_train_kernel<true, 4>), grid_dim, dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;

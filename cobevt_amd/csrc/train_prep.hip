@@ -91,24 +91,27 @@ __global__ __launch_bounds__(kThreads) void conv3_weight_operands_kernel(const f
 // ---- dense projections on the inference row-GEMM kernel (gemm_rows3.hip): the fp32 master weight (N, K) -> its fragment table
 // [Np/32][Kp/16][2 halves][32][8] bf16 (ops.ConvPlan.wfrag_rows: Kp = K rounded up to 128, Np = N rounded up to 128, zero padding), for the
 // projection itself (rows = output features) or, transposed, for its input gradient dx = dy W (rows = input features, contraction over N).
-__global__ __launch_bounds__(kThreads) void linear_weight_frags_kernel(const float* __restrict__ w, uint4* __restrict__ frag, int N, int K, int transpose,
-                                                                       int Rp, int Cp, long pieces) {
-    const long i = (long)blockIdx.x * kThreads + threadIdx.x;
-    if (i >= pieces) return;
-    // rows R (padded Rp) x contraction C (padded Cp) of the GEMM: forward R = N, C = K, value w[r][c]; transposed R = K, C = N, value w[c][r]
+__global__ __launch_bounds__(kThreads) void linear_weight_frags_kernel(const float* __restrict__ w, uint4* __restrict__ frag_f, uint4* __restrict__ frag_t,
+                                                                       int N, int K, long pieces_f, long pieces_t) {
+    long i = (long)blockIdx.x * kThreads + threadIdx.x;
+    // pieces [0, pieces_f): the projection's table (rows N, contraction K, value w[r][c]); then the transposed one (rows K, contraction N, w[c][r])
+    const bool transpose = i >= pieces_f;
+    if (transpose) i -= pieces_f;
+    if (transpose ? i >= pieces_t : i >= pieces_f) return;
+    const int R = transpose ? K : N, C = transpose ? N : K;
+    const int Cp = (C + 127) / 128 * 128;
     const int n = (int)(i & 31), half = (int)((i >> 5) & 1);
     long t = i >> 6;
     const int kgs = Cp >> 4;
     const int kg = (int)(t % kgs), tile = (int)(t / kgs);
     const int r = tile * 32 + n, c0 = kg * 16 + half * 8;
-    const int R = transpose ? K : N, C = transpose ? N : K;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = c0 + e;
         v[e] = (r < R && c < C) ? (transpose ? w[(long)c * K + r] : w[(long)r * K + c]) : 0.f;
     }
-    frag[i] = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+    (transpose ? frag_t : frag_f)[i] = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
 }
 
 // one thread = (n, padded row, block, 8-channel group): 8 pixels x 8 channels in, 8 channels x 8 pixels out
@@ -216,16 +219,16 @@ extern "C" int cobevt_conv3_weight_operands(const float* w, void* frag, void* ro
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
-extern "C" int cobevt_linear_weight_frags(const float* w, void* frag, const int* dims, hipStream_t stream) {
-    // dims: [N, K, transpose]; frag: (Rp / 32) x (Cp / 16) x 64 x 16 bytes with (R, C) = (N, K) or, transposed, (K, N); Rp, Cp rounded up to 128
-    if (!w || !frag || !dims) return COBEVT_ERR_ARG;
-    const int N = dims[0], K = dims[1], tr = dims[2];
-    if (N < 1 || K < 1 || (tr != 0 && tr != 1)) return COBEVT_ERR_SHAPE;
-    const int R = tr ? K : N, C = tr ? N : K;
-    const int Rp = (R + 127) / 128 * 128, Cp = (C + 127) / 128 * 128;
-    const long pieces = (long)Rp * Cp / 8;
-    hipLaunchKernelGGL(linear_weight_frags_kernel, dim3((unsigned)((pieces + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, w, (uint4*)frag, N, K, tr,
-                       Rp, Cp, pieces);
+extern "C" int cobevt_linear_weight_frags(const float* w, void* frag, void* frag_t, const int* dims, hipStream_t stream) {
+    // dims: [N, K]; frag (nullable): the projection's table, (Np / 32) x (Kp / 16) x 64 x 16 bytes; frag_t (nullable): the transposed one,
+    // (Kp / 32) x (Np / 16) x 64 x 16 bytes; Np, Kp = N, K rounded up to 128.  One launch for both.
+    if (!w || (!frag && !frag_t) || !dims) return COBEVT_ERR_ARG;
+    const int N = dims[0], K = dims[1];
+    if (N < 1 || K < 1) return COBEVT_ERR_SHAPE;
+    const long Np = (N + 127) / 128 * 128, Kp = (K + 127) / 128 * 128;
+    const long pf = frag ? Np * Kp / 8 : 0, pt = frag_t ? Np * Kp / 8 : 0;
+    hipLaunchKernelGGL(linear_weight_frags_kernel, dim3((unsigned)((pf + pt + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, w, (uint4*)frag,
+                       (uint4*)frag_t, N, K, pf, pt);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 

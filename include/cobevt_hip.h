@@ -578,10 +578,10 @@ int cobevt_conv_weight_rows(const float* w, void* rows_fwd, void* rows_dgrad, co
  */
 int cobevt_conv3_weight_operands(const float* w, void* frag, void* rows3, const int* dims, hipStream_t stream);
 /* The same for a dense projection / 1x1 stride-1 convolution on the inference row-GEMM kernel (cobevt_linear_rows_small_k) in training:
- * fp32 master weight (N, K) -> the bf16 fragment table of cobevt_linear_rows_small_k ([Rp/32][Cp/16][64 lanes][8], both padded to 128) for
- * the projection (dims[2] = 0: rows N, contraction K) or its input gradient dx = dy W (dims[2] = 1: rows K, contraction N).
- * dims (int32[3]): N, K, transpose. */
-int cobevt_linear_weight_frags(const float* w, void* frag, const int* dims, hipStream_t stream);
+ * fp32 master weight (N, K) -> the bf16 fragment tables of cobevt_linear_rows_small_k ([Rp/32][Cp/16][64 lanes][8], both padded to 128):
+ * `frag` for the projection (rows N, contraction K), `frag_t` for its input gradient dx = dy W (rows K, contraction N); either nullable,
+ * one launch.  dims (int32[2]): N, K. */
+int cobevt_linear_weight_frags(const float* w, void* frag, void* frag_t, const int* dims, hipStream_t stream);
 /*
  * Weight gradient of a 3x3 / stride-1 / pad-1 convolution from the channels-last bf16 maps themselves (csrc/wgrad3.hip: the
  * pixel-major operands of the matrix instruction come out of LDS through ds_read_b64_tr_b16, no blocked copies, no atomics):

@@ -1133,9 +1133,12 @@ def test_linear_weight_frags_kernel_matches_plan_layout(cuda, n, k):
     w = torch.randn(n, k, generator=g)
     wd = w.to(cuda)
     plan = ops.ConvPlan(w[:, :, None, None], None, stride=1, pad=0, act=0, dtype=torch.bfloat16, device=cuda)
-    assert torch.equal(ag.linear_weight_frags(wd, False).reshape(-1), plan.wfrag_rows.reshape(-1))
+    f, t = ag.linear_weight_frags(wd, True, True)
+    assert torch.equal(f.reshape(-1), plan.wfrag_rows.reshape(-1))
     plant = ops.ConvPlan(w.t().contiguous()[:, :, None, None], None, stride=1, pad=0, act=0, dtype=torch.bfloat16, device=cuda)
-    assert torch.equal(ag.linear_weight_frags(wd, True).reshape(-1), plant.wfrag_rows.reshape(-1))
+    assert torch.equal(t.reshape(-1), plant.wfrag_rows.reshape(-1))
+    only = ag.linear_weight_frags(wd, False, True)
+    assert only[0] is None and torch.equal(only[1], t)
 
 
 def test_zero_pool_hands_out_disjoint_zeroed_slices(cuda):
