@@ -643,6 +643,23 @@ def conv3_weight_operand(weight, variant, dgrad):
     return op
 
 
+def conv3_weight_operand_pair(weight, var_f, var_d):
+    """conv3_weight_operand(weight, var_f, False) and (var_d >= 0) conv3_weight_operand(weight, var_d, True) from ONE launch"""
+    cout, cin = weight.shape[:2]
+    w = _f32c(weight.detach(), "weight")
+
+    def buf(o, i, variant):
+        if variant:
+            return torch.empty(((o + 127) // 128 * 4, i // 64, 9, 4, 64, 8), device=w.device, dtype=torch.bfloat16)
+        return torch.empty((o, i // 64, 9, 64), device=w.device, dtype=torch.bfloat16)
+    f = buf(cout, cin, var_f)
+    d = buf(cin, cout, var_d) if var_d >= 0 else None
+    outs = (ctypes.c_void_p * 4)(f.data_ptr() if var_f else None, None if var_f else f.data_ptr(),
+                                 d.data_ptr() if (d is not None and var_d) else None, d.data_ptr() if (d is not None and not var_d) else None)
+    _L.check(_L.load().cobevt_conv3_weight_operands2(_p(w), outs, _ints([cout, cin]), _stream()), "cobevt_conv3_weight_operands2")
+    return f, d
+
+
 def _conv3_strips(x, operand, variant, cout, bias, stride):
     """x (N, H, W, Cin) bf16 channels-last -> (N, Ho, Wo, Cout) bf16: cobevt_conv3x3_wfrag_nhwc / cobevt_conv3x3_nhwc (csrc/conv3x3.hip) with
     the operand conv3_weight_operand made for `variant`; bias fp32 (Cout,) | None"""
@@ -798,9 +815,9 @@ class Conv2dFn(torch.autograd.Function):
             var_d = -2 if need_d else -1
         elif strips:
             var_f = conv3_strips_plan(n, ho, wo, cin, cout, stride)
-            out = _conv3_strips(xl, conv3_weight_operand(weight, var_f, False), var_f, cout, bias, stride)
-            rows_d = conv3_weight_operand(weight, var_d, True) if var_d >= 0 else \
-                conv_weight_rows(weight, xl.dtype, False, need_d)[1]
+            op_f, op_d = conv3_weight_operand_pair(weight, var_f, var_d)      # both directions' operands from one launch
+            out = _conv3_strips(xl, op_f, var_f, cout, bias, stride)
+            rows_d = op_d if var_d >= 0 else conv_weight_rows(weight, xl.dtype, False, need_d)[1]
         else:
             rows_f, rows_d = conv_weight_rows(weight, xl.dtype, True, need_d and var_d < 0)
             out = _igemm_rows(xl, rows_f, cout, cin, kh, kw, bias, stride, pad, ho, wo)

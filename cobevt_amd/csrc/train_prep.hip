@@ -49,43 +49,54 @@ __global__ __launch_bounds__(kThreads) void conv_weight_rows_kernel(const float*
 //   frag:  [Op/32][I/64][9 taps][4 k-groups][2 halves][32][8]  (ops.ConvPlan.wfrag: MFMA B fragments, Op = O rounded up to 128, zero rows)
 //   rows3: [O][I/64][9 taps][64]                               (ops.ConvPlan.wgt3: the LDS-staged kernel's rows)
 // One thread per 16-byte piece; pieces [0, nfrag) then [nfrag, nfrag + nrows).
-__global__ __launch_bounds__(kThreads) void conv3_weight_operands_kernel(const float* __restrict__ w, uint4* __restrict__ frag, uint4* __restrict__ rows3,
-                                                                         int O, int I, int Cin_w, int dgrad, long nfrag, long nrows) {
-    long i = (long)blockIdx.x * kThreads + threadIdx.x;
+struct Conv3OperandJob {
+    uint4* frag;      // nullable
+    uint4* rows3;     // nullable
+    long nfrag, nrows;
+    int O, I, dgrad;
+};
+
+__device__ __forceinline__ void conv3_operand_piece(const float* __restrict__ w, const Conv3OperandJob& j, int Cin_w, long i) {
     int o, i0, tap;
     uint4* dst;
-    if (i < nfrag) {
-        dst = frag + i;
+    if (i < j.nfrag) {
+        dst = j.frag + i;
         const int n = (int)(i & 31), half = (int)((i >> 5) & 1), kg = (int)((i >> 6) & 3);
         long t = i >> 8;
         tap = (int)(t % 9);
         t /= 9;
-        const int chunks = I >> 6;
+        const int chunks = j.I >> 6;
         const int chunk = (int)(t % chunks), ct = (int)(t / chunks);
         o = ct * 32 + n;
         i0 = chunk * 64 + kg * 16 + half * 8;
-    } else if (i - nfrag < nrows) {
-        i -= nfrag;
-        dst = rows3 + i;
-        const int j = (int)(i & 7);
+    } else {
+        i -= j.nfrag;
+        dst = j.rows3 + i;
+        const int jj = (int)(i & 7);
         long t = i >> 3;
         tap = (int)(t % 9);
         t /= 9;
-        const int chunks = I >> 6;
+        const int chunks = j.I >> 6;
         const int chunk = (int)(t % chunks);
         o = (int)(t / chunks);
-        i0 = chunk * 64 + j * 8;
-    } else {
-        return;
+        i0 = chunk * 64 + jj * 8;
     }
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         // w is (Cout, Cin_w, 3, 3): forward w[o][i0 + e][tap], input gradient w[i0 + e][o][8 - tap]
-        const long idx = dgrad ? (((long)(i0 + e) * Cin_w + o) * 9 + (8 - tap)) : (((long)o * Cin_w + (i0 + e)) * 9 + tap);
-        v[e] = o < O ? w[idx] : 0.f;
+        const long idx = j.dgrad ? (((long)(i0 + e) * Cin_w + o) * 9 + (8 - tap)) : (((long)o * Cin_w + (i0 + e)) * 9 + tap);
+        v[e] = o < j.O ? w[idx] : 0.f;
     }
     *dst = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+}
+
+// pieces of job a, then of job b (the forward convolution's operand and its input gradient's: one launch per convolution and step)
+__global__ __launch_bounds__(kThreads) void conv3_weight_operands_kernel(const float* __restrict__ w, Conv3OperandJob a, Conv3OperandJob b, int Cin_w) {
+    long i = (long)blockIdx.x * kThreads + threadIdx.x;
+    const long na = a.nfrag + a.nrows, nb = b.nfrag + b.nrows;
+    if (i < na) conv3_operand_piece(w, a, Cin_w, i);
+    else if (i - na < nb) conv3_operand_piece(w, b, Cin_w, i - na);
 }
 
 // ---- dense projections on the inference row-GEMM kernel (gemm_rows3.hip): the fp32 master weight (N, K) -> its fragment table
@@ -203,19 +214,42 @@ extern "C" int cobevt_conv_weight_rows(const float* w, void* rows_fwd, void* row
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
+static bool conv3_job(Conv3OperandJob& j, void* frag, void* rows3, int Cout, int Cin, int dgrad) {
+    j.frag = (uint4*)frag; j.rows3 = (uint4*)rows3; j.dgrad = dgrad;
+    j.O = dgrad ? Cin : Cout; j.I = dgrad ? Cout : Cin;
+    j.nfrag = 0; j.nrows = 0;
+    if (!frag && !rows3) return true;
+    if (j.I % 64 != 0) return false;
+    const int Op = (j.O + 127) / 128 * 128;
+    j.nfrag = frag ? (long)Op * j.I * 9 / 8 : 0;
+    j.nrows = rows3 ? (long)j.O * j.I * 9 / 8 : 0;
+    return true;
+}
+
 extern "C" int cobevt_conv3_weight_operands(const float* w, void* frag, void* rows3, const int* dims, hipStream_t stream) {
     // dims: [Cout, Cin, dgrad]; bf16 outputs (either nullable).  Forward: O = Cout, I = Cin; input gradient: O = Cin, I = Cout.
     if (!w || !dims || (!frag && !rows3)) return COBEVT_ERR_ARG;
     const int Cout = dims[0], Cin = dims[1], dgrad = dims[2];
     if (Cout < 1 || Cin < 1 || (dgrad != 0 && dgrad != 1)) return COBEVT_ERR_SHAPE;
-    const int O = dgrad ? Cin : Cout, I = dgrad ? Cout : Cin;
-    if (I % 64 != 0) return COBEVT_ERR_SHAPE;
-    const int Op = (O + 127) / 128 * 128;
-    const long nfrag = frag ? (long)Op * I * 9 / 8 : 0, nrows = rows3 ? (long)O * I * 9 / 8 : 0;
-    const long total = nfrag + nrows;
+    Conv3OperandJob a, b;
+    if (!conv3_job(a, frag, rows3, Cout, Cin, dgrad) || !conv3_job(b, nullptr, nullptr, Cout, Cin, 0)) return COBEVT_ERR_SHAPE;
+    const long total = a.nfrag + a.nrows;
     if (total > 0x7fffffffL * (long)kThreads) return COBEVT_ERR_SHAPE;
-    hipLaunchKernelGGL(conv3_weight_operands_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, w,
-                       (uint4*)frag, (uint4*)rows3, O, I, Cin, dgrad, nfrag, nrows);
+    hipLaunchKernelGGL(conv3_weight_operands_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, w, a, b, Cin);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// both directions in one launch: outs = [fwd frag, fwd rows3, dgrad frag, dgrad rows3], each nullable
+extern "C" int cobevt_conv3_weight_operands2(const float* w, void* const* outs, const int* dims, hipStream_t stream) {
+    // dims: [Cout, Cin]
+    if (!w || !dims || !outs || (!outs[0] && !outs[1] && !outs[2] && !outs[3])) return COBEVT_ERR_ARG;
+    const int Cout = dims[0], Cin = dims[1];
+    if (Cout < 1 || Cin < 1) return COBEVT_ERR_SHAPE;
+    Conv3OperandJob a, b;
+    if (!conv3_job(a, outs[0], outs[1], Cout, Cin, 0) || !conv3_job(b, outs[2], outs[3], Cout, Cin, 1)) return COBEVT_ERR_SHAPE;
+    const long total = a.nfrag + a.nrows + b.nfrag + b.nrows;
+    if (total > 0x7fffffffL * (long)kThreads) return COBEVT_ERR_SHAPE;
+    hipLaunchKernelGGL(conv3_weight_operands_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, w, a, b, Cin);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 

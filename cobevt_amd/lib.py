@@ -108,6 +108,7 @@ SIGNATURES = {
     "cobevt_sttf_warp_bwd": (ctypes.c_int, [_vp, _vp, _vp, _vp] + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_float, _vp]),
     "cobevt_conv_weight_rows": (ctypes.c_int, [_vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_conv3_weight_operands": (ctypes.c_int, [_vp, _vp, _vp, _c_int_p, _vp]),
+    "cobevt_conv3_weight_operands2": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_void_p), _c_int_p, _vp]),
     "cobevt_linear_weight_frags": (ctypes.c_int, [_vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_conv_wgrad3_chunks": (ctypes.c_int, [_c_int_p]),
     "cobevt_conv_wgrad3": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp]),

@@ -577,6 +577,9 @@ int cobevt_conv_weight_rows(const float* w, void* rows_fwd, void* rows_dgrad, co
  * roles swapped and the taps flipped (O = Cin, I = Cout) - what cuDNN's backward-data does under train_camera.py:143-179.
  */
 int cobevt_conv3_weight_operands(const float* w, void* frag, void* rows3, const int* dims, hipStream_t stream);
+/* ... both directions from one launch: outs[4] = {forward frag, forward rows3, input-gradient frag, input-gradient rows3}, each nullable;
+ * dims (int32[2]): Cout, Cin. */
+int cobevt_conv3_weight_operands2(const float* w, void* const* outs, const int* dims, hipStream_t stream);
 /* The same for a dense projection / 1x1 stride-1 convolution on the inference row-GEMM kernel (cobevt_linear_rows_small_k) in training:
  * fp32 master weight (N, K) -> the bf16 fragment tables of cobevt_linear_rows_small_k ([Rp/32][Cp/16][64 lanes][8], both padded to 128):
  * `frag` for the projection (rows N, contraction K), `frag_t` for its input gradient dx = dy W (rows K, contraction N); either nullable,

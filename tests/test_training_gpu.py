@@ -1066,6 +1066,13 @@ def test_conv3_weight_operand_kernel_matches_plan_layouts(cuda, cout, cin):
         pland = ops.ConvPlan(w.flip(2, 3).transpose(0, 1).contiguous(), None, stride=1, pad=1, act=0, dtype=torch.bfloat16, device=cuda)
         assert torch.equal(ag.conv3_weight_operand(wd, 143, True).reshape(-1), pland.wfrag.reshape(-1))
         assert torch.equal(ag.conv3_weight_operand(wd, 0, True).reshape(-1), pland.wgt3.reshape(-1))
+        # both directions from one launch, every combination of the two layouts
+        for vf, vd in ((150, 143), (0, 0), (131, 0), (0, 152)):
+            f, d = ag.conv3_weight_operand_pair(wd, vf, vd)
+            assert torch.equal(f.reshape(-1), (plan.wfrag if vf else plan.wgt3).reshape(-1))
+            assert torch.equal(d.reshape(-1), (pland.wfrag if vd else pland.wgt3).reshape(-1))
+    f, d = ag.conv3_weight_operand_pair(wd, 150, -1)
+    assert d is None and torch.equal(f.reshape(-1), plan.wfrag.reshape(-1))
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [(3, 7, 32, 64, 32), (1, 4, 16, 32, 64), (2, 33, 128, 64, 64), (20, 16, 16, 128, 96)])
