@@ -121,11 +121,15 @@ __device__ __forceinline__ float half_wave_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void layernorm_bwd_narrow_kernel(const void* __restrict__ x, const void* __restrict__ dy,
+// NW waves per workgroup: 16 on big inputs - every workgroup ends in 2 C atomics on the SAME words, and 1,024 four-wave workgroups made the
+// 81,920-row launches 49 us for 105 MB (a serialised tail of ~1,000 atomics per word); the same waves in a quarter of the workgroups
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void layernorm_bwd_narrow_kernel(const void* __restrict__ x, const void* __restrict__ dy,
                                                                    const float* __restrict__ gamma, void* __restrict__ dx,
                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C,
                                                                    float eps, int rows_per_block, int xb, int db_, int ob) {
-    __shared__ float red[2][8][128];
+    constexpr int HW = NW * 2;                        // half-waves = rows in flight per round
+    __shared__ float red[2][HW][128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane & 31, sub = lane >> 5;
     const int groups = C >> 2;
@@ -136,8 +140,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_narrow_kernel(const void* _
     const int row1 = min(rows, row0 + rows_per_block);
     const float invC = 1.f / (float)C;
     // two rows in flight per half-wave
-    for (int row = row0 + wave * 2 + sub; row < row1; row += 16) {
-        const int rowb = row + 8;
+    for (int row = row0 + wave * 2 + sub; row < row1; row += 2 * HW) {
+        const int rowb = row + HW;
         const bool okb = rowb < row1;
         float4 xv[2], dv[2];
         xv[0] = ok ? ld4(x, xb, (size_t)row * C + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -171,10 +175,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_narrow_kernel(const void* _
         *(float4*)&red[1][wave * 2 + sub][4 * g] = db;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < C; c += NW * 64) {
         float a = 0.f, b = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { a += red[0][k][c]; b += red[1][k][c]; }
+        for (int k = 0; k < HW; ++k) { a += red[0][k][c]; b += red[1][k][c]; }
         atomicAdd(dgamma + c, a);
         atomicAdd(dbeta + c, b);
     }
@@ -545,9 +549,15 @@ extern "C" int cobevt_layernorm_bwd(const float* x, const float* dy, const float
     rpb = ((rpb + 3) / 4) * 4;
     const int blocks = (rows + rpb - 1) / rpb;
     if (C <= 128) {
-        rpb = ((rpb + 15) / 16) * 16;
-        hipLaunchKernelGGL(layernorm_bwd_narrow_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), 0, stream, (const void*)x, (const void*)dy, gamma,
-                           (void*)dx, dgamma, dbeta, rows, C, eps, rpb, 0, 0, 0);
+        if (rows >= 16384) {
+            rpb = ((rows + 255) / 256 + 63) / 64 * 64;
+            hipLaunchKernelGGL(layernorm_bwd_narrow_kernel<16>, dim3((rows + rpb - 1) / rpb), dim3(1024), 0, stream, (const void*)x, (const void*)dy,
+                               gamma, (void*)dx, dgamma, dbeta, rows, C, eps, rpb, 0, 0, 0);
+        } else {
+            rpb = ((rpb + 15) / 16) * 16;
+            hipLaunchKernelGGL(layernorm_bwd_narrow_kernel<4>, dim3((rows + rpb - 1) / rpb), dim3(256), 0, stream, (const void*)x, (const void*)dy,
+                               gamma, (void*)dx, dgamma, dbeta, rows, C, eps, rpb, 0, 0, 0);
+        }
         return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, stream, (const void*)x, (const void*)dy, gamma, (void*)dx, dgamma, dbeta, rows, C,
@@ -565,9 +575,15 @@ extern "C" int cobevt_layernorm_bwd_t(const void* x, const void* dy, const float
     rpb = ((rpb + 3) / 4) * 4;
     const int blocks = (rows + rpb - 1) / rpb;
     if (C <= 128) {
-        rpb = ((rpb + 15) / 16) * 16;
-        hipLaunchKernelGGL(layernorm_bwd_narrow_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), 0, stream, x, dy, gamma, dx, dgamma, dbeta, rows, C,
-                           eps, rpb, dtypes[0] == 0, dtypes[1] == 0, dtypes[2] == 0);
+        if (rows >= 16384) {
+            rpb = ((rows + 255) / 256 + 63) / 64 * 64;
+            hipLaunchKernelGGL(layernorm_bwd_narrow_kernel<16>, dim3((rows + rpb - 1) / rpb), dim3(1024), 0, stream, x, dy, gamma, dx, dgamma, dbeta, rows,
+                               C, eps, rpb, dtypes[0] == 0, dtypes[1] == 0, dtypes[2] == 0);
+        } else {
+            rpb = ((rpb + 15) / 16) * 16;
+            hipLaunchKernelGGL(layernorm_bwd_narrow_kernel<4>, dim3((rows + rpb - 1) / rpb), dim3(256), 0, stream, x, dy, gamma, dx, dgamma, dbeta, rows,
+                               C, eps, rpb, dtypes[0] == 0, dtypes[1] == 0, dtypes[2] == 0);
+        }
         return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, stream, x, dy, gamma, dx, dgamma, dbeta, rows, C, eps, rpb,

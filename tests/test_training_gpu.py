@@ -334,7 +334,7 @@ def test_window_self_attention_on_the_fused_projection(cuda, amp):
 
 def test_layernorm_and_gelu_backward(cuda):
     g = torch.Generator().manual_seed(3)
-    for rows, C in ((1000, 128), (37, 64), (5000, 256), (16, 512)):
+    for rows, C in ((1000, 128), (37, 64), (5000, 256), (16, 512), (20001, 128)):      # >= 16,384 narrow rows: the 16-wave workgroups
         x0 = torch.randn(rows, C, generator=g) * 2 + 0.5
         ln = torch.nn.LayerNorm(C).to(cuda)
         with torch.no_grad():
