@@ -101,14 +101,14 @@ template <typename T, int NT, int NPX, int BN> struct Conv3Store {
                     for (int e = 0; e < CH; ++e) v[e] += rv[e];
                 }
 #pragma unroll
-                for (int e = 0; e < CH; ++e) v[e] = p.act == 1 ? fmaxf(v[e], 0.f) : (p.act == 2 ? gelu_erf(v[e]) : v[e]);
+                for (int e = 0; e < CH; ++e) v[e] = p.act == 1 ? fmaxf(v[e], 0.f) : (p.act == 2 ? gelu_t<T>(v[e]) : v[e]);
                 *(uint4*)(out + off[i]) = f32_to_chunk<T>(v);
             } else {                                      // ragged Cout (not a multiple of the 16-byte chunk): scalar
                 const int col = n0 + cj * CH;
                 for (int e = 0; e < CH && col + e < p.Cout; ++e) {
                     float x = v[e];
                     if (p.residual) x += load_elem<T>((const T*)p.residual, off[i] + e);
-                    x = p.act == 1 ? fmaxf(x, 0.f) : (p.act == 2 ? gelu_erf(x) : x);
+                    x = p.act == 1 ? fmaxf(x, 0.f) : (p.act == 2 ? gelu_t<T>(x) : x);
                     store_elem<T>(out, off[i] + e, x);
                 }
             }
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(kConv3Threads) void conv3x3_kernel(Conv3Params p) {
                 const int oc = cj * CH + e, c = oc >> 2, q = oc & 3;
                 const int px = (2 * qy + (q >> 1)) * TW + 2 * qx + (q & 1);
                 float x = stage[px * SROW + c];
-                x = p.act == 1 ? fmaxf(x, 0.f) : (p.act == 2 ? gelu_erf(x) : x);
+                x = p.act == 1 ? fmaxf(x, 0.f) : (p.act == 2 ? gelu_t<T>(x) : x);
                 v[e] = x;
                 any |= (n0 + c) < p.Cout;
             }
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
                 const int oc = cj * CH + e, c = oc >> 2, qd = oc & 3;
                 const int px = s * 32 + (qd >> 1) * 16 + 2 * qx + (qd & 1);
                 float x = stage[px * SROW + c];
-                x = p.act == 1 ? fmaxf(x, 0.f) : (p.act == 2 ? gelu_erf(x) : x);
+                x = p.act == 1 ? fmaxf(x, 0.f) : (p.act == 2 ? gelu_t<T>(x) : x);
                 v[e] = x;
                 any |= (n0 + c) < p.Cout;
             }

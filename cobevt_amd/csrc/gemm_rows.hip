@@ -341,7 +341,7 @@ __global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams
                 for (int e = 0; e < CH; ++e) v[e] += rv[e];
             }
 #pragma unroll
-            for (int e = 0; e < CH; ++e) v[e] = p.act == 1 ? fmaxf(v[e], 0.f) : (p.act == 2 ? gelu_erf(v[e]) : (p.act >= 3 ? apply_act(v[e], p.act) : v[e]));
+            for (int e = 0; e < CH; ++e) v[e] = p.act == 1 ? fmaxf(v[e], 0.f) : (p.act == 2 ? gelu_t<T>(v[e]) : (p.act >= 3 ? apply_act<T>(v[e], p.act) : v[e]));
             *(uint4*)(out + (size_t)orow[i] * p.N + n0 + cj * CH) = f32_to_chunk<T>(v);
         }
     } else {                                          // ragged N (not a multiple of the 16-byte chunk): scalar
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams
             for (int e = 0; e < CH && col + e < p.N; ++e) {
                 float x = stage[row * SROW + cj * CH + e];
                 if (p.residual) x += load_elem<T>((const T*)p.residual, (size_t)m * p.N + col + e);
-                x = p.act == 1 ? fmaxf(x, 0.f) : (p.act == 2 ? gelu_erf(x) : (p.act >= 3 ? apply_act(x, p.act) : x));
+                x = p.act == 1 ? fmaxf(x, 0.f) : (p.act == 2 ? gelu_t<T>(x) : (p.act >= 3 ? apply_act<T>(x, p.act) : x));
                 store_elem<T>(out, orow * p.N + col + e, x);
             }
         }
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(kGrThreads, 2) void gemm_rows2_kernel(GemmRowsParam
                         }
                     }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = p.act == 1 ? fmaxf(v[e], 0.f) : (p.act == 2 ? gelu_erf(v[e]) : (p.act >= 3 ? apply_act(v[e], p.act) : v[e]));
+                    for (int e = 0; e < 4; ++e) v[e] = p.act == 1 ? fmaxf(v[e], 0.f) : (p.act == 2 ? gelu_t<T>(v[e]) : (p.act >= 3 ? apply_act<T>(v[e], p.act) : v[e]));
                 }
                 unsigned char* d = Cs + row * CROW + (c0w + 8 * k) * EB;
                 if constexpr (Elem<T>::kIsBf16) *(uint2*)d = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(ROWS * 8, 4) void gemm_rows3_kernel(Gr3Params p) {
             const float4 b = *(const float4*)(sb + col0);
             float v0 = acc[4 * k] + b.x + bf2f(rs[k].x & 0xffff), v1 = acc[4 * k + 1] + b.y + bf2f(rs[k].x >> 16);
             float v2 = acc[4 * k + 2] + b.z + bf2f(rs[k].y & 0xffff), v3 = acc[4 * k + 3] + b.w + bf2f(rs[k].y >> 16);
-            if (p.act) { v0 = apply_act(v0, p.act); v1 = apply_act(v1, p.act); v2 = apply_act(v2, p.act); v3 = apply_act(v3, p.act); }
+            if (p.act) { v0 = apply_act<bf16_t>(v0, p.act); v1 = apply_act<bf16_t>(v1, p.act); v2 = apply_act<bf16_t>(v2, p.act); v3 = apply_act<bf16_t>(v3, p.act); }
             *(uint2*)(Ys + row * kG3Row + (cbase + 8 * k) * 2) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
         }
         __syncthreads();                              // ROWS x 128 result staged in Ys

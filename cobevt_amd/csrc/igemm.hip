@@ -254,8 +254,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
                 if (col_ok && m < p.M) {
                     if (p.residual) v += load_elem<T>((const T*)p.residual, (size_t)m * p.Cout + col);
                     if (p.act == 1) v = fmaxf(v, 0.f);
-                    else if (p.act == 2) v = gelu_erf(v);
-                    else if (p.act >= 3) v = apply_act(v, p.act);
+                    else if (p.act == 2) v = gelu_t<T>(v);
+                    else if (p.act >= 3) v = apply_act<T>(v, p.act);
                     if (plain) store_elem<T>((T*)p.out, (size_t)m * p.Cout + col, v);
                     else store_generic<T>(p.out, p.store_mode, p.Ho, p.Wo, p.out_H, p.out_W, p.Cout, m, col, v);
                 }

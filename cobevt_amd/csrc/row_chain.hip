@@ -205,8 +205,8 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
             const int col0 = pass * 128 + cbase + 8 * k;
             const float4 b = bias4(kRcB1, col0);
             uint2 o = make_uint2(0, 0);
-            if (col0 < p.Hd) o = pack4(gelu_erf(acc[4 * k] + b.x), gelu_erf(acc[4 * k + 1] + b.y),
-                                       gelu_erf(acc[4 * k + 2] + b.z), gelu_erf(acc[4 * k + 3] + b.w));
+            if (col0 < p.Hd) o = pack4(gelu_bf16(acc[4 * k] + b.x), gelu_bf16(acc[4 * k + 1] + b.y),
+                                       gelu_bf16(acc[4 * k + 2] + b.z), gelu_bf16(acc[4 * k + 3] + b.w));
             *(uint2*)(Hs + row * kRcHRow + col0 * 2) = o;
         }
     };
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(ROWS * 8, 4) void row_chain_kernel(RowChainParams p
             const float4 b = bias4(kRcBn, col0);
             float v0 = acc[4 * k] + b.x, v1 = acc[4 * k + 1] + b.y, v2 = acc[4 * k + 2] + b.z, v3 = acc[4 * k + 3] + b.w;
             if (p.next_act == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-            else if (p.next_act == 2) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+            else if (p.next_act == 2) { v0 = gelu_bf16(v0); v1 = gelu_bf16(v1); v2 = gelu_bf16(v2); v3 = gelu_bf16(v3); }
             *(uint2*)(Ys + row * kRcRow + (cbase + 8 * k) * 2) = pack4(v0, v1, v2, v3);
         }
         __syncthreads();                              // 64 x 128 result staged in Ys

@@ -193,8 +193,8 @@ __global__ __launch_bounds__(NW * 64, 2) void row_chain64_kernel(RowChainParams 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float4 b = bias4(kB1, n, k);
-                hv[4 * k] = gelu_erf(acc[4 * k] + b.x); hv[4 * k + 1] = gelu_erf(acc[4 * k + 1] + b.y);
-                hv[4 * k + 2] = gelu_erf(acc[4 * k + 2] + b.z); hv[4 * k + 3] = gelu_erf(acc[4 * k + 3] + b.w);
+                hv[4 * k] = gelu_bf16(acc[4 * k] + b.x); hv[4 * k + 1] = gelu_bf16(acc[4 * k + 1] + b.y);
+                hv[4 * k + 2] = gelu_bf16(acc[4 * k + 2] + b.z); hv[4 * k + 3] = gelu_bf16(acc[4 * k + 3] + b.w);
             }
             hid[2 * n] = pack8(hv);
             hid[2 * n + 1] = pack8(hv + 8);
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(NW * 64, 2) void row_chain64_kernel(RowChainParams 
                     for (int r = 0; r < 16; ++r) nv[r] = fmaxf(nv[r], 0.f);
                 } else if (p.next_act == 2) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) nv[r] = gelu_erf(nv[r]);
+                    for (int r = 0; r < 16; ++r) nv[r] = gelu_bf16(nv[r]);
                 }
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {

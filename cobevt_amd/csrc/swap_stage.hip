@@ -447,8 +447,8 @@ __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams
             const int col0 = pass * 128 + cbase + 8 * k;
             const float4 bv = bias4(kB1, col0);
             uint2 o = make_uint2(0, 0);
-            if (col0 < p.Hd) o = pack4(gelu_erf(acc[4 * k] + bv.x), gelu_erf(acc[4 * k + 1] + bv.y),
-                                       gelu_erf(acc[4 * k + 2] + bv.z), gelu_erf(acc[4 * k + 3] + bv.w));
+            if (col0 < p.Hd) o = pack4(gelu_bf16(acc[4 * k] + bv.x), gelu_bf16(acc[4 * k + 1] + bv.y),
+                                       gelu_bf16(acc[4 * k + 2] + bv.z), gelu_bf16(acc[4 * k + 3] + bv.w));
             *(uint2*)(Hs + row * kHRow + col0 * 2) = o;
         }
     };
