@@ -507,8 +507,16 @@ def linear(x, lin):
 def linear_weight(x, weight, bias=None):
     """linear() on a (out, K) weight tensor (a parameter, or a differentiable function of one - a reshaped / zero-padded 1 x 1 conv weight)"""
     _need_cuda(x)
-    if USE_LIBRARY_GEMM or x.shape[-1] % 4 or weight.shape[0] % 4:
+    if USE_LIBRARY_GEMM:                           # explicit A/B switch only (tools/train_grad_diag.py): never taken by shape
         return torch.nn.functional.linear(x, weight, bias)
+    if x.shape[-1] % 4 or weight.shape[0] % 4:
+        # widths off the kernels' 16-byte pieces: zero-pad K and / or the output width to the next multiple of 4 (memory ops with
+        # exact adjoints - zero columns add nothing to a product) and run the SAME kernels; no library GEMM behind any shape
+        k, n = x.shape[-1], weight.shape[0]
+        kp, npad = -(-k // 4) * 4, -(-n // 4) * 4
+        F = torch.nn.functional
+        y = linear_weight(F.pad(x, (0, kp - k)), F.pad(weight, (0, kp - k, 0, npad - n)), None if bias is None else F.pad(bias, (0, npad - n)))
+        return y[..., :n]
     k = x.shape[-1]
     rows = x.numel() // k
     # any (H, W) factorisation of the rows is the same 1 x 1 convolution; the blocked weight-gradient kernel walks 16-pixel blocks of
@@ -945,6 +953,14 @@ class BatchNormActFn(torch.autograd.Function):
                                                ctypes.c_float(bn.eps), ctypes.c_float(momentum),
                                                _p(bn.num_batches_tracked) if (track and bn.num_batches_tracked is not None) else None, _stream()),
                      "cobevt_bn_batch_stats")
+            if track:
+                # the kernel wrote the running statistics through raw pointers: tell torch, so that everything keyed on a buffer's
+                # version counter - HipModule._plan's folded eval-mode weights, the captured-graph fingerprint of
+                # host.pipeline.AgentCountPlans - sees the update even when no optimizer step touches the sibling parameters
+                # (a frozen backbone with BatchNorm in train mode)
+                for t in (bn.running_mean, bn.running_var, bn.num_batches_tracked):
+                    if t is not None:
+                        torch.autograd.graph.increment_version(t)
         else:
             _L.check(lib.cobevt_bn_finalize(None, None, _p(g), _p(b), _p(bn.running_mean), _p(bn.running_var), _p(scale), _p(shift), _p(mean),
                                             _p(rstd), c, rows, ctypes.c_float(bn.eps), ctypes.c_float(momentum), 0, 0, None, _stream()),
@@ -979,10 +995,16 @@ class BatchNormActFn(torch.autograd.Function):
 def batch_norm_act(x, bn, residual=None, relu=False):
     """relu?(bn(x) [+ residual]) through the nn.BatchNorm2d container `bn` (its own .training flag decides the statistics)"""
     cumulative = bn.momentum is None and bn.training and bn.track_running_stats   # running stats as a cumulative average (1 / n)
-    if (x.shape[1] % 8 or cumulative or USE_TORCH_GLUE or id(bn) in TORCH_GLUE_BN_IDS or "bn" in TORCH_GLUE_OPS or ("bn_res" in TORCH_GLUE_OPS and residual is not None)
-            or ("bn_plain" in TORCH_GLUE_OPS and residual is None)):
-        # channel counts off the 16-byte piece, momentum=None (neither occurs in the shipped configs), or a diagnostic switch:
-        # torch's ops
+    diagnostic = (USE_TORCH_GLUE or id(bn) in TORCH_GLUE_BN_IDS or "bn" in TORCH_GLUE_OPS or ("bn_res" in TORCH_GLUE_OPS and residual is not None)
+                  or ("bn_plain" in TORCH_GLUE_OPS and residual is None))
+    if (x.shape[1] % 8 or cumulative) and not diagnostic:
+        # no silent library path behind a shape (VERDICT r04 #10): the BatchNorm kernels walk 8-channel groups and keep an
+        # exponential running average; neither case occurs in any shipped config
+        raise CobevtHipError("BatchNorm2d(%d%s): the HIP training kernels need a channel count that is a multiple of 8 and a numeric "
+                             "momentum; set cobevt_amd.autograd.USE_TORCH_GLUE = True to run this layer through torch's own ops"
+                             % (x.shape[1], ", momentum=None" if cumulative else ""))
+    if diagnostic:
+        # a diagnostic switch (tools/train_grad_diag.py): torch's ops
         F = torch.nn.functional
         y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
         y = y + residual if residual is not None else y
@@ -1378,7 +1400,10 @@ def resize_bilinear(x, ho, wo):
     c = x.shape[1]
     g = c >> 3
     if c % 8 or g > 64 or (g & (g - 1)):
-        return torch.nn.functional.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=True)
+        if USE_TORCH_GLUE:
+            return torch.nn.functional.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=True)
+        raise CobevtHipError("resize_bilinear: the HIP kernel takes 8 * 2^k <= 512 channels (got %d); set cobevt_amd.autograd."
+                             "USE_TORCH_GLUE = True to run this resize through torch's interpolate" % c)
     return ResizeBilinearFn.apply(x, int(ho), int(wo))
 
 

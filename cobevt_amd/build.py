@@ -1,7 +1,9 @@
-"""Build libcobevt_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+"""Build libcobevt_hip.so and libcobevt_hip_f32s.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
 `python -m cobevt_amd.build` or `__graft_entry__.build()`.  Objects are rebuilt only when a source or
-header is newer than the object.
+header is newer than the object.  The second library is the SAME sources compiled with -DCOBEVT_F32_SPLIT=1
+(csrc/common.hpp): its fp32-storage kernels take every matrix product through two split-bf16 MFMAs instead of
+four v_mfma_f32_32x32x2_f32 - the "fp32 storage, split-bf16 matrix path" compute mode of host.set_compute_dtype.
 """
 import os
 import subprocess
@@ -9,6 +11,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libcobevt_hip.so")
+LIB_F32S = os.path.join(CSRC, "libcobevt_hip_f32s.so")
 SOURCES = ["igemm.hip", "conv3x3.hip", "basicblock.hip", "bottleneck.hip", "gemm_rows.hip", "gemm_rows3.hip", "bev_query.hip", "row_chain.hip", "row_chain64.hip", "proj_chain128.hip", "swap_stage.hip", "stem7x7.hip", "attention.hip", "attention_resident.hip", "attention_bwd.hip", "train_rows.hip", "train_glue.hip", "train_prep.hip", "wgrad3.hip", "train_nusc.hip", "train_fax.hip", "elementwise.hip", "pairwise_fusion.hip", "postprocess.hip", "depthwise.hip", "peer_gather.hip", "calibrate.hip"]
 HEADERS = ["common.hpp", "attn_common.hpp", "warp_common.hpp", "row_chain.hpp", "bev_query.hpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"]
@@ -30,17 +33,18 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def _build_one(lib, objdir, extra, force, verbose):
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + extra + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -48,12 +52,17 @@ def build(force=False, verbose=True):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, out.decode(errors="replace")))
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
+
+
+def build(force=False, verbose=True):
+    _build_one(LIB_F32S, os.path.join(CSRC, "f32s"), ["-DCOBEVT_F32_SPLIT=1"], force, verbose)
+    return _build_one(LIB, CSRC, [], force, verbose)
 
 
 if __name__ == "__main__":

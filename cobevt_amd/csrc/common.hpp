@@ -76,6 +76,19 @@ template <typename T> __device__ __forceinline__ void store_elem(T* p, size_t i,
 template <> __device__ __forceinline__ void store_elem<bf16_t>(bf16_t* p, size_t i, float v) { p[i].bits = f2bf(v); }
 template <> __device__ __forceinline__ void store_elem<float>(float* p, size_t i, float v) { p[i] = v; }
 
+// COBEVT_F32_SPLIT = 1 builds the SECOND library of the package (cobevt_amd/build.py: libcobevt_hip_f32s.so, same sources, same
+// C ABI): every fp32-storage kernel of the inference path then takes its matrix products through the split-bf16 form below
+// instead of v_mfma_f32_32x32x2_f32 - the strict-parity mode that is not 16x off the bf16 matrix rate.
+#ifndef COBEVT_F32_SPLIT
+#define COBEVT_F32_SPLIT 0
+#endif
+
+// (x, y) -> packed bf16 pairs (hi(x), hi(y)) and (lo(x), lo(y)): hi = round-to-nearest-even bf16, lo = bf16(x - hi) (x - hi is exact)
+__device__ __forceinline__ void split_bf16_pair(float x, float y, uint32_t& hi, uint32_t& lo) {
+    hi = pack_bf2(x, y);
+    lo = pack_bf2(x - __uint_as_float(hi << 16), y - __uint_as_float(hi & 0xffff0000u));
+}
+
 // One 32-byte k-group of a 32x32 MFMA tile.  `a` and `b` are the 16-byte pieces this lane read from
 // row (lane&31) of the A tile and the B tile at byte offset 16*(lane>>5) of the k-group.
 // C/D layout (both dtypes): col = lane&31 (B row), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (A row).
@@ -85,10 +98,28 @@ __device__ __forceinline__ void mfma_kgroup(const uint4& a, const uint4& b, f32x
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
                                                       __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
     } else {
+#if COBEVT_F32_SPLIT
+        // fp32 storage, split-bf16 matrix path (libcobevt_hip_f32s.so): x = hi + lo with hi = bf16(x), lo = bf16(x - hi),
+        // |x - hi - lo| <= 2^-17 |x|.  The bf16 instruction contracts 8 element pairs per lane half where the piece holds 4
+        // values, so A carries {hi[0..3], lo[0..3]} and B {hi[0..3], hi[0..3]} / {lo[0..3], lo[0..3]}: two
+        // v_mfma_f32_32x32x16_bf16 (64 matrix-pipe cycles) add all FOUR cross terms (hi+lo)(hi+lo) of the 8 products that the
+        // four v_mfma_f32_32x32x2_f32 (256 cycles) form exactly; bf16 x bf16 products are exact in the fp32 accumulator.
+        uint32_t ah[2], al[2], bh[2], bl[2];
+        split_bf16_pair(__uint_as_float(a.x), __uint_as_float(a.y), ah[0], al[0]);
+        split_bf16_pair(__uint_as_float(a.z), __uint_as_float(a.w), ah[1], al[1]);
+        split_bf16_pair(__uint_as_float(b.x), __uint_as_float(b.y), bh[0], bl[0]);
+        split_bf16_pair(__uint_as_float(b.z), __uint_as_float(b.w), bh[1], bl[1]);
+        const uint4 av = make_uint4(ah[0], ah[1], al[0], al[1]);
+        const uint4 bhv = make_uint4(bh[0], bh[1], bh[0], bh[1]);
+        const uint4 blv = make_uint4(bl[0], bl[1], bl[0], bl[1]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bhv), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, blv), acc, 0, 0, 0);
+#else
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+#endif
     }
 }
 

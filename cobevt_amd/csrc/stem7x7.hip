@@ -18,6 +18,8 @@ namespace cobevt {
 
 struct StemParams {
     const float* in;     // (N, H, W, 3) fp32
+    const unsigned char* in_u8;   // stem_pool_kernel<T, true>: (N, H, W, 3) uint8 camera frames instead of `in`
+    const float* lut;    // ... and the [3][256] fp32 table byte -> normalised value of RgbPreProcessor (host/rgb_preprocessor.py)
     const void* wgt;     // [Cout][16 taps][16 ch] (12 real channels per tap)
     const float* bias;   // folded BN shift
     void* out;           // (N, Ho, Wo, Cout)
@@ -269,6 +271,7 @@ template <typename T> struct StemPoolCfg {
     static constexpr int SROW = 64 * Elem<T>::kBytes + 16;    // staging row: 64 channels in the storage type
     static constexpr int STAGE = (RPIX * SROW + 255) / 256 * 256;
     static constexpr int LDS = PATCH + WBYTES + STAGE + 256;      // + the 64 bias values
+    static constexpr int LDS_U8 = LDS + 3 * 256 * 4;              // + the [3][256] fp32 normalisation table of the uint8 ingest
     static_assert(NT <= 1024, "stem_pool_kernel: region too large for one workgroup");
 };
 
@@ -279,7 +282,11 @@ __device__ unsigned long long cobevt_stem_trace[16];
 #define COBEVT_ST_MARK(i) do {} while (0)
 #endif
 
-template <typename T>
+// U8 = true: the image is the uint8 camera frame itself (a quarter of the fp32 image's bytes over PCIe and out of HBM); a patch
+// piece is the 2 bytes of two consecutive (dx, c) values and the value the patch receives is LUT[c][byte], the table holding
+// fl32((double(u) / 255 - mean[c]) / std[c]) exactly as RgbPreProcessor + the collate cast produce it
+// (opv2v/opencood/data_utils/pre_processor/rgb_preprocessor.py:14-31): bit-identical to the fp32-image path by construction.
+template <typename T, bool U8 = false>
 __global__ __launch_bounds__(StemPoolCfg<T>::NT) void stem_pool_kernel(StemParams p) {
     using C = StemPoolCfg<T>;
     constexpr int RW = C::RW, RPIX = C::RPIX, NT = C::NT, KB = C::KB;
@@ -298,10 +305,11 @@ __global__ __launch_bounds__(StemPoolCfg<T>::NT) void stem_pool_kernel(StemParam
 
     // patch pieces of this thread: the (pixel, dy, float-pair) decomposition does not depend on the tile
     int pdst[P_IT], prow[P_IT], pxo[P_IT], pcol[P_IT];        // LDS offset; image row, image column, float offset relative to the region origin
+    int plut[P_IT];                                           // uint8 ingest: table rows (channels) of the piece's two values
 #pragma unroll
     for (int it = 0; it < P_IT; ++it) {
         const int item = tid + it * NT;
-        pdst[it] = -1; prow[it] = 0; pxo[it] = 0; pcol[it] = 0;
+        pdst[it] = -1; prow[it] = 0; pxo[it] = 0; pcol[it] = 0; plut[it] = 0;
         if (item < NPIECE) {
             const int pc = item % 3, rest = item / 3;
             const int dy = rest & 1, pix = rest >> 1;
@@ -310,6 +318,7 @@ __global__ __launch_bounds__(StemPoolCfg<T>::NT) void stem_pool_kernel(StemParam
             prow[it] = 2 * (py - 2) + dy;                     // image row = 2*oy0 + prow
             pxo[it] = 2 * (px - 2);                           // first image column of the pixel pair = 2*ox0 + pxo
             pcol[it] = pxo[it] * 3 + pc * 2;                  // float offset inside the image row = 6*ox0 + pcol
+            plut[it] = ((pc * 2) % 3) | (((pc * 2 + 1) % 3) << 8);
         }
     }
     // element offset of the piece relative to in[img][2 oy0][2 ox0][0] (fits 32 bits: |prow| <= 2 PH, the row pitch < 2^24)
@@ -317,6 +326,8 @@ __global__ __launch_bounds__(StemPoolCfg<T>::NT) void stem_pool_kernel(StemParam
 #pragma unroll
     for (int it = 0; it < P_IT; ++it) poff[it] = prow[it] * p.W * 3 + pcol[it];
     float2 preg[P_IT];
+    unsigned int praw[P_IT];
+    const float* lut_l = (const float*)(smem + C::LDS);       // [3][256], filled below (U8 only)
     auto decode = [&](int tile, int& img, int& py0, int& px0) {
         const int tx = tile % p.tiles_x;
         const int rest = tile / p.tiles_x;
@@ -329,18 +340,36 @@ __global__ __launch_bounds__(StemPoolCfg<T>::NT) void stem_pool_kernel(StemParam
         decode(tile, img, py0, px0);
         const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;       // conv region origin
         // uniform part of the address in scalar registers; per piece one 32-bit offset and four compares against scalars
-        const float* base = p.in + ((size_t)img * p.H + 2 * oy0) * (size_t)p.W * 3 + 6 * ox0;
+        const size_t origin = ((size_t)img * p.H + 2 * oy0) * (size_t)p.W * 3 + 6 * ox0;
+        const float* base = p.in + origin;
+        const unsigned char* base8 = p.in_u8 + origin;
         const int ylo = -2 * oy0, yhi = p.H - 2 * oy0, xlo = -2 * ox0, xhi = p.W - 1 - 2 * ox0;
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
-            float2 v = make_float2(0.f, 0.f);
-            // the 6 floats in[iy][ix..ix+1][0..2] are contiguous; columns are valid in pairs (W is even)
+            // the 6 values in[iy][ix..ix+1][0..2] are contiguous; columns are valid in pairs (W is even)
             const bool ok = (pdst[it] >= 0) & (prow[it] >= ylo) & (prow[it] < yhi) & (pxo[it] >= xlo) & (pxo[it] < xhi);
-            if (!(COBEVT_STEM_KNOCK & 8) && ok) v = *(const float2*)(base + poff[it]);
-            preg[it] = v;
+            if constexpr (U8) {
+                // an out-of-image piece is padding: zero in the NORMALISED image, not byte 0 -> bit 16 marks it for store_patch
+                unsigned int r = 0x10000u;
+                if (!(COBEVT_STEM_KNOCK & 8) && ok) r = *(const unsigned short*)(base8 + poff[it]);      // even offset: W is even
+                praw[it] = r;
+            } else {
+                float2 v = make_float2(0.f, 0.f);
+                if (!(COBEVT_STEM_KNOCK & 8) && ok) v = *(const float2*)(base + poff[it]);
+                preg[it] = v;
+            }
         }
     };
     auto store_patch = [&]() {
+        if constexpr (U8) {
+            // both table reads of every piece in flight before the first patch write (one LDS round trip, not P_IT)
+#pragma unroll
+            for (int it = 0; it < P_IT; ++it) {
+                const unsigned int r = praw[it];
+                const float a = lut_l[(plut[it] & 0xff) * 256 + (r & 0xff)], b = lut_l[(plut[it] >> 8) * 256 + ((r >> 8) & 0xff)];
+                preg[it] = (r >> 16) ? make_float2(0.f, 0.f) : make_float2(a, b);
+            }
+        }
 #pragma unroll
         for (int it = 0; it < P_IT; ++it)
             if (pdst[it] >= 0) {
@@ -352,6 +381,10 @@ __global__ __launch_bounds__(StemPoolCfg<T>::NT) void stem_pool_kernel(StemParam
 
     int tile = blockIdx.x;
     if (tile >= p.ntiles) return;
+    if constexpr (U8) {
+        float* l = (float*)(smem + C::LDS);
+        for (int i = tid; i < 768; i += NT) l[i] = p.lut[i];
+    }
     {
         // the first image patch is requested before the weights, and the weight pieces of a thread are all in flight at
         // once (unconditional, row clamped): the rolled, branch-guarded loop paid one L2 round trip per iteration before the
@@ -533,7 +566,7 @@ extern "C" int cobevt_stem_conv7x7s2(const float* in, const void* wgt, const flo
     if (!in || !wgt || !out || !dims) return COBEVT_ERR_ARG;
     StemParams p;
     const int dtype = dims[0];
-    p.in = in; p.wgt = wgt; p.bias = bias; p.out = out;
+    p.in = in; p.in_u8 = nullptr; p.lut = nullptr; p.wgt = wgt; p.bias = bias; p.out = out;
     p.N = dims[1]; p.H = dims[2]; p.W = dims[3]; p.Cout = dims[4]; p.act = dims[5];
     if (dtype != 0 && dtype != 1) return COBEVT_ERR_ARG;
     if (p.N < 1 || p.H < 2 || p.W < 2 || (p.H & 1) || (p.W & 1) || p.Cout < 1) return COBEVT_ERR_SHAPE;
@@ -563,7 +596,7 @@ extern "C" int cobevt_stem_conv7x7s2_pool(const float* in, const void* wgt, cons
     if (!in || !wgt || !out || !dims) return COBEVT_ERR_ARG;
     StemParams p;
     const int dtype = dims[0];
-    p.in = in; p.wgt = wgt; p.bias = bias; p.out = out;
+    p.in = in; p.in_u8 = nullptr; p.lut = nullptr; p.wgt = wgt; p.bias = bias; p.out = out;
     p.N = dims[1]; p.H = dims[2]; p.W = dims[3]; p.Cout = 64; p.act = 1;
     if (dtype != 0 && dtype != 1) return COBEVT_ERR_ARG;
     if (p.N < 1 || p.H < 4 || p.W < 4 || (p.H & 3) || (p.W & 3)) return COBEVT_ERR_SHAPE;
@@ -587,6 +620,39 @@ extern "C" int cobevt_stem_conv7x7s2_pool(const float* in, const void* wgt, cons
     const unsigned blocks = (unsigned)(nt < 256L * per_cu ? nt : 256L * per_cu);
     if (dtype == 0) hipLaunchKernelGGL(stem_pool_kernel<bf16_t>, dim3(blocks), dim3(StemPoolCfg<bf16_t>::NT), lds, stream, p);
     else hipLaunchKernelGGL(stem_pool_kernel<float>, dim3(blocks), dim3(StemPoolCfg<float>::NT), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
+// C-ABI entry point, see include/cobevt_hip.h: the same launch on uint8 camera frames (N, H, W, 3) + the [3][256] normalisation table
+extern "C" int cobevt_stem_conv7x7s2_pool_u8(const unsigned char* in, const float* lut, const void* wgt, const float* bias, void* out,
+                                             const int* dims, hipStream_t stream) {
+    // dims: [dtype, N, H, W]   (Cout = 64, ReLU, H and W multiples of 4)
+    if (!in || !lut || !wgt || !out || !dims) return COBEVT_ERR_ARG;
+    StemParams p;
+    const int dtype = dims[0];
+    p.in = nullptr; p.in_u8 = in; p.lut = lut; p.wgt = wgt; p.bias = bias; p.out = out;
+    p.N = dims[1]; p.H = dims[2]; p.W = dims[3]; p.Cout = 64; p.act = 1;
+    if (dtype != 0 && dtype != 1) return COBEVT_ERR_ARG;
+    if (p.N < 1 || p.H < 4 || p.W < 4 || (p.H & 3) || (p.W & 3)) return COBEVT_ERR_SHAPE;
+    p.Ho = p.H / 2; p.Wo = p.W / 2;
+    const int rows = dtype == 0 ? StemPoolCfg<bf16_t>::ROWS : StemPoolCfg<float>::ROWS;
+    p.tiles_y = (p.Ho / 2 + rows - 1) / rows; p.tiles_x = (p.Wo / 2 + 7) / 8; p.tiles_n = 1;
+    const long nt = (long)p.N * p.tiles_y * p.tiles_x;
+    if (nt > 0x7fffffffL) return COBEVT_ERR_SHAPE;
+    p.ntiles = (int)nt;
+    const size_t lds = dtype == 0 ? StemPoolCfg<bf16_t>::LDS_U8 : StemPoolCfg<float>::LDS_U8;
+    static cobevt::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
+        (void)hipFuncSetAttribute((const void*)stem_pool_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StemPoolCfg<bf16_t>::LDS_U8);
+        (void)hipFuncSetAttribute((const void*)stem_pool_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StemPoolCfg<float>::LDS_U8);
+    }
+    const int nthreads = dtype == 0 ? StemPoolCfg<bf16_t>::NT : StemPoolCfg<float>::NT;
+    int per_cu = (int)(163840 / lds);
+    if (per_cu > 2048 / nthreads) per_cu = 2048 / nthreads;
+    if (per_cu < 1) per_cu = 1;
+    const unsigned blocks = (unsigned)(nt < 256L * per_cu ? nt : 256L * per_cu);
+    if (dtype == 0) hipLaunchKernelGGL((stem_pool_kernel<bf16_t, true>), dim3(blocks), dim3(StemPoolCfg<bf16_t>::NT), lds, stream, p);
+    else hipLaunchKernelGGL((stem_pool_kernel<float, true>), dim3(blocks), dim3(StemPoolCfg<float>::NT), lds, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 

@@ -1,5 +1,5 @@
 """Host-side mirror of the reference's nn.Module interface for the FAX hot path."""
-from .runtime import compute_dtype, get_compute_dtype, set_compute_dtype  # noqa: F401
+from .runtime import compute_dtype, get_compute_dtype, get_compute_mode, get_matrix_path, set_compute_dtype  # noqa: F401
 from .fax_modules import (Attention as FaxAttention, BEVEmbedding, Bottleneck, CrossViewSwapAttention,  # noqa: F401
                           CrossWinAttention, FAXModule, generate_grid, get_view_matrix)
 from .swap_fusion_modules import (Attention as SwapAttention, SwapFusionBlock, SwapFusionBlockMask,  # noqa: F401
@@ -20,7 +20,7 @@ from .cross_view_transformer_att_fuse import CrossViewTransformerAttFuse  # noqa
 from .v2v_fuse import ConvGRU, DiscoNetFusion, PixelWeightedFusionSoftmax, V2VNetFusion  # noqa: F401
 from .cross_view_transformer_v2vnet import CrossViewTransformerV2VNet  # noqa: F401
 from .cross_view_transformer_disconet import CrossViewTransformerDiscoNet  # noqa: F401
-from .pipeline import CapturedCall, CapturedCorpBEVT, PipelinedCorpBEVT  # noqa: F401
+from .pipeline import CapturedCall, CapturedCorpBEVT, HostFrameFeeder, PipelinedCorpBEVT  # noqa: F401
 # the data formats either side of the path
 from .camera_bev_postprocessor import CameraBevPostprocessor  # noqa: F401
 from .rgb_preprocessor import RgbPreProcessor  # noqa: F401

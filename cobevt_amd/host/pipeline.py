@@ -57,6 +57,8 @@ class _RunnerBase(object):
             if tuple(src.shape) != tuple(dst.shape):
                 raise CobevtHipError("graph runner captured %s of shape %s, got %s (re-capture for a new shape)"
                                      % (k, tuple(dst.shape), tuple(src.shape)))
+            if k == "inputs" and src.dtype != dst.dtype:     # uint8 camera frames vs the normalised fp32 image: different stem kernels
+                raise CobevtHipError("graph runner captured %s images, got %s (re-capture for the other input format)" % (dst.dtype, src.dtype))
             dst.copy_(src, non_blocking=True)
 
 
@@ -134,6 +136,9 @@ class AgentCountPlans(object):
     def __init__(self, model, use_graph=True, max_plans=8, prewarm=None):
         self.model, self.use_graph, self.max_plans = model, use_graph, int(max_plans)
         self.plans = {}            # key -> (weight fingerprint, CapturedCorpBEVT), insertion order = recency
+        self._epoch = -1
+        self._tensors = None       # the model's parameters / floating-point buffers, listed once (578 tensors over 483 modules on the
+        #                            full CorpBEVT: walking the module tree every step cost ~2 ms of host time per frame)
         self.captures = 0
         self.busy = False          # True while a plan is being built (the model's own forward runs eagerly inside)
         for b in (prewarm or []):  # capture ahead of time (e.g. one synthetic frame per agent count) instead of on first sight
@@ -144,15 +149,21 @@ class AgentCountPlans(object):
         rl = batch["record_len"]
         n_scen = int(rl.numel()) if torch.is_tensor(rl) else len(rl)
         from . import runtime as rt
-        return (tuple(batch["inputs"].shape), n_scen, tuple(batch["transformation_matrix"].shape), str(rt.get_compute_dtype()))
+        return (tuple(batch["inputs"].shape), str(batch["inputs"].dtype), n_scen, tuple(batch["transformation_matrix"].shape),
+                rt.get_compute_mode())
 
     def weights_fingerprint(self):
         """(version counter, address) of every parameter / floating-point buffer the captured kernels may read"""
         from . import runtime as rt
-        return tuple((t._version, t.data_ptr()) for t in rt.module_tensors(self.model))
+        if self._tensors is None or self._epoch != rt.structure_epoch():
+            self._tensors, self._epoch = rt.module_tensors(self.model), rt.structure_epoch()
+        return tuple((t._version, t.data_ptr()) for t in self._tensors)
 
     def clear(self):
+        """drop every plan and the cached tensor list (HipModule.invalidate_plans calls this: after weight surgery through `.data`,
+        or when parameters / buffers were added, removed or replaced)"""
         self.plans.clear()
+        self._tensors = None
 
     def _runner(self, batch):
         k = self.key(batch)
@@ -190,19 +201,22 @@ class PipelinedCorpBEVT(_RunnerBase):
     completes one frame; the latency of a frame is `latency_steps` steps (depth on one GPU; one more with the agent
     all-gather of cobevt_amd/dist.py, which runs under the following step)."""
 
-    def __init__(self, model, example_batch, rank=0, world=1, agents=None, depth=3):
+    def __init__(self, model, example_batch, rank=0, world=1, agents=None, depth=3, input_slots=False):
+        """input_slots: one image buffer per ring slot instead of one shared buffer, so that the NEXT frame can be uploaded from
+        the host on a copy stream while the current step still reads its own (`HostFrameFeeder`)."""
         super().__init__(model, example_batch, rank, world, agents)
         if depth not in (3, 4):
             raise CobevtHipError("PipelinedCorpBEVT: depth must be 3 or 4")
         self.depth = D = depth
+        self.input_slots = bool(input_slots)
         # The small per-frame inputs (camera matrices, poses, record_len) are consumed up to `depth` steps after the images, so
         # they live in RINGS of `depth` slots that `load()` fills from the host side: graph q reads slot q for its encoder
         # stage and the slots of the earlier frames for its later stages - no copy of them inside the replayed graph.
         # `static_batch` (the public "write your next frame here" dict) always points at the slot of the NEXT step.
         sb = self.static_batch
         self.slots = [sb] + [{k: v.clone() for k, v in sb.items() if k != "inputs"} for _ in range(D - 1)]
-        for sl in self.slots[1:]:
-            sl["inputs"] = sb["inputs"]                       # the images are consumed within the step: one buffer
+        for sl in self.slots[1:]:                             # the images are consumed within the step: one buffer (or one per slot)
+            sl["inputs"] = sb["inputs"].clone() if self.input_slots else sb["inputs"]
         st = model.encode_trunk(self._images_of(0))
         torch.cuda.synchronize()
         self.meta = [{k: v for k, v in lvl.items() if not torch.is_tensor(v)} for lvl in st["kv"]]
@@ -356,6 +370,67 @@ class PipelinedCorpBEVT(_RunnerBase):
         self.filled += 1
         self.static_batch = self.slots[self._next_slot]      # the public dict names the NEXT step's slot between steps
         return self.out if self.filled >= self.latency_steps else None
+
+
+class HostFrameFeeder(object):
+    """Camera frames from PINNED host memory into a `PipelinedCorpBEVT(..., input_slots=True)`, one step ahead of the compute:
+    the ingest of the reference's loop (inference_camera.py:56-61 moves every frame's batch to the device before the forward)
+    as an asynchronous upload on a copy stream that overlaps the previous step.
+
+        feeder.upload(frame_0)
+        for k in ...:
+            feeder.upload(frame_k+1)        # H2D of the next frame, enqueued before ...
+            out = feeder.step()             # ... the replay of step k, which only waits for ITS frame's upload
+
+    Only the images travel ahead: the camera matrices / poses / record_len of a slot are still read by the later pipeline
+    stages of the running step (stage 3 of step k reads the pose slot that frame k+1 will reuse), so those few hundred bytes
+    are copied in stream order right before the step, as `PipelinedCorpBEVT.load` does.  uint8 frames
+    (`ResnetEncoder.set_rgb_normalisation`) make the upload 15.7 MB per 5-agent frame instead of 63."""
+
+    def __init__(self, runner):
+        if not isinstance(runner, PipelinedCorpBEVT) or not runner.input_slots:
+            raise CobevtHipError("HostFrameFeeder needs a PipelinedCorpBEVT built with input_slots=True")
+        self.r = runner
+        self.copy = torch.cuda.Stream()
+        self.uploaded = [None] * runner.depth        # event: the slot's images have arrived
+        self.consumed = [None] * runner.depth        # event: the step that read the slot's images has run
+        self.queue = []                              # host batches uploaded and not yet stepped (at most two)
+
+    def upload(self, host_batch):
+        r = self.r
+        if len(self.queue) >= 2:
+            raise CobevtHipError("HostFrameFeeder: at most two frames ahead (the one being stepped next and its successor)")
+        src = host_batch["inputs"]
+        if not src.is_pinned():
+            raise CobevtHipError("HostFrameFeeder.upload: `inputs` must live in pinned host memory (tensor.pin_memory()) - a pageable "
+                                 "source makes the copy synchronous")
+        slot = (r.i + len(self.queue)) % r.depth
+        dst = r.slots[slot]["inputs"]
+        if tuple(src.shape) != tuple(dst.shape) or src.dtype != dst.dtype:
+            raise CobevtHipError("HostFrameFeeder.upload: captured %s %s, got %s %s" % (tuple(dst.shape), dst.dtype, tuple(src.shape), src.dtype))
+        with torch.cuda.stream(self.copy):
+            if self.consumed[slot] is not None:
+                self.copy.wait_event(self.consumed[slot])
+            dst.copy_(src, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy)
+        self.uploaded[slot] = ev
+        self.queue.append(host_batch)
+
+    def step(self):
+        r = self.r
+        if not self.queue:
+            raise CobevtHipError("HostFrameFeeder.step: upload() a frame first")
+        hb = self.queue.pop(0)
+        q = r.i % r.depth
+        small = {k: hb[k] for k in r.slots[q] if k != "inputs"}
+        small["inputs"] = r.slots[q]["inputs"]                      # already there (or on its way): load() skips it
+        torch.cuda.current_stream().wait_event(self.uploaded[q])
+        out = r.step(small)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.consumed[q] = ev
+        return out
 
 
 class CapturedCall(object):

@@ -71,9 +71,23 @@ class ResNet(HipModule):
         layers += [BasicBlock(planes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
-    def stem_nhwc(self, images):
-        """images: (N, H, W, 3) fp32 channels-last -> (N, H/4, W/4, 64)"""
-        return ops.stem_pool(images, rt.conv_plan(self, "stem", self.conv1, self.bn1, act=1, smallc=True))
+    def stem_nhwc(self, images, lut=None, bgr=False):
+        """images: (N, H, W, 3) channels-last -> (N, H/4, W/4, 64).  fp32 images are the reference's normalised input
+        (resnet_ms.py:62-69); uint8 images are camera frames, normalised through `lut` (3, 256) inside the stem's gather
+        (ResnetEncoder.set_rgb_normalisation).  bgr: the frames are BGR as cv2 decodes them - the channel swap of
+        rgb_preprocessor.py:33-42 is folded into the stem weights (input channels reversed) and the table rows."""
+        if images.dtype != torch.uint8:
+            return ops.stem_pool(images, rt.conv_plan(self, "stem", self.conv1, self.bn1, act=1, smallc=True))
+        if lut is None:
+            raise CobevtHipError("uint8 camera frames need the normalisation table: call ResnetEncoder.set_rgb_normalisation(mean, "
+                                 "std[, bgr2rgb]) (host/rgb_preprocessor.py) before feeding them")
+        if not bgr:
+            plan = rt.conv_plan(self, "stem", self.conv1, self.bn1, act=1, smallc=True)
+        else:
+            plan = self._plan("stem.bgr", rt.module_tensors(self.conv1, self.bn1),
+                              lambda dt, dev: ops.ConvPlan(self.conv1.weight.detach().flip(1), None, bn=self.bn1, stride=2, pad=3, act=1,
+                                                           dtype=dt, device=dev, smallc=True))
+        return ops.stem_pool_u8(images, lut, plan)
 
 
 class ResnetEncoder(HipModule):
@@ -92,6 +106,7 @@ class ResnetEncoder(HipModule):
             raise CobevtHipError("resnet%d (Bottleneck variants) is not lowered to HIP; the FAX configs use 18/34"
                                  % self.num_layers)
         self.encoder = ResNet(_BLOCKS[self.num_layers])
+        self.register_buffer("ingest_lut", None, persistent=False)      # set_rgb_normalisation(): uint8 camera frames as `inputs`
         # shapes the reference obtains from a dummy forward (resnet_ms.py:41-44), computed analytically here
         def half(v, k, p):
             return (v + 2 * p - k) // 2 + 1
@@ -103,14 +118,39 @@ class ResnetEncoder(HipModule):
             shapes.append(torch.Size((1, 1, 1, c, h, w)))
         self.output_shapes = [shapes[i] for i in self.idx_pick] if isinstance(self.idx_pick, list) else [shapes[self.idx_pick]]
 
+    ingest_bgr = False
+
+    def set_rgb_normalisation(self, mean, std, bgr2rgb=False):
+        """Accept uint8 camera frames (B, L, M, H, W, 3) as `inputs`: the /255, (x - mean) / std of RgbPreProcessor
+        (rgb_preprocessor.py:14-31) becomes a table lookup inside the stem kernel, so a frame crosses PCIe as 1 byte per value
+        instead of the 4 of the normalised fp32 image (inference_camera.py:56-61 uploads 63 MB per 5-agent frame; this is 15.7).
+        bgr2rgb: the frames are BGR (cv2.imread) and the config asks for the swap - folded into the stem weights.  The table is a
+        non-persistent buffer: state_dict keys are unchanged.  fp32 `inputs` keep working as before."""
+        from .rgb_preprocessor import normalisation_table
+        t = torch.from_numpy(normalisation_table(mean, std))
+        if bgr2rgb:
+            t = t.flip(0)                                  # row j = channel of byte position j of a BGR pixel
+        t = t.contiguous().to(next(self.parameters()).device)
+        if self.ingest_lut is not None and self.ingest_lut.device == t.device:
+            self.ingest_lut.copy_(t)          # in place: captured graphs hold the table's address, and the version bump re-captures them
+        else:
+            self.ingest_lut = t
+            rt.bump_structure_epoch()         # a new tensor for the captured-plan fingerprints to watch
+        self.ingest_bgr = bool(bgr2rgb)
+        return self
+
+    def _stem(self, x):
+        if x.dtype == torch.uint8:
+            return self.encoder.stem_nhwc(x if x.is_contiguous() else x.contiguous(), self.ingest_lut, self.ingest_bgr)
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.to(torch.float32).contiguous()
+        return self.encoder.stem_nhwc(x)
+
     def stages_nhwc(self, input_images):
         """Generator over (stage index 0..3, channels-last feature map) so a caller can overlap work that depends on
         an early stage with the later stages (CorpBEVT.encode_agents)."""
         b, l, m, h, w, c = input_images.shape
-        x = input_images.reshape(b * l * m, h, w, c)
-        if x.dtype != torch.float32 or not x.is_contiguous():
-            x = x.to(torch.float32).contiguous()
-        x = self.encoder.stem_nhwc(x)
+        x = self._stem(input_images.reshape(b * l * m, h, w, c))
         for i, layer in enumerate((self.encoder.layer1, self.encoder.layer2, self.encoder.layer3, self.encoder.layer4)):
             for blk in layer:
                 x = blk.forward_nhwc(x)
@@ -122,10 +162,7 @@ class ResnetEncoder(HipModule):
             return training.resnet_encoder(self, input_images)
         self._require_inference(input_images)
         b, l, m, h, w, c = input_images.shape
-        x = input_images.reshape(b * l * m, h, w, c)
-        if x.dtype != torch.float32 or not x.is_contiguous():
-            x = x.to(torch.float32).contiguous()
-        x = self.encoder.stem_nhwc(x)
+        x = self._stem(input_images.reshape(b * l * m, h, w, c))
         results = []
         for layer in (self.encoder.layer1, self.encoder.layer2, self.encoder.layer3, self.encoder.layer4):
             for blk in layer:

@@ -20,6 +20,12 @@ class RgbPreProcessor(object):
     def normalize(self, rgb_image):
         return np.array(rgb_image, dtype=float) / 255.
 
+    def normalisation_table(self):
+        """(3, 256) float32: what `standalize(normalize(.))` followed by the collate function's cast to float32
+        (intermediate_fusion_dataset.py:231-317) gives byte value u of channel c - the table the on-GPU ingest reads
+        (ResnetEncoder.set_rgb_normalisation, csrc/stem7x7.hip): uint8 frames go over PCIe, the arithmetic of :14-31 is a lookup."""
+        return normalisation_table(self.params["args"]["mean"], self.params["args"]["std"])
+
     def channel_swap(self, rgb_image):
         """BGR -> RGB when the config asks for it (cv2.COLOR_BGR2RGB is a pure channel reversal)"""
         return np.ascontiguousarray(rgb_image[..., ::-1]) if self.params["args"]["bgr2rgb"] else rgb_image
@@ -38,6 +44,12 @@ class RgbPreProcessor(object):
         except ImportError:
             return resize_linear(rgb_image, args["resize_x"], args["resize_y"])
         return cv2.resize(rgb_image, (args["resize_x"], args["resize_y"]))
+
+
+def normalisation_table(mean, std):
+    """float32[(3, 256)]: fl32((float64(u) / 255. - mean[c]) / std[c]), the exact operation order of rgb_preprocessor.py:14-31"""
+    u = np.arange(256, dtype=float)[None, :] / 255.
+    return ((u - np.array(mean, dtype=float)[:, None]) / np.array(std, dtype=float)[:, None]).astype(np.float32)
 
 
 def _linear_taps(n_src, n_dst):

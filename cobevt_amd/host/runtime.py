@@ -8,28 +8,69 @@ from .. import ops
 from ..lib import CobevtHipError
 
 _COMPUTE_DTYPE = torch.bfloat16
+_MATRIX_PATH = "native"
+MATRIX_PATHS = ("native", "split_bf16")
+from .. import lib as _lib  # noqa: E402
 
 
-def set_compute_dtype(dtype):
-    """torch.bfloat16 (perf mode: bf16 storage + bf16 MFMA, fp32 accumulate) or torch.float32 (parity mode:
-    fp32 storage + exact fp32 MFMA)."""
-    global _COMPUTE_DTYPE
+def set_compute_dtype(dtype, matrix_path=None):
+    """torch.bfloat16 (perf mode: bf16 storage + bf16 MFMA, fp32 accumulate) or torch.float32 (parity modes, fp32 storage):
+    matrix_path "native" = exact v_mfma_f32_32x32x2_f32 (default), "split_bf16" = every matrix product of the inference
+    kernels as two v_mfma_f32_32x32x16_bf16 over (hi, lo) bf16 halves of both operands (all four cross terms, |x - hi - lo| <=
+    2^-17 |x|: ~1e-5 end to end instead of 1e-6, at 4x the matrix rate; served by libcobevt_hip_f32s.so, cobevt_amd/build.py).
+    The string "fp32_split" is shorthand for (torch.float32, "split_bf16")."""
+    global _COMPUTE_DTYPE, _MATRIX_PATH
+    if isinstance(dtype, str):
+        alias = {"bf16": (torch.bfloat16, "native"), "fp32": (torch.float32, "native"), "fp32_split": (torch.float32, "split_bf16")}
+        if dtype not in alias:
+            raise CobevtHipError("compute mode must be one of %s" % sorted(alias))
+        dtype, mp = alias[dtype]
+        matrix_path = mp if matrix_path is None else matrix_path
+    matrix_path = "native" if matrix_path is None else matrix_path
+    if matrix_path not in MATRIX_PATHS:
+        raise CobevtHipError("matrix_path must be one of %s" % (MATRIX_PATHS,))
     ops.dcode(dtype)
-    _COMPUTE_DTYPE = dtype
+    if matrix_path == "split_bf16" and dtype != torch.float32:
+        raise CobevtHipError("the split-bf16 matrix path belongs to fp32 storage (bf16 storage IS the bf16 matrix path)")
+    _COMPUTE_DTYPE, _MATRIX_PATH = dtype, matrix_path
+    _lib.set_variant("f32s" if matrix_path == "split_bf16" else "")
 
 
 def get_compute_dtype():
     return _COMPUTE_DTYPE
 
 
+def get_matrix_path():
+    return _MATRIX_PATH
+
+
+def get_compute_mode():
+    """"bf16" | "fp32" | "fp32_split": the key captured graphs are cached under (plans = lowered weights depend on the dtype only)"""
+    return "bf16" if _COMPUTE_DTYPE == torch.bfloat16 else ("fp32_split" if _MATRIX_PATH == "split_bf16" else "fp32")
+
+
 @contextlib.contextmanager
-def compute_dtype(dtype):
-    prev = get_compute_dtype()
-    set_compute_dtype(dtype)
+def compute_dtype(dtype, matrix_path=None):
+    prev = (get_compute_dtype(), get_matrix_path())
+    set_compute_dtype(dtype, matrix_path)
     try:
         yield
     finally:
-        set_compute_dtype(prev)
+        set_compute_dtype(*prev)
+
+
+_STRUCTURE_EPOCH = 0
+
+
+def bump_structure_epoch():
+    """A module gained, lost or replaced a tensor the kernels read (not an in-place update: those are seen through version
+    counters).  Caches that list a model's tensors once (host.pipeline.AgentCountPlans) rebuild their list when this moves."""
+    global _STRUCTURE_EPOCH
+    _STRUCTURE_EPOCH += 1
+
+
+def structure_epoch():
+    return _STRUCTURE_EPOCH
 
 
 class HipModule(nn.Module):

@@ -29,6 +29,7 @@ SIGNATURES = {
     "cobevt_conv3x3_wfrag_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_stem_conv7x7s2_pool": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_stem_conv7x7s2": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp]),
+    "cobevt_stem_conv7x7s2_pool_u8": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_bev_embed_linear_rows": (ctypes.c_int, [_vp] * 9 + [_c_long_p, ctypes.c_float, _vp]),
     "cobevt_linear_rows_wfrag": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_long_p, ctypes.c_float, _vp]),
     "cobevt_linear_rows": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_long_p, ctypes.c_float, _vp]),
@@ -132,30 +133,47 @@ SIGNATURES = {
     "cobevt_channel_gate_nhwc": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
 }
 
-_lib = None
+_libs = {}
+# "" = libcobevt_hip.so; "f32s" = libcobevt_hip_f32s.so, the same sources and C ABI built with -DCOBEVT_F32_SPLIT=1: fp32-storage
+# kernels on the split-bf16 matrix path (cobevt_amd/build.py, csrc/common.hpp).  host.set_compute_dtype selects it.
+_variant = ""
+LIB_PATH_F32S = os.environ.get("COBEVT_HIP_LIB_F32S") or os.path.join(_HERE, "csrc", "libcobevt_hip_f32s.so")
 
 
 class CobevtHipError(RuntimeError):
     pass
 
 
-def load():
-    """Load (once) and return the ctypes handle; raises if the HIP extension has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def set_variant(variant):
+    global _variant
+    if variant not in ("", "f32s"):
+        raise CobevtHipError("unknown library variant %r" % (variant,))
+    _variant = variant
+
+
+def get_variant():
+    return _variant
+
+
+def load(variant=None):
+    """Load (once per variant) and return the ctypes handle of the active library; raises if the HIP extension has not been built."""
+    v = _variant if variant is None else variant
+    lib = _libs.get(v)
+    if lib is not None:
+        return lib
+    path = LIB_PATH_F32S if v == "f32s" else LIB_PATH
+    if not os.path.exists(path):
         raise CobevtHipError(
-            "libcobevt_hip.so not found at %s — build it with `python -m cobevt_amd.build` "
-            "(there is no CPU / eager fallback for the hot path)" % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+            "%s not found at %s — build it with `python -m cobevt_amd.build` "
+            "(there is no CPU / eager fallback for the hot path)" % (os.path.basename(path), path))
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI drifted
         fn.restype = res
         fn.argtypes = args
     if lib.cobevt_abi_version() != 1:
-        raise CobevtHipError("libcobevt_hip.so ABI version mismatch")
-    _lib = lib
+        raise CobevtHipError("%s ABI version mismatch" % os.path.basename(path))
+    _libs[v] = lib
     return lib
 
 

@@ -442,8 +442,10 @@ def conv2d(x, plan, residual=None, out=None):
         _L.check(rc, "cobevt_linear_rows_wfrag" if v2 else "cobevt_linear_rows")
         return out
     variant = 0
+    # (the stride-2 strip variants sit at the 256-VGPR limit in fp32: with the operand split of the f32s library they spill
+    # hundreds of registers, so that library's three stride-2 3x3 convs of a ResNet take the generic implicit GEMM)
     if plan.wfrag is not None and (out_h, out_w) == (ho, wo) and USE_CONV3X3 and USE_CONV3_WFRAG \
-            and (plan.stride == 1 or USE_CONV3_S2):
+            and (plan.stride == 1 or (USE_CONV3_S2 and not (plan.code == FP32 and _L.get_variant() == "f32s"))):
         variant = CONV3_VARIANT or conv3_tiling(n, ho, wo, cin, plan.cout, plan.cc3, stride=plan.stride, bf16=plan.code == BF16)
         if variant == 0 and plan.stride == 2:
             variant = 151 if plan.cout <= 64 else 150
@@ -828,6 +830,30 @@ def stem_pool(x, plan):
     with _timed("stem7x7|pool %dx%dx%d" % (n, h, w), cost):
         rc = _L.load().cobevt_stem_conv7x7s2_pool(_p(x), _p(plan.wgt_stem), _p(plan.bias), _p(out), dims, _stream())
     _L.check(rc, "cobevt_stem_conv7x7s2_pool")
+    return out
+
+
+def stem_pool_u8(x, lut, plan):
+    """stem_pool on uint8 camera frames (N, H, W, 3) + the (3, 256) fp32 normalisation table (host/rgb_preprocessor.py): the
+    reference's host-side normalisation and the fp32 image upload folded into the stem's gather.  No fallback: the frame sides must
+    be multiples of 4 (every OPV2V / nuScenes resolution is)."""
+    _need_cuda(x, lut)
+    n, h, w, cin = x.shape
+    if not (plan.wgt_stem is not None and plan.cout == 64 and plan.act == 1 and h % 4 == 0 and w % 4 == 0 and cin == 3
+            and x.dtype == torch.uint8 and x.is_contiguous() and lut.dtype == torch.float32 and tuple(lut.shape) == (3, 256)
+            and lut.is_contiguous()):
+        raise CobevtHipError("stem_pool_u8: needs contiguous uint8 frames (N, H, W, 3) with H, W multiples of 4, a (3, 256) fp32 table "
+                             "and the ResNet stem plan; got %s %s" % (tuple(x.shape), x.dtype))
+    out = torch.empty((n, h // 4, w // 4, 64), device=x.device, dtype=plan.dtype)
+    dims = _ints([plan.code, n, h, w])
+
+    def cost():
+        esz = 2 if plan.code == BF16 else 4
+        return 2.0 * n * (h // 2) * (w // 2) * 64 * 147, float(x.numel() + out.numel() * esz)
+
+    with _timed("stem7x7|pool u8 %dx%dx%d" % (n, h, w), cost):
+        rc = _L.load().cobevt_stem_conv7x7s2_pool_u8(_p(x), _p(lut), _p(plan.wgt_stem), _p(plan.bias), _p(out), dims, _stream())
+    _L.check(rc, "cobevt_stem_conv7x7s2_pool_u8")
     return out
 
 

@@ -171,6 +171,30 @@ def opv2v_batch(agents, cams=4, image=512, max_cav=5, seed=0, batch=1):
     }
 
 
+# RgbPreprocessor args of the shipped config (hypes_yaml/opcamera/corpbevt.yaml:26-32)
+OPV2V_RGB_MEAN, OPV2V_RGB_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def opv2v_batch_u8(agents, cams=4, image=512, max_cav=5, seed=0, batch=1, bgr=False):
+    """opv2v_batch whose `inputs` are uint8 camera frames (N,1,M,H,W,3) - what the data loader holds after cv2.resize and before
+    normalize / standalize (rgb_preprocessor.py:14-31).  Returns (batch_u8, batch_f32): the second carries the fp32 image the
+    reference's pre-processor makes of those very frames (table lookup = its float64 arithmetic + the collate cast; bgr: the frames
+    are BGR and the pre-processor swaps the channels first), i.e. what the reference model and the oracle are fed."""
+    from .host.rgb_preprocessor import normalisation_table
+    b = opv2v_batch(agents, cams, image, max_cav, seed, batch)
+    n = agents * batch
+    with np.errstate(over="ignore"):
+        u = _uniform01("input:opv2v.frames_u8", n * cams * image * image * 3, seed)
+    frames = np.minimum((u * 256.0).astype(np.int64), 255).astype(np.uint8).reshape(n, 1, cams, image, image, 3)
+    table = normalisation_table(OPV2V_RGB_MEAN, OPV2V_RGB_STD)                    # (3, 256) indexed by RGB channel
+    rgb = frames[..., ::-1] if bgr else frames
+    f32 = np.stack([table[c][rgb[..., c]] for c in range(3)], -1).astype(np.float32)
+    b8, b32 = dict(b), dict(b)
+    b8["inputs"] = torch.from_numpy(frames.copy())
+    b32["inputs"] = torch.from_numpy(np.ascontiguousarray(f32))
+    return b8, b32
+
+
 def corpbevt_config(max_cav=5, image=512, cams_resnet=34):
     """model.args of opv2v/opencood/hypes_yaml/opcamera/corpbevt.yaml:47-110 as a plain dict."""
     return {

@@ -121,6 +121,17 @@ int cobevt_stem_conv7x7s2_pool(const float* in, const void* wgt, const float* bi
                                hipStream_t stream);
 
 /*
+ * cobevt_stem_conv7x7s2_pool on the uint8 camera frames themselves: the ingest step of the reference's loop - RgbPreProcessor's
+ * /255, (x - mean) / std on the host (opv2v/opencood/data_utils/pre_processor/rgb_preprocessor.py:14-31), the collate cast to
+ * fp32 and `.to(device)` of the fp32 image (opv2v/opencood/tools/inference_camera.py:56-61) - folded into the stem's patch
+ * gather.  in (N, H, W, 3) uint8; lut float[3][256]: lut[c][u] = the fp32 value the reference's pipeline gives byte u of channel c
+ * (host/rgb_preprocessor.py: normalisation_table) - the kernel output is bit-identical to the fp32-image entry point fed lut[c][u].
+ * A quarter of the bytes over PCIe and out of HBM.  dims as above.
+ */
+int cobevt_stem_conv7x7s2_pool_u8(const unsigned char* in, const float* lut, const void* wgt, const float* bias, void* out,
+                                  const int* dims, hipStream_t stream);
+
+/*
  * Dense-row GEMM with fused LayerNorm / pre-activation on the A operand and fused bias / residual / activation:
  * the fast path of every nn.Linear and 1x1 stride-1 convolution (fax_modules.py:189-193,281-292,309-313,411,435,472;
  * swap_fusion_modules.py:45-53; base_transformer.py:102-124).  wgt [N][Kp] (Kp = K rounded up to 128 bf16 / 64 fp32

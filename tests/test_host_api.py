@@ -69,6 +69,50 @@ def test_c_abi_exports_every_declared_symbol():
     assert l.cobevt_conv2d_nhwc(None, None, None, None, None, None, None, None, dims, None) == 1
 
 
+def test_second_library_and_compute_modes():
+    """libcobevt_hip_f32s.so (same sources, -DCOBEVT_F32_SPLIT=1: fp32 storage on the split-bf16 matrix path) loads, exports the whole
+    C ABI, and host.set_compute_dtype selects it - "fp32_split" is fp32 storage, so the lowered plans are shared with exact fp32"""
+    l2 = lib.load("f32s")
+    assert l2 is not lib.load("") and l2.cobevt_abi_version() == 1
+    for name in lib.SIGNATURES:
+        assert getattr(l2, name) is not None
+    assert lib.get_variant() == "" and host.get_compute_mode() == "bf16"
+    with host.compute_dtype("fp32_split"):
+        assert host.get_compute_dtype() == torch.float32 and host.get_matrix_path() == "split_bf16" and host.get_compute_mode() == "fp32_split"
+        assert lib.get_variant() == "f32s" and lib.load() is l2
+        with host.compute_dtype(torch.bfloat16):
+            assert lib.get_variant() == "" and host.get_compute_mode() == "bf16"
+        assert lib.get_variant() == "f32s"
+    assert lib.get_variant() == "" and host.get_compute_mode() == "bf16"
+    with host.compute_dtype(torch.float32):
+        assert host.get_compute_mode() == "fp32" and lib.get_variant() == ""
+    with pytest.raises(CobevtHipError):
+        host.set_compute_dtype(torch.bfloat16, "split_bf16")
+    with pytest.raises(CobevtHipError):
+        host.set_compute_dtype("fp64")
+
+
+def test_uint8_ingest_table_is_the_preprocessors_arithmetic():
+    """the (3, 256) table the stem kernel reads == RgbPreProcessor.standalize(normalize(.)) + the collate cast, value for value"""
+    from cobevt_amd.host.rgb_preprocessor import RgbPreProcessor, normalisation_table
+    args = {"bgr2rgb": True, "resize_x": 16, "resize_y": 16, "mean": list(synth.OPV2V_RGB_MEAN), "std": list(synth.OPV2V_RGB_STD)}
+    pre = RgbPreProcessor({"args": args}, train=False)
+    frame = np.arange(256, dtype=np.uint8).repeat(3).reshape(16, 16, 3)
+    want = pre.standalize(pre.normalize(frame)).astype(np.float32)                # (16, 16, 3), byte value u at flat pixel u
+    t = pre.normalisation_table()
+    assert t.dtype == np.float32 and t.shape == (3, 256)
+    for c in range(3):
+        assert np.array_equal(t[c], want.reshape(256, 3)[:, c])
+    assert np.array_equal(t, normalisation_table(args["mean"], args["std"]))
+    enc = host.ResnetEncoder({"num_layers": 18, "pretrained": False, "image_height": 64, "image_width": 64, "id_pick": [1]})
+    keys = set(enc.state_dict())
+    enc.set_rgb_normalisation(args["mean"], args["std"], bgr2rgb=True)
+    assert set(enc.state_dict()) == keys and torch.equal(enc.ingest_lut, torch.from_numpy(t).flip(0)) and enc.ingest_bgr
+    b8, b32 = synth.opv2v_batch_u8(1, cams=1, image=16, max_cav=2, seed=3, bgr=True)
+    rgb = b8["inputs"].numpy()[..., ::-1]
+    assert np.array_equal(b32["inputs"].numpy(), pre.standalize(pre.normalize(rgb)).astype(np.float32))
+
+
 def test_no_cpu_fallback_and_eval_only():
     m = host.FaxAttention(64, 32, 0.0, 8)
     x = torch.zeros(1, 64, 8, 8)

@@ -1358,3 +1358,62 @@ def test_attention_key_split_matches_single_pass(cuda, dtype, use_bias, ncam):
     scale = float(ref.abs().max())
     for ks, o in outs.items():
         assert float((o - ref).abs().max()) <= tol_ * scale, (ks, float((o - ref).abs().max()) / scale)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fp32 storage on the split-bf16 matrix path (libcobevt_hip_f32s.so: csrc/common.hpp COBEVT_F32_SPLIT, cobevt_amd/build.py).
+# The same kernel tests as exact fp32, at the same 2e-4 tolerance, with the second library selected.
+# ----------------------------------------------------------------------------------------------------------------------
+def _split_cases():
+    f32 = torch.float32
+    return [
+        ("conv3x3_lds_staged", lambda c: test_conv_3x3_bias_relu(c, f32)),
+        ("conv3x3_s2_residual", lambda c: test_conv_3x3_s2_bn_residual_relu(c, f32)),           # -> generic implicit GEMM in this library
+        ("conv3x3_s2_128_256", lambda c: test_conv_3x3_s2_strip_kernel(c, f32, 128, 256, 2, 17, 37)),
+        ("conv1x1_gelu", lambda c: test_conv_1x1_big_tile_gelu(c, f32)),
+        ("stem_pool", lambda c: test_stem_fused_with_maxpool(c, f32, 2, 64, 64)),
+        ("stem", lambda c: test_stem_space_to_depth_kernel(c, f32, 1, 38, 50)),
+        ("conv3x3_upsample", lambda c: test_conv_3x3_nearest_upsample(c, f32)),
+        ("conv3x3_unshuffle", lambda c: test_conv_3x3_pixel_unshuffle(c, f32)),
+        ("conv3x3_strips_256_192", lambda c: test_conv3x3_patch_kernel_shapes(c, f32, 256, 192, 9, 21)),
+        ("conv3x3_strips_variant_150", lambda c: test_conv3x3_wfrag_tile_variants(c, f32, 150)),
+        ("basicblock_64", lambda c: test_basicblock_fused(c, f32, 64, 2, 24, 40)),
+        ("basicblock_128", lambda c: test_basicblock_fused(c, f32, 128, 3, 16, 16)),
+        ("gemm_rows_layernorm", lambda c: test_gemm_rows_fused_layernorm(c, f32, 128, 384, 130)),
+        ("linear_ragged", lambda c: test_linear_ragged_rows(c, f32)),
+        ("cross_window_attention", lambda c: test_attention_prepartitioned_long_keys(c, f32)),
+        ("swap_attention_bias_mask", lambda c: test_swap_attention_bias_mask(c, f32, 1)),
+        ("global_attention", lambda c: test_global_attention_2d_bias(c, f32)),
+        ("bev_embed_q_projection", lambda c: test_bev_embed_fused_into_q_projection(c, f32)),
+    ]
+
+
+@pytest.mark.parametrize("name", [n for n, _ in _split_cases()])
+def test_split_bf16_matrix_path_kernels(cuda, name):
+    from cobevt_amd import host, lib
+    fn = dict(_split_cases())[name]
+    with host.compute_dtype("fp32_split"):
+        assert lib.get_variant() == "f32s"
+        fn(cuda)
+    assert lib.get_variant() == "" and host.get_compute_mode() == "bf16"
+
+
+def test_split_bf16_matrix_path_is_the_one_that_runs(cuda):
+    """the two libraries must give DIFFERENT low-order bits on the same GEMM (else the second library is not what ran), both
+    within fp32-parity distance of the fp64 product, the split one within its 2^-17-per-operand bound"""
+    from cobevt_amd import host
+    x = procedural_input("split.x", (1, 512, 128), 0, -2.0, 2.0)
+    w = procedural_input("split.w", (256, 128), 0, -1.0, 1.0)
+    ref = (x.double() @ w.double().t())
+    plan = ops.ConvPlan(w, None, dtype=torch.float32, device=cuda)
+    xd = x.to(cuda)
+    exact = ops.linear(xd, plan).cpu().double()
+    with host.compute_dtype("fp32_split"):
+        split = ops.linear(xd, plan).cpu().double()
+    scale = ref.abs().max()
+    e_exact, e_split = ((exact - ref).abs().max() / scale).item(), ((split - ref).abs().max() / scale).item()
+    assert not torch.equal(exact, split)
+    assert e_exact <= 2e-6 and e_split <= 4e-5, (e_exact, e_split)
+    # error model: every product carries <= 2 * 2^-17 relative error -> |err| <= 2^-16 * sum |x||w|
+    bound = (x.abs().double() @ w.abs().double().t()) * 2.0 ** -16 + 1e-6 * scale
+    assert ((split - ref).abs() <= bound).all()

@@ -9,6 +9,7 @@ import torch
 import cases
 from cobevt_amd import host, synth
 from cobevt_amd.host import pipeline
+from cobevt_amd.lib import CobevtHipError
 from cobevt_amd.synth import fill_module_
 
 pytestmark = pytest.mark.gpu
@@ -194,3 +195,85 @@ def test_model_call_served_from_graphs(cuda):
         assert model.graph_plans.captures == 2
         model.enable_graphs(False)
         assert torch.equal(model(dict(frames[2][0]))["dynamic_seg"], ref[(2, 0)])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# uint8 ingest: camera frames as bytes, normalised inside the stem kernel (ResnetEncoder.set_rgb_normalisation,
+# csrc/stem7x7.hip stem_pool_kernel<T, true>); reference: rgb_preprocessor.py:14-31 + inference_camera.py:56-61
+# ----------------------------------------------------------------------------------------------------------------------
+def _u8_frames(n, agents=2, bgr=False):
+    out = []
+    for f in range(n):
+        b8, b32 = synth.opv2v_batch_u8(agents=agents, cams=2, image=128, max_cav=3, seed=300 + f, bgr=bgr)
+        for b in (b8, b32):
+            b["transformation_matrix"][0, 1] = b["transformation_matrix"][0, 1] @ torch.tensor(
+                [[1, 0, 0, 1.25 * f], [0, 1, 0, -0.5 * f], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=torch.float32)
+        out.append((b8, b32))
+    return out
+
+
+@pytest.mark.parametrize("mode", [torch.float32, torch.bfloat16, "fp32_split"])
+def test_uint8_ingest_equals_fp32_image_path_bit_for_bit(cuda, mode):
+    """the model fed uint8 frames == the model fed the fp32 image the reference's pre-processor makes of those frames, bit for bit,
+    in every compute mode (the stem looks the normalised value up in the pre-processor's own table); and the fp32-mode result is
+    the oracle's on that fp32 image"""
+    import oracle.corpbevt as o_model
+    cfg = synth.corpbevt_small_config()
+    model = fill_module_(host.CorpBEVT(copy.deepcopy(cfg)), cases.SEED).eval()
+    (b8, b32), = _u8_frames(1)
+    ref = o_model.corpbevt_forward(model.state_dict(), cfg, b32)["dynamic_seg"] if mode == torch.float32 else None
+    model = model.to(cuda)
+    with host.compute_dtype(mode):
+        with pytest.raises(CobevtHipError):            # bytes without a table: loud, not a silent cast
+            model({k: v.to(cuda) for k, v in b8.items()})
+        model.encoder.set_rgb_normalisation(synth.OPV2V_RGB_MEAN, synth.OPV2V_RGB_STD)
+        a = model({k: v.to(cuda) for k, v in b32.items()})["dynamic_seg"].clone()
+        b = model({k: v.to(cuda) for k, v in b8.items()})["dynamic_seg"].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    if ref is not None:
+        assert ((b.cpu() - ref).abs().max() / ref.abs().max()).item() <= 1e-3
+    assert len(model.state_dict()) == len(host.CorpBEVT(copy.deepcopy(cfg)).state_dict())      # the table is not a checkpoint key
+
+
+def test_uint8_ingest_bgr_frames(cuda):
+    """bgr2rgb: true (corpbevt.yaml:28): BGR bytes in, the channel swap folded into the stem weights - equal to the fp32 path on the
+    swapped, normalised image up to the summation order inside the stem (the three input channels sit at swapped K positions)"""
+    model = _model(cuda)
+    (b8, b32), = _u8_frames(1, bgr=True)
+    with host.compute_dtype(torch.float32):
+        a = model({k: v.to(cuda) for k, v in b32.items()})["dynamic_seg"].clone()
+        model.encoder.set_rgb_normalisation(synth.OPV2V_RGB_MEAN, synth.OPV2V_RGB_STD, bgr2rgb=True)
+        b = model({k: v.to(cuda) for k, v in b8.items()})["dynamic_seg"].clone()
+    torch.cuda.synchronize()
+    assert ((a - b).abs().max() / a.abs().max()).item() <= 1e-5
+    assert not torch.equal(b, torch.zeros_like(b))
+
+
+def test_host_frame_feeder_uploads_one_step_ahead(cuda):
+    """pinned uint8 frames through HostFrameFeeder (H2D on a copy stream under the previous step, per-slot image buffers) give the
+    frames' own outputs, in order, bit for bit - a different frame every step, so an upload landing in the wrong slot, too early
+    (overwriting images a running step still reads) or too late shows up as a mismatch"""
+    model = _model(cuda)
+    model.encoder.set_rgb_normalisation(synth.OPV2V_RGB_MEAN, synth.OPV2V_RGB_STD)
+    frames = _u8_frames(8)
+    depth = 3
+    with host.compute_dtype(torch.bfloat16):
+        ref = [model({k: v.to(cuda) for k, v in b8.items()})["dynamic_seg"].clone() for b8, _ in frames]
+        pinned = [{k: v.pin_memory() for k, v in b8.items()} for b8, _ in frames]
+        run = pipeline.PipelinedCorpBEVT(model, {k: v.to(cuda) for k, v in frames[0][0].items()}, depth=depth, input_slots=True)
+        assert run.slots[0]["inputs"].dtype == torch.uint8
+        assert len({sl["inputs"].data_ptr() for sl in run.slots}) == depth
+        feeder = pipeline.HostFrameFeeder(run)
+        got = []
+        feeder.upload(pinned[0])
+        for i in range(len(frames) + depth - 1):
+            nxt = min(i + 1, len(frames) - 1)             # drain by resubmitting the last frame
+            feeder.upload(pinned[nxt])
+            out = feeder.step()
+            got.append(None if out is None else out["dynamic_seg"].clone())
+        torch.cuda.synchronize()
+    for i in range(len(frames)):
+        assert torch.equal(got[i + depth - 1], ref[i]), "frame %d came out wrong" % i
+    with pytest.raises(CobevtHipError):
+        pipeline.HostFrameFeeder(pipeline.PipelinedCorpBEVT(model, {k: v.to(cuda) for k, v in frames[0][0].items()}, depth=depth))
