@@ -162,6 +162,9 @@ template <typename T> __device__ __forceinline__ float gelu_t(float x) {
     if constexpr (sizeof(T) == 2) return gelu_bf16(x);
     else return gelu_erf(x);
 }
+#ifdef COBEVT_GELU_EXACT          // A/B builds only (tools/build_variant.py): the erf form in the bf16 kernels too
+#define gelu_bf16 gelu_erf
+#endif
 
 // epilogue activations by code: 0 none, 1 ReLU, 2 exact GELU, 3 swish x * sigmoid(x) (EfficientNet MBConv), 4 sigmoid
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }

@@ -157,6 +157,16 @@ extern "C" int cobevt_peer_window_status(const void* window, long bytes, int* st
     return COBEVT_OK;
 }
 
+// The same read without a synchronisation: the window's flag words are copied to `host_words` (pinned host memory, kFlagWords = 32
+// 32-bit words; status at [18], completed exchanges at [16]) in stream order - the caller records an event behind it and looks at the
+// words once the event has completed (FrameShardedCorpBEVT checks every step this way instead of draining the pipeline).
+extern "C" int cobevt_peer_window_status_async(const void* window, long bytes, unsigned int* host_words, hipStream_t stream) {
+    if (!window || !host_words) return COBEVT_ERR_ARG;
+    if (hipMemcpyAsync(host_words, (const char*)window + bytes, kFlagWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess)
+        return COBEVT_ERR_LAUNCH;
+    return COBEVT_OK;
+}
+
 // One exchange.  `windows`: host array of `world` device pointers (this process's mappings of every rank's window, own
 // window at [rank]); local: n_local contiguous blocks of block_bytes; dest_rank[j] (-1 = all ranks) / dest_block[j]: where
 // local block j goes; window_bytes: the data size passed to cobevt_peer_window_alloc.

@@ -259,6 +259,36 @@ class DirectExchange(object):
                       "cobevt_peer_window_status")
         return st.value, ep.value
 
+    _st_host = None
+
+    def status_async(self):
+        """enqueue a read of the window's status words behind everything issued so far on the current stream (no synchronisation);
+        `status_poll()` looks at the reads that have completed"""
+        if self._st_host is None:
+            self._st_host = [torch.zeros(32, dtype=torch.int32).pin_memory() for _ in range(4)]
+            self._st_ev, self._st_n = [None] * 4, 0
+        j = self._st_n % 4
+        if self._st_ev[j] is not None and not self._st_ev[j].query():
+            return                                     # four reads already in flight: the oldest will report
+        stream = self._ct.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self._L.check(self._L.load().cobevt_peer_window_status_async(self._ct.c_void_p(self._own), self.window_bytes,
+                                                                     self._ct.c_void_p(self._st_host[j].data_ptr()), stream),
+                      "cobevt_peer_window_status_async")
+        ev = torch.cuda.Event()
+        ev.record()
+        self._st_ev[j] = ev
+        self._st_n += 1
+
+    def status_poll(self):
+        """largest status word among the asynchronous reads that have completed (0: every bounded wait they saw had completed; the
+        word is sticky, so a timeout is reported by every later read)"""
+        worst = 0
+        if self._st_host is not None:
+            for j in range(4):
+                if self._st_ev[j] is not None and self._st_ev[j].query():
+                    worst = max(worst, int(self._st_host[j][18]))
+        return worst
+
     def close(self):
         lib = self._L.load()
         torch.cuda.synchronize(self.device)

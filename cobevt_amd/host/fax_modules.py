@@ -305,6 +305,10 @@ class CrossViewSwapAttention(HipModule):
             kk = ops.proj_chain(feature, plan_key, pk, residual=img, out_next=o.get("kk"))
             vv = ops.proj_chain(feature, plan_val, pv, out_next=o.get("vv"))
             return {"n": n, "hp": hp, "wp": wp, "kk": kk, "vv": vv}
+        if not padded and plan_key is not None and ops.proj_chain_kv_fusable(feature, plan_key, plan_val, pk, pv, img):
+            # 256- / 512-channel features (pyramid levels 1 and 2): both operands' chains in ONE launch (csrc/proj_chain_k.hip)
+            kk, vv = ops.proj_chain_kv(feature, plan_key, plan_val, pk, pv, residual=img, out_k=o.get("kk"), out_v=o.get("vv"))
+            return {"n": n, "hp": hp, "wp": wp, "kk": kk, "vv": vv}
         if self.feature_proj is not None:
             key = ops.conv2d(feature, plan_key, residual=img, out=kv_buffer("key"))
         elif padded:

@@ -480,10 +480,13 @@ class FrameShardedCorpBEVT(object):
     depth = 2: step i runs encode + exchange of frame i and, on a second stream of the same graph, fusion + decoder of frame
                i - 1 (two alternating windows / buffers); one frame in, one frame out per step, latency two steps."""
 
-    #: direct gather: `step()` reads the windows' status words after the first step and then every `status_every` steps
-    #: (one stream synchronise each time) and raises when a bounded flag wait gave up - a stalled or missing rank must not
-    #: turn into a normal-looking output fused from a partially filled window.  0 switches the periodic check off.
-    status_every = 64
+    #: direct gather: EVERY step enqueues an asynchronous read of the windows' status words behind the step (pinned host
+    #: buffer + event, no synchronisation) and looks at the reads that have completed: a bounded flag wait that gave up raises
+    #: one or two steps later - a stalled or missing rank must not turn into a run of normal-looking outputs fused from a
+    #: partially filled window.  The raise is local to this rank: the caller must tear the runner down collectively (the ranks'
+    #: epochs are out of step).  `status_every` > 0 adds the synchronising check (`status()`) after the first step and every so
+    #: many steps; `status()` at the end of a run is the caller's (bench.py does).
+    status_every = 0
 
     def __init__(self, model, sub_batch, frame_batch, rank, world, agents, use_graph=True, gather="rccl", depth=1, group=None):
         if model.training:
@@ -586,8 +589,15 @@ class FrameShardedCorpBEVT(object):
     def _finish(self, q):
         self.i += 1
         self.filled += 1
-        if self.windows and self.status_every and (self.i == 1 or self.i % self.status_every == 0):
-            self.status()
+        if self.windows:
+            for w in self.windows:
+                st = w.status_poll()
+                if st:
+                    raise CobevtHipError("peer-window exchange timed out (status %d): a rank is missing or stalled; rebuild the runner "
+                                         "on every rank" % st)
+                w.status_async()
+            if self.status_every and (self.i == 1 or self.i % self.status_every == 0):
+                self.status()
         self.out = self.outs[(q - (self.depth - 1)) % self.depth]
         return self.out if self.filled >= self.latency_steps else None
 

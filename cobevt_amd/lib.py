@@ -90,6 +90,7 @@ SIGNATURES = {
     "cobevt_se_gate": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "cobevt_mean_linear_rows_small_k": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_long_p, ctypes.c_float, _vp]),
     "cobevt_proj_chain": (ctypes.c_int, [_vp] * 10 + [_c_int_p, ctypes.c_float, _vp]),
+    "cobevt_proj_chain_kv": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_void_p), _c_int_p, ctypes.c_float, _vp]),
     "cobevt_swap_fusion_stage": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int_p,
                                                 ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
     "cobevt_channel_sums": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_int, _vp]),
@@ -125,6 +126,7 @@ SIGNATURES = {
     "cobevt_peer_window_close": (ctypes.c_int, [_vp]),
     "cobevt_peer_window_free": (ctypes.c_int, [_vp]),
     "cobevt_peer_window_status": (ctypes.c_int, [_vp, ctypes.c_long, _c_int_p, _c_int_p, _vp]),
+    "cobevt_peer_window_status_async": (ctypes.c_int, [_vp, ctypes.c_long, _vp, _vp]),
     "cobevt_calibrate_mfma": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "cobevt_calibrate_copy": (ctypes.c_int, [_vp, _vp, ctypes.c_long, _vp]),
     "cobevt_calibrate_clock_khz": (ctypes.c_int, [_c_int_p, _c_int_p]),

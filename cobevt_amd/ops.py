@@ -44,6 +44,7 @@ USE_CHAIN_NEXT = True  # ... and let the row-local GEMM that consumes its output
 USE_HEAD_CONV = True    # 3x3 convs with <= 4 output channels to NCHW fp32 logits (BevSegHead) on the direct kernel
 USE_PROJ_CHAIN = True   # FAX key / value side at 128 feature channels: BN -> ReLU -> 1x1 conv (+ ray embedding) -> LayerNorm -> to_k | to_v
                         # of both attentions in ONE launch per operand, the key / value map itself never reaches HBM (row_chain.hip)
+USE_PROJ_CHAIN_KV = True     # FAX key AND value side of a level with 256 / 384 / 512 feature channels in ONE launch (proj_chain_k.hip) instead of four
 USE_PROJ_CHAIN_WAVE = True   # ... on maps of >= 32768 rows as independent waves with the rows in registers and the weights in LDS (proj_chain128.hip)
 USE_SWAP_STAGE = True   # a SwapFusionBlock half (attention + row chain + next to_qkv) as one launch (swap_stage.hip)
 USE_BOTTLENECK = True   # FAX ResNetBottleNeck (128 -> 32 -> 32 -> 128) as one launch (bottleneck.hip) instead of three
@@ -1121,6 +1122,54 @@ def proj_chain(x, plan_p, next_plan, residual=None, out_next=None):
                                          ctypes.c_float(next_plan.ln_eps), _stream())
     _L.check(rc, "cobevt_proj_chain")
     return out_next
+
+
+def proj_chain_kv_fusable(x, plan_key, plan_val, next_key, next_val, residual):
+    k = x.shape[-1]
+    if not (USE_PROJ_CHAIN_KV and x.dtype == torch.bfloat16 and x.is_contiguous() and k in (256, 384, 512)):
+        return False
+    for pl in (plan_key, plan_val):
+        if pl is None:
+            continue
+        if not (pl.wfrag_rows is not None and pl.kp_rows == k and pl.K == k and pl.cout == 128 and pl.act == 0 and not pl.has_ln
+                and pl.stride == 1):
+            return False
+    for pn in (next_key, next_val):
+        if not (chain_next_fusable(pn, 128) and pn.act == 0):
+            return False
+    return (plan_val is not None and next_key.cout == next_val.cout and next_key.has_ln == next_val.has_ln and next_key.ln_eps == next_val.ln_eps
+            and (residual is None or (plan_key is not None and residual.is_contiguous() and residual.dtype == x.dtype
+                                      and tuple(residual.shape) == tuple(x.shape[:-1]) + (128,))))
+
+
+def proj_chain_kv(x, plan_key, plan_val, next_key, next_val, residual=None, out_k=None, out_v=None):
+    """(next_key(plan_key(x) + residual), next_val(plan_val(x))) on (..., K) feature rows, K = 256 / 384 / 512 -> two (..., Nn) maps, ONE
+    launch (cobevt_proj_chain_kv); neither 128-channel intermediate map reaches HBM.  plan_key None (`no_image_features`: the key is
+    the ray embedding alone, fax_modules.py:392-396) is not served here."""
+    _need_cuda(x, residual)
+    k, nn_ = x.shape[-1], next_key.cout
+    m = x.numel() // k
+    outs = []
+    for o in (out_k, out_v):
+        if o is None:
+            o = torch.empty(x.shape[:-1] + (nn_,), device=x.device, dtype=x.dtype)
+        elif o.numel() != m * nn_ or not o.is_contiguous() or o.dtype != x.dtype:
+            raise CobevtHipError("proj_chain_kv: result buffers must be contiguous (.., %d) of dtype %s" % (nn_, x.dtype))
+        outs.append(o)
+    ptrs = (ctypes.c_void_p * 18)()
+    for s_, (pp, pn, res, o) in enumerate(((plan_key, next_key, residual, outs[0]), (plan_val, next_val, None, outs[1]))):
+        vals = (pp.pre_scale, pp.pre_shift, pp.wfrag_rows, pp.bias, res, pn.wfrag_rows, pn.bias, None, o)
+        for j, t in enumerate(vals):
+            ptrs[9 * s_ + j] = None if t is None else t.data_ptr()
+    dims = _ints([0, m, k, nn_, int(next_key.has_ln), 2, plan_key.pre_relu, 0, plan_val.pre_relu, 0])
+
+    def cost():
+        return 2.0 * 2 * m * (k * 128 + 128 * nn_), float(m * (k + (128 if residual is not None else 0) + 2 * nn_) * 2 + 2 * (k * 128 + 128 * nn_) * 2)
+
+    with _timed("row_chain|proj kv K%d M=%d +next%d" % (k, m, nn_), cost):
+        rc = _L.load().cobevt_proj_chain_kv(_p(x), ptrs, dims, ctypes.c_float(next_key.ln_eps), _stream())
+    _L.check(rc, "cobevt_proj_chain_kv")
+    return outs[0], outs[1]
 
 
 def swap_stage_fusable(qkv, x, tmap, heads, plan_p, plan_1, plan_2, next_plan, mask):

@@ -486,6 +486,18 @@ int cobevt_proj_chain(const void* a, const float* pre_scale, const float* pre_sh
                       float eps_next, hipStream_t stream);
 
 /*
+ * Key AND value side of a FAX pyramid level whose image features are wider than the level, one launch (csrc/proj_chain_k.hip):
+ *   key = ReLU(BN(feature)) . Wk^T + ray embedding, val = ReLU(BN'(feature)) . Wv^T   (feature_proj / feature_linear, fax_modules.py:281-292,392-396)
+ *   kk = LN(key) . [to_k of attention 1 | attention 2]^T, vv = LN(val) . [to_v | to_v]^T            (fax_modules.py:201-205)
+ * for K = 256 / 384 / 512 feature channels and 128 level channels; the key / value maps stay in LDS.  a (M, K) bf16.  ptrs: host
+ * array of 18 device pointers, side s (0 key, 1 value) at [9 s ..]: pre_scale, pre_shift (float[K] or null), wp (fragment-ordered
+ * [4][K/16]), bp (float[128] or null), skip ((skip_rows, 128) bf16 or null), wn (fragment-ordered stacked next projection), bn
+ * (float[Nn]), out ((M, 128) or null), out_next (M, Nn).  dims (int32[10]): dtype (0), M, K, Nn, next_ln, nsides (1 | 2),
+ * pre_relu_0, skip_rows_0 (0 = M), pre_relu_1, skip_rows_1.
+ */
+int cobevt_proj_chain_kv(const void* a, const void* const* ptrs, const int* dims, float eps_next, hipStream_t stream);
+
+/*
  * One half of a SwapFusionBlock in ONE launch (bf16 mode, 128 channels = 4 heads of 32): PreNormResidual(Attention) +
  * PreNormResidual(FeedForward) over the window (map mode 0) or dilated-grid (mode 1) partition of (B, L, H, W, 128) agent maps
  * = opv2v/opencood/models/fusion_modules/swap_fusion_modules.py:87-128 (attention with the 3-D relative position bias and the
@@ -658,6 +670,9 @@ int cobevt_peer_window_free(void* dptr);
 /* Synchronise `stream`, then read the local window's status (0 = every bounded wait so far completed, 1 = a peer's
  * "window free" acknowledgement timed out, 2 = a peer's data-ready flag timed out) and the count of completed exchanges. */
 int cobevt_peer_window_status(const void* window, long bytes, int* status, int* epoch, hipStream_t stream);
+/* The same read in stream order, no synchronisation: the window's 32 flag words (status at [18], completed exchanges at [16]) are copied
+ * to `host_words` (pinned host memory); look at them after an event recorded behind this call has completed. */
+int cobevt_peer_window_status_async(const void* window, long bytes, unsigned int* host_words, hipStream_t stream);
 /* One exchange, two launches on `stream` (capturable in a HIP graph: the epoch lives in the window).  windows: HOST array
  * of `world` (<= 8) device pointers = this process's mappings of every rank's window, the own window at [rank].  local:
  * n_local (<= 16) contiguous blocks of block_bytes; block j is stored at block slot dest_block[j] of rank dest_rank[j]'s

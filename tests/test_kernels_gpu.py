@@ -181,7 +181,13 @@ def test_stem_fused_with_maxpool(cuda, dtype, n, h, w):
     finally:
         ops.USE_STEM_POOL = True
     assert y.shape == (n, h // 4, w // 4, 64)
-    assert torch.equal(y, y2), "fused stem+pool differs from stem -> pool in %d values" % (y != y2).sum()
+    from cobevt_amd import lib as _lib
+    if _lib.get_variant() == "f32s":
+        # split-bf16 matrix path: the two kernels hand (patch, weights) to the MFMA in opposite operand roles, and the split form adds
+        # its four cross terms in an operand-dependent order - equal to rounding, not bit for bit
+        assert (y - y2).abs().max().item() <= 2e-5 * y2.abs().max().item()
+    else:
+        assert torch.equal(y, y2), "fused stem+pool differs from stem -> pool in %d values" % (y != y2).sum()
     wref = plan.wgt.float().cpu()[:, :plan.K].reshape(64, 7, 7, 3).permute(0, 3, 1, 2)
     ref = F.max_pool2d(F.relu(F.conv2d(rnd(x, dtype), wref, plan.bias.cpu(), stride=2, padding=3)), 3, 2, 1)
     check(y.permute(0, 3, 1, 2), ref, dtype, "stem+pool vs torch")
@@ -1417,3 +1423,51 @@ def test_split_bf16_matrix_path_is_the_one_that_runs(cuda):
     # error model: every product carries <= 2 * 2^-17 relative error -> |err| <= 2^-16 * sum |x||w|
     bound = (x.abs().double() @ w.abs().double().t()) * 2.0 ** -16 + 1e-6 * scale
     assert ((split - ref).abs() <= bound).all()
+
+
+@pytest.mark.parametrize("k,rows", [(256, 20480), (512, 5120), (512, 1000), (384, 77), (256, 31)])
+def test_projection_chain_key_and_value_single_launch(cuda, k, rows):
+    """cobevt_proj_chain_kv (csrc/proj_chain_k.hip): BN -> ReLU -> 1x1 conv K -> 128 (+ ray embedding on the key side) -> LayerNorm ->
+    stacked to_k | to_v of both attentions, key and value side in ONE launch (fax_modules.py:281-292,377-396,201-205), against the
+    four launches it replaces and against fp32 torch on the same bf16-rounded operands; ragged row counts, every chunk count"""
+    import torch.nn as nn
+    from cobevt_amd import host
+    from cobevt_amd.host import runtime as rt
+    g = torch.Generator().manual_seed(7)
+    owner = host.runtime.HipModule()
+    for tag in ("k", "v"):
+        bn, conv, ln, lin = nn.BatchNorm2d(k), nn.Conv2d(k, 128, 1, bias=False), nn.LayerNorm(128), nn.Linear(128, 256, bias=True)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(k, generator=g) + 0.5); bn.bias.copy_(torch.randn(k, generator=g) * 0.2)
+            bn.running_mean.copy_(torch.randn(k, generator=g) * 0.3); bn.running_var.copy_(torch.rand(k, generator=g) + 0.5)
+            ln.weight.copy_(torch.rand(128, generator=g) + 0.5); ln.bias.copy_(torch.randn(128, generator=g) * 0.2)
+            conv.weight.copy_(torch.randn(128, k, 1, 1, generator=g) * (1.0 / k) ** 0.5)
+        for nm, mod in (("bn", bn.eval()), ("conv", conv), ("ln", ln), ("lin", lin)):
+            setattr(owner, nm + tag, mod)
+    owner = owner.to(cuda)
+    x = torch.randn(rows, k, generator=g)
+    res = torch.randn(rows, 128, generator=g)
+    xb, rb = x.to(torch.bfloat16).to(cuda), res.to(torch.bfloat16).to(cuda)
+    with host.compute_dtype(torch.bfloat16):
+        ppk, ppv = rt.conv_plan(owner, "pk", owner.convk, pre_bn=owner.bnk), rt.conv_plan(owner, "pv", owner.convv, pre_bn=owner.bnv)
+        pnk, pnv = rt.linear_plan(owner, "nk", owner.link, ln=owner.lnk), rt.linear_plan(owner, "nv", owner.linv, ln=owner.lnv)
+        assert ops.proj_chain_kv_fusable(xb, ppk, ppv, pnk, pnv, rb)
+        kk, vv = ops.proj_chain_kv(xb, ppk, ppv, pnk, pnv, residual=rb)
+        key = ops.conv2d(xb.reshape(1, 1, rows, k), ppk, residual=rb.reshape(1, 1, rows, 128)).reshape(rows, 128)
+        val = ops.conv2d(xb.reshape(1, 1, rows, k), ppv).reshape(rows, 128)
+        kk4, vv4 = ops.linear(key, pnk), ops.linear(val, pnv)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        refs = []
+        for tag, r in (("k", rb), ("v", None)):
+            bn, conv, ln, lin = (getattr(owner, nm + tag) for nm in ("bn", "conv", "ln", "lin"))
+            a = torch.relu(bn(xb.float().t().reshape(1, k, rows, 1))).reshape(k, rows).t().to(torch.bfloat16).float()
+            y = a @ conv.weight.reshape(128, k).to(torch.bfloat16).float().t()
+            if r is not None:
+                y = y + r.float()
+            refs.append(lin(ln(y.to(torch.bfloat16).float())).cpu())
+    for got, four, ref, what in ((kk, kk4, refs[0], "key side"), (vv, vv4, refs[1], "value side")):
+        s = float(ref.abs().max())
+        assert tuple(got.shape) == (rows, 256) and torch.isfinite(got.float()).all()
+        assert (got.float().cpu() - ref).abs().max().item() <= 1e-2 * s, what
+        assert (got.float() - four.float()).abs().max().item() <= 1e-2 * s, what
