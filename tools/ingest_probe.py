@@ -1,0 +1,125 @@
+#!/usr/bin/env python
+"""Where does the time of the H2D-inclusive loop go?  The three-frames-in-flight pipeline on uint8 frames, stepped
+  (a) with the frames resident, (b) + the small per-frame tensors copied from pinned memory before every step, (c) + the image upload
+  on the copy stream WITHOUT making the step wait for it, (d) the full HostFrameFeeder protocol, (e) the upload alone (no compute),
+  (f) the upload through a raw hipMemcpyAsync on a non-blocking stream, (g) as (d) with the upload issued AFTER the replay.
+Usage: python tools/ingest_probe.py [steps]"""
+import copy
+import ctypes
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cobevt_amd import host, synth  # noqa: E402
+from cobevt_amd.host import pipeline  # noqa: E402
+
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+torch.set_grad_enabled(False)
+dev = torch.device("cuda:0")
+host.set_compute_dtype(torch.bfloat16)
+cfg = synth.corpbevt_config(max_cav=5)
+model = synth.fill_module_(host.CorpBEVT(copy.deepcopy(cfg)), 0).eval().to(dev)
+model.encoder.set_rgb_normalisation(synth.OPV2V_RGB_MEAN, synth.OPV2V_RGB_STD)
+b8c, _ = synth.opv2v_batch_u8(agents=5, max_cav=5, seed=0)
+b8 = {k: v.to(dev) for k, v in b8c.items()}
+run = pipeline.PipelinedCorpBEVT(model, b8, depth=3, input_slots=True)
+R = 4
+pinned = []
+for r in range(R):
+    hb = {k: v.pin_memory() for k, v in b8c.items() if torch.is_tensor(v)}
+    hb["record_len"] = b8c["record_len"].to(torch.int32).pin_memory()
+    hb["inputs"] = torch.roll(b8c["inputs"], shifts=7 * r, dims=3).contiguous().pin_memory()
+    pinned.append(hb)
+
+
+def timed(step, warm=10):
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / K * 1e3
+
+
+print("(a) resident                         %.4f ms/step" % timed(lambda: run.step()))
+k = [0]
+
+
+def small_only():
+    hb = pinned[k[0] % R]
+    q = run.i % run.depth
+    small = {kk: hb[kk] for kk in run.slots[q] if kk != "inputs"}
+    small["inputs"] = run.slots[q]["inputs"]
+    run.step(small)
+    k[0] += 1
+
+
+print("(b) + small tensors from pinned host  %.4f ms/step" % timed(small_only))
+copy_s = torch.cuda.Stream()
+
+
+def upload_nowait():
+    slot = (run.i + 1) % run.depth
+    with torch.cuda.stream(copy_s):
+        run.slots[slot]["inputs"].copy_(pinned[k[0] % R]["inputs"], non_blocking=True)
+    run.step()
+    k[0] += 1
+
+
+print("(c) + image upload, step not waiting  %.4f ms/step" % timed(upload_nowait))
+torch.cuda.synchronize()
+feeder = pipeline.HostFrameFeeder(run)
+feeder.upload(pinned[0])
+
+
+def full():
+    feeder.upload(pinned[(k[0] + 1) % R])
+    feeder.step()
+    k[0] += 1
+
+
+print("(d) HostFrameFeeder                   %.4f ms/step" % timed(full))
+torch.cuda.synchronize()
+
+
+def upload_only():
+    with torch.cuda.stream(copy_s):
+        run.slots[k[0] % 3]["inputs"].copy_(pinned[k[0] % R]["inputs"], non_blocking=True)
+    k[0] += 1
+
+
+print("(e) upload alone                      %.4f ms/step" % timed(upload_only))
+hip = ctypes.CDLL("libamdhip64.so")
+raw = ctypes.c_void_p()
+assert hip.hipStreamCreateWithFlags(ctypes.byref(raw), 1) == 0          # hipStreamNonBlocking
+nbytes = b8c["inputs"].numel()
+
+
+def raw_upload_nowait():
+    slot = (run.i + 1) % run.depth
+    rc = hip.hipMemcpyAsync(ctypes.c_void_p(run.slots[slot]["inputs"].data_ptr()), ctypes.c_void_p(pinned[k[0] % R]["inputs"].data_ptr()),
+                            ctypes.c_size_t(nbytes), 1, raw)
+    assert rc == 0
+    run.step()
+    k[0] += 1
+
+
+print("(f) raw hipMemcpyAsync, not waiting   %.4f ms/step" % timed(raw_upload_nowait))
+hip.hipStreamSynchronize(raw)
+
+
+def upload_after():
+    run.step()
+    slot = run.i % run.depth                 # the NEXT step's slot (run.i already advanced)
+    with torch.cuda.stream(copy_s):
+        run.slots[slot]["inputs"].copy_(pinned[k[0] % R]["inputs"], non_blocking=True)
+    k[0] += 1
+
+
+print("(g) upload issued after the replay    %.4f ms/step" % timed(upload_after))
