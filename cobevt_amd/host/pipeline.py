@@ -373,19 +373,23 @@ class PipelinedCorpBEVT(_RunnerBase):
 
 
 class HostFrameFeeder(object):
-    """Camera frames from PINNED host memory into a `PipelinedCorpBEVT(..., input_slots=True)`, one step ahead of the compute:
-    the ingest of the reference's loop (inference_camera.py:56-61 moves every frame's batch to the device before the forward)
-    as an asynchronous upload on a copy stream that overlaps the previous step.
+    """Camera frames from PINNED host memory into a `PipelinedCorpBEVT(..., input_slots=True)`, ahead of the compute: the ingest of
+    the reference's loop (inference_camera.py:56-61 moves every frame's batch to the device before the forward) as an asynchronous
+    upload on a copy stream under the steps in front of it.
 
-        feeder.upload(frame_0)
+        feeder.upload(frame_0); feeder.upload(frame_1)
         for k in ...:
-            feeder.upload(frame_k+1)        # H2D of the next frame, enqueued before ...
-            out = feeder.step()             # ... the replay of step k, which only waits for ITS frame's upload
+            feeder.upload(frame_k+2)        # H2D of the frame two steps ahead, enqueued before ...
+            out = feeder.step()             # ... the replay of step k, whose own frame arrived a step ago
 
-    Only the images travel ahead: the camera matrices / poses / record_len of a slot are still read by the later pipeline
-    stages of the running step (stage 3 of step k reads the pose slot that frame k+1 will reuse), so those few hundred bytes
-    are copied in stream order right before the step, as `PipelinedCorpBEVT.load` does.  uint8 frames
-    (`ResnetEncoder.set_rgb_normalisation`) make the upload 15.7 MB per 5-agent frame instead of 63."""
+    Upload TWO steps ahead: a replay that waits for an event recorded only a step earlier costs ~0.2 ms per step on ROCm 7.2 (the
+    launch is held back until the event has completed; tools/ingest_probe.py, profiles/r05_ingest_probe.txt: 1.89 ms per step one
+    ahead, 1.67 two ahead, 1.68 with the frames resident), while an event that completed a whole step ago is free.  The image slot of
+    frame k+2 is the one step k-1 read, so the copy stream waits for that step's completion event - never the compute stream.
+    Only the images travel ahead: the camera matrices / poses / record_len of a slot are still read by the later pipeline stages
+    of the running steps (stage 3 of step k+1 reads the pose slot that frame k+2 will reuse), so those few hundred bytes are copied
+    in stream order right before their step, as `PipelinedCorpBEVT.load` does - from pinned memory as well, or the copies turn
+    synchronous.  uint8 frames (`ResnetEncoder.set_rgb_normalisation`) make the upload 15.7 MB per 5-agent frame instead of 63."""
 
     def __init__(self, runner):
         if not isinstance(runner, PipelinedCorpBEVT) or not runner.input_slots:
@@ -394,12 +398,12 @@ class HostFrameFeeder(object):
         self.copy = torch.cuda.Stream()
         self.uploaded = [None] * runner.depth        # event: the slot's images have arrived
         self.consumed = [None] * runner.depth        # event: the step that read the slot's images has run
-        self.queue = []                              # host batches uploaded and not yet stepped (at most two)
+        self.queue = []                              # host batches uploaded and not yet stepped (at most `depth`)
 
     def upload(self, host_batch):
         r = self.r
-        if len(self.queue) >= 2:
-            raise CobevtHipError("HostFrameFeeder: at most two frames ahead (the one being stepped next and its successor)")
+        if len(self.queue) >= r.depth:
+            raise CobevtHipError("HostFrameFeeder: at most %d frames ahead (one image slot per pipeline slot)" % r.depth)
         src = host_batch["inputs"]
         if not src.is_pinned():
             raise CobevtHipError("HostFrameFeeder.upload: `inputs` must live in pinned host memory (tensor.pin_memory()) - a pageable "

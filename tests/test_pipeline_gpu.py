@@ -250,8 +250,8 @@ def test_uint8_ingest_bgr_frames(cuda):
     assert not torch.equal(b, torch.zeros_like(b))
 
 
-def test_host_frame_feeder_uploads_one_step_ahead(cuda):
-    """pinned uint8 frames through HostFrameFeeder (H2D on a copy stream under the previous step, per-slot image buffers) give the
+def test_host_frame_feeder_uploads_ahead_of_the_compute(cuda):
+    """pinned uint8 frames through HostFrameFeeder (H2D on a copy stream two steps ahead, per-slot image buffers) give the
     frames' own outputs, in order, bit for bit - a different frame every step, so an upload landing in the wrong slot, too early
     (overwriting images a running step still reads) or too late shows up as a mismatch"""
     model = _model(cuda)
@@ -267,11 +267,14 @@ def test_host_frame_feeder_uploads_one_step_ahead(cuda):
         feeder = pipeline.HostFrameFeeder(run)
         got = []
         feeder.upload(pinned[0])
+        feeder.upload(pinned[1])
         for i in range(len(frames) + depth - 1):
-            nxt = min(i + 1, len(frames) - 1)             # drain by resubmitting the last frame
+            nxt = min(i + 2, len(frames) - 1)             # two steps ahead; drain by resubmitting the last frame
             feeder.upload(pinned[nxt])
             out = feeder.step()
             got.append(None if out is None else out["dynamic_seg"].clone())
+        with pytest.raises(CobevtHipError):               # (two frames are still queued: a fourth would need a fourth image slot)
+            feeder.upload(pinned[0]); feeder.upload(pinned[0])
         torch.cuda.synchronize()
     for i in range(len(frames)):
         assert torch.equal(got[i + depth - 1], ref[i]), "frame %d came out wrong" % i

@@ -28,7 +28,7 @@ from cobevt_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 dtype = torch.bfloat16
-SHAPES = [(20, 32, 32, 256, 256)]
+SHAPES = [(20, 32, 32, 256, 256), (20, 16, 16, 512, 512)] if os.environ.get("SHAPES") == "both" else [(20, 32, 32, 256, 256)]
 VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "150").split(",")]
 vp = ctypes.c_void_p
 

@@ -123,3 +123,53 @@ def upload_after():
 
 
 print("(g) upload issued after the replay    %.4f ms/step" % timed(upload_after))
+
+
+# ---- which part of the feeder protocol costs?  (variants that drop a dependency are for TIMING only: their outputs are racy)
+class Variant(object):
+    def __init__(self, main_waits=True, copy_waits=True, ahead=1, small=True, reuse_events=False):
+        self.main_waits, self.copy_waits, self.ahead, self.small, self.reuse = main_waits, copy_waits, ahead, small, reuse_events
+        D = run.depth
+        self.up = [torch.cuda.Event() for _ in range(D)] if reuse_events else [None] * D
+        self.done = [torch.cuda.Event() for _ in range(D)] if reuse_events else [None] * D
+        self.live_up, self.live_done = [False] * D, [False] * D
+        self.n = 0
+        torch.cuda.synchronize()
+        for a in range(ahead):
+            self.upload(a)
+
+    def upload(self, j):                       # frame index j -> slot of step run.i + (j - self.n)
+        slot = (run.i + (j - self.n)) % run.depth
+        with torch.cuda.stream(copy_s):
+            if self.copy_waits and self.live_done[slot]:
+                copy_s.wait_event(self.done[slot])
+            run.slots[slot]["inputs"].copy_(pinned[j % R]["inputs"], non_blocking=True)
+            ev = self.up[slot] if self.reuse else torch.cuda.Event()
+            ev.record(copy_s)
+        self.up[slot], self.live_up[slot] = ev, True
+
+    def step(self):
+        self.upload(self.n + self.ahead)
+        q = run.i % run.depth
+        hb = pinned[self.n % R]
+        if self.main_waits and self.live_up[q]:
+            torch.cuda.current_stream().wait_event(self.up[q])
+        if self.small:
+            sm = {kk: hb[kk] for kk in run.slots[q] if kk != "inputs"}
+            sm["inputs"] = run.slots[q]["inputs"]
+            run.step(sm)
+        else:
+            run.step()
+        ev = self.done[q] if self.reuse else torch.cuda.Event()
+        ev.record()
+        self.done[q], self.live_done[q] = ev, True
+        self.n += 1
+
+
+for name, kw in (("(d) full protocol again", {}), ("(d1) main does not wait for the upload", dict(main_waits=False)),
+                 ("(d2) copy does not wait for the consumer", dict(copy_waits=False)), ("(d3) no small tensors", dict(small=False)),
+                 ("(d4) upload TWO steps ahead", dict(ahead=2)), ("(d5) events reused", dict(reuse_events=True)),
+                 ("(d6) two ahead, no small tensors", dict(ahead=2, small=False))):
+    torch.cuda.synchronize()
+    v = Variant(**kw)
+    print("%-42s %.4f ms/step" % (name, timed(v.step)))
