@@ -336,6 +336,8 @@ class PipelinedCorpBEVT(_RunnerBase):
 
     def capture(self):
         D = self.depth
+        # (high-priority streams for the later stages - so that their small launches are dispatched ahead of the encoder's full-chip
+        #  workgroups - measured +0.1-0.2 % in two same-job pairs, i.e. nothing: profiles/r05_ab_same_job.txt)
         self.streams = tuple(torch.cuda.Stream() for _ in range(D - 1))
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -395,7 +397,11 @@ class HostFrameFeeder(object):
         if not isinstance(runner, PipelinedCorpBEVT) or not runner.input_slots:
             raise CobevtHipError("HostFrameFeeder needs a PipelinedCorpBEVT built with input_slots=True")
         self.r = runner
-        self.copy = torch.cuda.Stream()
+        # A HIGH-PRIORITY stream: ROCm maps the streams of a process onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by
+        # default) per priority level, and a copy stream that lands on the queue of one of the compute streams puts its transfer IN
+        # FRONT of that stream's kernels (bench.py's process, with a dozen streams alive, measured step + copy time: 2.24 ms instead of
+        # 1.64; the probe process, with fewer streams, did not).  The priority level gives the uploads a queue of their own.
+        self.copy = torch.cuda.Stream(priority=-1)
         self.uploaded = [None] * runner.depth        # event: the slot's images have arrived
         self.consumed = [None] * runner.depth        # event: the step that read the slot's images has run
         self.queue = []                              # host batches uploaded and not yet stepped (at most `depth`)

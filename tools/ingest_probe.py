@@ -173,3 +173,40 @@ for name, kw in (("(d) full protocol again", {}), ("(d1) main does not wait for 
     torch.cuda.synchronize()
     v = Variant(**kw)
     print("%-42s %.4f ms/step" % (name, timed(v.step)))
+
+
+# ---- does a per-step TIMING event (bench.py's timed_loop records one after every step for its median / p95) interact with the protocol?
+def timed_with_events(step, warm=10):
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(K):
+        step()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / K * 1e3
+
+
+torch.cuda.synchronize()
+v = Variant(ahead=2)
+print("(d4) two ahead, plain loop                 %.4f ms/step" % timed(v.step))
+print("(d4) two ahead, timing event per step      %.4f ms/step" % timed_with_events(v.step))
+torch.cuda.synchronize()
+run2 = pipeline.PipelinedCorpBEVT(model, b8, depth=3, input_slots=True)
+f2 = pipeline.HostFrameFeeder(run2)
+f2.upload(pinned[0]); f2.upload(pinned[1])
+kk = [0]
+
+
+def fstep():
+    f2.upload(pinned[(kk[0] + 2) % R])
+    f2.step()
+    kk[0] += 1
+
+
+print("HostFrameFeeder two ahead, plain loop      %.4f ms/step" % timed(fstep))
+print("HostFrameFeeder two ahead, timing events   %.4f ms/step" % timed_with_events(fstep))
+print("resident, timing events                    %.4f ms/step" % timed_with_events(lambda: run.step()))
