@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the eager / fp32 / other-config legs")
+    ap.add_argument("--no-ingest", action="store_true", help="skip the host-to-device ingest leg (`ingest`, `value_with_h2d`)")
     ap.add_argument("--direct-probe", action="store_true", help=argparse.SUPPRESS)   # the isolated child job of direct_probe_child()
     return ap.parse_args()
 
@@ -773,13 +774,13 @@ def main():
             safe(result, "one_frame_at_a_time", lambda: dict(
                 quick(runner.step, 5, 50), note="cobevt_amd.host.pipeline.CapturedCorpBEVT: the same forward from captured graphs "
                                                "without the cross-frame pipeline = the latency of a frame"))
-        if not args.no_extra and in_flight > 1 and args.agents <= 5:
+        if not args.no_ingest and in_flight > 1 and args.agents <= 5:
             def ingest():
                 """The reference's loop moves every frame to the device before the forward (inference_camera.py:56-61); `value` above
                 replays frames that already sit in HBM.  Here the frames come from PINNED HOST memory every step: uint8 camera frames
                 (the data loader's format after cv2.resize; /255, (x - mean) / std of rgb_preprocessor.py:14-31 folded into the stem
-                kernel's gather as a table lookup, ResnetEncoder.set_rgb_normalisation) uploaded on a copy stream two steps ahead of
-                the compute (host.pipeline.HostFrameFeeder), three frames in flight as in `value`.  Beside it: the same loop on the
+                kernel's gather as a table lookup, ResnetEncoder.set_rgb_normalisation) pulled over PCIe by a fetch kernel inside every
+                step's captured graph (host.pipeline.HostFrameFeeder), three frames in flight as in `value`.  Beside it: the same loop on the
                 fp32 image the reference uploads (63 MB per 5-agent frame instead of 15.7)."""
                 A = args.agents
                 b8c, b32c = synth.opv2v_batch_u8(agents=A, max_cav=cfg["max_cav"], seed=0)
@@ -791,46 +792,50 @@ def main():
                 out = {"uint8_path_bit_identical_to_fp32_image_path": bool(same),
                        "h2d_mbyte_per_frame_uint8": round(b8c["inputs"].numel() / 1e6, 2),
                        "h2d_mbyte_per_frame_fp32_image": round(b32c["inputs"].numel() * 4 / 1e6, 2)}
-                W, K, R = 10, max(20, min(args.steps, 100)), 4
+                W, K = 10, max(20, min(args.steps, 100))
                 for tag, bc, bd in (("uint8", b8c, b8), ("fp32_image", b32c, b32)):
-                    run = pipeline.PipelinedCorpBEVT(model, bd, depth=in_flight, input_slots=True)
-                    pinned = []
-                    for r_ in range(R):          # R distinct frames: the images rolled by r_ rows (same statistics, different bytes)
-                        hb = {k: v.pin_memory() for k, v in bc.items() if torch.is_tensor(v)}      # (pageable sources make the copies synchronous)
-                        hb["record_len"] = bc["record_len"].to(torch.int32).pin_memory()
-                        hb["inputs"] = torch.roll(bc["inputs"], shifts=7 * r_, dims=3).contiguous().pin_memory()
-                        pinned.append(hb)
-                    if tag == "uint8":
-                        el, _ = timed_loop(run.step, W, K, 1, dev)
+                    if tag == "uint8":         # the frames resident (no pull): the same pipeline as `value` on bytes
+                        res = pipeline.PipelinedCorpBEVT(model, bd, depth=in_flight)
+                        el, _ = timed_loop(res.step, W, K, 1, dev)
                         out["value_uint8_frames_resident"] = round(K / el, 3)
+                        del res
+                    run = pipeline.PipelinedCorpBEVT(model, bd, depth=in_flight, host_ingest=True)
+                    for r_ in range(in_flight):          # one distinct frame per pinned ring slot (the images rolled by 7 r_ rows)
+                        run.pinned[r_].copy_(torch.roll(bc["inputs"], shifts=7 * r_, dims=3))
+                    small = {k: v.pin_memory() for k, v in bc.items() if torch.is_tensor(v) and k != "inputs"}      # (pageable sources make the copies synchronous)
+                    small["record_len"] = bc["record_len"].to(torch.int32).pin_memory()
                     feeder = pipeline.HostFrameFeeder(run)
-                    k_ = [0]
-                    feeder.upload(pinned[0])
-                    feeder.upload(pinned[1])
+                    feeder.put(dict(small, inputs=feeder.host_slot()))
 
                     def step():
-                        feeder.upload(pinned[(k_[0] + 2) % R])
+                        # the frame is already in its ring slot (a loader decodes into host_slot()): put() only takes it over
+                        feeder.put(dict(small, inputs=feeder.host_slot()))
                         feeder.step()
-                        k_[0] += 1
                     el, per = timed_loop(step, W, K, 1, dev)
                     out["value_with_h2d_" + tag] = round(K / el, 3)
                     out["ms_per_step_with_h2d_" + tag] = round(el / K * 1e3, 4)
-                    # the copy on its own: what the link delivers for this frame
+                    # the pull on its own: what the link delivers for this frame through the fetch kernel, and through the copy engine
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     dst = run.slots[0]["inputs"]
-                    torch.cuda.synchronize()
-                    e0.record()
-                    for r_ in range(8):
-                        dst.copy_(pinned[r_ % R]["inputs"], non_blocking=True)
-                    e1.record()
-                    torch.cuda.synchronize()
-                    ms = e0.elapsed_time(e1) / 8
-                    out["h2d_ms_per_frame_" + tag] = round(ms, 4)
-                    out["h2d_gbyte_s_" + tag] = round(dst.numel() * dst.element_size() / (ms * 1e-3) / 1e9, 2)
-                    del run, feeder, pinned
+                    for which in ("fetch_kernel", "copy_engine"):
+                        torch.cuda.synchronize()
+                        e0.record()
+                        for r_ in range(8):
+                            if which == "fetch_kernel":
+                                ops.host_fetch(run.pinned[r_ % in_flight], dst)
+                            else:
+                                dst.copy_(run.pinned[r_ % in_flight], non_blocking=True)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        ms = e0.elapsed_time(e1) / 8
+                        out["h2d_ms_per_frame_%s_%s" % (tag, which)] = round(ms, 4)
+                        out["h2d_gbyte_s_%s_%s" % (tag, which)] = round(dst.numel() * dst.element_size() / (ms * 1e-3) / 1e9, 2)
+                    del run, feeder
                 out["steps"], out["warmup"] = K, W
-                out["note"] = ("frames/s of the same three-frames-in-flight pipeline as `value` with every frame uploaded from pinned host "
-                               "memory inside the timed loop (copy stream, two steps ahead; HostFrameFeeder); R = 4 distinct frames")
+                out["note"] = ("frames/s of the same three-frames-in-flight pipeline as `value` with every step pulling the next frame's images "
+                               "out of a ring of pinned host buffers inside the timed loop (a fetch kernel captured in the step's graph, "
+                               "host.pipeline.HostFrameFeeder; one distinct frame per ring slot, the loader's decode into the ring is host work "
+                               "outside this figure)")
                 return out
             safe(result, "ingest", ingest)
             if isinstance(result.get("ingest"), dict) and "value_with_h2d_uint8" in result["ingest"]:

@@ -15,6 +15,7 @@
 //   * online softmax with a deferred rescale (the running maximum only moves when a tile exceeds it by more than 2^8), row
 //     maxima by v_max3 + one v_permlane32_swap.
 // MFMA mapping as in attention.hip: S^T = K.Q^T (lane = query), O^T += V^T.P^T.
+#include <stdlib.h>
 #include "attn_common.hpp"
 
 namespace cobevt {
@@ -81,10 +82,16 @@ template <int NT> struct ResLds {
 // W8 (BIAS only): 8 x 8 windows and no padded keys - a 64-key tile is exactly one agent's window, so the padded key term of the
 // quad (tile c, sub-tile s, accumulator quad g, half h) is the constant 960 c + 256 s + 64 g + 16 h bytes: the four bias reads
 // of a sub-tile are immediate offsets from one per-lane pointer (no key-term lookup, no address arithmetic).
-template <int NT, int NW, bool MEAN, bool BIAS, bool MASK, bool RAGGED, bool W8 = false>
+// PERSIST: a workgroup walks SEVERAL (window, head) items (grid.x < the item count) and issues the K / V / mask loads of its next
+// item BEFORE the query loop of the current one, so the global round trip of a prologue hides under ~24k cycles of MFMA / VALU work.
+// For the shapes with ONE workgroup per CU (the 512-key LiDAR FuseBEVT windows: 136 KB of LDS), where nothing else overlaps a
+// prologue - 13.5k of a workgroup's 37k cycles in the s_memtime trace.  With grid.x a multiple of 8 x heads a
+// workgroup keeps its head, so the four shifted copies of the bias column (58 KB) are built once per workgroup instead of once per
+// window.  The prefetch registers (~50) live across the query loop: only instantiated where the VGPR budget is 256.
+template <int NT, int NW, bool MEAN, bool BIAS, bool MASK, bool RAGGED, bool W8 = false, bool PERSIST = false>
 // Register budget: the plain variants keep 4 waves per SIMD (35 KB of LDS -> 4 workgroups per CU); with a bias table / mask the
 // LDS footprint (>= 56 KB for the shipped windows) allows 2 waves per SIMD at most, so those variants may use 256 VGPRs.
-__global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void attn_resident_kernel(AttnParams p, int qsplit) {
+__global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 : 3)) void attn_resident_kernel(AttnParams p, int qsplit) {
     using L = ResLds<NT>;
     constexpr int NKP = L::kNkp;
     constexpr int NTHR = NW * 64;
@@ -119,18 +126,24 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
     // grid.x = qsplit x (windows * heads), query split OUTER: the workgroups sharing a (window, head) are L * heads apart in
     // dispatch order = on the same XCD for the usual multiple-of-8 counts, so its L2 serves their common K / V
     const int LH = p.L * p.heads;
-    const int qs = blockIdx.x / LH, lh = blockIdx.x - qs * LH;
+    const int nitems = LH * qsplit;
     // ... and the heads of one window too (they read the same 128-byte lines of the K / V / Q rows: a row holds all heads):
-    // workgroup lh -> (window, head) such that the heads of a window are 8 apart in dispatch order (8 XCDs, round-robin)
-    int l, head;
-    if ((p.L & 7) == 0) {
-        const int grp = lh / (8 * p.heads), within = lh - grp * (8 * p.heads);
-        head = within >> 3;
-        l = grp * 8 + (within & 7);
-    } else {
-        l = lh / p.heads;
-        head = lh - l * p.heads;
-    }
+    // item lh -> (window, head) such that the heads of a window are 8 apart in dispatch order (8 XCDs, round-robin)
+    auto decode_item = [&](int it, int& qs_, int& l_, int& head_) {
+        qs_ = it / LH;
+        const int lh = it - qs_ * LH;
+        if ((p.L & 7) == 0) {
+            const int grp = lh / (8 * p.heads), within = lh - grp * (8 * p.heads);
+            head_ = within >> 3;
+            l_ = grp * 8 + (within & 7);
+        } else {
+            l_ = lh / p.heads;
+            head_ = lh - l_ * p.heads;
+        }
+    };
+    int item = blockIdx.x;
+    int qs, l, head;
+    decode_item(item, qs, l, head);
 
     RES_MARK(0);
     // ---- prologue, ONE global round trip: with one workgroup per CU (the 512-key windows) nothing else runs on the CU while a
@@ -152,56 +165,69 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
         return c;
     };
     auto key_coord = [&](int tk) { return fast_coord(p.kmap, tk); };
-    const RowAffine kaff = row_affine(p.kmap, b, l), qaff = row_affine(p.qmap, b, l), oaff = row_affine(p.omap, b, l);
-    auto key_row = [&](int tk) { return tk < p.Nk ? row_of(kaff, key_coord(tk)) : -1; };
 
-    // (a) this thread's keys of the tables: coordinates, row, mask word
+    // (a) this thread's keys of the tables: coordinates, row, mask word ; (b) K / V staging loads (rows, 16-byte chunks; key
+    // pairs x dh quads), rows derived per staging item.  Both for ONE (window, head) item, into registers that live until its
+    // staging: PERSIST issues them for the NEXT item in front of the current item's query loop
     constexpr int NKT = (NKP + NTHR - 1) / NTHR;
     TokCoord tkc[NKT];
     int trow[NKT];
     float tmask[NKT];
-#pragma unroll
-    for (int u = 0; u < NKT; ++u) {
-        const int tk = tid + u * NTHR;
-        const bool in = tk < p.Nk;
-        tkc[u] = key_coord(in ? tk : 0);
-        trow[u] = in ? row_of(kaff, tkc[u]) : -1;
-        tmask[u] = 1.f;
-        if (MASK) {                                   // unconditional load (address of token 0 for the padded keys)
-            size_t mi;
-            if (p.kmap.mode == 2) {
-                mi = ((((size_t)b * p.L + l) * p.kmap.w1 + tkc[u].i) * p.kmap.w2 + tkc[u].j) * p.kmap.ncam + tkc[u].cam;
-            } else {
-                const int ph = kaff.ph0 + tkc[u].i * kaff.pi, pw = kaff.pw0 + tkc[u].j * kaff.pj;
-                mi = (((size_t)b * p.kmap.HH + ph) * p.kmap.WW + pw) * p.kmap.ncam + tkc[u].cam;
-            }
-            tmask[u] = p.mask[mi];
-        }
-    }
-    // (b) K / V staging loads (rows, 16-byte chunks; key pairs x dh quads), rows derived per item
-    const bf16_t* kbase = (const bf16_t*)p.k + p.koff + head * 32;
-    const bf16_t* vbase = (const bf16_t*)p.v + p.voff + head * 32;
     uint4 kreg[NITEM];
     uint2 v0[NITEM], v1[NITEM];
     int krow[NITEM], vr0[NITEM], vr1[NITEM];
+    auto issue_item_loads = [&](int l_, int head_, int tidp) {
+        const RowAffine kaff = row_affine(p.kmap, b, l_);
+        auto key_row = [&](int tk) { return tk < p.Nk ? row_of(kaff, key_coord(tk)) : -1; };
 #pragma unroll
-    for (int it = 0; it < NITEM; ++it) {
-        const int item = tid + it * NTHR;
-        const int kk = item >> 2, cj = item & 3;
-        krow[it] = key_row(kk);
-        // unconditional loads from a clamped row, zeroed afterwards: a load under a branch makes hipcc wait for it inside the
-        // branch (vmcnt(0) per load = one serialised HBM round trip per staging item)
-        kreg[it] = *(const uint4*)(kbase + (size_t)(krow[it] < 0 ? 0 : krow[it]) * p.ldk + cj * 8);
-    }
+        for (int u = 0; u < NKT; ++u) {
+            const int tk = tidp + u * NTHR;
+            const bool in = tk < p.Nk;
+            tkc[u] = key_coord(in ? tk : 0);
+            trow[u] = in ? row_of(kaff, tkc[u]) : -1;
+            tmask[u] = 1.f;
+            if (MASK) {                                   // unconditional load (address of token 0 for the padded keys)
+                size_t mi;
+                if (p.kmap.mode == 2) {
+                    mi = ((((size_t)b * p.L + l_) * p.kmap.w1 + tkc[u].i) * p.kmap.w2 + tkc[u].j) * p.kmap.ncam + tkc[u].cam;
+                } else {
+                    const int ph = kaff.ph0 + tkc[u].i * kaff.pi, pw = kaff.pw0 + tkc[u].j * kaff.pj;
+                    mi = (((size_t)b * p.kmap.HH + ph) * p.kmap.WW + pw) * p.kmap.ncam + tkc[u].cam;
+                }
+                tmask[u] = p.mask[mi];
+            }
+        }
+        const bf16_t* kbase = (const bf16_t*)p.k + p.koff + head_ * 32;
+        const bf16_t* vbase = (const bf16_t*)p.v + p.voff + head_ * 32;
 #pragma unroll
-    for (int it = 0; it < NITEM; ++it) {
-        const int item = tid + it * NTHR;
-        const int kp = item >> 3, dq = item & 7;
-        vr0[it] = key_row(2 * kp);
-        vr1[it] = key_row(2 * kp + 1);
-        v0[it] = *(const uint2*)(vbase + (size_t)(vr0[it] < 0 ? 0 : vr0[it]) * p.ldv + dq * 4);
-        v1[it] = *(const uint2*)(vbase + (size_t)(vr1[it] < 0 ? 0 : vr1[it]) * p.ldv + dq * 4);
-    }
+        for (int it = 0; it < NITEM; ++it) {
+            const int si = tidp + it * NTHR;
+            const int kk = si >> 2, cj = si & 3;
+            krow[it] = key_row(kk);
+            // unconditional loads from a clamped row, zeroed afterwards: a load under a branch makes hipcc wait for it inside the
+            // branch (vmcnt(0) per load = one serialised HBM round trip per staging item)
+            kreg[it] = *(const uint4*)(kbase + (size_t)(krow[it] < 0 ? 0 : krow[it]) * p.ldk + cj * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < NITEM; ++it) {
+            const int si = tidp + it * NTHR;
+            const int kp = si >> 3, dq = si & 7;
+            vr0[it] = key_row(2 * kp);
+            vr1[it] = key_row(2 * kp + 1);
+            v0[it] = *(const uint2*)(vbase + (size_t)(vr0[it] < 0 ? 0 : vr0[it]) * p.ldv + dq * 4);
+            v1[it] = *(const uint2*)(vbase + (size_t)(vr1[it] < 0 ? 0 : vr1[it]) * p.ldv + dq * 4);
+        }
+    };
+    issue_item_loads(l, head, tid);
+    int head_built = -1;                               // (BIAS) the head whose table column the four copies in LDS hold
+    bool first_item = true;
+    do {
+    // the prologue's thread index, opaque per iteration: hoisted out of the item loop its address arithmetic (staging stores, table
+    // slots, bias groups) stays live across the query loop - 125 spilled VGPRs in the first persistent build
+    int tidp = tid;
+    if (PERSIST) asm volatile("" : "+v"(tidp));
+    const RowAffine qaff = row_affine(p.qmap, b, l), oaff = row_affine(p.omap, b, l);
+    const bool build_bias = BIAS && head != head_built;
     // (c) the head's bias column.  A thread fills aligned 16-byte groups of the four shifted copies: group m of copy sh holds
     // rev[4 m + sh .. + 3], so the seven values rev[4 m .. 4 m + 6] make the group in all four copies (8 ds_write_b128 per thread
     // instead of 32 scattered ds_write_b32).  rev[x] = padded table entry Rp - 1 - x (0 in the padding column and past the end).
@@ -215,7 +241,7 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
     auto bias_fetch = [&](int base) {
 #pragma unroll
         for (int u = 0; u < BG; ++u) {
-            const int m = base + u * NTHR + tid;
+            const int m = base + u * NTHR + tidp;
             tvok[u] = 0u;
 #pragma unroll
             for (int e = 0; e < 7; ++e) {
@@ -231,7 +257,7 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
     auto bias_store = [&](int base) {
 #pragma unroll
         for (int u = 0; u < BG; ++u) {
-            const int m = base + u * NTHR + tid;
+            const int m = base + u * NTHR + tidp;
             if (m < NG) {
                 float val[7];
 #pragma unroll
@@ -242,14 +268,14 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
             }
         }
     };
-    if (BIAS) bias_fetch(0);
+    if (build_bias) bias_fetch(0);
     __builtin_amdgcn_sched_barrier(0);
     // (d) table arithmetic under the loads: query rows / output rows / bias bases, key terms
-    for (int t = tid; t < NQ; t += NTHR) {
+    for (int t = tidp; t < NQ; t += NTHR) {
         const TokCoord qc = fast_coord(p.qmap, t);          // mean mode: t < P -> camera 0
         qtab[t] = row_of(qaff, qc);
         otab[t] = row_of(oaff, qc);
-        if (BIAS) {
+        if (BIAS && first_item) {                           // (window- and head-independent)
             // padded index = query term - key term (linear in the coordinates, attn_common.hpp); reversed: a + key term
             const int qterm = ((qc.cam + p.bias_L - 1) * (2 * p.kmap.w1 - 1) + qc.i + p.kmap.w1 - 1) * Wp + qc.j + p.kmap.w2 - 1;
             const int a = Rp - 1 - qterm, sh = a & 3;
@@ -258,7 +284,7 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
     }
 #pragma unroll
     for (int u = 0; u < NKT; ++u) {
-        const int tk = tid + u * NTHR;
+        const int tk = tidp + u * NTHR;
         if (tk < NKP) {
             ktab[tk] = trow[u];
             if (BIAS) kinfo4[tk] = trow[u] >= 0 ? 4 * ((tkc[u].cam * (2 * p.kmap.w1 - 1) + tkc[u].i) * Wp + tkc[u].j) : 0;
@@ -272,16 +298,17 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
     RES_MARK(1);
     // (e) the loads land: bias copies, then K (rows, 16-byte chunks XOR-swizzled by (key >> 2) & 3) and V^T (dh rows, 16-byte
     // chunks XOR-swizzled by dh & 15)
-    if (BIAS) {
+    if (build_bias) {
         for (int base = 0; base < NG; base += NTHR * BG) {
             if (base > 0) bias_fetch(base);            // tables wider than one batch
             bias_store(base);
         }
+        head_built = head;
     }
     {
 #pragma unroll
         for (int it = 0; it < NITEM; ++it) {
-            const int item = tid + it * NTHR;
+            const int item = tidp + it * NTHR;
             const int kk = item >> 2, cj = item & 3;
             // K pre-scaled by scale * log2(e) (one extra bf16 rounding, once per workgroup): the score MFMA then delivers base-2
             // logits and, with C = -reference maximum, the exponent's argument itself - no per-score VALU before v_exp_f32
@@ -290,7 +317,7 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
         }
 #pragma unroll
         for (int it = 0; it < NITEM; ++it) {
-            const int item = tid + it * NTHR;
+            const int item = tidp + it * NTHR;
             const int kp = item >> 3, dq = item & 7;
             const uint2 w0 = vr0[it] >= 0 ? v0[it] : make_uint2(0, 0), w1 = vr1[it] >= 0 ? v1[it] : make_uint2(0, 0);
             const int pos = ((2 * kp) & ~15) | perm16((2 * kp) & 15);     // even key of the pair; its partner sits at pos + 1
@@ -305,6 +332,11 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
     }
     __syncthreads();
     RES_MARK(2);
+    int nqs = qs, nl = l, nhead = head;
+    if (PERSIST && item + (int)gridDim.x < nitems) {        // the next item's global loads: in flight under this item's query loop
+        decode_item(item + gridDim.x, nqs, nl, nhead);
+        issue_item_loads(nl, nhead, tidp);
+    }
 
     // ---- per-lane LDS read bases (everything else is an immediate offset)
     const uint32_t kx = (ql >> 2) & 3;
@@ -522,16 +554,22 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK) ? 2 : (MEAN ? 2 : 3)) void 
         }
     }
     RES_MARK(3);
+    if (!PERSIST || item + (int)gridDim.x >= nitems) break;
+    __syncthreads();                               // every wave is done with this item's K / V / tables: the next item overwrites them
+    item += gridDim.x;
+    qs = nqs; l = nl; head = nhead;
+    first_item = false;
+    } while (true);
 }
 
-template <int NT, int NW>
+template <int NT, int NW, bool P = false>
 int launch_nt(const AttnParams& p, int qsplit, size_t lds, dim3 grid, hipStream_t stream) {
     const bool hb = p.bias_mode != 0, hm = p.mask != nullptr, mean = p.mean_q != 0;
     const bool ragged = p.Nk != NT * 64;
 #define COBEVT_RES_LAUNCH(M, B, K, R) \
-    hipLaunchKernelGGL((attn_resident_kernel<NT, NW, M, B, K, R>), grid, dim3(NW * 64), lds, stream, p, qsplit)
+    hipLaunchKernelGGL((attn_resident_kernel<NT, NW, M, B, K, R, false, P>), grid, dim3(NW * 64), lds, stream, p, qsplit)
 #define COBEVT_RES_LAUNCH_W8(K) \
-    hipLaunchKernelGGL((attn_resident_kernel<NT, NW, false, true, K, false, true>), grid, dim3(NW * 64), lds, stream, p, qsplit)
+    hipLaunchKernelGGL((attn_resident_kernel<NT, NW, false, true, K, false, true, P>), grid, dim3(NW * 64), lds, stream, p, qsplit)
     const bool w8 = hb && p.kmap.w1 == 8 && p.kmap.w2 == 8 && p.Nk == NT * 64;
     if (mean) {
         if (hb || hm) return -1;                       // the camera mean only occurs in the plain cross attention
@@ -550,6 +588,12 @@ int launch_nt(const AttnParams& p, int qsplit, size_t lds, dim3 grid, hipStream_
 }
 
 }  // namespace
+
+// A/B switch: COBEVT_ATTN_PERSIST=0 in the environment keeps one (window, head) item per workgroup on every shape
+static bool attn_persist_enabled() {
+    static const bool on = [] { const char* e = getenv("COBEVT_ATTN_PERSIST"); return !(e && e[0] == '0'); }();
+    return on;
+}
 
 int launch_attn_resident(const AttnParams& p, int qsplit_hint, hipStream_t stream) {
     if (p.Nk < 65 || p.Nk > 512) return -1;            // <= 64 keys: one streaming tile is already optimal; > 512: LDS
@@ -595,15 +639,32 @@ int launch_attn_resident(const AttnParams& p, int qsplit_hint, hipStream_t strea
     if (qsplit_hint <= 0 && (long)p.B * p.L * p.heads * qsplit < 256) return -1;
     dim3 grid(p.L * p.heads * qsplit, p.B);
     if (grid.y > 65535) return -1;
+    // one workgroup per CU (> 80 KB of LDS) and several items per CU: persistent workgroups, a whole number of (8 windows x heads)
+    // groups of them so that a workgroup keeps its head (and its bias copies) across its items
+    bool persist = false;
+    if (attn_persist_enabled() && nw == 8 && lds > 80 * 1024 && !mean) {
+        static int cus = 0;
+        if (cus == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        }
+        const int per = 8 * p.heads;
+        int gx = cus >= per && (p.L & 7) == 0 ? (cus / per) * per : cus;
+        if ((long)gx * 2 <= (long)grid.x) {             // at least two items per workgroup, else the plain form
+            grid.x = gx;
+            persist = true;
+        }
+    }
     switch (nt * 10 + nw) {
         case 24: return launch_nt<2, 4>(p, qsplit, lds, grid, stream);
         case 44: return launch_nt<4, 4>(p, qsplit, lds, grid, stream);
         case 64: return launch_nt<6, 4>(p, qsplit, lds, grid, stream);
         case 84: return launch_nt<8, 4>(p, qsplit, lds, grid, stream);
-        case 28: return launch_nt<2, 8>(p, qsplit, lds, grid, stream);
-        case 48: return launch_nt<4, 8>(p, qsplit, lds, grid, stream);
-        case 68: return launch_nt<6, 8>(p, qsplit, lds, grid, stream);
-        case 88: return launch_nt<8, 8>(p, qsplit, lds, grid, stream);
+        case 28: return persist ? launch_nt<2, 8, true>(p, qsplit, lds, grid, stream) : launch_nt<2, 8>(p, qsplit, lds, grid, stream);
+        case 48: return persist ? launch_nt<4, 8, true>(p, qsplit, lds, grid, stream) : launch_nt<4, 8>(p, qsplit, lds, grid, stream);
+        case 68: return persist ? launch_nt<6, 8, true>(p, qsplit, lds, grid, stream) : launch_nt<6, 8>(p, qsplit, lds, grid, stream);
+        case 88: return persist ? launch_nt<8, 8, true>(p, qsplit, lds, grid, stream) : launch_nt<8, 8>(p, qsplit, lds, grid, stream);
         default: return -1;
     }
 }

@@ -573,6 +573,38 @@ extern "C" int cobevt_channel_affine(const float* in, const float* scale, const 
     return launch1d(channel_affine_kernel, N * C * HW, stream, in, scale, shift, out, N * C * HW, C, HW);
 }
 
+// Ingest inside the captured graph: a few workgroups pull the NEXT frame out of pinned (device-visible, fine-grained) host memory
+// over PCIe while the step's kernels run.  The fetch waves need no LDS and ~20 VGPRs, so they sit beside the convolution
+// workgroups that own every CU's LDS; eight 8-byte loads per lane in flight (128 workgroups x 256 lanes x 64 B = 2 MB) cover the
+// link's bandwidth-delay product many times over.  No copy engine, no extra stream, no event between replays: see
+// host.pipeline.HostFrameFeeder for why that matters (ROCm shares 4 hardware queues among a process's streams).
+// Loads at SYSTEM scope (sc0 sc1: past the GPU's caches): the host rewrites a ring slot between two pulls of it, and a line of the
+// previous frame must not be served from L2 - pinned memory from hipHostMalloc(default flags) is not guaranteed fine-grained.
+__global__ __launch_bounds__(256) void host_fetch_kernel(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst, long n8) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    constexpr int U = 8;
+    for (; i + (U - 1) * stride < n8; i += U * stride) {
+        unsigned long long v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __hip_atomic_load(src + i + u * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+        for (int u = 0; u < U; ++u) dst[i + u * stride] = v[u];
+    }
+    for (; i < n8; i += stride) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// C-ABI entry point, see include/cobevt_hip.h
+extern "C" int cobevt_host_fetch(const void* host_src, void* dst, long bytes, int blocks, hipStream_t stream) {
+    if (!host_src || !dst) return COBEVT_ERR_ARG;
+    if (bytes < 16 || bytes % 16 || ((size_t)host_src & 15) || ((size_t)dst & 15)) return COBEVT_ERR_SHAPE;
+    if (blocks < 1) blocks = 128;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(host_fetch_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned long long*)host_src, (unsigned long long*)dst, bytes / 8);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
 extern "C" const char* cobevt_strerror(int code) {
     switch (code) {
         case COBEVT_OK: return "ok";

@@ -18,6 +18,7 @@ data loader can write into `runner.static_batch[...]` directly).  Multi-GPU (`ra
 import torch
 
 from .. import dist as cdist
+from .. import ops
 from ..lib import CobevtHipError
 
 _IMAGE_KEYS = ("inputs", "intrinsic", "extrinsic")
@@ -201,14 +202,18 @@ class PipelinedCorpBEVT(_RunnerBase):
     completes one frame; the latency of a frame is `latency_steps` steps (depth on one GPU; one more with the agent
     all-gather of cobevt_amd/dist.py, which runs under the following step)."""
 
-    def __init__(self, model, example_batch, rank=0, world=1, agents=None, depth=3, input_slots=False):
-        """input_slots: one image buffer per ring slot instead of one shared buffer, so that the NEXT frame can be uploaded from
-        the host on a copy stream while the current step still reads its own (`HostFrameFeeder`)."""
+    def __init__(self, model, example_batch, rank=0, world=1, agents=None, depth=3, input_slots=False, host_ingest=False):
+        """input_slots: one image buffer per ring slot instead of one shared buffer.
+        host_ingest (implies input_slots): every step also PULLS THE NEXT FRAME'S IMAGES out of a ring of pinned host buffers
+        (`self.pinned[slot]`, one per ring slot) with a fetch kernel captured in the step's graph (ops.host_fetch): step k reads
+        pinned slot (k + 1) % depth into image slot (k + 1) % depth while its own kernels run.  `HostFrameFeeder` is the
+        host-side protocol around it."""
         super().__init__(model, example_batch, rank, world, agents)
         if depth not in (3, 4):
             raise CobevtHipError("PipelinedCorpBEVT: depth must be 3 or 4")
         self.depth = D = depth
-        self.input_slots = bool(input_slots)
+        self.host_ingest = bool(host_ingest)
+        self.input_slots = bool(input_slots) or self.host_ingest
         # The small per-frame inputs (camera matrices, poses, record_len) are consumed up to `depth` steps after the images, so
         # they live in RINGS of `depth` slots that `load()` fills from the host side: graph q reads slot q for its encoder
         # stage and the slots of the earlier frames for its later stages - no copy of them inside the replayed graph.
@@ -217,6 +222,10 @@ class PipelinedCorpBEVT(_RunnerBase):
         self.slots = [sb] + [{k: v.clone() for k, v in sb.items() if k != "inputs"} for _ in range(D - 1)]
         for sl in self.slots[1:]:                             # the images are consumed within the step: one buffer (or one per slot)
             sl["inputs"] = sb["inputs"].clone() if self.input_slots else sb["inputs"]
+        self.pinned = None
+        if self.host_ingest:
+            src = sb["inputs"].cpu()
+            self.pinned = [src.clone().pin_memory() for _ in range(D)]
         st = model.encode_trunk(self._images_of(0))
         torch.cuda.synchronize()
         self.meta = [{k: v for k, v in lvl.items() if not torch.is_tensor(v)} for lvl in st["kv"]]
@@ -314,15 +323,27 @@ class PipelinedCorpBEVT(_RunnerBase):
         for s in self.streams:
             s.wait_stream(main)
         nlev = len(self.meta)
+
+        def pull():
+            # the next step's images: pinned host ring -> image slot, beside this step's kernels.  Issued on stage 3's stream, IN
+            # FRONT of it: that branch (fusion + decoder, ~0.3 ms of small launches) has a millisecond of slack in the step, whereas
+            # a branch of its own was serialised in front of the encoder by the graph executor (+0.33 ms per step = the pull's own
+            # duration).  Same-job A/B of placement and size (gpurun_out/r05j, resident 1.73 ms per step on that box): in front of
+            # stage 3 with 32 workgroups 1.89 ms, behind it 1.95 (32) / 2.00 (128) / 2.03 (512), behind stage 2 2.02
+            if self.host_ingest:
+                nxt = (q + 1) % D
+                ops.host_fetch(self.pinned[nxt], self.slots[nxt]["inputs"], blocks=32)
         if D == 3:
             s2, s3 = self.streams
             with torch.cuda.stream(s3):
+                pull()
                 out = self._s3(q)
             with torch.cuda.stream(s2):                                       # frame i-1 -> its features into slot q
                 self.model.fax_query(self._state((q - 1) % D), joined=False, out=self.f[q])
         else:
             s2a, s2b, s3 = self.streams
             with torch.cuda.stream(s3):
+                pull()
                 out = self._s3(q)
             with torch.cuda.stream(s2b):                                      # frame i-2: K/V from two steps ago, x from one
                 self.model.fax_query(self._state((q - 2) % D), joined=False, levels=(1, nlev), x=self.x[(q - 1) % D],
@@ -375,71 +396,68 @@ class PipelinedCorpBEVT(_RunnerBase):
 
 
 class HostFrameFeeder(object):
-    """Camera frames from PINNED host memory into a `PipelinedCorpBEVT(..., input_slots=True)`, ahead of the compute: the ingest of
-    the reference's loop (inference_camera.py:56-61 moves every frame's batch to the device before the forward) as an asynchronous
-    upload on a copy stream under the steps in front of it.
+    """Camera frames from PINNED host memory into a `PipelinedCorpBEVT(..., host_ingest=True)`: the ingest of the reference's loop
+    (inference_camera.py:56-61 moves every frame's batch to the device before the forward) as part of the captured step.
 
-        feeder.upload(frame_0); feeder.upload(frame_1)
+        feeder = HostFrameFeeder(pipe)
+        feeder.put(frame_0)
         for k in ...:
-            feeder.upload(frame_k+2)        # H2D of the frame two steps ahead, enqueued before ...
-            out = feeder.step()             # ... the replay of step k, whose own frame arrived a step ago
+            feeder.put(frame_k+1)           # into the pinned ring (or decode straight into feeder.host_slot(): no copy at all)
+            out = feeder.step()             # step k computes on frame k and pulls frame k+1 over PCIe beside its kernels
 
-    Upload TWO steps ahead: a replay that waits for an event recorded only a step earlier costs ~0.2 ms per step on ROCm 7.2 (the
-    launch is held back until the event has completed; tools/ingest_probe.py, profiles/r05_ingest_probe.txt: 1.89 ms per step one
-    ahead, 1.67 two ahead, 1.68 with the frames resident), while an event that completed a whole step ago is free.  The image slot of
-    frame k+2 is the one step k-1 read, so the copy stream waits for that step's completion event - never the compute stream.
-    Only the images travel ahead: the camera matrices / poses / record_len of a slot are still read by the later pipeline stages
-    of the running steps (stage 3 of step k+1 reads the pose slot that frame k+2 will reuse), so those few hundred bytes are copied
-    in stream order right before their step, as `PipelinedCorpBEVT.load` does - from pinned memory as well, or the copies turn
-    synchronous.  uint8 frames (`ResnetEncoder.set_rgb_normalisation`) make the upload 15.7 MB per 5-agent frame instead of 63."""
+    How the bytes travel: a fetch kernel inside the step's HIP graph (csrc/elementwise.hip host_fetch_kernel, 128 workgroups of
+    non-temporal 16-byte loads from the device-visible pinned buffer) - no copy engine, no extra stream, no event between replays.
+    The stream-based form (hipMemcpyAsync on a copy stream + events) was built first and measured (tools/ingest_probe.py,
+    profiles/r05_ingest_probe.txt): ROCm maps a process's streams onto 4 hardware queues, and whenever the copy
+    stream shared one with a branch of the step's graph the transfer sat IN FRONT of that branch's kernels - step + copy time
+    (2.22 ms instead of 1.64) in bench.py's process, free in a process with fewer streams, worse with a high-priority stream or
+    more queues; a replay waiting for a one-step-old event was held back another ~0.2 ms.  Inside the graph there is nothing to
+    collide with.  Only the images come from the ring: camera matrices / poses / record_len (a few hundred bytes, still read by
+    later pipeline stages of running steps) are copied in stream order right before their step - pass them pinned as well, or
+    those copies turn synchronous.  uint8 frames (`ResnetEncoder.set_rgb_normalisation`) make a 5-agent frame 15.7 MB instead of 63."""
 
     def __init__(self, runner):
-        if not isinstance(runner, PipelinedCorpBEVT) or not runner.input_slots:
-            raise CobevtHipError("HostFrameFeeder needs a PipelinedCorpBEVT built with input_slots=True")
+        if not isinstance(runner, PipelinedCorpBEVT) or not runner.host_ingest:
+            raise CobevtHipError("HostFrameFeeder needs a PipelinedCorpBEVT built with host_ingest=True")
         self.r = runner
-        # A HIGH-PRIORITY stream: ROCm maps the streams of a process onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by
-        # default) per priority level, and a copy stream that lands on the queue of one of the compute streams puts its transfer IN
-        # FRONT of that stream's kernels (bench.py's process, with a dozen streams alive, measured step + copy time: 2.24 ms instead of
-        # 1.64; the probe process, with fewer streams, did not).  The priority level gives the uploads a queue of their own.
-        self.copy = torch.cuda.Stream(priority=-1)
-        self.uploaded = [None] * runner.depth        # event: the slot's images have arrived
-        self.consumed = [None] * runner.depth        # event: the step that read the slot's images has run
-        self.queue = []                              # host batches uploaded and not yet stepped (at most `depth`)
+        self.base = runner.i                          # step index of frame 0
+        self.fetched = [None] * runner.depth          # event: the step that pulled this pinned slot has run
+        self.queue = []                               # (frame index, small tensors) handed over and not yet stepped
+        self.n_put = 0
 
-    def upload(self, host_batch):
+    def host_slot(self):
+        """the pinned buffer the NEXT put() frame belongs in - a loader may decode straight into it and pass it to put()"""
+        return self.r.pinned[(self.base + self.n_put) % self.r.depth]
+
+    def put(self, host_batch):
         r = self.r
-        if len(self.queue) >= r.depth:
-            raise CobevtHipError("HostFrameFeeder: at most %d frames ahead (one image slot per pipeline slot)" % r.depth)
-        src = host_batch["inputs"]
-        if not src.is_pinned():
-            raise CobevtHipError("HostFrameFeeder.upload: `inputs` must live in pinned host memory (tensor.pin_memory()) - a pageable "
-                                 "source makes the copy synchronous")
-        slot = (r.i + len(self.queue)) % r.depth
-        dst = r.slots[slot]["inputs"]
+        if len(self.queue) >= 2:
+            raise CobevtHipError("HostFrameFeeder: one frame ahead of the step in flight (put, step, put, step, ...)")
+        j = self.n_put
+        slot = (self.base + j) % r.depth
+        src, dst = host_batch["inputs"], r.pinned[slot]
         if tuple(src.shape) != tuple(dst.shape) or src.dtype != dst.dtype:
-            raise CobevtHipError("HostFrameFeeder.upload: captured %s %s, got %s %s" % (tuple(dst.shape), dst.dtype, tuple(src.shape), src.dtype))
-        with torch.cuda.stream(self.copy):
-            if self.consumed[slot] is not None:
-                self.copy.wait_event(self.consumed[slot])
-            dst.copy_(src, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.copy)
-        self.uploaded[slot] = ev
-        self.queue.append(host_batch)
+            raise CobevtHipError("HostFrameFeeder.put: captured %s %s, got %s %s" % (tuple(dst.shape), dst.dtype, tuple(src.shape), src.dtype))
+        if self.fetched[slot] is not None:
+            self.fetched[slot].synchronize()          # the pull of the frame that lived here (three steps ago) has finished
+        if src.data_ptr() != dst.data_ptr():
+            dst.copy_(src)                            # host memcpy into the ring (skipped when the loader wrote in place)
+        if j == 0:                                    # nothing pulls the very first frame: put it where step 0 reads it
+            r.slots[slot]["inputs"].copy_(dst, non_blocking=True)
+        self.queue.append({k: host_batch[k] for k in r.slots[slot] if k != "inputs"})
+        self.n_put += 1
 
     def step(self):
         r = self.r
         if not self.queue:
-            raise CobevtHipError("HostFrameFeeder.step: upload() a frame first")
-        hb = self.queue.pop(0)
+            raise CobevtHipError("HostFrameFeeder.step: put() a frame first")
+        small = self.queue.pop(0)
         q = r.i % r.depth
-        small = {k: hb[k] for k in r.slots[q] if k != "inputs"}
-        small["inputs"] = r.slots[q]["inputs"]                      # already there (or on its way): load() skips it
-        torch.cuda.current_stream().wait_event(self.uploaded[q])
+        small["inputs"] = r.slots[q]["inputs"]                      # pulled by the previous step: load() skips it
         out = r.step(small)
         ev = torch.cuda.Event()
         ev.record()
-        self.consumed[q] = ev
+        self.fetched[(q + 1) % r.depth] = ev                        # this step pulled pinned slot q + 1
         return out
 
 

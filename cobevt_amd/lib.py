@@ -132,6 +132,7 @@ SIGNATURES = {
     "cobevt_calibrate_clock_khz": (ctypes.c_int, [_c_int_p, _c_int_p]),
     "cobevt_peer_exchange": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long,
                                             _c_int_p, _c_int_p, ctypes.c_long, ctypes.c_long, _vp]),
+    "cobevt_host_fetch": (ctypes.c_int, [_vp, _vp, ctypes.c_long, ctypes.c_int, _vp]),
     "cobevt_channel_gate_nhwc": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
 }
 

@@ -858,6 +858,21 @@ def stem_pool_u8(x, lut, plan):
     return out
 
 
+def host_fetch(src_pinned, dst, blocks=0):
+    """dst (device) <- src_pinned (pinned host tensor of the same shape / dtype) by a kernel that reads the host buffer over PCIe
+    (cobevt_host_fetch): capturable in a HIP graph, runs beside the compute kernels."""
+    _need_cuda(dst)
+    if src_pinned.is_cuda or not src_pinned.is_pinned():
+        raise CobevtHipError("host_fetch: the source must be a pinned host tensor (tensor.pin_memory())")
+    nbytes = dst.numel() * dst.element_size()
+    if (tuple(src_pinned.shape) != tuple(dst.shape) or src_pinned.dtype != dst.dtype or not src_pinned.is_contiguous() or not dst.is_contiguous()
+            or nbytes % 16):
+        raise CobevtHipError("host_fetch: contiguous tensors of one shape / dtype, a multiple of 16 bytes")
+    rc = _L.load().cobevt_host_fetch(ctypes.c_void_p(src_pinned.data_ptr()), _p(dst), nbytes, int(blocks), _stream())
+    _L.check(rc, "cobevt_host_fetch")
+    return dst
+
+
 def maxpool3x3s2(x):
     _need_cuda(x)
     n, h, w, c = x.shape

@@ -363,6 +363,14 @@ int cobevt_resize_nhwc(const void* in, void* out, int dtype, int N, int H, int W
 int cobevt_channel_affine(const float* in, const float* scale, const float* shift, float* out, long N, int C, long HW,
                           hipStream_t stream);
 
+/*
+ * Pull `bytes` (a multiple of 16) from pinned, device-visible HOST memory (hipHostMalloc / torch .pin_memory(): the host pointer is
+ * the device pointer) into device memory with `blocks` (0 = 128) workgroups of non-temporal 16-byte loads: the ingest step of the
+ * reference's loop (opv2v/opencood/tools/inference_camera.py:56-61 `.to(device)`) as a kernel that can be CAPTURED in the step's
+ * HIP graph and runs beside the compute kernels (no LDS, ~20 VGPRs) - host.pipeline.PipelinedCorpBEVT(host_ingest=True).
+ */
+int cobevt_host_fetch(const void* host_src, void* dst, long bytes, int blocks, hipStream_t stream);
+
 /* ---- downstream of the hot path: the logits -> scored maps -------------------------------------- */
 
 /* CameraBevPostprocessor.softmax_argmax, opv2v/opencood/data_utils/post_processor/camera_bev_postprocessor.py:55-59:

@@ -250,10 +250,11 @@ def test_uint8_ingest_bgr_frames(cuda):
     assert not torch.equal(b, torch.zeros_like(b))
 
 
-def test_host_frame_feeder_uploads_ahead_of_the_compute(cuda):
-    """pinned uint8 frames through HostFrameFeeder (H2D on a copy stream two steps ahead, per-slot image buffers) give the
-    frames' own outputs, in order, bit for bit - a different frame every step, so an upload landing in the wrong slot, too early
-    (overwriting images a running step still reads) or too late shows up as a mismatch"""
+def test_host_frame_feeder_pulls_frames_inside_the_graph(cuda):
+    """pinned uint8 frames through HostFrameFeeder (every step's graph pulls the NEXT frame's images from the pinned host ring with a
+    fetch kernel, ops.host_fetch) give the frames' own outputs, in order, bit for bit - a different frame every step, so a pull
+    from the wrong slot, a frame overwritten before it was pulled or consumed before it arrived shows up as a mismatch; frames are
+    handed over both ways: copied into the ring by put(), and written in place into feeder.host_slot()"""
     model = _model(cuda)
     model.encoder.set_rgb_normalisation(synth.OPV2V_RGB_MEAN, synth.OPV2V_RGB_STD)
     frames = _u8_frames(8)
@@ -261,22 +262,55 @@ def test_host_frame_feeder_uploads_ahead_of_the_compute(cuda):
     with host.compute_dtype(torch.bfloat16):
         ref = [model({k: v.to(cuda) for k, v in b8.items()})["dynamic_seg"].clone() for b8, _ in frames]
         pinned = [{k: v.pin_memory() for k, v in b8.items()} for b8, _ in frames]
-        run = pipeline.PipelinedCorpBEVT(model, {k: v.to(cuda) for k, v in frames[0][0].items()}, depth=depth, input_slots=True)
-        assert run.slots[0]["inputs"].dtype == torch.uint8
+        run = pipeline.PipelinedCorpBEVT(model, {k: v.to(cuda) for k, v in frames[0][0].items()}, depth=depth, host_ingest=True)
+        assert run.slots[0]["inputs"].dtype == torch.uint8 and run.pinned[0].is_pinned()
         assert len({sl["inputs"].data_ptr() for sl in run.slots}) == depth
+        for warm in range(4):                           # the feeder may start at any step of a running pipeline
+            run.step()
         feeder = pipeline.HostFrameFeeder(run)
         got = []
-        feeder.upload(pinned[0])
-        feeder.upload(pinned[1])
+
+        def hand_over(j):
+            j = min(j, len(frames) - 1)                  # drain by resubmitting the last frame
+            if j % 2:                                    # in place: the loader decodes straight into the ring slot
+                slot = feeder.host_slot()
+                slot.copy_(pinned[j]["inputs"])
+                feeder.put(dict(pinned[j], inputs=slot))
+            else:
+                feeder.put(pinned[j])
+        hand_over(0)
         for i in range(len(frames) + depth - 1):
-            nxt = min(i + 2, len(frames) - 1)             # two steps ahead; drain by resubmitting the last frame
-            feeder.upload(pinned[nxt])
+            hand_over(i + 1)
             out = feeder.step()
-            got.append(None if out is None else out["dynamic_seg"].clone())
-        with pytest.raises(CobevtHipError):               # (two frames are still queued: a fourth would need a fourth image slot)
-            feeder.upload(pinned[0]); feeder.upload(pinned[0])
+            got.append(out["dynamic_seg"].clone())
+        with pytest.raises(CobevtHipError):               # one frame ahead of the step in flight, not more
+            feeder.put(pinned[0]); feeder.put(pinned[0])
         torch.cuda.synchronize()
-    for i in range(len(frames)):
-        assert torch.equal(got[i + depth - 1], ref[i]), "frame %d came out wrong" % i
+    which = [[j for j in range(len(frames)) if torch.equal(got[i + depth - 1], ref[j])] for i in range(len(frames))]
+    assert which == [[i] for i in range(len(frames))], "output i should be frame i's: %s" % which
     with pytest.raises(CobevtHipError):
         pipeline.HostFrameFeeder(pipeline.PipelinedCorpBEVT(model, {k: v.to(cuda) for k, v in frames[0][0].items()}, depth=depth))
+
+
+def test_host_fetch_kernel_copies_pinned_memory(cuda):
+    from cobevt_amd import ops
+    for n in (16, 4096 + 16, 3 * 1024 * 1024 + 48):
+        src = torch.randint(0, 255, (n,), dtype=torch.uint8).pin_memory()
+        dst = torch.zeros(n, dtype=torch.uint8, device=cuda)
+        ops.host_fetch(src, dst)
+        torch.cuda.synchronize()
+        assert torch.equal(dst.cpu(), src)
+    with pytest.raises(CobevtHipError):
+        ops.host_fetch(torch.zeros(32, dtype=torch.uint8), torch.zeros(32, dtype=torch.uint8, device=cuda))    # pageable source
+    # replayed from a captured graph while the host REWRITES the pinned buffer between replays (what the feeder does): every replay
+    # must see the new bytes (system-scope loads: no line of the previous frame out of the GPU's caches)
+    n = 2 * 1024 * 1024
+    src = torch.zeros(n, dtype=torch.uint8).pin_memory()
+    dst = torch.zeros(n, dtype=torch.uint8, device=cuda)
+    run = pipeline.CapturedCall(lambda d: ops.host_fetch(src, d), dst)
+    for it in range(6):
+        fresh = torch.randint(0, 255, (n,), dtype=torch.uint8)
+        src.copy_(fresh)
+        out = run.step(None)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), fresh), "replay %d saw stale host bytes" % it

@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """Where does the time of the H2D-inclusive loop go?  The three-frames-in-flight pipeline on uint8 frames, stepped
   (a) with the frames resident, (b) + the small per-frame tensors copied from pinned memory before every step, (c) + the image upload
-  on the copy stream WITHOUT making the step wait for it, (d) the full HostFrameFeeder protocol, (e) the upload alone (no compute),
-  (f) the upload through a raw hipMemcpyAsync on a non-blocking stream, (g) as (d) with the upload issued AFTER the replay.
+  on the copy stream WITHOUT making the step wait for it, (d) the full copy-stream protocol (one step ahead), (e) the upload alone (no compute),
+  (f) the upload through a raw hipMemcpyAsync on a non-blocking stream, (g) as (d) with the upload issued AFTER the replay;
+  then variants of the protocol (which dependency costs what), and at the end the form the package ships: the pull INSIDE the captured
+  graph (PipelinedCorpBEVT(host_ingest=True) + HostFrameFeeder).
 Usage: python tools/ingest_probe.py [steps]"""
 import copy
 import ctypes
@@ -74,17 +76,38 @@ def upload_nowait():
 
 print("(c) + image upload, step not waiting  %.4f ms/step" % timed(upload_nowait))
 torch.cuda.synchronize()
-feeder = pipeline.HostFrameFeeder(run)
-feeder.upload(pinned[0])
+_done, _up = [None] * 3, [None] * 3
+
+
+def _upload1(j):
+    slot = (run.i + (j - k[0])) % run.depth
+    with torch.cuda.stream(copy_s):
+        if _done[slot] is not None:
+            copy_s.wait_event(_done[slot])
+        run.slots[slot]["inputs"].copy_(pinned[j % R]["inputs"], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(copy_s)
+    _up[slot] = ev
+
+
+_upload1(k[0])
 
 
 def full():
-    feeder.upload(pinned[(k[0] + 1) % R])
-    feeder.step()
+    _upload1(k[0] + 1)
+    q = run.i % run.depth
+    hb = pinned[k[0] % R]
+    sm = {kk: hb[kk] for kk in run.slots[q] if kk != "inputs"}
+    sm["inputs"] = run.slots[q]["inputs"]
+    torch.cuda.current_stream().wait_event(_up[q])
+    run.step(sm)
+    ev = torch.cuda.Event()
+    ev.record()
+    _done[q] = ev
     k[0] += 1
 
 
-print("(d) HostFrameFeeder                   %.4f ms/step" % timed(full))
+print("(d) copy stream, one step ahead       %.4f ms/step" % timed(full))
 torch.cuda.synchronize()
 
 
@@ -195,18 +218,30 @@ v = Variant(ahead=2)
 print("(d4) two ahead, plain loop                 %.4f ms/step" % timed(v.step))
 print("(d4) two ahead, timing event per step      %.4f ms/step" % timed_with_events(v.step))
 torch.cuda.synchronize()
-run2 = pipeline.PipelinedCorpBEVT(model, b8, depth=3, input_slots=True)
+print("resident, timing events                    %.4f ms/step" % timed_with_events(lambda: run.step()))
+
+# ---- the shipped form: the pull inside the captured graph
+run2 = pipeline.PipelinedCorpBEVT(model, b8, depth=3, host_ingest=True)
+for r in range(3):
+    run2.pinned[r].copy_(pinned[r]["inputs"])
 f2 = pipeline.HostFrameFeeder(run2)
-f2.upload(pinned[0]); f2.upload(pinned[1])
-kk = [0]
+small = {kk: vv for kk, vv in pinned[0].items() if kk != "inputs"}
+f2.put(dict(small, inputs=f2.host_slot()))
 
 
 def fstep():
-    f2.upload(pinned[(kk[0] + 2) % R])
+    f2.put(dict(small, inputs=f2.host_slot()))
     f2.step()
-    kk[0] += 1
 
 
-print("HostFrameFeeder two ahead, plain loop      %.4f ms/step" % timed(fstep))
-print("HostFrameFeeder two ahead, timing events   %.4f ms/step" % timed_with_events(fstep))
-print("resident, timing events                    %.4f ms/step" % timed_with_events(lambda: run.step()))
+print("in-graph fetch kernel, plain loop          %.4f ms/step" % timed(fstep))
+print("in-graph fetch kernel, timing events       %.4f ms/step" % timed_with_events(fstep))
+# ... and with a dozen more streams alive in the process (what bench.py's process looks like)
+extra = [torch.cuda.Stream() for _ in range(12)]
+for st in extra:
+    with torch.cuda.stream(st):
+        torch.zeros(1, device=dev)
+torch.cuda.synchronize()
+print("in-graph fetch kernel, 12 more streams     %.4f ms/step" % timed(fstep))
+v = Variant(ahead=2)
+print("copy stream two ahead, 12 more streams     %.4f ms/step" % timed(v.step))
