@@ -60,7 +60,7 @@ __device__ __forceinline__ float xor32_sum(float v) {
 __device__ unsigned long long g_res_trace[4 * 8192];
 #define RES_MARK(i)                                                                                   \
     do {                                                                                               \
-        const unsigned wgid = blockIdx.x + gridDim.x * blockIdx.y;                                     \
+        const unsigned wgid = item + nitems * blockIdx.y;          /* one record per (window, head) item */ \
         if (threadIdx.x == 0 && wgid < 8192) g_res_trace[4 * wgid + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
@@ -88,6 +88,10 @@ template <int NT> struct ResLds {
 // prologue - 13.5k of a workgroup's 37k cycles in the s_memtime trace.  With grid.x a multiple of 8 x heads a
 // workgroup keeps its head, so the four shifted copies of the bias column (58 KB) are built once per workgroup instead of once per
 // window.  The prefetch registers (~50) live across the query loop: only instantiated where the VGPR budget is 256.
+#ifndef COBEVT_ATTN_PREFETCH
+#define COBEVT_ATTN_PREFETCH 0
+#endif
+constexpr bool kPrefetch = COBEVT_ATTN_PREFETCH != 0;
 template <int NT, int NW, bool MEAN, bool BIAS, bool MASK, bool RAGGED, bool W8 = false, bool PERSIST = false>
 // Register budget: the plain variants keep 4 waves per SIMD (35 KB of LDS -> 4 workgroups per CU); with a bias table / mask the
 // LDS footprint (>= 56 KB for the shipped windows) allows 2 waves per SIMD at most, so those variants may use 256 VGPRs.
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
             v1[it] = *(const uint2*)(vbase + (size_t)(vr1[it] < 0 ? 0 : vr1[it]) * p.ldv + dq * 4);
         }
     };
-    issue_item_loads(l, head, tid);
+    if (kPrefetch || !PERSIST) issue_item_loads(l, head, tid);
     int head_built = -1;                               // (BIAS) the head whose table column the four copies in LDS hold
     bool first_item = true;
     do {
@@ -226,6 +230,9 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
     // slots, bias groups) stays live across the query loop - 125 spilled VGPRs in the first persistent build
     int tidp = tid;
     if (PERSIST) asm volatile("" : "+v"(tidp));
+    if (!first_item) RES_MARK(0);
+    if (PERSIST && !kPrefetch) issue_item_loads(l, head, tidp);     // (unconditional: behind `!first_item` the staging registers
+    //                                                                    would be live around the back edge, i.e. across the query loop)
     const RowAffine qaff = row_affine(p.qmap, b, l), oaff = row_affine(p.omap, b, l);
     const bool build_bias = BIAS && head != head_built;
     // (c) the head's bias column.  A thread fills aligned 16-byte groups of the four shifted copies: group m of copy sh holds
@@ -333,9 +340,12 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
     __syncthreads();
     RES_MARK(2);
     int nqs = qs, nl = l, nhead = head;
-    if (PERSIST && item + (int)gridDim.x < nitems) {        // the next item's global loads: in flight under this item's query loop
+    if (PERSIST && item + (int)gridDim.x < nitems) {
         decode_item(item + gridDim.x, nqs, nl, nhead);
-        issue_item_loads(nl, nhead, tidp);
+        // kPrefetch: the next item's global loads in flight under this item's query loop.  Measured with s_memtime marks
+        // (tools/attn_trace.py --lidar, profiles/r05_attn_trace_lidar.txt): it takes the prologue from 12.8k to 3.9k cycles per item
+        // but the ~50 registers it keeps live push the kernel from 171 to 251 VGPRs and the query loop from 24.2k to 31.3k cycles
+        if (kPrefetch) issue_item_loads(nl, nhead, tidp);
     }
 
     // ---- per-lane LDS read bases (everything else is an immediate offset)
