@@ -9,7 +9,7 @@ TAG=${2:-r02}
 ROOT=$(pwd)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-extra --frames-in-flight 1"
+CMD="python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-extra --no-ingest --frames-in-flight 1"
 cd /tmp
 rocprofv3 -L > "$ROOT/$OUT/counters_available.txt" 2>&1 || true
 pass() {   # name, counters...

@@ -15,7 +15,7 @@ import sys
 FAMILIES = [("conv3x3_strips_kernel", "conv3x3"), ("conv3x3_kernel", "conv3x3"), ("basicblock_kernel", "basicblock"), ("dsblock_kernel", "basicblock"),
             ("bottleneck_kernel", "bottleneck"), ("gemm_rows3_kernel", "gemm_rows"), ("gemm_rows_kernel", "gemm_rows"),
             ("gemm_rows2_kernel", "gemm_rows"), ("bev_query_kernel", "gemm_rows"), ("row_chain64_kernel", "row_chain"),
-            ("proj_chain128_kernel", "row_chain"), ("row_chain_kernel", "row_chain"), ("swap_stage_kernel", "swap_stage"), ("attn_resident_kernel", "attention"),
+            ("proj_chain128_kernel", "row_chain"), ("proj_chain_k_kernel", "row_chain"), ("row_chain_kernel", "row_chain"), ("swap_stage_kernel", "swap_stage"), ("attn_resident_kernel", "attention"),
             ("attn_gather_kernel", "attention"), ("igemm_kernel", "igemm"), ("stem7x7_kernel", "stem7x7"),
             ("stem_pool_kernel", "stem7x7")]
 N_SE, N_SIMD = 32, 4 * 256

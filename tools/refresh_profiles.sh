@@ -14,10 +14,10 @@ cp "$OUT/pmc/pmc_${TAG}.json" "profiles/pmc_${TAG}.json" 2>/dev/null       # ben
     -d "$ROOT/$OUT/lds" -o p -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-extra --frames-in-flight 1 > "$ROOT/$OUT/lds.log" 2>&1)
 python tools/pmc_summary.py $(find "$OUT/lds" -name "*.db") > "$OUT/${TAG}_lds_pmc.txt" 2>&1
 timeout 600 python bench.py > "$OUT/${TAG}_bench_full.json" 2> "$OUT/bench_full.err"
-(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/kt" -o p -- python "$ROOT/bench.py" --steps 40 --warmup 10 --no-cpu-baseline --no-roofline --no-extra > "$ROOT/$OUT/kt.log" 2>&1)
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/kt" -o p -- python "$ROOT/bench.py" --steps 40 --warmup 10 --no-cpu-baseline --no-roofline --no-extra --no-ingest > "$ROOT/$OUT/kt.log" 2>&1)
 python tools/rocprof_summary.py $(find "$OUT/kt" -name "*.db" | head -1) --steady 30 --skip-last 55 --busy 10 > "$OUT/${TAG}_kernel_trace_stats.txt" 2>&1
-(cd /tmp && timeout 400 rocprofv3 --kernel-trace -d "$ROOT/$OUT/tl" -o p -- python "$ROOT/bench.py" --steps 30 --warmup 10 --frames-in-flight 1 --no-cpu-baseline --no-roofline --no-extra > "$ROOT/$OUT/tl.log" 2>&1)
-python tools/rocprof_summary.py $(find "$OUT/tl" -name "*.db" | head -1) --steady 20 --by-grid --timeline 83 --densest > "$OUT/${TAG}_frame_timeline.txt" 2>&1
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace -d "$ROOT/$OUT/tl" -o p -- python "$ROOT/bench.py" --steps 30 --warmup 10 --frames-in-flight 1 --no-cpu-baseline --no-roofline --no-extra --no-ingest > "$ROOT/$OUT/tl.log" 2>&1)
+python tools/rocprof_summary.py $(find "$OUT/tl" -name "*.db" | head -1) --steady 20 --by-grid --timeline 80 --densest > "$OUT/${TAG}_frame_timeline.txt" 2>&1
 rm -rf "$OUT/kt" "$OUT/tl" "$OUT/lds" "$OUT"/pmc/fetch "$OUT"/pmc/write "$OUT"/pmc/sq
 ls -la "$OUT"
 cut -c1-400 "$OUT/${TAG}_bench_full.json"
