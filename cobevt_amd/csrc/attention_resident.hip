@@ -88,6 +88,9 @@ template <int NT> struct ResLds {
 // prologue - 13.5k of a workgroup's 37k cycles in the s_memtime trace.  With grid.x a multiple of 8 x heads a
 // workgroup keeps its head, so the four shifted copies of the bias column (58 KB) are built once per workgroup instead of once per
 // window.  The prefetch registers (~50) live across the query loop: only instantiated where the VGPR budget is 256.
+#ifndef COBEVT_ATTN_PLAIN_WAVES      // waves per SIMD the plain (no camera mean, no bias / mask) variants with >= 256 keys are compiled for
+#define COBEVT_ATTN_PLAIN_WAVES 3
+#endif
 #ifndef COBEVT_ATTN_PREFETCH
 #define COBEVT_ATTN_PREFETCH 0
 #endif
@@ -95,7 +98,7 @@ constexpr bool kPrefetch = COBEVT_ATTN_PREFETCH != 0;
 template <int NT, int NW, bool MEAN, bool BIAS, bool MASK, bool RAGGED, bool W8 = false, bool PERSIST = false>
 // Register budget: the plain variants keep 4 waves per SIMD (35 KB of LDS -> 4 workgroups per CU); with a bias table / mask the
 // LDS footprint (>= 56 KB for the shipped windows) allows 2 waves per SIMD at most, so those variants may use 256 VGPRs.
-__global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 : 3)) void attn_resident_kernel(AttnParams p, int qsplit) {
+__global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 : (NT >= 4 ? COBEVT_ATTN_PLAIN_WAVES : 3))) void attn_resident_kernel(AttnParams p, int qsplit) {
     using L = ResLds<NT>;
     constexpr int NKP = L::kNkp;
     constexpr int NTHR = NW * 64;
@@ -337,6 +340,20 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
             }
         }
     }
+    // this wave's FIRST task's query rows, requested before the barrier (rows derived directly: the query table is not readable
+    // yet): together with the next-task prefetch inside the tile loop no task starts with an exposed global round trip any more
+    // (before: one per 32-query tile - two of a LiDAR wave's two tasks per item, two of a level-0 wave's eight)
+    const int ntiles = (NQ + 31) >> 5;                  // 32-query tiles (mean mode: position tiles)
+    const int tstep = qsplit * NW;
+    const size_t qcam_stride = MEAN ? (p.qmap.mode == 2 ? (size_t)p.L * P : (size_t)p.qmap.HH * p.qmap.WW) : 0;
+    const bf16_t* qbase = (const bf16_t*)p.q + p.qoff + head * 32 + h * 8;
+    uint4 qf[2];
+    {
+        const int t0 = (qs + qsplit * wave) * 32 + ql;
+        const bf16_t* qrow = qbase + (size_t)(unsigned)row_of(qaff, fast_coord(p.qmap, t0 < NQ ? t0 : 0)) * p.ldq;
+        qf[0] = *(const uint4*)(qrow);
+        qf[1] = *(const uint4*)(qrow + 16);
+    }
     __syncthreads();
     RES_MARK(2);
     int nqs = qs, nl = l, nhead = head;
@@ -355,10 +372,7 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
     const uint32_t vlow = (uint32_t)(ql & 15) << 4;                          // swizzle term, pre-shifted
     const unsigned char* vrow = Vts + ql * L::kVRow;                         // multiple of 256 B: the low byte is free for the XOR
 
-    const int ntiles = (NQ + 31) >> 5;                  // 32-query tiles (mean mode: position tiles)
     const int ncam = MEAN ? p.qmap.ncam : 1;
-    const size_t qcam_stride = MEAN ? (p.qmap.mode == 2 ? (size_t)p.L * P : (size_t)p.qmap.HH * p.qmap.WW) : 0;
-    const bf16_t* qbase = (const bf16_t*)p.q + p.qoff + head * 32 + h * 8;
     const float inv_ncam = 1.0f / (float)ncam;
 
     float m_run = 0.f;                             // softmax reference value, carried across this lane's tasks
@@ -372,11 +386,14 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
     // qaug0 = {0, 1} is the B operand of the throw-away pass that measures a tile's exact maximum.
     const uint32_t qaug0 = h == 0 ? pack_bf2(0.f, 1.0f) : 0u;
     uint32_t qaugm = qaug0;
-    for (int tile = qs + qsplit * wave; tile < ntiles; tile += qsplit * NW) {
+    for (int tile = qs + qsplit * wave; tile < ntiles; tile += tstep) {
         const int t = tile * 32 + ql;
         const bool q_ok = t < NQ;
         const int tq = q_ok ? t : 0;
         const size_t qrow0 = (size_t)(unsigned)qtab[tq];
+        // first row of this lane's query in this wave's NEXT tile (this tile when there is none: loaded, never used)
+        const int tnx = (tile + tstep < ntiles ? tile + tstep : tile) * 32 + ql;
+        const size_t qrow_next_tile = (size_t)(unsigned)qtab[tnx < NQ ? tnx : 0];
         // LDS address of this query's base inside its (aligned) copy of the reversed bias column: a quad of keys reads 16 bytes
         // at this plus the quad's key term (one v_add)
         const unsigned char* bias_qp = (const unsigned char*)bias4 + (BIAS ? qbias[tq] : 0);
@@ -385,18 +402,13 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
 #pragma unroll
             for (int r = 0; r < 16; ++r) osum[r] = 0.f;
         }
-        uint4 qf[2];
-        {
-            const bf16_t* qrow = qbase + qrow0 * p.ldq;
-            qf[0] = *(const uint4*)(qrow);                 // tq is clamped: rows of lanes past the end are loaded but never stored
-            qf[1] = *(const uint4*)(qrow + 16);
-        }
         f32x16 ot;
         for (int cam = 0; cam < ncam; ++cam) {
             uint4 qn[2];
-            if (MEAN) {            // next camera's query rows (clamped, unconditional): in flight under this camera's tiles
-                const int cn = cam + 1 < ncam ? cam + 1 : cam;
-                const bf16_t* qrow = qbase + (qrow0 + (size_t)cn * qcam_stride) * p.ldq;
+            {   // the NEXT task's query rows (unconditional, clamped: rows of lanes past the end are loaded but never stored), in
+                // flight under this task's key tiles: the next camera of this tile, else camera 0 of this wave's next tile
+                const bool more_cam = cam + 1 < ncam;
+                const bf16_t* qrow = qbase + (more_cam ? qrow0 + (size_t)(cam + 1) * qcam_stride : qrow_next_tile) * p.ldq;
                 qn[0] = *(const uint4*)(qrow);
                 qn[1] = *(const uint4*)(qrow + 16);
             }
@@ -545,11 +557,11 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
             const float inv = 1.0f / l_run;                // an all-masked row yields NaN like the reference softmax
             if (MEAN) {
                 osum += ot * inv;                              // v_pk_fma_f32 x 8
-                qf[0] = qn[0];
-                qf[1] = qn[1];
             } else {
                 ot *= inv;
             }
+            qf[0] = qn[0];
+            qf[1] = qn[1];
         }
         if (MEAN) ot = osum * inv_ncam;
         if (q_ok) {

@@ -8,7 +8,7 @@ OUT=${1:-gpurun_out/pmc_l2}
 ROOT=$(pwd)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-extra --frames-in-flight 1"
+CMD="python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-extra --no-ingest --frames-in-flight 1"
 cd /tmp
 pass() {
     local name=$1; shift
