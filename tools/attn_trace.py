@@ -47,6 +47,11 @@ def report(name, nwg):
     print("%-28s %5d wgs | tables %7.0f  staging %7.0f  loop %8.0f cycles (median) | first start -> last end %9.0f cycles | "
           "start spread: median wg starts at %8.0f, last at %8.0f" %
           (name, n, ph[:, 0].median(), ph[:, 1].median(), ph[:, 2].median(), (t[:, 3].max() - t0), (t[:, 0] - t0).median(), (t[:, 0] - t0).max()))
+    if n >= 2048 and os.environ.get("COBEVT_ATTN_PERSIST", "1") != "0":        # persistent workgroups: item = workgroup + 256 x iteration
+        for it in range(n // 256):
+            sl = ph[it * 256:(it + 1) * 256]
+            print("    iteration %d of the persistent workgroups: tables %6.0f staging %6.0f loop %7.0f (median over 256 items)" %
+                  (it, sl[:, 0].median(), sl[:, 1].median(), sl[:, 2].median()))
     for q in (0.1, 0.5, 0.9):
         k = int(q * (n - 1))
         order = torch.argsort(t[:, 0])
