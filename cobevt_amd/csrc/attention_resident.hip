@@ -544,11 +544,25 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
                     have_m = true;
                     l_run += psum;
                     // ---- O^T += V^T . P^T
+                    if constexpr (PERSIST) {
+                        // all four V^T fragments requested before the first PV MFMA, the order pinned: inside the item loop the
+                        // scheduler otherwise issues them one at a time, each behind lgkmcnt(0) in front of its MFMA
+                        uint4 va[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t lowc = (uint32_t)(par * 8 + j * 2) << 4;
+                            va[j] = *(const uint4*)(vp + ((lowc | ((uint32_t)h << 4)) ^ vlow));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) mfma_kgroup<bf16_t>(va[j], pb[j], ot);
+                    } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {            // j = s * 2 + u: keys key0 + s*32 + u*16 .. +15, this half's 8 slots
                         const uint32_t lowc = (uint32_t)(par * 8 + j * 2) << 4;      // chunk within the 256-byte group (+ h)
                         const uint4 va = *(const uint4*)(vp + ((lowc | ((uint32_t)h << 4)) ^ vlow));
                         mfma_kgroup<bf16_t>(va, pb[j], ot);
+                    }
                     }
                 }
             }
