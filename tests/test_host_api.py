@@ -243,3 +243,33 @@ def test_training_host_index_helpers():
     w = torch.arange(2 * 3 * 3 * 3, dtype=torch.float32).reshape(2, 3, 3, 3)
     wt = training._flipped_taps(w)
     assert all(float(wt[o, c, u, v]) == float(w[o, c, v, 2 - u]) for o in range(2) for c in range(3) for u in range(3) for v in range(3))
+
+
+def test_bench_line_finishing_touches():
+    """bench.finish_line (pure host logic): top-level copies of the other configs' figures, fractions against the box calibration
+    beside the spec-peak ones, the headline definition - and nothing breaks when legs are missing or carry an error"""
+    import bench
+    line = {"value": 600.0, "unit": "frames/s", "ms_per_step": 1.66, "ms_per_step_median": 1.66, "scaling": "weak", "mode": "throughput",
+            "dtype": "bf16", "config": {"workload": "OPV2V-camera CoBEVT (corpbevt.yaml): 5 agents"},
+            "box_calibration": {"mfma_bf16_tflops": 2000.0, "hbm_copy_gbs": 5000.0, "sclk_mhz_under_mfma_load": 2000.0},
+            "roofline": {"kernel": "conv3x3", "bound": "mfma", "achieved": 600.0, "peak": 2500.0, "frac": 0.24},
+            "roofline_other_kernels": [{"kernel": "gemm_rows", "bound": "hbm", "achieved": 1000.0, "frac": 0.125},
+                                       {"kernel": "row_chain", "bound": "valu", "achieved": 128.0, "frac": 0.2083}, {"error": "x"}],
+            "roofline_fax_attention": {"bound": "mfma", "achieved": 500.0, "frac": 0.2},
+            "fp32_parity_mode": {"frames_per_sec": 140.0}, "one_frame_at_a_time": {"error": "boom"},
+            "other_configs": {"lidar_fusebevt": {"frames_per_sec": 515.0, "roofline": [{"kernel": "attention", "bound": "mfma", "achieved": 400.0}]},
+                              "nuscenes_sinbevt_from_images": {"error": "no"}, "train_step_bf16_autocast": {"frames_per_sec": 40.0}}}
+    bench.finish_line(line, 1)
+    assert line["lidar_fusebevt_frames_per_sec"] == 515.0 and line["fp32_parity_mode_frames_per_sec"] == 140.0
+    assert line["train_steps_per_sec_bf16_autocast"] == 40.0
+    assert "nuscenes_sinbevt_from_images_frames_per_sec" not in line and "one_frame_at_a_time_frames_per_sec" not in line
+    assert line["roofline"]["frac_of_box_calibrated_peak"] == 0.3
+    assert line["roofline_other_kernels"][0]["frac_of_box_calibrated_peak"] == 0.2
+    assert line["roofline_other_kernels"][1]["frac_of_box_calibrated_peak"] == 0.25          # 128 G wave-instr/s of 1024 x 2.0 GHz / 4
+    assert line["roofline_fax_attention"]["useful_mfma_frac_of_box_calibrated_peak"] == 0.25
+    assert line["other_configs"]["lidar_fusebevt"]["roofline"][0]["frac_of_box_calibrated_peak"] == 0.2
+    assert line["headline_version"] == 2 and "throughput" in line["headline_definition"] and "throughput_mode" not in line
+    multi = dict(line, n_gpus=8)
+    bench.finish_line(multi, 8)
+    assert multi["throughput_mode"]["value"] == 600.0 and multi["throughput_mode"]["mode"] == "throughput"
+    bench.finish_line({"value": 1.0, "config": {"workload": "OPV2V-LiDAR FuseBEVT"}}, 1)     # a line without any of the legs
