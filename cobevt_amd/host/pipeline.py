@@ -373,7 +373,7 @@ class PipelinedCorpBEVT(_RunnerBase):
         pool = None
         for q in range(D):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool):           # (capturing on a high-priority stream - the encoder's - measured nothing either)
                 self.outs.append(self._step_body(q))
             pool = g.pool()
             self.graphs.append(g)
