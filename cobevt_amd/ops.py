@@ -49,10 +49,11 @@ USE_PROJ_CHAIN_WAVE = True   # ... on maps of >= 32768 rows as independent waves
 USE_SWAP_STAGE = True   # a SwapFusionBlock half (attention + row chain + next to_qkv) as one launch (swap_stage.hip)
 USE_BOTTLENECK = True   # FAX ResNetBottleNeck (128 -> 32 -> 32 -> 128) as one launch (bottleneck.hip) instead of three
 ATTN_VARIANT = 0    # 0 = automatic (K/V-resident attention kernel where it applies), 1 = always the streaming kernel, 2 = ... with 64-key tiles (A/B runs)
-ATTN_KSPLIT = 0     # streaming attention on a small grid with >= 1024 keys (FAX level 2 / global attention): share the keys of a window out
-                    # over this many workgroups per query tile + a merge pass (0 / 1 = off).  Off: same-job A/B 0 / 2 / 4 = 2.081 / 2.078 /
-                    # 2.083 ms per frame, 582 / 578 / 569 frames/s (profiles/r03_ab_key_split.txt) - the merge launch costs what the shorter
-                    # tile loop saves; parity-tested (tests/test_kernels_gpu.py::test_attention_key_split_matches_single_pass)
+ATTN_KSPLIT = 2     # streaming attention on a small grid with >= 1024 keys (FAX level 2 / global attention): share the keys of a window out
+                    # over this many workgroups per query tile + a merge pass (0 / 1 = off).  Round 3 measured it neutral (0 / 2 / 4 =
+                    # 582 / 578 / 569 frames/s, profiles/r03_ab_key_split.txt) and left it off; with the round-5 pipeline 2 is a small
+                    # consistent gain: 0 / 2 / 4 = 590.9 / 598.3 / 593.0 and 591.4 / 595.2 / 593.4 frames/s, one frame 2.037 / 2.033 /
+                    # 2.037 ms (profiles/r05_ab_same_job.txt); parity-tested (tests/test_kernels_gpu.py::test_attention_key_split_matches_single_pass)
 ATTN_QSPLIT = 0     # 0 = automatic query split of the resident attention kernel; > 0 pins it (tools/attn_probe.py)
 
 
