@@ -90,7 +90,8 @@ class CapturedCorpBEVT(_RunnerBase):
         return self.out
 
     def capture(self):
-        """encode and fuse as two HIP graphs (the collective, if any, stays eager between them)"""
+        """one HIP graph for the whole frame on one GPU; with world > 1 encode and fuse are two graphs and the collective stays eager
+        between them"""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -99,10 +100,16 @@ class CapturedCorpBEVT(_RunnerBase):
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g1 = torch.cuda.CUDAGraph()
+        if self.world == 1:                   # nothing between the two halves: ONE graph, one replay (a replay boundary is ~20 us)
+            with torch.cuda.graph(g1):
+                self.feats = self.fuse_in = self._encode()
+                self.out = self._fuse(self.fuse_in)
+            self.graphs = (g1,)
+            return
         with torch.cuda.graph(g1):
             feats = self._encode()
         self.feats = feats
-        self.fuse_in = feats if self.world == 1 else torch.empty_like(feats)
+        self.fuse_in = torch.empty_like(feats)
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2):
             self.out = self._fuse(self.fuse_in)
@@ -115,7 +122,7 @@ class CapturedCorpBEVT(_RunnerBase):
         self.graphs[0].replay()
         if self.world > 1:
             cdist.exchange_features(self.feats, self.rank, self.world, self.agents, out=self.fuse_in)
-        self.graphs[1].replay()
+            self.graphs[1].replay()
         return self.out
 
 
