@@ -340,6 +340,9 @@ class PipelinedCorpBEVT(_RunnerBase):
             if self.host_ingest:
                 nxt = (q + 1) % D
                 ops.host_fetch(self.pinned[nxt], self.slots[nxt]["inputs"], blocks=32)
+        # Capture order = dispatch order of the graph's roots, and it matters: oldest frame first (stage 3, stage 2, then the encoder)
+        # 640-650 frames/s on the box of profiles/r05_ab_same_job.txt, stage 2 before stage 3 the same (641-657), the encoder first
+        # 579-586 (its full-chip workgroups then starve the later stages' small dependent launches, whose chains end up as the step's tail)
         if D == 3:
             s2, s3 = self.streams
             with torch.cuda.stream(s3):
