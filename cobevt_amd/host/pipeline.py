@@ -415,8 +415,12 @@ class HostFrameFeeder(object):
             feeder.put(frame_k+1)           # into the pinned ring (or decode straight into feeder.host_slot(): no copy at all)
             out = feeder.step()             # step k computes on frame k and pulls frame k+1 over PCIe beside its kernels
 
-    How the bytes travel: a fetch kernel inside the step's HIP graph (csrc/elementwise.hip host_fetch_kernel, 128 workgroups of
-    non-temporal 16-byte loads from the device-visible pinned buffer) - no copy engine, no extra stream, no event between replays.
+    put() the next frame BEFORE step() as above and the transfer is hidden; put() after step() (put, step, put, step) is still
+    correct - the step notices that its frame was not in the ring when the previous step pulled, and copies it in stream order - but
+    then nothing overlaps.
+
+    How the bytes travel: a fetch kernel inside the step's HIP graph (csrc/elementwise.hip host_fetch_kernel, 32 workgroups of
+    system-scope 8-byte loads from the device-visible pinned buffer) - no copy engine, no extra stream, no event between replays.
     The stream-based form (hipMemcpyAsync on a copy stream + events) was built first and measured (tools/ingest_probe.py,
     profiles/r05_ingest_probe.txt): ROCm maps a process's streams onto 4 hardware queues, and whenever the copy
     stream shared one with a branch of the step's graph the transfer sat IN FRONT of that branch's kernels - step + copy time
@@ -431,30 +435,31 @@ class HostFrameFeeder(object):
             raise CobevtHipError("HostFrameFeeder needs a PipelinedCorpBEVT built with host_ingest=True")
         self.r = runner
         self.base = runner.i                          # step index of frame 0
-        self.fetched = [None] * runner.depth          # event: the step that pulled this pinned slot has run
-        self.queue = []                               # (frame index, small tensors) handed over and not yet stepped
+        self.fetched = [None] * runner.depth          # event: every device read of this pinned slot issued so far has run
+        self.queue = []                               # small tensors of the frames handed over and not yet stepped
         self.n_put = 0
+        self.pulled = False                           # did the previous step's graph pull the frame the next step() computes on?
 
     def host_slot(self):
-        """the pinned buffer the NEXT put() frame belongs in - a loader may decode straight into it and pass it to put()"""
-        return self.r.pinned[(self.base + self.n_put) % self.r.depth]
+        """the pinned buffer the NEXT put() frame belongs in - a loader may decode straight into it and pass it to put().
+        Waits until the device has finished reading the frame that lived there (`depth` frames ago)."""
+        slot = (self.base + self.n_put) % self.r.depth
+        if self.fetched[slot] is not None:
+            self.fetched[slot].synchronize()
+        return self.r.pinned[slot]
 
     def put(self, host_batch):
         r = self.r
         if len(self.queue) >= 2:
-            raise CobevtHipError("HostFrameFeeder: one frame ahead of the step in flight (put, step, put, step, ...)")
-        j = self.n_put
-        slot = (self.base + j) % r.depth
-        src, dst = host_batch["inputs"], r.pinned[slot]
-        if tuple(src.shape) != tuple(dst.shape) or src.dtype != dst.dtype:
-            raise CobevtHipError("HostFrameFeeder.put: captured %s %s, got %s %s" % (tuple(dst.shape), dst.dtype, tuple(src.shape), src.dtype))
-        if self.fetched[slot] is not None:
-            self.fetched[slot].synchronize()          # the pull of the frame that lived here (three steps ago) has finished
+            raise CobevtHipError("HostFrameFeeder: one frame ahead of the step in flight (put, put, step, put, step, ...)")
+        src = host_batch["inputs"]
+        ref = r.pinned[0]
+        if tuple(src.shape) != tuple(ref.shape) or src.dtype != ref.dtype:
+            raise CobevtHipError("HostFrameFeeder.put: captured %s %s, got %s %s" % (tuple(ref.shape), ref.dtype, tuple(src.shape), src.dtype))
+        dst = self.host_slot()
         if src.data_ptr() != dst.data_ptr():
             dst.copy_(src)                            # host memcpy into the ring (skipped when the loader wrote in place)
-        if j == 0:                                    # nothing pulls the very first frame: put it where step 0 reads it
-            r.slots[slot]["inputs"].copy_(dst, non_blocking=True)
-        self.queue.append({k: host_batch[k] for k in r.slots[slot] if k != "inputs"})
+        self.queue.append({k: host_batch[k] for k in r.slots[0] if k != "inputs"})
         self.n_put += 1
 
     def step(self):
@@ -463,11 +468,17 @@ class HostFrameFeeder(object):
             raise CobevtHipError("HostFrameFeeder.step: put() a frame first")
         small = self.queue.pop(0)
         q = r.i % r.depth
-        small["inputs"] = r.slots[q]["inputs"]                      # pulled by the previous step: load() skips it
+        late = not self.pulled
+        if late:      # the first frame, or one put() after the previous step was launched: that step's pull read the slot too early
+            r.slots[q]["inputs"].copy_(r.pinned[q], non_blocking=True)
+        small["inputs"] = r.slots[q]["inputs"]                      # in place already: load() skips it
+        self.pulled = bool(self.queue)                              # the next frame is in the ring while this step pulls it
         out = r.step(small)
         ev = torch.cuda.Event()
         ev.record()
         self.fetched[(q + 1) % r.depth] = ev                        # this step pulled pinned slot q + 1
+        if late:
+            self.fetched[q] = ev
         return out
 
 

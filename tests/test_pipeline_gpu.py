@@ -288,6 +288,21 @@ def test_host_frame_feeder_pulls_frames_inside_the_graph(cuda):
         torch.cuda.synchronize()
     which = [[j for j in range(len(frames)) if torch.equal(got[i + depth - 1], ref[j])] for i in range(len(frames))]
     assert which == [[i] for i in range(len(frames))], "output i should be frame i's: %s" % which
+    # the other order - put, step, put, step: the step's frame was not in the ring when the previous step pulled; still every
+    # frame's own output (no overlap then), also when the two orders alternate
+    with host.compute_dtype(torch.bfloat16):
+        feeder = pipeline.HostFrameFeeder(run)
+        got = []
+        for i in range(len(frames) + depth - 1):
+            j = min(i, len(frames) - 1)
+            if not feeder.queue:
+                feeder.put(pinned[j])
+            if i % 3 == 0 and i + 1 < len(frames):        # ... and every third step also has its successor in the ring already
+                feeder.put(pinned[i + 1])
+            got.append(feeder.step()["dynamic_seg"].clone())
+        torch.cuda.synchronize()
+    which = [[j for j in range(len(frames)) if torch.equal(got[i + depth - 1], ref[j])] for i in range(len(frames))]
+    assert which == [[i] for i in range(len(frames))], "late hand-over: output i should be frame i's: %s" % which
     with pytest.raises(CobevtHipError):
         pipeline.HostFrameFeeder(pipeline.PipelinedCorpBEVT(model, {k: v.to(cuda) for k, v in frames[0][0].items()}, depth=depth))
 
