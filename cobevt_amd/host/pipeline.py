@@ -20,6 +20,7 @@ import torch
 from .. import dist as cdist
 from .. import ops
 from ..lib import CobevtHipError
+from .runtime import GraphOwner
 
 _IMAGE_KEYS = ("inputs", "intrinsic", "extrinsic")
 
@@ -31,7 +32,7 @@ def _static_copy(batch, dev):
     return out
 
 
-class _RunnerBase(object):
+class _RunnerBase(GraphOwner):
     def __init__(self, model, example_batch, rank=0, world=1, agents=None):
         if model.training:
             raise CobevtHipError("graph runners implement inference: call model.eval() first")
@@ -469,8 +470,9 @@ class HostFrameFeeder(object):
         small = self.queue.pop(0)
         q = r.i % r.depth
         late = not self.pulled
-        if late:      # the first frame, or one put() after the previous step was launched: that step's pull read the slot too early
-            r.slots[q]["inputs"].copy_(r.pinned[q], non_blocking=True)
+        if late:      # the first frame, or one put() after the previous step was launched: that step's pull read the slot too early.
+            #           The same fetch kernel in stream order, not a copy-engine transfer (see the class docstring)
+            ops.host_fetch(r.pinned[q], r.slots[q]["inputs"])
         small["inputs"] = r.slots[q]["inputs"]                      # in place already: load() skips it
         self.pulled = bool(self.queue)                              # the next frame is in the ring while this step pulls it
         out = r.step(small)
@@ -482,7 +484,7 @@ class HostFrameFeeder(object):
         return out
 
 
-class CapturedCall(object):
+class CapturedCall(GraphOwner):
     """`fn(*args)` replayed from one captured HIP graph; the arguments are held in static device buffers (`self.args`,
     refreshed by `step(*new_args)`), the result tensors are the graph's own output buffers.  Used for the operator-level
     workloads (LiDAR FuseBEVT `SwapFusionEncoder`, nuScenes SinBEVT) whose forward is a single stage."""
@@ -516,7 +518,7 @@ class CapturedCall(object):
         return self.out
 
 
-class FrameShardedCorpBEVT(object):
+class FrameShardedCorpBEVT(GraphOwner):
     """Strong scaling ("latency mode"; BASELINE.json north_star: one agent per GPU, ONE all-gather before
     FuseBEVT): ONE frame over `world` GPUs.  Rank r encodes the agents r, r + world, .. of the frame (its sub-batch is
     `static_sub`), one exchange hands every rank all agents' (H, W, C) features, and the 18-GF STTF + fusion + decoder tail

@@ -73,6 +73,21 @@ def structure_epoch():
     return _STRUCTURE_EPOCH
 
 
+class GraphOwner(object):
+    """Base of every object that owns captured HIP graphs (the runners of host/pipeline.py, host/train_graph.py).  Destroying a
+    graph while a replay of it is still running on the GPU takes the process down on ROCm 7.2 - an abort a few launches later, seen in
+    2 of 8 runs of tests/test_pipeline_gpu.py where `enable_graphs(False)` dropped a plan right after its replay - so an owner waits for
+    the device before its graph objects go (`__del__` runs before the attributes are released).  Runners die rarely (a re-capture
+    after a weight update, an evicted plan, the end of a run): the wait is off every hot path."""
+
+    def __del__(self):
+        try:
+            if torch.cuda.is_available() and torch.cuda.is_initialized():
+                torch.cuda.synchronize()
+        except Exception:      # interpreter shutdown: torch may be half gone, and then so is every stream
+            pass
+
+
 class HipModule(nn.Module):
     """nn.Module whose parameters are plain torch containers (reference-compatible state_dict keys) and whose
     forward is HIP kernels.  Lowered weights ("plans": folded BatchNorm, [Cout][K] layout, compute dtype) are

@@ -11,6 +11,7 @@ import torch
 
 from .. import autograd as ag
 from ..lib import CobevtHipError
+from .runtime import GraphOwner
 
 
 def _state_tensors(optimizer):
@@ -20,7 +21,7 @@ def _state_tensors(optimizer):
                 yield v
 
 
-class CapturedTrainStep(object):
+class CapturedTrainStep(GraphOwner):
     """step(batch) == one eager training step on `batch`, returning the (static) loss tensor.
 
     model      a HipModule in train() mode on a ROCm device (CorpBEVT / FaxFusedTransformer)
