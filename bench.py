@@ -814,6 +814,8 @@ def main():
                     el, per = timed_loop(step, W, K, 1, dev)
                     out["value_with_h2d_" + tag] = round(K / el, 3)
                     out["ms_per_step_with_h2d_" + tag] = round(el / K * 1e3, 4)
+                    out["ms_per_step_median_with_h2d_" + tag] = round(pct(per, 0.5), 4)
+                    out["ms_per_step_max_with_h2d_" + tag] = round(per[-1], 4)
                     # the pull on its own: what the link delivers for this frame through the fetch kernel, and through the copy engine
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     dst = run.slots[0]["inputs"]

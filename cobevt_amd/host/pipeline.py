@@ -460,6 +460,11 @@ class HostFrameFeeder(object):
         dst = self.host_slot()
         if src.data_ptr() != dst.data_ptr():
             dst.copy_(src)                            # host memcpy into the ring (skipped when the loader wrote in place)
+        if self.n_put == 0:
+            # nothing pulls the very first frame: fetch it now, in stream order, while the pipeline is not stepping yet (the same
+            # transfer issued between two replays of a running loop is the late path of step(); profiles/r05_ab_same_job.txt)
+            ops.host_fetch(dst, r.slots[(self.base) % r.depth]["inputs"])
+            self.pulled = True
         self.queue.append({k: host_batch[k] for k in r.slots[0] if k != "inputs"})
         self.n_put += 1
 
