@@ -463,7 +463,10 @@ class HostFrameFeeder(object):
         if self.n_put == 0:
             # nothing pulls the very first frame: fetch it now, in stream order, while the pipeline is not stepping yet (the same
             # transfer issued between two replays of a running loop is the late path of step(); profiles/r05_ab_same_job.txt)
-            ops.host_fetch(dst, r.slots[(self.base) % r.depth]["inputs"])
+            slot = self.base % r.depth
+            ops.host_fetch(dst, r.slots[slot]["inputs"])
+            self.fetched[slot] = torch.cuda.Event()
+            self.fetched[slot].record()               # the put() that rewrites this ring slot (`depth` frames on) waits for this read
             self.pulled = True
         self.queue.append({k: host_batch[k] for k in r.slots[0] if k != "inputs"})
         self.n_put += 1
