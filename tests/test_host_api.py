@@ -273,3 +273,83 @@ def test_bench_line_finishing_touches():
     bench.finish_line(multi, 8)
     assert multi["throughput_mode"]["value"] == 600.0 and multi["throughput_mode"]["mode"] == "throughput"
     bench.finish_line({"value": 1.0, "config": {"workload": "OPV2V-LiDAR FuseBEVT"}}, 1)     # a line without any of the legs
+
+
+def test_host_frame_feeder_protocol(monkeypatch):
+    """HostFrameFeeder's hand-over protocol on a stand-in runner (no GPU: the fetch kernel and the events are recorded, not run): which
+    pinned slot is fetched into which image slot and when, which event a put() waits for before it rewrites a ring slot, and that a frame
+    handed over AFTER the previous step (put, step, put, step) is fetched in stream order instead of being lost"""
+    from cobevt_amd.host import pipeline
+    log = []
+
+    class Event(object):
+        count = 0
+
+        def __init__(self):
+            Event.count += 1
+            self.id = Event.count
+
+        def record(self):
+            log.append(("record", self.id))
+
+        def synchronize(self):
+            log.append(("wait", self.id))
+
+    def runner():
+        r = object.__new__(pipeline.PipelinedCorpBEVT)
+        r.host_ingest, r.depth, r.i = True, 3, 0
+        r.pinned = [torch.zeros(16, dtype=torch.uint8) for _ in range(3)]
+        r.slots = [{"inputs": torch.zeros(16, dtype=torch.uint8), "intrinsic": None, "extrinsic": None, "transformation_matrix": None,
+                    "record_len": None} for _ in range(3)]
+
+        def step(small):
+            assert small["inputs"] is r.slots[r.i % 3]["inputs"]
+            log.append(("step", r.i))
+            r.i += 1
+            return r.i - 1
+        r.step = step
+        return r
+
+    def name(r, t):
+        for i in range(3):
+            if t.data_ptr() == r.pinned[i].data_ptr():
+                return "pinned%d" % i
+            if t.data_ptr() == r.slots[i]["inputs"].data_ptr():
+                return "slot%d" % i
+        return "?"
+    monkeypatch.setattr(pipeline.torch.cuda, "Event", Event)
+    small = {"intrinsic": 1, "extrinsic": 2, "transformation_matrix": 3, "record_len": 4}
+    frame = lambda: dict(small, inputs=torch.ones(16, dtype=torch.uint8))          # noqa: E731
+
+    # one frame ahead of the step: only the very first frame is fetched outside a graph; put(k + 3) waits for the read of frame k
+    r = runner()
+    monkeypatch.setattr(pipeline.ops, "host_fetch", lambda src, dst, blocks=0: log.append(("fetch", name(r, src), name(r, dst))))
+    f = pipeline.HostFrameFeeder(r)
+    f.put(frame())
+    first = [e for e in log if e[0] == "record"][0][1]
+    for k in range(5):
+        f.put(frame())
+        assert f.step() == k
+    assert [e for e in log if e[0] == "fetch"] == [("fetch", "pinned0", "slot0")]
+    waits = [e[1] for e in log if e[0] == "wait"]
+    records = [e[1] for e in log if e[0] == "record"]
+    assert waits[0] == first and waits[1:] == records[1:1 + len(waits) - 1]     # put(3) waits for the first fetch, put(4) for step 0's pull, ..
+    with pytest.raises(CobevtHipError):
+        f.put(frame()); f.put(frame())
+
+    # put AFTER the step: every frame after the first missed the pull and is fetched (pinned q -> image slot q) before its own step
+    del log[:]
+    r = runner()
+    f = pipeline.HostFrameFeeder(r)
+    for k in range(5):
+        f.put(frame())
+        assert f.step() == k
+    order = [e for e in log if e[0] in ("fetch", "step")]
+    want = [("fetch", "pinned0", "slot0"), ("step", 0)]
+    for k in range(1, 5):
+        want += [("fetch", "pinned%d" % (k % 3), "slot%d" % (k % 3)), ("step", k)]
+    assert order == want
+    with pytest.raises(CobevtHipError):
+        f.step()                                                   # nothing handed over
+    with pytest.raises(CobevtHipError):
+        f.put(dict(small, inputs=torch.ones(8, dtype=torch.uint8)))
