@@ -1,9 +1,11 @@
-"""Build libcobevt_hip.so and libcobevt_hip_f32s.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+"""Build libcobevt_hip.so, libcobevt_hip_f32s.so and libcobevt_hip_f32h.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
 `python -m cobevt_amd.build` or `__graft_entry__.build()`.  Objects are rebuilt only when a source or
 header is newer than the object.  The second library is the SAME sources compiled with -DCOBEVT_F32_SPLIT=1
 (csrc/common.hpp): its fp32-storage kernels take every matrix product through two split-bf16 MFMAs instead of
-four v_mfma_f32_32x32x2_f32 - the "fp32 storage, split-bf16 matrix path" compute mode of host.set_compute_dtype.
+four v_mfma_f32_32x32x2_f32 - the "fp32 storage, split-bf16 matrix path" compute mode of host.set_compute_dtype.  The third
+(-DCOBEVT_F32_SPLIT=2) takes them through ONE fp16 MFMA with the weight operand as a single fp16 term: the ResNet encoder's library
+under host.set_compute_dtype("fp32_fast").
 """
 import os
 import subprocess
@@ -12,6 +14,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libcobevt_hip.so")
 LIB_F32S = os.path.join(CSRC, "libcobevt_hip_f32s.so")
+LIB_F32H = os.path.join(CSRC, "libcobevt_hip_f32h.so")
 SOURCES = ["igemm.hip", "conv3x3.hip", "basicblock.hip", "bottleneck.hip", "gemm_rows.hip", "gemm_rows3.hip", "bev_query.hip", "row_chain.hip", "row_chain64.hip", "proj_chain128.hip", "proj_chain_k.hip", "swap_stage.hip", "stem7x7.hip", "attention.hip", "attention_resident.hip", "attention_bwd.hip", "train_rows.hip", "train_glue.hip", "train_prep.hip", "wgrad3.hip", "train_nusc.hip", "train_fax.hip", "elementwise.hip", "pairwise_fusion.hip", "postprocess.hip", "depthwise.hip", "peer_gather.hip", "calibrate.hip"]
 HEADERS = ["common.hpp", "attn_common.hpp", "warp_common.hpp", "row_chain.hpp", "bev_query.hpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"]
@@ -62,6 +65,7 @@ def _build_one(lib, objdir, extra, force, verbose):
 
 def build(force=False, verbose=True):
     _build_one(LIB_F32S, os.path.join(CSRC, "f32s"), ["-DCOBEVT_F32_SPLIT=1"], force, verbose)
+    _build_one(LIB_F32H, os.path.join(CSRC, "f32h"), ["-DCOBEVT_F32_SPLIT=2"], force, verbose)
     return _build_one(LIB, CSRC, [], force, verbose)
 
 

@@ -118,7 +118,7 @@ __device__ __forceinline__ void bb_conv_chunk(const unsigned char* patch, const 
             if (n + 2 < 36) read_a(af[(n + 2) % 3], n + 2);
 #pragma unroll
             for (int t = 0; t < NTW; ++t)
-                if (ok[t]) mfma_kgroup<T>(bq[tap % 3][g], af[n % 3][t], acc[t]);   // D = W . X^T: lane <-> pixel, registers <-> couts
+                if (ok[t]) mfma_kgroup_xs<T>(bq[tap % 3][g], af[n % 3][t], acc[t]);   // D = W . X^T: lane <-> pixel, registers <-> couts
             if (Elem<T>::kIsBf16 && n + 2 < 36) {
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) {
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
 #pragma unroll
         for (int it = 0; it < P_IT; ++it)
             if (plds[it] >= 0)
-                *(uint4*)(patch1 + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : preg[it];
+                *(uint4*)(patch1 + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : stage_x_piece<T>(preg[it]);
     };
     // weight fragments of this wave's cout tile: step s = chunk * 9 + tap -> 4 k-groups x 64 lanes
     uint4 bq[R][4];
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
                 for (int e = 0; e < 4; ++e) v[e] = inside ? fmaxf(v[e], 0.f) : 0.f;
                 unsigned char* d = patch2 + ry * G::PITCH2 + rx * PSTR2 + (c0 + 8 * k) * Elem<T>::kBytes;
                 if constexpr (Elem<T>::kIsBf16) *(uint2*)d = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                else *(float4*)d = make_float4(v[0], v[1], v[2], v[3]);
+                else *(uint4*)d = stage_x_piece<T>(make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
             }
         }
     }

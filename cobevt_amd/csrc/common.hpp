@@ -89,16 +89,57 @@ __device__ __forceinline__ void split_bf16_pair(float x, float y, uint32_t& hi, 
     lo = pack_bf2(x - __uint_as_float(hi << 16), y - __uint_as_float(hi & 0xffff0000u));
 }
 
+// COBEVT_F32_SPLIT = 2 builds the THIRD library (libcobevt_hip_f32h.so; round 6): fp32 storage, ONE
+// v_mfma_f32_32x32x16_f16 per 16-byte piece.  The activation-side piece x[0..3] goes in as an fp16 pair per value -
+// hi = fp16(x), lo = fp16((x - hi) * 2^kF16LoShift): 22 significand bits - and the weight-side piece w[0..3] as ONE fp16 term, once
+// at full scale against the hi slots and once scaled by 2^-kF16LoShift against the lo slots: sum_k (x_hi + x_lo) w_hi, i.e. the
+// weights are rounded to 11 bits and nothing else is.  Half the matrix time of the split-bf16 form; only the ResNet encoder's
+// convolutions are routed through this library (host/resnet_ms.py under set_compute_dtype("fp32_fast")): measured with the CPU
+// oracle (tools/precision_emul.py, mode fp16_we) that costs 2.7-2.8e-4 max-rel / 1.0-1.5e-4 rms-rel on the 5-agent frame's logits,
+// where fp16 weights in EVERY product cost 0.8-1.0e-3 and fp16 operands on both sides 1.6e-3 (the north-star's gate is 1e-3).
+// The shift keeps the lo slots out of fp16's subnormal range for |x| >= 4e-3 (lo ~ 2^-12 |x|) whether or not the matrix pipe
+// flushes subnormals; the scaled weight copy is normal for |w| >= 4e-3 and below that the lo term it would carry is < 2^-12 * 4e-3 |x|.
+// Range: |x|, |w| <= 65504 (fp16) - the same precondition as the reference's own fp16 autocast (train_camera.py:157-160).
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+constexpr float kF16LoScale = 64.0f;             // 2^6
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+// activation-side piece -> {hi(x0,x1), hi(x2,x3), lo(x0,x1), lo(x2,x3)}
+__device__ __forceinline__ uint4 split_f16_piece(const uint4& x) {
+    const float x0 = __uint_as_float(x.x), x1 = __uint_as_float(x.y), x2 = __uint_as_float(x.z), x3 = __uint_as_float(x.w);
+    const uint32_t h01 = pack_h2(x0, x1), h23 = pack_h2(x2, x3);
+    const f16x2 a = __builtin_bit_cast(f16x2, h01), b = __builtin_bit_cast(f16x2, h23);
+    const uint32_t l01 = pack_h2((x0 - (float)a[0]) * kF16LoScale, (x1 - (float)a[1]) * kF16LoScale);
+    const uint32_t l23 = pack_h2((x2 - (float)b[0]) * kF16LoScale, (x3 - (float)b[1]) * kF16LoScale);
+    return make_uint4(h01, h23, l01, l23);
+}
+// weight-side piece -> {w01, w23, w01 / 2^s, w23 / 2^s} as fp16
+__device__ __forceinline__ uint4 dup_f16_piece(const uint4& w) {
+    const uint32_t h01 = pack_h2(__uint_as_float(w.x), __uint_as_float(w.y)), h23 = pack_h2(__uint_as_float(w.z), __uint_as_float(w.w));
+    const f16x2 inv = {(_Float16)(1.0f / kF16LoScale), (_Float16)(1.0f / kF16LoScale)};
+    const f16x2 s01 = __builtin_bit_cast(f16x2, h01) * inv, s23 = __builtin_bit_cast(f16x2, h23) * inv;
+    return make_uint4(h01, h23, __builtin_bit_cast(uint32_t, s01), __builtin_bit_cast(uint32_t, s23));
+}
+
 // One 32-byte k-group of a 32x32 MFMA tile.  `a` and `b` are the 16-byte pieces this lane read from
 // row (lane&31) of the A tile and the B tile at byte offset 16*(lane>>5) of the k-group.
 // C/D layout (both dtypes): col = lane&31 (B row), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (A row).
-template <typename T>
+// kWeightsFirst: which operand is the weight-like one (D = W . X^T kernels pass the weights as `a`) - only the fp16 form of the
+// third library distinguishes the two sides.
+template <typename T, bool kWeightsFirst = true>
 __device__ __forceinline__ void mfma_kgroup(const uint4& a, const uint4& b, f32x16& acc) {
     if constexpr (Elem<T>::kIsBf16) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
                                                       __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
     } else {
-#if COBEVT_F32_SPLIT
+#if COBEVT_F32_SPLIT == 2
+        const uint4 av = kWeightsFirst ? dup_f16_piece(a) : split_f16_piece(a);
+        const uint4 bv = kWeightsFirst ? split_f16_piece(b) : dup_f16_piece(b);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), acc, 0, 0, 0);
+#elif COBEVT_F32_SPLIT
         // fp32 storage, split-bf16 matrix path (libcobevt_hip_f32s.so): x = hi + lo with hi = bf16(x), lo = bf16(x - hi),
         // |x - hi - lo| <= 2^-17 |x|.  The bf16 instruction contracts 8 element pairs per lane half where the piece holds 4
         // values, so A carries {hi[0..3], lo[0..3]} and B {hi[0..3], hi[0..3]} / {lo[0..3], lo[0..3]}: two
@@ -120,6 +161,24 @@ __device__ __forceinline__ void mfma_kgroup(const uint4& a, const uint4& b, f32x
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
 #endif
+    }
+}
+
+// Activation pieces split ONCE, when a kernel stages them into an LDS patch that only feeds MFMA operand reads (third library, fp32
+// storage): the in-loop form above spends ~12 VALU instructions per MFMA on the split and is VALU-bound (256 -> 256 on 20 x 32 x 32:
+// 103 us split-bf16 -> 77 us), while a patch piece is read by 9 taps x every cout tile of the workgroup.  stage_x_piece is the identity
+// in every other build / type, and mfma_kgroup_xs is mfma_kgroup<T> (weights first) there.
+template <typename T> constexpr bool kXSplit = (COBEVT_F32_SPLIT == 2) && !Elem<T>::kIsBf16;
+template <typename T> __device__ __forceinline__ uint4 stage_x_piece(const uint4& x) {
+    if constexpr (kXSplit<T>) return split_f16_piece(x);
+    else return x;
+}
+template <typename T> __device__ __forceinline__ void mfma_kgroup_xs(const uint4& w, const uint4& xs, f32x16& acc) {
+    if constexpr (kXSplit<T>) {
+        const uint4 wv = dup_f16_piece(w);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wv), __builtin_bit_cast(f16x8, xs), acc, 0, 0, 0);
+    } else {
+        mfma_kgroup<T>(w, xs, acc);
     }
 }
 
@@ -145,7 +204,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 
 // GELU of the bf16 kernels (fax_modules.py:309-313, base_transformer.py:108): x Phi(x) as x * sigmoid(x (p0 + p1 x^2 + p2 x^4))
 // with (p0, p1, p2) = (1.59433946, 0.0745210325, -7.69554552e-4) fitted to the exact x Phi(x) (the tanh form's 0.044715 cubic
-// plus a quintic term): |error| <= 6.2e-5 everywhere and <= 0.38 of the bf16 rounding error 2^-9 max(|gelu(x)|, 0.01) the result
+// plus a quintic term): |error| <= 6.2e-5 for x >= -8 (below that the result is x * 7e-12 instead of a value tending to -0: < 1e-9 in magnitude down to x = -100) and <= 0.38 of the bf16 rounding error 2^-9 max(|gelu(x)|, 0.01) the result
 // meets next - it is stored as bf16 in every kernel that calls this.  Seven VALU instructions (one v_exp_f32, one v_rcp_f32)
 // against ~25 for the A&S erf form, which was 3.2k of the 5.5k VALU instructions of a 32-row block of the level-0 row chain.
 // The polynomial turns over beyond |x| ~ 8.2, so its argument is clamped to [-8, 8] (sigmoid there: 1 - 7e-12 / 7e-12);
@@ -158,13 +217,13 @@ __device__ __forceinline__ float gelu_bf16(float x) {
     const float e = __builtin_amdgcn_exp2f(xc * w);
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
+#ifdef COBEVT_GELU_EXACT          // A/B builds only (tools/build_variant.py): the erf form in the bf16 kernels too.  In front of gelu_t,
+#define gelu_bf16 gelu_erf        // so that apply_act<T> (conv3x3, gemm_rows, gemm_rows3, igemm epilogues) switches with the direct callers
+#endif
 template <typename T> __device__ __forceinline__ float gelu_t(float x) {
     if constexpr (sizeof(T) == 2) return gelu_bf16(x);
     else return gelu_erf(x);
 }
-#ifdef COBEVT_GELU_EXACT          // A/B builds only (tools/build_variant.py): the erf form in the bf16 kernels too
-#define gelu_bf16 gelu_erf
-#endif
 
 // epilogue activations by code: 0 none, 1 ReLU, 2 exact GELU, 3 swish x * sigmoid(x) (EfficientNet MBConv), 4 sigmoid
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }

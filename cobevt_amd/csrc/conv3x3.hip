@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kConv3Threads) void conv3x3_kernel(Conv3Params p) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) bf[b] = *(const uint4*)(pb + b * 32 * WSTR + g * 32);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) mfma_kgroup<T>(af, bf[b], acc[b]);
+            for (int b = 0; b < 2; ++b) mfma_kgroup<T, false>(af, bf[b], acc[b]);    // A = pixels, B = weights
         }
         if (step + 1 < nsteps) store_w(RS, buf ^ 1);
         if (tap == 8 && next_chunk) {
@@ -549,14 +549,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
 #pragma unroll
         for (int it = 0; it < P_IT; ++it)
             if (plds[it] >= 0)
-                *(uint4*)(dst + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : preg[it];
+                *(uint4*)(dst + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : stage_x_piece<T>(preg[it]);
     };
     constexpr int PSN = 9 - COBEVT_CONV3_PSTORE_FIRST;               // taps that carry stores
     auto store_patch_part = [&](unsigned char* dst, int part) {      // one share of the pieces (part = 0 .. PSN - 1, compile-time after unrolling)
 #pragma unroll
         for (int it = 0; it < P_IT; ++it)
             if (it % PSN == part && plds[it] >= 0)
-                *(uint4*)(dst + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : preg[it];
+                *(uint4*)(dst + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : stage_x_piece<T>(preg[it]);
     };
     auto load_b = [&](uint4 (&b)[KGW], int step) {
 #pragma unroll
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
             }
 #pragma unroll
             for (int u = 0; u < BATCH; ++u)
-                if (dst[u] >= 0) *(uint4*)(patch + dst[u]) = v[u];
+                if (dst[u] >= 0) *(uint4*)(patch + dst[u]) = stage_x_piece<T>(v[u]);      // split(0) = 0: the padding stays zero
         }
     };
 
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
 #pragma unroll
                 for (int a = 0; a < MT; ++a) {
                     if (COBEVT_CONV3_KNOCK & 2) acc[a][0] += __uint_as_float((af[n % 3][a].x ^ bq[tap % R][g].x) & 0x3fffffffu);
-                    else mfma_kgroup<T>(bq[tap % R][g], af[n % 3][a], acc[a]);   // D = W X^T: rows = couts, cols = pixels
+                    else mfma_kgroup_xs<T>(bq[tap % R][g], af[n % 3][a], acc[a]);   // D = W X^T: rows = couts, cols = pixels
                 }
                 if (Elem<T>::kIsBf16 && n + 2 < NG) {
 #pragma unroll

@@ -265,8 +265,8 @@ __global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams
             const uint4 af = *(const uint4*)(As + abase + g * 32);
             const uint4 b0 = *(const uint4*)(Ws + bbase + g * 32);
             const uint4 b1 = *(const uint4*)(Ws + bbase + 32 * kGrRow + g * 32);
-            mfma_kgroup<T>(af, b0, acc[0]);
-            mfma_kgroup<T>(af, b1, acc[1]);
+            mfma_kgroup<T, false>(af, b0, acc[0]);    // A = activation rows, B = weights
+            mfma_kgroup<T, false>(af, b1, acc[1]);
         }
     }
     COBEVT_GT_MARK(3);

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b) mfma_kgroup<T>(af[a], bfr[b], acc[a][b]);
+                for (int b = 0; b < TN; ++b) mfma_kgroup<T, false>(af[a], bfr[b], acc[a][b]);    // A = gathered pixels, B = weights
         }
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();

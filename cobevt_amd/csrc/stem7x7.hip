@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(StemParams p) {
                 }
                 const uint4 b0 = *(const uint4*)pw;
                 const uint4 b1 = *(const uint4*)(pw + 32 * C::WROW);
-                mfma_kgroup<T>(af, b0, acc[0]);
-                mfma_kgroup<T>(af, b1, acc[1]);
+                mfma_kgroup<T, false>(af, b0, acc[0]);    // A = activation rows, B = weights
+                mfma_kgroup<T, false>(af, b1, acc[1]);
             }
         }
         // ---- epilogue: bias + activation staged as fp32, then coalesced 16-byte stores

@@ -8,6 +8,7 @@ accepted and ignored (no network; the reference would download ImageNet weights,
 import torch
 import torch.nn as nn
 
+from .. import lib as _L
 from .. import ops
 from ..lib import CobevtHipError
 from . import runtime as rt
@@ -150,10 +151,14 @@ class ResnetEncoder(HipModule):
         """Generator over (stage index 0..3, channels-last feature map) so a caller can overlap work that depends on
         an early stage with the later stages (CorpBEVT.encode_agents)."""
         b, l, m, h, w, c = input_images.shape
-        x = self._stem(input_images.reshape(b * l * m, h, w, c))
+        # encoder_scope: under set_compute_dtype("fp32_fast") these launches go to the one-fp16-MFMA library (runtime.py); the
+        # scope is closed around every yield - the caller's work between two stages must not inherit it
+        with _L.encoder_scope():
+            x = self._stem(input_images.reshape(b * l * m, h, w, c))
         for i, layer in enumerate((self.encoder.layer1, self.encoder.layer2, self.encoder.layer3, self.encoder.layer4)):
-            for blk in layer:
-                x = blk.forward_nhwc(x)
+            with _L.encoder_scope():
+                for blk in layer:
+                    x = blk.forward_nhwc(x)
             yield i, x
 
     def forward(self, input_images):
@@ -162,13 +167,14 @@ class ResnetEncoder(HipModule):
             return training.resnet_encoder(self, input_images)
         self._require_inference(input_images)
         b, l, m, h, w, c = input_images.shape
-        x = self._stem(input_images.reshape(b * l * m, h, w, c))
         results = []
-        for layer in (self.encoder.layer1, self.encoder.layer2, self.encoder.layer3, self.encoder.layer4):
-            for blk in layer:
-                x = blk.forward_nhwc(x)
-            v = rt.nchw_view(x)
-            results.append(v.reshape(b, l, m, *v.shape[1:]))
+        with _L.encoder_scope():
+            x = self._stem(input_images.reshape(b * l * m, h, w, c))
+            for layer in (self.encoder.layer1, self.encoder.layer2, self.encoder.layer3, self.encoder.layer4):
+                for blk in layer:
+                    x = blk.forward_nhwc(x)
+                v = rt.nchw_view(x)
+                results.append(v.reshape(b, l, m, *v.shape[1:]))
         if isinstance(self.idx_pick, list):
             return [results[i] for i in self.idx_pick]
         return results[self.idx_pick]

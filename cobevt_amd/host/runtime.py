@@ -9,7 +9,7 @@ from ..lib import CobevtHipError
 
 _COMPUTE_DTYPE = torch.bfloat16
 _MATRIX_PATH = "native"
-MATRIX_PATHS = ("native", "split_bf16")
+MATRIX_PATHS = ("native", "split_bf16", "split_bf16_enc_fp16")
 from .. import lib as _lib  # noqa: E402
 
 
@@ -18,10 +18,17 @@ def set_compute_dtype(dtype, matrix_path=None):
     matrix_path "native" = exact v_mfma_f32_32x32x2_f32 (default), "split_bf16" = every matrix product of the inference
     kernels as two v_mfma_f32_32x32x16_bf16 over (hi, lo) bf16 halves of both operands (all four cross terms, |x - hi - lo| <=
     2^-17 |x|: ~1e-5 end to end instead of 1e-6, at 4x the matrix rate; served by libcobevt_hip_f32s.so, cobevt_amd/build.py).
-    The string "fp32_split" is shorthand for (torch.float32, "split_bf16")."""
+    The string "fp32_split" is shorthand for (torch.float32, "split_bf16").
+    "fp32_fast" = (torch.float32, "split_bf16_enc_fp16") (round 6): as "fp32_split", except that the ResNet encoder's convolutions -
+    80 % of a frame's flops - take ONE v_mfma_f32_32x32x16_f16 per 16-byte piece: activations as fp16 (hi, lo) pairs (22 bits),
+    the folded weights as a single fp16 term (libcobevt_hip_f32h.so; csrc/common.hpp COBEVT_F32_SPLIT == 2).  Still fp32 storage
+    everywhere; ~3e-4 max-rel on the 5-agent frame (inside the north-star's 1e-3, not the 1e-5 of "fp32_split"), half the
+    encoder's matrix time.  Precondition: encoder activations and folded weights within fp16 range (|v| <= 65504), as under the
+    reference's own fp16 autocast (train_camera.py:157-160)."""
     global _COMPUTE_DTYPE, _MATRIX_PATH
     if isinstance(dtype, str):
-        alias = {"bf16": (torch.bfloat16, "native"), "fp32": (torch.float32, "native"), "fp32_split": (torch.float32, "split_bf16")}
+        alias = {"bf16": (torch.bfloat16, "native"), "fp32": (torch.float32, "native"), "fp32_split": (torch.float32, "split_bf16"),
+                 "fp32_fast": (torch.float32, "split_bf16_enc_fp16")}
         if dtype not in alias:
             raise CobevtHipError("compute mode must be one of %s" % sorted(alias))
         dtype, mp = alias[dtype]
@@ -30,10 +37,11 @@ def set_compute_dtype(dtype, matrix_path=None):
     if matrix_path not in MATRIX_PATHS:
         raise CobevtHipError("matrix_path must be one of %s" % (MATRIX_PATHS,))
     ops.dcode(dtype)
-    if matrix_path == "split_bf16" and dtype != torch.float32:
-        raise CobevtHipError("the split-bf16 matrix path belongs to fp32 storage (bf16 storage IS the bf16 matrix path)")
+    if matrix_path != "native" and dtype != torch.float32:
+        raise CobevtHipError("the split-bf16 matrix paths belong to fp32 storage (bf16 storage IS the bf16 matrix path)")
     _COMPUTE_DTYPE, _MATRIX_PATH = dtype, matrix_path
-    _lib.set_variant("f32s" if matrix_path == "split_bf16" else "")
+    _lib.set_variant("" if matrix_path == "native" else "f32s")
+    _lib.set_encoder_variant("f32h" if matrix_path == "split_bf16_enc_fp16" else None)
 
 
 def get_compute_dtype():
@@ -45,8 +53,10 @@ def get_matrix_path():
 
 
 def get_compute_mode():
-    """"bf16" | "fp32" | "fp32_split": the key captured graphs are cached under (plans = lowered weights depend on the dtype only)"""
-    return "bf16" if _COMPUTE_DTYPE == torch.bfloat16 else ("fp32_split" if _MATRIX_PATH == "split_bf16" else "fp32")
+    """"bf16" | "fp32" | "fp32_split" | "fp32_fast": the key captured graphs are cached under (plans = lowered weights depend on the dtype only)"""
+    if _COMPUTE_DTYPE == torch.bfloat16:
+        return "bf16"
+    return {"native": "fp32", "split_bf16": "fp32_split", "split_bf16_enc_fp16": "fp32_fast"}[_MATRIX_PATH]
 
 
 @contextlib.contextmanager

@@ -139,8 +139,15 @@ SIGNATURES = {
 _libs = {}
 # "" = libcobevt_hip.so; "f32s" = libcobevt_hip_f32s.so, the same sources and C ABI built with -DCOBEVT_F32_SPLIT=1: fp32-storage
 # kernels on the split-bf16 matrix path (cobevt_amd/build.py, csrc/common.hpp).  host.set_compute_dtype selects it.
+# "f32h" = libcobevt_hip_f32h.so (-DCOBEVT_F32_SPLIT=2, round 6): fp32 storage, one fp16 MFMA per 16-byte piece with the weight
+# operand as a single fp16 term - half the split-bf16 matrix time at 11-bit weights.  Only the ResNet encoder's convolutions are
+# routed through it, and only under host.set_compute_dtype("fp32_fast"): `set_encoder_variant` names the library `encoder_scope()`
+# switches to for the launches issued inside it (host/resnet_ms.py).
 _variant = ""
+_encoder_variant = None
+VARIANTS = ("", "f32s", "f32h")
 LIB_PATH_F32S = os.environ.get("COBEVT_HIP_LIB_F32S") or os.path.join(_HERE, "csrc", "libcobevt_hip_f32s.so")
+LIB_PATH_F32H = os.environ.get("COBEVT_HIP_LIB_F32H") or os.path.join(_HERE, "csrc", "libcobevt_hip_f32h.so")
 
 
 class CobevtHipError(RuntimeError):
@@ -149,7 +156,7 @@ class CobevtHipError(RuntimeError):
 
 def set_variant(variant):
     global _variant
-    if variant not in ("", "f32s"):
+    if variant not in VARIANTS:
         raise CobevtHipError("unknown library variant %r" % (variant,))
     _variant = variant
 
@@ -158,13 +165,41 @@ def get_variant():
     return _variant
 
 
+def set_encoder_variant(variant):
+    """The library the ResNet encoder's launches use instead of the active one (None: no override)."""
+    global _encoder_variant
+    if variant is not None and variant not in VARIANTS:
+        raise CobevtHipError("unknown library variant %r" % (variant,))
+    _encoder_variant = variant
+
+
+def get_encoder_variant():
+    return _encoder_variant
+
+
+class encoder_scope(object):
+    """with lib.encoder_scope(): ...  - launches issued inside go to the encoder's library variant, when one is set."""
+
+    def __enter__(self):
+        global _variant
+        self.prev = _variant
+        if _encoder_variant is not None:
+            _variant = _encoder_variant
+        return self
+
+    def __exit__(self, *exc):
+        global _variant
+        _variant = self.prev
+        return False
+
+
 def load(variant=None):
     """Load (once per variant) and return the ctypes handle of the active library; raises if the HIP extension has not been built."""
     v = _variant if variant is None else variant
     lib = _libs.get(v)
     if lib is not None:
         return lib
-    path = LIB_PATH_F32S if v == "f32s" else LIB_PATH
+    path = {"f32s": LIB_PATH_F32S, "f32h": LIB_PATH_F32H}.get(v, LIB_PATH)
     if not os.path.exists(path):
         raise CobevtHipError(
             "%s not found at %s — build it with `python -m cobevt_amd.build` "

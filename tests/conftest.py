@@ -23,3 +23,17 @@ def cuda():
     from cobevt_amd import lib
     lib.load()  # fail loudly if the HIP extension is missing
     return torch.device("cuda:0")
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """The ten parity comparisons closest to their gates (tests/util.py GATE_RATIOS)."""
+    try:
+        from util import GATE_RATIOS
+    except Exception:
+        return
+    if not GATE_RATIOS:
+        return
+    tr = terminalreporter
+    tr.section("parity gate headroom: the 10 comparisons closest to their gates (measured / gate)")
+    for ratio, norm, measured, gate, what, tid in sorted(GATE_RATIOS, key=lambda t: -t[0])[:10]:
+        tr.write_line("%.3f  %s-rel %.3e / %.2e  %s  [%s]" % (ratio, norm, measured, gate, what, tid))

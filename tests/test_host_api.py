@@ -92,6 +92,35 @@ def test_second_library_and_compute_modes():
         host.set_compute_dtype("fp64")
 
 
+def test_third_library_is_the_encoders_library_in_fast_mode():
+    """libcobevt_hip_f32h.so (-DCOBEVT_F32_SPLIT=2: one fp16 MFMA per piece, weights as a single fp16 term) loads and exports the whole
+    C ABI; "fp32_fast" = the fp32_split library everywhere, with the launches issued inside lib.encoder_scope() - the ResNet encoder's,
+    host/resnet_ms.py - going to the third library; no other mode has an encoder override."""
+    l3 = lib.load("f32h")
+    assert l3 is not lib.load("") and l3 is not lib.load("f32s") and l3.cobevt_abi_version() == 1
+    for name in lib.SIGNATURES:
+        assert getattr(l3, name) is not None
+    assert lib.get_encoder_variant() is None
+    with lib.encoder_scope():
+        assert lib.get_variant() == ""                     # no override outside fp32_fast
+    with host.compute_dtype("fp32_fast"):
+        assert host.get_compute_dtype() == torch.float32 and host.get_compute_mode() == "fp32_fast"
+        assert host.get_matrix_path() == "split_bf16_enc_fp16"
+        assert lib.get_variant() == "f32s" and lib.get_encoder_variant() == "f32h"
+        with lib.encoder_scope():
+            assert lib.get_variant() == "f32h" and lib.load() is l3
+            with lib.encoder_scope():                      # re-entrant
+                assert lib.get_variant() == "f32h"
+            assert lib.get_variant() == "f32h"
+        assert lib.get_variant() == "f32s"
+        with host.compute_dtype("fp32_split"):
+            assert lib.get_encoder_variant() is None
+        assert lib.get_encoder_variant() == "f32h"
+    assert lib.get_variant() == "" and lib.get_encoder_variant() is None and host.get_compute_mode() == "bf16"
+    with pytest.raises(CobevtHipError):
+        host.set_compute_dtype(torch.bfloat16, "split_bf16_enc_fp16")
+
+
 def test_uint8_ingest_table_is_the_preprocessors_arithmetic():
     """the (3, 256) table the stem kernel reads == RgbPreProcessor.standalize(normalize(.)) + the collate cast, value for value"""
     from cobevt_amd.host.rgb_preprocessor import RgbPreProcessor, normalisation_table

@@ -64,6 +64,12 @@ BF16 = "bf16: reference-derived gate"
 RMS_FRACTION = {True: 0.9, False: 1.0}           # keyed by "tol is a bf16 gate" (tol > 2e-3)
 _REF_BF16 = None
 _REPORT = os.environ.get("COBEVT_PARITY_REPORT")
+# Headroom policy.  Gates are never re-derived from what the HIP path measures: fp32 modes 1e-3 (north-star),
+# bf16 max(1e-2, the reference's own bf16-autocast deviation).  A comparison may therefore sit close to its gate - in round 5
+# CrossViewModule (0.98), resnet34[2] (0.95) and FAXModule (0.92) did - and a change of summation order moves a bf16 max-norm by
+# +-30 % (profiles/r04_level0_error_probe.txt).  So every assert_close records measured / gate here and tests/conftest.py prints the
+# ten largest ratios at the end of the run: a near-miss is visible in a GREEN run, before a kernel change turns it into a red one.
+GATE_RATIOS = []                                 # (ratio, "max" | "rms", measured, gate, what, test id)
 
 
 def reference_bf16_deviation(case):
@@ -97,6 +103,9 @@ def assert_close(got, ref, tol, what, case=None):
         with open(_REPORT, "a") as f:
             f.write("%s\t%s\tmax_rel=%.3e\trms_rel=%.3e\tgate=%.2e\trms_gate=%.2e\n"
                     % (os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], what, e, r, tol, rms_gate))
+    tid = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    GATE_RATIOS.append((e / tol, "max", e, tol, what, tid))
+    GATE_RATIOS.append((r / rms_gate, "rms", r, rms_gate, what, tid))
     assert e <= tol, "%s: rel err %.3e > %.2e" % (what, e, tol)
     assert r <= rms_gate, "%s: rms rel err %.3e > %.2e" % (what, r, rms_gate)
     return e
