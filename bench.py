@@ -894,6 +894,25 @@ def main():
                             q["three_frames_in_flight"] = {"ms_median": p3["ms_median"], "frames_per_sec": p3["frames_per_sec"]}
                     return q
                 safe(result, "fp32_parity_mode", split_mode)
+
+                # "fp32_fast" (round 6): fp32_split with the ResNet encoder's convolutions - 80 % of the frame's flops - on ONE fp16 MFMA
+                # per 16-byte piece (activations as fp16 (hi, lo) pairs split once at patch staging, folded weights as a single fp16 term;
+                # libcobevt_hip_f32h.so).  Still inside the north-star's 1e-3 (parity in `parity_fp32_fast`), not the 1e-5 of fp32_split.
+                def fast_mode():
+                    with host.compute_dtype("fp32_fast"):
+                        r2 = pipeline.CapturedCorpBEVT(model, batch, use_graph=not args.no_graph)
+                        q = dict(quick(r2.step, 2, 20), note="one frame at a time from captured graphs; fp32 storage everywhere, ResNet encoder "
+                                 "convolutions as one v_mfma_f32_32x32x16_f16 per piece with fp16 weights (csrc/common.hpp COBEVT_F32_SPLIT == 2), "
+                                 "everything else on the split-bf16 path of fp32_parity_mode; parity in `parity_fp32_fast`")
+                        outs["fp32_fast"] = {k: v.clone() for k, v in r2.step().items()}
+                        if graph_ok_main:
+                            r3 = pipeline.PipelinedCorpBEVT(model, batch, depth=3)
+                            for _ in range(8):
+                                r3.step()
+                            p3 = quick(r3.step, 3, 30)
+                            q["three_frames_in_flight"] = {"ms_median": p3["ms_median"], "frames_per_sec": p3["frames_per_sec"]}
+                    return q
+                safe(result, "fp32_fast_mode", fast_mode)
                 safe(result, "fp32_exact_mode", other_dtype)
             else:
                 safe(result, "bf16_mode", other_dtype)
@@ -999,9 +1018,13 @@ def finish_line(result, world):
                      ("opv2v_2_agents_frames_per_sec", "opv2v_2_agents"), ("train_steps_per_sec_bf16_autocast", "train_step_bf16_autocast")):
         if isinstance(oc.get(src), dict) and "frames_per_sec" in oc[src]:
             result[key] = oc[src]["frames_per_sec"]
-    for key, src in (("fp32_parity_mode_frames_per_sec", "fp32_parity_mode"), ("one_frame_at_a_time_frames_per_sec", "one_frame_at_a_time")):
+    for key, src in (("fp32_parity_mode_frames_per_sec", "fp32_parity_mode"), ("fp32_fast_mode_frames_per_sec", "fp32_fast_mode"),
+                     ("one_frame_at_a_time_frames_per_sec", "one_frame_at_a_time")):
         if isinstance(result.get(src), dict) and "frames_per_sec" in result[src]:
             result[key] = result[src]["frames_per_sec"]
+            tf = result[src].get("three_frames_in_flight")
+            if isinstance(tf, dict) and "frames_per_sec" in tf:
+                result[key.replace("_frames_per_sec", "_three_in_flight_frames_per_sec")] = tf["frames_per_sec"]
     cal = result.get("box_calibration") or {}
     ents = [result.get("roofline"), result.get("roofline_fax_attention")] + list(result.get("roofline_other_kernels") or [])
     lid = (oc.get("lidar_fusebevt") or {}).get("roofline") if isinstance(oc.get("lidar_fusebevt"), dict) else None

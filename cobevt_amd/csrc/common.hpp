@@ -182,6 +182,19 @@ template <typename T> __device__ __forceinline__ void mfma_kgroup_xs(const uint4
     }
 }
 
+// Both operands staged: a kernel that also keeps its WEIGHTS in LDS (the stem) converts them once with stage_w_piece and multiplies
+// the staged pieces as they are.
+template <typename T> __device__ __forceinline__ uint4 stage_w_piece(const uint4& w) {
+    if constexpr (kXSplit<T>) return dup_f16_piece(w);
+    else return w;
+}
+template <typename T> __device__ __forceinline__ void mfma_kgroup_staged(const uint4& ws, const uint4& xs, f32x16& acc) {
+    if constexpr (kXSplit<T>)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ws), __builtin_bit_cast(f16x8, xs), acc, 0, 0, 0);
+    else
+        mfma_kgroup<T>(ws, xs, acc);
+}
+
 // accumulator register r of the 32x32 C/D fragment -> row within the tile
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

@@ -375,7 +375,16 @@ __global__ __launch_bounds__(StemPoolCfg<T>::NT) void stem_pool_kernel(StemParam
             if (pdst[it] >= 0) {
                 unsigned char* dst = patch + pdst[it];
                 if constexpr (Elem<T>::kIsBf16) *(uint32_t*)dst = pack_bf2(preg[it].x, preg[it].y);
-                else *(float2*)dst = preg[it];
+                else if constexpr (kXSplit<T>) {
+                    // third library: the 16-byte operand piece {x0..x3} lives in LDS as {hi(x0,x1), hi(x2,x3), lo(x0,x1), lo(x2,x3)} fp16
+                    // (common.hpp split_f16_piece); this float pair is the first or the second half of its piece
+                    const uint32_t hi = pack_h2(preg[it].x, preg[it].y);
+                    const f16x2 hv = __builtin_bit_cast(f16x2, hi);
+                    const uint32_t lo = pack_h2((preg[it].x - (float)hv[0]) * kF16LoScale, (preg[it].y - (float)hv[1]) * kF16LoScale);
+                    unsigned char* pb = patch + (pdst[it] & ~15) + ((pdst[it] >> 1) & 4);
+                    *(uint32_t*)pb = hi;
+                    *(uint32_t*)(pb + 8) = lo;
+                } else *(float2*)dst = preg[it];
             }
     };
 
@@ -413,7 +422,7 @@ __global__ __launch_bounds__(StemPoolCfg<T>::NT) void stem_pool_kernel(StemParam
                     *(uint2*)d = make_uint2(v.x, v.y);
                     if (part == 0) *(uint2*)(d + 8) = make_uint2(v.z, v.w);
                 } else if (part < 3) {
-                    *(uint4*)d = v;
+                    *(uint4*)d = stage_w_piece<T>(v);
                 }
             }
         }
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(StemPoolCfg<T>::NT) void stem_pool_kernel(StemParam
             if (i + RS - 1 < NS && !(COBEVT_STEM_KNOCK & 1)) fetch((i + RS - 1) % RS, i + RS - 1);
             if constexpr (COBEVT_STEM_KNOCK & 2) asm volatile("" :: "v"(rb[i % RS].x), "v"(rb[i % RS].y), "v"(rb[i % RS].z), "v"(rb[i % RS].w), "v"(ra[i % RS].x), "v"(ra[i % RS].y), "v"(ra[i % RS].z), "v"(ra[i % RS].w));
             else
-            mfma_kgroup<T>(rb[i % RS], ra[i % RS], acc);      // D = W . X^T: lane <-> pixel, registers <-> couts
+            mfma_kgroup_staged<T>(rb[i % RS], ra[i % RS], acc);      // D = W . X^T: lane <-> pixel, registers <-> couts
             __builtin_amdgcn_sched_barrier(0);
         }
         COBEVT_ST_MARK(3);

@@ -1425,6 +1425,120 @@ def test_split_bf16_matrix_path_is_the_one_that_runs(cuda):
     assert ((split - ref).abs() <= bound).all()
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# fp32 storage, ONE fp16 MFMA per piece (libcobevt_hip_f32h.so: csrc/common.hpp COBEVT_F32_SPLIT == 2; round 6): the ResNet encoder's
+# library under host.set_compute_dtype("fp32_fast").  The arithmetic is pinned, not just bounded: the kernels must equal the convolution
+# of the UNROUNDED activations with the folded weights ROUNDED TO fp16 (activations enter as fp16 (hi, lo) pairs = 22 bits), to 3e-5
+# of the output scale - and must differ from the split-bf16 library, or the third library is not what ran.
+# ----------------------------------------------------------------------------------------------------------------------
+def _h(w):
+    return w.to(torch.float16).to(torch.float32)
+
+
+def _enc_lib():
+    from cobevt_amd import host, lib
+
+    class _Scope(object):
+        def __enter__(self):
+            self.a = host.compute_dtype("fp32_fast")
+            self.a.__enter__()
+            self.b = lib.encoder_scope()
+            self.b.__enter__()
+            assert lib.get_variant() == "f32h"
+
+        def __exit__(self, *e):
+            self.b.__exit__(*e)
+            self.a.__exit__(*e)
+    return _Scope()
+
+
+def _close_f16w(y, ref, what, rel=3e-5):
+    y, ref = y.detach().double().cpu(), ref.double()
+    assert y.shape == ref.shape and torch.isfinite(y).all(), what
+    e = ((y - ref).abs().max() / ref.abs().max()).item()
+    assert e <= rel, "%s: %.3e of the output scale (the fp16-weight product should be met to %.0e)" % (what, e, rel)
+    return e
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w,stride", [(256, 192, 2, 9, 21, 1), (256, 256, 5, 32, 32, 1), (512, 512, 3, 16, 16, 1), (128, 128, 2, 20, 24, 1),
+                                                  (128, 256, 2, 17, 37, 2), (64, 128, 2, 24, 40, 2), (256, 512, 3, 16, 32, 2)])
+def test_fp16_weight_matrix_path_conv3x3(cuda, cin, cout, n, h, w, stride):
+    """the strip / LDS-staged 3x3 kernels (stride 1 and 2, ragged strips, cout tails, BN folded, residual + ReLU) in the third library"""
+    from cobevt_amd import host
+    f32 = torch.float32
+    x = procedural_input("f16w.x%d" % cin, (n, cin, h, w), 0, -2.0, 2.0)
+    wt = procedural_input("f16w.w%d_%d" % (cin, cout), (cout, cin, 3, 3), 0) * math.sqrt(3.0 / (cin * 9))
+    plan = ops.ConvPlan(wt, None, bn=FakeBN(cout, "f16w.bn%d" % cout), stride=stride, pad=1, act=1, dtype=f32, device=cuda)
+    wref = plan.wgt.float().cpu()[:, :plan.K].reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    res = procedural_input("f16w.res", (n, cout, ho, wo), 0)
+    ref = F.relu(F.conv2d(x.double(), _h(wref).double(), plan.bias.cpu().double(), stride=stride, padding=1) + res.double())
+    ref_exact = F.relu(F.conv2d(x.double(), wref.double(), plan.bias.cpu().double(), stride=stride, padding=1) + res.double())
+    xd, rd = nhwc(x).to(cuda), nhwc(res).to(cuda)
+    with _enc_lib():
+        y = ops.conv2d(xd, plan, residual=rd)
+    with host.compute_dtype("fp32_split"):
+        ys = ops.conv2d(xd, plan, residual=rd)
+    _close_f16w(y.permute(0, 3, 1, 2), ref, "conv3x3 %d->%d s%d" % (cin, cout, stride))
+    assert not torch.equal(y, ys)
+    # against the UNROUNDED weights the result is off by the fp16 rounding of the weights: <= 2^-11 sum |x||w| per output, and visibly so
+    bound = F.conv2d(x.abs().double(), wref.abs().double(), None, stride=stride, padding=1) * 2.0 ** -11 + 1e-6 * ref.abs().max()
+    d = (y.permute(0, 3, 1, 2).double().cpu() - ref_exact).abs()
+    assert (d <= bound).all() and d.max() > 2e-5 * ref_exact.abs().max()
+
+
+@pytest.mark.parametrize("c,n,h,w", [(64, 2, 24, 40), (128, 3, 16, 16), (64, 1, 13, 21), (128, 2, 9, 35)])
+def test_fp16_weight_matrix_path_basicblock(cuda, c, n, h, w):
+    """the fused BasicBlock: both convolutions with fp16 weights, the intermediate map kept in fp32 (split again for conv2)"""
+    f32 = torch.float32
+    x = procedural_input("bb.x", (n, c, h, w), 0)
+    w1 = procedural_input("bb.w1", (c, c, 3, 3), 0) * math.sqrt(3.0 / (c * 9))
+    w2 = procedural_input("bb.w2", (c, c, 3, 3), 0) * math.sqrt(3.0 / (c * 9))
+    p1 = ops.ConvPlan(w1, None, bn=FakeBN(c, "bb.bn1"), stride=1, pad=1, act=1, dtype=f32, device=cuda)
+    p2 = ops.ConvPlan(w2, None, bn=FakeBN(c, "bb.bn2"), stride=1, pad=1, act=1, dtype=f32, device=cuda)
+    xd = nhwc(x).to(cuda)
+    with _enc_lib():
+        assert ops.basicblock_fusable(xd, p1, p2)
+        y = ops.basicblock(xd, p1, p2)
+    wr1 = _h(p1.wgt.float().cpu()[:, :p1.K].reshape(c, 3, 3, c).permute(0, 3, 1, 2)).double()
+    wr2 = _h(p2.wgt.float().cpu()[:, :p2.K].reshape(c, 3, 3, c).permute(0, 3, 1, 2)).double()
+    mid = F.relu(F.conv2d(x.double(), wr1, p1.bias.cpu().double(), padding=1))
+    ref = F.relu(F.conv2d(mid, wr2, p2.bias.cpu().double(), padding=1) + x.double())
+    _close_f16w(y.permute(0, 3, 1, 2), ref, "fused basicblock %d" % c)
+
+
+@pytest.mark.parametrize("n,h,w", [(3, 128, 96), (1, 36, 52)])
+def test_fp16_weight_matrix_path_stem(cuda, n, h, w):
+    """stem conv 7x7 / 2 + BN + ReLU + max-pool: image pieces split when the patch is staged, weights converted once into LDS; fp32
+    image and uint8 frames (the table value is what gets split) give the same bits"""
+    f32 = torch.float32
+    x8 = (procedural_input("sp8.x", (n, h, w, 3), 0, 0.0, 1.0) * 255).round().clamp(0, 255).to(torch.uint8)
+    lut = torch.stack([(torch.arange(256, dtype=torch.float64) / 255 - m) / sd for m, sd in ((0.485, 0.229), (0.456, 0.224), (0.406, 0.225))]).float()
+    x = torch.stack([lut[c][x8[..., c].long()] for c in range(3)], -1)                 # (n, h, w, 3) normalised image
+    wt = procedural_input("sp.w", (64, 3, 7, 7), 0) * math.sqrt(3.0 / 147)
+    plan = ops.ConvPlan(wt, None, bn=FakeBN(64, "sp.bn"), stride=2, pad=3, act=1, dtype=f32, device=cuda, smallc=True)
+    with _enc_lib():
+        y = ops.stem_pool(x.to(cuda), plan)
+        y8 = ops.stem_pool_u8(x8.to(cuda), lut.to(cuda), plan)
+    assert torch.equal(y, y8)
+    wref = _h(plan.wgt.float().cpu()[:, :plan.K].reshape(64, 7, 7, 3).permute(0, 3, 1, 2)).double()
+    ref = F.max_pool2d(F.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), wref, plan.bias.cpu().double(), stride=2, padding=3)), 3, 2, 1)
+    _close_f16w(y.permute(0, 3, 1, 2), ref, "stem + pool")
+
+
+def test_fp16_weight_matrix_path_downsample_1x1(cuda):
+    """the 1x1 / stride-2 projection shortcut of a down-sampling BasicBlock (dense-row kernel, weights as the SECOND MFMA operand)"""
+    f32 = torch.float32
+    x = procedural_input("ds1.x", (2, 128, 18, 26), 0, -2.0, 2.0)
+    wt = procedural_input("ds1.w", (256, 128, 1, 1), 0) * math.sqrt(3.0 / 128)
+    plan = ops.ConvPlan(wt, None, bn=FakeBN(256, "ds1.bn"), stride=2, pad=0, act=0, dtype=f32, device=cuda)
+    with _enc_lib():
+        y = ops.conv2d(nhwc(x).to(cuda), plan)
+    wref = _h(plan.wgt.float().cpu()[:, :plan.K].reshape(256, 1, 1, 128).permute(0, 3, 1, 2)).double()
+    ref = F.conv2d(x.double(), wref, plan.bias.cpu().double(), stride=2)
+    _close_f16w(y.permute(0, 3, 1, 2), ref, "1x1 stride-2 shortcut")
+
+
 @pytest.mark.parametrize("k,rows", [(256, 20480), (512, 5120), (512, 1000), (384, 77), (256, 31)])
 def test_projection_chain_key_and_value_single_launch(cuda, k, rows):
     """cobevt_proj_chain_kv (csrc/proj_chain_k.hip): BN -> ReLU -> 1x1 conv K -> 128 (+ ray embedding on the key side) -> LayerNorm ->

@@ -212,7 +212,7 @@ def _u8_frames(n, agents=2, bgr=False):
     return out
 
 
-@pytest.mark.parametrize("mode", [torch.float32, torch.bfloat16, "fp32_split"])
+@pytest.mark.parametrize("mode", [torch.float32, torch.bfloat16, "fp32_split", "fp32_fast"])
 def test_uint8_ingest_equals_fp32_image_path_bit_for_bit(cuda, mode):
     """the model fed uint8 frames == the model fed the fp32 image the reference's pre-processor makes of those frames, bit for bit,
     in every compute mode (the stem looks the normalised value up in the pre-processor's own table); and the fp32-mode result is
