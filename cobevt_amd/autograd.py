@@ -10,6 +10,11 @@ The attention / LayerNorm / GELU kernels compute in fp32 (their inputs are cast 
 the convolution family follows a bf16 autocast region (bf16 storage, fp32 master weights and gradients).
 
 No CPU path: every Function raises on CPU tensors (lib.CobevtHipError) like the inference ops do.
+
+Library variant: every launch below goes to `_L.load("")`, the native library, whatever host.set_compute_dtype selected for INFERENCE
+(under "fp32_split" / "fp32_fast" the process-global variant would otherwise route train_rows.hip and attention_bwd.hip
+through split products while wgrad3 and the rest stayed exact - a mixed, untested training arithmetic).  The split matrix paths are
+inference modes; training is exact fp32 or bf16 autocast.
 """
 import ctypes
 
@@ -129,7 +134,7 @@ class WindowAttentionFn(torch.autograd.Function):
         out = torch.empty((out_rows, d), device=q.device, dtype=torch.float32)
         lse = torch.empty((batch, L, heads, nq), device=q.device, dtype=torch.float32)
         dims = _attn_dims(batch, heads, ldq, ldk, ldv, d, table, bias_L, qmap, kmap, omap)
-        rc = _L.load().cobevt_window_attention_lse(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(table), _p(mk), dims,
+        rc = _L.load("").cobevt_window_attention_lse(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(table), _p(mk), dims,
                                                    ctypes.c_float(scale), ctypes.c_float(drop_p), ctypes.c_uint(drop_seed), _p(seed_dev),
                                                    _stream())
         _L.check(rc, "cobevt_window_attention_lse")
@@ -158,7 +163,7 @@ class WindowAttentionFn(torch.autograd.Function):
             dims = _attn_dims(batch, heads, d, d, d, d, table, bias_L, qmap, kmap, omap)
         if bf16_mm:
             dims[0] |= 0x100 if USE_ATTN_KV2 else 0x300   # the five products on the bf16 matrix path (operands rounded as they are staged; softmax, sums fp32)
-        rc = _L.load().cobevt_window_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), _p(dl), _p(dq), _p(dk), _p(dv),
+        rc = _L.load("").cobevt_window_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), _p(dl), _p(dq), _p(dk), _p(dv),
                                                    _p(dbias), _p(table), _p(mk), dims, ctypes.c_float(scale), ctypes.c_float(drop_p),
                                                    ctypes.c_uint(drop_seed), _p(seed_dev), _stream())
         _L.check(rc, "cobevt_window_attention_bwd")
@@ -187,7 +192,7 @@ class WindowSelfAttentionFn(torch.autograd.Function):
         lse = torch.empty((batch, L, heads, nq), device=qkv.device, dtype=torch.float32)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         dims = _attn_dims(batch, heads, 3 * d, 3 * d, 3 * d, d, table, bias_L, qmap, kmap, omap)
-        rc = _L.load().cobevt_window_attention_lse(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(table), _p(mk), dims,
+        rc = _L.load("").cobevt_window_attention_lse(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(table), _p(mk), dims,
                                                    ctypes.c_float(scale), ctypes.c_float(drop_p), ctypes.c_uint(drop_seed), _p(seed_dev),
                                                    _stream())
         _L.check(rc, "cobevt_window_attention_lse")
@@ -208,7 +213,7 @@ class WindowSelfAttentionFn(torch.autograd.Function):
             dims[0] |= 0x100 if USE_ATTN_KV2 else 0x300
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         dq, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
-        rc = _L.load().cobevt_window_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), None, _p(dq), _p(dk), _p(dv),
+        rc = _L.load("").cobevt_window_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), None, _p(dq), _p(dk), _p(dv),
                                                    _p(dbias), _p(table), _p(mk), dims, ctypes.c_float(scale), ctypes.c_float(drop_p),
                                                    ctypes.c_uint(drop_seed), _p(seed_dev), _stream())
         _L.check(rc, "cobevt_window_attention_bwd")
@@ -264,7 +269,7 @@ class WindowAttentionHalfFn(torch.autograd.Function):
         lse = torch.empty((2, batch, L, heads, nq), device=q.device, dtype=torch.float32)
         dims = _attn_dims(batch, heads, q.stride(0), k.stride(0), v.stride(0), d, table, bias_L, qmap, kmap, omap)
         dims[0] = ops.BF16
-        rc = _L.load().cobevt_window_attention_lse(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(table), _p(mk), dims,
+        rc = _L.load("").cobevt_window_attention_lse(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(table), _p(mk), dims,
                                                    ctypes.c_float(scale), ctypes.c_float(0.0), ctypes.c_uint(0), None, _stream())
         _L.check(rc, "cobevt_window_attention_lse")
         if fused:
@@ -294,7 +299,7 @@ class WindowAttentionHalfFn(torch.autograd.Function):
         dbias = None if table is None else _zeros(table.shape, table.device, table.dtype)
         dims = _attn_dims(batch, heads, q.stride(0), k.stride(0), v.stride(0), d, table, bias_L, qmap, kmap, omap)
         dims[0] = ops.BF16 | 0x100 | (0x400 if USE_ATTN_D_SCRATCH else 0)
-        rc = _L.load().cobevt_window_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), None, _p(dq), _p(dk), _p(dv),
+        rc = _L.load("").cobevt_window_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), None, _p(dq), _p(dk), _p(dv),
                                                    _p(dbias), _p(table), _p(mk), dims, ctypes.c_float(scale), ctypes.c_float(0.0),
                                                    ctypes.c_uint(0), None, _stream())
         _L.check(rc, "cobevt_window_attention_bwd")
@@ -352,7 +357,7 @@ def attention_dropout_mask(batch, windows, heads, nq, nk, drop_p, drop_seed, dev
     """bool (batch, windows, heads, nq, nk): the keep mask the training kernels use for (drop_p, drop_seed) (test hook)"""
     keep = torch.empty((batch, windows, heads, nq, nk), device=device, dtype=torch.uint8)
     _need_cuda(keep)
-    rc = _L.load().cobevt_attention_dropout_mask(batch, windows, heads, nq, nk, ctypes.c_float(drop_p), ctypes.c_uint(drop_seed),
+    rc = _L.load("").cobevt_attention_dropout_mask(batch, windows, heads, nq, nk, ctypes.c_float(drop_p), ctypes.c_uint(drop_seed),
                                                  _p(keep), _stream())
     _L.check(rc, "cobevt_attention_dropout_mask")
     return keep.bool()
@@ -384,7 +389,7 @@ class LayerNormFn(torch.autograd.Function):
         else:
             C = x.shape[-1]
             y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
-            rc = _L.load().cobevt_layernorm_fwd_t(_p(x), _p(g), _p(b), _p(y), x.numel() // C, C, ctypes.c_float(eps),
+            rc = _L.load("").cobevt_layernorm_fwd_t(_p(x), _p(g), _p(b), _p(y), x.numel() // C, C, ctypes.c_float(eps),
                                                   _ints([ops.dcode(x.dtype), ops.dcode(y.dtype)]), _stream())
             _L.check(rc, "cobevt_layernorm_fwd_t")
         ctx.save_for_backward(x, g)
@@ -403,10 +408,10 @@ class LayerNormFn(torch.autograd.Function):
         dg = _zeros(C, x.device, torch.float32)
         db = _zeros(C, x.device, torch.float32)
         if x.dtype == torch.float32 and dy.dtype == torch.float32:
-            rc = _L.load().cobevt_layernorm_bwd(_p(x), _p(dy), _p(g), _p(dx), _p(dg), _p(db), rows, C, ctypes.c_float(ctx.eps), _stream())
+            rc = _L.load("").cobevt_layernorm_bwd(_p(x), _p(dy), _p(g), _p(dx), _p(dg), _p(db), rows, C, ctypes.c_float(ctx.eps), _stream())
             _L.check(rc, "cobevt_layernorm_bwd")
         else:
-            rc = _L.load().cobevt_layernorm_bwd_t(_p(x), _p(dy), _p(g), _p(dx), _p(dg), _p(db), rows, C, ctypes.c_float(ctx.eps),
+            rc = _L.load("").cobevt_layernorm_bwd_t(_p(x), _p(dy), _p(g), _p(dx), _p(dg), _p(db), rows, C, ctypes.c_float(ctx.eps),
                                                   _ints([ops.dcode(x.dtype), ops.dcode(dy.dtype), ops.dcode(dx.dtype)]), _stream())
             _L.check(rc, "cobevt_layernorm_bwd_t")
         return dx, dg, db, None, None
@@ -434,11 +439,11 @@ class GeluFn(torch.autograd.Function):
         x = x if x.is_contiguous() else x.contiguous()
         y = torch.empty_like(x)
         if x.dtype == torch.bfloat16:
-            rc = _L.load().cobevt_gelu_bf16(_p(x), None, _p(y), x.numel(), _stream())
+            rc = _L.load("").cobevt_gelu_bf16(_p(x), None, _p(y), x.numel(), _stream())
             _L.check(rc, "cobevt_gelu_bf16")
         else:
             x = _f32c(x, "gelu input")
-            rc = _L.load().cobevt_gelu(_p(x), None, _p(y), x.numel(), _stream())
+            rc = _L.load("").cobevt_gelu(_p(x), None, _p(y), x.numel(), _stream())
             _L.check(rc, "cobevt_gelu")
         ctx.save_for_backward(x)
         return y
@@ -450,10 +455,10 @@ class GeluFn(torch.autograd.Function):
         dy = dy if dy.is_contiguous() else dy.contiguous()
         dx = torch.empty_like(x)
         if x.dtype == torch.bfloat16:
-            rc = _L.load().cobevt_gelu_bf16(_p(x), _p(dy), _p(dx), x.numel(), _stream())
+            rc = _L.load("").cobevt_gelu_bf16(_p(x), _p(dy), _p(dx), x.numel(), _stream())
             _L.check(rc, "cobevt_gelu_bf16")
         else:
-            rc = _L.load().cobevt_gelu(_p(x), _p(dy), _p(dx), x.numel(), _stream())
+            rc = _L.load("").cobevt_gelu(_p(x), _p(dy), _p(dx), x.numel(), _stream())
             _L.check(rc, "cobevt_gelu")
         return dx
 
@@ -481,7 +486,7 @@ def column_sum(rows2d):
     _need_cuda(rows2d)
     m, c = rows2d.shape
     acc = torch.empty(c, device=rows2d.device, dtype=torch.float64)
-    lib = _L.load()
+    lib = _L.load("")
     if c % 8:
         out = torch.empty(c, device=rows2d.device, dtype=torch.float32)
         _L.check(lib.cobevt_channel_sums(_p(rows2d), None, _p(acc), None, None, None, 0, ops.dcode(rows2d.dtype), m, c, _stream()),
@@ -599,7 +604,7 @@ def conv_weight_rows(weight, dtype, fwd=True, dgrad=False):
     rf = torch.empty((cout, kpf), device=w.device, dtype=dtype) if fwd else None
     rd = torch.empty((cin, kpd), device=w.device, dtype=dtype) if dgrad else None
     dims = _ints([ops.dcode(dtype), cout, cin, kh, kw, kpf, kpd])
-    _L.check(_L.load().cobevt_conv_weight_rows(_p(w), _p(rf), _p(rd), dims, _stream()), "cobevt_conv_weight_rows")
+    _L.check(_L.load("").cobevt_conv_weight_rows(_p(w), _p(rf), _p(rd), dims, _stream()), "cobevt_conv_weight_rows")
     return rf, rd
 
 
@@ -618,7 +623,7 @@ def _igemm_rows(x, w2, cout, cin, kh, kw, bias, stride, pad, ho, wo):
     out = torch.empty((n, ho, wo, cout), device=x.device, dtype=w2.dtype)
     dims = _ints([ops.BF16 if bf16 else ops.FP32, n, h, w, cin, ho, wo, cout, kh, kw, stride, pad, K, kpad, 0, 0, 0, 0, ho, wo, smallc])
     b = None if bias is None else _f32c(bias.detach().float(), "bias")
-    rc = _L.load().cobevt_conv2d_nhwc(_p(x), _p(w2), _p(b), None, None, None, _p(klut), _p(out), dims, _stream())
+    rc = _L.load("").cobevt_conv2d_nhwc(_p(x), _p(w2), _p(b), None, None, None, _p(klut), _p(out), dims, _stream())
     _L.check(rc, "cobevt_conv2d_nhwc")
     return out
 
@@ -646,7 +651,7 @@ def conv3_weight_operand(weight, variant, dgrad):
         op = torch.empty(((o + 127) // 128 * 4, i // 64, 9, 4, 64, 8), device=w.device, dtype=torch.bfloat16)
     else:
         op = torch.empty((o, i // 64, 9, 64), device=w.device, dtype=torch.bfloat16)
-    _L.check(_L.load().cobevt_conv3_weight_operands(_p(w), _p(op) if variant else None, None if variant else _p(op),
+    _L.check(_L.load("").cobevt_conv3_weight_operands(_p(w), _p(op) if variant else None, None if variant else _p(op),
                                                     _ints([cout, cin, int(dgrad)]), _stream()), "cobevt_conv3_weight_operands")
     return op
 
@@ -664,7 +669,7 @@ def conv3_weight_operand_pair(weight, var_f, var_d):
     d = buf(cin, cout, var_d) if var_d >= 0 else None
     outs = (ctypes.c_void_p * 4)(f.data_ptr() if var_f else None, None if var_f else f.data_ptr(),
                                  d.data_ptr() if (d is not None and var_d) else None, d.data_ptr() if (d is not None and not var_d) else None)
-    _L.check(_L.load().cobevt_conv3_weight_operands2(_p(w), outs, _ints([cout, cin]), _stream()), "cobevt_conv3_weight_operands2")
+    _L.check(_L.load("").cobevt_conv3_weight_operands2(_p(w), outs, _ints([cout, cin]), _stream()), "cobevt_conv3_weight_operands2")
     return f, d
 
 
@@ -677,11 +682,11 @@ def _conv3_strips(x, operand, variant, cout, bias, stride):
     b = None if bias is None else _f32c(bias.detach().float(), "bias")
     if variant:
         dims = _ints([ops.BF16, n, h, w, cin, cout, 0, 0, 0, 64, (cout + 127) // 128 * 128, variant, stride])
-        rc = _L.load().cobevt_conv3x3_wfrag_nhwc(_p(x), _p(operand), _p(b), None, _p(out), dims, _stream())
+        rc = _L.load("").cobevt_conv3x3_wfrag_nhwc(_p(x), _p(operand), _p(b), None, _p(out), dims, _stream())
         _L.check(rc, "cobevt_conv3x3_wfrag_nhwc")
     else:
         dims = _ints([ops.BF16, n, h, w, cin, cout, 0, 0, 0, 64])
-        rc = _L.load().cobevt_conv3x3_nhwc(_p(x), _p(operand), _p(b), None, _p(out), dims, _stream())
+        rc = _L.load("").cobevt_conv3x3_nhwc(_p(x), _p(operand), _p(b), None, _p(out), dims, _stream())
         _L.check(rc, "cobevt_conv3x3_nhwc")
     return out
 
@@ -697,7 +702,7 @@ def linear_weight_frags(weight2d, forward=True, transposed=False):
     np_, kp = (n + 127) // 128 * 128, (k + 127) // 128 * 128
     f = torch.empty((np_ // 32, kp // 16, 64, 8), device=w.device, dtype=torch.bfloat16) if forward else None
     t = torch.empty((kp // 32, np_ // 16, 64, 8), device=w.device, dtype=torch.bfloat16) if transposed else None
-    _L.check(_L.load().cobevt_linear_weight_frags(_p(w), _p(f), _p(t), _ints([n, k]), _stream()), "cobevt_linear_weight_frags")
+    _L.check(_L.load("").cobevt_linear_weight_frags(_p(w), _p(f), _p(t), _ints([n, k]), _stream()), "cobevt_linear_weight_frags")
     return f, t
 
 
@@ -707,7 +712,7 @@ def _rows_gemm(x2d, frag, n_out, k_in, bias):
     out = torch.empty((m, n_out), device=x2d.device, dtype=torch.bfloat16)
     b = None if bias is None else _f32c(bias.detach().float(), "bias")
     d3 = (ctypes.c_long * 14)(ops.BF16, m, n_out, k_in, k_in, 0, 0, 0, 1, m, 1, m, 1, 32)
-    rc = _L.load().cobevt_linear_rows_small_k(_p(x2d), _p(frag), _p(b), None, None, None, _p(out), d3, ctypes.c_float(0.0), _stream())
+    rc = _L.load("").cobevt_linear_rows_small_k(_p(x2d), _p(frag), _p(b), None, None, None, _p(out), d3, ctypes.c_float(0.0), _stream())
     _L.check(rc, "cobevt_linear_rows_small_k")
     return out
 
@@ -779,7 +784,7 @@ def blocked_operands(xl, dyl, k, pad, stride=1, mode=0):
         return xb, db, hp, nxb, ndb
     xb = torch.empty((n, hp, nxb, planes, cin, 8), device=xl.device, dtype=xl.dtype)
     db = torch.empty((n, ho, ndb, 1, cout, 8), device=xl.device, dtype=xl.dtype)
-    lib = _L.load()
+    lib = _L.load("")
     _L.check(lib.cobevt_wgrad_block_operand(_p(xl), _p(xb), _ints([n, h, w, cin, hp, nxb, pad, pad, planes, sx]), _stream()),
              "cobevt_wgrad_block_operand")
     _L.check(lib.cobevt_wgrad_block_operand(_p(dyl), _p(db), _ints([n, ho, wo, cout, ho, ndb, 0, 0, 1, 1]), _stream()),
@@ -859,21 +864,21 @@ class Conv2dFn(torch.autograd.Function):
                 dx = _igemm_rows(g, rows_d, cin, cout, kh, kw, None, 1, kh - 1 - pad, h, w).permute(0, 3, 1, 2)
         chunks3 = -1
         if ctx.needs_input_grad[1] and USE_WGRAD3 and xl.dtype == torch.bfloat16 and kh == 3 and kw == 3 and stride == 1 and pad == 1:
-            chunks3 = _L.load().cobevt_conv_wgrad3_chunks(_ints([n, h, w, cin, cout]))
+            chunks3 = _L.load("").cobevt_conv_wgrad3_chunks(_ints([n, h, w, cin, cout]))
         chunks1 = -1
         if ctx.needs_input_grad[1] and USE_WGRAD3 and xl.dtype == torch.bfloat16 and kh == 1 and kw == 1 and stride == 1 and pad == 0:
-            chunks1 = _L.load().cobevt_linear_wgrad_chunks((ctypes.c_long * 3)(n * h * w, cin, cout))
+            chunks1 = _L.load("").cobevt_linear_wgrad_chunks((ctypes.c_long * 3)(n * h * w, cin, cout))
         if chunks1 > 0:
             # a dense projection: dy^T x over the rows (csrc/wgrad3.hip), dw written, partial sums in a scratch buffer
             dw = torch.empty((cout, cin, 1, 1), device=dyl.device, dtype=torch.float32)
             scratch = torch.empty((chunks1, cout * cin), device=dyl.device, dtype=torch.float32)
-            rc = _L.load().cobevt_linear_wgrad(_p(xl), _p(dyl), _p(dw), _p(scratch), (ctypes.c_long * 4)(n * h * w, cin, cout, chunks1), _stream())
+            rc = _L.load("").cobevt_linear_wgrad(_p(xl), _p(dyl), _p(dw), _p(scratch), (ctypes.c_long * 4)(n * h * w, cin, cout, chunks1), _stream())
             _L.check(rc, "cobevt_linear_wgrad")
         elif chunks3 > 0:
             # straight from the channels-last maps (csrc/wgrad3.hip): dw is written, partial sums in a scratch buffer
             dw = torch.empty((cout, cin, kh, kw), device=dyl.device, dtype=torch.float32)
             scratch = torch.empty((chunks3, cout * cin * 9), device=dyl.device, dtype=torch.float32)
-            rc = _L.load().cobevt_conv_wgrad3(_p(xl), _p(dyl), _p(dw), _p(scratch), _ints([n, h, w, cin, cout, chunks3]), _stream())
+            rc = _L.load("").cobevt_conv_wgrad3(_p(xl), _p(dyl), _p(dw), _p(scratch), _ints([n, h, w, cin, cout, chunks3]), _stream())
             _L.check(rc, "cobevt_conv_wgrad3")
         elif ctx.needs_input_grad[1]:
             dw = _zeros((cout, cin, kh, kw), dyl.device, torch.float32)
@@ -883,11 +888,11 @@ class Conv2dFn(torch.autograd.Function):
             if mode is not None:
                 x_blk, dy_blk, hp, nxb, ndb = blocked_operands(xl, dyl, kh, pad, stride, mode)
                 dims = _ints([n, hp, nxb, cin, ho, ndb, cout, kh, stride, mode])
-                rc = _L.load().cobevt_conv_wgrad_blocked(_p(x_blk), _p(dy_blk), _p(dw), dims, _stream())
+                rc = _L.load("").cobevt_conv_wgrad_blocked(_p(x_blk), _p(dy_blk), _p(dw), dims, _stream())
                 _L.check(rc, "cobevt_conv_wgrad_blocked")
             else:
                 dims = _ints([n, h, w, cin, ho, wo, cout, kh, stride, pad, ops.BF16 if xl.dtype == torch.bfloat16 else ops.FP32])
-                rc = _L.load().cobevt_conv_wgrad(_p(xl), _p(dyl), _p(dw), dims, _stream())
+                rc = _L.load("").cobevt_conv_wgrad(_p(xl), _p(dyl), _p(dw), dims, _stream())
                 _L.check(rc, "cobevt_conv_wgrad")
         if has_bias and ctx.needs_input_grad[2]:
             db = column_sum(dyl.reshape(-1, cout)).to(ctx.bias_dtype)
@@ -937,7 +942,7 @@ class BatchNormActFn(torch.autograd.Function):
         n, h, w, c = xl.shape
         rows = n * h * w
         dev = xl.device
-        lib = _L.load()
+        lib = _L.load("")
         dt = ops.dcode(xl.dtype)
         scale, shift = torch.empty(c, device=dev), torch.empty(c, device=dev)
         mean, rstd = torch.empty(c, device=dev), torch.empty(c, device=dev)
@@ -983,7 +988,7 @@ class BatchNormActFn(torch.autograd.Function):
         f = torch.empty((2, c), device=xl.device, dtype=torch.float32) if (has_g or has_b) else None
         dx = torch.empty_like(xl)
         dres = torch.empty_like(xl) if has_res else None
-        lib = _L.load()
+        lib = _L.load("")
         _L.check(lib.cobevt_bn_backward(_p(xl), _p(y), _p(dyl), _p(mean), _p(rstd), _p(g), _p(acc), _p(f), _p(_scratch(c, xl.device)),
                                         _SCRATCH_BLOCKS, _p(dx), _p(dres), ops.dcode(xl.dtype), rows, c, act, training, _stream()),
                  "cobevt_bn_backward")
@@ -1023,7 +1028,7 @@ class GroupMeanFn(torch.autograd.Function):
         b, n = x.shape[:2]
         inner = x.numel() // (b * n)
         out = torch.empty((b,) + tuple(x.shape[2:]), device=x.device, dtype=x.dtype)
-        _L.check(_L.load().cobevt_group_mean(_p(x), _p(out), ops.dcode(x.dtype), b, n, inner, 0, _stream()), "cobevt_group_mean")
+        _L.check(_L.load("").cobevt_group_mean(_p(x), _p(out), ops.dcode(x.dtype), b, n, inner, 0, _stream()), "cobevt_group_mean")
         ctx.shape = tuple(x.shape)
         ctx.dtype = x.dtype
         return out
@@ -1034,7 +1039,7 @@ class GroupMeanFn(torch.autograd.Function):
         dy = dy.to(ctx.dtype)
         dy = dy if dy.is_contiguous() else dy.contiguous()
         dx = torch.empty(ctx.shape, device=dy.device, dtype=dy.dtype)
-        _L.check(_L.load().cobevt_group_mean(_p(dy), _p(dx), ops.dcode(dy.dtype), b, n, dy.numel() // b, 1, _stream()), "cobevt_group_mean")
+        _L.check(_L.load("").cobevt_group_mean(_p(dy), _p(dx), ops.dcode(dy.dtype), b, n, dy.numel() // b, 1, _stream()), "cobevt_group_mean")
         return dx
 
 
@@ -1072,7 +1077,7 @@ class FaxBevQueryFn(torch.autograd.Function):
         d = w.shape[0]
         out = torch.empty((B, n, H, W, d), device=grid.device, dtype=torch.float32)
         dims = _ints([B, n, H, W, d, int(round_bf16), kd, int(per_batch)])
-        _L.check(_L.load().cobevt_fax_bev_query_train(_p(grid), _p(w), _p(bb), _p(c), _p(x), _p(out), dims, _stream()), "cobevt_fax_bev_query_train")
+        _L.check(_L.load("").cobevt_fax_bev_query_train(_p(grid), _p(w), _p(bb), _p(c), _p(x), _p(out), dims, _stream()), "cobevt_fax_bev_query_train")
         ctx.save_for_backward(grid, w, bb, c)
         ctx.cfg = (B, n, H, W, d, int(round_bf16), kd, int(per_batch), tuple(weight.shape), bias is not None, x is not None)
         return out
@@ -1086,7 +1091,7 @@ class FaxBevQueryFn(torch.autograd.Function):
         dw = _zeros((d, kd), dq.device, torch.float32)
         db = _zeros(d, dq.device, torch.float32) if has_bias else None
         dc = _zeros((B * n, d), dq.device, torch.float32)
-        _L.check(_L.load().cobevt_fax_bev_query_train_bwd(_p(grid), _p(w), _p(bb), _p(c), _p(dq), _p(dx), _p(dw), _p(db), _p(dc),
+        _L.check(_L.load("").cobevt_fax_bev_query_train_bwd(_p(grid), _p(w), _p(bb), _p(c), _p(dq), _p(dx), _p(dw), _p(db), _p(dc),
                                                           _ints([B, n, H, W, d, rb, kd, per_batch]), _stream()), "cobevt_fax_bev_query_train_bwd")
         return dx, None, dw.reshape(wshape), db, dc, None, None
 
@@ -1132,7 +1137,7 @@ class MaxPool3x3s2Fn(torch.autograd.Function):
         n, h, w, c = xl.shape
         dyl = _nhwc(dy.to(xl.dtype))
         dx = torch.empty_like(xl)
-        _L.check(_L.load().cobevt_maxpool3x3s2_bwd_t(_p(xl), _p(dyl), _p(dx), ops.dcode(xl.dtype), n, h, w, c, _stream()),
+        _L.check(_L.load("").cobevt_maxpool3x3s2_bwd_t(_p(xl), _p(dyl), _p(dx), ops.dcode(xl.dtype), n, h, w, c, _stream()),
                  "cobevt_maxpool3x3s2_bwd_t")
         return dx.permute(0, 3, 1, 2)
 
@@ -1151,7 +1156,7 @@ def _pixel_unshuffle(tl, inverse):
     else:
         ho, wo, cc = h // 2, w // 2, c
         out = torch.empty((n, ho, wo, 4 * c), device=tl.device, dtype=tl.dtype)
-    _L.check(_L.load().cobevt_pixel_unshuffle2_nhwc(_p(tl), _p(out), ops.dcode(tl.dtype), n, ho, wo, cc, int(inverse), _stream()),
+    _L.check(_L.load("").cobevt_pixel_unshuffle2_nhwc(_p(tl), _p(out), ops.dcode(tl.dtype), n, ho, wo, cc, int(inverse), _stream()),
              "cobevt_pixel_unshuffle2_nhwc")
     return out
 
@@ -1184,7 +1189,7 @@ def _upsample2(tl, backward):
         out = torch.empty((n, h, w, c), device=tl.device, dtype=tl.dtype)
     else:
         out = torch.empty((n, 2 * h, 2 * w, c), device=tl.device, dtype=tl.dtype)
-    _L.check(_L.load().cobevt_upsample_nearest2_nhwc(_p(tl), _p(out), ops.dcode(tl.dtype), n, h, w, c, int(backward), _stream()),
+    _L.check(_L.load("").cobevt_upsample_nearest2_nhwc(_p(tl), _p(out), ops.dcode(tl.dtype), n, h, w, c, int(backward), _stream()),
              "cobevt_upsample_nearest2_nhwc")
     return out
 
@@ -1235,7 +1240,7 @@ class SttfWarpFn(torch.autograd.Function):
         h, w, c = shape[-3:]
         dout = _f32c(dout.float(), "dout")
         dx = torch.zeros(shape, device=dout.device, dtype=torch.float32)
-        _L.check(_L.load().cobevt_sttf_warp_bwd(_p(dout), _p(tm), _p(record_len), _p(dx), b, l, h, w, c, ctypes.c_float(ratio),
+        _L.check(_L.load("").cobevt_sttf_warp_bwd(_p(dout), _p(tm), _p(record_len), _p(dx), b, l, h, w, c, ctypes.c_float(ratio),
                                                 ctypes.c_float(rate), _stream()), "cobevt_sttf_warp_bwd")
         return dx.to(dt), None, None, None, None, None
 
@@ -1264,7 +1269,7 @@ class WeightedCrossEntropyFn(torch.autograd.Function):
         n, c, h, w = x.shape
         dx = torch.empty_like(x)
         up = dloss.reshape(1).to(torch.float32).contiguous()
-        rc = _L.load().cobevt_weighted_cross_entropy_bwd(_p(x), _p(y), _p(wt), _p(stats), _p(up), _p(dx), n, c, h * w, _stream())
+        rc = _L.load("").cobevt_weighted_cross_entropy_bwd(_p(x), _p(y), _p(wt), _p(stats), _p(up), _p(dx), n, c, h * w, _stream())
         _L.check(rc, "cobevt_weighted_cross_entropy_bwd")
         return dx, None, None
 
@@ -1289,7 +1294,7 @@ class SwishFn(torch.autograd.Function):
         if not (xc.is_contiguous() or (xc.dim() == 4 and xc.is_contiguous(memory_format=torch.channels_last))):
             xc = xc.contiguous()
         out = torch.empty_like(xc)                          # same strides
-        _L.check(_L.load().cobevt_swish(_p(xc), None, _p(out), ops.dcode(xc.dtype), xc.numel(), _stream()), "cobevt_swish")
+        _L.check(_L.load("").cobevt_swish(_p(xc), None, _p(out), ops.dcode(xc.dtype), xc.numel(), _stream()), "cobevt_swish")
         ctx.save_for_backward(xc)
         return out
 
@@ -1300,7 +1305,7 @@ class SwishFn(torch.autograd.Function):
         if g.stride() != xc.stride():                       # bring the gradient into x's memory order
             g = torch.empty_like(xc).copy_(g)
         dx = torch.empty_like(xc)
-        _L.check(_L.load().cobevt_swish(_p(xc), _p(g), _p(dx), ops.dcode(xc.dtype), xc.numel(), _stream()), "cobevt_swish")
+        _L.check(_L.load("").cobevt_swish(_p(xc), _p(g), _p(dx), ops.dcode(xc.dtype), xc.numel(), _stream()), "cobevt_swish")
         return dx
 
 
@@ -1330,7 +1335,7 @@ class DepthwiseConvFn(torch.autograd.Function):
         zero = _zeros(c, xl.device, torch.float32)
         out = torch.empty((n, ho, wo, c), device=xl.device, dtype=xl.dtype)
         dims = _ints([ops.dcode(xl.dtype), n, h, w, c, k, stride, pad[0], pad[0], ho, wo, 0])
-        _L.check(_L.load().cobevt_depthwise_conv_nhwc(_p(xl), _p(taps), _p(zero), _p(out), dims, _stream()), "cobevt_depthwise_conv_nhwc")
+        _L.check(_L.load("").cobevt_depthwise_conv_nhwc(_p(xl), _p(taps), _p(zero), _p(out), dims, _stream()), "cobevt_depthwise_conv_nhwc")
         ctx.save_for_backward(xl, taps, zero)
         ctx.cfg = (int(stride), (int(pad[0]), int(pad[1])), k, weight.dtype)
         return out.permute(0, 3, 1, 2)
@@ -1343,7 +1348,7 @@ class DepthwiseConvFn(torch.autograd.Function):
         n, h, w, c = xl.shape
         dyl = _nhwc(dy.to(xl.dtype))
         ho, wo = dyl.shape[1:3]
-        lib = _L.load()
+        lib = _L.load("")
         dx = dw = None
         if ctx.needs_input_grad[0]:
             g = dyl
@@ -1391,7 +1396,7 @@ class ResizeBilinearFn(torch.autograd.Function):
         n, h, w, c = ctx.shape
         dyl = _nhwc(dy.to(ctx.dt))
         dx = torch.zeros((n, h, w, c), device=dyl.device, dtype=torch.float32)
-        _L.check(_L.load().cobevt_resize_bilinear_bwd(_p(dyl), _p(dx), ops.dcode(dyl.dtype), n, h, w, c, dyl.shape[1], dyl.shape[2], _stream()),
+        _L.check(_L.load("").cobevt_resize_bilinear_bwd(_p(dyl), _p(dx), ops.dcode(dyl.dtype), n, h, w, c, dyl.shape[1], dyl.shape[2], _stream()),
                  "cobevt_resize_bilinear_bwd")
         return dx.to(ctx.dt).permute(0, 3, 1, 2), None, None
 
@@ -1419,7 +1424,7 @@ class SigmoidFocalLossFn(torch.autograd.Function):
         nl = label.shape[1]
         scratch = torch.empty(2 * n * ((hw + 2047) // 2048), device=pred.device, dtype=torch.float32)
         out = torch.empty(3, device=pred.device, dtype=torch.float32)
-        rc = _L.load().cobevt_sigmoid_focal_loss(_p(p32), _p(label), _p(vis), _p(masks), _p(scratch), _p(out), n, c, nl, hw, min_visibility,
+        rc = _L.load("").cobevt_sigmoid_focal_loss(_p(p32), _p(label), _p(vis), _p(masks), _p(scratch), _p(out), n, c, nl, hw, min_visibility,
                                                  ctypes.c_float(alpha), ctypes.c_float(gamma), int(soft), _stream())
         _L.check(rc, "cobevt_sigmoid_focal_loss")
         ctx.save_for_backward(p32, label, vis, masks, out)
@@ -1433,7 +1438,7 @@ class SigmoidFocalLossFn(torch.autograd.Function):
         n, c, hw = p32.shape
         dp = torch.empty_like(p32)
         gs = g.reshape(1).float().contiguous()
-        rc = _L.load().cobevt_sigmoid_focal_loss_bwd(_p(p32), _p(label), _p(vis), _p(masks), _p(out), _p(gs), _p(dp), n, c, label.shape[1], hw,
+        rc = _L.load("").cobevt_sigmoid_focal_loss_bwd(_p(p32), _p(label), _p(vis), _p(masks), _p(out), _p(gs), _p(dp), n, c, label.shape[1], hw,
                                                      min_visibility, ctypes.c_float(alpha), ctypes.c_float(gamma), int(soft), _stream())
         _L.check(rc, "cobevt_sigmoid_focal_loss_bwd")
         return dp, None, None, None, None
@@ -1456,7 +1461,7 @@ class PairwiseWarpFn(torch.autograd.Function):
         (n, h, w, c), l, dr, ds = ctx.cfg
         dnb = dnb.contiguous()
         dx = torch.zeros((n, h, w, c), device=dnb.device, dtype=torch.float32)
-        rc = _L.load().cobevt_pairwise_warp_bwd(_p(dnb), _p(pairwise), _p(record_len), _p(dx), ops.dcode(dnb.dtype), record_len.shape[0], l,
+        rc = _L.load("").cobevt_pairwise_warp_bwd(_p(dnb), _p(pairwise), _p(record_len), _p(dx), ops.dcode(dnb.dtype), record_len.shape[0], l,
                                                 h, w, c, ctypes.c_float(dr), ctypes.c_float(ds), _stream())
         _L.check(rc, "cobevt_pairwise_warp_bwd")
         return dx.to(dnb.dtype), None, None, None, None, None

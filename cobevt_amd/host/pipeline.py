@@ -15,6 +15,8 @@ Both take the batch through STATIC device buffers (`runner.static_batch`): a cap
 `step(batch)` first copies the caller's tensors into them (skipped for tensors that already ARE the static buffers - a
 data loader can write into `runner.static_batch[...]` directly).  Multi-GPU (`rank`, `world`): see cobevt_amd/dist.py.
 """
+import os
+
 import torch
 
 from .. import dist as cdist
@@ -340,27 +342,56 @@ class PipelinedCorpBEVT(_RunnerBase):
             # stage 3 with 32 workgroups 1.89 ms, behind it 1.95 (32) / 2.00 (128) / 2.03 (512), behind stage 2 2.02
             if self.host_ingest:
                 nxt = (q + 1) % D
-                ops.host_fetch(self.pinned[nxt], self.slots[nxt]["inputs"], blocks=32)
+                ops.host_fetch(self.pinned[nxt], self.slots[nxt]["inputs"], blocks=16)     # 16: profiles/r06_ingest_split_ab.txt (0.918 vs 0.888 with 32)
+
+        # A/B knob (tools only; unset = the placement above): COBEVT_INGEST_PLAN="s3f:0.5,s2f:0.5" pulls byte shares of the frame at
+        # several points of the step - s3f / s3b = in front of / behind stage 3 on its stream, s2f / s2b the same for stage 2, s1f in
+        # front of the encoder; COBEVT_INGEST_BLOCKS = workgroups per pull (profiles/r06_ingest_split_ab.txt)
+        plan_env = os.environ.get("COBEVT_INGEST_PLAN") if self.host_ingest else None
+        shares = {}
+        if plan_env:
+            nxt = (q + 1) % D
+            src8, dst8 = self.pinned[nxt].view(-1).view(torch.uint8), self.slots[nxt]["inputs"].view(-1).view(torch.uint8)
+            total, lo = src8.numel(), 0
+            items = [(t.split(":")[0], float(t.split(":")[1])) for t in plan_env.split(",")]
+            for j, (pos, frac) in enumerate(items):
+                hi = total if j == len(items) - 1 else min(total, (lo + int(total * frac)) // 4096 * 4096)
+                shares.setdefault(pos, []).append((lo, hi))
+                lo = hi
+            nblk = int(os.environ.get("COBEVT_INGEST_BLOCKS", "16"))
+
+            def pull_at(pos):
+                for a, b in shares.get(pos, []):
+                    if b > a:
+                        ops.host_fetch(src8[a:b], dst8[a:b], blocks=nblk)
+        else:
+            def pull_at(pos):
+                if pos == "s3f":
+                    pull()
         # Capture order = dispatch order of the graph's roots, and it matters: oldest frame first (stage 3, stage 2, then the encoder)
         # 640-650 frames/s on the box of profiles/r05_ab_same_job.txt, stage 2 before stage 3 the same (641-657), the encoder first
         # 579-586 (its full-chip workgroups then starve the later stages' small dependent launches, whose chains end up as the step's tail)
         if D == 3:
             s2, s3 = self.streams
             with torch.cuda.stream(s3):
-                pull()
+                pull_at("s3f")
                 out = self._s3(q)
+                pull_at("s3b")
             with torch.cuda.stream(s2):                                       # frame i-1 -> its features into slot q
+                pull_at("s2f")
                 self.model.fax_query(self._state((q - 1) % D), joined=False, out=self.f[q])
+                pull_at("s2b")
         else:
             s2a, s2b, s3 = self.streams
             with torch.cuda.stream(s3):
-                pull()
+                pull_at("s3f")
                 out = self._s3(q)
             with torch.cuda.stream(s2b):                                      # frame i-2: K/V from two steps ago, x from one
                 self.model.fax_query(self._state((q - 2) % D), joined=False, levels=(1, nlev), x=self.x[(q - 1) % D],
                                      out=self.f[q])
             with torch.cuda.stream(s2a):                                      # frame i-1
                 self.model.fax_query(self._state((q - 1) % D), joined=False, levels=(0, 1), out=self.x[q])
+        pull_at("s1f")
         self._s1(q)
         for s in self.streams:
             main.wait_stream(s)
@@ -428,8 +459,11 @@ class HostFrameFeeder(object):
     (2.22 ms instead of 1.64) in bench.py's process, free in a process with fewer streams, worse with a high-priority stream or
     more queues; a replay waiting for a one-step-old event was held back another ~0.2 ms.  Inside the graph there is nothing to
     collide with.  Only the images come from the ring: camera matrices / poses / record_len (a few hundred bytes, still read by
-    later pipeline stages of running steps) are copied in stream order right before their step - pass them pinned as well, or
-    those copies turn synchronous.  uint8 frames (`ResnetEncoder.set_rgb_normalisation`) make a 5-agent frame 15.7 MB instead of 63."""
+    later pipeline stages of running steps) are copied in stream order right before their step.  put() copies THEM too - into a
+    feeder-owned ring of pinned host sets, one per frame handed over (queued by reference, a loader that reuses its
+    buffers for the next frame overwrote frame k's poses before step(k) uploaded them, and could race the pending asynchronous
+    copy after it) - so the caller may reuse every buffer of `host_batch` as soon as put() returns.  A set is rewritten only after
+    the event behind the step that uploaded it.  uint8 frames (`ResnetEncoder.set_rgb_normalisation`) make a 5-agent frame 15.7 MB instead of 63."""
 
     def __init__(self, runner):
         if not isinstance(runner, PipelinedCorpBEVT) or not runner.host_ingest:
@@ -440,6 +474,30 @@ class HostFrameFeeder(object):
         self.queue = []                               # small tensors of the frames handed over and not yet stepped
         self.n_put = 0
         self.pulled = False                           # did the previous step's graph pull the frame the next step() computes on?
+        self.small_sets = [None] * (2 * runner.depth)  # feeder-owned pinned copies of the small tensors, one set per frame handed over
+        self.small_used = [None] * (2 * runner.depth)  # event behind the step that uploaded the set
+
+    def _stage_small(self, host_batch):
+        """the frame's small tensors copied into the next pinned set of the ring (non-tensors pass through)"""
+        i = self.n_put % len(self.small_sets)
+        if self.small_used[i] is not None:
+            self.small_used[i].synchronize()          # the step that uploaded this set has read it
+            self.small_used[i] = None
+        cur = self.small_sets[i] or {}
+        out = {}
+        for k in self.r.slots[0]:
+            if k == "inputs":
+                continue
+            v = host_batch[k]
+            if torch.is_tensor(v):
+                buf = cur.get(k)
+                if not torch.is_tensor(buf) or buf.shape != v.shape or buf.dtype != v.dtype:
+                    buf = torch.empty(v.shape, dtype=v.dtype, pin_memory=torch.cuda.is_available())
+                buf.copy_(v)
+                v = buf
+            out[k] = v
+        self.small_sets[i] = out
+        return i, out
 
     def host_slot(self):
         """the pinned buffer the NEXT put() frame belongs in - a loader may decode straight into it and pass it to put().
@@ -468,14 +526,15 @@ class HostFrameFeeder(object):
             self.fetched[slot] = torch.cuda.Event()
             self.fetched[slot].record()               # the put() that rewrites this ring slot (`depth` frames on) waits for this read
             self.pulled = True
-        self.queue.append({k: host_batch[k] for k in r.slots[0] if k != "inputs"})
+        self.queue.append(self._stage_small(host_batch))
         self.n_put += 1
 
     def step(self):
         r = self.r
         if not self.queue:
             raise CobevtHipError("HostFrameFeeder.step: put() a frame first")
-        small = self.queue.pop(0)
+        small_set, small = self.queue.pop(0)
+        small = dict(small)
         q = r.i % r.depth
         late = not self.pulled
         if late:      # the first frame, or one put() after the previous step was launched: that step's pull read the slot too early.
@@ -487,6 +546,7 @@ class HostFrameFeeder(object):
         ev = torch.cuda.Event()
         ev.record()
         self.fetched[(q + 1) % r.depth] = ev                        # this step pulled pinned slot q + 1
+        self.small_used[small_set] = ev                             # ... and uploaded this set of small tensors
         if late:
             self.fetched[q] = ev
         return out

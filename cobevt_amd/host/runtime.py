@@ -83,6 +83,28 @@ def structure_epoch():
     return _STRUCTURE_EPOCH
 
 
+def _install_structure_hooks():
+    """Every way a module can gain or REPLACE a tensor or a child moves the epoch (AgentCountPlans lists the model's
+    tensors once, and a replaced Parameter object - `m.weight = nn.Parameter(..)`, register_buffer, pruning / parametrize, BN fusing -
+    kept the old tensor in that list, so the fingerprint stayed equal and a captured graph kept replaying the old weights).
+    torch's global registration hooks fire from Module.register_parameter / register_buffer / register_module AND from
+    Module.__setattr__ when a Parameter, a registered buffer or a child module is assigned, on every nn.Module - the parameter
+    containers (nn.Linear, nn.Conv2d, ...) inside the HIP modules included.  HipModule._apply covers conversions that swap Parameter
+    objects (torch.__future__.set_overwrite_module_params_on_conversion).  In-place updates are seen through version counters and
+    `.data` writes are documented under HipModule.invalidate_plans."""
+    import torch.nn.modules.module as _m
+
+    def bump(*_args):
+        bump_structure_epoch()
+        return None
+    for reg in ("register_module_parameter_registration_hook", "register_module_buffer_registration_hook",
+                "register_module_module_registration_hook"):
+        getattr(_m, reg)(bump)
+
+
+_install_structure_hooks()
+
+
 class GraphOwner(object):
     """Base of every object that owns captured HIP graphs (the runners of host/pipeline.py, host/train_graph.py).  Destroying a
     graph while a replay of it is still running on the GPU takes the process down on ROCm 7.2 - an abort a few launches later, seen in
@@ -132,6 +154,11 @@ class HipModule(nn.Module):
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
         self.invalidate_plans()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        bump_structure_epoch()        # .to() / .half() / .float(): tensors may have been replaced (always re-list them)
         return out
 
     def _require_inference(self, *tensors):

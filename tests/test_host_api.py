@@ -382,3 +382,61 @@ def test_host_frame_feeder_protocol(monkeypatch):
         f.step()                                                   # nothing handed over
     with pytest.raises(CobevtHipError):
         f.put(dict(small, inputs=torch.ones(8, dtype=torch.uint8)))
+
+    # the small tensors are COPIED at put(): a loader that reuses its pose buffers for frame k + 1 before step(k) must not
+    # change what step(k) uploads; a set of the feeder's ring is rewritten only behind the event of the step that uploaded it
+    del log[:]
+    r = runner()
+    seen = []
+    inner = r.step
+    r.step = lambda sm: (seen.append(float(sm["transformation_matrix"][0])), inner(sm))[1]
+    f = pipeline.HostFrameFeeder(r)
+    pose = torch.zeros(4)
+    mk = lambda: {"inputs": torch.ones(16, dtype=torch.uint8), "intrinsic": 1, "extrinsic": 2, "transformation_matrix": pose, "record_len": 4}   # noqa: E731
+    pose.fill_(0.0)
+    f.put(mk())
+    for k in range(8):
+        pose.fill_(float(k + 1))              # the loader's buffer, rewritten for frame k + 1 ...
+        f.put(mk())
+        assert f.step() == k                  # ... before frame k is stepped
+    assert seen == [float(k) for k in range(8)]
+    n = len(f.small_sets)
+    assert n == 6 and f.small_sets[0]["transformation_matrix"].data_ptr() != pose.data_ptr()
+    step_events = [e[1] for e in log if e[0] == "record"][1:]           # [0] = the first frame's fetch
+    late_waits = [e[1] for e in log if e[0] == "wait"]
+    assert step_events[0] in late_waits and step_events[1] in late_waits  # puts 6, 7 reused sets 0, 1: behind the events of steps 0, 1
+
+
+def test_plan_fingerprint_follows_replaced_tensors():
+    """AgentCountPlans lists the model's tensors once and re-lists them when the structure epoch moves; every way a module
+    can REPLACE a tensor object must move it (torch's global registration hooks, host/runtime.py), or a captured graph would keep
+    replaying the old weights with an unchanged fingerprint"""
+    import torch.nn as nn
+    from cobevt_amd.host import pipeline, runtime as rt
+
+    class Tiny(rt.HipModule):
+        def __init__(self):
+            super().__init__()
+            self.lin = nn.Linear(4, 4)
+            self.bn = nn.BatchNorm1d(4)
+    m = Tiny()
+    plans = pipeline.AgentCountPlans(m, use_graph=False)
+    fp0 = plans.weights_fingerprint()
+    assert plans.weights_fingerprint() == fp0
+    m.lin.weight = nn.Parameter(torch.ones(4, 4))                   # a new Parameter OBJECT on a plain nn.Linear container
+    fp1 = plans.weights_fingerprint()
+    assert fp1 != fp0 and any(t is m.lin.weight for t in plans._tensors)
+    m.bn.running_mean = torch.full((4,), 2.0)                        # a registered buffer re-assigned
+    fp2 = plans.weights_fingerprint()
+    assert fp2 != fp1 and any(t is m.bn.running_mean for t in plans._tensors)
+    m.bn.register_buffer("extra_scale", torch.ones(4))               # a tensor added
+    assert len(plans.weights_fingerprint()) == len(fp2) + 1
+    m.lin = nn.Linear(4, 4)                                          # a child module replaced (BN fusing, surgery)
+    fp3 = plans.weights_fingerprint()
+    assert any(t is m.lin.weight for t in plans._tensors)
+    with torch.no_grad():
+        m.lin.weight.mul_(2.0)                                       # in place: seen through the version counter, no re-listing needed
+    assert plans.weights_fingerprint() != fp3
+    e = rt.structure_epoch()
+    m.float()                                                        # conversions re-list as well (HipModule._apply)
+    assert rt.structure_epoch() > e
