@@ -408,12 +408,21 @@ def lidar_roofline(enc, x, mask, dtype_name):
     summ = prof.summary()
     peak = PEAK_TFLOPS[dtype_name]
     fams = sorted(summ, key=lambda f: -summ[f]["ms"])
+    # `traffic` / `mfma_util_pmc`: this workload's own rocprofv3 PMC passes (tools/pmc_collect.sh <out> <tag> lidar), newest committed file
+    pmc, pmc_file = {}, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_lidar_r*.json")))
+    if files and dtype_name == "bf16":
+        pmc, pmc_file = json.load(open(files[-1])).get("families", {}), os.path.basename(files[-1])
     ent = []
     for f in fams:
         d = summ[f]
         tf, gbs = d["flops"] / (d["ms"] * 1e-3) / 1e12, d["bytes"] / (d["ms"] * 1e-3) / 1e9
         hbm = f in HBM_BOUND_FAMILIES
-        ent.append({"kernel": f, "traffic": None, "launches_per_frame": d["calls"], "avg_launch_us": round(d["ms"] * 1e3 / d["calls"], 2),
+        pf = pmc.get(f, {})
+        ent.append({"kernel": f, "traffic": pf.get("hbm_bytes"), "mfma_util_pmc": pf.get("mfma_util"),
+                    "avg_duration_us_profiled": pf.get("avg_duration_us_profiled"), "pmc_source": pmc_file,
+                    "algorithmic_mbyte_per_launch": round(d["bytes"] / 1e6 / d["calls"], 2),
+                    "launches_per_frame": d["calls"], "avg_launch_us": round(d["ms"] * 1e3 / d["calls"], 2),
                     "bound": "hbm" if hbm else "mfma", "achieved": round(gbs if hbm else tf, 2),
                     "peak": PEAK_HBM_GBS if hbm else peak, "unit": "GB/s" if hbm else "TFLOP/s",
                     "frac": round((gbs / PEAK_HBM_GBS) if hbm else (tf / peak), 4)})

@@ -92,7 +92,7 @@ class CorpBEVT(HipModule):
     overlap_streams = True   # run each level's key/value path on a side HIP stream under the remaining encoder stages
     overlap_kv = os.environ.get("COBEVT_OVERLAP_KV", "1") != "0"
 
-    def encode_trunk(self, batch_dict, kv_out=None):
+    def encode_trunk(self, batch_dict, kv_out=None, stage_hook=None):
         """Stage 1 of the per-agent SinBEVT: the camera encoder and everything of the FAX pyramid that depends only on
         the images and the camera geometry (ray embedding, feature projections, K/V projections of both attentions of
         every level).  Returns the state `fax_query` needs: {"kv": [per-level dict], "E_inv", "batch"}.
@@ -113,6 +113,8 @@ class CorpBEVT(HipModule):
                           lambda dt, dev: [torch.cuda.Stream(device=dev) for _ in range(len(pick))])
         feats, kv = {}, {}
         for stage, x in self.encoder.stages_nhwc(images):
+            if stage_hook is not None:
+                stage_hook(stage)            # a pipeline may order the encoder's next stage behind its other branches (A/B knob)
             if stage not in pick:
                 continue
             level = pick.index(stage)

@@ -281,7 +281,20 @@ class PipelinedCorpBEVT(_RunnerBase):
                 "E_inv": self.einv[slot], "batch": self.batch}
 
     def _s1(self, slot):
-        st = self.model.encode_trunk(self._images_of(slot), kv_out=self.kv[slot])      # K/V land in the slot directly
+        # A/B knob (tools only): COBEVT_PIPE_GATE="s3@1,s2@2" makes the encoder's stage AFTER ResNet stage k (0..3) wait for the named
+        # branch of this step - do the small-launch stages collide less with the layer-3 / 4 convolutions, which own their CUs,
+        # when they are confined to the first half of the step?  (profiles/r06_pipe_gate_ab.txt)
+        gate = os.environ.get("COBEVT_PIPE_GATE")
+        hook = None
+        if gate and self.depth == 3:
+            names = {"s2": self.streams[0], "s3": self.streams[1]}
+            plan = [(names[t.split("@")[0]], int(t.split("@")[1])) for t in gate.split(",")]
+
+            def hook(stage):
+                for strm, k in plan:
+                    if k == stage:
+                        torch.cuda.current_stream().wait_stream(strm)
+        st = self.model.encode_trunk(self._images_of(slot), kv_out=self.kv[slot], stage_hook=hook)      # K/V land in the slot directly
         main = torch.cuda.current_stream()
         for level, lvl in enumerate(st["kv"]):
             main.wait_stream(st["side"][level])

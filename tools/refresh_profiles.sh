@@ -10,6 +10,9 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 bash tools/pmc_collect.sh "$OUT/pmc" "$TAG" > "$OUT/pmc_collect.log" 2>&1
 cp "$OUT/pmc/pmc_${TAG}.json" "profiles/pmc_${TAG}.json" 2>/dev/null       # bench.py reads roofline.traffic from it
+bash tools/pmc_collect.sh "$OUT/pmc_lidar" "$TAG" lidar > "$OUT/pmc_collect_lidar.log" 2>&1      # the LiDAR FuseBEVT workload's own PMC passes
+cp "$OUT/pmc_lidar/pmc_lidar_${TAG}.json" "profiles/pmc_lidar_${TAG}.json" 2>/dev/null
+rm -rf "$OUT"/pmc_lidar/fetch "$OUT"/pmc_lidar/write "$OUT"/pmc_lidar/sq
 (cd /tmp && timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_UNALIGNED_STALL SQ_WAIT_INST_LDS SQ_BUSY_CYCLES \
     -d "$ROOT/$OUT/lds" -o p -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-extra --frames-in-flight 1 > "$ROOT/$OUT/lds.log" 2>&1)
 python tools/pmc_summary.py $(find "$OUT/lds" -name "*.db") > "$OUT/${TAG}_lds_pmc.txt" 2>&1
