@@ -574,9 +574,9 @@ extern "C" int cobevt_channel_affine(const float* in, const float* scale, const 
 }
 
 // Ingest inside the captured graph: a few workgroups pull the NEXT frame out of pinned (device-visible, fine-grained) host memory
-// over PCIe while the step's kernels run.  The fetch waves need no LDS and ~20 VGPRs, so they sit beside the convolution
-// workgroups that own every CU's LDS; eight 8-byte loads per lane in flight (128 workgroups x 256 lanes x 64 B = 2 MB) cover the
-// link's bandwidth-delay product many times over.  No copy engine, no extra stream, no event between replays: see
+// over PCIe while the step's kernels run.  The fetch waves need no LDS and 52 VGPRs, so they sit beside the convolution
+// workgroups that own every CU's LDS; eight 8-byte loads per lane in flight (the captured step launches 16 workgroups x 256 lanes x
+// 64 B = 256 KB in flight; 8 workgroups no longer fill the link, 32+ only add interference: profiles/r06_ingest_split_ab.txt).  No copy engine, no extra stream, no event between replays: see
 // host.pipeline.HostFrameFeeder for why that matters (ROCm shares 4 hardware queues among a process's streams).
 // Loads at SYSTEM scope (sc0 sc1: past the GPU's caches): the host rewrites a ring slot between two pulls of it, and a line of the
 // previous frame must not be served from L2 - pinned memory from hipHostMalloc(default flags) is not guaranteed fine-grained.

@@ -365,9 +365,11 @@ int cobevt_channel_affine(const float* in, const float* scale, const float* shif
 
 /*
  * Pull `bytes` (a multiple of 16) from pinned, device-visible HOST memory (hipHostMalloc / torch .pin_memory(): the host pointer is
- * the device pointer) into device memory with `blocks` (0 = 128) workgroups of non-temporal 16-byte loads: the ingest step of the
- * reference's loop (opv2v/opencood/tools/inference_camera.py:56-61 `.to(device)`) as a kernel that can be CAPTURED in the step's
- * HIP graph and runs beside the compute kernels (no LDS, ~20 VGPRs) - host.pipeline.PipelinedCorpBEVT(host_ingest=True).
+ * the device pointer) into device memory with `blocks` (0 = 128; the captured step uses 16) workgroups of 256 lanes, each lane with eight
+ * 8-byte SYSTEM-SCOPE relaxed atomic loads in flight (global_load_dwordx2 sc0 sc1 behind an acquire fence: a ring slot the host has
+ * rewritten is never served out of the GPU's caches) and plain 8-byte stores: the ingest step of the reference's loop
+ * (opv2v/opencood/tools/inference_camera.py:56-61 `.to(device)`) as a kernel that can be CAPTURED in the step's HIP graph and runs
+ * beside the compute kernels (no LDS, 52 VGPRs) - host.pipeline.PipelinedCorpBEVT(host_ingest=True).
  */
 int cobevt_host_fetch(const void* host_src, void* dst, long bytes, int blocks, hipStream_t stream);
 

@@ -511,6 +511,7 @@ def gv17():
     save("gv17_cvt_baselines", **out)
 
 GV18_SEEDS = (0, 1, 2, 3)
+_AMP_DTYPE = torch.bfloat16          # gv19() re-runs gv18's cases under float16: the reference's OWN mixed-precision dtype
 
 
 def _dev_stats(run, class_dim):
@@ -519,7 +520,7 @@ def _dev_stats(run, class_dim):
     nuscenes/scripts/benchmark.py:45 wrap the same forward in torch.cuda.amp.autocast).
     -> {output key: (max|d| / max|ref|, ||d||_2 / ||ref||_2, arg-max agreement along class_dim or 1.0)}"""
     ref = run()
-    with torch.autocast("cpu", dtype=torch.bfloat16):
+    with torch.autocast("cpu", dtype=_AMP_DTYPE):
         amp = run()
     if torch.is_tensor(ref):
         ref, amp = {"": ref}, {"": amp}
@@ -547,11 +548,11 @@ def _dev(out, name, build, class_dim=None, seeds=GV18_SEEDS):
         v = np.array([p[k] for p in per], dtype=np.float64)            # (seeds, 3)
         out[key] = np.array([v[:, 0].max(), v[:, 1].max(), v[:, 2].min()])
         out[key + "#seeds"] = v
-        print("  reference bf16-autocast vs fp32 %-44s max-rel %.3e (%s)  rms-rel %.3e (%s)  arg-max agreement >= %.4f"
+        print("  reference " + str(_AMP_DTYPE).split(".")[-1] + "-autocast vs fp32 %-44s max-rel %.3e (%s)  rms-rel %.3e (%s)  arg-max agreement >= %.4f"
               % (key, out[key][0], " ".join("%.2e" % x for x in v[:, 0]), out[key][1], " ".join("%.2e" % x for x in v[:, 1]), out[key][2]))
 
 
-def gv18(full=None):
+def gv18(full=None, fixture="gv18_reference_bf16_autocast"):
     """The REFERENCE's own bf16 mixed-precision deviation: every module / model of GV2-GV11, GV13, GV17 and
     the full-size corpbevt.yaml frame run by the reference in fp32 and under torch.autocast(bfloat16) on the tests' procedural
     inputs, for the procedural weight sets 0..3.  These numbers - not anything measured on the HIP path - are what the bf16
@@ -768,7 +769,22 @@ def gv18(full=None):
                 synth.balance_seg_head_(mf, agents)
                 return lambda: mf({k: v.clone() for k, v in bf.items()})["dynamic_seg"]
             _dev(out, "CorpBEVT.full %d agents balanced head" % agents, build, class_dim=2, seeds=(0,))
-    save("gv18_reference_bf16_autocast", **out)
+    save(fixture, **out)
+
+
+def gv19():
+    """the same cases as gv18 under torch.autocast("cpu", dtype=torch.float16) - float16 is the dtype the reference's
+    own mixed-precision runs use (torch.cuda.amp.autocast in opv2v/opencood/tools/train_camera.py:157-160 and
+    nuscenes/scripts/benchmark.py:45 defaults to float16 on a GPU).  A second yardstick beside gv18's bfloat16 one: how far the
+    reference's fp16 run moves away from its fp32 forward.  Nothing in the test gates reads this fixture (there is no fp16 compute mode
+    in the product); tests/test_oracle_golden.py checks that it is there and ordered as expected against gv18."""
+    global _AMP_DTYPE
+    prev = _AMP_DTYPE
+    _AMP_DTYPE = torch.float16
+    try:
+        gv18(fixture="gv19_reference_fp16_autocast")
+    finally:
+        _AMP_DTYPE = prev
 
 
 if __name__ == "__main__":

@@ -283,3 +283,21 @@ def test_gv18_reference_bf16_fixture_backs_every_bf16_gate():
                                                          ("both", "static_seg"), ("both", "dynamic_seg")))
     missing = sorted(n for n in names if n not in g.files and n != "regroup")
     assert not missing, missing
+
+
+def test_gv19_reference_fp16_autocast_yardstick():
+    """the reference under ITS OWN mixed-precision dtype (torch.autocast float16: train_camera.py:157-160,
+    nuscenes/scripts/benchmark.py:45) beside gv18's bfloat16 run - same cases, same weight sets.  No gate reads this fixture; it is the
+    second yardstick: on the 5-agent frame the reference's fp16 run is 1.1e-2 max-rel / 1.4e-3 rms-rel away from its fp32 forward, its
+    bf16 run 1.5e-2 / 6.9e-3 - and the product's tolerance modes sit far inside both (fp32_fast 2.4e-4, fp32_split 1e-5)."""
+    import numpy as np
+    from util import golden
+    g16, gbf = golden("gv19_reference_fp16_autocast"), golden("gv18_reference_bf16_autocast")
+    assert set(g16.files) == set(gbf.files)
+    for key in ("CorpBEVT.full 5 agents balanced head", "CorpBEVT.full 5 agents.fax", "CorpBEVT.full 5 agents.resnet34_f2", "CorpBEVT.small.dynamic_seg"):
+        a, b = g16[key], gbf[key]
+        assert a.shape == (3,) and np.isfinite(a).all() and a[0] > 0
+        assert a[1] < b[1], "%s: fp16 autocast (rms %.2e) should deviate less than bf16 autocast (rms %.2e)" % (key, a[1], b[1])
+    # 3 more mantissa bits are worth ~8x on the encoder (no warp, no tiny logit scale in the way)
+    r = gbf["CorpBEVT.full 5 agents.resnet34_f2"][1] / g16["CorpBEVT.full 5 agents.resnet34_f2"][1]
+    assert 4.0 < r < 16.0, r

@@ -104,8 +104,9 @@ def assert_close(got, ref, tol, what, case=None):
             f.write("%s\t%s\tmax_rel=%.3e\trms_rel=%.3e\tgate=%.2e\trms_gate=%.2e\n"
                     % (os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], what, e, r, tol, rms_gate))
     tid = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
-    GATE_RATIOS.append((e / tol, "max", e, tol, what, tid))
-    GATE_RATIOS.append((r / rms_gate, "rms", r, rms_gate, what, tid))
+    if tol > 0 and rms_gate > 0:              # (a zero gate is a bit-exact comparison: nothing to rank)
+        GATE_RATIOS.append((e / tol, "max", e, tol, what, tid))
+        GATE_RATIOS.append((r / rms_gate, "rms", r, rms_gate, what, tid))
     assert e <= tol, "%s: rel err %.3e > %.2e" % (what, e, tol)
     assert r <= rms_gate, "%s: rms rel err %.3e > %.2e" % (what, r, rms_gate)
     return e
