@@ -164,35 +164,68 @@ __device__ __forceinline__ void mfma_kgroup(const uint4& a, const uint4& b, f32x
     }
 }
 
-// Activation pieces split ONCE, when a kernel stages them into an LDS patch that only feeds MFMA operand reads (third library, fp32
-// storage): the in-loop form above spends ~12 VALU instructions per MFMA on the split and is VALU-bound (256 -> 256 on 20 x 32 x 32:
-// 103 us split-bf16 -> 77 us), while a patch piece is read by 9 taps x every cout tile of the workgroup.  stage_x_piece is the identity
-// in every other build / type, and mfma_kgroup_xs is mfma_kgroup<T> (weights first) there.
-template <typename T> constexpr bool kXSplit = (COBEVT_F32_SPLIT == 2) && !Elem<T>::kIsBf16;
-template <typename T> __device__ __forceinline__ uint4 stage_x_piece(const uint4& x) {
-    if constexpr (kXSplit<T>) return split_f16_piece(x);
-    else return x;
+// Activation pieces split ONCE, when a kernel stages them into an LDS patch that only feeds MFMA operand reads (fp32 storage in the
+// second and third library): the in-loop forms above spend 12-14 VALU instructions per MFMA on the split, in a dependent chain between
+// the LDS read and the MFMA (third library, 256 -> 256 on 20 x 32 x 32: 77 us in-loop, 54.7 us staged), while a patch piece is read by
+// 9 taps x every cout tile of the workgroup.  Staged form of a piece {x0..x3}: {hi(x0,x1), hi(x2,x3), lo(x0,x1), lo(x2,x3)} - bf16 halves
+// in the second library (x = hi + lo to 2^-17), fp16 halves with the scaled lo in the third.  stage_x_piece is the identity in the native
+// library and for bf16 storage, and mfma_kgroup_xs is mfma_kgroup<T> (weights first) there.
+template <typename T> constexpr bool kXSplit = (COBEVT_F32_SPLIT != 0) && !Elem<T>::kIsBf16;
+__device__ __forceinline__ void split_pair_staged(float x, float y, uint32_t& hi, uint32_t& lo) {
+#if COBEVT_F32_SPLIT == 2
+    hi = pack_h2(x, y);
+    const f16x2 hv = __builtin_bit_cast(f16x2, hi);
+    lo = pack_h2((x - (float)hv[0]) * kF16LoScale, (y - (float)hv[1]) * kF16LoScale);
+#else
+    split_bf16_pair(x, y, hi, lo);
+#endif
 }
+template <typename T> __device__ __forceinline__ uint4 stage_x_piece(const uint4& x) {
+    if constexpr (kXSplit<T>) {
+        uint32_t h01, h23, l01, l23;
+        split_pair_staged(__uint_as_float(x.x), __uint_as_float(x.y), h01, l01);
+        split_pair_staged(__uint_as_float(x.z), __uint_as_float(x.w), h23, l23);
+        return make_uint4(h01, h23, l01, l23);
+    } else {
+        return x;
+    }
+}
+// w = the raw fp32 weight piece (a register fragment shared by the MT strips / pixel tiles of the wave: its split is amortised), xs = staged
 template <typename T> __device__ __forceinline__ void mfma_kgroup_xs(const uint4& w, const uint4& xs, f32x16& acc) {
     if constexpr (kXSplit<T>) {
+#if COBEVT_F32_SPLIT == 2
         const uint4 wv = dup_f16_piece(w);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wv), __builtin_bit_cast(f16x8, xs), acc, 0, 0, 0);
+#else
+        // (w_hi, w_hi) . (x_hi, x_lo) + (w_lo, w_lo) . (x_hi, x_lo): the same four cross terms as mfma_kgroup's split form
+        uint32_t h01, h23, l01, l23;
+        split_bf16_pair(__uint_as_float(w.x), __uint_as_float(w.y), h01, l01);
+        split_bf16_pair(__uint_as_float(w.z), __uint_as_float(w.w), h23, l23);
+        const uint4 wh = make_uint4(h01, h23, h01, h23), wl = make_uint4(l01, l23, l01, l23);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh), __builtin_bit_cast(bf16x8, xs), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wl), __builtin_bit_cast(bf16x8, xs), acc, 0, 0, 0);
+#endif
     } else {
         mfma_kgroup<T>(w, xs, acc);
     }
 }
 
-// Both operands staged: a kernel that also keeps its WEIGHTS in LDS (the stem) converts them once with stage_w_piece and multiplies
-// the staged pieces as they are.
+// Both operands staged: a kernel that also keeps its WEIGHTS in LDS (the stem) converts them once with stage_w_piece where ONE staged form
+// serves (third library); in the second library a weight piece needs its (hi, hi) and (lo, lo) forms, so it stays raw and is split at use.
 template <typename T> __device__ __forceinline__ uint4 stage_w_piece(const uint4& w) {
+#if COBEVT_F32_SPLIT == 2
     if constexpr (kXSplit<T>) return dup_f16_piece(w);
-    else return w;
+#endif
+    return w;
 }
 template <typename T> __device__ __forceinline__ void mfma_kgroup_staged(const uint4& ws, const uint4& xs, f32x16& acc) {
-    if constexpr (kXSplit<T>)
+#if COBEVT_F32_SPLIT == 2
+    if constexpr (kXSplit<T>) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ws), __builtin_bit_cast(f16x8, xs), acc, 0, 0, 0);
-    else
-        mfma_kgroup<T>(ws, xs, acc);
+        return;
+    }
+#endif
+    mfma_kgroup_xs<T>(ws, xs, acc);
 }
 
 // accumulator register r of the 32x32 C/D fragment -> row within the tile

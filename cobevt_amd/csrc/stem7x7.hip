@@ -376,11 +376,10 @@ __global__ __launch_bounds__(StemPoolCfg<T>::NT) void stem_pool_kernel(StemParam
                 unsigned char* dst = patch + pdst[it];
                 if constexpr (Elem<T>::kIsBf16) *(uint32_t*)dst = pack_bf2(preg[it].x, preg[it].y);
                 else if constexpr (kXSplit<T>) {
-                    // third library: the 16-byte operand piece {x0..x3} lives in LDS as {hi(x0,x1), hi(x2,x3), lo(x0,x1), lo(x2,x3)} fp16
-                    // (common.hpp split_f16_piece); this float pair is the first or the second half of its piece
-                    const uint32_t hi = pack_h2(preg[it].x, preg[it].y);
-                    const f16x2 hv = __builtin_bit_cast(f16x2, hi);
-                    const uint32_t lo = pack_h2((preg[it].x - (float)hv[0]) * kF16LoScale, (preg[it].y - (float)hv[1]) * kF16LoScale);
+                    // second / third library: the 16-byte operand piece {x0..x3} lives in LDS as {hi(x0,x1), hi(x2,x3), lo(x0,x1), lo(x2,x3)}
+                    // (common.hpp stage_x_piece); this float pair is the first or the second half of its piece
+                    uint32_t hi, lo;
+                    split_pair_staged(preg[it].x, preg[it].y, hi, lo);
                     unsigned char* pb = patch + (pdst[it] & ~15) + ((pdst[it] >> 1) & 4);
                     *(uint32_t*)pb = hi;
                     *(uint32_t*)(pb + 8) = lo;
