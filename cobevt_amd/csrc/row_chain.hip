@@ -351,7 +351,15 @@ extern "C" int cobevt_attn_mlp_chain(const void* a, const void* skip, void* out,
                                      hipStream_t stream) {
     // dims: [dtype, M, C, Hd, Hdp, Nn, next_ln, next_act, rows_per_workgroup, skip_rows]
     if (!a || !out || !wp || !w1 || !b1 || !w2 || !b2 || !dims) return COBEVT_ERR_ARG;
-    if (dims[0] != 0) return COBEVT_ERR_UNSUPPORTED;           // bf16 mode only; fp32 runs the GEMMs separately
+    if (dims[0] != 0 && dims[0] != 1) return COBEVT_ERR_ARG;
+    if (dims[0] == 1) {                                        // fp32 storage: the C = 128 / hidden 256 chain (row_chain_f32.hip); other widths run the GEMMs separately
+        if ((post_gamma == nullptr) != (post_beta == nullptr) || (wnext == nullptr) != (out_next == nullptr)) return COBEVT_ERR_ARG;
+        const int M = dims[1], sr = dims[9] > 0 ? dims[9] : dims[1];
+        if (M < 1 || sr > M || M % sr || (wnext && (dims[7] < 0 || dims[7] > 2))) return COBEVT_ERR_SHAPE;
+        const int rc = launch_row_chain_f32(a, skip, out, wp, bp, w1, b1, w2, b2, post_gamma, post_beta, wnext, bnext, out_next, M, dims[2], dims[3],
+                                            dims[4], dims[5], dims[6], dims[7], sr, eps1, eps_post, eps_next, stream);
+        return rc < 0 ? COBEVT_ERR_UNSUPPORTED : rc;
+    }
     RowChainParams p;
     p.a = (const bf16_t*)a; p.skip = (const bf16_t*)skip; p.out = (bf16_t*)out;
     p.wp = (const uint4*)wp; p.bp = bp; p.w1 = (const uint4*)w1; p.b1 = b1; p.w2 = (const uint4*)w2; p.b2 = b2;

@@ -37,4 +37,10 @@ int launch_row_chain64(const RowChainParams& p, hipStream_t stream);
 // proj_chain128.hip: the projection chain (MLP = false form: pre-activation -> Wp + skip -> LN -> Wn) on big 128-channel maps, same idea
 int launch_proj_chain128(const RowChainParams& p, hipStream_t stream);
 
+// row_chain_f32.hip: the same chain for fp32 storage (C = 128, hidden 256; exact / split-bf16 matrix path by library); -1 = shape does not qualify
+int launch_row_chain_f32(const void* a, const void* skip, void* out, const void* wp, const float* bp, const void* w1, const float* b1,
+                         const void* w2, const float* b2, const float* post_g, const float* post_b, const void* wnext, const float* bnext,
+                         void* out_next, int M, int C, int Hd, int Hdp, int Nn, int next_ln, int next_act, int skip_rows, float eps1,
+                         float eps_post, float eps_next, hipStream_t stream);
+
 }  // namespace cobevt

@@ -31,6 +31,7 @@ USE_STEM_POOL = True  # stem conv + max pool in one launch (the stem map never r
 USE_STEM = True       # 7x7/s2 image stem through the space-to-depth kernel instead of the generic small-Cin igemm
 ROW_CHAIN_ROWS = 0     # rows per workgroup of the fused row chain: 0 = default (32), 64
 USE_ROW_CHAIN = True  # fuse out-proj + skip + pre-norm MLP (+ post-norm) after attention into one launch (bf16)
+USE_ROW_CHAIN_F32 = True  # ... and its fp32-storage form for C = 128 / hidden 256 (csrc/row_chain_f32.hip; round 6)
 BASICBLOCK_TILE_ROWS = 0   # 0 = kernel default; 8 | 16 pins the output tile height (tools/bb_probe.py)
 USE_BASICBLOCK = True  # stride-1 BasicBlocks on 64 / 128 channels as one launch (intermediate map stays in LDS)
 USE_DSBLOCK = True  # layer2's stride-2 BasicBlock with its projection shortcut as one launch (bf16)
@@ -1071,11 +1072,15 @@ def attn_mlp_chain(a, skip, plan_p, plan_1, plan_2, post_ln=None, next_plan=None
     skip_rows = 0
     if skip is not None and batch_broadcast(skip) and skip.shape == a.shape:
         skip_rows = skip[0].numel() // c           # one slice shared by the whole batch: the kernel indexes it modulo
-    fusable = (USE_ROW_CHAIN and a.dtype == torch.bfloat16 and plan_p.wfrag_rows is not None and plan_1.wfrag_rows is not None
+    # fp32 storage (round 6, csrc/row_chain_f32.hip): the C = 128 / hidden 256 chain of every FAX level and of the camera fusion stage
+    f32 = a.dtype == torch.float32
+    fusable = (USE_ROW_CHAIN and (a.dtype == torch.bfloat16 or (f32 and USE_ROW_CHAIN_F32 and c == 128 and hd == 256 and plan_2.kp_rows == 256))
+               and plan_p.wfrag_rows is not None and plan_1.wfrag_rows is not None
                and plan_2.wfrag_rows is not None and plan_2.kp_rows <= 256 and plan_1.has_ln and plan_1.act == 2 and plan_p.act == 0
                and plan_2.act == 0 and not plan_p.has_ln and not plan_2.has_ln and plan_p.K == c and plan_1.K == c
                and plan_2.K == hd and plan_2.cout == c and c <= 128 and c % 8 == 0 and hd <= 256 and hd % 8 == 0
                and plan_p.kp_rows == 128 and plan_1.kp_rows == 128 and a.shape[-1] == c and a.is_contiguous()
+               and (skip is None or skip.dtype == a.dtype)
                and (skip is None or skip_rows or (skip.is_contiguous() and skip.shape == a.shape)))
     if not fusable:
         y = linear(a, plan_p, residual=skip.contiguous() if skip is not None else None)
@@ -1087,13 +1092,14 @@ def attn_mlp_chain(a, skip, plan_p, plan_1, plan_2, post_ln=None, next_plan=None
     fuse_next = USE_CHAIN_NEXT and chain_next_fusable(next_plan, c)
     nn_ = next_plan.cout if fuse_next else 0
     out_next = torch.empty(a.shape[:-1] + (nn_,), device=a.device, dtype=a.dtype) if fuse_next else None
-    dims = _ints([0, m, c, hd, plan_2.kp_rows, nn_, int(next_plan.has_ln) if fuse_next else 0,
+    dims = _ints([plan_p.code, m, c, hd, plan_2.kp_rows, nn_, int(next_plan.has_ln) if fuse_next else 0,
                   next_plan.act if fuse_next else 0, ROW_CHAIN_ROWS, skip_rows])
     pg, pb, pe = post_ln if post_ln is not None else (None, None, 0.0)
 
     def cost():
         flops = 2.0 * m * (c * c + 2 * c * hd + c * nn_)
-        return flops, float((2 * m + (0 if skip is None else skip_rows or m)) * c * 2 + m * nn_ * 2 + (c * c + 2 * c * hd + c * nn_) * 2)
+        esz = a.element_size()
+        return flops, float((2 * m + (0 if skip is None else skip_rows or m)) * c * esz + m * nn_ * esz + (c * c + 2 * c * hd + c * nn_) * esz)
 
     with _timed("row_chain|C%d H%d M=%d%s%s" % (c, hd, m, " post" if post_ln is not None else "",
                                                   " +next%d" % nn_ if fuse_next else ""), cost):

@@ -160,7 +160,7 @@ int cobevt_linear_rows_wfrag(const void* in, const void* wfrag, const float* bia
                              hipStream_t stream);
 
 /*
- * Fused row-local chain after an attention (bf16 mode):  y = a.Wp^T (+bp) + skip ;  z = y + fc2(GELU(fc1'(norm(y)))) ;
+ * Fused row-local chain after an attention (bf16 storage, or fp32 storage for C = 128 / hidden 256):  y = a.Wp^T (+bp) + skip ;  z = y + fc2(GELU(fc1'(norm(y)))) ;
  * out = post-LayerNorm(z) (optional) ;  out_next = act(norm?(out).Wn'^T + bn') (optional).  Replaces
  * fax_modules.py:240,246-247 + :411 / :435-437 and swap_fusion_modules.py:126,177 + base_transformer.py:102-124 in one
  * launch (hidden activations stay in LDS); the optional next projection is the row-local GEMM that reads `out` next in
@@ -169,7 +169,9 @@ int cobevt_linear_rows_wfrag(const void* in, const void* wfrag, const float* bia
  * wp (C x 128), w1 (Hd x 128, LayerNorm affine folded in), w2 (C x Hdp), wnext (Nn x 128, LayerNorm affine / BN folded
  * in; nullable together with out_next [M][Nn]) are given in MFMA fragment order: rows zero-padded to a multiple of 128,
  * [rows/32][Kp/16][64 lanes][16 bytes] with lane = 32*half + row%32 holding bytes [32*kgroup + 16*half, +16) of its row,
- * so a wave's weight operand is one coalesced 1-KB load and no weight panel passes through LDS.  dims (int32[10]): dtype(0), M, C(<=128), Hd(<=256), Hdp, Nn (<= 768),
+ * so a wave's weight operand is one coalesced 1-KB load and no weight panel passes through LDS.  dims (int32[10]): dtype (0 bf16; 1 fp32
+ * storage - round 6, csrc/row_chain_f32.hip: C == 128, Hd == Hdp == 256, fragments [rows/32][Kp/8][64 lanes][16 bytes] of fp32, the matrix
+ * path of the library it is called from; other fp32 widths return COBEVT_ERR_UNSUPPORTED and the caller runs the GEMMs separately), M, C(<=128), Hd(<=256), Hdp, Nn (<= 768),
  * next_ln (1 = normalise the stored `out` rows first), next_act (0 none, 1 ReLU, 2 GELU), rows per workgroup (0 = 32; 64),
  * skip_rows (0 = M; a divisor of M: `skip` has that many rows and row m adds skip[m % skip_rows] - the learned prior
  * broadcast over the batch, fax_modules.py:509-510).

@@ -615,6 +615,70 @@ def test_attn_mlp_chain_next_projection(cuda, c, rows, nn_, next_ln, next_act, p
     assert (nx.float() - nx_b.float()).abs().max().item() <= 1e-2 * s
 
 
+@pytest.mark.parametrize("mode", ["fp32", "fp32_split"])
+@pytest.mark.parametrize("rows,batch,nn_,next_ln,next_act,post,proj_bias,skip", [
+    (1000, 1, 384, True, 0, False, True, "full"), (130, 1, 0, False, 0, True, False, "full"), (333, 1, 32, False, 1, True, True, "none"),
+    (96, 3, 128, True, 2, False, False, "broadcast"), (5120, 1, 256, True, 0, False, True, "full")])
+def test_attn_mlp_chain_fp32_storage(cuda, mode, rows, batch, nn_, next_ln, next_act, post, proj_bias, skip):
+    """csrc/row_chain_f32.hip (round 6): the chain for fp32 storage (C = 128, hidden 256) in ONE launch - exact fp32 MFMA and the
+    split-bf16 matrix path - against the separate dense-row launches it replaces (same library) and fp64 torch: ragged row counts,
+    with / without projection bias, skip (full, broadcast over the batch, none), post-LayerNorm and the next projection (LayerNorm / ReLU /
+    GELU, 32-384 columns).  Gates: 2e-4 of the output scale like every fp32 kernel test; fused vs separate 2e-5."""
+    from cobevt_amd import host
+    dtype, c, hd = torch.float32, 128, 256
+    a = procedural_input("cf.a", (batch, rows, c), 0, -2, 2)
+    sk = None if skip == "none" else procedural_input("cf.s", (rows, c) if skip == "broadcast" else (batch, rows, c), 0, -1, 1)
+    mk = lambda key, shape, fan: procedural_input(key, shape, 0) * math.sqrt(3.0 / fan)
+    wp, w1, w2 = mk("cf.wp", (c, c), c), mk("cf.w1", (hd, c), c), mk("cf.w2", (c, hd), hd)
+    bp = procedural_input("cf.bp", (c,), 0, -0.2, 0.2) if proj_bias else None
+    b1, b2 = procedural_input("cf.b1", (hd,), 0, -0.2, 0.2), procedural_input("cf.b2", (c,), 0, -0.2, 0.2)
+
+    class LN1(object):
+        weight, bias, eps = 0.8 + 0.4 * procedural_input("cf.g1", (c,), 0, 0, 1), procedural_input("cf.be1", (c,), 0, -0.2, 0.2), 1e-5
+
+    class LNn(object):
+        weight, bias, eps = 0.8 + 0.4 * procedural_input("cf.gn", (c,), 0, 0, 1), procedural_input("cf.ben", (c,), 0, -0.2, 0.2), 1e-5
+    g2, be2 = 0.8 + 0.4 * procedural_input("cf.g2", (c,), 0, 0, 1), procedural_input("cf.be2", (c,), 0, -0.2, 0.2)
+    pp = ops.ConvPlan(wp, bp, dtype=dtype, device=cuda)
+    p1 = ops.ConvPlan(w1, b1, act=2, dtype=dtype, device=cuda, ln=LN1)
+    p2 = ops.ConvPlan(w2, b2, dtype=dtype, device=cuda)
+    pn = None
+    if nn_:
+        wn, bn_ = mk("cf.wn", (nn_, c), c), procedural_input("cf.bn", (nn_,), 0, -0.2, 0.2)
+        pn = ops.ConvPlan(wn, bn_, act=next_act, dtype=dtype, device=cuda, ln=LNn if next_ln else None)
+    post_ln = (g2.to(cuda), be2.to(cuda), 1e-5) if post else None
+    ad = a.to(cuda)
+    sd = None if sk is None else (sk.to(cuda)[None].expand(batch, rows, c) if skip == "broadcast" else sk.to(cuda))
+    with host.compute_dtype(mode):
+        assert ops.USE_ROW_CHAIN and ops.USE_ROW_CHAIN_F32
+        with ops.LaunchProfile() as prof:
+            r = ops.attn_mlp_chain(ad, sd, pp, p1, p2, post_ln, next_plan=pn)
+        assert sum(d["calls"] for d in prof.summary().values()) == 1, "the fp32 chain must be ONE launch: %s" % prof.summary()
+        ops.USE_ROW_CHAIN_F32 = False
+        try:
+            r3 = ops.attn_mlp_chain(ad, sd, pp, p1, p2, post_ln, next_plan=pn)
+        finally:
+            ops.USE_ROW_CHAIN_F32 = True
+    y, nx = (r if nn_ else (r, None))
+    y3, nx3 = (r3 if nn_ else (r3, None))
+    d64 = torch.float64
+    yy = F.linear(a.to(d64), wp.to(d64), None if bp is None else bp.to(d64)) + (0 if sk is None else sk.to(d64))
+    zz = yy + F.linear(F.gelu(F.linear(F.layer_norm(yy, (c,), LN1.weight.to(d64), LN1.bias.to(d64), 1e-5), w1.to(d64), b1.to(d64))), w2.to(d64), b2.to(d64))
+    ref = F.layer_norm(zz, (c,), g2.to(d64), be2.to(d64), 1e-5) if post else zz
+    s = ref.abs().max().item()
+    assert y.shape == ref.shape and torch.isfinite(y).all()
+    assert (y.double().cpu() - ref).abs().max().item() <= 2e-4 * s
+    assert (y.double() - y3.double()).abs().max().item() <= 2e-5 * s
+    if nn_:
+        xin = F.layer_norm(ref, (c,), LNn.weight.to(d64), LNn.bias.to(d64), 1e-5) if next_ln else ref
+        rn = F.linear(xin, wn.to(d64), bn_.to(d64))
+        rn = F.relu(rn) if next_act == 1 else (F.gelu(rn) if next_act == 2 else rn)
+        sn = rn.abs().max().item()
+        assert nx.shape == rn.shape
+        assert (nx.double().cpu() - rn).abs().max().item() <= 2e-4 * sn
+        assert (nx.double() - nx3.double()).abs().max().item() <= 2e-5 * sn
+
+
 @pytest.mark.parametrize("rows,nn_,next_ln,next_act,post", [(16384 + 40, 192, True, 0, False), (20000, 0, False, 0, True),
                                                             (16384, 64, False, 1, True), (33000, 128, True, 2, False)])
 def test_row_chain64_wave_level_kernel(cuda, rows, nn_, next_ln, next_act, post):
