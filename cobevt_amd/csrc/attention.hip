@@ -82,7 +82,24 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
     else { tq = qtile * 32 * (nthr >> 6) + wave * 32 + ql; q_ok = tq < (pair ? P : p.Nq); }
     const TokCoord qc = tok_coord(p.qmap, q_ok ? tq : 0);          // pair mode: tq < P -> camera 0
 
+    // Split-bf16 library, fp32 storage (round 6): the K tile and the V^T tile are written to LDS already split into (hi, lo) bf16 halves
+    // (common.hpp stage_x_piece: a staged tile is read by every query tile of the workgroup) and the query fragments are split once per
+    // query tile, so a score MFMA pair has no conversion in front of it and a PV pair only the split of its probabilities - the in-loop
+    // form split all four operands per 16-byte piece: ~380 of the ~500 VALU instructions of a 64-key tile against 32 MFMAs.
+    constexpr bool kStage = (COBEVT_F32_SPLIT == 1) && !Elem<T>::kIsBf16;
+    auto dup_split = [](const uint4& x, uint4& hh, uint4& ll) {           // {x0..x3} -> {hi01, hi23, hi01, hi23}, {lo01, lo23, lo01, lo23}
+        uint32_t h01, h23, l01, l23;
+        split_bf16_pair(__uint_as_float(x.x), __uint_as_float(x.y), h01, l01);
+        split_bf16_pair(__uint_as_float(x.z), __uint_as_float(x.w), h23, l23);
+        hh = make_uint4(h01, h23, h01, h23);
+        ll = make_uint4(l01, l23, l01, l23);
+    };
+    auto mfma_staged_pair = [](const uint4& a_staged, const uint4& b_hh, const uint4& b_ll, f32x16& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_staged), __builtin_bit_cast(bf16x8, b_hh), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_staged), __builtin_bit_cast(bf16x8, b_ll), acc, 0, 0, 0);
+    };
     uint4 qf[NG];
+    uint4 qhh[kStage ? NG : 1], qll[kStage ? NG : 1];
     auto load_q = [&](int cam) {
         TokCoord c = qc;
         c.cam += cam;
@@ -90,6 +107,10 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
 #pragma unroll
         for (int g = 0; g < NG; ++g)
             qf[g] = q_ok ? *(const uint4*)(qrow + g * (2 * CH) + h * CH) : make_uint4(0, 0, 0, 0);
+        if constexpr (kStage) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) dup_split(qf[g], qhh[g], qll[g]);
+        }
     };
     load_q(0);
     int q_cam = 0;
@@ -212,7 +233,8 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
         for (int it = 0; it < K_IT; ++it) {
             const int item = tid + it * 256;
             const int kk = item / CPR, cj = item - kk * CPR;
-            *(uint4*)(Ks + kk * L::kKRow + cj * 16) = kreg[it];
+            if constexpr (kStage) *(uint4*)(Ks + kk * L::kKRow + cj * 16) = stage_x_piece<T>(kreg[it]);
+            else *(uint4*)(Ks + kk * L::kKRow + cj * 16) = kreg[it];
             if (INFO && cj == 0) kinfo[kk] = ireg[it];
         }
 #pragma unroll
@@ -229,8 +251,22 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
             } else {
                 const int kk = item >> 3, dq = item & 7;
                 const uint32_t w[4] = {vreg[it].x, vreg[it].y, vreg[it].z, vreg[it].w};
+                if constexpr (kStage) {
+                    // the 16-byte operand piece of V^T row dh holds keys 4j .. 4j + 3 as {hi(k0,k1), hi(k2,k3), lo(k0,k1), lo(k2,k3)}:
+                    // this item's key is slot kk & 3 of piece kk >> 2 -> one 16-bit write into the hi half, one into the lo half
+                    uint32_t hi2[2], lo2[2];
+                    split_bf16_pair(__uint_as_float(w[0]), __uint_as_float(w[1]), hi2[0], lo2[0]);
+                    split_bf16_pair(__uint_as_float(w[2]), __uint_as_float(w[3]), hi2[1], lo2[1]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        unsigned char* d = Vts + (dq * 4 + e) * L::kVRow + (kk >> 2) * 16 + (kk & 3) * 2;
+                        *(uint16_t*)d = (uint16_t)(hi2[e >> 1] >> ((e & 1) * 16));
+                        *(uint16_t*)(d + 8) = (uint16_t)(lo2[e >> 1] >> ((e & 1) * 16));
+                    }
+                } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) *(uint32_t*)(Vts + (dq * 4 + e) * L::kVRow + kk * 4) = w[e];
+                }
             }
         }
     };
@@ -269,7 +305,8 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const uint4 a = *(const uint4*)(Ks + (s * 32 + ql) * L::kKRow + g * 32 + h * 16);
-                mfma_kgroup<T>(a, qf[g], st[s]);
+                if constexpr (kStage) mfma_staged_pair(a, qhh[g], qll[g], st[s]);
+                else mfma_kgroup<T>(a, qf[g], st[s]);
             }
         }
         // ---- softmax numerators in the base-2 domain: p = 2^(s*scale*log2e [+ bias*log2e] - m)
@@ -353,7 +390,13 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
                     pb.x = __float_as_uint(st[s][4 * u + 0]); pb.y = __float_as_uint(st[s][4 * u + 1]);
                     pb.z = __float_as_uint(st[s][4 * u + 2]); pb.w = __float_as_uint(st[s][4 * u + 3]);
                     const uint4 a = *(const uint4*)(Vts + ql * L::kVRow + (s * 32 + 8 * u + 4 * h) * 4);
-                    mfma_kgroup<T>(a, pb, ot);
+                    if constexpr (kStage) {
+                        uint4 phh, pll;
+                        dup_split(pb, phh, pll);
+                        mfma_staged_pair(a, phh, pll, ot);
+                    } else {
+                        mfma_kgroup<T>(a, pb, ot);
+                    }
                 }
             }
         }
