@@ -228,6 +228,35 @@ template <typename T> __device__ __forceinline__ void mfma_kgroup_staged(const u
     mfma_kgroup_xs<T>(ws, xs, acc);
 }
 
+// BOTH operands staged through LDS (the LDS-staged 3x3 kernel, the 128 x 128 dense-row kernel, the implicit GEMM): activations first.
+// Second library: both tiles hold the {hi01, hi23, lo01, lo23} form; x . w = (x_hi, x_lo) . (w_hi, w_lo) + (x_hi, x_lo) . (w_lo, w_hi) -
+// the second product takes the weight piece with its halves swapped (four register moves), so the loop has no conversion at all where the
+// in-loop split spent 36 VALU instructions per two MFMA pairs.  Third library: x staged, w in the duplicated form, one fp16 MFMA.
+template <typename T> __device__ __forceinline__ uint4 stage_ws_piece(const uint4& w) {
+    if constexpr (kXSplit<T>) {
+#if COBEVT_F32_SPLIT == 2
+        return dup_f16_piece(w);
+#else
+        return stage_x_piece<T>(w);
+#endif
+    } else {
+        return w;
+    }
+}
+template <typename T> __device__ __forceinline__ void mfma_kgroup_ss(const uint4& xs, const uint4& ws, f32x16& acc) {
+    if constexpr (kXSplit<T>) {
+#if COBEVT_F32_SPLIT == 2
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xs), __builtin_bit_cast(f16x8, ws), acc, 0, 0, 0);
+#else
+        const uint4 wsw = make_uint4(ws.z, ws.w, ws.x, ws.y);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xs), __builtin_bit_cast(bf16x8, ws), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xs), __builtin_bit_cast(bf16x8, wsw), acc, 0, 0, 0);
+#endif
+    } else {
+        mfma_kgroup<T, false>(xs, ws, acc);
+    }
+}
+
 // accumulator register r of the 32x32 C/D fragment -> row within the tile
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kConv3Threads) void conv3x3_kernel(Conv3Params p) {
     auto store_patch = [&]() {
 #pragma unroll
         for (int it = 0; it < P_IT; ++it)
-            if (plds[it] >= 0) *(uint4*)(patch + plds[it]) = pzero[it] ? make_uint4(0, 0, 0, 0) : preg[it];
+            if (plds[it] >= 0) *(uint4*)(patch + plds[it]) = pzero[it] ? make_uint4(0, 0, 0, 0) : stage_x_piece<T>(preg[it]);
     };
     auto load_w = [&](uint4 (&wreg)[W_IT], int step) {
 #pragma unroll
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kConv3Threads) void conv3x3_kernel(Conv3Params p) {
         unsigned char* wb = wbuf + buf * C::W_BYTES;
 #pragma unroll
         for (int it = 0; it < W_IT; ++it)
-            if (wlds[it] >= 0) *(uint4*)(wb + wlds[it]) = wzero[it] ? make_uint4(0, 0, 0, 0) : wreg[it];
+            if (wlds[it] >= 0) *(uint4*)(wb + wlds[it]) = wzero[it] ? make_uint4(0, 0, 0, 0) : stage_ws_piece<T>(wreg[it]);
     };
 
     f32x16 acc[2];
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kConv3Threads) void conv3x3_kernel(Conv3Params p) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) bf[b] = *(const uint4*)(pb + b * 32 * WSTR + g * 32);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) mfma_kgroup<T, false>(af, bf[b], acc[b]);    // A = pixels, B = weights
+            for (int b = 0; b < 2; ++b) mfma_kgroup_ss<T>(af, bf[b], acc[b]);    // A = pixels, B = weights (both staged: common.hpp)
         }
         if (step + 1 < nsteps) store_w(RS, buf ^ 1);
         if (tap == 8 && next_chunk) {

@@ -236,8 +236,8 @@ __global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams
     auto store_tile = [&]() {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            *(uint4*)(As + srow * kGrRow + (sub * 4 + j) * 16) = areg[j];
-            *(uint4*)(Ws + srow * kGrRow + (sub * 4 + j) * 16) = wreg[j];
+            *(uint4*)(As + srow * kGrRow + (sub * 4 + j) * 16) = stage_x_piece<T>(areg[j]);
+            *(uint4*)(Ws + srow * kGrRow + (sub * 4 + j) * 16) = stage_ws_piece<T>(wreg[j]);
         }
     };
 
@@ -265,8 +265,8 @@ __global__ __launch_bounds__(kGrThreads, 4) void gemm_rows_kernel(GemmRowsParams
             const uint4 af = *(const uint4*)(As + abase + g * 32);
             const uint4 b0 = *(const uint4*)(Ws + bbase + g * 32);
             const uint4 b1 = *(const uint4*)(Ws + bbase + 32 * kGrRow + g * 32);
-            mfma_kgroup<T, false>(af, b0, acc[0]);    // A = activation rows, B = weights
-            mfma_kgroup<T, false>(af, b1, acc[1]);
+            mfma_kgroup_ss<T>(af, b0, acc[0]);    // A = activation rows, B = weights (both staged: common.hpp)
+            mfma_kgroup_ss<T>(af, b1, acc[1]);
         }
     }
     COBEVT_GT_MARK(3);
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(kGrThreads, 2) void gemm_rows2_kernel(GemmRowsParam
             transform_a(kt);
             if (kt > 0) __syncthreads();              // the previous K-tile is consumed
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *(uint4*)(As + srow * kGrRow + (sub * 4 + j) * 16) = areg[j];
+            for (int j = 0; j < 4; ++j) *(uint4*)(As + srow * kGrRow + (sub * 4 + j) * 16) = stage_x_piece<T>(areg[j]);
             if (!resident_b) load_b(kt);
             __syncthreads();
             // next A rows: the following K-tile of this tile, or the first K-tile of the workgroup's next row tile
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(kGrThreads, 2) void gemm_rows2_kernel(GemmRowsParam
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) {
                         const uint4 af = *(const uint4*)(As + (wm * 64 + rt * 32 + ql) * kGrRow + h * 16 + g * 32);
-                        mfma_kgroup<T>(bfrag[g], af, acc[rt]);     // D = W . X^T : lane <-> row, registers <-> columns
+                        mfma_kgroup_xs<T>(bfrag[g], af, acc[rt]);     // D = W . X^T : lane <-> row, registers <-> columns (A rows staged: common.hpp)
                     }
                     if (Elem<T>::kIsBf16) {                        // pin "read, MFMA": unpinned, LLVM hoists all 16 fragment
 #pragma unroll                                                      // reads (64 VGPRs) above the MFMAs

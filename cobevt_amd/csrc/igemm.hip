@@ -194,11 +194,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         unsigned char* Bs = smem[buf] + BM * kRowBytes;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it)
-            *(uint4*)(As + (rowp + 64 * it) * kRowBytes + j * 16) = a_reg[it];
+            *(uint4*)(As + (rowp + 64 * it) * kRowBytes + j * 16) = stage_x_piece<T>(a_reg[it]);
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             const int br = rowp + 64 * it;
-            if (br < BN) *(uint4*)(Bs + br * kRowBytes + j * 16) = b_reg[it];
+            if (br < BN) *(uint4*)(Bs + br * kRowBytes + j * 16) = stage_ws_piece<T>(b_reg[it]);
         }
     };
 
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b) mfma_kgroup<T, false>(af[a], bfr[b], acc[a][b]);    // A = gathered pixels, B = weights
+                for (int b = 0; b < TN; ++b) mfma_kgroup_ss<T>(af[a], bfr[b], acc[a][b]);    // A = gathered pixels, B = weights (both staged: common.hpp)
         }
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();

@@ -63,5 +63,5 @@ for mode in MODES:
         print("   %-12s %3d launches %8.3f ms  %7.1f TFLOP/s  %7.1f GB/s" % (fam, d["calls"], d["ms"], d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] else 0,
                                                                              d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] else 0))
     if mode != "bf16":
-        for k, d in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])[:14]:
+        for k, d in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("SPLIT_PROFILE_TOP", "14"))]:
             print("      %-60s %3d x %8.1f us  %7.1f TFLOP/s" % (k[:60], d["calls"], d["ms"] * 1e3 / d["calls"], d["flops"] / (d["ms"] * 1e-3) / 1e12))
