@@ -88,9 +88,11 @@ template <typename T, int NTW>
 __device__ __forceinline__ void bb_conv_chunk(const unsigned char* patch, const int (&aoff)[NTW], const bool (&ok)[NTW],
                                               int row_pitch, int pstr, const uint4* wsrc, int step0, int nstep,
                                               uint4 (&bq)[3][4], f32x16 (&acc)[NTW], int odd_off = -1) {
+    constexpr bool PACK = kXPack<T, 4>;                         // third library: one fp16 per activation, an A operand spans two k-groups (common.hpp)
+    constexpr int KGA = PACK ? 2 : 4, NG = 9 * KGA;
     uint4 af[3][NTW];
-    auto read_a = [&](uint4 (&dst)[NTW], int n) {               // n = tap * 4 + k-group (compile-time after unrolling)
-        const int tap = n >> 2, g = n & 3;
+    auto read_a = [&](uint4 (&dst)[NTW], int n) {               // n = tap * KGA + operand group (compile-time after unrolling)
+        const int tap = n / KGA, g = n % KGA;
         // odd_off >= 0: a stride-2 convolution out of a patch whose rows are de-interleaved by column parity ([even columns][odd
         // columns]; the lane base steps two patch rows / one plane pixel per output pixel): tap column 0 / 1 / 2 = even plane,
         // odd plane, even plane + 1 pixel
@@ -113,13 +115,18 @@ __device__ __forceinline__ void bb_conv_chunk(const unsigned char* patch, const 
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = tap * 4 + g;
-            if (n + 2 < 36) read_a(af[(n + 2) % 3], n + 2);
+        for (int g = 0; g < KGA; ++g) {
+            const int n = tap * KGA + g;
+            if (n + 2 < NG) read_a(af[(n + 2) % 3], n + 2);
+            uint4 wpk = make_uint4(0, 0, 0, 0);
+            if constexpr (PACK) wpk = pack_f16_pair(bq[tap % 3][(2 * g) & 3], bq[tap % 3][(2 * g + 1) & 3]);
 #pragma unroll
             for (int t = 0; t < NTW; ++t)
-                if (ok[t]) mfma_kgroup_xs<T>(bq[tap % 3][g], af[n % 3][t], acc[t]);   // D = W . X^T: lane <-> pixel, registers <-> couts
-            if (Elem<T>::kIsBf16 && n + 2 < 36) {
+                if (ok[t]) {
+                    if constexpr (PACK) mfma_f16_packed(wpk, af[n % 3][t], acc[t]);
+                    else mfma_kgroup_xs<T>(bq[tap % 3][g], af[n % 3][t], acc[t]);   // D = W . X^T: lane <-> pixel, registers <-> couts
+                }
+            if (Elem<T>::kIsBf16 && n + 2 < NG) {
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
             if (item < P1_ITEMS) {
                 const int pix = item / PIECES, j = item - pix * PIECES;
                 const int py = pix / P1W, px = pix - py * P1W;
-                const int lds = py * G::PITCH1 + px * PSTR1 + j * 16;
+                const int lds = py * G::PITCH1 + px * PSTR1 + (kXPack<T, 4> ? packed_piece_offset(j) : j * 16);
                 const int iy = oy0 - 2 + py, ix = ox0 - 2 + px;
                 const bool inside = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
                 if (inside) pgoff[it] = ((img * p.H + iy) * p.W + ix) * C + j * CH;
@@ -204,7 +211,10 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
 #pragma unroll
         for (int it = 0; it < P_IT; ++it)
             if (plds[it] >= 0)
-                *(uint4*)(patch1 + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : stage_x_piece<T>(preg[it]);
+            {
+                if constexpr (kXPack<T, 4>) *(uint2*)(patch1 + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint2(0, 0) : pack_f16_hi(preg[it]);
+                else *(uint4*)(patch1 + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : stage_x_piece<T>(preg[it]);
+            }
     };
     // weight fragments of this wave's cout tile: step s = chunk * 9 + tap -> 4 k-groups x 64 lanes
     uint4 bq[R][4];
@@ -298,6 +308,8 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
                 for (int e = 0; e < 4; ++e) v[e] = inside ? fmaxf(v[e], 0.f) : 0.f;
                 unsigned char* d = patch2 + ry * G::PITCH2 + rx * PSTR2 + (c0 + 8 * k) * Elem<T>::kBytes;
                 if constexpr (Elem<T>::kIsBf16) *(uint2*)d = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                else if constexpr (kXPack<T, 4>)        // channels c0 + 8k .. +3 = piece 2k + h of 128-byte chunk ct: its 8 bytes of the chunk's packed image
+                    *(uint2*)(patch2 + ry * G::PITCH2 + rx * PSTR2 + ct * 128 + packed_piece_offset(2 * k + h)) = make_uint2(pack_h2(v[0], v[1]), pack_h2(v[2], v[3]));
                 else *(uint4*)d = stage_x_piece<T>(make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
             }
         }

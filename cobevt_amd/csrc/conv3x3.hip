@@ -474,6 +474,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
     constexpr int PATCH_ITEMS = MT * STRIP_ITEMS;
     constexpr int P_IT = S == 1 ? (PATCH_ITEMS + NT - 1) / NT : 1;   // S = 2 refills the patch without resident registers
     constexpr int PF = 2, R = 3;
+    // third library, fp32 storage, an even number of k-groups per wave and tap: the patch holds ONE fp16 per activation and a 16-byte
+    // A operand spans two k-groups (common.hpp kXPack) - KGA operand groups per tap instead of KGW
+    constexpr bool PACK = kXPack<T, KGW>;
+    constexpr int KGA = PACK ? KGW / 2 : KGW;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* patch = smem;
@@ -528,7 +532,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
             const int s = item / STRIP_ITEMS, r = item - s * STRIP_ITEMS;
             const int pix = r / PIECES, j = r - pix * PIECES;
             const int py = pix / PW, px = pix - py * PW;
-            int lds = s * STRIP + py * PROW + px * PSTR + j * 16;
+            int lds = s * STRIP + py * PROW + px * PSTR + (PACK ? packed_piece_offset(j) : j * 16);
             const int4 sc = *(const int4*)&stab[s * 4];
             const int img = sc.x, sy = sc.y, sx = sc.z;
             const int vy = sy * 2 - 1 + py, vx = sx * 16 - 1 + px;
@@ -548,15 +552,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
     auto store_patch = [&](unsigned char* dst) {
 #pragma unroll
         for (int it = 0; it < P_IT; ++it)
-            if (plds[it] >= 0)
-                *(uint4*)(dst + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : stage_x_piece<T>(preg[it]);
+            if (plds[it] >= 0) {
+                if constexpr (PACK) *(uint2*)(dst + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint2(0, 0) : pack_f16_hi(preg[it]);
+                else *(uint4*)(dst + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : stage_x_piece<T>(preg[it]);
+            }
     };
     constexpr int PSN = 9 - COBEVT_CONV3_PSTORE_FIRST;               // taps that carry stores
     auto store_patch_part = [&](unsigned char* dst, int part) {      // one share of the pieces (part = 0 .. PSN - 1, compile-time after unrolling)
 #pragma unroll
         for (int it = 0; it < P_IT; ++it)
-            if (it % PSN == part && plds[it] >= 0)
-                *(uint4*)(dst + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : stage_x_piece<T>(preg[it]);
+            if (it % PSN == part && plds[it] >= 0) {
+                if constexpr (PACK) *(uint2*)(dst + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint2(0, 0) : pack_f16_hi(preg[it]);
+                else *(uint4*)(dst + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : stage_x_piece<T>(preg[it]);
+            }
     };
     auto load_b = [&](uint4 (&b)[KGW], int step) {
 #pragma unroll
@@ -577,7 +585,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
                     const int st = item / STRIP_ITEMS, r = item - st * STRIP_ITEMS;
                     const int pix = r / PIECES, j = r - pix * PIECES;
                     const int py = pix / PW, px = pix - py * PW;
-                    dst[u] = st * STRIP + py * PROW + (px & 1) * C::PLANE + (px >> 1) * PSTR + j * 16;
+                    dst[u] = st * STRIP + py * PROW + (px & 1) * C::PLANE + (px >> 1) * PSTR + (PACK ? packed_piece_offset(j) : j * 16);
                     const int4 sc = *(const int4*)&stab[st * 4];
                     if (sc.w) {
                         const int img = sc.x, sy = sc.y, sx = sc.z;
@@ -589,7 +597,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
             }
 #pragma unroll
             for (int u = 0; u < BATCH; ++u)
-                if (dst[u] >= 0) *(uint4*)(patch + dst[u]) = stage_x_piece<T>(v[u]);      // split(0) = 0: the padding stays zero
+                if (dst[u] >= 0) {                                                        // split(0) = 0: the padding stays zero
+                    if constexpr (PACK) *(uint2*)(patch + dst[u]) = pack_f16_hi(v[u]);
+                    else *(uint4*)(patch + dst[u]) = stage_x_piece<T>(v[u]);
+                }
         }
     };
 
@@ -599,7 +610,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
-    const int abase = (ql >> 4) * S * PROW + (ql & 15) * PSTR + h * 16 + ks * KGW * 32;
+    const int abase = (ql >> 4) * S * PROW + (ql & 15) * PSTR + h * 16 + ks * KGA * 32;
 
     uint4 bq[R][KGW];
     COBEVT_TRACE_MARK(0);
@@ -630,11 +641,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
         // fragment is requested 2 * MT MFMAs (>= 320 cycles) before its first use.  A wave alone on its SIMD then
         // keeps the MFMA pipe busy (the s_memtime trace showed the younger wave of each SIMD finishing a chunk ~2k
         // cycles after the older one with the A reads only one MFMA ahead of their use).
-        constexpr int NG = 9 * KGW;                      // k-groups of this wave per chunk
+        constexpr int NG = 9 * KGA;                      // A-operand groups of this wave per chunk
         static_assert(NG % 3 == 0, "A-fragment ring slots must be static");
         uint4 af[3][MT];
         auto read_a = [&](uint4 (&dst)[MT], int n) {     // n = group index inside the chunk (compile-time after unrolling)
-            const int t2 = n / KGW, g2 = n - t2 * KGW;
+            const int t2 = n / KGA, g2 = n - t2 * KGA;
             const int kh2 = t2 / 3, kw2 = t2 - kh2 * 3;
             const int toff = S == 1 ? kh2 * PROW + kw2 * PSTR : kh2 * PROW + (kw2 & 1) * C::PLANE + (kw2 >> 1) * PSTR;
             const unsigned char* pn = pbuf + toff + abase + g2 * 32;
@@ -661,12 +672,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < KGW; ++g) {
-                const int n = tap * KGW + g;
+            for (int g = 0; g < KGA; ++g) {
+                const int n = tap * KGA + g;
                 if (n + 2 < NG && (!(COBEVT_CONV3_KNOCK & 4) || chunk == 0)) read_a(af[(n + 2) % 3], n + 2);
+                uint4 wpk = make_uint4(0, 0, 0, 0);
+                if constexpr (PACK) wpk = pack_f16_pair(bq[tap % R][(2 * g) % KGW], bq[tap % R][(2 * g + 1) % KGW]);
 #pragma unroll
                 for (int a = 0; a < MT; ++a) {
                     if (COBEVT_CONV3_KNOCK & 2) acc[a][0] += __uint_as_float((af[n % 3][a].x ^ bq[tap % R][g].x) & 0x3fffffffu);
+                    else if constexpr (PACK) mfma_f16_packed(wpk, af[n % 3][a], acc[a]);
                     else mfma_kgroup_xs<T>(bq[tap % R][g], af[n % 3][a], acc[a]);   // D = W X^T: rows = couts, cols = pixels
                 }
                 if (Elem<T>::kIsBf16 && n + 2 < NG) {
