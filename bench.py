@@ -904,14 +904,15 @@ def main():
                     return q
                 safe(result, "fp32_parity_mode", split_mode)
 
-                # "fp32_fast" (round 6): fp32_split with the ResNet encoder's convolutions - 80 % of the frame's flops - on ONE fp16 MFMA
-                # per 16-byte piece (activations as fp16 (hi, lo) pairs split once at patch staging, folded weights as a single fp16 term;
-                # libcobevt_hip_f32h.so).  Still inside the north-star's 1e-3 (parity in `parity_fp32_fast`), not the 1e-5 of fp32_split.
+                # "fp32_fast" (round 6): fp32_split with the ResNet encoder's convolutions - 80 % of the frame's flops - on fp16 MFMAs with
+                # fp16 operands out of fp32 storage (weights one fp16 term; activations one fp16 value in the packed form - two k-groups per
+                # MFMA - or an fp16 (hi, lo) pair, converted once at patch staging; libcobevt_hip_f32h.so).  Still inside the north-star's
+                # 1e-3 (parity in `parity_fp32_fast`), not the 1e-5 of fp32_split.
                 def fast_mode():
                     with host.compute_dtype("fp32_fast"):
                         r2 = pipeline.CapturedCorpBEVT(model, batch, use_graph=not args.no_graph)
                         q = dict(quick(r2.step, 2, 20), note="one frame at a time from captured graphs; fp32 storage everywhere, ResNet encoder "
-                                 "convolutions as one v_mfma_f32_32x32x16_f16 per piece with fp16 weights (csrc/common.hpp COBEVT_F32_SPLIT == 2), "
+                                 "convolutions on v_mfma_f32_32x32x16_f16 with fp16 operands (csrc/common.hpp COBEVT_F32_SPLIT == 2), "
                                  "everything else on the split-bf16 path of fp32_parity_mode; parity in `parity_fp32_fast`")
                         outs["fp32_fast"] = {k: v.clone() for k, v in r2.step().items()}
                         if graph_ok_main:

@@ -20,11 +20,12 @@ def set_compute_dtype(dtype, matrix_path=None):
     2^-17 |x|: ~1e-5 end to end instead of 1e-6, at 4x the matrix rate; served by libcobevt_hip_f32s.so, cobevt_amd/build.py).
     The string "fp32_split" is shorthand for (torch.float32, "split_bf16").
     "fp32_fast" = (torch.float32, "split_bf16_enc_fp16") (round 6): as "fp32_split", except that the ResNet encoder's convolutions -
-    80 % of a frame's flops - take ONE v_mfma_f32_32x32x16_f16 per 16-byte piece: activations as fp16 (hi, lo) pairs (22 bits),
-    the folded weights as a single fp16 term (libcobevt_hip_f32h.so; csrc/common.hpp COBEVT_F32_SPLIT == 2).  Still fp32 storage
-    everywhere; ~3e-4 max-rel on the 5-agent frame (inside the north-star's 1e-3, not the 1e-5 of "fp32_split"), half the
-    encoder's matrix time.  Precondition: encoder activations and folded weights within fp16 range (|v| <= 65504), as under the
-    reference's own fp16 autocast (train_camera.py:157-160)."""
+    80 % of a frame's flops - run on v_mfma_f32_32x32x16_f16 with fp16 OPERANDS out of fp32 storage (libcobevt_hip_f32h.so;
+    csrc/common.hpp COBEVT_F32_SPLIT == 2): the folded weights as one fp16 term, the activations as one fp16 value where a wave owns
+    two k-groups per tap (the packed form: one MFMA per two k-groups - the strip kernels' 128-cout tiles, the BasicBlocks) and as an
+    fp16 (hi, lo) pair elsewhere (stem, 64-cout tiles, 1x1 shortcuts).  fp32 accumulation, fp32 storage, every residual added in
+    fp32; ~3e-4 max-rel on the 5-agent frame (inside the north-star's 1e-3, not the 1e-5 of "fp32_split").  Precondition: encoder
+    activations and folded weights within fp16 range (|v| <= 65504), as under the reference's own fp16 autocast (train_camera.py:157-160)."""
     global _COMPUTE_DTYPE, _MATRIX_PATH
     if isinstance(dtype, str):
         alias = {"bf16": (torch.bfloat16, "native"), "fp32": (torch.float32, "native"), "fp32_split": (torch.float32, "split_bf16"),

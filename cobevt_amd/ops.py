@@ -320,7 +320,7 @@ def ln_fusable(plan):
     return USE_GEMM_ROWS and plan.wgt_rows is not None and plan.K <= (128 if plan.code == BF16 else 64)
 
 
-def conv3_tiling(n, ho, wo, cin, cout, cc, cus=256, stride=1, bf16=True):
+def conv3_tiling(n, ho, wo, cin, cout, cc, cus=256, stride=1, bf16=True, packed=False):
     """Pick the 3x3 kernel / tile shape for one launch: 0 = the LDS-staged kernel (cobevt_conv3x3_nhwc), else the
     `variant` of cobevt_conv3x3_wfrag_nhwc (100 + 10*MT + bn64: MT strips of 2x16 pixels x 128|64 couts per workgroup).
     The LDS-staged kernel runs two workgroups per CU and wins once its grid is >= 2 per CU; below that the kernel time
@@ -342,7 +342,7 @@ def conv3_tiling(n, ho, wo, cin, cout, cc, cus=256, stride=1, bf16=True):
             return 0
         th, bn = (16, 64) if cout <= 64 else (8, 128)
         blocks_old = n * (-(-ho // th)) * (-(-wo // 16)) * (-(-cout // bn))
-        if blocks_old >= 2 * cus:
+        if blocks_old >= 2 * cus and not (packed and cout >= 128):      # (the LDS-staged kernel has no packed form)
             return 0
     nstrips = n * (-(-ho // 2)) * (-(-wo // 16))
     nsteps = 9 * (cin // cc)
@@ -351,7 +351,10 @@ def conv3_tiling(n, ho, wo, cin, cout, cc, cus=256, stride=1, bf16=True):
         tile_n = 64 if bn64 else 128
         for mt in (3, 4, 5, 6):
             blocks = -(-nstrips // mt) * -(-cout // tile_n)
-            cost = -(-blocks // cus) * (12000 + nsteps * mt * (tile_n // 32) * 40
+            # packed (third library, fp32 storage): the 128-cout tiles' waves own two k-groups per tap and issue ONE MFMA for both
+            # (csrc/common.hpp kXPack); the 64-cout tiles' waves own one and cannot
+            per_step = 20 if (packed and not bn64) else 40
+            cost = -(-blocks // cus) * (12000 + nsteps * mt * (tile_n // 32) * per_step
                                        + (1500 * mt * (cin // cc) if stride == 2 else 0))   # exposed patch refills
             if best is None or cost < best[0]:
                 best = (cost, 100 + 10 * mt + bn64)
@@ -449,7 +452,8 @@ def conv2d(x, plan, residual=None, out=None):
     # hundreds of registers, so that library's three stride-2 3x3 convs of a ResNet take the generic implicit GEMM)
     if plan.wfrag is not None and (out_h, out_w) == (ho, wo) and USE_CONV3X3 and USE_CONV3_WFRAG \
             and (plan.stride == 1 or (USE_CONV3_S2 and not (plan.code == FP32 and _L.get_variant() == "f32s"))):
-        variant = CONV3_VARIANT or conv3_tiling(n, ho, wo, cin, plan.cout, plan.cc3, stride=plan.stride, bf16=plan.code == BF16)
+        variant = CONV3_VARIANT or conv3_tiling(n, ho, wo, cin, plan.cout, plan.cc3, stride=plan.stride, bf16=plan.code == BF16,
+                                                packed=plan.code == FP32 and _L.get_variant() == "f32h")
         if variant == 0 and plan.stride == 2:
             variant = 151 if plan.cout <= 64 else 150
     if variant > 0:

@@ -23,8 +23,9 @@ torch.set_grad_enabled(False)
 # BF16: gate = max(1e-2, the reference's own bf16-autocast deviation), util.py.  "fp32_split": fp32 storage with every matrix
 # product on the split-bf16 MFMA path (libcobevt_hip_f32s.so, csrc/common.hpp) - the north-star's 1e-3 gate, like exact fp32
 MODES = [(torch.float32, 1e-3), (torch.bfloat16, BF16), ("fp32_split", 1e-3)]
-# "fp32_fast" (round 6): "fp32_split" with the ResNet encoder's convolutions on ONE fp16 MFMA per piece - activations as fp16
-# (hi, lo) pairs, the folded weights as a single fp16 term (libcobevt_hip_f32h.so).  Same max-norm gate (the north-star's 1e-3);
+# "fp32_fast" (round 6): "fp32_split" with the ResNet encoder's convolutions on fp16 MFMAs with fp16 operands out of fp32 storage
+# (weights one fp16 term; activations one fp16 value in the packed form, an fp16 (hi, lo) pair elsewhere; libcobevt_hip_f32h.so).
+# Same max-norm gate (the north-star's 1e-3);
 # every module outside the encoder runs the fp32_split library unchanged, so only encoder-containing tests take this mode.
 MODES_ENC = MODES + [("fp32_fast", 1e-3)]
 
@@ -283,8 +284,8 @@ def test_corpbevt_full_config_vs_oracle(cuda, agents):
     es, rs, ss = rel_err(ys, ref), rms_rel_err(ys, ref), class_margin_stats(ys, ref, 2)
     print("full CorpBEVT %d agents: fp32 storage / split-bf16 MFMA max-rel %.2e rms-rel %.2e argmax %.5f" % (agents, es, rs, ss["agreement"]))
     assert es <= 1e-3 and rs <= 1e-4 and ss["agreement"] >= 0.999
-    # "fp32_fast": fp16 weights in the encoder's convolutions only.  Max norm at the north-star's 1e-3; rms at 5e-4 (the CPU emulation
-    # of exactly this rounding, tests/precision_emul.py mode fp16_we: 2.7-2.8e-4 max-rel, 1.0-1.5e-4 rms-rel on this frame)
+    # "fp32_fast": fp16 operands in the encoder's convolutions only.  Max norm at the north-star's 1e-3; rms at 5e-4 (the CPU emulation
+    # of exactly this rounding, tests/precision_emul.py modes fp16_we / fp16_e2: 2.7-2.8e-4 max-rel, 1.0-1.5e-4 rms-rel on this frame)
     yf = got["fp32_fast"]["logits"]
     ef, rf, sf = rel_err(yf, ref), rms_rel_err(yf, ref), class_margin_stats(yf, ref, 2)
     print("full CorpBEVT %d agents: fp32 storage / encoder on one fp16 MFMA max-rel %.2e rms-rel %.2e argmax %.5f" % (agents, ef, rf, sf["agreement"]))
