@@ -11,7 +11,13 @@
  *   - plain C types only: device pointers (hipMalloc'ed / torch data_ptr()), ints, floats, a hipStream_t.
  *   - all work is enqueued asynchronously on `stream`; nothing is allocated, nothing synchronises.
  *   - return value: 0 = COBEVT_OK, otherwise an error code (see cobevt_strerror); on error nothing was launched.
- *   - dtype code: 0 = bf16 storage + bf16 MFMA + fp32 accumulate ; 1 = fp32 storage + fp32 MFMA (parity mode).
+ *   - dtype code: 0 = bf16 storage + bf16 MFMA + fp32 accumulate ; 1 = fp32 storage (parity modes); the matrix path of
+ *     dtype 1 is a property of the LIBRARY - the same sources and the same ABI are built three times (cobevt_amd/build.py):
+ *       libcobevt_hip.so       exact v_mfma_f32_32x32x2_f32
+ *       libcobevt_hip_f32s.so  every product as two v_mfma_f32_32x32x16_bf16 over (hi, lo) bf16 halves (-DCOBEVT_F32_SPLIT=1; ~1e-5 end to end)
+ *       libcobevt_hip_f32h.so  v_mfma_f32_32x32x16_f16 with fp16 operands, the weight-side operand as ONE fp16 term (-DCOBEVT_F32_SPLIT=2):
+ *                              the ResNet encoder's library under host.set_compute_dtype("fp32_fast"), not meant for any other launch
+ *     (csrc/common.hpp; dtype 0 is identical in all three).
  *   - activations are channels-last ("NHWC", token-major); weights are [Cout][Kpad] with
  *     k = (kh*Kw + kw)*Cin + c, zero padded to a multiple of 32 (bf16) / 16 (fp32) elements.
  */
