@@ -89,21 +89,26 @@ __device__ __forceinline__ void bb_conv_chunk(const unsigned char* patch, const 
                                               int row_pitch, int pstr, const uint4* wsrc, int step0, int nstep,
                                               uint4 (&bq)[3][4], f32x16 (&acc)[NTW], int odd_off = -1) {
     constexpr bool PACK = kXPack<T, 4>;                         // third library: one fp16 per activation, an A operand spans two k-groups (common.hpp)
-    constexpr int KGA = PACK ? 2 : 4, NG = 9 * KGA;
-    uint4 af[3][NTW];
-    auto read_a = [&](uint4 (&dst)[NTW], int n) {               // n = tap * KGA + operand group (compile-time after unrolling)
+    constexpr bool PACK3 = kXPack3<T, 4>;                       // second library: the three-term form on k-group pairs (hi and lo operands, two ring slots)
+    constexpr int KGA = (PACK || PACK3) ? 2 : 4, NG = 9 * KGA, RA = PACK3 ? 2 : 3;
+    uint4 af[RA][NTW];
+    uint4 al[PACK3 ? RA : 1][PACK3 ? NTW : 1];
+    auto read_a = [&](int slot, int n) {                        // n = tap * KGA + operand group (compile-time after unrolling)
         const int tap = n / KGA, g = n % KGA;
         // odd_off >= 0: a stride-2 convolution out of a patch whose rows are de-interleaved by column parity ([even columns][odd
         // columns]; the lane base steps two patch rows / one plane pixel per output pixel): tap column 0 / 1 / 2 = even plane,
         // odd plane, even plane + 1 pixel
         const int kw = tap % 3;
-        const int off = (tap / 3) * row_pitch + (odd_off < 0 ? kw * pstr : (kw == 1 ? odd_off : (kw == 2 ? pstr : 0))) + g * 32;      // row_pitch in bytes
+        const int off = (tap / 3) * row_pitch + (odd_off < 0 ? kw * pstr : (kw == 1 ? odd_off : (kw == 2 ? pstr : 0))) + g * (PACK3 ? 64 : 32);      // row_pitch in bytes
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
-            if (ok[t]) dst[t] = *(const uint4*)(patch + aoff[t] + off);
+            if (ok[t]) {
+                af[slot][t] = *(const uint4*)(patch + aoff[t] + off);
+                if constexpr (PACK3) al[slot][t] = *(const uint4*)(patch + aoff[t] + off + 16);
+            }
     };
-    read_a(af[0], 0);
-    read_a(af[1], 1);
+    read_a(0, 0);
+    if (RA == 3) read_a(1, 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -117,14 +122,16 @@ __device__ __forceinline__ void bb_conv_chunk(const unsigned char* patch, const 
 #pragma unroll
         for (int g = 0; g < KGA; ++g) {
             const int n = tap * KGA + g;
-            if (n + 2 < NG) read_a(af[(n + 2) % 3], n + 2);
-            uint4 wpk = make_uint4(0, 0, 0, 0);
+            if (n + RA - 1 < NG) read_a((n + RA - 1) % RA, n + RA - 1);
+            uint4 wpk = make_uint4(0, 0, 0, 0), wlo = make_uint4(0, 0, 0, 0);
             if constexpr (PACK) wpk = pack_f16_pair(bq[tap % 3][(2 * g) & 3], bq[tap % 3][(2 * g + 1) & 3]);
+            if constexpr (PACK3) split_w_pair(bq[tap % 3][(2 * g) & 3], bq[tap % 3][(2 * g + 1) & 3], wpk, wlo);
 #pragma unroll
             for (int t = 0; t < NTW; ++t)
                 if (ok[t]) {
-                    if constexpr (PACK) mfma_f16_packed(wpk, af[n % 3][t], acc[t]);
-                    else mfma_kgroup_xs<T>(bq[tap % 3][g], af[n % 3][t], acc[t]);   // D = W . X^T: lane <-> pixel, registers <-> couts
+                    if constexpr (PACK) mfma_f16_packed(wpk, af[n % RA][t], acc[t]);
+                    else if constexpr (PACK3) mfma_3term(wpk, wlo, af[n % RA][t], al[PACK3 ? n % RA : 0][PACK3 ? t : 0], acc[t]);
+                    else mfma_kgroup_xs<T>(bq[tap % 3][g], af[n % RA][t], acc[t]);   // D = W . X^T: lane <-> pixel, registers <-> couts
                 }
             if (Elem<T>::kIsBf16 && n + 2 < NG) {
 #pragma unroll
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
             if (item < P1_ITEMS) {
                 const int pix = item / PIECES, j = item - pix * PIECES;
                 const int py = pix / P1W, px = pix - py * P1W;
-                const int lds = py * G::PITCH1 + px * PSTR1 + (kXPack<T, 4> ? packed_piece_offset(j) : j * 16);
+                const int lds = py * G::PITCH1 + px * PSTR1 + (kXPack<T, 4> ? packed_piece_offset(j) : kXPack3<T, 4> ? packed3_piece_offset(j) : j * 16);
                 const int iy = oy0 - 2 + py, ix = ox0 - 2 + px;
                 const bool inside = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
                 if (inside) pgoff[it] = ((img * p.H + iy) * p.W + ix) * C + j * CH;
@@ -213,6 +220,7 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
             if (plds[it] >= 0)
             {
                 if constexpr (kXPack<T, 4>) *(uint2*)(patch1 + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint2(0, 0) : pack_f16_hi(preg[it]);
+                else if constexpr (kXPack3<T, 4>) store_piece_packed3(patch1 + (plds[it] & 0x3fffffff), preg[it], (plds[it] >> 30) != 0);
                 else *(uint4*)(patch1 + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : stage_x_piece<T>(preg[it]);
             }
     };
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
         int pr = tile * 32 + ql;
         if (pr >= R1) pr = R1 - 1;                              // padding lanes of the last tile compute a duplicate
         const int ry = pr / R1W, rx = pr - ry * R1W;
-        a1[t] = ry * G::PITCH1 + rx * PSTR1 + h * 16;
+        a1[t] = ry * G::PITCH1 + rx * PSTR1 + h * (kXPack3<T, 4> ? 32 : 16);
     }
     f32x16 acc1[T1W];
 
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
 #pragma unroll
     for (int t = 0; t < T2W; ++t) {
         const int tl = pg + t * NPG;
-        a2[t] = (tl * 2 + (ql >> 4)) * G::PITCH2 + (ql & 15) * PSTR2 + h * 16;
+        a2[t] = (tl * 2 + (ql >> 4)) * G::PITCH2 + (ql & 15) * PSTR2 + h * (kXPack3<T, 4> ? 32 : 16);
         t2_ok[t] = true;
     }
 #pragma unroll 1
@@ -310,6 +318,9 @@ __global__ __launch_bounds__(512, (C == 64 && TH_ == 8 && Elem<T>::kIsBf16) ? 4 
                 if constexpr (Elem<T>::kIsBf16) *(uint2*)d = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                 else if constexpr (kXPack<T, 4>)        // channels c0 + 8k .. +3 = piece 2k + h of 128-byte chunk ct: its 8 bytes of the chunk's packed image
                     *(uint2*)(patch2 + ry * G::PITCH2 + rx * PSTR2 + ct * 128 + packed_piece_offset(2 * k + h)) = make_uint2(pack_h2(v[0], v[1]), pack_h2(v[2], v[3]));
+                else if constexpr (kXPack3<T, 4>)
+                    store_piece_packed3(patch2 + ry * G::PITCH2 + rx * PSTR2 + ct * 128 + packed3_piece_offset(2 * k + h),
+                                        make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])), false);
                 else *(uint4*)d = stage_x_piece<T>(make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
             }
         }

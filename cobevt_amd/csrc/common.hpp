@@ -278,6 +278,36 @@ __device__ __forceinline__ void mfma_f16_packed(const uint4& w, const uint4& x, 
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
 }
 
+// THREE-TERM form on k-group pairs (second library): where a wave owns an even number of k-groups per tap, the staged
+// patch keeps the hi halves and the lo halves of a PAIR of k-groups as two separate 16-byte operands per lane half - {hi(2q): 4 values,
+// hi(2q + 1): 4 values} and the same for lo - and a pair of weight fragments is split the same way: w_hi . x_hi + w_hi . x_lo + w_lo . x_hi,
+// THREE v_mfma_f32_32x32x16_bf16 per two k-groups instead of four.  The dropped w_lo . x_lo term is 2^-16 of a product, the same order as
+// the operands' own 2^-17 residuals: ~2e-5 end to end instead of 1e-5.
+template <typename T, int KGW> constexpr bool kXPack3 = (COBEVT_F32_SPLIT == 1) && !Elem<T>::kIsBf16 && (KGW % 2 == 0);
+// byte offset of the hi half (8 bytes; the lo half sits 16 bytes further) of piece j = 2 * kgroup + half inside the image of a 128-byte chunk
+__device__ __forceinline__ constexpr int packed3_piece_offset(int j) { return (j >> 2) * 64 + (j & 1) * 32 + ((j >> 1) & 1) * 8; }
+__device__ __forceinline__ void store_piece_packed3(unsigned char* dst, const uint4& x, bool zero) {
+    uint32_t h01, h23, l01, l23;
+    split_bf16_pair(__uint_as_float(x.x), __uint_as_float(x.y), h01, l01);
+    split_bf16_pair(__uint_as_float(x.z), __uint_as_float(x.w), h23, l23);
+    *(uint2*)dst = zero ? make_uint2(0, 0) : make_uint2(h01, h23);
+    *(uint2*)(dst + 16) = zero ? make_uint2(0, 0) : make_uint2(l01, l23);
+}
+__device__ __forceinline__ void split_w_pair(const uint4& w0, const uint4& w1, uint4& wh, uint4& wl) {
+    uint32_t h[4], l[4];
+    split_bf16_pair(__uint_as_float(w0.x), __uint_as_float(w0.y), h[0], l[0]);
+    split_bf16_pair(__uint_as_float(w0.z), __uint_as_float(w0.w), h[1], l[1]);
+    split_bf16_pair(__uint_as_float(w1.x), __uint_as_float(w1.y), h[2], l[2]);
+    split_bf16_pair(__uint_as_float(w1.z), __uint_as_float(w1.w), h[3], l[3]);
+    wh = make_uint4(h[0], h[1], h[2], h[3]);
+    wl = make_uint4(l[0], l[1], l[2], l[3]);
+}
+__device__ __forceinline__ void mfma_3term(const uint4& wh, const uint4& wl, const uint4& xh, const uint4& xl, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh), __builtin_bit_cast(bf16x8, xh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh), __builtin_bit_cast(bf16x8, xl), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wl), __builtin_bit_cast(bf16x8, xh), acc, 0, 0, 0);
+}
+
 // accumulator register r of the 32x32 C/D fragment -> row within the tile
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

@@ -477,7 +477,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
     // third library, fp32 storage, an even number of k-groups per wave and tap: the patch holds ONE fp16 per activation and a 16-byte
     // A operand spans two k-groups (common.hpp kXPack) - KGA operand groups per tap instead of KGW
     constexpr bool PACK = kXPack<T, KGW>;
-    constexpr int KGA = PACK ? KGW / 2 : KGW;
+    // second library, same condition: the three-term form on k-group pairs - hi and lo operands of a pair as two 16-byte reads, an operand
+    // ring of two slots instead of three (the registers), three MFMAs per pair (common.hpp kXPack3)
+    constexpr bool PACK3 = kXPack3<T, KGW>;
+    constexpr int KGA = (PACK || PACK3) ? KGW / 2 : KGW;
+    constexpr int RA = PACK3 ? 2 : 3;                 // slots of the A-operand ring
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* patch = smem;
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
             const int s = item / STRIP_ITEMS, r = item - s * STRIP_ITEMS;
             const int pix = r / PIECES, j = r - pix * PIECES;
             const int py = pix / PW, px = pix - py * PW;
-            int lds = s * STRIP + py * PROW + px * PSTR + (PACK ? packed_piece_offset(j) : j * 16);
+            int lds = s * STRIP + py * PROW + px * PSTR + (PACK ? packed_piece_offset(j) : PACK3 ? packed3_piece_offset(j) : j * 16);
             const int4 sc = *(const int4*)&stab[s * 4];
             const int img = sc.x, sy = sc.y, sx = sc.z;
             const int vy = sy * 2 - 1 + py, vx = sx * 16 - 1 + px;
@@ -554,6 +558,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
         for (int it = 0; it < P_IT; ++it)
             if (plds[it] >= 0) {
                 if constexpr (PACK) *(uint2*)(dst + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint2(0, 0) : pack_f16_hi(preg[it]);
+                else if constexpr (PACK3) store_piece_packed3(dst + (plds[it] & 0x3fffffff), preg[it], (plds[it] >> 30) != 0);
                 else *(uint4*)(dst + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : stage_x_piece<T>(preg[it]);
             }
     };
@@ -563,6 +568,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
         for (int it = 0; it < P_IT; ++it)
             if (it % PSN == part && plds[it] >= 0) {
                 if constexpr (PACK) *(uint2*)(dst + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint2(0, 0) : pack_f16_hi(preg[it]);
+                else if constexpr (PACK3) store_piece_packed3(dst + (plds[it] & 0x3fffffff), preg[it], (plds[it] >> 30) != 0);
                 else *(uint4*)(dst + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : stage_x_piece<T>(preg[it]);
             }
     };
@@ -585,7 +591,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
                     const int st = item / STRIP_ITEMS, r = item - st * STRIP_ITEMS;
                     const int pix = r / PIECES, j = r - pix * PIECES;
                     const int py = pix / PW, px = pix - py * PW;
-                    dst[u] = st * STRIP + py * PROW + (px & 1) * C::PLANE + (px >> 1) * PSTR + (PACK ? packed_piece_offset(j) : j * 16);
+                    dst[u] = st * STRIP + py * PROW + (px & 1) * C::PLANE + (px >> 1) * PSTR + (PACK ? packed_piece_offset(j) : PACK3 ? packed3_piece_offset(j) : j * 16);
                     const int4 sc = *(const int4*)&stab[st * 4];
                     if (sc.w) {
                         const int img = sc.x, sy = sc.y, sx = sc.z;
@@ -599,6 +605,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
             for (int u = 0; u < BATCH; ++u)
                 if (dst[u] >= 0) {                                                        // split(0) = 0: the padding stays zero
                     if constexpr (PACK) *(uint2*)(patch + dst[u]) = pack_f16_hi(v[u]);
+                    else if constexpr (PACK3) store_piece_packed3(patch + dst[u], v[u], false);
                     else *(uint4*)(patch + dst[u]) = stage_x_piece<T>(v[u]);
                 }
         }
@@ -610,7 +617,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
-    const int abase = (ql >> 4) * S * PROW + (ql & 15) * PSTR + h * 16 + ks * KGA * 32;
+    const int abase = (ql >> 4) * S * PROW + (ql & 15) * PSTR + (PACK3 ? h * 32 + ks * KGA * 64 : h * 16 + ks * KGA * 32);
 
     uint4 bq[R][KGW];
     COBEVT_TRACE_MARK(0);
@@ -642,18 +649,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
         // keeps the MFMA pipe busy (the s_memtime trace showed the younger wave of each SIMD finishing a chunk ~2k
         // cycles after the older one with the A reads only one MFMA ahead of their use).
         constexpr int NG = 9 * KGA;                      // A-operand groups of this wave per chunk
-        static_assert(NG % 3 == 0, "A-fragment ring slots must be static");
-        uint4 af[3][MT];
-        auto read_a = [&](uint4 (&dst)[MT], int n) {     // n = group index inside the chunk (compile-time after unrolling)
+        uint4 af[RA][MT];
+        uint4 al[PACK3 ? RA : 1][PACK3 ? MT : 1];        // three-term form: the lo operands of the pair
+        auto read_a = [&](int slot, int n) {             // n = group index inside the chunk (compile-time after unrolling)
             const int t2 = n / KGA, g2 = n - t2 * KGA;
             const int kh2 = t2 / 3, kw2 = t2 - kh2 * 3;
             const int toff = S == 1 ? kh2 * PROW + kw2 * PSTR : kh2 * PROW + (kw2 & 1) * C::PLANE + (kw2 >> 1) * PSTR;
-            const unsigned char* pn = pbuf + toff + abase + g2 * 32;
+            const unsigned char* pn = pbuf + toff + abase + g2 * (PACK3 ? 64 : 32);
 #pragma unroll
-            for (int a = 0; a < MT; ++a) dst[a] = *(const uint4*)(pn + a * STRIP);
+            for (int a = 0; a < MT; ++a) {
+                af[slot][a] = *(const uint4*)(pn + a * STRIP);
+                if constexpr (PACK3) al[slot][a] = *(const uint4*)(pn + a * STRIP + 16);
+            }
         };
-        read_a(af[0], 0);
-        read_a(af[1], 1);
+        read_a(0, 0);
+        if (RA == 3) read_a(1, 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -674,14 +684,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
 #pragma unroll
             for (int g = 0; g < KGA; ++g) {
                 const int n = tap * KGA + g;
-                if (n + 2 < NG && (!(COBEVT_CONV3_KNOCK & 4) || chunk == 0)) read_a(af[(n + 2) % 3], n + 2);
-                uint4 wpk = make_uint4(0, 0, 0, 0);
+                if (n + RA - 1 < NG && (!(COBEVT_CONV3_KNOCK & 4) || chunk == 0)) read_a((n + RA - 1) % RA, n + RA - 1);
+                uint4 wpk = make_uint4(0, 0, 0, 0), wlo = make_uint4(0, 0, 0, 0);
                 if constexpr (PACK) wpk = pack_f16_pair(bq[tap % R][(2 * g) % KGW], bq[tap % R][(2 * g + 1) % KGW]);
+                if constexpr (PACK3) split_w_pair(bq[tap % R][(2 * g) % KGW], bq[tap % R][(2 * g + 1) % KGW], wpk, wlo);
 #pragma unroll
                 for (int a = 0; a < MT; ++a) {
-                    if (COBEVT_CONV3_KNOCK & 2) acc[a][0] += __uint_as_float((af[n % 3][a].x ^ bq[tap % R][g].x) & 0x3fffffffu);
-                    else if constexpr (PACK) mfma_f16_packed(wpk, af[n % 3][a], acc[a]);
-                    else mfma_kgroup_xs<T>(bq[tap % R][g], af[n % 3][a], acc[a]);   // D = W X^T: rows = couts, cols = pixels
+                    if (COBEVT_CONV3_KNOCK & 2) acc[a][0] += __uint_as_float((af[n % RA][a].x ^ bq[tap % R][g].x) & 0x3fffffffu);
+                    else if constexpr (PACK) mfma_f16_packed(wpk, af[n % RA][a], acc[a]);
+                    else if constexpr (PACK3) mfma_3term(wpk, wlo, af[n % RA][a], al[PACK3 ? n % RA : 0][PACK3 ? a : 0], acc[a]);
+                    else mfma_kgroup_xs<T>(bq[tap % R][g], af[n % RA][a], acc[a]);   // D = W X^T: rows = couts, cols = pixels
                 }
                 if (Elem<T>::kIsBf16 && n + 2 < NG) {
 #pragma unroll

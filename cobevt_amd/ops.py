@@ -320,7 +320,7 @@ def ln_fusable(plan):
     return USE_GEMM_ROWS and plan.wgt_rows is not None and plan.K <= (128 if plan.code == BF16 else 64)
 
 
-def conv3_tiling(n, ho, wo, cin, cout, cc, cus=256, stride=1, bf16=True, packed=False):
+def conv3_tiling(n, ho, wo, cin, cout, cc, cus=256, stride=1, bf16=True, packed=0):
     """Pick the 3x3 kernel / tile shape for one launch: 0 = the LDS-staged kernel (cobevt_conv3x3_nhwc), else the
     `variant` of cobevt_conv3x3_wfrag_nhwc (100 + 10*MT + bn64: MT strips of 2x16 pixels x 128|64 couts per workgroup).
     The LDS-staged kernel runs two workgroups per CU and wins once its grid is >= 2 per CU; below that the kernel time
@@ -353,7 +353,8 @@ def conv3_tiling(n, ho, wo, cin, cout, cc, cus=256, stride=1, bf16=True, packed=
             blocks = -(-nstrips // mt) * -(-cout // tile_n)
             # packed (third library, fp32 storage): the 128-cout tiles' waves own two k-groups per tap and issue ONE MFMA for both
             # (csrc/common.hpp kXPack); the 64-cout tiles' waves own one and cannot
-            per_step = 20 if (packed and not bn64) else 40
+            # (second library: three MFMAs per k-group pair instead of four on those tiles, kXPack3 - packed = 0.75)
+            per_step = int(40 * (float(packed) if packed else 1.0)) if (packed and not bn64) else 40
             cost = -(-blocks // cus) * (12000 + nsteps * mt * (tile_n // 32) * per_step
                                        + (1500 * mt * (cin // cc) if stride == 2 else 0))   # exposed patch refills
             if best is None or cost < best[0]:
@@ -453,7 +454,7 @@ def conv2d(x, plan, residual=None, out=None):
     if plan.wfrag is not None and (out_h, out_w) == (ho, wo) and USE_CONV3X3 and USE_CONV3_WFRAG \
             and (plan.stride == 1 or (USE_CONV3_S2 and not (plan.code == FP32 and _L.get_variant() == "f32s"))):
         variant = CONV3_VARIANT or conv3_tiling(n, ho, wo, cin, plan.cout, plan.cc3, stride=plan.stride, bf16=plan.code == BF16,
-                                                packed=plan.code == FP32 and _L.get_variant() == "f32h")
+                                                packed=(0.5 if _L.get_variant() == "f32h" else 0.75 if _L.get_variant() == "f32s" else 0) if plan.code == FP32 else 0)
         if variant == 0 and plan.stride == 2:
             variant = 151 if plan.cout <= 64 else 150
     if variant > 0:
