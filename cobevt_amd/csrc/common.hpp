@@ -210,22 +210,31 @@ template <typename T> __device__ __forceinline__ void mfma_kgroup_xs(const uint4
     }
 }
 
-// Both operands staged: a kernel that also keeps its WEIGHTS in LDS (the stem) converts them once with stage_w_piece where ONE staged form
-// serves (third library); in the second library a weight piece needs its (hi, hi) and (lo, lo) forms, so it stays raw and is split at use.
+// Both operands staged, weights first: a kernel that also keeps its WEIGHTS in LDS (the stem) converts them once with stage_w_piece - the
+// duplicated form in the third library, the (hi, lo) form in the second, whose second product takes the weight piece with its halves swapped.
 template <typename T> __device__ __forceinline__ uint4 stage_w_piece(const uint4& w) {
+    if constexpr (kXSplit<T>) {
 #if COBEVT_F32_SPLIT == 2
-    if constexpr (kXSplit<T>) return dup_f16_piece(w);
+        return dup_f16_piece(w);
+#else
+        return stage_x_piece<T>(w);          // {hi01, hi23, lo01, lo23}: the second product of mfma_kgroup_staged takes it with the halves swapped
 #endif
-    return w;
+    } else {
+        return w;
+    }
 }
 template <typename T> __device__ __forceinline__ void mfma_kgroup_staged(const uint4& ws, const uint4& xs, f32x16& acc) {
-#if COBEVT_F32_SPLIT == 2
     if constexpr (kXSplit<T>) {
+#if COBEVT_F32_SPLIT == 2
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ws), __builtin_bit_cast(f16x8, xs), acc, 0, 0, 0);
-        return;
-    }
+#else
+        const uint4 wsw = make_uint4(ws.z, ws.w, ws.x, ws.y);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ws), __builtin_bit_cast(bf16x8, xs), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wsw), __builtin_bit_cast(bf16x8, xs), acc, 0, 0, 0);
 #endif
-    mfma_kgroup_xs<T>(ws, xs, acc);
+    } else {
+        mfma_kgroup<T>(ws, xs, acc);
+    }
 }
 
 // BOTH operands staged through LDS (the LDS-staged 3x3 kernel, the 128 x 128 dense-row kernel, the implicit GEMM): activations first.
