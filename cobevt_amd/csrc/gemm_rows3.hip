@@ -252,11 +252,20 @@ __global__ __launch_bounds__(ROWS * 8, 4) void gemm_rows3_kernel(Gr3Params p) {
 using namespace cobevt;
 
 // C-ABI entry point, see include/cobevt_hip.h
+namespace cobevt {
+int launch_linear_rows_f32(const void* in, const void* wfrag, const float* bias, const void* residual, const float* pre_scale,
+                           const float* pre_shift, void* out, const long* dims, float ln_eps, hipStream_t stream);   // gemm_rows3_f32.hip
+}
+
 extern "C" int cobevt_linear_rows_small_k(const void* in, const void* wfrag, const float* bias, const void* residual,
                                           const float* pre_scale, const float* pre_shift, void* out, const long* dims, float ln_eps,
                                           hipStream_t stream) {
     // dims: [dtype(0), M, N, K, lda, pre_relu, act, ln, in_stride, src_H, src_W, in_H, in_W, rows_per_workgroup]
     if (!in || !wfrag || !out || !dims) return COBEVT_ERR_ARG;
+    if (dims[0] == 1) {                                  // fp32 storage: gemm_rows3_f32.hip (round 6)
+        const int rc = cobevt::launch_linear_rows_f32(in, wfrag, bias, residual, pre_scale, pre_shift, out, dims, ln_eps, stream);
+        return rc < 0 ? COBEVT_ERR_UNSUPPORTED : rc;
+    }
     if (dims[0] != 0) return COBEVT_ERR_UNSUPPORTED;
     Gr3Params p;
     p.in = (const bf16_t*)in; p.wfrag = (const uint4*)wfrag; p.bias = bias; p.residual = (const bf16_t*)residual;

@@ -31,6 +31,7 @@ USE_STEM_POOL = True  # stem conv + max pool in one launch (the stem map never r
 USE_STEM = True       # 7x7/s2 image stem through the space-to-depth kernel instead of the generic small-Cin igemm
 ROW_CHAIN_ROWS = 0     # rows per workgroup of the fused row chain: 0 = default (32), 64
 USE_ROW_CHAIN = True  # fuse out-proj + skip + pre-norm MLP (+ post-norm) after attention into one launch (bf16)
+USE_GEMM_ROWS3_F32 = True  # dense-row GEMMs of the fp32 modes on 32-row workgroups with fragment-ordered weights (csrc/gemm_rows3_f32.hip; round 6)
 USE_ROW_CHAIN_F32 = True  # ... and its fp32-storage form for C = 128 / hidden 256 (csrc/row_chain_f32.hip; round 6)
 BASICBLOCK_TILE_ROWS = 0   # 0 = kernel default; 8 | 16 pins the output tile height (tools/bb_probe.py)
 USE_BASICBLOCK = True  # stride-1 BasicBlocks on 64 / 128 channels as one launch (intermediate map stays in LDS)
@@ -426,6 +427,11 @@ def conv2d(x, plan, residual=None, out=None):
               and plan.K % 8 == 0 and (out_h, out_w) == (ho, wo) and plan.cout % 8 == 0 and plan.cout <= 4096 and sm == 0
               and not (plan.stride > 1 and (residual is not None or not GEMM_ROWS3_STRIDED))
               and not (ln and plan.kp_rows > 128) and n * ho * wo >= GEMM_ROWS3_MIN_M)
+        # ... and its fp32-storage form (round 6, csrc/gemm_rows3_f32.hip): K <= 512, the fused LayerNorm for K = 128
+        v3 = v3 or (USE_GEMM_ROWS3_F32 and plan.code == FP32 and plan.wfrag_rows is not None and plan.kp_rows <= 512 and plan.K % 4 == 0
+                    and (out_h, out_w) == (ho, wo) and plan.cout % 4 == 0 and plan.cout <= 4096 and sm == 0
+                    and not (plan.stride > 1 and residual is not None) and not (ln and plan.K != 128)
+                    and not (ln and plan.pre_scale is not None) and n * ho * wo >= GEMM_ROWS3_MIN_M)
         if v3:
             d3 = (ctypes.c_long * 14)(plan.code, n * ho * wo, plan.cout, plan.K, cin, plan.pre_relu, plan.act, int(ln),
                                       plan.stride, ho, wo, h, w,
