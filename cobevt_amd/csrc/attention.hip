@@ -86,8 +86,13 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
     // (common.hpp stage_x_piece: a staged tile is read by every query tile of the workgroup) and the query fragments are split once per
     // query tile, so a score MFMA pair has no conversion in front of it and a PV pair only the split of its probabilities - the in-loop
     // form split all four operands per 16-byte piece: ~380 of the ~500 VALU instructions of a 64-key tile against 32 MFMAs.
-    constexpr bool kStage = (COBEVT_F32_SPLIT == 1) && !Elem<T>::kIsBf16;
+    // Third library (round 6, "fp32_fast" routes the attention launches to it): K / V^T staged as fp16 (hi, lo) pairs, the query fragments
+    // and the probabilities as ONE fp16 term - a single fp16 MFMA per piece, four conversions per probability piece.  tests/precision_emul.py
+    // mode fp16_qp: rounding queries and probabilities to fp16 changes the 5-agent frame's logit error in the third digit (2.6-2.9e-4).
+    constexpr bool kStage = (COBEVT_F32_SPLIT != 0) && !Elem<T>::kIsBf16;
+    constexpr bool kStage16 = (COBEVT_F32_SPLIT == 2) && !Elem<T>::kIsBf16;
     auto dup_split = [](const uint4& x, uint4& hh, uint4& ll) {           // {x0..x3} -> {hi01, hi23, hi01, hi23}, {lo01, lo23, lo01, lo23}
+        if constexpr (kStage16) { hh = dup_f16_piece(x); ll = hh; return; }
         uint32_t h01, h23, l01, l23;
         split_bf16_pair(__uint_as_float(x.x), __uint_as_float(x.y), h01, l01);
         split_bf16_pair(__uint_as_float(x.z), __uint_as_float(x.w), h23, l23);
@@ -95,8 +100,12 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
         ll = make_uint4(l01, l23, l01, l23);
     };
     auto mfma_staged_pair = [](const uint4& a_staged, const uint4& b_hh, const uint4& b_ll, f32x16& acc) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_staged), __builtin_bit_cast(bf16x8, b_hh), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_staged), __builtin_bit_cast(bf16x8, b_ll), acc, 0, 0, 0);
+        if constexpr (kStage16) {       // b_hh = the duplicated fp16 form {b, b / 2^s} (common.hpp dup_f16_piece); b_ll unused
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_staged), __builtin_bit_cast(f16x8, b_hh), acc, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_staged), __builtin_bit_cast(bf16x8, b_hh), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_staged), __builtin_bit_cast(bf16x8, b_ll), acc, 0, 0, 0);
+        }
     };
     uint4 qf[NG];
     uint4 qhh[kStage ? NG : 1], qll[kStage ? NG : 1];
@@ -255,8 +264,8 @@ __global__ __launch_bounds__(512) void attn_gather_kernel(AttnParams p) {
                     // the 16-byte operand piece of V^T row dh holds keys 4j .. 4j + 3 as {hi(k0,k1), hi(k2,k3), lo(k0,k1), lo(k2,k3)}:
                     // this item's key is slot kk & 3 of piece kk >> 2 -> one 16-bit write into the hi half, one into the lo half
                     uint32_t hi2[2], lo2[2];
-                    split_bf16_pair(__uint_as_float(w[0]), __uint_as_float(w[1]), hi2[0], lo2[0]);
-                    split_bf16_pair(__uint_as_float(w[2]), __uint_as_float(w[3]), hi2[1], lo2[1]);
+                    split_pair_staged(__uint_as_float(w[0]), __uint_as_float(w[1]), hi2[0], lo2[0]);
+                    split_pair_staged(__uint_as_float(w[2]), __uint_as_float(w[3]), hi2[1], lo2[1]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         unsigned char* d = Vts + (dq * 4 + e) * L::kVRow + (kk >> 2) * 16 + (kk & 3) * 2;

@@ -702,7 +702,9 @@ def window_attention(q, k, v, out, qmap, kmap, omap, batch, heads, scale, ldq, l
     ks = ATTN_KSPLIT if ksplit is None else int(ksplit)
     use_ks = (ks > 1 and not mean_q and nk_ >= 1024 and batch * L * heads * ((nq_ + 127) // 128) * ks <= 1024
               and out.is_contiguous() and ldo == out.shape[-1] and ooff == 0 and omap[1] == qmap[1])
-    with _timed("attention|B%d L%d h%d Nq%d Nk%d%s" % (batch, L, heads, nq_, nk_, " ks%d" % ks if use_ks else ""), cost):
+    # "fp32_fast": the attention launches go to the third library as well (lib.encoder_scope() is a no-op in every other mode) - fp16
+    # queries / probabilities against fp16 (hi, lo) keys / values, csrc/attention.hip kStage16
+    with _L.encoder_scope(), _timed("attention|B%d L%d h%d Nq%d Nk%d%s" % (batch, L, heads, nq_, nk_, " ks%d" % ks if use_ks else ""), cost):
         if use_ks:
             rows = out.numel() // out.shape[-1]
             part_out = torch.empty((ks, rows, heads * 32), device=out.device, dtype=out.dtype)

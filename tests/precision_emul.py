@@ -14,6 +14,7 @@ length >= 8 are touched: the camera-geometry products (K = 3 / 4) are fp32 VALU 
                       everything else exact; fp16_w1 = the complement (1x1 / Linear / attention products only)
             fp16_we   fp16_w on the ResNet encoder's k x k convolutions only (80 % of the frame's flops)
             fp16_e2   BOTH operands fp16 in the ResNet encoder's k x k convolutions only (would run them at the bf16 kernels' matrix rate)
+            fp16_qp   fp16_e2 plus, in the attention products only, the FIRST operand (queries; probabilities) rounded to fp16, keys / values exact
             bf16      both operands rounded to bf16 (calibration: the shipped bf16 mode measures 1.06e-2 / 4.5e-3 on this frame)
 
 This is a tool (it imports oracle/ as the thing evaluated, like bench.py's cpu_baseline leg); the product never does.
@@ -48,7 +49,9 @@ class OperandRounding(TorchFunctionMode):
 
     def _pair(self, a, w):
         m = self.mode
-        if m in ("fp16", "bf16", "fp16_st", "fp16_e2"):
+        if m == "fp16_qp" and getattr(self, "_in_matmul", False):
+            return _r(a, self.dt), w
+        if m in ("fp16", "bf16", "fp16_st", "fp16_e2", "fp16_qp"):
             return _r(a, self.dt), _r(w, self.dt)
         if m in ("fp16_w", "fp16_w3", "fp16_w1", "fp16_we"):
             return a, _r(w, self.dt)
@@ -64,14 +67,14 @@ class OperandRounding(TorchFunctionMode):
         if func is F.conv2d:
             x, w = args[0], args[1]
             big = w.shape[2] * w.shape[3] > 1
-            skip = (self.mode == "fp16_w3" and not big) or (self.mode == "fp16_w1" and big) or (self.mode in ("fp16_we", "fp16_e2") and not (big and id(w) in self.encoder_ids))
+            skip = (self.mode == "fp16_w3" and not big) or (self.mode == "fp16_w1" and big) or (self.mode in ("fp16_we", "fp16_e2", "fp16_qp") and not (big and id(w) in self.encoder_ids))
             if w.shape[1] * w.shape[2] * w.shape[3] >= 8 and x.dtype == torch.float32 and not skip:
                 self.n += 1
                 x, w = self._pair(x, w)
                 return self._out(func(x, w, *args[2:], **kwargs))
         elif func is F.linear:
             x, w = args[0], args[1]
-            if w.shape[-1] >= 8 and x.dtype == torch.float32 and self.mode not in ("fp16_w3", "fp16_we", "fp16_e2"):
+            if w.shape[-1] >= 8 and x.dtype == torch.float32 and self.mode not in ("fp16_w3", "fp16_we", "fp16_e2", "fp16_qp"):
                 self.n += 1
                 x, w = self._pair(x, w)
                 return self._out(func(x, w, *args[2:], **kwargs))
@@ -79,9 +82,13 @@ class OperandRounding(TorchFunctionMode):
             a, b = args[0], args[1]
             if torch.is_tensor(a) and torch.is_tensor(b) and a.dtype == torch.float32 and a.shape[-1] >= 8 and self.mode not in ("fp16_w3", "fp16_we", "fp16_e2"):
                 self.n += 1
+                self._in_matmul = True
                 # attention products: q k^T (first = queries, second = keys), att v (first = probabilities, second = values);
                 # the device kernels feed K / V^T as the MFMA's A operand and Q / P^T as B - "weights" = the key / value side
-                a, b = self._pair(a, b)
+                try:
+                    a, b = self._pair(a, b)
+                finally:
+                    self._in_matmul = False
                 return self._out(func(a, b, *args[2:], **kwargs))
         return func(*args, **kwargs)
 
