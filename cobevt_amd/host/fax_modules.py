@@ -68,9 +68,12 @@ class Bottleneck(HipModule):
     def forward_nhwc(self, x, y1=None):
         if y1 is None and self.fusable(x):
             return ops.bottleneck(x, self.fused_plan())
-        y = ops.conv2d(x, self.entry_plan()) if y1 is None else y1
-        y = ops.conv2d(y, rt.conv_plan(self, "c2", self.conv2, self.bn2, act=1))
-        return ops.conv2d(y, rt.conv_plan(self, "c3", self.conv3, self.bn3, act=1), residual=x)
+        p1, p2, p3 = self.entry_plan(), rt.conv_plan(self, "c2", self.conv2, self.bn2, act=1), rt.conv_plan(self, "c3", self.conv3, self.bn3, act=1)
+        if ops.bottleneck_f32_fusable(x, p1, p2, p3, y1):       # fp32 storage: one launch (csrc/bottleneck_f32.hip), conv1 from the producer if it made it
+            return ops.bottleneck_f32(x, p1, p2, p3, y1)
+        y = ops.conv2d(x, p1) if y1 is None else y1
+        y = ops.conv2d(y, p2)
+        return ops.conv2d(y, p3, residual=x)
 
     def forward(self, x):
         if self.training:

@@ -83,6 +83,7 @@ SIGNATURES = {
                                          ctypes.c_int, ctypes.c_int, _vp]),
     "cobevt_agent_max": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long, _vp]),
     "cobevt_bottleneck_nhwc": (ctypes.c_int, [_vp] * 8 + [_c_int_p, _vp]),
+    "cobevt_bottleneck_f32_nhwc": (ctypes.c_int, [_vp] * 9 + [_c_int_p, _vp]),
     "cobevt_attention_index_map": (ctypes.c_int, [_c_int_p, ctypes.c_int, _vp, _vp]),
     "cobevt_attention_bias_index": (ctypes.c_int, [_c_int_p, _c_int_p, ctypes.c_int, _vp, _vp]),
     "cobevt_depthwise_conv_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp]),

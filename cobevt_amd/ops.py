@@ -31,6 +31,7 @@ USE_STEM_POOL = True  # stem conv + max pool in one launch (the stem map never r
 USE_STEM = True       # 7x7/s2 image stem through the space-to-depth kernel instead of the generic small-Cin igemm
 ROW_CHAIN_ROWS = 0     # rows per workgroup of the fused row chain: 0 = default (32), 64
 USE_ROW_CHAIN = True  # fuse out-proj + skip + pre-norm MLP (+ post-norm) after attention into one launch (bf16)
+USE_BOTTLENECK_F32 = True  # the FAX Bottleneck(128, 32) as one launch in fp32 storage (csrc/bottleneck_f32.hip; round 6)
 USE_GEMM_ROWS3_F32 = True  # dense-row GEMMs of the fp32 modes on 32-row workgroups with fragment-ordered weights (csrc/gemm_rows3_f32.hip; round 6)
 USE_ROW_CHAIN_F32 = True  # ... and its fp32-storage form for C = 128 / hidden 256 (csrc/row_chain_f32.hip; round 6)
 BASICBLOCK_TILE_ROWS = 0   # 0 = kernel default; 8 | 16 pins the output tile height (tools/bb_probe.py)
@@ -600,6 +601,36 @@ def bottleneck(x, plan, tile_rows=0):
         rc = _L.load().cobevt_bottleneck_nhwc(_p(x), _p(plan.w1), _p(plan.w2), _p(plan.w3), _p(plan.b1), _p(plan.b2), _p(plan.b3),
                                               _p(out), dims, _stream())
     _L.check(rc, "cobevt_bottleneck_nhwc")
+    return out
+
+
+def bottleneck_f32_fusable(x, p1, p2, p3, y1=None):
+    """the fp32-storage Bottleneck(128, 32) as one launch (csrc/bottleneck_f32.hip; round 6): the three separate launches' own plans"""
+    return (USE_BOTTLENECK_F32 and x.dtype == torch.float32 and x.dim() == 4 and x.shape[3] == 128 and x.is_contiguous() and x.numel() < 2 ** 31
+            and p1.code == FP32 and p1.wfrag_rows is not None and (p1.K, p1.cout, p1.kp_rows, p1.act, p1.stride) == (128, 32, 128, 1, 1)
+            and not p1.has_ln and p1.pre_scale is None and p1.bias is not None
+            and p2.wfrag is not None and (p2.cin, p2.cout, p2.cc3, p2.stride, p2.act) == (32, 32, 32, 1, 1) and not p2.upsample
+            and p2.store_mode == 0 and p2.bias is not None
+            and p3.wfrag_rows is not None and (p3.K, p3.cout, p3.act, p3.stride) == (32, 128, 1, 1) and not p3.has_ln and p3.pre_scale is None
+            and p3.bias is not None
+            and (y1 is None or (y1.dtype == torch.float32 and y1.is_contiguous() and tuple(y1.shape) == tuple(x.shape[:3]) + (32,))))
+
+
+def bottleneck_f32(x, p1, p2, p3, y1=None):
+    """relu(conv3(relu(conv2(relu(conv1(x))))) + x) on (N, H, W, 128) fp32 channels-last; y1 = relu(conv1(x)) when the producer made it."""
+    _need_cuda(x, y1)
+    n, h, w, c = x.shape
+    out = torch.empty_like(x)
+    dims = _ints([n, h, w, p3.kp_rows // 8 * 64])
+
+    def cost():
+        m = n * h * w
+        return 2.0 * m * ((0 if y1 is not None else 128 * 32) + 32 * 32 * 9 + 32 * 128), float((2 * x.numel() + (y1.numel() if y1 is not None else 0)) * 4)
+
+    with _timed("bottleneck|%dx%dx%d%s" % (n, h, w, " y1" if y1 is not None else ""), cost):
+        rc = _L.load().cobevt_bottleneck_f32_nhwc(_p(x), _p(y1), _p(p1.wfrag_rows), _p(p1.bias), _p(p2.wfrag), _p(p2.bias),
+                                                  _p(p3.wfrag_rows), _p(p3.bias), _p(out), dims, _stream())
+    _L.check(rc, "cobevt_bottleneck_f32_nhwc")
     return out
 
 

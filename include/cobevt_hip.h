@@ -272,6 +272,17 @@ int cobevt_agent_max(const void* in, void* out, int dtype, int B, int L, long pe
 int cobevt_bottleneck_nhwc(const void* in, const void* w1, const void* w2, const void* w3, const float* b1, const float* b2,
                            const float* b3, void* out, const int* dims, hipStream_t stream);
 
+/*
+ * The same block for fp32 STORAGE (round 6, csrc/bottleneck_f32.hip; the matrix path is the library's): in (N, H, W, 128) fp32, out the same;
+ * y1 (N, H, W, 32) = ReLU(conv1(x) + b1) when the producer of x already computed it (the row chain's `next` projection), else null and the
+ * kernel computes conv1 on the tile's halo region itself.  w1frag / w3frag: the fp32 fragment tables of cobevt_linear_rows_small_k for the
+ * folded 32 x 128 / 128 x 32 matrices ([rows/32][Kp/8][64 lanes][16 bytes], Kp = K rounded up to 64), w2frag: the table of
+ * cobevt_conv3x3_wfrag_nhwc for the folded 3x3 ([tile][1 chunk][9 taps][4 k-groups][64 lanes][16 bytes]; tile 0 is used).
+ * dims (int32[4]): N, H, W, w3 tile stride in 16-byte units (= Kp / 8 * 64).
+ */
+int cobevt_bottleneck_f32_nhwc(const void* in, const void* y1, const void* w1frag, const float* b1, const void* w2frag, const float* b2,
+                               const void* w3frag, const float* b3, void* out, const int* dims, hipStream_t stream);
+
 /* Test hooks for the integer part of the attention kernels (north-star: window index arithmetic bit-exact), computed by the
  * same device functions the attention kernels use.  cobevt_attention_index_map: rows[b][l][t] (int32, B * X*Y * ncam*w1*w2) =
  * row of token t of window l in the (B*ncam, HH, WW) token matrix, for one token map {mode, ncam, HH, WW, w1, w2, X, Y}:

@@ -348,6 +348,52 @@ def test_bottleneck_fused(cuda, n, h, w, tile_rows):
     assert (y.float() - z.float()).abs().max().item() <= 1e-2 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("mode", ["fp32", "fp32_split"])
+@pytest.mark.parametrize("with_y1", [False, True])
+@pytest.mark.parametrize("n,h,w", [(2, 32, 32), (1, 21, 37), (3, 16, 48), (1, 5, 3), (5, 128, 128)])
+def test_bottleneck_fp32_storage(cuda, n, h, w, with_y1, mode):
+    """cobevt_bottleneck_f32_nhwc (round 6): the FAX ResNetBottleNeck(128) in fp32 storage as ONE launch - conv1 computed on the halo
+    region by the kernel, or taken from the producer (y1) - against the three launches it replaces (same library, 2e-5) and fp64 torch
+    (2e-4); ragged maps cover the zero padding and the partial tiles, the last case is the level-0 map"""
+    import torch.nn as nn
+    from cobevt_amd import host
+    from cobevt_amd.synth import fill_module_
+
+    class B(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1, self.bn1 = nn.Conv2d(128, 32, 1, bias=False), nn.BatchNorm2d(32)
+            self.conv2, self.bn2 = nn.Conv2d(32, 32, 3, 1, 1, bias=False), nn.BatchNorm2d(32)
+            self.conv3, self.bn3 = nn.Conv2d(32, 128, 1, bias=False), nn.BatchNorm2d(128)
+    m = fill_module_(B(), 5).eval()
+    f32 = torch.float32
+    p1 = ops.ConvPlan(m.conv1.weight, None, bn=m.bn1, act=1, dtype=f32, device=cuda)
+    p2 = ops.ConvPlan(m.conv2.weight, None, bn=m.bn2, stride=1, pad=1, act=1, dtype=f32, device=cuda)
+    p3 = ops.ConvPlan(m.conv3.weight, None, bn=m.bn3, act=1, dtype=f32, device=cuda)
+    x = procedural_input("bnk.x", (n, 128, h, w), 0)
+    xd = nhwc(x).to(cuda)
+    with host.compute_dtype(mode):
+        y1 = ops.conv2d(xd, p1) if with_y1 else None
+        assert ops.bottleneck_f32_fusable(xd, p1, p2, p3, y1)
+        with ops.LaunchProfile() as prof:
+            y = ops.bottleneck_f32(xd, p1, p2, p3, y1)
+        assert sum(d["calls"] for d in prof.summary().values()) == 1
+        z = ops.conv2d(ops.conv2d(ops.conv2d(xd, p1), p2), p3, residual=xd)
+    torch.cuda.synchronize()
+
+    def fold(conv, bn):
+        sc, sh = ops.bn_affine(bn)
+        return conv.weight.double() * sc[:, None, None, None].double(), sh.double()
+    (w1, b1), (w2, b2), (w3, b3) = fold(m.conv1, m.bn1), fold(m.conv2, m.bn2), fold(m.conv3, m.bn3)
+    xr = x.double()
+    ref = F.relu(F.conv2d(F.relu(F.conv2d(F.relu(F.conv2d(xr, w1, b1)), w2, b2, padding=1)), w3, b3) + xr)
+    s = ref.abs().max().item()
+    yd = y.permute(0, 3, 1, 2).double().cpu()
+    assert yd.shape == ref.shape and torch.isfinite(yd).all()
+    assert (yd - ref).abs().max().item() <= 2e-4 * s
+    assert (y.double() - z.double()).abs().max().item() <= 2e-5 * s
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("c,n,h,w", [(64, 2, 24, 40), (128, 3, 16, 16), (64, 1, 13, 21), (128, 2, 9, 35)])
 def test_basicblock_fused(cuda, dtype, c, n, h, w):
