@@ -19,6 +19,7 @@
 //     the two 8-byte column runs of the accumulator order and back;
 //   * waves never synchronise, so 12-16 independent waves per CU hide each other's load latency (the barrier-phased form ran
 //     157 us per launch, a 64-row tile costing ~20k cycles of mostly exposed round trips).
+#include <stdlib.h>
 #include "row_chain.hpp"
 
 namespace cobevt {
@@ -72,7 +73,9 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
 __device__ __forceinline__ float rbf(float x) { return bf2f(f2bf(x)); }          // the value a bf16 store would keep
 
 // NNT2: 32-column tiles of the next projection (Nn = 32 NNT2 <= 192; 0 = none).  NW waves per workgroup.
-template <int NNT2, int NW>
+// PF (round 6): the NEXT block's a / skip rows are requested before the current block's chain starts (32 more registers: four waves per
+// workgroup instead of six) - the shipped form, launch64 below.
+template <int NNT2, int NW, bool PF = false>
 __global__ __launch_bounds__(NW * 64, 2) void row_chain64_kernel(RowChainParams p, int nblk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint4* wl = (const uint4*)smem;
@@ -128,20 +131,38 @@ __global__ __launch_bounds__(NW * 64, 2) void row_chain64_kernel(RowChainParams 
     auto bias4 = [&](int table, int t, int k) { return *(const float4*)(sb + table + 32 * t + 8 * k + 4 * h); };
 
     const int nwaves = gridDim.x * NW;
+    uint4 afn[PF ? 4 : 1], skn[PF ? 4 : 1];
+    auto load_rows = [&](int blk, uint4 (&a4)[4], uint4 (&s4)[4]) {
+        const int m0 = blk * 32;
+        const int grow = m0 + ql < p.M ? m0 + ql : p.M - 1;          // tail block: clamped row (finite data, never stored)
+        const bf16_t* arow = p.a + (size_t)grow * 64;
+        const bf16_t* srow = p.skip + (size_t)grow * 64;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) a4[g] = *(const uint4*)(arow + 16 * g + 8 * h);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) s4[g] = *(const uint4*)(srow + 16 * g + 8 * h);
+    };
+    if constexpr (PF) {
+        const int b0 = blockIdx.x * NW + wave;
+        load_rows(b0 < nblk ? b0 : nblk - 1, (uint4(&)[4])afn, (uint4(&)[4])skn);
+    }
     for (int blk = blockIdx.x * NW + wave; blk < nblk; blk += nwaves) {
         asm volatile("" : "+v"(opq));
         const int m0 = blk * 32;
-        const int grow = m0 + ql < p.M ? m0 + ql : p.M - 1;          // tail block: clamped row (finite data, never stored)
         const bool live = m0 + ql < p.M;
-        const bf16_t* arow = p.a + (size_t)grow * 64;
-        const bf16_t* srow = p.skip + (size_t)grow * 64;
+        const int grow = live ? m0 + ql : p.M - 1;                   // tail block: clamped row (finite data, never stored)
 
         // ---- loads: a as natural B operands (k-group g: channels 16 g + 8 h ..), skip as 16-byte pieces
         uint4 af[4], sk[4];
+        if constexpr (PF) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) af[g] = *(const uint4*)(arow + 16 * g + 8 * h);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) sk[g] = *(const uint4*)(srow + 16 * g + 8 * h);
+            for (int g = 0; g < 4; ++g) { af[g] = afn[g]; sk[g] = skn[g]; }
+            const int nb = blk + nwaves;
+            load_rows(nb < nblk ? nb : nblk - 1, (uint4(&)[4])afn, (uint4(&)[4])skn);      // unconditional (clamped): in flight under this block's chain
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            load_rows(blk, af, sk);
+        }
 
         // ---- phase A: y = a . Wp^T + bp + skip, rounded to bf16 (what the unfused path stores)
         float y[2][16];
@@ -289,17 +310,25 @@ __global__ __launch_bounds__(NW * 64, 2) void row_chain64_kernel(RowChainParams 
     }
 }
 
-template <int NNT2> int launch64(const RowChainParams& p, hipStream_t stream) {
-    constexpr int NW = 6;                                  // 2 workgroups x 6 waves per CU = 3 waves per SIMD
+template <int NNT2, int NW, bool PF> int launch64v(const RowChainParams& p, hipStream_t stream) {
     static cobevt::PerDeviceOnce attr_once;
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)row_chain64_kernel<NNT2, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void*)row_chain64_kernel<NNT2, NW, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     }
     const int nblk = (p.M + 31) / 32;
     int blocks = (nblk + NW - 1) / NW;
     if (blocks > 512) blocks = 512;                        // persistent: two workgroups per CU walk the 32-row blocks
-    hipLaunchKernelGGL((row_chain64_kernel<NNT2, NW>), dim3((unsigned)blocks), dim3(NW * 64), kLdsBytes, stream, p, nblk);
+    hipLaunchKernelGGL((row_chain64_kernel<NNT2, NW, PF>), dim3((unsigned)blocks), dim3(NW * 64), kLdsBytes, stream, p, nblk);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+template <int NNT2> int launch64(const RowChainParams& p, hipStream_t stream) {
+    // Round 6, same-job A/B on the LiDAR FuseBEVT workload (profiles/r06_rc64_prefetch_ab.txt): the next block's rows prefetched under the
+    // current block's chain, 2 x 4 waves per CU at 192 VGPRs - 102 -> 87 us per launch (370 MB: 3.6 -> 4.25 TB/s), 525 -> 538 frames/s; the
+    // same prefetch with six waves per workgroup (one workgroup per CU fits) 103 us.  COBEVT_RC64_PREFETCH=0 selects the round-5 form.
+    static const int mode = [] { const char* e = getenv("COBEVT_RC64_PREFETCH"); return e ? atoi(e) : 1; }();
+    if (mode == 1) return launch64v<NNT2, 4, true>(p, stream);
+    if (mode == 2) return launch64v<NNT2, 6, true>(p, stream);
+    return launch64v<NNT2, 6, false>(p, stream);                    // 2 workgroups x 6 waves per CU = 3 waves per SIMD, no prefetch
 }
 
 }  // namespace
