@@ -15,7 +15,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libcobevt_hip.so")
 LIB_F32S = os.path.join(CSRC, "libcobevt_hip_f32s.so")
 LIB_F32H = os.path.join(CSRC, "libcobevt_hip_f32h.so")
-SOURCES = ["igemm.hip", "conv3x3.hip", "basicblock.hip", "bottleneck.hip", "bottleneck_f32.hip", "gemm_rows.hip", "gemm_rows3.hip", "gemm_rows3_f32.hip", "bev_query.hip", "row_chain.hip", "row_chain_f32.hip", "row_chain64.hip", "proj_chain128.hip", "proj_chain_k.hip", "swap_stage.hip", "stem7x7.hip", "attention.hip", "attention_resident.hip", "attention_bwd.hip", "train_rows.hip", "train_glue.hip", "train_prep.hip", "wgrad3.hip", "train_nusc.hip", "train_fax.hip", "elementwise.hip", "pairwise_fusion.hip", "postprocess.hip", "depthwise.hip", "peer_gather.hip", "calibrate.hip"]
+SOURCES = ["igemm.hip", "conv3x3.hip", "basicblock.hip", "bottleneck.hip", "bottleneck_f32.hip", "gemm_rows.hip", "gemm_rows3.hip", "gemm_rows3_f32.hip", "bev_query.hip", "row_chain.hip", "row_chain_f32.hip", "row_chain64.hip", "ln_linear64.hip", "proj_chain128.hip", "proj_chain_k.hip", "swap_stage.hip", "stem7x7.hip", "attention.hip", "attention_resident.hip", "attention_bwd.hip", "train_rows.hip", "train_glue.hip", "train_prep.hip", "wgrad3.hip", "train_nusc.hip", "train_fax.hip", "elementwise.hip", "pairwise_fusion.hip", "postprocess.hip", "depthwise.hip", "peer_gather.hip", "calibrate.hip"]
 HEADERS = ["common.hpp", "attn_common.hpp", "warp_common.hpp", "row_chain.hpp", "bev_query.hpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"]
 # per-source extra flags (none at present)

@@ -255,6 +255,8 @@ using namespace cobevt;
 namespace cobevt {
 int launch_linear_rows_f32(const void* in, const void* wfrag, const float* bias, const void* residual, const float* pre_scale,
                            const float* pre_shift, void* out, const long* dims, float ln_eps, hipStream_t stream);   // gemm_rows3_f32.hip
+int launch_ln_linear64(const void* in, const void* wfrag, const float* bias, void* out, int M, int N, int K, long lda, int act, float eps,
+                       hipStream_t stream);                                                                          // ln_linear64.hip
 }
 
 extern "C" int cobevt_linear_rows_small_k(const void* in, const void* wfrag, const float* bias, const void* residual,
@@ -282,6 +284,10 @@ extern "C" int cobevt_linear_rows_small_k(const void* in, const void* wfrag, con
     if ((pre_scale == nullptr) != (pre_shift == nullptr)) return COBEVT_ERR_ARG;
     if (p.ln && pre_scale) return COBEVT_ERR_UNSUPPORTED;
     if (p.act < 0 || p.act > 4) return COBEVT_ERR_ARG;
+    if (p.ln && !residual && !pre_scale && !p.pre_relu && p.in_stride == 1) {   // LayerNorm + Linear of a big 64-channel map: independent waves
+        const int rc = cobevt::launch_ln_linear64(in, wfrag, bias, out, p.M, p.N, p.K, p.lda, p.act, ln_eps, stream);
+        if (rc >= 0) return rc;
+    }
     const int rows = dims[13] == 64 ? 64 : 32;                     // dims[13]: rows per workgroup (0 = 32)
     const size_t lds = (size_t)rows * (p.Kp * 2 + 16) + (size_t)rows * kG3Row + (size_t)((p.N + 127) / 128) * 128 * 4;
     const unsigned blocks = (unsigned)((p.M + rows - 1) / rows);

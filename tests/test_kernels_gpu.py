@@ -542,6 +542,38 @@ def test_gemm_rows_fused_layernorm(cuda, dtype, k, n, rows):
     check(y, y2.float().cpu(), dtype, "gemm_rows vs igemm")
 
 
+@pytest.mark.parametrize("n,rows,act", [(192, 65536 + 37, 0), (64, 70000, 2), (160, 65536, 0)])
+def test_ln_linear64_big_map(cuda, n, rows, act):
+    """LayerNorm -> Linear on a big 64-channel map (>= 65,536 rows, the LiDAR encoder's first to_qkv) takes the independent-waves kernel
+    (ln_linear64.hip) inside cobevt_linear_rows_small_k: vs torch, and vs the generic dense-row kernel the same rows take in a smaller call
+    (rounding of the normalised row to bf16 may differ by one ulp where the two LayerNorm sums round differently, nothing more)."""
+    dtype, k = torch.bfloat16, 64
+    x = procedural_input("l64.x", (rows, k), 0, -2, 3)
+    w = procedural_input("l64.w", (n, k), 0) * math.sqrt(3.0 / k)
+    b = procedural_input("l64.b", (n,), 0, -0.2, 0.2)
+    g = 0.8 + 0.4 * procedural_input("l64.g", (k,), 0, 0, 1)
+    be = procedural_input("l64.be", (k,), 0, -0.2, 0.2)
+
+    class LN(object):
+        weight, bias, eps = g, be, 1e-5
+    plan = ops.ConvPlan(w, b, act=act, dtype=dtype, device=cuda, ln=LN)
+    xd = x.to(cuda).to(dtype)
+    y = ops.linear(xd, plan)
+    assert y.shape == (rows, n)
+    xhat = rnd(F.layer_norm(rnd(x, dtype), (k,), None, None, 1e-5), dtype)
+    ref = F.linear(xhat, plan.wgt_rows.float().cpu()[:, :k], plan.bias.cpu())
+    ref = F.gelu(ref) if act == 2 else ref
+    check(y, ref, dtype, "ln_linear64 n=%d" % n)
+    for lo in (0, rows - 4133):                            # the same rows through the generic kernel (below the size threshold)
+        y2 = ops.linear(xd[lo:lo + 4133].contiguous(), plan)
+        d = (y[lo:lo + 4133].float() - y2.float()).abs().max().item()
+        assert d <= 2.0 ** -7 * ref.abs().max().item(), d
+    # nothing written past the last row: a tail block's dead lanes must not store
+    buf = torch.full((rows + 64, n), 7.0, dtype=dtype, device=cuda)
+    ops.linear(xd, plan, out=buf[:rows])
+    assert (buf[rows:] == 7.0).all() and torch.equal(buf[:rows], y)
+
+
 @pytest.mark.parametrize("c,rows,batch,nn_", [(128, 96, 3, 128), (64, 50, 4, 0), (128, 1000, 2, 0)])
 def test_attn_mlp_chain_broadcast_skip(cuda, c, rows, batch, nn_):
     """skip = one (rows, C) slice shared by every batch entry (the learned BEV prior at the first pyramid level,
