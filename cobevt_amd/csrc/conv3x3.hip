@@ -407,6 +407,12 @@ static int launch_conv3(Conv3Params p, hipStream_t stream) {
 #ifndef COBEVT_CONV3_PSTORE_FIRST
 #define COBEVT_CONV3_PSTORE_FIRST 6      // spread form: the stores go out in equal shares over taps FIRST .. 8
 #endif
+#ifndef COBEVT_CONV3_CONT
+#define COBEVT_CONV3_CONT 1           // the A-operand ring runs on across channel chunks (bf16, stride 1, eight waves); 0 = restart it behind every chunk barrier
+#endif
+#ifndef COBEVT_CONV3_CONT_LEAD
+#define COBEVT_CONV3_CONT_LEAD 3      // CONT: taps between the request of the next chunk's patch and its first LDS store (as PLOAD_TAP 3 -> PSTORE_FIRST 6)
+#endif
 #ifndef COBEVT_CONV3_KNOCK
 #define COBEVT_CONV3_KNOCK 0          // tools/conv_probe.py builds knock-out copies of this file (never the product .so)
 #endif
@@ -482,6 +488,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
     constexpr bool PACK3 = kXPack3<T, KGW>;
     constexpr int KGA = (PACK || PACK3) ? KGW / 2 : KGW;
     constexpr int RA = PACK3 ? 2 : 3;                 // slots of the A-operand ring
+    // CONT: the ring does not restart at a chunk boundary.  A chunk is NG = 9 KGA operand groups, a multiple of the ring's three slots, so
+    // group NG + i of chunk c IS group i of chunk c + 1 in the same slot; the read of group m is issued while group m - 2 multiplies, so
+    // the chunk barrier (next patch complete, this one no longer read) sits in front of group NG - 2 = the first group of tap TB: the
+    // operands of the chunk's last two groups are in registers by then, and the reads issued under them take the next chunk's patch.
+    constexpr bool CONT = COBEVT_CONV3_CONT && S == 1 && !HALF && Elem<T>::kIsBf16 && (KGA == 1 || KGA == 2) && MT <= 5;   // MT = 6: the carried ring spills
+    constexpr int TB = CONT ? (9 * KGA - 2) / KGA : 9;               // the tap the chunk barrier stands in front of (8, or 7 for KGA = 1)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* patch = smem;
@@ -562,7 +574,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
                 else *(uint4*)(dst + (plds[it] & 0x3fffffff)) = (plds[it] >> 30) ? make_uint4(0, 0, 0, 0) : stage_x_piece<T>(preg[it]);
             }
     };
-    constexpr int PSN = 9 - COBEVT_CONV3_PSTORE_FIRST;               // taps that carry stores
+    constexpr int PSF = CONT ? TB - 3 : COBEVT_CONV3_PSTORE_FIRST;   // first tap that carries stores of the next chunk's patch
+    constexpr int PSN = TB - PSF;                                    // taps that carry stores
     auto store_patch_part = [&](unsigned char* dst, int part) {      // one share of the pieces (part = 0 .. PSN - 1, compile-time after unrolling)
 #pragma unroll
         for (int it = 0; it < P_IT; ++it)
@@ -636,7 +649,25 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
         oy = sc.y * 2 + ((px >> 4) & 1); ox = sc.z * 16 + (px & 15);
         return (sc.w != 0) & (oy < p.Ho) & (ox < p.Wo);
     };
-    constexpr int PLT = (S == 1 && !HALF) ? COBEVT_CONV3_PLOAD_TAP : 0;
+    constexpr int PLT = (S == 1 && !HALF) ? (CONT ? PSF - COBEVT_CONV3_CONT_LEAD : COBEVT_CONV3_PLOAD_TAP) : 0;
+    uint4 af[RA][MT];                                    // the A-operand ring (CONT: carried across chunks)
+    uint4 al[PACK3 ? RA : 1][PACK3 ? MT : 1];            // three-term form: the lo operands of the pair
+    auto read_a_from = [&](const unsigned char* pb, int slot, int n) {   // n = group index inside the chunk (compile-time after unrolling)
+        const int t2 = n / KGA, g2 = n - t2 * KGA;
+        const int kh2 = t2 / 3, kw2 = t2 - kh2 * 3;
+        const int toff = S == 1 ? kh2 * PROW + kw2 * PSTR : kh2 * PROW + (kw2 & 1) * C::PLANE + (kw2 >> 1) * PSTR;
+        const unsigned char* pn = pb + toff + abase + g2 * (PACK3 ? 64 : 32);
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            af[slot][a] = *(const uint4*)(pn + a * STRIP);
+            if constexpr (PACK3) al[slot][a] = *(const uint4*)(pn + a * STRIP + 16);
+        }
+    };
+    if (CONT) {
+        read_a_from(patch, 0, 0);
+        read_a_from(patch, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     auto run_chunk = [&](int chunk, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;          // the peeled last chunk: its residual loads ride at tap PLT too
         const bool more = chunk + 1 < nchunk;
@@ -649,26 +680,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
         // keeps the MFMA pipe busy (the s_memtime trace showed the younger wave of each SIMD finishing a chunk ~2k
         // cycles after the older one with the A reads only one MFMA ahead of their use).
         constexpr int NG = 9 * KGA;                      // A-operand groups of this wave per chunk
-        uint4 af[RA][MT];
-        uint4 al[PACK3 ? RA : 1][PACK3 ? MT : 1];        // three-term form: the lo operands of the pair
-        auto read_a = [&](int slot, int n) {             // n = group index inside the chunk (compile-time after unrolling)
-            const int t2 = n / KGA, g2 = n - t2 * KGA;
-            const int kh2 = t2 / 3, kw2 = t2 - kh2 * 3;
-            const int toff = S == 1 ? kh2 * PROW + kw2 * PSTR : kh2 * PROW + (kw2 & 1) * C::PLANE + (kw2 >> 1) * PSTR;
-            const unsigned char* pn = pbuf + toff + abase + g2 * (PACK3 ? 64 : 32);
-#pragma unroll
-            for (int a = 0; a < MT; ++a) {
-                af[slot][a] = *(const uint4*)(pn + a * STRIP);
-                if constexpr (PACK3) al[slot][a] = *(const uint4*)(pn + a * STRIP + 16);
-            }
-        };
-        read_a(0, 0);
-        if (RA == 3) read_a(1, 1);
-        __builtin_amdgcn_sched_barrier(0);
+        auto read_a = [&](int slot, int n) { read_a_from(pbuf, slot, n); };
+        if (!CONT) {
+            read_a(0, 0);
+            if (RA == 3) read_a(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int step = chunk * 9 + tap;
             if (chunk < 4) COBEVT_TRACE_MARK(2 + chunk * 9 + tap);
+            if (CONT && tap == TB) {                     // the next chunk's patch is complete; nobody reads this one any more (see CONT)
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #ifdef COBEVT_CONV3_SETPRIO
             // issue arbitration favours the older wave of a SIMD; alternate it per tap so both waves of a SIMD reach
             // the chunk barrier together instead of the younger one finishing its taps alone
@@ -684,7 +709,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
 #pragma unroll
             for (int g = 0; g < KGA; ++g) {
                 const int n = tap * KGA + g;
-                if (n + RA - 1 < NG && (!(COBEVT_CONV3_KNOCK & 4) || chunk == 0)) read_a((n + RA - 1) % RA, n + RA - 1);
+                if (n + RA - 1 < NG) { if (!(COBEVT_CONV3_KNOCK & 4) || chunk == 0) read_a((n + RA - 1) % RA, n + RA - 1); }
+                else if (CONT && !LAST && !(COBEVT_CONV3_KNOCK & 4)) read_a_from(pother, (n + RA - 1) % RA, n + RA - 1 - NG);
                 uint4 wpk = make_uint4(0, 0, 0, 0), wlo = make_uint4(0, 0, 0, 0);
                 if constexpr (PACK) wpk = pack_f16_pair(bq[tap % R][(2 * g) % KGW], bq[tap % R][(2 * g + 1) % KGW]);
                 if constexpr (PACK3) split_w_pair(bq[tap % R][(2 * g) % KGW], bq[tap % R][(2 * g + 1) % KGW], wpk, wlo);
@@ -695,7 +721,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
                     else if constexpr (PACK3) mfma_3term(wpk, wlo, af[n % RA][a], al[PACK3 ? n % RA : 0][PACK3 ? a : 0], acc[a]);
                     else mfma_kgroup_xs<T>(bq[tap % R][g], af[n % RA][a], acc[a]);   // D = W X^T: rows = couts, cols = pixels
                 }
-                if (Elem<T>::kIsBf16 && n + 2 < NG) {
+                if (Elem<T>::kIsBf16 && (n + 2 < NG || (CONT && !LAST))) {
 #pragma unroll
                     for (int a = 0; a < MT; ++a) {
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one ds_read ...
@@ -706,8 +732,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
             }
             // the other buffer has been free since the last barrier: write the next chunk's patch under taps 7-8
             if (S == 1 && !HALF && more && !LAST && !(COBEVT_CONV3_KNOCK & 8)) {
-                if (COBEVT_CONV3_PSTORE_SPREAD) {
-                    if (tap >= COBEVT_CONV3_PSTORE_FIRST) { store_patch_part(pother, tap - COBEVT_CONV3_PSTORE_FIRST); __builtin_amdgcn_sched_barrier(0); }
+                if (COBEVT_CONV3_PSTORE_SPREAD || CONT) {
+                    if (tap >= PSF && tap < TB) { store_patch_part(pother, tap - PSF); __builtin_amdgcn_sched_barrier(0); }
                 } else if (tap == 6) {
                     store_patch(pother);
                     __builtin_amdgcn_sched_barrier(0);
@@ -723,7 +749,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
             cobevt_conv3_trace[49 + wave] |= (unsigned long long)((hw >> 4) & 3) << 60;
         }
 #endif
-        __syncthreads();
+        if (!CONT) __syncthreads();
         if (HALF && more) {                          // single patch buffer: every wave is done reading it, write the next chunk
             store_patch(pbuf);
             __syncthreads();
