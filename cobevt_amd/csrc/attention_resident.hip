@@ -95,6 +95,9 @@ template <int NT> struct ResLds {
 #define COBEVT_ATTN_PREFETCH 0
 #endif
 constexpr bool kPrefetch = COBEVT_ATTN_PREFETCH != 0;
+#ifndef COBEVT_ATTN_PIPE             // software-pipelined key loop of the eight-wave bias / mask variants (below); 0 = the per-tile loop everywhere
+#define COBEVT_ATTN_PIPE 1
+#endif
 template <int NT, int NW, bool MEAN, bool BIAS, bool MASK, bool RAGGED, bool W8 = false, bool PERSIST = false>
 // Register budget: the plain variants keep 4 waves per SIMD (35 KB of LDS -> 4 workgroups per CU); with a bias table / mask the
 // LDS footprint (>= 56 KB for the shipped windows) allows 2 waves per SIMD at most, so those variants may use 256 VGPRs.
@@ -103,6 +106,7 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
     constexpr int NKP = L::kNkp;
     constexpr int NTHR = NW * 64;
     constexpr bool INFO = BIAS || MASK;
+    constexpr bool PIPE = COBEVT_ATTN_PIPE != 0 && INFO && NW == 8;     // two waves per SIMD, 256-VGPR budget
     constexpr int NITEM = NKP * 4 / NTHR;              // staging items per thread (K: 16-byte chunks; V: key pair x dh quad)
     static_assert(NKP * 4 % NTHR == 0 && NITEM >= 1, "tile / workgroup shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -423,6 +427,91 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
 #pragma unroll
             for (int r = 0; r < 16; ++r) ot[r] = 0.f;
             l_run = 0.f;
+            if (PIPE && exact == 0) {
+                // ---- the regular pass, software-pipelined over 32-key sub-tiles.  The per-tile loop below is a dependent chain per tile -
+                // score MFMAs -> v_exp -> row-sum / PV MFMAs -> a wave-uniform branch on the tile's row sum - so a wave has either matrix
+                // or VALU work to issue, never both, and with two waves per SIMD (one 8-wave workgroup per CU: the 512-key windows) the
+                // two pipes were each ~60 % busy (747 cycles per 64-key tile and wave against 448 of MFMA issue / 456 of VALU).  Here the
+                // scores of sub-tile u + 1 are issued BEFORE the exponentials of sub-tile u, their LDS operands (K rows, bias quads, key
+                // mask word) one step earlier still, and nothing branches: the row sums accumulate on the matrix pipe over the whole task
+                // and the range check moves to its end (a task whose sum left [2^-80, 2^40] - or is not finite - is redone by the exact
+                // per-tile loop, exactly as a failed tile was).  Same arithmetic per score; the row sum is associated differently.
+                f32x16 lt;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lt[r] = 0.f;
+                const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+                const uint4 qa = make_uint4(qaugm, 0u, 0u, 0u);
+                // LDS operands of sub-tile u (0..3) of key-tile pair kp2v; st = the accumulator image (the bias tile, or zero)
+                auto sub_reads = [&](int kp2v, int u, uint4& a0, uint4& a1, uint32_t& ka, f32x16& st) {
+                    const int off = kp2v * (128 * 64) + u * (32 * 64);
+                    a0 = *(const uint4*)(kptr0 + off);
+                    a1 = *(const uint4*)(kptr1 + off);
+                    const int kt = kp2v * 128 + u * 32;
+                    if (BIAS) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 bb = W8 ? *(const f32x4*)(bias_qp + 16 * h + kp2v * 1920 + (u >> 1) * 960 + (u & 1) * 256 + g * 64)
+                                                : *(const f32x4*)(bias_qp + kinfo4[kt + 8 * g + 4 * h]);
+                            st[4 * g] = bb.x; st[4 * g + 1] = bb.y; st[4 * g + 2] = bb.z; st[4 * g + 3] = bb.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+                    }
+                    ka = kaug[2 * (kt + ql) + h];
+                };
+                auto sub_scores = [&](const uint4& a0, const uint4& a1, uint32_t ka, f32x16& st) {
+                    mfma_kgroup<bf16_t>(a0, qs0, st);
+                    mfma_kgroup<bf16_t>(a1, qs1, st);
+                    mfma_kgroup<bf16_t>(make_uint4(ka, 0u, 0u, 0u), qa, st);
+                };
+                f32x16 sc;
+                {
+                    uint4 a0, a1;
+                    uint32_t ka;
+                    sub_reads(0, 0, a0, a1, ka, sc);
+                    sub_scores(a0, a1, ka, sc);
+                }
+#pragma unroll 1
+                for (int kp2 = 0; kp2 < NT / 2; ++kp2) {
+                    const int kp2n = kp2 + 1 < NT / 2 ? kp2 + 1 : kp2;       // past the last pair: its first sub-tile again, never used
+                    const unsigned char* vp = vrow + kp2 * 256;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        f32x16 sn;
+                        uint4 b0, b1, va[2];
+                        uint32_t kb;
+                        sub_reads(u < 3 ? kp2 : kp2n, (u + 1) & 3, b0, b1, kb, sn);
+#pragma unroll
+                        for (int uu = 0; uu < 2; ++uu) {
+                            const uint32_t lowc = (uint32_t)((u >> 1) * 8 + ((u & 1) * 2 + uu) * 2) << 4;
+                            va[uu] = *(const uint4*)(vp + ((lowc | ((uint32_t)h << 4)) ^ vlow));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        float e[16];
+                        uint4 pA, pB;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) e[r] = __builtin_amdgcn_exp2f(sc[r]);
+                        pA = make_uint4(pack_bf2(e[0], e[1]), pack_bf2(e[2], e[3]), pack_bf2(e[4], e[5]), pack_bf2(e[6], e[7]));
+                        __builtin_amdgcn_sched_barrier(0);
+                        sub_scores(b0, b1, kb, sn);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int r = 8; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(sc[r]);
+                        pB = make_uint4(pack_bf2(e[8], e[9]), pack_bf2(e[10], e[11]), pack_bf2(e[12], e[13]), pack_bf2(e[14], e[15]));
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_kgroup<bf16_t>(ones, pA, lt);
+                        mfma_kgroup<bf16_t>(va[0], pA, ot);
+                        mfma_kgroup<bf16_t>(ones, pB, lt);
+                        mfma_kgroup<bf16_t>(va[1], pB, ot);
+                        __builtin_amdgcn_sched_barrier(0);
+                        sc = sn;
+                    }
+                }
+                l_run = lt[0];
+                if (!__any(!(l_run <= kHeadroom) || !(l_run >= kTiny))) break;
+                continue;                                   // redo this task exactly
+            }
             bool have_m = exact == 0;
             if (exact) m_run = -INFINITY;
             // two 64-key tiles per iteration: inside a pair every LDS address is a per-lane base + an immediate (the V^T swizzle
