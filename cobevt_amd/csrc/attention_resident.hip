@@ -106,7 +106,8 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
     constexpr int NKP = L::kNkp;
     constexpr int NTHR = NW * 64;
     constexpr bool INFO = BIAS || MASK;
-    constexpr bool PIPE = COBEVT_ATTN_PIPE != 0 && INFO && NW == 8;     // two waves per SIMD, 256-VGPR budget
+    // two waves per SIMD, 256-VGPR budget; COBEVT_ATTN_PIPE = 2 (probe builds): the camera-mean variant (level-0 cross attention) as well
+    constexpr bool PIPE = (COBEVT_ATTN_PIPE != 0 && INFO && NW == 8) || (COBEVT_ATTN_PIPE == 2 && MEAN && !RAGGED);
     constexpr int NITEM = NKP * 4 / NTHR;              // staging items per thread (K: 16-byte chunks; V: key pair x dh quad)
     static_assert(NKP * 4 % NTHR == 0 && NITEM >= 1, "tile / workgroup shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
                 // or VALU work to issue, never both, and with two waves per SIMD (one 8-wave workgroup per CU: the 512-key windows) the
                 // two pipes were each ~60 % busy (747 cycles per 64-key tile and wave against 448 of MFMA issue / 456 of VALU).  Here the
                 // scores of sub-tile u + 1 are issued BEFORE the exponentials of sub-tile u, their LDS operands (K rows, bias quads, key
-                // mask word) one step earlier still, and nothing branches: the row sums accumulate on the matrix pipe over the whole task
+                // mask word) a whole step earlier still, and nothing branches: the row sums accumulate on the matrix pipe over the whole task
                 // and the range check moves to its end (a task whose sum left [2^-80, 2^40] - or is not finite - is redone by the exact
                 // per-tile loop, exactly as a failed tile was).  Same arithmetic per score; the row sum is associated differently.
                 f32x16 lt;
@@ -454,34 +455,39 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
                                                 : *(const f32x4*)(bias_qp + kinfo4[kt + 8 * g + 4 * h]);
                             st[4 * g] = bb.x; st[4 * g + 1] = bb.y; st[4 * g + 2] = bb.z; st[4 * g + 3] = bb.w;
                         }
-                    } else {
+                    } else if (INFO) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) st[r] = 0.f;
                     }
-                    ka = kaug[2 * (kt + ql) + h];
+                    ka = INFO ? kaug[2 * (kt + ql) + h] : 0u;
                 };
                 auto sub_scores = [&](const uint4& a0, const uint4& a1, uint32_t ka, f32x16& st) {
+                    if (!INFO) st = mneg;                     // (the first MFMA's C operand)
                     mfma_kgroup<bf16_t>(a0, qs0, st);
                     mfma_kgroup<bf16_t>(a1, qs1, st);
-                    mfma_kgroup<bf16_t>(make_uint4(ka, 0u, 0u, 0u), qa, st);
+                    if (INFO) mfma_kgroup<bf16_t>(make_uint4(ka, 0u, 0u, 0u), qa, st);
                 };
-                f32x16 sc;
+                f32x16 sc, sn;
+                uint4 n0, n1;                               // operands of the sub-tile whose scores are issued next
+                uint32_t nk;
                 {
                     uint4 a0, a1;
                     uint32_t ka;
                     sub_reads(0, 0, a0, a1, ka, sc);
+                    sub_reads(0, 1, n0, n1, nk, sn);
                     sub_scores(a0, a1, ka, sc);
                 }
 #pragma unroll 1
                 for (int kp2 = 0; kp2 < NT / 2; ++kp2) {
-                    const int kp2n = kp2 + 1 < NT / 2 ? kp2 + 1 : kp2;       // past the last pair: its first sub-tile again, never used
+                    const int kp2n = kp2 + 1 < NT / 2 ? kp2 + 1 : kp2;       // past the last pair: its first sub-tiles again, never used
                     const unsigned char* vp = vrow + kp2 * 256;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        f32x16 sn;
-                        uint4 b0, b1, va[2];
-                        uint32_t kb;
-                        sub_reads(u < 3 ? kp2 : kp2n, (u + 1) & 3, b0, b1, kb, sn);
+                        // LDS reads: sub-tile u + 2's score operands (a whole step ahead of their MFMAs), this sub-tile's V^T fragments
+                        f32x16 sm;
+                        uint4 m0, m1, va[2];
+                        uint32_t mk;
+                        sub_reads(u < 2 ? kp2 : kp2n, (u + 2) & 3, m0, m1, mk, sm);
 #pragma unroll
                         for (int uu = 0; uu < 2; ++uu) {
                             const uint32_t lowc = (uint32_t)((u >> 1) * 8 + ((u & 1) * 2 + uu) * 2) << 4;
@@ -494,7 +500,7 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
                         for (int r = 0; r < 8; ++r) e[r] = __builtin_amdgcn_exp2f(sc[r]);
                         pA = make_uint4(pack_bf2(e[0], e[1]), pack_bf2(e[2], e[3]), pack_bf2(e[4], e[5]), pack_bf2(e[6], e[7]));
                         __builtin_amdgcn_sched_barrier(0);
-                        sub_scores(b0, b1, kb, sn);
+                        sub_scores(n0, n1, nk, sn);          // sub-tile u + 1
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int r = 8; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(sc[r]);
@@ -506,6 +512,7 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
                         mfma_kgroup<bf16_t>(va[1], pB, ot);
                         __builtin_amdgcn_sched_barrier(0);
                         sc = sn;
+                        sn = sm; n0 = m0; n1 = m1; nk = mk;
                     }
                 }
                 l_run = lt[0];
