@@ -467,6 +467,7 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
                     mfma_kgroup<bf16_t>(a1, qs1, st);
                     if (INFO) mfma_kgroup<bf16_t>(make_uint4(ka, 0u, 0u, 0u), qa, st);
                 };
+                constexpr bool AHEAD2 = INFO;               // operand reads two sub-tiles ahead (the 256-VGPR variants), else one
                 f32x16 sc, sn;
                 uint4 n0, n1;                               // operands of the sub-tile whose scores are issued next
                 uint32_t nk;
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
                     uint4 a0, a1;
                     uint32_t ka;
                     sub_reads(0, 0, a0, a1, ka, sc);
-                    sub_reads(0, 1, n0, n1, nk, sn);
+                    if (AHEAD2) sub_reads(0, 1, n0, n1, nk, sn);
                     sub_scores(a0, a1, ka, sc);
                 }
 #pragma unroll 1
@@ -487,7 +488,8 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
                         f32x16 sm;
                         uint4 m0, m1, va[2];
                         uint32_t mk;
-                        sub_reads(u < 2 ? kp2 : kp2n, (u + 2) & 3, m0, m1, mk, sm);
+                        if (AHEAD2) sub_reads(u < 2 ? kp2 : kp2n, (u + 2) & 3, m0, m1, mk, sm);
+                        else sub_reads(u < 3 ? kp2 : kp2n, (u + 1) & 3, n0, n1, nk, sn);
 #pragma unroll
                         for (int uu = 0; uu < 2; ++uu) {
                             const uint32_t lowc = (uint32_t)((u >> 1) * 8 + ((u & 1) * 2 + uu) * 2) << 4;
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
                         mfma_kgroup<bf16_t>(va[1], pB, ot);
                         __builtin_amdgcn_sched_barrier(0);
                         sc = sn;
-                        sn = sm; n0 = m0; n1 = m1; nk = mk;
+                        if (AHEAD2) { sn = sm; n0 = m0; n1 = m1; nk = mk; }
                     }
                 }
                 l_run = lt[0];
