@@ -91,10 +91,12 @@ template <int NT> struct ResLds {
 #ifndef COBEVT_ATTN_PLAIN_WAVES      // waves per SIMD the plain (no camera mean, no bias / mask) variants with >= 256 keys are compiled for
 #define COBEVT_ATTN_PLAIN_WAVES 3
 #endif
+#ifndef COBEVT_ATTN_PIPE_SUMV
+#define COBEVT_ATTN_PIPE_SUMV 1
+#endif
 #ifndef COBEVT_ATTN_PREFETCH
 #define COBEVT_ATTN_PREFETCH 0
 #endif
-constexpr bool kPrefetch = COBEVT_ATTN_PREFETCH != 0;
 #ifndef COBEVT_ATTN_PIPE             // software-pipelined key loop of the eight-wave bias / mask variants (below); 0 = the per-tile loop everywhere
 #define COBEVT_ATTN_PIPE 1
 #endif
@@ -188,9 +190,12 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
     uint4 kreg[NITEM];
     uint2 v0[NITEM], v1[NITEM];
     int krow[NITEM], vr0[NITEM], vr1[NITEM];
-    auto issue_item_loads = [&](int l_, int head_, int tidp) {
+    // part A: the table keys' coordinates / rows / mask words and the K rows; part B: the V rows.  kPrefetch == 2 issues part A of the NEXT
+    // item in front of the query loop (25 registers across it) and part B at the item's start, under the table arithmetic and the K staging
+    auto issue_item_loads = [&](int l_, int head_, int tidp, bool part_a, bool part_b) {
         const RowAffine kaff = row_affine(p.kmap, b, l_);
         auto key_row = [&](int tk) { return tk < p.Nk ? row_of(kaff, key_coord(tk)) : -1; };
+        if (part_a) {
 #pragma unroll
         for (int u = 0; u < NKT; ++u) {
             const int tk = tidp + u * NTHR;
@@ -210,7 +215,6 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
             }
         }
         const bf16_t* kbase = (const bf16_t*)p.k + p.koff + head_ * 32;
-        const bf16_t* vbase = (const bf16_t*)p.v + p.voff + head_ * 32;
 #pragma unroll
         for (int it = 0; it < NITEM; ++it) {
             const int si = tidp + it * NTHR;
@@ -220,17 +224,22 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
             // branch (vmcnt(0) per load = one serialised HBM round trip per staging item)
             kreg[it] = *(const uint4*)(kbase + (size_t)(krow[it] < 0 ? 0 : krow[it]) * p.ldk + cj * 8);
         }
+        }
+        if (part_b) {
+            const bf16_t* vbase = (const bf16_t*)p.v + p.voff + head_ * 32;
 #pragma unroll
-        for (int it = 0; it < NITEM; ++it) {
-            const int si = tidp + it * NTHR;
-            const int kp = si >> 3, dq = si & 7;
-            vr0[it] = key_row(2 * kp);
-            vr1[it] = key_row(2 * kp + 1);
-            v0[it] = *(const uint2*)(vbase + (size_t)(vr0[it] < 0 ? 0 : vr0[it]) * p.ldv + dq * 4);
-            v1[it] = *(const uint2*)(vbase + (size_t)(vr1[it] < 0 ? 0 : vr1[it]) * p.ldv + dq * 4);
+            for (int it = 0; it < NITEM; ++it) {
+                const int si = tidp + it * NTHR;
+                const int kp = si >> 3, dq = si & 7;
+                vr0[it] = key_row(2 * kp);
+                vr1[it] = key_row(2 * kp + 1);
+                v0[it] = *(const uint2*)(vbase + (size_t)(vr0[it] < 0 ? 0 : vr0[it]) * p.ldv + dq * 4);
+                v1[it] = *(const uint2*)(vbase + (size_t)(vr1[it] < 0 ? 0 : vr1[it]) * p.ldv + dq * 4);
+            }
         }
     };
-    if (kPrefetch || !PERSIST) issue_item_loads(l, head, tid);
+    constexpr int kPf = PERSIST ? COBEVT_ATTN_PREFETCH : 0;     // 0: none, 1: the whole next item, 2: its tables + K rows
+    if (kPf != 0 || !PERSIST) issue_item_loads(l, head, tid, true, kPf != 2);
     int head_built = -1;                               // (BIAS) the head whose table column the four copies in LDS hold
     bool first_item = true;
     do {
@@ -239,7 +248,8 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
     int tidp = tid;
     if (PERSIST) asm volatile("" : "+v"(tidp));
     if (!first_item) RES_MARK(0);
-    if (PERSIST && !kPrefetch) issue_item_loads(l, head, tidp);     // (unconditional: behind `!first_item` the staging registers
+    if (PERSIST && kPf == 2) issue_item_loads(l, head, tidp, false, true);
+    if (PERSIST && kPf == 0) issue_item_loads(l, head, tidp, true, true);     // (unconditional: behind `!first_item` the staging registers
     //                                                                    would be live around the back edge, i.e. across the query loop)
     const RowAffine qaff = row_affine(p.qmap, b, l), oaff = row_affine(p.omap, b, l);
     const bool build_bias = BIAS && head != head_built;
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
         // kPrefetch: the next item's global loads in flight under this item's query loop.  Measured with s_memtime marks
         // (tools/attn_trace.py --lidar, profiles/r05_attn_trace_lidar.txt): it takes the prologue from 12.8k to 3.9k cycles per item
         // but the ~50 registers it keeps live push the kernel from 171 to 251 VGPRs and the query loop from 24.2k to 31.3k cycles
-        if (kPrefetch) issue_item_loads(nl, nhead, tidp);
+        if (kPf != 0) issue_item_loads(nl, nhead, tidp, true, kPf != 2);
     }
 
     // ---- per-lane LDS read bases (everything else is an immediate offset)
@@ -440,6 +450,11 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
                 f32x16 lt;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) lt[r] = 0.f;
+                // SUMV: the row sums as packed fp32 adds of the exponentials (this lane's 16 keys of a sub-tile, the two half-waves meet
+                // once per task) instead of two ones(32 x 16) . P^T MFMAs per sub-tile: with the branches and the per-tile bookkeeping gone
+                // the matrix pipe (7 MFMAs = 224 cycles per sub-tile and wave) is the longer side, the VALU (~180) has the room
+                constexpr bool SUMV = COBEVT_ATTN_PIPE_SUMV != 0;
+                f32x2 ls2[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
                 const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
                 const uint4 qa = make_uint4(qaugm, 0u, 0u, 0u);
                 // LDS operands of sub-tile u (0..3) of key-tile pair kp2v; st = the accumulator image (the bias tile, or zero)
@@ -496,28 +511,39 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
                             va[uu] = *(const uint4*)(vp + ((lowc | ((uint32_t)h << 4)) ^ vlow));
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                        float e[16];
+                        f32x2 e2[8];                         // pairs: the row-sum adds below are v_pk_add_f32 on them
                         uint4 pA, pB;
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) e[r] = __builtin_amdgcn_exp2f(sc[r]);
-                        pA = make_uint4(pack_bf2(e[0], e[1]), pack_bf2(e[2], e[3]), pack_bf2(e[4], e[5]), pack_bf2(e[6], e[7]));
+                        for (int r = 0; r < 4; ++r) e2[r] = f32x2{__builtin_amdgcn_exp2f(sc[2 * r]), __builtin_amdgcn_exp2f(sc[2 * r + 1])};
+                        pA = make_uint4(pack_bf2(e2[0].x, e2[0].y), pack_bf2(e2[1].x, e2[1].y), pack_bf2(e2[2].x, e2[2].y), pack_bf2(e2[3].x, e2[3].y));
                         __builtin_amdgcn_sched_barrier(0);
                         sub_scores(n0, n1, nk, sn);          // sub-tile u + 1
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int r = 8; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(sc[r]);
-                        pB = make_uint4(pack_bf2(e[8], e[9]), pack_bf2(e[10], e[11]), pack_bf2(e[12], e[13]), pack_bf2(e[14], e[15]));
+                        for (int r = 4; r < 8; ++r) e2[r] = f32x2{__builtin_amdgcn_exp2f(sc[2 * r]), __builtin_amdgcn_exp2f(sc[2 * r + 1])};
+                        pB = make_uint4(pack_bf2(e2[4].x, e2[4].y), pack_bf2(e2[5].x, e2[5].y), pack_bf2(e2[6].x, e2[6].y), pack_bf2(e2[7].x, e2[7].y));
                         __builtin_amdgcn_sched_barrier(0);
-                        mfma_kgroup<bf16_t>(ones, pA, lt);
+                        if (SUMV) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r)     // (as inline asm: the register allocator then keeps the exponentials in aligned pairs)
+                                asm("v_pk_add_f32 %0, %1, %2" : "=v"(ls2[r & 3]) : "v"(ls2[r & 3]), "v"(e2[r]));
+                        } else {
+                            mfma_kgroup<bf16_t>(ones, pA, lt);
+                            mfma_kgroup<bf16_t>(ones, pB, lt);
+                        }
                         mfma_kgroup<bf16_t>(va[0], pA, ot);
-                        mfma_kgroup<bf16_t>(ones, pB, lt);
                         mfma_kgroup<bf16_t>(va[1], pB, ot);
                         __builtin_amdgcn_sched_barrier(0);
                         sc = sn;
                         if (AHEAD2) { sn = sm; n0 = m0; n1 = m1; nk = mk; }
                     }
                 }
-                l_run = lt[0];
+                if (SUMV) {
+                    const f32x2 t2 = (ls2[0] + ls2[1]) + (ls2[2] + ls2[3]);
+                    l_run = xor32_sum(t2.x + t2.y);
+                } else {
+                    l_run = lt[0];
+                }
                 if (!__any(!(l_run <= kHeadroom) || !(l_run >= kTiny))) break;
                 continue;                                   // redo this task exactly
             }
