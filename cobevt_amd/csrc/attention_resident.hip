@@ -32,6 +32,21 @@ __device__ __forceinline__ int perm16(int k) {   // swap bits 2 and 3: key order
 
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
+// The A operand V^T (rows = dh, k = 16 keys) of a PV MFMA out of a ROW-MAJOR V image [key][32 dh] (64 B per key, staged with the same
+// coalesced 16-byte copies as K): gfx950's transpose read.  ds_read_b64_tr_b16: every lane reads 8 bytes at its own address, then inside
+// each 16-lane group lane c receives element (c & 3) of what lanes 4 j + (c >> 2) read (j = 0 .. 3) - so with lane s of a group reading
+// row (s >> 2), columns 4 (s & 3) .. + 3 of a 4-key x 16-dh block, lane c ends up with column c of the four keys (checked on the
+// device: tools/_probe/trt).  Lane (h, dh) of the MFMA holds k-slots 8 h .. 8 h + 7 = the keys {4 h .. 4 h + 3, 8 + 4 h .. 8 + 4 h + 3}
+// of the 16-key block in the score registers' order: two reads, 8 rows apart.  Lanes 0-31 of a read cover four whole 64-byte rows =
+// 256 contiguous bytes: conflict-free without a swizzle.  p = this lane's address for the block's first read.
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 read_vt16(const unsigned char* p) {
+    const v4s16 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)p);
+    const v4s16 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(p + 8 * 64));
+    const uint2 x = __builtin_bit_cast(uint2, a), y = __builtin_bit_cast(uint2, b);
+    return make_uint4(x.x, x.y, y.x, y.y);
+}
+
 // 8 bf16 values times a scalar, rounded back to bf16 (v_pk_mul_f32 + v_cvt_pk_bf16_f32 per pair)
 __device__ __forceinline__ uint4 scale_bf16x8(const uint4& v, float sc) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -90,6 +105,9 @@ template <int NT> struct ResLds {
 // window.  The prefetch registers (~50) live across the query loop: only instantiated where the VGPR budget is 256.
 #ifndef COBEVT_ATTN_PLAIN_WAVES      // waves per SIMD the plain (no camera mean, no bias / mask) variants with >= 256 keys are compiled for
 #define COBEVT_ATTN_PLAIN_WAVES 3
+#endif
+#ifndef COBEVT_ATTN_VTR              // V of the window as a row-major [key][32 dh] LDS image read through ds_read_b64_tr_b16 (below); 0 = the transposed image
+#define COBEVT_ATTN_VTR 1
 #endif
 #ifndef COBEVT_ATTN_PIPE_SUMV
 #define COBEVT_ATTN_PIPE_SUMV 1
@@ -188,8 +206,10 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
     int trow[NKT];
     float tmask[NKT];
     uint4 kreg[NITEM];
-    uint2 v0[NITEM], v1[NITEM];
-    int krow[NITEM], vr0[NITEM], vr1[NITEM];
+    constexpr bool VTR = COBEVT_ATTN_VTR != 0;
+    uint2 v0[VTR ? 1 : NITEM], v1[VTR ? 1 : NITEM];
+    uint4 vreg[VTR ? NITEM : 1];                         // VTR: 16-byte pieces of the V rows, the K staging's item map
+    int krow[NITEM], vr0[NITEM], vr1[VTR ? 1 : NITEM];
     // part A: the table keys' coordinates / rows / mask words and the K rows; part B: the V rows.  kPrefetch == 2 issues part A of the NEXT
     // item in front of the query loop (25 registers across it) and part B at the item's start, under the table arithmetic and the K staging
     auto issue_item_loads = [&](int l_, int head_, int tidp, bool part_a, bool part_b) {
@@ -231,10 +251,15 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
             for (int it = 0; it < NITEM; ++it) {
                 const int si = tidp + it * NTHR;
                 const int kp = si >> 3, dq = si & 7;
-                vr0[it] = key_row(2 * kp);
-                vr1[it] = key_row(2 * kp + 1);
-                v0[it] = *(const uint2*)(vbase + (size_t)(vr0[it] < 0 ? 0 : vr0[it]) * p.ldv + dq * 4);
-                v1[it] = *(const uint2*)(vbase + (size_t)(vr1[it] < 0 ? 0 : vr1[it]) * p.ldv + dq * 4);
+                if constexpr (VTR) {
+                    vr0[it] = key_row(si >> 2);
+                    vreg[it] = *(const uint4*)(vbase + (size_t)(vr0[it] < 0 ? 0 : vr0[it]) * p.ldv + (si & 3) * 8);
+                } else {
+                    vr0[it] = key_row(2 * kp);
+                    vr1[it] = key_row(2 * kp + 1);
+                    v0[it] = *(const uint2*)(vbase + (size_t)(vr0[it] < 0 ? 0 : vr0[it]) * p.ldv + dq * 4);
+                    v1[it] = *(const uint2*)(vbase + (size_t)(vr1[it] < 0 ? 0 : vr1[it]) * p.ldv + dq * 4);
+                }
             }
         }
     };
@@ -340,6 +365,13 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
             const uint4 kv = krow[it] >= 0 ? scale_bf16x8(kreg[it], sl2) : make_uint4(0, 0, 0, 0);
             *(uint4*)(Ks + kk * 64 + ((cj ^ ((kk >> 2) & 3)) << 4)) = kv;
         }
+        if constexpr (VTR) {
+#pragma unroll
+            for (int it = 0; it < NITEM; ++it) {         // V rows as they are: [key][32 dh], 16-byte pieces (padded / masked-out rows zero)
+                const int item = tidp + it * NTHR;
+                *(uint4*)(Vts + (item >> 2) * 64 + (item & 3) * 16) = vr0[it] >= 0 ? vreg[it] : make_uint4(0, 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int it = 0; it < NITEM; ++it) {
             const int item = tidp + it * NTHR;
@@ -386,6 +418,8 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
     const unsigned char* kptr1 = Ks + ql * 64 + (((2 + h) ^ kx) << 4);     // k-group 1: chunk 2 + h
     const uint32_t vlow = (uint32_t)(ql & 15) << 4;                          // swizzle term, pre-shifted
     const unsigned char* vrow = Vts + ql * L::kVRow;                         // multiple of 256 B: the low byte is free for the XOR
+    // VTR: this lane's address inside a 16-key block's first transpose read (see read_vt16): row 4 h + ((lane & 15) >> 2), dh half (lane >> 4) & 1
+    const unsigned char* vtr = Vts + (4 * h + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
 
     const int ncam = MEAN ? p.qmap.ncam : 1;
     const float inv_ncam = 1.0f / (float)ncam;
@@ -508,7 +542,8 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
 #pragma unroll
                         for (int uu = 0; uu < 2; ++uu) {
                             const uint32_t lowc = (uint32_t)((u >> 1) * 8 + ((u & 1) * 2 + uu) * 2) << 4;
-                            va[uu] = *(const uint4*)(vp + ((lowc | ((uint32_t)h << 4)) ^ vlow));
+                            if constexpr (VTR) va[uu] = read_vt16(vtr + (kp2 * 128 + u * 32 + uu * 16) * 64);
+                            else va[uu] = *(const uint4*)(vp + ((lowc | ((uint32_t)h << 4)) ^ vlow));
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         f32x2 e2[8];                         // pairs: the row-sum adds below are v_pk_add_f32 on them
@@ -675,7 +710,8 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const uint32_t lowc = (uint32_t)(par * 8 + j * 2) << 4;
-                            va[j] = *(const uint4*)(vp + ((lowc | ((uint32_t)h << 4)) ^ vlow));
+                            if constexpr (VTR) va[j] = read_vt16(vtr + (key0 + j * 16) * 64);
+                            else va[j] = *(const uint4*)(vp + ((lowc | ((uint32_t)h << 4)) ^ vlow));
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -684,7 +720,7 @@ __global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {            // j = s * 2 + u: keys key0 + s*32 + u*16 .. +15, this half's 8 slots
                         const uint32_t lowc = (uint32_t)(par * 8 + j * 2) << 4;      // chunk within the 256-byte group (+ h)
-                        const uint4 va = *(const uint4*)(vp + ((lowc | ((uint32_t)h << 4)) ^ vlow));
+                        const uint4 va = VTR ? read_vt16(vtr + (key0 + j * 16) * 64) : *(const uint4*)(vp + ((lowc | ((uint32_t)h << 4)) ^ vlow));
                         mfma_kgroup<bf16_t>(va, pb[j], ot);
                     }
                     }
