@@ -140,4 +140,20 @@ static inline TokMap read_map(const int* d) {
 // -1 when it does not apply (the caller then uses the streaming kernel).  hint: 0 auto, >0 = query split to use
 int launch_attn_resident(const AttnParams& p, int qsplit_hint, hipStream_t stream);
 
+// The A operand V^T (rows = dh, k = 16 keys) of a PV MFMA out of a ROW-MAJOR V image [key][32 dh] (64 B per key, staged with the same
+// coalesced 16-byte copies as K): gfx950's transpose read.  ds_read_b64_tr_b16: every lane reads 8 bytes at its own address, then inside
+// each 16-lane group lane c receives element (c & 3) of what lanes 4 j + (c >> 2) read (j = 0 .. 3) - so with lane s of a group reading
+// row (s >> 2), columns 4 (s & 3) .. + 3 of a 4-key x 16-dh block, lane c ends up with column c of the four keys (checked on the
+// device: tools/tr_read_probe.hip).  Lane (h, dh) of the MFMA holds k-slots 8 h .. 8 h + 7 = the keys {4 h .. 4 h + 3, 8 + 4 h .. 8 + 4 h + 3}
+// of the 16-key block in the score registers' order: two reads, 8 rows apart.  Lanes 0-31 of a read cover four whole 64-byte rows =
+// 256 contiguous bytes: conflict-free without a swizzle.  p = this lane's address for the block's first read.
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 read_vt16(const unsigned char* p) {
+    const v4s16 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)p);
+    const v4s16 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(p + 8 * 64));
+    const uint2 x = __builtin_bit_cast(uint2, a), y = __builtin_bit_cast(uint2, b);
+    return make_uint4(x.x, x.y, y.x, y.y);
+}
+
+
 }  // namespace cobevt

@@ -16,7 +16,7 @@
 //   row chain   the 32 x 128 attention output never leaves LDS: out-projection + residual -> LayerNorm -> fc1 + GELU -> fc2 +
 //               residual -> (LayerNorm -> next to_qkv), the phases of row_chain_kernel<2, 32, true> with the rows addressed through
 //               the group's token -> row table (gather of the residual rows, scatter of the results; the maps stay (b, l, h, w, d)).
-// LDS: the attention region (V^T of 4 heads 84 KB + bias columns 32 KB + key tables) is dead when the chain starts and is reused
+// LDS: the attention region (V of 4 heads 80 KB, row-major, read through the transpose read + bias columns 40 KB + key tables) is dead when the chain starts and is reused
 // for its y / hidden / staging tiles; ~130 KB per workgroup, one workgroup per CU (the grid has 160).
 #include "attn_common.hpp"
 
@@ -93,6 +93,9 @@ __device__ __forceinline__ void normalise128(float (&v)[16], float eps) {
 
 // LDS layout (bytes).  Fixed part: the attention output / LN tile and the token -> row table of the workgroup's 32 queries.
 // Region R is used twice: by the attention phase (V^T, bias columns, key tables) and then by the chain (y, hidden, biases).
+#ifndef COBEVT_STAGE_VTR
+#define COBEVT_STAGE_VTR 1
+#endif
 struct StageLds {
     int vstr, vt, bias, brows, ktab, kmadd, kterm, qterm, attn_bytes, total;
     __host__ __device__ StageLds(int nkp, int bias_rows) {
@@ -100,7 +103,8 @@ struct StageLds {
         if ((vstr % 256) != 144 && (vstr % 256) != 112) vstr += ((144 - (vstr % 256)) + 256) % 256;
         brows = (bias_rows + 3) & ~3;
         vt = 0;
-        bias = vt + 4 * 32 * vstr;
+        // COBEVT_STAGE_VTR: V of a head as the row-major image [key][32 dh] (64 B per key) read through ds_read_b64_tr_b16
+        bias = vt + (COBEVT_STAGE_VTR ? 4 * nkp * 64 : 4 * 32 * vstr);
         ktab = bias + kBiasCopyBytes;                   // the bias image is copied whole (unconditional 16-byte pieces)
         kmadd = ktab + nkp * 4;
         kterm = kmadd + nkp * 4;
@@ -219,10 +223,32 @@ __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams
         }
     }
     {
-        unsigned char* vth = Vt + head * 32 * L.vstr;
-        // ---- V^T of this head -> LDS: item = (key pair, dh quad); 16-key blocks in the score registers' key order (perm16)
         const bf16_t* vbase = p.qkv + 2 * C + head * 32;
         constexpr int VIT = NT * 2;                         // NT * 32 keys x 4 dh quads / 2 keys per item / 64 lanes
+#if COBEVT_STAGE_VTR
+        // ---- V of this head -> LDS as it is: [key][32 dh], item = (key, 16-byte piece) - one 16-byte gather and one ds_write_b128 per
+        // item where the transposed image took two 8-byte gathers and four 4-byte writes; the PV operand comes out of it through the
+        // transpose read (attn_common.hpp read_vt16).  Rows of padded keys: row 0, finite, weight exactly 0 (as below).
+        unsigned char* vth = Vt + head * p.NKP * 64;
+        {
+            int rk[VIT];
+#pragma unroll
+            for (int u = 0; u < VIT; ++u) rk[u] = ktab[(u * 64 + lane) >> 2];
+            STAGE_MARK(8);
+            uint4 vv[VIT];
+#pragma unroll
+            for (int u = 0; u < VIT; ++u) vv[u] = *(const uint4*)(vbase + (size_t)max(rk[u], 0) * ld + (lane & 3) * 8);
+            STAGE_MARK(9);
+#ifdef COBEVT_STAGE_TRACE
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            STAGE_MARK(10);
+#endif
+#pragma unroll
+            for (int u = 0; u < VIT; ++u) *(uint4*)(vth + (u * 64 + lane) * 16) = vv[u];
+        }
+#else
+        unsigned char* vth = Vt + head * 32 * L.vstr;
+        // ---- V^T of this head -> LDS: item = (key pair, dh quad); 16-key blocks in the score registers' key order (perm16)
         // Rows of padded keys are read from row 0 and NOT zeroed: their probabilities are exactly 0 (additive -inf) and row 0 holds
         // finite values, so they add nothing - while a `row >= 0 ? load : 0` select makes hipcc put the load under a branch
         // (s_cbranch_execz + a full lgkmcnt / vmcnt drain per item: 15k of the first version's 47k cycles).  Two 8-byte gathers per
@@ -258,16 +284,23 @@ __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams
                 *(uint32_t*)(vth + dh * L.vstr + pos * 2) = lo | (hi << 16);
             }
         }
+#endif
     }
     STAGE_MARK(11);
     __syncthreads();          // (a wave only reads its own head's V^T; the barrier just keeps the hand-over free of ordering assumptions)
     STAGE_MARK(2);
     {
+#if COBEVT_STAGE_VTR
+        const unsigned char* vtr = Vt + head * p.NKP * 64 + (4 * h + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+#else
         unsigned char* vth = Vt + head * 32 * L.vstr;
+#endif
 
         const unsigned char* bias_qp = (const unsigned char*)(biasl + head * L.brows) + qterm[ql];
         const float sl2 = p.scale * kLog2e;
+#if !COBEVT_STAGE_VTR
         const unsigned char* vrow = vth + ql * L.vstr + h * 16;
+#endif
 
         // Two-pass softmax over the WHOLE key set (NT * 32 <= 384 keys = NT * 16 score registers per lane; a workgroup owns its CU,
         // so a lane may use ~450 VGPRs): every K fragment load, every score MFMA and every bias gather is independent of the
@@ -351,7 +384,11 @@ __global__ __launch_bounds__(kThreads, 1) void swap_stage_kernel(SwapStageParams
                 pb.y = pack_bf2(e[8 * u + 2], e[8 * u + 3]);
                 pb.z = pack_bf2(e[8 * u + 4], e[8 * u + 5]);
                 pb.w = pack_bf2(e[8 * u + 6], e[8 * u + 7]);
+#if COBEVT_STAGE_VTR
+                const uint4 va = read_vt16(vtr + (t * 32 + u * 16) * 64);
+#else
                 const uint4 va = *(const uint4*)(vrow + (t * 2 + u) * 32);
+#endif
                 mfma_kgroup<bf16_t>(va, pb, ot);             // O^T += V^T . P^T : rows = dh, column = query
             }
         }
