@@ -31,6 +31,9 @@ struct Conv3Params {
     int act;
     int store_mode;     // 0 NHWC, 1 PixelUnshuffle(2) NHWC
     int tiles_y, tiles_x, tiles_n;
+    // cobevt_conv3x3_ds_wfrag_nhwc: the 1x1 / stride-2 projection shortcut of a down-sampling BasicBlock as extra one-tap channel chunks
+    const void* in2 = nullptr;   // x, (N, H2, W2, Cin2): the block's input, read at (2 oy, 2 ox)
+    int H2 = 0, W2 = 0, Cin2 = 0;
 };
 
 // NHWC store pass shared by the three kernels: the fp32 staging tile [NPX pixels][BN couts] -> + residual -> activation
@@ -467,8 +470,13 @@ template <typename T, int MT, int WN, int KS, int S = 1, int NW = 8> struct Conv
     static_assert(WN * KS == NW && (NW == 8 || (NW == 4 && S == 1)), "eight waves, or four (stride 1)");
 };
 
-template <typename T, int MT, int WN, int KS, int S, int NW>
+// DS (bf16, stride 1, eight waves): out = act(conv3x3(in) + conv1x1/s2(in2) + bias) - the second convolution of a down-sampling BasicBlock
+// with the block's projection shortcut accumulated into the same registers: behind the nine-tap chunks of `in` come Cin2 / 64 ONE-tap
+// chunks whose A operand is x(2 oy, 2 ox), written to the patch positions the centre tap reads; their weight fragments follow the 3x3's
+// in the table ([tile][Cin/64 * 9 + Cin2/64 steps]).
+template <typename T, int MT, int WN, int KS, int S, int NW, bool DS = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kernel(Conv3Params p) {
+    static_assert(!DS || (Elem<T>::kIsBf16 && S == 1 && NW == 8), "the shortcut form is bf16 / stride 1 / eight waves");
     using C = Conv3SCfg<T, MT, WN, KS, S, NW>;
     constexpr bool HALF = C::HALF;
     constexpr int NT = C::NT, KG = C::KG, KGW = C::KGW, BN = C::BN, PW = C::PW;
@@ -516,7 +524,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
     const int h = lane >> 5, ql = lane & 31;
     const int wn = wave % WN, ks = wave / WN;
     const int nchunk = p.Cin / CC;
-    const int nsteps = nchunk * 9;
+    const int nchunk2 = DS ? p.Cin2 / CC : 0;
+    const int nsteps = nchunk * 9 + nchunk2;                     // fragment steps per cout tile (DS: the shortcut's one-tap steps behind the 3x3's)
     const T* in = (const T*)p.in;
 
     // (image, strip row, strip column) of the workgroup's MT strips, divided once by MT lanes: a runtime integer division
@@ -758,8 +767,38 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
     };
     // the last chunk is peeled so the residual loads of the store pass can be issued (unconditionally, keeping the
     // vmcnt waits counted) one chunk of MFMAs before they are needed
+    // (DS) the projection shortcut's Cin2 / 64 one-tap chunks.  Items = (strip, output pixel 0..31, 16-byte piece): x(2 oy, 2 ox) goes
+    // to patch pixel (row + 1, col + 1) of slot 0, where tap (1, 1) reads it; the first two chunks' pieces are requested before the
+    // last nine-tap chunk and written behind it (every wave is then past the last chunk barrier: nobody reads the patch any more).
+    constexpr int XI = MT * 32 * PIECES, X_IT = DS ? (XI + NT - 1) / NT : 1;
+    int xoff[X_IT], xlds[X_IT];
+    const T* in2 = (const T*)p.in2;
+    uint4 xr[2][X_IT];
+    auto load_x = [&](uint4 (&x)[X_IT], int e) {
+#pragma unroll
+        for (int it = 0; it < X_IT; ++it) x[it] = *(const uint4*)(in2 + xoff[it] + e * CC);
+    };
     if (S == 1) {
         for (int chunk = 0; chunk + 1 < nchunk; ++chunk) run_chunk(chunk, std::false_type{});
+        if constexpr (DS) {                          // in flight under the last nine-tap chunk (its patch-prefetch registers are free)
+#pragma unroll
+            for (int it = 0; it < X_IT; ++it) {
+                const int item = tid + it * NT;
+                xoff[it] = 0;
+                xlds[it] = -1;
+                if (item < XI) {
+                    const int st_ = item / (32 * PIECES), r = item - st_ * (32 * PIECES);
+                    const int pix = r / PIECES, j = r - pix * PIECES;
+                    const int4 sc = *(const int4*)&stab[st_ * 4];
+                    const int oy = sc.y * 2 + (pix >> 4), ox = sc.z * 16 + (pix & 15);
+                    const bool valid = (sc.w != 0) & (oy < p.Ho) & (ox < p.Wo);
+                    xoff[it] = valid ? ((sc.x * p.H2 + 2 * oy) * p.W2 + 2 * ox) * p.Cin2 + j * CH : 0;
+                    xlds[it] = (st_ * STRIP + ((pix >> 4) + 1) * PROW + ((pix & 15) + 1) * PSTR + j * 16) | (valid ? 0 : (1 << 30));
+                }
+            }
+            load_x(xr[0], 0);
+            load_x(xr[1], nchunk2 > 1 ? 1 : 0);
+        }
         if (PLT == 0 && EARLY_RES && p.store_mode == 0) st.prepare(p, tid, n0, coord);
         __builtin_amdgcn_sched_barrier(0);           // keep the residual loads up here
         run_chunk(nchunk - 1, std::true_type{});
@@ -775,6 +814,35 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
             }
             run_chunk(chunk, std::false_type{});
         }
+    }
+    if constexpr (DS) {
+        const int abase_c = PROW + PSTR + abase;                 // tap (1, 1)
+#pragma unroll 1
+        for (int e = 0; e < nchunk2; ++e) {
+            uint4 b2[KGW];
+            load_b(b2, nchunk * 9 + e);
+            if (e > 0) __syncthreads();                          // the previous chunk's operands have been read
+#pragma unroll
+            for (int it = 0; it < X_IT; ++it)
+                if (xlds[it] >= 0) {                             // (selects, not a runtime index: xr stays in registers)
+                    const uint4 x0 = xr[0][it], x1 = xr[1][it];
+                    const uint4 xv = (e & 1) ? x1 : x0;
+                    *(uint4*)(patch + (xlds[it] & 0x3fffffff)) = (xlds[it] >> 30) ? make_uint4(0, 0, 0, 0) : xv;
+                }
+            __syncthreads();
+            if (e + 2 < nchunk2) {                               // (runtime slot index: two explicit copies keep xr in registers)
+                if (e & 1) load_x(xr[1], e + 2); else load_x(xr[0], e + 2);
+            }
+#pragma unroll
+            for (int g = 0; g < KGW; ++g) {
+                uint4 a_[MT];
+#pragma unroll
+                for (int a = 0; a < MT; ++a) a_[a] = *(const uint4*)(patch + abase_c + g * 32 + a * STRIP);
+#pragma unroll
+                for (int a = 0; a < MT; ++a) mfma_kgroup_xs<T>(b2[g], a_[a], acc[a]);
+            }
+        }
+        __syncthreads();                                         // the staging tile of the epilogue reuses the patch
     }
     COBEVT_TRACE_MARK(38);
 
@@ -851,10 +919,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
     COBEVT_TRACE_RT(1);
 }
 
-template <typename T, int MT, int WN, int KS, int S, int NW = 8>
+template <typename T, int MT, int WN, int KS, int S, int NW = 8, bool DS = false>
 static int launch_conv3s(Conv3Params p, int coutp, hipStream_t stream) {
     using C = Conv3SCfg<T, MT, WN, KS, S, NW>;
     if ((long)p.N * p.H * p.W * p.Cin >= 0x7fffffffL) return COBEVT_ERR_UNSUPPORTED;   // 32-bit patch offsets
+    if (DS && (long)p.N * p.H2 * p.W2 * p.Cin2 >= 0x7fffffffL) return COBEVT_ERR_UNSUPPORTED;
     p.tiles_y = (p.Ho + 1) / 2;
     p.tiles_x = (p.Wo + 15) / 16;
     p.tiles_n = (p.Cout + C::BN - 1) / C::BN;
@@ -865,9 +934,9 @@ static int launch_conv3s(Conv3Params p, int coutp, hipStream_t stream) {
     constexpr size_t lds = C::LDS_BYTES;
     static cobevt::PerDeviceOnce attr_once;
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_strips_kernel<T, MT, WN, KS, S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv3x3_strips_kernel<T, MT, WN, KS, S, NW, DS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    hipLaunchKernelGGL((conv3x3_strips_kernel<T, MT, WN, KS, S, NW>), dim3((unsigned)blocks), dim3(C::NT), lds, stream, p);
+    hipLaunchKernelGGL((conv3x3_strips_kernel<T, MT, WN, KS, S, NW, DS>), dim3((unsigned)blocks), dim3(C::NT), lds, stream, p);
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
@@ -956,6 +1025,36 @@ extern "C" int cobevt_conv3x3_wfrag_nhwc(const void* in, const void* wfrag, cons
     const int kg = cc * (dtype == 0 ? 2 : 4) / 32;
     return dtype == 0 ? dispatch_conv3f<bf16_t>(p, kg, coutp, variant, stride, stream)
                       : dispatch_conv3f<float>(p, kg, coutp, variant, stride, stream);
+}
+
+// C-ABI entry point, see include/cobevt_hip.h
+extern "C" int cobevt_conv3x3_ds_wfrag_nhwc(const void* in, const void* in2, const void* wfrag, const float* bias, void* out, const int* dims,
+                                            hipStream_t stream) {
+    // dims: [dtype(0), N, H, W, Cin, Cout, act, padded_cout, variant, H2, W2, Cin2]
+    if (!in || !in2 || !wfrag || !out || !dims) return COBEVT_ERR_ARG;
+    if (dims[0] != 0) return COBEVT_ERR_UNSUPPORTED;
+    Conv3Params p;
+    p.in = in; p.wgt = wfrag; p.bias = bias; p.residual = nullptr; p.out = out; p.in2 = in2;
+    p.N = dims[1]; p.H = dims[2]; p.W = dims[3]; p.Cin = dims[4]; p.Cout = dims[5];
+    p.upsample = 0; p.act = dims[6]; p.store_mode = 0;
+    const int coutp = dims[7], variant = dims[8];
+    p.H2 = dims[9]; p.W2 = dims[10]; p.Cin2 = dims[11];
+    p.Ho = p.H; p.Wo = p.W;
+    if (p.N < 1 || p.H < 1 || p.W < 1 || p.Cin < 64 || p.Cin % 64 || p.Cout < 1 || p.Cin2 < 64 || p.Cin2 % 64) return COBEVT_ERR_SHAPE;
+    if ((p.H2 - 1) / 2 + 1 != p.H || (p.W2 - 1) / 2 + 1 != p.W) return COBEVT_ERR_SHAPE;      // in2 is the stride-2 source of the in / out grid
+    if (coutp % 32 != 0 || coutp < p.Cout) return COBEVT_ERR_SHAPE;
+    if (p.act < 0 || p.act > 2) return COBEVT_ERR_ARG;
+    const int mt = (variant - 100) / 10, bn64 = (variant - 100) % 10;
+    if (variant < 100 || bn64 > 1) return COBEVT_ERR_ARG;
+    switch (mt * 2 + bn64) {
+        case 6: return launch_conv3s<bf16_t, 3, 4, 2, 1, 8, true>(p, coutp, stream);
+        case 7: return launch_conv3s<bf16_t, 3, 2, 4, 1, 8, true>(p, coutp, stream);
+        case 8: return launch_conv3s<bf16_t, 4, 4, 2, 1, 8, true>(p, coutp, stream);
+        case 9: return launch_conv3s<bf16_t, 4, 2, 4, 1, 8, true>(p, coutp, stream);
+        case 10: return launch_conv3s<bf16_t, 5, 4, 2, 1, 8, true>(p, coutp, stream);
+        case 11: return launch_conv3s<bf16_t, 5, 2, 4, 1, 8, true>(p, coutp, stream);
+        default: return COBEVT_ERR_UNSUPPORTED;
+    }
 }
 
 #ifdef COBEVT_CONV3_TRACE

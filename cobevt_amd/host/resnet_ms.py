@@ -39,6 +39,9 @@ class BasicBlock(HipModule):
             pd = rt.conv_plan(self, "ds", self.downsample[0], self.downsample[1])
             if ops.dsblock_fusable(x, p1, p2, pd):
                 return ops.dsblock(x, p1, p2, pd)
+            variant = ops.conv3_ds_fusable(x, p1, p2, pd)
+            if variant:                                  # layer3.0 / layer4.0: the shortcut rides in conv2's launch
+                return ops.conv3_ds(ops.conv2d(x, p1), x, p2, pd, variant)
             identity = ops.conv2d(x, pd)
         if self.downsample is None and self.stride == 1 and ops.basicblock_fusable(x, p1, p2):
             return ops.basicblock(x, p1, p2)

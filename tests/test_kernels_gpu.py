@@ -255,6 +255,42 @@ def test_conv3x3_wfrag_tile_variants(cuda, dtype, variant):
         ops.CONV3_VARIANT = 0
 
 
+@pytest.mark.parametrize("variant", [130, 131, 140, 141, 150, 151])
+@pytest.mark.parametrize("c,cin2,n,h2,w2", [(256, 128, 3, 24, 40), (128, 64, 2, 19, 37), (256, 256, 1, 12, 12)])
+def test_conv3x3_with_projection_shortcut(cuda, variant, c, cin2, n, h2, w2):
+    """cobevt_conv3x3_ds_wfrag_nhwc: the second 3x3 of a down-sampling BasicBlock with the 1x1 / stride-2 shortcut as extra one-tap chunks
+    (layer3.0 / layer4.0), every tile shape, odd source sizes and ragged strips: vs torch on the same rounded operands (the shortcut is
+    NOT rounded to bf16 in between, the fused kernel accumulates it in fp32) and vs the two launches it replaces."""
+    dtype = torch.bfloat16
+    x = procedural_input("ds.x", (n, cin2, h2, w2), variant, -1, 1)
+    ho, wo = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
+    y = procedural_input("ds.y", (n, c, ho, wo), variant, -1, 1)
+    w2_ = procedural_input("ds.w2", (c, c, 3, 3), 0) * math.sqrt(3.0 / (9 * c))
+    wd = procedural_input("ds.wd", (c, cin2, 1, 1), 0) * math.sqrt(3.0 / cin2)
+    bn2, bnd = FakeBN(c, "ds.bn2"), FakeBN(c, "ds.bnd")
+    p1 = ops.ConvPlan(torch.zeros(c, cin2, 3, 3), None, bn=FakeBN(c, "ds.bn1"), stride=2, pad=1, act=1, dtype=dtype, device=cuda)
+    p2 = ops.ConvPlan(w2_, None, bn=bn2, stride=1, pad=1, act=1, dtype=dtype, device=cuda)
+    pd = ops.ConvPlan(wd, None, bn=bnd, stride=2, pad=0, act=0, dtype=dtype, device=cuda)
+    xd, yd = nhwc(x).to(cuda).to(dtype), nhwc(y).to(cuda).to(dtype)
+    ops.CONV3_VARIANT = variant
+    try:
+        assert ops.conv3_ds_fusable(xd, p1, p2, pd) == variant
+        out = ops.conv3_ds(yd, xd, p2, pd, variant)
+        two = ops.conv2d(yd, p2, residual=ops.conv2d(xd, pd))
+    finally:
+        ops.CONV3_VARIANT = 0
+    torch.cuda.synchronize()
+    # the folded weights as the plans hold them (BatchNorm scale folded in, then rounded to bf16)
+    s2, sh2 = ops.bn_affine(bn2)
+    sd, shd = ops.bn_affine(bnd)
+    w2r = rnd(w2_ * s2.cpu().float().view(-1, 1, 1, 1), dtype)
+    wdr = rnd(wd * sd.cpu().float().view(-1, 1, 1, 1), dtype)
+    ref = F.relu(F.conv2d(rnd(y, dtype), w2r, sh2.cpu().float(), 1, 1) + F.conv2d(rnd(x, dtype), wdr, shd.cpu().float(), 2, 0))
+    check(out, nhwc(ref), dtype, "conv3x3 + projection shortcut v%d" % variant)
+    d = (out.float() - two.float()).abs().max().item()
+    assert d <= 2.0 ** -6 * ref.abs().max().item(), d      # (the two-launch path rounds the shortcut to bf16 before the add)
+
+
 @pytest.mark.parametrize("variant", [133, 143, 153])
 def test_conv3x3_wfrag_four_wave_32_cout_tiles(cuda, variant):
     """the four-wave / 32-cout-tile form (bf16, stride 1; what layers with <= 32 output channels are routed to): ragged strips, a
