@@ -33,6 +33,7 @@ struct Conv3Params {
     int tiles_y, tiles_x, tiles_n;
     // cobevt_conv3x3_ds_wfrag_nhwc: the 1x1 / stride-2 projection shortcut of a down-sampling BasicBlock as extra one-tap channel chunks
     const void* in2 = nullptr;   // x, (N, H2, W2, Cin2): the block's input, read at (2 oy, 2 ox)
+    const float* bias2 = nullptr;   // the shortcut's bias (its folded BatchNorm shift)
     int H2 = 0, W2 = 0, Cin2 = 0;
 };
 
@@ -470,10 +471,11 @@ template <typename T, int MT, int WN, int KS, int S = 1, int NW = 8> struct Conv
     static_assert(WN * KS == NW && (NW == 8 || (NW == 4 && S == 1)), "eight waves, or four (stride 1)");
 };
 
-// DS (bf16, stride 1, eight waves): out = act(conv3x3(in) + conv1x1/s2(in2) + bias) - the second convolution of a down-sampling BasicBlock
-// with the block's projection shortcut accumulated into the same registers: behind the nine-tap chunks of `in` come Cin2 / 64 ONE-tap
-// chunks whose A operand is x(2 oy, 2 ox), written to the patch positions the centre tap reads; their weight fragments follow the 3x3's
-// in the table ([tile][Cin/64 * 9 + Cin2/64 steps]).
+// DS (bf16, stride 1, eight waves): out = act(conv3x3(in) + bias + round(conv1x1/s2(in2) + bias2)) - the second convolution of a
+// down-sampling BasicBlock with the block's projection shortcut in the same launch: behind the nine-tap chunks of `in` a wave computes
+// the complete shortcut of some of its (strip, 32 couts) tiles from x(2 oy, 2 ox) (Cin2 / 64 chunks x four k-groups, one 16-register
+// accumulator), rounds it as its own launch would store it and adds it to its partial sum; the shortcut's weight fragments follow the
+// 3x3's in the table ([tile][Cin/64 * 9 + Cin2/64 steps]).
 template <typename T, int MT, int WN, int KS, int S, int NW, bool DS = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kernel(Conv3Params p) {
     static_assert(!DS || (Elem<T>::kIsBf16 && S == 1 && NW == 8), "the shortcut form is bf16 / stride 1 / eight waves");
@@ -533,9 +535,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
     // trace showed 3.2k cycles in the store set-up alone)
     __shared__ __attribute__((aligned(16))) int stab[8 * 4];
     __shared__ __attribute__((aligned(16))) float sbias[BN];               // this tile's bias, fetched now: the epilogue must not start with a global round trip
+    __shared__ __attribute__((aligned(16))) float sbias2[DS ? BN : 4];     // (DS) the projection shortcut's bias
     if (tid >= NT - BN) {
         const int c = n0 + tid - (NT - BN);
         sbias[tid - (NT - BN)] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
+        if (DS) sbias2[tid - (NT - BN)] = (p.bias2 && c < p.Cout) ? p.bias2[c] : 0.f;
     }
     if (tid < MT) {
         const int q = q0 + tid;
@@ -646,6 +650,42 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
     if (S == 1) load_patch(0);
 #pragma unroll
     for (int s = 0; s < PF; ++s) load_b(bq[s], s < nsteps ? s : nsteps - 1);
+    // The KS k-split partials of the accumulators meet in the fp32 staging tile [MT*32 pixels][BN] (it reuses the patch memory).  With the
+    // operands swapped a lane holds, per accumulator tile, one pixel (lane & 31) and four runs of four consecutive couts
+    // (8k + 4*(lane>>5) + 0..3), i.e. 16-byte staging accesses instead of sixteen scalar ones.  The KS rounds rotate over
+    // the accumulator tiles - in round r the waves of k-split ks handle the tiles a with (a - r) mod KS == ks, storing
+    // partial + bias in round 0 and adding into the tile afterwards - so all eight waves work in every round (with
+    // "split kk stores / adds its whole accumulator in round kk" four, then two, of the eight idled: 4.3k-5.8k cycles).
+    float* stage = (float*)smem;
+    constexpr int SROW = C::SSTR / 4;
+    auto reduce_ksplit = [&](const float* bias_lds, bool trace) {
+        const int c0 = wn * 32 + 4 * h;
+        float4 bias4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bias4[k] = *(const float4*)&bias_lds[c0 + 8 * k];
+        if (trace) COBEVT_TRACE_MARK(57);
+#pragma unroll
+        for (int r = 0; r < KS; ++r) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                if (((a + KS - r) % KS) != ks) continue;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float4* d = (float4*)(stage + (a * 32 + ql) * SROW + c0 + 8 * k);
+                    float4 v = make_float4(acc[a][4 * k], acc[a][4 * k + 1], acc[a][4 * k + 2], acc[a][4 * k + 3]);
+                    if (r == 0) {
+                        v.x += bias4[k].x; v.y += bias4[k].y; v.z += bias4[k].z; v.w += bias4[k].w;
+                    } else {
+                        const float4 o = *d;
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    *d = v;
+                }
+            }
+            __syncthreads();
+            if (trace && r == 0) COBEVT_TRACE_MARK(58);
+        }
+    };
     if (S == 1) store_patch(patch);
     else fill_patch_s2(0);
     __syncthreads();
@@ -767,10 +807,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
     };
     // the last chunk is peeled so the residual loads of the store pass can be issued (unconditionally, keeping the
     // vmcnt waits counted) one chunk of MFMAs before they are needed
-    // (DS) the projection shortcut's Cin2 / 64 one-tap chunks.  Items = (strip, output pixel 0..31, 16-byte piece): x(2 oy, 2 ox) goes
-    // to patch pixel (row + 1, col + 1) of slot 0, where tap (1, 1) reads it; the first two chunks' pieces are requested before the
-    // last nine-tap chunk and written behind it (every wave is then past the last chunk barrier: nobody reads the patch any more).
-    constexpr int XI = MT * 32 * PIECES, X_IT = DS ? (XI + NT - 1) / NT : 1;
+    // (DS) the projection shortcut: x(2 oy, 2 ox) of the workgroup's MT * 32 output pixels, Cin2 / 64 chunks, in a compact LDS image
+    // [chunk][pixel][PSTR] over the (by then dead) patch memory.  Items = (strip, pixel 0..31, 16-byte piece); the first two chunks'
+    // pieces are requested in front of the last nine-tap chunk (its patch-prefetch registers are free) and written behind it.
+    constexpr int XI = MT * 32 * PIECES, X_IT = DS ? (XI + NT - 1) / NT : 1, XCH = MT * 32 * PSTR;
     int xoff[X_IT], xlds[X_IT];
     const T* in2 = (const T*)p.in2;
     uint4 xr[2][X_IT];
@@ -778,22 +818,26 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) x[it] = *(const uint4*)(in2 + xoff[it] + e * CC);
     };
+    auto store_x = [&](const uint4 (&x)[X_IT], int e) {
+#pragma unroll
+        for (int it = 0; it < X_IT; ++it)
+            if (xlds[it] >= 0) *(uint4*)(patch + e * XCH + (xlds[it] & 0x3fffffff)) = (xlds[it] >> 30) ? make_uint4(0, 0, 0, 0) : x[it];
+    };
     if (S == 1) {
         for (int chunk = 0; chunk + 1 < nchunk; ++chunk) run_chunk(chunk, std::false_type{});
-        if constexpr (DS) {                          // in flight under the last nine-tap chunk (its patch-prefetch registers are free)
+        if constexpr (DS) {
 #pragma unroll
             for (int it = 0; it < X_IT; ++it) {
                 const int item = tid + it * NT;
                 xoff[it] = 0;
                 xlds[it] = -1;
                 if (item < XI) {
-                    const int st_ = item / (32 * PIECES), r = item - st_ * (32 * PIECES);
-                    const int pix = r / PIECES, j = r - pix * PIECES;
-                    const int4 sc = *(const int4*)&stab[st_ * 4];
-                    const int oy = sc.y * 2 + (pix >> 4), ox = sc.z * 16 + (pix & 15);
+                    const int pi = item / PIECES, j = item - pi * PIECES;          // pi = strip * 32 + pixel of the strip
+                    const int4 sc = *(const int4*)&stab[(pi >> 5) * 4];
+                    const int oy = sc.y * 2 + ((pi >> 4) & 1), ox = sc.z * 16 + (pi & 15);
                     const bool valid = (sc.w != 0) & (oy < p.Ho) & (ox < p.Wo);
                     xoff[it] = valid ? ((sc.x * p.H2 + 2 * oy) * p.W2 + 2 * ox) * p.Cin2 + j * CH : 0;
-                    xlds[it] = (st_ * STRIP + ((pix >> 4) + 1) * PROW + ((pix & 15) + 1) * PSTR + j * 16) | (valid ? 0 : (1 << 30));
+                    xlds[it] = (pi * PSTR + j * 16) | (valid ? 0 : (1 << 30));
                 }
             }
             load_x(xr[0], 0);
@@ -816,72 +860,68 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv3x3_strips_kerne
         }
     }
     if constexpr (DS) {
-        const int abase_c = PROW + PSTR + abase;                 // tap (1, 1)
-#pragma unroll 1
-        for (int e = 0; e < nchunk2; ++e) {
-            uint4 b2[KGW];
-            load_b(b2, nchunk * 9 + e);
-            if (e > 0) __syncthreads();                          // the previous chunk's operands have been read
-#pragma unroll
-            for (int it = 0; it < X_IT; ++it)
-                if (xlds[it] >= 0) {                             // (selects, not a runtime index: xr stays in registers)
-                    const uint4 x0 = xr[0][it], x1 = xr[1][it];
-                    const uint4 xv = (e & 1) ? x1 : x0;
-                    *(uint4*)(patch + (xlds[it] & 0x3fffffff)) = (xlds[it] >> 30) ? make_uint4(0, 0, 0, 0) : xv;
-                }
-            __syncthreads();
-            if (e + 2 < nchunk2) {                               // (runtime slot index: two explicit copies keep xr in registers)
-                if (e & 1) load_x(xr[1], e + 2); else load_x(xr[0], e + 2);
+        // Every wave is past the last chunk barrier: nobody reads the patch any more.  The shortcut is NOT k-split: the waves of k-split ks
+        // take the strips a with a % KS == ks and all four k-groups of every chunk, so a wave holds the COMPLETE shortcut sum of its
+        // (strip, 32 couts) tiles, rounds it (+ its bias) to the storage type - exactly what the separate launch stores - and adds it to
+        // its own partial sum of the 3x3; the epilogue's reduction does the rest.  The result differs from the three-launch block by fp32
+        // summation order only (no bf16 parity gate moves); one 16-register accumulator at a time.
+        for (int e0 = 0; e0 < nchunk2; e0 += 2) {
+            if (e0 > 0) {                                        // (layers with more than two shortcut chunks: exposed loads)
+                load_x(xr[0], e0);
+                load_x(xr[1], e0 + 1 < nchunk2 ? e0 + 1 : e0);
             }
+            store_x(xr[0], e0);
+            if (e0 + 1 < nchunk2) store_x(xr[1], e0 + 1);
+        }
+        __syncthreads();
+        {
+            const int c0 = wn * 32 + 4 * h;
+            float4 bias4[4];
 #pragma unroll
-            for (int g = 0; g < KGW; ++g) {
-                uint4 a_[MT];
+            for (int k = 0; k < 4; ++k) bias4[k] = *(const float4*)&sbias2[c0 + 8 * k];
+            const uint4* wd = (const uint4*)p.wgt + ((size_t)(n0 / 32 + wn) * nsteps + nchunk * 9) * (KG * 64) + lane;   // all k-groups
+            // the shortcut's weight fragments of this wave's cout tile, all (<= 4) chunks, once: the rings of the main loop are dead,
+            // the registers are there, and a load in front of every strip's MFMAs would be an exposed L2 round trip each time
+            uint4 bw[4][KG];
 #pragma unroll
-                for (int a = 0; a < MT; ++a) a_[a] = *(const uint4*)(patch + abase_c + g * 32 + a * STRIP);
+            for (int e = 0; e < 4; ++e)
+                if (e < nchunk2) {
 #pragma unroll
-                for (int a = 0; a < MT; ++a) mfma_kgroup_xs<T>(b2[g], a_[a], acc[a]);
+                    for (int g = 0; g < KG; ++g) bw[e][g] = wd[(size_t)e * (KG * 64) + g * 64];
+                }
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                if ((a % KS) != ks) continue;
+                f32x16 dacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
+                const unsigned char* xa = patch + (a * 32 + ql) * PSTR + h * 16;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (e >= nchunk2) continue;
+                    uint4 ax[KG];
+#pragma unroll
+                    for (int g = 0; g < KG; ++g) ax[g] = *(const uint4*)(xa + e * XCH + g * 32);
+#pragma unroll
+                    for (int g = 0; g < KG; ++g) mfma_kgroup_xs<T>(bw[e][g], ax[g], dacc);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t lo = pack_bf2(dacc[4 * k] + bias4[k].x, dacc[4 * k + 1] + bias4[k].y);
+                    const uint32_t hi = pack_bf2(dacc[4 * k + 2] + bias4[k].z, dacc[4 * k + 3] + bias4[k].w);
+                    acc[a][4 * k] += __uint_as_float(lo << 16);
+                    acc[a][4 * k + 1] += __uint_as_float(lo & 0xffff0000u);
+                    acc[a][4 * k + 2] += __uint_as_float(hi << 16);
+                    acc[a][4 * k + 3] += __uint_as_float(hi & 0xffff0000u);
+                }
             }
         }
-        __syncthreads();                                         // the staging tile of the epilogue reuses the patch
+        __syncthreads();                                         // the staging tile of the epilogue reuses this memory
     }
     COBEVT_TRACE_MARK(38);
 
-    // ---- epilogue: the KS k-split partials meet in the fp32 staging tile [MT*32 pixels][BN].  With the operands
-    // swapped a lane holds, per accumulator tile, one pixel (lane & 31) and four runs of four consecutive couts
-    // (8k + 4*(lane>>5) + 0..3), i.e. 16-byte staging accesses instead of sixteen scalar ones.  The KS rounds rotate over
-    // the accumulator tiles - in round r the waves of k-split ks handle the tiles a with (a - r) mod KS == ks, storing
-    // partial + bias in round 0 and adding into the tile afterwards - so all eight waves work in every round (with
-    // "split kk stores / adds its whole accumulator in round kk" four, then two, of the eight idled: 4.3k-5.8k cycles).
-    float* stage = (float*)smem;
-    constexpr int SROW = C::SSTR / 4;
-    {
-        const int c0 = wn * 32 + 4 * h;
-        float4 bias4[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) bias4[k] = *(const float4*)&sbias[c0 + 8 * k];
-        COBEVT_TRACE_MARK(57);
-#pragma unroll
-        for (int r = 0; r < KS; ++r) {
-#pragma unroll
-            for (int a = 0; a < MT; ++a) {
-                if (((a + KS - r) % KS) != ks) continue;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float4* d = (float4*)(stage + (a * 32 + ql) * SROW + c0 + 8 * k);
-                    float4 v = make_float4(acc[a][4 * k], acc[a][4 * k + 1], acc[a][4 * k + 2], acc[a][4 * k + 3]);
-                    if (r == 0) {
-                        v.x += bias4[k].x; v.y += bias4[k].y; v.z += bias4[k].z; v.w += bias4[k].w;
-                    } else {
-                        const float4 o = *d;
-                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                    }
-                    *d = v;
-                }
-            }
-            __syncthreads();
-            if (r == 0) COBEVT_TRACE_MARK(58);
-        }
-    }
+    // ---- epilogue: the k-split partials meet in the staging tile (reduce_ksplit above), then the store pass
+    reduce_ksplit(sbias, true);
     COBEVT_TRACE_MARK(39);
     T* out = (T*)p.out;
     if (p.store_mode == 0) {
@@ -924,6 +964,7 @@ static int launch_conv3s(Conv3Params p, int coutp, hipStream_t stream) {
     using C = Conv3SCfg<T, MT, WN, KS, S, NW>;
     if ((long)p.N * p.H * p.W * p.Cin >= 0x7fffffffL) return COBEVT_ERR_UNSUPPORTED;   // 32-bit patch offsets
     if (DS && (long)p.N * p.H2 * p.W2 * p.Cin2 >= 0x7fffffffL) return COBEVT_ERR_UNSUPPORTED;
+    if (DS && (long)(p.Cin2 / 64) * MT * 32 * C::PSTR > (long)C::LDS_BYTES) return COBEVT_ERR_UNSUPPORTED;   // the shortcut's x image lives in the patch memory
     p.tiles_y = (p.Ho + 1) / 2;
     p.tiles_x = (p.Wo + 15) / 16;
     p.tiles_n = (p.Cout + C::BN - 1) / C::BN;
@@ -1028,19 +1069,20 @@ extern "C" int cobevt_conv3x3_wfrag_nhwc(const void* in, const void* wfrag, cons
 }
 
 // C-ABI entry point, see include/cobevt_hip.h
-extern "C" int cobevt_conv3x3_ds_wfrag_nhwc(const void* in, const void* in2, const void* wfrag, const float* bias, void* out, const int* dims,
-                                            hipStream_t stream) {
+extern "C" int cobevt_conv3x3_ds_wfrag_nhwc(const void* in, const void* in2, const void* wfrag, const float* bias, const float* bias2, void* out,
+                                            const int* dims, hipStream_t stream) {
     // dims: [dtype(0), N, H, W, Cin, Cout, act, padded_cout, variant, H2, W2, Cin2]
     if (!in || !in2 || !wfrag || !out || !dims) return COBEVT_ERR_ARG;
     if (dims[0] != 0) return COBEVT_ERR_UNSUPPORTED;
     Conv3Params p;
-    p.in = in; p.wgt = wfrag; p.bias = bias; p.residual = nullptr; p.out = out; p.in2 = in2;
+    p.in = in; p.wgt = wfrag; p.bias = bias; p.bias2 = bias2; p.residual = nullptr; p.out = out; p.in2 = in2;
     p.N = dims[1]; p.H = dims[2]; p.W = dims[3]; p.Cin = dims[4]; p.Cout = dims[5];
     p.upsample = 0; p.act = dims[6]; p.store_mode = 0;
     const int coutp = dims[7], variant = dims[8];
     p.H2 = dims[9]; p.W2 = dims[10]; p.Cin2 = dims[11];
     p.Ho = p.H; p.Wo = p.W;
     if (p.N < 1 || p.H < 1 || p.W < 1 || p.Cin < 64 || p.Cin % 64 || p.Cout < 1 || p.Cin2 < 64 || p.Cin2 % 64) return COBEVT_ERR_SHAPE;
+    if (p.Cin2 > 256) return COBEVT_ERR_UNSUPPORTED;           // at most four shortcut chunks (their weight fragments live in registers)
     if ((p.H2 - 1) / 2 + 1 != p.H || (p.W2 - 1) / 2 + 1 != p.W) return COBEVT_ERR_SHAPE;      // in2 is the stride-2 source of the in / out grid
     if (coutp % 32 != 0 || coutp < p.Cout) return COBEVT_ERR_SHAPE;
     if (p.act < 0 || p.act > 2) return COBEVT_ERR_ARG;

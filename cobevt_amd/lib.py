@@ -27,7 +27,7 @@ SIGNATURES = {
     "cobevt_basicblock_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_dsblock_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_conv3x3_wfrag_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _c_int_p, _vp]),
-    "cobevt_conv3x3_ds_wfrag_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _c_int_p, _vp]),
+    "cobevt_conv3x3_ds_wfrag_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_stem_conv7x7s2_pool": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_stem_conv7x7s2": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_int_p, _vp]),
     "cobevt_stem_conv7x7s2_pool_u8": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _c_int_p, _vp]),

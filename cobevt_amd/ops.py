@@ -549,7 +549,7 @@ def conv3_ds_fusable(x, plan1, plan2, plan_ds):
             and x.dim() == 4 and x.is_contiguous() and plan2.wfrag is not None and plan_ds.wgt_rows is not None
             and plan1.stride == 2 and plan2.stride == 1 and plan_ds.stride == 2 and plan2.cc3 == 64
             and plan1.cout == plan2.cin == plan2.cout == plan_ds.cout and plan_ds.cin == x.shape[3] and x.shape[3] % 64 == 0
-            and plan2.cin % 64 == 0 and plan2.act in (0, 1) and plan_ds.act == 0 and plan_ds.pre_scale is None and not plan_ds.has_ln
+            and x.shape[3] <= 256 and plan2.cin % 64 == 0 and plan2.act in (0, 1) and plan_ds.act == 0 and plan_ds.pre_scale is None and not plan_ds.has_ln
             and not plan2.upsample and plan2.store_mode == 0 and plan2.bias is not None and plan_ds.bias is not None
             and x.numel() < 2 ** 31):
         return 0
@@ -564,7 +564,7 @@ def _conv3_ds_table(plan2, plan_ds):
     """conv2's fragment table with the shortcut's one-tap steps appended per 32-cout tile (cached on plan2, keyed by the shortcut plan)"""
     cached = getattr(plan2, "_ds_fused", None)
     if cached is not None and cached[0] is plan_ds:
-        return cached[1], cached[2]
+        return cached[1]
     coutp, cin, cin2 = plan2.coutp3, plan2.cin, plan_ds.cin
     t = coutp // 32
     main = plan2.wfrag.reshape(t, (cin // 64) * 9, 2048)
@@ -572,17 +572,16 @@ def _conv3_ds_table(plan2, plan_ds):
     wd[:plan_ds.cout] = plan_ds.wgt_rows[:, :cin2]
     extra = wd.reshape(t, 32, cin2 // 64, 4, 2, 8).permute(0, 2, 3, 4, 1, 5).reshape(t, cin2 // 64, 2048)
     table = torch.cat([main, extra], dim=1).contiguous()
-    bias = (plan2.bias.float() + plan_ds.bias.float()).contiguous()
-    plan2._ds_fused = (plan_ds, table, bias)
-    return table, bias
+    plan2._ds_fused = (plan_ds, table)
+    return table
 
 
 def conv3_ds(y, x, plan2, plan_ds, variant):
-    """act(conv2(y) + ds(x)) for BN-folded plans: y (N, H/2, W/2, C) = the block's first convolution's output, x (N, H, W, Cin2) its input."""
+    """act(conv2(y) + round(ds(x))) for BN-folded plans (the shortcut rounded to the storage type as its own launch would store it): y (N, H/2, W/2, C) = the block's first convolution's output, x (N, H, W, Cin2) its input."""
     _need_cuda(y, x)
     n, ho, wo, c = y.shape
     _, h, w, cin2 = x.shape
-    table, bias = _conv3_ds_table(plan2, plan_ds)
+    table = _conv3_ds_table(plan2, plan_ds)
     out = torch.empty((n, ho, wo, plan2.cout), dtype=y.dtype, device=y.device)
     dims = _ints([plan2.code, n, ho, wo, c, plan2.cout, plan2.act, plan2.coutp3, variant, h, w, cin2])
 
@@ -591,7 +590,7 @@ def conv3_ds(y, x, plan2, plan_ds, variant):
         return 2.0 * px * plan2.cout * (9 * c + cin2), float(2 * (y.numel() + px * cin2 + out.numel()) + 2 * plan2.cout * (9 * c + cin2))
 
     with _timed("conv3x3|%d->%d +ds%d %dx%dx%d" % (c, plan2.cout, cin2, n, ho, wo), cost):
-        rc = _L.load().cobevt_conv3x3_ds_wfrag_nhwc(_p(y), _p(x), _p(table), _p(bias), _p(out), dims, _stream())
+        rc = _L.load().cobevt_conv3x3_ds_wfrag_nhwc(_p(y), _p(x), _p(table), _p(plan2.bias), _p(plan_ds.bias), _p(out), dims, _stream())
     _L.check(rc, "cobevt_conv3x3_ds_wfrag_nhwc")
     return out
 

@@ -87,17 +87,18 @@ int cobevt_conv3x3_wfrag_nhwc(const void* in, const void* wfrag, const float* bi
 /*
  * The SECOND 3x3 convolution of a down-sampling BasicBlock together with the block's projection shortcut (torchvision
  * resnet.BasicBlock.forward with `downsample`, layer3.0 / layer4.0 as reached from resnet_ms.py:67-74), bf16:
- *     out = act(conv3x3(in; W2) + conv1x1/stride2(in2; Wd) + bias)      bias = b2 + b_ds, eval BatchNorms folded
+ *     out = act(conv3x3(in; W2) + bias + bf16(conv1x1/stride2(in2; Wd) + bias2))      eval BatchNorms folded
  * in (N, H, W, Cin) = the block's first convolution's output, in2 (N, H2, W2, Cin2) = the block's input with
  * ((H2-1)/2+1, (W2-1)/2+1) = (H, W).  One launch instead of two (the shortcut's dense-row launch and its 2 x N*H*W*Cout
- * bytes of round trip go): the shortcut is accumulated in fp32 in the convolution's own accumulators (the two-launch path
- * rounds it to bf16 first) as Cin2 / 64 extra ONE-tap channel chunks whose A operand is in2(2 oy, 2 ox).  wfrag: per
+ * bytes of round trip go): behind the 3x3's channel chunks every wave computes the complete shortcut sum of some of its
+ * output tiles from in2(2 oy, 2 ox), rounds it to bf16 as the separate launch stores it and adds it to its partial sum of
+ * the 3x3 - the result differs from the two-launch path by fp32 summation order only.  wfrag: per
  * 32-cout tile the Cin/64 * 9 steps of cobevt_conv3x3_wfrag_nhwc's table followed by Cin2/64 steps of the same
  * [4 k-groups][64 lanes][16 bytes] shape built from Wd.  dims (int32[12]): dtype (0), N, H, W, Cin, Cout, act, Cout_p,
- * variant (100 + 10*MT + (1 for 64-cout tiles), MT in 3..5), H2, W2, Cin2; Cin % 64 == Cin2 % 64 == 0.
+ * variant (100 + 10*MT + (1 for 64-cout tiles), MT in 3..5), H2, W2, Cin2; Cin % 64 == Cin2 % 64 == 0, Cin2 <= 256.
  */
-int cobevt_conv3x3_ds_wfrag_nhwc(const void* in, const void* in2, const void* wfrag, const float* bias, void* out, const int* dims,
-                                 hipStream_t stream);
+int cobevt_conv3x3_ds_wfrag_nhwc(const void* in, const void* in2, const void* wfrag, const float* bias, const float* bias2, void* out,
+                                 const int* dims, hipStream_t stream);
 
 /*
  * Fused ResNet BasicBlock (stride 1, no downsample, C in {64, 128}): out = ReLU(conv2(ReLU(conv1(x) + b1)) + b2 + x) with

@@ -259,8 +259,8 @@ def test_conv3x3_wfrag_tile_variants(cuda, dtype, variant):
 @pytest.mark.parametrize("c,cin2,n,h2,w2", [(256, 128, 3, 24, 40), (128, 64, 2, 19, 37), (256, 256, 1, 12, 12)])
 def test_conv3x3_with_projection_shortcut(cuda, variant, c, cin2, n, h2, w2):
     """cobevt_conv3x3_ds_wfrag_nhwc: the second 3x3 of a down-sampling BasicBlock with the 1x1 / stride-2 shortcut as extra one-tap chunks
-    (layer3.0 / layer4.0), every tile shape, odd source sizes and ragged strips: vs torch on the same rounded operands (the shortcut is
-    NOT rounded to bf16 in between, the fused kernel accumulates it in fp32) and vs the two launches it replaces."""
+    (layer3.0 / layer4.0), every tile shape, odd source sizes and ragged strips: vs torch on the same rounded operands (the shortcut
+    rounded to bf16 before the add, as its own launch stores it) and vs the two launches it replaces (fp32 summation order only)."""
     dtype = torch.bfloat16
     x = procedural_input("ds.x", (n, cin2, h2, w2), variant, -1, 1)
     ho, wo = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
@@ -285,10 +285,11 @@ def test_conv3x3_with_projection_shortcut(cuda, variant, c, cin2, n, h2, w2):
     sd, shd = ops.bn_affine(bnd)
     w2r = rnd(w2_ * s2.cpu().float().view(-1, 1, 1, 1), dtype)
     wdr = rnd(wd * sd.cpu().float().view(-1, 1, 1, 1), dtype)
-    ref = F.relu(F.conv2d(rnd(y, dtype), w2r, sh2.cpu().float(), 1, 1) + F.conv2d(rnd(x, dtype), wdr, shd.cpu().float(), 2, 0))
+    ref = F.relu(F.conv2d(rnd(y, dtype), w2r, sh2.cpu().float(), 1, 1) + rnd(F.conv2d(rnd(x, dtype), wdr, shd.cpu().float(), 2, 0), dtype))
     check(out, nhwc(ref), dtype, "conv3x3 + projection shortcut v%d" % variant)
-    d = (out.float() - two.float()).abs().max().item()
-    assert d <= 2.0 ** -6 * ref.abs().max().item(), d      # (the two-launch path rounds the shortcut to bf16 before the add)
+    diff = (out.float() - two.float()).abs()
+    assert diff.max().item() <= 2.0 ** -7 * ref.abs().max().item(), diff.max().item()      # rare one-ulp flips of the bf16 stores ...
+    assert (diff > 0).float().mean().item() < 0.02                                          # ... and only those
 
 
 @pytest.mark.parametrize("variant", [133, 143, 153])
