@@ -106,7 +106,7 @@ template <int NT> struct ResLds {
 template <int NT, int NW, bool MEAN, bool BIAS, bool MASK, bool RAGGED, bool W8 = false, bool PERSIST = false>
 // Register budget: the plain variants keep 4 waves per SIMD (35 KB of LDS -> 4 workgroups per CU); with a bias table / mask the
 // LDS footprint (>= 56 KB for the shipped windows) allows 2 waves per SIMD at most, so those variants may use 256 VGPRs.
-__global__ __launch_bounds__(NW * 64, (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 : (NT >= 4 ? COBEVT_ATTN_PLAIN_WAVES : 3))) void attn_resident_kernel(AttnParams p, int qsplit) {
+__global__ __launch_bounds__(NW * 64, NT > 8 ? 1 : (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 : (NT >= 4 ? COBEVT_ATTN_PLAIN_WAVES : 3))) void attn_resident_kernel(AttnParams p, int qsplit) {
     using L = ResLds<NT>;
     constexpr int NKP = L::kNkp;
     constexpr int NTHR = NW * 64;
@@ -768,7 +768,21 @@ int launch_nt(const AttnParams& p, int qsplit, size_t lds, dim3 grid, hipStream_
     return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
 }
 
+// windows of 513 .. 1024 keys: the plain variant only (four waves, one workgroup per CU)
+template <int NT>
+int launch_big(const AttnParams& p, int qsplit, size_t lds, dim3 grid, hipStream_t stream) {
+    if (p.Nk != NT * 64) hipLaunchKernelGGL((attn_resident_kernel<NT, 4, false, false, false, true>), grid, dim3(256), lds, stream, p, qsplit);
+    else hipLaunchKernelGGL((attn_resident_kernel<NT, 4, false, false, false, false>), grid, dim3(256), lds, stream, p, qsplit);
+    return hipGetLastError() == hipSuccess ? COBEVT_OK : COBEVT_ERR_LAUNCH;
+}
+
 }  // namespace
+
+// A/B switch: COBEVT_ATTN_BIG=0 in the environment keeps windows of more than 512 keys on the streaming kernel
+static bool attn_big_enabled() {
+    static const bool on = [] { const char* e = getenv("COBEVT_ATTN_BIG"); return !(e && e[0] == '0'); }();
+    return on;
+}
 
 // A/B switch: COBEVT_ATTN_PERSIST=0 in the environment keeps one (window, head) item per workgroup on every shape
 static bool attn_persist_enabled() {
@@ -777,7 +791,11 @@ static bool attn_persist_enabled() {
 }
 
 int launch_attn_resident(const AttnParams& p, int qsplit_hint, hipStream_t stream) {
-    if (p.Nk < 65 || p.Nk > 512) return -1;            // <= 64 keys: one streaming tile is already optimal; > 512: LDS
+    // <= 64 keys: one streaming tile is already optimal; > 512: LDS - except the plain variant (no bias / mask / camera mean), whose K / V
+    // of up to 1024 keys (the FAX level-2 and global attentions: one whole-map window per agent) fit as 128 KB + tables: four-wave
+    // workgroups, one per CU, one 32-query tile per wave instead of the streaming kernel's key split + merge launch (round 6)
+    const bool big = p.Nk > 512;
+    if (p.Nk < 65 || p.Nk > 1024 || (big && (p.bias_mode != 0 || p.mask != nullptr || p.mean_q != 0 || !attn_big_enabled()))) return -1;
     const int nt = ((p.Nk + 127) / 128) * 2;           // 64-key tiles, even
     const int P = p.qmap.w1 * p.qmap.w2;
     const bool mean = p.mean_q != 0;
@@ -800,7 +818,7 @@ int launch_attn_resident(const AttnParams& p, int qsplit_hint, hipStream_t strea
     // waves per workgroup: 8 when the LDS footprint leaves room for one or two workgroups per CU only and the window has the
     // query tiles to feed them (LiDAR FuseBEVT: 512 tokens per window)
     // (16 waves = 4 per SIMD at one workgroup per CU was measured 2x slower for the 512-key bias + mask windows: 128 VGPRs spill)
-    const int nw = (lds > 40 * 1024 && ntiles >= 16) ? 8 : 4;
+    const int nw = big ? 4 : (lds > 40 * 1024 && ntiles >= 16) ? 8 : 4;
     // query split: enough workgroups to fill 256 CUs x (4 | 2 | 1 resident workgroups), every wave keeping >= 1 tile
     int qsplit = qsplit_hint;
     if (qsplit <= 0) {
@@ -813,11 +831,15 @@ int launch_attn_resident(const AttnParams& p, int qsplit_hint, hipStream_t strea
         // tiles): keep splitting while a workgroup keeps two tiles - 13.2 us against the streaming kernel's 14.9 us in-graph
         if (info) while (base * qsplit < 256L && ntiles >= 4 * qsplit) qsplit *= 2;
     }
+    if (big && qsplit_hint <= 0) {                      // one query tile per wave where the window has them
+        qsplit = 1;
+        while (qsplit * 2 * nw <= ntiles) qsplit *= 2;
+    }
     if (qsplit > ntiles) qsplit = ntiles;
     if (qsplit < 1) qsplit = 1;
     // fewer workgroups than CUs (nuScenes: 100 windows x 1 head; the 5-agent fusion: 16 windows x 4 heads): the streaming kernel's
     // finer query split fills the chip better than one staging per (window, head) can (measured: 31 vs 52 us, 25 vs 29 us)
-    if (qsplit_hint <= 0 && (long)p.B * p.L * p.heads * qsplit < 256) return -1;
+    if (qsplit_hint <= 0 && !big && (long)p.B * p.L * p.heads * qsplit < 256) return -1;
     dim3 grid(p.L * p.heads * qsplit, p.B);
     if (grid.y > 65535) return -1;
     // one workgroup per CU (> 80 KB of LDS) and several items per CU: persistent workgroups, a whole number of (8 windows x heads)
@@ -846,6 +868,10 @@ int launch_attn_resident(const AttnParams& p, int qsplit_hint, hipStream_t strea
         case 48: return persist ? launch_nt<4, 8, true>(p, qsplit, lds, grid, stream) : launch_nt<4, 8>(p, qsplit, lds, grid, stream);
         case 68: return persist ? launch_nt<6, 8, true>(p, qsplit, lds, grid, stream) : launch_nt<6, 8>(p, qsplit, lds, grid, stream);
         case 88: return persist ? launch_nt<8, 8, true>(p, qsplit, lds, grid, stream) : launch_nt<8, 8>(p, qsplit, lds, grid, stream);
+        case 104: return launch_big<10>(p, qsplit, lds, grid, stream);
+        case 124: return launch_big<12>(p, qsplit, lds, grid, stream);
+        case 144: return launch_big<14>(p, qsplit, lds, grid, stream);
+        case 164: return launch_big<16>(p, qsplit, lds, grid, stream);
         default: return -1;
     }
 }

@@ -53,6 +53,9 @@ USE_PROJ_CHAIN_WAVE = True   # ... on maps of >= 32768 rows as independent waves
 USE_SWAP_STAGE = True   # a SwapFusionBlock half (attention + row chain + next to_qkv) as one launch (swap_stage.hip)
 USE_BOTTLENECK = True   # FAX ResNetBottleNeck (128 -> 32 -> 32 -> 128) as one launch (bottleneck.hip) instead of three
 ATTN_VARIANT = 0    # 0 = automatic (K/V-resident attention kernel where it applies), 1 = always the streaming kernel, 2 = ... with 64-key tiles (A/B runs)
+USE_ATTN_BIG_RESIDENT = False  # plain bf16 windows of 513 .. 1024 keys on the K/V-resident kernel (one launch) instead of key split + merge:
+                               # built and measured neutral (659.0 / 659.7 / 668.2 vs 659.2 / 660.3 / 660.5 frames/s, one frame 1.900 vs 1.904 ms,
+                               # profiles/r06_attn_big_resident_ab.txt) - kept as an opt-in switch, the key split stays the default
 ATTN_KSPLIT = 2     # streaming attention on a small grid with >= 1024 keys (FAX level 2 / global attention): share the keys of a window out
                     # over this many workgroups per query tile + a merge pass (0 / 1 = off).  Round 3 measured it neutral (0 / 2 / 4 =
                     # 582 / 578 / 569 frames/s, profiles/r03_ab_key_split.txt) and left it off; with the round-5 pipeline 2 is a small
@@ -785,7 +788,11 @@ def window_attention(q, k, v, out, qmap, kmap, omap, batch, heads, scale, ldq, l
 
     nq_, nk_ = qmap[1] * qmap[4] * qmap[5], kmap[1] * kmap[4] * kmap[5]
     ks = ATTN_KSPLIT if ksplit is None else int(ksplit)
-    use_ks = (ks > 1 and not mean_q and nk_ >= 1024 and batch * L * heads * ((nq_ + 127) // 128) * ks <= 1024
+    # plain bf16 windows of 513 .. 1024 keys (the FAX level-2 / global attention: one whole-map window per agent): K / V resident in LDS,
+    # one launch (attention_resident.hip, round 6) instead of the key split + merge of the streaming kernel
+    big_resident = (USE_ATTN_BIG_RESIDENT and ksplit is None and q.dtype == torch.bfloat16 and bias_table is None and mask is None and not mean_q
+                    and 512 < nk_ <= 1024 and (ATTN_VARIANT if variant is None else int(variant)) == 0 and omap[1] == qmap[1])
+    use_ks = (ks > 1 and not big_resident and not mean_q and nk_ >= 1024 and batch * L * heads * ((nq_ + 127) // 128) * ks <= 1024
               and out.is_contiguous() and ldo == out.shape[-1] and ooff == 0 and omap[1] == qmap[1])
     # "fp32_fast": the attention launches go to the third library as well (lib.encoder_scope() is a no-op in every other mode) - fp16
     # queries / probabilities against fp16 (hi, lo) keys / values, csrc/attention.hip kStage16

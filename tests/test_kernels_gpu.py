@@ -1558,6 +1558,18 @@ def test_attention_key_split_matches_single_pass(cuda, dtype, use_bias, ncam):
     ref = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), vf).reshape(B * nq, d)
     tol_ = 1e-2 if dtype == torch.bfloat16 else 1e-4
     scale = float(ref.abs().max())
+    if dtype == torch.bfloat16 and not use_bias:
+        # the same windows with K / V resident in LDS (attention_resident.hip: plain bf16 windows of 513 .. 1024 keys, opt-in switch)
+        saved = ops.USE_ATTN_BIG_RESIDENT
+        ops.USE_ATTN_BIG_RESIDENT = True
+        try:
+            out = torch.empty(rows_q, d, device=cuda, dtype=dtype)
+            with ops.LaunchProfile() as prof:
+                ops.window_attention(q, k, v, out, qmap, kmap, qmap, B, heads, 32 ** -0.5, d, d, d, d)
+            assert "ks" not in list(prof.summary(by_shape=True))[0]
+            outs["resident"] = out.float().cpu()
+        finally:
+            ops.USE_ATTN_BIG_RESIDENT = saved
     for ks, o in outs.items():
         assert float((o - ref).abs().max()) <= tol_ * scale, (ks, float((o - ref).abs().max()) / scale)
 
