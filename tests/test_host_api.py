@@ -440,3 +440,32 @@ def test_plan_fingerprint_follows_replaced_tensors():
     e = rt.structure_epoch()
     m.float()                                                        # conversions re-list as well (HipModule._apply)
     assert rt.structure_epoch() > e
+
+
+def test_projection_shortcut_fragment_table_layout():
+    """ops._conv3_ds_table (host side of cobevt_conv3x3_ds_wfrag_nhwc): per 32-cout tile the 3x3's Cin/64 * 9 fragment steps followed by
+    the shortcut's Cin2/64 one-tap steps.  Decoded back on the CPU exactly as the kernel addresses it - step, k-group g, lane = 32 * half
+    + cout % 32, eight consecutive channels 64 * chunk + 16 * g + 8 * half .. - the table reproduces conv3x3(y; W2) + conv1x1(x; Wd) of the
+    folded weights (no GPU: only the layout the kernel is handed)."""
+    from cobevt_amd import ops
+    g = torch.Generator().manual_seed(3)
+    c, cin2 = 128, 64
+    w2 = torch.randn(c, c, 3, 3, generator=g) * 0.05
+    wd = torch.randn(c, cin2, 1, 1, generator=g) * 0.1
+    p2 = ops.ConvPlan(w2, None, stride=1, pad=1, act=1, dtype=torch.bfloat16, device="cpu")
+    pd = ops.ConvPlan(wd, None, stride=2, pad=0, act=0, dtype=torch.bfloat16, device="cpu")
+    table = ops._conv3_ds_table(p2, pd).float()
+    assert ops._conv3_ds_table(p2, pd) is p2._ds_fused[1]                      # cached per shortcut plan
+    tiles, nmain, nextra = p2.coutp3 // 32, (c // 64) * 9, cin2 // 64
+    assert table.shape == (tiles, nmain + nextra, 2048)
+    t = table.reshape(tiles, nmain + nextra, 4, 2, 32, 8)                      # [tile][step][k-group][half][cout % 32][8 channels]
+    w2r, wdr = w2.to(torch.bfloat16).float(), wd.to(torch.bfloat16).float()
+    for cout in (0, 37, 127):
+        tile, r = cout // 32, cout % 32
+        for chunk in range(c // 64):
+            for tap in range(9):
+                got = t[tile, chunk * 9 + tap, :, :, r, :].reshape(64)          # channel 16 g + 8 half + e of the chunk
+                assert torch.equal(got, w2r[cout, chunk * 64:(chunk + 1) * 64, tap // 3, tap % 3])
+        for chunk in range(nextra):
+            got = t[tile, nmain + chunk, :, :, r, :].reshape(64)
+            assert torch.equal(got, wdr[cout, chunk * 64:(chunk + 1) * 64, 0, 0])
