@@ -97,6 +97,10 @@ template <int NT> struct ResLds {
 #ifndef COBEVT_ATTN_PIPE_SUMV
 #define COBEVT_ATTN_PIPE_SUMV 1
 #endif
+#ifndef COBEVT_ATTN_MEAN_WAVES       // waves per SIMD the camera-mean variant is compiled for (2 = up to 256 VGPRs; it uses ~150 = three waves; 4 = 128 VGPRs spills 25
+                                     // registers: one frame 2.003 -> 2.018 ms, measured and left)
+#define COBEVT_ATTN_MEAN_WAVES 2
+#endif
 #ifndef COBEVT_ATTN_PREFETCH
 #define COBEVT_ATTN_PREFETCH 0
 #endif
@@ -106,7 +110,7 @@ template <int NT> struct ResLds {
 template <int NT, int NW, bool MEAN, bool BIAS, bool MASK, bool RAGGED, bool W8 = false, bool PERSIST = false>
 // Register budget: the plain variants keep 4 waves per SIMD (35 KB of LDS -> 4 workgroups per CU); with a bias table / mask the
 // LDS footprint (>= 56 KB for the shipped windows) allows 2 waves per SIMD at most, so those variants may use 256 VGPRs.
-__global__ __launch_bounds__(NW * 64, NT > 8 ? 1 : (BIAS || MASK || PERSIST) ? 2 : (MEAN ? 2 : (NT >= 4 ? COBEVT_ATTN_PLAIN_WAVES : 3))) void attn_resident_kernel(AttnParams p, int qsplit) {
+__global__ __launch_bounds__(NW * 64, NT > 8 ? 1 : (BIAS || MASK || PERSIST) ? 2 : (MEAN ? COBEVT_ATTN_MEAN_WAVES : (NT >= 4 ? COBEVT_ATTN_PLAIN_WAVES : 3))) void attn_resident_kernel(AttnParams p, int qsplit) {
     using L = ResLds<NT>;
     constexpr int NKP = L::kNkp;
     constexpr int NTHR = NW * 64;
