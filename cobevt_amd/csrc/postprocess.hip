@@ -421,7 +421,10 @@ extern "C" int cobevt_sigmoid_focal_loss(const float* pred, const float* label, 
 // the weights are wave-uniform scalar loads.
 namespace cobevt {
 
-template <typename T, int COUT>
+// CPP: 16-byte pieces per pixel when known at compile time (4 = the shipped heads' 32 bf16 channels; 0 = run-time): with the tap / piece
+// loops unrolled the 72 wave-uniform weight loads of a thread are all requested up front instead of one exposed scalar round trip per
+// (tap, piece) iteration; same summation order
+template <typename T, int COUT, int CPP = 0>
 __global__ __launch_bounds__(256) void conv3x3_head_kernel(const T* in, const float* wgt, const float* bias, float* out, int N, int H,
                                                            int W, int Cin) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(256) void conv3x3_head_kernel(const T* in, const fl
     const int pstr = Cin * (int)sizeof(T) + 16;                 // patch pixel stride in bytes (odd multiple of 16: conflict-free)
     const int tid = threadIdx.x;
     const int tx = blockIdx.x * 16, ty = blockIdx.y * 16, n = blockIdx.z;
-    const int cpp = Cin / CH;                                   // 16-byte pieces per pixel
+    const int cpp = CPP ? CPP : Cin / CH;                       // 16-byte pieces per pixel
     for (int item = tid; item < 18 * 18 * cpp; item += 256) {
         const int pix = item / cpp, j = item - pix * cpp;
         const int py = pix / 18, px = pix - py * 18;
@@ -443,8 +446,10 @@ __global__ __launch_bounds__(256) void conv3x3_head_kernel(const T* in, const fl
     float acc[COUT];
 #pragma unroll
     for (int o = 0; o < COUT; ++o) acc[o] = bias ? bias[o] : 0.f;
+#pragma unroll(CPP ? 9 : 1)
     for (int tap = 0; tap < 9; ++tap) {
         const unsigned char* pp = smem + ((ly + tap / 3) * 18 + lx + tap % 3) * pstr;
+#pragma unroll(CPP ? CPP : 1)
         for (int j = 0; j < cpp; ++j) {
             float v[8];
             chunk_to_f32<T>(*(const uint4*)(pp + j * 16), v);
@@ -470,7 +475,9 @@ static int launch_head(const void* in, const float* wgt, const float* bias, floa
     const size_t lds = (size_t)18 * 18 * (Cin * sizeof(T) + 16);
     if (lds > 96 * 1024) return COBEVT_ERR_UNSUPPORTED;            // a pixel row of at most 256 bytes
     switch (Cout) {
-#define COBEVT_HEAD_CASE(c) case c: (void)hipFuncSetAttribute((const void*)conv3x3_head_kernel<T, c>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); hipLaunchKernelGGL((conv3x3_head_kernel<T, c>), grid, block, lds, stream, (const T*)in, wgt, bias, out, N, H, W, Cin); break;
+#define COBEVT_HEAD_CASE(c) case c: \
+        if (Cin * (int)sizeof(T) == 64) { hipLaunchKernelGGL((conv3x3_head_kernel<T, c, 4>), grid, block, lds, stream, (const T*)in, wgt, bias, out, N, H, W, Cin); break; } \
+        (void)hipFuncSetAttribute((const void*)conv3x3_head_kernel<T, c>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); hipLaunchKernelGGL((conv3x3_head_kernel<T, c>), grid, block, lds, stream, (const T*)in, wgt, bias, out, N, H, W, Cin); break;
         COBEVT_HEAD_CASE(1) COBEVT_HEAD_CASE(2) COBEVT_HEAD_CASE(3) COBEVT_HEAD_CASE(4)
 #undef COBEVT_HEAD_CASE
         default: return COBEVT_ERR_SHAPE;
