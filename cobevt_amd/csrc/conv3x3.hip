@@ -1000,6 +1000,10 @@ static int dispatch_conv3f(const Conv3Params& p, int kg, int coutp, int variant,
     if (variant == 0) variant = p.Cout <= 64 ? 151 : 150;
     const int mt = (variant - 100) / 10, bn64 = (variant - 100) % 10;
     if (variant < 100 || bn64 > 3) return COBEVT_ERR_ARG;
+    if constexpr (Elem<T>::kIsBf16) {                      // one / two strips per four-wave workgroup: tiny grids (a 1-image decoder map), code 3 only
+        if (bn64 == 3 && stride == 1 && mt == 1) return launch_conv3s<T, 1, 1, 4, 1, 4>(p, coutp, stream);
+        if (bn64 == 3 && stride == 1 && mt == 2) return launch_conv3s<T, 2, 1, 4, 1, 4>(p, coutp, stream);
+    }
     switch (mt) {
         case 3: return launch_conv3s_bn<T, 3>(p, coutp, bn64, stride, stream);
         case 4: return launch_conv3s_bn<T, 4>(p, coutp, bn64, stride, stream);

@@ -16,6 +16,7 @@ from .lib import CobevtHipError
 BF16, FP32 = 0, 1
 USE_CONV3X3 = True   # route eligible 3x3 convs to the LDS-patch kernel (tests flip this to cover both paths)
 USE_CONV3_S2 = True      # 3x3 / stride-2 convs through the strip kernel instead of the generic implicit GEMM
+USE_CONV3_SMALL_TILES = True   # grids below the CU count: 32-cout tiles in four-wave workgroups of one / two strips (conv3_tiling)
 USE_CONV3_DS = True      # layer3.0 / layer4.0: the projection shortcut inside conv2's launch (cobevt_conv3x3_ds_wfrag_nhwc)
 USE_CONV3_WFRAG = True   # ... and, where the fragment-ordered weight table exists, to the barrier-free-per-tap variant
 CONV3_VARIANT = 0    # 0 = automatic tile choice of cobevt_conv3x3_wfrag_nhwc; >0 pins one (tools/conv_probe.py)
@@ -338,7 +339,7 @@ def conv3_tiling(n, ho, wo, cin, cout, cc, cus=256, stride=1, bf16=True, packed=
             # 2 * cus workgroups if the strips allow it, else the fewest strips per workgroup (tools/conv_graph_probe.py)
             nstrips = n * (-(-ho // 2)) * (-(-wo // 16))
             best = None
-            for mt in (3, 4, 5):
+            for mt in ((1, 2, 3, 4, 5) if USE_CONV3_SMALL_TILES else (3, 4, 5)):
                 blocks = -(-nstrips // mt) * -(-cout // 32)
                 cost = -(-blocks // (2 * cus)) * (6000 + 9 * (cin // cc) * mt * 80)
                 if best is None or cost < best[0]:
@@ -364,7 +365,15 @@ def conv3_tiling(n, ho, wo, cin, cout, cc, cus=256, stride=1, bf16=True, packed=
             cost = -(-blocks // cus) * (12000 + nsteps * mt * (tile_n // 32) * per_step
                                        + (1500 * mt * (cin // cc) if stride == 2 else 0))   # exposed patch refills
             if best is None or cost < best[0]:
-                best = (cost, 100 + 10 * mt + bn64)
+                best = (cost, 100 + 10 * mt + bn64, blocks)
+    if USE_CONV3_SMALL_TILES and stride == 1 and bf16 and cc == 64 and not packed and best[2] < cus:
+        # a grid that does not reach the CU count (one image: the decoder maps, the small FAX maps): the launch lasts one workgroup
+        # lifetime, so the shortest workgroup wins - 32-cout tiles in four-wave workgroups with one or two strips each (round 6)
+        for mt in (1, 2, 3, 4, 5):
+            blocks = -(-nstrips // mt) * -(-cout // 32)
+            cost = -(-blocks // (2 * cus)) * (6000 + nsteps * mt * 80)
+            if cost < best[0]:
+                best = (cost, 100 + 10 * mt + 3, blocks)
     return best[1]
 
 

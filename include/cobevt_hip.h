@@ -77,7 +77,8 @@ int cobevt_conv3x3_nhwc(const void* in, const void* wgt, const float* bias, cons
  * the input patch and there is one barrier per channel chunk instead of one per tap.  A workgroup owns MT strips of
  * 2 x 16 output pixels (numbered across image, row pair, column block) x 128 or 64 couts.  dims (int32[13]): dtype, N,
  * H, W, Cin, Cout, upsample, act, store_mode (0 NHWC, 1 PixelUnshuffle(2)), cc (bf16: 64, fp32: 32), Cout_p, variant =
- * 100 + 10*MT + (1 for 64-cout tiles), MT in 3..6 (0 = MT 5); the host picks MT so that the grid is a whole number of
+ * 100 + 10*MT + (1 for 64-cout tiles; 3 = 32-cout tiles in four-wave workgroups, bf16 / stride 1, MT in 1..5), MT in 3..6
+ * (0 = MT 5); the host picks MT so that the grid is a whole number of
  * workgroups per CU (cobevt_amd/ops.py conv3_tiling); stride (1, or 2 = the first conv of a down-sampling BasicBlock:
  * out (Ho, Wo) = ((H-1)/2+1, (W-1)/2+1), plain NHWC store, no up-sampling).  Needs N*H*W*Cin < 2^31.
  */

@@ -292,7 +292,7 @@ def test_conv3x3_with_projection_shortcut(cuda, variant, c, cin2, n, h2, w2):
     assert (diff > 0).float().mean().item() < 0.02                                          # ... and only those
 
 
-@pytest.mark.parametrize("variant", [133, 143, 153])
+@pytest.mark.parametrize("variant", [113, 123, 133, 143, 153])
 def test_conv3x3_wfrag_four_wave_32_cout_tiles(cuda, variant):
     """the four-wave / 32-cout-tile form (bf16, stride 1; what layers with <= 32 output channels are routed to): ragged strips, a
     cout tail over several tiles, 1-3 channel chunks (single-buffered patch refill), residual / up-sampled / PixelUnshuffle epilogues"""
@@ -305,9 +305,12 @@ def test_conv3x3_wfrag_four_wave_32_cout_tiles(cuda, variant):
             _conv_case(cuda, torch.bfloat16, "wf4_%d_%d" % (variant, i), 2, 64 * nch, h, w, cout, 3, 1, 1, **kw)
     finally:
         ops.CONV3_VARIANT = 0
-    # the automatic choice takes this form for cout <= 32 and only then
-    assert ops.conv3_tiling(5, 128, 128, 128, 32, 64) % 10 == 3 and ops.conv3_tiling(5, 64, 64, 128, 32, 64) == 133
-    assert ops.conv3_tiling(5, 128, 128, 128, 32, 32, bf16=False) == 0 and ops.conv3_tiling(5, 64, 64, 128, 64, 64) % 10 != 3
+    # the automatic choice takes this form for cout <= 32, and for wider layers only where the eight-wave grid stays below the CU count
+    # (one-image decoder maps, the small FAX maps: one or two strips per workgroup - the launch lasts one workgroup lifetime)
+    assert ops.conv3_tiling(5, 128, 128, 128, 32, 64) % 10 == 3 and ops.conv3_tiling(5, 64, 64, 128, 32, 64) % 10 == 3
+    assert ops.conv3_tiling(1, 32, 32, 128, 128, 64) == 113 and ops.conv3_tiling(1, 128, 128, 64, 64, 64) == 123
+    assert ops.conv3_tiling(5, 128, 128, 128, 32, 32, bf16=False) == 0 and ops.conv3_tiling(5, 64, 64, 128, 128, 64) % 10 != 3
+    assert ops.conv3_tiling(20, 32, 32, 256, 256, 64) == 150 and ops.conv3_tiling(20, 16, 16, 512, 512, 64) == 151
     with pytest.raises(ops.CobevtHipError):                       # not built for fp32
         ops.CONV3_VARIANT = 153
         try:
