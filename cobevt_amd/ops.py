@@ -38,6 +38,7 @@ USE_GEMM_ROWS3_F32 = True  # dense-row GEMMs of the fp32 modes on 32-row workgro
 USE_ROW_CHAIN_F32 = True  # ... and its fp32-storage form for C = 128 / hidden 256 (csrc/row_chain_f32.hip; round 6)
 BASICBLOCK_TILE_ROWS = 0   # 0 = kernel default; 8 | 16 pins the output tile height (tools/bb_probe.py)
 USE_BASICBLOCK = True  # stride-1 BasicBlocks on 64 / 128 channels as one launch (intermediate map stays in LDS)
+BASICBLOCK_MAX_C = 128   # widest stride-1 BasicBlock run as one launch (A/B: 64 = the 128-channel blocks of layer 2 as two strip launches)
 USE_DSBLOCK = True  # layer2's stride-2 BasicBlock with its projection shortcut as one launch (bf16)
 USE_EMBED_GEMM = False  # compute the BEV query embedding inside the to_q GEMM instead of materialising the query:
 USE_EMBED_GEMM3 = True    # the BEV query produced inside the launch that projects it.  128 -> 128 with LayerNorm (every OPV2V level): the
@@ -79,7 +80,7 @@ def _apply_env_flags():
         if "=" in item:
             k, v = item.split("=", 1)
             k = k.strip()
-            if k not in globals() or not (k.startswith("USE_") or k in ("CONV3_VARIANT", "BASICBLOCK_TILE_ROWS", "ROW_CHAIN_ROWS", "GEMM_ROWS3_MIN_M", "GEMM_ROWS3_MAX_K", "GEMM_ROWS3_STRIDED", "GEMM_ROWS3_ROWS64_MIN_M", "ATTN_VARIANT", "ATTN_QSPLIT", "ATTN_KSPLIT")):
+            if k not in globals() or not (k.startswith("USE_") or k in ("CONV3_VARIANT", "BASICBLOCK_TILE_ROWS", "ROW_CHAIN_ROWS", "GEMM_ROWS3_MIN_M", "GEMM_ROWS3_MAX_K", "GEMM_ROWS3_STRIDED", "GEMM_ROWS3_ROWS64_MIN_M", "BASICBLOCK_MAX_C", "ATTN_VARIANT", "ATTN_QSPLIT", "ATTN_KSPLIT")):
                 raise CobevtHipError("COBEVT_FLAGS: unknown switch %r" % k)
             globals()[k] = int(v) if not k.startswith("USE_") else bool(int(v))
 
@@ -502,7 +503,7 @@ def conv2d(x, plan, residual=None, out=None):
 def basicblock_fusable(x, plan1, plan2):
     """stride-1 BasicBlock without downsample on 64 / 128 channels: both 3x3 convs in one launch (basicblock.hip)"""
     return (USE_BASICBLOCK and plan1.wfrag is not None and plan2.wfrag is not None and plan1.cin == plan1.cout == plan2.cin
-            == plan2.cout and plan1.cout in (64, 128) and plan1.act == 1 and plan2.act == 1 and not plan1.upsample
+            == plan2.cout and plan1.cout in (64, 128) and plan1.cout <= BASICBLOCK_MAX_C and plan1.act == 1 and plan2.act == 1 and not plan1.upsample
             and not plan2.upsample and plan1.store_mode == 0 and plan2.store_mode == 0 and x.is_contiguous()
             and x.dtype == plan1.dtype and x.numel() < 2 ** 31)
 
