@@ -100,14 +100,34 @@ __global__ __launch_bounds__(BnCfg<TH>::NTHR, 2) void bottleneck_kernel(Bottlene
     }
     // ---- weights + biases -> LDS (fragment order: a wave's A operand is one contiguous 1-KB read)
     {
-        const uint4* src[3] = {p.w1, p.w2, p.w3};
-        unsigned char* dst[3] = {sw1, sw2, sw3};
-        const int n16[3] = {kW1 / 16, kW2 / 16, kW3 / 16};
+        // the three tables are consecutive in LDS; every thread requests ALL its pieces (and its bias value) before it stores the first:
+        // as rolled copy loops (load, wait, store per iteration) the 34 KB cost nine serialised L2 round trips per workgroup - ~3 us of
+        // the ~10 us a launch on a small map lasts (round 6)
+        constexpr int N1_ = kW1 / 16, N2_ = kW2 / 16, TOT = (kW1 + kW2 + kW3) / 16, PER = (TOT + NTHR - 1) / NTHR;
+        uint4 tmp[PER];
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            for (int i = tid; i < n16[k]; i += NTHR) *(uint4*)(dst[k] + i * 16) = src[k][i];
-        for (int i = tid; i < kMid + kMid + kC; i += NTHR)
-            sb[i] = i < kMid ? p.b1[i] : (i < 2 * kMid ? p.b2[i - kMid] : p.b3[i - 2 * kMid]);
+        for (int u = 0; u < PER; ++u) {
+            const int i = tid + u * NTHR, ic = i < TOT ? i : TOT - 1;
+            const uint4* s_ = ic < N1_ ? p.w1 + ic : (ic < N1_ + N2_ ? p.w2 + (ic - N1_) : p.w3 + (ic - N1_ - N2_));
+            tmp[u] = *s_;
+        }
+        constexpr int NB = kMid + kMid + kC, PB = (NB + NTHR - 1) / NTHR;
+        float bt[PB];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int i = tid + u * NTHR, ic = i < NB ? i : NB - 1;
+            bt[u] = ic < kMid ? p.b1[ic] : (ic < 2 * kMid ? p.b2[ic - kMid] : p.b3[ic - 2 * kMid]);
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = tid + u * NTHR;
+            if (i < TOT) *(uint4*)(smem + i * 16) = tmp[u];
+        }
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int i = tid + u * NTHR;
+            if (i < NB) sb[i] = bt[u];
+        }
     }
     __syncthreads();
 
