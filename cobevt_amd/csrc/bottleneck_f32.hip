@@ -69,14 +69,24 @@ __global__ __launch_bounds__(kThreads, 2) void bottleneck_f32_kernel(BnF32Params
     // ---- phase 1: the conv1 patch [180 region pixels][32 channels]
     if (p.y1) {
         // the producer's conv1 output: 8 sixteen-byte pieces per region pixel, zeros outside the image
-        for (int item = tid; item < kR1 * 8; item += kThreads) {
-            const int r = item >> 3, j = item & 7;
+        // (every piece of the thread requested before the first is written: as a rolled load / store loop the six iterations were six
+        //  serialised round trips; unconditional loads from a clamped pixel, zeroed afterwards)
+        constexpr int NIT = (kR1 * 8 + kThreads - 1) / kThreads;
+        uint4 v[NIT];
+        bool ok[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int item = tid + u * kThreads, ic = item < kR1 * 8 ? item : kR1 * 8 - 1;
+            const int r = ic >> 3, j = ic & 7;
             const int ry = r / kR1W, rx = r - ry * kR1W;
             const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                v = stage_x_piece<float>(*(const uint4*)(p.y1 + (((size_t)img * p.H + iy) * p.W + ix) * 32 + j * 4));
-            *(uint4*)(P1 + r * kPix + j * 16) = v;
+            ok[u] = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            v[u] = *(const uint4*)(p.y1 + (((size_t)img * p.H + (ok[u] ? iy : 0)) * p.W + (ok[u] ? ix : 0)) * 32 + j * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int item = tid + u * kThreads;
+            if (item < kR1 * 8) *(uint4*)(P1 + (item >> 3) * kPix + (item & 7) * 16) = ok[u] ? stage_x_piece<float>(v[u]) : make_uint4(0, 0, 0, 0);
         }
         __syncthreads();
     } else {

@@ -433,6 +433,26 @@ __global__ __launch_bounds__(256) void conv3x3_head_kernel(const T* in, const fl
     const int tid = threadIdx.x;
     const int tx = blockIdx.x * 16, ty = blockIdx.y * 16, n = blockIdx.z;
     const int cpp = CPP ? CPP : Cin / CH;                       // 16-byte pieces per pixel
+    if constexpr (CPP != 0) {
+        // every piece of the thread requested before the first is written (the rolled form below pays one exposed round trip per iteration)
+        constexpr int NIT = (18 * 18 * CPP + 255) / 256;
+        uint4 v[NIT];
+        bool ok[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int item = tid + u * 256, ic = item < 18 * 18 * CPP ? item : 18 * 18 * CPP - 1;
+            const int pix = ic / CPP, j = ic - pix * CPP;
+            const int py = pix / 18, px = pix - py * 18;
+            const int y = ty - 1 + py, x = tx - 1 + px;
+            ok[u] = y >= 0 && y < H && x >= 0 && x < W;
+            v[u] = *(const uint4*)(in + (((size_t)n * H + (ok[u] ? y : 0)) * W + (ok[u] ? x : 0)) * Cin + j * CH);
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int item = tid + u * 256;
+            if (item < 18 * 18 * CPP) *(uint4*)(smem + (item / CPP) * pstr + (item % CPP) * 16) = ok[u] ? v[u] : make_uint4(0, 0, 0, 0);
+        }
+    } else
     for (int item = tid; item < 18 * 18 * cpp; item += 256) {
         const int pix = item / cpp, j = item - pix * cpp;
         const int py = pix / 18, px = pix - py * 18;
